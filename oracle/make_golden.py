@@ -1,0 +1,164 @@
+"""Generates tests/golden/*.npz by running the REAL reference (imported from
+/root/reference, build container only) on seeded inputs.  TEST INFRASTRUCTURE.
+
+    python oracle/make_golden.py            # rewrites every fixture
+
+The fixtures hold data only: inputs, parameters (float32 arrays) and the outputs the
+reference's own code produced for them:
+  gat_<mode>_N<N>_G<G>_K<K>_P<P>.npz   GraphFilterBatchAttentional.forward
+                                       (utils/graphUtils/graphML.py:4636-4671), both merges
+  model_<name>.npz                     DecentralPlannerGATNet.addGSO + forward
+                                       (graphs/models/decentralplanner_GAT_bottleneck*.py)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle._ref_import import import_reference, make_config  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def tricky_gso(gen, B, N, density, f64):
+    """Symmetric random graph + the edge cases SURVEY.md section 4 lists: an isolated node,
+    an asymmetric (directed) edge pair, tiny values around the 1e-9 threshold, 1/lambda_max
+    scaling, and one NaN entry (layer level: |NaN|>1e-9 is False -> no edge)."""
+    W = (torch.rand(B, N, N, generator=gen) < density).double()
+    W = torch.triu(W, 1)
+    W = W + W.transpose(1, 2)
+    for b in range(B):
+        iso = (3 + b) % N
+        W[b, iso, :] = 0
+        W[b, :, iso] = 0
+        i, j = (1 + b) % N, (5 + 2 * b) % N
+        if i != j and i != iso and j != iso:
+            W[b, i, j] = 1.0
+            W[b, j, i] = 0.0           # asymmetric mask
+        lam = float(np.max(np.real(np.linalg.eigvals(W[b].numpy())))) or 1.0
+        W[b] = W[b] / max(lam, 1e-6)
+        k, l = (2 + b) % N, (7 + b) % N
+        if k != l and iso not in (k, l):
+            W[b, k, l] = 5e-10         # below zeroTolerance -> not an edge
+            W[b, l, k] = -3e-9         # |.| above zeroTolerance -> an edge
+    W[0, 0, (N - 1)] = float("nan")
+    return W if f64 else W.float()
+
+
+def layer_fixture(gml, mode, N, G, K, P, seed, density, f64):
+    gen = torch.Generator().manual_seed(seed)
+    B, F = 2, G
+    layers = {}
+    for concat in (True, False):
+        torch.manual_seed(seed)
+        layers[concat] = gml.GraphFilterBatchAttentional(G, F, K, P, 1, True, concatenate=concat,
+                                                         attentionMode=mode)
+    ref = layers[True]
+    with torch.no_grad():
+        ref.weight_bias.uniform_(-0.3, 0.3, generator=gen)   # reference init is 0; exercise it
+        layers[False].load_state_dict(ref.state_dict())
+    x = torch.randn(B, G, N, generator=gen) * 0.7
+    S = tricky_gso(gen, B, N, density, f64).unsqueeze(1)
+    out = {}
+    with torch.no_grad():
+        for concat, lay in layers.items():
+            lay.addGSO(S)
+            y = lay(x)
+            out["y_concat" if concat else "y_mean"] = y.numpy()
+        out["aij"] = ref.aij.astype(np.float32)
+        # Nin < N zero-padding path (graphML.py:4642-4646, 4669-4670)
+        nin = max(1, N - 3)
+        out["y_concat_nin"] = ref(x[:, :, :nin].contiguous()).numpy()
+        out["nin"] = np.int64(nin)
+    out.update(x=x.numpy(), S=S.numpy(), mode=np.array(mode), N=N, G=G, K=K, P=P)
+    for k, v in ref.state_dict().items():
+        out["p_" + k] = v.numpy()
+    return out
+
+
+def fov_states(gen, B, N):
+    """Binary 3-channel FOV tensors shaped like AgentState.toInputTensor output
+    (dataloader/statetransformer_Guidance.py:185-239): 9x9 FOV inside a zero 1-px border."""
+    x = torch.zeros(B, N, 3, 11, 11)
+    x[:, :, 0, 1:10, 1:10] = (torch.rand(B, N, 9, 9, generator=gen) < 0.1).float()
+    gi = torch.randint(0, 81, (B, N), generator=gen)
+    goal = torch.zeros(B, N, 121)
+    goal.scatter_(2, ((gi // 9 + 1) * 11 + gi % 9 + 1).unsqueeze(-1), 1.0)
+    x[:, :, 1] = goal.view(B, N, 11, 11)
+    x[:, :, 2, 1:10, 1:10] = (torch.rand(B, N, 9, 9, generator=gen) < 0.08).float()
+    x[:, :, 2, 5, 5] = 1.0
+    return x
+
+
+def model_fixture(classes, name, seed, B, **cfgkw):
+    cfg = make_config(**cfgkw)
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    model = classes[cfg.bottleneckMode](cfg).eval()
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.2, generator=gen)
+                mod.running_var.uniform_(0.5, 1.5, generator=gen)
+                mod.bias.normal_(0, 0.1, generator=gen)
+        model.GFL[0].weight_bias.uniform_(-0.3, 0.3, generator=gen)
+        for n_, p_ in model.named_parameters():
+            if n_.endswith(".bias") and p_.dim() == 1 and "bn" not in n_ and "downsample" not in n_:
+                p_.normal_(0, 0.05, generator=gen)
+    N = cfg.num_agents
+    x = fov_states(gen, B, N)
+    f64 = cfgkw.get("_f64", True)
+    S = tricky_gso(gen, B, N, 0.25 if N <= 20 else 0.08, True)
+    if cfg.bottleneckMode != "BottomNeck_only":
+        S[torch.isnan(S)] = 0.3        # Skip* variants do not scrub NaN (file diff); keep finite
+    S_in = S.clone()
+    model.addGSO(S)
+    with torch.no_grad():
+        logits = model(x)
+    out = dict(x=x.numpy().astype(np.uint8), S=S_in.numpy(), S_after=S.numpy(), logits=logits.numpy(),
+               aij=model.GFL[0].aij.astype(np.float32), cfg=np.array(repr(vars(cfg))))
+    for k, v in model.state_dict().items():
+        out["sd/" + k] = v.numpy()
+    return out
+
+
+def main():
+    gml, classes = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    shapes = [(10, 128, 2, 1), (20, 128, 3, 4), (100, 128, 3, 4), (100, 32, 3, 4), (12, 16, 3, 4)]
+    for mode in ("KeyQuery", "GAT_modified"):
+        for si, (N, G, K, P) in enumerate(shapes):
+            fx = layer_fixture(gml, mode, N, G, K, P, seed=1337 + 17 * si + (0 if mode == "KeyQuery" else 5),
+                               density=0.3 if N <= 20 else 0.1, f64=(si % 2 == 0))
+            path = os.path.join(OUT, "gat_%s_N%d_G%d_K%d_P%d.npz" % (mode, N, G, K, P))
+            np.savez_compressed(path, **fx)
+            print("wrote", path, os.path.getsize(path) // 1024, "KB")
+    models = [
+        ("bottleneck_c1", dict(num_agents=10, nGraphFilterTaps=2, nAttentionHeads=1, B=2)),
+        ("skipconcat_c3", dict(num_agents=100, nGraphFilterTaps=3, nAttentionHeads=4, B=2,
+                               bottleneckMode="BottomNeck_skipConcat")),
+        ("skipconcatgnn_b32_mean", dict(num_agents=20, nGraphFilterTaps=2, nAttentionHeads=4, B=3,
+                                        bottleneckFeature=32, AttentionConcat=False,
+                                        bottleneckMode="BottomNeck_skipConcatGNN", GSO_mode="dist_GSO_one")),
+        ("skipadd_slim_modified", dict(num_agents=12, nGraphFilterTaps=3, nAttentionHeads=2, B=2,
+                                       AttentionConcat=False, attentionMode="GAT_modified",
+                                       CNN_mode="ResNetSlim", bottleneckMode="BottomNeck_skipAddGNN")),
+        ("default_cnn", dict(num_agents=10, nGraphFilterTaps=3, nAttentionHeads=4, B=2, CNN_mode="Default",
+                             attentionMode="GAT_modified")),
+        ("legacy_gat_dropout", dict(num_agents=8, nGraphFilterTaps=2, nAttentionHeads=2, B=2,
+                                    bottleneckMode="", use_dropout=True, numInputFeatures=64,
+                                    CNN_mode="ResNetSlim_withMLP", GSO_mode="full_GSO")),
+    ]
+    for i, (name, kw) in enumerate(models):
+        B = kw.pop("B")
+        fx = model_fixture(classes, name, 4242 + i, B, **kw)
+        path = os.path.join(OUT, "model_%s.npz" % name)
+        np.savez_compressed(path, **fx)
+        print("wrote", path, os.path.getsize(path) // 1024, "KB")
+
+
+if __name__ == "__main__":
+    main()

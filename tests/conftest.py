@@ -1,0 +1,43 @@
+import glob
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_paths(prefix):
+    return sorted(glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+def load_layer_fixture(path):
+    import torch
+    z = np.load(path, allow_pickle=False)
+    p = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p_")}
+    return z, p
+
+
+def load_model_fixture(path):
+    import torch
+    z = np.load(path, allow_pickle=False)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    cfg = types.SimpleNamespace(**eval(str(z["cfg"]), {"__builtins__": {}}))
+    return z, sd, cfg
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    return torch.device("cuda:0")

@@ -1,0 +1,63 @@
+"""Pins oracle/magat_oracle.py to the reference-made golden vectors (CPU only)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_paths, load_layer_fixture, load_model_fixture
+from oracle import magat_oracle as orc
+
+LAYER = golden_paths("gat_")
+MODEL = golden_paths("model_")
+
+
+def test_fixtures_present():
+    assert len(LAYER) == 10 and len(MODEL) == 6
+
+
+@pytest.mark.parametrize("path", LAYER, ids=[os.path.basename(p)[:-4] for p in LAYER])
+def test_layer_oracle_matches_reference(path):
+    z, p = load_layer_fixture(path)
+    x, S = torch.from_numpy(z["x"]), torch.from_numpy(z["S"])
+    mode = str(z["mode"])
+    for concat, key in ((True, "y_concat"), (False, "y_mean")):
+        y, aij = orc.gat_layer_forward(x, S, p, mode, concat)
+        np.testing.assert_allclose(y.numpy(), z[key], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(aij.numpy(), z["aij"], rtol=0, atol=1e-6)
+    nin = int(z["nin"])
+    y, _ = orc.gat_layer_forward(x[:, :, :nin].contiguous(), S, p, mode, True)
+    np.testing.assert_allclose(y.numpy(), z["y_concat_nin"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("path", [p for p in LAYER if "_N100_G128" not in p],
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_loop_oracle_matches_reference(path):
+    """The edge-by-edge float64 restatement agrees too (independent derivation)."""
+    z, p = load_layer_fixture(path)
+    mode = str(z["mode"])
+    for concat, key in ((True, "y_concat"), (False, "y_mean")):
+        y, aij = orc.gat_layer_forward_loops(z["x"], z["S"], p, mode, concat)
+        np.testing.assert_allclose(y, z[key], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(aij, z["aij"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("path", MODEL, ids=[os.path.basename(p)[:-4] for p in MODEL])
+def test_model_oracle_matches_reference(path):
+    z, sd, cfg = load_model_fixture(path)
+    x = torch.from_numpy(z["x"].astype(np.float32))
+    S = torch.from_numpy(z["S"].copy())
+    logits, parts = orc.planner_forward(x, S, sd, cfg, return_parts=True)
+    np.testing.assert_allclose(logits.numpy(), z["logits"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(parts["aij"].numpy(), z["aij"], rtol=0, atol=1e-6)
+    # addGSO's in-place mutation of the caller's tensor is part of the contract
+    np.testing.assert_array_equal(np.nan_to_num(S.numpy(), nan=-7.0), np.nan_to_num(z["S_after"], nan=-7.0))
+
+
+def test_init_state_dict_shapes_match_reference_fixture():
+    for path in MODEL:
+        z, sd, cfg = load_model_fixture(path)
+        mine = orc.init_state_dict(cfg, seed=1)
+        assert set(mine) == set(sd), (path, set(mine) ^ set(sd))
+        for k in sd:
+            assert tuple(mine[k].shape) == tuple(sd[k].shape), (path, k)
