@@ -1,0 +1,141 @@
+/* magat_hip.h -- C ABI of libmagat_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (proroklab/magat_pathplanning) is pure Python/PyTorch and has no FFI of its
+ * own, so the "binding a maintainer would add" is a ctypes stub.  Every
+ * entry point below names the reference code it replaces.  Conventions:
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only
+ *     enqueues work on that stream, never allocates, never synchronises;
+ *   - the caller owns every buffer including `workspace` (size from the matching
+ *     *_workspace_bytes query; 256-byte aligned);
+ *   - return value: MAGAT_OK (0) or a negative MAGAT_ERR_* code; nothing throws.
+ * Layout vocabulary: B planning instances, N agents per instance, M = B*N agent rows,
+ * G in-features, F out-features per head, K filter taps, P attention heads.
+ */
+#ifndef MAGAT_HIP_H
+#define MAGAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAGAT_OK 0
+#define MAGAT_ERR_BAD_SHAPE (-1)   /* non-positive or inconsistent dimensions                */
+#define MAGAT_ERR_UNSUPPORTED (-2) /* feature width / mode the gfx950 kernels do not cover   */
+#define MAGAT_ERR_WORKSPACE (-3)   /* workspace NULL, misaligned or smaller than required    */
+#define MAGAT_ERR_LAUNCH (-4)      /* hipLaunchKernel / hipGetLastError reported a failure   */
+#define MAGAT_ERR_NULL (-5)        /* a required pointer is NULL                             */
+
+#define MAGAT_MODE_KEYQUERY 0     /* attentionMode == 'KeyQuery'      graphML.py:1180-1286 */
+#define MAGAT_MODE_GAT_MODIFIED 1 /* attentionMode == 'GAT_modified'  graphML.py:713-823   */
+
+int magat_abi_version(void);
+const char* magat_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * GAT layer: GraphFilterBatchAttentional.forward  (utils/graphUtils/graphML.py:4636-4671)
+ *   = graphAttentionLSIGFBatch_{KeyQuery,modified} (graphML.py:1724-1827)
+ *   + learnAttentionGSOBatch{_KeyQuery,}           (graphML.py:1180-1286, 713-823)
+ *   + ReLU / head concat or head mean              (graphML.py:4654-4667)
+ *
+ * X  [B,N,G]  row-major node features (= reference x (B,G,N) transposed; it is what
+ *             compressMLP produces before the reference's permute, …bottleneck.py:302-306)
+ * S  [B,N,N]  GSO exactly as handed to addGSO (float32, or float64 when s_is_f64 != 0);
+ *             only |S| > 1e-9 is used (graphML.py:1274-1276).  NaN entries are non-edges.
+ * weight      KeyQuery: (P,1,G,G); GAT_modified: (P,1,F,G)          GFL.0.weight
+ * weight_bias (P,1,F)   used by GAT_modified only                   GFL.0.weight_bias
+ * mixer       (P,1,2F)  used by GAT_modified only                   GFL.0.mixer
+ * taps        (P,F,1,K,G)                                           GFL.0.filterWeight
+ * bias        (F) or NULL                                           GFL.0.bias
+ * Y  concat: [B,N,P*F] with feature index p*F+f (graphML.py:4657-4662); mean: [B,N,F]
+ *    (= reference output (B,PF|F,N) transposed, i.e. already in the (B*N, features) layout
+ *    actionsMLP consumes, …bottleneck.py:331).  ldy = row stride of Y in floats (>= width),
+ *    so Y may be a column block of a wider skip-concat buffer.
+ * A_opt [B,P,N,N] attention (aij of graphML.py:4650) or NULL (not materialised).
+ * Supported: G,F in {16,32,64,128,256}, 1 <= N <= 128 (dense mask path), K >= 1, P >= 1.
+ */
+size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode);
+int magat_gat_pack_weights(const float* weight, const float* weight_bias, const float* mixer,
+                           const float* taps, float* packed, int G, int F, int K, int P, int mode,
+                           void* stream);
+size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, int P, int mode, int concat);
+int magat_gat_forward_packed_f32(const float* X, const void* S, int s_is_f64, const float* packed,
+                                 const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
+                                 size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
+                                 int mode, int concat, void* stream);
+/* convenience: pack (into the tail of workspace) + forward; workspace must hold
+ * magat_gat_workspace_bytes(...) + 4*magat_gat_packed_floats(...) bytes. */
+int magat_gat_forward_dense_f32(const float* X, const void* S, int s_is_f64, const float* weight,
+                                const float* weight_bias, const float* mixer, const float* taps,
+                                const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
+                                size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
+                                int mode, int concat, void* stream);
+
+/* addGSO's in-place scrub of the caller's tensor (decentralplanner_GAT_bottleneck.py:272-277):
+ * scrub_nan: S[isnan(S)] = 0;  gso_mode 1 ('dist_GSO_one'): S[S>0] = 1;  2 ('full_GSO'): S = 1. */
+int magat_gso_prepare(void* S, int s_is_f64, size_t count, int scrub_nan, int gso_mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense per-agent maps on fp32 MFMA (v_mfma_f32_32x32x2_f32): one "segmented-K" NT GEMM that
+ * serves nn.Linear, the folded conv3x3/1x1+BN(+residual)+ReLU blocks of
+ * graphs/models/resnet_pytorch.py:40-73,427-524 and the GAT layer's hoisted linear maps.
+ *
+ * Activations are pixel-major: in[(iy*Win+ix)][m][c], m in [0,M), row stride lda floats,
+ * pixel stride in_pix_stride floats.  For output pixel (oy,ox):
+ *   out[(oy*Wout+ox)][m][n] = act( bias[n] + sum_{ty,tx valid} sum_c in[iy,ix][m][c] * wt[n][(ty*kW+tx)*Cin + c]
+ *                                         + sum_c in2[oy*stride2, ox*stride2][m][c] * wt[n][kH*kW*Cin + c] )
+ * with iy = oy*stride - pad + ty (taps falling in the zero padding are skipped, not multiplied).
+ * in2 (optional, C2 > 0) is the residual branch's 1x1 strided conv or a skip-concat source.
+ * wt is [Cout][Ktot], Ktot = kH*kW*Cin + C2.  Cin, C2, lda, lda2, ldc multiples of 4.
+ */
+typedef struct magat_conv_gemm_desc {
+  const float* in;
+  const float* in2;
+  const float* wt;
+  const float* bias;
+  float* out;
+  int64_t in_pix_stride, in2_pix_stride, out_pix_stride;
+  int M;
+  int Cin, lda, Hin, Win, kH, kW, stride, pad, Hout, Wout;
+  int C2, lda2, W2, stride2;
+  int Cout, ldc, relu;
+} magat_conv_gemm_desc;
+int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
+
+/* y[M,N] = act(x[M,K] @ w[N,K]^T + b)   (torch.nn.Linear; …bottleneck.py:105,160,229) */
+int magat_linear_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M,
+                     int N, int K, int relu, void* stream);
+
+/* First encoder layer: conv3x3(3->32, pad 1, no bias)+BN+ReLU on the (M,3,H,W) NCHW state tensor
+ * (resnet_pytorch.py:439-441, 495-498) -> pixel-major [H*W][M][32].  wt [32][27] BN-folded
+ * (index c*9+ty*3+tx), bias [32]. */
+int magat_conv_first_f32(const float* x, const float* wt, const float* bias, float* out, int M, int H,
+                         int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole per-agent encoder  ConvLayers (+Flatten+Linear for *_withMLP) -> compressMLP
+ * (decentralplanner_GAT_bottleneck.py:90-166, 291-302) from a BN-folded parameter pack.
+ * variant: 0 = ResNet(BasicBlock,[1,1,1]) "ResNetLarge", 1 = ResNetSlim(BasicBlock,[1,1]).
+ * The pack layout is produced by magat_pathplanning_amd.encoder.fold_resnet (documented there
+ * and in DESIGN.md); offsets are passed explicitly so the ABI does not hard-code it.
+ */
+typedef struct magat_encoder_desc {
+  int variant;     /* 0 large, 1 slim */
+  int H, W;        /* FOV+2 (11) */
+  int n_feat;      /* numFeatureMap: width of `feat` (128 for *_withMLP, 1152 otherwise) */
+  int n_comp;      /* bottleneckFeature G (0: skip compressMLP) */
+  const float* pack; /* device pointer to the folded parameter pack */
+  int64_t off[32];   /* float offsets into pack: see DESIGN.md "encoder pack" */
+} magat_encoder_desc;
+size_t magat_encoder_workspace_bytes(const magat_encoder_desc* desc_host, int M);
+int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* x /*M,3,H,W*/,
+                              float* feat, int ldfeat, float* comp, int ldcomp, void* workspace,
+                              size_t workspace_bytes, int M, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGAT_HIP_H */

@@ -1,0 +1,96 @@
+"""ctypes binding of libmagat_hip.so (C ABI declared in include/magat_hip.h).
+
+There is no CPU or torch fallback behind this module: if the shared library is missing or a
+call returns an error code, a MagatNativeError is raised.
+"""
+import ctypes
+import os
+import threading
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libmagat_hip.so")
+
+MODE_KEYQUERY = 0
+MODE_GAT_MODIFIED = 1
+
+_lock = threading.Lock()
+_lib = None
+
+
+class MagatNativeError(RuntimeError):
+    pass
+
+
+class ConvGemmDesc(ctypes.Structure):
+    _fields_ = [("inp", ctypes.c_void_p), ("in2", ctypes.c_void_p), ("wt", ctypes.c_void_p),
+                ("bias", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("in_pix_stride", ctypes.c_int64), ("in2_pix_stride", ctypes.c_int64),
+                ("out_pix_stride", ctypes.c_int64), ("M", ctypes.c_int),
+                ("Cin", ctypes.c_int), ("lda", ctypes.c_int), ("Hin", ctypes.c_int), ("Win", ctypes.c_int),
+                ("kH", ctypes.c_int), ("kW", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int),
+                ("Hout", ctypes.c_int), ("Wout", ctypes.c_int),
+                ("C2", ctypes.c_int), ("lda2", ctypes.c_int), ("W2", ctypes.c_int), ("stride2", ctypes.c_int),
+                ("Cout", ctypes.c_int), ("ldc", ctypes.c_int), ("relu", ctypes.c_int)]
+
+
+class EncoderDesc(ctypes.Structure):
+    _fields_ = [("variant", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
+                ("n_feat", ctypes.c_int), ("n_comp", ctypes.c_int), ("pack", ctypes.c_void_p),
+                ("off", ctypes.c_int64 * 32)]
+
+
+_I, _P, _Z = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+_SIGNATURES = {
+    "magat_abi_version": (ctypes.c_int, []),
+    "magat_error_string": (ctypes.c_char_p, [_I]),
+    "magat_gat_packed_floats": (_Z, [_I] * 5),
+    "magat_gat_pack_weights": (_I, [_P] * 5 + [_I] * 5 + [_P]),
+    "magat_gat_workspace_bytes": (_Z, [_I] * 8),
+    "magat_gat_forward_packed_f32": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
+    "magat_gat_forward_dense_f32": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
+    "magat_gso_prepare": (_I, [_P, _I, _Z, _I, _I, _P]),
+    "magat_conv_gemm_f32": (_I, [ctypes.POINTER(ConvGemmDesc), _P]),
+    "magat_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "magat_conv_first_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "magat_encoder_workspace_bytes": (_Z, [ctypes.POINTER(EncoderDesc), _I]),
+    "magat_encoder_forward_f32": (_I, [ctypes.POINTER(EncoderDesc), _P, _P, _I, _P, _I, _P, _Z, _I, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def library_present():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """The loaded library (loaded once per process; fails loudly if it is not built)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise MagatNativeError(
+                        "libmagat_hip.so is not built (%s). Run `python -m magat_pathplanning_amd.build_native` "
+                        "(needs hipcc); there is no fallback path." % LIB_PATH)
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in _SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.restype, fn.argtypes = res, args
+                _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().magat_error_string(rc)
+        raise MagatNativeError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", rc))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,234 @@
+// Segmented-K fp32 NT GEMM on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// Serves every dense per-agent map of the MAGAT forward:
+//   - conv3x3 / conv1x1 + folded BatchNorm (+ residual 1x1 branch as an extra K segment) + ReLU
+//     of BasicBlock / ResNet (reference graphs/models/resnet_pytorch.py:40-73, 427-524),
+//   - avgpool+fc+Flatten+Linear folded into one 6x6 "valid" conv,
+//   - nn.Linear (compressMLP, actionsMLP; decentralplanner_GAT_bottleneck.py:155-166, 221-239),
+//   - the GAT layer's hoisted linear maps X @ [W_p | H_{p,k}]^T (graphML.py:1257, 1765-1770).
+//
+// Activations are pixel-major [pixel][agent][channel]: for one output pixel a 3x3 conv is a
+// sum over <= 9 taps of plain [agents x Cin] @ [Cin x Cout] GEMMs whose A rows are contiguous,
+// so there is no im2col gather and taps that fall in the zero padding are skipped outright.
+//
+// Tile: BM x BN x 32, 256 threads = 4 waves, each wave TM x TN MFMA tiles of 32x32.
+// LDS rows are padded to 36 floats: a ds_read_b128 16-lane group then touches 16 distinct
+// 16-byte slots (9*r mod 16 is a permutation) -> conflict-free.  Inside a 32-wide K slab the
+// lane halves own k = 0..15 / 16..31, so each lane fetches its 16 A (or B) operands of a row
+// with four ds_read_b128; the MFMA's k-pairing is (s, 16+s), a reordering of the same sum.
+#include "magat_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+struct ConvGemmParams {
+  const float* in;
+  const float* in2;
+  const float* wt;
+  const float* bias;
+  float* out;
+  long long in_pix_stride, in2_pix_stride, out_pix_stride;
+  int M, Mt;
+  int Cin, lda, Hin, Win, kH, kW, stride, pad, Hout, Wout;
+  int C2, lda2, W2, stride2;
+  int Cout, Ktot, ldc, relu;
+  int ntn, npix;
+};
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AI = BM / 32, BI = BN / 32;  // float4 loads per thread per slab
+  __shared__ float lds[2 * (BM + BN) * LDS_LD];
+  float* As = lds;
+  float* Bs = lds + 2 * BM * LDS_LD;
+
+  // XCD-aware block -> tile map: the dispatcher places block b on XCD b % 8, so give each XCD
+  // whole agent tiles (all pixels x all Cout tiles): the tile's inputs stay in that XCD's L2
+  // while its <= 9-fold tap re-reads happen.
+  const int bid = blockIdx.x;
+  const int xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
+  const int per_m = p.npix * p.ntn;
+  const int mtile = xcd + MAGAT_NUM_XCD * (slot / per_m);
+  if (mtile >= p.Mt) return;
+  const int rem = slot % per_m;
+  const int pix = rem / p.ntn, ntile = rem % p.ntn;
+  const int m0 = mtile * BM, n0 = ntile * BN;
+  const int oy = pix / p.Wout, ox = pix % p.Wout;
+
+  // valid tap window of this output pixel
+  const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+  const int ty0 = iy0 < 0 ? -iy0 : 0, tx0 = ix0 < 0 ? -ix0 : 0;
+  const int ty1 = min(p.kH, p.Hin - iy0), tx1 = min(p.kW, p.Win - ix0);
+  const int ntx = tx1 - tx0;
+  const int ntaps = (ty1 - ty0) * ntx;
+  const int spt = (p.Cin + BK - 1) / BK;
+  const int spt2 = (p.C2 + BK - 1) / BK;
+  const int nslab = ntaps * spt + spt2;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int c4 = t & 7, r0 = t >> 3;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[AI], rb[BI];
+
+  auto load_slab = [&](int s) {
+    const float* abase;
+    long long lda;
+    int bk, kvalid;
+    if (s < ntaps * spt) {
+      const int tap = s / spt, k0 = (s - tap * spt) * BK;
+      const int ty = ty0 + tap / ntx, tx = tx0 + tap % ntx;
+      abase = p.in + (long long)((iy0 + ty) * p.Win + (ix0 + tx)) * p.in_pix_stride + k0;
+      lda = p.lda;
+      bk = (ty * p.kW + tx) * p.Cin + k0;
+      kvalid = p.Cin - k0;
+    } else {
+      const int k0 = (s - ntaps * spt) * BK;
+      abase = p.in2 + (long long)(oy * p.stride2 * p.W2 + ox * p.stride2) * p.in2_pix_stride + k0;
+      lda = p.lda2;
+      bk = p.kH * p.kW * p.Cin + k0;
+      kvalid = p.C2 - k0;
+    }
+    const bool kok = c4 * 4 < kvalid;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int m = m0 + r0 + 32 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (kok && m < p.M) v = *reinterpret_cast<const f32x4*>(abase + (long long)m * lda + c4 * 4);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int n = n0 + r0 + 32 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (kok && n < p.Cout) v = *reinterpret_cast<const f32x4*>(p.wt + (long long)n * p.Ktot + bk + c4 * 4);
+      rb[i] = v;
+    }
+  };
+  auto store_slab = [&](int buf) {
+    float* a = As + buf * BM * LDS_LD;
+    float* b = Bs + buf * BN * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDS_LD + c4 * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDS_LD + c4 * 4) = rb[i];
+  };
+
+  if (nslab > 0) {
+    load_slab(0);
+    store_slab(0);
+  }
+  __syncthreads();
+
+  const int frag_off = (lane & 31) * LDS_LD + 16 * (lane >> 5);
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) load_slab(s + 1);
+    const float* a = As + buf * BM * LDS_LD + (wm * WTM) * LDS_LD + frag_off;
+    const float* b = Bs + buf * BN * LDS_LD + (wn * WTN) * LDS_LD + frag_off;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // two halves of the lane's 16 k values: bounds live registers
+      f32x4 fa[TM][2], fb[TN][2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          fa[i][q] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS_LD + (2 * h + q) * 4);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          fb[j][q] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS_LD + (2 * h + q) * 4);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q][e], fb[j][q][e], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < nslab) store_slab(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: bias (+ReLU); C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* obase = p.out + (long long)pix * p.out_pix_stride;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+    const bool nok = n < p.Cout;
+    const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        float v = acc[i][j][r] + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (nok && m < p.M) obase[(long long)m * p.ldc + n] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch(ConvGemmParams& p, hipStream_t st) {
+  p.Mt = (p.M + BM - 1) / BM;
+  p.ntn = (p.Cout + BN - 1) / BN;
+  const long long groups = (p.Mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD;
+  const long long grid = groups * MAGAT_NUM_XCD * p.npix * p.ntn;
+  if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  return magat_check_launch();
+}
+
+}  // namespace
+
+extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) {
+  if (!d || !d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
+  if (d->M <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->kH <= 0 || d->kW <= 0 ||
+      d->stride <= 0 || d->pad < 0 || d->C2 < 0)
+    return MAGAT_ERR_BAD_SHAPE;
+  if ((d->Cin & 3) || (d->C2 & 3) || (d->lda & 3) || d->lda < d->Cin || d->ldc < d->Cout) return MAGAT_ERR_BAD_SHAPE;
+  if (d->C2 > 0 && (!d->in2 || (d->lda2 & 3) || d->lda2 < d->C2 || d->stride2 <= 0)) return MAGAT_ERR_BAD_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(d->in) | reinterpret_cast<uintptr_t>(d->wt) |
+       reinterpret_cast<uintptr_t>(d->in2)) & 15)
+    return MAGAT_ERR_BAD_SHAPE;
+  ConvGemmParams p;
+  p.in = d->in; p.in2 = d->in2; p.wt = d->wt; p.bias = d->bias; p.out = d->out;
+  p.in_pix_stride = d->in_pix_stride; p.in2_pix_stride = d->in2_pix_stride; p.out_pix_stride = d->out_pix_stride;
+  p.M = d->M; p.Cin = d->Cin; p.lda = d->lda; p.Hin = d->Hin; p.Win = d->Win; p.kH = d->kH; p.kW = d->kW;
+  p.stride = d->stride; p.pad = d->pad; p.Hout = d->Hout; p.Wout = d->Wout;
+  p.C2 = d->C2; p.lda2 = d->lda2; p.W2 = d->W2; p.stride2 = d->stride2;
+  p.Cout = d->Cout; p.Ktot = d->kH * d->kW * d->Cin + d->C2; p.ldc = d->ldc; p.relu = d->relu;
+  p.npix = d->Hout * d->Wout;
+  if ((p.in_pix_stride & 3) || (p.in2_pix_stride & 3)) return MAGAT_ERR_BAD_SHAPE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (p.Cout > 64) return launch<128, 128, 2, 2>(p, st);
+  if (p.Cout > 32) return launch<128, 64, 2, 2>(p, st);
+  return launch<128, 32, 4, 1>(p, st);
+}
+
+extern "C" int magat_linear_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M,
+                                int N, int K, int relu, void* stream) {
+  magat_conv_gemm_desc d = {};
+  d.in = x; d.wt = w; d.bias = b; d.out = y;
+  d.M = M; d.Cin = K; d.lda = ldx; d.Hin = d.Win = 1; d.kH = d.kW = 1; d.stride = 1; d.pad = 0;
+  d.Hout = d.Wout = 1; d.Cout = N; d.ldc = ldy; d.relu = relu;
+  return magat_conv_gemm_f32(&d, stream);
+}

@@ -1,0 +1,164 @@
+// Per-agent CNN encoder + compressMLP on gfx950 (reference decentralplanner_GAT_bottleneck.py:90-166,
+// 291-302; graphs/models/resnet_pytorch.py:40-73, 334-524), inference form: BatchNorm folded into the
+// conv weights host-side (fp64 fold, fp32 store), residual 1x1 branch appended as an extra K segment,
+// avgpool+fc(+Flatten+Linear) folded into one "valid" conv.  All GEMM-shaped layers run on the fp32
+// MFMA kernel of conv_gemm_f32.hip; only the 3-channel first conv is a direct VALU kernel.
+#include <cstdlib>
+
+#include "magat_common.h"
+
+namespace {
+
+// conv3x3(3->32, pad 1)+BN+ReLU on (M,3,H,W) NCHW -> pixel-major [H*W][M][32].
+// One thread per (pixel, agent) computes all 32 output channels; the 32x27 weights are wave-uniform
+// (scalar loads), the output row is 128 contiguous bytes.
+__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         int M, int H, int W) {
+  __shared__ float ws[27 * 32 + 32];
+  for (int i = threadIdx.x; i < 27 * 32; i += blockDim.x) {
+    const int co = i / 27, k = i % 27;
+    ws[k * 32 + co] = wt[i];
+  }
+  for (int i = threadIdx.x; i < 32; i += blockDim.x) ws[27 * 32 + i] = bias[i];
+  __syncthreads();
+  const long long total = (long long)H * W * M;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int pix = (int)(idx / M), m = (int)(idx % M);
+    const int oy = pix / W, ox = pix % W;
+    float acc[32];
+#pragma unroll
+    for (int co = 0; co < 32; ++co) acc[co] = ws[27 * 32 + co];
+    const float* xm = x + (long long)m * 3 * H * W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const int iy = oy + ty - 1, ix = ox + tx - 1;
+          float v = 0.f;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = xm[(c * H + iy) * W + ix];
+          const float* wk = ws + (c * 9 + ty * 3 + tx) * 32;
+#pragma unroll
+          for (int co = 0; co < 32; ++co) acc[co] = fmaf(v, wk[co], acc[co]);
+        }
+    float* o = out + ((long long)pix * M + m) * 32;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      f32x4 v = {fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f),
+                 fmaxf(acc[4 * q + 3], 0.f)};
+      *reinterpret_cast<f32x4*>(o + 4 * q) = v;
+    }
+  }
+}
+
+int enc_chunk_agents(int M) {
+  const char* env = getenv("MAGAT_ENC_CHUNK");
+  long long c = env ? atoll(env) : 8192;
+  if (c < 128) c = 128;
+  if (c > M) c = M;
+  return (int)c;
+}
+
+struct BlockShape {
+  int cin, cout, stride;
+};
+
+}  // namespace
+
+extern "C" int magat_conv_first_f32(const float* x, const float* wt, const float* bias, float* out, int M, int H,
+                                    int W, void* stream) {
+  if (!x || !wt || !bias || !out) return MAGAT_ERR_NULL;
+  if (M <= 0 || H <= 0 || W <= 0) return MAGAT_ERR_BAD_SHAPE;
+  long long blocks = ((long long)H * W * M + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, wt,
+                     bias, out, M, H, W);
+  return magat_check_launch();
+}
+
+// floats per agent of one rotating activation buffer
+static size_t enc_buf_floats_per_agent(const magat_encoder_desc* d) {
+  const int Ho = (d->H + 2 - 3) / 2 + 1, Wo = (d->W + 2 - 3) / 2 + 1;
+  const size_t a0 = (size_t)d->H * d->W * 32;
+  const size_t a3 = (size_t)Ho * Wo * (d->variant == 0 ? 128 : 64);
+  return a0 > a3 ? a0 : a3;
+}
+
+extern "C" size_t magat_encoder_workspace_bytes(const magat_encoder_desc* d, int M) {
+  if (!d || M <= 0) return 0;
+  const int mc = enc_chunk_agents(M);
+  return 3 * magat_align_up(enc_buf_floats_per_agent(d) * (size_t)mc * sizeof(float), 256);
+}
+
+extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const float* x, float* feat, int ldfeat,
+                                         float* comp, int ldcomp, void* workspace, size_t workspace_bytes, int M,
+                                         void* stream) {
+  if (!d || !x || !feat || !d->pack) return MAGAT_ERR_NULL;
+  if (M <= 0 || d->H < 3 || d->W < 3 || d->n_feat <= 0) return MAGAT_ERR_BAD_SHAPE;
+  if (d->variant != 0 && d->variant != 1) return MAGAT_ERR_UNSUPPORTED;
+  if (d->n_comp > 0 && !comp) return MAGAT_ERR_NULL;
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) ||
+      workspace_bytes < magat_encoder_workspace_bytes(d, M))
+    return MAGAT_ERR_WORKSPACE;
+  const int H = d->H, W = d->W;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int mc = enc_chunk_agents(M);
+  const size_t bstride = magat_align_up(enc_buf_floats_per_agent(d) * (size_t)mc * sizeof(float), 256) / sizeof(float);
+  float* buf[3] = {static_cast<float*>(workspace), static_cast<float*>(workspace) + bstride,
+                   static_cast<float*>(workspace) + 2 * bstride};
+  const float* pk = d->pack;
+  const BlockShape shapes[3] = {{32, 32, 2}, {32, 64, 1}, {64, 128, 1}};
+  const int nblocks = d->variant == 0 ? 3 : 2;
+
+  for (int m0 = 0; m0 < M; m0 += mc) {
+    const int mm = (M - m0) < mc ? (M - m0) : mc;
+    int rc = magat_conv_first_f32(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W, stream);
+    if (rc != MAGAT_OK) return rc;
+    int cur = 0;              // buffer holding the block input
+    int hin = H, win = W;
+    for (int l = 0; l < nblocks; ++l) {
+      const BlockShape s = shapes[l];
+      const int hout = s.stride == 2 ? Ho : hin, wout = s.stride == 2 ? Wo : win;
+      const int mid = (cur + 1) % 3, nxt = (cur + 2) % 3;
+      magat_conv_gemm_desc g = {};
+      // conv1 + bn1 + relu
+      g.in = buf[cur]; g.wt = pk + d->off[2 + 4 * l]; g.bias = pk + d->off[3 + 4 * l]; g.out = buf[mid];
+      g.in_pix_stride = (int64_t)mm * s.cin; g.out_pix_stride = (int64_t)mm * s.cout;
+      g.M = mm; g.Cin = s.cin; g.lda = s.cin; g.Hin = hin; g.Win = win; g.kH = g.kW = 3; g.stride = s.stride;
+      g.pad = 1; g.Hout = hout; g.Wout = wout; g.Cout = s.cout; g.ldc = s.cout; g.relu = 1;
+      rc = magat_conv_gemm_f32(&g, stream);
+      if (rc != MAGAT_OK) return rc;
+      // conv2 + bn2 + (1x1 strided downsample + bn) + relu
+      magat_conv_gemm_desc h = {};
+      h.in = buf[mid]; h.in2 = buf[cur]; h.wt = pk + d->off[4 + 4 * l]; h.bias = pk + d->off[5 + 4 * l];
+      h.out = buf[nxt];
+      h.in_pix_stride = (int64_t)mm * s.cout; h.in2_pix_stride = (int64_t)mm * s.cin;
+      h.out_pix_stride = (int64_t)mm * s.cout;
+      h.M = mm; h.Cin = s.cout; h.lda = s.cout; h.Hin = hout; h.Win = wout; h.kH = h.kW = 3; h.stride = 1; h.pad = 1;
+      h.Hout = hout; h.Wout = wout; h.C2 = s.cin; h.lda2 = s.cin; h.W2 = win; h.stride2 = s.stride;
+      h.Cout = s.cout; h.ldc = s.cout; h.relu = 1;
+      rc = magat_conv_gemm_f32(&h, stream);
+      if (rc != MAGAT_OK) return rc;
+      cur = nxt; hin = hout; win = wout;
+    }
+    // head: avgpool(2)+fc(+Flatten+Linear) folded into a (hin x win) valid conv -> [mm][n_feat]
+    const int clast = shapes[nblocks - 1].cout;
+    magat_conv_gemm_desc g = {};
+    g.in = buf[cur]; g.wt = pk + d->off[14]; g.bias = pk + d->off[15];
+    g.out = feat + (size_t)m0 * ldfeat;
+    g.in_pix_stride = (int64_t)mm * clast; g.M = mm; g.Cin = clast; g.lda = clast; g.Hin = hin; g.Win = win;
+    g.kH = hin; g.kW = win; g.stride = 1; g.pad = 0; g.Hout = g.Wout = 1; g.Cout = d->n_feat; g.ldc = ldfeat;
+    g.relu = 0;
+    rc = magat_conv_gemm_f32(&g, stream);
+    if (rc != MAGAT_OK) return rc;
+    if (d->n_comp > 0) {
+      rc = magat_linear_f32(feat + (size_t)m0 * ldfeat, ldfeat, pk + d->off[16], pk + d->off[17],
+                            comp + (size_t)m0 * ldcomp, ldcomp, mm, d->n_comp, d->n_feat, 1, stream);
+      if (rc != MAGAT_OK) return rc;
+    }
+  }
+  return MAGAT_OK;
+}

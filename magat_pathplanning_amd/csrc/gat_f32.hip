@@ -1,0 +1,466 @@
+// GraphFilterBatchAttentional.forward on gfx950 (reference utils/graphUtils/graphML.py:4636-4671,
+// 1724-1827, 1180-1286, 713-823), dense-GSO path (N <= 128).
+//
+// Algebra (SURVEY.md section 8(a) "verified restatement"), with X[b,n,:] the node-feature rows:
+//   M[i,j]   = |S[b,i,j]| > 1e-9
+//   KeyQuery : e[i,j] = x_i . q_j,  q_j = W_p x_j
+//   modified : e[i,j] = lrelu_0.2(c1_j + c2_i),  c1 = X (W_p^T a1) + a1.wb,  c2 = X (W_p^T a2) + a2.wb
+//   A[i,j]   = softmax over the edges of row i (rows without edges are all zero)
+//   Y_p      = U_0 + A^T (U_1 + A^T (U_2 + ...)),   U_k = X H_{p,k}^T     (Horner form of sum_k (A^T)^k X H_k^T)
+//   concat: out[n, p*F+f] = relu(Y_p[n,f] + bias[f]);  mean: relu(sum_p (Y_p + bias) / P)
+//
+// Two launches per call (per chunk of instances):
+//   1. the dense per-agent maps Z = X @ [W_p | H_{p,k}]^T on fp32 MFMA (conv_gemm_f32.hip) - they do not
+//      shrink with graph sparsity and are ~95 % of the layer's flops;
+//   2. gat_dense_kernel below: one workgroup per (instance, head).  Q_p and the hop operand tiles are staged
+//      in LDS with coalesced 16-byte row loads, edge scores use 16-lane dot products straight out of LDS,
+//      the row softmax is a 64-lane wavefront reduction, and the K-1 hops gather neighbour rows from LDS
+//      (column aggregation with row-normalised weights - the reference's x @ aij quirk).  Y is written once,
+//      already in the (B*N, P*F) layout actionsMLP consumes.  This kernel is ~3 flop/byte: HBM-bound.
+#include "magat_common.h"
+
+namespace {
+
+struct GatParams {
+  const float* X;   // [B*N, ldx]
+  const void* S;    // [B,N,N] f32 or f64
+  const float* Z;   // [chunkB*N, NC]  hoisted linear maps of this chunk
+  const float* bias;
+  float* Y;         // concat: [B*N, ldy] (+ head*F);  mean: Ytmp [B*N, P*F]
+  float* A_opt;     // [B,P,N,N] or null
+  int B, N, K, P, mode, concat, s_is_f64;
+  int ldx, ldy, NC, lda_a;
+  int qoff, uoff, c1off, c2off;  // column offsets inside a Z row
+  int b0;                        // first instance of this chunk
+};
+
+__device__ __forceinline__ bool is_edge(const void* S, long long idx, int f64) {
+  if (f64) return fabs(static_cast<const double*>(S)[idx]) > 1e-9;
+  return fabsf(static_cast<const float*>(S)[idx]) > 1e-9f;
+}
+
+template <int G, int F>
+__global__ void gat_dense_kernel(const GatParams p) {
+  constexpr int RW = G > F ? G : F;
+  constexpr int GC = G / 4, FC = F / 4;             // 16-byte chunks per row
+  constexpr int LE = GC < 16 ? GC : 16;             // lanes per edge in the score phase
+  constexpr int CPL = GC / LE;                      // chunks per lane
+  constexpr int EPS = 64 / LE;                      // edges per wave step
+  constexpr int LF = FC < 64 ? FC : 64;             // lanes per output row in the hop phase
+  constexpr int RPW = 64 / LF;                      // rows per wave step
+  static_assert(FC <= 64, "F <= 256");
+  extern __shared__ __align__(16) float smem[];
+
+  const int N = p.N;
+  const int bid = blockIdx.x;
+  const int xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
+  const int bl = xcd + MAGAT_NUM_XCD * (slot / p.P);   // heads of one instance share an XCD (X_b, S_b in L2)
+  const int head = slot % p.P;
+  if (bl >= p.B) return;
+  const int b = p.b0 + bl;
+
+  float* R0 = smem;
+  float* R1 = R0 + N * RW;
+  float* A = R1 + N * F;
+  float* c1s = A + N * p.lda_a;
+  int* nbr = reinterpret_cast<int*>(c1s + ((N + 3) & ~3));
+
+  const int t = threadIdx.x, NT = blockDim.x, lane = t & 63, wave = t >> 6, nwaves = NT >> 6;
+  const float* Zb = p.Z + (long long)bl * N * p.NC;
+  const float* Xb = p.X + (long long)b * N * p.ldx;
+  const long long sbase = (long long)b * N * N;
+  const int K = p.K;
+
+  // ---- phase 0: stage Q_p (KeyQuery) and the deepest hop operand U_{K-1} in LDS
+  if (p.mode == MAGAT_MODE_KEYQUERY) {
+    const int qo = p.qoff + head * G;
+    for (int idx = t; idx < N * GC; idx += NT) {
+      const int n = idx / GC, c = idx - n * GC;
+      *reinterpret_cast<f32x4*>(R0 + n * G + 4 * c) =
+          *reinterpret_cast<const f32x4*>(Zb + (long long)n * p.NC + qo + 4 * c);
+    }
+  } else {
+    for (int n = t; n < N; n += NT) c1s[n] = Zb[(long long)n * p.NC + p.c1off + head];
+  }
+  if (K > 1) {
+    const int uo = p.uoff + (head * K + (K - 1)) * F;
+    for (int idx = t; idx < N * FC; idx += NT) {
+      const int n = idx / FC, c = idx - n * FC;
+      *reinterpret_cast<f32x4*>(R1 + n * F + 4 * c) =
+          *reinterpret_cast<const f32x4*>(Zb + (long long)n * p.NC + uo + 4 * c);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 1: attention rows (one wave per row)
+  if (K > 1 || p.A_opt) {
+    int* nb = nbr + wave * 128;
+    const int sub = lane % LE, grp = lane / LE;
+    for (int i = wave; i < N; i += nwaves) {
+      const bool m0 = lane < N && is_edge(p.S, sbase + (long long)i * N + lane, p.s_is_f64);
+      const bool m1 = lane + 64 < N && is_edge(p.S, sbase + (long long)i * N + lane + 64, p.s_is_f64);
+      const unsigned long long k0 = __ballot(m0), k1 = __ballot(m1);
+      const int deg0 = __popcll(k0), deg = deg0 + __popcll(k1);
+      float v0 = 0.f, v1 = 0.f;
+      if (p.mode == MAGAT_MODE_KEYQUERY) {
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if (m0) nb[__popcll(k0 & lt)] = lane;
+        if (m1) nb[deg0 + __popcll(k1 & lt)] = lane + 64;
+        f32x4 xi[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q)
+          xi[q] = *reinterpret_cast<const f32x4*>(Xb + (long long)i * p.ldx + 4 * (sub + LE * q));
+        __builtin_amdgcn_wave_barrier();
+        for (int t0 = 0; t0 < deg; t0 += EPS) {
+          const int ei = t0 + grp;
+          const bool ok = ei < deg;
+          const int j = ok ? nb[ei] : 0;
+          float d = 0.f;
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(R0 + j * G + 4 * (sub + LE * q));
+            d = fmaf(xi[q][0], qv[0], d);
+            d = fmaf(xi[q][1], qv[1], d);
+            d = fmaf(xi[q][2], qv[2], d);
+            d = fmaf(xi[q][3], qv[3], d);
+          }
+#pragma unroll
+          for (int o = LE / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+          if (ok && sub == 0) A[i * p.lda_a + j] = d;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (m0) v0 = A[i * p.lda_a + lane];
+        if (m1) v1 = A[i * p.lda_a + lane + 64];
+      } else {
+        const float c2 = Zb[(long long)i * p.NC + p.c2off + head];
+        if (m0) { const float e = c1s[lane] + c2; v0 = e > 0.f ? e : 0.2f * e; }
+        if (m1) { const float e = c1s[lane + 64] + c2; v1 = e > 0.f ? e : 0.2f * e; }
+      }
+      const float ninf = -__builtin_inff();
+      const float mx = wave_max(fmaxf(m0 ? v0 : ninf, m1 ? v1 : ninf));
+      const float e0 = m0 ? expf(v0 - mx) : 0.f, e1 = m1 ? expf(v1 - mx) : 0.f;
+      const float sum = wave_sum(e0 + e1);
+      const float a0 = m0 ? e0 / sum : 0.f, a1 = m1 ? e1 / sum : 0.f;
+      if (lane < N) A[i * p.lda_a + lane] = a0;
+      if (lane + 64 < N) A[i * p.lda_a + lane + 64] = a1;
+      if (p.A_opt) {
+        float* ao = p.A_opt + (((long long)b * p.P + head) * N + i) * N;
+        if (lane < N) ao[lane] = a0;
+        if (lane + 64 < N) ao[lane + 64] = a1;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: Horner hops  T <- U_k + A^T T   (k = K-2 .. 0), last one fused with bias/ReLU/store
+  const int sub = lane % LF, grp = lane / LF;
+  const unsigned long long gmask = LF == 64 ? ~0ull : ((1ull << LF) - 1ull);
+  float* Rold = R1;
+  float* Rnew = R0;
+  for (int k = K - 2; k >= -1; --k) {
+    if (k < 0 && K > 1) break;
+    const int kk = k < 0 ? 0 : k;               // K == 1: plain Y = U_0 (+bias)
+    const int uo = p.uoff + (head * K + kk) * F;
+    const bool last = kk == 0;
+    for (int jb = wave * RPW; jb < N; jb += nwaves * RPW) {
+      const int j = jb + grp;
+      const bool jok = j < N;
+      f32x4 u = {0.f, 0.f, 0.f, 0.f};
+      if (jok) u = *reinterpret_cast<const f32x4*>(Zb + (long long)j * p.NC + uo + 4 * sub);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (K > 1) {
+        for (int r0 = 0; r0 < N; r0 += LF) {
+          const int i = r0 + sub;
+          const float a = (jok && i < N) ? A[i * p.lda_a + j] : 0.f;
+          const unsigned long long bal = __ballot(a != 0.f);
+          unsigned long long mine = (bal >> (grp * LF)) & gmask;
+          while (mine) {
+            const int ii = r0 + __builtin_ctzll(mine);
+            mine &= mine - 1;
+            const float av = A[ii * p.lda_a + j];
+            const f32x4 tv = *reinterpret_cast<const f32x4*>(Rold + ii * F + 4 * sub);
+            acc[0] = fmaf(av, tv[0], acc[0]);
+            acc[1] = fmaf(av, tv[1], acc[1]);
+            acc[2] = fmaf(av, tv[2], acc[2]);
+            acc[3] = fmaf(av, tv[3], acc[3]);
+          }
+        }
+      }
+      f32x4 res = u + acc;
+      if (!jok) continue;
+      if (last) {
+        if (p.bias) res += *reinterpret_cast<const f32x4*>(p.bias + 4 * sub);
+        if (p.concat) {
+          res[0] = fmaxf(res[0], 0.f); res[1] = fmaxf(res[1], 0.f);
+          res[2] = fmaxf(res[2], 0.f); res[3] = fmaxf(res[3], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(p.Y + ((long long)b * N + j) * p.ldy + head * F + 4 * sub) = res;
+      } else {
+        *reinterpret_cast<f32x4*>(Rnew + j * F + 4 * sub) = res;
+      }
+    }
+    if (last) break;
+    __syncthreads();
+    float* tmp = Rold; Rold = Rnew; Rnew = tmp;
+  }
+}
+
+// mean over heads then ReLU (graphML.py:4663-4667)
+__global__ void head_mean_relu_kernel(const float* __restrict__ ytmp, float* __restrict__ y, long long M, int P,
+                                      int F, int ldy) {
+  const int FC = F / 4;
+  const long long total = M * FC;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long m = idx / FC;
+    const int c = (int)(idx - m * FC);
+    f32x4 s = *reinterpret_cast<const f32x4*>(ytmp + m * (long long)P * F + 4 * c);
+    for (int q = 1; q < P; ++q) s += *reinterpret_cast<const f32x4*>(ytmp + (m * P + q) * (long long)F + 4 * c);
+    const float fp = (float)P;
+    f32x4 r = {fmaxf(s[0] / fp, 0.f), fmaxf(s[1] / fp, 0.f), fmaxf(s[2] / fp, 0.f), fmaxf(s[3] / fp, 0.f)};
+    *reinterpret_cast<f32x4*>(y + m * ldy + 4 * c) = r;
+  }
+}
+
+// ---- weight packing: Bt [NC][G] + column bias [NC]
+struct PackLayout {
+  int NC, qoff, uoff, c1off, c2off;
+};
+PackLayout pack_layout(int G, int F, int K, int P, int mode) {
+  PackLayout L;
+  if (mode == MAGAT_MODE_KEYQUERY) {
+    L.qoff = 0;
+    L.uoff = P * G;
+    L.c1off = L.c2off = 0;
+    L.NC = P * G + P * K * F;
+  } else {
+    L.qoff = 0;
+    L.uoff = 0;
+    L.c1off = P * K * F;
+    L.c2off = L.c1off + P;
+    L.NC = (L.c2off + P + 3) & ~3;
+  }
+  return L;
+}
+
+__global__ void pack_kernel(const float* __restrict__ weight, const float* __restrict__ wbias,
+                            const float* __restrict__ mixer, const float* __restrict__ taps,
+                            float* __restrict__ packed, int G, int F, int K, int P, int mode, PackLayout L) {
+  float* Bt = packed;
+  float* cb = packed + (long long)L.NC * G;
+  const long long total = (long long)L.NC * G;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total + L.NC;
+       idx += (long long)gridDim.x * blockDim.x) {
+    if (idx >= total) {  // column bias
+      const int col = (int)(idx - total);
+      float v = 0.f;
+      if (mode == MAGAT_MODE_GAT_MODIFIED && col >= L.c1off && col < L.c2off + P) {
+        const int which = col >= L.c2off, hp = which ? col - L.c2off : col - L.c1off;
+        for (int f = 0; f < F; ++f) v = fmaf(mixer[(long long)hp * 2 * F + which * F + f], wbias[hp * F + f], v);
+      }
+      cb[col] = v;
+      continue;
+    }
+    const int col = (int)(idx / G), g = (int)(idx % G);
+    float v = 0.f;
+    if (mode == MAGAT_MODE_KEYQUERY && col < L.uoff) {
+      v = weight[(long long)col * G + g];  // (P,1,G,G): row p*G+g' = W_p[g',:]
+    } else if (col >= L.uoff && col < L.uoff + P * K * F) {
+      const int r = col - L.uoff, hp = r / (K * F), k = (r / F) % K, f = r % F;
+      v = taps[(((long long)hp * F + f) * K + k) * G + g];  // (P,F,1,K,G)
+    } else if (mode == MAGAT_MODE_GAT_MODIFIED && col >= L.c1off && col < L.c2off + P) {
+      const int which = col >= L.c2off, hp = which ? col - L.c2off : col - L.c1off;
+      for (int f = 0; f < F; ++f)
+        v = fmaf(mixer[(long long)hp * 2 * F + which * F + f], weight[((long long)hp * F + f) * G + g], v);
+    }
+    Bt[idx] = v;
+  }
+}
+
+bool supported_width(int w) { return w == 16 || w == 32 || w == 64 || w == 128 || w == 256; }
+
+size_t gat_lds_bytes(int N, int G, int F, int nwaves) {
+  const int RW = G > F ? G : F;
+  const int lda = N | 1;
+  return sizeof(float) * ((size_t)N * RW + (size_t)N * F + (size_t)N * lda + ((N + 3) & ~3)) +
+         sizeof(int) * 128 * (size_t)nwaves;
+}
+
+int gat_block_threads(int N) {
+  if (N <= 16) return 128;
+  if (N <= 32) return 256;
+  if (N <= 64) return 512;
+  return 1024;
+}
+
+// instances per chunk: keep the hoisted-map intermediate Z (chunk*N*NC floats) inside the 256 MiB
+// Infinity Cache so the sparse kernel re-reads it on-die rather than from HBM.
+int gat_chunk_instances(int B, int N, int NC) {
+  const char* env = getenv("MAGAT_GAT_CHUNK_MB");
+  const double mb = env ? atof(env) : 96.0;
+  long long per = (long long)N * NC * 4;
+  long long c = (long long)(mb * 1048576.0) / (per > 0 ? per : 1);
+  if (c < 8) c = 8;
+  if (c > B) c = B;
+  return (int)c;
+}
+
+template <int G, int F>
+int launch_gat(const GatParams& p, int blocks, int threads, size_t lds, hipStream_t st) {
+  static size_t configured = 0;
+  if (lds > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gat_dense_kernel<G, F>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return MAGAT_ERR_LAUNCH;
+    configured = lds;
+  }
+  hipLaunchKernelGGL((gat_dense_kernel<G, F>), dim3(blocks), dim3(threads), lds, st, p);
+  return magat_check_launch();
+}
+
+}  // namespace
+
+extern "C" size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode) {
+  if (G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
+  const PackLayout L = pack_layout(G, F, K, P, mode);
+  return (size_t)L.NC * (G + 1);
+}
+
+extern "C" int magat_gat_pack_weights(const float* weight, const float* weight_bias, const float* mixer,
+                                      const float* taps, float* packed, int G, int F, int K, int P, int mode,
+                                      void* stream) {
+  if (!weight || !taps || !packed) return MAGAT_ERR_NULL;
+  if (mode == MAGAT_MODE_GAT_MODIFIED && (!weight_bias || !mixer)) return MAGAT_ERR_NULL;
+  if (G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
+  if (mode != MAGAT_MODE_KEYQUERY && mode != MAGAT_MODE_GAT_MODIFIED) return MAGAT_ERR_UNSUPPORTED;
+  const PackLayout L = pack_layout(G, F, K, P, mode);
+  const long long total = (long long)L.NC * (G + 1);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), weight, weight_bias,
+                     mixer, taps, packed, G, F, K, P, mode, L);
+  return magat_check_launch();
+}
+
+extern "C" size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, int P, int mode, int concat) {
+  if (B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
+  const PackLayout L = pack_layout(G, F, K, P, mode);
+  const int chunk = gat_chunk_instances(B, N, L.NC);
+  size_t bytes = magat_align_up((size_t)chunk * N * L.NC * sizeof(float), 256);
+  if (!concat) bytes += magat_align_up((size_t)B * N * P * F * sizeof(float), 256);
+  return bytes;
+}
+
+extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s_is_f64, const float* packed,
+                                            const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
+                                            size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
+                                            int mode, int concat, void* stream) {
+  if (!X || !S || !packed || !Y) return MAGAT_ERR_NULL;
+  if (B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
+  if (mode != MAGAT_MODE_KEYQUERY && mode != MAGAT_MODE_GAT_MODIFIED) return MAGAT_ERR_UNSUPPORTED;
+  if (G != F || !supported_width(G) || N > 128) return MAGAT_ERR_UNSUPPORTED;
+  const int width = concat ? P * F : F;
+  if (ldy < width || (ldy & 3)) return MAGAT_ERR_BAD_SHAPE;
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) ||
+      workspace_bytes < magat_gat_workspace_bytes(B, N, G, F, K, P, mode, concat))
+    return MAGAT_ERR_WORKSPACE;
+  const int threads = gat_block_threads(N);
+  const size_t lds = gat_lds_bytes(N, G, F, threads / 64);
+  if (lds > 160 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+
+  const PackLayout L = pack_layout(G, F, K, P, mode);
+  const int chunk = gat_chunk_instances(B, N, L.NC);
+  float* Z = static_cast<float*>(workspace);
+  float* Ytmp = reinterpret_cast<float*>(static_cast<char*>(workspace) +
+                                         magat_align_up((size_t)chunk * N * L.NC * sizeof(float), 256));
+  GatParams p;
+  p.X = X; p.S = S; p.Z = Z; p.bias = bias; p.A_opt = A_opt;
+  p.Y = concat ? Y : Ytmp;
+  p.N = N; p.K = K; p.P = P; p.mode = mode; p.concat = concat; p.s_is_f64 = s_is_f64;
+  p.ldx = G; p.ldy = concat ? ldy : P * F; p.NC = L.NC; p.lda_a = N | 1;
+  p.qoff = L.qoff; p.uoff = L.uoff; p.c1off = L.c1off; p.c2off = L.c2off;
+
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int cb = (B - b0) < chunk ? (B - b0) : chunk;
+    int rc = magat_linear_f32(X + (size_t)b0 * N * G, G, packed, packed + (size_t)L.NC * G, Z, L.NC, cb * N, L.NC,
+                              G, 0, stream);
+    if (rc != MAGAT_OK) return rc;
+    p.B = cb; p.b0 = b0;
+    const int blocks = (cb + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD * P;
+    switch (G) {
+      case 16: rc = launch_gat<16, 16>(p, blocks, threads, lds, st); break;
+      case 32: rc = launch_gat<32, 32>(p, blocks, threads, lds, st); break;
+      case 64: rc = launch_gat<64, 64>(p, blocks, threads, lds, st); break;
+      case 128: rc = launch_gat<128, 128>(p, blocks, threads, lds, st); break;
+      case 256: rc = launch_gat<256, 256>(p, blocks, threads, lds, st); break;
+      default: rc = MAGAT_ERR_UNSUPPORTED;
+    }
+    if (rc != MAGAT_OK) return rc;
+  }
+  if (!concat) {
+    const long long M = (long long)B * N;
+    long long blocks = (M * (F / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(head_mean_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Ytmp, Y, M, P, F, ldy);
+    return magat_check_launch();
+  }
+  return MAGAT_OK;
+}
+
+extern "C" int magat_gat_forward_dense_f32(const float* X, const void* S, int s_is_f64, const float* weight,
+                                           const float* weight_bias, const float* mixer, const float* taps,
+                                           const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
+                                           size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
+                                           int mode, int concat, void* stream) {
+  const size_t base = magat_gat_workspace_bytes(B, N, G, F, K, P, mode, concat);
+  const size_t pf = magat_gat_packed_floats(G, F, K, P, mode);
+  if (base == 0 || pf == 0) return MAGAT_ERR_BAD_SHAPE;
+  if (!workspace || workspace_bytes < base + pf * sizeof(float)) return MAGAT_ERR_WORKSPACE;
+  float* packed = reinterpret_cast<float*>(static_cast<char*>(workspace) + base);
+  int rc = magat_gat_pack_weights(weight, weight_bias, mixer, taps, packed, G, F, K, P, mode, stream);
+  if (rc != MAGAT_OK) return rc;
+  return magat_gat_forward_packed_f32(X, S, s_is_f64, packed, bias, Y, ldy, A_opt, workspace, base, B, N, G, F, K,
+                                      P, mode, concat, stream);
+}
+
+// addGSO's in-place scrub (decentralplanner_GAT_bottleneck.py:272-277)
+template <typename T>
+__global__ void gso_prepare_kernel(T* S, size_t count, int scrub_nan, int gso_mode) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    T v = S[i];
+    if (scrub_nan && v != v) v = (T)0;
+    if (gso_mode == 1 && v > (T)0) v = (T)1;
+    if (gso_mode == 2) v = (T)1;
+    S[i] = v;
+  }
+}
+
+extern "C" int magat_gso_prepare(void* S, int s_is_f64, size_t count, int scrub_nan, int gso_mode, void* stream) {
+  if (!S) return MAGAT_ERR_NULL;
+  if (count == 0) return MAGAT_OK;
+  size_t blocks = (count + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (s_is_f64)
+    hipLaunchKernelGGL(gso_prepare_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st,
+                       static_cast<double*>(S), count, scrub_nan, gso_mode);
+  else
+    hipLaunchKernelGGL(gso_prepare_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st,
+                       static_cast<float*>(S), count, scrub_nan, gso_mode);
+  return magat_check_launch();
+}
+
+extern "C" int magat_abi_version(void) { return 1; }
+
+extern "C" const char* magat_error_string(int code) {
+  switch (code) {
+    case MAGAT_OK: return "ok";
+    case MAGAT_ERR_BAD_SHAPE: return "bad shape / stride / alignment";
+    case MAGAT_ERR_UNSUPPORTED: return "unsupported width, mode or graph size for the gfx950 kernels";
+    case MAGAT_ERR_WORKSPACE: return "workspace missing, misaligned or too small";
+    case MAGAT_ERR_LAUNCH: return "HIP kernel launch failed";
+    case MAGAT_ERR_NULL: return "required pointer is NULL";
+    default: return "unknown magat error";
+  }
+}

@@ -1,0 +1,103 @@
+"""Inference-time parameter folding for the per-agent CNN encoder.
+
+Turns the reference-layout parameters of ConvLayers / compressMLP
+(graphs/models/resnet_pytorch.py:40-73, 334-524; decentralplanner_GAT_bottleneck.py:90-166) into
+the "encoder pack" consumed by magat_encoder_forward_f32 (include/magat_hip.h):
+
+  off[0]  conv1 weight  [32][27]      (BN folded)          off[1]  conv1 bias [32]
+  per BasicBlock l = 0..2 (Slim: 0..1):
+  off[2+4l] conv1 weight [Cout][9*Cin]  (ty,tx,c order)    off[3+4l] bias [Cout]
+  off[4+4l] [conv2 | downsample] weight [Cout][9*Cout+Cin] off[5+4l] bias_conv2 + bias_down
+  off[14] head weight [n_feat][Ho*Wo*Clast]  (avgpool(2)+fc(+Flatten+Linear) folded)
+  off[15] head bias [n_feat]
+  off[16] compressMLP weight [G][n_feat]                   off[17] compressMLP bias [G]
+
+Every offset is a multiple of 4 floats.  Folding is done in float64 and stored as float32.
+"""
+import torch
+
+BN_EPS = 1e-5
+
+
+def _bn_scale_shift(sd, pre):
+    s = sd[pre + ".weight"].double() / torch.sqrt(sd[pre + ".running_var"].double() + BN_EPS)
+    return s, sd[pre + ".bias"].double() - sd[pre + ".running_mean"].double() * s
+
+
+def _conv_rows(w, scale):
+    """(Cout,Cin,kH,kW) -> [Cout][(ty*kW+tx)*Cin + c], rows scaled."""
+    co = w.shape[0]
+    return (w.double() * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(co, -1)
+
+
+def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
+    """sd: state_dict-like {name: tensor}.  linear = (weight, bias) of ConvLayers.3 for *_withMLP modes
+    else None.  compress = (weight, bias) of compressMLP.0 or None.
+    Returns (pack float32 1-D CPU tensor, offsets list[32], meta dict)."""
+    sd = {k: v.detach().cpu() for k, v in sd.items() if k.startswith(pre)}
+    parts, offs = [], [0] * 32
+    cursor = [0]
+
+    def put(slot, t):
+        t = t.reshape(-1)
+        offs[slot] = cursor[0]
+        pad = (-t.numel()) % 4
+        if pad:
+            t = torch.cat((t, torch.zeros(pad, dtype=t.dtype)))
+        parts.append(t)
+        cursor[0] += t.numel()
+
+    s, b = _bn_scale_shift(sd, pre + ".bn1")
+    put(0, sd[pre + ".conv1.weight"].double().reshape(32, 27) * s.view(-1, 1))
+    put(1, b)
+    large = (pre + ".layer3.0.conv1.weight") in sd
+    nblocks = 3 if large else 2
+    clast = 32
+    for l in range(nblocks):
+        bp = "%s.layer%d.0" % (pre, l + 1)
+        w1 = sd[bp + ".conv1.weight"]
+        cout, cin = w1.shape[0], w1.shape[1]
+        s1, b1 = _bn_scale_shift(sd, bp + ".bn1")
+        put(2 + 4 * l, _conv_rows(w1, s1))
+        put(3 + 4 * l, b1)
+        s2, b2 = _bn_scale_shift(sd, bp + ".bn2")
+        w2 = _conv_rows(sd[bp + ".conv2.weight"], s2)
+        if (bp + ".downsample.0.weight") in sd:
+            sdn, bdn = _bn_scale_shift(sd, bp + ".downsample.1")
+            wd = sd[bp + ".downsample.0.weight"].double().reshape(cout, cin) * sdn.view(-1, 1)
+        else:
+            wd, bdn = torch.eye(cout, cin, dtype=torch.float64), torch.zeros(cout, dtype=torch.float64)
+        put(4 + 4 * l, torch.cat((w2, wd), dim=1))
+        put(5 + 4 * l, b2 + bdn)
+        clast = cout
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    Hp, Wp = Ho // 2, Wo // 2
+    fc = sd[pre + ".fc.weight"].double().reshape(-1, clast)       # (128, clast)
+    fcb = sd[pre + ".fc.bias"].double()
+    nq = fc.shape[0]
+    if linear is not None:
+        Lw, Lb = linear[0].detach().cpu().double(), linear[1].detach().cpu().double()
+        assert Lw.shape[1] == nq * Hp * Wp, "Linear in_features must equal 128*pooled pixels"
+        L4 = Lw.reshape(-1, nq, Hp, Wp)
+        W2 = torch.einsum("oqyx,qc->oyxc", L4, fc)                 # (n_feat, Hp, Wp, clast)
+        b2 = Lb + torch.einsum("oqyx,q->o", L4, fcb)
+        n_feat = Lw.shape[0]
+    else:
+        eye = torch.eye(Hp * Wp, dtype=torch.float64).reshape(Hp, Wp, Hp, Wp)
+        W2 = torch.einsum("qc,abyx->qabyxc", fc, eye).reshape(nq * Hp * Wp, Hp, Wp, clast)
+        b2 = fcb.repeat_interleave(Hp * Wp)
+        n_feat = nq * Hp * Wp
+    Weff = torch.zeros(n_feat, Ho, Wo, clast, dtype=torch.float64)
+    for py in range(2 * Hp):
+        for px in range(2 * Wp):
+            Weff[:, py, px, :] = 0.25 * W2[:, py // 2, px // 2, :]
+    put(14, Weff)
+    put(15, b2)
+    n_comp = 0
+    if compress is not None:
+        put(16, compress[0].detach().cpu().double())
+        put(17, compress[1].detach().cpu().double())
+        n_comp = compress[0].shape[0]
+    pack = torch.cat(parts).to(torch.float32).contiguous()
+    meta = dict(variant=0 if large else 1, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast)
+    return pack, offs, meta

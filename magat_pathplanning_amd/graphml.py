@@ -1,0 +1,207 @@
+"""GraphFilterBatchAttentional with the reference's constructor / addGSO / forward /
+returnAttentionGSO surface (utils/graphUtils/graphML.py:4506-4685) on top of the gfx950 kernels.
+
+Inference (no autograd) runs the HIP path through the C ABI; there is no CPU fallback: a CPU
+tensor under no_grad raises.  When autograd is required (training)
+the layer evaluates the same algebra with differentiable torch ops on whatever device the
+tensors live on -- that composite exists for backward only and is never used for inference.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _native as nat
+
+ZERO_TOLERANCE = 1e-9
+_MODES = {"KeyQuery": nat.MODE_KEYQUERY, "GAT_modified": nat.MODE_GAT_MODIFIED}
+
+
+class _Scratch:
+    """Per-module device scratch (packed weights, workspace); never pickled."""
+
+    def __init__(self):
+        self.packed = None
+        self.packed_key = None
+        self.workspace = None
+
+
+def _param_key(*tensors):
+    return tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
+
+
+def gat_forward_rows(X, S, layer, out=None, want_attention=False):
+    """Kernel-facing form.  X (B,N,G) f32 contiguous device rows; S (B,N,N) or (B,1,N,N) f32|f64;
+    out: optional (B*N, ld) float32 view whose first P*F|F columns receive the result.
+    Returns (out (B*N, ld) with the result in columns [0, width), aij (B,P,1,N,N) device tensor or None)."""
+    if not X.is_cuda:
+        raise nat.MagatNativeError("the HIP GAT path needs device tensors; got %s (no CPU fallback)" % X.device)
+    lib = nat.lib()
+    B, N, G = X.shape
+    F, K, P = layer.F, layer.K, layer.P
+    mode = _MODES[layer.attentionMode]
+    concat = 1 if layer.concatenate else 0
+    width = P * F if concat else F
+    X = X.contiguous()
+    if X.dtype != torch.float32:
+        X = X.float()
+    S3 = S.reshape(B, N, N)
+    if S3.dtype not in (torch.float32, torch.float64):
+        S3 = S3.float()
+    if not S3.is_contiguous():
+        S3 = S3.contiguous()
+    if S3.device != X.device:
+        S3 = S3.to(X.device)
+    dev = X.device
+    sc = layer._scratch
+    key = _param_key(layer.weight, layer.weight_bias, layer.mixer, layer.filterWeight) + (str(dev),)
+    with torch.cuda.device(dev):
+        stream = nat.current_stream(dev)
+        if sc.packed is None or sc.packed_key != key:
+            nfl = lib.magat_gat_packed_floats(G, F, K, P, mode)
+            if nfl == 0:
+                raise nat.MagatNativeError("bad GAT shape G=%d F=%d K=%d P=%d" % (G, F, K, P))
+            sc.packed = torch.empty(nfl, dtype=torch.float32, device=dev)
+            w = [t.detach().to(dev, torch.float32).contiguous()
+                 for t in (layer.weight, layer.weight_bias, layer.mixer, layer.filterWeight)]
+            nat.check(lib.magat_gat_pack_weights(nat.ptr(w[0]), nat.ptr(w[1]), nat.ptr(w[2]), nat.ptr(w[3]),
+                                                 nat.ptr(sc.packed), G, F, K, P, mode, stream), "magat_gat_pack_weights")
+            sc.packed_key = key
+        need = lib.magat_gat_workspace_bytes(B, N, G, F, K, P, mode, concat)
+        if sc.workspace is None or sc.workspace.numel() < need or sc.workspace.device != dev:
+            sc.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        if out is None:
+            out = torch.empty(B * N, width, dtype=torch.float32, device=dev)
+        ldy = out.stride(0)
+        aij = torch.empty(B, P, 1, N, N, dtype=torch.float32, device=dev) if want_attention else None
+        bias = None if layer.bias is None else layer.bias.detach().to(dev, torch.float32).reshape(-1).contiguous()
+        nat.check(lib.magat_gat_forward_packed_f32(
+            nat.ptr(X), nat.ptr(S3), 1 if S3.dtype == torch.float64 else 0, nat.ptr(sc.packed), nat.ptr(bias),
+            nat.ptr(out), ldy, nat.ptr(aij), nat.ptr(sc.workspace), sc.workspace.numel(),
+            B, N, G, F, K, P, mode, concat, stream), "magat_gat_forward_packed_f32")
+    return out, aij
+
+
+def _composite(layer, x, S):
+    """Differentiable torch-op evaluation (training only).  x (B,G,N); S (B,1,N,N)."""
+    B, G, N = x.shape
+    P, F, K = layer.P, layer.F, layer.K
+    X = x.transpose(1, 2)                                            # B,N,G
+    M = (S.detach().abs().sum(dim=1) > ZERO_TOLERANCE).to(x.dtype).unsqueeze(1)   # B,1,N,N
+    if layer.attentionMode == "KeyQuery":
+        Q = torch.einsum("bng,pog->bpno", X, layer.weight[:, 0])     # q_j = W x_j
+        e = torch.einsum("big,bpjg->bpij", X, Q)
+    else:
+        Wx = torch.einsum("bng,pfg->bpnf", X, layer.weight[:, 0]) + layer.weight_bias[:, 0].view(1, P, 1, F)
+        c1 = torch.einsum("bpnf,pf->bpn", Wx, layer.mixer[:, 0, :F])
+        c2 = torch.einsum("bpnf,pf->bpn", Wx, layer.mixer[:, 0, F:])
+        e = nn.functional.leaky_relu(c1.unsqueeze(2) + c2.unsqueeze(3), 0.2)
+    A = torch.softmax(e * M - (1 - M) * 1e12, dim=3) * M             # B,P,N,N
+    At = A.transpose(2, 3)
+    Z = X.unsqueeze(1).expand(B, P, N, G)
+    y = torch.einsum("bpng,pfg->bpnf", Z, layer.filterWeight[:, :, 0, 0])
+    for k in range(1, K):
+        Z = torch.matmul(At, Z)
+        y = y + torch.einsum("bpng,pfg->bpnf", Z, layer.filterWeight[:, :, 0, k])
+    if layer.bias is not None:
+        y = y + layer.bias.view(1, 1, 1, F)
+    if layer.concatenate:
+        out = torch.relu(y).permute(0, 2, 1, 3).reshape(B, N, P * F)
+    else:
+        out = torch.relu(y.mean(dim=1))
+    return out.transpose(1, 2), A.unsqueeze(2)
+
+
+class GraphFilterBatchAttentional(nn.Module):
+    """Drop-in for the reference class of the same name (graphML.py:4506-4685)."""
+
+    def __init__(self, G, F, K, P, E=1, bias=True, nonlinearity=nn.functional.relu, concatenate=True,
+                 attentionMode="GAT_modified"):
+        super().__init__()
+        if E != 1:
+            raise NotImplementedError("edge_features E=1 only (the planner models use E=1, …bottleneck.py:181)")
+        if nonlinearity is not nn.functional.relu and nonlinearity is not torch.relu:
+            raise NotImplementedError("the fused kernel applies ReLU (the only nonlinearity the models use)")
+        if attentionMode not in _MODES:
+            raise NotImplementedError("attentionMode %r: KeyQuery and GAT_modified are built" % (attentionMode,))
+        self.G, self.F, self.K, self.P, self.E = G, F, K, P, E
+        self.S = None
+        self.aij = None
+        self.nonlinearity = nonlinearity
+        self.concatenate = concatenate
+        self.attentionMode = attentionMode
+        self.return_attention = False      # materialise aij (B,P,E,N,N) like graphML.py:4650 only on request
+        self.mixer = nn.Parameter(torch.empty(P, E, 2 * F))
+        self.weight_bias = nn.Parameter(torch.empty(P, E, F))
+        self.filterWeight = nn.Parameter(torch.empty(P, F, E, K, G))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(F, 1))
+        else:
+            self.register_parameter("bias", None)
+        if attentionMode == "KeyQuery":
+            self.weight = nn.Parameter(torch.empty(P, E, G, G))
+        else:
+            self.weight = nn.Parameter(torch.empty(P, E, F, G))
+        self._scratch = _Scratch()
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # graphML.py:4604-4612
+        stdv = 1.0 / math.sqrt(self.G * self.P)
+        with torch.no_grad():
+            self.weight.uniform_(-stdv, stdv)
+            self.weight_bias.zero_()
+            self.mixer.uniform_(-stdv, stdv)
+            self.filterWeight.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_scratch"] = None
+        st["aij"] = None
+        return st
+
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        self._scratch = _Scratch()
+
+    def addGSO(self, S):
+        assert len(S.shape) == 4
+        assert S.shape[1] == self.E
+        self.N = S.shape[2]
+        assert S.shape[3] == self.N
+        self.S = S
+
+    def returnAttentionGSO(self):
+        if self.aij is None:
+            raise RuntimeError("attention was not materialised: set layer.return_attention = True before forward")
+        aij = self.aij.detach().cpu().numpy() if torch.is_tensor(self.aij) else self.aij
+        assert len(aij.shape) == 5 and aij.shape[2] == self.E
+        return np.mean(aij, axis=1)
+
+    def forward(self, x):
+        B, Gin, Nin = x.shape
+        assert self.S is not None, "addGSO must be called before forward"
+        if Nin < self.N:
+            x = torch.cat((x, torch.zeros(B, Gin, self.N - Nin, dtype=x.dtype, device=x.device)), dim=2)
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            y, aij = _composite(self, x, self.S.to(x.device))
+            self.aij = aij.detach() if self.return_attention else None
+        else:
+            out, aij = gat_forward_rows(x.permute(0, 2, 1).contiguous(), self.S, self,
+                                        want_attention=self.return_attention)
+            self.aij = aij
+            y = out.reshape(B, self.N, out.shape[1]).permute(0, 2, 1)
+        if Nin < self.N:
+            y = y[:, :, :Nin]
+        return y
+
+    def extra_repr(self):
+        s = "in_features=%d, out_features=%d, filter_taps=%d, attention_heads=%d, edge_features=%d, bias=%s, " % (
+            self.G, self.F, self.K, self.P, self.E, self.bias is not None)
+        s += "attentionMode=%s, " % self.attentionMode
+        s += ("GSO stored: number_nodes=%d" % self.N) if self.S is not None else "no GSO stored"
+        return s

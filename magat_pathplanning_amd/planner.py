@@ -1,0 +1,285 @@
+"""DecentralPlannerGATNet -- drop-in for the class of the same name in the reference's
+graphs/models/decentralplanner_GAT_bottleneck{,_SkipConcat,_SkipConcatGNN,_SkipAddGNN}.py and
+decentralplanner_GAT.py (selected by config.bottleneckMode exactly like
+agents/decentralplannerlocal_OnlineExpert_GAT.py:66-83 selects the file).
+
+Same constructor (config object), addGSO(S), forward(x) -> (B*N, 5) logits and state_dict layout.
+Inference (eval / no_grad) runs entirely on the gfx950 kernels behind include/magat_hip.h:
+  ConvLayers + compressMLP  -> magat_encoder_forward_f32   (fp32 MFMA implicit GEMMs, BN folded)
+  GFL                       -> magat_gat_forward_packed_f32 (hoisted MFMA GEMM + LDS/wave-softmax kernel)
+  actionsMLP (+skip inputs) -> magat_conv_gemm_f32          (skip source as second K segment)
+Training (autograd on) evaluates the same modules with torch ops (backward is SURVEY 8(f) row 1).
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _native as nat
+from . import encoder as enc
+from .graphml import GraphFilterBatchAttentional, gat_forward_rows
+from .resnet import ResNet, ResNetSlim
+
+_SKIP_FILES = {
+    "BottomNeck_only": "only",
+    "BottomNeck_skipConcat": "skipConcat",
+    "BottomNeck_skipConcatGNN": "skipConcatGNN",
+    "BottomNeck_skipAddGNN": "skipAddGNN",
+}
+
+
+def weights_init(m):
+    """graphs/weights_initializer.py:11-23."""
+    name = m.__class__.__name__
+    if name.find("Conv") != -1:
+        nn.init.xavier_normal_(m.weight)
+    elif name.find("BatchNorm") != -1:
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0.0)
+    elif name.find("Linear") != -1:
+        nn.init.xavier_normal_(m.weight)
+        m.bias.data.fill_(0.0)
+
+
+class _Runtime:
+    """Device-side caches of one module instance (never pickled)."""
+
+    def __init__(self):
+        self.key = None
+        self.pack = None
+        self.desc = None
+        self.act = None
+        self.buffers = {}
+        self.ws = None
+
+
+class DecentralPlannerGATNet(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.S = None
+        self.numAgents = config.num_agents
+        self.skip = _SKIP_FILES.get(getattr(config, "bottleneckMode", ""), "legacy")
+        inW = inH = config.FOV + 2
+        numAction = 5
+        bottleneck = config.bottleneckFeature if self.skip != "legacy" else config.numInputFeatures
+
+        mode = config.CNN_mode
+        if self.skip == "skipAddGNN" and mode in ("ResNetSlim_withMLP", "ResNetLarge_withMLP"):
+            mode = "Default"    # that reference file has no *_withMLP branch (…SkipAddGNN.py:90-117)
+        self.cnn_mode = mode
+        if mode in ("ResNetSlim_withMLP", "ResNetLarge_withMLP"):
+            body = ResNetSlim() if "Slim" in mode else ResNet()
+            self.ConvLayers = nn.Sequential(body, nn.Dropout(0.2), nn.Flatten(),
+                                            nn.Linear(1152, config.numInputFeatures, bias=True))
+            numFeatureMap = config.numInputFeatures
+        elif mode in ("ResNetSlim", "ResNetLarge"):
+            body = ResNetSlim() if "Slim" in mode else ResNet()
+            self.ConvLayers = nn.Sequential(body, nn.Dropout(0.2))
+            numFeatureMap = 1152
+        else:
+            chans = [3, 32, 32, 64, 64, 128]
+            layers, w, h = [], inW, inH
+            for l in range(5):
+                layers += [nn.Conv2d(chans[l], chans[l + 1], 3, 1, 1, bias=True), nn.BatchNorm2d(chans[l + 1]),
+                           nn.ReLU(inplace=True)]
+                if l % 2 == 0:
+                    layers.append(nn.MaxPool2d(kernel_size=2))
+                    w, h = (w - 2) // 2 + 1, (h - 2) // 2 + 1
+            self.ConvLayers = nn.Sequential(*layers)
+            numFeatureMap = chans[-1] * w * h
+        self.numFeatureMap = numFeatureMap
+        self.compressMLP = nn.Sequential(nn.Linear(numFeatureMap, bottleneck, bias=True), nn.ReLU(inplace=True))
+        self.numFeatures2Share = bottleneck
+
+        self.L = 1
+        self.F = [bottleneck, bottleneck]
+        self.K = [config.nGraphFilterTaps]
+        self.P = [config.nAttentionHeads]
+        self.E = 1
+        self.bias = True
+        if config.attentionMode not in ("GAT_modified", "KeyQuery"):
+            raise NotImplementedError("attentionMode %r is outside the built hot path (SURVEY.md section 8(f))"
+                                      % (config.attentionMode,))
+        self.GFL = nn.Sequential(GraphFilterBatchAttentional(
+            self.F[0], self.F[1], self.K[0], self.P[0], self.E, self.bias,
+            concatenate=config.AttentionConcat, attentionMode=config.attentionMode))
+
+        width = self.F[-1] * config.nAttentionHeads if config.AttentionConcat else self.F[-1]
+        self.gat_width = width
+        if self.skip == "skipConcat":
+            width += numFeatureMap
+        elif self.skip == "skipConcatGNN":
+            width += bottleneck
+        if config.use_dropout:
+            self.actionsMLP = nn.Sequential(nn.Linear(width, config.numInputFeatures), nn.ReLU(inplace=True),
+                                            nn.Dropout(p=0.2), nn.Linear(config.numInputFeatures, numAction),
+                                            nn.Dropout(p=0.2))
+        else:
+            self.actionsMLP = nn.Sequential(nn.Linear(width, numAction))
+        self.apply(weights_init)
+        self._rt = _Runtime()
+
+    # ------------------------------------------------------------------ pickling (spawned workers)
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_rt"] = None
+        st["S"] = None
+        return st
+
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        self._rt = _Runtime()
+
+    # ------------------------------------------------------------------ boundary
+    def addGSO(self, S):
+        """…bottleneck.py:262-278: aliases the caller's tensor and scrubs it in place."""
+        assert len(S.shape) == 3
+        scrub = self.skip in ("only", "legacy")        # only these reference files zero NaNs
+        gso_mode = {"dist_GSO_one": 1, "full_GSO": 2}.get(self.config.GSO_mode, 0)
+        if S.is_cuda and S.is_contiguous() and S.dtype in (torch.float32, torch.float64) and gso_mode != 2:
+            if scrub or gso_mode:
+                with torch.cuda.device(S.device):
+                    nat.check(nat.lib().magat_gso_prepare(nat.ptr(S), 1 if S.dtype == torch.float64 else 0,
+                                                          S.numel(), 1 if scrub else 0, gso_mode,
+                                                          nat.current_stream(S.device)), "magat_gso_prepare")
+            self.S = S.unsqueeze(1)
+            return
+        self.S = S.unsqueeze(1)
+        if scrub:
+            self.S[torch.isnan(self.S)] = 0
+        if gso_mode == 1:
+            self.S[self.S > 0] = 1
+        elif gso_mode == 2:
+            self.S = torch.ones_like(self.S).to(self.config.device)
+
+    def returnAttentionGSO(self):
+        return self.GFL[0].returnAttentionGSO()
+
+    def forward(self, inputTensor):
+        (B, N, C, W, H) = inputTensor.shape
+        dev = torch.device(self.config.device)
+        x = inputTensor.reshape(B * N, C, W, H).to(dev)
+        if self.S is None:
+            raise TypeError("addGSO must be called before forward")
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad or self.training:
+            return self._forward_autograd(x, B, N)
+        return self._forward_hip(x, B, N)
+
+    # ------------------------------------------------------------------ training path (torch ops)
+    def _forward_autograd(self, x, B, N):
+        feat = self.ConvLayers(x)
+        feat = feat.view(feat.size(0), -1)
+        comp = self.compressMLP(feat)
+        xg = comp.reshape(B, N, self.numFeatures2Share).permute(0, 2, 1)
+        self.GFL[0].addGSO(self.S)
+        shared = self.GFL(xg)
+        shared = shared.permute(0, 2, 1).reshape(B * N, shared.shape[1])
+        if self.skip == "skipConcat":
+            shared = torch.cat((feat, shared), dim=1)
+        elif self.skip == "skipConcatGNN":
+            shared = torch.cat((comp, shared), dim=1)
+        elif self.skip == "skipAddGNN":
+            shared = torch.add(comp, shared)
+        return self.actionsMLP(shared)
+
+    # ------------------------------------------------------------------ inference path (HIP)
+    def _refresh(self, dev):
+        rt = self._rt
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
+            tuple((b.data_ptr(), b._version) for b in self.buffers()) + (str(dev),)
+        if rt.key == key:
+            return rt
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        rt.pack = rt.desc = None
+        if self.cnn_mode.startswith("ResNet"):
+            lin = (sd["ConvLayers.3.weight"], sd["ConvLayers.3.bias"]) if self.cnn_mode.endswith("_withMLP") else None
+            pack, offs, meta = enc.fold_resnet(sd, self.config.FOV + 2, self.config.FOV + 2, "ConvLayers.0", lin,
+                                               (sd["compressMLP.0.weight"], sd["compressMLP.0.bias"]))
+            rt.pack = pack.to(dev)
+            d = nat.EncoderDesc()
+            d.variant, d.H, d.W = meta["variant"], meta["H"], meta["W"]
+            d.n_feat, d.n_comp = meta["n_feat"], meta["n_comp"]
+            d.pack = rt.pack.data_ptr()
+            for i, o in enumerate(offs):
+                d.off[i] = o
+            rt.desc = d
+        # actionsMLP first layer: [w_skip | w_gat] -> in (skip source) + in2 (GAT output) K segments
+        w0 = sd["actionsMLP.0.weight"].to(dev, torch.float32)
+        if self.skip == "skipAddGNN":
+            w0 = torch.cat((w0, w0), dim=1)
+        rt.act = [w0.contiguous(), sd["actionsMLP.0.bias"].to(dev, torch.float32).contiguous()]
+        if self.config.use_dropout:
+            rt.act += [sd["actionsMLP.3.weight"].to(dev, torch.float32).contiguous(),
+                       sd["actionsMLP.3.bias"].to(dev, torch.float32).contiguous()]
+        rt.cw = sd["compressMLP.0.weight"].to(dev, torch.float32).contiguous()
+        rt.cb = sd["compressMLP.0.bias"].to(dev, torch.float32).contiguous()
+        rt.key = key
+        return rt
+
+    def _buf(self, name, shape, dev):
+        t = self._rt.buffers.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != dev:
+            t = torch.empty(shape, dtype=torch.float32, device=dev)
+            self._rt.buffers[name] = t
+        return t
+
+    @torch.no_grad()
+    def _forward_hip(self, x, B, N):
+        if not x.is_cuda:
+            raise nat.MagatNativeError("inference runs on the HIP path only; config.device=%r is not a GPU "
+                                       "(no CPU fallback)" % (self.config.device,))
+        lib = nat.lib()
+        dev = x.device
+        M = B * N
+        rt = self._refresh(dev)
+        x = x.contiguous().float()
+        G = self.numFeatures2Share
+        nfm = self.numFeatureMap
+        with torch.cuda.device(dev):
+            stream = nat.current_stream(dev)
+            feat = self._buf("feat", (M, nfm), dev)
+            comp = self._buf("comp", (M, G), dev)
+            if rt.desc is not None:
+                need = lib.magat_encoder_workspace_bytes(ctypes.byref(rt.desc), M)
+                if rt.ws is None or rt.ws.numel() < need or rt.ws.device != dev:
+                    rt.ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                nat.check(lib.magat_encoder_forward_f32(ctypes.byref(rt.desc), nat.ptr(x), nat.ptr(feat), nfm,
+                                                        nat.ptr(comp), G, nat.ptr(rt.ws), rt.ws.numel(), M, stream),
+                          "magat_encoder_forward_f32")
+            else:
+                # CNN_mode=Default (conv+BN+ReLU+MaxPool stack): torch/MIOpen ops, then our compressMLP GEMM
+                f = self.ConvLayers(x)
+                feat.copy_(f.view(M, -1))
+                nat.check(lib.magat_linear_f32(nat.ptr(feat), nfm, nat.ptr(rt.cw), nat.ptr(rt.cb), nat.ptr(comp), G,
+                                               M, G, nfm, 1, stream), "magat_linear_f32")
+            layer = self.GFL[0]
+            layer.addGSO(self.S)
+            gat = self._buf("gat", (M, self.gat_width), dev)
+            _, aij = gat_forward_rows(comp.view(B, N, G), self.S, layer, out=gat,
+                                      want_attention=layer.return_attention or
+                                      bool(getattr(self.config, "return_attentionGSO", False)))
+            layer.aij = aij
+            # actionsMLP
+            nout = rt.act[0].shape[0]
+            out = torch.empty(M, nout, dtype=torch.float32, device=dev)
+            d = nat.ConvGemmDesc()
+            if self.skip in ("skipConcat", "skipConcatGNN", "skipAddGNN"):
+                src = feat if self.skip == "skipConcat" else comp
+                d.inp, d.Cin, d.lda = src.data_ptr(), src.shape[1], src.stride(0)
+                d.in2, d.C2, d.lda2 = gat.data_ptr(), gat.shape[1], gat.stride(0)
+                d.W2, d.stride2 = 1, 1
+            else:
+                d.inp, d.Cin, d.lda = gat.data_ptr(), gat.shape[1], gat.stride(0)
+            d.wt, d.bias, d.out = rt.act[0].data_ptr(), rt.act[1].data_ptr(), out.data_ptr()
+            d.M, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad, d.Hout, d.Wout = M, 1, 1, 1, 1, 1, 0, 1, 1
+            d.Cout, d.ldc, d.relu = nout, nout, 1 if self.config.use_dropout else 0
+            nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), stream), "magat_conv_gemm_f32(actionsMLP.0)")
+            if self.config.use_dropout:
+                out2 = torch.empty(M, rt.act[2].shape[0], dtype=torch.float32, device=dev)
+                nat.check(lib.magat_linear_f32(nat.ptr(out), nout, nat.ptr(rt.act[2]), nat.ptr(rt.act[3]),
+                                               nat.ptr(out2), out2.shape[1], M, out2.shape[1], nout, 0, stream),
+                          "magat_linear_f32(actionsMLP.3)")
+                out = out2
+        return out

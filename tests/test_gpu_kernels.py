@@ -1,0 +1,158 @@
+"""GPU parity of the individual gfx950 kernels, called through the C ABI (ctypes), against fp64
+torch references and the reference-made golden vectors."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as tnf
+
+from conftest import golden_paths, load_layer_fixture
+
+pytestmark = pytest.mark.gpu
+
+LAYER = golden_paths("gat_")
+
+
+def _nat():
+    from magat_pathplanning_amd import _native as nat
+    return nat, nat.lib()
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(300, 128, 128, 0), (1000, 2048, 128, 0), (257, 5, 640, 0),
+                                        (130, 64, 96, 1), (64, 32, 1152, 1), (5, 128, 36, 1)])
+def test_linear_f32(gpu_device, M, N, K, relu):
+    nat, lib = _nat()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    xd, wd, bd = x.to(gpu_device), w.to(gpu_device), b.to(gpu_device)
+    y = torch.full((M, N), float("nan"), device=gpu_device)
+    nat.check(lib.magat_linear_f32(nat.ptr(xd), K, nat.ptr(wd), nat.ptr(bd), nat.ptr(y), N, M, N, K, relu,
+                                   nat.current_stream(gpu_device)), "linear")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.cpu().numpy(), ref.float().numpy(), rtol=0, atol=2e-5)
+
+
+def _to_pixel_major(t):           # (M,C,H,W) -> [H*W][M][C]
+    M, C, H, W = t.shape
+    return t.permute(2, 3, 0, 1).reshape(H * W, M, C).contiguous()
+
+
+def _from_pixel_major(t, H, W):   # [H*W][M][C] -> (M,C,H,W)
+    return t.reshape(H, W, t.shape[1], t.shape[2]).permute(2, 3, 0, 1).contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,hin,stride,c2", [(32, 32, 11, 2, 0), (32, 32, 6, 1, 32), (32, 64, 6, 1, 0),
+                                                     (64, 64, 6, 1, 32), (64, 128, 6, 1, 0), (128, 128, 6, 1, 64)])
+def test_conv_gemm_vs_conv2d(gpu_device, cin, cout, hin, stride, c2):
+    """3x3 pad-1 conv (+ optional strided 1x1 residual branch as second K segment) + bias + ReLU."""
+    nat, lib = _nat()
+    M = 150
+    g = torch.Generator().manual_seed(cin * cout + hin)
+    hout = (hin + 2 - 3) // stride + 1
+    x = torch.randn(M, cin, hin, hin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = tnf.conv2d(x.double(), w.double(), b.double(), stride, 1)
+    wt = w.permute(0, 2, 3, 1).reshape(cout, -1)
+    x2 = None
+    if c2:
+        # residual source has the resolution of the block input: use stride2 = 1 at the same map size
+        x2 = torch.randn(M, c2, hout, hout, generator=g)
+        w2 = torch.randn(cout, c2, 1, 1, generator=g) / c2 ** 0.5
+        ref = ref + tnf.conv2d(x2.double(), w2.double())
+        wt = torch.cat((wt, w2.reshape(cout, c2)), dim=1)
+    ref = ref.clamp_min(0)
+    xin = _to_pixel_major(x).to(gpu_device)
+    wtd, bd = wt.contiguous().to(gpu_device), b.to(gpu_device)
+    out = torch.full((hout * hout, M, cout), float("nan"), device=gpu_device)
+    d = nat.ConvGemmDesc()
+    d.inp, d.wt, d.bias, d.out = xin.data_ptr(), wtd.data_ptr(), bd.data_ptr(), out.data_ptr()
+    d.in_pix_stride, d.out_pix_stride = M * cin, M * cout
+    d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, hin, hin, 3, 3, stride, 1
+    d.Hout, d.Wout, d.Cout, d.ldc, d.relu = hout, hout, cout, cout, 1
+    if c2:
+        x2d = _to_pixel_major(x2).to(gpu_device)
+        d.in2, d.in2_pix_stride, d.C2, d.lda2, d.W2, d.stride2 = x2d.data_ptr(), M * c2, c2, c2, hout, 1
+    nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "conv_gemm")
+    torch.cuda.synchronize()
+    got = _from_pixel_major(out.cpu(), hout, hout)
+    np.testing.assert_allclose(got.numpy(), ref.float().numpy(), rtol=0, atol=3e-5)
+
+
+def test_conv_first(gpu_device):
+    nat, lib = _nat()
+    M, H = 77, 11
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(M, 3, H, H, generator=g) < 0.3).float()
+    w = torch.randn(32, 3, 3, 3, generator=g)
+    b = torch.randn(32, generator=g)
+    ref = tnf.conv2d(x.double(), w.double(), b.double(), 1, 1).clamp_min(0)
+    out = torch.full((H * H, M, 32), float("nan"), device=gpu_device)
+    xd, wd, bd = x.to(gpu_device), w.reshape(32, 27).contiguous().to(gpu_device), b.to(gpu_device)
+    nat.check(lib.magat_conv_first_f32(nat.ptr(xd), nat.ptr(wd), nat.ptr(bd), nat.ptr(out), M, H, H,
+                                       nat.current_stream(gpu_device)), "conv_first")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(_from_pixel_major(out.cpu(), H, H).numpy(), ref.float().numpy(), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("path", LAYER, ids=[os.path.basename(p)[:-4] for p in LAYER])
+def test_gat_layer_vs_reference_golden(gpu_device, path):
+    """HIP GraphFilterBatchAttentional vs the outputs the real reference produced (tolerance: north star 1e-4;
+    observed ~1e-6)."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    z, p = load_layer_fixture(path)
+    mode, N, G, K, P = str(z["mode"]), int(z["N"]), int(z["G"]), int(z["K"]), int(z["P"])
+    x = torch.from_numpy(z["x"]).to(gpu_device)
+    S = torch.from_numpy(z["S"]).to(gpu_device)
+    for concat, key in ((True, "y_concat"), (False, "y_mean")):
+        layer = GraphFilterBatchAttentional(G, G, K, P, 1, True, concatenate=concat, attentionMode=mode)
+        layer.load_state_dict(p)
+        layer = layer.to(gpu_device).eval()
+        layer.return_attention = True
+        layer.addGSO(S)
+        with torch.no_grad():
+            y = layer(x)
+        torch.cuda.synchronize()
+        assert tuple(y.shape) == tuple(z[key].shape)
+        np.testing.assert_allclose(y.cpu().numpy(), z[key], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(layer.aij.cpu().numpy(), z["aij"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(layer.returnAttentionGSO(), z["aij"].mean(axis=1), rtol=0, atol=2e-6)
+        if concat:
+            nin = int(z["nin"])
+            with torch.no_grad():
+                yn = layer(x[:, :, :nin].contiguous())
+            np.testing.assert_allclose(yn.cpu().numpy(), z["y_concat_nin"], rtol=0, atol=1e-5)
+
+
+def test_gat_isolated_rows_are_exact_zero_not_nan(gpu_device):
+    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    layer = GraphFilterBatchAttentional(32, 32, 3, 2, attentionMode="KeyQuery").to(gpu_device).eval()
+    layer.return_attention = True
+    S = torch.zeros(2, 1, 9, 9, device=gpu_device)
+    S[1, 0, 2, 4] = 0.5
+    layer.addGSO(S)
+    with torch.no_grad():
+        y = layer(torch.randn(2, 32, 9, device=gpu_device))
+    assert torch.isfinite(y).all()
+    a = layer.aij
+    assert float(a[0].abs().max()) == 0.0
+    assert float(a[1, :, 0, 2, 4].min()) == 1.0 and float(a[1].sum()) == 2.0
+
+
+def test_errors_are_loud(gpu_device):
+    nat, lib = _nat()
+    x = torch.zeros(4, 4, device=gpu_device)
+    assert lib.magat_linear_f32(nat.ptr(x), 4, None, None, nat.ptr(x), 4, 4, 4, 4, 0, None) == -5
+    assert lib.magat_gat_workspace_bytes(0, 4, 16, 16, 2, 1, 0, 1) == 0
+    rc = lib.magat_gat_forward_packed_f32(nat.ptr(x), nat.ptr(x), 0, nat.ptr(x), None, nat.ptr(x), 16, None,
+                                          nat.ptr(x), 16, 1, 4, 24, 24, 2, 1, 0, 1, None)
+    assert rc == -2
+    with pytest.raises(nat.MagatNativeError):
+        nat.check(rc, "unsupported width")

@@ -1,0 +1,123 @@
+"""CPU-only checks: the C-ABI library loads and exports every declared symbol, host-side folding /
+module surface / state_dict layout, the training composite against the pinned oracle."""
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_paths, load_layer_fixture, load_model_fixture
+from oracle import magat_oracle as orc
+
+MODEL = golden_paths("model_")
+LAYER = golden_paths("gat_")
+
+
+def test_library_exports_every_declared_symbol():
+    from magat_pathplanning_amd import _native as nat
+    hdr = open(os.path.join(ROOT, "include", "magat_hip.h")).read()
+    declared = set(re.findall(r"\b(magat_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"magat_conv_gemm_desc", "magat_encoder_desc"}
+    assert declared == set(nat.EXPORTED_SYMBOLS), declared ^ set(nat.EXPORTED_SYMBOLS)
+    lib = nat.lib()                       # loads without a GPU
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.magat_abi_version() == 1
+    assert lib.magat_error_string(-2).decode().startswith("unsupported")
+    # pure host queries work without a device
+    assert lib.magat_gat_packed_floats(128, 128, 3, 4, 0) == (4 * 128 + 4 * 3 * 128) * 129
+    assert lib.magat_gat_workspace_bytes(2, 10, 128, 128, 2, 1, 0, 1) >= 2 * 10 * 384 * 4
+
+
+@pytest.mark.parametrize("path", MODEL, ids=[os.path.basename(p)[:-4] for p in MODEL])
+def test_state_dict_layout_and_training_path_match_reference(path):
+    """Reference checkpoints load strictly; the autograd (training) composite reproduces the
+    reference logits on CPU in eval-BN mode."""
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    z, sd, cfg = load_model_fixture(path)
+    cfg.device = "cpu"
+    net = DecentralPlannerGATNet(cfg)
+    net.load_state_dict(sd, strict=True)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.eval()
+    x = torch.from_numpy(z["x"].astype(np.float32))
+    S = torch.from_numpy(z["S"].copy())
+    net.addGSO(S)
+    y = net(x)                      # grad enabled -> differentiable composite
+    assert y.requires_grad
+    np.testing.assert_allclose(y.detach().numpy(), z["logits"], rtol=0, atol=5e-6)
+    np.testing.assert_array_equal(np.nan_to_num(S.numpy(), nan=-7.0), np.nan_to_num(z["S_after"], nan=-7.0))
+    y.sum().backward()
+    assert net.GFL[0].filterWeight.grad is not None and torch.isfinite(net.GFL[0].filterWeight.grad).all()
+
+
+def test_encoder_fold_matches_unfolded_cnn():
+    """BN folding + avgpool/fc/Linear folding reproduce conv_layers_forward when evaluated densely on CPU."""
+    import torch.nn.functional as tnf
+    from magat_pathplanning_amd import encoder as enc
+    from magat_pathplanning_amd.synthetic import fov_states, make_config
+    for mode in ("ResNetLarge_withMLP", "ResNetSlim_withMLP", "ResNetLarge", "ResNetSlim"):
+        cfg = make_config(CNN_mode=mode, device="cpu")
+        sd = orc.init_state_dict(cfg, seed=3)
+        lin = (sd["ConvLayers.3.weight"], sd["ConvLayers.3.bias"]) if mode.endswith("_withMLP") else None
+        pack, offs, meta = enc.fold_resnet(sd, 11, 11, "ConvLayers.0", lin,
+                                           (sd["compressMLP.0.weight"], sd["compressMLP.0.bias"]))
+        assert all(o % 4 == 0 for o in offs)
+        x = fov_states(1, 6, seed=9).reshape(6, 3, 11, 11)
+        want = orc.conv_layers_forward(x, sd, mode)
+
+        def seg(slot, *shape):
+            n = int(np.prod(shape))
+            return pack[offs[slot]:offs[slot] + n].reshape(*shape)
+
+        y = torch.relu(tnf.conv2d(x, seg(0, 32, 3, 3, 3), seg(1, 32), 1, 1))
+        cin = 32
+        for l, (cout, stride) in enumerate([(32, 2), (64, 1), (128, 1)][:3 if meta["variant"] == 0 else 2]):
+            w1 = seg(2 + 4 * l, cout, 3, 3, cin).permute(0, 3, 1, 2)
+            h = torch.relu(tnf.conv2d(y, w1, seg(3 + 4 * l, cout), stride, 1))
+            wcat = seg(4 + 4 * l, cout, 9 * cout + cin)
+            w2 = wcat[:, :9 * cout].reshape(cout, 3, 3, cout).permute(0, 3, 1, 2)
+            wd = wcat[:, 9 * cout:].reshape(cout, cin, 1, 1)
+            y = torch.relu(tnf.conv2d(h, w2, seg(5 + 4 * l, cout), 1, 1) + tnf.conv2d(y, wd, None, stride))
+            cin = cout
+        wh = seg(14, meta["n_feat"], 6, 6, cin).permute(0, 3, 1, 2)
+        feat = tnf.conv2d(y, wh, seg(15, meta["n_feat"])).flatten(1)
+        np.testing.assert_allclose(feat.numpy(), want.numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("path", [p for p in LAYER if "N12" in p or "N10" in p],
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_layer_training_composite_matches_reference(path):
+    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    z, p = load_layer_fixture(path)
+    G, K, P = int(z["G"]), int(z["K"]), int(z["P"])
+    layer = GraphFilterBatchAttentional(G, G, K, P, attentionMode=str(z["mode"]))
+    layer.load_state_dict(p)
+    layer.addGSO(torch.from_numpy(z["S"]))
+    y = layer(torch.from_numpy(z["x"]))
+    np.testing.assert_allclose(y.detach().numpy(), z["y_concat"], rtol=0, atol=5e-6)
+    assert "attentionMode=%s" % str(z["mode"]) in repr(layer)
+
+
+def test_module_pickles_without_device_state():
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    from magat_pathplanning_amd.synthetic import make_config
+    net = DecentralPlannerGATNet(make_config(device="cpu"))
+    blob = pickle.dumps(net)
+    clone = pickle.loads(blob)
+    for (k1, v1), (k2, v2) in zip(net.state_dict().items(), clone.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    assert clone._rt.key is None and clone.GFL[0]._scratch.packed is None
+
+
+def test_synthetic_inputs_are_seeded_and_well_formed():
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states
+    x1, x2 = fov_states(3, 20, seed=5), fov_states(3, 20, seed=5)
+    assert torch.equal(x1, x2) and set(x1.unique().tolist()) <= {0.0, 1.0}
+    assert torch.all(x1[:, :, 1].sum(dim=(2, 3)) == 1) and torch.all(x1[:, :, 2, 5, 5] == 1)
+    assert float(x1[:, :, :, 0, :].abs().max()) == 0.0
+    S = comm_gso(4, 20, 28, seed=6, dtype=torch.float64)
+    assert torch.equal(S, S.transpose(1, 2)) and float(torch.diagonal(S, dim1=1, dim2=2).abs().max()) == 0.0
