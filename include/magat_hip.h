@@ -88,7 +88,7 @@ int magat_gso_prepare(void* S, int s_is_f64, size_t count, int scrub_nan, int gs
  *   out[(oy*Wout+ox)][m][n] = act( bias[n] + sum_{ty,tx valid} sum_c in[iy,ix][m][c] * wt[n][(ty*kW+tx)*Cin + c]
  *                                         + sum_c in2[oy*stride2, ox*stride2][m][c] * wt[n][kH*kW*Cin + c] )
  * with iy = oy*stride - pad + ty (taps falling in the zero padding are skipped, not multiplied).
- * in2 (optional, C2 > 0) is the residual branch's 1x1 strided conv or a skip-concat source.
+ * in2 (optional, C2 > 0) is the residual branch's 1x1 strided conv or a skip-concat source (never pooled).
  * wt is [Cout][Ktot], Ktot = kH*kW*Cin + C2.  Cin, C2, lda, lda2, ldc multiples of 4.
  */
 typedef struct magat_conv_gemm_desc {
@@ -102,12 +102,20 @@ typedef struct magat_conv_gemm_desc {
   int Cin, lda, Hin, Win, kH, kW, stride, pad, Hout, Wout;
   int C2, lda2, W2, stride2;
   int Cout, ldc, relu;
+  int tag;    /* MAGAT_TAG_* used by the optional profiling hooks (0 = untagged) */
+  int pool;   /* 1: `in` is read through a 2x2 SUM-pool: logical pixel (iy,ix) of the Hin x Win map =
+                 sum of physical pixels (2iy+{0,1}, 2ix+{0,1}) of a map that is pool_w pixels wide
+                 (AvgPool2d(2) of resnet_pytorch.py:450 with the 1/4 folded into wt) */
+  int pool_w;
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 
 /* y[M,N] = act(x[M,K] @ w[N,K]^T + b)   (torch.nn.Linear; …bottleneck.py:105,160,229) */
 int magat_linear_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M,
                      int N, int K, int relu, void* stream);
+/* same, with a MAGAT_TAG_* for the profiling hooks */
+int magat_linear_tagged_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M,
+                            int N, int K, int relu, int tag, void* stream);
 
 /* First encoder layer: conv3x3(3->32, pad 1, no bias)+BN+ReLU on the (M,3,H,W) NCHW state tensor
  * (resnet_pytorch.py:439-441, 495-498) -> pixel-major [H*W][M][32].  wt [32][27] BN-folded
@@ -134,6 +142,28 @@ size_t magat_encoder_workspace_bytes(const magat_encoder_desc* desc_host, int M)
 int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* x /*M,3,H,W*/,
                               float* feat, int ldfeat, float* comp, int ldcomp, void* workspace,
                               size_t workspace_bytes, int M, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optional per-kernel timing (bench.py roofline leg).  When enabled every kernel the library
+ * launches is bracketed by hipEvents on its launch stream; after the caller synchronises,
+ * magat_profile_collect() folds them into per-tag (count, total ms).  Off by default.
+ */
+#define MAGAT_TAG_UNTAGGED 0
+#define MAGAT_TAG_CONV_FIRST 1
+#define MAGAT_TAG_BLOCK_CONV 2  /* +2*l: conv1 of BasicBlock l, +2*l+1: conv2(+downsample) of block l (l=0..2) */
+#define MAGAT_TAG_HEAD 8        /* avgpool+fc(+Linear) folded conv */
+#define MAGAT_TAG_COMPRESS 9
+#define MAGAT_TAG_GAT_MAPS 10   /* hoisted X @ [W_p | H_pk]^T GEMM */
+#define MAGAT_TAG_GAT_GRAPH 11  /* scores + softmax + hops kernel */
+#define MAGAT_TAG_ACTIONS 12
+#define MAGAT_TAG_HEAD_MEAN 13
+#define MAGAT_TAG_GAT_PACK 14
+#define MAGAT_TAG_GSO_PREPARE 15
+#define MAGAT_PROF_TAGS 16
+int magat_profile_enable(int on);
+int magat_profile_collect(void);
+int magat_profile_read(int tag, long long* count, double* total_ms);
+int magat_profile_reset(void);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,11 @@ LIB_PATH = os.path.join(PKG, "lib", "libmagat_hip.so")
 
 MODE_KEYQUERY = 0
 MODE_GAT_MODIFIED = 1
+TAGS = {0: "untagged", 1: "conv_first", 2: "layer1.conv1", 3: "layer1.conv2+ds", 4: "layer2.conv1",
+        5: "layer2.conv2+ds", 6: "layer3.conv1", 7: "layer3.conv2+ds", 8: "head(avgpool+fc+linear)",
+        9: "compressMLP", 10: "gat_maps_gemm", 11: "gat_graph", 12: "actionsMLP", 13: "head_mean",
+        14: "gat_pack", 15: "gso_prepare"}
+TAG_ACTIONS = 12
 
 _lock = threading.Lock()
 _lib = None
@@ -30,7 +35,8 @@ class ConvGemmDesc(ctypes.Structure):
                 ("kH", ctypes.c_int), ("kW", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int),
                 ("Hout", ctypes.c_int), ("Wout", ctypes.c_int),
                 ("C2", ctypes.c_int), ("lda2", ctypes.c_int), ("W2", ctypes.c_int), ("stride2", ctypes.c_int),
-                ("Cout", ctypes.c_int), ("ldc", ctypes.c_int), ("relu", ctypes.c_int)]
+                ("Cout", ctypes.c_int), ("ldc", ctypes.c_int), ("relu", ctypes.c_int), ("tag", ctypes.c_int),
+                ("pool", ctypes.c_int), ("pool_w", ctypes.c_int)]
 
 
 class EncoderDesc(ctypes.Structure):
@@ -51,6 +57,11 @@ _SIGNATURES = {
     "magat_gso_prepare": (_I, [_P, _I, _Z, _I, _I, _P]),
     "magat_conv_gemm_f32": (_I, [ctypes.POINTER(ConvGemmDesc), _P]),
     "magat_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "magat_linear_tagged_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "magat_profile_enable": (_I, [_I]),
+    "magat_profile_collect": (_I, []),
+    "magat_profile_read": (_I, [_I, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),
+    "magat_profile_reset": (_I, []),
     "magat_conv_first_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "magat_encoder_workspace_bytes": (_Z, [ctypes.POINTER(EncoderDesc), _I]),
     "magat_encoder_forward_f32": (_I, [ctypes.POINTER(EncoderDesc), _P, _P, _I, _P, _I, _P, _Z, _I, _P]),

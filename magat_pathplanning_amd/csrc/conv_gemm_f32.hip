@@ -35,9 +35,11 @@ struct ConvGemmParams {
   int C2, lda2, W2, stride2;
   int Cout, Ktot, ldc, relu;
   int ntn, npix;
+  int tag;
+  int pool_w;   // POOL: physical input width (input pixel (iy,ix) = sum of the 2x2 physical pixels)
 };
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool POOL>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -90,7 +92,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     if (s < ntaps * spt) {
       const int tap = s / spt, k0 = (s - tap * spt) * BK;
       const int ty = ty0 + tap / ntx, tx = tx0 + tap % ntx;
-      abase = p.in + (long long)((iy0 + ty) * p.Win + (ix0 + tx)) * p.in_pix_stride + k0;
+      if (POOL)
+        abase = p.in + (long long)(2 * (iy0 + ty) * p.pool_w + 2 * (ix0 + tx)) * p.in_pix_stride + k0;
+      else
+        abase = p.in + (long long)((iy0 + ty) * p.Win + (ix0 + tx)) * p.in_pix_stride + k0;
       lda = p.lda;
       bk = (ty * p.kW + tx) * p.Cin + k0;
       kvalid = p.Cin - k0;
@@ -106,7 +111,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     for (int i = 0; i < AI; ++i) {
       const int m = m0 + r0 + 32 * i;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kok && m < p.M) v = *reinterpret_cast<const f32x4*>(abase + (long long)m * lda + c4 * 4);
+      if (kok && m < p.M) {
+        const float* src = abase + (long long)m * lda + c4 * 4;
+        v = *reinterpret_cast<const f32x4*>(src);
+        if (POOL && s < ntaps * spt) {   // 2x2 sum-pool on load (the 1/4 lives in the weights)
+          v += *reinterpret_cast<const f32x4*>(src + p.in_pix_stride);
+          v += *reinterpret_cast<const f32x4*>(src + (long long)p.pool_w * p.in_pix_stride);
+          v += *reinterpret_cast<const f32x4*>(src + (long long)(p.pool_w + 1) * p.in_pix_stride);
+        }
+      }
       ra[i] = v;
     }
 #pragma unroll
@@ -186,14 +199,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool POOL = false>
 int launch(ConvGemmParams& p, hipStream_t st) {
   p.Mt = (p.M + BM - 1) / BM;
   p.ntn = (p.Cout + BN - 1) / BN;
   const long long groups = (p.Mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD;
   const long long grid = groups * MAGAT_NUM_XCD * p.npix * p.ntn;
   if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  const int pid = magat_prof_begin(p.tag, st);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, POOL>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  magat_prof_end(pid, st);
   return magat_check_launch();
 }
 
@@ -217,8 +232,15 @@ extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) 
   p.C2 = d->C2; p.lda2 = d->lda2; p.W2 = d->W2; p.stride2 = d->stride2;
   p.Cout = d->Cout; p.Ktot = d->kH * d->kW * d->Cin + d->C2; p.ldc = d->ldc; p.relu = d->relu;
   p.npix = d->Hout * d->Wout;
+  p.tag = d->tag;
+  p.pool_w = 0;
+  if (d->pool) {   // input map is the 2x2 sum-pool of a physical (2*Hin.. x pool_w) map
+    if (d->pool_w < 2 * d->Win) return MAGAT_ERR_BAD_SHAPE;
+    p.pool_w = d->pool_w;
+  }
   if ((p.in_pix_stride & 3) || (p.in2_pix_stride & 3)) return MAGAT_ERR_BAD_SHAPE;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (d->pool) return launch<128, 128, 2, 2, true>(p, st);
   if (p.Cout > 64) return launch<128, 128, 2, 2>(p, st);
   if (p.Cout > 32) return launch<128, 64, 2, 2>(p, st);
   return launch<128, 32, 4, 1>(p, st);
@@ -226,7 +248,13 @@ extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) 
 
 extern "C" int magat_linear_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M,
                                 int N, int K, int relu, void* stream) {
+  return magat_linear_tagged_f32(x, ldx, w, b, y, ldy, M, N, K, relu, MAGAT_TAG_UNTAGGED, stream);
+}
+
+extern "C" int magat_linear_tagged_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
+                                       int M, int N, int K, int relu, int tag, void* stream) {
   magat_conv_gemm_desc d = {};
+  d.tag = tag;
   d.in = x; d.wt = w; d.bias = b; d.out = y;
   d.M = M; d.Cin = K; d.lda = ldx; d.Hin = d.Win = 1; d.kH = d.kW = 1; d.stride = 1; d.pad = 0;
   d.Hout = d.Wout = 1; d.Cout = N; d.ldc = ldy; d.relu = relu;

@@ -9,54 +9,68 @@
 
 namespace {
 
-// conv3x3(3->32, pad 1)+BN+ReLU on (M,3,H,W) NCHW -> pixel-major [H*W][M][32].
-// One thread per (pixel, agent) computes all 32 output channels; the 32x27 weights are wave-uniform
-// (scalar loads), the output row is 128 contiguous bytes.
+// conv3x3(3->32, pad 1)+BN+ReLU on (M,3,H,W) NCHW -> pixel-major [H*W][M][32], as an MFMA GEMM with the
+// 27-wide im2col row padded to K=32.  A workgroup stages 32 agents' zero-padded images in LDS
+// ((H+2)x(W+2) per channel, odd agent stride -> conflict-free column reads); each wave then walks
+// output pixels: its 32x32 tile is (32 agents) x (32 channels) at one pixel, i.e. 4 KB of contiguous
+// output, from 16 v_mfma_f32_32x32x2_f32 whose A operands are plain ds_read_b32 gathers.
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          int M, int H, int W) {
-  __shared__ float ws[27 * 32 + 32];
-  for (int i = threadIdx.x; i < 27 * 32; i += blockDim.x) {
-    const int co = i / 27, k = i % 27;
-    ws[k * 32 + co] = wt[i];
-  }
-  for (int i = threadIdx.x; i < 32; i += blockDim.x) ws[27 * 32 + i] = bias[i];
+  extern __shared__ float img[];
+  const int PW = W + 2, PHW = (H + 2) * PW;
+  const int PS = (3 * PHW) | 1;            // odd per-agent stride
+  const int HW = H * W;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m0 = blockIdx.x * 32;
+  for (int i = t; i < 32 * PS; i += 256) img[i] = 0.f;
   __syncthreads();
-  const long long total = (long long)H * W * M;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int pix = (int)(idx / M), m = (int)(idx % M);
-    const int oy = pix / W, ox = pix % W;
-    float acc[32];
+  const int per = 3 * HW;
+  for (int i = t; i < 32 * per; i += 256) {
+    const int a = i / per, r = i - a * per;
+    const int c = r / HW, q = r - c * HW;
+    const int y = q / W, xx = q - y * W;
+    if (m0 + a < M) img[a * PS + c * PHW + (y + 1) * PW + xx + 1] = x[(long long)(m0 + a) * per + r];
+  }
+  // B operand (weights) and per-k LDS tap offsets for this lane half: k = s + 16*(lane>>5)
+  float bw[16];
+  int koff[16];
+  const int co = lane & 31;
 #pragma unroll
-    for (int co = 0; co < 32; ++co) acc[co] = ws[27 * 32 + co];
-    const float* xm = x + (long long)m * 3 * H * W;
+  for (int s = 0; s < 16; ++s) {
+    const int k = s + 16 * (lane >> 5);
+    const bool kok = k < 27;
+    bw[s] = kok ? wt[co * 27 + k] : 0.f;
+    const int kk = kok ? k : 0;
+    koff[s] = (kk / 9) * PHW + ((kk % 9) / 3) * PW + (kk % 3);
+  }
+  const float bv = bias[co];
+  __syncthreads();
+  const int abase = (lane & 31) * PS;
+  for (int pix = wave; pix < HW; pix += 4) {
+    const int oy = pix / W, ox = pix - oy * W;
+    const int base = abase + oy * PW + ox;
+    f32x16 acc;
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int ty = 0; ty < 3; ++ty)
+    for (int s = 0; s < 16; ++s) {
+      float a = img[base + koff[s]];
+      if (s + 16 * (lane >> 5) >= 27) a = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[s], acc, 0, 0, 0);
+    }
+    float* o = out + ((long long)pix * M + m0) * 32 + co;
 #pragma unroll
-        for (int tx = 0; tx < 3; ++tx) {
-          const int iy = oy + ty - 1, ix = ox + tx - 1;
-          float v = 0.f;
-          if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = xm[(c * H + iy) * W + ix];
-          const float* wk = ws + (c * 9 + ty * 3 + tx) * 32;
-#pragma unroll
-          for (int co = 0; co < 32; ++co) acc[co] = fmaf(v, wk[co], acc[co]);
-        }
-    float* o = out + ((long long)pix * M + m) * 32;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      f32x4 v = {fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f),
-                 fmaxf(acc[4 * q + 3], 0.f)};
-      *reinterpret_cast<f32x4*>(o + 4 * q) = v;
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m0 + row < M) o[row * 32] = fmaxf(acc[r] + bv, 0.f);
     }
   }
 }
 
 int enc_chunk_agents(int M) {
   const char* env = getenv("MAGAT_ENC_CHUNK");
-  long long c = env ? atoll(env) : 8192;
+  long long c = env ? atoll(env) : 65536;
   if (c < 128) c = 128;
   if (c > M) c = M;
   return (int)c;
@@ -72,10 +86,13 @@ extern "C" int magat_conv_first_f32(const float* x, const float* wt, const float
                                     int W, void* stream) {
   if (!x || !wt || !bias || !out) return MAGAT_ERR_NULL;
   if (M <= 0 || H <= 0 || W <= 0) return MAGAT_ERR_BAD_SHAPE;
-  long long blocks = ((long long)H * W * M + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, wt,
-                     bias, out, M, H, W);
+  const size_t lds = sizeof(float) * 32 * (size_t)((3 * (H + 2) * (W + 2)) | 1);
+  if (lds > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  const int blocks = (M + 31) / 32;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int pid = magat_prof_begin(MAGAT_TAG_CONV_FIRST, st);
+  hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W);
+  magat_prof_end(pid, st);
   return magat_check_launch();
 }
 
@@ -129,6 +146,7 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       g.in_pix_stride = (int64_t)mm * s.cin; g.out_pix_stride = (int64_t)mm * s.cout;
       g.M = mm; g.Cin = s.cin; g.lda = s.cin; g.Hin = hin; g.Win = win; g.kH = g.kW = 3; g.stride = s.stride;
       g.pad = 1; g.Hout = hout; g.Wout = wout; g.Cout = s.cout; g.ldc = s.cout; g.relu = 1;
+      g.tag = MAGAT_TAG_BLOCK_CONV + 2 * l;
       rc = magat_conv_gemm_f32(&g, stream);
       if (rc != MAGAT_OK) return rc;
       // conv2 + bn2 + (1x1 strided downsample + bn) + relu
@@ -140,23 +158,27 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       h.M = mm; h.Cin = s.cout; h.lda = s.cout; h.Hin = hout; h.Win = wout; h.kH = h.kW = 3; h.stride = 1; h.pad = 1;
       h.Hout = hout; h.Wout = wout; h.C2 = s.cin; h.lda2 = s.cin; h.W2 = win; h.stride2 = s.stride;
       h.Cout = s.cout; h.ldc = s.cout; h.relu = 1;
+      h.tag = MAGAT_TAG_BLOCK_CONV + 2 * l + 1;
       rc = magat_conv_gemm_f32(&h, stream);
       if (rc != MAGAT_OK) return rc;
       cur = nxt; hin = hout; win = wout;
     }
-    // head: avgpool(2)+fc(+Flatten+Linear) folded into a (hin x win) valid conv -> [mm][n_feat]
+    // head: AvgPool2d(2) (sum-pool on load, 1/4 in the weights) + fc(+Flatten+Linear) folded into one
+    // (hin/2 x win/2) valid conv over the pooled map -> [mm][n_feat]
     const int clast = shapes[nblocks - 1].cout;
     magat_conv_gemm_desc g = {};
     g.in = buf[cur]; g.wt = pk + d->off[14]; g.bias = pk + d->off[15];
     g.out = feat + (size_t)m0 * ldfeat;
-    g.in_pix_stride = (int64_t)mm * clast; g.M = mm; g.Cin = clast; g.lda = clast; g.Hin = hin; g.Win = win;
-    g.kH = hin; g.kW = win; g.stride = 1; g.pad = 0; g.Hout = g.Wout = 1; g.Cout = d->n_feat; g.ldc = ldfeat;
-    g.relu = 0;
+    g.in_pix_stride = (int64_t)mm * clast; g.M = mm; g.Cin = clast; g.lda = clast; g.Hin = hin / 2; g.Win = win / 2;
+    g.kH = hin / 2; g.kW = win / 2; g.stride = 1; g.pad = 0; g.Hout = g.Wout = 1; g.Cout = d->n_feat; g.ldc = ldfeat;
+    g.relu = 0; g.pool = 1; g.pool_w = win;
+    g.tag = MAGAT_TAG_HEAD;
     rc = magat_conv_gemm_f32(&g, stream);
     if (rc != MAGAT_OK) return rc;
     if (d->n_comp > 0) {
-      rc = magat_linear_f32(feat + (size_t)m0 * ldfeat, ldfeat, pk + d->off[16], pk + d->off[17],
-                            comp + (size_t)m0 * ldcomp, ldcomp, mm, d->n_comp, d->n_feat, 1, stream);
+      rc = magat_linear_tagged_f32(feat + (size_t)m0 * ldfeat, ldfeat, pk + d->off[16], pk + d->off[17],
+                                   comp + (size_t)m0 * ldcomp, ldcomp, mm, d->n_comp, d->n_feat, 1,
+                                   MAGAT_TAG_COMPRESS, stream);
       if (rc != MAGAT_OK) return rc;
     }
   }

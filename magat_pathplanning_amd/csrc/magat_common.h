@@ -11,6 +11,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MAGAT_WAVE 64
 #define MAGAT_NUM_XCD 8
 
+// per-kernel timing hooks (profile.hip); tags are listed in include/magat_hip.h
+int magat_prof_begin(int tag, hipStream_t st);
+void magat_prof_end(int id, hipStream_t st);
+
 static inline int magat_check_launch() {
   return hipGetLastError() == hipSuccess ? MAGAT_OK : MAGAT_ERR_LAUNCH;
 }

@@ -8,7 +8,8 @@ the "encoder pack" consumed by magat_encoder_forward_f32 (include/magat_hip.h):
   per BasicBlock l = 0..2 (Slim: 0..1):
   off[2+4l] conv1 weight [Cout][9*Cin]  (ty,tx,c order)    off[3+4l] bias [Cout]
   off[4+4l] [conv2 | downsample] weight [Cout][9*Cout+Cin] off[5+4l] bias_conv2 + bias_down
-  off[14] head weight [n_feat][Ho*Wo*Clast]  (avgpool(2)+fc(+Flatten+Linear) folded)
+  off[14] head weight [n_feat][Hp*Wp*Clast]  (fc(+Flatten+Linear) folded, x 1/4 of AvgPool2d(2);
+          the GEMM sum-pools the 2x2 windows while loading its A operand)
   off[15] head bias [n_feat]
   off[16] compressMLP weight [G][n_feat]                   off[17] compressMLP bias [G]
 
@@ -87,11 +88,7 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
         W2 = torch.einsum("qc,abyx->qabyxc", fc, eye).reshape(nq * Hp * Wp, Hp, Wp, clast)
         b2 = fcb.repeat_interleave(Hp * Wp)
         n_feat = nq * Hp * Wp
-    Weff = torch.zeros(n_feat, Ho, Wo, clast, dtype=torch.float64)
-    for py in range(2 * Hp):
-        for px in range(2 * Wp):
-            Weff[:, py, px, :] = 0.25 * W2[:, py // 2, px // 2, :]
-    put(14, Weff)
+    put(14, 0.25 * W2)      # the kernel sum-pools 2x2 on load; the 1/4 lives here
     put(15, b2)
     n_comp = 0
     if compress is not None:

@@ -275,6 +275,7 @@ class DecentralPlannerGATNet(nn.Module):
             d.wt, d.bias, d.out = rt.act[0].data_ptr(), rt.act[1].data_ptr(), out.data_ptr()
             d.M, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad, d.Hout, d.Wout = M, 1, 1, 1, 1, 1, 0, 1, 1
             d.Cout, d.ldc, d.relu = nout, nout, 1 if self.config.use_dropout else 0
+            d.tag = nat.TAG_ACTIONS
             nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), stream), "magat_conv_gemm_f32(actionsMLP.0)")
             if self.config.use_dropout:
                 out2 = torch.empty(M, rt.act[2].shape[0], dtype=torch.float32, device=dev)

@@ -83,8 +83,8 @@ def test_encoder_fold_matches_unfolded_cnn():
             wd = wcat[:, 9 * cout:].reshape(cout, cin, 1, 1)
             y = torch.relu(tnf.conv2d(h, w2, seg(5 + 4 * l, cout), 1, 1) + tnf.conv2d(y, wd, None, stride))
             cin = cout
-        wh = seg(14, meta["n_feat"], 6, 6, cin).permute(0, 3, 1, 2)
-        feat = tnf.conv2d(y, wh, seg(15, meta["n_feat"])).flatten(1)
+        wh = seg(14, meta["n_feat"], 3, 3, cin).permute(0, 3, 1, 2)      # x 1/4; kernel sum-pools 2x2 on load
+        feat = tnf.conv2d(4.0 * tnf.avg_pool2d(y, 2), wh, seg(15, meta["n_feat"])).flatten(1)
         np.testing.assert_allclose(feat.numpy(), want.numpy(), rtol=0, atol=2e-5)
 
 
