@@ -67,6 +67,25 @@ def per_agent_work(cfg, N, S_bytes):
     return w
 
 
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/<round>/summary_*.json, made by
+    tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction).  PMC counters
+    cannot be collected from inside this process, so the latest committed summary of the same workload is used."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary_*.json")))
+    if not paths:
+        return {}
+    try:
+        d = json.load(open(paths[-1]))
+    except Exception:
+        return {}
+    out = {}
+    for k, v in d.get("layers", {}).items():
+        if "hbm_bytes_per_launch" in v:
+            out[k] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.relpath(paths[-1], ROOT)}
+    return out
+
+
 def build_model(cfg, device, seed=1337):
     from magat_pathplanning_amd import DecentralPlannerGATNet
     torch.manual_seed(seed)
@@ -191,6 +210,7 @@ def main():
                           "global_batch": B * world, "agents": N, "parallelism": "instance-sharded x%d" % world}}
         if timing:
             work = per_agent_work(cfg, N, 4)
+            TAG_OF = {v: k for k, v in nat.TAGS.items()}
             kernels, dom = {}, None
             agent_steps = B * N * args.steps
             for tag, name in nat.TAGS.items():
@@ -216,11 +236,18 @@ def main():
                     dom = (name, tot.value)
             res["kernels"] = kernels
 
+            pmc = load_pmc_traffic() if args.workload == "c3" and not args.batch else {}
+
             def roof(name):
                 e = kernels[name]
+                tr = pmc.get(name)
                 return {"kernel": name, "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"],
-                        "unit": e["unit"], "frac": e["frac"], "traffic": None, "avg_us": e["avg_us"],
-                        "launches": e["launches"]}
+                        "unit": e["unit"], "frac": e["frac"],
+                        "traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
+                        "traffic_source": None if tr is None else tr["source"],
+                        "algorithmic_per_launch": round((work[TAG_OF[name]][1] if e["bound"] == "hbm" else
+                                                         work[TAG_OF[name]][0]) * B * N),
+                        "avg_us": e["avg_us"], "launches": e["launches"]}
             if dom:
                 res["roofline"] = roof(dom[0])
             if "gat_graph" in kernels:

@@ -1,0 +1,115 @@
+"""Folds rocprofv3 CSV output (kernel stats + FETCH_SIZE / WRITE_SIZE PMC passes) into small, committable
+summaries:  gpurun_out/prof_<tag>/summary_<tag>.{txt,json}.  HBM bytes follow MI355X_MICROARCH.md section HBM:
+FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly 1/2 of a wide coalesced streaming read,
+so read bytes = 2 * FETCH_SIZE * 1024 (WRITE_SIZE is taken as reported: uncalibrated, see the guide)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    for key, s in (("conv_gemm_kernel<128, 128, 2, 2, true>", "conv_gemm<128,128,pool>"),
+                   ("conv_gemm_kernel<128, 128", "conv_gemm<128,128>"), ("conv_gemm_kernel<128, 64", "conv_gemm<128,64>"),
+                   ("conv_gemm_kernel<128, 32", "conv_gemm<128,32>"), ("conv_first_kernel", "conv_first"),
+                   ("gat_dense_kernel", "gat_dense_kernel"), ("head_mean_relu", "head_mean_relu"),
+                   ("pack_kernel", "gat_pack"), ("gso_prepare", "gso_prepare")):
+        if key in name:
+            return s
+    return name[:60]
+
+
+def find(root, pattern):
+    hits = glob.glob(os.path.join(root, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    res = {"tag": tag, "kernels": {}}
+    lines = []
+    st = find(os.path.join(out, "trace"), "*kernel_stats.csv")
+    if st:
+        lines.append("== rocprofv3 --kernel-trace --stats (bench.py --steps 5 --warmup 2): per-kernel durations (ns)")
+        with open(st) as f:
+            for row in csv.DictReader(f):
+                n = short(row["Name"])
+                lines.append("%-28s calls=%6s avg_ns=%12s total_ns=%14s pct=%6s" % (
+                    n, row["Calls"], row["AverageNs"], row["TotalDurationNs"], row["Percentage"]))
+                res["kernels"].setdefault(n, {}).update(calls=int(row["Calls"]), avg_us=float(row["AverageNs"]) / 1e3,
+                                                        pct=float(row["Percentage"]))
+    for ctr, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+        cc = find(os.path.join(out, sub), "*counter_collection.csv")
+        if not cc:
+            continue
+        acc = defaultdict(lambda: [0, 0.0])
+        with open(cc) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") != ctr:
+                    continue
+                k = short(row["Kernel_Name"])
+                acc[k][0] += 1
+                acc[k][1] += float(row["Counter_Value"])
+        lines.append("== rocprofv3 --pmc %s: per-launch average (KiB as reported)" % ctr)
+        for k, (n, tot) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            lines.append("%-28s launches=%5d avg_KiB=%14.1f" % (k, n, tot / n))
+            res["kernels"].setdefault(k, {})[ctr + "_KiB_per_launch"] = tot / n
+    # per-layer split: our library launches a fixed 12-kernel sequence per addGSO+forward step (c3 workload)
+    SEQ = ["conv_first", "layer1.conv1", "layer1.conv2+ds", "layer2.conv1", "layer2.conv2+ds", "layer3.conv1",
+           "layer3.conv2+ds", "head(avgpool+fc+linear)", "compressMLP", "gat_maps_gemm", "gat_graph", "actionsMLP"]
+    ours = ("conv_gemm_kernel", "conv_first_kernel", "gat_dense_kernel")
+    layers = defaultdict(dict)
+    tr = find(os.path.join(out, "trace"), "*kernel_trace.csv")
+    if tr:
+        rows = [r for r in csv.DictReader(open(tr)) if any(o in r["Kernel_Name"] for o in ours)]
+        if len(rows) % len(SEQ) == 0:
+            dur = defaultdict(list)
+            for i, r in enumerate(rows):
+                dur[SEQ[i % len(SEQ)]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            for k, v in dur.items():
+                layers[k]["avg_us"] = sum(v) / len(v)
+                layers[k]["launches"] = len(v)
+    for ctr, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+        cc = find(os.path.join(out, sub), "*counter_collection.csv")
+        if not cc:
+            continue
+        rows = [r for r in csv.DictReader(open(cc)) if r.get("Counter_Name") == ctr and
+                any(o in r["Kernel_Name"] for o in ours)]
+        if len(rows) % len(SEQ) == 0:
+            acc2 = defaultdict(list)
+            for i, r in enumerate(rows):
+                acc2[SEQ[i % len(SEQ)]].append(float(r["Counter_Value"]))
+            for k, v in acc2.items():
+                layers[k][ctr + "_KiB_per_launch"] = sum(v) / len(v)
+    lines.append("== per-layer view (dispatch order within a step): avg_us | HBM read MB (2*FETCH) | write MB")
+    for k in SEQ:
+        v = layers.get(k)
+        if not v:
+            continue
+        rd = 2.0 * v.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024.0
+        wr = v.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024.0
+        v["hbm_read_bytes_per_launch"], v["hbm_write_bytes_per_launch"], v["hbm_bytes_per_launch"] = rd, wr, rd + wr
+        lines.append("%-26s avg_us=%10.2f read=%9.1f MB write=%9.1f MB" % (k, v.get("avg_us", float("nan")), rd / 1e6, wr / 1e6))
+    res["layers"] = layers
+    for k, v in res["kernels"].items():
+        if "FETCH_SIZE_KiB_per_launch" in v:
+            rd = 2.0 * v["FETCH_SIZE_KiB_per_launch"] * 1024.0
+            wr = v.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024.0
+            v["hbm_bytes_per_launch"] = rd + wr
+            v["hbm_read_bytes_per_launch"], v["hbm_write_bytes_per_launch"] = rd, wr
+    lines.append("== corrected HBM bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 rule)")
+    for k, v in res["kernels"].items():
+        if "hbm_bytes_per_launch" in v:
+            lines.append("%-28s read=%.1f MB write=%.1f MB" % (k, v["hbm_read_bytes_per_launch"] / 1e6,
+                                                              v["hbm_write_bytes_per_launch"] / 1e6))
+    with open(os.path.join(out, "summary_%s.txt" % tag), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    with open(os.path.join(out, "summary_%s.json" % tag), "w") as f:
+        json.dump(res, f, indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
