@@ -1,0 +1,36 @@
+"""Instance sharding across the GPUs of a node (one process per GPU, torch.distributed; backend "nccl" is
+RCCL over xGMI on ROCm, "gloo" in the CPU tests).  Planning instances are independent (the GSO is
+block-diagonal over B), so the forward needs NO collective: each rank runs its
+contiguous slice of the batch.  Only callers that want the whole batch's logits on every rank pay one
+all_gather of (B/R*N, 5) floats (8 MB total at B=4096, N=100)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_instances, rank, world):
+    """Contiguous, balanced slice [start, stop) of the instance axis owned by `rank`."""
+    base, rem = divmod(num_instances, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def sharded_forward(model, x, S, group=None, gather=True):
+    """x (B,N,3,W,H), S (B,N,N): the FULL batch on every rank (or anything indexable the same way).
+    Runs addGSO+forward on this rank's instances only.  gather=False -> local logits ((b1-b0)*N, 5);
+    gather=True -> full (B*N, 5) logits on every rank, identical to the single-process result."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B, N = x.shape[0], x.shape[1]
+    b0, b1 = shard_range(B, rank, world)
+    Sl = S[b0:b1].contiguous()
+    model.addGSO(Sl)
+    local = model(x[b0:b1])
+    if not gather or world == 1:
+        return local
+    cap = (B + world - 1) // world * N
+    pad = torch.zeros(cap, local.shape[1], dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local.detach()
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    rows = [shard_range(B, r, world) for r in range(world)]
+    return torch.cat([parts[r][: (e - s) * N] for r, (s, e) in enumerate(rows)], dim=0)
