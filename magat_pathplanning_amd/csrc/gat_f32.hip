@@ -34,6 +34,8 @@ struct GatParams {
   int ldx, ldy, NC, lda_a;
   int qoff, uoff, c1off, c2off;  // column offsets inside a Z row
   int b0;                        // first instance of this chunk
+  long long* dbg;                // optional phase timestamps [blocks][8] (instrumentation; null in production)
+  int skip;                      // instrumentation: bit0 skip scores, bit1 skip hops (wrong results; for PMC deltas)
 };
 
 __device__ __forceinline__ bool is_edge(const void* S, long long idx, int f64) {
@@ -41,6 +43,10 @@ __device__ __forceinline__ bool is_edge(const void* S, long long idx, int f64) {
   return fabsf(static_cast<const float*>(S)[idx]) > 1e-9f;
 }
 
+// Block size is 8 threads per (power-of-two-rounded) node, so every staging loop below is a fixed, fully
+// unrolled handful of 16-byte loads per thread: ALL of a workgroup's global reads (Q_p, X_b, the GSO mask,
+// U_{K-1}, and the first hop's U rows) are issued back to back at kernel entry and land while the earlier
+// phases run out of LDS.
 template <int G, int F>
 __global__ void gat_dense_kernel(const GatParams p) {
   constexpr int RW = G > F ? G : F;
@@ -50,6 +56,12 @@ __global__ void gat_dense_kernel(const GatParams p) {
   constexpr int EPS = 64 / LE;                      // edges per wave step
   constexpr int LF = FC < 64 ? FC : 64;             // lanes per output row in the hop phase
   constexpr int RPW = 64 / LF;                      // rows per wave step
+  constexpr int QG = GC / 8 > 0 ? GC / 8 : 1;       // staged chunks per thread (NT >= 8 N)
+  constexpr int QF = FC / 8 > 0 ? FC / 8 : 1;
+  constexpr bool WIDE = G >= 64 && F >= 64;         // one wave spans a whole feature row
+  constexpr int VEC = WIDE ? F / 64 : 4;            // floats per lane of a feature row in the hop phase
+  constexpr int HMAX = WIDE ? 8 : (8 / RPW > 0 ? 8 / RPW : 1);   // hop rows (row-groups) per wave
+  typedef float fvec __attribute__((ext_vector_type(VEC)));
   static_assert(FC <= 64, "F <= 256");
   extern __shared__ __align__(16) float smem[];
 
@@ -61,80 +73,236 @@ __global__ void gat_dense_kernel(const GatParams p) {
   if (bl >= p.B) return;
   const int b = p.b0 + bl;
 
-  float* R0 = smem;
-  float* R1 = R0 + N * RW;
-  float* A = R1 + N * F;
+  float* R0 = smem;                      // Q_p, later hop buffer
+  float* R1 = R0 + N * RW;               // X_b during the score phase, then U_{K-1} / hop buffer
+  float* A = R1 + N * RW;                // mask, then attention (N x lda_a)
   float* c1s = A + N * p.lda_a;
-  int* nbr = reinterpret_cast<int*>(c1s + ((N + 3) & ~3));
+  float* c2s = c1s + ((N + 3) & ~3);
+  int* nbr = reinterpret_cast<int*>(c2s + ((N + 3) & ~3));
+  unsigned* rmask = reinterpret_cast<unsigned*>(                                  // [N][4] edge bitmask per row, 16-B aligned
+      (reinterpret_cast<uintptr_t>(nbr + 128 * (blockDim.x >> 6)) + 15) & ~static_cast<uintptr_t>(15));
 
   const int t = threadIdx.x, NT = blockDim.x, lane = t & 63, wave = t >> 6, nwaves = NT >> 6;
   const float* Zb = p.Z + (long long)bl * N * p.NC;
   const float* Xb = p.X + (long long)b * N * p.ldx;
   const long long sbase = (long long)b * N * N;
   const int K = p.K;
+  const bool keyquery = p.mode == MAGAT_MODE_KEYQUERY;
+  const bool need_att = K > 1 || p.A_opt;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  long long* dbg = p.dbg ? p.dbg + (long long)bid * 8 : nullptr;
+  if (dbg && t == 0) dbg[0] = clock64();
 
-  // ---- phase 0: stage Q_p (KeyQuery) and the deepest hop operand U_{K-1} in LDS
-  if (p.mode == MAGAT_MODE_KEYQUERY) {
-    const int qo = p.qoff + head * G;
-    for (int idx = t; idx < N * GC; idx += NT) {
-      const int n = idx / GC, c = idx - n * GC;
-      *reinterpret_cast<f32x4*>(R0 + n * G + 4 * c) =
-          *reinterpret_cast<const f32x4*>(Zb + (long long)n * p.NC + qo + 4 * c);
+  // ---- phase 0: issue every global read of the first three phases
+  f32x4 qst[QG], xst[QG], ust[QF];
+  fvec ucur[HMAX], unext[HMAX];
+  fvec zerov;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) zerov[e] = 0.f;
+  const int qo = p.qoff + head * G;
+  if (keyquery && need_att) {
+#pragma unroll
+    for (int q = 0; q < QG; ++q) {
+      const int idx = t + q * NT, n = idx / GC, c = idx % GC;
+      qst[q] = zero4; xst[q] = zero4;
+      if (n < N) {
+        qst[q] = *reinterpret_cast<const f32x4*>(Zb + (long long)n * p.NC + qo + 4 * c);
+        xst[q] = *reinterpret_cast<const f32x4*>(Xb + (long long)n * p.ldx + 4 * c);
+      }
     }
-  } else {
-    for (int n = t; n < N; n += NT) c1s[n] = Zb[(long long)n * p.NC + p.c1off + head];
+  }
+  if (need_att) {
+    if constexpr (WIDE) {   // GSO rows -> 128-bit edge masks (one wave per row, coalesced reads, ballot)
+      for (int i = wave; i < N; i += nwaves) {
+        const bool f0 = lane < N && is_edge(p.S, sbase + (long long)i * N + lane, p.s_is_f64);
+        const bool f1 = lane + 64 < N && is_edge(p.S, sbase + (long long)i * N + lane + 64, p.s_is_f64);
+        const unsigned long long k0 = __ballot(f0), k1 = __ballot(f1);
+        if (lane == 0) {
+          rmask[4 * i + 0] = (unsigned)k0; rmask[4 * i + 1] = (unsigned)(k0 >> 32);
+          rmask[4 * i + 2] = (unsigned)k1; rmask[4 * i + 3] = (unsigned)(k1 >> 32);
+        }
+      }
+    } else {                // mask -> A (1/0)
+      for (int idx = t; idx < N * N; idx += NT) {
+        const int i = idx / N, j = idx - i * N;
+        A[i * p.lda_a + j] = is_edge(p.S, sbase + idx, p.s_is_f64) ? 1.f : 0.f;
+      }
+    }
+    if (!keyquery)
+      for (int n = t; n < N; n += NT) {
+        c1s[n] = Zb[(long long)n * p.NC + p.c1off + head];
+        c2s[n] = Zb[(long long)n * p.NC + p.c2off + head];
+      }
   }
   if (K > 1) {
     const int uo = p.uoff + (head * K + (K - 1)) * F;
-    for (int idx = t; idx < N * FC; idx += NT) {
-      const int n = idx / FC, c = idx - n * FC;
-      *reinterpret_cast<f32x4*>(R1 + n * F + 4 * c) =
-          *reinterpret_cast<const f32x4*>(Zb + (long long)n * p.NC + uo + 4 * c);
+#pragma unroll
+    for (int q = 0; q < QF; ++q) {
+      const int idx = t + q * NT, n = idx / FC, c = idx % FC;
+      ust[q] = zero4;
+      if (n < N) ust[q] = *reinterpret_cast<const f32x4*>(Zb + (long long)n * p.NC + uo + 4 * c);
+    }
+  }
+  // hop-phase lane map.  WIDE: a wave owns one output row, lane -> VEC consecutive features.
+  // otherwise: LF lanes per row (16 B each), RPW rows per wave step.
+  const int sub = WIDE ? lane : lane % LF, grp = WIDE ? 0 : lane / LF;
+  const int rpw = WIDE ? 1 : RPW;
+  {
+    const int uo = p.uoff + (head * K + (K > 1 ? K - 2 : 0)) * F;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+      const int j = (wave + h * nwaves) * rpw + grp;
+      ucur[h] = zerov;
+      if (j < N) ucur[h] = *reinterpret_cast<const fvec*>(Zb + (long long)j * p.NC + uo + VEC * sub);
+    }
+  }
+  if (keyquery && need_att) {
+#pragma unroll
+    for (int q = 0; q < QG; ++q) {
+      const int idx = t + q * NT, n = idx / GC, c = idx % GC;
+      if (n < N) {
+        *reinterpret_cast<f32x4*>(R0 + n * G + 4 * c) = qst[q];
+        *reinterpret_cast<f32x4*>(R1 + n * G + 4 * c) = xst[q];
+      }
     }
   }
   __syncthreads();
+  if (dbg && t == 0) dbg[1] = clock64();
 
-  // ---- phase 1: attention rows (one wave per row)
-  if (K > 1 || p.A_opt) {
+  // ---- phase 1: attention rows out of LDS.
+  // WIDE (G >= 64): a 16-lane row of the wave owns one graph row (4 rows per wave step); its lanes walk the
+  // row's edge bitmask, each edge costing CPL ds_read_b128 + 4*CPL FMA + 4 DPP adds; the masked softmax then
+  // runs with lane = neighbour slot (8 slots per lane), reductions again on DPP.  No ds_bpermute anywhere.
+  if (need_att && !(p.skip & 1)) {
+    if constexpr (WIDE) {
+      // 8 lanes per graph row (8 rows per wave step); lane es owns chunks es + 8*(q ^ (eg&1)) of a feature row:
+      // odd groups start on the other 128-byte half, so the 16-lane ds_read_b128 service groups never collide.
+      constexpr int CP8 = GC / 8;
+      const int es = lane & 7, eg = lane >> 3, par = eg & 1;
+      for (int ib = 8 * wave; ib < N; ib += 8 * nwaves) {
+        const int i = ib + eg;
+        const bool iok = i < N;
+        const int ir = iok ? i : 0;
+        float* Arow = A + ir * p.lda_a;
+        const uint4 mk = *reinterpret_cast<const uint4*>(rmask + 4 * ir);
+        unsigned w[4] = {iok ? mk.x : 0u, iok ? mk.y : 0u, iok ? mk.z : 0u, iok ? mk.w : 0u};
+        if (keyquery) {
+          f32x4 xi[CP8];
+#pragma unroll
+          for (int q = 0; q < CP8; ++q)
+            xi[q] = *reinterpret_cast<const f32x4*>(R1 + ir * G + 4 * (es + 8 * (q ^ par)));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            unsigned ww = w[r];
+            while (ww) {          // two edges of this row per trip: both neighbour rows in flight together
+              const int j0 = 32 * r + __builtin_ctz(ww);
+              ww &= ww - 1;
+              const bool two = ww != 0;
+              const int j1 = two ? 32 * r + __builtin_ctz(ww) : j0;
+              ww &= ww - 1;
+              float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+              for (int q = 0; q < CP8; ++q) {
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(R0 + j0 * G + 4 * (es + 8 * (q ^ par)));
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(R0 + j1 * G + 4 * (es + 8 * (q ^ par)));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  d0 = fmaf(xi[q][e], q0[e], d0);
+                  d1 = fmaf(xi[q][e], q1[e], d1);
+                }
+              }
+              d0 = oct_sum(d0);
+              d1 = oct_sum(d1);
+              if (es == 0) {
+                Arow[j0] = d0;
+                if (two) Arow[j1] = d1;
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        // masked softmax, lane = neighbour slot j = es + 8*r
+        float v[16];
+        float mx = -__builtin_inff();
+        const float c2 = keyquery ? 0.f : c2s[ir];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = es + 8 * r;
+          const bool f = (w[r >> 2] >> (j & 31)) & 1u;
+          v[r] = -__builtin_inff();
+          if (8 * r < N && f) {
+            if (keyquery) {
+              v[r] = Arow[j];
+            } else {
+              const float e = c1s[j] + c2;
+              v[r] = e > 0.f ? e : 0.2f * e;
+            }
+          }
+          mx = fmaxf(mx, v[r]);
+        }
+        mx = oct_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[r] = v[r] > -__builtin_inff() ? __expf(v[r] - mx) : 0.f;
+          sum += v[r];
+        }
+        sum = oct_sum(sum);
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;
+        float* ao = p.A_opt ? p.A_opt + (((long long)b * p.P + head) * N + ir) * N : nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = es + 8 * r;
+          if (8 * r < N && iok && j < N) {
+            const float a = v[r] * inv;
+            Arow[j] = a;
+            if (ao) ao[j] = a;
+          }
+        }
+      }
+    } else {
     int* nb = nbr + wave * 128;
-    const int sub = lane % LE, grp = lane / LE;
+    const int es = lane % LE, eg = lane / LE;
     for (int i = wave; i < N; i += nwaves) {
-      const bool m0 = lane < N && is_edge(p.S, sbase + (long long)i * N + lane, p.s_is_f64);
-      const bool m1 = lane + 64 < N && is_edge(p.S, sbase + (long long)i * N + lane + 64, p.s_is_f64);
+      const bool m0 = lane < N && A[i * p.lda_a + lane] != 0.f;
+      const bool m1 = lane + 64 < N && A[i * p.lda_a + lane + 64] != 0.f;
       const unsigned long long k0 = __ballot(m0), k1 = __ballot(m1);
       const int deg0 = __popcll(k0), deg = deg0 + __popcll(k1);
       float v0 = 0.f, v1 = 0.f;
-      if (p.mode == MAGAT_MODE_KEYQUERY) {
+      if (keyquery) {
         const unsigned long long lt = (1ull << lane) - 1ull;
         if (m0) nb[__popcll(k0 & lt)] = lane;
         if (m1) nb[deg0 + __popcll(k1 & lt)] = lane + 64;
         f32x4 xi[CPL];
 #pragma unroll
-        for (int q = 0; q < CPL; ++q)
-          xi[q] = *reinterpret_cast<const f32x4*>(Xb + (long long)i * p.ldx + 4 * (sub + LE * q));
+        for (int q = 0; q < CPL; ++q) xi[q] = *reinterpret_cast<const f32x4*>(R1 + i * G + 4 * (es + LE * q));
         __builtin_amdgcn_wave_barrier();
         for (int t0 = 0; t0 < deg; t0 += EPS) {
-          const int ei = t0 + grp;
+          const int ei = t0 + eg;
           const bool ok = ei < deg;
           const int j = ok ? nb[ei] : 0;
           float d = 0.f;
 #pragma unroll
           for (int q = 0; q < CPL; ++q) {
-            const f32x4 qv = *reinterpret_cast<const f32x4*>(R0 + j * G + 4 * (sub + LE * q));
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(R0 + j * G + 4 * (es + LE * q));
             d = fmaf(xi[q][0], qv[0], d);
             d = fmaf(xi[q][1], qv[1], d);
             d = fmaf(xi[q][2], qv[2], d);
             d = fmaf(xi[q][3], qv[3], d);
           }
+          if (LE == 16) {
+            d = row16_sum(d);
+          } else {
 #pragma unroll
-          for (int o = LE / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-          if (ok && sub == 0) A[i * p.lda_a + j] = d;
+            for (int o = LE / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+          }
+          if (ok && es == 0) A[i * p.lda_a + j] = d;
         }
         __builtin_amdgcn_wave_barrier();
         if (m0) v0 = A[i * p.lda_a + lane];
         if (m1) v1 = A[i * p.lda_a + lane + 64];
       } else {
-        const float c2 = Zb[(long long)i * p.NC + p.c2off + head];
+        const float c2 = c2s[i];
         if (m0) { const float e = c1s[lane] + c2; v0 = e > 0.f ? e : 0.2f * e; }
         if (m1) { const float e = c1s[lane + 64] + c2; v1 = e > 0.f ? e : 0.2f * e; }
       }
@@ -151,59 +319,113 @@ __global__ void gat_dense_kernel(const GatParams p) {
         if (lane + 64 < N) ao[lane + 64] = a1;
       }
     }
+    }
   }
   __syncthreads();
+  if (dbg && t == 0) dbg[2] = clock64();
+  if (K > 1) {      // X_b is dead: the deepest hop operand takes its place
+#pragma unroll
+    for (int q = 0; q < QF; ++q) {
+      const int idx = t + q * NT, n = idx / FC, c = idx % FC;
+      if (n < N) *reinterpret_cast<f32x4*>(R1 + n * F + 4 * c) = ust[q];
+    }
+    __syncthreads();
+  }
 
-  // ---- phase 2: Horner hops  T <- U_k + A^T T   (k = K-2 .. 0), last one fused with bias/ReLU/store
-  const int sub = lane % LF, grp = lane / LF;
+  // ---- phase 2: Horner hops  T <- U_k + A^T T   (k = K-2 .. 0), last one fused with bias/ReLU/store.
+  // WIDE: one wave per output row j.  The attention column A[:,j] is read once (2 conflict-free ds_read_b32
+  // per lane), its non-zeros become a wave-uniform 128-bit mask (ballot), and the gather loop is scalar:
+  // s_ff1 -> v_readlane (weight) -> one ds_read of the neighbour's feature row -> VEC FMAs, two neighbours
+  // in flight per iteration.
   const unsigned long long gmask = LF == 64 ? ~0ull : ((1ull << LF) - 1ull);
   float* Rold = R1;
   float* Rnew = R0;
-  for (int k = K - 2; k >= -1; --k) {
-    if (k < 0 && K > 1) break;
-    const int kk = k < 0 ? 0 : k;               // K == 1: plain Y = U_0 (+bias)
-    const int uo = p.uoff + (head * K + kk) * F;
-    const bool last = kk == 0;
-    for (int jb = wave * RPW; jb < N; jb += nwaves * RPW) {
+  for (int k = K > 1 ? K - 2 : 0; k >= 0; --k) {
+    if (p.skip & 2) break;
+    const bool last = k == 0;
+    if (!last) {      // next hop's U rows: in flight during this hop
+      const int uo = p.uoff + (head * K + (k - 1)) * F;
+#pragma unroll
+      for (int h = 0; h < HMAX; ++h) {
+        const int j = (wave + h * nwaves) * rpw + grp;
+        unext[h] = zerov;
+        if (j < N) unext[h] = *reinterpret_cast<const fvec*>(Zb + (long long)j * p.NC + uo + VEC * sub);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+      const int jb = (wave + h * nwaves) * rpw;
+      if (jb >= N) break;
       const int j = jb + grp;
       const bool jok = j < N;
-      f32x4 u = {0.f, 0.f, 0.f, 0.f};
-      if (jok) u = *reinterpret_cast<const f32x4*>(Zb + (long long)j * p.NC + uo + 4 * sub);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      fvec acc = zerov;
       if (K > 1) {
-        for (int r0 = 0; r0 < N; r0 += LF) {
-          const int i = r0 + sub;
-          const float a = (jok && i < N) ? A[i * p.lda_a + j] : 0.f;
-          const unsigned long long bal = __ballot(a != 0.f);
-          unsigned long long mine = (bal >> (grp * LF)) & gmask;
-          while (mine) {
-            const int ii = r0 + __builtin_ctzll(mine);
-            mine &= mine - 1;
-            const float av = A[ii * p.lda_a + j];
-            const f32x4 tv = *reinterpret_cast<const f32x4*>(Rold + ii * F + 4 * sub);
-            acc[0] = fmaf(av, tv[0], acc[0]);
-            acc[1] = fmaf(av, tv[1], acc[1]);
-            acc[2] = fmaf(av, tv[2], acc[2]);
-            acc[3] = fmaf(av, tv[3], acc[3]);
+        if constexpr (WIDE) {
+          const float c0 = lane < N ? A[lane * p.lda_a + j] : 0.f;
+          const float c1 = lane + 64 < N ? A[(lane + 64) * p.lda_a + j] : 0.f;
+          const unsigned long long k0 = __ballot(c0 != 0.f), k1 = __ballot(c1 != 0.f);
+          const float* Tl = Rold + VEC * lane;
+          auto gather = [&](unsigned long long km, float cv, int base) {
+            while (km) {          // two neighbour rows in flight per trip (weights via v_readlane)
+              const int i0 = __builtin_ctzll(km);
+              km &= km - 1;
+              const float a0 = lane_bcast(cv, i0);
+              const fvec t0 = *reinterpret_cast<const fvec*>(Tl + (base + i0) * F);
+              if (km) {
+                const int i1 = __builtin_ctzll(km);
+                km &= km - 1;
+                const float a1 = lane_bcast(cv, i1);
+                const fvec t1 = *reinterpret_cast<const fvec*>(Tl + (base + i1) * F);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = fmaf(a1, t1[e], fmaf(a0, t0[e], acc[e]));
+              } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = fmaf(a0, t0[e], acc[e]);
+              }
+            }
+          };
+          gather(k0, c0, 0);
+          gather(k1, c1, 64);
+        } else {
+          for (int r0 = 0; r0 < N; r0 += LF) {
+            const int i = r0 + sub;
+            const float a = (jok && i < N) ? A[i * p.lda_a + j] : 0.f;
+            const unsigned long long bal = __ballot(a != 0.f);
+            unsigned long long mine = (bal >> (grp * LF)) & gmask;
+            while (mine) {
+              const int ii = r0 + __builtin_ctzll(mine);
+              mine &= mine - 1;
+              const float av = A[ii * p.lda_a + j];
+              const fvec tv = *reinterpret_cast<const fvec*>(Rold + ii * F + VEC * sub);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) acc[e] = fmaf(av, tv[e], acc[e]);
+            }
           }
         }
       }
-      f32x4 res = u + acc;
+      fvec res = ucur[h] + acc;
       if (!jok) continue;
       if (last) {
-        if (p.bias) res += *reinterpret_cast<const f32x4*>(p.bias + 4 * sub);
+        if (p.bias) res += *reinterpret_cast<const fvec*>(p.bias + VEC * sub);
         if (p.concat) {
-          res[0] = fmaxf(res[0], 0.f); res[1] = fmaxf(res[1], 0.f);
-          res[2] = fmaxf(res[2], 0.f); res[3] = fmaxf(res[3], 0.f);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) res[e] = fmaxf(res[e], 0.f);
         }
-        *reinterpret_cast<f32x4*>(p.Y + ((long long)b * N + j) * p.ldy + head * F + 4 * sub) = res;
+        *reinterpret_cast<fvec*>(p.Y + ((long long)b * N + j) * p.ldy + head * F + VEC * sub) = res;
       } else {
-        *reinterpret_cast<f32x4*>(Rnew + j * F + 4 * sub) = res;
+        *reinterpret_cast<fvec*>(Rnew + j * F + VEC * sub) = res;
       }
     }
     if (last) break;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) ucur[h] = unext[h];
     __syncthreads();
+    if (dbg && t == 0) dbg[3 + (K - 2 - k)] = clock64();
     float* tmp = Rold; Rold = Rnew; Rnew = tmp;
+  }
+  if (dbg) {
+    __syncthreads();
+    if (t == 0) { dbg[6] = clock64(); dbg[7] = wall_clock64(); }
   }
 }
 
@@ -279,13 +501,15 @@ __global__ void pack_kernel(const float* __restrict__ weight, const float* __res
   }
 }
 
+long long* g_gat_dbg = nullptr;   // see magat_gat_set_debug_buffer
+
 bool supported_width(int w) { return w == 16 || w == 32 || w == 64 || w == 128 || w == 256; }
 
 size_t gat_lds_bytes(int N, int G, int F, int nwaves) {
   const int RW = G > F ? G : F;
   const int lda = N | 1;
-  return sizeof(float) * ((size_t)N * RW + (size_t)N * F + (size_t)N * lda + ((N + 3) & ~3)) +
-         sizeof(int) * 128 * (size_t)nwaves;
+  return sizeof(float) * (2 * (size_t)N * RW + (size_t)N * lda + 2 * ((N + 3) & ~3)) +
+         sizeof(int) * 128 * (size_t)nwaves + sizeof(unsigned) * 4 * (size_t)N + 16;
 }
 
 int gat_block_threads(int N) {
@@ -324,6 +548,13 @@ int launch_gat(const GatParams& p, int blocks, int threads, size_t lds, hipStrea
 }
 
 }  // namespace
+
+// Instrumentation only: device buffer of [grid][8] int64 receiving per-workgroup phase timestamps
+// (clock64 at entry / after staging / after scores / after each hop / exit, wall_clock64 at exit).
+extern "C" int magat_gat_set_debug_buffer(long long* dev_buf) {
+  g_gat_dbg = dev_buf;
+  return MAGAT_OK;
+}
 
 extern "C" size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode) {
   if (G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
@@ -380,6 +611,8 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
   float* Ytmp = reinterpret_cast<float*>(static_cast<char*>(workspace) +
                                          magat_align_up((size_t)chunk * N * L.NC * sizeof(float), 256));
   GatParams p;
+  p.dbg = g_gat_dbg;
+  { static int sk = -1; if (sk < 0) { const char* e = getenv("MAGAT_GAT_SKIP"); sk = e ? atoi(e) : 0; } p.skip = sk; }
   p.X = X; p.S = S; p.Z = Z; p.bias = bias; p.A_opt = A_opt;
   p.Y = concat ? Y : Ytmp;
   p.N = N; p.K = K; p.P = P; p.mode = mode; p.concat = concat; p.s_is_f64 = s_is_f64;

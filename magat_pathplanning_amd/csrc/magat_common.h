@@ -21,13 +21,48 @@ static inline int magat_check_launch() {
 
 static inline size_t magat_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// DPP cross-lane moves run at VALU speed (no LDS crossbar round trip like ds_bpermute / __shfl).
+// row_ror:n rotates inside each 16-lane row: four of them all-reduce a row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0x128>(v);
+  v += dpp_mov<0x124>(v);
+  v += dpp_mov<0x122>(v);
+  v += dpp_mov<0x121>(v);
   return v;
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0x128>(v));
+  v = fmaxf(v, dpp_mov<0x124>(v));
+  v = fmaxf(v, dpp_mov<0x122>(v));
+  v = fmaxf(v, dpp_mov<0x121>(v));
   return v;
+}
+// all-reduce over aligned 8-lane groups: xor 1, xor 2 inside quads, then mirror the half row
+__device__ __forceinline__ float oct_sum(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ float oct_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// wave-uniform results (4 rows combined through scalar registers)
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+  return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 }
