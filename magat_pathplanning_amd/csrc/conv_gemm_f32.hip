@@ -16,6 +16,8 @@
 // 16-byte slots (9*r mod 16 is a permutation) -> conflict-free.  Inside a 32-wide K slab the
 // lane halves own k = 0..15 / 16..31, so each lane fetches its 16 A (or B) operands of a row
 // with four ds_read_b128; the MFMA's k-pairing is (s, 16+s), a reordering of the same sum.
+#include <cstdlib>
+
 #include "magat_common.h"
 
 namespace {
@@ -39,14 +41,18 @@ struct ConvGemmParams {
   int pool_w;   // POOL: physical input width (input pixel (iy,ix) = sum of the 2x2 physical pixels)
 };
 
-template <int BM, int BN, int WGM, int WGN, bool POOL>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+// FULL: M % BM == 0, Cout % BN == 0, Cin % 32 == 0, C2 % 32 == 0 -> the loader has no bounds checks and
+// addresses every 16-byte load as (wave-uniform 64-bit base) + (per-thread 32-bit byte offset).
+// NBUF = 2: register-staged double buffer, one barrier per slab.  NBUF = 1: single LDS buffer, two barriers
+// per slab, half the LDS -> one more workgroup per CU.
+template <int BM, int BN, int WGM, int WGN, bool POOL, bool FULL, int NBUF, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int AI = BM / 32, BI = BN / 32;  // float4 loads per thread per slab
-  __shared__ float lds[2 * (BM + BN) * LDS_LD];
+  __shared__ float lds[NBUF * (BM + BN) * LDS_LD];
   float* As = lds;
-  float* Bs = lds + 2 * BM * LDS_LD;
+  float* Bs = lds + NBUF * BM * LDS_LD;
 
   // XCD-aware block -> tile map: the dispatcher places block b on XCD b % 8, so give each XCD
   // whole agent tiles (all pixels x all Cout tiles): the tile's inputs stay in that XCD's L2
@@ -84,27 +90,71 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 ra[AI], rb[BI];
+  unsigned aoff[AI], aoff2[AI], boff[BI];   // FULL path: per-thread byte offsets
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    aoff[i] = (unsigned)(((long long)(m0 + r0 + 32 * i) * p.lda + c4 * 4) * 4);
+    aoff2[i] = (unsigned)(((long long)(m0 + r0 + 32 * i) * p.lda2 + c4 * 4) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < BI; ++i) boff[i] = (unsigned)(((long long)(n0 + r0 + 32 * i) * p.Ktot + c4 * 4) * 4);
+
+  // slab cursor (slabs are visited strictly in order, so the tap / channel-slab position is advanced
+  // incrementally: no integer divisions on the scalar unit between MFMA bursts)
+  int cur_ty = ty0, cur_tx = tx0, cur_ks = 0;
+  bool cur_main = ntaps > 0;
+  auto tap_base = [&](int ty, int tx) -> const float* {
+    if (POOL) return p.in + (long long)(2 * (iy0 + ty) * p.pool_w + 2 * (ix0 + tx)) * p.in_pix_stride;
+    return p.in + (long long)((iy0 + ty) * p.Win + (ix0 + tx)) * p.in_pix_stride;
+  };
+  const float* cur_tap = tap_base(ty0, tx0);
+  const float* const seg2_base =
+      p.in2 + (long long)(oy * p.stride2 * p.W2 + ox * p.stride2) * p.in2_pix_stride;
 
   auto load_slab = [&](int s) {
+    (void)s;
     const float* abase;
     long long lda;
     int bk, kvalid;
-    if (s < ntaps * spt) {
-      const int tap = s / spt, k0 = (s - tap * spt) * BK;
-      const int ty = ty0 + tap / ntx, tx = tx0 + tap % ntx;
-      if (POOL)
-        abase = p.in + (long long)(2 * (iy0 + ty) * p.pool_w + 2 * (ix0 + tx)) * p.in_pix_stride + k0;
-      else
-        abase = p.in + (long long)((iy0 + ty) * p.Win + (ix0 + tx)) * p.in_pix_stride + k0;
+    const bool main_seg = cur_main;
+    const int k0 = cur_ks * BK;
+    if (main_seg) {
+      abase = cur_tap + k0;
       lda = p.lda;
-      bk = (ty * p.kW + tx) * p.Cin + k0;
+      bk = (cur_ty * p.kW + cur_tx) * p.Cin + k0;
       kvalid = p.Cin - k0;
+      if (++cur_ks == spt) {
+        cur_ks = 0;
+        if (++cur_tx == tx1) {
+          cur_tx = tx0;
+          if (++cur_ty == ty1) cur_main = false;
+        }
+        if (cur_main) cur_tap = tap_base(cur_ty, cur_tx);
+      }
     } else {
-      const int k0 = (s - ntaps * spt) * BK;
-      abase = p.in2 + (long long)(oy * p.stride2 * p.W2 + ox * p.stride2) * p.in2_pix_stride + k0;
+      abase = seg2_base + k0;
       lda = p.lda2;
       bk = p.kH * p.kW * p.Cin + k0;
       kvalid = p.C2 - k0;
+      ++cur_ks;
+    }
+    if constexpr (FULL) {
+      const char* ab = reinterpret_cast<const char*>(abase);
+      const char* bb = reinterpret_cast<const char*>(p.wt + bk);
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const char* src = ab + (main_seg ? aoff[i] : aoff2[i]);
+        f32x4 v = *reinterpret_cast<const f32x4*>(src);
+        if (POOL && main_seg) {
+          v += *reinterpret_cast<const f32x4*>(src + 4 * p.in_pix_stride);
+          v += *reinterpret_cast<const f32x4*>(src + 4 * (long long)p.pool_w * p.in_pix_stride);
+          v += *reinterpret_cast<const f32x4*>(src + 4 * (long long)(p.pool_w + 1) * p.in_pix_stride);
+        }
+        ra[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bb + boff[i]);
+      return;
     }
     const bool kok = c4 * 4 < kvalid;
 #pragma unroll
@@ -114,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       if (kok && m < p.M) {
         const float* src = abase + (long long)m * lda + c4 * 4;
         v = *reinterpret_cast<const f32x4*>(src);
-        if (POOL && s < ntaps * spt) {   // 2x2 sum-pool on load (the 1/4 lives in the weights)
+        if (POOL && main_seg) {   // 2x2 sum-pool on load (the 1/4 lives in the weights)
           v += *reinterpret_cast<const f32x4*>(src + p.in_pix_stride);
           v += *reinterpret_cast<const f32x4*>(src + (long long)p.pool_w * p.in_pix_stride);
           v += *reinterpret_cast<const f32x4*>(src + (long long)(p.pool_w + 1) * p.in_pix_stride);
@@ -139,16 +189,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDS_LD + c4 * 4) = rb[i];
   };
 
-  if (nslab > 0) {
-    load_slab(0);
-    store_slab(0);
-  }
-  __syncthreads();
-
   const int frag_off = (lane & 31) * LDS_LD + 16 * (lane >> 5);
-  for (int s = 0; s < nslab; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nslab) load_slab(s + 1);
+  auto compute = [&](int buf) {
     const float* a = As + buf * BM * LDS_LD + (wm * WTM) * LDS_LD + frag_off;
     const float* b = Bs + buf * BN * LDS_LD + (wn * WTN) * LDS_LD + frag_off;
 #pragma unroll
@@ -174,8 +216,30 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q][e], fb[j][q][e], acc[i][j], 0, 0, 0);
     }
-    if (s + 1 < nslab) store_slab(buf ^ 1);
+  };
+
+  if constexpr (NBUF == 2) {
+    if (nslab > 0) {
+      load_slab(0);
+      store_slab(0);
+    }
     __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nslab) load_slab(s + 1);
+      compute(buf);
+      if (s + 1 < nslab) store_slab(buf ^ 1);
+      __syncthreads();
+    }
+  } else {
+    if (nslab > 0) load_slab(0);
+    for (int s = 0; s < nslab; ++s) {
+      if (s > 0) __syncthreads();      // every wave is done reading the previous slab
+      store_slab(0);
+      __syncthreads();
+      if (s + 1 < nslab) load_slab(s + 1);   // in flight under this slab's MFMAs
+      compute(0);
+    }
   }
 
   // epilogue: bias (+ReLU); C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -199,6 +263,31 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   }
 }
 
+int conv_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MAGAT_CONV_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+template <int BM, int BN, int WGM, int WGN, bool POOL, bool FULL>
+int launch2(ConvGemmParams& p, hipStream_t st, long long grid) {
+  const int pid = magat_prof_begin(p.tag, st);
+  // Measured on MI355X (tools/conv_bench.py, 51200 agents): the single-buffer form wins everywhere because it
+  // fits one more workgroup per CU (l3.conv2: 122 -> 129 TF); capping the 128x128 tile at 128 registers
+  // (4 waves/SIMD, 11 spilled VGPRs) adds another 2-3 % (131.6 TF).  MAGAT_CONV_VARIANT=9 keeps the
+  // double-buffered kernel selectable for A/B runs.
+  constexpr int MINW = (BM == 128 && BN == 128) ? 4 : 1;
+  if (conv_variant() != 9)
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, POOL, FULL, 1, MINW>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, POOL, FULL, 2>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
+}
+
 template <int BM, int BN, int WGM, int WGN, bool POOL = false>
 int launch(ConvGemmParams& p, hipStream_t st) {
   p.Mt = (p.M + BM - 1) / BM;
@@ -206,10 +295,10 @@ int launch(ConvGemmParams& p, hipStream_t st) {
   const long long groups = (p.Mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD;
   const long long grid = groups * MAGAT_NUM_XCD * p.npix * p.ntn;
   if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
-  const int pid = magat_prof_begin(p.tag, st);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, POOL>), dim3((unsigned)grid), dim3(256), 0, st, p);
-  magat_prof_end(pid, st);
-  return magat_check_launch();
+  const bool full = p.M % BM == 0 && p.Cout % BN == 0 && p.Cin % BK == 0 && p.C2 % BK == 0 &&
+                    (long long)p.M * (p.lda > p.lda2 ? p.lda : p.lda2) * 4 < 0xffffffffLL &&
+                    (long long)p.Cout * p.Ktot * 4 < 0xffffffffLL;
+  return full ? launch2<BM, BN, WGM, WGN, POOL, true>(p, st, grid) : launch2<BM, BN, WGM, WGN, POOL, false>(p, st, grid);
 }
 
 }  // namespace
