@@ -33,6 +33,8 @@ WORKLOADS = {
     "c2": (1024, 20, 28, 3, 4, 128, "BottomNeck_only", "ResNetLarge_withMLP", True),
     "c1": (64, 10, 20, 2, 1, 128, "BottomNeck_only", "ResNetLarge_withMLP", True),
     "n100b1024": (1024, 100, 50, 3, 4, 128, "BottomNeck_skipConcat", "ResNetLarge_withMLP", True),
+    # config 5 shape in fp32 (large sparse graph -> CSR kernels; the bf16-storage variant is not built yet)
+    "c5": (128, 1000, 160, 2, 4, 128, "BottomNeck_only", "ResNetLarge_withMLP", True),
 }
 
 

@@ -57,6 +57,7 @@ const char* magat_error_string(int code);
  * A_opt [B,P,N,N] attention (aij of graphML.py:4650) or NULL (not materialised).
  * Supported: G,F in {16,32,64,128,256}, 1 <= N <= 128 (dense mask path), K >= 1, P >= 1.
  */
+int magat_gat_dense_supported(int N, int G, int F); /* 1: dense-GSO kernel covers it; 0: use the *_csr_* entry point */
 size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode);
 int magat_gat_pack_weights(const float* weight, const float* weight_bias, const float* mixer,
                            const float* taps, float* packed, int G, int F, int K, int P, int mode,
@@ -73,6 +74,20 @@ int magat_gat_forward_dense_f32(const float* X, const void* S, int s_is_f64, con
                                 const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
                                 size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
                                 int mode, int concat, void* stream);
+
+/* Sparse / large-graph form of the same layer (BASELINE config 5: N = 1000 agents, comm-radius graph).  The GSO is
+ * given as its edge structure: rowptr [B*(N+1)] ABSOLUTE offsets into colidx (rowptr[b*(N+1)+N] == rowptr[(b+1)*(N+1)]),
+ * colidx[e] = j of the e-th edge i -> j, i.e. exactly the entries with |S[b,i,j]| > 1e-9 (graphML.py:1274-1276),
+ * ascending j inside a row.  att_opt [P][nnz] receives the attention values in CSR order (or NULL).
+ * Any N (<= 8190), G == F in {16,32,64,128,256}.  Gathers feature rows from global memory (L2) instead of LDS. */
+size_t magat_gat_csr_workspace_bytes(int B, int N, long long nnz, int G, int F, int K, int P, int mode, int concat);
+int magat_gat_forward_csr_f32(const float* X, const int* rowptr, const int* colidx, long long nnz, const float* packed,
+                              const float* bias, float* Y, int ldy, float* att_opt, void* workspace,
+                              size_t workspace_bytes, int B, int N, int G, int F, int K, int P, int mode, int concat,
+                              void* stream);
+/* dense GSO -> CSR in two steps (the caller prefix-sums the degrees in between): per-row edge counts, then column fill */
+int magat_gso_row_degrees(const void* S, int s_is_f64, int* deg /*B*N*/, int B, int N, void* stream);
+int magat_gso_fill_csr(const void* S, int s_is_f64, const int* rowstart /*B*N*/, int* colidx, int B, int N, void* stream);
 
 /* addGSO's in-place scrub of the caller's tensor (decentralplanner_GAT_bottleneck.py:272-277):
  * scrub_nan: S[isnan(S)] = 0;  gso_mode 1 ('dist_GSO_one'): S[S>0] = 1;  2 ('full_GSO'): S = 1. */

@@ -49,11 +49,16 @@ _I, _P, _Z = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 _SIGNATURES = {
     "magat_abi_version": (ctypes.c_int, []),
     "magat_error_string": (ctypes.c_char_p, [_I]),
+    "magat_gat_dense_supported": (_I, [_I] * 3),
     "magat_gat_packed_floats": (_Z, [_I] * 5),
     "magat_gat_pack_weights": (_I, [_P] * 5 + [_I] * 5 + [_P]),
     "magat_gat_workspace_bytes": (_Z, [_I] * 8),
     "magat_gat_forward_packed_f32": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_forward_dense_f32": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
+    "magat_gat_csr_workspace_bytes": (_Z, [_I, _I, ctypes.c_longlong] + [_I] * 6),
+    "magat_gat_forward_csr_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
+    "magat_gso_row_degrees": (_I, [_P, _I, _P, _I, _I, _P]),
+    "magat_gso_fill_csr": (_I, [_P, _I, _P, _P, _I, _I, _P]),
     "magat_gso_prepare": (_I, [_P, _I, _Z, _I, _I, _P]),
     "magat_conv_gemm_f32": (_I, [ctypes.POINTER(ConvGemmDesc), _P]),
     "magat_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -1,0 +1,525 @@
+// GraphFilterBatchAttentional.forward for LARGE / SPARSE graphs (CSR GSO, any N): BASELINE config 5
+// (1000 agents, comm-radius graph).  Same algebra as gat_f32.hip (reference graphML.py:4636-4671, 1724-1827,
+// 1180-1286, 713-823) with the GSO given as its edge structure:
+//   rowptr [B*(N+1)] absolute offsets into colidx, colidx[e] = j for the e-th edge i -> j of row i
+//   (edge (i,j) present  <=>  |S[b,i,j]| > 1e-9 in the dense form).
+// Neighbour rows no longer fit LDS (N*G*4 = 512 KB at N=1000), so the kernels gather feature rows straight
+// from global memory with 512-byte coalesced row reads that hit the XCD's L2 (all heads of an instance are
+// mapped to one XCD); the per-row work mirrors the dense kernel: 8-lane dot products + DPP reductions for the
+// scores, wave-uniform scalar loops for the hops.
+//   1. csr_transpose_kernel : CSC view (in-edges of every node, sorted by source, with the CSR position of each
+//                             edge) - needed because the reference aggregates over COLUMNS of the row-softmax
+//                             (x @ aij, graphML.py:1757)
+//   2. Z = X @ [W_p | H_pk]^T on fp32 MFMA (conv_gemm_f32.hip)
+//   3. csr_scores_kernel    : e_ij, row softmax -> att[p][e]   (CSR order)
+//   4. csr_hop_kernel (K-1x): T <- U_k + A^T T, last one fused with bias / ReLU / concat store
+#include <cstdlib>
+
+#include "magat_common.h"
+
+namespace {
+
+struct CsrParams {
+  const float* X;      // [B*N, G]
+  const float* Z;      // [B*N, NC]
+  const int* rowptr;   // [B*(N+1)]
+  const int* colidx;   // [nnz]
+  const int* cscptr;   // [B*(N+1)] (workspace)
+  const int* cscsrc;   // [nnz] source node i of each in-edge
+  const int* cscpos;   // [nnz] position of that edge in CSR order
+  float* att;          // [P][nnz] attention values in CSR order
+  const float* Told;   // hop input rows  [B*N*P? see ldt]  (row = (b*N+i), head offset applied by caller)
+  float* Tnew;
+  const float* bias;
+  float* Y;
+  int B, N, K, P, mode, concat;
+  int NC, qoff, uoff, c1off, c2off, ldy;
+  long long nnz;
+  int k;               // hop index (U_k added)
+  int told_ld, told_head_stride;   // addressing of Told rows: Told + (b*N+i)*told_ld + head*told_head_stride
+  int last;
+};
+
+// ---- 1. CSR -> CSC (per instance), deterministic: counting sort + per-column insertion sort by source
+__global__ __launch_bounds__(256) void csr_transpose_kernel(const int* __restrict__ rowptr,
+                                                            const int* __restrict__ colidx, int* __restrict__ cscptr,
+                                                            int* __restrict__ cscsrc, int* __restrict__ cscpos, int N) {
+  extern __shared__ int cnt[];          // [N+1] counts -> offsets, then [N] cursors
+  int* cur = cnt + N + 1;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int* rp = rowptr + (long long)b * (N + 1);
+  const int e0 = rp[0], e1 = rp[N];
+  for (int j = t; j <= N; j += 256) cnt[j] = 0;
+  __syncthreads();
+  for (int e = e0 + t; e < e1; e += 256) atomicAdd(&cnt[colidx[e] + 1], 1);
+  __syncthreads();
+  if (t < 64) {                         // exclusive scan by one wave
+    int carry = 0;
+    for (int base = 0; base <= N; base += 64) {
+      const int j = base + t;
+      int v = j <= N ? cnt[j] : 0, inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o, 64);
+        if (t >= o) inc += u;
+      }
+      if (j <= N) cnt[j] = carry + inc;
+      carry += __shfl(inc, 63, 64);
+    }
+  }
+  __syncthreads();
+  int* cp = cscptr + (long long)b * (N + 1);
+  for (int j = t; j <= N; j += 256) cp[j] = e0 + cnt[j];
+  for (int j = t; j < N; j += 256) cur[j] = cnt[j];
+  __syncthreads();
+  for (int e = e0 + t; e < e1; e += 256) {      // unordered parallel fill ...
+    const int slot = e0 + atomicAdd(&cur[colidx[e]], 1);
+    cscpos[slot] = e;
+  }
+  __syncthreads();
+  // ... then every column is sorted by CSR position (= by source row, rows being contiguous in CSR order), which
+  // makes the in-edge order - and therefore the floating-point summation order of the hops - deterministic
+  for (int j = t; j < N; j += 256) {
+    const int a = e0 + cnt[j], bnd = e0 + cnt[j + 1];
+    for (int x = a + 1; x < bnd; ++x) {
+      const int v = cscpos[x];
+      int y = x - 1;
+      while (y >= a && cscpos[y] > v) {
+        cscpos[y + 1] = cscpos[y];
+        --y;
+      }
+      cscpos[y + 1] = v;
+    }
+    int i = 0;                                   // source row of each in-edge: walk rowptr monotonically
+    for (int x = a; x < bnd; ++x) {
+      const int e = cscpos[x];
+      while (rp[i + 1] <= e) ++i;
+      cscsrc[x] = i;
+    }
+  }
+}
+
+// ---- 3. scores + row softmax.  8 lanes per row, 32 rows per 256-thread block.
+template <int G>
+__global__ __launch_bounds__(256) void csr_scores_kernel(const CsrParams p) {
+  constexpr int GC = G / 4, CP8 = GC / 8 > 0 ? GC / 8 : 1, LE = GC < 8 ? GC : 8;
+  const int N = p.N;
+  const int rows_per_block = 256 / LE;
+  const int tiles = (N + rows_per_block - 1) / rows_per_block;
+  // block -> (instance, head, row tile): heads and tiles of an instance stay on one XCD
+  const int bid = blockIdx.x, xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
+  const int per = p.P * tiles;
+  const int b = xcd + MAGAT_NUM_XCD * (slot / per);
+  if (b >= p.B) return;
+  const int head = (slot % per) / tiles, tile = slot % tiles;
+  const int t = threadIdx.x, es = t % LE, i = tile * rows_per_block + t / LE;
+  if (i >= N) return;
+  const int* rp = p.rowptr + (long long)b * (N + 1);
+  const int e0 = rp[i], e1 = rp[i + 1];
+  if (e1 <= e0) return;
+  const float* Zb = p.Z + (long long)b * N * p.NC;
+  float* att = p.att + (long long)head * p.nnz;
+  // Row softmax without cross-lane memory traffic: the raw scores are written by one lane and later rewritten
+  // by that same lane (program order makes its own stores visible to it); max and sum are carried online in
+  // registers, identically in every lane of the group.
+  float mx = -__builtin_inff(), sum = 0.f;
+  auto online = [&](float d) {
+    const float m2 = fmaxf(mx, d);
+    sum = sum * __expf(mx - m2) + __expf(d - m2);
+    mx = m2;
+  };
+  if (p.mode == MAGAT_MODE_KEYQUERY) {
+    const float* xr = p.X + ((long long)b * N + i) * G;
+    f32x4 xi[CP8];
+#pragma unroll
+    for (int q = 0; q < CP8; ++q) xi[q] = *reinterpret_cast<const f32x4*>(xr + 4 * (es + LE * q));
+    const int qo = p.qoff + head * G;
+    for (int e = e0; e < e1; e += 2) {
+      const int j0 = p.colidx[e];
+      const bool two = e + 1 < e1;
+      const int j1 = two ? p.colidx[e + 1] : j0;
+      const float* q0 = Zb + (long long)j0 * p.NC + qo;
+      const float* q1 = Zb + (long long)j1 * p.NC + qo;
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < CP8; ++q) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(q0 + 4 * (es + LE * q));
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(q1 + 4 * (es + LE * q));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          d0 = fmaf(xi[q][c], a0[c], d0);
+          d1 = fmaf(xi[q][c], a1[c], d1);
+        }
+      }
+      if (LE == 8) {
+        d0 = oct_sum(d0);
+        d1 = oct_sum(d1);
+      } else {
+#pragma unroll
+        for (int o = LE / 2; o > 0; o >>= 1) {
+          d0 += __shfl_xor(d0, o, 64);
+          d1 += __shfl_xor(d1, o, 64);
+        }
+      }
+      if (es == 0) {
+        att[e] = d0;
+        if (two) att[e + 1] = d1;
+      }
+      online(d0);
+      if (two) online(d1);
+    }
+    if (es == 0) {
+      const float inv = 1.f / sum;
+      for (int e = e0; e < e1; ++e) att[e] = __expf(att[e] - mx) * inv;
+    }
+  } else {
+    const float c2 = Zb[(long long)i * p.NC + p.c2off + head];
+    for (int e = e0 + es; e < e1; e += LE) {
+      const float v = Zb[(long long)p.colidx[e] * p.NC + p.c1off + head] + c2;
+      const float l = v > 0.f ? v : 0.2f * v;
+      att[e] = l;
+      online(l);
+    }
+    // combine the lanes' (max, sum) pairs
+    float gm = mx;
+    if (LE == 8) gm = oct_max(gm);
+    else
+#pragma unroll
+      for (int o = LE / 2; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
+    float gs = sum > 0.f ? sum * __expf(mx - gm) : 0.f;
+    if (LE == 8) gs = oct_sum(gs);
+    else
+#pragma unroll
+      for (int o = LE / 2; o > 0; o >>= 1) gs += __shfl_xor(gs, o, 64);
+    const float inv = 1.f / gs;
+    for (int e = e0 + es; e < e1; e += LE) att[e] = __expf(att[e] - gm) * inv;
+  }
+}
+
+// ---- 4. one Horner hop: out[j] = U_k[j] + sum_{in-edges (i -> j)} att[pos] * Told[i]; wave per output row
+template <int F>
+__global__ __launch_bounds__(256) void csr_hop_kernel(const CsrParams p) {
+  constexpr int VEC = F >= 64 ? F / 64 : 1;
+  constexpr int LANES = F >= 64 ? 64 : F;
+  typedef float fvec __attribute__((ext_vector_type(VEC)));
+  const int N = p.N;
+  const int tiles = (N + 3) / 4;         // 4 rows (waves) per block
+  const int bid = blockIdx.x, xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
+  const int per = p.P * tiles;
+  const int b = xcd + MAGAT_NUM_XCD * (slot / per);
+  if (b >= p.B) return;
+  const int head = (slot % per) / tiles, tile = slot % tiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = tile * 4 + wave;
+  if (j >= N || lane >= LANES) return;
+  const int* cp = p.cscptr + (long long)b * (N + 1);
+  const int s0 = cp[j], s1 = cp[j + 1];
+  const float* att = p.att + (long long)head * p.nnz;
+  const float* Tb = p.Told + (long long)b * N * p.told_ld + (long long)head * p.told_head_stride + VEC * lane;
+  const float* Zr = p.Z + ((long long)b * N + j) * p.NC + p.uoff + (head * p.K + p.k) * F + VEC * lane;
+  fvec acc = *reinterpret_cast<const fvec*>(Zr);
+  for (int s = s0; s < s1; s += 2) {
+    const int i0 = p.cscsrc[s];
+    const float a0 = att[p.cscpos[s]];
+    const fvec t0 = *reinterpret_cast<const fvec*>(Tb + (long long)i0 * p.told_ld);
+    if (s + 1 < s1) {
+      const int i1 = p.cscsrc[s + 1];
+      const float a1 = att[p.cscpos[s + 1]];
+      const fvec t1 = *reinterpret_cast<const fvec*>(Tb + (long long)i1 * p.told_ld);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) acc[c] = fmaf(a1, t1[c], fmaf(a0, t0[c], acc[c]));
+    } else {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) acc[c] = fmaf(a0, t0[c], acc[c]);
+    }
+  }
+  if (p.last) {
+    if (p.bias) acc += *reinterpret_cast<const fvec*>(p.bias + VEC * lane);
+    if (p.concat) {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) acc[c] = fmaxf(acc[c], 0.f);
+    }
+    *reinterpret_cast<fvec*>(p.Y + ((long long)b * N + j) * p.ldy + head * F + VEC * lane) = acc;
+  } else {
+    *reinterpret_cast<fvec*>(p.Tnew + (((long long)b * N + j) * p.P + head) * F + VEC * lane) = acc;
+  }
+}
+
+// K == 1: Y = U_0 + bias (no graph work)
+template <int F>
+__global__ void csr_k1_kernel(const CsrParams p) {
+  const long long total = (long long)p.B * p.N * p.P * (F / 4);
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % (F / 4));
+    const long long r = idx / (F / 4);
+    const int head = (int)(r % p.P);
+    const long long m = r / p.P;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.Z + m * p.NC + p.uoff + head * F + 4 * c);
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + 4 * c);
+    if (p.concat) {
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(p.Y + m * p.ldy + head * F + 4 * c) = v;
+  }
+}
+
+struct Layout {
+  int NC, qoff, uoff, c1off, c2off;
+};
+Layout layout(int G, int F, int K, int P, int mode) {   // must match pack_layout() in gat_f32.hip
+  Layout L;
+  if (mode == MAGAT_MODE_KEYQUERY) {
+    L.qoff = 0; L.uoff = P * G; L.c1off = L.c2off = 0; L.NC = P * G + P * K * F;
+  } else {
+    L.qoff = 0; L.uoff = 0; L.c1off = P * K * F; L.c2off = L.c1off + P; L.NC = (L.c2off + P + 3) & ~3;
+  }
+  return L;
+}
+
+struct WsLayout {
+  size_t z, cscptr, cscsrc, cscpos, att, t0, t1, ytmp, total;
+};
+WsLayout ws_layout(int B, int N, long long nnz, int G, int F, int K, int P, int mode, int concat) {
+  const Layout L = layout(G, F, K, P, mode);
+  WsLayout w;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o += magat_align_up(bytes, 256); return at; };
+  w.z = take((size_t)B * N * L.NC * sizeof(float));
+  w.cscptr = take((size_t)B * (N + 1) * sizeof(int));
+  w.cscsrc = take((size_t)nnz * sizeof(int));
+  w.cscpos = take((size_t)nnz * sizeof(int));
+  w.att = take((size_t)P * nnz * sizeof(float));
+  const size_t tb = K > 2 ? (size_t)B * N * P * F * sizeof(float) : 0;
+  w.t0 = take(tb);
+  w.t1 = take(K > 3 ? tb : 0);
+  w.ytmp = take(concat ? 0 : (size_t)B * N * P * F * sizeof(float));
+  w.total = o;
+  return w;
+}
+
+template <int G>
+int run_scores(const CsrParams& p, hipStream_t st) {
+  constexpr int LE = (G / 4) < 8 ? (G / 4) : 8;
+  const int rows = 256 / LE, tiles = (p.N + rows - 1) / rows;
+  const long long grid = (long long)((p.B + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD) * MAGAT_NUM_XCD * p.P * tiles;
+  if (grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
+  const int pid = magat_prof_begin(MAGAT_TAG_GAT_GRAPH, st);
+  hipLaunchKernelGGL((csr_scores_kernel<G>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
+}
+template <int F>
+int run_hop(const CsrParams& p, hipStream_t st) {
+  const int tiles = (p.N + 3) / 4;
+  const long long grid = (long long)((p.B + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD) * MAGAT_NUM_XCD * p.P * tiles;
+  if (grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
+  const int pid = magat_prof_begin(MAGAT_TAG_GAT_GRAPH, st);
+  hipLaunchKernelGGL((csr_hop_kernel<F>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
+}
+template <int F>
+int run_k1(const CsrParams& p, hipStream_t st) {
+  hipLaunchKernelGGL((csr_k1_kernel<F>), dim3(2048), dim3(256), 0, st, p);
+  return magat_check_launch();
+}
+
+__global__ void head_mean_relu_csr_kernel(const float* __restrict__ ytmp, float* __restrict__ y, long long M, int P,
+                                          int F, int ldy) {
+  const int FC = F / 4;
+  const long long total = M * FC;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long m = idx / FC;
+    const int c = (int)(idx - m * FC);
+    f32x4 s = *reinterpret_cast<const f32x4*>(ytmp + m * (long long)P * F + 4 * c);
+    for (int q = 1; q < P; ++q) s += *reinterpret_cast<const f32x4*>(ytmp + (m * P + q) * (long long)F + 4 * c);
+    const float fp = (float)P;
+    f32x4 r = {fmaxf(s[0] / fp, 0.f), fmaxf(s[1] / fp, 0.f), fmaxf(s[2] / fp, 0.f), fmaxf(s[3] / fp, 0.f)};
+    *reinterpret_cast<f32x4*>(y + m * ldy + 4 * c) = r;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t magat_gat_csr_workspace_bytes(int B, int N, long long nnz, int G, int F, int K, int P, int mode,
+                                                int concat) {
+  if (B <= 0 || N <= 0 || nnz < 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
+  return ws_layout(B, N, nnz, G, F, K, P, mode, concat).total;
+}
+
+extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, const int* colidx, long long nnz,
+                                         const float* packed, const float* bias, float* Y, int ldy, float* att_opt,
+                                         void* workspace, size_t workspace_bytes, int B, int N, int G, int F, int K,
+                                         int P, int mode, int concat, void* stream) {
+  if (!X || !rowptr || !packed || !Y || (nnz > 0 && !colidx)) return MAGAT_ERR_NULL;
+  if (B <= 0 || N <= 0 || nnz < 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
+  if (mode != MAGAT_MODE_KEYQUERY && mode != MAGAT_MODE_GAT_MODIFIED) return MAGAT_ERR_UNSUPPORTED;
+  if (G != F || !(G == 16 || G == 32 || G == 64 || G == 128 || G == 256)) return MAGAT_ERR_UNSUPPORTED;
+  if ((size_t)(2 * N + 2) * sizeof(int) > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;   // transpose LDS (N <= 8190)
+  const int width = concat ? P * F : F;
+  if (ldy < width || (ldy & 3)) return MAGAT_ERR_BAD_SHAPE;
+  const WsLayout w = ws_layout(B, N, nnz, G, F, K, P, mode, concat);
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < w.total)
+    return MAGAT_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* ws = static_cast<char*>(workspace);
+  const Layout L = layout(G, F, K, P, mode);
+  float* Z = reinterpret_cast<float*>(ws + w.z);
+  int* cscptr = reinterpret_cast<int*>(ws + w.cscptr);
+  int* cscsrc = reinterpret_cast<int*>(ws + w.cscsrc);
+  int* cscpos = reinterpret_cast<int*>(ws + w.cscpos);
+  float* att = att_opt ? att_opt : reinterpret_cast<float*>(ws + w.att);
+  float* tbuf[2] = {reinterpret_cast<float*>(ws + w.t0), reinterpret_cast<float*>(ws + w.t1)};
+  float* Ytmp = reinterpret_cast<float*>(ws + w.ytmp);
+
+  int rc = magat_linear_tagged_f32(X, G, packed, packed + (size_t)L.NC * G, Z, L.NC, B * N, L.NC, G, 0,
+                                   MAGAT_TAG_GAT_MAPS, stream);
+  if (rc != MAGAT_OK) return rc;
+
+  CsrParams p = {};
+  p.X = X; p.Z = Z; p.rowptr = rowptr; p.colidx = colidx; p.cscptr = cscptr; p.cscsrc = cscsrc; p.cscpos = cscpos;
+  p.att = att; p.bias = bias; p.Y = concat ? Y : Ytmp; p.ldy = concat ? ldy : P * F;
+  p.B = B; p.N = N; p.K = K; p.P = P; p.mode = mode; p.concat = concat; p.nnz = nnz;
+  p.NC = L.NC; p.qoff = L.qoff; p.uoff = L.uoff; p.c1off = L.c1off; p.c2off = L.c2off;
+
+  if (K == 1 && !att_opt) {
+    switch (F) {
+      case 16: rc = run_k1<16>(p, st); break;
+      case 32: rc = run_k1<32>(p, st); break;
+      case 64: rc = run_k1<64>(p, st); break;
+      case 128: rc = run_k1<128>(p, st); break;
+      default: rc = run_k1<256>(p, st);
+    }
+    if (rc != MAGAT_OK) return rc;
+  } else {
+    if (K > 1) {
+      const int pid = magat_prof_begin(MAGAT_TAG_GAT_PACK, st);
+      hipLaunchKernelGGL(csr_transpose_kernel, dim3(B), dim3(256), (size_t)(2 * N + 2) * sizeof(int), st, rowptr, colidx,
+                         cscptr, cscsrc, cscpos, N);
+      magat_prof_end(pid, st);
+      if ((rc = magat_check_launch()) != MAGAT_OK) return rc;
+    }
+    switch (G) {
+      case 16: rc = run_scores<16>(p, st); break;
+      case 32: rc = run_scores<32>(p, st); break;
+      case 64: rc = run_scores<64>(p, st); break;
+      case 128: rc = run_scores<128>(p, st); break;
+      default: rc = run_scores<256>(p, st);
+    }
+    if (rc != MAGAT_OK) return rc;
+    if (K == 1) {
+      switch (F) {
+        case 16: rc = run_k1<16>(p, st); break;
+        case 32: rc = run_k1<32>(p, st); break;
+        case 64: rc = run_k1<64>(p, st); break;
+        case 128: rc = run_k1<128>(p, st); break;
+        default: rc = run_k1<256>(p, st);
+      }
+      if (rc != MAGAT_OK) return rc;
+    }
+    // hops k = K-2 .. 0; the first reads U_{K-1} straight out of Z
+    for (int k = K - 2, h = 0; k >= 0; --k, ++h) {
+      p.k = k;
+      p.last = k == 0;
+      if (h == 0) {
+        p.Told = Z + L.uoff + (K - 1) * F;   // row (b*N+i): + i*NC, head: + head*K*F
+        p.told_ld = L.NC;
+        p.told_head_stride = K * F;
+      } else {
+        p.Told = tbuf[(h - 1) & 1];
+        p.told_ld = P * F;
+        p.told_head_stride = F;
+      }
+      p.Tnew = tbuf[h & 1];
+      switch (F) {
+        case 16: rc = run_hop<16>(p, st); break;
+        case 32: rc = run_hop<32>(p, st); break;
+        case 64: rc = run_hop<64>(p, st); break;
+        case 128: rc = run_hop<128>(p, st); break;
+        default: rc = run_hop<256>(p, st);
+      }
+      if (rc != MAGAT_OK) return rc;
+    }
+  }
+  if (!concat) {
+    const long long M = (long long)B * N;
+    long long blocks = (M * (F / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    const int pid = magat_prof_begin(MAGAT_TAG_HEAD_MEAN, st);
+    hipLaunchKernelGGL(head_mean_relu_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Ytmp, Y, M, P, F, ldy);
+    magat_prof_end(pid, st);
+    return magat_check_launch();
+  }
+  return MAGAT_OK;
+}
+
+// Dense GSO -> CSR edge structure (|S| > 1e-9), two calls: count (rowptr via caller-side prefix) is avoided by
+// writing per-row degrees first.  deg [B*N] ints.
+template <typename T>
+__global__ void gso_row_degree_kernel(const T* __restrict__ S, int* __restrict__ deg, int N, long long rows) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* r = S + row * N;
+  int c = 0;
+  for (int j = lane; j < N; j += 64) {
+    const T v = r[j];
+    c += ((v < 0 ? -v : v) > (T)1e-9) ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if (lane == 0) deg[row] = c;
+}
+template <typename T>
+__global__ void gso_fill_csr_kernel(const T* __restrict__ S, const int* __restrict__ rowstart,
+                                    int* __restrict__ colidx, int N, long long rows) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* r = S + row * N;
+  int base = rowstart[row];
+  for (int j0 = 0; j0 < N; j0 += 64) {
+    const int j = j0 + lane;
+    bool f = false;
+    if (j < N) {
+      const T v = r[j];
+      f = (v < 0 ? -v : v) > (T)1e-9;
+    }
+    const unsigned long long m = __ballot(f);
+    if (f) colidx[base + __popcll(m & ((1ull << lane) - 1ull))] = j;
+    base += __popcll(m);
+  }
+}
+
+extern "C" int magat_gso_row_degrees(const void* S, int s_is_f64, int* deg, int B, int N, void* stream) {
+  if (!S || !deg) return MAGAT_ERR_NULL;
+  if (B <= 0 || N <= 0) return MAGAT_ERR_BAD_SHAPE;
+  const long long rows = (long long)B * N;
+  const unsigned blocks = (unsigned)((rows + 3) / 4);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (s_is_f64)
+    hipLaunchKernelGGL(gso_row_degree_kernel<double>, dim3(blocks), dim3(256), 0, st, static_cast<const double*>(S),
+                       deg, N, rows);
+  else
+    hipLaunchKernelGGL(gso_row_degree_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(S), deg,
+                       N, rows);
+  return magat_check_launch();
+}
+
+extern "C" int magat_gso_fill_csr(const void* S, int s_is_f64, const int* rowstart, int* colidx, int B, int N,
+                                  void* stream) {
+  if (!S || !rowstart || !colidx) return MAGAT_ERR_NULL;
+  if (B <= 0 || N <= 0) return MAGAT_ERR_BAD_SHAPE;
+  const long long rows = (long long)B * N;
+  const unsigned blocks = (unsigned)((rows + 3) / 4);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (s_is_f64)
+    hipLaunchKernelGGL(gso_fill_csr_kernel<double>, dim3(blocks), dim3(256), 0, st, static_cast<const double*>(S),
+                       rowstart, colidx, N, rows);
+  else
+    hipLaunchKernelGGL(gso_fill_csr_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(S),
+                       rowstart, colidx, N, rows);
+  return magat_check_launch();
+}

@@ -578,6 +578,12 @@ extern "C" int magat_gat_pack_weights(const float* weight, const float* weight_b
   return magat_check_launch();
 }
 
+// 1 when the LDS-resident dense-GSO kernel covers this shape, 0 when the caller must use the CSR entry point
+extern "C" int magat_gat_dense_supported(int N, int G, int F) {
+  if (N <= 0 || N > 128 || G != F || !supported_width(G)) return 0;
+  return gat_lds_bytes(N, G, F, gat_block_threads(N) / 64) <= 160 * 1024 ? 1 : 0;
+}
+
 extern "C" size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, int P, int mode, int concat) {
   if (B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
   const PackLayout L = pack_layout(G, F, K, P, mode);

@@ -31,6 +31,88 @@ def _param_key(*tensors):
     return tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
 
 
+def _packed_weights(layer, dev, stream, G, F, K, P, mode):
+    lib = nat.lib()
+    sc = layer._scratch
+    key = _param_key(layer.weight, layer.weight_bias, layer.mixer, layer.filterWeight) + (str(dev),)
+    if sc.packed is None or sc.packed_key != key:
+        nfl = lib.magat_gat_packed_floats(G, F, K, P, mode)
+        if nfl == 0:
+            raise nat.MagatNativeError("bad GAT shape G=%d F=%d K=%d P=%d" % (G, F, K, P))
+        sc.packed = torch.empty(nfl, dtype=torch.float32, device=dev)
+        w = [t.detach().to(dev, torch.float32).contiguous()
+             for t in (layer.weight, layer.weight_bias, layer.mixer, layer.filterWeight)]
+        nat.check(lib.magat_gat_pack_weights(nat.ptr(w[0]), nat.ptr(w[1]), nat.ptr(w[2]), nat.ptr(w[3]),
+                                             nat.ptr(sc.packed), G, F, K, P, mode, stream), "magat_gat_pack_weights")
+        sc.packed_key = key
+    return sc.packed
+
+
+def dense_gso_to_csr(S3):
+    """(B,N,N) device GSO -> (rowptr int32 [B*(N+1)] absolute offsets, colidx int32 [nnz], nnz) with the
+    reference's edge rule |S| > 1e-9 (graphML.py:1274-1276).  Two HIP kernels + one torch cumsum."""
+    lib = nat.lib()
+    B, N, _ = S3.shape
+    dev = S3.device
+    f64 = 1 if S3.dtype == torch.float64 else 0
+    with torch.cuda.device(dev):
+        stream = nat.current_stream(dev)
+        deg = torch.empty(B * N, dtype=torch.int32, device=dev)
+        nat.check(lib.magat_gso_row_degrees(nat.ptr(S3), f64, nat.ptr(deg), B, N, stream), "magat_gso_row_degrees")
+        ends = torch.cumsum(deg, 0, dtype=torch.int32)
+        starts = (ends - deg).contiguous()
+        nnz = int(ends[-1].item())
+        colidx = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+        nat.check(lib.magat_gso_fill_csr(nat.ptr(S3), f64, nat.ptr(starts), nat.ptr(colidx), B, N, stream),
+                  "magat_gso_fill_csr")
+        rowptr = torch.empty(B, N + 1, dtype=torch.int32, device=dev)
+        rowptr[:, :N] = starts.view(B, N)
+        rowptr[:, N] = ends.view(B, N)[:, N - 1]
+    return rowptr.reshape(-1).contiguous(), colidx, nnz
+
+
+def gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=None, want_attention=False):
+    """CSR / large-graph form (any N).  X (B,N,G) device rows; rowptr int32 [B*(N+1)] absolute offsets; colidx int32.
+    Returns (out (B*N, ld), att (P, nnz) CSR-ordered attention or None)."""
+    if not X.is_cuda:
+        raise nat.MagatNativeError("the HIP GAT path needs device tensors; got %s (no CPU fallback)" % X.device)
+    lib = nat.lib()
+    B, N, G = X.shape
+    F, K, P = layer.F, layer.K, layer.P
+    mode = _MODES[layer.attentionMode]
+    concat = 1 if layer.concatenate else 0
+    width = P * F if concat else F
+    X = X.contiguous().float()
+    dev = X.device
+    sc = layer._scratch
+    with torch.cuda.device(dev):
+        stream = nat.current_stream(dev)
+        packed = _packed_weights(layer, dev, stream, G, F, K, P, mode)
+        need = lib.magat_gat_csr_workspace_bytes(B, N, nnz, G, F, K, P, mode, concat)
+        if sc.workspace is None or sc.workspace.numel() < need or sc.workspace.device != dev:
+            sc.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        if out is None:
+            out = torch.empty(B * N, width, dtype=torch.float32, device=dev)
+        att = torch.empty(P, max(nnz, 1), dtype=torch.float32, device=dev) if want_attention else None
+        bias = None if layer.bias is None else layer.bias.detach().to(dev, torch.float32).reshape(-1).contiguous()
+        nat.check(lib.magat_gat_forward_csr_f32(
+            nat.ptr(X), nat.ptr(rowptr), nat.ptr(colidx), nnz, nat.ptr(packed), nat.ptr(bias), nat.ptr(out),
+            out.stride(0), nat.ptr(att), nat.ptr(sc.workspace), sc.workspace.numel(), B, N, G, F, K, P, mode, concat,
+            stream), "magat_gat_forward_csr_f32")
+    return out, att
+
+
+def _csr_attention_to_dense(att, rowptr, colidx, nnz, B, N, P):
+    """(P,nnz) CSR-ordered attention -> (B,P,1,N,N) dense, only for returnAttentionGSO() callers."""
+    dev = att.device
+    rp = rowptr.view(B, N + 1).long()
+    deg = (rp[:, 1:] - rp[:, :-1]).reshape(-1)
+    rows = torch.repeat_interleave(torch.arange(B * N, device=dev), deg)
+    dense = torch.zeros(P, B * N, N, dtype=torch.float32, device=dev)
+    dense[:, rows, colidx[:nnz].long()] = att[:, :nnz]
+    return dense.view(P, B, N, N).permute(1, 0, 2, 3).unsqueeze(2).contiguous()
+
+
 def gat_forward_rows(X, S, layer, out=None, want_attention=False):
     """Kernel-facing form.  X (B,N,G) f32 contiguous device rows; S (B,N,N) or (B,1,N,N) f32|f64;
     out: optional (B*N, ld) float32 view whose first P*F|F columns receive the result.
@@ -55,19 +137,15 @@ def gat_forward_rows(X, S, layer, out=None, want_attention=False):
         S3 = S3.to(X.device)
     dev = X.device
     sc = layer._scratch
-    key = _param_key(layer.weight, layer.weight_bias, layer.mixer, layer.filterWeight) + (str(dev),)
+    if not lib.magat_gat_dense_supported(N, G, F):
+        # graph too large for the LDS-resident kernel: same layer through the CSR kernels
+        rowptr, colidx, nnz = dense_gso_to_csr(S3)
+        out, att = gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=out, want_attention=want_attention)
+        aij = _csr_attention_to_dense(att, rowptr, colidx, nnz, B, N, P) if want_attention else None
+        return out, aij
     with torch.cuda.device(dev):
         stream = nat.current_stream(dev)
-        if sc.packed is None or sc.packed_key != key:
-            nfl = lib.magat_gat_packed_floats(G, F, K, P, mode)
-            if nfl == 0:
-                raise nat.MagatNativeError("bad GAT shape G=%d F=%d K=%d P=%d" % (G, F, K, P))
-            sc.packed = torch.empty(nfl, dtype=torch.float32, device=dev)
-            w = [t.detach().to(dev, torch.float32).contiguous()
-                 for t in (layer.weight, layer.weight_bias, layer.mixer, layer.filterWeight)]
-            nat.check(lib.magat_gat_pack_weights(nat.ptr(w[0]), nat.ptr(w[1]), nat.ptr(w[2]), nat.ptr(w[3]),
-                                                 nat.ptr(sc.packed), G, F, K, P, mode, stream), "magat_gat_pack_weights")
-            sc.packed_key = key
+        _packed_weights(layer, dev, stream, G, F, K, P, mode)
         need = lib.magat_gat_workspace_bytes(B, N, G, F, K, P, mode, concat)
         if sc.workspace is None or sc.workspace.numel() < need or sc.workspace.device != dev:
             sc.workspace = torch.empty(need, dtype=torch.uint8, device=dev)

@@ -156,3 +156,55 @@ def test_errors_are_loud(gpu_device):
     assert rc == -2
     with pytest.raises(nat.MagatNativeError):
         nat.check(rc, "unsupported width")
+
+
+@pytest.mark.parametrize("mode,concat,N,G,K,P", [("KeyQuery", True, 150, 128, 3, 4), ("KeyQuery", False, 200, 64, 2, 2),
+                                                ("GAT_modified", True, 130, 32, 4, 3), ("KeyQuery", True, 40, 128, 3, 4),
+                                                ("GAT_modified", False, 300, 128, 2, 4), ("KeyQuery", True, 64, 16, 1, 2)])
+def test_gat_csr_path_vs_oracle(gpu_device, mode, concat, N, G, K, P):
+    """Large-graph (CSR) kernels against the pinned dense oracle; N <= 128 cases force the CSR entry point."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from magat_pathplanning_amd.graphml import dense_gso_to_csr, gat_forward_rows_csr, _csr_attention_to_dense
+    from magat_pathplanning_amd.synthetic import comm_gso
+    from oracle import magat_oracle as orc
+    B = 3
+    g = torch.Generator().manual_seed(N + G)
+    layer = GraphFilterBatchAttentional(G, G, K, P, concatenate=concat, attentionMode=mode)
+    with torch.no_grad():
+        layer.weight_bias.uniform_(-0.3, 0.3, generator=g)
+    x = torch.randn(B, G, N, generator=g) * 0.7
+    S = comm_gso(B, N, int(8 * N ** 0.5), seed=N, dtype=torch.float64)
+    S[0, 5, :] = 0                     # a row without edges
+    S[0, :, 7] = 0                     # a node nobody listens to
+    S[1, 3, 9], S[1, 9, 3] = 0.5, 0.0  # asymmetric pair
+    params = {k: v.detach() for k, v in layer.state_dict().items()}
+    y_ref, a_ref = orc.gat_layer_forward(x, S.unsqueeze(1), params, mode, concat)
+    layer = layer.to(gpu_device).eval()
+    X = x.permute(0, 2, 1).contiguous().to(gpu_device)
+    rowptr, colidx, nnz = dense_gso_to_csr(S.to(gpu_device))
+    assert nnz == int((S.abs() > 1e-9).sum())
+    with torch.no_grad():
+        out, att = gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, want_attention=True)
+    torch.cuda.synchronize()
+    y = out.reshape(B, N, -1).permute(0, 2, 1).cpu()
+    np.testing.assert_allclose(y.numpy(), y_ref.numpy(), rtol=0, atol=2e-5)
+    if K > 1:
+        dense = _csr_attention_to_dense(att, rowptr, colidx, nnz, B, N, P).cpu()
+        np.testing.assert_allclose(dense.numpy(), a_ref.numpy(), rtol=0, atol=3e-6)
+
+
+def test_gat_module_switches_to_csr_for_large_graphs(gpu_device):
+    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from magat_pathplanning_amd.synthetic import comm_gso
+    from oracle import magat_oracle as orc
+    B, N, G = 2, 1000, 128
+    layer = GraphFilterBatchAttentional(G, G, 2, 4, attentionMode="KeyQuery")
+    x = torch.randn(B, G, N, generator=torch.Generator().manual_seed(1)) * 0.5
+    S = comm_gso(B, N, 160, seed=2)
+    y_ref, _ = orc.gat_layer_forward(x, S.unsqueeze(1), {k: v.detach() for k, v in layer.state_dict().items()},
+                                     "KeyQuery", True)
+    layer = layer.to(gpu_device).eval()
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    with torch.no_grad():
+        y = layer(x.to(gpu_device))
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), rtol=0, atol=2e-5)
