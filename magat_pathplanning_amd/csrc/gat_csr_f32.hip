@@ -43,7 +43,7 @@ struct CsrParams {
 // ---- 1. CSR -> CSC (per instance), deterministic: counting sort + per-column insertion sort by source
 __global__ __launch_bounds__(256) void csr_transpose_kernel(const int* __restrict__ rowptr,
                                                             const int* __restrict__ colidx, int* __restrict__ cscptr,
-                                                            int* __restrict__ cscsrc, int* __restrict__ cscpos, int N) {
+                                                            int* __restrict__ csctmp, int N) {
   extern __shared__ int cnt[];          // [N+1] counts -> offsets, then [N] cursors
   int* cur = cnt + N + 1;
   const int b = blockIdx.x, t = threadIdx.x;
@@ -72,30 +72,36 @@ __global__ __launch_bounds__(256) void csr_transpose_kernel(const int* __restric
   for (int j = t; j <= N; j += 256) cp[j] = e0 + cnt[j];
   for (int j = t; j < N; j += 256) cur[j] = cnt[j];
   __syncthreads();
-  for (int e = e0 + t; e < e1; e += 256) {      // unordered parallel fill ...
+  for (int e = e0 + t; e < e1; e += 256) {      // unordered parallel fill (slot order depends on timing) ...
     const int slot = e0 + atomicAdd(&cur[colidx[e]], 1);
-    cscpos[slot] = e;
+    csctmp[slot] = e;
   }
-  __syncthreads();
-  // ... then every column is sorted by CSR position (= by source row, rows being contiguous in CSR order), which
-  // makes the in-edge order - and therefore the floating-point summation order of the hops - deterministic
-  for (int j = t; j < N; j += 256) {
-    const int a = e0 + cnt[j], bnd = e0 + cnt[j + 1];
-    for (int x = a + 1; x < bnd; ++x) {
-      const int v = cscpos[x];
-      int y = x - 1;
-      while (y >= a && cscpos[y] > v) {
-        cscpos[y + 1] = cscpos[y];
-        --y;
-      }
-      cscpos[y + 1] = v;
+}
+
+// ... which csr_sort_columns_kernel turns into a deterministic order: one wave per column rank-sorts the column's
+// CSR positions (= source rows ascending) and looks the source row of each in-edge up by bisection in rowptr.
+__global__ __launch_bounds__(256) void csr_sort_columns_kernel(const int* __restrict__ rowptr,
+                                                               const int* __restrict__ cscptr,
+                                                               const int* __restrict__ csctmp, int* __restrict__ cscsrc,
+                                                               int* __restrict__ cscpos, int N, long long cols) {
+  const int lane = threadIdx.x & 63;
+  const long long col = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (col >= cols) return;
+  const int b = (int)(col / N), j = (int)(col % N);
+  const int* rp = rowptr + (long long)b * (N + 1);
+  const int* cp = cscptr + (long long)b * (N + 1);
+  const int a = cp[j], d = cp[j + 1] - a;
+  for (int t = lane; t < d; t += 64) {
+    const int v = csctmp[a + t];
+    int rank = 0;
+    for (int u = 0; u < d; ++u) rank += csctmp[a + u] < v ? 1 : 0;
+    int lo = 0, hi = N - 1;                      // last row i with rp[i] <= v
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (rp[mid] <= v) lo = mid; else hi = mid - 1;
     }
-    int i = 0;                                   // source row of each in-edge: walk rowptr monotonically
-    for (int x = a; x < bnd; ++x) {
-      const int e = cscpos[x];
-      while (rp[i + 1] <= e) ++i;
-      cscsrc[x] = i;
-    }
+    cscpos[a + rank] = v;
+    cscsrc[a + rank] = lo;
   }
 }
 
@@ -278,7 +284,7 @@ Layout layout(int G, int F, int K, int P, int mode) {   // must match pack_layou
 }
 
 struct WsLayout {
-  size_t z, cscptr, cscsrc, cscpos, att, t0, t1, ytmp, total;
+  size_t z, cscptr, cscsrc, cscpos, csctmp, att, t0, t1, ytmp, total;
 };
 WsLayout ws_layout(int B, int N, long long nnz, int G, int F, int K, int P, int mode, int concat) {
   const Layout L = layout(G, F, K, P, mode);
@@ -289,6 +295,7 @@ WsLayout ws_layout(int B, int N, long long nnz, int G, int F, int K, int P, int 
   w.cscptr = take((size_t)B * (N + 1) * sizeof(int));
   w.cscsrc = take((size_t)nnz * sizeof(int));
   w.cscpos = take((size_t)nnz * sizeof(int));
+  w.csctmp = take((size_t)nnz * sizeof(int));
   w.att = take((size_t)P * nnz * sizeof(float));
   const size_t tb = K > 2 ? (size_t)B * N * P * F * sizeof(float) : 0;
   w.t0 = take(tb);
@@ -396,8 +403,12 @@ extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, cons
   } else {
     if (K > 1) {
       const int pid = magat_prof_begin(MAGAT_TAG_GAT_PACK, st);
+      int* csctmp = reinterpret_cast<int*>(ws + w.csctmp);
       hipLaunchKernelGGL(csr_transpose_kernel, dim3(B), dim3(256), (size_t)(2 * N + 2) * sizeof(int), st, rowptr, colidx,
-                         cscptr, cscsrc, cscpos, N);
+                         cscptr, csctmp, N);
+      const long long cols = (long long)B * N;
+      hipLaunchKernelGGL(csr_sort_columns_kernel, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, st, rowptr, cscptr,
+                         csctmp, cscsrc, cscpos, N, cols);
       magat_prof_end(pid, st);
       if ((rc = magat_check_launch()) != MAGAT_OK) return rc;
     }
