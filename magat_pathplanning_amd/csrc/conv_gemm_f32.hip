@@ -329,8 +329,11 @@ extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) 
   }
   if ((p.in_pix_stride & 3) || (p.in2_pix_stride & 3)) return MAGAT_ERR_BAD_SHAPE;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (d->pool) return launch<128, 128, 2, 2, true>(p, st);
-  if (p.Cout > 64) return launch<128, 128, 2, 2>(p, st);
+  // few-block launches (head, compressMLP at moderate M): 64-row tiles double the number of workgroups
+  const long long blocks128 = (long long)((p.M + 127) / 128) * p.npix * ((p.Cout + 127) / 128);
+  const bool small_grid = blocks128 < 1536;
+  if (d->pool) return small_grid ? launch<64, 128, 2, 2, true>(p, st) : launch<128, 128, 2, 2, true>(p, st);
+  if (p.Cout > 64) return small_grid ? launch<64, 128, 2, 2>(p, st) : launch<128, 128, 2, 2>(p, st);
   if (p.Cout > 32) return launch<128, 64, 2, 2>(p, st);
   return launch<128, 32, 4, 1>(p, st);
 }

@@ -14,10 +14,15 @@ namespace {
 // ((H+2)x(W+2) per channel, odd agent stride -> conflict-free column reads); each wave then walks
 // output pixels: its 32x32 tile is (32 agents) x (32 channels) at one pixel, i.e. 4 KB of contiguous
 // output, from 16 v_mfma_f32_32x32x2_f32 whose A operands are plain ds_read_b32 gathers.
+// HC/WC: compile-time map size (0 = runtime H, W).  With constants every index split is a multiply-shift and the
+// staging loop unrolls into 12 back-to-back 16-byte loads per thread (the 32 agents' inputs are one contiguous
+// 46 KB run), instead of 46 dependent load->divide->store rounds.
+template <int HC, int WC>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                          const float* __restrict__ bias, float* __restrict__ out,
-                                                         int M, int H, int W) {
+                                                         int M, int Hr, int Wr) {
   extern __shared__ float img[];
+  const int H = HC ? HC : Hr, W = WC ? WC : Wr;
   const int PW = W + 2, PHW = (H + 2) * PW;
   const int PS = (3 * PHW) | 1;            // odd per-agent stride
   const int HW = H * W;
@@ -26,11 +31,47 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
   for (int i = t; i < 32 * PS; i += 256) img[i] = 0.f;
   __syncthreads();
   const int per = 3 * HW;
-  for (int i = t; i < 32 * per; i += 256) {
-    const int a = i / per, r = i - a * per;
-    const int c = r / HW, q = r - c * HW;
-    const int y = q / W, xx = q - y * W;
-    if (m0 + a < M) img[a * PS + c * PHW + (y + 1) * PW + xx + 1] = x[(long long)(m0 + a) * per + r];
+  if constexpr (HC != 0 && (32 * 3 * HC * WC) % 4 == 0) {
+    constexpr int NV = 32 * 3 * HC * WC / 4;          // float4s in the block's contiguous input run
+    constexpr int IT = (NV + 255) / 256;
+    const long long navail = ((long long)(M - m0) * per) / 4;   // run may be cut short by the batch end
+    const f32x4* src = reinterpret_cast<const f32x4*>(x + (long long)m0 * per);
+    f32x4 v[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      const int i4 = t + 256 * k;
+      v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i4 < NV && i4 < navail) v[k] = src[i4];
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      const int i4 = t + 256 * k;
+      if (i4 < NV && i4 < navail) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int f = 4 * i4 + e;
+          const int a = f / per, r = f - a * per;
+          const int c = r / HW, q = r - c * HW;
+          const int y = q / W, xx = q - y * W;
+          img[a * PS + c * PHW + (y + 1) * PW + xx + 1] = v[k][e];
+        }
+      }
+    }
+    // a batch end that is not float4-aligned leaves < 4 trailing floats: scalar tail
+    const long long done = navail * 4, want = (long long)(M - m0 < 32 ? M - m0 : 32) * per;
+    for (long long f = done + t; f < want; f += 256) {
+      const int a = (int)(f / per), r = (int)(f - (long long)a * per);
+      const int c = r / HW, q = r - c * HW;
+      const int y = q / W, xx = q - y * W;
+      img[a * PS + c * PHW + (y + 1) * PW + xx + 1] = x[(long long)m0 * per + f];
+    }
+  } else {
+    for (int i = t; i < 32 * per; i += 256) {
+      const int a = i / per, r = i - a * per;
+      const int c = r / HW, q = r - c * HW;
+      const int y = q / W, xx = q - y * W;
+      if (m0 + a < M) img[a * PS + c * PHW + (y + 1) * PW + xx + 1] = x[(long long)(m0 + a) * per + r];
+    }
   }
   // B operand (weights) and per-k LDS tap offsets for this lane half: k = s + 16*(lane>>5)
   float bw[16];
@@ -44,7 +85,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
     const int kk = kok ? k : 0;
     koff[s] = (kk / 9) * PHW + ((kk % 9) / 3) * PW + (kk % 3);
   }
-  const float bv = bias[co];
+  f32x4 bch[4];     // bias of the channels this lane stores: 8q + 4*(lane>>5) + 0..3
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bch[q] = *reinterpret_cast<const f32x4*>(bias + 8 * q + 4 * (lane >> 5));
   __syncthreads();
   const int abase = (lane & 31) * PS;
   for (int pix = wave; pix < HW; pix += 4) {
@@ -57,13 +100,20 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
     for (int s = 0; s < 16; ++s) {
       float a = img[base + koff[s]];
       if (s + 16 * (lane >> 5) >= 27) a = 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[s], acc, 0, 0, 0);
+      // operands swapped (weights as the row operand): D[channel][agent], so a lane ends up with four runs of
+      // 4 consecutive channels of ONE agent -> 16-byte stores instead of 4-byte ones
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[s], a, acc, 0, 0, 0);
     }
-    float* o = out + ((long long)pix * M + m0) * 32 + co;
+    const int agent = m0 + (lane & 31);
+    if (agent < M) {
+      float* o = out + ((long long)pix * M + agent) * 32 + 4 * (lane >> 5);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (m0 + row < M) o[row * 32] = fmaxf(acc[r] + bv, 0.f);
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[4 * q + c] + bch[q][c], 0.f);
+        *reinterpret_cast<f32x4*>(o + 8 * q) = v;
+      }
     }
   }
 }
@@ -91,7 +141,10 @@ extern "C" int magat_conv_first_f32(const float* x, const float* wt, const float
   const int blocks = (M + 31) / 32;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int pid = magat_prof_begin(MAGAT_TAG_CONV_FIRST, st);
-  hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W);
+  if (H == 11 && W == 11 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    hipLaunchKernelGGL((conv_first_kernel<11, 11>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W);
+  else
+    hipLaunchKernelGGL((conv_first_kernel<0, 0>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
