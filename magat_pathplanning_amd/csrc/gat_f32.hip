@@ -36,6 +36,8 @@ struct GatParams {
   int b0;                        // first instance of this chunk
   long long* dbg;                // optional phase timestamps [blocks][8] (instrumentation; null in production)
   int skip;                      // instrumentation: bit0 skip scores, bit1 skip hops (wrong results; for PMC deltas)
+  const int* over;               // when set: only instances with over[bl] != 0 are processed here (the rest were
+                                 // handled by the list kernel, gat_list_f32.hip)
 };
 
 __device__ __forceinline__ bool is_edge(const void* S, long long idx, int f64) {
@@ -71,6 +73,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
   const int bl = xcd + MAGAT_NUM_XCD * (slot / p.P);   // heads of one instance share an XCD (X_b, S_b in L2)
   const int head = slot % p.P;
   if (bl >= p.B) return;
+  if (p.over && !p.over[bl]) return;
   const int b = p.b0 + bl;
 
   float* R0 = smem;                      // Q_p, later hop buffer
@@ -584,12 +587,22 @@ extern "C" int magat_gat_dense_supported(int N, int G, int F) {
   return gat_lds_bytes(N, G, F, gat_block_threads(N) / 64) <= 160 * 1024 ? 1 : 0;
 }
 
+bool gat_list_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MAGAT_GAT_LIST");
+    v = e ? atoi(e) : 0;     // opt-in: see the status note in gat_list_f32.hip
+  }
+  return v != 0;
+}
+
 extern "C" size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, int P, int mode, int concat) {
   if (B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
   const PackLayout L = pack_layout(G, F, K, P, mode);
   const int chunk = gat_chunk_instances(B, N, L.NC);
   size_t bytes = magat_align_up((size_t)chunk * N * L.NC * sizeof(float), 256);
   if (!concat) bytes += magat_align_up((size_t)B * N * P * F * sizeof(float), 256);
+  bytes += magat_gat_list_workspace_bytes(chunk, N, G, F);
   return bytes;
 }
 
@@ -616,7 +629,10 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
   float* Z = static_cast<float*>(workspace);
   float* Ytmp = reinterpret_cast<float*>(static_cast<char*>(workspace) +
                                          magat_align_up((size_t)chunk * N * L.NC * sizeof(float), 256));
+  char* list_ws = reinterpret_cast<char*>(Ytmp) + (concat ? 0 : magat_align_up((size_t)B * N * P * F * sizeof(float), 256));
+  const bool use_list = gat_list_enabled() && magat_gat_list_capacity(N, G, F) > 0;
   GatParams p;
+  p.over = nullptr;
   p.dbg = g_gat_dbg;
   { static int sk = -1; if (sk < 0) { const char* e = getenv("MAGAT_GAT_SKIP"); sk = e ? atoi(e) : 0; } p.skip = sk; }
   p.X = X; p.S = S; p.Z = Z; p.bias = bias; p.A_opt = A_opt;
@@ -631,6 +647,16 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
                                      L.NC, G, 0, MAGAT_TAG_GAT_MAPS, stream);
     if (rc != MAGAT_OK) return rc;
     p.B = cb; p.b0 = b0;
+    if (use_list) {     // sparse instances: structure pass + list kernel; dense ones stay flagged for the kernel below
+      if (A_opt &&
+          hipMemsetAsync(A_opt + (size_t)b0 * P * N * N, 0, (size_t)cb * P * N * N * sizeof(float), st) != hipSuccess)
+        return MAGAT_ERR_LAUNCH;
+      int* over = nullptr;
+      rc = magat_gat_list_run(X, S, s_is_f64, Z, bias, p.Y, p.ldy, A_opt, list_ws, cb, b0, N, G, K, P, mode, concat,
+                              L.NC, L.qoff, L.uoff, L.c1off, L.c2off, &over, st);
+      if (rc != MAGAT_OK) return rc;
+      p.over = over;
+    }
     const int blocks = (cb + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD * P;
     switch (G) {
       case 16: rc = launch_gat<16, 16>(p, blocks, threads, lds, st); break;

@@ -15,6 +15,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 int magat_prof_begin(int tag, hipStream_t st);
 void magat_prof_end(int id, hipStream_t st);
 
+// sparse-structure GAT kernel (gat_list_f32.hip), driven by magat_gat_forward_packed_f32
+int magat_gat_list_capacity(int N, int G, int F);
+size_t magat_gat_list_workspace_bytes(int B, int N, int G, int F);
+int magat_gat_list_run(const float* X, const void* S, int s_is_f64, const float* Z, const float* bias, float* Y,
+                       int ldy, float* A_opt, void* ws, int B, int b0, int N, int G, int K, int P, int mode,
+                       int concat, int NC, int qoff, int uoff, int c1off, int c2off, int** over_out, hipStream_t st);
+
 static inline int magat_check_launch() {
   return hipGetLastError() == hipSuccess ? MAGAT_OK : MAGAT_ERR_LAUNCH;
 }

@@ -208,3 +208,30 @@ def test_gat_module_switches_to_csr_for_large_graphs(gpu_device):
     with torch.no_grad():
         y = layer(x.to(gpu_device))
     np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("mode,concat", [("KeyQuery", True), ("GAT_modified", False)])
+def test_gat_mixed_density_batch_list_and_dense_kernels(gpu_device, mode, concat):
+    """One batch holding sparse instances (list kernel), fully connected ones (over the LDS list capacity ->
+    dense-tile kernel) and an empty graph: every instance must match the oracle, attention included."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from magat_pathplanning_amd.synthetic import comm_gso, random_gso
+    from oracle import magat_oracle as orc
+    N, G, K, P = 100, 128, 3, 4
+    g = torch.Generator().manual_seed(11)
+    S = torch.cat((comm_gso(3, N, 50, seed=5), random_gso(2, N, 1.0, seed=6), torch.zeros(1, N, N),
+                   random_gso(2, N, 0.5, seed=7), comm_gso(1, N, 30, seed=8)), dim=0)
+    B = S.shape[0]
+    layer = GraphFilterBatchAttentional(G, G, K, P, concatenate=concat, attentionMode=mode)
+    with torch.no_grad():
+        layer.weight_bias.uniform_(-0.3, 0.3, generator=g)
+    x = torch.randn(B, G, N, generator=g) * 0.5
+    y_ref, a_ref = orc.gat_layer_forward(x, S.unsqueeze(1), {k: v.detach() for k, v in layer.state_dict().items()},
+                                         mode, concat)
+    layer = layer.to(gpu_device).eval()
+    layer.return_attention = True
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    with torch.no_grad():
+        y = layer(x.to(gpu_device))
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(layer.aij.cpu().numpy(), a_ref.numpy(), rtol=0, atol=3e-6)
