@@ -122,6 +122,12 @@ typedef struct magat_conv_gemm_desc {
                  sum of physical pixels (2iy+{0,1}, 2ix+{0,1}) of a map that is pool_w pixels wide
                  (AvgPool2d(2) of resnet_pytorch.py:450 with the 1/4 folded into wt) */
   int pool_w;
+  /* Operand formats.  0 = float32.  1 = "bf16x3": every value carried as three bf16 planes x1+x2+x3 (fp32-exact
+   * to 2^-24), plane p at base + p * *_plane_stride elements; with in_fmt = 1 the GEMM runs on the bf16 matrix
+   * cores as six partial products (conv_gemm_bf16x6.hip) and in, in2, wt are all bf16x3 (wt planes are
+   * Cout*Ktot apart).  out_fmt = 1 makes the epilogue emit the 3-plane form for the next layer. */
+  int in_fmt, out_fmt;
+  int64_t in_plane_stride, in2_plane_stride, out_plane_stride;
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 

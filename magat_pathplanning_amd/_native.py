@@ -8,7 +8,7 @@ import os
 import threading
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "lib", "libmagat_hip.so")
+LIB_PATH = os.environ.get("MAGAT_LIB_PATH") or os.path.join(PKG, "lib", "libmagat_hip.so")   # override: A/B builds
 
 MODE_KEYQUERY = 0
 MODE_GAT_MODIFIED = 1
@@ -36,7 +36,10 @@ class ConvGemmDesc(ctypes.Structure):
                 ("Hout", ctypes.c_int), ("Wout", ctypes.c_int),
                 ("C2", ctypes.c_int), ("lda2", ctypes.c_int), ("W2", ctypes.c_int), ("stride2", ctypes.c_int),
                 ("Cout", ctypes.c_int), ("ldc", ctypes.c_int), ("relu", ctypes.c_int), ("tag", ctypes.c_int),
-                ("pool", ctypes.c_int), ("pool_w", ctypes.c_int)]
+                ("pool", ctypes.c_int), ("pool_w", ctypes.c_int),
+                ("in_fmt", ctypes.c_int), ("out_fmt", ctypes.c_int),
+                ("in_plane_stride", ctypes.c_int64), ("in2_plane_stride", ctypes.c_int64),
+                ("out_plane_stride", ctypes.c_int64)]
 
 
 class EncoderDesc(ctypes.Structure):

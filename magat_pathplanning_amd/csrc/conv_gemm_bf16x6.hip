@@ -1,0 +1,271 @@
+// fp32-accurate segmented-K conv/linear GEMM on the bf16 matrix cores ("bf16x6" split).
+//
+// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (157 TF); v_mfma_f32_32x32x16_bf16 is 16x faster.  Every
+// fp32 value is therefore carried as THREE bf16 planes  x = x1 + x2 + x3  (x1 = bf16(x), x2 = bf16(x - x1),
+// x3 = bf16(x - x1 - x2): 3 x 8 significand bits = the fp32 mantissa, same exponent range, products of bf16
+// pairs are exact in the fp32 accumulator) and a product is evaluated as the six partial products with
+// i + j <= 4:   x.w ~= x1w1 + x1w2 + x2w1 + x1w3 + x2w2 + x3w1   (dropped terms <= 2^-24 |x.w|, i.e. the fp32
+// rounding class).  Six bf16 MFMAs replace one fp32 MFMA's worth of work at 16/6 = 2.67x the rate.
+// Used for the two layer-3 convolutions (62 % of the step); the producing epilogues write the 3-plane form
+// directly, weights are split host-side.  Same pixel-major / tap-skipping / residual-K-segment structure as
+// conv_gemm_f32.hip.
+//
+// Tile 128x128x32, 4 waves (2x2, wave tile 64x64).  LDS rows are 32 bf16 = 64 B, unpadded, with the 16-byte
+// chunk index XOR-ed by (row>>2)&3: a ds_read_b128 16-lane group (16 consecutive rows, same k chunk) then covers
+// all 64 banks exactly once.
+#include <cstdlib>
+
+#include "magat_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+
+struct SplitParams {
+  const u16* in;
+  const u16* in2;
+  const u16* wt;
+  const float* bias;
+  void* out;
+  long long in_pix_stride, in2_pix_stride, out_pix_stride;
+  long long in_plane, in2_plane, out_plane, wt_plane;
+  int M, Mt;
+  int Cin, lda, Hin, Win, kH, kW, stride, pad, Hout, Wout;
+  int C2, lda2, W2, stride2;
+  int Cout, Ktot, ldc, relu;
+  int ntn, npix, tag, out_split;
+};
+
+__device__ __forceinline__ u16 bf16_rne(float v) { return magat_bf16_rne(v); }
+__device__ __forceinline__ float bf16_f32(u16 h) { return magat_bf16_f32(h); }
+
+__global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitParams p) {
+  __shared__ __attribute__((aligned(16))) u16 lds[2 * 3 * 128 * 32];   // A planes | B planes  (48 KB)
+  u16* As = lds;
+  u16* Bs = lds + 3 * 128 * 32;
+
+  const int bid = blockIdx.x;
+  const int xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
+  const int per_m = p.npix * p.ntn;
+  const int mtile = xcd + MAGAT_NUM_XCD * (slot / per_m);
+  if (mtile >= p.Mt) return;
+  const int rem = slot % per_m;
+  const int pix = rem / p.ntn, ntile = rem % p.ntn;
+  const int m0 = mtile * BM, n0 = ntile * BN;
+  const int oy = pix / p.Wout, ox = pix % p.Wout;
+  const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+  const int ty0 = iy0 < 0 ? -iy0 : 0, tx0 = ix0 < 0 ? -ix0 : 0;
+  const int ty1 = min(p.kH, p.Hin - iy0), tx1 = min(p.kW, p.Win - ix0);
+  const int ntaps = (ty1 - ty0) * (tx1 - tx0);
+  const int spt = p.Cin / BK, spt2 = p.C2 / BK;
+  const int nslab = ntaps * spt + spt2;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = t >> 2, lchunk = t & 3;          // loader: rows lrow, lrow+64; 16-byte chunk lchunk
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-thread byte offsets (rows past M are clamped: their results are never stored)
+  unsigned aoff[2], aoff2[2], boff[2], loff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = min(m0 + lrow + 64 * i, p.M - 1);
+    aoff[i] = (unsigned)(((long long)m * p.lda + lchunk * 8) * 2);
+    aoff2[i] = (unsigned)(((long long)m * p.lda2 + lchunk * 8) * 2);
+    boff[i] = (unsigned)(((long long)(n0 + lrow + 64 * i) * p.Ktot + lchunk * 8) * 2);
+    const int row = lrow + 64 * i;
+    loff[i] = (unsigned)((row * 4 + (lchunk ^ ((row >> 2) & 3))) * 16);
+  }
+
+  int cur_ty = ty0, cur_tx = tx0, cur_ks = 0;
+  bool cur_main = ntaps > 0;
+  auto tap_base = [&](int ty, int tx) -> const u16* {
+    return p.in + (long long)((iy0 + ty) * p.Win + (ix0 + tx)) * p.in_pix_stride;
+  };
+  const u16* cur_tap = tap_base(ty0, tx0);
+  const u16* const seg2_base = p.in2 + (long long)(oy * p.stride2 * p.W2 + ox * p.stride2) * p.in2_pix_stride;
+
+  u32x4 ra[3][2], rb[3][2];
+  auto load_slab = [&]() {
+    const bool main_seg = cur_main;
+    const int k0 = cur_ks * BK;
+    const char* ab;
+    long long aplane;
+    int bk;
+    if (main_seg) {
+      ab = reinterpret_cast<const char*>(cur_tap + k0);
+      aplane = p.in_plane * 2;
+      bk = (cur_ty * p.kW + cur_tx) * p.Cin + k0;
+      if (++cur_ks == spt) {
+        cur_ks = 0;
+        if (++cur_tx == tx1) {
+          cur_tx = tx0;
+          if (++cur_ty == ty1) cur_main = false;
+        }
+        if (cur_main) cur_tap = tap_base(cur_ty, cur_tx);
+      }
+    } else {
+      ab = reinterpret_cast<const char*>(seg2_base + k0);
+      aplane = p.in2_plane * 2;
+      bk = p.kH * p.kW * p.Cin + k0;
+      ++cur_ks;
+    }
+    const char* bb = reinterpret_cast<const char*>(p.wt + bk);
+    const long long bplane = p.wt_plane * 2;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ra[pl][i] = *reinterpret_cast<const u32x4*>(ab + pl * aplane + (main_seg ? aoff[i] : aoff2[i]));
+        rb[pl][i] = *reinterpret_cast<const u32x4*>(bb + pl * bplane + boff[i]);
+      }
+  };
+  auto store_slab = [&]() {
+    char* a = reinterpret_cast<char*>(As);
+    char* b = reinterpret_cast<char*>(Bs);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        *reinterpret_cast<u32x4*>(a + pl * (128 * 64) + loff[i]) = ra[pl][i];
+        *reinterpret_cast<u32x4*>(b + pl * (128 * 64) + loff[i]) = rb[pl][i];
+      }
+  };
+
+  // fragment addressing: row = tile row (lane&31), k chunk c = 2*s + (lane>>5)
+  const int fr = lane & 31, fh = lane >> 5;
+  auto frag = [&](const u16* base, int row, int s) -> bf16x8 {
+    const int c = 2 * s + fh;
+    return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(base) +
+                                            (row * 4 + (c ^ ((row >> 2) & 3))) * 16);
+  };
+
+  if (nslab > 0) load_slab();
+  for (int s = 0; s < nslab; ++s) {
+    if (s > 0) __syncthreads();
+    store_slab();
+    __syncthreads();
+    if (s + 1 < nslab) load_slab();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          fa[i][pl] = frag(As + pl * 128 * 32, wm * 64 + i * 32 + fr, ks);
+          fb[i][pl] = frag(Bs + pl * 128 * 32, wn * 64 + i * 32 + fr, ks);
+        }
+      // six partial products, smallest terms first (the dominant x1*w1 last); the four accumulators are
+      // interleaved so consecutive MFMAs never depend on each other
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][PB[q]], fa[i][PA[q]], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // epilogue: weights are the MFMA row operand -> D[channel][agent]; agent = lane&31,
+  // channel = (r&3) + 8*(r>>2) + 4*(lane>>5): four consecutive channels per register quad -> wide stores
+  const bool vec = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (p.out_plane & 3) == 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int nb = n0 + wn * 64 + j * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wm * 64 + i * 32 + (lane & 31);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = nb + 8 * q;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          v[c] = acc[i][j][4 * q + c] + (p.bias ? p.bias[n + c] : 0.f);
+          if (p.relu) v[c] = fmaxf(v[c], 0.f);
+        }
+        const long long o = (long long)pix * p.out_pix_stride + (long long)m * p.ldc + n;
+        if (p.out_split) {
+          u16* ob = static_cast<u16*>(p.out);
+          u16 h[3][4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            h[0][c] = bf16_rne(v[c]);
+            const float r1 = v[c] - bf16_f32(h[0][c]);
+            h[1][c] = bf16_rne(r1);
+            h[2][c] = bf16_rne(r1 - bf16_f32(h[1][c]));
+          }
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            u16* dst = ob + pl * p.out_plane + o;
+            if (vec) {
+              uint2 pk;
+              pk.x = (unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16);
+              pk.y = (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16);
+              *reinterpret_cast<uint2*>(dst) = pk;
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) dst[c] = h[pl][c];
+            }
+          }
+        } else if (vec) {
+          *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + o) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) static_cast<float*>(p.out)[o + c] = v[c];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// in_fmt must be 1 (bf16x3 planes); Cout % 128 == 0, Cin % 32 == 0, C2 % 32 == 0, lda/lda2 % 8 == 0.
+int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
+  if (!d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
+  if (d->M <= 0 || d->Cin <= 0 || d->Cout <= 0) return MAGAT_ERR_BAD_SHAPE;
+  if ((d->Cout % BN) || (d->Cin % BK) || (d->C2 % BK) || (d->lda % 8) || (d->C2 > 0 && (d->lda2 % 8)) || d->pool)
+    return MAGAT_ERR_UNSUPPORTED;
+  SplitParams p;
+  p.in = static_cast<const u16*>(static_cast<const void*>(d->in));
+  p.in2 = static_cast<const u16*>(static_cast<const void*>(d->in2));
+  p.wt = static_cast<const u16*>(static_cast<const void*>(d->wt));
+  p.bias = d->bias;
+  p.out = d->out;
+  p.in_pix_stride = d->in_pix_stride; p.in2_pix_stride = d->in2_pix_stride; p.out_pix_stride = d->out_pix_stride;
+  p.in_plane = d->in_plane_stride; p.in2_plane = d->in2_plane_stride; p.out_plane = d->out_plane_stride;
+  p.M = d->M; p.Cin = d->Cin; p.lda = d->lda; p.Hin = d->Hin; p.Win = d->Win; p.kH = d->kH; p.kW = d->kW;
+  p.stride = d->stride; p.pad = d->pad; p.Hout = d->Hout; p.Wout = d->Wout;
+  p.C2 = d->C2; p.lda2 = d->lda2; p.W2 = d->W2; p.stride2 = d->stride2;
+  p.Cout = d->Cout; p.Ktot = d->kH * d->kW * d->Cin + d->C2; p.ldc = d->ldc; p.relu = d->relu;
+  p.wt_plane = (long long)p.Cout * p.Ktot;
+  p.npix = d->Hout * d->Wout; p.tag = d->tag; p.out_split = d->out_fmt == 1;
+  p.Mt = (p.M + BM - 1) / BM;
+  p.ntn = p.Cout / BN;
+  if ((long long)p.M * (p.lda > p.lda2 ? p.lda : p.lda2) * 2 >= 0xffffffffLL ||
+      (long long)p.Cout * p.Ktot * 2 >= 0xffffffffLL)
+    return MAGAT_ERR_UNSUPPORTED;
+  const long long groups = (p.Mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD;
+  const long long grid = groups * MAGAT_NUM_XCD * p.npix * p.ntn;
+  if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
+  const int pid = magat_prof_begin(p.tag, st);
+  hipLaunchKernelGGL(conv_gemm_bf16x6_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
+}

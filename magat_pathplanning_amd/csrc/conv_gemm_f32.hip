@@ -39,6 +39,8 @@ struct ConvGemmParams {
   int ntn, npix;
   int tag;
   int pool_w;   // POOL: physical input width (input pixel (iy,ix) = sum of the 2x2 physical pixels)
+  int out_split;            // epilogue writes three bf16 planes (out_plane elements apart) instead of float32
+  long long out_plane;
 };
 
 // FULL: M % BM == 0, Cout % BN == 0, Cin % 32 == 0, C2 % 32 == 0 -> the loader has no bounds checks and
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q][e], fb[j][q][e], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][q][e], fa[i][q][e], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -242,22 +244,60 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
     }
   }
 
-  // epilogue: bias (+ReLU); C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // epilogue: bias (+ReLU).  The weight tile is the MFMA's ROW operand, so D[channel][agent]:
+  // agent = lane&31, channel = (r&3) + 8*(r>>2) + 4*(lane>>5): registers 4q..4q+3 hold four consecutive channels
+  // of one agent -> one 16-byte store (float32) or one 8-byte store per plane (bf16x3) instead of four scalars.
   float* obase = p.out + (long long)pix * p.out_pix_stride;
+  unsigned short* sbase = reinterpret_cast<unsigned short*>(p.out) + (long long)pix * p.out_pix_stride;
+  const bool vec = FULL && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (p.out_plane & 3) == 0;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-    const bool nok = n < p.Cout;
-    const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+    const int nb = n0 + wn * WTN + j * 32 + 4 * (lane >> 5);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
+      const int m = m0 + wm * WTM + i * 32 + (lane & 31);
+      if (m >= p.M) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        float v = acc[i][j][r] + bv;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (nok && m < p.M) obase[(long long)m * p.ldc + n] = v;
+      for (int q = 0; q < 4; ++q) {
+        const int n = nb + 8 * q;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool nok = n + c < p.Cout;
+          v[c] = acc[i][j][4 * q + c] + ((nok && p.bias) ? p.bias[n + c] : 0.f);
+          if (p.relu) v[c] = fmaxf(v[c], 0.f);
+        }
+        const long long o = (long long)m * p.ldc + n;
+        if (p.out_split) {
+          unsigned short h[3][4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            h[0][c] = magat_bf16_rne(v[c]);
+            const float r1 = v[c] - magat_bf16_f32(h[0][c]);
+            h[1][c] = magat_bf16_rne(r1);
+            h[2][c] = magat_bf16_rne(r1 - magat_bf16_f32(h[1][c]));
+          }
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            unsigned short* dst = sbase + pl * p.out_plane + o;
+            if (vec) {
+              uint2 pk;
+              pk.x = (unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16);
+              pk.y = (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16);
+              *reinterpret_cast<uint2*>(dst) = pk;
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (n + c < p.Cout) dst[c] = h[pl][c];
+            }
+          }
+        } else if (vec) {
+          *reinterpret_cast<f32x4*>(obase + o) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (n + c < p.Cout) obase[o + c] = v[c];
+        }
       }
     }
   }
@@ -305,6 +345,8 @@ int launch(ConvGemmParams& p, hipStream_t st) {
 
 extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) {
   if (!d || !d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
+  if (d->in_fmt == 1) return magat_conv_gemm_bf16x6(d, static_cast<hipStream_t>(stream));
+  if (d->in_fmt != 0 || (d->out_fmt != 0 && d->out_fmt != 1)) return MAGAT_ERR_UNSUPPORTED;
   if (d->M <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->kH <= 0 || d->kW <= 0 ||
       d->stride <= 0 || d->pad < 0 || d->C2 < 0)
     return MAGAT_ERR_BAD_SHAPE;
@@ -322,6 +364,8 @@ extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) 
   p.Cout = d->Cout; p.Ktot = d->kH * d->kW * d->Cin + d->C2; p.ldc = d->ldc; p.relu = d->relu;
   p.npix = d->Hout * d->Wout;
   p.tag = d->tag;
+  p.out_split = d->out_fmt == 1;
+  p.out_plane = d->out_plane_stride;
   p.pool_w = 0;
   if (d->pool) {   // input map is the 2x2 sum-pool of a physical (2*Hin.. x pool_w) map
     if (d->pool_w < 2 * d->Win) return MAGAT_ERR_BAD_SHAPE;

@@ -15,6 +15,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 int magat_prof_begin(int tag, hipStream_t st);
 void magat_prof_end(int id, hipStream_t st);
 
+// bf16x6 split-MFMA GEMM (conv_gemm_bf16x6.hip), reached through magat_conv_gemm_f32 when desc->in_fmt == 1
+int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st);
+
+// fp32 -> three bf16 planes (round-to-nearest-even each)
+__device__ __forceinline__ unsigned short magat_bf16_rne(float v) {
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float magat_bf16_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+
 // sparse-structure GAT kernel (gat_list_f32.hip), driven by magat_gat_forward_packed_f32
 int magat_gat_list_capacity(int N, int G, int F);
 size_t magat_gat_list_workspace_bytes(int B, int N, int G, int F);

@@ -12,6 +12,8 @@ the "encoder pack" consumed by magat_encoder_forward_f32 (include/magat_hip.h):
           the GEMM sum-pools the 2x2 windows while loading its A operand)
   off[15] head bias [n_feat]
   off[16] compressMLP weight [G][n_feat]                   off[17] compressMLP bias [G]
+  off[18] layer3.conv1 weight as bf16x3 planes [3][128][9*64]      (raw bf16 bits, ResNetLarge only)
+  off[19] layer3.[conv2|downsample] weight as bf16x3 planes [3][128][9*128+64]
 
 Every offset is a multiple of 4 floats.  Folding is done in float64 and stored as float32.
 """
@@ -96,5 +98,33 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
         put(17, compress[1].detach().cpu().double())
         n_comp = compress[0].shape[0]
     pack = torch.cat(parts).to(torch.float32).contiguous()
+    if large:
+        # layer-3 weights once more as bf16x3 planes (raw bf16 bits stored inside the float32 pack) for the
+        # split-MFMA kernel (csrc/conv_gemm_bf16x6.hip): off[18] = layer3.conv1, off[19] = layer3.[conv2|downsample]
+        raws = []
+        cursor_f = pack.numel()
+        for slot, src in ((18, 2 + 4 * 2), (19, 4 + 4 * 2)):
+            nxt = sorted(o for o in offs if o > offs[src])
+            end = nxt[0] if nxt else pack.numel()
+            w32 = pack[offs[src]:end]
+            # drop the <=3 floats of alignment padding: weight sizes here are multiples of 4 already
+            planes = split_bf16x3(w32).view(torch.float32).reshape(-1)
+            pad = (-planes.numel()) % 4
+            if pad:
+                planes = torch.cat((planes, torch.zeros(pad)))
+            offs[slot] = cursor_f
+            cursor_f += planes.numel()
+            raws.append(planes)
+        pack = torch.cat([pack] + raws).contiguous()
     meta = dict(variant=0 if large else 1, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast)
     return pack, offs, meta
+
+
+def split_bf16x3(t):
+    """fp32 tensor -> (3, *t.shape) bfloat16 planes with t == p0 + p1 + p2 to 2^-24 (round-to-nearest-even each)."""
+    t = t.float()
+    p0 = t.bfloat16()
+    r = t - p0.float()
+    p1 = r.bfloat16()
+    p2 = (r - p1.float()).bfloat16()
+    return torch.stack((p0, p1, p2), dim=0).contiguous()

@@ -235,3 +235,74 @@ def test_gat_mixed_density_batch_list_and_dense_kernels(gpu_device, mode, concat
         y = layer(x.to(gpu_device))
     np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), rtol=0, atol=2e-5)
     np.testing.assert_allclose(layer.aij.cpu().numpy(), a_ref.numpy(), rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize("cin,cout,c2,M", [(64, 128, 0, 200), (128, 128, 64, 131), (32, 128, 32, 64)])
+def test_conv_gemm_bf16x6_split_mfma_matches_fp64(gpu_device, cin, cout, c2, M):
+    """bf16x6 split-MFMA conv (3 bf16 planes per operand, six partial products) is fp32-accurate: compared with an
+    fp64 conv2d of the same fp32 inputs; also checks the 3-plane output format round trip."""
+    from magat_pathplanning_amd.encoder import split_bf16x3
+    nat, lib = _nat()
+    g = torch.Generator().manual_seed(cin + cout + c2)
+    x = torch.randn(M, cin, 6, 6, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = tnf.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    wt = w.permute(0, 2, 3, 1).reshape(cout, -1)
+    d = nat.ConvGemmDesc()
+    keep = []
+    if c2:
+        x2 = torch.randn(M, c2, 6, 6, generator=g)
+        w2 = torch.randn(cout, c2, 1, 1, generator=g) / c2 ** 0.5
+        ref = ref + tnf.conv2d(x2.double(), w2.double())
+        wt = torch.cat((wt, w2.reshape(cout, c2)), dim=1)
+        x2s = split_bf16x3(_to_pixel_major(x2)).to(gpu_device)
+        keep.append(x2s)
+        d.in2, d.in2_pix_stride, d.C2, d.lda2, d.W2, d.stride2 = x2s.data_ptr(), M * c2, c2, c2, 6, 1
+        d.in2_plane_stride = 36 * M * c2
+    ref = ref.clamp_min(0)
+    xs = split_bf16x3(_to_pixel_major(x)).to(gpu_device)
+    ws = split_bf16x3(wt.contiguous()).to(gpu_device)
+    bd = b.to(gpu_device)
+    d.inp, d.wt, d.bias = xs.data_ptr(), ws.data_ptr(), bd.data_ptr()
+    d.in_pix_stride, d.out_pix_stride = M * cin, M * cout
+    d.in_plane_stride = 36 * M * cin
+    d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, 6, 6, 3, 3, 1, 1
+    d.Hout, d.Wout, d.Cout, d.ldc, d.relu, d.in_fmt = 6, 6, cout, cout, 1, 1
+    for out_fmt in (0, 1):
+        d.out_fmt = out_fmt
+        if out_fmt == 0:
+            out = torch.full((36, M, cout), float("nan"), device=gpu_device)
+        else:
+            out = torch.zeros(3, 36, M, cout, dtype=torch.bfloat16, device=gpu_device)
+            d.out_plane_stride = 36 * M * cout
+        d.out = out.data_ptr()
+        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "conv_gemm bf16x6")
+        torch.cuda.synchronize()
+        got = out.cpu() if out_fmt == 0 else out.float().sum(dim=0).cpu()
+        got = _from_pixel_major(got, 6, 6)
+        err = (got.double() - ref).abs().max().item()
+        assert err <= 8e-6, (out_fmt, err)     # fp32 rounding class (the fp32 MFMA kernel sits at ~2e-6 here)
+
+
+def test_f32_conv_emits_bf16x3_planes(gpu_device):
+    nat, lib = _nat()
+    M, cin, cout = 96, 32, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(36, M, cin, generator=g).to(gpu_device)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(gpu_device)
+    out32 = torch.empty(36, M, cout, device=gpu_device)
+    out3 = torch.zeros(3, 36, M, cout, dtype=torch.bfloat16, device=gpu_device)
+    d = nat.ConvGemmDesc()
+    d.inp, d.wt = x.data_ptr(), w.data_ptr()
+    d.in_pix_stride, d.out_pix_stride, d.out_plane_stride = M * cin, M * cout, 36 * M * cout
+    d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, 6, 6, 1, 1, 1, 0
+    d.Hout, d.Wout, d.Cout, d.ldc = 6, 6, cout, cout
+    d.out, d.out_fmt = out32.data_ptr(), 0
+    nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "f32 out")
+    d.out, d.out_fmt = out3.data_ptr(), 1
+    nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "split out")
+    torch.cuda.synchronize()
+    rec = out3[0].float() + out3[1].float() + out3[2].float()
+    rel = ((rec - out32).abs() / out32.abs().clamp_min(1e-20)).max().item()
+    assert rel <= 2 ** -22, rel

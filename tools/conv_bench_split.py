@@ -1,0 +1,36 @@
+"""bf16x6 split-MFMA vs fp32-MFMA conv on the layer-3 shapes (GPU only)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from magat_pathplanning_amd import _native as nat
+from magat_pathplanning_amd.encoder import split_bf16x3
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 51200
+dev = torch.device("cuda:0"); lib = nat.lib()
+def taps():
+    one = sum(sum(1 for t in range(3) if 0 <= o - 1 + t < 6) for o in range(6)); return one * one
+for name, cin, cout, c2 in (("l3.conv1", 64, 128, 0), ("l3.conv2+ds", 128, 128, 64)):
+    x = torch.relu(torch.randn(36, M, cin, device=dev)); x2 = torch.relu(torch.randn(36, M, max(c2, 8), device=dev))
+    w = torch.randn(cout, 9 * cin + c2, device=dev) * 0.05; b = torch.randn(cout, device=dev)
+    res = {}
+    for fmt in (0, 1):
+        d = nat.ConvGemmDesc()
+        xs = split_bf16x3(x) if fmt else x; x2s = split_bf16x3(x2) if fmt else x2; ws = split_bf16x3(w) if fmt else w
+        out = torch.empty(36, M, cout, device=dev)
+        d.inp, d.wt, d.bias, d.out = xs.data_ptr(), ws.data_ptr(), b.data_ptr(), out.data_ptr()
+        d.in_pix_stride, d.out_pix_stride, d.in_plane_stride = M * cin, M * cout, 36 * M * cin
+        d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, 6, 6, 3, 3, 1, 1
+        d.Hout, d.Wout, d.Cout, d.ldc, d.relu, d.in_fmt = 6, 6, cout, cout, 1, fmt
+        if c2:
+            d.in2, d.in2_pix_stride, d.C2, d.lda2, d.W2, d.stride2 = x2s.data_ptr(), M * c2, c2, c2, 6, 1
+            d.in2_plane_stride = 36 * M * c2
+        st = nat.current_stream(dev); ts = []
+        for r in range(9):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), st), name); e1.record()
+            torch.cuda.synchronize()
+            if r >= 2: ts.append(e0.elapsed_time(e1) * 1e3)
+        ts.sort(); res[fmt] = (ts[len(ts) // 2], out.clone())
+    fl = 2.0 * M * (taps() * cin * cout + 36 * c2 * cout)
+    print("%-12s fp32 %8.1f us (%.1f TF)   bf16x6 %8.1f us (%.1f TF-equiv, %.0f TF bf16)   speedup %.2fx   max|diff| %.2e" % (
+        name, res[0][0], fl / res[0][0] / 1e6, res[1][0], fl / res[1][0] / 1e6, 6 * fl / res[1][0] / 1e6,
+        res[0][0] / res[1][0], (res[0][1] - res[1][1]).abs().max().item()))
