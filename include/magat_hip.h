@@ -125,7 +125,9 @@ typedef struct magat_conv_gemm_desc {
   /* Operand formats.  0 = float32.  1 = "bf16x3": every value carried as three bf16 planes x1+x2+x3 (fp32-exact
    * to 2^-24), plane p at base + p * *_plane_stride elements; with in_fmt = 1 the GEMM runs on the bf16 matrix
    * cores as six partial products (conv_gemm_bf16x6.hip) and in, in2, wt are all bf16x3 (wt planes are
-   * Cout*Ktot apart).  out_fmt = 1 makes the epilogue emit the 3-plane form for the next layer. */
+   * Cout*Ktot apart).  in_fmt = 2: same kernel, but in / in2 stay float32 in memory and are split into their three
+   * planes by the loader on the way into LDS (wt still bf16x3).  out_fmt = 1 makes the epilogue emit the 3-plane
+   * form. */
   int in_fmt, out_fmt;
   int64_t in_plane_stride, in2_plane_stride, out_plane_stride;
 } magat_conv_gemm_desc;

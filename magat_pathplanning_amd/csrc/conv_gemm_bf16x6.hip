@@ -43,6 +43,25 @@ struct SplitParams {
 __device__ __forceinline__ u16 bf16_rne(float v) { return magat_bf16_rne(v); }
 __device__ __forceinline__ float bf16_f32(u16 h) { return magat_bf16_f32(h); }
 
+// two floats -> two RNE bf16 packed in one dword (lo = a, hi = b)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// (x, y) -> three packed bf16 pairs with x = x1+x2+x3, y likewise
+__device__ __forceinline__ void split_pair(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = cvt_pk_bf16(x, y);
+  const float rx = x - __builtin_bit_cast(float, p1 << 16), ry = y - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  p2 = cvt_pk_bf16(rx, ry);
+  const float sx = rx - __builtin_bit_cast(float, p2 << 16), sy = ry - __builtin_bit_cast(float, p2 & 0xffff0000u);
+  p3 = cvt_pk_bf16(sx, sy);
+}
+
+// AF32: the activation operands (in, in2) are plain float32 and are split into their three bf16 planes by the
+// loader on the way into LDS (no 3-plane tensors in HBM, 2/3 of the activation traffic); weights are always
+// pre-split bf16x3.
+template <bool AF32>
 __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitParams p) {
   __shared__ __attribute__((aligned(16))) u16 lds[2 * 3 * 128 * 32];   // A planes | B planes  (48 KB)
   u16* As = lds;
@@ -88,15 +107,31 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
     loff[i] = (unsigned)((row * 4 + (lchunk ^ ((row >> 2) & 3))) * 16);
   }
 
+  // AF32 loader: row fr0 + 32 i, float4 index fc4 (k = 4 fc4 .. +3): lands in 16-byte chunk fc4>>1, half fc4&1
+  const int fr0 = t >> 3, fc4 = t & 7;
+  unsigned faoff[4], faoff2[4], floff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = min(m0 + fr0 + 32 * i, p.M - 1);
+    faoff[i] = (unsigned)(((long long)m * p.lda + fc4 * 4) * 4);
+    faoff2[i] = (unsigned)(((long long)m * p.lda2 + fc4 * 4) * 4);
+    const int row = fr0 + 32 * i;
+    floff[i] = (unsigned)((row * 4 + ((fc4 >> 1) ^ ((row >> 2) & 3))) * 16 + (fc4 & 1) * 8);
+  }
+
+  // element size of the activation operands in global memory
+  constexpr int AE = AF32 ? 4 : 2;
   int cur_ty = ty0, cur_tx = tx0, cur_ks = 0;
   bool cur_main = ntaps > 0;
-  auto tap_base = [&](int ty, int tx) -> const u16* {
-    return p.in + (long long)((iy0 + ty) * p.Win + (ix0 + tx)) * p.in_pix_stride;
+  auto tap_base = [&](int ty, int tx) -> const char* {
+    return reinterpret_cast<const char*>(p.in) + (long long)((iy0 + ty) * p.Win + (ix0 + tx)) * p.in_pix_stride * AE;
   };
-  const u16* cur_tap = tap_base(ty0, tx0);
-  const u16* const seg2_base = p.in2 + (long long)(oy * p.stride2 * p.W2 + ox * p.stride2) * p.in2_pix_stride;
+  const char* cur_tap = tap_base(ty0, tx0);
+  const char* const seg2_base = reinterpret_cast<const char*>(p.in2) +
+                                (long long)(oy * p.stride2 * p.W2 + ox * p.stride2) * p.in2_pix_stride * AE;
 
   u32x4 ra[3][2], rb[3][2];
+  f32x4 fa32[4];
   auto load_slab = [&]() {
     const bool main_seg = cur_main;
     const int k0 = cur_ks * BK;
@@ -104,7 +139,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
     long long aplane;
     int bk;
     if (main_seg) {
-      ab = reinterpret_cast<const char*>(cur_tap + k0);
+      ab = cur_tap + (long long)k0 * AE;
       aplane = p.in_plane * 2;
       bk = (cur_ty * p.kW + cur_tx) * p.Cin + k0;
       if (++cur_ks == spt) {
@@ -116,29 +151,46 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
         if (cur_main) cur_tap = tap_base(cur_ty, cur_tx);
       }
     } else {
-      ab = reinterpret_cast<const char*>(seg2_base + k0);
+      ab = seg2_base + (long long)k0 * AE;
       aplane = p.in2_plane * 2;
       bk = p.kH * p.kW * p.Cin + k0;
       ++cur_ks;
     }
     const char* bb = reinterpret_cast<const char*>(p.wt + bk);
     const long long bplane = p.wt_plane * 2;
+    if constexpr (AF32) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa32[i] = *reinterpret_cast<const f32x4*>(ab + (main_seg ? faoff[i] : faoff2[i]));
+    }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ra[pl][i] = *reinterpret_cast<const u32x4*>(ab + pl * aplane + (main_seg ? aoff[i] : aoff2[i]));
+        if constexpr (!AF32)
+          ra[pl][i] = *reinterpret_cast<const u32x4*>(ab + pl * aplane + (main_seg ? aoff[i] : aoff2[i]));
         rb[pl][i] = *reinterpret_cast<const u32x4*>(bb + pl * bplane + boff[i]);
       }
   };
   auto store_slab = [&]() {
     char* a = reinterpret_cast<char*>(As);
     char* b = reinterpret_cast<char*>(Bs);
+    if constexpr (AF32) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned q1[2], q2[2], q3[2];
+        split_pair(fa32[i][0], fa32[i][1], q1[0], q2[0], q3[0]);
+        split_pair(fa32[i][2], fa32[i][3], q1[1], q2[1], q3[1]);
+        *reinterpret_cast<uint2*>(a + 0 * (128 * 64) + floff[i]) = uint2{q1[0], q1[1]};
+        *reinterpret_cast<uint2*>(a + 1 * (128 * 64) + floff[i]) = uint2{q2[0], q2[1]};
+        *reinterpret_cast<uint2*>(a + 2 * (128 * 64) + floff[i]) = uint2{q3[0], q3[1]};
+      }
+    }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        *reinterpret_cast<u32x4*>(a + pl * (128 * 64) + loff[i]) = ra[pl][i];
+        if constexpr (!AF32) *reinterpret_cast<u32x4*>(a + pl * (128 * 64) + loff[i]) = ra[pl][i];
         *reinterpret_cast<u32x4*>(b + pl * (128 * 64) + loff[i]) = rb[pl][i];
       }
   };
@@ -236,12 +288,13 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 
 }  // namespace
 
-// in_fmt must be 1 (bf16x3 planes); Cout % 128 == 0, Cin % 32 == 0, C2 % 32 == 0, lda/lda2 % 8 == 0.
+// in_fmt 1: in/in2/wt all bf16x3 planes; in_fmt 2: in/in2 float32 (split on load), wt bf16x3 planes; Cout % 128 == 0, Cin % 32 == 0, C2 % 32 == 0, lda/lda2 % 8 == 0.
 int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   if (!d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
   if (d->M <= 0 || d->Cin <= 0 || d->Cout <= 0) return MAGAT_ERR_BAD_SHAPE;
   if ((d->Cout % BN) || (d->Cin % BK) || (d->C2 % BK) || (d->lda % 8) || (d->C2 > 0 && (d->lda2 % 8)) || d->pool)
     return MAGAT_ERR_UNSUPPORTED;
+  if (d->in_fmt != 1 && d->in_fmt != 2) return MAGAT_ERR_UNSUPPORTED;
   SplitParams p;
   p.in = static_cast<const u16*>(static_cast<const void*>(d->in));
   p.in2 = static_cast<const u16*>(static_cast<const void*>(d->in2));
@@ -258,14 +311,17 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.npix = d->Hout * d->Wout; p.tag = d->tag; p.out_split = d->out_fmt == 1;
   p.Mt = (p.M + BM - 1) / BM;
   p.ntn = p.Cout / BN;
-  if ((long long)p.M * (p.lda > p.lda2 ? p.lda : p.lda2) * 2 >= 0xffffffffLL ||
+  if ((long long)p.M * (p.lda > p.lda2 ? p.lda : p.lda2) * 4 >= 0xffffffffLL ||
       (long long)p.Cout * p.Ktot * 2 >= 0xffffffffLL)
     return MAGAT_ERR_UNSUPPORTED;
   const long long groups = (p.Mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD;
   const long long grid = groups * MAGAT_NUM_XCD * p.npix * p.ntn;
   if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
   const int pid = magat_prof_begin(p.tag, st);
-  hipLaunchKernelGGL(conv_gemm_bf16x6_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+  if (d->in_fmt == 2)
+    hipLaunchKernelGGL(conv_gemm_bf16x6_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(conv_gemm_bf16x6_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }

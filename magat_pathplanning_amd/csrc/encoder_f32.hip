@@ -164,8 +164,7 @@ static bool enc_use_split(const magat_encoder_desc* d) {
 static size_t enc_buf_floats_per_agent(const magat_encoder_desc* d) {
   const int Ho = (d->H + 2 - 3) / 2 + 1, Wo = (d->W + 2 - 3) / 2 + 1;
   const size_t a0 = (size_t)d->H * d->W * 32;
-  size_t a3 = (size_t)Ho * Wo * (d->variant == 0 ? 128 : 64);
-  if (enc_use_split(d)) a3 = a3 * 3 / 2;      // three bf16 planes = 6 bytes per element
+  const size_t a3 = (size_t)Ho * Wo * (d->variant == 0 ? 128 : 64);
   return a0 > a3 ? a0 : a3;
 }
 
@@ -213,10 +212,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       g.M = mm; g.Cin = s.cin; g.lda = s.cin; g.Hin = hin; g.Win = win; g.kH = g.kW = 3; g.stride = s.stride;
       g.pad = 1; g.Hout = hout; g.Wout = wout; g.Cout = s.cout; g.ldc = s.cout; g.relu = 1;
       g.tag = MAGAT_TAG_BLOCK_CONV + 2 * l;
-      if (split && l == 2) {     // T4 (bf16x3) -> T5 (bf16x3) on the split-MFMA kernel
-        g.in_fmt = 1; g.out_fmt = 1; g.wt = pk + d->off[18];
-        g.in_plane_stride = (int64_t)hin * win * mm * s.cin;
-        g.out_plane_stride = (int64_t)hout * wout * mm * s.cout;
+      if (split && l == 2) {     // bf16x6 split-MFMA kernel: float32 activations split by its loader, bf16x3 weights
+        g.in_fmt = 2; g.wt = pk + d->off[18];
       }
       rc = magat_conv_gemm_f32(&g, stream);
       if (rc != MAGAT_OK) return rc;
@@ -230,14 +227,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       h.Hout = hout; h.Wout = wout; h.C2 = s.cin; h.lda2 = s.cin; h.W2 = win; h.stride2 = s.stride;
       h.Cout = s.cout; h.ldc = s.cout; h.relu = 1;
       h.tag = MAGAT_TAG_BLOCK_CONV + 2 * l + 1;
-      if (split && l == 1) {     // layer2's output feeds only layer3: emit it as bf16x3 planes
-        h.out_fmt = 1;
-        h.out_plane_stride = (int64_t)hout * wout * mm * s.cout;
-      }
-      if (split && l == 2) {     // T5, T4 (bf16x3) -> T6 (float32, read by the pooled head GEMM)
-        h.in_fmt = 1; h.wt = pk + d->off[19];
-        h.in_plane_stride = (int64_t)hout * wout * mm * s.cout;
-        h.in2_plane_stride = (int64_t)hin * win * mm * s.cin;
+      if (split && l == 2) {
+        h.in_fmt = 2; h.wt = pk + d->off[19];
       }
       rc = magat_conv_gemm_f32(&h, stream);
       if (rc != MAGAT_OK) return rc;

@@ -269,7 +269,15 @@ def test_conv_gemm_bf16x6_split_mfma_matches_fp64(gpu_device, cin, cout, c2, M):
     d.in_plane_stride = 36 * M * cin
     d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, 6, 6, 3, 3, 1, 1
     d.Hout, d.Wout, d.Cout, d.ldc, d.relu, d.in_fmt = 6, 6, cout, cout, 1, 1
-    for out_fmt in (0, 1):
+    keep32 = [_to_pixel_major(x).to(gpu_device)]
+    if c2:
+        keep32.append(_to_pixel_major(x2).to(gpu_device))
+    for out_fmt in (0, 1, 2):
+        if out_fmt == 2:        # float32 activations split by the loader (in_fmt = 2), float32 output
+            d.in_fmt, d.inp = 2, keep32[0].data_ptr()
+            if c2:
+                d.in2 = keep32[1].data_ptr()
+            out_fmt = 0
         d.out_fmt = out_fmt
         if out_fmt == 0:
             out = torch.full((36, M, cout), float("nan"), device=gpu_device)
