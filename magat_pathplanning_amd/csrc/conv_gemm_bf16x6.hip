@@ -23,7 +23,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BK = 32;
 
 struct SplitParams {
   const u16* in;
@@ -61,11 +61,14 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned& p1, unsig
 // AF32: the activation operands (in, in2) are plain float32 and are split into their three bf16 planes by the
 // loader on the way into LDS (no 3-plane tensors in HBM, 2/3 of the activation traffic); weights are always
 // pre-split bf16x3.
-template <bool AF32>
+// BN = 128 / 64 / 32 output channels per tile; waves WGM x WGN, wave tile (128/WGM) x (BN/WGN).
+template <bool AF32, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitParams p) {
-  __shared__ __attribute__((aligned(16))) u16 lds[2 * 3 * 128 * 32];   // A planes | B planes  (48 KB)
+  constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int BI = BN >= 64 ? BN / 64 : 1;      // weight-tile 16-byte loads per thread and plane
+  __shared__ __attribute__((aligned(16))) u16 lds[3 * (BM + BN) * 32];   // A planes | B planes
   u16* As = lds;
-  u16* Bs = lds + 3 * 128 * 32;
+  u16* Bs = lds + 3 * BM * 32;
 
   const int bid = blockIdx.x;
   const int xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
@@ -84,14 +87,14 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
   const int nslab = ntaps * spt + spt2;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int lrow = t >> 2, lchunk = t & 3;          // loader: rows lrow, lrow+64; 16-byte chunk lchunk
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -102,10 +105,12 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
     const int m = min(m0 + lrow + 64 * i, p.M - 1);
     aoff[i] = (unsigned)(((long long)m * p.lda + lchunk * 8) * 2);
     aoff2[i] = (unsigned)(((long long)m * p.lda2 + lchunk * 8) * 2);
-    boff[i] = (unsigned)(((long long)(n0 + lrow + 64 * i) * p.Ktot + lchunk * 8) * 2);
+    const int nrow = min(lrow + 64 * i, BN - 1);      // BN = 32: upper half of the threads duplicate row BN-1
+    boff[i] = (unsigned)(((long long)(n0 + nrow) * p.Ktot + lchunk * 8) * 2);
     const int row = lrow + 64 * i;
     loff[i] = (unsigned)((row * 4 + (lchunk ^ ((row >> 2) & 3))) * 16);
   }
+  const bool bload = lrow < BN;                       // weight-tile loader participation (BN = 32)
 
   // AF32 loader: row fr0 + 32 i, float4 index fc4 (k = 4 fc4 .. +3): lands in 16-byte chunk fc4>>1, half fc4&1
   const int fr0 = t >> 3, fc4 = t & 7;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
   const char* const seg2_base = reinterpret_cast<const char*>(p.in2) +
                                 (long long)(oy * p.stride2 * p.W2 + ox * p.stride2) * p.in2_pix_stride * AE;
 
-  u32x4 ra[3][2], rb[3][2];
+  u32x4 ra[3][2], rb[3][BI];
   f32x4 fa32[4];
   auto load_slab = [&]() {
     const bool main_seg = cur_main;
@@ -164,13 +169,15 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
         fa32[i] = *reinterpret_cast<const f32x4*>(ab + (main_seg ? faoff[i] : faoff2[i]));
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < 3; ++pl) {
+      if constexpr (!AF32) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if constexpr (!AF32)
+        for (int i = 0; i < 2; ++i)
           ra[pl][i] = *reinterpret_cast<const u32x4*>(ab + pl * aplane + (main_seg ? aoff[i] : aoff2[i]));
-        rb[pl][i] = *reinterpret_cast<const u32x4*>(bb + pl * bplane + boff[i]);
       }
+#pragma unroll
+      for (int i = 0; i < BI; ++i) rb[pl][i] = *reinterpret_cast<const u32x4*>(bb + pl * bplane + boff[i]);
+    }
   };
   auto store_slab = [&]() {
     char* a = reinterpret_cast<char*>(As);
@@ -181,18 +188,21 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
         unsigned q1[2], q2[2], q3[2];
         split_pair(fa32[i][0], fa32[i][1], q1[0], q2[0], q3[0]);
         split_pair(fa32[i][2], fa32[i][3], q1[1], q2[1], q3[1]);
-        *reinterpret_cast<uint2*>(a + 0 * (128 * 64) + floff[i]) = uint2{q1[0], q1[1]};
-        *reinterpret_cast<uint2*>(a + 1 * (128 * 64) + floff[i]) = uint2{q2[0], q2[1]};
-        *reinterpret_cast<uint2*>(a + 2 * (128 * 64) + floff[i]) = uint2{q3[0], q3[1]};
+        *reinterpret_cast<uint2*>(a + 0 * (BM * 64) + floff[i]) = uint2{q1[0], q1[1]};
+        *reinterpret_cast<uint2*>(a + 1 * (BM * 64) + floff[i]) = uint2{q2[0], q2[1]};
+        *reinterpret_cast<uint2*>(a + 2 * (BM * 64) + floff[i]) = uint2{q3[0], q3[1]};
       }
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < 3; ++pl) {
+      if constexpr (!AF32) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if constexpr (!AF32) *reinterpret_cast<u32x4*>(a + pl * (128 * 64) + loff[i]) = ra[pl][i];
-        *reinterpret_cast<u32x4*>(b + pl * (128 * 64) + loff[i]) = rb[pl][i];
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(a + pl * (BM * 64) + loff[i]) = ra[pl][i];
       }
+#pragma unroll
+      for (int i = 0; i < BI; ++i)
+        if (bload) *reinterpret_cast<u32x4*>(b + pl * (BN * 64) + loff[i]) = rb[pl][i];
+    }
   };
 
   // fragment addressing: row = tile row (lane&31), k chunk c = 2*s + (lane>>5)
@@ -211,23 +221,23 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
     if (s + 1 < nslab) load_slab();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[2][3], fb[2][3];
+      bf16x8 fa[TM][3], fb[TN][3];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          fa[i][pl] = frag(As + pl * 128 * 32, wm * 64 + i * 32 + fr, ks);
-          fb[i][pl] = frag(Bs + pl * 128 * 32, wn * 64 + i * 32 + fr, ks);
-        }
+        for (int i = 0; i < TM; ++i) fa[i][pl] = frag(As + pl * BM * 32, wm * WTM + i * 32 + fr, ks);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j][pl] = frag(Bs + pl * BN * 32, wn * WTN + j * 32 + fr, ks);
+      }
       // six partial products, smallest terms first (the dominant x1*w1 last); the four accumulators are
       // interleaved so consecutive MFMAs never depend on each other
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
       for (int q = 0; q < 6; ++q)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][PB[q]], fa[i][PA[q]], acc[i][j], 0, 0, 0);
     }
   }
@@ -236,11 +246,11 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
   // channel = (r&3) + 8*(r>>2) + 4*(lane>>5): four consecutive channels per register quad -> wide stores
   const bool vec = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (p.out_plane & 3) == 0;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int nb = n0 + wn * 64 + j * 32 + 4 * (lane >> 5);
+  for (int j = 0; j < TN; ++j) {
+    const int nb = n0 + wn * WTN + j * 32 + 4 * (lane >> 5);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + wm * 64 + i * 32 + (lane & 31);
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WTM + i * 32 + (lane & 31);
       if (m >= p.M) continue;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -292,6 +302,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   if (!d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
   if (d->M <= 0 || d->Cin <= 0 || d->Cout <= 0) return MAGAT_ERR_BAD_SHAPE;
+  const int BN = d->Cout % 128 == 0 ? 128 : (d->Cout % 64 == 0 ? 64 : 32);
   if ((d->Cout % BN) || (d->Cin % BK) || (d->C2 % BK) || (d->lda % 8) || (d->C2 > 0 && (d->lda2 % 8)) || d->pool)
     return MAGAT_ERR_UNSUPPORTED;
   if (d->in_fmt != 1 && d->in_fmt != 2) return MAGAT_ERR_UNSUPPORTED;
@@ -318,10 +329,18 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   const long long grid = groups * MAGAT_NUM_XCD * p.npix * p.ntn;
   if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
   const int pid = magat_prof_begin(p.tag, st);
-  if (d->in_fmt == 2)
-    hipLaunchKernelGGL(conv_gemm_bf16x6_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL(conv_gemm_bf16x6_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, p);
+  const bool af32 = d->in_fmt == 2;
+#define MAGAT_SPLIT_LAUNCH(BNV, WM, WN)                                                                              \
+  do {                                                                                                              \
+    if (af32)                                                                                                       \
+      hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<true, BNV, WM, WN>), dim3((unsigned)grid), dim3(256), 0, st, p);  \
+    else                                                                                                            \
+      hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<false, BNV, WM, WN>), dim3((unsigned)grid), dim3(256), 0, st, p); \
+  } while (0)
+  if (BN == 128) MAGAT_SPLIT_LAUNCH(128, 2, 2);
+  else if (BN == 64) MAGAT_SPLIT_LAUNCH(64, 2, 2);
+  else MAGAT_SPLIT_LAUNCH(32, 4, 1);
+#undef MAGAT_SPLIT_LAUNCH
   magat_prof_end(pid, st);
   return magat_check_launch();
 }

@@ -149,15 +149,19 @@ extern "C" int magat_conv_first_f32(const float* x, const float* wt, const float
   return magat_check_launch();
 }
 
-// layer-3 convolutions on the bf16x6 split-MFMA kernel (ResNetLarge with split weights in the pack; on by default,
-// MAGAT_CONV_SPLIT=0 keeps every layer on the fp32 MFMA kernel)
-static bool enc_use_split(const magat_encoder_desc* d) {
+// Block convolutions on the bf16x6 split-MFMA kernel (split weights in the pack).  MAGAT_CONV_SPLIT = bit mask of
+// BasicBlocks that use it (bit l = layer l+1); default 6 = layers 2 and 3 (layer 1, Cin = Cout = 32, is a wash:
+// 360 vs 348 us and 322 vs 328 us on MI355X); 0 keeps every layer on the fp32 MFMA kernel.
+static int enc_split_mask(const magat_encoder_desc* d) {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("MAGAT_CONV_SPLIT");
-    v = e ? atoi(e) : 1;
+    v = e ? atoi(e) : 6;
   }
-  return v != 0 && d->variant == 0 && d->off[18] > 0 && d->off[19] > 0;
+  int m = 0;
+  for (int l = 0; l < 3; ++l)
+    if ((v >> l & 1) && d->off[18 + 2 * l] > 0 && d->off[19 + 2 * l] > 0) m |= 1 << l;
+  return m;
 }
 
 // floats per agent of one rotating activation buffer
@@ -193,7 +197,7 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   const float* pk = d->pack;
   const BlockShape shapes[3] = {{32, 32, 2}, {32, 64, 1}, {64, 128, 1}};
   const int nblocks = d->variant == 0 ? 3 : 2;
-  const bool split = enc_use_split(d);
+  const int split = enc_split_mask(d);
 
   for (int m0 = 0; m0 < M; m0 += mc) {
     const int mm = (M - m0) < mc ? (M - m0) : mc;
@@ -212,8 +216,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       g.M = mm; g.Cin = s.cin; g.lda = s.cin; g.Hin = hin; g.Win = win; g.kH = g.kW = 3; g.stride = s.stride;
       g.pad = 1; g.Hout = hout; g.Wout = wout; g.Cout = s.cout; g.ldc = s.cout; g.relu = 1;
       g.tag = MAGAT_TAG_BLOCK_CONV + 2 * l;
-      if (split && l == 2) {     // bf16x6 split-MFMA kernel: float32 activations split by its loader, bf16x3 weights
-        g.in_fmt = 2; g.wt = pk + d->off[18];
+      if (split >> l & 1) {      // bf16x6 split-MFMA kernel: float32 activations split by its loader, bf16x3 weights
+        g.in_fmt = 2; g.wt = pk + d->off[18 + 2 * l];
       }
       rc = magat_conv_gemm_f32(&g, stream);
       if (rc != MAGAT_OK) return rc;
@@ -227,8 +231,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       h.Hout = hout; h.Wout = wout; h.C2 = s.cin; h.lda2 = s.cin; h.W2 = win; h.stride2 = s.stride;
       h.Cout = s.cout; h.ldc = s.cout; h.relu = 1;
       h.tag = MAGAT_TAG_BLOCK_CONV + 2 * l + 1;
-      if (split && l == 2) {
-        h.in_fmt = 2; h.wt = pk + d->off[19];
+      if (split >> l & 1) {
+        h.in_fmt = 2; h.wt = pk + d->off[19 + 2 * l];
       }
       rc = magat_conv_gemm_f32(&h, stream);
       if (rc != MAGAT_OK) return rc;

@@ -475,6 +475,8 @@ __global__ void pack_kernel(const float* __restrict__ weight, const float* __res
                             float* __restrict__ packed, int G, int F, int K, int P, int mode, PackLayout L) {
   float* Bt = packed;
   float* cb = packed + (long long)L.NC * G;
+  // bf16x3 planes of Bt for the split-MFMA GEMM (raw bf16 bits), 16-byte aligned behind the column bias
+  unsigned short* Bs = reinterpret_cast<unsigned short*>(packed + (((long long)L.NC * (G + 1) + 3) & ~3LL));
   const long long total = (long long)L.NC * G;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total + L.NC;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -501,6 +503,12 @@ __global__ void pack_kernel(const float* __restrict__ weight, const float* __res
         v = fmaf(mixer[(long long)hp * 2 * F + which * F + f], weight[((long long)hp * F + f) * G + g], v);
     }
     Bt[idx] = v;
+    const unsigned short h1 = magat_bf16_rne(v);
+    const float r1 = v - magat_bf16_f32(h1);
+    const unsigned short h2 = magat_bf16_rne(r1);
+    Bs[idx] = h1;
+    Bs[total + idx] = h2;
+    Bs[2 * total + idx] = magat_bf16_rne(r1 - magat_bf16_f32(h2));
   }
 }
 
@@ -562,7 +570,29 @@ extern "C" int magat_gat_set_debug_buffer(long long* dev_buf) {
 extern "C" size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode) {
   if (G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
   const PackLayout L = pack_layout(G, F, K, P, mode);
-  return (size_t)L.NC * (G + 1);
+  return (((size_t)L.NC * (G + 1) + 3) & ~(size_t)3) + ((size_t)3 * L.NC * G + 1) / 2;
+}
+
+// hoisted dense maps Z = X @ Bt^T + colbias: bf16x6 split-MFMA GEMM when the shape allows, else fp32 MFMA
+static int gat_maps_gemm(const float* X, const float* packed, float* Z, int M, int G, const PackLayout& L,
+                         void* stream) {
+  static int use_split = -1;
+  if (use_split < 0) {
+    const char* e = getenv("MAGAT_GAT_SPLIT");
+    use_split = e ? atoi(e) : 1;
+  }
+  if (use_split && L.NC % 32 == 0 && G % 32 == 0) {
+    magat_conv_gemm_desc d = {};
+    d.in = X;
+    d.wt = packed + (((size_t)L.NC * (G + 1) + 3) & ~(size_t)3);
+    d.bias = packed + (size_t)L.NC * G;
+    d.out = Z;
+    d.M = M; d.Cin = G; d.lda = G; d.Hin = d.Win = 1; d.kH = d.kW = 1; d.stride = 1; d.Hout = d.Wout = 1;
+    d.Cout = L.NC; d.ldc = L.NC; d.tag = MAGAT_TAG_GAT_MAPS; d.in_fmt = 2;
+    return magat_conv_gemm_f32(&d, stream);
+  }
+  return magat_linear_tagged_f32(X, G, packed, packed + (size_t)L.NC * G, Z, L.NC, M, L.NC, G, 0, MAGAT_TAG_GAT_MAPS,
+                                 stream);
 }
 
 extern "C" int magat_gat_pack_weights(const float* weight, const float* weight_bias, const float* mixer,
@@ -643,8 +673,7 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
 
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int cb = (B - b0) < chunk ? (B - b0) : chunk;
-    int rc = magat_linear_tagged_f32(X + (size_t)b0 * N * G, G, packed, packed + (size_t)L.NC * G, Z, L.NC, cb * N,
-                                     L.NC, G, 0, MAGAT_TAG_GAT_MAPS, stream);
+    int rc = gat_maps_gemm(X + (size_t)b0 * N * G, packed, Z, cb * N, G, L, stream);
     if (rc != MAGAT_OK) return rc;
     p.B = cb; p.b0 = b0;
     if (use_list) {     // sparse instances: structure pass + list kernel; dense ones stay flagged for the kernel below

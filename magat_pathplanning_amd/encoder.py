@@ -12,8 +12,8 @@ the "encoder pack" consumed by magat_encoder_forward_f32 (include/magat_hip.h):
           the GEMM sum-pools the 2x2 windows while loading its A operand)
   off[15] head bias [n_feat]
   off[16] compressMLP weight [G][n_feat]                   off[17] compressMLP bias [G]
-  off[18] layer3.conv1 weight as bf16x3 planes [3][128][9*64]      (raw bf16 bits, ResNetLarge only)
-  off[19] layer3.[conv2|downsample] weight as bf16x3 planes [3][128][9*128+64]
+  off[18+2l] layer(l+1).conv1 weight as bf16x3 planes [3][Cout][9*Cin]            (raw bf16 bits)
+  off[19+2l] layer(l+1).[conv2|downsample] weight as bf16x3 planes [3][Cout][9*Cout+Cin]
 
 Every offset is a multiple of 4 floats.  Folding is done in float64 and stored as float32.
 """
@@ -98,12 +98,15 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
         put(17, compress[1].detach().cpu().double())
         n_comp = compress[0].shape[0]
     pack = torch.cat(parts).to(torch.float32).contiguous()
-    if large:
-        # layer-3 weights once more as bf16x3 planes (raw bf16 bits stored inside the float32 pack) for the
-        # split-MFMA kernel (csrc/conv_gemm_bf16x6.hip): off[18] = layer3.conv1, off[19] = layer3.[conv2|downsample]
+    if True:
+        # block-conv weights once more as bf16x3 planes (raw bf16 bits stored inside the float32 pack) for the
+        # split-MFMA kernel (csrc/conv_gemm_bf16x6.hip): off[18+2l] = layer(l+1).conv1, off[19+2l] = [conv2|downsample]
         raws = []
         cursor_f = pack.numel()
-        for slot, src in ((18, 2 + 4 * 2), (19, 4 + 4 * 2)):
+        pairs = []
+        for l in range(nblocks):
+            pairs += [(18 + 2 * l, 2 + 4 * l), (19 + 2 * l, 4 + 4 * l)]
+        for slot, src in pairs:
             nxt = sorted(o for o in offs if o > offs[src])
             end = nxt[0] if nxt else pack.numel()
             w32 = pack[offs[src]:end]

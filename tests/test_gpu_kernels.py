@@ -237,7 +237,8 @@ def test_gat_mixed_density_batch_list_and_dense_kernels(gpu_device, mode, concat
     np.testing.assert_allclose(layer.aij.cpu().numpy(), a_ref.numpy(), rtol=0, atol=3e-6)
 
 
-@pytest.mark.parametrize("cin,cout,c2,M", [(64, 128, 0, 200), (128, 128, 64, 131), (32, 128, 32, 64)])
+@pytest.mark.parametrize("cin,cout,c2,M", [(64, 128, 0, 200), (128, 128, 64, 131), (32, 128, 32, 64), (32, 64, 0, 130),
+                                           (64, 64, 32, 77), (32, 32, 32, 129), (32, 32, 0, 40)])
 def test_conv_gemm_bf16x6_split_mfma_matches_fp64(gpu_device, cin, cout, c2, M):
     """bf16x6 split-MFMA conv (3 bf16 planes per operand, six partial products) is fp32-accurate: compared with an
     fp64 conv2d of the same fp32 inputs; also checks the 3-plane output format round trip."""

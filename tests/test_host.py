@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
     assert lib.magat_abi_version() == 1
     assert lib.magat_error_string(-2).decode().startswith("unsupported")
     # pure host queries work without a device
-    assert lib.magat_gat_packed_floats(128, 128, 3, 4, 0) == (4 * 128 + 4 * 3 * 128) * 129
+    nc = 4 * 128 + 4 * 3 * 128            # fp32 [NC][G] + column bias [NC] + bf16x3 planes [3][NC][G]
+    assert lib.magat_gat_packed_floats(128, 128, 3, 4, 0) == nc * 129 + 3 * nc * 128 // 2
     assert lib.magat_gat_workspace_bytes(2, 10, 128, 128, 2, 1, 0, 1) >= 2 * 10 * 384 * 4
 
 
