@@ -8,7 +8,7 @@ cd $R
 python - <<PY
 import csv, glob, collections
 SEQ = ["conv_first", "l1.conv1", "l1.conv2+ds", "l2.conv1", "l2.conv2+ds", "l3.conv1", "l3.conv2+ds", "head", "compress", "gat_maps", "gat_graph", "actions"]
-ours = ("conv_gemm_kernel", "conv_first_kernel", "gat_dense_kernel")
+ours = ("conv_gemm_kernel", "conv_gemm_bf16x6_kernel", "conv_first_kernel", "gat_dense_kernel")
 for f in sorted(glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True)):
     rows = [r for r in csv.DictReader(open(f)) if any(o in r["Kernel_Name"] for o in ours)]
     ctrs = sorted(set(r["Counter_Name"] for r in rows))

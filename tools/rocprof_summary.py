@@ -11,9 +11,15 @@ from collections import defaultdict
 
 
 def short(name):
-    for key, s in (("conv_gemm_kernel<128, 128, 2, 2, true>", "conv_gemm<128,128,pool>"),
-                   ("conv_gemm_kernel<128, 128", "conv_gemm<128,128>"), ("conv_gemm_kernel<128, 64", "conv_gemm<128,64>"),
-                   ("conv_gemm_kernel<128, 32", "conv_gemm<128,32>"), ("conv_first_kernel", "conv_first"),
+    for key, s in (("conv_gemm_bf16x6_kernel<true, 128", "conv_gemm_bf16x6<f32-in,128>"),
+                   ("conv_gemm_bf16x6_kernel<true, 64", "conv_gemm_bf16x6<f32-in,64>"),
+                   ("conv_gemm_bf16x6_kernel<true, 32", "conv_gemm_bf16x6<f32-in,32>"),
+                   ("conv_gemm_bf16x6_kernel<false", "conv_gemm_bf16x6<planes>"),
+                   ("conv_gemm_kernel<64, 128, 2, 2, true", "conv_gemm_f32<64,128,pool>"),
+                   ("conv_gemm_kernel<128, 128, 2, 2, true", "conv_gemm_f32<128,128,pool>"),
+                   ("conv_gemm_kernel<64, 128", "conv_gemm_f32<64,128>"),
+                   ("conv_gemm_kernel<128, 128", "conv_gemm_f32<128,128>"), ("conv_gemm_kernel<128, 64", "conv_gemm_f32<128,64>"),
+                   ("conv_gemm_kernel<128, 32", "conv_gemm_f32<128,32>"), ("conv_first_kernel", "conv_first"),
                    ("gat_dense_kernel", "gat_dense_kernel"), ("head_mean_relu", "head_mean_relu"),
                    ("pack_kernel", "gat_pack"), ("gso_prepare", "gso_prepare")):
         if key in name:
@@ -59,7 +65,7 @@ def main():
     # per-layer split: our library launches a fixed 12-kernel sequence per addGSO+forward step (c3 workload)
     SEQ = ["conv_first", "layer1.conv1", "layer1.conv2+ds", "layer2.conv1", "layer2.conv2+ds", "layer3.conv1",
            "layer3.conv2+ds", "head(avgpool+fc+linear)", "compressMLP", "gat_maps_gemm", "gat_graph", "actionsMLP"]
-    ours = ("conv_gemm_kernel", "conv_first_kernel", "gat_dense_kernel")
+    ours = ("conv_gemm_kernel", "conv_gemm_bf16x6_kernel", "conv_first_kernel", "gat_dense_kernel")
     layers = defaultdict(dict)
     tr = find(os.path.join(out, "trace"), "*kernel_trace.csv")
     if tr:
