@@ -120,7 +120,8 @@ typedef struct magat_conv_gemm_desc {
   int tag;    /* MAGAT_TAG_* used by the optional profiling hooks (0 = untagged) */
   int pool;   /* 1: `in` is read through a 2x2 SUM-pool: logical pixel (iy,ix) of the Hin x Win map =
                  sum of physical pixels (2iy+{0,1}, 2ix+{0,1}) of a map that is pool_w pixels wide
-                 (AvgPool2d(2) of resnet_pytorch.py:450 with the 1/4 folded into wt) */
+                 (AvgPool2d(2) of resnet_pytorch.py:450 with the 1/4 folded into wt);
+                 2: same addressing with MAX (nn.MaxPool2d(2) of decentralplanner_GAT_bottleneck.py:137) */
   int pool_w;
   /* Operand formats.  0 = float32.  1 = "bf16x3": every value carried as three bf16 planes x1+x2+x3 (fp32-exact
    * to 2^-24), plane p at base + p * *_plane_stride elements; with in_fmt = 1 the GEMM runs on the bf16 matrix
@@ -149,7 +150,10 @@ int magat_conv_first_f32(const float* x, const float* wt, const float* bias, flo
 /* ------------------------------------------------------------------------------------------
  * Whole per-agent encoder  ConvLayers (+Flatten+Linear for *_withMLP) -> compressMLP
  * (decentralplanner_GAT_bottleneck.py:90-166, 291-302) from a BN-folded parameter pack.
- * variant: 0 = ResNet(BasicBlock,[1,1,1]) "ResNetLarge", 1 = ResNetSlim(BasicBlock,[1,1]).
+ * variant: 0 = ResNet(BasicBlock,[1,1,1]) "ResNetLarge", 1 = ResNetSlim(BasicBlock,[1,1]),
+ * 2 = CNN_mode "Default": 5 x [conv3x3(bias)+BN+ReLU], MaxPool2d(2) after layers 0, 2, 4
+ * (decentralplanner_GAT_bottleneck.py:118-147); pack: off[0..1] conv0, off[2+2i], off[3+2i] weight/bias of conv i+1
+ * (i = 0..3), off[14] 128x128 identity (final max-pool as a pooled 1x1 GEMM), off[16..17] compressMLP.
  * The pack layout is produced by magat_pathplanning_amd.encoder.fold_resnet (documented there
  * and in DESIGN.md); offsets are passed explicitly so the ABI does not hard-code it.
  */

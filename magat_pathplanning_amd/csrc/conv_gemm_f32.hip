@@ -38,7 +38,8 @@ struct ConvGemmParams {
   int Cout, Ktot, ldc, relu;
   int ntn, npix;
   int tag;
-  int pool_w;   // POOL: physical input width (input pixel (iy,ix) = sum of the 2x2 physical pixels)
+  int pool_w;   // POOL: physical input width (input pixel (iy,ix) = sum or max of the 2x2 physical pixels)
+  int pool_max; // POOL: 0 = sum (AvgPool2d with 1/4 in the weights), 1 = max (MaxPool2d)
   int out_split;            // epilogue writes three bf16 planes (out_plane elements apart) instead of float32
   long long out_plane;
 };
@@ -148,9 +149,11 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
         const char* src = ab + (main_seg ? aoff[i] : aoff2[i]);
         f32x4 v = *reinterpret_cast<const f32x4*>(src);
         if (POOL && main_seg) {
-          v += *reinterpret_cast<const f32x4*>(src + 4 * p.in_pix_stride);
-          v += *reinterpret_cast<const f32x4*>(src + 4 * (long long)p.pool_w * p.in_pix_stride);
-          v += *reinterpret_cast<const f32x4*>(src + 4 * (long long)(p.pool_w + 1) * p.in_pix_stride);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4 * p.in_pix_stride);
+          const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + 4 * (long long)p.pool_w * p.in_pix_stride);
+          const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + 4 * (long long)(p.pool_w + 1) * p.in_pix_stride);
+          v = p.pool_max ? __builtin_elementwise_max(__builtin_elementwise_max(v, v1), __builtin_elementwise_max(v2, v3))
+                         : v + v1 + v2 + v3;
         }
         ra[i] = v;
       }
@@ -166,10 +169,12 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
       if (kok && m < p.M) {
         const float* src = abase + (long long)m * lda + c4 * 4;
         v = *reinterpret_cast<const f32x4*>(src);
-        if (POOL && main_seg) {   // 2x2 sum-pool on load (the 1/4 lives in the weights)
-          v += *reinterpret_cast<const f32x4*>(src + p.in_pix_stride);
-          v += *reinterpret_cast<const f32x4*>(src + (long long)p.pool_w * p.in_pix_stride);
-          v += *reinterpret_cast<const f32x4*>(src + (long long)(p.pool_w + 1) * p.in_pix_stride);
+        if (POOL && main_seg) {   // 2x2 pool on load (sum: the 1/4 lives in the weights; or max)
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + p.in_pix_stride);
+          const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (long long)p.pool_w * p.in_pix_stride);
+          const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + (long long)(p.pool_w + 1) * p.in_pix_stride);
+          v = p.pool_max ? __builtin_elementwise_max(__builtin_elementwise_max(v, v1), __builtin_elementwise_max(v2, v3))
+                         : v + v1 + v2 + v3;
         }
       }
       ra[i] = v;
@@ -367,8 +372,9 @@ extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) 
   p.out_split = d->out_fmt == 1;
   p.out_plane = d->out_plane_stride;
   p.pool_w = 0;
-  if (d->pool) {   // input map is the 2x2 sum-pool of a physical (2*Hin.. x pool_w) map
-    if (d->pool_w < 2 * d->Win) return MAGAT_ERR_BAD_SHAPE;
+  p.pool_max = d->pool == 2;
+  if (d->pool) {   // input map is the 2x2 sum- or max-pool of a physical (2*Hin.. x pool_w) map
+    if (d->pool_w < 2 * d->Win || (d->pool != 1 && d->pool != 2)) return MAGAT_ERR_BAD_SHAPE;
     p.pool_w = d->pool_w;
   }
   if ((p.in_pix_stride & 3) || (p.in2_pix_stride & 3)) return MAGAT_ERR_BAD_SHAPE;

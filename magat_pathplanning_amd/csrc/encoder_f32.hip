@@ -166,6 +166,7 @@ static int enc_split_mask(const magat_encoder_desc* d) {
 
 // floats per agent of one rotating activation buffer
 static size_t enc_buf_floats_per_agent(const magat_encoder_desc* d) {
+  if (d->variant == 2) return (size_t)d->H * d->W * 32;    // Default CNN: the first map is the largest
   const int Ho = (d->H + 2 - 3) / 2 + 1, Wo = (d->W + 2 - 3) / 2 + 1;
   const size_t a0 = (size_t)d->H * d->W * 32;
   const size_t a3 = (size_t)Ho * Wo * (d->variant == 0 ? 128 : 64);
@@ -183,7 +184,7 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
                                          void* stream) {
   if (!d || !x || !feat || !d->pack) return MAGAT_ERR_NULL;
   if (M <= 0 || d->H < 3 || d->W < 3 || d->n_feat <= 0) return MAGAT_ERR_BAD_SHAPE;
-  if (d->variant != 0 && d->variant != 1) return MAGAT_ERR_UNSUPPORTED;
+  if (d->variant < 0 || d->variant > 2) return MAGAT_ERR_UNSUPPORTED;
   if (d->n_comp > 0 && !comp) return MAGAT_ERR_NULL;
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) ||
       workspace_bytes < magat_encoder_workspace_bytes(d, M))
@@ -198,6 +199,48 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   const BlockShape shapes[3] = {{32, 32, 2}, {32, 64, 1}, {64, 128, 1}};
   const int nblocks = d->variant == 0 ? 3 : 2;
   const int split = enc_split_mask(d);
+
+  if (d->variant == 2) {     // CNN_mode Default: conv-BN-ReLU x5 with MaxPool2d(2) after layers 0, 2, 4
+    if (d->n_feat != 128) return MAGAT_ERR_BAD_SHAPE;
+    const int chans[6] = {3, 32, 32, 64, 64, 128};
+    for (int m0 = 0; m0 < M; m0 += mc) {
+      const int mm = (M - m0) < mc ? (M - m0) : mc;
+      int rc = magat_conv_first_f32(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W, stream);
+      if (rc != MAGAT_OK) return rc;
+      int cur = 0, hp = H, wp = W;          // physical size of the map in buf[cur]
+      for (int l = 1; l < 5; ++l) {
+        const bool pooled = (l - 1) % 2 == 0;                 // the previous layer (0, 2) was followed by a pool
+        const int hin = pooled ? hp / 2 : hp, win = pooled ? wp / 2 : wp;
+        magat_conv_gemm_desc g = {};
+        g.in = buf[cur]; g.wt = pk + d->off[2 + 2 * (l - 1)]; g.bias = pk + d->off[3 + 2 * (l - 1)];
+        g.out = buf[(cur + 1) % 3];
+        g.in_pix_stride = (int64_t)mm * chans[l]; g.out_pix_stride = (int64_t)mm * chans[l + 1];
+        g.M = mm; g.Cin = chans[l]; g.lda = chans[l]; g.Hin = hin; g.Win = win; g.kH = g.kW = 3; g.stride = 1; g.pad = 1;
+        g.Hout = hin; g.Wout = win; g.Cout = chans[l + 1]; g.ldc = chans[l + 1]; g.relu = 1;
+        g.tag = MAGAT_TAG_BLOCK_CONV + (l - 1);
+        if (pooled) { g.pool = 2; g.pool_w = wp; }
+        rc = magat_conv_gemm_f32(&g, stream);
+        if (rc != MAGAT_OK) return rc;
+        cur = (cur + 1) % 3; hp = hin; wp = win;
+      }
+      // final MaxPool2d(2) -> [mm][128]: pooled 1x1 GEMM with identity weights
+      magat_conv_gemm_desc g = {};
+      g.in = buf[cur]; g.wt = pk + d->off[14]; g.out = feat + (size_t)m0 * ldfeat;
+      g.in_pix_stride = (int64_t)mm * 128; g.M = mm; g.Cin = 128; g.lda = 128; g.Hin = hp / 2; g.Win = wp / 2;
+      g.kH = hp / 2; g.kW = wp / 2; g.stride = 1; g.pad = 0; g.Hout = g.Wout = 1; g.Cout = 128; g.ldc = ldfeat;
+      g.pool = 2; g.pool_w = wp; g.tag = MAGAT_TAG_HEAD;
+      if (hp / 2 != 1 || wp / 2 != 1) return MAGAT_ERR_UNSUPPORTED;   // FOV 9 (11x11 input) geometry
+      rc = magat_conv_gemm_f32(&g, stream);
+      if (rc != MAGAT_OK) return rc;
+      if (d->n_comp > 0) {
+        rc = magat_linear_tagged_f32(feat + (size_t)m0 * ldfeat, ldfeat, pk + d->off[16], pk + d->off[17],
+                                     comp + (size_t)m0 * ldcomp, ldcomp, mm, d->n_comp, d->n_feat, 1,
+                                     MAGAT_TAG_COMPRESS, stream);
+        if (rc != MAGAT_OK) return rc;
+      }
+    }
+    return MAGAT_OK;
+  }
 
   for (int m0 = 0; m0 < M; m0 += mc) {
     const int mm = (M - m0) < mc ? (M - m0) : mc;

@@ -131,3 +131,44 @@ def split_bf16x3(t):
     p1 = r.bfloat16()
     p2 = (r - p1.float()).bfloat16()
     return torch.stack((p0, p1, p2), dim=0).contiguous()
+
+
+def fold_default_cnn(sd, H=11, W=11, pre="ConvLayers", compress=None):
+    """CNN_mode "Default" (decentralplanner_GAT_bottleneck.py:118-147): 5 x [Conv2d(bias) + BatchNorm2d + ReLU] with
+    MaxPool2d(2) after layers 0, 2, 4.  Sequential indices: conv at 0, 4, 7, 11, 14 (bn = conv+1).  Pack (variant 2):
+    off[0..1] conv0 [32][27] / bias, off[2+2i], off[3+2i] conv i+1 weight [Cout][9*Cin] / bias, off[14] identity
+    [128][128] (the last max-pool runs as a pooled 1x1 GEMM), off[16..17] compressMLP."""
+    sd = {k: v.detach().cpu() for k, v in sd.items() if k.startswith(pre)}
+    parts, offs, cursor = [], [0] * 32, [0]
+
+    def put(slot, t):
+        t = t.reshape(-1).double()
+        offs[slot] = cursor[0]
+        pad = (-t.numel()) % 4
+        if pad:
+            t = torch.cat((t, torch.zeros(pad, dtype=t.dtype)))
+        parts.append(t)
+        cursor[0] += t.numel()
+
+    idx, convs = 0, []
+    for l in range(5):
+        convs.append(idx)
+        idx += 3 + (1 if l % 2 == 0 else 0)
+    for l, ci in enumerate(convs):
+        w, b = sd["%s.%d.weight" % (pre, ci)].double(), sd["%s.%d.bias" % (pre, ci)].double()
+        s, sh = _bn_scale_shift(sd, "%s.%d" % (pre, ci + 1))
+        bias = b * s + sh
+        if l == 0:
+            put(0, w.reshape(32, 27) * s.view(-1, 1))
+            put(1, bias)
+        else:
+            put(2 + 2 * (l - 1), _conv_rows(w, s))
+            put(3 + 2 * (l - 1), bias)
+    put(14, torch.eye(128, dtype=torch.float64))
+    n_comp = 0
+    if compress is not None:
+        put(16, compress[0].detach().cpu().double())
+        put(17, compress[1].detach().cpu().double())
+        n_comp = compress[0].shape[0]
+    pack = torch.cat(parts).to(torch.float32).contiguous()
+    return pack, offs, dict(variant=2, H=H, W=W, n_feat=128, n_comp=n_comp, clast=128)

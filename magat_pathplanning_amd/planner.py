@@ -205,6 +205,17 @@ class DecentralPlannerGATNet(nn.Module):
             for i, o in enumerate(offs):
                 d.off[i] = o
             rt.desc = d
+        elif self.config.FOV + 2 == 11:
+            pack, offs, meta = enc.fold_default_cnn(sd, 11, 11, "ConvLayers",
+                                                    (sd["compressMLP.0.weight"], sd["compressMLP.0.bias"]))
+            rt.pack = pack.to(dev)
+            d = nat.EncoderDesc()
+            d.variant, d.H, d.W = meta["variant"], meta["H"], meta["W"]
+            d.n_feat, d.n_comp = meta["n_feat"], meta["n_comp"]
+            d.pack = rt.pack.data_ptr()
+            for i, o in enumerate(offs):
+                d.off[i] = o
+            rt.desc = d
         # actionsMLP first layer: [w_skip | w_gat] -> in (skip source) + in2 (GAT output) K segments
         w0 = sd["actionsMLP.0.weight"].to(dev, torch.float32)
         if self.skip == "skipAddGNN":
@@ -249,7 +260,8 @@ class DecentralPlannerGATNet(nn.Module):
                                                         nat.ptr(comp), G, nat.ptr(rt.ws), rt.ws.numel(), M, stream),
                           "magat_encoder_forward_f32")
             else:
-                # CNN_mode=Default (conv+BN+ReLU+MaxPool stack): torch/MIOpen ops, then our compressMLP GEMM
+                # CNN_mode=Default at a FOV other than 9 (the max-pool-on-load HIP path assumes the 11x11 geometry):
+                # torch/MIOpen convs, then our compressMLP GEMM
                 f = self.ConvLayers(x)
                 feat.copy_(f.view(M, -1))
                 nat.check(lib.magat_linear_f32(nat.ptr(feat), nfm, nat.ptr(rt.cw), nat.ptr(rt.cb), nat.ptr(comp), G,
