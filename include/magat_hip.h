@@ -131,6 +131,12 @@ typedef struct magat_conv_gemm_desc {
    * form. */
   int in_fmt, out_fmt;
   int64_t in_plane_stride, in2_plane_stride, out_plane_stride;
+  /* Agent-tile strides (elements).  Row m of a pixel lives at  (m / 128) * tile_stride + (m % 128) * ld.
+   * 0 = 128 * ld, i.e. plain row-major [M][ld] per pixel (and pixel planes *_pix_stride apart: "pixel-major").
+   * The encoder uses the TILE-major form [agent tile][pixel][128][C] (pix_stride = 128*C, tile_stride =
+   * npix*128*C): everything a workgroup touches is one contiguous ~0.5-2 MB run instead of <= 121 pieces a
+   * multi-MB plane stride apart (channel/TLB-aliasing hazard of the plane form on large batches). */
+  int64_t in_tile_stride, in2_tile_stride, out_tile_stride;
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 
@@ -146,6 +152,9 @@ int magat_linear_tagged_f32(const float* x, int ldx, const float* w, const float
  * (index c*9+ty*3+tx), bias [32]. */
 int magat_conv_first_f32(const float* x, const float* wt, const float* bias, float* out, int M, int H,
                          int W, void* stream);
+/* same, writing the TILE-major form [agent tile of 128][H*W][128][32] (out must hold ceil(M/128) full tiles) */
+int magat_conv_first_tiled_f32(const float* x, const float* wt, const float* bias, float* out, int M, int H,
+                               int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Whole per-agent encoder  ConvLayers (+Flatten+Linear for *_withMLP) -> compressMLP

@@ -39,7 +39,9 @@ class ConvGemmDesc(ctypes.Structure):
                 ("pool", ctypes.c_int), ("pool_w", ctypes.c_int),
                 ("in_fmt", ctypes.c_int), ("out_fmt", ctypes.c_int),
                 ("in_plane_stride", ctypes.c_int64), ("in2_plane_stride", ctypes.c_int64),
-                ("out_plane_stride", ctypes.c_int64)]
+                ("out_plane_stride", ctypes.c_int64),
+                ("in_tile_stride", ctypes.c_int64), ("in2_tile_stride", ctypes.c_int64),
+                ("out_tile_stride", ctypes.c_int64)]
 
 
 class EncoderDesc(ctypes.Structure):
@@ -72,6 +74,7 @@ _SIGNATURES = {
     "magat_profile_read": (_I, [_I, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),
     "magat_profile_reset": (_I, []),
     "magat_conv_first_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "magat_conv_first_tiled_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "magat_encoder_workspace_bytes": (_Z, [ctypes.POINTER(EncoderDesc), _I]),
     "magat_encoder_forward_f32": (_I, [ctypes.POINTER(EncoderDesc), _P, _P, _I, _P, _I, _P, _Z, _I, _P]),
 }

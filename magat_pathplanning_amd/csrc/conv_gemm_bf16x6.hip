@@ -32,6 +32,7 @@ struct SplitParams {
   const float* bias;
   void* out;
   long long in_pix_stride, in2_pix_stride, out_pix_stride;
+  long long in_tile, in2_tile, out_tile;
   long long in_plane, in2_plane, out_plane, wt_plane;
   int M, Mt;
   int Cin, lda, Hin, Win, kH, kW, stride, pad, Hout, Wout;
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = min(m0 + lrow + 64 * i, p.M - 1);
-    aoff[i] = (unsigned)(((long long)m * p.lda + lchunk * 8) * 2);
-    aoff2[i] = (unsigned)(((long long)m * p.lda2 + lchunk * 8) * 2);
+    aoff[i] = (unsigned)((magat_row_off(m, p.lda, p.in_tile) + lchunk * 8) * 2);
+    aoff2[i] = (unsigned)((magat_row_off(m, p.lda2, p.in2_tile) + lchunk * 8) * 2);
     const int nrow = min(lrow + 64 * i, BN - 1);      // BN = 32: upper half of the threads duplicate row BN-1
     boff[i] = (unsigned)(((long long)(n0 + nrow) * p.Ktot + lchunk * 8) * 2);
     const int row = lrow + 64 * i;
@@ -118,8 +119,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = min(m0 + fr0 + 32 * i, p.M - 1);
-    faoff[i] = (unsigned)(((long long)m * p.lda + fc4 * 4) * 4);
-    faoff2[i] = (unsigned)(((long long)m * p.lda2 + fc4 * 4) * 4);
+    faoff[i] = (unsigned)((magat_row_off(m, p.lda, p.in_tile) + fc4 * 4) * 4);
+    faoff2[i] = (unsigned)((magat_row_off(m, p.lda2, p.in2_tile) + fc4 * 4) * 4);
     const int row = fr0 + 32 * i;
     floff[i] = (unsigned)((row * 4 + ((fc4 >> 1) ^ ((row >> 2) & 3))) * 16 + (fc4 & 1) * 8);
   }
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
           v[c] = acc[i][j][4 * q + c] + (p.bias ? p.bias[n + c] : 0.f);
           if (p.relu) v[c] = fmaxf(v[c], 0.f);
         }
-        const long long o = (long long)pix * p.out_pix_stride + (long long)m * p.ldc + n;
+        const long long o = (long long)pix * p.out_pix_stride + magat_row_off(m, p.ldc, p.out_tile) + n;
         if (p.out_split) {
           u16* ob = static_cast<u16*>(p.out);
           u16 h[3][4];
@@ -314,6 +315,10 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.out = d->out;
   p.in_pix_stride = d->in_pix_stride; p.in2_pix_stride = d->in2_pix_stride; p.out_pix_stride = d->out_pix_stride;
   p.in_plane = d->in_plane_stride; p.in2_plane = d->in2_plane_stride; p.out_plane = d->out_plane_stride;
+  p.in_tile = d->in_tile_stride ? d->in_tile_stride : (long long)MAGAT_TILE_ROWS * d->lda;
+  p.in2_tile = d->in2_tile_stride ? d->in2_tile_stride : (long long)MAGAT_TILE_ROWS * d->lda2;
+  p.out_tile = d->out_tile_stride ? d->out_tile_stride : (long long)MAGAT_TILE_ROWS * d->ldc;
+  if ((p.in_tile & 7) || (p.in2_tile & 7)) return MAGAT_ERR_BAD_SHAPE;
   p.M = d->M; p.Cin = d->Cin; p.lda = d->lda; p.Hin = d->Hin; p.Win = d->Win; p.kH = d->kH; p.kW = d->kW;
   p.stride = d->stride; p.pad = d->pad; p.Hout = d->Hout; p.Wout = d->Wout;
   p.C2 = d->C2; p.lda2 = d->lda2; p.W2 = d->W2; p.stride2 = d->stride2;
@@ -322,7 +327,8 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.npix = d->Hout * d->Wout; p.tag = d->tag; p.out_split = d->out_fmt == 1;
   p.Mt = (p.M + BM - 1) / BM;
   p.ntn = p.Cout / BN;
-  if ((long long)p.M * (p.lda > p.lda2 ? p.lda : p.lda2) * 4 >= 0xffffffffLL ||
+  if (magat_row_off(p.M, p.lda, p.in_tile) * 4 >= 0xffffffffLL ||
+      (p.C2 > 0 && magat_row_off(p.M, p.lda2, p.in2_tile) * 4 >= 0xffffffffLL) ||
       (long long)p.Cout * p.Ktot * 2 >= 0xffffffffLL)
     return MAGAT_ERR_UNSUPPORTED;
   const long long groups = (p.Mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD;

@@ -32,6 +32,7 @@ struct ConvGemmParams {
   const float* bias;
   float* out;
   long long in_pix_stride, in2_pix_stride, out_pix_stride;
+  long long in_tile, in2_tile, out_tile;   // agent-tile strides (magat_row_off)
   int M, Mt;
   int Cin, lda, Hin, Win, kH, kW, stride, pad, Hout, Wout;
   int C2, lda2, W2, stride2;
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
   unsigned aoff[AI], aoff2[AI], boff[BI];   // FULL path: per-thread byte offsets
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    aoff[i] = (unsigned)(((long long)(m0 + r0 + 32 * i) * p.lda + c4 * 4) * 4);
-    aoff2[i] = (unsigned)(((long long)(m0 + r0 + 32 * i) * p.lda2 + c4 * 4) * 4);
+    aoff[i] = (unsigned)((magat_row_off(m0 + r0 + 32 * i, p.lda, p.in_tile) + c4 * 4) * 4);
+    aoff2[i] = (unsigned)((magat_row_off(m0 + r0 + 32 * i, p.lda2, p.in2_tile) + c4 * 4) * 4);
   }
 #pragma unroll
   for (int i = 0; i < BI; ++i) boff[i] = (unsigned)(((long long)(n0 + r0 + 32 * i) * p.Ktot + c4 * 4) * 4);
@@ -117,13 +118,14 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
   auto load_slab = [&](int s) {
     (void)s;
     const float* abase;
-    long long lda;
+    long long lda, atile;
     int bk, kvalid;
     const bool main_seg = cur_main;
     const int k0 = cur_ks * BK;
     if (main_seg) {
       abase = cur_tap + k0;
       lda = p.lda;
+      atile = p.in_tile;
       bk = (cur_ty * p.kW + cur_tx) * p.Cin + k0;
       kvalid = p.Cin - k0;
       if (++cur_ks == spt) {
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
     } else {
       abase = seg2_base + k0;
       lda = p.lda2;
+      atile = p.in2_tile;
       bk = p.kH * p.kW * p.Cin + k0;
       kvalid = p.C2 - k0;
       ++cur_ks;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
       const int m = m0 + r0 + 32 * i;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (kok && m < p.M) {
-        const float* src = abase + (long long)m * lda + c4 * 4;
+        const float* src = abase + magat_row_off(m, lda, atile) + c4 * 4;
         v = *reinterpret_cast<const f32x4*>(src);
         if (POOL && main_seg) {   // 2x2 pool on load (sum: the 1/4 lives in the weights; or max)
           const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + p.in_pix_stride);
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
           v[c] = acc[i][j][4 * q + c] + ((nok && p.bias) ? p.bias[n + c] : 0.f);
           if (p.relu) v[c] = fmaxf(v[c], 0.f);
         }
-        const long long o = (long long)m * p.ldc + n;
+        const long long o = magat_row_off(m, p.ldc, p.out_tile) + n;
         if (p.out_split) {
           unsigned short h[3][4];
 #pragma unroll
@@ -341,7 +344,8 @@ int launch(ConvGemmParams& p, hipStream_t st) {
   const long long grid = groups * MAGAT_NUM_XCD * p.npix * p.ntn;
   if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
   const bool full = p.M % BM == 0 && p.Cout % BN == 0 && p.Cin % BK == 0 && p.C2 % BK == 0 &&
-                    (long long)p.M * (p.lda > p.lda2 ? p.lda : p.lda2) * 4 < 0xffffffffLL &&
+                    magat_row_off(p.M, p.lda, p.in_tile) * 4 < 0xffffffffLL &&
+                    (p.C2 == 0 || magat_row_off(p.M, p.lda2, p.in2_tile) * 4 < 0xffffffffLL) &&
                     (long long)p.Cout * p.Ktot * 4 < 0xffffffffLL;
   return full ? launch2<BM, BN, WGM, WGN, POOL, true>(p, st, grid) : launch2<BM, BN, WGM, WGN, POOL, false>(p, st, grid);
 }
@@ -363,6 +367,10 @@ extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) 
   ConvGemmParams p;
   p.in = d->in; p.in2 = d->in2; p.wt = d->wt; p.bias = d->bias; p.out = d->out;
   p.in_pix_stride = d->in_pix_stride; p.in2_pix_stride = d->in2_pix_stride; p.out_pix_stride = d->out_pix_stride;
+  p.in_tile = d->in_tile_stride ? d->in_tile_stride : (long long)MAGAT_TILE_ROWS * d->lda;
+  p.in2_tile = d->in2_tile_stride ? d->in2_tile_stride : (long long)MAGAT_TILE_ROWS * d->lda2;
+  p.out_tile = d->out_tile_stride ? d->out_tile_stride : (long long)MAGAT_TILE_ROWS * d->ldc;
+  if ((p.in_tile & 3) || (p.in2_tile & 3)) return MAGAT_ERR_BAD_SHAPE;
   p.M = d->M; p.Cin = d->Cin; p.lda = d->lda; p.Hin = d->Hin; p.Win = d->Win; p.kH = d->kH; p.kW = d->kW;
   p.stride = d->stride; p.pad = d->pad; p.Hout = d->Hout; p.Wout = d->Wout;
   p.C2 = d->C2; p.lda2 = d->lda2; p.W2 = d->W2; p.stride2 = d->stride2;

@@ -20,7 +20,8 @@ namespace {
 template <int HC, int WC>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                          const float* __restrict__ bias, float* __restrict__ out,
-                                                         int M, int Hr, int Wr) {
+                                                         int M, int Hr, int Wr, long long out_pix_stride,
+                                                         long long out_tile_stride) {
   extern __shared__ float img[];
   const int H = HC ? HC : Hr, W = WC ? WC : Wr;
   const int PW = W + 2, PHW = (H + 2) * PW;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
     }
     const int agent = m0 + (lane & 31);
     if (agent < M) {
-      float* o = out + ((long long)pix * M + agent) * 32 + 4 * (lane >> 5);
+      float* o = out + (long long)pix * out_pix_stride + magat_row_off(agent, 32, out_tile_stride) + 4 * (lane >> 5);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 v;
@@ -132,8 +133,22 @@ struct BlockShape {
 
 }  // namespace
 
+static int conv_first_launch(const float* x, const float* wt, const float* bias, float* out, int M, int H, int W,
+                             long long pix_stride, long long tile_stride, void* stream);
+
 extern "C" int magat_conv_first_f32(const float* x, const float* wt, const float* bias, float* out, int M, int H,
                                     int W, void* stream) {
+  return conv_first_launch(x, wt, bias, out, M, H, W, (long long)M * 32, (long long)MAGAT_TILE_ROWS * 32, stream);
+}
+
+extern "C" int magat_conv_first_tiled_f32(const float* x, const float* wt, const float* bias, float* out, int M, int H,
+                                          int W, void* stream) {
+  return conv_first_launch(x, wt, bias, out, M, H, W, (long long)MAGAT_TILE_ROWS * 32,
+                           (long long)H * W * MAGAT_TILE_ROWS * 32, stream);
+}
+
+static int conv_first_launch(const float* x, const float* wt, const float* bias, float* out, int M, int H, int W,
+                             long long pix_stride, long long tile_stride, void* stream) {
   if (!x || !wt || !bias || !out) return MAGAT_ERR_NULL;
   if (M <= 0 || H <= 0 || W <= 0) return MAGAT_ERR_BAD_SHAPE;
   const size_t lds = sizeof(float) * 32 * (size_t)((3 * (H + 2) * (W + 2)) | 1);
@@ -142,9 +157,11 @@ extern "C" int magat_conv_first_f32(const float* x, const float* wt, const float
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int pid = magat_prof_begin(MAGAT_TAG_CONV_FIRST, st);
   if (H == 11 && W == 11 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
-    hipLaunchKernelGGL((conv_first_kernel<11, 11>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W);
+    hipLaunchKernelGGL((conv_first_kernel<11, 11>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W,
+                       pix_stride, tile_stride);
   else
-    hipLaunchKernelGGL((conv_first_kernel<0, 0>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W);
+    hipLaunchKernelGGL((conv_first_kernel<0, 0>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W,
+                       pix_stride, tile_stride);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
@@ -175,7 +192,7 @@ static size_t enc_buf_floats_per_agent(const magat_encoder_desc* d) {
 
 extern "C" size_t magat_encoder_workspace_bytes(const magat_encoder_desc* d, int M) {
   if (!d || M <= 0) return 0;
-  const int mc = enc_chunk_agents(M);
+  const int mc = (enc_chunk_agents(M) + MAGAT_TILE_ROWS - 1) / MAGAT_TILE_ROWS * MAGAT_TILE_ROWS;   // whole agent tiles
   return 3 * magat_align_up(enc_buf_floats_per_agent(d) * (size_t)mc * sizeof(float), 256);
 }
 
@@ -192,7 +209,11 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   const int H = d->H, W = d->W;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int mc = enc_chunk_agents(M);
-  const size_t bstride = magat_align_up(enc_buf_floats_per_agent(d) * (size_t)mc * sizeof(float), 256) / sizeof(float);
+  const int mcp = (mc + MAGAT_TILE_ROWS - 1) / MAGAT_TILE_ROWS * MAGAT_TILE_ROWS;
+  const size_t bstride = magat_align_up(enc_buf_floats_per_agent(d) * (size_t)mcp * sizeof(float), 256) / sizeof(float);
+  // activations are TILE-major: [agent tile][pixel][128][C]
+  auto pixs = [](int c) { return (int64_t)MAGAT_TILE_ROWS * c; };
+  auto tiles = [](int npix, int c) { return (int64_t)npix * MAGAT_TILE_ROWS * c; };
   float* buf[3] = {static_cast<float*>(workspace), static_cast<float*>(workspace) + bstride,
                    static_cast<float*>(workspace) + 2 * bstride};
   const float* pk = d->pack;
@@ -205,7 +226,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
     const int chans[6] = {3, 32, 32, 64, 64, 128};
     for (int m0 = 0; m0 < M; m0 += mc) {
       const int mm = (M - m0) < mc ? (M - m0) : mc;
-      int rc = magat_conv_first_f32(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W, stream);
+      int rc = magat_conv_first_tiled_f32(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W,
+                                          stream);
       if (rc != MAGAT_OK) return rc;
       int cur = 0, hp = H, wp = W;          // physical size of the map in buf[cur]
       for (int l = 1; l < 5; ++l) {
@@ -214,7 +236,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
         magat_conv_gemm_desc g = {};
         g.in = buf[cur]; g.wt = pk + d->off[2 + 2 * (l - 1)]; g.bias = pk + d->off[3 + 2 * (l - 1)];
         g.out = buf[(cur + 1) % 3];
-        g.in_pix_stride = (int64_t)mm * chans[l]; g.out_pix_stride = (int64_t)mm * chans[l + 1];
+        g.in_pix_stride = pixs(chans[l]); g.out_pix_stride = pixs(chans[l + 1]);
+        g.in_tile_stride = tiles(hp * wp, chans[l]); g.out_tile_stride = tiles(hin * win, chans[l + 1]);
         g.M = mm; g.Cin = chans[l]; g.lda = chans[l]; g.Hin = hin; g.Win = win; g.kH = g.kW = 3; g.stride = 1; g.pad = 1;
         g.Hout = hin; g.Wout = win; g.Cout = chans[l + 1]; g.ldc = chans[l + 1]; g.relu = 1;
         g.tag = MAGAT_TAG_BLOCK_CONV + (l - 1);
@@ -226,7 +249,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       // final MaxPool2d(2) -> [mm][128]: pooled 1x1 GEMM with identity weights
       magat_conv_gemm_desc g = {};
       g.in = buf[cur]; g.wt = pk + d->off[14]; g.out = feat + (size_t)m0 * ldfeat;
-      g.in_pix_stride = (int64_t)mm * 128; g.M = mm; g.Cin = 128; g.lda = 128; g.Hin = hp / 2; g.Win = wp / 2;
+      g.in_pix_stride = pixs(128); g.in_tile_stride = tiles(hp * wp, 128);
+      g.M = mm; g.Cin = 128; g.lda = 128; g.Hin = hp / 2; g.Win = wp / 2;
       g.kH = hp / 2; g.kW = wp / 2; g.stride = 1; g.pad = 0; g.Hout = g.Wout = 1; g.Cout = 128; g.ldc = ldfeat;
       g.pool = 2; g.pool_w = wp; g.tag = MAGAT_TAG_HEAD;
       if (hp / 2 != 1 || wp / 2 != 1) return MAGAT_ERR_UNSUPPORTED;   // FOV 9 (11x11 input) geometry
@@ -244,7 +268,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
 
   for (int m0 = 0; m0 < M; m0 += mc) {
     const int mm = (M - m0) < mc ? (M - m0) : mc;
-    int rc = magat_conv_first_f32(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W, stream);
+    int rc = magat_conv_first_tiled_f32(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W,
+                                        stream);
     if (rc != MAGAT_OK) return rc;
     int cur = 0;              // buffer holding the block input
     int hin = H, win = W;
@@ -255,7 +280,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       magat_conv_gemm_desc g = {};
       // conv1 + bn1 + relu
       g.in = buf[cur]; g.wt = pk + d->off[2 + 4 * l]; g.bias = pk + d->off[3 + 4 * l]; g.out = buf[mid];
-      g.in_pix_stride = (int64_t)mm * s.cin; g.out_pix_stride = (int64_t)mm * s.cout;
+      g.in_pix_stride = pixs(s.cin); g.out_pix_stride = pixs(s.cout);
+      g.in_tile_stride = tiles(hin * win, s.cin); g.out_tile_stride = tiles(hout * wout, s.cout);
       g.M = mm; g.Cin = s.cin; g.lda = s.cin; g.Hin = hin; g.Win = win; g.kH = g.kW = 3; g.stride = s.stride;
       g.pad = 1; g.Hout = hout; g.Wout = wout; g.Cout = s.cout; g.ldc = s.cout; g.relu = 1;
       g.tag = MAGAT_TAG_BLOCK_CONV + 2 * l;
@@ -268,8 +294,9 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       magat_conv_gemm_desc h = {};
       h.in = buf[mid]; h.in2 = buf[cur]; h.wt = pk + d->off[4 + 4 * l]; h.bias = pk + d->off[5 + 4 * l];
       h.out = buf[nxt];
-      h.in_pix_stride = (int64_t)mm * s.cout; h.in2_pix_stride = (int64_t)mm * s.cin;
-      h.out_pix_stride = (int64_t)mm * s.cout;
+      h.in_pix_stride = pixs(s.cout); h.in2_pix_stride = pixs(s.cin); h.out_pix_stride = pixs(s.cout);
+      h.in_tile_stride = tiles(hout * wout, s.cout); h.in2_tile_stride = tiles(hin * win, s.cin);
+      h.out_tile_stride = tiles(hout * wout, s.cout);
       h.M = mm; h.Cin = s.cout; h.lda = s.cout; h.Hin = hout; h.Win = wout; h.kH = h.kW = 3; h.stride = 1; h.pad = 1;
       h.Hout = hout; h.Wout = wout; h.C2 = s.cin; h.lda2 = s.cin; h.W2 = win; h.stride2 = s.stride;
       h.Cout = s.cout; h.ldc = s.cout; h.relu = 1;
@@ -287,7 +314,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
     magat_conv_gemm_desc g = {};
     g.in = buf[cur]; g.wt = pk + d->off[14]; g.bias = pk + d->off[15];
     g.out = feat + (size_t)m0 * ldfeat;
-    g.in_pix_stride = (int64_t)mm * clast; g.M = mm; g.Cin = clast; g.lda = clast; g.Hin = hin / 2; g.Win = win / 2;
+    g.in_pix_stride = pixs(clast); g.in_tile_stride = tiles(hin * win, clast);
+    g.M = mm; g.Cin = clast; g.lda = clast; g.Hin = hin / 2; g.Win = win / 2;
     g.kH = hin / 2; g.kW = win / 2; g.stride = 1; g.pad = 0; g.Hout = g.Wout = 1; g.Cout = d->n_feat; g.ldc = ldfeat;
     g.relu = 0; g.pool = 1; g.pool_w = win;
     g.tag = MAGAT_TAG_HEAD;

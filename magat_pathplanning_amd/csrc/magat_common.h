@@ -9,6 +9,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MAGAT_WAVE 64
+#define MAGAT_TILE_ROWS 128   // agent-tile height of the tile-major activation layout
+// element offset of row m: (m / 128) * tile_stride + (m % 128) * ld
+__host__ __device__ __forceinline__ long long magat_row_off(long long m, long long ld, long long tile_stride) {
+  return (m >> 7) * tile_stride + (m & 127) * ld;
+}
 #define MAGAT_NUM_XCD 8
 
 // per-kernel timing hooks (profile.hip); tags are listed in include/magat_hip.h
