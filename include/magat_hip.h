@@ -85,6 +85,21 @@ int magat_gat_forward_csr_f32(const float* X, const int* rowptr, const int* coli
                               const float* bias, float* Y, int ldy, float* att_opt, void* workspace,
                               size_t workspace_bytes, int B, int N, int G, int F, int K, int P, int mode, int concat,
                               void* stream);
+/* Training support (caller: loss.backward() at agents/decentralplannerlocal_OnlineExpert_GAT.py:564).
+ * Forward that keeps what the backward needs: Ypre [M][P*F] = per-head filter outputs + bias BEFORE ReLU / head merge
+ * (the caller's autograd owns those), att [P][nnz] (CSR order), Z [M][NC], T [(K-2)][M][P*F] (intermediate hop
+ * states, NULL if K <= 2) and the CSC view (cscptr [B*(N+1)], cscsrc/cscpos/csctmp [nnz]).
+ * Backward of the graph part: dZ [M][NC] (gradient wrt every column of Z) and dXd [M][G] (direct score term of dX);
+ * the caller finishes with two plain GEMMs  dX = dXd + dZ @ Bt,  dBt = dZ^T @ X.  datt [P][nnz] is scratch. */
+int magat_gat_train_forward_f32(const float* X, const int* rowptr, const int* colidx, long long nnz, const float* packed,
+                                const float* bias, float* Ypre, float* att, float* Z, float* T, int* cscptr,
+                                int* cscsrc, int* cscpos, int* csctmp, int B, int N, int G, int F, int K, int P,
+                                int mode, void* stream);
+int magat_gat_train_backward_f32(const float* dYpre, const float* X, const float* Z, const float* att, const float* T,
+                                 const int* rowptr, const int* colidx, const int* cscptr, const int* cscsrc,
+                                 const int* cscpos, long long nnz, float* dZ, float* dXd, float* datt, int B, int N,
+                                 int G, int F, int K, int P, int mode, void* stream);
+
 /* dense GSO -> CSR in two steps (the caller prefix-sums the degrees in between): per-row edge counts, then column fill */
 int magat_gso_row_degrees(const void* S, int s_is_f64, int* deg /*B*N*/, int B, int N, void* stream);
 int magat_gso_fill_csr(const void* S, int s_is_f64, const int* rowstart /*B*N*/, int* colidx, int B, int N, void* stream);

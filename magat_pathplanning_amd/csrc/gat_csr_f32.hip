@@ -38,6 +38,7 @@ struct CsrParams {
   int k;               // hop index (U_k added)
   int told_ld, told_head_stride;   // addressing of Told rows: Told + (b*N+i)*told_ld + head*told_head_stride
   int last;
+  int act_relu;           // apply ReLU in the last hop's store (inference); 0 in training (autograd owns it)
 };
 
 // ---- 1. CSR -> CSC (per instance), deterministic: counting sort + per-column insertion sort by source
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void csr_hop_kernel(const CsrParams p) {
   }
   if (p.last) {
     if (p.bias) acc += *reinterpret_cast<const fvec*>(p.bias + VEC * lane);
-    if (p.concat) {
+    if (p.act_relu) {
 #pragma unroll
       for (int c = 0; c < VEC; ++c) acc[c] = fmaxf(acc[c], 0.f);
     }
@@ -263,7 +264,7 @@ __global__ void csr_k1_kernel(const CsrParams p) {
     const long long m = r / p.P;
     f32x4 v = *reinterpret_cast<const f32x4*>(p.Z + m * p.NC + p.uoff + head * F + 4 * c);
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + 4 * c);
-    if (p.concat) {
+    if (p.act_relu) {
       v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
     }
     *reinterpret_cast<f32x4*>(p.Y + m * p.ldy + head * F + 4 * c) = v;
@@ -389,6 +390,7 @@ extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, cons
   p.X = X; p.Z = Z; p.rowptr = rowptr; p.colidx = colidx; p.cscptr = cscptr; p.cscsrc = cscsrc; p.cscpos = cscpos;
   p.att = att; p.bias = bias; p.Y = concat ? Y : Ytmp; p.ldy = concat ? ldy : P * F;
   p.B = B; p.N = N; p.K = K; p.P = P; p.mode = mode; p.concat = concat; p.nnz = nnz;
+  p.act_relu = concat;
   p.NC = L.NC; p.qoff = L.qoff; p.uoff = L.uoff; p.c1off = L.c1off; p.c2off = L.c2off;
 
   if (K == 1 && !att_opt) {
@@ -533,4 +535,298 @@ extern "C" int magat_gso_fill_csr(const void* S, int s_is_f64, const int* rowsta
     hipLaunchKernelGGL(gso_fill_csr_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(S),
                        rowstart, colidx, N, rows);
   return magat_check_launch();
+}
+
+// =====================================================================================================
+// Training support: forward that keeps what the backward needs, and the
+// backward of the graph part of the layer.  The layer is
+//     T_{K-1} = U_{K-1};  T_k = U_k + A^T T_{k+1};  Ypre = T_0 + bias;  A = row-softmax(E) on the edges
+//     E_ij = x_i . q_j (KeyQuery)  |  lrelu(c1_j + c2_i) (GAT_modified);   [Q | U | c1 c2] = X @ Bt^T + cb
+// Given dYpre the kernels below produce dZ (gradient wrt every column of Z) and the direct part of dX;
+// the two dense products dX += dZ @ Bt and dBt = dZ^T @ X are plain library GEMMs done by the caller.
+//     dT_0 = dYpre;   dT_{k+1} = A dT_k;   dA_ij = sum_k T_{k+1}[i] . dT_k[j];   dU_k = dT_k
+//     dE_ij = a_ij (dA_ij - sum_j' a_ij' dA_ij')
+//     KeyQuery: dX_i += sum_j dE_ij q_j,  dQ_j = sum_i dE_ij x_i
+//     modified: g_ij = dE_ij * lrelu'(c1_j + c2_i),  dc2_i = sum_j g_ij,  dc1_j = sum_i g_ij
+// =====================================================================================================
+namespace {
+
+struct TrainParams {
+  const float* X;
+  const float* Z;
+  const float* T;        // [(K-2)][M][P*F]   T_k at slot K-2-k  (1 <= k <= K-2)
+  const float* att;      // [P][nnz]
+  float* datt;           // [P][nnz]  dA, then dE / g in place
+  float* dZ;             // [M][NC]
+  float* dXd;            // [M][G]
+  const int* rowptr; const int* colidx; const int* cscptr; const int* cscsrc; const int* cscpos;
+  int B, N, K, P, mode, NC, qoff, uoff, c1off, c2off;
+  long long nnz, M;
+  int k;                 // hop being differentiated (reads dT_k, writes dT_{k+1})
+};
+
+template <int F>
+__global__ __launch_bounds__(256) void bwd_hop_kernel(const TrainParams p) {
+  constexpr int VEC = F >= 64 ? F / 64 : 1, LANES = F >= 64 ? 64 : F;
+  typedef float fvec __attribute__((ext_vector_type(VEC)));
+  const int N = p.N, tiles = (N + 3) / 4;
+  const int bid = blockIdx.x, xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD, per = p.P * tiles;
+  const int b = xcd + MAGAT_NUM_XCD * (slot / per);
+  if (b >= p.B) return;
+  const int head = (slot % per) / tiles, tile = slot % tiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = tile * 4 + wave;
+  if (i >= N) return;
+  const bool on = lane < LANES;
+  const int* rp = p.rowptr + (long long)b * (N + 1);
+  const int e0 = rp[i], e1 = rp[i + 1];
+  const float* att = p.att + (long long)head * p.nnz;
+  float* datt = p.datt + (long long)head * p.nnz;
+  const long long row0 = (long long)b * N;
+  const int k = p.k, K = p.K;
+  // T_{k+1}[i]
+  fvec tn;
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) tn[c] = 0.f;
+  if (on) {
+    if (k + 1 == K - 1)
+      tn = *reinterpret_cast<const fvec*>(p.Z + (row0 + i) * p.NC + p.uoff + (head * K + (K - 1)) * F + VEC * lane);
+    else
+      tn = *reinterpret_cast<const fvec*>(p.T + ((long long)(K - 2 - (k + 1)) * p.M + row0 + i) * p.P * F + head * F +
+                                          VEC * lane);
+  }
+  const long long ucur = p.uoff + (head * K + k) * F + VEC * lane;       // dT_k lives in dZ's U_k block
+  fvec acc;
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
+  for (int e = e0; e < e1; ++e) {
+    const int j = p.colidx[e];
+    const float a = att[e];
+    fvec d;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) d[c] = 0.f;
+    if (on) d = *reinterpret_cast<const fvec*>(p.dZ + (row0 + j) * p.NC + ucur);
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      acc[c] = fmaf(a, d[c], acc[c]);
+      dot = fmaf(tn[c], d[c], dot);
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) datt[e] = (k == 0 ? 0.f : datt[e]) + dot;
+  }
+  if (on) *reinterpret_cast<fvec*>(p.dZ + (row0 + i) * p.NC + p.uoff + (head * K + k + 1) * F + VEC * lane) = acc;
+}
+
+// softmax backward per row (all heads), then the row-side score gradients
+template <int G>
+__global__ __launch_bounds__(256) void bwd_scores_rows_kernel(const TrainParams p) {
+  constexpr int VEC = G >= 64 ? G / 64 : 1, LANES = G >= 64 ? 64 : G;
+  typedef float fvec __attribute__((ext_vector_type(VEC)));
+  const int N = p.N, tiles = (N + 3) / 4;
+  const int bid = blockIdx.x, xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
+  const int b = xcd + MAGAT_NUM_XCD * (slot / tiles);
+  if (b >= p.B) return;
+  const int tile = slot % tiles, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = tile * 4 + wave;
+  if (i >= N) return;
+  const bool on = lane < LANES;
+  const int* rp = p.rowptr + (long long)b * (N + 1);
+  const int e0 = rp[i], e1 = rp[i + 1];
+  const long long row0 = (long long)b * N;
+  fvec accx;
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) accx[c] = 0.f;
+  for (int head = 0; head < p.P; ++head) {
+    const float* att = p.att + (long long)head * p.nnz;
+    float* datt = p.datt + (long long)head * p.nnz;
+    float s = 0.f;
+    for (int e = e0 + lane; e < e1; e += 64) s = fmaf(att[e], datt[e], s);
+    s = wave_sum(s);
+    if (p.mode == MAGAT_MODE_KEYQUERY) {
+      for (int e = e0; e < e1; ++e) {
+        const float dE = att[e] * (datt[e] - s);
+        if (on) {
+          const fvec q = *reinterpret_cast<const fvec*>(p.Z + (row0 + p.colidx[e]) * p.NC + p.qoff + head * G + VEC * lane);
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) accx[c] = fmaf(dE, q[c], accx[c]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) datt[e] = dE;
+      }
+    } else {
+      const float c2 = p.Z[(row0 + i) * p.NC + p.c2off + head];
+      float g2 = 0.f;
+      for (int e = e0 + lane; e < e1; e += 64) {
+        const float pre = p.Z[(row0 + p.colidx[e]) * p.NC + p.c1off + head] + c2;
+        const float g = att[e] * (datt[e] - s) * (pre > 0.f ? 1.f : 0.2f);
+        datt[e] = g;
+        g2 += g;
+      }
+      g2 = wave_sum(g2);
+      if (lane == 0) p.dZ[(row0 + i) * p.NC + p.c2off + head] = g2;
+    }
+  }
+  if (p.mode == MAGAT_MODE_KEYQUERY && on) *reinterpret_cast<fvec*>(p.dXd + (row0 + i) * G + VEC * lane) = accx;
+}
+
+// column-side score gradients: dQ_j (KeyQuery) or dc1_j (modified), via the CSC view
+template <int G>
+__global__ __launch_bounds__(256) void bwd_scores_cols_kernel(const TrainParams p) {
+  constexpr int VEC = G >= 64 ? G / 64 : 1, LANES = G >= 64 ? 64 : G;
+  typedef float fvec __attribute__((ext_vector_type(VEC)));
+  const int N = p.N, tiles = (N + 3) / 4;
+  const int bid = blockIdx.x, xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
+  const int b = xcd + MAGAT_NUM_XCD * (slot / tiles);
+  if (b >= p.B) return;
+  const int tile = slot % tiles, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = tile * 4 + wave;
+  if (j >= N) return;
+  const bool on = lane < LANES;
+  const int* cp = p.cscptr + (long long)b * (N + 1);
+  const int s0 = cp[j], s1 = cp[j + 1];
+  const long long row0 = (long long)b * N;
+  for (int head = 0; head < p.P; ++head) {
+    const float* dE = p.datt + (long long)head * p.nnz;
+    if (p.mode == MAGAT_MODE_KEYQUERY) {
+      fvec acc;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
+      for (int s = s0; s < s1; ++s) {
+        const float g = dE[p.cscpos[s]];
+        if (on) {
+          const fvec x = *reinterpret_cast<const fvec*>(p.X + (row0 + p.cscsrc[s]) * G + VEC * lane);
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) acc[c] = fmaf(g, x[c], acc[c]);
+        }
+      }
+      if (on) *reinterpret_cast<fvec*>(p.dZ + (row0 + j) * p.NC + p.qoff + head * G + VEC * lane) = acc;
+    } else {
+      float g1 = 0.f;
+      for (int s = s0 + lane; s < s1; s += 64) g1 += dE[p.cscpos[s]];
+      g1 = wave_sum(g1);
+      if (lane == 0) p.dZ[(row0 + j) * p.NC + p.c1off + head] = g1;
+    }
+  }
+}
+
+// dU_0 = dYpre
+__global__ void bwd_seed_kernel(const float* __restrict__ dY, float* __restrict__ dZ, long long M, int P, int F, int K,
+                                int NC, int uoff) {
+  const int FC = F / 4;
+  const long long total = M * P * FC;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % FC);
+    const long long r = idx / FC;
+    const int head = (int)(r % P);
+    const long long m = r / P;
+    *reinterpret_cast<f32x4*>(dZ + m * NC + uoff + (head * K) * F + 4 * c) =
+        *reinterpret_cast<const f32x4*>(dY + (m * P + head) * F + 4 * c);
+  }
+}
+
+template <int W, typename KFn>
+int launch_rows(KFn kern, const TrainParams& p, int per_instance_factor, hipStream_t st) {
+  const int tiles = (p.N + 3) / 4;
+  const long long grid = (long long)((p.B + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD) * MAGAT_NUM_XCD * per_instance_factor * tiles;
+  if (grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, st, p);
+  return magat_check_launch();
+}
+
+#define MAGAT_WIDTH_SWITCH(W, CALL)        \
+  switch (W) {                             \
+    case 16: { constexpr int WW = 16; CALL; } break;   \
+    case 32: { constexpr int WW = 32; CALL; } break;   \
+    case 64: { constexpr int WW = 64; CALL; } break;   \
+    case 128: { constexpr int WW = 128; CALL; } break; \
+    default: { constexpr int WW = 256; CALL; }         \
+  }
+
+}  // namespace
+
+extern "C" int magat_gat_train_forward_f32(const float* X, const int* rowptr, const int* colidx, long long nnz,
+                                           const float* packed, const float* bias, float* Ypre, float* att, float* Z,
+                                           float* T, int* cscptr, int* cscsrc, int* cscpos, int* csctmp, int B, int N,
+                                           int G, int F, int K, int P, int mode, void* stream) {
+  if (!X || !rowptr || !packed || !Ypre || !att || !Z || !cscptr || !cscsrc || !cscpos || !csctmp) return MAGAT_ERR_NULL;
+  if (nnz > 0 && !colidx) return MAGAT_ERR_NULL;
+  if (K > 2 && !T) return MAGAT_ERR_NULL;
+  if (B <= 0 || N <= 0 || nnz < 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
+  if (mode != MAGAT_MODE_KEYQUERY && mode != MAGAT_MODE_GAT_MODIFIED) return MAGAT_ERR_UNSUPPORTED;
+  if (G != F || !(G == 16 || G == 32 || G == 64 || G == 128 || G == 256)) return MAGAT_ERR_UNSUPPORTED;
+  if ((size_t)(2 * N + 2) * sizeof(int) > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const Layout L = layout(G, F, K, P, mode);
+  const long long M = (long long)B * N;
+  int rc = magat_linear_tagged_f32(X, G, packed, packed + (size_t)L.NC * G, Z, L.NC, (int)M, L.NC, G, 0,
+                                   MAGAT_TAG_GAT_MAPS, stream);
+  if (rc != MAGAT_OK) return rc;
+  CsrParams p = {};
+  p.X = X; p.Z = Z; p.rowptr = rowptr; p.colidx = colidx; p.cscptr = cscptr; p.cscsrc = cscsrc; p.cscpos = cscpos;
+  p.att = att; p.bias = bias; p.Y = Ypre; p.ldy = P * F;
+  p.B = B; p.N = N; p.K = K; p.P = P; p.mode = mode; p.concat = 1; p.act_relu = 0; p.nnz = nnz;
+  p.NC = L.NC; p.qoff = L.qoff; p.uoff = L.uoff; p.c1off = L.c1off; p.c2off = L.c2off;
+  hipLaunchKernelGGL(csr_transpose_kernel, dim3(B), dim3(256), (size_t)(2 * N + 2) * sizeof(int), st, rowptr, colidx,
+                     cscptr, csctmp, N);
+  hipLaunchKernelGGL(csr_sort_columns_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, rowptr, cscptr, csctmp,
+                     cscsrc, cscpos, N, M);
+  if ((rc = magat_check_launch()) != MAGAT_OK) return rc;
+  MAGAT_WIDTH_SWITCH(G, rc = run_scores<WW>(p, st));
+  if (rc != MAGAT_OK) return rc;
+  if (K == 1) {
+    MAGAT_WIDTH_SWITCH(F, rc = run_k1<WW>(p, st));
+    return rc;
+  }
+  for (int k = K - 2, h = 0; k >= 0; --k, ++h) {
+    p.k = k;
+    p.last = k == 0;
+    if (h == 0) {
+      p.Told = Z + L.uoff + (K - 1) * F; p.told_ld = L.NC; p.told_head_stride = K * F;
+    } else {
+      p.Told = T + (size_t)(h - 1) * M * P * F; p.told_ld = P * F; p.told_head_stride = F;
+    }
+    p.Tnew = T ? T + (size_t)h * M * P * F : nullptr;     // T_k for k = K-2-h (kept for the backward)
+    MAGAT_WIDTH_SWITCH(F, rc = run_hop<WW>(p, st));
+    if (rc != MAGAT_OK) return rc;
+  }
+  return MAGAT_OK;
+}
+
+extern "C" int magat_gat_train_backward_f32(const float* dYpre, const float* X, const float* Z, const float* att,
+                                            const float* T, const int* rowptr, const int* colidx, const int* cscptr,
+                                            const int* cscsrc, const int* cscpos, long long nnz, float* dZ, float* dXd,
+                                            float* datt, int B, int N, int G, int F, int K, int P, int mode,
+                                            void* stream) {
+  if (!dYpre || !X || !Z || !att || !rowptr || !cscptr || !cscsrc || !cscpos || !dZ || !dXd || !datt) return MAGAT_ERR_NULL;
+  if (B <= 0 || N <= 0 || nnz < 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
+  if (G != F || !(G == 16 || G == 32 || G == 64 || G == 128 || G == 256)) return MAGAT_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const Layout L = layout(G, F, K, P, mode);
+  TrainParams p = {};
+  p.X = X; p.Z = Z; p.T = T; p.att = att; p.datt = datt; p.dZ = dZ; p.dXd = dXd;
+  p.rowptr = rowptr; p.colidx = colidx; p.cscptr = cscptr; p.cscsrc = cscsrc; p.cscpos = cscpos;
+  p.B = B; p.N = N; p.K = K; p.P = P; p.mode = mode; p.NC = L.NC; p.qoff = L.qoff; p.uoff = L.uoff;
+  p.c1off = L.c1off; p.c2off = L.c2off; p.nnz = nnz; p.M = (long long)B * N;
+  if (hipMemsetAsync(dZ, 0, (size_t)p.M * L.NC * sizeof(float), st) != hipSuccess) return MAGAT_ERR_LAUNCH;
+  if (hipMemsetAsync(dXd, 0, (size_t)p.M * G * sizeof(float), st) != hipSuccess) return MAGAT_ERR_LAUNCH;
+  {
+    long long blocks = (p.M * P * (F / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bwd_seed_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dYpre, dZ, p.M, P, F, K, L.NC, L.uoff);
+    int rc = magat_check_launch();
+    if (rc != MAGAT_OK) return rc;
+  }
+  if (K == 1) return MAGAT_OK;     // no graph terms: dZ = [0 | dYpre]
+  int rc = MAGAT_OK;
+  for (int k = 0; k <= K - 2; ++k) {
+    p.k = k;
+    MAGAT_WIDTH_SWITCH(F, rc = launch_rows<WW>(bwd_hop_kernel<WW>, p, P, st));
+    if (rc != MAGAT_OK) return rc;
+  }
+  MAGAT_WIDTH_SWITCH(G, rc = launch_rows<WW>(bwd_scores_rows_kernel<WW>, p, 1, st));
+  if (rc != MAGAT_OK) return rc;
+  MAGAT_WIDTH_SWITCH(G, rc = launch_rows<WW>(bwd_scores_cols_kernel<WW>, p, 1, st));
+  return rc;
 }

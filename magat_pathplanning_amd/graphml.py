@@ -4,7 +4,9 @@ returnAttentionGSO surface (utils/graphUtils/graphML.py:4506-4685) on top of the
 Inference (no autograd) runs the HIP path through the C ABI; there is no CPU fallback: a CPU
 tensor under no_grad raises.  When autograd is required (training)
 the layer evaluates the same algebra with differentiable torch ops on whatever device the
-tensors live on -- that composite exists for backward only and is never used for inference.
+tensors live on -- that composite exists for backward only and is never used for inference.  On GPU tensors the
+training forward and backward of the graph part run on the HIP kernels too (_GatTrainFunction); the composite then only
+serves CPU tensors (the gloo / host tests) and requests for the dense attention tensor under autograd.
 """
 import math
 
@@ -161,6 +163,97 @@ def gat_forward_rows(X, S, layer, out=None, want_attention=False):
     return out, aij
 
 
+def pack_torch(weight, weight_bias, mixer, taps, mode_name):
+    """Differentiable torch twin of pack_kernel (csrc/gat_f32.hip): Bt [NC][G] and column bias [NC]."""
+    P, F, _, K, G = taps.shape
+    U = taps[:, :, 0].permute(0, 2, 1, 3).reshape(P * K * F, G)
+    if mode_name == "KeyQuery":
+        Bt = torch.cat((weight[:, 0].reshape(P * G, G), U), dim=0)
+        return Bt, torch.zeros(Bt.shape[0], dtype=Bt.dtype, device=Bt.device)
+    W = weight[:, 0]                                            # (P,F,G)
+    a1, a2 = mixer[:, 0, :F], mixer[:, 0, F:]
+    v1, v2 = torch.einsum("pf,pfg->pg", a1, W), torch.einsum("pf,pfg->pg", a2, W)
+    nc = (P * K * F + 2 * P + 3) // 4 * 4
+    pad = torch.zeros(nc - P * K * F - 2 * P, G, dtype=U.dtype, device=U.device)
+    Bt = torch.cat((U, v1, v2, pad), dim=0)
+    wb = weight_bias[:, 0]
+    cb = torch.cat((torch.zeros(P * K * F, dtype=U.dtype, device=U.device), (a1 * wb).sum(1), (a2 * wb).sum(1),
+                    torch.zeros(nc - P * K * F - 2 * P, dtype=U.dtype, device=U.device)))
+    return Bt, cb
+
+
+class _GatTrainFunction(torch.autograd.Function):
+    """HIP forward + backward of the graph-attention layer for training (pre-activation, per-head output)."""
+
+    @staticmethod
+    def forward(ctx, X, weight, weight_bias, mixer, taps, bias, rowptr, colidx, nnz, layer):
+        lib = nat.lib()
+        B, N, G = X.shape
+        F, K, P = layer.F, layer.K, layer.P
+        mode = _MODES[layer.attentionMode]
+        dev = X.device
+        M = B * N
+        Xc = X.detach().contiguous().float()
+        with torch.cuda.device(dev):
+            stream = nat.current_stream(dev)
+            packed = _packed_weights(layer, dev, stream, G, F, K, P, mode)
+            nc = (lib.magat_gat_packed_floats(G, F, K, P, mode) - 0)  # total floats; NC recovered below
+            NC = P * G + P * K * F if mode == nat.MODE_KEYQUERY else (P * K * F + 2 * P + 3) // 4 * 4
+            Ypre = torch.empty(M, P * F, dtype=torch.float32, device=dev)
+            att = torch.empty(P, max(nnz, 1), dtype=torch.float32, device=dev)
+            Z = torch.empty(M, NC, dtype=torch.float32, device=dev)
+            T = torch.empty(max(K - 2, 0), M, P * F, dtype=torch.float32, device=dev) if K > 2 else None
+            cscptr = torch.empty(B * (N + 1), dtype=torch.int32, device=dev)
+            csc = torch.empty(3, max(nnz, 1), dtype=torch.int32, device=dev)
+            b1 = None if bias is None else bias.detach().reshape(-1).contiguous().float()
+            nat.check(lib.magat_gat_train_forward_f32(
+                nat.ptr(Xc), nat.ptr(rowptr), nat.ptr(colidx), nnz, nat.ptr(packed), nat.ptr(b1), nat.ptr(Ypre),
+                nat.ptr(att), nat.ptr(Z), nat.ptr(T), nat.ptr(cscptr), nat.ptr(csc[0]), nat.ptr(csc[1]),
+                nat.ptr(csc[2]), B, N, G, F, K, P, mode, stream), "magat_gat_train_forward_f32")
+        ctx.layer, ctx.nnz, ctx.dims = layer, nnz, (B, N, G, F, K, P, mode, NC)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(Xc, Z, att, T if T is not None else torch.empty(0, device=dev), rowptr, colidx, cscptr,
+                              csc, packed, weight, weight_bias, mixer, taps)
+        return Ypre
+
+    @staticmethod
+    def backward(ctx, dYpre):
+        lib = nat.lib()
+        Xc, Z, att, T, rowptr, colidx, cscptr, csc, packed, weight, weight_bias, mixer, taps = ctx.saved_tensors
+        B, N, G, F, K, P, mode, NC = ctx.dims
+        dev, M = Xc.device, B * N
+        dY = dYpre.contiguous().float()
+        with torch.cuda.device(dev):
+            stream = nat.current_stream(dev)
+            dZ = torch.empty(M, NC, dtype=torch.float32, device=dev)
+            dXd = torch.empty(M, G, dtype=torch.float32, device=dev)
+            datt = torch.empty(P, max(ctx.nnz, 1), dtype=torch.float32, device=dev)
+            nat.check(lib.magat_gat_train_backward_f32(
+                nat.ptr(dY), nat.ptr(Xc), nat.ptr(Z), nat.ptr(att), nat.ptr(T if T.numel() else None), nat.ptr(rowptr),
+                nat.ptr(colidx), nat.ptr(cscptr), nat.ptr(csc[0]), nat.ptr(csc[1]), ctx.nnz, nat.ptr(dZ), nat.ptr(dXd),
+                nat.ptr(datt), B, N, G, F, K, P, mode, stream), "magat_gat_train_backward_f32")
+        Bt = packed[:NC * G].view(NC, G)
+        X2 = Xc.view(M, G)
+        dX = (dXd + dZ @ Bt).view(B, N, G)                 # plain library GEMMs
+        dBt, dcb = dZ.t() @ X2, dZ.sum(dim=0)
+        grads = [None, None, None, None]
+        params = [weight, weight_bias, mixer, taps]
+        need = [i for i, t in enumerate(params) if t.requires_grad]
+        if need:
+            with torch.enable_grad():
+                leaves = [t.detach().requires_grad_(True) for t in params]
+                Bt_t, cb_t = pack_torch(*leaves, ctx.layer.attentionMode)
+                outs, gouts = [Bt_t], [dBt]
+                if cb_t.requires_grad:          # KeyQuery has a constant (zero) column bias
+                    outs.append(cb_t)
+                    gouts.append(dcb)
+                got = torch.autograd.grad(outs, [leaves[i] for i in need], gouts, allow_unused=True)
+            for i, g in zip(need, got):
+                grads[i] = g
+        dbias = dY.view(M, P, F).sum(dim=(0, 1)).view(F, 1) if ctx.has_bias else None
+        return dX, grads[0], grads[1], grads[2], grads[3], dbias, None, None, None, None
+
+
 def _composite(layer, x, S):
     """Differentiable torch-op evaluation (training only).  x (B,G,N); S (B,1,N,N)."""
     B, G, N = x.shape
@@ -265,7 +358,22 @@ class GraphFilterBatchAttentional(nn.Module):
         if Nin < self.N:
             x = torch.cat((x, torch.zeros(B, Gin, self.N - Nin, dtype=x.dtype, device=x.device)), dim=2)
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if needs_grad:
+        if needs_grad and x.is_cuda and not self.return_attention:
+            # training on the GPU: HIP forward + backward of the graph layer (CSR kernels), ReLU / head merge in torch
+            N = self.N
+            S3 = self.S.reshape(B, N, N).to(x.device)
+            if S3.dtype not in (torch.float32, torch.float64):
+                S3 = S3.float()
+            rowptr, colidx, nnz = dense_gso_to_csr(S3.contiguous())
+            Ypre = _GatTrainFunction.apply(x.permute(0, 2, 1).contiguous(), self.weight, self.weight_bias, self.mixer,
+                                           self.filterWeight, self.bias, rowptr, colidx, nnz, self)
+            Yh = Ypre.view(B, N, self.P, self.F)
+            if self.concatenate:
+                y = torch.relu(Yh).reshape(B, N, self.P * self.F).permute(0, 2, 1)
+            else:
+                y = torch.relu(Yh.mean(dim=2)).permute(0, 2, 1)
+            self.aij = None
+        elif needs_grad:
             y, aij = _composite(self, x, self.S.to(x.device))
             self.aij = aij.detach() if self.return_attention else None
         else:
