@@ -31,6 +31,11 @@ extern "C" {
 
 #define MAGAT_MODE_KEYQUERY 0     /* attentionMode == 'KeyQuery'      graphML.py:1180-1286 */
 #define MAGAT_MODE_GAT_MODIFIED 1 /* attentionMode == 'GAT_modified'  graphML.py:713-823   */
+#define MAGAT_MODE_GAT_ORIGIN 2   /* attentionMode == 'GAT_origin' (GraphFilterBatchAttentional_Origin, graphML.py:4175-4339,
+                                     964-1069, 1939-2002): self-loops added to the GSO (mask = |float(S)+I| > 1e-9), scores
+                                     lrelu(a1.Wx_j + a2.Wx_i) without weight_bias, filter taps h[p,f,k,g] = filterWeight[0,k] * W[p,g,f]
+                                     (transposed: the reference's permute+reshape, graphML.py:1967-1969).
+                                     pack_weights: `taps` = filterWeight (E=1,K), `weight_bias` ignored. */
 
 int magat_abi_version(void);
 const char* magat_error_string(int code);
@@ -101,8 +106,10 @@ int magat_gat_train_backward_f32(const float* dYpre, const float* X, const float
                                  int G, int F, int K, int P, int mode, void* stream);
 
 /* dense GSO -> CSR in two steps (the caller prefix-sums the degrees in between): per-row edge counts, then column fill */
-int magat_gso_row_degrees(const void* S, int s_is_f64, int* deg /*B*N*/, int B, int N, void* stream);
-int magat_gso_fill_csr(const void* S, int s_is_f64, const int* rowstart /*B*N*/, int* colidx, int B, int N, void* stream);
+int magat_gso_row_degrees(const void* S, int s_is_f64, int self_loops /*GAT_origin: S + I*/, int* deg /*B*N*/, int B,
+                          int N, void* stream);
+int magat_gso_fill_csr(const void* S, int s_is_f64, int self_loops, const int* rowstart /*B*N*/, int* colidx, int B,
+                       int N, void* stream);
 
 /* addGSO's in-place scrub of the caller's tensor (decentralplanner_GAT_bottleneck.py:272-277):
  * scrub_nan: S[isnan(S)] = 0;  gso_mode 1 ('dist_GSO_one'): S[S>0] = 1;  2 ('full_GSO'): S = 1. */

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("MAGAT_LIB_PATH") or os.path.join(PKG, "lib", "libmaga
 
 MODE_KEYQUERY = 0
 MODE_GAT_MODIFIED = 1
+MODE_GAT_ORIGIN = 2
 TAGS = {0: "untagged", 1: "conv_first", 2: "layer1.conv1", 3: "layer1.conv2+ds", 4: "layer2.conv1",
         5: "layer2.conv2+ds", 6: "layer3.conv1", 7: "layer3.conv2+ds", 8: "head(avgpool+fc+linear)",
         9: "compressMLP", 10: "gat_maps_gemm", 11: "gat_graph", 12: "actionsMLP", 13: "head_mean",
@@ -64,8 +65,8 @@ _SIGNATURES = {
     "magat_gat_forward_csr_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_train_forward_f32": (_I, [_P, _P, _P, ctypes.c_longlong] + [_P] * 10 + [_I] * 7 + [_P]),
     "magat_gat_train_backward_f32": (_I, [_P] * 10 + [ctypes.c_longlong] + [_P] * 3 + [_I] * 7 + [_P]),
-    "magat_gso_row_degrees": (_I, [_P, _I, _P, _I, _I, _P]),
-    "magat_gso_fill_csr": (_I, [_P, _I, _P, _P, _I, _I, _P]),
+    "magat_gso_row_degrees": (_I, [_P, _I, _I, _P, _I, _I, _P]),
+    "magat_gso_fill_csr": (_I, [_P, _I, _I, _P, _P, _I, _I, _P]),
     "magat_gso_prepare": (_I, [_P, _I, _Z, _I, _I, _P]),
     "magat_conv_gemm_f32": (_I, [ctypes.POINTER(ConvGemmDesc), _P]),
     "magat_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

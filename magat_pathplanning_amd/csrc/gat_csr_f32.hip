@@ -363,7 +363,7 @@ extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, cons
                                          int P, int mode, int concat, void* stream) {
   if (!X || !rowptr || !packed || !Y || (nnz > 0 && !colidx)) return MAGAT_ERR_NULL;
   if (B <= 0 || N <= 0 || nnz < 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
-  if (mode != MAGAT_MODE_KEYQUERY && mode != MAGAT_MODE_GAT_MODIFIED) return MAGAT_ERR_UNSUPPORTED;
+  if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GAT_ORIGIN) return MAGAT_ERR_UNSUPPORTED;
   if (G != F || !(G == 16 || G == 32 || G == 64 || G == 128 || G == 256)) return MAGAT_ERR_UNSUPPORTED;
   if ((size_t)(2 * N + 2) * sizeof(int) > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;   // transpose LDS (N <= 8190)
   const int width = concat ? P * F : F;
@@ -470,43 +470,48 @@ extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, cons
 
 // Dense GSO -> CSR edge structure (|S| > 1e-9), two calls: count (rowptr via caller-side prefix) is avoided by
 // writing per-row degrees first.  deg [B*N] ints.
+// edge rule of the reference: |S| > 1e-9 in S's dtype; with self_loops (GAT_origin) |float(S) + delta_ij| > 1e-9f
 template <typename T>
-__global__ void gso_row_degree_kernel(const T* __restrict__ S, int* __restrict__ deg, int N, long long rows) {
+__device__ __forceinline__ bool gso_edge(T v, bool diag, int self_loops) {
+  if (self_loops) return fabsf((float)v + (diag ? 1.f : 0.f)) > 1e-9f;
+  return (v < 0 ? -v : v) > (T)1e-9;
+}
+
+template <typename T>
+__global__ void gso_row_degree_kernel(const T* __restrict__ S, int* __restrict__ deg, int N, long long rows,
+                                      int self_loops) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const T* r = S + row * N;
+  const int i = (int)(row % N);
   int c = 0;
-  for (int j = lane; j < N; j += 64) {
-    const T v = r[j];
-    c += ((v < 0 ? -v : v) > (T)1e-9) ? 1 : 0;
-  }
+  for (int j = lane; j < N; j += 64) c += gso_edge(r[j], j == i, self_loops) ? 1 : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
   if (lane == 0) deg[row] = c;
 }
 template <typename T>
 __global__ void gso_fill_csr_kernel(const T* __restrict__ S, const int* __restrict__ rowstart,
-                                    int* __restrict__ colidx, int N, long long rows) {
+                                    int* __restrict__ colidx, int N, long long rows, int self_loops) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const T* r = S + row * N;
+  const int i = (int)(row % N);
   int base = rowstart[row];
   for (int j0 = 0; j0 < N; j0 += 64) {
     const int j = j0 + lane;
     bool f = false;
-    if (j < N) {
-      const T v = r[j];
-      f = (v < 0 ? -v : v) > (T)1e-9;
-    }
+    if (j < N) f = gso_edge(r[j], j == i, self_loops);
     const unsigned long long m = __ballot(f);
     if (f) colidx[base + __popcll(m & ((1ull << lane) - 1ull))] = j;
     base += __popcll(m);
   }
 }
 
-extern "C" int magat_gso_row_degrees(const void* S, int s_is_f64, int* deg, int B, int N, void* stream) {
+extern "C" int magat_gso_row_degrees(const void* S, int s_is_f64, int self_loops, int* deg, int B, int N,
+                                     void* stream) {
   if (!S || !deg) return MAGAT_ERR_NULL;
   if (B <= 0 || N <= 0) return MAGAT_ERR_BAD_SHAPE;
   const long long rows = (long long)B * N;
@@ -514,15 +519,15 @@ extern "C" int magat_gso_row_degrees(const void* S, int s_is_f64, int* deg, int 
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (s_is_f64)
     hipLaunchKernelGGL(gso_row_degree_kernel<double>, dim3(blocks), dim3(256), 0, st, static_cast<const double*>(S),
-                       deg, N, rows);
+                       deg, N, rows, self_loops);
   else
     hipLaunchKernelGGL(gso_row_degree_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(S), deg,
-                       N, rows);
+                       N, rows, self_loops);
   return magat_check_launch();
 }
 
-extern "C" int magat_gso_fill_csr(const void* S, int s_is_f64, const int* rowstart, int* colidx, int B, int N,
-                                  void* stream) {
+extern "C" int magat_gso_fill_csr(const void* S, int s_is_f64, int self_loops, const int* rowstart, int* colidx, int B,
+                                  int N, void* stream) {
   if (!S || !rowstart || !colidx) return MAGAT_ERR_NULL;
   if (B <= 0 || N <= 0) return MAGAT_ERR_BAD_SHAPE;
   const long long rows = (long long)B * N;
@@ -530,10 +535,10 @@ extern "C" int magat_gso_fill_csr(const void* S, int s_is_f64, const int* rowsta
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (s_is_f64)
     hipLaunchKernelGGL(gso_fill_csr_kernel<double>, dim3(blocks), dim3(256), 0, st, static_cast<const double*>(S),
-                       rowstart, colidx, N, rows);
+                       rowstart, colidx, N, rows, self_loops);
   else
     hipLaunchKernelGGL(gso_fill_csr_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(S),
-                       rowstart, colidx, N, rows);
+                       rowstart, colidx, N, rows, self_loops);
   return magat_check_launch();
 }
 
@@ -754,7 +759,7 @@ extern "C" int magat_gat_train_forward_f32(const float* X, const int* rowptr, co
   if (nnz > 0 && !colidx) return MAGAT_ERR_NULL;
   if (K > 2 && !T) return MAGAT_ERR_NULL;
   if (B <= 0 || N <= 0 || nnz < 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
-  if (mode != MAGAT_MODE_KEYQUERY && mode != MAGAT_MODE_GAT_MODIFIED) return MAGAT_ERR_UNSUPPORTED;
+  if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GAT_ORIGIN) return MAGAT_ERR_UNSUPPORTED;
   if (G != F || !(G == 16 || G == 32 || G == 64 || G == 128 || G == 256)) return MAGAT_ERR_UNSUPPORTED;
   if ((size_t)(2 * N + 2) * sizeof(int) > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -40,7 +40,12 @@ struct GatParams {
                                  // handled by the list kernel, gat_list_f32.hip)
 };
 
-__device__ __forceinline__ bool is_edge(const void* S, long long idx, int f64) {
+// diag: 1 on the diagonal when the mode adds self-loops (GAT_origin: S.float() + I, graphML.py:1018)
+__device__ __forceinline__ bool is_edge(const void* S, long long idx, int f64, float diag = 0.f) {
+  if (diag != 0.f) {
+    const float v = f64 ? (float)static_cast<const double*>(S)[idx] : static_cast<const float*>(S)[idx];
+    return fabsf(v + diag) > 1e-9f;
+  }
   if (f64) return fabs(static_cast<const double*>(S)[idx]) > 1e-9;
   return fabsf(static_cast<const float*>(S)[idx]) > 1e-9f;
 }
@@ -117,8 +122,10 @@ __global__ void gat_dense_kernel(const GatParams p) {
   if (need_att) {
     if constexpr (WIDE) {   // GSO rows -> 128-bit edge masks (one wave per row, coalesced reads, ballot)
       for (int i = wave; i < N; i += nwaves) {
-        const bool f0 = lane < N && is_edge(p.S, sbase + (long long)i * N + lane, p.s_is_f64);
-        const bool f1 = lane + 64 < N && is_edge(p.S, sbase + (long long)i * N + lane + 64, p.s_is_f64);
+        const float sl = p.mode == MAGAT_MODE_GAT_ORIGIN ? 1.f : 0.f;
+        const bool f0 = lane < N && is_edge(p.S, sbase + (long long)i * N + lane, p.s_is_f64, lane == i ? sl : 0.f);
+        const bool f1 = lane + 64 < N &&
+                        is_edge(p.S, sbase + (long long)i * N + lane + 64, p.s_is_f64, lane + 64 == i ? sl : 0.f);
         const unsigned long long k0 = __ballot(f0), k1 = __ballot(f1);
         if (lane == 0) {
           rmask[4 * i + 0] = (unsigned)k0; rmask[4 * i + 1] = (unsigned)(k0 >> 32);
@@ -128,7 +135,8 @@ __global__ void gat_dense_kernel(const GatParams p) {
     } else {                // mask -> A (1/0)
       for (int idx = t; idx < N * N; idx += NT) {
         const int i = idx / N, j = idx - i * N;
-        A[i * p.lda_a + j] = is_edge(p.S, sbase + idx, p.s_is_f64) ? 1.f : 0.f;
+        const float sl = (p.mode == MAGAT_MODE_GAT_ORIGIN && i == j) ? 1.f : 0.f;
+        A[i * p.lda_a + j] = is_edge(p.S, sbase + idx, p.s_is_f64, sl) ? 1.f : 0.f;
       }
     }
     if (!keyquery)
@@ -483,7 +491,7 @@ __global__ void pack_kernel(const float* __restrict__ weight, const float* __res
     if (idx >= total) {  // column bias
       const int col = (int)(idx - total);
       float v = 0.f;
-      if (mode == MAGAT_MODE_GAT_MODIFIED && col >= L.c1off && col < L.c2off + P) {
+      if (mode == MAGAT_MODE_GAT_MODIFIED && col >= L.c1off && col < L.c2off + P) {   // GAT_origin has no weight_bias
         const int which = col >= L.c2off, hp = which ? col - L.c2off : col - L.c1off;
         for (int f = 0; f < F; ++f) v = fmaf(mixer[(long long)hp * 2 * F + which * F + f], wbias[hp * F + f], v);
       }
@@ -496,8 +504,13 @@ __global__ void pack_kernel(const float* __restrict__ weight, const float* __res
       v = weight[(long long)col * G + g];  // (P,1,G,G): row p*G+g' = W_p[g',:]
     } else if (col >= L.uoff && col < L.uoff + P * K * F) {
       const int r = col - L.uoff, hp = r / (K * F), k = (r / F) % K, f = r % F;
-      v = taps[(((long long)hp * F + f) * K + k) * G + g];  // (P,F,1,K,G)
-    } else if (mode == MAGAT_MODE_GAT_MODIFIED && col >= L.c1off && col < L.c2off + P) {
+      if (mode == MAGAT_MODE_GAT_ORIGIN)
+        // scalar taps (E=1,K) x W: the reference reshapes permute(0,3,1,2)(W) = (P,G,E,F) straight into (P,F,E,1,G)
+        // (graphML.py:1967-1969), so with F == G the filter is W TRANSPOSED: h[p,f,k,g] = h_k * W[p,0,g,f]
+        v = taps[k] * weight[((long long)hp * F + g) * G + f];
+      else
+        v = taps[(((long long)hp * F + f) * K + k) * G + g];  // (P,F,1,K,G)
+    } else if (mode != MAGAT_MODE_KEYQUERY && col >= L.c1off && col < L.c2off + P) {
       const int which = col >= L.c2off, hp = which ? col - L.c2off : col - L.c1off;
       for (int f = 0; f < F; ++f)
         v = fmaf(mixer[(long long)hp * 2 * F + which * F + f], weight[((long long)hp * F + f) * G + g], v);
@@ -600,8 +613,9 @@ extern "C" int magat_gat_pack_weights(const float* weight, const float* weight_b
                                       void* stream) {
   if (!weight || !taps || !packed) return MAGAT_ERR_NULL;
   if (mode == MAGAT_MODE_GAT_MODIFIED && (!weight_bias || !mixer)) return MAGAT_ERR_NULL;
+  if (mode == MAGAT_MODE_GAT_ORIGIN && !mixer) return MAGAT_ERR_NULL;
   if (G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
-  if (mode != MAGAT_MODE_KEYQUERY && mode != MAGAT_MODE_GAT_MODIFIED) return MAGAT_ERR_UNSUPPORTED;
+  if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GAT_ORIGIN) return MAGAT_ERR_UNSUPPORTED;
   const PackLayout L = pack_layout(G, F, K, P, mode);
   const long long total = (long long)L.NC * (G + 1);
   int blocks = (int)((total + 255) / 256);
@@ -642,7 +656,7 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
                                             int mode, int concat, void* stream) {
   if (!X || !S || !packed || !Y) return MAGAT_ERR_NULL;
   if (B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
-  if (mode != MAGAT_MODE_KEYQUERY && mode != MAGAT_MODE_GAT_MODIFIED) return MAGAT_ERR_UNSUPPORTED;
+  if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GAT_ORIGIN) return MAGAT_ERR_UNSUPPORTED;
   if (G != F || !supported_width(G) || N > 128) return MAGAT_ERR_UNSUPPORTED;
   const int width = concat ? P * F : F;
   if (ldy < width || (ldy & 3)) return MAGAT_ERR_BAD_SHAPE;
@@ -660,7 +674,7 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
   float* Ytmp = reinterpret_cast<float*>(static_cast<char*>(workspace) +
                                          magat_align_up((size_t)chunk * N * L.NC * sizeof(float), 256));
   char* list_ws = reinterpret_cast<char*>(Ytmp) + (concat ? 0 : magat_align_up((size_t)B * N * P * F * sizeof(float), 256));
-  const bool use_list = gat_list_enabled() && magat_gat_list_capacity(N, G, F) > 0;
+  const bool use_list = gat_list_enabled() && mode != MAGAT_MODE_GAT_ORIGIN && magat_gat_list_capacity(N, G, F) > 0;
   GatParams p;
   p.over = nullptr;
   p.dbg = g_gat_dbg;

@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import _native as nat
 
 ZERO_TOLERANCE = 1e-9
-_MODES = {"KeyQuery": nat.MODE_KEYQUERY, "GAT_modified": nat.MODE_GAT_MODIFIED}
+_MODES = {"KeyQuery": nat.MODE_KEYQUERY, "GAT_modified": nat.MODE_GAT_MODIFIED, "GAT_origin": nat.MODE_GAT_ORIGIN}
 
 
 class _Scratch:
@@ -36,23 +36,24 @@ def _param_key(*tensors):
 def _packed_weights(layer, dev, stream, G, F, K, P, mode):
     lib = nat.lib()
     sc = layer._scratch
-    key = _param_key(layer.weight, layer.weight_bias, layer.mixer, layer.filterWeight) + (str(dev),)
+    tensors = layer._pack_tensors()          # (weight, weight_bias | None, mixer, taps)
+    key = _param_key(*[t for t in tensors if t is not None]) + (str(dev),)
     if sc.packed is None or sc.packed_key != key:
         nfl = lib.magat_gat_packed_floats(G, F, K, P, mode)
         if nfl == 0:
             raise nat.MagatNativeError("bad GAT shape G=%d F=%d K=%d P=%d" % (G, F, K, P))
         sc.packed = torch.empty(nfl, dtype=torch.float32, device=dev)
-        w = [t.detach().to(dev, torch.float32).contiguous()
-             for t in (layer.weight, layer.weight_bias, layer.mixer, layer.filterWeight)]
+        w = [None if t is None else t.detach().to(dev, torch.float32).contiguous() for t in tensors]
         nat.check(lib.magat_gat_pack_weights(nat.ptr(w[0]), nat.ptr(w[1]), nat.ptr(w[2]), nat.ptr(w[3]),
                                              nat.ptr(sc.packed), G, F, K, P, mode, stream), "magat_gat_pack_weights")
         sc.packed_key = key
     return sc.packed
 
 
-def dense_gso_to_csr(S3):
+def dense_gso_to_csr(S3, self_loops=False):
     """(B,N,N) device GSO -> (rowptr int32 [B*(N+1)] absolute offsets, colidx int32 [nnz], nnz) with the
-    reference's edge rule |S| > 1e-9 (graphML.py:1274-1276).  Two HIP kernels + one torch cumsum."""
+    reference's edge rule |S| > 1e-9 (graphML.py:1274-1276), or |float(S) + I| > 1e-9 for GAT_origin
+    (graphML.py:1018).  Two HIP kernels + one torch cumsum."""
     lib = nat.lib()
     B, N, _ = S3.shape
     dev = S3.device
@@ -60,12 +61,13 @@ def dense_gso_to_csr(S3):
     with torch.cuda.device(dev):
         stream = nat.current_stream(dev)
         deg = torch.empty(B * N, dtype=torch.int32, device=dev)
-        nat.check(lib.magat_gso_row_degrees(nat.ptr(S3), f64, nat.ptr(deg), B, N, stream), "magat_gso_row_degrees")
+        sl = 1 if self_loops else 0
+        nat.check(lib.magat_gso_row_degrees(nat.ptr(S3), f64, sl, nat.ptr(deg), B, N, stream), "magat_gso_row_degrees")
         ends = torch.cumsum(deg, 0, dtype=torch.int32)
         starts = (ends - deg).contiguous()
         nnz = int(ends[-1].item())
         colidx = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
-        nat.check(lib.magat_gso_fill_csr(nat.ptr(S3), f64, nat.ptr(starts), nat.ptr(colidx), B, N, stream),
+        nat.check(lib.magat_gso_fill_csr(nat.ptr(S3), f64, sl, nat.ptr(starts), nat.ptr(colidx), B, N, stream),
                   "magat_gso_fill_csr")
         rowptr = torch.empty(B, N + 1, dtype=torch.int32, device=dev)
         rowptr[:, :N] = starts.view(B, N)
@@ -141,7 +143,7 @@ def gat_forward_rows(X, S, layer, out=None, want_attention=False):
     sc = layer._scratch
     if not lib.magat_gat_dense_supported(N, G, F):
         # graph too large for the LDS-resident kernel: same layer through the CSR kernels
-        rowptr, colidx, nnz = dense_gso_to_csr(S3)
+        rowptr, colidx, nnz = dense_gso_to_csr(S3, self_loops=layer.attentionMode == "GAT_origin")
         out, att = gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=out, want_attention=want_attention)
         aij = _csr_attention_to_dense(att, rowptr, colidx, nnz, B, N, P) if want_attention else None
         return out, aij
@@ -165,8 +167,13 @@ def gat_forward_rows(X, S, layer, out=None, want_attention=False):
 
 def pack_torch(weight, weight_bias, mixer, taps, mode_name):
     """Differentiable torch twin of pack_kernel (csrc/gat_f32.hip): Bt [NC][G] and column bias [NC]."""
-    P, F, _, K, G = taps.shape
-    U = taps[:, :, 0].permute(0, 2, 1, 3).reshape(P * K * F, G)
+    if mode_name == "GAT_origin":          # taps = filterWeight (1,K); h[p,f,k,g] = h_k * W[p,0,g,f]
+        P, _, F, G = weight.shape
+        K = taps.shape[1]
+        U = torch.einsum("k,pgf->pkfg", taps[0], weight[:, 0]).reshape(P * K * F, G)
+    else:
+        P, F, _, K, G = taps.shape
+        U = taps[:, :, 0].permute(0, 2, 1, 3).reshape(P * K * F, G)
     if mode_name == "KeyQuery":
         Bt = torch.cat((weight[:, 0].reshape(P * G, G), U), dim=0)
         return Bt, torch.zeros(Bt.shape[0], dtype=Bt.dtype, device=Bt.device)
@@ -176,6 +183,8 @@ def pack_torch(weight, weight_bias, mixer, taps, mode_name):
     nc = (P * K * F + 2 * P + 3) // 4 * 4
     pad = torch.zeros(nc - P * K * F - 2 * P, G, dtype=U.dtype, device=U.device)
     Bt = torch.cat((U, v1, v2, pad), dim=0)
+    if weight_bias is None:
+        return Bt, torch.zeros(nc, dtype=U.dtype, device=U.device)
     wb = weight_bias[:, 0]
     cb = torch.cat((torch.zeros(P * K * F, dtype=U.dtype, device=U.device), (a1 * wb).sum(1), (a2 * wb).sum(1),
                     torch.zeros(nc - P * K * F - 2 * P, dtype=U.dtype, device=U.device)))
@@ -212,8 +221,10 @@ class _GatTrainFunction(torch.autograd.Function):
                 nat.ptr(csc[2]), B, N, G, F, K, P, mode, stream), "magat_gat_train_forward_f32")
         ctx.layer, ctx.nnz, ctx.dims = layer, nnz, (B, N, G, F, K, P, mode, NC)
         ctx.has_bias = bias is not None
+        ctx.no_wb = weight_bias is None
         ctx.save_for_backward(Xc, Z, att, T if T is not None else torch.empty(0, device=dev), rowptr, colidx, cscptr,
-                              csc, packed, weight, weight_bias, mixer, taps)
+                              csc, packed, weight, weight_bias if weight_bias is not None else torch.empty(0, device=dev),
+                              mixer, taps)
         return Ypre
 
     @staticmethod
@@ -237,11 +248,11 @@ class _GatTrainFunction(torch.autograd.Function):
         dX = (dXd + dZ @ Bt).view(B, N, G)                 # plain library GEMMs
         dBt, dcb = dZ.t() @ X2, dZ.sum(dim=0)
         grads = [None, None, None, None]
-        params = [weight, weight_bias, mixer, taps]
-        need = [i for i, t in enumerate(params) if t.requires_grad]
+        params = [weight, None if ctx.no_wb else weight_bias, mixer, taps]
+        need = [i for i, t in enumerate(params) if t is not None and t.requires_grad]
         if need:
             with torch.enable_grad():
-                leaves = [t.detach().requires_grad_(True) for t in params]
+                leaves = [None if t is None else t.detach().requires_grad_(True) for t in params]
                 Bt_t, cb_t = pack_torch(*leaves, ctx.layer.attentionMode)
                 outs, gouts = [Bt_t], [dBt]
                 if cb_t.requires_grad:          # KeyQuery has a constant (zero) column bias
@@ -259,22 +270,30 @@ def _composite(layer, x, S):
     B, G, N = x.shape
     P, F, K = layer.P, layer.F, layer.K
     X = x.transpose(1, 2)                                            # B,N,G
+    if layer.attentionMode == "GAT_origin":
+        S = S.detach().float() + torch.eye(N, dtype=torch.float32, device=S.device).view(1, 1, N, N)
     M = (S.detach().abs().sum(dim=1) > ZERO_TOLERANCE).to(x.dtype).unsqueeze(1)   # B,1,N,N
     if layer.attentionMode == "KeyQuery":
         Q = torch.einsum("bng,pog->bpno", X, layer.weight[:, 0])     # q_j = W x_j
         e = torch.einsum("big,bpjg->bpij", X, Q)
     else:
-        Wx = torch.einsum("bng,pfg->bpnf", X, layer.weight[:, 0]) + layer.weight_bias[:, 0].view(1, P, 1, F)
+        Wx = torch.einsum("bng,pfg->bpnf", X, layer.weight[:, 0])
+        if layer.attentionMode != "GAT_origin":
+            Wx = Wx + layer.weight_bias[:, 0].view(1, P, 1, F)
         c1 = torch.einsum("bpnf,pf->bpn", Wx, layer.mixer[:, 0, :F])
         c2 = torch.einsum("bpnf,pf->bpn", Wx, layer.mixer[:, 0, F:])
         e = nn.functional.leaky_relu(c1.unsqueeze(2) + c2.unsqueeze(3), 0.2)
     A = torch.softmax(e * M - (1 - M) * 1e12, dim=3) * M             # B,P,N,N
     At = A.transpose(2, 3)
     Z = X.unsqueeze(1).expand(B, P, N, G)
-    y = torch.einsum("bpng,pfg->bpnf", Z, layer.filterWeight[:, :, 0, 0])
+    if layer.attentionMode == "GAT_origin":      # h[p,f,k,g] = h_k * W[p,0,g,f]
+        taps = torch.einsum("k,pgf->pfkg", layer.filterWeight[0], layer.weight[:, 0])
+    else:
+        taps = layer.filterWeight[:, :, 0]
+    y = torch.einsum("bpng,pfg->bpnf", Z, taps[:, :, 0])
     for k in range(1, K):
         Z = torch.matmul(At, Z)
-        y = y + torch.einsum("bpng,pfg->bpnf", Z, layer.filterWeight[:, :, 0, k])
+        y = y + torch.einsum("bpng,pfg->bpnf", Z, taps[:, :, k])
     if layer.bias is not None:
         y = y + layer.bias.view(1, 1, 1, F)
     if layer.concatenate:
@@ -316,6 +335,9 @@ class GraphFilterBatchAttentional(nn.Module):
             self.weight = nn.Parameter(torch.empty(P, E, F, G))
         self._scratch = _Scratch()
         self.reset_parameters()
+
+    def _pack_tensors(self):
+        return self.weight, self.weight_bias, self.mixer, self.filterWeight
 
     def reset_parameters(self):
         # graphML.py:4604-4612
@@ -364,9 +386,10 @@ class GraphFilterBatchAttentional(nn.Module):
             S3 = self.S.reshape(B, N, N).to(x.device)
             if S3.dtype not in (torch.float32, torch.float64):
                 S3 = S3.float()
-            rowptr, colidx, nnz = dense_gso_to_csr(S3.contiguous())
-            Ypre = _GatTrainFunction.apply(x.permute(0, 2, 1).contiguous(), self.weight, self.weight_bias, self.mixer,
-                                           self.filterWeight, self.bias, rowptr, colidx, nnz, self)
+            rowptr, colidx, nnz = dense_gso_to_csr(S3.contiguous(), self_loops=self.attentionMode == "GAT_origin")
+            w_, wb_, mx_, tp_ = self._pack_tensors()
+            Ypre = _GatTrainFunction.apply(x.permute(0, 2, 1).contiguous(), w_, wb_, mx_, tp_, self.bias, rowptr,
+                                           colidx, nnz, self)
             Yh = Ypre.view(B, N, self.P, self.F)
             if self.concatenate:
                 y = torch.relu(Yh).reshape(B, N, self.P * self.F).permute(0, 2, 1)
@@ -391,3 +414,47 @@ class GraphFilterBatchAttentional(nn.Module):
         s += "attentionMode=%s, " % self.attentionMode
         s += ("GSO stored: number_nodes=%d" % self.N) if self.S is not None else "no GSO stored"
         return s
+
+
+class GraphFilterBatchAttentional_Origin(GraphFilterBatchAttentional):
+    """Drop-in for the reference class of the same name (graphML.py:4175-4339), attentionMode 'GAT_origin': the
+    GAT baseline of the paper.  Parameters: mixer (P,E,2F), weight (P,E,F,G), filterWeight (E,K) scalar taps, bias (F,1).
+    Self-loops are added to the GSO; the filter is h_k * W (transposed, see oracle.attention notes).  Same kernels as
+    GAT_modified with a different weight packing and mask rule (MAGAT_MODE_GAT_ORIGIN)."""
+
+    def __init__(self, G, F, K, P, E=1, bias=True, nonlinearity=nn.functional.relu, concatenate=True,
+                 attentionMode="GAT_origin"):
+        nn.Module.__init__(self)
+        if E != 1:
+            raise NotImplementedError("edge_features E=1 only")
+        if G != F:
+            raise NotImplementedError("GAT_origin needs F == G (the reference reshapes W (P,G,E,F) into (P,F,E,1,G))")
+        self.G, self.F, self.K, self.P, self.E = G, F, K, P, E
+        self.S = None
+        self.aij = None
+        self.nonlinearity = nonlinearity
+        self.concatenate = concatenate
+        self.attentionMode = "GAT_origin"
+        self.return_attention = False
+        self.mixer = nn.Parameter(torch.empty(P, E, 2 * F))
+        self.weight = nn.Parameter(torch.empty(P, E, F, G))
+        self.filterWeight = nn.Parameter(torch.empty(E, K))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(F, 1))
+        else:
+            self.register_parameter("bias", None)
+        self._scratch = _Scratch()
+        self.reset_parameters()
+
+    def _pack_tensors(self):
+        return self.weight, None, self.mixer, self.filterWeight
+
+    def reset_parameters(self):
+        # graphML.py:4259-4266
+        stdv = 1.0 / math.sqrt(self.G * self.P)
+        with torch.no_grad():
+            self.weight.uniform_(-stdv, stdv)
+            self.mixer.uniform_(-stdv, stdv)
+            self.filterWeight.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import _native as nat
 from . import encoder as enc
-from .graphml import GraphFilterBatchAttentional, gat_forward_rows
+from .graphml import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin, gat_forward_rows
 from .resnet import ResNet, ResNetSlim
 
 _SKIP_FILES = {
@@ -98,10 +98,11 @@ class DecentralPlannerGATNet(nn.Module):
         self.P = [config.nAttentionHeads]
         self.E = 1
         self.bias = True
-        if config.attentionMode not in ("GAT_modified", "KeyQuery"):
+        if config.attentionMode not in ("GAT_modified", "KeyQuery", "GAT_origin"):
             raise NotImplementedError("attentionMode %r is outside the built hot path (SURVEY.md section 8(f))"
                                       % (config.attentionMode,))
-        self.GFL = nn.Sequential(GraphFilterBatchAttentional(
+        layer_cls = GraphFilterBatchAttentional_Origin if config.attentionMode == "GAT_origin" else GraphFilterBatchAttentional
+        self.GFL = nn.Sequential(layer_cls(
             self.F[0], self.F[1], self.K[0], self.P[0], self.E, self.bias,
             concatenate=config.AttentionConcat, attentionMode=config.attentionMode))
 

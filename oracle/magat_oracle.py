@@ -87,6 +87,20 @@ def attention_modified(x, mixer, W, Wb, S4, negative_slope=0.2):
     return a * m
 
 
+def attention_origin(x, mixer, W, S4, negative_slope=0.2):
+    """GAT_origin scores (graphML.py:964-1069): self-loops added to the GSO (S.float() + I), no weight_bias."""
+    B, G, N = x.shape
+    P, E, F = W.shape[0], W.shape[1], W.shape[2]
+    S4 = S4.float() + torch.eye(N, dtype=torch.float32).reshape(1, 1, N, N)
+    Wx = torch.matmul(W.reshape(1, P, E, F, G), x.reshape(B, 1, 1, G, N))
+    row = torch.matmul(mixer[:, :, :F].reshape(1, P, E, 1, F), Wx)
+    col = torch.matmul(mixer[:, :, F:].reshape(1, P, E, 1, F), Wx).transpose(3, 4)
+    e = tnf.leaky_relu(row + col, negative_slope)
+    m = edge_mask(S4, x.dtype)
+    a = torch.softmax(e * m - (1 - m) * INFINITE_NUMBER, dim=4)
+    return a * m
+
+
 def lsigf_attention(h, x, aij, b):
     """K-tap filter with the learned attention as shift (graphML.py:1744-1775):
     z_0 = x, z_k = z_{k-1} @ aij (column aggregation), y = sum_k z_k h_k + b.
@@ -115,14 +129,24 @@ def gat_layer_forward(x, S4, p, mode="KeyQuery", concat=True, n_graph=None):
     N = S4.shape[2] if n_graph is None else n_graph
     if Nin < N:
         x = torch.cat((x, torch.zeros(B, G, N - Nin, dtype=x.dtype)), dim=2)
+    taps = p["filterWeight"]
     if mode == "KeyQuery":
         aij = attention_keyquery(x, p["weight"], S4)
     elif "GAT_modified" in mode:
         aij = attention_modified(x, p["mixer"], p["weight"], p["weight_bias"], S4)
+    elif mode == "GAT_origin":
+        # GraphFilterBatchAttentional_Origin (graphML.py:4175-4339): scalar taps (E,K) times W (graphML.py:1967-1970)
+        aij = attention_origin(x, p["mixer"], p["weight"], S4)
+        W = p["weight"]                                              # (P,E,F,G)
+        Pn, En, Fn, Gn = W.shape
+        # the reference builds "P x F x E x G" with permute(0,3,1,2) -- which is (P,G,E,F) -- and then RESHAPES it to
+        # (P,F,E,1,G) (graphML.py:1967-1969): with F == G the filter uses W transposed, h[p,f,k,g] = hk * W[p,0,g,f]
+        Wq = W.permute(0, 3, 1, 2).reshape(Pn, Fn, En, 1, Gn)
+        taps = taps.reshape(1, 1, En, -1, 1) * Wq                    # (P,F,E,K,G)
     else:
-        raise ValueError("oracle covers KeyQuery and GAT_modified only, got %r" % mode)
-    y = lsigf_attention(p["filterWeight"], x, aij, p.get("bias"))
-    P, F = p["filterWeight"].shape[0], p["filterWeight"].shape[1]
+        raise ValueError("oracle covers KeyQuery, GAT_modified and GAT_origin, got %r" % mode)
+    y = lsigf_attention(taps, x, aij, p.get("bias"))
+    P, F = taps.shape[0], taps.shape[1]
     if concat:
         y = torch.relu(y)
         y = y.permute(0, 3, 1, 2).reshape(B, N, P * F).permute(0, 2, 1)
@@ -142,6 +166,9 @@ def gat_layer_forward_loops(x, S4, p, mode="KeyQuery", concat=True):
     B, G, N = x.shape
     W = np.asarray(p["weight"], np.float64)
     Hf = np.asarray(p["filterWeight"], np.float64)
+    origin = mode == "GAT_origin"
+    if origin:     # h[p,f,0,k,g] = h_k * W[p,0,g,f]  (transposed W: graphML.py:1967-1969, F == G)
+        Hf = np.einsum("k,pgf->pfkg", Hf.reshape(-1), W[:, 0])[:, :, None]
     P, F, _, K, _ = Hf.shape
     bias = None if p.get("bias") is None else np.asarray(p["bias"], np.float64).reshape(F)
     X = x.transpose(0, 2, 1)                                   # B,N,G rows = nodes
@@ -149,12 +176,15 @@ def gat_layer_forward_loops(x, S4, p, mode="KeyQuery", concat=True):
     Y = np.zeros((B, P, N, F))
     for b in range(B):
         M = np.abs(S[b]).sum(axis=0) > ZERO_TOLERANCE
+        if origin:     # self-loops: |float32(S) + I| > 1e-9
+            with np.errstate(invalid="ignore"):
+                M = np.abs(np.asarray(S4[b][0], np.float32) + np.eye(N, dtype=np.float32)) > np.float32(ZERO_TOLERANCE)
         for q in range(P):
             if mode == "KeyQuery":
                 Q = X[b] @ W[q, 0].T                           # Q[j] = W x_j
             else:
                 a = np.asarray(p["mixer"], np.float64)[q, 0]
-                wb = np.asarray(p["weight_bias"], np.float64)[q, 0]
+                wb = 0.0 if origin else np.asarray(p["weight_bias"], np.float64)[q, 0]
                 Wx = X[b] @ W[q, 0].T + wb
                 c1, c2 = Wx @ a[:F], Wx @ a[F:]
             for i in range(N):
@@ -253,7 +283,7 @@ def planner_forward(x, S, sd, cfg, return_parts=False):
     comp = torch.relu(tnf.linear(feat, sd["compressMLP.0.weight"], sd["compressMLP.0.bias"]))
     G = comp.shape[1]
     xg = comp.reshape(B, N, G).permute(0, 2, 1)
-    gp = {k: sd["GFL.0." + k] for k in ("mixer", "weight_bias", "filterWeight", "bias", "weight")}
+    gp = {k: sd["GFL.0." + k] for k in ("mixer", "weight_bias", "filterWeight", "bias", "weight") if "GFL.0." + k in sd}
     yg, aij = gat_layer_forward(xg, S4, gp, cfg.attentionMode, cfg.AttentionConcat)
     shared = yg.permute(0, 2, 1).reshape(B * N, yg.shape[1])
     if mode == "BottomNeck_skipConcat":
@@ -340,10 +370,15 @@ def init_state_dict(cfg, seed=1337, perturb_bn=True):
         return (torch.rand(*shape, generator=g) * 2 - 1) * stdv
 
     sd["GFL.0.mixer"] = uni(P, 1, 2 * F)
-    sd["GFL.0.weight_bias"] = uni(P, 1, F) * (1.0 if perturb_bn else 0.0)
-    sd["GFL.0.filterWeight"] = uni(P, F, 1, K, G)
-    sd["GFL.0.bias"] = uni(F, 1)
-    sd["GFL.0.weight"] = uni(P, 1, G, G) if cfg.attentionMode == "KeyQuery" else uni(P, 1, F, G)
+    if cfg.attentionMode == "GAT_origin":
+        sd["GFL.0.weight"] = uni(P, 1, F, G)
+        sd["GFL.0.filterWeight"] = uni(1, K)
+        sd["GFL.0.bias"] = uni(F, 1)
+    else:
+        sd["GFL.0.weight_bias"] = uni(P, 1, F) * (1.0 if perturb_bn else 0.0)
+        sd["GFL.0.filterWeight"] = uni(P, F, 1, K, G)
+        sd["GFL.0.bias"] = uni(F, 1)
+        sd["GFL.0.weight"] = uni(P, 1, G, G) if cfg.attentionMode == "KeyQuery" else uni(P, 1, F, G)
     nin = P * F if cfg.AttentionConcat else F
     if bmode == "BottomNeck_skipConcat":
         nin += nfm

@@ -52,13 +52,14 @@ def layer_fixture(gml, mode, N, G, K, P, seed, density, f64):
     gen = torch.Generator().manual_seed(seed)
     B, F = 2, G
     layers = {}
+    cls = gml.GraphFilterBatchAttentional_Origin if mode == "GAT_origin" else gml.GraphFilterBatchAttentional
     for concat in (True, False):
         torch.manual_seed(seed)
-        layers[concat] = gml.GraphFilterBatchAttentional(G, F, K, P, 1, True, concatenate=concat,
-                                                         attentionMode=mode)
+        layers[concat] = cls(G, F, K, P, 1, True, concatenate=concat, attentionMode=mode)
     ref = layers[True]
     with torch.no_grad():
-        ref.weight_bias.uniform_(-0.3, 0.3, generator=gen)   # reference init is 0; exercise it
+        if mode != "GAT_origin":
+            ref.weight_bias.uniform_(-0.3, 0.3, generator=gen)   # reference init is 0; exercise it
         layers[False].load_state_dict(ref.state_dict())
     x = torch.randn(B, G, N, generator=gen) * 0.7
     S = tricky_gso(gen, B, N, density, f64).unsqueeze(1)
@@ -104,7 +105,8 @@ def model_fixture(classes, name, seed, B, **cfgkw):
                 mod.running_mean.normal_(0, 0.2, generator=gen)
                 mod.running_var.uniform_(0.5, 1.5, generator=gen)
                 mod.bias.normal_(0, 0.1, generator=gen)
-        model.GFL[0].weight_bias.uniform_(-0.3, 0.3, generator=gen)
+        if hasattr(model.GFL[0], "weight_bias"):
+            model.GFL[0].weight_bias.uniform_(-0.3, 0.3, generator=gen)
         for n_, p_ in model.named_parameters():
             if n_.endswith(".bias") and p_.dim() == 1 and "bn" not in n_ and "downsample" not in n_:
                 p_.normal_(0, 0.05, generator=gen)
@@ -123,6 +125,23 @@ def model_fixture(classes, name, seed, B, **cfgkw):
     for k, v in model.state_dict().items():
         out["sd/" + k] = v.numpy()
     return out
+
+
+def main_origin():
+    """GAT_origin fixtures (added after the first set; generated separately so the earlier files stay byte-identical)."""
+    gml, classes = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    for si, (N, G, K, P) in enumerate([(10, 128, 2, 1), (20, 128, 3, 4), (100, 32, 3, 4), (12, 16, 3, 4)]):
+        fx = layer_fixture(gml, "GAT_origin", N, G, K, P, seed=2337 + 13 * si, density=0.3 if N <= 20 else 0.1,
+                           f64=(si % 2 == 1))
+        path = os.path.join(OUT, "gat_GAT_origin_N%d_G%d_K%d_P%d.npz" % (N, G, K, P))
+        np.savez_compressed(path, **fx)
+        print("wrote", path, os.path.getsize(path) // 1024, "KB")
+    fx = model_fixture(classes, "origin_skipconcat", 5151, 2, num_agents=16, nGraphFilterTaps=3, nAttentionHeads=4,
+                       attentionMode="GAT_origin", bottleneckMode="BottomNeck_skipConcat", bottleneckFeature=64)
+    path = os.path.join(OUT, "model_origin_skipconcat.npz")
+    np.savez_compressed(path, **fx)
+    print("wrote", path, os.path.getsize(path) // 1024, "KB")
 
 
 def main():
@@ -161,4 +180,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--origin" in sys.argv:
+        main_origin()
+    else:
+        main()

@@ -106,13 +106,14 @@ def test_conv_first(gpu_device):
 def test_gat_layer_vs_reference_golden(gpu_device, path):
     """HIP GraphFilterBatchAttentional vs the outputs the real reference produced (tolerance: north star 1e-4;
     observed ~1e-6)."""
-    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from magat_pathplanning_amd import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin
     z, p = load_layer_fixture(path)
     mode, N, G, K, P = str(z["mode"]), int(z["N"]), int(z["G"]), int(z["K"]), int(z["P"])
     x = torch.from_numpy(z["x"]).to(gpu_device)
     S = torch.from_numpy(z["S"]).to(gpu_device)
+    cls = GraphFilterBatchAttentional_Origin if mode == "GAT_origin" else GraphFilterBatchAttentional
     for concat, key in ((True, "y_concat"), (False, "y_mean")):
-        layer = GraphFilterBatchAttentional(G, G, K, P, 1, True, concatenate=concat, attentionMode=mode)
+        layer = cls(G, G, K, P, 1, True, concatenate=concat, attentionMode=mode)
         layer.load_state_dict(p)
         layer = layer.to(gpu_device).eval()
         layer.return_attention = True
@@ -160,18 +161,22 @@ def test_errors_are_loud(gpu_device):
 
 @pytest.mark.parametrize("mode,concat,N,G,K,P", [("KeyQuery", True, 150, 128, 3, 4), ("KeyQuery", False, 200, 64, 2, 2),
                                                 ("GAT_modified", True, 130, 32, 4, 3), ("KeyQuery", True, 40, 128, 3, 4),
-                                                ("GAT_modified", False, 300, 128, 2, 4), ("KeyQuery", True, 64, 16, 1, 2)])
+                                                ("GAT_modified", False, 300, 128, 2, 4), ("KeyQuery", True, 64, 16, 1, 2),
+                                                ("GAT_origin", True, 140, 64, 3, 4), ("GAT_origin", False, 50, 128, 2, 2)])
 def test_gat_csr_path_vs_oracle(gpu_device, mode, concat, N, G, K, P):
     """Large-graph (CSR) kernels against the pinned dense oracle; N <= 128 cases force the CSR entry point."""
-    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from magat_pathplanning_amd import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin
     from magat_pathplanning_amd.graphml import dense_gso_to_csr, gat_forward_rows_csr, _csr_attention_to_dense
     from magat_pathplanning_amd.synthetic import comm_gso
     from oracle import magat_oracle as orc
     B = 3
     g = torch.Generator().manual_seed(N + G)
-    layer = GraphFilterBatchAttentional(G, G, K, P, concatenate=concat, attentionMode=mode)
+    origin = mode == "GAT_origin"
+    layer = (GraphFilterBatchAttentional_Origin if origin else GraphFilterBatchAttentional)(
+        G, G, K, P, concatenate=concat, attentionMode=mode)
     with torch.no_grad():
-        layer.weight_bias.uniform_(-0.3, 0.3, generator=g)
+        if not origin:
+            layer.weight_bias.uniform_(-0.3, 0.3, generator=g)
     x = torch.randn(B, G, N, generator=g) * 0.7
     S = comm_gso(B, N, int(8 * N ** 0.5), seed=N, dtype=torch.float64)
     S[0, 5, :] = 0                     # a row without edges
@@ -181,8 +186,9 @@ def test_gat_csr_path_vs_oracle(gpu_device, mode, concat, N, G, K, P):
     y_ref, a_ref = orc.gat_layer_forward(x, S.unsqueeze(1), params, mode, concat)
     layer = layer.to(gpu_device).eval()
     X = x.permute(0, 2, 1).contiguous().to(gpu_device)
-    rowptr, colidx, nnz = dense_gso_to_csr(S.to(gpu_device))
-    assert nnz == int((S.abs() > 1e-9).sum())
+    rowptr, colidx, nnz = dense_gso_to_csr(S.to(gpu_device), self_loops=origin)
+    S_eff = S.float().double() + torch.eye(N, dtype=torch.float64) if origin else S
+    assert nnz == int((S_eff.abs() > 1e-9).sum())
     with torch.no_grad():
         out, att = gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, want_attention=True)
     torch.cuda.synchronize()
@@ -319,18 +325,22 @@ def test_f32_conv_emits_bf16x3_planes(gpu_device):
 
 @pytest.mark.parametrize("mode,concat,N,G,K,P", [("KeyQuery", True, 12, 64, 3, 2), ("KeyQuery", False, 20, 128, 2, 4),
                                                 ("GAT_modified", True, 9, 32, 4, 3), ("KeyQuery", True, 30, 16, 1, 2),
-                                                ("GAT_modified", False, 40, 128, 3, 2)])
+                                                ("GAT_modified", False, 40, 128, 3, 2), ("GAT_origin", True, 14, 32, 3, 4),
+                                                ("GAT_origin", False, 25, 64, 2, 2)])
 def test_gat_training_backward_matches_autograd(gpu_device, mode, concat, N, G, K, P):
     """HIP training forward/backward of the layer vs float64 autograd of the composite (same algebra as the pinned
     oracle) on CPU: output, dx and every parameter gradient."""
-    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from magat_pathplanning_amd import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin
     from magat_pathplanning_amd.graphml import _composite
     from magat_pathplanning_amd.synthetic import comm_gso
     B = 3
     g = torch.Generator().manual_seed(N * 7 + G)
-    ref = GraphFilterBatchAttentional(G, G, K, P, concatenate=concat, attentionMode=mode).double()
+    origin = mode == "GAT_origin"
+    cls = GraphFilterBatchAttentional_Origin if origin else GraphFilterBatchAttentional
+    ref = cls(G, G, K, P, concatenate=concat, attentionMode=mode).double()
     with torch.no_grad():
-        ref.weight_bias.uniform_(-0.3, 0.3, generator=g)
+        if not origin:
+            ref.weight_bias.uniform_(-0.3, 0.3, generator=g)
     x = (torch.randn(B, G, N, generator=g) * 0.6).double().requires_grad_(True)
     S = comm_gso(B, N, max(6, int(4 * N ** 0.5)), seed=N, dtype=torch.float64)
     S[0, 2, :] = 0
@@ -338,7 +348,7 @@ def test_gat_training_backward_matches_autograd(gpu_device, mode, concat, N, G, 
     wgt = torch.randn(B, P * G if concat else G, N, generator=g).double()
     y_ref, _ = _composite(ref, x, S.unsqueeze(1))
     (y_ref * wgt).sum().backward()
-    layer = GraphFilterBatchAttentional(G, G, K, P, concatenate=concat, attentionMode=mode)
+    layer = cls(G, G, K, P, concatenate=concat, attentionMode=mode)
     layer.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
     layer = layer.to(gpu_device).train()
     xg = x.detach().float().to(gpu_device).requires_grad_(True)
@@ -354,9 +364,11 @@ def test_gat_training_backward_matches_autograd(gpu_device, mode, concat, N, G, 
 
     close(y, y_ref, "y")
     close(xg.grad, x.grad, "dx")
-    names = ["filterWeight", "bias"] + (["weight"] if K > 1 else [])
+    names = ["filterWeight", "bias"] + (["weight"] if K > 1 or origin else [])
     if mode == "GAT_modified" and K > 1:
         names += ["mixer", "weight_bias"]
+    if origin and K > 1:
+        names += ["mixer"]
     for n_ in names:
         close(getattr(layer, n_).grad, getattr(ref, n_).grad, n_)
 

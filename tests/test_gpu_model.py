@@ -46,6 +46,7 @@ def test_model_vs_reference_golden(gpu_device, path):
     (16, 20, 3, 4, "KeyQuery", True, "BottomNeck_only"),
     (64, 10, 2, 1, "KeyQuery", True, "BottomNeck_only"),
     (4, 100, 3, 4, "GAT_modified", False, "BottomNeck_skipConcatGNN"),
+    (4, 100, 3, 4, "GAT_origin", True, "BottomNeck_skipConcat"),
 ])
 def test_model_vs_oracle_benchmark_shapes(gpu_device, B, N, K, P, mode, concat, skip):
     from oracle import magat_oracle as orc

@@ -92,10 +92,11 @@ def test_encoder_fold_matches_unfolded_cnn():
 @pytest.mark.parametrize("path", [p for p in LAYER if "N12" in p or "N10" in p],
                          ids=lambda p: os.path.basename(p)[:-4])
 def test_layer_training_composite_matches_reference(path):
-    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from magat_pathplanning_amd import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin
     z, p = load_layer_fixture(path)
     G, K, P = int(z["G"]), int(z["K"]), int(z["P"])
-    layer = GraphFilterBatchAttentional(G, G, K, P, attentionMode=str(z["mode"]))
+    cls = GraphFilterBatchAttentional_Origin if str(z["mode"]) == "GAT_origin" else GraphFilterBatchAttentional
+    layer = cls(G, G, K, P, attentionMode=str(z["mode"]))
     layer.load_state_dict(p)
     layer.addGSO(torch.from_numpy(z["S"]))
     y = layer(torch.from_numpy(z["x"]))

@@ -13,7 +13,7 @@ MODEL = golden_paths("model_")
 
 
 def test_fixtures_present():
-    assert len(LAYER) == 10 and len(MODEL) == 6
+    assert len(LAYER) == 14 and len(MODEL) == 7
 
 
 @pytest.mark.parametrize("path", LAYER, ids=[os.path.basename(p)[:-4] for p in LAYER])
