@@ -90,6 +90,15 @@ int magat_gat_forward_csr_f32(const float* X, const int* rowptr, const int* coli
                               const float* bias, float* Y, int ldy, float* att_opt, void* workspace,
                               size_t workspace_bytes, int B, int N, int G, int F, int K, int P, int mode, int concat,
                               void* stream);
+/* bf16-STORAGE variant (BASELINE config 5: "1000 agents, CSR, bf16"; SURVEY.md 8(b) `..._csr_{f32,bf16}`): X, the hoisted
+ * maps Z, the hop intermediates and Y are bf16 in HBM (raw uint16 bit patterns, RNE), all arithmetic accumulates in
+ * fp32 (bf16 MFMA for the maps GEMM with the RNE-bf16 plane of the packed weights; fp32 scores / softmax / gathers),
+ * attention values stay fp32.  Same packed weights as the f32 entry point.  Needs G % 32 == 0.  ldy in elements. */
+size_t magat_gat_csr_bf16_workspace_bytes(int B, int N, long long nnz, int G, int F, int K, int P, int mode, int concat);
+int magat_gat_forward_csr_bf16(const uint16_t* X, const int* rowptr, const int* colidx, long long nnz,
+                               const float* packed, const float* bias, uint16_t* Y, int ldy, float* att_opt,
+                               void* workspace, size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
+                               int mode, int concat, void* stream);
 /* Training support (caller: loss.backward() at agents/decentralplannerlocal_OnlineExpert_GAT.py:564).
  * Forward that keeps what the backward needs: Ypre [M][P*F] = per-head filter outputs + bias BEFORE ReLU / head merge
  * (the caller's autograd owns those), att [P][nnz] (CSR order), Z [M][NC], T [(K-2)][M][P*F] (intermediate hop
@@ -150,7 +159,8 @@ typedef struct magat_conv_gemm_desc {
    * cores as six partial products (conv_gemm_bf16x6.hip) and in, in2, wt are all bf16x3 (wt planes are
    * Cout*Ktot apart).  in_fmt = 2: same kernel, but in / in2 stay float32 in memory and are split into their three
    * planes by the loader on the way into LDS (wt still bf16x3).  out_fmt = 1 makes the epilogue emit the 3-plane
-   * form. */
+   * form.  in_fmt = 3: in, in2 and wt are ONE bf16 plane each (plain bf16 GEMM, fp32 accumulate); out_fmt = 2: the
+   * epilogue emits one RNE bf16 plane.  Formats 1-3 need Cin, C2, Cout % 32 == 0 and no pooling. */
   int in_fmt, out_fmt;
   int64_t in_plane_stride, in2_plane_stride, out_plane_stride;
   /* Agent-tile strides (elements).  Row m of a pixel lives at  (m / 128) * tile_stride + (m % 128) * ld.

@@ -63,6 +63,8 @@ _SIGNATURES = {
     "magat_gat_forward_dense_f32": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_csr_workspace_bytes": (_Z, [_I, _I, ctypes.c_longlong] + [_I] * 6),
     "magat_gat_forward_csr_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
+    "magat_gat_csr_bf16_workspace_bytes": (_Z, [_I, _I, ctypes.c_longlong] + [_I] * 6),
+    "magat_gat_forward_csr_bf16": (_I, [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_train_forward_f32": (_I, [_P, _P, _P, ctypes.c_longlong] + [_P] * 10 + [_I] * 7 + [_P]),
     "magat_gat_train_backward_f32": (_I, [_P] * 10 + [ctypes.c_longlong] + [_P] * 3 + [_I] * 7 + [_P]),
     "magat_gso_row_degrees": (_I, [_P, _I, _I, _P, _I, _I, _P]),

@@ -63,13 +63,16 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned& p1, unsig
 // loader on the way into LDS (no 3-plane tensors in HBM, 2/3 of the activation traffic); weights are always
 // pre-split bf16x3.
 // BN = 128 / 64 / 32 output channels per tile; waves WGM x WGN, wave tile (128/WGM) x (BN/WGN).
-template <bool AF32, int BN, int WGM, int WGN>
+// NPL = 3: the bf16x6 split product.  NPL = 1: plain bf16 storage (in_fmt 3: one bf16 plane for activations AND
+// weights, one product) - the bf16 variant of the GAT maps GEMM for BASELINE config 5.
+template <bool AF32, int BN, int WGM, int WGN, int NPL = 3>
 __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitParams p) {
+  static_assert(NPL == 3 || (NPL == 1 && !AF32), "plane count");
   constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 32, TN = WTN / 32;
   constexpr int BI = BN >= 64 ? BN / 64 : 1;      // weight-tile 16-byte loads per thread and plane
-  __shared__ __attribute__((aligned(16))) u16 lds[3 * (BM + BN) * 32];   // A planes | B planes
+  __shared__ __attribute__((aligned(16))) u16 lds[NPL * (BM + BN) * 32];   // A planes | B planes
   u16* As = lds;
-  u16* Bs = lds + 3 * BM * 32;
+  u16* Bs = lds + NPL * BM * 32;
 
   const int bid = blockIdx.x;
   const int xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
   const char* const seg2_base = reinterpret_cast<const char*>(p.in2) +
                                 (long long)(oy * p.stride2 * p.W2 + ox * p.stride2) * p.in2_pix_stride * AE;
 
-  u32x4 ra[3][2], rb[3][BI];
+  u32x4 ra[NPL][2], rb[NPL][BI];
   f32x4 fa32[4];
   auto load_slab = [&]() {
     const bool main_seg = cur_main;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
         fa32[i] = *reinterpret_cast<const f32x4*>(ab + (main_seg ? faoff[i] : faoff2[i]));
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < NPL; ++pl) {
       if constexpr (!AF32) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
       }
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < NPL; ++pl) {
       if constexpr (!AF32) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(a + pl * (BM * 64) + loff[i]) = ra[pl][i];
@@ -222,9 +225,9 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
     if (s + 1 < nslab) load_slab();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[TM][3], fb[TN][3];
+      bf16x8 fa[TM][NPL], fb[TN][NPL];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[i][pl] = frag(As + pl * BM * 32, wm * WTM + i * 32 + fr, ks);
 #pragma unroll
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
       // interleaved so consecutive MFMAs never depend on each other
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
+      for (int q = (NPL == 3 ? 0 : 5); q < 6; ++q)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -263,7 +266,15 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
           if (p.relu) v[c] = fmaxf(v[c], 0.f);
         }
         const long long o = (long long)pix * p.out_pix_stride + magat_row_off(m, p.ldc, p.out_tile) + n;
-        if (p.out_split) {
+        if (p.out_split == 2) {            // one RNE bf16 plane
+          u16* dst = static_cast<u16*>(p.out) + o;
+          if (vec) {
+            *reinterpret_cast<uint2*>(dst) = uint2{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[c] = bf16_rne(v[c]);
+          }
+        } else if (p.out_split) {
           u16* ob = static_cast<u16*>(p.out);
           u16 h[3][4];
 #pragma unroll
@@ -299,14 +310,16 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 
 }  // namespace
 
-// in_fmt 1: in/in2/wt all bf16x3 planes; in_fmt 2: in/in2 float32 (split on load), wt bf16x3 planes; Cout % 128 == 0, Cin % 32 == 0, C2 % 32 == 0, lda/lda2 % 8 == 0.
+// in_fmt 1: in/in2/wt all bf16x3 planes; in_fmt 2: in/in2 float32 (split on load), wt bf16x3 planes; in_fmt 3: in/in2/wt
+// ONE bf16 plane each (plain bf16 GEMM, fp32 accumulate).  out_fmt 0 f32, 1 bf16x3 planes, 2 one bf16 plane.
+// Cout % 32 == 0, Cin % 32 == 0, C2 % 32 == 0, lda/lda2 % 8 == 0.
 int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   if (!d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
   if (d->M <= 0 || d->Cin <= 0 || d->Cout <= 0) return MAGAT_ERR_BAD_SHAPE;
   const int BN = d->Cout % 128 == 0 ? 128 : (d->Cout % 64 == 0 ? 64 : 32);
   if ((d->Cout % BN) || (d->Cin % BK) || (d->C2 % BK) || (d->lda % 8) || (d->C2 > 0 && (d->lda2 % 8)) || d->pool)
     return MAGAT_ERR_UNSUPPORTED;
-  if (d->in_fmt != 1 && d->in_fmt != 2) return MAGAT_ERR_UNSUPPORTED;
+  if (d->in_fmt < 1 || d->in_fmt > 3 || d->out_fmt < 0 || d->out_fmt > 2) return MAGAT_ERR_UNSUPPORTED;
   SplitParams p;
   p.in = static_cast<const u16*>(static_cast<const void*>(d->in));
   p.in2 = static_cast<const u16*>(static_cast<const void*>(d->in2));
@@ -324,7 +337,7 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.C2 = d->C2; p.lda2 = d->lda2; p.W2 = d->W2; p.stride2 = d->stride2;
   p.Cout = d->Cout; p.Ktot = d->kH * d->kW * d->Cin + d->C2; p.ldc = d->ldc; p.relu = d->relu;
   p.wt_plane = (long long)p.Cout * p.Ktot;
-  p.npix = d->Hout * d->Wout; p.tag = d->tag; p.out_split = d->out_fmt == 1;
+  p.npix = d->Hout * d->Wout; p.tag = d->tag; p.out_split = d->out_fmt;
   p.Mt = (p.M + BM - 1) / BM;
   p.ntn = p.Cout / BN;
   if (magat_row_off(p.M, p.lda, p.in_tile) * 4 >= 0xffffffffLL ||
@@ -338,7 +351,10 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   const bool af32 = d->in_fmt == 2;
 #define MAGAT_SPLIT_LAUNCH(BNV, WM, WN)                                                                              \
   do {                                                                                                              \
-    if (af32)                                                                                                       \
+    if (d->in_fmt == 3)                                                                                             \
+      hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<false, BNV, WM, WN, 1>), dim3((unsigned)grid), dim3(256), 0, st,  \
+                         p);                                                                                        \
+    else if (af32)                                                                                                  \
       hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<true, BNV, WM, WN>), dim3((unsigned)grid), dim3(256), 0, st, p);  \
     else                                                                                                            \
       hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<false, BNV, WM, WN>), dim3((unsigned)grid), dim3(256), 0, st, p); \

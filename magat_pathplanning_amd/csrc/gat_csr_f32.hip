@@ -19,24 +19,53 @@
 
 namespace {
 
+typedef unsigned short u16;
+
+// Storage type of the node-feature tensors (X, Z, hop intermediates, Y): float, or bf16 (u16) for the bf16-storage
+// variant of BASELINE config 5.  Arithmetic is fp32 either way; attention values stay fp32.
+template <typename ST> __device__ __forceinline__ float to_f32(ST v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<u16>(u16 v) { return magat_bf16_f32(v); }
+template <typename ST> __device__ __forceinline__ ST from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ u16 from_f32<u16>(float v) { return magat_bf16_rne(v); }
+template <typename ST, int V>
+struct __attribute__((aligned(sizeof(ST) * V))) Pack {
+  ST v[V];
+};
+template <int V, typename ST>
+__device__ __forceinline__ void load_vec(const ST* ptr, float (&o)[V]) {
+  const Pack<ST, V> r = *reinterpret_cast<const Pack<ST, V>*>(ptr);
+#pragma unroll
+  for (int c = 0; c < V; ++c) o[c] = to_f32<ST>(r.v[c]);
+}
+template <int V, typename ST>
+__device__ __forceinline__ void store_vec(ST* ptr, const float (&o)[V]) {
+  Pack<ST, V> r;
+#pragma unroll
+  for (int c = 0; c < V; ++c) r.v[c] = from_f32<ST>(o[c]);
+  *reinterpret_cast<Pack<ST, V>*>(ptr) = r;
+}
+
 struct CsrParams {
-  const float* X;      // [B*N, G]
-  const float* Z;      // [B*N, NC]
+  const void* X;       // [B*N, G]   (ST)
+  const void* Z;       // [B*N, NC]  (ST)
   const int* rowptr;   // [B*(N+1)]
   const int* colidx;   // [nnz]
   const int* cscptr;   // [B*(N+1)] (workspace)
   const int* cscsrc;   // [nnz] source node i of each in-edge
   const int* cscpos;   // [nnz] position of that edge in CSR order
   float* att;          // [P][nnz] attention values in CSR order
-  const float* Told;   // hop input rows  [B*N*P? see ldt]  (row = (b*N+i), head offset applied by caller)
-  float* Tnew;
+  const void* Told;    // hop input rows (ST)  (row = (b*N+i), head offset applied by caller)
+  void* Tnew;          // (ST)
   const float* bias;
-  float* Y;
+  void* Y;             // (ST)
   int B, N, K, P, mode, concat;
   int NC, qoff, uoff, c1off, c2off, ldy;
   long long nnz;
   int k;               // hop index (U_k added)
-  int told_ld, told_head_stride;   // addressing of Told rows: Told + (b*N+i)*told_ld + head*told_head_stride
+  long long told_off;              // element offset of the first Told row inside its buffer
+  int told_ld, told_head_stride;   // addressing of Told rows: Told + told_off + (b*N+i)*told_ld + head*told_head_stride
   int last;
   int act_relu;           // apply ReLU in the last hop's store (inference); 0 in training (autograd owns it)
 };
@@ -107,7 +136,7 @@ __global__ __launch_bounds__(256) void csr_sort_columns_kernel(const int* __rest
 }
 
 // ---- 3. scores + row softmax.  8 lanes per row, 32 rows per 256-thread block.
-template <int G>
+template <int G, typename ST>
 __global__ __launch_bounds__(256) void csr_scores_kernel(const CsrParams p) {
   constexpr int GC = G / 4, CP8 = GC / 8 > 0 ? GC / 8 : 1, LE = GC < 8 ? GC : 8;
   const int N = p.N;
@@ -124,7 +153,7 @@ __global__ __launch_bounds__(256) void csr_scores_kernel(const CsrParams p) {
   const int* rp = p.rowptr + (long long)b * (N + 1);
   const int e0 = rp[i], e1 = rp[i + 1];
   if (e1 <= e0) return;
-  const float* Zb = p.Z + (long long)b * N * p.NC;
+  const ST* Zb = static_cast<const ST*>(p.Z) + (long long)b * N * p.NC;
   float* att = p.att + (long long)head * p.nnz;
   // Row softmax without cross-lane memory traffic: the raw scores are written by one lane and later rewritten
   // by that same lane (program order makes its own stores visible to it); max and sum are carried online in
@@ -136,22 +165,23 @@ __global__ __launch_bounds__(256) void csr_scores_kernel(const CsrParams p) {
     mx = m2;
   };
   if (p.mode == MAGAT_MODE_KEYQUERY) {
-    const float* xr = p.X + ((long long)b * N + i) * G;
-    f32x4 xi[CP8];
+    const ST* xr = static_cast<const ST*>(p.X) + ((long long)b * N + i) * G;
+    float xi[CP8][4];
 #pragma unroll
-    for (int q = 0; q < CP8; ++q) xi[q] = *reinterpret_cast<const f32x4*>(xr + 4 * (es + LE * q));
+    for (int q = 0; q < CP8; ++q) load_vec<4, ST>(xr + 4 * (es + LE * q), xi[q]);
     const int qo = p.qoff + head * G;
     for (int e = e0; e < e1; e += 2) {
       const int j0 = p.colidx[e];
       const bool two = e + 1 < e1;
       const int j1 = two ? p.colidx[e + 1] : j0;
-      const float* q0 = Zb + (long long)j0 * p.NC + qo;
-      const float* q1 = Zb + (long long)j1 * p.NC + qo;
+      const ST* q0 = Zb + (long long)j0 * p.NC + qo;
+      const ST* q1 = Zb + (long long)j1 * p.NC + qo;
       float d0 = 0.f, d1 = 0.f;
 #pragma unroll
       for (int q = 0; q < CP8; ++q) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(q0 + 4 * (es + LE * q));
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(q1 + 4 * (es + LE * q));
+        float a0[4], a1[4];
+        load_vec<4, ST>(q0 + 4 * (es + LE * q), a0);
+        load_vec<4, ST>(q1 + 4 * (es + LE * q), a1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           d0 = fmaf(xi[q][c], a0[c], d0);
@@ -180,9 +210,9 @@ __global__ __launch_bounds__(256) void csr_scores_kernel(const CsrParams p) {
       for (int e = e0; e < e1; ++e) att[e] = __expf(att[e] - mx) * inv;
     }
   } else {
-    const float c2 = Zb[(long long)i * p.NC + p.c2off + head];
+    const float c2 = to_f32<ST>(Zb[(long long)i * p.NC + p.c2off + head]);
     for (int e = e0 + es; e < e1; e += LE) {
-      const float v = Zb[(long long)p.colidx[e] * p.NC + p.c1off + head] + c2;
+      const float v = to_f32<ST>(Zb[(long long)p.colidx[e] * p.NC + p.c1off + head]) + c2;
       const float l = v > 0.f ? v : 0.2f * v;
       att[e] = l;
       online(l);
@@ -204,11 +234,10 @@ __global__ __launch_bounds__(256) void csr_scores_kernel(const CsrParams p) {
 }
 
 // ---- 4. one Horner hop: out[j] = U_k[j] + sum_{in-edges (i -> j)} att[pos] * Told[i]; wave per output row
-template <int F>
+template <int F, typename ST>
 __global__ __launch_bounds__(256) void csr_hop_kernel(const CsrParams p) {
   constexpr int VEC = F >= 64 ? F / 64 : 1;
   constexpr int LANES = F >= 64 ? 64 : F;
-  typedef float fvec __attribute__((ext_vector_type(VEC)));
   const int N = p.N;
   const int tiles = (N + 3) / 4;         // 4 rows (waves) per block
   const int bid = blockIdx.x, xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
@@ -222,17 +251,21 @@ __global__ __launch_bounds__(256) void csr_hop_kernel(const CsrParams p) {
   const int* cp = p.cscptr + (long long)b * (N + 1);
   const int s0 = cp[j], s1 = cp[j + 1];
   const float* att = p.att + (long long)head * p.nnz;
-  const float* Tb = p.Told + (long long)b * N * p.told_ld + (long long)head * p.told_head_stride + VEC * lane;
-  const float* Zr = p.Z + ((long long)b * N + j) * p.NC + p.uoff + (head * p.K + p.k) * F + VEC * lane;
-  fvec acc = *reinterpret_cast<const fvec*>(Zr);
+  const ST* Tb = static_cast<const ST*>(p.Told) + p.told_off + (long long)b * N * p.told_ld +
+                 (long long)head * p.told_head_stride + VEC * lane;
+  const ST* Zr = static_cast<const ST*>(p.Z) + ((long long)b * N + j) * p.NC + p.uoff + (head * p.K + p.k) * F + VEC * lane;
+  float acc[VEC];
+  load_vec<VEC, ST>(Zr, acc);
   for (int s = s0; s < s1; s += 2) {
     const int i0 = p.cscsrc[s];
     const float a0 = att[p.cscpos[s]];
-    const fvec t0 = *reinterpret_cast<const fvec*>(Tb + (long long)i0 * p.told_ld);
+    float t0[VEC];
+    load_vec<VEC, ST>(Tb + (long long)i0 * p.told_ld, t0);
     if (s + 1 < s1) {
       const int i1 = p.cscsrc[s + 1];
       const float a1 = att[p.cscpos[s + 1]];
-      const fvec t1 = *reinterpret_cast<const fvec*>(Tb + (long long)i1 * p.told_ld);
+      float t1[VEC];
+      load_vec<VEC, ST>(Tb + (long long)i1 * p.told_ld, t1);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) acc[c] = fmaf(a1, t1[c], fmaf(a0, t0[c], acc[c]));
     } else {
@@ -241,19 +274,22 @@ __global__ __launch_bounds__(256) void csr_hop_kernel(const CsrParams p) {
     }
   }
   if (p.last) {
-    if (p.bias) acc += *reinterpret_cast<const fvec*>(p.bias + VEC * lane);
+    if (p.bias) {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) acc[c] += p.bias[VEC * lane + c];
+    }
     if (p.act_relu) {
 #pragma unroll
       for (int c = 0; c < VEC; ++c) acc[c] = fmaxf(acc[c], 0.f);
     }
-    *reinterpret_cast<fvec*>(p.Y + ((long long)b * N + j) * p.ldy + head * F + VEC * lane) = acc;
+    store_vec<VEC, ST>(static_cast<ST*>(p.Y) + ((long long)b * N + j) * p.ldy + head * F + VEC * lane, acc);
   } else {
-    *reinterpret_cast<fvec*>(p.Tnew + (((long long)b * N + j) * p.P + head) * F + VEC * lane) = acc;
+    store_vec<VEC, ST>(static_cast<ST*>(p.Tnew) + (((long long)b * N + j) * p.P + head) * F + VEC * lane, acc);
   }
 }
 
 // K == 1: Y = U_0 + bias (no graph work)
-template <int F>
+template <int F, typename ST>
 __global__ void csr_k1_kernel(const CsrParams p) {
   const long long total = (long long)p.B * p.N * p.P * (F / 4);
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -262,12 +298,14 @@ __global__ void csr_k1_kernel(const CsrParams p) {
     const long long r = idx / (F / 4);
     const int head = (int)(r % p.P);
     const long long m = r / p.P;
-    f32x4 v = *reinterpret_cast<const f32x4*>(p.Z + m * p.NC + p.uoff + head * F + 4 * c);
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + 4 * c);
-    if (p.act_relu) {
-      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    float v[4];
+    load_vec<4, ST>(static_cast<const ST*>(p.Z) + m * p.NC + p.uoff + head * F + 4 * c, v);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (p.bias) v[q] += p.bias[4 * c + q];
+      if (p.act_relu) v[q] = fmaxf(v[q], 0.f);
     }
-    *reinterpret_cast<f32x4*>(p.Y + m * p.ldy + head * F + 4 * c) = v;
+    store_vec<4, ST>(static_cast<ST*>(p.Y) + m * p.ldy + head * F + 4 * c, v);
   }
 }
 
@@ -279,7 +317,7 @@ Layout layout(int G, int F, int K, int P, int mode) {   // must match pack_layou
   if (mode == MAGAT_MODE_KEYQUERY) {
     L.qoff = 0; L.uoff = P * G; L.c1off = L.c2off = 0; L.NC = P * G + P * K * F;
   } else {
-    L.qoff = 0; L.uoff = 0; L.c1off = P * K * F; L.c2off = L.c1off + P; L.NC = (L.c2off + P + 3) & ~3;
+    L.qoff = 0; L.uoff = 0; L.c1off = P * K * F; L.c2off = L.c1off + P; L.NC = (L.c2off + P + 31) & ~31;
   }
   return L;
 }
@@ -287,53 +325,55 @@ Layout layout(int G, int F, int K, int P, int mode) {   // must match pack_layou
 struct WsLayout {
   size_t z, cscptr, cscsrc, cscpos, csctmp, att, t0, t1, ytmp, total;
 };
-WsLayout ws_layout(int B, int N, long long nnz, int G, int F, int K, int P, int mode, int concat) {
+WsLayout ws_layout(int B, int N, long long nnz, int G, int F, int K, int P, int mode, int concat,
+                   size_t esz = sizeof(float)) {
   const Layout L = layout(G, F, K, P, mode);
   WsLayout w;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += magat_align_up(bytes, 256); return at; };
-  w.z = take((size_t)B * N * L.NC * sizeof(float));
+  w.z = take((size_t)B * N * L.NC * esz);
   w.cscptr = take((size_t)B * (N + 1) * sizeof(int));
   w.cscsrc = take((size_t)nnz * sizeof(int));
   w.cscpos = take((size_t)nnz * sizeof(int));
   w.csctmp = take((size_t)nnz * sizeof(int));
   w.att = take((size_t)P * nnz * sizeof(float));
-  const size_t tb = K > 2 ? (size_t)B * N * P * F * sizeof(float) : 0;
+  const size_t tb = K > 2 ? (size_t)B * N * P * F * esz : 0;
   w.t0 = take(tb);
   w.t1 = take(K > 3 ? tb : 0);
-  w.ytmp = take(concat ? 0 : (size_t)B * N * P * F * sizeof(float));
+  w.ytmp = take(concat ? 0 : (size_t)B * N * P * F * esz);
   w.total = o;
   return w;
 }
 
-template <int G>
+template <int G, typename ST = float>
 int run_scores(const CsrParams& p, hipStream_t st) {
   constexpr int LE = (G / 4) < 8 ? (G / 4) : 8;
   const int rows = 256 / LE, tiles = (p.N + rows - 1) / rows;
   const long long grid = (long long)((p.B + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD) * MAGAT_NUM_XCD * p.P * tiles;
   if (grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
   const int pid = magat_prof_begin(MAGAT_TAG_GAT_GRAPH, st);
-  hipLaunchKernelGGL((csr_scores_kernel<G>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((csr_scores_kernel<G, ST>), dim3((unsigned)grid), dim3(256), 0, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
-template <int F>
+template <int F, typename ST = float>
 int run_hop(const CsrParams& p, hipStream_t st) {
   const int tiles = (p.N + 3) / 4;
   const long long grid = (long long)((p.B + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD) * MAGAT_NUM_XCD * p.P * tiles;
   if (grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
   const int pid = magat_prof_begin(MAGAT_TAG_GAT_GRAPH, st);
-  hipLaunchKernelGGL((csr_hop_kernel<F>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((csr_hop_kernel<F, ST>), dim3((unsigned)grid), dim3(256), 0, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
-template <int F>
+template <int F, typename ST = float>
 int run_k1(const CsrParams& p, hipStream_t st) {
-  hipLaunchKernelGGL((csr_k1_kernel<F>), dim3(2048), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((csr_k1_kernel<F, ST>), dim3(2048), dim3(256), 0, st, p);
   return magat_check_launch();
 }
 
-__global__ void head_mean_relu_csr_kernel(const float* __restrict__ ytmp, float* __restrict__ y, long long M, int P,
+template <typename ST>
+__global__ void head_mean_relu_csr_kernel(const ST* __restrict__ ytmp, ST* __restrict__ y, long long M, int P,
                                           int F, int ldy) {
   const int FC = F / 4;
   const long long total = M * FC;
@@ -341,26 +381,56 @@ __global__ void head_mean_relu_csr_kernel(const float* __restrict__ ytmp, float*
        idx += (long long)gridDim.x * blockDim.x) {
     const long long m = idx / FC;
     const int c = (int)(idx - m * FC);
-    f32x4 s = *reinterpret_cast<const f32x4*>(ytmp + m * (long long)P * F + 4 * c);
-    for (int q = 1; q < P; ++q) s += *reinterpret_cast<const f32x4*>(ytmp + (m * P + q) * (long long)F + 4 * c);
+    float s[4], u[4];
+    load_vec<4, ST>(ytmp + m * (long long)P * F + 4 * c, s);
+    for (int q = 1; q < P; ++q) {
+      load_vec<4, ST>(ytmp + (m * P + q) * (long long)F + 4 * c, u);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += u[e];
+    }
     const float fp = (float)P;
-    f32x4 r = {fmaxf(s[0] / fp, 0.f), fmaxf(s[1] / fp, 0.f), fmaxf(s[2] / fp, 0.f), fmaxf(s[3] / fp, 0.f)};
-    *reinterpret_cast<f32x4*>(y + m * ldy + 4 * c) = r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = fmaxf(s[e] / fp, 0.f);
+    store_vec<4, ST>(y + m * ldy + 4 * c, s);
   }
 }
 
-}  // namespace
 
-extern "C" size_t magat_gat_csr_workspace_bytes(int B, int N, long long nnz, int G, int F, int K, int P, int mode,
-                                                int concat) {
-  if (B <= 0 || N <= 0 || nnz < 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
-  return ws_layout(B, N, nnz, G, F, K, P, mode, concat).total;
+
+#define MAGAT_CSR_DISPATCH(WIDTH, FN, ST)                   \
+  switch (WIDTH) {                                         \
+    case 16: rc = FN<16, ST>(p, st); break;                \
+    case 32: rc = FN<32, ST>(p, st); break;                \
+    case 64: rc = FN<64, ST>(p, st); break;                \
+    case 128: rc = FN<128, ST>(p, st); break;              \
+    default: rc = FN<256, ST>(p, st);                      \
+  }
+
+// maps GEMM Z = X @ Bt^T + colbias in the storage type: fp32 (fp32 MFMA / bf16x6 split) or bf16 in, bf16 out
+// (one bf16 MFMA product per element pair, fp32 accumulate; weights = plane 0 of the packed bf16x3 block)
+template <typename ST>
+int csr_maps_gemm(const ST* X, const float* packed, ST* Z, int M, int G, const Layout& L, void* stream);
+template <>
+int csr_maps_gemm<float>(const float* X, const float* packed, float* Z, int M, int G, const Layout& L, void* stream) {
+  return magat_gat_maps_gemm(X, packed, Z, M, G, L.NC, L.NC, stream);
+}
+template <>
+int csr_maps_gemm<u16>(const u16* X, const float* packed, u16* Z, int M, int G, const Layout& L, void* stream) {
+  if ((L.NC % 32) || (G % 32)) return MAGAT_ERR_UNSUPPORTED;
+  magat_conv_gemm_desc d = {};
+  d.in = reinterpret_cast<const float*>(X);
+  d.wt = packed + (((size_t)L.NC * (G + 1) + 3) & ~(size_t)3);     // bf16x3 planes; plane 0 = RNE bf16 of Bt
+  d.bias = packed + (size_t)L.NC * G;
+  d.out = reinterpret_cast<float*>(Z);
+  d.M = M; d.Cin = G; d.lda = G; d.Hin = d.Win = 1; d.kH = d.kW = 1; d.stride = 1; d.Hout = d.Wout = 1;
+  d.Cout = L.NC; d.ldc = L.NC; d.tag = MAGAT_TAG_GAT_MAPS; d.in_fmt = 3; d.out_fmt = 2;
+  return magat_conv_gemm_f32(&d, stream);
 }
 
-extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, const int* colidx, long long nnz,
-                                         const float* packed, const float* bias, float* Y, int ldy, float* att_opt,
-                                         void* workspace, size_t workspace_bytes, int B, int N, int G, int F, int K,
-                                         int P, int mode, int concat, void* stream) {
+template <typename ST>
+int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz, const float* packed,
+                const float* bias, ST* Y, int ldy, float* att_opt, void* workspace, size_t workspace_bytes, int B,
+                int N, int G, int F, int K, int P, int mode, int concat, void* stream) {
   if (!X || !rowptr || !packed || !Y || (nnz > 0 && !colidx)) return MAGAT_ERR_NULL;
   if (B <= 0 || N <= 0 || nnz < 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
   if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GAT_ORIGIN) return MAGAT_ERR_UNSUPPORTED;
@@ -368,22 +438,21 @@ extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, cons
   if ((size_t)(2 * N + 2) * sizeof(int) > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;   // transpose LDS (N <= 8190)
   const int width = concat ? P * F : F;
   if (ldy < width || (ldy & 3)) return MAGAT_ERR_BAD_SHAPE;
-  const WsLayout w = ws_layout(B, N, nnz, G, F, K, P, mode, concat);
+  const WsLayout w = ws_layout(B, N, nnz, G, F, K, P, mode, concat, sizeof(ST));
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < w.total)
     return MAGAT_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* ws = static_cast<char*>(workspace);
   const Layout L = layout(G, F, K, P, mode);
-  float* Z = reinterpret_cast<float*>(ws + w.z);
+  ST* Z = reinterpret_cast<ST*>(ws + w.z);
   int* cscptr = reinterpret_cast<int*>(ws + w.cscptr);
   int* cscsrc = reinterpret_cast<int*>(ws + w.cscsrc);
   int* cscpos = reinterpret_cast<int*>(ws + w.cscpos);
   float* att = att_opt ? att_opt : reinterpret_cast<float*>(ws + w.att);
-  float* tbuf[2] = {reinterpret_cast<float*>(ws + w.t0), reinterpret_cast<float*>(ws + w.t1)};
-  float* Ytmp = reinterpret_cast<float*>(ws + w.ytmp);
+  ST* tbuf[2] = {reinterpret_cast<ST*>(ws + w.t0), reinterpret_cast<ST*>(ws + w.t1)};
+  ST* Ytmp = reinterpret_cast<ST*>(ws + w.ytmp);
 
-  int rc = magat_linear_tagged_f32(X, G, packed, packed + (size_t)L.NC * G, Z, L.NC, B * N, L.NC, G, 0,
-                                   MAGAT_TAG_GAT_MAPS, stream);
+  int rc = csr_maps_gemm<ST>(X, packed, Z, B * N, G, L, stream);
   if (rc != MAGAT_OK) return rc;
 
   CsrParams p = {};
@@ -394,13 +463,7 @@ extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, cons
   p.NC = L.NC; p.qoff = L.qoff; p.uoff = L.uoff; p.c1off = L.c1off; p.c2off = L.c2off;
 
   if (K == 1 && !att_opt) {
-    switch (F) {
-      case 16: rc = run_k1<16>(p, st); break;
-      case 32: rc = run_k1<32>(p, st); break;
-      case 64: rc = run_k1<64>(p, st); break;
-      case 128: rc = run_k1<128>(p, st); break;
-      default: rc = run_k1<256>(p, st);
-    }
+    MAGAT_CSR_DISPATCH(F, run_k1, ST)
     if (rc != MAGAT_OK) return rc;
   } else {
     if (K > 1) {
@@ -414,22 +477,10 @@ extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, cons
       magat_prof_end(pid, st);
       if ((rc = magat_check_launch()) != MAGAT_OK) return rc;
     }
-    switch (G) {
-      case 16: rc = run_scores<16>(p, st); break;
-      case 32: rc = run_scores<32>(p, st); break;
-      case 64: rc = run_scores<64>(p, st); break;
-      case 128: rc = run_scores<128>(p, st); break;
-      default: rc = run_scores<256>(p, st);
-    }
+    MAGAT_CSR_DISPATCH(G, run_scores, ST)
     if (rc != MAGAT_OK) return rc;
     if (K == 1) {
-      switch (F) {
-        case 16: rc = run_k1<16>(p, st); break;
-        case 32: rc = run_k1<32>(p, st); break;
-        case 64: rc = run_k1<64>(p, st); break;
-        case 128: rc = run_k1<128>(p, st); break;
-        default: rc = run_k1<256>(p, st);
-      }
+      MAGAT_CSR_DISPATCH(F, run_k1, ST)
       if (rc != MAGAT_OK) return rc;
     }
     // hops k = K-2 .. 0; the first reads U_{K-1} straight out of Z
@@ -437,22 +488,18 @@ extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, cons
       p.k = k;
       p.last = k == 0;
       if (h == 0) {
-        p.Told = Z + L.uoff + (K - 1) * F;   // row (b*N+i): + i*NC, head: + head*K*F
+        p.Told = Z;                          // row (b*N+i): + i*NC, head: + head*K*F
+        p.told_off = L.uoff + (K - 1) * F;
         p.told_ld = L.NC;
         p.told_head_stride = K * F;
       } else {
         p.Told = tbuf[(h - 1) & 1];
+        p.told_off = 0;
         p.told_ld = P * F;
         p.told_head_stride = F;
       }
       p.Tnew = tbuf[h & 1];
-      switch (F) {
-        case 16: rc = run_hop<16>(p, st); break;
-        case 32: rc = run_hop<32>(p, st); break;
-        case 64: rc = run_hop<64>(p, st); break;
-        case 128: rc = run_hop<128>(p, st); break;
-        default: rc = run_hop<256>(p, st);
-      }
+      MAGAT_CSR_DISPATCH(F, run_hop, ST)
       if (rc != MAGAT_OK) return rc;
     }
   }
@@ -461,11 +508,40 @@ extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, cons
     long long blocks = (M * (F / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     const int pid = magat_prof_begin(MAGAT_TAG_HEAD_MEAN, st);
-    hipLaunchKernelGGL(head_mean_relu_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Ytmp, Y, M, P, F, ldy);
+    hipLaunchKernelGGL((head_mean_relu_csr_kernel<ST>), dim3((unsigned)blocks), dim3(256), 0, st, Ytmp, Y, M, P, F, ldy);
     magat_prof_end(pid, st);
     return magat_check_launch();
   }
   return MAGAT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t magat_gat_csr_workspace_bytes(int B, int N, long long nnz, int G, int F, int K, int P, int mode,
+                                                int concat) {
+  if (B <= 0 || N <= 0 || nnz < 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
+  return ws_layout(B, N, nnz, G, F, K, P, mode, concat).total;
+}
+extern "C" size_t magat_gat_csr_bf16_workspace_bytes(int B, int N, long long nnz, int G, int F, int K, int P, int mode,
+                                                     int concat) {
+  if (B <= 0 || N <= 0 || nnz < 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
+  return ws_layout(B, N, nnz, G, F, K, P, mode, concat, sizeof(u16)).total;
+}
+
+extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, const int* colidx, long long nnz,
+                                         const float* packed, const float* bias, float* Y, int ldy, float* att_opt,
+                                         void* workspace, size_t workspace_bytes, int B, int N, int G, int F, int K,
+                                         int P, int mode, int concat, void* stream) {
+  return csr_forward<float>(X, rowptr, colidx, nnz, packed, bias, Y, ldy, att_opt, workspace, workspace_bytes, B, N, G,
+                            F, K, P, mode, concat, stream);
+}
+
+extern "C" int magat_gat_forward_csr_bf16(const uint16_t* X, const int* rowptr, const int* colidx, long long nnz,
+                                          const float* packed, const float* bias, uint16_t* Y, int ldy,
+                                          float* att_opt, void* workspace, size_t workspace_bytes, int B, int N, int G,
+                                          int F, int K, int P, int mode, int concat, void* stream) {
+  return csr_forward<u16>(X, rowptr, colidx, nnz, packed, bias, Y, ldy, att_opt, workspace, workspace_bytes, B, N, G, F,
+                          K, P, mode, concat, stream);
 }
 
 // Dense GSO -> CSR edge structure (|S| > 1e-9), two calls: count (rowptr via caller-side prefix) is avoided by
@@ -765,8 +841,7 @@ extern "C" int magat_gat_train_forward_f32(const float* X, const int* rowptr, co
   hipStream_t st = static_cast<hipStream_t>(stream);
   const Layout L = layout(G, F, K, P, mode);
   const long long M = (long long)B * N;
-  int rc = magat_linear_tagged_f32(X, G, packed, packed + (size_t)L.NC * G, Z, L.NC, (int)M, L.NC, G, 0,
-                                   MAGAT_TAG_GAT_MAPS, stream);
+  int rc = magat_gat_maps_gemm(X, packed, Z, (int)M, G, L.NC, L.NC, stream);
   if (rc != MAGAT_OK) return rc;
   CsrParams p = {};
   p.X = X; p.Z = Z; p.rowptr = rowptr; p.colidx = colidx; p.cscptr = cscptr; p.cscsrc = cscsrc; p.cscpos = cscpos;

@@ -18,6 +18,7 @@
 //      (column aggregation with row-normalised weights - the reference's x @ aij quirk).  Y is written once,
 //      already in the (B*N, P*F) layout actionsMLP consumes.  This kernel is ~3 flop/byte: HBM-bound.
 #include <cstdlib>
+#include <type_traits>
 
 #include "magat_common.h"
 
@@ -38,6 +39,8 @@ struct GatParams {
   int skip;                      // instrumentation: bit0 skip scores, bit1 skip hops (wrong results; for PMC deltas)
   const int* over;               // when set: only instances with over[bl] != 0 are processed here (the rest were
                                  // handled by the list kernel, gat_list_f32.hip)
+  int hpb;                       // heads per workgroup (1, or P: the workgroup walks all heads of its instance and
+                                 // loads the next head's Q tile while the current head computes)
 };
 
 // diag: 1 on the diagonal when the mode adds self-loops (GAT_origin: S.float() + I, graphML.py:1018)
@@ -75,8 +78,9 @@ __global__ void gat_dense_kernel(const GatParams p) {
   const int N = p.N;
   const int bid = blockIdx.x;
   const int xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
-  const int bl = xcd + MAGAT_NUM_XCD * (slot / p.P);   // heads of one instance share an XCD (X_b, S_b in L2)
-  const int head = slot % p.P;
+  const int hpb = p.hpb, hgroups = p.P / hpb;
+  const int bl = xcd + MAGAT_NUM_XCD * (slot / hgroups);   // heads of one instance share an XCD (X_b, S_b in L2)
+  const int head0 = (slot % hgroups) * hpb;
   if (bl >= p.B) return;
   if (p.over && !p.over[bl]) return;
   const int b = p.b0 + bl;
@@ -101,22 +105,81 @@ __global__ void gat_dense_kernel(const GatParams p) {
   long long* dbg = p.dbg ? p.dbg + (long long)bid * 8 : nullptr;
   if (dbg && t == 0) dbg[0] = clock64();
 
-  // ---- phase 0: issue every global read of the first three phases
+  // ---- phase 0 (once per workgroup): the GSO edge masks, this wave's x_i rows, the first head's tiles.
+  // WIDE path: the Q_p and U_{K-1} tiles ([N][128] floats, rows NC floats apart in Z) travel global -> LDS with the
+  // LDS-direct load (global_load_lds_dwordx4: no destination registers, so nothing for the compiler to guard with
+  // s_waitcnt vmcnt(0) and nothing to spill).  A workgroup walks hpb heads; while a head's last hop runs, the next
+  // head's Q tile streams into the hop buffer that is no longer read, and that head's U_{K-1} tile streams in during
+  // its score phase - only the very first tile's latency is exposed.
+  // Narrow path (G < 64, hpb == 1): tiles are staged through registers as before.
   f32x4 qst[QG], xst[QG], ust[QF];
-  fvec ucur[HMAX], unext[HMAX];
   fvec zerov;
 #pragma unroll
   for (int e = 0; e < VEC; ++e) zerov[e] = 0.f;
-  const int qo = p.qoff + head * G;
-  if (keyquery && need_att) {
+  // "settle": an empty asm that reads and redefines a register.  The compiler waits for the load that produced the
+  // value right here (where waiting is harmless) and afterwards no longer tracks it as an outstanding memory
+  // result - otherwise its loop-carried bookkeeping guards later uses with s_waitcnt vmcnt(0), which would also
+  // wait for the LDS-direct tile loads in flight.
+#define MAGAT_SETTLE_F(x) asm volatile("" : "+v"(x))
+  // one wave instruction moves 64 consecutive 16-byte chunks of the tile (LDS address = M0 + 16 * lane)
+  auto dma_tile = [&](float* dst, int col_off, int tv) {
+    const int lane_ = tv & 63;
+    const int wave_ = __builtin_amdgcn_readfirstlane(tv >> 6);
+    const int total = N * GC;
+    for (int g = wave_; g * 64 < total; g += nwaves) {
+      const int idx = g * 64 + lane_;
+      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)dst + (unsigned)g * 1024u);
+      if (idx < total) {
+        const int n = idx / GC, c = idx % GC;
+        const float* src = Zb + (long long)n * p.NC + col_off + 4 * c;
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+      }
+    }
+  };
+  auto tiles_landed = [&]() {      // this wave's outstanding loads are done; then everybody's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  auto issue_q = [&](int head, int tl) {
+    const int qo = p.qoff + head * G;
+#pragma unroll
+    for (int q = 0; q < QG; ++q) {
+      const int idx = tl + q * NT, n = idx / GC, c = idx % GC;
+      qst[q] = *reinterpret_cast<const f32x4*>(Zb + (long long)(n < N ? n : 0) * p.NC + qo + 4 * c);
+    }
+  };
+  auto issue_u = [&](int head, int tl) {
+    const int uo = p.uoff + (head * K + (K - 1)) * F;
+#pragma unroll
+    for (int q = 0; q < QF; ++q) {
+      const int idx = tl + q * NT, n = idx / FC, c = idx % FC;
+      ust[q] = *reinterpret_cast<const f32x4*>(Zb + (long long)(n < N ? n : 0) * p.NC + uo + 4 * c);
+    }
+  };
+  float* Rq = R0;     // LDS buffer holding the current head's Q tile (WIDE: alternates between heads)
+  float* Ru = R1;     // ... and its U_{K-1} tile
+  // WIDE score phase: 8 lanes per graph row (8 rows per wave step, exactly one step per wave since NT >= 8 N); lane es
+  // owns chunks es + 8*(q ^ (eg&1)) of a feature row: odd groups start on the other 128-byte half, so the 16-lane
+  // ds_read_b128 service groups never collide.  The x_i row of the group is the same for every head: registers.
+  constexpr int CP8 = GC / 8 > 0 ? GC / 8 : 1;
+  f32x4 xi[CP8];
+  if constexpr (WIDE) {
+    if (keyquery && need_att) {
+      dma_tile(Rq, p.qoff + head0 * G, t);
+      const int es0 = lane & 7, eg0 = lane >> 3, par0 = eg0 & 1;
+      const int i = 8 * wave + eg0, ir = i < N ? i : 0;
+#pragma unroll
+      for (int q = 0; q < CP8; ++q)
+        xi[q] = *reinterpret_cast<const f32x4*>(Xb + (long long)ir * p.ldx + 4 * (es0 + 8 * (q ^ par0)));
+    }
+    if (K > 1) dma_tile(Ru, p.uoff + (head0 * K + (K - 1)) * F, t);
+  } else if (keyquery && need_att) {
+    issue_q(head0, t);
 #pragma unroll
     for (int q = 0; q < QG; ++q) {
       const int idx = t + q * NT, n = idx / GC, c = idx % GC;
-      qst[q] = zero4; xst[q] = zero4;
-      if (n < N) {
-        qst[q] = *reinterpret_cast<const f32x4*>(Zb + (long long)n * p.NC + qo + 4 * c);
-        xst[q] = *reinterpret_cast<const f32x4*>(Xb + (long long)n * p.ldx + 4 * c);
-      }
+      xst[q] = zero4;
+      if (n < N) xst[q] = *reinterpret_cast<const f32x4*>(Xb + (long long)n * p.ldx + 4 * c);
     }
   }
   if (need_att) {
@@ -139,46 +202,68 @@ __global__ void gat_dense_kernel(const GatParams p) {
         A[i * p.lda_a + j] = is_edge(p.S, sbase + idx, p.s_is_f64, sl) ? 1.f : 0.f;
       }
     }
-    if (!keyquery)
-      for (int n = t; n < N; n += NT) {
-        c1s[n] = Zb[(long long)n * p.NC + p.c1off + head];
-        c2s[n] = Zb[(long long)n * p.NC + p.c2off + head];
-      }
   }
-  if (K > 1) {
-    const int uo = p.uoff + (head * K + (K - 1)) * F;
+  const int rpw = WIDE ? 1 : RPW;
+  // bias slice of this lane (hop-phase lane map), loaded once
+  fvec biasv = zerov;
+  if (p.bias) biasv = *reinterpret_cast<const fvec*>(p.bias + VEC * (WIDE ? lane : lane % LF));
+  if constexpr (WIDE) {
 #pragma unroll
-    for (int q = 0; q < QF; ++q) {
-      const int idx = t + q * NT, n = idx / FC, c = idx % FC;
-      ust[q] = zero4;
-      if (n < N) ust[q] = *reinterpret_cast<const f32x4*>(Zb + (long long)n * p.NC + uo + 4 * c);
+    for (int e = 0; e < VEC; ++e) MAGAT_SETTLE_F(biasv[e]);
+    if (keyquery && need_att) {
+#pragma unroll
+      for (int q = 0; q < CP8; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) MAGAT_SETTLE_F(xi[q][e]);
     }
   }
+
+  for (int hh = 0; hh < hpb; ++hh) {
+  const int head = head0 + hh;
+  // the thread index is laundered once per head so every per-thread address / lane-map quantity below is
+  // recomputed (a few VALU ops) instead of being hoisted out of the head loop into ~50 long-lived registers
+  int tl = threadIdx.x;
+  asm volatile("" : "+v"(tl));
+  const int t = tl, lane = tl & 63, wave = tl >> 6, wl = wave;
+  const int es8 = lane & 7, eg8 = lane >> 3, par8 = eg8 & 1;
   // hop-phase lane map.  WIDE: a wave owns one output row, lane -> VEC consecutive features.
   // otherwise: LF lanes per row (16 B each), RPW rows per wave step.
   const int sub = WIDE ? lane : lane % LF, grp = WIDE ? 0 : lane / LF;
-  const int rpw = WIDE ? 1 : RPW;
-  {
+  fvec ucur[HMAX];   // per-head
+  if (dbg && t == 0 && hh == hpb - 1 && hh > 0) dbg[0] = clock64();   // instrumentation follows the LAST head
+  if (need_att && !keyquery)
+    for (int n = t; n < N; n += NT) {
+      c1s[n] = Zb[(long long)n * p.NC + p.c1off + head];
+      c2s[n] = Zb[(long long)n * p.NC + p.c2off + head];
+    }
+  if constexpr (WIDE) {
+    // Q tile (prefetched during the previous head's last hop, or above) is in Rq once every wave's loads are done;
+    // the same barrier retires the previous head's reads of Ru and A
+    tiles_landed();
+    if (hh > 0 && keyquery && need_att && K > 1) dma_tile(Ru, p.uoff + (head * K + (K - 1)) * F, tl);
+  } else {
+    if (keyquery && need_att) {
+#pragma unroll
+      for (int q = 0; q < QG; ++q) {
+        const int idx = tl + q * NT, n = idx / GC, c = idx % GC;
+        if (n < N) {
+          *reinterpret_cast<f32x4*>(R0 + n * G + 4 * c) = qst[q];
+          *reinterpret_cast<f32x4*>(R1 + n * G + 4 * c) = xst[q];
+        }
+      }
+    }
+    __syncthreads();
+    if (K > 1) issue_u(head, tl);     // in flight during the score phase
+  }
+  if (dbg && t == 0 && hh == hpb - 1) dbg[1] = clock64();
+  {   // the first hop's U rows: in flight during the score phase
     const int uo = p.uoff + (head * K + (K > 1 ? K - 2 : 0)) * F;
 #pragma unroll
     for (int h = 0; h < HMAX; ++h) {
-      const int j = (wave + h * nwaves) * rpw + grp;
-      ucur[h] = zerov;
-      if (j < N) ucur[h] = *reinterpret_cast<const fvec*>(Zb + (long long)j * p.NC + uo + VEC * sub);
+      const int j = (wl + h * nwaves) * rpw + grp;
+      ucur[h] = *reinterpret_cast<const fvec*>(Zb + (long long)(j < N ? j : 0) * p.NC + uo + VEC * sub);
     }
   }
-  if (keyquery && need_att) {
-#pragma unroll
-    for (int q = 0; q < QG; ++q) {
-      const int idx = t + q * NT, n = idx / GC, c = idx % GC;
-      if (n < N) {
-        *reinterpret_cast<f32x4*>(R0 + n * G + 4 * c) = qst[q];
-        *reinterpret_cast<f32x4*>(R1 + n * G + 4 * c) = xst[q];
-      }
-    }
-  }
-  __syncthreads();
-  if (dbg && t == 0) dbg[1] = clock64();
 
   // ---- phase 1: attention rows out of LDS.
   // WIDE (G >= 64): a 16-lane row of the wave owns one graph row (4 rows per wave step); its lanes walk the
@@ -186,10 +271,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
   // runs with lane = neighbour slot (8 slots per lane), reductions again on DPP.  No ds_bpermute anywhere.
   if (need_att && !(p.skip & 1)) {
     if constexpr (WIDE) {
-      // 8 lanes per graph row (8 rows per wave step); lane es owns chunks es + 8*(q ^ (eg&1)) of a feature row:
-      // odd groups start on the other 128-byte half, so the 16-lane ds_read_b128 service groups never collide.
-      constexpr int CP8 = GC / 8;
-      const int es = lane & 7, eg = lane >> 3, par = eg & 1;
+      const int es = es8, eg = eg8, par = par8;
       for (int ib = 8 * wave; ib < N; ib += 8 * nwaves) {
         const int i = ib + eg;
         const bool iok = i < N;
@@ -198,10 +280,6 @@ __global__ void gat_dense_kernel(const GatParams p) {
         const uint4 mk = *reinterpret_cast<const uint4*>(rmask + 4 * ir);
         unsigned w[4] = {iok ? mk.x : 0u, iok ? mk.y : 0u, iok ? mk.z : 0u, iok ? mk.w : 0u};
         if (keyquery) {
-          f32x4 xi[CP8];
-#pragma unroll
-          for (int q = 0; q < CP8; ++q)
-            xi[q] = *reinterpret_cast<const f32x4*>(R1 + ir * G + 4 * (es + 8 * (q ^ par)));
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             unsigned ww = w[r];
@@ -214,8 +292,8 @@ __global__ void gat_dense_kernel(const GatParams p) {
               float d0 = 0.f, d1 = 0.f;
 #pragma unroll
               for (int q = 0; q < CP8; ++q) {
-                const f32x4 q0 = *reinterpret_cast<const f32x4*>(R0 + j0 * G + 4 * (es + 8 * (q ^ par)));
-                const f32x4 q1 = *reinterpret_cast<const f32x4*>(R0 + j1 * G + 4 * (es + 8 * (q ^ par)));
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(Rq + j0 * G + 4 * (es + 8 * (q ^ par)));
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(Rq + j1 * G + 4 * (es + 8 * (q ^ par)));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   d0 = fmaf(xi[q][e], q0[e], d0);
@@ -232,23 +310,28 @@ __global__ void gat_dense_kernel(const GatParams p) {
           }
           __builtin_amdgcn_wave_barrier();
         }
-        // masked softmax, lane = neighbour slot j = es + 8*r
+        // masked softmax, lane = neighbour slot j = es + 8*r.  Branch-free: all 16 slots are read back to back
+        // (one LDS wait instead of sixteen predicated read+wait blocks) and selected by the edge bits afterwards;
+        // slots without an edge hold stale or foreign data that never enters the arithmetic.
         float v[16];
         float mx = -__builtin_inff();
         const float c2 = keyquery ? 0.f : c2s[ir];
+        const float* srow = keyquery ? Arow : c1s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = es + 8 * r;
-          const bool f = (w[r >> 2] >> (j & 31)) & 1u;
-          v[r] = -__builtin_inff();
-          if (8 * r < N && f) {
-            if (keyquery) {
-              v[r] = Arow[j];
-            } else {
-              const float e = c1s[j] + c2;
-              v[r] = e > 0.f ? e : 0.2f * e;
-            }
+          v[r] = srow[j < N ? j : N - 1];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = es + 8 * r;
+          const bool f = (w[r >> 2] >> (j & 31)) & 1u;      // bits at and beyond N are never set
+          float e = v[r];
+          if (!keyquery) {
+            e += c2;
+            e = e > 0.f ? e : 0.2f * e;
           }
+          v[r] = f ? e : -__builtin_inff();
           mx = fmaxf(mx, v[r]);
         }
         mx = oct_max(mx);
@@ -332,9 +415,17 @@ __global__ void gat_dense_kernel(const GatParams p) {
     }
     }
   }
-  __syncthreads();
-  if (dbg && t == 0) dbg[2] = clock64();
-  if (K > 1) {      // X_b is dead: the deepest hop operand takes its place
+  if constexpr (WIDE) {
+    tiles_landed();     // attention complete, U_{K-1} tile in Ru, first hop's U rows in registers
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) MAGAT_SETTLE_F(ucur[h][e]);
+  } else {
+    __syncthreads();
+  }
+  if (dbg && t == 0 && hh == hpb - 1) dbg[2] = clock64();
+  if (!WIDE && K > 1) {      // narrow path: X_b is dead, the deepest hop operand takes its place in R1
 #pragma unroll
     for (int q = 0; q < QF; ++q) {
       const int idx = t + q * NT, n = idx / FC, c = idx % FC;
@@ -349,23 +440,18 @@ __global__ void gat_dense_kernel(const GatParams p) {
   // s_ff1 -> v_readlane (weight) -> one ds_read of the neighbour's feature row -> VEC FMAs, two neighbours
   // in flight per iteration.
   const unsigned long long gmask = LF == 64 ? ~0ull : ((1ull << LF) - 1ull);
-  float* Rold = R1;
-  float* Rnew = R0;
-  for (int k = K > 1 ? K - 2 : 0; k >= 0; --k) {
-    if (p.skip & 2) break;
-    const bool last = k == 0;
-    if (!last) {      // next hop's U rows: in flight during this hop
-      const int uo = p.uoff + (head * K + (k - 1)) * F;
-#pragma unroll
-      for (int h = 0; h < HMAX; ++h) {
-        const int j = (wave + h * nwaves) * rpw + grp;
-        unext[h] = zerov;
-        if (j < N) unext[h] = *reinterpret_cast<const fvec*>(Zb + (long long)j * p.NC + uo + VEC * sub);
-      }
-    }
+  float* Rold = Ru;
+  float* Rnew = Rq;
+  // rows of one hop; LAST is a compile-time tag (std::true_type / false_type): the final hop is a separate copy of
+  // this code with no `unext` registers anywhere near it, so the LDS-direct prefetch issued in front of it is not
+  // caught by compiler-inserted s_waitcnt vmcnt(0) guards for registers with pending loads
+  auto hop_rows = [&](auto last_tag, const float* Rold_, float* Rnew_) {
+    constexpr bool last = decltype(last_tag)::value;
 #pragma unroll
     for (int h = 0; h < HMAX; ++h) {
-      const int jb = (wave + h * nwaves) * rpw;
+      int wq = wl;                       // laundered per row: keeps the 8 unrolled rows' address math from being
+      asm volatile("" : "+v"(wq));       // hoisted in front of the hop loop (register pressure)
+      const int jb = (wq + h * nwaves) * rpw;
       if (jb >= N) break;
       const int j = jb + grp;
       const bool jok = j < N;
@@ -375,7 +461,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
           const float c0 = lane < N ? A[lane * p.lda_a + j] : 0.f;
           const float c1 = lane + 64 < N ? A[(lane + 64) * p.lda_a + j] : 0.f;
           const unsigned long long k0 = __ballot(c0 != 0.f), k1 = __ballot(c1 != 0.f);
-          const float* Tl = Rold + VEC * lane;
+          const float* Tl = Rold_ + VEC * lane;
           auto gather = [&](unsigned long long km, float cv, int base) {
             while (km) {          // two neighbour rows in flight per trip (weights via v_readlane)
               const int i0 = __builtin_ctzll(km);
@@ -407,7 +493,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
               const int ii = r0 + __builtin_ctzll(mine);
               mine &= mine - 1;
               const float av = A[ii * p.lda_a + j];
-              const fvec tv = *reinterpret_cast<const fvec*>(Rold + ii * F + VEC * sub);
+              const fvec tv = *reinterpret_cast<const fvec*>(Rold_ + ii * F + VEC * sub);
 #pragma unroll
               for (int e = 0; e < VEC; ++e) acc[e] = fmaf(av, tv[e], acc[e]);
             }
@@ -416,24 +502,59 @@ __global__ void gat_dense_kernel(const GatParams p) {
       }
       fvec res = ucur[h] + acc;
       if (!jok) continue;
-      if (last) {
-        if (p.bias) res += *reinterpret_cast<const fvec*>(p.bias + VEC * sub);
+      if constexpr (last) {
+        res += biasv;
         if (p.concat) {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) res[e] = fmaxf(res[e], 0.f);
         }
         *reinterpret_cast<fvec*>(p.Y + ((long long)b * N + j) * p.ldy + head * F + VEC * sub) = res;
       } else {
-        *reinterpret_cast<fvec*>(Rnew + j * F + VEC * sub) = res;
+        *reinterpret_cast<fvec*>(Rnew_ + j * F + VEC * sub) = res;
       }
     }
-    if (last) break;
+  };
+  if (!(p.skip & 2)) {
+    for (int k = K - 2; k >= 1; --k) {      // all hops but the last
+      int tk = threadIdx.x;      // laundered per hop: load addresses are computed at the point of use
+      asm volatile("" : "+v"(tk));
+      fvec unext[HMAX];          // next hop's U rows: in flight during this hop
+      const int uo = p.uoff + (head * K + (k - 1)) * F;
 #pragma unroll
-    for (int h = 0; h < HMAX; ++h) ucur[h] = unext[h];
-    __syncthreads();
-    if (dbg && t == 0) dbg[3 + (K - 2 - k)] = clock64();
-    float* tmp = Rold; Rold = Rnew; Rnew = tmp;
+      for (int h = 0; h < HMAX; ++h) {
+        const int j = ((tk >> 6) + h * nwaves) * rpw + grp;
+        unext[h] = *reinterpret_cast<const fvec*>(Zb + (long long)(j < N ? j : 0) * p.NC + uo + VEC * sub);
+      }
+      hop_rows(std::false_type{}, Rold, Rnew);
+#pragma unroll
+      for (int h = 0; h < HMAX; ++h) ucur[h] = unext[h];
+      __syncthreads();
+      if constexpr (WIDE) {
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) MAGAT_SETTLE_F(ucur[h][e]);
+      }
+      if (dbg && t == 0 && hh == hpb - 1) dbg[3 + (K - 2 - k)] = clock64();
+      float* tmp = Rold; Rold = Rnew; Rnew = tmp;
+    }
+    if constexpr (WIDE) {
+      if (hh + 1 < hpb) {
+        // Rnew is not read any more: the next head's first tile streams into it during the last hop (every register
+        // the rows below consume has been settled, so nothing waits for it)
+        int tk = threadIdx.x;
+        asm volatile("" : "+v"(tk));
+        if (keyquery && need_att) dma_tile(Rnew, p.qoff + (head + 1) * G, tk);
+        else if (K > 1) dma_tile(Rnew, p.uoff + ((head + 1) * K + (K - 1)) * F, tk);
+      }
+    }
+    hop_rows(std::true_type{}, Rold, Rnew);
   }
+  if constexpr (WIDE) {      // buffer roles of the next head (its first tile went to Rnew)
+    if (keyquery && need_att) { Rq = Rnew; Ru = Rold; }
+    else { Ru = Rnew; Rq = Rold; }
+  }
+  }  // heads
   if (dbg) {
     __syncthreads();
     if (t == 0) { dbg[6] = clock64(); dbg[7] = wall_clock64(); }
@@ -473,7 +594,7 @@ PackLayout pack_layout(int G, int F, int K, int P, int mode) {
     L.uoff = 0;
     L.c1off = P * K * F;
     L.c2off = L.c1off + P;
-    L.NC = (L.c2off + P + 3) & ~3;
+    L.NC = (L.c2off + P + 31) & ~31;   // multiple of 32: the maps GEMM can always use the bf16 matrix-core tiles
   }
   return L;
 }
@@ -587,24 +708,35 @@ extern "C" size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode) 
 }
 
 // hoisted dense maps Z = X @ Bt^T + colbias: bf16x6 split-MFMA GEMM when the shape allows, else fp32 MFMA
-static int gat_maps_gemm(const float* X, const float* packed, float* Z, int M, int G, const PackLayout& L,
-                         void* stream) {
+// row stride of the hoisted-map intermediate Z in the dense path: NC + pad.  NC is a multiple of 128 floats at the
+// benchmark shapes (2048 -> 8 KB rows): the tiles a workgroup reads are 512-byte row pieces exactly 8 KB apart, which
+// all land in the same HBM channels; a 128-byte skew per row spreads them.
+static int gat_zpad() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MAGAT_GAT_ZPAD");
+    v = e ? atoi(e) : 32;
+    if (v < 0 || (v & 3)) v = 0;
+  }
+  return v;
+}
+int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, int G, int NC, int ldz, void* stream) {
   static int use_split = -1;
   if (use_split < 0) {
     const char* e = getenv("MAGAT_GAT_SPLIT");
     use_split = e ? atoi(e) : 1;
   }
-  if (use_split && L.NC % 32 == 0 && G % 32 == 0) {
+  if (use_split && NC % 32 == 0 && G % 32 == 0) {
     magat_conv_gemm_desc d = {};
     d.in = X;
-    d.wt = packed + (((size_t)L.NC * (G + 1) + 3) & ~(size_t)3);
-    d.bias = packed + (size_t)L.NC * G;
+    d.wt = packed + (((size_t)NC * (G + 1) + 3) & ~(size_t)3);
+    d.bias = packed + (size_t)NC * G;
     d.out = Z;
     d.M = M; d.Cin = G; d.lda = G; d.Hin = d.Win = 1; d.kH = d.kW = 1; d.stride = 1; d.Hout = d.Wout = 1;
-    d.Cout = L.NC; d.ldc = L.NC; d.tag = MAGAT_TAG_GAT_MAPS; d.in_fmt = 2;
+    d.Cout = NC; d.ldc = ldz; d.tag = MAGAT_TAG_GAT_MAPS; d.in_fmt = 2;
     return magat_conv_gemm_f32(&d, stream);
   }
-  return magat_linear_tagged_f32(X, G, packed, packed + (size_t)L.NC * G, Z, L.NC, M, L.NC, G, 0, MAGAT_TAG_GAT_MAPS,
+  return magat_linear_tagged_f32(X, G, packed, packed + (size_t)NC * G, Z, ldz, M, NC, G, 0, MAGAT_TAG_GAT_MAPS,
                                  stream);
 }
 
@@ -643,8 +775,9 @@ bool gat_list_enabled() {
 extern "C" size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, int P, int mode, int concat) {
   if (B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
   const PackLayout L = pack_layout(G, F, K, P, mode);
-  const int chunk = gat_chunk_instances(B, N, L.NC);
-  size_t bytes = magat_align_up((size_t)chunk * N * L.NC * sizeof(float), 256);
+  const int ldz = L.NC + gat_zpad();
+  const int chunk = gat_chunk_instances(B, N, ldz);
+  size_t bytes = magat_align_up((size_t)chunk * N * ldz * sizeof(float), 256);
   if (!concat) bytes += magat_align_up((size_t)B * N * P * F * sizeof(float), 256);
   bytes += magat_gat_list_workspace_bytes(chunk, N, G, F);
   return bytes;
@@ -669,10 +802,11 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
   hipStream_t st = static_cast<hipStream_t>(stream);
 
   const PackLayout L = pack_layout(G, F, K, P, mode);
-  const int chunk = gat_chunk_instances(B, N, L.NC);
+  const int ldz = L.NC + gat_zpad();
+  const int chunk = gat_chunk_instances(B, N, ldz);
   float* Z = static_cast<float*>(workspace);
   float* Ytmp = reinterpret_cast<float*>(static_cast<char*>(workspace) +
-                                         magat_align_up((size_t)chunk * N * L.NC * sizeof(float), 256));
+                                         magat_align_up((size_t)chunk * N * ldz * sizeof(float), 256));
   char* list_ws = reinterpret_cast<char*>(Ytmp) + (concat ? 0 : magat_align_up((size_t)B * N * P * F * sizeof(float), 256));
   const bool use_list = gat_list_enabled() && mode != MAGAT_MODE_GAT_ORIGIN && magat_gat_list_capacity(N, G, F) > 0;
   GatParams p;
@@ -682,12 +816,12 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
   p.X = X; p.S = S; p.Z = Z; p.bias = bias; p.A_opt = A_opt;
   p.Y = concat ? Y : Ytmp;
   p.N = N; p.K = K; p.P = P; p.mode = mode; p.concat = concat; p.s_is_f64 = s_is_f64;
-  p.ldx = G; p.ldy = concat ? ldy : P * F; p.NC = L.NC; p.lda_a = N | 1;
+  p.ldx = G; p.ldy = concat ? ldy : P * F; p.NC = ldz; p.lda_a = N | 1;
   p.qoff = L.qoff; p.uoff = L.uoff; p.c1off = L.c1off; p.c2off = L.c2off;
 
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int cb = (B - b0) < chunk ? (B - b0) : chunk;
-    int rc = gat_maps_gemm(X + (size_t)b0 * N * G, packed, Z, cb * N, G, L, stream);
+    int rc = magat_gat_maps_gemm(X + (size_t)b0 * N * G, packed, Z, cb * N, G, L.NC, ldz, stream);
     if (rc != MAGAT_OK) return rc;
     p.B = cb; p.b0 = b0;
     if (use_list) {     // sparse instances: structure pass + list kernel; dense ones stay flagged for the kernel below
@@ -696,11 +830,20 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
         return MAGAT_ERR_LAUNCH;
       int* over = nullptr;
       rc = magat_gat_list_run(X, S, s_is_f64, Z, bias, p.Y, p.ldy, A_opt, list_ws, cb, b0, N, G, K, P, mode, concat,
-                              L.NC, L.qoff, L.uoff, L.c1off, L.c2off, &over, st);
+                              ldz, L.qoff, L.uoff, L.c1off, L.c2off, &over, st);
       if (rc != MAGAT_OK) return rc;
       p.over = over;
     }
-    const int blocks = (cb + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD * P;
+    // heads per workgroup: when the LDS tiles allow only one workgroup per CU there is nothing to overlap a
+    // workgroup's loads with, so one workgroup walks all P heads of its instance and prefetches the next head's
+    // Q tile during the current head's compute; needs enough instances to fill the chip.
+    static int hpb_env = -1;
+    if (hpb_env < 0) { const char* e = getenv("MAGAT_GAT_HPB"); hpb_env = e ? atoi(e) : 0; }
+    int hpb = 1;
+    if (G >= 64 && P > 1 && lds > 80 * 1024 && cb >= 256) hpb = P;
+    if (hpb_env > 0 && G >= 64 && P % hpb_env == 0) hpb = hpb_env;
+    p.hpb = hpb;
+    const int blocks = (cb + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD * (P / hpb);
     switch (G) {
       case 16: rc = launch_gat<16, 16>(p, blocks, threads, lds, st); break;
       case 32: rc = launch_gat<32, 32>(p, blocks, threads, lds, st); break;

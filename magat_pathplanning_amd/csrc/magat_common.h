@@ -23,6 +23,10 @@ void magat_prof_end(int id, hipStream_t st);
 // bf16x6 split-MFMA GEMM (conv_gemm_bf16x6.hip), reached through magat_conv_gemm_f32 when desc->in_fmt == 1
 int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st);
 
+// hoisted GAT maps Z [M][ldz >= NC] = X [M][G] @ Bt^T + colbias from the packed weights (gat_f32.hip): bf16x6 split when
+// NC % 32 == 0 and G % 32 == 0, else fp32 MFMA
+int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, int G, int NC, int ldz, void* stream);
+
 // fp32 -> three bf16 planes (round-to-nearest-even each)
 __device__ __forceinline__ unsigned short magat_bf16_rne(float v) {
   unsigned u = __builtin_bit_cast(unsigned, v);

@@ -77,7 +77,9 @@ def dense_gso_to_csr(S3, self_loops=False):
 
 def gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=None, want_attention=False):
     """CSR / large-graph form (any N).  X (B,N,G) device rows; rowptr int32 [B*(N+1)] absolute offsets; colidx int32.
-    Returns (out (B*N, ld), att (P, nnz) CSR-ordered attention or None)."""
+    X float32 -> fp32 kernels; X bfloat16 -> the bf16-STORAGE kernels (BASELINE config 5: X, maps, hop states and the
+    result are bf16 in HBM, fp32 arithmetic; `out`, if given, must be bfloat16 too).
+    Returns (out (B*N, ld), att (P, nnz) CSR-ordered fp32 attention or None)."""
     if not X.is_cuda:
         raise nat.MagatNativeError("the HIP GAT path needs device tensors; got %s (no CPU fallback)" % X.device)
     lib = nat.lib()
@@ -86,23 +88,30 @@ def gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=None, want_attention
     mode = _MODES[layer.attentionMode]
     concat = 1 if layer.concatenate else 0
     width = P * F if concat else F
-    X = X.contiguous().float()
+    bf16 = X.dtype == torch.bfloat16
+    X = X.contiguous() if bf16 else X.contiguous().float()
+    sdt = torch.bfloat16 if bf16 else torch.float32
+    ws_fn = lib.magat_gat_csr_bf16_workspace_bytes if bf16 else lib.magat_gat_csr_workspace_bytes
+    fwd_fn, fwd_name = ((lib.magat_gat_forward_csr_bf16, "magat_gat_forward_csr_bf16") if bf16 else
+                        (lib.magat_gat_forward_csr_f32, "magat_gat_forward_csr_f32"))
     dev = X.device
     sc = layer._scratch
     with torch.cuda.device(dev):
         stream = nat.current_stream(dev)
         packed = _packed_weights(layer, dev, stream, G, F, K, P, mode)
-        need = lib.magat_gat_csr_workspace_bytes(B, N, nnz, G, F, K, P, mode, concat)
+        need = ws_fn(B, N, nnz, G, F, K, P, mode, concat)
         if sc.workspace is None or sc.workspace.numel() < need or sc.workspace.device != dev:
             sc.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
         if out is None:
-            out = torch.empty(B * N, width, dtype=torch.float32, device=dev)
+            out = torch.empty(B * N, width, dtype=sdt, device=dev)
+        elif out.dtype != sdt:
+            raise TypeError("out must be %s for %s rows" % (sdt, X.dtype))
         att = torch.empty(P, max(nnz, 1), dtype=torch.float32, device=dev) if want_attention else None
         bias = None if layer.bias is None else layer.bias.detach().to(dev, torch.float32).reshape(-1).contiguous()
-        nat.check(lib.magat_gat_forward_csr_f32(
+        nat.check(fwd_fn(
             nat.ptr(X), nat.ptr(rowptr), nat.ptr(colidx), nnz, nat.ptr(packed), nat.ptr(bias), nat.ptr(out),
             out.stride(0), nat.ptr(att), nat.ptr(sc.workspace), sc.workspace.numel(), B, N, G, F, K, P, mode, concat,
-            stream), "magat_gat_forward_csr_f32")
+            stream), fwd_name)
     return out, att
 
 
@@ -130,7 +139,8 @@ def gat_forward_rows(X, S, layer, out=None, want_attention=False):
     concat = 1 if layer.concatenate else 0
     width = P * F if concat else F
     X = X.contiguous()
-    if X.dtype != torch.float32:
+    bf16 = X.dtype == torch.bfloat16           # bf16 storage: always the CSR kernels (the LDS kernel is fp32-only)
+    if X.dtype != torch.float32 and not bf16:
         X = X.float()
     S3 = S.reshape(B, N, N)
     if S3.dtype not in (torch.float32, torch.float64):
@@ -141,7 +151,7 @@ def gat_forward_rows(X, S, layer, out=None, want_attention=False):
         S3 = S3.to(X.device)
     dev = X.device
     sc = layer._scratch
-    if not lib.magat_gat_dense_supported(N, G, F):
+    if bf16 or not lib.magat_gat_dense_supported(N, G, F):
         # graph too large for the LDS-resident kernel: same layer through the CSR kernels
         rowptr, colidx, nnz = dense_gso_to_csr(S3, self_loops=layer.attentionMode == "GAT_origin")
         out, att = gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=out, want_attention=want_attention)
@@ -180,7 +190,7 @@ def pack_torch(weight, weight_bias, mixer, taps, mode_name):
     W = weight[:, 0]                                            # (P,F,G)
     a1, a2 = mixer[:, 0, :F], mixer[:, 0, F:]
     v1, v2 = torch.einsum("pf,pfg->pg", a1, W), torch.einsum("pf,pfg->pg", a2, W)
-    nc = (P * K * F + 2 * P + 3) // 4 * 4
+    nc = (P * K * F + 2 * P + 31) // 32 * 32
     pad = torch.zeros(nc - P * K * F - 2 * P, G, dtype=U.dtype, device=U.device)
     Bt = torch.cat((U, v1, v2, pad), dim=0)
     if weight_bias is None:
@@ -207,7 +217,7 @@ class _GatTrainFunction(torch.autograd.Function):
             stream = nat.current_stream(dev)
             packed = _packed_weights(layer, dev, stream, G, F, K, P, mode)
             nc = (lib.magat_gat_packed_floats(G, F, K, P, mode) - 0)  # total floats; NC recovered below
-            NC = P * G + P * K * F if mode == nat.MODE_KEYQUERY else (P * K * F + 2 * P + 3) // 4 * 4
+            NC = P * G + P * K * F if mode == nat.MODE_KEYQUERY else (P * K * F + 2 * P + 31) // 32 * 32
             Ypre = torch.empty(M, P * F, dtype=torch.float32, device=dev)
             att = torch.empty(P, max(nnz, 1), dtype=torch.float32, device=dev)
             Z = torch.empty(M, NC, dtype=torch.float32, device=dev)
@@ -336,6 +346,10 @@ class GraphFilterBatchAttentional(nn.Module):
         self._scratch = _Scratch()
         self.reset_parameters()
 
+    # torch.float32 (default) or torch.bfloat16: HBM storage type of the node features inside the layer at inference
+    # (BASELINE config 5).  bf16 always takes the CSR kernels; arithmetic stays fp32.  Not part of the state_dict.
+    storage_dtype = torch.float32
+
     def _pack_tensors(self):
         return self.weight, self.weight_bias, self.mixer, self.filterWeight
 
@@ -400,10 +414,12 @@ class GraphFilterBatchAttentional(nn.Module):
             y, aij = _composite(self, x, self.S.to(x.device))
             self.aij = aij.detach() if self.return_attention else None
         else:
-            out, aij = gat_forward_rows(x.permute(0, 2, 1).contiguous(), self.S, self,
-                                        want_attention=self.return_attention)
+            rows = x.permute(0, 2, 1).contiguous()
+            if self.storage_dtype == torch.bfloat16:
+                rows = rows.to(torch.bfloat16)
+            out, aij = gat_forward_rows(rows, self.S, self, want_attention=self.return_attention)
             self.aij = aij
-            y = out.reshape(B, self.N, out.shape[1]).permute(0, 2, 1)
+            y = out.reshape(B, self.N, out.shape[1]).permute(0, 2, 1).float()
         if Nin < self.N:
             y = y[:, :, :Nin]
         return y

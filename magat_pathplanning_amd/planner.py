@@ -105,6 +105,13 @@ class DecentralPlannerGATNet(nn.Module):
         self.GFL = nn.Sequential(layer_cls(
             self.F[0], self.F[1], self.K[0], self.P[0], self.E, self.bias,
             concatenate=config.AttentionConcat, attentionMode=config.attentionMode))
+        # optional key (not in the reference's configs): HBM storage type inside the GAT layer at inference,
+        # 'fp32' (default, the 1e-4 parity path) or 'bf16' (BASELINE config 5)
+        storage = getattr(config, "gat_storage", "fp32")
+        if storage not in ("fp32", "bf16"):
+            raise ValueError("config.gat_storage must be 'fp32' or 'bf16', got %r" % (storage,))
+        if storage == "bf16":
+            self.GFL[0].storage_dtype = torch.bfloat16
 
         width = self.F[-1] * config.nAttentionHeads if config.AttentionConcat else self.F[-1]
         self.gat_width = width
@@ -270,9 +277,15 @@ class DecentralPlannerGATNet(nn.Module):
             layer = self.GFL[0]
             layer.addGSO(self.S)
             gat = self._buf("gat", (M, self.gat_width), dev)
-            _, aij = gat_forward_rows(comp.view(B, N, G), self.S, layer, out=gat,
-                                      want_attention=layer.return_attention or
-                                      bool(getattr(self.config, "return_attentionGSO", False)))
+            want_att = layer.return_attention or bool(getattr(self.config, "return_attentionGSO", False))
+            if layer.storage_dtype == torch.bfloat16:
+                # bf16 storage inside the GAT layer (config.gat_storage='bf16', BASELINE config 5): the layer reads
+                # and writes bf16 rows; the CNN/MLP GEMMs around it stay fp32
+                gat16, aij = gat_forward_rows(comp.view(B, N, G).to(torch.bfloat16), self.S, layer,
+                                              want_attention=want_att)
+                gat.copy_(gat16)
+            else:
+                _, aij = gat_forward_rows(comp.view(B, N, G), self.S, layer, out=gat, want_attention=want_att)
             layer.aij = aij
             # actionsMLP
             nout = rt.act[0].shape[0]

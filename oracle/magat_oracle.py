@@ -157,6 +157,63 @@ def gat_layer_forward(x, S4, p, mode="KeyQuery", concat=True, n_graph=None):
     return y, aij
 
 
+def _r16(t):
+    """round-to-nearest-even to bfloat16, carried as float32"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def gat_layer_forward_bf16_storage(x, S4, p, mode="KeyQuery", concat=True):
+    """The layer with bf16 STORAGE of the node features (BASELINE config 5).  NO REFERENCE COUNTERPART: the reference
+    has no bf16 path, so this is gat_layer_forward's algebra in the Horner order the kernels use
+    (Y = U_0 + A^T(U_1 + A^T U_2), U_k = X H_k^T) with RNE-bf16 rounding inserted exactly where the HIP bf16 path stores
+    to HBM: the input rows X, the packed score/tap weights, the hoisted maps Z = [Q | U | c1 c2], every hop state and
+    the result.  Arithmetic in float32, attention fp32.  The bf16 path is judged (a) as error against the pinned fp32
+    oracle and (b) for agreement with this emulation to ~1 bf16 ulp.
+    x (B,G,N) f32; returns (y (B,P*F|F,N) f32 holding bf16-representable values, aij (B,P,1,N,N))."""
+    B, G, N = x.shape
+    X = _r16(x.permute(0, 2, 1).float())                                  # (B,N,G)
+    W = p["weight"].float()
+    P = W.shape[0]
+    bias = p.get("bias")
+    if mode == "GAT_origin":
+        fw = p["filterWeight"].float().reshape(-1)
+        taps = torch.einsum("k,pgf->pfkg", fw, W[:, 0])                    # (P,F,K,G)
+    else:
+        taps = p["filterWeight"].float()[:, :, 0]                          # (P,F,K,G)
+    F, K = taps.shape[1], taps.shape[2]
+    U = _r16(torch.einsum("bng,pfkg->bpknf", X, _r16(taps)))               # bias-free maps, stored bf16
+    mask = edge_mask(S4 if mode != "GAT_origin" else S4.float() + torch.eye(N).view(1, 1, N, N), torch.float32)[:, 0, 0]
+    if mode == "KeyQuery":
+        Q = _r16(torch.einsum("bng,phg->bpnh", X, _r16(W[:, 0])))          # Q[j] = W x_j
+        e = torch.einsum("big,bpjg->bpij", X, Q)
+    else:
+        a1, a2 = p["mixer"].float()[:, 0, :F], p["mixer"].float()[:, 0, F:]
+        v1, v2 = _r16(torch.einsum("pf,pfg->pg", a1, W[:, 0])), _r16(torch.einsum("pf,pfg->pg", a2, W[:, 0]))
+        if mode == "GAT_origin":
+            cb1 = cb2 = torch.zeros(P)
+        else:
+            wb = p["weight_bias"].float()[:, 0]
+            cb1, cb2 = (a1 * wb).sum(1), (a2 * wb).sum(1)
+        c1 = _r16(torch.einsum("bng,pg->bpn", X, v1) + cb1.view(1, P, 1))
+        c2 = _r16(torch.einsum("bng,pg->bpn", X, v2) + cb2.view(1, P, 1))
+        e = tnf.leaky_relu(c1.unsqueeze(2) + c2.unsqueeze(3), 0.2)          # e[i,j] = lrelu(c1[j] + c2[i])
+    m4 = mask.unsqueeze(1)
+    aij = torch.softmax(e * m4 - (1 - m4) * INFINITE_NUMBER, dim=3) * m4     # (B,P,N,N)
+    At = aij.transpose(2, 3)
+    T = U[:, :, K - 1]
+    for k in range(K - 2, -1, -1):
+        T = U[:, :, k] + torch.matmul(At, T)
+        if k > 0:
+            T = _r16(T)
+    if bias is not None:
+        T = T + bias.float().reshape(1, 1, 1, F)
+    if concat:
+        y = _r16(torch.relu(T)).permute(0, 2, 1, 3).reshape(B, N, P * F)
+    else:
+        y = _r16(torch.relu(_r16(T).mean(dim=1)))
+    return y.permute(0, 2, 1), aij.unsqueeze(2)
+
+
 # ------------------------------------------------- loop-level numpy cross-check
 def gat_layer_forward_loops(x, S4, p, mode="KeyQuery", concat=True):
     """Same layer, written edge-by-edge in float64 numpy straight from the formulas of

@@ -395,3 +395,68 @@ def test_model_training_step_runs_on_gpu(gpu_device):
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     assert net.GFL[0].filterWeight.grad is not None and float(net.GFL[0].filterWeight.grad.abs().sum()) > 0
+
+
+BF16_LAYER = [p_ for p_ in LAYER if int(np.load(p_)["G"]) % 32 == 0]
+
+
+@pytest.mark.parametrize("path", BF16_LAYER, ids=[os.path.basename(p)[:-4] for p in BF16_LAYER])
+def test_gat_csr_bf16_storage(gpu_device, path):
+    """bf16-STORAGE CSR kernels (BASELINE config 5, magat_gat_forward_csr_bf16) on the reference-made fixtures:
+    (a) against the oracle's bf16-storage emulation (same rounding points) to ~1 bf16 ulp of the output scale,
+    (b) against the reference's fp32 output within the bf16 error budget (2 % of the output scale),
+    (c) attention (fp32 softmax of bf16-stored scores) against the reference's aij."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin
+    from magat_pathplanning_amd.graphml import dense_gso_to_csr, gat_forward_rows_csr, _csr_attention_to_dense
+    from oracle import magat_oracle as orc
+    z, p = load_layer_fixture(path)
+    mode, N, G, K, P = str(z["mode"]), int(z["N"]), int(z["G"]), int(z["K"]), int(z["P"])
+    origin = mode == "GAT_origin"
+    x = torch.from_numpy(z["x"])
+    S = torch.nan_to_num(torch.from_numpy(z["S"]), nan=0.0)
+    B = x.shape[0]
+    cls = GraphFilterBatchAttentional_Origin if origin else GraphFilterBatchAttentional
+    for concat, key in ((True, "y_concat"), (False, "y_mean")):
+        layer = cls(G, G, K, P, 1, True, concatenate=concat, attentionMode=mode)
+        layer.load_state_dict(p)
+        layer = layer.to(gpu_device).eval()
+        y_emul, a_emul = orc.gat_layer_forward_bf16_storage(x, S, p, mode, concat)
+        X = x.permute(0, 2, 1).contiguous().to(gpu_device).to(torch.bfloat16)
+        rowptr, colidx, nnz = dense_gso_to_csr(S.reshape(B, N, N).to(gpu_device), self_loops=origin)
+        with torch.no_grad():
+            out, att = gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, want_attention=True)
+        torch.cuda.synchronize()
+        assert out.dtype == torch.bfloat16
+        y = out.float().reshape(B, N, -1).permute(0, 2, 1).cpu()
+        y_ref = torch.from_numpy(z[key])
+        scale = float(y_ref.abs().max())
+        assert float((y - y_emul).abs().max()) <= 2.0 ** -7 * scale, (float((y - y_emul).abs().max()), scale)
+        assert float((y - y_ref).abs().max()) <= 2e-2 * scale, (float((y - y_ref).abs().max()), scale)
+        if K > 1:
+            dense = _csr_attention_to_dense(att, rowptr, colidx, nnz, B, N, P).cpu()
+            np.testing.assert_allclose(dense.numpy(), a_emul.numpy(), rtol=0, atol=4e-3)
+            np.testing.assert_allclose(dense.numpy(), np.nan_to_num(z["aij"]), rtol=0, atol=2e-2)
+
+
+def test_gat_module_bf16_storage_switch(gpu_device):
+    """layer.storage_dtype = torch.bfloat16 routes the module through the bf16 CSR kernels; output stays float32."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from magat_pathplanning_amd.synthetic import comm_gso
+    from oracle import magat_oracle as orc
+    B, N, G, K, P = 2, 300, 128, 2, 4
+    g = torch.Generator().manual_seed(5)
+    layer = GraphFilterBatchAttentional(G, G, K, P, attentionMode="KeyQuery")
+    x = torch.randn(B, G, N, generator=g) * 0.5
+    S = comm_gso(B, N, 90, seed=8)
+    params = {k: v.detach() for k, v in layer.state_dict().items()}
+    y_ref, _ = orc.gat_layer_forward(x, S.unsqueeze(1), params, "KeyQuery", True)
+    y_emul, _ = orc.gat_layer_forward_bf16_storage(x, S.unsqueeze(1), params, "KeyQuery", True)
+    layer = layer.to(gpu_device).eval()
+    layer.storage_dtype = torch.bfloat16
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    with torch.no_grad():
+        y = layer(x.to(gpu_device))
+    assert y.dtype == torch.float32 and tuple(y.shape) == (B, P * G, N)
+    scale = float(y_ref.abs().max())
+    assert float((y.cpu() - y_emul).abs().max()) <= 2.0 ** -7 * scale
+    assert float((y.cpu() - y_ref).abs().max()) <= 2e-2 * scale

@@ -155,3 +155,27 @@ def test_graph_capture_replay_matches_eager(gpu_device):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, eager)
+
+
+def test_model_bf16_gat_storage_config5_shape(gpu_device):
+    """BASELINE config 5 in miniature (sparse comm-radius graph beyond the LDS kernel's N, K=2, P=4,
+    config.gat_storage='bf16'): logits against the fp32 oracle -- error reported and bounded, greedy actions agree
+    (SURVEY.md 8(d) parity gate for the bf16 configuration)."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N = 2, 400
+    cfg = make_config(num_agents=N, nGraphFilterTaps=2, nAttentionHeads=4, gat_storage="bf16")
+    sd = orc.init_state_dict(cfg, seed=21)
+    x = fov_states(B, N, seed=5)
+    S = comm_gso(B, N, 100, seed=6, dtype=torch.float64)
+    ref = orc.planner_forward(x, S.clone(), sd, cfg)
+    net = _build(cfg, sd, gpu_device)
+    assert net.GFL[0].storage_dtype == torch.bfloat16
+    with torch.no_grad():
+        net.addGSO(S.to(gpu_device))
+        got = net(x.to(gpu_device)).cpu()
+    err = (got - ref).abs().max().item()
+    agree = (got.argmax(1) == ref.argmax(1)).float().mean().item()
+    print("bf16 GAT storage: max|dlogit| = %.3e, argmax agreement = %.4f" % (err, agree))
+    assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
+    assert agree >= 0.97, agree
