@@ -79,11 +79,12 @@ __global__ void gat_dense_kernel(const GatParams p) {
   const int bid = blockIdx.x;
   const int xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
   const int hpb = p.hpb, hgroups = p.P / hpb;
-  const int bl = xcd + MAGAT_NUM_XCD * (slot / hgroups);   // heads of one instance share an XCD (X_b, S_b in L2)
+  // heads of one instance share an XCD (X_b, S_b in L2).  A workgroup walks instances bl0, bl0 + istride, ...
+  // (istride >= B: one instance per workgroup); the first tile of the next instance is prefetched like a next head.
+  const int bl0 = xcd + MAGAT_NUM_XCD * (slot / hgroups);
+  const int istride = MAGAT_NUM_XCD * ((int)gridDim.x / MAGAT_NUM_XCD / hgroups);
   const int head0 = (slot % hgroups) * hpb;
-  if (bl >= p.B) return;
-  if (p.over && !p.over[bl]) return;
-  const int b = p.b0 + bl;
+  if (bl0 >= p.B) return;
 
   float* R0 = smem;                      // Q_p, later hop buffer
   float* R1 = R0 + N * RW;               // X_b during the score phase, then U_{K-1} / hop buffer
@@ -95,15 +96,13 @@ __global__ void gat_dense_kernel(const GatParams p) {
       (reinterpret_cast<uintptr_t>(nbr + 128 * (blockDim.x >> 6)) + 15) & ~static_cast<uintptr_t>(15));
 
   const int t = threadIdx.x, NT = blockDim.x, lane = t & 63, wave = t >> 6, nwaves = NT >> 6;
-  const float* Zb = p.Z + (long long)bl * N * p.NC;
-  const float* Xb = p.X + (long long)b * N * p.ldx;
-  const long long sbase = (long long)b * N * N;
   const int K = p.K;
   const bool keyquery = p.mode == MAGAT_MODE_KEYQUERY;
   const bool need_att = K > 1 || p.A_opt;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   long long* dbg = p.dbg ? p.dbg + (long long)bid * 8 : nullptr;
   if (dbg && t == 0) dbg[0] = clock64();
+  const float* Zb = p.Z + (long long)bl0 * N * p.NC;     // current instance (updated by the instance loop)
 
   // ---- phase 0 (once per workgroup): the GSO edge masks, this wave's x_i rows, the first head's tiles.
   // WIDE path: the Q_p and U_{K-1} tiles ([N][128] floats, rows NC floats apart in Z) travel global -> LDS with the
@@ -122,7 +121,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
   // wait for the LDS-direct tile loads in flight.
 #define MAGAT_SETTLE_F(x) asm volatile("" : "+v"(x))
   // one wave instruction moves 64 consecutive 16-byte chunks of the tile (LDS address = M0 + 16 * lane)
-  auto dma_tile = [&](float* dst, int col_off, int tv) {
+  auto dma_tile = [&](float* dst, const float* zb, int col_off, int tv) {
     const int lane_ = tv & 63;
     const int wave_ = __builtin_amdgcn_readfirstlane(tv >> 6);
     const int total = N * GC;
@@ -131,7 +130,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
       const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)dst + (unsigned)g * 1024u);
       if (idx < total) {
         const int n = idx / GC, c = idx % GC;
-        const float* src = Zb + (long long)n * p.NC + col_off + 4 * c;
+        const float* src = zb + (long long)n * p.NC + col_off + 4 * c;
         asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
       }
     }
@@ -158,6 +157,26 @@ __global__ void gat_dense_kernel(const GatParams p) {
   };
   float* Rq = R0;     // LDS buffer holding the current head's Q tile (WIDE: alternates between heads)
   float* Ru = R1;     // ... and its U_{K-1} tile
+  const int rpw = WIDE ? 1 : RPW;
+  // bias slice of this lane (hop-phase lane map), loaded once
+  fvec biasv = zerov;
+  if (p.bias) biasv = *reinterpret_cast<const fvec*>(p.bias + VEC * (WIDE ? lane : lane % LF));
+  if constexpr (WIDE) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) MAGAT_SETTLE_F(biasv[e]);
+  }
+
+  for (int bl = bl0; bl < p.B; bl += istride) {     // ---- instances of this workgroup
+  if (p.over && !p.over[bl]) continue;               // (host never combines the list path with istride < B)
+  const int b = p.b0 + bl;
+  int ti = threadIdx.x;              // laundered per instance (see the note at the head loop)
+  asm volatile("" : "+v"(ti));
+  const int t = ti, lane = ti & 63, wave = ti >> 6;
+  long long t_inst = 0;
+  if (dbg && t == 0) t_inst = clock64();
+  Zb = p.Z + (long long)bl * N * p.NC;
+  const float* Xb = p.X + (long long)b * N * p.ldx;
+  const long long sbase = (long long)b * N * N;
   // WIDE score phase: 8 lanes per graph row (8 rows per wave step, exactly one step per wave since NT >= 8 N); lane es
   // owns chunks es + 8*(q ^ (eg&1)) of a feature row: odd groups start on the other 128-byte half, so the 16-lane
   // ds_read_b128 service groups never collide.  The x_i row of the group is the same for every head: registers.
@@ -165,14 +184,14 @@ __global__ void gat_dense_kernel(const GatParams p) {
   f32x4 xi[CP8];
   if constexpr (WIDE) {
     if (keyquery && need_att) {
-      dma_tile(Rq, p.qoff + head0 * G, t);
+      if (bl == bl0) dma_tile(Rq, Zb, p.qoff + head0 * G, t);
       const int es0 = lane & 7, eg0 = lane >> 3, par0 = eg0 & 1;
       const int i = 8 * wave + eg0, ir = i < N ? i : 0;
 #pragma unroll
       for (int q = 0; q < CP8; ++q)
         xi[q] = *reinterpret_cast<const f32x4*>(Xb + (long long)ir * p.ldx + 4 * (es0 + 8 * (q ^ par0)));
     }
-    if (K > 1) dma_tile(Ru, p.uoff + (head0 * K + (K - 1)) * F, t);
+    if (K > 1 && bl == bl0) dma_tile(Ru, Zb, p.uoff + (head0 * K + (K - 1)) * F, t);
   } else if (keyquery && need_att) {
     issue_q(head0, t);
 #pragma unroll
@@ -184,17 +203,46 @@ __global__ void gat_dense_kernel(const GatParams p) {
   }
   if (need_att) {
     if constexpr (WIDE) {   // GSO rows -> 128-bit edge masks (one wave per row, coalesced reads, ballot)
-      for (int i = wave; i < N; i += nwaves) {
-        const float sl = p.mode == MAGAT_MODE_GAT_ORIGIN ? 1.f : 0.f;
-        const bool f0 = lane < N && is_edge(p.S, sbase + (long long)i * N + lane, p.s_is_f64, lane == i ? sl : 0.f);
-        const bool f1 = lane + 64 < N &&
-                        is_edge(p.S, sbase + (long long)i * N + lane + 64, p.s_is_f64, lane + 64 == i ? sl : 0.f);
-        const unsigned long long k0 = __ballot(f0), k1 = __ballot(f1);
-        if (lane == 0) {
-          rmask[4 * i + 0] = (unsigned)k0; rmask[4 * i + 1] = (unsigned)(k0 >> 32);
-          rmask[4 * i + 2] = (unsigned)k1; rmask[4 * i + 3] = (unsigned)(k1 >> 32);
+      // every wave owns rows wave, wave + nwaves, ... (at most 8 since NT >= 8 N): all their loads are issued
+      // first and the ballots run afterwards - one memory latency per instance instead of one per row
+      const float sl = p.mode == MAGAT_MODE_GAT_ORIGIN ? 1.f : 0.f;
+      auto stage_masks = [&](auto tag) {
+        typedef decltype(tag) ST;
+        const ST* Sp = static_cast<const ST*>(p.S) + sbase;
+        for (int hb = 0; hb < 8; hb += 4) {       // two batches of four rows (register budget)
+        if (wave + hb * nwaves >= N) break;
+        ST v0[4], v1[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const int i = wave + (hb + h) * nwaves, ic = i < N ? i : N - 1;
+          v0[h] = Sp[(long long)ic * N + (lane < N ? lane : N - 1)];
+          v1[h] = Sp[(long long)ic * N + (lane + 64 < N ? lane + 64 : N - 1)];
         }
-      }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const int i = wave + (hb + h) * nwaves;
+          if (i >= N) break;
+          bool f0, f1;
+          if (sl != 0.f) {      // GAT_origin: |float(S) + I| > 1e-9f
+            f0 = fabsf((float)v0[h] + (lane == i ? sl : 0.f)) > 1e-9f;
+            f1 = fabsf((float)v1[h] + (lane + 64 == i ? sl : 0.f)) > 1e-9f;
+          } else if (sizeof(ST) == 8) {
+            f0 = fabs((double)v0[h]) > 1e-9;
+            f1 = fabs((double)v1[h]) > 1e-9;
+          } else {
+            f0 = fabsf((float)v0[h]) > 1e-9f;
+            f1 = fabsf((float)v1[h]) > 1e-9f;
+          }
+          const unsigned long long k0 = __ballot(f0 && lane < N), k1 = __ballot(f1 && lane + 64 < N);
+          if (lane == 0) {
+            rmask[4 * i + 0] = (unsigned)k0; rmask[4 * i + 1] = (unsigned)(k0 >> 32);
+            rmask[4 * i + 2] = (unsigned)k1; rmask[4 * i + 3] = (unsigned)(k1 >> 32);
+          }
+        }
+        }
+      };
+      if (p.s_is_f64) stage_masks(double{});
+      else stage_masks(float{});
     } else {                // mask -> A (1/0)
       for (int idx = t; idx < N * N; idx += NT) {
         const int i = idx / N, j = idx - i * N;
@@ -203,13 +251,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
       }
     }
   }
-  const int rpw = WIDE ? 1 : RPW;
-  // bias slice of this lane (hop-phase lane map), loaded once
-  fvec biasv = zerov;
-  if (p.bias) biasv = *reinterpret_cast<const fvec*>(p.bias + VEC * (WIDE ? lane : lane % LF));
   if constexpr (WIDE) {
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) MAGAT_SETTLE_F(biasv[e]);
     if (keyquery && need_att) {
 #pragma unroll
       for (int q = 0; q < CP8; ++q)
@@ -236,11 +278,29 @@ __global__ void gat_dense_kernel(const GatParams p) {
       c1s[n] = Zb[(long long)n * p.NC + p.c1off + head];
       c2s[n] = Zb[(long long)n * p.NC + p.c2off + head];
     }
+  // U rows of this wave's output rows: one per-lane base pointer, rows nwaves * rpw apart (rows past N re-read row 0
+  // of the group: harmless, never stored)
+  const int ws_head = __builtin_amdgcn_readfirstlane(wl);
+  auto load_urows = [&](fvec (&dst)[HMAX], int kk) {
+    const float* base = Zb + (long long)(ws_head * rpw + grp) * p.NC + p.uoff + (head * K + kk) * F + VEC * sub;
+    const long long step = (long long)nwaves * rpw * p.NC;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+      const bool ok = (ws_head + h * nwaves) * rpw + grp < N;
+      dst[h] = *reinterpret_cast<const fvec*>(ok ? base + h * step : base);
+    }
+  };
+  // the first hop's U rows travel during the score phase.  For the very first head of a workgroup they are issued
+  // before the wait for the tiles (everything is in flight together: short score phases, e.g. N = 20, do not cover a
+  // second memory latency); for later heads after it (the wait must not include them).
+  const bool first_head = hh == 0 && bl == bl0;
+  if (WIDE && first_head) load_urows(ucur, K > 1 ? K - 2 : 0);
   if constexpr (WIDE) {
     // Q tile (prefetched during the previous head's last hop, or above) is in Rq once every wave's loads are done;
     // the same barrier retires the previous head's reads of Ru and A
     tiles_landed();
-    if (hh > 0 && keyquery && need_att && K > 1) dma_tile(Ru, p.uoff + (head * K + (K - 1)) * F, tl);
+    if ((hh > 0 || bl != bl0) && keyquery && need_att && K > 1)
+      dma_tile(Ru, Zb, p.uoff + (head * K + (K - 1)) * F, tl);
   } else {
     if (keyquery && need_att) {
 #pragma unroll
@@ -256,14 +316,8 @@ __global__ void gat_dense_kernel(const GatParams p) {
     if (K > 1) issue_u(head, tl);     // in flight during the score phase
   }
   if (dbg && t == 0 && hh == hpb - 1) dbg[1] = clock64();
-  {   // the first hop's U rows: in flight during the score phase
-    const int uo = p.uoff + (head * K + (K > 1 ? K - 2 : 0)) * F;
-#pragma unroll
-    for (int h = 0; h < HMAX; ++h) {
-      const int j = (wl + h * nwaves) * rpw + grp;
-      ucur[h] = *reinterpret_cast<const fvec*>(Zb + (long long)(j < N ? j : 0) * p.NC + uo + VEC * sub);
-    }
-  }
+  if (dbg && t == 0 && hh == 0) { dbg[4] += clock64() - t_inst; dbg[5] += 1; }   // instance prologue + first barrier
+  if (!(WIDE && first_head)) load_urows(ucur, K > 1 ? K - 2 : 0);
 
   // ---- phase 1: attention rows out of LDS.
   // WIDE (G >= 64): a 16-lane row of the wave owns one graph row (4 rows per wave step); its lanes walk the
@@ -289,19 +343,20 @@ __global__ void gat_dense_kernel(const GatParams p) {
               const bool two = ww != 0;
               const int j1 = two ? 32 * r + __builtin_ctz(ww) : j0;
               ww &= ww - 1;
-              float d0 = 0.f, d1 = 0.f;
+              // packed fp32 FMAs (v_pk_fma_f32): even / odd elements accumulate separately, summed at the end
+              f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f};
 #pragma unroll
               for (int q = 0; q < CP8; ++q) {
                 const f32x4 q0 = *reinterpret_cast<const f32x4*>(Rq + j0 * G + 4 * (es + 8 * (q ^ par)));
                 const f32x4 q1 = *reinterpret_cast<const f32x4*>(Rq + j1 * G + 4 * (es + 8 * (q ^ par)));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  d0 = fmaf(xi[q][e], q0[e], d0);
-                  d1 = fmaf(xi[q][e], q1[e], d1);
-                }
+                const f32x2 xl = {xi[q][0], xi[q][1]}, xh = {xi[q][2], xi[q][3]};
+                p0 = __builtin_elementwise_fma(xl, f32x2{q0[0], q0[1]}, p0);
+                p1 = __builtin_elementwise_fma(xl, f32x2{q1[0], q1[1]}, p1);
+                p0 = __builtin_elementwise_fma(xh, f32x2{q0[2], q0[3]}, p0);
+                p1 = __builtin_elementwise_fma(xh, f32x2{q1[2], q1[3]}, p1);
               }
-              d0 = oct_sum(d0);
-              d1 = oct_sum(d1);
+              float d0 = oct_sum(p0[0] + p0[1]);
+              float d1 = oct_sum(p1[0] + p1[1]);
               if (es == 0) {
                 Arow[j0] = d0;
                 if (two) Arow[j1] = d1;
@@ -447,21 +502,28 @@ __global__ void gat_dense_kernel(const GatParams p) {
   // caught by compiler-inserted s_waitcnt vmcnt(0) guards for registers with pending loads
   auto hop_rows = [&](auto last_tag, const float* Rold_, float* Rnew_) {
     constexpr bool last = decltype(last_tag)::value;
+    // wave-uniform row bookkeeping lives in SGPRs; per-lane bases are computed once per hop
+    const int ws = __builtin_amdgcn_readfirstlane(wl);
+    const float* Ac0 = A + (lane < N ? lane : 0) * p.lda_a;            // attention column walkers (lanes i, i + 64)
+    const float* Ac1 = A + (lane + 64 < N ? lane + 64 : 0) * p.lda_a;
+    const bool lv0 = lane < N, lv1 = lane + 64 < N;
+    float* yrow = p.Y + ((long long)b * N + ws * rpw + grp) * p.ldy + head * F + VEC * sub;
+    const long long ystep = (long long)nwaves * rpw * p.ldy;
 #pragma unroll
     for (int h = 0; h < HMAX; ++h) {
-      int wq = wl;                       // laundered per row: keeps the 8 unrolled rows' address math from being
-      asm volatile("" : "+v"(wq));       // hoisted in front of the hop loop (register pressure)
-      const int jb = (wq + h * nwaves) * rpw;
+      const int jb = (ws + h * nwaves) * rpw;
       if (jb >= N) break;
       const int j = jb + grp;
       const bool jok = j < N;
       fvec acc = zerov;
       if (K > 1) {
         if constexpr (WIDE) {
-          const float c0 = lane < N ? A[lane * p.lda_a + j] : 0.f;
-          const float c1 = lane + 64 < N ? A[(lane + 64) * p.lda_a + j] : 0.f;
-          const unsigned long long k0 = __ballot(c0 != 0.f), k1 = __ballot(c1 != 0.f);
+          // attention column j: lanes i and i + 64 (unconditional reads from clamped rows, masked by lv0 / lv1)
+          const float c0 = Ac0[j], c1 = Ac1[j];
+          const unsigned long long k0 = __ballot(lv0 && c0 != 0.f), k1 = __ballot(lv1 && c1 != 0.f);
           const float* Tl = Rold_ + VEC * lane;
+          // (reading up to 8 neighbour rows before the first FMA was tried: 16.5k instead of 10k cycles per hop - the
+          // hop is bound by VALU issue, not by LDS latency, and the batched form needs more instructions per row)
           auto gather = [&](unsigned long long km, float cv, int base) {
             while (km) {          // two neighbour rows in flight per trip (weights via v_readlane)
               const int i0 = __builtin_ctzll(km);
@@ -508,7 +570,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) res[e] = fmaxf(res[e], 0.f);
         }
-        *reinterpret_cast<fvec*>(p.Y + ((long long)b * N + j) * p.ldy + head * F + VEC * sub) = res;
+        *reinterpret_cast<fvec*>(yrow + h * ystep) = res;
       } else {
         *reinterpret_cast<fvec*>(Rnew_ + j * F + VEC * sub) = res;
       }
@@ -519,12 +581,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
       int tk = threadIdx.x;      // laundered per hop: load addresses are computed at the point of use
       asm volatile("" : "+v"(tk));
       fvec unext[HMAX];          // next hop's U rows: in flight during this hop
-      const int uo = p.uoff + (head * K + (k - 1)) * F;
-#pragma unroll
-      for (int h = 0; h < HMAX; ++h) {
-        const int j = ((tk >> 6) + h * nwaves) * rpw + grp;
-        unext[h] = *reinterpret_cast<const fvec*>(Zb + (long long)(j < N ? j : 0) * p.NC + uo + VEC * sub);
-      }
+      load_urows(unext, k - 1);
       hop_rows(std::false_type{}, Rold, Rnew);
 #pragma unroll
       for (int h = 0; h < HMAX; ++h) ucur[h] = unext[h];
@@ -539,13 +596,16 @@ __global__ void gat_dense_kernel(const GatParams p) {
       float* tmp = Rold; Rold = Rnew; Rnew = tmp;
     }
     if constexpr (WIDE) {
-      if (hh + 1 < hpb) {
-        // Rnew is not read any more: the next head's first tile streams into it during the last hop (every register
-        // the rows below consume has been settled, so nothing waits for it)
+      const bool more_heads = hh + 1 < hpb;
+      if (more_heads || bl + istride < p.B) {
+        // Rnew is not read any more: the first tile of the next head (or of the next instance's first head) streams
+        // into it during the last hop (every register the rows below consume has been settled: nothing waits for it)
         int tk = threadIdx.x;
         asm volatile("" : "+v"(tk));
-        if (keyquery && need_att) dma_tile(Rnew, p.qoff + (head + 1) * G, tk);
-        else if (K > 1) dma_tile(Rnew, p.uoff + ((head + 1) * K + (K - 1)) * F, tk);
+        const float* zbn = more_heads ? Zb : p.Z + (long long)(bl + istride) * N * p.NC;
+        const int hn = more_heads ? head + 1 : head0;
+        if (keyquery && need_att) dma_tile(Rnew, zbn, p.qoff + hn * G, tk);
+        else if (K > 1) dma_tile(Rnew, zbn, p.uoff + (hn * K + (K - 1)) * F, tk);
       }
     }
     hop_rows(std::true_type{}, Rold, Rnew);
@@ -555,6 +615,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
     else { Ru = Rnew; Rq = Rold; }
   }
   }  // heads
+  }  // instances
   if (dbg) {
     __syncthreads();
     if (t == 0) { dbg[6] = clock64(); dbg[7] = wall_clock64(); }
@@ -843,7 +904,13 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
     if (G >= 64 && P > 1 && lds > 80 * 1024 && cb >= 256) hpb = P;
     if (hpb_env > 0 && G >= 64 && P % hpb_env == 0) hpb = hpb_env;
     p.hpb = hpb;
-    const int blocks = (cb + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD * (P / hpb);
+    // with one workgroup per CU (hpb == P case) the grid is capped at one workgroup per CU and every workgroup walks
+    // several instances, prefetching across the instance boundary as well
+    int inst_slots = (cb + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD;
+    static int persist_env = -1;
+    if (persist_env < 0) { const char* e = getenv("MAGAT_GAT_PERSIST"); persist_env = e ? atoi(e) : 1; }
+    if (persist_env && hpb == P && hpb > 1 && !use_list && inst_slots > 256) inst_slots = 256;
+    const int blocks = inst_slots * (P / hpb);
     switch (G) {
       case 16: rc = launch_gat<16, 16>(p, blocks, threads, lds, st); break;
       case 32: rc = launch_gat<32, 32>(p, blocks, threads, lds, st); break;

@@ -34,6 +34,9 @@ print("blocks", d.shape[0], "total cycles mean %.0f" % tot.mean().item())
 for n, s_ in zip(names, seg):
     if s_ is not None:
         print("  %-18s mean %8.0f  p10 %8.0f  p90 %8.0f" % (n, s_.mean().item(), s_.quantile(0.1).item(), s_.quantile(0.9).item()))
+if d[:, 5].max() > 0:
+    print("  instance prologue (masks, x_i, first tile wait): mean %.0f cycles per instance, %.1f instances per workgroup"
+          % ((d[:, 4] / d[:, 5].clamp_min(1)).mean().item(), d[:, 5].mean().item()))
 wall = d[:, 7]
 print("kernel span (100MHz wall clock): %.1f us" % ((wall.max() - wall.min()).item() / 100.0))
 first = d[:, 0].min()
