@@ -114,6 +114,22 @@ int magat_gat_train_backward_f32(const float* dYpre, const float* X, const float
                                  const int* cscpos, long long nnz, float* dZ, float* dXd, float* datt, int B, int N,
                                  int G, int F, int K, int P, int mode, void* stream);
 
+/* ---- Batched on-device simulator front-end: the two per-step host loops in front of the model.
+ * magat_sim_gso: multiRobotSimNew.computeAdjacencyMatrix, fixed-radius branch (utils/new_simulator.py:783-804, called by
+ *   getGSO :301-321): pos [B][N][2] int32 (row, col) -> S [B][N][N] float32|float64,  W = (euclidean distance < R) with zero
+ *   diagonal, optional D^-1/2 W D^-1/2 (config.symmetric_norm), then W / lambda_max(W) when `normalize` (an edgeless
+ *   instance stays zero).  Edge structure is bit-exact; lambda_max (-> lambda_out [B], may be NULL) comes from Lanczos +
+ *   Sturm bisection in float64 (the reference: numpy.linalg.eigvalsh on the host), values agree to ~1e-12 relative.
+ *   The step-0 radius growth loop (grow R by 10 % until the graph is connected, :761-768) stays with the caller.
+ * magat_sim_fov_states: AgentState.toInputTensor for guidance 'Project_G' (dataloader/statetransformer_Guidance.py:
+ *   88-124, 185-239): obstacle map [B or 1][H][W] uint8 (non-zero = obstacle; outside the map counts as obstacle),
+ *   pos / goal [B][N][2] int32 -> x [B][N][3][FOV+2][FOV+2] float32 in {0,1}: channel 0 obstacles, 1 goal or projected
+ *   goal, 2 agents (self included); bit-exact. */
+int magat_sim_gso(const int32_t* pos, double comm_radius, int symmetric_norm, int normalize, void* S, int s_is_f64,
+                  double* lambda_out, int B, int N, void* stream);
+int magat_sim_fov_states(const uint8_t* map, int map_batched, int H, int W, const int32_t* pos, const int32_t* goal,
+                         float* x, int FOV, int B, int N, void* stream);
+
 /* dense GSO -> CSR in two steps (the caller prefix-sums the degrees in between): per-row edge counts, then column fill */
 int magat_gso_row_degrees(const void* S, int s_is_f64, int self_loops /*GAT_origin: S + I*/, int* deg /*B*N*/, int B,
                           int N, void* stream);

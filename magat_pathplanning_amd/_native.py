@@ -69,6 +69,8 @@ _SIGNATURES = {
     "magat_gat_train_backward_f32": (_I, [_P] * 10 + [ctypes.c_longlong] + [_P] * 3 + [_I] * 7 + [_P]),
     "magat_gso_row_degrees": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "magat_gso_fill_csr": (_I, [_P, _I, _I, _P, _P, _I, _I, _P]),
+    "magat_sim_gso": (_I, [_P, ctypes.c_double, _I, _I, _P, _I, _P, _I, _I, _P]),
+    "magat_sim_fov_states": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "magat_gso_prepare": (_I, [_P, _I, _Z, _I, _I, _P]),
     "magat_conv_gemm_f32": (_I, [ctypes.POINTER(ConvGemmDesc), _P]),
     "magat_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

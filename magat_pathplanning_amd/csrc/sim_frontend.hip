@@ -1,0 +1,303 @@
+// Batched on-device simulator front-end: the two per-step host loops that feed the hot path
+// (reference: utils/new_simulator.py:279-321, 745-818 and
+// dataloader/statetransformer_Guidance.py:88-124, 185-239, guidance 'Project_G').
+//   magat_sim_gso         positions -> GSO  S = W / lambda_max(W),  W = (euclidean distance < R), zero diagonal,
+//                         optional D^-1/2 W D^-1/2; edge structure bit-exact, lambda_max by Lanczos + Sturm
+//                         bisection in float64 (the reference calls numpy.linalg.eigvalsh per instance on the host)
+//   magat_sim_fov_states  obstacle map + agent / goal coordinates -> (B,N,3,FOV+2,FOV+2) {0,1} state tensor,
+//                         bit-exact (integer work; the goal projection reproduces arctan2 / round-half-even)
+// One workgroup per planning instance; everything an instance needs sits in LDS.
+#include <cstdint>
+
+#include "magat_common.h"
+
+namespace {
+
+constexpr int SIM_THREADS = 256;
+
+__device__ __forceinline__ double block_sum(double v, double* red, int t, int nt) {
+  // wave reduction through DPP-free shuffles (doubles), then one LDS pass over the waves
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((t & 63) == 0) red[t >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < (nt + 63) / 64; ++w) s += red[w];
+  return s;
+}
+
+// rows of W as bit masks in LDS while they fit (N <= ~1000: 128 KB); larger instances evaluate the distance test on
+// the fly (N <= 2048)
+template <bool MASK>
+__global__ __launch_bounds__(SIM_THREADS) void gso_kernel(const int* __restrict__ pos, double R, int symmetric_norm,
+                                                          int normalize, void* __restrict__ S, int s_is_f64,
+                                                          double* __restrict__ lambda_out, int N) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  const int words = (N + 31) / 32;
+  int* px = reinterpret_cast<int*>(smem_raw);
+  int* py = px + N;
+  double* v = reinterpret_cast<double*>(py + N + ((2 * N) & 1));      // 8-byte aligned
+  double* y = v + N;
+  double* inv = y + N;
+  double* red = inv + N;                                             // [16] wave partials, then [160] alpha, [161] beta
+  unsigned* rows = reinterpret_cast<unsigned*>(red + 16 + 160 + 162);   // [N][words]   (MASK only)
+  __shared__ int any_edge;
+  if (t == 0) any_edge = 0;
+  for (int n = t; n < N; n += nt) {
+    px[n] = pos[((long long)b * N + n) * 2 + 0];
+    py[n] = pos[((long long)b * N + n) * 2 + 1];
+  }
+  __syncthreads();
+  auto edge = [&](int i, int j) -> bool {
+    if (i == j) return false;
+    const long long dx = px[i] - px[j], dy = py[i] - py[j];
+    return sqrt((double)(dx * dx + dy * dy)) < R;       // squareform(pdist(.)) < R, float64 like the reference
+  };
+  // degrees (+ bit rows)
+  for (int i = t; i < N; i += nt) {
+    int deg = 0;
+    if (MASK) {
+      for (int w = 0; w < words; ++w) {
+        unsigned m = 0;
+        for (int q = 0; q < 32; ++q) {
+          const int j = 32 * w + q;
+          if (j < N && edge(i, j)) m |= 1u << q;
+        }
+        rows[i * words + w] = m;
+        deg += __popc(m);
+      }
+    } else {
+      for (int j = 0; j < N; ++j) deg += edge(i, j) ? 1 : 0;
+    }
+    if (deg) any_edge = 1;
+    double s = 1.0;
+    if (symmetric_norm) {                       // deg -> 1/sqrt(deg), isolated nodes -> 0 (new_simulator.py:787-793)
+      s = deg > 0 ? sqrt(1.0 / (double)deg) : 0.0;
+    }
+    inv[i] = s;
+    v[i] = 1.0;
+  }
+  __syncthreads();
+  const bool has_edges = any_edge != 0;
+  double lam = 0.0;
+  if (has_edges && normalize) {
+    // Lanczos on the symmetric matrix W (no reorthogonalisation: only the extreme Ritz value is wanted, and that one
+    // converges first and stays put).  The all-ones start has a component along the Perron vector of every connected
+    // component, so the largest Ritz value tends to lambda_max(W) = max over components.  Every LCHK steps the largest
+    // eigenvalue of the tridiagonal T_k is located by Sturm bisection; stop when it no longer moves.
+    constexpr int LMAX = 160, LCHK = 8;
+    double* alpha = red + 16;            // [LMAX]
+    double* beta = alpha + LMAX;         // [LMAX + 1]   beta[k] couples v_{k-1} and v_k
+    // v = ones / sqrt(N), v_prev = 0   (y holds v_prev, inv stays the D^-1/2 scaling)
+    double* vprev = y;
+    double* wv = vprev + 0;              // w is accumulated into registers and written over vprev's slot after use
+    const double s0 = 1.0 / sqrt((double)N);
+    for (int i = t; i < N; i += nt) { v[i] = s0; vprev[i] = 0.0; }
+    if (t == 0) beta[0] = 0.0;
+    __syncthreads();
+    double prev = -1.0;
+    int steps = 0, stable = 0;
+    for (int k = 0; k < LMAX; ++k) {
+      // w_i = (W v)_i - beta_k * vprev_i ; alpha = v . w
+      double wloc[(2048 + SIM_THREADS - 1) / SIM_THREADS];
+      double dot = 0.0;
+      const double bk = beta[k];
+      int q = 0;
+      for (int i = t; i < N; i += nt, ++q) {
+        double acc = 0.0;
+        if (MASK) {
+          for (int w = 0; w < words; ++w) {
+            unsigned m = rows[i * words + w];
+            while (m) {
+              const int j = 32 * w + __builtin_ctz(m);
+              m &= m - 1;
+              acc += inv[j] * v[j];
+            }
+          }
+        } else {
+          for (int j = 0; j < N; ++j)
+            if (edge(i, j)) acc += inv[j] * v[j];
+        }
+        const double wi = inv[i] * acc - bk * vprev[i];
+        wloc[q] = wi;
+        dot += v[i] * wi;
+      }
+      const double ak = block_sum(dot, red, t, nt);
+      double nrm = 0.0;
+      q = 0;
+      for (int i = t; i < N; i += nt, ++q) {
+        wloc[q] -= ak * v[i];
+        nrm += wloc[q] * wloc[q];
+      }
+      const double bn = sqrt(block_sum(nrm, red, t, nt));
+      if (t == 0) { alpha[k] = ak; beta[k + 1] = bn; }
+      steps = k + 1;
+      const bool breakdown = !(bn > 1e-13 * (fabs(ak) + bk + 1.0));      // invariant subspace reached: T_k is exact
+      q = 0;
+      for (int i = t; i < N; i += nt, ++q) {
+        vprev[i] = v[i];
+      }
+      __syncthreads();
+      q = 0;
+      if (!breakdown)
+        for (int i = t; i < N; i += nt, ++q) v[i] = wloc[q] / bn;
+      __syncthreads();
+      if (breakdown || (steps % LCHK) == 0 || steps == LMAX || steps >= N) {
+        // largest eigenvalue of T_steps (alpha[0..steps), beta[1..steps)) by multisection on the Sturm count: every
+        // thread probes its own abscissa inside [lo, hi], the interval shrinks (nt + 1)-fold per pass
+        double lo = alpha[0], hi = alpha[0];
+        for (int r = 0; r < steps; ++r) {
+          const double off = (r > 0 ? fabs(beta[r]) : 0.0) + (r + 1 < steps ? fabs(beta[r + 1]) : 0.0);
+          lo = fmin(lo, alpha[r] - off);
+          hi = fmax(hi, alpha[r] + off);
+        }
+        int* best = reinterpret_cast<int*>(red + 15);       // red[0..nt/64) are the reduction slots; [15] is free
+        for (int pass = 0; pass < 12 && hi - lo > 4e-16 * fmax(fabs(lo), fabs(hi)); ++pass) {
+          if (t == 0) *best = -1;
+          __syncthreads();
+          const double x = lo + (hi - lo) * (double)(t + 1) / (double)(nt + 1);
+          int below = 0;                                     // eigenvalues of T below x = negative pivots of T - x I
+          double d = 1.0;
+          for (int r = 0; r < steps; ++r) {
+            d = (alpha[r] - x) - (r > 0 ? beta[r] * beta[r] / d : 0.0);
+            if (d == 0.0) d = 1e-300;
+            if (d < 0.0) ++below;
+          }
+          if (below < steps) atomicMax(best, t);             // lambda_max >= x_t
+          __syncthreads();
+          const int bt = *best;
+          const double nlo = bt >= 0 ? lo + (hi - lo) * (double)(bt + 1) / (double)(nt + 1) : lo;
+          const double nhi = bt + 1 < nt ? lo + (hi - lo) * (double)(bt + 2) / (double)(nt + 1) : hi;
+          lo = nlo;
+          hi = nhi;
+          __syncthreads();
+        }
+        lam = 0.5 * (lo + hi);
+        if (breakdown || steps >= N) break;
+        if (fabs(lam - prev) <= 1e-13 * fabs(lam)) {
+          if (++stable >= 2) break;
+        } else {
+          stable = 0;
+        }
+        prev = lam;
+      }
+    }
+    (void)wv;
+  }
+  if (lambda_out && t == 0) lambda_out[b] = lam;
+  const double div = (has_edges && normalize) ? lam : 1.0;
+  const long long base = (long long)b * N * N;
+  for (long long idx = t; idx < (long long)N * N; idx += nt) {
+    const int i = (int)(idx / N), j = (int)(idx - (long long)i * N);
+    bool e;
+    if (MASK) e = (rows[i * words + (j >> 5)] >> (j & 31)) & 1u;
+    else e = edge(i, j);
+    const double val = e ? (inv[i] * 1.0 * inv[j]) / div : 0.0;
+    if (s_is_f64) static_cast<double*>(S)[base + idx] = val;
+    else static_cast<float*>(S)[base + idx] = (float)val;
+  }
+}
+
+size_t gso_lds_bytes(int N, bool mask) {
+  size_t b = (size_t)2 * N * sizeof(int) + 8 + (size_t)3 * N * sizeof(double) + (16 + 160 + 162) * sizeof(double);
+  if (mask) b += (size_t)N * ((N + 31) / 32) * sizeof(unsigned);
+  return b;
+}
+
+// ---- FOV state tensors
+__global__ __launch_bounds__(SIM_THREADS) void fov_states_kernel(const uint8_t* __restrict__ map, long long map_stride,
+                                                                 int H, int Wm, const int* __restrict__ pos,
+                                                                 const int* __restrict__ goal, float* __restrict__ x,
+                                                                 int fov, int N) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  const int Wt = fov + 2, half = fov / 2, dist = Wt / 2;
+  unsigned* occ = reinterpret_cast<unsigned*>(smem_raw);             // agent occupancy bitmap [H*Wm bits]
+  const int occ_words = (H * Wm + 31) / 32;
+  int* gmark = reinterpret_cast<int*>(occ + occ_words);              // per agent: goal marker pixel (row * Wt + col)
+  const uint8_t* mp = map + (long long)b * map_stride;
+  for (int w = t; w < occ_words; w += nt) occ[w] = 0u;
+  __syncthreads();
+  for (int n = t; n < N; n += nt) {
+    const int cx = pos[((long long)b * N + n) * 2], cy = pos[((long long)b * N + n) * 2 + 1];
+    const int gx = goal[((long long)b * N + n) * 2], gy = goal[((long long)b * N + n) * 2 + 1];
+    if (cx >= 0 && cx < H && cy >= 0 && cy < Wm) atomicOr(&occ[(cx * Wm + cy) >> 5], 1u << ((cx * Wm + cy) & 31));
+    int row, col;
+    const int dx = gx - cx, dy = gy - cy;
+    const bool in_map = gx >= 0 && gx < H && gy >= 0 && gy < Wm;
+    if (in_map && dx >= -half && dx <= half && dy >= -half && dy <= half) {     // goal inside the FOV window
+      row = dx + half + 1;
+      col = dy + half + 1;
+    } else {
+      // projectedgoal (statetransformer_Guidance.py:103-124): the arctan2 test "pi/4 <= |angle| <= 3pi/4" is
+      // |dy| >= |dx| for integer offsets (on the exact diagonals both branches give the same pixel); np.round is
+      // round-half-to-even = rint in the default rounding mode
+      const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
+      const int sx = (dx > 0) - (dx < 0), sy = (dy > 0) - (dy < 0);
+      if (ady >= adx) {
+        col = dist * (sy + 1);
+        row = (int)((double)dist + rint((double)dist * (double)dx / (double)ady));
+      } else {
+        row = dist * (sx + 1);
+        col = (int)((double)dist + rint((double)dist * (double)dy / (double)adx));
+      }
+    }
+    gmark[n] = row * Wt + col;
+  }
+  __syncthreads();
+  const int per_agent = 3 * Wt * Wt;
+  float* xb = x + (long long)b * N * per_agent;
+  for (int idx = t; idx < N * per_agent; idx += nt) {
+    const int n = idx / per_agent, r = idx - n * per_agent;
+    const int ch = r / (Wt * Wt), pix = r - ch * Wt * Wt;
+    const int a = pix / Wt, c = pix - a * Wt;
+    float val = 0.f;
+    if (ch == 1) {
+      val = gmark[n] == pix ? 1.f : 0.f;
+    } else if (a >= 1 && a <= fov && c >= 1 && c <= fov) {
+      const int gx = pos[((long long)b * N + n) * 2] - half + (a - 1);
+      const int gy = pos[((long long)b * N + n) * 2 + 1] - half + (c - 1);
+      const bool inside = gx >= 0 && gx < H && gy >= 0 && gy < Wm;
+      if (ch == 0) val = inside ? (mp[gx * Wm + gy] ? 1.f : 0.f) : 1.f;          // outside the map = obstacle
+      else val = inside && ((occ[(gx * Wm + gy) >> 5] >> ((gx * Wm + gy) & 31)) & 1u) ? 1.f : 0.f;
+    }
+    xb[idx] = val;
+  }
+}
+
+}  // namespace
+
+extern "C" int magat_sim_gso(const int32_t* pos, double comm_radius, int symmetric_norm, int normalize, void* S,
+                             int s_is_f64, double* lambda_out, int B, int N, void* stream) {
+  if (!pos || !S) return MAGAT_ERR_NULL;
+  if (B <= 0 || N <= 0 || !(comm_radius > 0.0)) return MAGAT_ERR_BAD_SHAPE;
+  if (N > 2048) return MAGAT_ERR_UNSUPPORTED;
+  const bool mask = gso_lds_bytes(N, true) <= 160 * 1024;          // bit rows of W in LDS (N <= ~1000), else on the fly
+  const size_t lds = gso_lds_bytes(N, mask);
+  if (lds > 160 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (mask) {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gso_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return MAGAT_ERR_LAUNCH;
+    hipLaunchKernelGGL(gso_kernel<true>, dim3(B), dim3(SIM_THREADS), lds, st, pos, comm_radius, symmetric_norm, normalize,
+                       S, s_is_f64, lambda_out, N);
+  } else {
+    hipLaunchKernelGGL(gso_kernel<false>, dim3(B), dim3(SIM_THREADS), lds, st, pos, comm_radius, symmetric_norm, normalize,
+                       S, s_is_f64, lambda_out, N);
+  }
+  return magat_check_launch();
+}
+
+extern "C" int magat_sim_fov_states(const uint8_t* map, int map_batched, int H, int W, const int32_t* pos,
+                                    const int32_t* goal, float* x, int FOV, int B, int N, void* stream) {
+  if (!map || !pos || !goal || !x) return MAGAT_ERR_NULL;
+  if (B <= 0 || N <= 0 || H <= 0 || W <= 0 || FOV <= 0 || !(FOV & 1)) return MAGAT_ERR_BAD_SHAPE;
+  const size_t lds = (size_t)((H * W + 31) / 32) * sizeof(unsigned) + (size_t)N * sizeof(int);
+  if (lds > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(fov_states_kernel, dim3(B), dim3(SIM_THREADS), lds, static_cast<hipStream_t>(stream), map,
+                     map_batched ? (long long)H * W : 0LL, H, W, pos, goal, x, FOV, N);
+  return magat_check_launch();
+}
