@@ -130,6 +130,19 @@ int magat_sim_gso(const int32_t* pos, double comm_radius, int symmetric_norm, in
 int magat_sim_fov_states(const uint8_t* map, int map_batched, int H, int W, const int32_t* pos, const int32_t* goal,
                          float* x, int FOV, int B, int N, void* stream);
 
+/* magat_sim_move: multiRobotSimNew.move + check_collision (utils/new_simulator.py:334-454, 471-520),
+ *   batched: action key = argmax of the 5 logits (convectToActionKey_softmax :863-869; or given keys `actions_in`), proposed
+ *   move (up 0, left 1, down 2, right 3, stop 4), shielding in the reference's order - out of the arena, face-to-face
+ *   swap, obstacle, several agents into one cell, backward cascade - and pos += move in place.  ONE deviation: where the
+ *   reference lets random.choice pick among several MOVING claimants of a cell, the lowest agent index wins (equal to
+ *   the reference run with random.choice := first; a stationary claimant always wins, as in the reference).
+ *   Outputs (each may be NULL): actions_out [B*N], moves_out [B][N][2] int8, reached_out [B][N] (new pos == goal),
+ *   flags_out [B] bit0 out-of-arena, bit1 swap, bit2 obstacle, bit3 cell conflict.  One workgroup per instance,
+ *   H*W*4 + 16 N bytes of LDS <= 160 KB, N <= 65535. */
+int magat_sim_move(const float* logits, const int32_t* actions_in, const uint8_t* map, int map_batched, int H, int W,
+                   int32_t* pos, const int32_t* goal, int32_t* actions_out, int8_t* moves_out, uint8_t* reached_out,
+                   int32_t* flags_out, int B, int N, void* stream);
+
 /* dense GSO -> CSR in two steps (the caller prefix-sums the degrees in between): per-row edge counts, then column fill */
 int magat_gso_row_degrees(const void* S, int s_is_f64, int self_loops /*GAT_origin: S + I*/, int* deg /*B*N*/, int B,
                           int N, void* stream);

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "magat_gso_fill_csr": (_I, [_P, _I, _I, _P, _P, _I, _I, _P]),
     "magat_sim_gso": (_I, [_P, ctypes.c_double, _I, _I, _P, _I, _P, _I, _I, _P]),
     "magat_sim_fov_states": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "magat_sim_move": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "magat_gso_prepare": (_I, [_P, _I, _Z, _I, _I, _P]),
     "magat_conv_gemm_f32": (_I, [ctypes.POINTER(ConvGemmDesc), _P]),
     "magat_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

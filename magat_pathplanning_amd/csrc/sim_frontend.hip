@@ -266,6 +266,130 @@ __global__ __launch_bounds__(SIM_THREADS) void fov_states_kernel(const uint8_t* 
   }
 }
 
+
+// ---- action decode + collision shielding + position update (new_simulator.py:334-454, 471-520).
+// One workgroup per instance; a single int32 cell grid in LDS is reused for the three lookups the reference does with
+// Python dicts: occupant of a cell (swap test), claimants of a target cell (atomicMin of a priority key), and the
+// "forced to stay" cells of the backward cascade.
+__global__ __launch_bounds__(1024) void sim_move_kernel(const float* __restrict__ logits, const int* __restrict__ actions_in,
+                                                        const uint8_t* __restrict__ map, long long map_stride, int H, int Wm,
+                                                        int* __restrict__ pos, const int* __restrict__ goal,
+                                                        int* __restrict__ actions_out, signed char* __restrict__ moves_out,
+                                                        uint8_t* __restrict__ reached_out, int* __restrict__ flags_out,
+                                                        int N) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  const int cells = H * Wm;
+  unsigned* grid = reinterpret_cast<unsigned*>(smem_raw);            // [cells]
+  int* px = reinterpret_cast<int*>(grid + cells);                    // [N]
+  int* py = px + N;
+  int* mc = py + N;                                                  // move code 0..4 (4 = stop)
+  int* aux = mc + N;                                                 // per-agent scratch: swap flag, then forced flag
+  __shared__ int changed, flags;
+  const uint8_t* mp = map + (long long)b * map_stride;
+  const int DX[5] = {-1, 0, 1, 0, 0}, DY[5] = {0, -1, 0, 1, 0};     // up, left, down, right, stop (:56-65)
+  if (t == 0) flags = 0;
+  for (int c = t; c < cells; c += nt) grid[c] = 0u;
+  __syncthreads();
+  for (int n = t; n < N; n += nt) {
+    const long long a = (long long)b * N + n;
+    const int x = pos[2 * a], y = pos[2 * a + 1];
+    int key;
+    if (logits) {                       // convectToActionKey_softmax: argmax, first maximum wins
+      const float* l = logits + a * 5;
+      key = 0;
+      float best = l[0];
+      for (int q = 1; q < 5; ++q)
+        if (l[q] > best) { best = l[q]; key = q; }
+    } else {
+      key = actions_in[a];
+      if (key < 0 || key > 4) key = 4;
+    }
+    if (actions_out) actions_out[a] = key;
+    const int nx = x + DX[key], ny = y + DY[key];
+    if (nx < 0 || ny < 0 || nx >= H || ny >= Wm) {                   // out of the arena -> stop (:354-357)
+      key = 4;
+      atomicOr(&flags, 1);
+    }
+    px[n] = x; py[n] = y; mc[n] = key; aux[n] = 0;
+    grid[x * Wm + y] = (unsigned)(n + 1);
+  }
+  __syncthreads();
+  // face-to-face swap: the agent in my target cell moves into my cell -> both stop (:361-375)
+  for (int n = t; n < N; n += nt) {
+    const int k = mc[n];
+    if (k != 4) {
+      const int j = (int)grid[(px[n] + DX[k]) * Wm + py[n] + DY[k]] - 1;
+      if (j >= 0) {
+        const int kj = mc[j];
+        if (kj != 4 && DX[kj] == -DX[k] && DY[kj] == -DY[k]) aux[n] = 1;
+      }
+    }
+  }
+  __syncthreads();
+  for (int n = t; n < N; n += nt) {
+    int k = mc[n];
+    int forced = 0;
+    if (aux[n]) { k = 4; atomicOr(&flags, 2); }
+    if (k != 4 && mp[(px[n] + DX[k]) * Wm + py[n] + DY[k]] != 0) {   // into an obstacle -> stop, cell stays taken (:392-403)
+      k = 4;
+      forced = 1;
+      atomicOr(&flags, 4);
+    }
+    mc[n] = k;
+    aux[n] = forced;
+  }
+  __syncthreads();
+  for (int c = t; c < cells; c += nt) grid[c] = 0xffffffffu;
+  __syncthreads();
+  // claimants of every target cell: a stationary claimant wins, otherwise the lowest agent index (the reference draws
+  // random.choice here, :416 - the one documented deviation)
+  for (int n = t; n < N; n += nt) {
+    const int k = mc[n];
+    atomicMin(&grid[(px[n] + DX[k]) * Wm + py[n] + DY[k]], (unsigned)((k == 4 ? 0 : 1) << 16 | n));
+  }
+  __syncthreads();
+  for (int n = t; n < N; n += nt) {
+    const int k = mc[n];
+    if (k != 4 && (int)(grid[(px[n] + DX[k]) * Wm + py[n] + DY[k]] & 0xffffu) != n) {
+      mc[n] = 4;
+      aux[n] = 1;
+      atomicOr(&flags, 8);
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < cells; c += nt) grid[c] = 0u;
+  __syncthreads();
+  for (int n = t; n < N; n += nt)
+    if (aux[n]) grid[px[n] * Wm + py[n]] = 1u;                        // cells whose occupant was forced to stay
+  // backward cascade (:424-446): whoever moves into such a cell stays as well, and its own cell joins the set
+  while (true) {
+    __syncthreads();
+    if (t == 0) changed = 0;
+    __syncthreads();
+    for (int n = t; n < N; n += nt) {
+      const int k = mc[n];
+      if (k != 4 && grid[(px[n] + DX[k]) * Wm + py[n] + DY[k]] != 0u) {
+        mc[n] = 4;
+        grid[px[n] * Wm + py[n]] = 1u;
+        changed = 1;
+      }
+    }
+    __syncthreads();
+    if (!changed) break;
+  }
+  for (int n = t; n < N; n += nt) {
+    const long long a = (long long)b * N + n;
+    const int k = mc[n];
+    const int nx = px[n] + DX[k], ny = py[n] + DY[k];
+    pos[2 * a] = nx;
+    pos[2 * a + 1] = ny;
+    if (moves_out) { moves_out[2 * a] = (signed char)DX[k]; moves_out[2 * a + 1] = (signed char)DY[k]; }
+    if (reached_out && goal) reached_out[a] = (nx == goal[2 * a] && ny == goal[2 * a + 1]) ? 1 : 0;
+  }
+  if (flags_out && t == 0) flags_out[b] = flags;
+}
+
 }  // namespace
 
 extern "C" int magat_sim_gso(const int32_t* pos, double comm_radius, int symmetric_norm, int normalize, void* S,
@@ -299,5 +423,24 @@ extern "C" int magat_sim_fov_states(const uint8_t* map, int map_batched, int H, 
   if (lds > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(fov_states_kernel, dim3(B), dim3(SIM_THREADS), lds, static_cast<hipStream_t>(stream), map,
                      map_batched ? (long long)H * W : 0LL, H, W, pos, goal, x, FOV, N);
+  return magat_check_launch();
+}
+
+extern "C" int magat_sim_move(const float* logits, const int32_t* actions_in, const uint8_t* map, int map_batched, int H,
+                              int W, int32_t* pos, const int32_t* goal, int32_t* actions_out, int8_t* moves_out,
+                              uint8_t* reached_out, int32_t* flags_out, int B, int N, void* stream) {
+  if ((!logits && !actions_in) || !map || !pos) return MAGAT_ERR_NULL;
+  if (B <= 0 || N <= 0 || N > 65535 || H <= 0 || W <= 0) return MAGAT_ERR_BAD_SHAPE;
+  const size_t lds = (size_t)H * W * sizeof(unsigned) + (size_t)4 * N * sizeof(int);
+  if (lds > 160 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&sim_move_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return MAGAT_ERR_LAUNCH;
+  int threads = 64;
+  while (threads < N && threads < 1024) threads *= 2;
+  hipLaunchKernelGGL(sim_move_kernel, dim3(B), dim3(threads), lds, static_cast<hipStream_t>(stream), logits, actions_in,
+                     map, map_batched ? (long long)H * W : 0LL, H, W, pos, goal, actions_out,
+                     reinterpret_cast<signed char*>(moves_out), reached_out, flags_out, N);
   return magat_check_launch();
 }

@@ -59,3 +59,32 @@ def batched_fov_states(obstacle_map, pos, goal, FOV=9):
                                                  nat.ptr(x), FOV, B, N, nat.current_stream(pos.device)),
                   "magat_sim_fov_states")
     return x
+
+
+def batched_move(obstacle_map, pos, logits=None, actions=None, goal=None):
+    """One closed-loop step for B instances on the device (multiRobotSimNew.move, utils/new_simulator.py:471-520):
+    decode the action keys from the model's logits (B*N,5) (or take `actions` (B,N)), shield the proposed moves exactly
+    like check_collision (:334-454; lowest index instead of random.choice among moving claimants) and advance `pos`
+    IN PLACE.  Returns dict(actions (B,N) int32, moves (B,N,2) int8, reached (B,N) bool or None, flags (B,) int32)."""
+    if pos.dtype != torch.int32 or not pos.is_cuda or not pos.is_contiguous():
+        raise nat.MagatNativeError("pos must be a contiguous int32 device tensor (it is updated in place)")
+    assert (logits is None) != (actions is None), "give logits or actions"
+    B, N, _ = pos.shape
+    dev = pos.device
+    m = obstacle_map.to(torch.uint8).contiguous()
+    if not m.is_cuda:
+        raise nat.MagatNativeError("obstacle_map must be a device tensor (no CPU fallback)")
+    batched = m.dim() == 3
+    H, W = m.shape[-2], m.shape[-1]
+    lg = None if logits is None else logits.reshape(B * N, 5).contiguous().float()
+    ac = None if actions is None else _dev_i32(actions, "actions").reshape(B * N)
+    gl = None if goal is None else _dev_i32(goal, "goal")
+    a_out = torch.empty(B, N, dtype=torch.int32, device=dev)
+    mv = torch.empty(B, N, 2, dtype=torch.int8, device=dev)
+    reached = torch.empty(B, N, dtype=torch.uint8, device=dev) if gl is not None else None
+    flags = torch.empty(B, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().magat_sim_move(nat.ptr(lg), nat.ptr(ac), nat.ptr(m), 1 if batched else 0, H, W, nat.ptr(pos),
+                                           nat.ptr(gl), nat.ptr(a_out), nat.ptr(mv), nat.ptr(reached), nat.ptr(flags), B, N,
+                                           nat.current_stream(dev)), "magat_sim_move")
+    return dict(actions=a_out, moves=mv, reached=None if reached is None else reached.bool(), flags=flags)

@@ -81,3 +81,88 @@ def fov_states(obstacle_map, pos, goal, fov=9):
             r, c = projected_goal(fov, cx, cy, gx, gy)
             out[n, 1, r, c] = 1
     return out
+
+
+# ------------------------------------------------------------------ action decode + shielding
+# move vectors by action key (utils/new_simulator.py:56-65): up 0, left 1, down 2, right 3, stop 4
+MOVES = np.array([[-1, 0], [0, -1], [1, 0], [0, 1], [0, 0]], np.int64)
+
+
+def decode_actions(logits):
+    """convectToActionKey_softmax (new_simulator.py:863-869): argmax of softmax(logits) = argmax of the logits
+    (first maximum wins, like torch.max).  logits (N,5) -> (N,) int64 action keys."""
+    return np.argmax(np.asarray(logits), axis=1).astype(np.int64)
+
+
+def shield_moves(obstacle_map, pos, move):
+    """multiRobotSimNew.check_collision (new_simulator.py:334-454) with ONE documented deviation: where the reference
+    lets `random.choice` pick the agent that may enter a cell claimed by several MOVING agents (:416), the lowest agent
+    index wins here (a batched kernel needs a deterministic rule; a stationary claimant always wins, as in the reference).
+    Everything else follows the reference step by step: out-of-arena moves stop (:354-357), face-to-face swaps stop both
+    (:361-375), moves into obstacles stop (:392-403), cell conflicts (:407-423), then the backward cascade: whoever
+    moves into the cell of an agent that was forced to stay stops as well (:424-446).
+    obstacle_map (H,W); pos (N,2) int; move (N,2) int in {-1,0,1}.  Returns (new_move (N,2), flags dict)."""
+    obstacle_map = np.asarray(obstacle_map)
+    H, W = obstacle_map.shape
+    pos = np.asarray(pos, np.int64)
+    move = np.array(move, np.int64)
+    N = len(pos)
+    new = pos + move
+    out = (new[:, 0] >= H) | (new[:, 1] >= W) | (new[:, 0] < 0) | (new[:, 1] < 0)
+    move[out] = 0
+    # face-to-face: same half-step position
+    half = {}
+    swap = []
+    newh = pos * 2 + move                       # doubled coordinates: exact half steps
+    for i in range(N):
+        key = (int(newh[i, 0]), int(newh[i, 1]))
+        if key in half:
+            j = half[key]
+            swap += [i, j]
+            move[i] = 0
+            move[j] = 0
+        half[key] = i
+    need_reverse = []
+    claims = {}
+    wall = []
+    for i in range(N):
+        tgt = pos[i] + move[i]
+        if obstacle_map[tgt[0], tgt[1]] != 0:
+            wall.append(i)
+            move[i] = 0
+            need_reverse.append(tuple(int(v) for v in pos[i]))
+            tgt = pos[i]
+        claims.setdefault((int(tgt[0]), int(tgt[1])), []).append(i)
+    collide = []
+    for cell, lst in claims.items():
+        if len(lst) > 1:
+            selected = min(lst)                                   # deviation: lowest index instead of random.choice
+            for i in lst:
+                if (move[i] == 0).all():
+                    selected = i
+            for i in lst:
+                if i != selected:
+                    move[i] = 0
+                    need_reverse.append(tuple(int(v) for v in pos[i]))
+            collide += lst
+    new = pos + move
+    into = {}
+    for i in range(N):
+        into.setdefault((int(new[i, 0]), int(new[i, 1])), []).append((i, (int(pos[i, 0]), int(pos[i, 1]))))
+    while need_reverse:
+        p = need_reverse.pop(0)
+        for agent, cur in into.get(p, []):
+            if cur != p:
+                need_reverse.append(cur)
+            move[agent] = 0
+    return move, dict(out_boundary=out, swap=sorted(set(swap)), wall=wall, collide=sorted(set(collide)))
+
+
+def move_step(obstacle_map, pos, goal, logits):
+    """One simulator step for one instance: multiRobotSimNew.move (new_simulator.py:471-520) without the bookkeeping of
+    makespan / flowtime: decode, propose, shield, advance, reach-goal test.  Returns (new_pos, actions, reached)."""
+    actions = decode_actions(logits)
+    new_move, _ = shield_moves(obstacle_map, pos, MOVES[actions])
+    new_pos = np.asarray(pos, np.int64) + new_move
+    reached = np.abs(new_pos - np.asarray(goal, np.int64)).sum(axis=1) == 0
+    return new_pos, actions, reached

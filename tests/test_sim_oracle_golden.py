@@ -42,3 +42,26 @@ def test_projected_goal_octants():
             (20, 10): (10, 7), (20, 6): (10, 7), (3, -10): (7, 0), (-7, 10): (1, 10), (10, -3): (10, 3), (-10, 5): (0, 7)}
     for (dx, dy), rc in want.items():
         assert so.projected_goal(9, 20, 20, 20 + dx, 20 + dy) == rc, (dx, dy)
+
+
+STEP = sorted(glob.glob(os.path.join(GOLDEN, "simstep_*.npz")))
+
+
+def test_simstep_fixture_inventory():
+    assert len(STEP) == 4
+
+
+@pytest.mark.parametrize("path", STEP, ids=[os.path.basename(p)[:-4] for p in STEP])
+def test_shielding_matches_reference(path):
+    """oracle.shield_moves against multiRobotSimNew.check_collision: identical wherever the reference's random tie-break
+    is irrelevant (`det`), and identical to the reference run with random.choice := "first claimant" everywhere (the
+    claim lists are in agent order, so "first" IS the lowest-index rule of the deterministic restatement)."""
+    z = np.load(path)
+    for b in range(z["pos"].shape[0]):
+        mv, _ = so.shield_moves(z["map"][b], z["pos"][b], so.MOVES[z["action"][b]])
+        np.testing.assert_array_equal(mv, z["move_first"][b])
+        if z["det"][b]:
+            np.testing.assert_array_equal(mv, z["move_last"][b])
+        new = z["pos"][b] + mv
+        assert len({tuple(p) for p in new}) == len(new)                      # no two agents in one cell
+        assert (z["map"][b][new[:, 0], new[:, 1]] == 0).all()                # nobody inside an obstacle
