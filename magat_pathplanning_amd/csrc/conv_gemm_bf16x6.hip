@@ -168,9 +168,12 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
     const char* bb = reinterpret_cast<const char*>(p.wt + bk);
     const long long bplane = p.wt_plane * 2;
     if constexpr (AF32) {
+      // (selecting between the two offset arrays per element - or per branch - was compiled into scratch-indexed
+      // loads on the address path; a masked delta keeps everything in registers)
+      const unsigned sel = main_seg ? 0xffffffffu : 0u;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        fa32[i] = *reinterpret_cast<const f32x4*>(ab + (main_seg ? faoff[i] : faoff2[i]));
+        fa32[i] = *reinterpret_cast<const f32x4*>(ab + (faoff2[i] + ((faoff[i] - faoff2[i]) & sel)));
     }
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) {
@@ -183,18 +186,32 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
       for (int i = 0; i < BI; ++i) rb[pl][i] = *reinterpret_cast<const u32x4*>(bb + pl * bplane + boff[i]);
     }
   };
-  auto store_slab = [&]() {
-    char* a = reinterpret_cast<char*>(As);
-    char* b = reinterpret_cast<char*>(Bs);
+  // AF32: the three-plane split of the freshly loaded activations runs right after a wave has issued its MFMAs of
+  // the current slab (the loads landed long ago; the VALU work overlaps the wave's own MFMA drain and the other
+  // waves' tails) instead of inside the barrier-to-barrier section, which is then only the LDS writes.
+  uint2 qs[3][4];
+  auto split_regs = [&]() {
     if constexpr (AF32) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         unsigned q1[2], q2[2], q3[2];
         split_pair(fa32[i][0], fa32[i][1], q1[0], q2[0], q3[0]);
         split_pair(fa32[i][2], fa32[i][3], q1[1], q2[1], q3[1]);
-        *reinterpret_cast<uint2*>(a + 0 * (BM * 64) + floff[i]) = uint2{q1[0], q1[1]};
-        *reinterpret_cast<uint2*>(a + 1 * (BM * 64) + floff[i]) = uint2{q2[0], q2[1]};
-        *reinterpret_cast<uint2*>(a + 2 * (BM * 64) + floff[i]) = uint2{q3[0], q3[1]};
+        qs[0][i] = uint2{q1[0], q1[1]};
+        qs[1][i] = uint2{q2[0], q2[1]};
+        qs[2][i] = uint2{q3[0], q3[1]};
+      }
+    }
+  };
+  auto store_slab = [&]() {
+    char* a = reinterpret_cast<char*>(As);
+    char* b = reinterpret_cast<char*>(Bs);
+    if constexpr (AF32) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<uint2*>(a + 0 * (BM * 64) + floff[i]) = qs[0][i];
+        *reinterpret_cast<uint2*>(a + 1 * (BM * 64) + floff[i]) = qs[1][i];
+        *reinterpret_cast<uint2*>(a + 2 * (BM * 64) + floff[i]) = qs[2][i];
       }
     }
 #pragma unroll
@@ -217,7 +234,10 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
                                             (row * 4 + (c ^ ((row >> 2) & 3))) * 16);
   };
 
-  if (nslab > 0) load_slab();
+  if (nslab > 0) {
+    load_slab();
+    split_regs();
+  }
   for (int s = 0; s < nslab; ++s) {
     if (s > 0) __syncthreads();
     store_slab();
@@ -233,17 +253,20 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[j][pl] = frag(Bs + pl * BN * 32, wn * WTN + j * 32 + fr, ks);
       }
-      // six partial products, smallest terms first (the dominant x1*w1 last); the four accumulators are
-      // interleaved so consecutive MFMAs never depend on each other
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+      // six partial products in plane-arrival order (planes are read 0, 1, 2: the first MFMAs start while the later
+      // fragments are still in flight; the running fp32 accumulator dwarfs every term of a slab, so adding the small
+      // terms first buys no accuracy); the four accumulators are interleaved so consecutive MFMAs never depend on
+      // each other
+      constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
 #pragma unroll
-      for (int q = (NPL == 3 ? 0 : 5); q < 6; ++q)
+      for (int q = 0; q < (NPL == 3 ? 6 : 1); ++q)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][PB[q]], fa[i][PA[q]], acc[i][j], 0, 0, 0);
     }
+    if (s + 1 < nslab) split_regs();
   }
 
   // epilogue: weights are the MFMA row operand -> D[channel][agent]; agent = lane&31,
