@@ -36,6 +36,9 @@ extern "C" {
                                      lrelu(a1.Wx_j + a2.Wx_i) without weight_bias, filter taps h[p,f,k,g] = filterWeight[0,k] * W[p,g,f]
                                      (transposed: the reference's permute+reshape, graphML.py:1967-1969).
                                      pack_weights: `taps` = filterWeight (E=1,K), `weight_bias` ignored. */
+#define MAGAT_MODE_GNN 3          /* no attention: GraphFilterBatch / BatchLSIGF (graphML.py:5485-5700), the GNN baseline:
+                                     z_k = z_{k-1} @ float(S), the edge weights are the GSO VALUES (CSR entry point only,
+                                     magat_gnn_forward_csr_f32; P = 1, taps = weight (F,1,K,G), no ReLU inside the layer) */
 
 int magat_abi_version(void);
 const char* magat_error_string(int code);
@@ -90,6 +93,15 @@ int magat_gat_forward_csr_f32(const float* X, const int* rowptr, const int* coli
                               const float* bias, float* Y, int ldy, float* att_opt, void* workspace,
                               size_t workspace_bytes, int B, int N, int G, int F, int K, int P, int mode, int concat,
                               void* stream);
+/* GraphFilterBatch.forward (graphML.py:5670-5689 -> BatchLSIGF :5485-5579), the non-attentional GNN baseline of the paper
+ * (SURVEY.md 8(f) row 2):  Y[n,f] = bias[f] + sum_k sum_g (x S^k)[g,n] h[f,0,k,g]  evaluated in the same Horner form on
+ * the CSR kernels, the edge weights being the GSO values vals[e] = float(S[b,i,j]) in CSR order (edges = entries with
+ * float(S) != 0: magat_gso_row_degrees / magat_gso_fill_csr with rule 2).  packed = magat_gat_pack_weights(weight = NULL,
+ * NULL, NULL, taps = weight (F,1,K,G), ..., P = 1, MAGAT_MODE_GNN).  F in {16,32,64,128,256}, G % 4 == 0, any N <= 8190.
+ * Workspace: magat_gat_csr_workspace_bytes(B, N, nnz, G, F, K, 1, MAGAT_MODE_GNN, 1). */
+int magat_gnn_forward_csr_f32(const float* X, const int* rowptr, const int* colidx, const float* vals, long long nnz,
+                              const float* packed, const float* bias, float* Y, int ldy, void* workspace,
+                              size_t workspace_bytes, int B, int N, int G, int F, int K, void* stream);
 /* bf16-STORAGE variant (BASELINE config 5: "1000 agents, CSR, bf16"; SURVEY.md 8(b) `..._csr_{f32,bf16}`): X, the hoisted
  * maps Z, the hop intermediates and Y are bf16 in HBM (raw uint16 bit patterns, RNE), all arithmetic accumulates in
  * fp32 (bf16 MFMA for the maps GEMM with the RNE-bf16 plane of the packed weights; fp32 scores / softmax / gathers),
@@ -144,7 +156,7 @@ int magat_sim_move(const float* logits, const int32_t* actions_in, const uint8_t
                    int32_t* flags_out, int B, int N, void* stream);
 
 /* dense GSO -> CSR in two steps (the caller prefix-sums the degrees in between): per-row edge counts, then column fill */
-int magat_gso_row_degrees(const void* S, int s_is_f64, int self_loops /*GAT_origin: S + I*/, int* deg /*B*N*/, int B,
+int magat_gso_row_degrees(const void* S, int s_is_f64, int self_loops /*edge rule: 0 |S|>1e-9, 1 GAT_origin |float(S)+I|>1e-9, 2 float(S)!=0*/, int* deg /*B*N*/, int B,
                           int N, void* stream);
 int magat_gso_fill_csr(const void* S, int s_is_f64, int self_loops, const int* rowstart /*B*N*/, int* colidx, int B,
                        int N, void* stream);

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("MAGAT_LIB_PATH") or os.path.join(PKG, "lib", "libmaga
 MODE_KEYQUERY = 0
 MODE_GAT_MODIFIED = 1
 MODE_GAT_ORIGIN = 2
+MODE_GNN = 3
 TAGS = {0: "untagged", 1: "conv_first", 2: "layer1.conv1", 3: "layer1.conv2+ds", 4: "layer2.conv1",
         5: "layer2.conv2+ds", 6: "layer3.conv1", 7: "layer3.conv2+ds", 8: "head(avgpool+fc+linear)",
         9: "compressMLP", 10: "gat_maps_gemm", 11: "gat_graph", 12: "actionsMLP", 13: "head_mean",
@@ -63,6 +64,7 @@ _SIGNATURES = {
     "magat_gat_forward_dense_f32": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_csr_workspace_bytes": (_Z, [_I, _I, ctypes.c_longlong] + [_I] * 6),
     "magat_gat_forward_csr_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
+    "magat_gnn_forward_csr_f32": (_I, [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P, _Z] + [_I] * 5 + [_P]),
     "magat_gat_csr_bf16_workspace_bytes": (_Z, [_I, _I, ctypes.c_longlong] + [_I] * 6),
     "magat_gat_forward_csr_bf16": (_I, [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_train_forward_f32": (_I, [_P, _P, _P, ctypes.c_longlong] + [_P] * 10 + [_I] * 7 + [_P]),

@@ -316,6 +316,8 @@ Layout layout(int G, int F, int K, int P, int mode) {   // must match pack_layou
   Layout L;
   if (mode == MAGAT_MODE_KEYQUERY) {
     L.qoff = 0; L.uoff = P * G; L.c1off = L.c2off = 0; L.NC = P * G + P * K * F;
+  } else if (mode == MAGAT_MODE_GNN) {
+    L.qoff = 0; L.uoff = 0; L.c1off = L.c2off = 0; L.NC = (P * K * F + 31) & ~31;
   } else {
     L.qoff = 0; L.uoff = 0; L.c1off = P * K * F; L.c2off = L.c1off + P; L.NC = (L.c2off + P + 31) & ~31;
   }
@@ -430,11 +432,14 @@ int csr_maps_gemm<u16>(const u16* X, const float* packed, u16* Z, int M, int G, 
 template <typename ST>
 int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz, const float* packed,
                 const float* bias, ST* Y, int ldy, float* att_opt, void* workspace, size_t workspace_bytes, int B,
-                int N, int G, int F, int K, int P, int mode, int concat, void* stream) {
+                int N, int G, int F, int K, int P, int mode, int concat, void* stream,
+                const float* edge_vals = nullptr) {
   if (!X || !rowptr || !packed || !Y || (nnz > 0 && !colidx)) return MAGAT_ERR_NULL;
   if (B <= 0 || N <= 0 || nnz < 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
-  if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GAT_ORIGIN) return MAGAT_ERR_UNSUPPORTED;
-  if (G != F || !(G == 16 || G == 32 || G == 64 || G == 128 || G == 256)) return MAGAT_ERR_UNSUPPORTED;
+  if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GNN) return MAGAT_ERR_UNSUPPORTED;
+  const bool gnn = mode == MAGAT_MODE_GNN;     // fixed edge weights (the GSO values) instead of attention
+  if (gnn && (P != 1 || (nnz > 0 && K > 1 && !edge_vals) || (G & 3))) return MAGAT_ERR_BAD_SHAPE;
+  if ((!gnn && G != F) || !(F == 16 || F == 32 || F == 64 || F == 128 || F == 256)) return MAGAT_ERR_UNSUPPORTED;
   if ((size_t)(2 * N + 2) * sizeof(int) > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;   // transpose LDS (N <= 8190)
   const int width = concat ? P * F : F;
   if (ldy < width || (ldy & 3)) return MAGAT_ERR_BAD_SHAPE;
@@ -448,7 +453,7 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
   int* cscptr = reinterpret_cast<int*>(ws + w.cscptr);
   int* cscsrc = reinterpret_cast<int*>(ws + w.cscsrc);
   int* cscpos = reinterpret_cast<int*>(ws + w.cscpos);
-  float* att = att_opt ? att_opt : reinterpret_cast<float*>(ws + w.att);
+  float* att = gnn ? const_cast<float*>(edge_vals) : (att_opt ? att_opt : reinterpret_cast<float*>(ws + w.att));
   ST* tbuf[2] = {reinterpret_cast<ST*>(ws + w.t0), reinterpret_cast<ST*>(ws + w.t1)};
   ST* Ytmp = reinterpret_cast<ST*>(ws + w.ytmp);
 
@@ -459,10 +464,10 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
   p.X = X; p.Z = Z; p.rowptr = rowptr; p.colidx = colidx; p.cscptr = cscptr; p.cscsrc = cscsrc; p.cscpos = cscpos;
   p.att = att; p.bias = bias; p.Y = concat ? Y : Ytmp; p.ldy = concat ? ldy : P * F;
   p.B = B; p.N = N; p.K = K; p.P = P; p.mode = mode; p.concat = concat; p.nnz = nnz;
-  p.act_relu = concat;
+  p.act_relu = gnn ? 0 : concat;        // GraphFilterBatch has no nonlinearity of its own
   p.NC = L.NC; p.qoff = L.qoff; p.uoff = L.uoff; p.c1off = L.c1off; p.c2off = L.c2off;
 
-  if (K == 1 && !att_opt) {
+  if (K == 1 && (!att_opt || gnn)) {
     MAGAT_CSR_DISPATCH(F, run_k1, ST)
     if (rc != MAGAT_OK) return rc;
   } else {
@@ -477,8 +482,10 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
       magat_prof_end(pid, st);
       if ((rc = magat_check_launch()) != MAGAT_OK) return rc;
     }
-    MAGAT_CSR_DISPATCH(G, run_scores, ST)
-    if (rc != MAGAT_OK) return rc;
+    if (!gnn) {
+      MAGAT_CSR_DISPATCH(G, run_scores, ST)
+      if (rc != MAGAT_OK) return rc;
+    }
     if (K == 1) {
       MAGAT_CSR_DISPATCH(F, run_k1, ST)
       if (rc != MAGAT_OK) return rc;
@@ -536,6 +543,14 @@ extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, cons
                             F, K, P, mode, concat, stream);
 }
 
+extern "C" int magat_gnn_forward_csr_f32(const float* X, const int* rowptr, const int* colidx, const float* vals,
+                                         long long nnz, const float* packed, const float* bias, float* Y, int ldy,
+                                         void* workspace, size_t workspace_bytes, int B, int N, int G, int F, int K,
+                                         void* stream) {
+  return csr_forward<float>(X, rowptr, colidx, nnz, packed, bias, Y, ldy, nullptr, workspace, workspace_bytes, B, N, G,
+                            F, K, 1, MAGAT_MODE_GNN, 1, stream, vals);
+}
+
 extern "C" int magat_gat_forward_csr_bf16(const uint16_t* X, const int* rowptr, const int* colidx, long long nnz,
                                           const float* packed, const float* bias, uint16_t* Y, int ldy,
                                           float* att_opt, void* workspace, size_t workspace_bytes, int B, int N, int G,
@@ -546,9 +561,11 @@ extern "C" int magat_gat_forward_csr_bf16(const uint16_t* X, const int* rowptr, 
 
 // Dense GSO -> CSR edge structure (|S| > 1e-9), two calls: count (rowptr via caller-side prefix) is avoided by
 // writing per-row degrees first.  deg [B*N] ints.
-// edge rule of the reference: |S| > 1e-9 in S's dtype; with self_loops (GAT_origin) |float(S) + delta_ij| > 1e-9f
+// edge rule of the reference: |S| > 1e-9 in S's dtype; rule 1 (GAT_origin) |float(S) + delta_ij| > 1e-9f; rule 2
+// (GraphFilterBatch multiplies by the values): float(S) != 0
 template <typename T>
 __device__ __forceinline__ bool gso_edge(T v, bool diag, int self_loops) {
+  if (self_loops == 2) return (float)v != 0.f;                          // GraphFilterBatch: every non-zero float(S)
   if (self_loops) return fabsf((float)v + (diag ? 1.f : 0.f)) > 1e-9f;
   return (v < 0 ? -v : v) > (T)1e-9;
 }

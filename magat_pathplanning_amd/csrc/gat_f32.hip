@@ -650,6 +650,11 @@ PackLayout pack_layout(int G, int F, int K, int P, int mode) {
     L.uoff = P * G;
     L.c1off = L.c2off = 0;
     L.NC = P * G + P * K * F;
+  } else if (mode == MAGAT_MODE_GNN) {     // filter taps only
+    L.qoff = 0;
+    L.uoff = 0;
+    L.c1off = L.c2off = 0;
+    L.NC = (P * K * F + 31) & ~31;
   } else {
     L.qoff = 0;
     L.uoff = 0;
@@ -692,7 +697,7 @@ __global__ void pack_kernel(const float* __restrict__ weight, const float* __res
         v = taps[k] * weight[((long long)hp * F + g) * G + f];
       else
         v = taps[(((long long)hp * F + f) * K + k) * G + g];  // (P,F,1,K,G)
-    } else if (mode != MAGAT_MODE_KEYQUERY && col >= L.c1off && col < L.c2off + P) {
+    } else if (mode != MAGAT_MODE_KEYQUERY && mode != MAGAT_MODE_GNN && col >= L.c1off && col < L.c2off + P) {
       const int which = col >= L.c2off, hp = which ? col - L.c2off : col - L.c1off;
       for (int f = 0; f < F; ++f)
         v = fmaf(mixer[(long long)hp * 2 * F + which * F + f], weight[((long long)hp * F + f) * G + g], v);
@@ -804,11 +809,11 @@ int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, in
 extern "C" int magat_gat_pack_weights(const float* weight, const float* weight_bias, const float* mixer,
                                       const float* taps, float* packed, int G, int F, int K, int P, int mode,
                                       void* stream) {
-  if (!weight || !taps || !packed) return MAGAT_ERR_NULL;
+  if ((!weight && mode != MAGAT_MODE_GNN) || !taps || !packed) return MAGAT_ERR_NULL;
   if (mode == MAGAT_MODE_GAT_MODIFIED && (!weight_bias || !mixer)) return MAGAT_ERR_NULL;
   if (mode == MAGAT_MODE_GAT_ORIGIN && !mixer) return MAGAT_ERR_NULL;
   if (G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
-  if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GAT_ORIGIN) return MAGAT_ERR_UNSUPPORTED;
+  if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GNN) return MAGAT_ERR_UNSUPPORTED;
   const PackLayout L = pack_layout(G, F, K, P, mode);
   const long long total = (long long)L.NC * (G + 1);
   int blocks = (int)((total + 255) / 256);

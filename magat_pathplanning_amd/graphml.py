@@ -61,7 +61,7 @@ def dense_gso_to_csr(S3, self_loops=False):
     with torch.cuda.device(dev):
         stream = nat.current_stream(dev)
         deg = torch.empty(B * N, dtype=torch.int32, device=dev)
-        sl = 1 if self_loops else 0
+        sl = int(self_loops)          # edge rule: 0 |S|>1e-9, 1 GAT_origin (S + I), 2 float(S) != 0 (GraphFilterBatch)
         nat.check(lib.magat_gso_row_degrees(nat.ptr(S3), f64, sl, nat.ptr(deg), B, N, stream), "magat_gso_row_degrees")
         ends = torch.cumsum(deg, 0, dtype=torch.int32)
         starts = (ends - deg).contiguous()
@@ -474,3 +474,101 @@ class GraphFilterBatchAttentional_Origin(GraphFilterBatchAttentional):
             self.filterWeight.uniform_(-stdv, stdv)
             if self.bias is not None:
                 self.bias.uniform_(-stdv, stdv)
+
+
+class GraphFilterBatch(nn.Module):
+    """Drop-in for the reference's non-attentional graph filter (graphML.py:5581-5700; BatchLSIGF :5485-5579), the GNN
+    baseline of the paper:  y = bias + sum_k (x S^k) h_k  with the GSO VALUES as edge weights (`x @ S.float()`), no
+    nonlinearity inside.  Parameters: weight (F,E,K,G), bias (F,1); init U(+-1/sqrt(G K)).  Inference on the HIP CSR kernels
+    (magat_gnn_forward_csr_f32); with autograd on, the torch composite below."""
+
+    def __init__(self, G, F, K, E=1, bias=True):
+        super().__init__()
+        if E != 1:
+            raise NotImplementedError("edge_features E=1 only")
+        self.G, self.F, self.K, self.E = G, F, K, E
+        self.S = None
+        self.weight = nn.Parameter(torch.empty(F, E, K, G))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(F, 1))
+        else:
+            self.register_parameter("bias", None)
+        self._scratch = _Scratch()
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.G * self.K)       # graphML.py:5654-5659
+        with torch.no_grad():
+            self.weight.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+    def addGSO(self, S):
+        assert len(S.shape) == 4 and S.shape[1] == self.E and S.shape[2] == S.shape[3]     # graphML.py:5661-5668
+        self.N = S.shape[2]
+        self.S = S
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_scratch"] = _Scratch()
+        return d
+
+    def forward(self, x):
+        B, Gin, Nin = x.shape
+        assert self.S is not None, "addGSO must be called before forward"
+        N = self.N
+        if Nin < N:
+            x = torch.cat((x, torch.zeros(B, Gin, N - Nin, dtype=x.dtype, device=x.device)), dim=2)
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            Sf = self.S.to(x.device)[:, 0].float()
+            z = x
+            y = torch.einsum("bgn,fg->bfn", z, self.weight[:, 0, 0])
+            for k in range(1, self.K):
+                z = torch.matmul(z, Sf)
+                y = y + torch.einsum("bgn,fg->bfn", z, self.weight[:, 0, k])
+            if self.bias is not None:
+                y = y + self.bias
+        else:
+            if not x.is_cuda:
+                raise nat.MagatNativeError("the HIP path needs device tensors; got %s (no CPU fallback)" % x.device)
+            lib = nat.lib()
+            dev = x.device
+            X = x.permute(0, 2, 1).contiguous().float()
+            S3 = self.S.reshape(B, N, N).to(dev)
+            if S3.dtype not in (torch.float32, torch.float64):
+                S3 = S3.float()
+            S3 = S3.contiguous()
+            rowptr, colidx, nnz = dense_gso_to_csr(S3, self_loops=2)          # rule 2: every non-zero float(S)
+            rp = rowptr.view(B, N + 1).long()
+            rows = torch.repeat_interleave(torch.arange(B * N, device=dev), (rp[:, 1:] - rp[:, :-1]).reshape(-1))
+            vals = S3.reshape(B * N, N)[rows, colidx[:nnz].long()].float().contiguous() if nnz else \
+                torch.zeros(1, dtype=torch.float32, device=dev)
+            sc = self._scratch
+            with torch.cuda.device(dev):
+                stream = nat.current_stream(dev)
+                key = _param_key(self.weight) + (str(dev),)
+                if sc.packed is None or sc.packed_key != key:
+                    nfl = lib.magat_gat_packed_floats(self.G, self.F, self.K, 1, nat.MODE_GNN)
+                    sc.packed = torch.empty(nfl, dtype=torch.float32, device=dev)
+                    w = self.weight.detach().to(dev, torch.float32).contiguous()
+                    nat.check(lib.magat_gat_pack_weights(None, None, None, nat.ptr(w), nat.ptr(sc.packed), self.G, self.F,
+                                                         self.K, 1, nat.MODE_GNN, stream), "magat_gat_pack_weights")
+                    sc.packed_key = key
+                need = lib.magat_gat_csr_workspace_bytes(B, N, nnz, self.G, self.F, self.K, 1, nat.MODE_GNN, 1)
+                if sc.workspace is None or sc.workspace.numel() < need or sc.workspace.device != dev:
+                    sc.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+                out = torch.empty(B * N, self.F, dtype=torch.float32, device=dev)
+                bias = None if self.bias is None else self.bias.detach().to(dev, torch.float32).reshape(-1).contiguous()
+                nat.check(lib.magat_gnn_forward_csr_f32(
+                    nat.ptr(X), nat.ptr(rowptr), nat.ptr(colidx), nat.ptr(vals), nnz, nat.ptr(sc.packed), nat.ptr(bias),
+                    nat.ptr(out), out.stride(0), nat.ptr(sc.workspace), sc.workspace.numel(), B, N, self.G, self.F,
+                    self.K, stream), "magat_gnn_forward_csr_f32")
+            y = out.view(B, N, self.F).permute(0, 2, 1)
+        if Nin < N:
+            y = y[:, :, :Nin]
+        return y
+
+    def extra_repr(self):
+        return "in_features=%d, out_features=%d, filter_taps=%d, edge_features=%d, bias=%s, GSO stored: %s" % (
+            self.G, self.F, self.K, self.E, self.bias is not None, self.S is not None)

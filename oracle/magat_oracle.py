@@ -214,6 +214,23 @@ def gat_layer_forward_bf16_storage(x, S4, p, mode="KeyQuery", concat=True):
     return y.permute(0, 2, 1), aij.unsqueeze(2)
 
 
+def graph_filter_batch_forward(x, S4, weight, bias=None):
+    """GraphFilterBatch.forward -> BatchLSIGF (graphML.py:5670-5689, 5485-5579), the non-attentional GNN baseline:
+    z_0 = x, z_k = z_{k-1} @ S.float() (:5562), y = cat_k(z_k) contracted with weight (F,E,K,G) (:5573-5574), + bias.
+    x (B,G,N) f32; S4 (B,1,N,N); returns (B,F,N)."""
+    B, G, N = x.shape
+    F, E, K, _ = weight.shape
+    Sf = S4.float()
+    xe = x.reshape(B, 1, G, N)
+    z = x.reshape(B, 1, 1, G, N).repeat(1, E, 1, 1, 1)
+    for _ in range(1, K):
+        xe = torch.matmul(xe, Sf)
+        z = torch.cat((z, xe.reshape(B, E, 1, G, N)), dim=2)
+    y = torch.matmul(z.permute(0, 4, 1, 2, 3).reshape(B, N, E * K * G), weight.reshape(F, E * K * G).permute(1, 0)).permute(0, 2, 1)
+    if bias is not None:
+        y = y + bias
+    return y
+
 # ------------------------------------------------- loop-level numpy cross-check
 def gat_layer_forward_loops(x, S4, p, mode="KeyQuery", concat=True):
     """Same layer, written edge-by-edge in float64 numpy straight from the formulas of

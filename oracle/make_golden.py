@@ -179,8 +179,34 @@ def main():
         print("wrote", path, os.path.getsize(path) // 1024, "KB")
 
 
+def main_gnn():
+    """GraphFilterBatch (non-attentional GNN baseline, graphML.py:5581-5700) fixtures, generated separately."""
+    gml, _ = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    for si, (N, G, F, K) in enumerate([(10, 128, 128, 2), (20, 128, 64, 3), (100, 32, 32, 3), (150, 64, 128, 4)]):
+        gen = torch.Generator().manual_seed(3337 + 11 * si)
+        torch.manual_seed(3337 + 11 * si)
+        layer = gml.GraphFilterBatch(G, F, K, 1, True)
+        B = 2
+        x = torch.randn(B, G, N, generator=gen) * 0.7
+        S = tricky_gso(gen, B, N, 0.3 if N <= 20 else 0.1, f64=(si % 2 == 0))
+        S[torch.isnan(S)] = 0.25                      # the GSO values are multiplied in: keep them finite
+        S = S.unsqueeze(1)
+        with torch.no_grad():
+            layer.addGSO(S)
+            y = layer(x)
+        out = dict(x=x.numpy(), S=S.numpy(), y=y.numpy(), N=N, G=G, F=F, K=K)
+        for k, v in layer.state_dict().items():
+            out["p_" + k] = v.numpy()
+        path = os.path.join(OUT, "gnn_N%d_G%d_F%d_K%d.npz" % (N, G, F, K))
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path) // 1024, "KB")
+
+
 if __name__ == "__main__":
-    if "--origin" in sys.argv:
+    if "--gnn" in sys.argv:
+        main_gnn()
+    elif "--origin" in sys.argv:
         main_origin()
     else:
         main()

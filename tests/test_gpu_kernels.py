@@ -460,3 +460,31 @@ def test_gat_module_bf16_storage_switch(gpu_device):
     scale = float(y_ref.abs().max())
     assert float((y.cpu() - y_emul).abs().max()) <= 2.0 ** -7 * scale
     assert float((y.cpu() - y_ref).abs().max()) <= 2e-2 * scale
+
+
+GNN_FIX = golden_paths("gnn_")
+
+
+@pytest.mark.parametrize("path", GNN_FIX, ids=[os.path.basename(p)[:-4] for p in GNN_FIX])
+def test_graph_filter_batch_vs_reference_golden(gpu_device, path):
+    """GraphFilterBatch (non-attentional GNN baseline) on the HIP CSR kernels against outputs of the
+    reference class: GSO VALUES as edge weights (incl. f64 GSOs, |S| < 1e-9 entries, asymmetric pairs, isolated nodes),
+    G != F, Nin < N zero padding."""
+    from magat_pathplanning_amd import GraphFilterBatch
+    z = np.load(path)
+    layer = GraphFilterBatch(int(z["G"]), int(z["F"]), int(z["K"]))
+    layer.load_state_dict({"weight": torch.from_numpy(z["p_weight"]), "bias": torch.from_numpy(z["p_bias"])})
+    layer = layer.to(gpu_device).eval()
+    x = torch.from_numpy(z["x"]).to(gpu_device)
+    layer.addGSO(torch.from_numpy(z["S"]).to(gpu_device))
+    with torch.no_grad():
+        y = layer(x)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(y.cpu().numpy(), z["y"], rtol=0, atol=1e-5)
+        nin = int(z["N"]) - 3
+        from oracle import magat_oracle as orc
+        xp = torch.cat((torch.from_numpy(z["x"])[:, :, :nin], torch.zeros(2, int(z["G"]), 3)), dim=2)
+        want = orc.graph_filter_batch_forward(xp, torch.from_numpy(z["S"]), torch.from_numpy(z["p_weight"]),
+                                              torch.from_numpy(z["p_bias"]))[:, :, :nin]
+        got = layer(x[:, :, :nin].contiguous())
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=1e-5)

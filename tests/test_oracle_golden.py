@@ -61,3 +61,18 @@ def test_init_state_dict_shapes_match_reference_fixture():
         assert set(mine) == set(sd), (path, set(mine) ^ set(sd))
         for k in sd:
             assert tuple(mine[k].shape) == tuple(sd[k].shape), (path, k)
+
+
+GNN = golden_paths("gnn_")
+
+
+def test_gnn_fixture_inventory():
+    assert len(GNN) == 4
+
+
+@pytest.mark.parametrize("path", GNN, ids=[os.path.basename(p)[:-4] for p in GNN])
+def test_graph_filter_batch_oracle_matches_reference(path):
+    z = np.load(path)
+    y = orc.graph_filter_batch_forward(torch.from_numpy(z["x"]), torch.from_numpy(z["S"]), torch.from_numpy(z["p_weight"]),
+                                       torch.from_numpy(z["p_bias"]))
+    np.testing.assert_allclose(y.numpy(), z["y"], rtol=0, atol=2e-6)
