@@ -1,3 +1,5 @@
+// Stand-alone check that gfx950 executes the LDS-direct load (global_load_lds_dwordx4, M0 = LDS byte base, lane i -> +16 i)
+// as gat_f32.hip uses it.  Build: hipcc --offload-arch=gfx950 -O3 tools/exp/ldsdma_test.hip -o tools/exp/ldsdma_test; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
