@@ -296,9 +296,11 @@ __global__ void gat_dense_kernel(const GatParams p) {
   const bool first_head = hh == 0 && bl == bl0;
   if (WIDE && first_head) load_urows(ucur, K > 1 ? K - 2 : 0);
   if constexpr (WIDE) {
-    // Q tile (prefetched during the previous head's last hop, or above) is in Rq once every wave's loads are done;
-    // the same barrier retires the previous head's reads of Ru and A
-    tiles_landed();
+    // Q tile (prefetched during the previous head's last hop, or above) is in Rq once every wave's loads are done
+    // (waited for at the end of that hop; only a workgroup's very first head waits here); the barrier also retires
+    // the previous head's reads of Ru and A
+    if (first_head || p.skip) tiles_landed();
+    else __syncthreads();
     if ((hh > 0 || bl != bl0) && keyquery && need_att && K > 1)
       dma_tile(Ru, Zb, p.uoff + (head * K + (K - 1)) * F, tl);
   } else {
@@ -333,16 +335,27 @@ __global__ void gat_dense_kernel(const GatParams p) {
         float* Arow = A + ir * p.lda_a;
         const uint4 mk = *reinterpret_cast<const uint4*>(rmask + 4 * ir);
         unsigned w[4] = {iok ? mk.x : 0u, iok ? mk.y : 0u, iok ? mk.z : 0u, iok ? mk.w : 0u};
+        // compact softmax state: edge number e of the row is kept by lane (e & 7) of the group in slot e >> 3 (rows of
+        // up to 16 edges); sc / sj = score and neighbour index of the lane's two slots
+        float sc0 = -__builtin_inff(), sc1 = -__builtin_inff();
+        int sj0 = 0, sj1 = 0, ecount = 0;
         if (keyquery) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            unsigned ww = w[r];
-            while (ww) {          // two edges of this row per trip: both neighbour rows in flight together
-              const int j0 = 32 * r + __builtin_ctz(ww);
-              ww &= ww - 1;
-              const bool two = ww != 0;
-              const int j1 = two ? 32 * r + __builtin_ctz(ww) : j0;
-              ww &= ww - 1;
+          // one walk over the whole 128-bit edge mask (two 64-bit halves), two edges of this row per trip (both
+          // neighbour rows in flight together): the wave runs max over its 8 rows of ceil(degree / 2) trips - walking
+          // the four 32-bit words one after the other cost the sum over words of the per-word maxima, about twice that
+          unsigned long long ma = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+          unsigned long long mb = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32);
+          {
+            while (ma | mb) {
+              int j0;
+              if (ma) { j0 = __builtin_ctzll(ma); ma &= ma - 1; }
+              else { j0 = 64 + __builtin_ctzll(mb); mb &= mb - 1; }
+              const bool two = (ma | mb) != 0;
+              int j1 = j0;
+              if (two) {
+                if (ma) { j1 = __builtin_ctzll(ma); ma &= ma - 1; }
+                else { j1 = 64 + __builtin_ctzll(mb); mb &= mb - 1; }
+              }
               // packed fp32 FMAs (v_pk_fma_f32): even / odd elements accumulate separately, summed at the end
               f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f};
 #pragma unroll
@@ -357,13 +370,39 @@ __global__ void gat_dense_kernel(const GatParams p) {
               }
               float d0 = oct_sum(p0[0] + p0[1]);
               float d1 = oct_sum(p1[0] + p1[1]);
-              if (es == 0) {
+              if (es == 0) {        // raw scores for the dense (fallback) softmax below
                 Arow[j0] = d0;
                 if (two) Arow[j1] = d1;
+              }
+              {
+                const bool mine = (ecount & 7) == es, hi = ecount >= 8;
+                if (mine && !hi) { sc0 = d0; sj0 = j0; }
+                if (mine && hi) { sc1 = d0; sj1 = j0; }
+                const int e1 = ecount + 1;
+                const bool mine1 = two && (e1 & 7) == es, hi1 = e1 >= 8;
+                if (mine1 && !hi1) { sc0 = d1; sj0 = j1; }
+                if (mine1 && hi1) { sc1 = d1; sj1 = j1; }
+                ecount += two ? 2 : 1;
               }
             }
           }
           __builtin_amdgcn_wave_barrier();
+        }
+        // Compact softmax (KeyQuery, every row of the wave has <= 16 edges, attention not exported): max / sum over the
+        // <= 2 scores per lane, written to the edge positions only.  The zero entries of the row are written once per
+        // instance (first head): every head of an instance has the same edge positions.  ~40 VALU ops instead of ~350.
+        if (keyquery && !p.A_opt && !__any(ecount > 16)) {
+          const float mxc = oct_max(fmaxf(sc0, sc1));
+          const float e0 = sc0 > -__builtin_inff() ? __expf(sc0 - mxc) : 0.f;
+          const float e1 = sc1 > -__builtin_inff() ? __expf(sc1 - mxc) : 0.f;
+          const float sm = oct_sum(e0 + e1);
+          const float invc = sm > 0.f ? 1.f / sm : 0.f;
+          if (hh == 0 && iok) {
+            for (int j = es; j < N; j += 8) Arow[j] = 0.f;
+          }
+          if (sc0 > -__builtin_inff()) Arow[sj0] = e0 * invc;
+          if (sc1 > -__builtin_inff()) Arow[sj1] = e1 * invc;
+          continue;
         }
         // masked softmax, lane = neighbour slot j = es + 8*r.  Branch-free: all 16 slots are read back to back
         // (one LDS wait instead of sixteen predicated read+wait blocks) and selected by the edge bits afterwards;
@@ -570,10 +609,20 @@ __global__ void gat_dense_kernel(const GatParams p) {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) res[e] = fmaxf(res[e], 0.f);
         }
-        *reinterpret_cast<fvec*>(yrow + h * ystep) = res;
+        if constexpr (WIDE) ucur[h] = res;      // stored after the tile wait below
+        else *reinterpret_cast<fvec*>(yrow + h * ystep) = res;
       } else {
         *reinterpret_cast<fvec*>(Rnew_ + j * F + VEC * sub) = res;
       }
+    }
+    if constexpr (last && WIDE) {
+      // The prefetched tile is waited for HERE, while the only outstanding requests are its LDS-direct loads (they had
+      // the whole hop to land), and the Y rows are stored afterwards: a wait at the next head's top would also cover
+      // these stores' write acknowledgements (loads and stores share vmcnt) - 5-7 k cycles per head.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int h = 0; h < HMAX; ++h)
+        if ((ws + h * nwaves) * rpw + grp < N) *reinterpret_cast<fvec*>(yrow + h * ystep) = ucur[h];
     }
   };
   if (!(p.skip & 2)) {
