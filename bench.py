@@ -50,7 +50,7 @@ def valid_taps(hin, hout, stride, k=3, pad=1):
 def split_tags(cfg):
     """Kernel tags that run on the bf16x6 split-MFMA kernel with the library's defaults (MAGAT_CONV_SPLIT mask,
     MAGAT_GAT_SPLIT), mirroring csrc/encoder_f32.hip::enc_split_mask and csrc/gat_f32.hip::gat_maps_gemm."""
-    mask = int(os.environ.get("MAGAT_CONV_SPLIT", "6"))
+    mask = int(os.environ.get("MAGAT_CONV_SPLIT", "7"))
     tags = set()
     for l in range(3):
         if mask >> l & 1:

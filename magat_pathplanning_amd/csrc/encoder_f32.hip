@@ -167,13 +167,14 @@ static int conv_first_launch(const float* x, const float* wt, const float* bias,
 }
 
 // Block convolutions on the bf16x6 split-MFMA kernel (split weights in the pack).  MAGAT_CONV_SPLIT = bit mask of
-// BasicBlocks that use it (bit l = layer l+1); default 6 = layers 2 and 3 (layer 1, Cin = Cout = 32, is a wash:
-// 360 vs 348 us and 322 vs 328 us on MI355X); 0 keeps every layer on the fp32 MFMA kernel.
+// BasicBlocks that use it (bit l = layer l+1); default 7 = all three (layer 1, Cin = Cout = 32 on the 128x32 tiles,
+// used to be a wash; since the activation split left the barrier section it wins: 351 -> 305 us and 342 -> 264 us);
+// 0 keeps every layer on the fp32 MFMA kernel.
 static int enc_split_mask(const magat_encoder_desc* d) {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("MAGAT_CONV_SPLIT");
-    v = e ? atoi(e) : 6;
+    v = e ? atoi(e) : 7;
   }
   int m = 0;
   for (int l = 0; l < 3; ++l)
