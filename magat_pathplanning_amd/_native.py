@@ -127,3 +127,16 @@ def ptr(t):
 def current_stream(device):
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def torch_composite_allowed():
+    """The differentiable torch composites of the graph layers (same algebra as the pinned oracle) exist so that host-side
+    tests can check state_dict / autograd semantics without a GPU.  They are NOT a product path: on CPU tensors they run
+    only when MAGAT_ALLOW_TORCH_COMPOSITE=1 (tests/conftest.py sets it); otherwise the modules fail loudly."""
+    return os.environ.get("MAGAT_ALLOW_TORCH_COMPOSITE", "0") == "1"
+
+
+def require_device_or_composite(t, what):
+    if not t.is_cuda and not torch_composite_allowed():
+        raise MagatNativeError("%s: CPU tensors are not supported (no CPU fallback); the torch composite used by the host "
+                               "tests needs MAGAT_ALLOW_TORCH_COMPOSITE=1" % what)

@@ -411,6 +411,7 @@ class GraphFilterBatchAttentional(nn.Module):
                 y = torch.relu(Yh.mean(dim=2)).permute(0, 2, 1)
             self.aij = None
         elif needs_grad:
+            nat.require_device_or_composite(x, "GraphFilterBatchAttentional under autograd")
             y, aij = _composite(self, x, self.S.to(x.device))
             self.aij = aij.detach() if self.return_attention else None
         else:
@@ -521,6 +522,7 @@ class GraphFilterBatch(nn.Module):
             x = torch.cat((x, torch.zeros(B, Gin, N - Nin, dtype=x.dtype, device=x.device)), dim=2)
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad:
+            nat.require_device_or_composite(x, "GraphFilterBatch under autograd")
             Sf = self.S.to(x.device)[:, 0].float()
             z = x
             y = torch.einsum("bgn,fg->bfn", z, self.weight[:, 0, 0])

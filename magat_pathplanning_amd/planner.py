@@ -172,6 +172,7 @@ class DecentralPlannerGATNet(nn.Module):
             raise TypeError("addGSO must be called before forward")
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if needs_grad or self.training:
+            nat.require_device_or_composite(x, "DecentralPlannerGATNet in training / autograd mode")
             return self._forward_autograd(x, B, N)
         return self._forward_hip(x, B, N)
 

@@ -1,5 +1,9 @@
 import glob
 import os
+
+# host-side tests exercise the differentiable torch composites on CPU tensors (state_dict / autograd semantics without a
+# GPU); the product refuses CPU tensors unless this is set (see _native.torch_composite_allowed)
+os.environ.setdefault("MAGAT_ALLOW_TORCH_COMPOSITE", "1")
 import sys
 import types
 
