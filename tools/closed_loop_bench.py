@@ -1,0 +1,53 @@
+"""Closed loop entirely on the device: per step  GSO construction -> FOV state tensors -> addGSO + forward -> action decode +
+collision shielding + position update, for B independent planning instances (what the reference does per instance on the
+host around a batch-1 forward: agents/decentralplannerlocal_OnlineExpert_GAT.py:880-905 -> utils/new_simulator.py).
+Reports agent-steps/s of the whole loop next to the forward alone."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from magat_pathplanning_amd import DecentralPlannerGATNet
+from magat_pathplanning_amd.simulator import batched_fov_states, batched_gso, batched_move
+from magat_pathplanning_amd.synthetic import make_config
+
+B, N, size, T = (int(a) for a in (sys.argv[1:5] + ["512", "100", "50", "20"][len(sys.argv) - 1:]))
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(3)
+m = (rng.random((size, size)) < 0.08).astype(np.uint8)
+free = np.argwhere(m == 0)
+pos = np.stack([free[rng.permutation(len(free))[:N]] for _ in range(B)]).astype(np.int32)
+goal = np.stack([free[rng.permutation(len(free))[:N]] for _ in range(B)]).astype(np.int32)
+dm, dpos, dgoal = torch.from_numpy(m).to(dev), torch.from_numpy(pos).to(dev).contiguous(), torch.from_numpy(goal).to(dev)
+cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat", device=str(dev))
+torch.manual_seed(0)
+net = DecentralPlannerGATNet(cfg).to(dev).eval()
+
+
+def step():
+    with torch.no_grad():
+        net.addGSO(batched_gso(dpos, 7.0))
+        logits = net(batched_fov_states(dm, dpos, dgoal, 9))
+    return batched_move(dm, dpos, logits=logits, goal=dgoal)
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(T):
+    out = step()
+torch.cuda.synchronize()
+loop = (time.perf_counter() - t0) / T
+x = batched_fov_states(dm, dpos, dgoal, 9)
+S = batched_gso(dpos, 7.0)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+with torch.no_grad():
+    for _ in range(T):
+        net.addGSO(S)
+        net(x)
+torch.cuda.synchronize()
+fwd = (time.perf_counter() - t0) / T
+print("B %d N %d map %dx%d: closed loop %.3f ms/step = %.2f M agent-steps/s   (forward alone %.3f ms = %.2f M; front/back end %.3f ms)"
+      % (B, N, size, size, loop * 1e3, B * N / loop / 1e6, fwd * 1e3, B * N / fwd / 1e6, (loop - fwd) * 1e3))
+print("reached goals after %d random-policy steps: %d of %d agents" % (T + 3, int(out["reached"].sum()), B * N))
