@@ -488,3 +488,32 @@ def test_graph_filter_batch_vs_reference_golden(gpu_device, path):
                                               torch.from_numpy(z["p_bias"]))[:, :, :nin]
         got = layer(x[:, :, :nin].contiguous())
         np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_persistent_dense_kernel_vs_csr_randomised(gpu_device, seed):
+    """The persistent dense kernel (workgroups walking instances and heads with LDS-direct prefetch) against the
+    independent CSR kernels on random shapes / densities / modes, plus run-to-run bit determinism: a race or a
+    prefetch-ordering bug would show up here (tools/gat_stress.py is the long version)."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin
+    from magat_pathplanning_amd.graphml import dense_gso_to_csr, gat_forward_rows, gat_forward_rows_csr
+    from magat_pathplanning_amd.synthetic import comm_gso, random_gso
+    rng = np.random.default_rng(seed)
+    for it in range(6):
+        mode = ["KeyQuery", "GAT_modified", "GAT_origin"][int(rng.integers(0, 3))]
+        G, N = int(rng.choice([64, 128])), int(rng.integers(40, 129))
+        K, P, B = int(rng.integers(1, 5)), int(rng.choice([1, 2, 4])), int(rng.choice([8, 260, 300]))
+        concat = bool(rng.integers(0, 2))
+        cls = GraphFilterBatchAttentional_Origin if mode == "GAT_origin" else GraphFilterBatchAttentional
+        layer = cls(G, G, K, P, concatenate=concat, attentionMode=mode).to(gpu_device).eval()
+        X = torch.randn(B, N, G, device=gpu_device) * 0.6
+        S = (comm_gso(B, N, int(6 * N ** 0.5), seed=int(rng.integers(1 << 30))) if it % 2 else
+             random_gso(B, N, float(rng.choice([0.03, 0.3, 1.0])), seed=int(rng.integers(1 << 30)))).to(gpu_device)
+        with torch.no_grad():
+            ya = gat_forward_rows(X, S, layer)[0].clone()
+            yb = gat_forward_rows(X, S, layer)[0].clone()
+            rowptr, colidx, nnz = dense_gso_to_csr(S.contiguous(), self_loops=mode == "GAT_origin")
+            yc = gat_forward_rows_csr(X, rowptr, colidx, nnz, layer)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb), (mode, B, N, G, K, P)
+        assert float((ya - yc).abs().max()) <= 5e-5 * max(1.0, float(yc.abs().max())), (mode, B, N, G, K, P, concat)
