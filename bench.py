@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_F32_TFLOPS = 157.3    # fp32 MFMA (v_mfma_f32_32x32x2_f32) = fp32 vector peak
-PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); the bf16x6 kernels issue 6 bf16 MFMA flops per fp32 flop
+PEAK_BF16_TFLOPS = 2500.0  # dense 16-bit MFMA (v_mfma_f32_32x32x16_{f16,bf16}); f16x3 issues 3, bf16x6 6 such flops per fp32 flop
 
 WORKLOADS = {
     # name: (B per GPU, N, map_w, K, P, G, bottleneckMode, CNN_mode, concat)
@@ -226,8 +226,8 @@ def main():
                "dtype": "f32" if cfg.gat_storage == "fp32" else "f32 arithmetic, bf16 storage inside the GAT layer",
                "data": "synthetic (seeded binary FOV states + comm-radius GSO; random-init weights, BN stats perturbed)",
                "config": {"precision": "float32 in / float32 out, logits within 1e-4 of the reference (observed 1e-6); dense maps on "
-                                       "fp32 MFMA or bf16x6 split products (3 bf16 planes per value, 6 bf16 MFMAs per product, "
-                                       "fp32 accumulate: fp32-equivalent accuracy)",
+                                       "fp32 MFMA or f16x3 split products (2 f16 planes per value = 22 significand bits, 3 f16 "
+                                       "MFMAs per product, fp32 accumulate: measured error vs float64 equal to the fp32 MFMA kernel)",
                           "workload": "%s: N=%d agents, %dx%d map, K=%d, P=%d, F=%d, %s, %s, KeyQuery, %s; batch %d per GPU "
                                       "(global %d); resident inputs, addGSO+forward per step"
                                       % (args.workload, N, map_w, map_w, K, P, G, bmode, cnn,
@@ -250,12 +250,15 @@ def main():
                 if tag in work and sec > 0:
                     fl, by, bound = work[tag]
                     if bound == "mfma" and tag in splits:
-                        # bf16x6: every fp32 multiply-add is six bf16 MFMA multiply-adds; price the kernel against
-                        # the bf16 matrix peak with the flops it actually issues, and keep the fp32-equivalent rate
-                        ach = 6 * fl * agent_steps / sec / 1e12
-                        ent.update(bound="mfma", mfma_dtype="bf16 (bf16x6 split, f32 accumulate)", achieved=round(ach, 1),
+                        # split-MFMA kernels: every fp32 multiply-add is issued as three f16 (f16x3, the default) or
+                        # six bf16 (bf16x6, MAGAT_CONV_F16=0) matrix-core multiply-adds; price the kernel against the
+                        # 16-bit matrix peak with the flops it actually issues, and keep the fp32-equivalent rate
+                        nprod = 3 if int(os.environ.get("MAGAT_CONV_F16", "1")) else 6
+                        ach = nprod * fl * agent_steps / sec / 1e12
+                        ent.update(bound="mfma", mfma_dtype="f16 (f16x3 split, f32 accumulate)" if nprod == 3 else
+                                   "bf16 (bf16x6 split, f32 accumulate)", achieved=round(ach, 1),
                                    peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                                   f32_equiv_tflops=round(ach / 6, 2), flops_per_agent_step=fl)
+                                   f32_equiv_tflops=round(ach / nprod, 2), flops_per_agent_step=fl)
                     elif bound == "mfma":
                         ach = fl * agent_steps / sec / 1e12
                         ent.update(bound="mfma", mfma_dtype="f32", achieved=round(ach, 2), peak=PEAK_F32_TFLOPS,

@@ -201,7 +201,11 @@ typedef struct magat_conv_gemm_desc {
    * Cout*Ktot apart).  in_fmt = 2: same kernel, but in / in2 stay float32 in memory and are split into their three
    * planes by the loader on the way into LDS (wt still bf16x3).  out_fmt = 1 makes the epilogue emit the 3-plane
    * form.  in_fmt = 3: in, in2 and wt are ONE bf16 plane each (plain bf16 GEMM, fp32 accumulate); out_fmt = 2: the
-   * epilogue emits one RNE bf16 plane.  Formats 1-3 need Cin, C2, Cout % 32 == 0 and no pooling. */
+   * epilogue emits one RNE bf16 plane.  in_fmt = 4 ("f16x3"): in / in2 float32, split by the loader into TWO f16 planes
+   * (22 significand bits; activations beyond +-1.3e5 would saturate); wt = [2][Cout][Ktot] f16 planes of (weight * 2^e)
+   * followed by one float32 2^-e (applied to the accumulator before the bias); three f16 MFMAs per product (the
+   * dropped plane-2 x plane-2 term is <= 2^-22 relative) - twice the matrix-core rate of the bf16x6 form at the same
+   * measured accuracy.  Formats 1-4 need Cin, C2, Cout % 32 == 0 and no pooling. */
   int in_fmt, out_fmt;
   int64_t in_plane_stride, in2_plane_stride, out_plane_stride;
   /* Agent-tile strides (elements).  Row m of a pixel lives at  (m / 128) * tile_stride + (m % 128) * ld.

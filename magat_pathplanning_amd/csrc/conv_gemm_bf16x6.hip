@@ -18,6 +18,8 @@
 #include "magat_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -39,6 +41,7 @@ struct SplitParams {
   int C2, lda2, W2, stride2;
   int Cout, Ktot, ldc, relu;
   int ntn, npix, tag, out_split;
+  const float* acc_scale;   // NPL == 2: device pointer to 1 / (power-of-two weight scale), applied before the bias
 };
 
 __device__ __forceinline__ u16 bf16_rne(float v) { return magat_bf16_rne(v); }
@@ -59,6 +62,21 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned& p1, unsig
   p3 = cvt_pk_bf16(sx, sy);
 }
 
+// fp16x2 split ("f16x3": x ~ h1 + h2, two RNE half planes = 22 significand bits; the product keeps h1g1 + h1g2 + h2g1,
+// dropping h2g2 <= 2^-22 |xw|): THREE v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones.  fp16 has the
+// narrow exponent, so activations are clamped to +-65504 per plane (values up to 1.3e5 stay exact through the second
+// plane; larger ones saturate - unreachable for this network) and residuals below 6e-5 go subnormal (absolute error
+// <= 3e-8, the fp32 spacing of values near 0.5); weights are pre-scaled by a power of two so that both planes are
+// normal numbers (the scale is undone in the epilogue).
+__device__ __forceinline__ void split_pair_f16(float x, float y, unsigned& p1, unsigned& p2) {
+  x = __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f);
+  y = __builtin_fminf(__builtin_fmaxf(y, -65504.f), 65504.f);
+  const f16x2 h = __builtin_convertvector(f32x2{x, y}, f16x2);
+  const f16x2 r = __builtin_convertvector(f32x2{x - (float)h[0], y - (float)h[1]}, f16x2);
+  p1 = __builtin_bit_cast(unsigned, h);
+  p2 = __builtin_bit_cast(unsigned, r);
+}
+
 // AF32: the activation operands (in, in2) are plain float32 and are split into their three bf16 planes by the
 // loader on the way into LDS (no 3-plane tensors in HBM, 2/3 of the activation traffic); weights are always
 // pre-split bf16x3.
@@ -67,7 +85,7 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned& p1, unsig
 // weights, one product) - the bf16 variant of the GAT maps GEMM for BASELINE config 5.
 template <bool AF32, int BN, int WGM, int WGN, int NPL = 3>
 __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitParams p) {
-  static_assert(NPL == 3 || (NPL == 1 && !AF32), "plane count");
+  static_assert(NPL == 3 || (NPL == 1 && !AF32) || (NPL == 2 && AF32), "plane count");
   constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 32, TN = WTN / 32;
   constexpr int BI = BN >= 64 ? BN / 64 : 1;      // weight-tile 16-byte loads per thread and plane
   __shared__ __attribute__((aligned(16))) u16 lds[NPL * (BM + BN) * 32];   // A planes | B planes
@@ -189,9 +207,9 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
   // AF32: the three-plane split of the freshly loaded activations runs right after a wave has issued its MFMAs of
   // the current slab (the loads landed long ago; the VALU work overlaps the wave's own MFMA drain and the other
   // waves' tails) instead of inside the barrier-to-barrier section, which is then only the LDS writes.
-  uint2 qs[3][4];
+  uint2 qs[NPL][4];
   auto split_regs = [&]() {
-    if constexpr (AF32) {
+    if constexpr (AF32 && NPL == 3) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         unsigned q1[2], q2[2], q3[2];
@@ -201,6 +219,15 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
         qs[1][i] = uint2{q2[0], q2[1]};
         qs[2][i] = uint2{q3[0], q3[1]};
       }
+    } else if constexpr (AF32 && NPL == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned q1[2], q2[2];
+        split_pair_f16(fa32[i][0], fa32[i][1], q1[0], q2[0]);
+        split_pair_f16(fa32[i][2], fa32[i][3], q1[1], q2[1]);
+        qs[0][i] = uint2{q1[0], q1[1]};
+        qs[1][i] = uint2{q2[0], q2[1]};
+      }
     }
   };
   auto store_slab = [&]() {
@@ -208,11 +235,9 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
     char* b = reinterpret_cast<char*>(Bs);
     if constexpr (AF32) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<uint2*>(a + 0 * (BM * 64) + floff[i]) = qs[0][i];
-        *reinterpret_cast<uint2*>(a + 1 * (BM * 64) + floff[i]) = qs[1][i];
-        *reinterpret_cast<uint2*>(a + 2 * (BM * 64) + floff[i]) = qs[2][i];
-      }
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(a + pl * (BM * 64) + floff[i]) = qs[pl][i];
     }
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) {
@@ -228,9 +253,9 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 
   // fragment addressing: row = tile row (lane&31), k chunk c = 2*s + (lane>>5)
   const int fr = lane & 31, fh = lane >> 5;
-  auto frag = [&](const u16* base, int row, int s) -> bf16x8 {
+  auto frag = [&](const u16* base, int row, int s) -> u32x4 {
     const int c = 2 * s + fh;
-    return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(base) +
+    return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) +
                                             (row * 4 + (c ^ ((row >> 2) & 3))) * 16);
   };
 
@@ -245,7 +270,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
     if (s + 1 < nslab) load_slab();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[TM][NPL], fb[TN][NPL];
+      u32x4 fa[TM][NPL], fb[TN][NPL];          // 8 packed 16-bit elements each (bf16 or f16 bits)
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
@@ -253,19 +278,27 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[j][pl] = frag(Bs + pl * BN * 32, wn * WTN + j * 32 + fr, ks);
       }
-      // six partial products in plane-arrival order (planes are read 0, 1, 2: the first MFMAs start while the later
+      // partial products in plane-arrival order (planes are read 0, 1, 2: the first MFMAs start while the later
       // fragments are still in flight; the running fp32 accumulator dwarfs every term of a slab, so adding the small
       // terms first buys no accuracy); the four accumulators are interleaved so consecutive MFMAs never depend on
       // each other.  (Tried without gain: s_setprio(1) around the MFMA cluster (3 % slower); reading both k-steps'
       // fragments before the first MFMA (the scheduler sinks the loads back, same 164 VGPRs, same time).)
+      //   NPL 3 (bf16x6): x1w1 x1w2 x2w1 x2w2 x1w3 x3w1      NPL 2 (f16x3): h1g1 h1g2 h2g1      NPL 1: one product
+      constexpr int NPROD = NPL == 3 ? 6 : (NPL == 2 ? 3 : 1);
       constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
 #pragma unroll
-      for (int q = 0; q < (NPL == 3 ? 6 : 1); ++q)
+      for (int q = 0; q < NPROD; ++q)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][PB[q]], fa[i][PA[q]], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) {
+            if constexpr (NPL == 2)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j][PB[q]]),
+                                                                 __builtin_bit_cast(f16x8, fa[i][PA[q]]), acc[i][j], 0, 0, 0);
+            else
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[j][PB[q]]),
+                                                                  __builtin_bit_cast(bf16x8, fa[i][PA[q]]), acc[i][j], 0, 0, 0);
+          }
     }
     if (s + 1 < nslab) split_regs();
   }
@@ -273,6 +306,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
   // epilogue: weights are the MFMA row operand -> D[channel][agent]; agent = lane&31,
   // channel = (r&3) + 8*(r>>2) + 4*(lane>>5): four consecutive channels per register quad -> wide stores
   const bool vec = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (p.out_plane & 3) == 0;
+  float acc_scale = 1.f;
+  if constexpr (NPL == 2) acc_scale = *p.acc_scale;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nb = n0 + wn * WTN + j * 32 + 4 * (lane >> 5);
@@ -286,7 +321,9 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
         float v[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          v[c] = acc[i][j][4 * q + c] + (p.bias ? p.bias[n + c] : 0.f);
+          float av = acc[i][j][4 * q + c];
+          if constexpr (NPL == 2) av *= acc_scale;
+          v[c] = av + (p.bias ? p.bias[n + c] : 0.f);
           if (p.relu) v[c] = fmaxf(v[c], 0.f);
         }
         const long long o = (long long)pix * p.out_pix_stride + magat_row_off(m, p.ldc, p.out_tile) + n;
@@ -334,6 +371,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 
 }  // namespace
 
+// in_fmt 4: in/in2 float32 split on load into two f16 planes, wt = [2][Cout][Ktot] f16 planes of (weight * 2^e) followed
+// by one float32 2^-e ("f16x3": three f16 MFMAs per product).
 // in_fmt 1: in/in2/wt all bf16x3 planes; in_fmt 2: in/in2 float32 (split on load), wt bf16x3 planes; in_fmt 3: in/in2/wt
 // ONE bf16 plane each (plain bf16 GEMM, fp32 accumulate).  out_fmt 0 f32, 1 bf16x3 planes, 2 one bf16 plane.
 // Cout % 32 == 0, Cin % 32 == 0, C2 % 32 == 0, lda/lda2 % 8 == 0.
@@ -343,7 +382,8 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   const int BN = d->Cout % 128 == 0 ? 128 : (d->Cout % 64 == 0 ? 64 : 32);
   if ((d->Cout % BN) || (d->Cin % BK) || (d->C2 % BK) || (d->lda % 8) || (d->C2 > 0 && (d->lda2 % 8)) || d->pool)
     return MAGAT_ERR_UNSUPPORTED;
-  if (d->in_fmt < 1 || d->in_fmt > 3 || d->out_fmt < 0 || d->out_fmt > 2) return MAGAT_ERR_UNSUPPORTED;
+  if (d->in_fmt < 1 || d->in_fmt > 4 || d->out_fmt < 0 || d->out_fmt > 2) return MAGAT_ERR_UNSUPPORTED;
+  if (d->in_fmt == 4 && d->out_fmt != 0) return MAGAT_ERR_UNSUPPORTED;
   SplitParams p;
   p.in = static_cast<const u16*>(static_cast<const void*>(d->in));
   p.in2 = static_cast<const u16*>(static_cast<const void*>(d->in2));
@@ -373,10 +413,15 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
   const int pid = magat_prof_begin(p.tag, st);
   const bool af32 = d->in_fmt == 2;
+  // f16x3 (in_fmt 4): wt = [2][Cout][Ktot] f16 bits followed by one float32 = 1 / weight scale (read by the kernel)
+  p.acc_scale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d->wt) + (size_t)2 * p.Cout * p.Ktot * sizeof(u16));
 #define MAGAT_SPLIT_LAUNCH(BNV, WM, WN)                                                                              \
   do {                                                                                                              \
     if (d->in_fmt == 3)                                                                                             \
       hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<false, BNV, WM, WN, 1>), dim3((unsigned)grid), dim3(256), 0, st,  \
+                         p);                                                                                        \
+    else if (d->in_fmt == 4)                                                                                        \
+      hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<true, BNV, WM, WN, 2>), dim3((unsigned)grid), dim3(256), 0, st,   \
                          p);                                                                                        \
     else if (af32)                                                                                                  \
       hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<true, BNV, WM, WN>), dim3((unsigned)grid), dim3(256), 0, st, p);  \

@@ -182,6 +182,17 @@ static int enc_split_mask(const magat_encoder_desc* d) {
   return m;
 }
 
+// Split flavour of those layers: f16x3 (two f16 planes, three v_mfma_f32_32x32x16_f16 per product, in_fmt 4) when the
+// pack carries the f16 weight planes, else bf16x6 (in_fmt 2).  MAGAT_CONV_F16=0 forces bf16x6.
+static bool enc_use_f16(const magat_encoder_desc* d, int l) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MAGAT_CONV_F16");
+    v = e ? atoi(e) : 1;
+  }
+  return v && d->off[24 + 2 * l] > 0 && d->off[25 + 2 * l] > 0;
+}
+
 // floats per agent of one rotating activation buffer
 static size_t enc_buf_floats_per_agent(const magat_encoder_desc* d) {
   if (d->variant == 2) return (size_t)d->H * d->W * 32;    // Default CNN: the first map is the largest
@@ -287,7 +298,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       g.pad = 1; g.Hout = hout; g.Wout = wout; g.Cout = s.cout; g.ldc = s.cout; g.relu = 1;
       g.tag = MAGAT_TAG_BLOCK_CONV + 2 * l;
       if (split >> l & 1) {      // bf16x6 split-MFMA kernel: float32 activations split by its loader, bf16x3 weights
-        g.in_fmt = 2; g.wt = pk + d->off[18 + 2 * l];
+        if (enc_use_f16(d, l)) { g.in_fmt = 4; g.wt = pk + d->off[24 + 2 * l]; }
+        else { g.in_fmt = 2; g.wt = pk + d->off[18 + 2 * l]; }
       }
       rc = magat_conv_gemm_f32(&g, stream);
       if (rc != MAGAT_OK) return rc;
@@ -303,7 +315,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       h.Cout = s.cout; h.ldc = s.cout; h.relu = 1;
       h.tag = MAGAT_TAG_BLOCK_CONV + 2 * l + 1;
       if (split >> l & 1) {
-        h.in_fmt = 2; h.wt = pk + d->off[19 + 2 * l];
+        if (enc_use_f16(d, l)) { h.in_fmt = 4; h.wt = pk + d->off[25 + 2 * l]; }
+        else { h.in_fmt = 2; h.wt = pk + d->off[19 + 2 * l]; }
       }
       rc = magat_conv_gemm_f32(&h, stream);
       if (rc != MAGAT_OK) return rc;

@@ -721,6 +721,7 @@ __global__ void pack_kernel(const float* __restrict__ weight, const float* __res
   float* cb = packed + (long long)L.NC * G;
   // bf16x3 planes of Bt for the split-MFMA GEMM (raw bf16 bits), 16-byte aligned behind the column bias
   unsigned short* Bs = reinterpret_cast<unsigned short*>(packed + (((long long)L.NC * (G + 1) + 3) & ~3LL));
+  unsigned short* Hs = reinterpret_cast<unsigned short*>(packed + magat_gat_f16_block_offset(L.NC, G));
   const long long total = (long long)L.NC * G;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total + L.NC;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -758,6 +759,14 @@ __global__ void pack_kernel(const float* __restrict__ weight, const float* __res
     Bs[idx] = h1;
     Bs[total + idx] = h2;
     Bs[2 * total + idx] = magat_bf16_rne(r1 - magat_bf16_f32(h2));
+    // f16x2 planes of v * 2^8 (fixed scale: |v| up to 255 representable, residual plane normal down to |v| ~ 5e-4,
+    // absolute error floor 1e-10 below that) followed by the inverse scale: the "f16x3" operand of the maps GEMM
+    const float vs = v * 256.f;
+    const _Float16 g1 = (_Float16)vs;
+    const _Float16 g2 = (_Float16)(vs - (float)g1);
+    Hs[idx] = __builtin_bit_cast(unsigned short, g1);
+    Hs[total + idx] = __builtin_bit_cast(unsigned short, g2);
+    if (idx == 0) *reinterpret_cast<float*>(Hs + 2 * total) = 1.f / 256.f;
   }
 }
 
@@ -819,7 +828,7 @@ extern "C" int magat_gat_set_debug_buffer(long long* dev_buf) {
 extern "C" size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode) {
   if (G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
   const PackLayout L = pack_layout(G, F, K, P, mode);
-  return (((size_t)L.NC * (G + 1) + 3) & ~(size_t)3) + ((size_t)3 * L.NC * G + 1) / 2;
+  return magat_gat_f16_block_offset(L.NC, G) + (size_t)L.NC * G + 4;
 }
 
 // hoisted dense maps Z = X @ Bt^T + colbias: bf16x6 split-MFMA GEMM when the shape allows, else fp32 MFMA
@@ -842,13 +851,18 @@ int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, in
     use_split = e ? atoi(e) : 1;
   }
   if (use_split && NC % 32 == 0 && G % 32 == 0) {
+    static int use_f16 = -1;
+    if (use_f16 < 0) {
+      const char* e = getenv("MAGAT_CONV_F16");
+      use_f16 = e ? atoi(e) : 1;
+    }
     magat_conv_gemm_desc d = {};
     d.in = X;
-    d.wt = packed + (((size_t)NC * (G + 1) + 3) & ~(size_t)3);
+    d.wt = use_f16 ? packed + magat_gat_f16_block_offset(NC, G) : packed + (((size_t)NC * (G + 1) + 3) & ~(size_t)3);
     d.bias = packed + (size_t)NC * G;
     d.out = Z;
     d.M = M; d.Cin = G; d.lda = G; d.Hin = d.Win = 1; d.kH = d.kW = 1; d.stride = 1; d.Hout = d.Wout = 1;
-    d.Cout = NC; d.ldc = ldz; d.tag = MAGAT_TAG_GAT_MAPS; d.in_fmt = 2;
+    d.Cout = NC; d.ldc = ldz; d.tag = MAGAT_TAG_GAT_MAPS; d.in_fmt = use_f16 ? 4 : 2;
     return magat_conv_gemm_f32(&d, stream);
   }
   return magat_linear_tagged_f32(X, G, packed, packed + (size_t)NC * G, Z, ldz, M, NC, G, 0, MAGAT_TAG_GAT_MAPS,

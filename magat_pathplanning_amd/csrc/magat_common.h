@@ -24,6 +24,13 @@ void magat_prof_end(int id, hipStream_t st);
 // bf16x6 split-MFMA GEMM (conv_gemm_bf16x6.hip), reached through magat_conv_gemm_f32 when desc->in_fmt == 1
 int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st);
 
+// packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of
+// Bt * 2^8: 2*NC*G u16][float 2^-8][pad]: float offset of the f16 block
+__host__ __device__ inline size_t magat_gat_f16_block_offset(int NC, int G) {
+  const size_t a = (((size_t)NC * (G + 1) + 3) & ~(size_t)3) + ((size_t)3 * NC * G + 1) / 2;
+  return (a + 3) & ~(size_t)3;
+}
+
 // hoisted GAT maps Z [M][ldz >= NC] = X [M][G] @ Bt^T + colbias from the packed weights (gat_f32.hip): bf16x6 split when
 // NC % 32 == 0 and G % 32 == 0, else fp32 MFMA
 int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, int G, int NC, int ldz, void* stream);

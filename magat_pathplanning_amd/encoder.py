@@ -14,9 +14,12 @@ the "encoder pack" consumed by magat_encoder_forward_f32 (include/magat_hip.h):
   off[16] compressMLP weight [G][n_feat]                   off[17] compressMLP bias [G]
   off[18+2l] layer(l+1).conv1 weight as bf16x3 planes [3][Cout][9*Cin]            (raw bf16 bits)
   off[19+2l] layer(l+1).[conv2|downsample] weight as bf16x3 planes [3][Cout][9*Cout+Cin]
+  off[24+2l], off[25+2l] the same two weights as f16x2 planes of (w * 2^e) + one float32 2^-e  ("f16x3" GEMM, in_fmt 4)
 
 Every offset is a multiple of 4 floats.  Folding is done in float64 and stored as float32.
 """
+import math
+
 import torch
 
 BN_EPS = 1e-5
@@ -103,12 +106,13 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
         # split-MFMA kernel (csrc/conv_gemm_bf16x6.hip): off[18+2l] = layer(l+1).conv1, off[19+2l] = [conv2|downsample]
         raws = []
         cursor_f = pack.numel()
+        n_f32 = pack.numel()
         pairs = []
         for l in range(nblocks):
             pairs += [(18 + 2 * l, 2 + 4 * l), (19 + 2 * l, 4 + 4 * l)]
         for slot, src in pairs:
-            nxt = sorted(o for o in offs if o > offs[src])
-            end = nxt[0] if nxt else pack.numel()
+            nxt = sorted(o for o in offs[:18] if o > offs[src])
+            end = nxt[0] if nxt else n_f32
             w32 = pack[offs[src]:end]
             # drop the <=3 floats of alignment padding: weight sizes here are multiples of 4 already
             planes = split_bf16x3(w32).view(torch.float32).reshape(-1)
@@ -118,6 +122,18 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
             offs[slot] = cursor_f
             cursor_f += planes.numel()
             raws.append(planes)
+        # ... and as f16x2 planes of the power-of-two-scaled weights followed by the inverse scale ("f16x3" GEMM, in_fmt 4):
+        # off[24+2l] = layer(l+1).conv1, off[25+2l] = [conv2|downsample]
+        for slot, src in pairs:
+            nxt = sorted(o for o in offs[:18] if o > offs[src])
+            end = nxt[0] if nxt else n_f32
+            blk, _ = split_f16x2(pack[offs[src]:end])
+            pad = (-blk.numel()) % 4
+            if pad:
+                blk = torch.cat((blk, torch.zeros(pad)))
+            offs[slot + 6] = cursor_f
+            cursor_f += blk.numel()
+            raws.append(blk)
         pack = torch.cat([pack] + raws).contiguous()
     meta = dict(variant=0 if large else 1, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast)
     return pack, offs, meta
@@ -131,6 +147,24 @@ def split_bf16x3(t):
     p1 = r.bfloat16()
     p2 = (r - p1.float()).bfloat16()
     return torch.stack((p0, p1, p2), dim=0).contiguous()
+
+
+def split_f16x2(t):
+    """fp32 weight tensor -> (float32 view of [2 f16 planes of t * 2^e | one float32 2^-e], e): the operand format of the
+    "f16x3" GEMM (csrc/conv_gemm_bf16x6.hip, in_fmt 4).  2^e scales the largest |weight| into [2^13, 2^14) so that both
+    planes (h1 = f16(w 2^e), h2 = f16(w 2^e - h1)) are normal half-precision numbers; h1 + h2 carries 22 significand bits."""
+    t = t.detach().float().cpu().reshape(-1)
+    mx = float(t.abs().max())
+    e = 0 if mx == 0.0 else 13 - int(math.floor(math.log2(mx)))
+    e = max(-14, min(e, 24))
+    ts = t * (2.0 ** e)
+    h1 = ts.half()
+    h2 = (ts - h1.float()).half()
+    planes = torch.cat((h1, h2)).view(torch.int16)
+    if planes.numel() % 2:
+        planes = torch.cat((planes, torch.zeros(1, dtype=torch.int16)))
+    out = torch.cat((planes.view(torch.float32), torch.tensor([2.0 ** (-e)], dtype=torch.float32)))
+    return out, e
 
 
 def fold_default_cnn(sd, H=11, W=11, pre="ConvLayers", compress=None):

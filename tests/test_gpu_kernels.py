@@ -517,3 +517,43 @@ def test_persistent_dense_kernel_vs_csr_randomised(gpu_device, seed):
         torch.cuda.synchronize()
         assert torch.equal(ya, yb), (mode, B, N, G, K, P)
         assert float((ya - yc).abs().max()) <= 5e-5 * max(1.0, float(yc.abs().max())), (mode, B, N, G, K, P, concat)
+
+
+@pytest.mark.parametrize("cin,cout,c2,M,scale", [(64, 128, 0, 200, 1.0), (128, 128, 64, 131, 1.0), (32, 128, 32, 64, 1.0),
+                                                 (32, 64, 0, 130, 1.0), (64, 64, 32, 77, 30.0), (32, 32, 32, 129, 1e-3),
+                                                 (32, 32, 0, 40, 1.0)])
+def test_conv_gemm_f16x3_split_mfma_matches_fp64(gpu_device, cin, cout, c2, M, scale):
+    """f16x3 split-MFMA conv (in_fmt 4: two f16 planes per operand, three products, power-of-two weight scale) against an
+    fp64 conv2d of the same fp32 inputs - same error bound as the fp32 MFMA / bf16x6 kernels; `scale` moves the
+    activations to large (x30) and tiny (x1e-3: second plane partly subnormal) magnitudes."""
+    from magat_pathplanning_amd.encoder import split_f16x2
+    nat, lib = _nat()
+    g = torch.Generator().manual_seed(cin + cout + c2 + 7)
+    x = torch.randn(M, cin, 6, 6, generator=g) * scale
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    b = torch.randn(cout, generator=g) * scale
+    ref = tnf.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    wt = w.permute(0, 2, 3, 1).reshape(cout, -1)
+    d = nat.ConvGemmDesc()
+    keep = [_to_pixel_major(x).to(gpu_device)]
+    if c2:
+        x2 = torch.randn(M, c2, 6, 6, generator=g) * scale
+        w2 = torch.randn(cout, c2, 1, 1, generator=g) / c2 ** 0.5
+        ref = ref + tnf.conv2d(x2.double(), w2.double())
+        wt = torch.cat((wt, w2.reshape(cout, c2)), dim=1)
+        keep.append(_to_pixel_major(x2).to(gpu_device))
+        d.in2, d.in2_pix_stride, d.C2, d.lda2, d.W2, d.stride2 = keep[1].data_ptr(), M * c2, c2, c2, 6, 1
+    ref = ref.clamp_min(0)
+    blk, e = split_f16x2(wt.contiguous())
+    ws, bd = blk.to(gpu_device), b.to(gpu_device)
+    out = torch.full((36, M, cout), float("nan"), device=gpu_device)
+    d.inp, d.wt, d.bias, d.out = keep[0].data_ptr(), ws.data_ptr(), bd.data_ptr(), out.data_ptr()
+    d.in_pix_stride, d.out_pix_stride = M * cin, M * cout
+    d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, 6, 6, 3, 3, 1, 1
+    d.Hout, d.Wout, d.Cout, d.ldc, d.relu, d.in_fmt = 6, 6, cout, cout, 1, 4
+    nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "conv_gemm f16x3")
+    torch.cuda.synchronize()
+    got = _from_pixel_major(out.cpu(), 6, 6)
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 8e-6 * max(1.0, scale), (err, e)
+

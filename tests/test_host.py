@@ -28,8 +28,8 @@ def test_library_exports_every_declared_symbol():
     assert lib.magat_abi_version() == 1
     assert lib.magat_error_string(-2).decode().startswith("unsupported")
     # pure host queries work without a device
-    nc = 4 * 128 + 4 * 3 * 128            # fp32 [NC][G] + column bias [NC] + bf16x3 planes [3][NC][G]
-    assert lib.magat_gat_packed_floats(128, 128, 3, 4, 0) == nc * 129 + 3 * nc * 128 // 2
+    nc = 4 * 128 + 4 * 3 * 128            # fp32 [NC][G] + column bias [NC] + bf16x3 planes [3][NC][G] + f16x2 planes + scale
+    assert lib.magat_gat_packed_floats(128, 128, 3, 4, 0) == nc * 129 + 3 * nc * 128 // 2 + nc * 128 + 4
     assert lib.magat_gat_workspace_bytes(2, 10, 128, 128, 2, 1, 0, 1) >= 2 * 10 * 384 * 4
 
 
@@ -168,3 +168,20 @@ def test_graph_filter_batch_state_dict_and_composite():
         with pytest.raises(Exception):
             with torch.no_grad():
                 layer(torch.from_numpy(z["x"]))        # inference is HIP-only: CPU tensors fail loudly
+
+
+def test_f16x2_weight_block_reconstructs_weights():
+    """encoder.split_f16x2: two half planes of w * 2^e + the inverse scale reproduce w to 2^-22 relative (absolute floor
+    2^-25 * 2^-e for the tiny entries)."""
+    from magat_pathplanning_amd.encoder import split_f16x2
+    g = torch.Generator().manual_seed(3)
+    for amp in (0.05, 3.0, 1e-4):
+        w = torch.randn(64, 288, generator=g) * amp
+        w[0, :4] = torch.tensor([0.0, 1e-9, -amp * 5, amp * 1e-5])
+        blk, e = split_f16x2(w)
+        n = w.numel()
+        h = blk[:n].view(torch.int16).view(torch.float16).float()
+        assert blk.numel() == n + 1 and blk[-1].item() == 2.0 ** (-e)
+        rec = (h[:n] + h[n:]) * blk[-1]
+        err = (rec - w.reshape(-1)).abs()
+        assert float(err.max()) <= max(2.0 ** -22 * float(w.abs().max()), 2.0 ** -24 * 2.0 ** (-e)), (amp, float(err.max()))

@@ -3,7 +3,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from magat_pathplanning_amd import _native as nat
-from magat_pathplanning_amd.encoder import split_bf16x3
+from magat_pathplanning_amd.encoder import split_bf16x3, split_f16x2
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 51200
 dev = torch.device("cuda:0"); lib = nat.lib()
 def taps():
@@ -12,9 +12,10 @@ for name, cin, cout, c2 in (("l3.conv1", 64, 128, 0), ("l3.conv2+ds", 128, 128, 
     x = torch.relu(torch.randn(36, M, cin, device=dev)); x2 = torch.relu(torch.randn(36, M, max(c2, 8), device=dev))
     w = torch.randn(cout, 9 * cin + c2, device=dev) * 0.05; b = torch.randn(cout, device=dev)
     res = {}
-    for fmt in (0, 1, 2):
+    for fmt in (0, 1, 2, 4):
         d = nat.ConvGemmDesc()
-        xs = split_bf16x3(x) if fmt == 1 else x; x2s = split_bf16x3(x2) if fmt == 1 else x2; ws = split_bf16x3(w) if fmt else w
+        xs = split_bf16x3(x) if fmt == 1 else x; x2s = split_bf16x3(x2) if fmt == 1 else x2
+        ws = w if fmt == 0 else (split_f16x2(w)[0].to(dev) if fmt == 4 else split_bf16x3(w))
         out = torch.empty(36, M, cout, device=dev)
         d.inp, d.wt, d.bias, d.out = xs.data_ptr(), ws.data_ptr(), b.data_ptr(), out.data_ptr()
         d.in_pix_stride, d.out_pix_stride, d.in_plane_stride = M * cin, M * cout, 36 * M * cin
@@ -31,6 +32,21 @@ for name, cin, cout, c2 in (("l3.conv1", 64, 128, 0), ("l3.conv2+ds", 128, 128, 
             if r >= 2: ts.append(e0.elapsed_time(e1) * 1e3)
         ts.sort(); res[fmt] = (ts[len(ts) // 2], out.clone())
     fl = 2.0 * M * (taps() * cin * cout + 36 * c2 * cout)
-    print("%-12s fp32 %8.1f us (%.1f TF)   bf16x6 planes %8.1f us (%.2fx)   bf16x6 split-on-load %8.1f us (%.1f TF-equiv, %.2fx)   max|diff| %.2e %.2e" % (
+    ref64 = None
+    print("%-12s fp32 %8.1f us (%.1f TF)   bf16x6 planes %8.1f us (%.2fx)   bf16x6 split-on-load %8.1f us (%.1f TF-equiv, %.2fx)   f16x3 %8.1f us (%.1f TF-equiv, %.2fx)   max|diff vs fp32 kernel| %.2e %.2e %.2e  (out scale %.2f)" % (
         name, res[0][0], fl / res[0][0] / 1e6, res[1][0], res[0][0] / res[1][0], res[2][0], fl / res[2][0] / 1e6,
-        res[0][0] / res[2][0], (res[0][1] - res[1][1]).abs().max().item(), (res[0][1] - res[2][1]).abs().max().item()))
+        res[0][0] / res[2][0], res[4][0], fl / res[4][0] / 1e6, res[0][0] / res[4][0],
+        (res[0][1] - res[1][1]).abs().max().item(), (res[0][1] - res[2][1]).abs().max().item(),
+        (res[0][1] - res[4][1]).abs().max().item(), res[0][1].abs().max().item()))
+    # accuracy against float64 on a slice of agents (pixel (2,2): all nine taps valid)
+    xs64 = x[:, :256].double().cpu(); w64 = w.double().cpu(); acc = torch.zeros(256, cout, dtype=torch.float64)
+    for ty in range(3):
+        for tx in range(3):
+            pix = (2 + ty - 1) * 6 + (2 + tx - 1)
+            acc += xs64[pix] @ w64[:, (ty * 3 + tx) * cin:(ty * 3 + tx + 1) * cin].T
+    if c2:
+        acc += x2[2 * 6 + 2, :256].double().cpu() @ w64[:, 9 * cin:].T
+    acc = torch.relu(acc + b.double().cpu())
+    for fmt, nm in ((0, "fp32 MFMA"), (2, "bf16x6"), (4, "f16x3")):
+        got = res[fmt][1][2 * 6 + 2, :256].double().cpu()
+        print("      %-10s vs float64: max|err| %.2e  rms %.2e" % (nm, (got - acc).abs().max().item(), (got - acc).pow(2).mean().sqrt().item()))
