@@ -85,7 +85,7 @@ __device__ __forceinline__ void split_pair_f16(float x, float y, unsigned& p1, u
 // weights, one product) - the bf16 variant of the GAT maps GEMM for BASELINE config 5.
 template <bool AF32, int BN, int WGM, int WGN, int NPL = 3>
 __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitParams p) {
-  static_assert(NPL == 3 || (NPL == 1 && !AF32) || (NPL == 2 && AF32), "plane count");
+  static_assert(NPL == 3 || (NPL == 1 && !AF32) || NPL == 2, "plane count");
   constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 32, TN = WTN / 32;
   constexpr int BI = BN >= 64 ? BN / 64 : 1;      // weight-tile 16-byte loads per thread and plane
   __shared__ __attribute__((aligned(16))) u16 lds[NPL * (BM + BN) * 32];   // A planes | B planes
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
     }
     const char* bb = reinterpret_cast<const char*>(p.wt + bk);
     const long long bplane = p.wt_plane * 2;
+    const unsigned selp = main_seg ? 0xffffffffu : 0u;
     if constexpr (AF32) {
       // (selecting between the two offset arrays per element - or per branch - was compiled into scratch-indexed
       // loads on the address path; a masked delta keeps everything in registers)
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
       if constexpr (!AF32) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          ra[pl][i] = *reinterpret_cast<const u32x4*>(ab + pl * aplane + (main_seg ? aoff[i] : aoff2[i]));
+          ra[pl][i] = *reinterpret_cast<const u32x4*>(ab + pl * aplane + (aoff2[i] + ((aoff[i] - aoff2[i]) & selp)));
       }
 #pragma unroll
       for (int i = 0; i < BI; ++i) rb[pl][i] = *reinterpret_cast<const u32x4*>(bb + pl * bplane + boff[i]);
@@ -335,6 +336,22 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 #pragma unroll
             for (int c = 0; c < 4; ++c) dst[c] = bf16_rne(v[c]);
           }
+        } else if (p.out_split == 3) {     // two f16 planes (the operand format of the next f16x3 layer: split once here,
+          u16* ob = static_cast<u16*>(p.out);   // not once per tap and slab by every consumer)
+          unsigned a1, a2, b1, b2;
+          split_pair_f16(v[0], v[1], a1, a2);
+          split_pair_f16(v[2], v[3], b1, b2);
+          if (vec) {
+            *reinterpret_cast<uint2*>(ob + o) = uint2{a1, b1};
+            *reinterpret_cast<uint2*>(ob + p.out_plane + o) = uint2{a2, b2};
+          } else {
+            const unsigned w1[2] = {a1, b1}, w2[2] = {a2, b2};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              ob[o + c] = (u16)(w1[c >> 1] >> (16 * (c & 1)));
+              ob[p.out_plane + o + c] = (u16)(w2[c >> 1] >> (16 * (c & 1)));
+            }
+          }
         } else if (p.out_split) {
           u16* ob = static_cast<u16*>(p.out);
           u16 h[3][4];
@@ -371,6 +388,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 
 }  // namespace
 
+// in_fmt 5: like 4, but in/in2 arrive as the two f16 planes already (written by a producer with out_fmt 3): no split work.
 // in_fmt 4: in/in2 float32 split on load into two f16 planes, wt = [2][Cout][Ktot] f16 planes of (weight * 2^e) followed
 // by one float32 2^-e ("f16x3": three f16 MFMAs per product).
 // in_fmt 1: in/in2/wt all bf16x3 planes; in_fmt 2: in/in2 float32 (split on load), wt bf16x3 planes; in_fmt 3: in/in2/wt
@@ -382,8 +400,9 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   const int BN = d->Cout % 128 == 0 ? 128 : (d->Cout % 64 == 0 ? 64 : 32);
   if ((d->Cout % BN) || (d->Cin % BK) || (d->C2 % BK) || (d->lda % 8) || (d->C2 > 0 && (d->lda2 % 8)) || d->pool)
     return MAGAT_ERR_UNSUPPORTED;
-  if (d->in_fmt < 1 || d->in_fmt > 4 || d->out_fmt < 0 || d->out_fmt > 2) return MAGAT_ERR_UNSUPPORTED;
-  if (d->in_fmt == 4 && d->out_fmt != 0) return MAGAT_ERR_UNSUPPORTED;
+  if (d->in_fmt < 1 || d->in_fmt > 5 || d->out_fmt < 0 || d->out_fmt > 3) return MAGAT_ERR_UNSUPPORTED;
+  if (d->in_fmt >= 4 && d->out_fmt != 0 && d->out_fmt != 3) return MAGAT_ERR_UNSUPPORTED;
+  if (d->out_fmt == 3 && d->in_fmt < 4) return MAGAT_ERR_UNSUPPORTED;
   SplitParams p;
   p.in = static_cast<const u16*>(static_cast<const void*>(d->in));
   p.in2 = static_cast<const u16*>(static_cast<const void*>(d->in2));
@@ -422,6 +441,9 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
                          p);                                                                                        \
     else if (d->in_fmt == 4)                                                                                        \
       hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<true, BNV, WM, WN, 2>), dim3((unsigned)grid), dim3(256), 0, st,   \
+                         p);                                                                                        \
+    else if (d->in_fmt == 5)                                                                                        \
+      hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<false, BNV, WM, WN, 2>), dim3((unsigned)grid), dim3(256), 0, st,  \
                          p);                                                                                        \
     else if (af32)                                                                                                  \
       hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<true, BNV, WM, WN>), dim3((unsigned)grid), dim3(256), 0, st, p);  \

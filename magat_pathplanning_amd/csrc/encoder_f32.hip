@@ -21,7 +21,7 @@ template <int HC, int WC>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          int M, int Hr, int Wr, long long out_pix_stride,
-                                                         long long out_tile_stride) {
+                                                         long long out_tile_stride, long long out_plane) {
   extern __shared__ float img[];
   const int H = HC ? HC : Hr, W = WC ? WC : Wr;
   const int PW = W + 2, PHW = (H + 2) * PW;
@@ -113,7 +113,24 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
         f32x4 v;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[4 * q + c] + bch[q][c], 0.f);
-        *reinterpret_cast<f32x4*>(o + 8 * q) = v;
+        if (out_plane == 0) {
+          *reinterpret_cast<f32x4*>(o + 8 * q) = v;
+        } else {      // two f16 planes (operand format of the f16x3 convs, conv_gemm_bf16x6.hip in_fmt 5)
+          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          unsigned short* ob = reinterpret_cast<unsigned short*>(out) + (o - out) + 8 * q;
+          unsigned w1[2], w2[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const float a = fminf(v[2 * c], 65504.f), b2 = fminf(v[2 * c + 1], 65504.f);
+            const h2 h = __builtin_convertvector(f2{a, b2}, h2);
+            const h2 r = __builtin_convertvector(f2{a - (float)h[0], b2 - (float)h[1]}, h2);
+            w1[c] = __builtin_bit_cast(unsigned, h);
+            w2[c] = __builtin_bit_cast(unsigned, r);
+          }
+          *reinterpret_cast<uint2*>(ob) = uint2{w1[0], w1[1]};
+          *reinterpret_cast<uint2*>(ob + out_plane) = uint2{w2[0], w2[1]};
+        }
       }
     }
   }
@@ -134,7 +151,7 @@ struct BlockShape {
 }  // namespace
 
 static int conv_first_launch(const float* x, const float* wt, const float* bias, float* out, int M, int H, int W,
-                             long long pix_stride, long long tile_stride, void* stream);
+                             long long pix_stride, long long tile_stride, void* stream, long long out_plane = 0);
 
 extern "C" int magat_conv_first_f32(const float* x, const float* wt, const float* bias, float* out, int M, int H,
                                     int W, void* stream) {
@@ -148,7 +165,7 @@ extern "C" int magat_conv_first_tiled_f32(const float* x, const float* wt, const
 }
 
 static int conv_first_launch(const float* x, const float* wt, const float* bias, float* out, int M, int H, int W,
-                             long long pix_stride, long long tile_stride, void* stream) {
+                             long long pix_stride, long long tile_stride, void* stream, long long out_plane) {
   if (!x || !wt || !bias || !out) return MAGAT_ERR_NULL;
   if (M <= 0 || H <= 0 || W <= 0) return MAGAT_ERR_BAD_SHAPE;
   const size_t lds = sizeof(float) * 32 * (size_t)((3 * (H + 2) * (W + 2)) | 1);
@@ -158,10 +175,10 @@ static int conv_first_launch(const float* x, const float* wt, const float* bias,
   const int pid = magat_prof_begin(MAGAT_TAG_CONV_FIRST, st);
   if (H == 11 && W == 11 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
     hipLaunchKernelGGL((conv_first_kernel<11, 11>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W,
-                       pix_stride, tile_stride);
+                       pix_stride, tile_stride, out_plane);
   else
     hipLaunchKernelGGL((conv_first_kernel<0, 0>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W,
-                       pix_stride, tile_stride);
+                       pix_stride, tile_stride, out_plane);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
@@ -278,10 +295,29 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
     return MAGAT_OK;
   }
 
+  // f16-plane activation chain (opt-in, MAGAT_CONV_PLANES=1): activations between layers live in HBM as the two f16 planes
+  // the f16x3 kernel consumes (same bytes as float32, bit-identical results): each value is split ONCE by its producer's
+  // epilogue instead of once per tap and slab by every consumer's loader; the last conv2 writes float32 for the pooled
+  // head.  Measured on MI355X: faster for an isolated layer (l3.conv1 1007 -> 847 us) but ~7 % SLOWER end to end (the
+  // epilogues' 8-byte plane stores and the split there cost more than the loaders save: the split-on-load VALU work is
+  // hidden behind the MFMA drain anyway), so float32 activations stay the default.
+  bool chain = split == (1 << nblocks) - 1;
+  for (int l = 0; l < nblocks; ++l) chain = chain && enc_use_f16(d, l);
+  {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MAGAT_CONV_PLANES"); v = e ? atoi(e) : 0; }
+    chain = chain && v;
+  }
+  // plane layout: [agent tile][plane][pixel][128][c] 16-bit elements - the two planes of a tile sit next to each other
+  // (a tensor-sized plane stride measured 10 % slower: everything a workgroup touches should stay one contiguous run)
+  auto planes = [&](int npix, int c) { return (int64_t)npix * MAGAT_TILE_ROWS * c; };
+  auto ptiles = [&](int npix, int c) { return (int64_t)2 * npix * MAGAT_TILE_ROWS * c; };
   for (int m0 = 0; m0 < M; m0 += mc) {
     const int mm = (M - m0) < mc ? (M - m0) : mc;
-    int rc = magat_conv_first_tiled_f32(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W,
-                                        stream);
+    int rc = conv_first_launch(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W,
+                               (long long)MAGAT_TILE_ROWS * 32,
+                               chain ? (long long)ptiles(H * W, 32) : (long long)H * W * MAGAT_TILE_ROWS * 32, stream,
+                               chain ? planes(H * W, 32) : 0);
     if (rc != MAGAT_OK) return rc;
     int cur = 0;              // buffer holding the block input
     int hin = H, win = W;
@@ -300,6 +336,11 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       if (split >> l & 1) {      // bf16x6 split-MFMA kernel: float32 activations split by its loader, bf16x3 weights
         if (enc_use_f16(d, l)) { g.in_fmt = 4; g.wt = pk + d->off[24 + 2 * l]; }
         else { g.in_fmt = 2; g.wt = pk + d->off[18 + 2 * l]; }
+        if (chain) {
+          g.in_fmt = 5; g.out_fmt = 3;
+          g.in_plane_stride = planes(hin * win, s.cin); g.out_plane_stride = planes(hout * wout, s.cout);
+          g.in_tile_stride = ptiles(hin * win, s.cin); g.out_tile_stride = ptiles(hout * wout, s.cout);
+        }
       }
       rc = magat_conv_gemm_f32(&g, stream);
       if (rc != MAGAT_OK) return rc;
@@ -317,6 +358,13 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       if (split >> l & 1) {
         if (enc_use_f16(d, l)) { h.in_fmt = 4; h.wt = pk + d->off[25 + 2 * l]; }
         else { h.in_fmt = 2; h.wt = pk + d->off[19 + 2 * l]; }
+        if (chain) {
+          h.in_fmt = 5; h.out_fmt = l + 1 < nblocks ? 3 : 0;
+          h.in_plane_stride = planes(hout * wout, s.cout); h.in2_plane_stride = planes(hin * win, s.cin);
+          h.out_plane_stride = planes(hout * wout, s.cout);
+          h.in_tile_stride = ptiles(hout * wout, s.cout); h.in2_tile_stride = ptiles(hin * win, s.cin);
+          if (l + 1 < nblocks) h.out_tile_stride = ptiles(hout * wout, s.cout);
+        }
       }
       rc = magat_conv_gemm_f32(&h, stream);
       if (rc != MAGAT_OK) return rc;

@@ -12,10 +12,14 @@ for name, cin, cout, c2 in (("l3.conv1", 64, 128, 0), ("l3.conv2+ds", 128, 128, 
     x = torch.relu(torch.randn(36, M, cin, device=dev)); x2 = torch.relu(torch.randn(36, M, max(c2, 8), device=dev))
     w = torch.randn(cout, 9 * cin + c2, device=dev) * 0.05; b = torch.randn(cout, device=dev)
     res = {}
-    for fmt in (0, 1, 2, 4):
+    def f16_planes(t):
+        t = t.clamp(-65504.0, 65504.0)
+        h1 = t.half()
+        return torch.stack((h1, (t - h1.float()).half())).contiguous()
+    for fmt in (0, 1, 2, 4, 5):
         d = nat.ConvGemmDesc()
-        xs = split_bf16x3(x) if fmt == 1 else x; x2s = split_bf16x3(x2) if fmt == 1 else x2
-        ws = w if fmt == 0 else (split_f16x2(w)[0].to(dev) if fmt == 4 else split_bf16x3(w))
+        xs = split_bf16x3(x) if fmt == 1 else (f16_planes(x) if fmt == 5 else x); x2s = split_bf16x3(x2) if fmt == 1 else (f16_planes(x2) if fmt == 5 else x2)
+        ws = w if fmt == 0 else (split_f16x2(w)[0].to(dev) if fmt >= 4 else split_bf16x3(w))
         out = torch.empty(36, M, cout, device=dev)
         d.inp, d.wt, d.bias, d.out = xs.data_ptr(), ws.data_ptr(), b.data_ptr(), out.data_ptr()
         d.in_pix_stride, d.out_pix_stride, d.in_plane_stride = M * cin, M * cout, 36 * M * cin
@@ -33,9 +37,10 @@ for name, cin, cout, c2 in (("l3.conv1", 64, 128, 0), ("l3.conv2+ds", 128, 128, 
         ts.sort(); res[fmt] = (ts[len(ts) // 2], out.clone())
     fl = 2.0 * M * (taps() * cin * cout + 36 * c2 * cout)
     ref64 = None
-    print("%-12s fp32 %8.1f us (%.1f TF)   bf16x6 planes %8.1f us (%.2fx)   bf16x6 split-on-load %8.1f us (%.1f TF-equiv, %.2fx)   f16x3 %8.1f us (%.1f TF-equiv, %.2fx)   max|diff vs fp32 kernel| %.2e %.2e %.2e  (out scale %.2f)" % (
+    print("%-12s fp32 %8.1f us (%.1f TF)   bf16x6 planes %8.1f us (%.2fx)   bf16x6 split-on-load %8.1f us (%.1f TF-equiv, %.2fx)   f16x3 %8.1f us (%.1f TF-equiv, %.2fx)   f16x3 planes-in %8.1f us (%.2fx, identical output: %s)   max|diff vs fp32 kernel| %.2e %.2e %.2e  (out scale %.2f)" % (
         name, res[0][0], fl / res[0][0] / 1e6, res[1][0], res[0][0] / res[1][0], res[2][0], fl / res[2][0] / 1e6,
         res[0][0] / res[2][0], res[4][0], fl / res[4][0] / 1e6, res[0][0] / res[4][0],
+        res[5][0], res[0][0] / res[5][0], bool(torch.equal(res[4][1], res[5][1])),
         (res[0][1] - res[1][1]).abs().max().item(), (res[0][1] - res[2][1]).abs().max().item(),
         (res[0][1] - res[4][1]).abs().max().item(), res[0][1].abs().max().item()))
     # accuracy against float64 on a slice of agents (pixel (2,2): all nine taps valid)
