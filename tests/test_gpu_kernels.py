@@ -557,3 +557,37 @@ def test_conv_gemm_f16x3_split_mfma_matches_fp64(gpu_device, cin, cout, c2, M, s
     err = (got.double() - ref).abs().max().item()
     assert err <= 8e-6 * max(1.0, scale), (err, e)
 
+
+
+def test_conv_gemm_f16_plane_formats(gpu_device):
+    """in_fmt 5 (activations already as two f16 planes) gives bit-identical results to in_fmt 4 (split on load), and
+    out_fmt 3 (epilogue writes the two planes) reproduces the float32 output to 2^-22."""
+    from magat_pathplanning_amd.encoder import split_f16x2
+    nat, lib = _nat()
+    M, cin, cout = 150, 64, 128
+    g = torch.Generator().manual_seed(5)
+    x = torch.relu(torch.randn(M, cin, 6, 6, generator=g))
+    wt = (torch.randn(cout, 9 * cin, generator=g) / (9 * cin) ** 0.5).contiguous()
+    b = torch.randn(cout, generator=g)
+    xp = _to_pixel_major(x).to(gpu_device)                           # [36][M][cin] float32
+    h1 = xp.clamp(-65504, 65504).half()
+    planes = torch.stack((h1, (xp - h1.float()).half())).contiguous()  # [2][36][M][cin]
+    ws, bd = split_f16x2(wt)[0].to(gpu_device), b.to(gpu_device)
+    outs = {}
+    for in_fmt, out_fmt in ((4, 0), (5, 0), (4, 3)):
+        d = nat.ConvGemmDesc()
+        src = planes if in_fmt == 5 else xp
+        out = (torch.zeros(2, 36, M, cout, dtype=torch.float16, device=gpu_device) if out_fmt == 3 else
+               torch.full((36, M, cout), float("nan"), device=gpu_device))
+        d.inp, d.wt, d.bias, d.out = src.data_ptr(), ws.data_ptr(), bd.data_ptr(), out.data_ptr()
+        d.in_pix_stride, d.out_pix_stride = M * cin, M * cout
+        d.in_plane_stride, d.out_plane_stride = 36 * M * cin, 36 * M * cout
+        d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, 6, 6, 3, 3, 1, 1
+        d.Hout, d.Wout, d.Cout, d.ldc, d.relu, d.in_fmt, d.out_fmt = 6, 6, cout, cout, 1, in_fmt, out_fmt
+        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "conv_gemm f16 planes")
+        torch.cuda.synchronize()
+        outs[(in_fmt, out_fmt)] = out
+    assert torch.equal(outs[(4, 0)], outs[(5, 0)])
+    rec = outs[(4, 3)][0].float() + outs[(4, 3)][1].float()
+    ref = outs[(4, 0)]
+    assert float((rec - ref).abs().max()) <= 2.0 ** -21 * float(ref.abs().max())
