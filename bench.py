@@ -200,6 +200,7 @@ def main():
             out = step()
         timing = rank == 0 and not args.no_kernel_timing
         if timing:
+            lib.magat_profile_reserve(32 * (args.steps + 1))      # event pairs created outside the timed region
             lib.magat_profile_reset()
             lib.magat_profile_enable(1)
         barrier()

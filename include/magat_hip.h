@@ -274,6 +274,7 @@ int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* 
 #define MAGAT_TAG_GSO_PREPARE 15
 #define MAGAT_PROF_TAGS 16
 int magat_gat_set_debug_buffer(long long* dev_buf); /* [grid][8] int64 phase timestamps of gat_dense_kernel; NULL = off */
+int magat_profile_reserve(int spans);   /* pre-create event pairs (keeps hipEventCreate out of a timed region) */
 int magat_profile_enable(int on);
 int magat_profile_collect(void);
 int magat_profile_read(int tag, long long* count, double* total_ms);

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "magat_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "magat_linear_tagged_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "magat_gat_set_debug_buffer": (_I, [_P]),
+    "magat_profile_reserve": (_I, [_I]),
     "magat_profile_enable": (_I, [_I]),
     "magat_profile_collect": (_I, []),
     "magat_profile_read": (_I, [_I, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),

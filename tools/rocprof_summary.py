@@ -11,6 +11,10 @@ from collections import defaultdict
 
 
 def short(name):
+    import re
+    m = re.search(r"conv_gemm_bf16x6_kernel<true, (\d+), \d+, \d+, 2>", name)
+    if m:                                       # NPL = 2: the f16x3 flavour of the split kernel
+        return "conv_gemm_f16x3<f32-in,%s>" % m.group(1)
     for key, s in (("conv_gemm_bf16x6_kernel<true, 128", "conv_gemm_bf16x6<f32-in,128>"),
                    ("conv_gemm_bf16x6_kernel<true, 64", "conv_gemm_bf16x6<f32-in,64>"),
                    ("conv_gemm_bf16x6_kernel<true, 32", "conv_gemm_bf16x6<f32-in,32>"),
