@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
       // fragments are still in flight; the running fp32 accumulator dwarfs every term of a slab, so adding the small
       // terms first buys no accuracy); the four accumulators are interleaved so consecutive MFMAs never depend on
       // each other.  (Tried without gain: s_setprio(1) around the MFMA cluster (3 % slower); reading both k-steps'
-      // fragments before the first MFMA (the scheduler sinks the loads back, same 164 VGPRs, same time).)
+      // fragments before the first MFMA (the scheduler sinks the loads back, same 164 VGPRs, same time); for f16x3,
+      // two LDS stages with ONE barrier per slab (64 KB, 2 workgroups per CU): 5-10 % slower than 3 workgroups per CU.)
       //   NPL 3 (bf16x6): x1w1 x1w2 x2w1 x2w2 x1w3 x3w1      NPL 2 (f16x3): h1g1 h1g2 h2g1      NPL 1: one product
       constexpr int NPROD = NPL == 3 ? 6 : (NPL == 2 ? 3 : 1);
       constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
