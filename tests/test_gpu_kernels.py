@@ -521,7 +521,7 @@ def test_persistent_dense_kernel_vs_csr_randomised(gpu_device, seed):
 
 @pytest.mark.parametrize("cin,cout,c2,M,scale", [(64, 128, 0, 200, 1.0), (128, 128, 64, 131, 1.0), (32, 128, 32, 64, 1.0),
                                                  (32, 64, 0, 130, 1.0), (64, 64, 32, 77, 30.0), (32, 32, 32, 129, 1e-3),
-                                                 (32, 32, 0, 40, 1.0)])
+                                                 (32, 32, 0, 40, 1.0), (64, 128, 0, 70, 3000.0)])
 def test_conv_gemm_f16x3_split_mfma_matches_fp64(gpu_device, cin, cout, c2, M, scale):
     """f16x3 split-MFMA conv (in_fmt 4: two f16 planes per operand, three products, power-of-two weight scale) against an
     fp64 conv2d of the same fp32 inputs - same error bound as the fp32 MFMA / bf16x6 kernels; `scale` moves the
