@@ -132,3 +132,21 @@ def test_closed_loop_step_on_device(gpu_device):
             np.testing.assert_array_equal(out["reached"][b].cpu().numpy(), want_reached)
             assert len({tuple(p) for p in new[b]}) == N and (m[new[b][:, 0], new[b][:, 1]] == 0).all()
             assert new[b].min() >= 0 and new[b].max() < size
+
+
+def test_gso_large_instances_vs_oracle(gpu_device):
+    """N above the workgroup size (strided row loops) and a disconnected graph (two far-apart clusters): lambda_max is
+    the maximum over components."""
+    from oracle import sim_oracle as so
+    from magat_pathplanning_amd.simulator import batched_gso
+    rng = np.random.default_rng(5)
+    N = 300
+    pos = rng.integers(0, 90, size=(3, N, 2)).astype(np.int32)
+    pos[1, : N // 2] = rng.integers(0, 30, size=(N // 2, 2))
+    pos[1, N // 2:] = rng.integers(200, 215, size=(N - N // 2, 2))        # two clusters, no edge between them
+    S, lam = batched_gso(torch.from_numpy(pos).to(gpu_device), 7.0, return_lambda=True)
+    for b in range(3):
+        ref = so.gso_from_positions(pos[b], 7.0)
+        got = S[b].cpu().numpy()
+        np.testing.assert_array_equal(got != 0, ref != 0)
+        np.testing.assert_allclose(got, ref, rtol=1e-9, atol=0)
