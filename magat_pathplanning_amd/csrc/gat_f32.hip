@@ -10,13 +10,18 @@
 //   concat: out[n, p*F+f] = relu(Y_p[n,f] + bias[f]);  mean: relu(sum_p (Y_p + bias) / P)
 //
 // Two launches per call (per chunk of instances):
-//   1. the dense per-agent maps Z = X @ [W_p | H_{p,k}]^T on fp32 MFMA (conv_gemm_f32.hip) - they do not
-//      shrink with graph sparsity and are ~95 % of the layer's flops;
-//   2. gat_dense_kernel below: one workgroup per (instance, head).  Q_p and the hop operand tiles are staged
-//      in LDS with coalesced 16-byte row loads, edge scores use 16-lane dot products straight out of LDS,
-//      the row softmax is a 64-lane wavefront reduction, and the K-1 hops gather neighbour rows from LDS
-//      (column aggregation with row-normalised weights - the reference's x @ aij quirk).  Y is written once,
-//      already in the (B*N, P*F) layout actionsMLP consumes.  This kernel is ~3 flop/byte: HBM-bound.
+//   1. the dense per-agent maps Z = X @ [W_p | H_{p,k}]^T on the split-MFMA GEMM (f16x3, conv_gemm_bf16x6.hip; fp32 MFMA
+//      for shapes it does not take) - they do not shrink with graph sparsity and are ~95 % of the layer's flops;
+//   2. gat_dense_kernel below.  Wide path (G, F >= 64): PERSISTENT workgroups - when the LDS tiles allow one workgroup
+//      per CU, the grid is one workgroup per CU and each walks its instances and all heads of an instance.  The
+//      [N][F] Q_p / U_{K-1} tiles travel global -> LDS with the LDS-direct load (global_load_lds_dwordx4): the next
+//      head's (or instance's) first tile streams in during the current head's last hop, U_{K-1} during the score
+//      phase.  Edge scores are 8-lane dot products out of LDS (packed FMAs, DPP reductions) over one walk of the row's
+//      128-bit edge mask; the softmax runs on the <= 2 scores a lane keeps in registers (dense fallback for rows of more
+//      than 16 edges); the K-1 hops gather neighbour rows from LDS with a wave-uniform scalar loop (column aggregation
+//      with row-normalised weights - the reference's x @ aij quirk).  Y is written once, already in the (B*N, P*F)
+//      layout actionsMLP consumes.  ~3 flop/byte: the kernel whose GB/s is quoted against the HBM roof.
+//      Narrow path (G < 64): one workgroup per (instance, head), tiles staged through registers.
 #include <cstdlib>
 #include <type_traits>
 
@@ -53,10 +58,8 @@ __device__ __forceinline__ bool is_edge(const void* S, long long idx, int f64, f
   return fabsf(static_cast<const float*>(S)[idx]) > 1e-9f;
 }
 
-// Block size is 8 threads per (power-of-two-rounded) node, so every staging loop below is a fixed, fully
-// unrolled handful of 16-byte loads per thread: ALL of a workgroup's global reads (Q_p, X_b, the GSO mask,
-// U_{K-1}, and the first hop's U rows) are issued back to back at kernel entry and land while the earlier
-// phases run out of LDS.
+// Block size is 8 threads per (power-of-two-rounded) node: the wide score phase is exactly one 8-row step per wave, and
+// every staging loop of the narrow path is a fixed, fully unrolled handful of 16-byte loads per thread.
 template <int G, int F>
 __global__ void gat_dense_kernel(const GatParams p) {
   constexpr int RW = G > F ? G : F;
