@@ -1,14 +1,19 @@
-// fp32-accurate segmented-K conv/linear GEMM on the bf16 matrix cores ("bf16x6" split).
+// fp32-accurate segmented-K conv/linear GEMM on the 16-bit matrix cores ("split MFMA": f16x3 and bf16x6 flavours).
 //
-// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (157 TF); v_mfma_f32_32x32x16_bf16 is 16x faster.  Every
-// fp32 value is therefore carried as THREE bf16 planes  x = x1 + x2 + x3  (x1 = bf16(x), x2 = bf16(x - x1),
-// x3 = bf16(x - x1 - x2): 3 x 8 significand bits = the fp32 mantissa, same exponent range, products of bf16
-// pairs are exact in the fp32 accumulator) and a product is evaluated as the six partial products with
-// i + j <= 4:   x.w ~= x1w1 + x1w2 + x2w1 + x1w3 + x2w2 + x3w1   (dropped terms <= 2^-24 |x.w|, i.e. the fp32
-// rounding class).  Six bf16 MFMAs replace one fp32 MFMA's worth of work at 16/6 = 2.67x the rate.
-// Used for the two layer-3 convolutions (62 % of the step); the producing epilogues write the 3-plane form
-// directly, weights are split host-side.  Same pixel-major / tap-skipping / residual-K-segment structure as
-// conv_gemm_f32.hip.
+// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (157 TF); v_mfma_f32_32x32x16_{f16,bf16} is 16x faster.  Every fp32
+// value is therefore carried as a few 16-bit planes and a product as the partial products that matter:
+//   f16x3  (NPL = 2, default): x = h1 + h2, two RNE half-precision planes (22 significand bits); x.w ~= h1g1 + h1g2 + h2g1
+//          (dropped h2g2 <= 2^-22 |x.w|): THREE f16 MFMAs per product = 5.3x the fp32-MFMA rate.  fp16's narrow exponent:
+//          activation planes are clamped to +-65504 (exact to 1.3e5 through the second plane), tiny residuals go
+//          subnormal (absolute error <= 3e-8), weights are pre-scaled by a power of two that the epilogue undoes.
+//          Measured against float64 it is as accurate as the fp32 MFMA kernel (tools/conv_bench_split.py).
+//   bf16x6 (NPL = 3): x = x1 + x2 + x3, three bf16 planes (24 bits, fp32 exponent range); six products with i + j <= 4
+//          (dropped terms <= 2^-24): 2.67x the fp32-MFMA rate.
+//   NPL = 1: plain bf16 GEMM (bf16 storage variant of the GAT maps, BASELINE config 5).
+// Activations normally stay float32 in HBM and are split by the loader (AF32) - after the wave has issued its MFMAs of
+// the previous slab, outside the barrier-to-barrier section; weights are split host-side / by pack_kernel.  Plane
+// tensors in HBM (AF32 = false; produced by out_fmt 1 / 3) exist as measured-and-rejected experiments.  Same
+// pixel-major / tap-skipping / residual-K-segment structure as conv_gemm_f32.hip.
 //
 // Tile 128x128x32, 4 waves (2x2, wave tile 64x64).  LDS rows are 32 bf16 = 64 B, unpadded, with the 16-byte
 // chunk index XOR-ed by (row>>2)&3: a ds_read_b128 16-lane group (16 consecutive rows, same k chunk) then covers
