@@ -44,6 +44,8 @@ struct GatParams {
   int skip;                      // instrumentation: bit0 skip scores, bit1 skip hops (wrong results; for PMC deltas)
   const int* over;               // when set: only instances with over[bl] != 0 are processed here (the rest were
                                  // handled by the list kernel, gat_list_f32.hip)
+  float* Ymean;                  // fused head-mean (mean merge, hpb == P): final output [B*N, ldym]; Y is unused then
+  int ldym;
   int hpb;                       // heads per workgroup (1, or P: the workgroup walks all heads of its instance and
                                  // loads the next head's Q tile while the current head computes)
 };
@@ -169,6 +171,13 @@ __global__ void gat_dense_kernel(const GatParams p) {
     for (int e = 0; e < VEC; ++e) MAGAT_SETTLE_F(biasv[e]);
   }
 
+  // fused head-mean: the workgroup walks all P heads of an instance, every wave owns the same output rows for every
+  // head, so sum_p (Y_p + bias) is carried in registers and relu(sum / P) is stored once (graphML.py:4663-4667) -
+  // same values and summation order as the separate head_mean_relu_kernel, without the [B*N, P*F] round trip
+  const bool fuse_mean = WIDE && p.Ymean != nullptr;
+  fvec ysum[HMAX];
+#pragma unroll
+  for (int h = 0; h < HMAX; ++h) ysum[h] = zerov;
   for (int bl = bl0; bl < p.B; bl += istride) {     // ---- instances of this workgroup
   if (p.over && !p.over[bl]) continue;               // (host never combines the list path with istride < B)
   const int b = p.b0 + bl;
@@ -623,9 +632,26 @@ __global__ void gat_dense_kernel(const GatParams p) {
       // the whole hop to land), and the Y rows are stored afterwards: a wait at the next head's top would also cover
       // these stores' write acknowledgements (loads and stores share vmcnt) - 5-7 k cycles per head.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (fuse_mean) {
+        const float invp = 1.f / (float)p.P;      // (the separate kernel divides by P as well: s / fp)
+        float* mrow = p.Ymean + ((long long)b * N + ws * rpw + grp) * p.ldym + VEC * sub;
+        const long long mstep = (long long)nwaves * rpw * p.ldym;
 #pragma unroll
-      for (int h = 0; h < HMAX; ++h)
-        if ((ws + h * nwaves) * rpw + grp < N) *reinterpret_cast<fvec*>(yrow + h * ystep) = ucur[h];
+        for (int h = 0; h < HMAX; ++h) {
+          ysum[h] = hh == 0 ? ucur[h] : ysum[h] + ucur[h];
+          if (hh == hpb - 1 && (ws + h * nwaves) * rpw + grp < N) {
+            fvec o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = fmaxf(ysum[h][e] / (float)p.P, 0.f);
+            *reinterpret_cast<fvec*>(mrow + h * mstep) = o;
+          }
+        }
+        (void)invp;
+      } else {
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+          if ((ws + h * nwaves) * rpw + grp < N) *reinterpret_cast<fvec*>(yrow + h * ystep) = ucur[h];
+      }
     }
   };
   if (!(p.skip & 2)) {
@@ -951,6 +977,16 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
   p.ldx = G; p.ldy = concat ? ldy : P * F; p.NC = ldz; p.lda_a = N | 1;
   p.qoff = L.qoff; p.uoff = L.uoff; p.c1off = L.c1off; p.c2off = L.c2off;
 
+  static int hpb_env = -1;
+  if (hpb_env < 0) { const char* e = getenv("MAGAT_GAT_HPB"); hpb_env = e ? atoi(e) : 0; }
+  auto hpb_for = [&](int cb) {
+    int h = 1;
+    if (G >= 64 && P > 1 && lds > 80 * 1024 && cb >= 256) h = P;
+    if (hpb_env > 0 && G >= 64 && P % hpb_env == 0) h = hpb_env;
+    return h;
+  };
+  bool all_fused = !concat && G >= 64 && !use_list;
+  for (int b0 = 0; b0 < B && all_fused; b0 += chunk) all_fused = hpb_for((B - b0) < chunk ? (B - b0) : chunk) == P;
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int cb = (B - b0) < chunk ? (B - b0) : chunk;
     int rc = magat_gat_maps_gemm(X + (size_t)b0 * N * G, packed, Z, cb * N, G, L.NC, ldz, stream);
@@ -969,12 +1005,12 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
     // heads per workgroup: when the LDS tiles allow only one workgroup per CU there is nothing to overlap a
     // workgroup's loads with, so one workgroup walks all P heads of its instance and prefetches the next head's
     // Q tile during the current head's compute; needs enough instances to fill the chip.
-    static int hpb_env = -1;
-    if (hpb_env < 0) { const char* e = getenv("MAGAT_GAT_HPB"); hpb_env = e ? atoi(e) : 0; }
-    int hpb = 1;
-    if (G >= 64 && P > 1 && lds > 80 * 1024 && cb >= 256) hpb = P;
-    if (hpb_env > 0 && G >= 64 && P % hpb_env == 0) hpb = hpb_env;
+    const int hpb = hpb_for(cb);
     p.hpb = hpb;
+    // mean merge fused into the graph kernel when one workgroup sees all heads of an instance (decided for the whole
+    // call: every chunk must qualify, otherwise the separate kernel merges everything from Ytmp)
+    p.Ymean = all_fused ? Y : nullptr;
+    p.ldym = ldy;
     // with one workgroup per CU (hpb == P case) the grid is capped at one workgroup per CU and every workgroup walks
     // several instances, prefetching across the instance boundary as well
     int inst_slots = (cb + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD;
@@ -992,7 +1028,7 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
     }
     if (rc != MAGAT_OK) return rc;
   }
-  if (!concat) {
+  if (!concat && !all_fused) {
     const long long M = (long long)B * N;
     long long blocks = (M * (F / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
