@@ -81,8 +81,9 @@ def per_agent_work(cfg, N, S_bytes):
     w[9] = (2 * nfm * G, 4 * (nfm + G), "mfma")
     w[10] = (2 * G * NC, 4 * (G + NC), "mfma")
     # graph kernel: SURVEY 8(d) "kernel (ii)" bytes per instance / N
-    w[11] = (0, (4 * (N * G + P * N * G + P * K * N * F + N * P * F) + S_bytes * N * N) / N, "hbm")
-    width = P * F + (nfm if cfg.bottleneckMode == "BottomNeck_skipConcat" else 0)
+    yw = P * F if cfg.AttentionConcat else F          # head-mean: one merged [N][F] row block is written
+    w[11] = (0, (4 * (N * G + P * N * G + P * K * N * F + N * yw) + S_bytes * N * N) / N, "hbm")
+    width = yw + (nfm if cfg.bottleneckMode == "BottomNeck_skipConcat" else 0)
     w[12] = (2 * width * 5, 4 * (width + 5), "hbm")
     return w
 
