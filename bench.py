@@ -62,8 +62,9 @@ def split_tags(cfg):
     return tags
 
 
-def per_agent_work(cfg, N, S_bytes):
-    """Algorithmic work per AGENT-STEP for each kernel tag: (flops, hbm_bytes, bound)."""
+def per_agent_work(cfg, N, S_bytes, deg=None):
+    """Algorithmic work per AGENT-STEP for each kernel tag: (flops, hbm_bytes, bound).  deg: mean out-degree, given
+    when the layer runs on the CSR kernels (N > 128 or bf16 storage)."""
     G, K, P = cfg.bottleneckFeature, cfg.nGraphFilterTaps, cfg.nAttentionHeads
     F = G
     nfm = cfg.numInputFeatures
@@ -83,6 +84,11 @@ def per_agent_work(cfg, N, S_bytes):
     # graph kernel: SURVEY 8(d) "kernel (ii)" bytes per instance / N
     yw = P * F if cfg.AttentionConcat else F          # head-mean: one merged [N][F] row block is written
     w[11] = (0, (4 * (N * G + P * N * G + P * K * N * F + N * yw) + S_bytes * N * N) / N, "hbm")
+    if deg is not None:
+        # CSR kernels: X, the hoisted maps Z and Y in the storage type (4 or 2 bytes), CSR + CSC index arrays, and the
+        # attention values written by the score kernel and read once per hop
+        es = 2 if getattr(cfg, "gat_storage", "fp32") == "bf16" else 4
+        w[11] = (0, es * (G + P * G + P * K * F + yw) + 4 * (2 + 3 * deg) + 4 * P * deg * K, "hbm")
     width = yw + (nfm if cfg.bottleneckMode == "BottomNeck_skipConcat" else 0)
     w[12] = (2 * width * 5, 4 * (width + 5), "hbm")
     return w
@@ -236,7 +242,8 @@ def main():
                                          "head-concat" if concat else "head-mean", B, B * world),
                           "global_batch": B * world, "agents": N, "parallelism": "instance-sharded x%d" % world}}
         if timing:
-            work = per_agent_work(cfg, N, 4)
+            csr = N > 128 or cfg.gat_storage == "bf16"
+            work = per_agent_work(cfg, N, 4, float((S != 0).sum().item()) / (B * N) if csr else None)
             TAG_OF = {v: k for k, v in nat.TAGS.items()}
             splits = split_tags(cfg)
             kernels, dom = {}, None
