@@ -214,6 +214,12 @@ typedef struct magat_conv_gemm_desc {
    * npix*128*C): everything a workgroup touches is one contiguous ~0.5-2 MB run instead of <= 121 pieces a
    * multi-MB plane stride apart (channel/TLB-aliasing hazard of the plane form on large batches). */
   int64_t in_tile_stride, in2_tile_stride, out_tile_stride;
+  /* Granule-major agent tiles (float32 operands only): inside its 128-agent tile, element (m, c) of a pixel lives at
+   * ((c / 4) * 128 + (m % 128)) * 4 + c % 4 instead of (m % 128) * ld + c - the 16-byte channel quads of the 128
+   * agents are contiguous, which is how one MFMA fragment lane per agent wants to load and store them (512-byte runs
+   * per half wave).  in_gl covers in AND in2; tiles keep their size (ld = channel count).  Taken by the f16x3
+   * direct kernel only (in_fmt 4, out_fmt 0; anything else returns MAGAT_ERR_UNSUPPORTED). */
+  int in_gl, out_gl;
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 

@@ -43,7 +43,8 @@ class ConvGemmDesc(ctypes.Structure):
                 ("in_plane_stride", ctypes.c_int64), ("in2_plane_stride", ctypes.c_int64),
                 ("out_plane_stride", ctypes.c_int64),
                 ("in_tile_stride", ctypes.c_int64), ("in2_tile_stride", ctypes.c_int64),
-                ("out_tile_stride", ctypes.c_int64)]
+                ("out_tile_stride", ctypes.c_int64),
+                ("in_gl", ctypes.c_int), ("out_gl", ctypes.c_int)]
 
 
 class EncoderDesc(ctypes.Structure):

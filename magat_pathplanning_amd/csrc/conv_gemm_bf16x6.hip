@@ -46,6 +46,7 @@ struct SplitParams {
   int C2, lda2, W2, stride2;
   int Cout, Ktot, ldc, relu;
   int ntn, npix, tag, out_split;
+  int in_gl, out_gl;        // direct kernel: granule-major agent tiles [C/4][128][4] for in/in2 resp. out
   const float* acc_scale;   // NPL == 2: device pointer to 1 / (power-of-two weight scale), applied before the bias
 };
 
@@ -392,7 +393,206 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
   }
 }
 
+// ---- f16x3, activations straight into registers ("direct" flavour; in_fmt 4, out_fmt 0) --------------------------------
+// The 2x2 kernel above moves every operand byte VGPR -> LDS -> VGPR; on gfx950 the VGPR -> LDS store path runs at only
+// ~80 B/clk/CU, so with three f16 MFMAs per product the LDS (656 cycles per 128x128x32 slab) sits next to the MFMA pipe
+// (768) and the two barely overlap.  Here the four waves split the tile by ROWS (wave tile 32 x BN): a wave's activation
+// fragment is needed by nobody else, so it goes global -> registers -> f16 planes -> MFMA operand and never touches LDS;
+// the weight slab is needed by all four waves and travels global -> LDS with the LDS-direct load (no VGPRs, no
+// ds_write), double-buffered, ONE barrier per slab with no stores inside it.  LDS traffic per slab: 64 KB of
+// ds_read_b128 (256 B/clk) + the 16 KB DMA fill instead of + 32 KB of ds_write.
+template <int BN>
+__global__ __launch_bounds__(256, 3) void conv_gemm_f16x3_direct_kernel(const SplitParams p) {
+  constexpr int TN = BN / 32;
+  constexpr int STAGE = 2 * BN * 64;                    // bytes per weight stage: two planes of BN rows x 64 B
+  __shared__ __attribute__((aligned(1024))) char Bs[2 * STAGE];
+
+  const int bid = blockIdx.x;
+  const int xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
+  const int per_m = p.npix * p.ntn;
+  const int mtile = xcd + MAGAT_NUM_XCD * (slot / per_m);
+  if (mtile >= p.Mt) return;
+  const int rem = slot % per_m;
+  const int pix = rem / p.ntn, ntile = rem % p.ntn;
+  const int m0 = mtile * BM, n0 = ntile * BN;
+  const int oy = pix / p.Wout, ox = pix % p.Wout;
+  const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+  const int ty0 = iy0 < 0 ? -iy0 : 0, tx0 = ix0 < 0 ? -ix0 : 0;
+  const int ty1 = min(p.kH, p.Hin - iy0), tx1 = min(p.kW, p.Win - ix0);
+  const int ntaps = (ty1 - ty0) * (tx1 - tx0);
+  const int spt = p.Cin / BK, spt2 = p.C2 / BK;
+  const int nslab = ntaps * spt + spt2;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // activation fragment of this lane: row m, floats k = 16 ks + 8 fh .. +7 of every slab (rows past M clamped)
+  // Granule-major tiles (in_gl: [C/4][128 agents][4 floats]) make every one of those 16-byte loads land next to its
+  // neighbour lanes' (32 agents x 16 B = 512 contiguous bytes per half wave) instead of one 64-B line per lane pair.
+  const int mrow = min(m0 + 32 * wave + fr, p.M - 1);
+  const unsigned aoff = p.in_gl ? (unsigned)(((mrow >> 7) * p.in_tile + (2 * fh * 128 + (mrow & 127)) * 4) * 4)
+                                : (unsigned)((magat_row_off(mrow, p.lda, p.in_tile) + 8 * fh) * 4);
+  const unsigned aoff2 = p.in_gl ? (unsigned)(((mrow >> 7) * p.in2_tile + (2 * fh * 128 + (mrow & 127)) * 4) * 4)
+                                 : (unsigned)((magat_row_off(mrow, p.lda2, p.in2_tile) + 8 * fh) * 4);
+  const int kmul = p.in_gl ? 512 : 4;                   // bytes per unit of k0 (k0 % 32 == 0)
+  const int di = p.in_gl ? 2048 : 16, dks = p.in_gl ? 8192 : 64;
+
+  // weight slab pieces (1 KB = 16 rows x 64 B of one plane) this wave copies: piece id = wave + 4 i; lane -> LDS bytes
+  // [16 lane, +16) of the piece, i.e. row lane/4, chunk slot lane%4, which holds k chunk slot ^ ((row>>2)&3)
+  long long boff[TN];
+  unsigned bm0[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int id = wave + 4 * i;
+    const int plane = id / (BN / 16), row = (id % (BN / 16)) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    boff[i] = ((long long)plane * p.wt_plane + (long long)(n0 + row) * p.Ktot + c * 8) * 2;
+    bm0[i] = (unsigned)(uintptr_t)Bs + (unsigned)id * 1024u;
+  }
+
+  int cur_ty = ty0, cur_tx = tx0, cur_ks = 0;
+  bool cur_main = ntaps > 0;
+  auto tap_base = [&](int ty, int tx) -> const char* {
+    return reinterpret_cast<const char*>(p.in) + (long long)((iy0 + ty) * p.Win + (ix0 + tx)) * p.in_pix_stride * 4;
+  };
+  const char* cur_tap = tap_base(ty0, tx0);
+  const char* const seg2_base = reinterpret_cast<const char*>(p.in2) +
+                                (long long)(oy * p.stride2 * p.W2 + ox * p.stride2) * p.in2_pix_stride * 4;
+  const char* const wtb = reinterpret_cast<const char*>(p.wt);
+
+  f32x4 fa32[4];
+  // issue the loads of the next slab: weight pieces -> LDS stage `stage`, activation floats -> fa32
+  auto load_slab = [&](int stage) {
+    const bool main_seg = cur_main;
+    const int k0 = cur_ks * BK;
+    const char* ab;
+    int bk;
+    if (main_seg) {
+      ab = cur_tap + (long long)k0 * kmul;
+      bk = (cur_ty * p.kW + cur_tx) * p.Cin + k0;
+      if (++cur_ks == spt) {
+        cur_ks = 0;
+        if (++cur_tx == tx1) {
+          cur_tx = tx0;
+          if (++cur_ty == ty1) cur_main = false;
+        }
+        if (cur_main) cur_tap = tap_base(cur_ty, cur_tx);
+      }
+    } else {
+      ab = seg2_base + (long long)k0 * kmul;
+      bk = p.kH * p.kW * p.Cin + k0;
+      ++cur_ks;
+    }
+    const char* bb = wtb + (long long)bk * 2;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const char* src = bb + boff[i];
+      const unsigned m0v = __builtin_amdgcn_readfirstlane(bm0[i] + (unsigned)stage * (unsigned)STAGE);
+      asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+    }
+    const unsigned sel = main_seg ? 0xffffffffu : 0u;
+    const char* a = ab + (aoff2 + ((aoff - aoff2) & sel));
+    fa32[0] = *reinterpret_cast<const f32x4*>(a);
+    fa32[1] = *reinterpret_cast<const f32x4*>(a + di);
+    fa32[2] = *reinterpret_cast<const f32x4*>(a + dks);
+    fa32[3] = *reinterpret_cast<const f32x4*>(a + dks + di);
+  };
+  u32x4 qa[2][2];                                       // [k step][plane]: the lane's 8 k values as packed f16
+  auto split_regs = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      unsigned h1[4], h2[4];
+      split_pair_f16(fa32[2 * ks][0], fa32[2 * ks][1], h1[0], h2[0]);
+      split_pair_f16(fa32[2 * ks][2], fa32[2 * ks][3], h1[1], h2[1]);
+      split_pair_f16(fa32[2 * ks + 1][0], fa32[2 * ks + 1][1], h1[2], h2[2]);
+      split_pair_f16(fa32[2 * ks + 1][2], fa32[2 * ks + 1][3], h1[3], h2[3]);
+      qa[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
+      qa[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
+    }
+  };
+  auto landed = [&]() {            // this wave's pieces are in LDS; then everybody's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  if (nslab > 0) {
+    load_slab(0);
+    split_regs();
+    landed();
+  }
+  for (int s = 0; s < nslab; ++s) {
+    if (s + 1 < nslab) load_slab((s + 1) & 1);
+    const char* bst = Bs + (s & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 fb[TN][2];
+      const int c = 2 * ks + fh;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = j * 32 + fr;
+          fb[j][pl] = *reinterpret_cast<const u32x4*>(bst + pl * (BN * 64) + (row * 4 + (c ^ ((row >> 2) & 3))) * 16);
+        }
+      constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};     // h1g1 h1g2 h2g1 (activation plane, weight plane)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j][PB[q]]),
+                                                          __builtin_bit_cast(f16x8, qa[ks][PA[q]]), acc[j], 0, 0, 0);
+    }
+    if (s + 1 < nslab) {
+      split_regs();
+      landed();
+    }
+  }
+
+  // epilogue: D[channel][agent]; agent = lane&31, channel = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool vec = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
+  const float acc_scale = *p.acc_scale;
+  const int m = m0 + 32 * wave + fr;
+  if (m >= p.M) return;
+  float* const orow = static_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +
+                      (p.out_gl ? (m >> 7) * p.out_tile + (m & 127) * 4 : magat_row_off(m, p.ldc, p.out_tile));
+  const int nmul = p.out_gl ? 128 : 1;                  // granule-major: channel quad n/4 is 128 agents x 4 floats away
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nb = n0 + j * 32 + 4 * fh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = nb + 8 * q;
+      float v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        v[c] = acc[j][4 * q + c] * acc_scale + (p.bias ? p.bias[n + c] : 0.f);
+        if (p.relu) v[c] = fmaxf(v[c], 0.f);
+      }
+      if (vec) {
+        *reinterpret_cast<f32x4*>(orow + (long long)n * nmul) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) orow[(long long)n * nmul + c] = v[c];
+      }
+    }
+  }
+}
+
 }  // namespace
+
+// MAGAT_CONV_DIRECT=0 keeps f16x3 (in_fmt 4, out_fmt 0) on the 2x2 LDS-staged kernel
+int magat_conv_direct_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MAGAT_CONV_DIRECT"); v = e ? atoi(e) : 1; }
+  return v;
+}
 
 // in_fmt 5: like 4, but in/in2 arrive as the two f16 planes already (written by a producer with out_fmt 3): no split work.
 // in_fmt 4: in/in2 float32 split on load into two f16 planes, wt = [2][Cout][Ktot] f16 planes of (weight * 2^e) followed
@@ -427,6 +627,7 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.Cout = d->Cout; p.Ktot = d->kH * d->kW * d->Cin + d->C2; p.ldc = d->ldc; p.relu = d->relu;
   p.wt_plane = (long long)p.Cout * p.Ktot;
   p.npix = d->Hout * d->Wout; p.tag = d->tag; p.out_split = d->out_fmt;
+  p.in_gl = d->in_gl; p.out_gl = d->out_gl;
   p.Mt = (p.M + BM - 1) / BM;
   p.ntn = p.Cout / BN;
   if (magat_row_off(p.M, p.lda, p.in_tile) * 4 >= 0xffffffffLL ||
@@ -456,7 +657,13 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
     else                                                                                                            \
       hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<false, BNV, WM, WN>), dim3((unsigned)grid), dim3(256), 0, st, p); \
   } while (0)
-  if (BN == 128) MAGAT_SPLIT_LAUNCH(128, 2, 2);
+  const int direct = magat_conv_direct_enabled();
+  if ((d->in_gl || d->out_gl) && !(d->in_fmt == 4 && d->out_fmt == 0 && direct)) return MAGAT_ERR_UNSUPPORTED;
+  if (d->in_fmt == 4 && d->out_fmt == 0 && direct) {
+    if (BN == 128) hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<128>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else if (BN == 64) hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<64>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<32>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  } else if (BN == 128) MAGAT_SPLIT_LAUNCH(128, 2, 2);
   else if (BN == 64) MAGAT_SPLIT_LAUNCH(64, 2, 2);
   else MAGAT_SPLIT_LAUNCH(32, 4, 1);
 #undef MAGAT_SPLIT_LAUNCH

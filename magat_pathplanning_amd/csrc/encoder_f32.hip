@@ -21,7 +21,7 @@ template <int HC, int WC>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          int M, int Hr, int Wr, long long out_pix_stride,
-                                                         long long out_tile_stride, long long out_plane) {
+                                                         long long out_tile_stride, long long out_plane, int out_gl) {
   extern __shared__ float img[];
   const int H = HC ? HC : Hr, W = WC ? WC : Wr;
   const int PW = W + 2, PHW = (H + 2) * PW;
@@ -108,12 +108,18 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
     const int agent = m0 + (lane & 31);
     if (agent < M) {
       float* o = out + (long long)pix * out_pix_stride + magat_row_off(agent, 32, out_tile_stride) + 4 * (lane >> 5);
+      // granule-major tile ([8 channel quads][128 agents][4], magat_hip.h in_gl/out_gl): quad 2q + (lane>>5) of agent
+      // a sits next to its neighbour agents' -> 512-byte runs per half wave and store
+      float* og = out + (long long)pix * out_pix_stride + (long long)(agent >> 7) * out_tile_stride +
+                  ((lane >> 5) * 128 + (agent & 127)) * 4;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 v;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[4 * q + c] + bch[q][c], 0.f);
-        if (out_plane == 0) {
+        if (out_gl) {
+          *reinterpret_cast<f32x4*>(og + q * 1024) = v;
+        } else if (out_plane == 0) {
           *reinterpret_cast<f32x4*>(o + 8 * q) = v;
         } else {      // two f16 planes (operand format of the f16x3 convs, conv_gemm_bf16x6.hip in_fmt 5)
           typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -151,7 +157,8 @@ struct BlockShape {
 }  // namespace
 
 static int conv_first_launch(const float* x, const float* wt, const float* bias, float* out, int M, int H, int W,
-                             long long pix_stride, long long tile_stride, void* stream, long long out_plane = 0);
+                             long long pix_stride, long long tile_stride, void* stream, long long out_plane = 0,
+                             int out_gl = 0);
 
 extern "C" int magat_conv_first_f32(const float* x, const float* wt, const float* bias, float* out, int M, int H,
                                     int W, void* stream) {
@@ -165,7 +172,7 @@ extern "C" int magat_conv_first_tiled_f32(const float* x, const float* wt, const
 }
 
 static int conv_first_launch(const float* x, const float* wt, const float* bias, float* out, int M, int H, int W,
-                             long long pix_stride, long long tile_stride, void* stream, long long out_plane) {
+                             long long pix_stride, long long tile_stride, void* stream, long long out_plane, int out_gl) {
   if (!x || !wt || !bias || !out) return MAGAT_ERR_NULL;
   if (M <= 0 || H <= 0 || W <= 0) return MAGAT_ERR_BAD_SHAPE;
   const size_t lds = sizeof(float) * 32 * (size_t)((3 * (H + 2) * (W + 2)) | 1);
@@ -175,10 +182,10 @@ static int conv_first_launch(const float* x, const float* wt, const float* bias,
   const int pid = magat_prof_begin(MAGAT_TAG_CONV_FIRST, st);
   if (H == 11 && W == 11 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
     hipLaunchKernelGGL((conv_first_kernel<11, 11>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W,
-                       pix_stride, tile_stride, out_plane);
+                       pix_stride, tile_stride, out_plane, out_gl);
   else
     hipLaunchKernelGGL((conv_first_kernel<0, 0>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W,
-                       pix_stride, tile_stride, out_plane);
+                       pix_stride, tile_stride, out_plane, out_gl);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
@@ -312,12 +319,17 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   // (a tensor-sized plane stride measured 10 % slower: everything a workgroup touches should stay one contiguous run)
   auto planes = [&](int npix, int c) { return (int64_t)npix * MAGAT_TILE_ROWS * c; };
   auto ptiles = [&](int npix, int c) { return (int64_t)2 * npix * MAGAT_TILE_ROWS * c; };
+  // Granule-major activation tiles ([C/4][128 agents][4], magat_hip.h in_gl/out_gl) between the layers when every
+  // BasicBlock conv runs on the f16x3 direct kernel: its one-lane-per-agent fragment loads and epilogue stores are then
+  // 512-byte runs.  The last conv2 writes row-major tiles again for the pooled head (fp32 MFMA kernel).
+  bool gl = !chain && split == (1 << nblocks) - 1 && magat_conv_direct_enabled();
+  for (int l = 0; l < nblocks; ++l) gl = gl && enc_use_f16(d, l);
   for (int m0 = 0; m0 < M; m0 += mc) {
     const int mm = (M - m0) < mc ? (M - m0) : mc;
     int rc = conv_first_launch(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W,
                                (long long)MAGAT_TILE_ROWS * 32,
                                chain ? (long long)ptiles(H * W, 32) : (long long)H * W * MAGAT_TILE_ROWS * 32, stream,
-                               chain ? planes(H * W, 32) : 0);
+                               chain ? planes(H * W, 32) : 0, gl ? 1 : 0);
     if (rc != MAGAT_OK) return rc;
     int cur = 0;              // buffer holding the block input
     int hin = H, win = W;
@@ -342,6 +354,7 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
           g.in_tile_stride = ptiles(hin * win, s.cin); g.out_tile_stride = ptiles(hout * wout, s.cout);
         }
       }
+      g.in_gl = g.out_gl = gl ? 1 : 0;
       rc = magat_conv_gemm_f32(&g, stream);
       if (rc != MAGAT_OK) return rc;
       // conv2 + bn2 + (1x1 strided downsample + bn) + relu
@@ -366,6 +379,7 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
           if (l + 1 < nblocks) h.out_tile_stride = ptiles(hout * wout, s.cout);
         }
       }
+      h.in_gl = gl ? 1 : 0; h.out_gl = gl && l + 1 < nblocks ? 1 : 0;
       rc = magat_conv_gemm_f32(&h, stream);
       if (rc != MAGAT_OK) return rc;
       cur = nxt; hin = hout; win = wout;

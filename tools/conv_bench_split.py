@@ -16,9 +16,19 @@ for name, cin, cout, c2 in (("l3.conv1", 64, 128, 0), ("l3.conv2+ds", 128, 128, 
         t = t.clamp(-65504.0, 65504.0)
         h1 = t.half()
         return torch.stack((h1, (t - h1.float()).half())).contiguous()
-    for fmt in (0, 1, 2, 4, 5):
+    def to_gl(t):     # [36][M][C] row-major -> granule-major agent tiles [36][M/128][C/4][128][4]
+        return t.view(36, M // 128, 128, t.shape[-1] // 4, 4).permute(0, 1, 3, 2, 4).contiguous()
+    def from_gl(t, c):
+        return t.view(36, M // 128, c // 4, 128, 4).permute(0, 1, 3, 2, 4).reshape(36, M, c)
+    for fmt in (0, 1, 2, 4, 5, 6, 7, 8):
         d = nat.ConvGemmDesc()
+        gl = fmt >= 6
+        gli, glo = fmt in (6, 7), fmt in (6, 8)
+        ofmt = fmt
+        if gl: fmt = 4
         xs = split_bf16x3(x) if fmt == 1 else (f16_planes(x) if fmt == 5 else x); x2s = split_bf16x3(x2) if fmt == 1 else (f16_planes(x2) if fmt == 5 else x2)
+        if gli: xs, x2s, d.in_gl = to_gl(x), to_gl(x2), 1
+        if glo: d.out_gl = 1
         ws = w if fmt == 0 else (split_f16x2(w)[0].to(dev) if fmt >= 4 else split_bf16x3(w))
         out = torch.empty(36, M, cout, device=dev)
         d.inp, d.wt, d.bias, d.out = xs.data_ptr(), ws.data_ptr(), b.data_ptr(), out.data_ptr()
@@ -34,9 +44,11 @@ for name, cin, cout, c2 in (("l3.conv1", 64, 128, 0), ("l3.conv2+ds", 128, 128, 
             e0.record(); nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), st), name); e1.record()
             torch.cuda.synchronize()
             if r >= 2: ts.append(e0.elapsed_time(e1) * 1e3)
-        ts.sort(); res[fmt] = (ts[len(ts) // 2], out.clone())
+        ts.sort(); res[ofmt] = (ts[len(ts) // 2], from_gl(out, cout).clone() if glo else out.clone())
     fl = 2.0 * M * (taps() * cin * cout + 36 * c2 * cout)
     ref64 = None
+    print("%-12s f16x3 direct: gl-in only %8.1f us (%s)   gl-out only %8.1f us (%s)" % (name, res[7][0], bool(torch.equal(res[4][1], res[7][1])), res[8][0], bool(torch.equal(res[4][1], res[8][1]))))
+    print("%-12s f16x3 granule-major tiles %8.1f us (%.1f TF-equiv), identical to row-major: %s" % (name, res[6][0], 2.0 * M * (taps() * cin * cout + 36 * c2 * cout) / res[6][0] / 1e6, bool(torch.equal(res[4][1], res[6][1]))))
     print("%-12s fp32 %8.1f us (%.1f TF)   bf16x6 planes %8.1f us (%.2fx)   bf16x6 split-on-load %8.1f us (%.1f TF-equiv, %.2fx)   f16x3 %8.1f us (%.1f TF-equiv, %.2fx)   f16x3 planes-in %8.1f us (%.2fx, identical output: %s)   max|diff vs fp32 kernel| %.2e %.2e %.2e  (out scale %.2f)" % (
         name, res[0][0], fl / res[0][0] / 1e6, res[1][0], res[0][0] / res[1][0], res[2][0], fl / res[2][0] / 1e6,
         res[0][0] / res[2][0], res[4][0], fl / res[4][0] / 1e6, res[0][0] / res[4][0],
