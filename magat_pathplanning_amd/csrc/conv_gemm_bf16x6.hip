@@ -401,8 +401,10 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 // the weight slab is needed by all four waves and travels global -> LDS with the LDS-direct load (no VGPRs, no
 // ds_write), double-buffered, ONE barrier per slab with no stores inside it.  LDS traffic per slab: 64 KB of
 // ds_read_b128 (256 B/clk) + the 16 KB DMA fill instead of + 32 KB of ds_write.
-template <int BN>
-__global__ __launch_bounds__(256, 3) void conv_gemm_f16x3_direct_kernel(const SplitParams p) {
+// TM = 32-agent row groups per wave (workgroup tile 128 TM agents x BN): TM = 2 halves the weight traffic (L2 -> LDS
+// fill and ds_read per MFMA) at 2 instead of 3 waves per SIMD.
+template <int BN, int TM>
+__global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_kernel(const SplitParams p) {
   constexpr int TN = BN / 32;
   constexpr int STAGE = 2 * BN * 64;                    // bytes per weight stage: two planes of BN rows x 64 B
   __shared__ __attribute__((aligned(1024))) char Bs[2 * STAGE];
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f16x3_direct_kernel(const Sp
   if (mtile >= p.Mt) return;
   const int rem = slot % per_m;
   const int pix = rem / p.ntn, ntile = rem % p.ntn;
-  const int m0 = mtile * BM, n0 = ntile * BN;
+  const int m0 = mtile * (BM * TM), n0 = ntile * BN;
   const int oy = pix / p.Wout, ox = pix % p.Wout;
   const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
   const int ty0 = iy0 < 0 ? -iy0 : 0, tx0 = ix0 < 0 ? -ix0 : 0;
@@ -427,20 +429,26 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f16x3_direct_kernel(const Sp
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int fr = lane & 31, fh = lane >> 5;
 
-  f32x16 acc[TN];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // activation fragment of this lane: row m, floats k = 16 ks + 8 fh .. +7 of every slab (rows past M clamped)
   // Granule-major tiles (in_gl: [C/4][128 agents][4 floats]) make every one of those 16-byte loads land next to its
   // neighbour lanes' (32 agents x 16 B = 512 contiguous bytes per half wave) instead of one 64-B line per lane pair.
-  const int mrow = min(m0 + 32 * wave + fr, p.M - 1);
-  const unsigned aoff = p.in_gl ? (unsigned)(((mrow >> 7) * p.in_tile + (2 * fh * 128 + (mrow & 127)) * 4) * 4)
-                                : (unsigned)((magat_row_off(mrow, p.lda, p.in_tile) + 8 * fh) * 4);
-  const unsigned aoff2 = p.in_gl ? (unsigned)(((mrow >> 7) * p.in2_tile + (2 * fh * 128 + (mrow & 127)) * 4) * 4)
-                                 : (unsigned)((magat_row_off(mrow, p.lda2, p.in2_tile) + 8 * fh) * 4);
+  unsigned aoff[TM], aoff2[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int mrow = min(m0 + 32 * (TM * wave + i) + fr, p.M - 1);
+    aoff[i] = p.in_gl ? (unsigned)(((mrow >> 7) * p.in_tile + (2 * fh * 128 + (mrow & 127)) * 4) * 4)
+                      : (unsigned)((magat_row_off(mrow, p.lda, p.in_tile) + 8 * fh) * 4);
+    aoff2[i] = p.in_gl ? (unsigned)(((mrow >> 7) * p.in2_tile + (2 * fh * 128 + (mrow & 127)) * 4) * 4)
+                       : (unsigned)((magat_row_off(mrow, p.lda2, p.in2_tile) + 8 * fh) * 4);
+  }
   const int kmul = p.in_gl ? 512 : 4;                   // bytes per unit of k0 (k0 % 32 == 0)
   const int di = p.in_gl ? 2048 : 16, dks = p.in_gl ? 8192 : 64;
 
@@ -467,7 +475,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f16x3_direct_kernel(const Sp
                                 (long long)(oy * p.stride2 * p.W2 + ox * p.stride2) * p.in2_pix_stride * 4;
   const char* const wtb = reinterpret_cast<const char*>(p.wt);
 
-  f32x4 fa32[4];
+  f32x4 fa32[TM][4];
   // issue the loads of the next slab: weight pieces -> LDS stage `stage`, activation floats -> fa32
   auto load_slab = [&](int stage) {
     const bool main_seg = cur_main;
@@ -491,34 +499,44 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f16x3_direct_kernel(const Sp
       ++cur_ks;
     }
     const char* bb = wtb + (long long)bk * 2;
+    const unsigned sel = main_seg ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const char* a = ab + (aoff2[i] + ((aoff[i] - aoff2[i]) & sel));
+      fa32[i][0] = *reinterpret_cast<const f32x4*>(a);
+      fa32[i][1] = *reinterpret_cast<const f32x4*>(a + di);
+      fa32[i][2] = *reinterpret_cast<const f32x4*>(a + dks);
+      fa32[i][3] = *reinterpret_cast<const f32x4*>(a + dks + di);
+    }
+    // (the LDS-direct loads go out AFTER the register loads: vmcnt retires in order, so the compiler's waits for the
+    // activation registers - it cannot see the asm loads - never include the weight fill)
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       const char* src = bb + boff[i];
       const unsigned m0v = __builtin_amdgcn_readfirstlane(bm0[i] + (unsigned)stage * (unsigned)STAGE);
       asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
     }
-    const unsigned sel = main_seg ? 0xffffffffu : 0u;
-    const char* a = ab + (aoff2 + ((aoff - aoff2) & sel));
-    fa32[0] = *reinterpret_cast<const f32x4*>(a);
-    fa32[1] = *reinterpret_cast<const f32x4*>(a + di);
-    fa32[2] = *reinterpret_cast<const f32x4*>(a + dks);
-    fa32[3] = *reinterpret_cast<const f32x4*>(a + dks + di);
   };
-  u32x4 qa[2][2];                                       // [k step][plane]: the lane's 8 k values as packed f16
+  u32x4 qa[TM][2][2];                                   // [row group][k step][plane]: the lane's 8 k values as packed f16
   auto split_regs = [&]() {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      unsigned h1[4], h2[4];
-      split_pair_f16(fa32[2 * ks][0], fa32[2 * ks][1], h1[0], h2[0]);
-      split_pair_f16(fa32[2 * ks][2], fa32[2 * ks][3], h1[1], h2[1]);
-      split_pair_f16(fa32[2 * ks + 1][0], fa32[2 * ks + 1][1], h1[2], h2[2]);
-      split_pair_f16(fa32[2 * ks + 1][2], fa32[2 * ks + 1][3], h1[3], h2[3]);
-      qa[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
-      qa[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
-    }
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        unsigned h1[4], h2[4];
+        split_pair_f16(fa32[i][2 * ks][0], fa32[i][2 * ks][1], h1[0], h2[0]);
+        split_pair_f16(fa32[i][2 * ks][2], fa32[i][2 * ks][3], h1[1], h2[1]);
+        split_pair_f16(fa32[i][2 * ks + 1][0], fa32[i][2 * ks + 1][1], h1[2], h2[2]);
+        split_pair_f16(fa32[i][2 * ks + 1][2], fa32[i][2 * ks + 1][3], h1[3], h2[3]);
+        qa[i][ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
+        qa[i][ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
+      }
   };
   auto landed = [&]() {            // this wave's pieces are in LDS; then everybody's
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the builtin, not inline asm: the compiler's waitcnt bookkeeping then knows that none of ITS loads is pending
+    // either - with an opaque asm wait it guarded the reuse of the activation registers with a vmcnt(0) placed right
+    // behind the next slab's LDS-direct loads, i.e. every wave sat out the weight fill before its MFMAs)
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt/lgkmcnt untouched
     __syncthreads();
   };
 
@@ -543,11 +561,17 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f16x3_direct_kernel(const Sp
         }
       constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};     // h1g1 h1g2 h2g1 (activation plane, weight plane)
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+#ifndef MAGAT_EXP_NQ
+#define MAGAT_EXP_NQ 3
+#endif
+      for (int q = 0; q < MAGAT_EXP_NQ; ++q)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j][PB[q]]),
-                                                          __builtin_bit_cast(f16x8, qa[ks][PA[q]]), acc[j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j][PB[q]]),
+                                                               __builtin_bit_cast(f16x8, qa[i][ks][PA[q]]), acc[i][j],
+                                                               0, 0, 0);
     }
     if (s + 1 < nslab) {
       split_regs();
@@ -555,31 +579,49 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f16x3_direct_kernel(const Sp
     }
   }
 
-  // epilogue: D[channel][agent]; agent = lane&31, channel = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // epilogue: D[channel][agent]; agent = lane&31, channel = (r&3) + 8*(r>>2) + 4*(lane>>5).  The lane's 4 TN bias quads
+  // are fetched as ONE batch of 16-byte loads (per-channel conditional loads cost one L2 round trip per quad).
   const bool vec = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
   const float acc_scale = *p.acc_scale;
-  const int m = m0 + 32 * wave + fr;
-  if (m >= p.M) return;
-  float* const orow = static_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +
-                      (p.out_gl ? (m >> 7) * p.out_tile + (m & 127) * 4 : magat_row_off(m, p.ldc, p.out_tile));
-  const int nmul = p.out_gl ? 128 : 1;                  // granule-major: channel quad n/4 is 128 agents x 4 floats away
+  f32x4 bq[TN][4];
+  if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int nb = n0 + j * 32 + 4 * fh;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = nb + 8 * q;
-      float v[4];
+      for (int q = 0; q < 4; ++q) bq[j][q] = *reinterpret_cast<const f32x4*>(p.bias + n0 + j * 32 + 4 * fh + 8 * q);
+  } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        v[c] = acc[j][4 * q + c] * acc_scale + (p.bias ? p.bias[n + c] : 0.f);
-        if (p.relu) v[c] = fmaxf(v[c], 0.f);
-      }
-      if (vec) {
-        *reinterpret_cast<f32x4*>(orow + (long long)n * nmul) = f32x4{v[0], v[1], v[2], v[3]};
-      } else {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) orow[(long long)n * nmul + c] = v[c];
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bq[j][q][c] = p.bias ? p.bias[n0 + j * 32 + 4 * fh + 8 * q + c] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + 32 * (TM * wave + i) + fr;
+    if (m >= p.M) continue;
+    float* const orow = static_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +
+                        (p.out_gl ? (m >> 7) * p.out_tile + (m & 127) * 4 : magat_row_off(m, p.ldc, p.out_tile));
+    const int nmul = p.out_gl ? 128 : 1;                // granule-major: channel quad n/4 is 128 agents x 4 floats away
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + j * 32 + 4 * fh;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = nb + 8 * q;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          v[c] = acc[i][j][4 * q + c] * acc_scale + bq[j][q][c];
+          if (p.relu) v[c] = fmaxf(v[c], 0.f);
+        }
+        if (vec) {
+          *reinterpret_cast<f32x4*>(orow + (long long)n * nmul) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) orow[(long long)n * nmul + c] = v[c];
+        }
       }
     }
   }
@@ -660,9 +702,23 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   const int direct = magat_conv_direct_enabled();
   if ((d->in_gl || d->out_gl) && !(d->in_fmt == 4 && d->out_fmt == 0 && direct)) return MAGAT_ERR_UNSUPPORTED;
   if (d->in_fmt == 4 && d->out_fmt == 0 && direct) {
-    if (BN == 128) hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<128>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    else if (BN == 64) hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<64>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<32>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    static int tm2 = -1;       // MAGAT_CONV_TM=1: one 32-agent row group per wave everywhere
+    if (tm2 < 0) { const char* e = getenv("MAGAT_CONV_TM"); tm2 = e ? atoi(e) : 2; }
+    const bool two = tm2 >= 2 && (long long)(p.Mt / 2) * p.npix * p.ntn >= 2048;   // enough 256-agent tiles to fill the chip
+    const long long mt = two ? (p.Mt + 1) / 2 : p.Mt;
+    const long long g2 = (mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD * p.npix * p.ntn;
+    p.Mt = (int)mt;
+#define MAGAT_DIRECT_LAUNCH(BNV)                                                                                     \
+  do {                                                                                                              \
+    if (two)                                                                                                        \
+      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2>), dim3((unsigned)g2), dim3(256), 0, st, p);         \
+    else                                                                                                            \
+      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1>), dim3((unsigned)g2), dim3(256), 0, st, p);         \
+  } while (0)
+    if (BN == 128) MAGAT_DIRECT_LAUNCH(128);
+    else if (BN == 64) MAGAT_DIRECT_LAUNCH(64);
+    else MAGAT_DIRECT_LAUNCH(32);
+#undef MAGAT_DIRECT_LAUNCH
   } else if (BN == 128) MAGAT_SPLIT_LAUNCH(128, 2, 2);
   else if (BN == 64) MAGAT_SPLIT_LAUNCH(64, 2, 2);
   else MAGAT_SPLIT_LAUNCH(32, 4, 1);
