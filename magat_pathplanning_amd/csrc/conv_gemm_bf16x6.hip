@@ -316,6 +316,20 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
   const bool vec = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (p.out_plane & 3) == 0;
   float acc_scale = 1.f;
   if constexpr (NPL == 2) acc_scale = *p.acc_scale;
+  f32x4 bq[TN][4];          // the lane's bias quads, fetched as one batch (not one L2 round trip per quad)
+  const bool bvec = p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + wn * WTN + j * 32 + 4 * (lane >> 5) + 8 * q;
+      if (bvec) {
+        bq[j][q] = *reinterpret_cast<const f32x4*>(p.bias + n);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bq[j][q][c] = p.bias ? p.bias[n + c] : 0.f;
+      }
+    }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nb = n0 + wn * WTN + j * 32 + 4 * (lane >> 5);
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
         for (int c = 0; c < 4; ++c) {
           float av = acc[i][j][4 * q + c];
           if constexpr (NPL == 2) av *= acc_scale;
-          v[c] = av + (p.bias ? p.bias[n + c] : 0.f);
+          v[c] = av + bq[j][q][c];
           if (p.relu) v[c] = fmaxf(v[c], 0.f);
         }
         const long long o = (long long)pix * p.out_pix_stride + magat_row_off(m, p.ldc, p.out_tile) + n;

@@ -258,6 +258,22 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
   float* obase = p.out + (long long)pix * p.out_pix_stride;
   unsigned short* sbase = reinterpret_cast<unsigned short*>(p.out) + (long long)pix * p.out_pix_stride;
   const bool vec = FULL && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (p.out_plane & 3) == 0;
+  // the lane's bias values first, as one batch of loads (a conditional load per channel inside the store loop costs
+  // one L2 round trip per channel quad)
+  f32x4 bq[TN][4];
+  const bool bvec = p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && n0 + BN <= p.Cout;
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + wn * WTN + j * 32 + 4 * (lane >> 5) + 8 * q;
+      if (bvec) {
+        bq[j][q] = *reinterpret_cast<const f32x4*>(p.bias + n);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bq[j][q][c] = (p.bias && n + c < p.Cout) ? p.bias[n + c] : 0.f;
+      }
+    }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nb = n0 + wn * WTN + j * 32 + 4 * (lane >> 5);
@@ -271,8 +287,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
         float v[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const bool nok = n + c < p.Cout;
-          v[c] = acc[i][j][4 * q + c] + ((nok && p.bias) ? p.bias[n + c] : 0.f);
+          v[c] = acc[i][j][4 * q + c] + bq[j][q][c];
           if (p.relu) v[c] = fmaxf(v[c], 0.f);
         }
         const long long o = magat_row_off(m, p.ldc, p.out_tile) + n;
