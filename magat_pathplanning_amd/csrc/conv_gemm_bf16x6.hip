@@ -19,6 +19,7 @@
 // chunk index XOR-ed by (row>>2)&3: a ds_read_b128 16-lane group (16 consecutive rows, same k chunk) then covers
 // all 64 banks exactly once.
 #include <cstdlib>
+#include <type_traits>
 
 #include "magat_common.h"
 
@@ -75,8 +76,9 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned& p1, unsig
 // <= 3e-8, the fp32 spacing of values near 0.5); weights are pre-scaled by a power of two so that both planes are
 // normal numbers (the scale is undone in the epilogue).
 __device__ __forceinline__ void split_pair_f16(float x, float y, unsigned& p1, unsigned& p2) {
-  x = __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f);
-  y = __builtin_fminf(__builtin_fmaxf(y, -65504.f), 65504.f);
+  // one v_med3_f32 per value (fminf(fmaxf()) costs an extra canonicalising v_max each)
+  x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+  y = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
   const f16x2 h = __builtin_convertvector(f32x2{x, y}, f16x2);
   const f16x2 r = __builtin_convertvector(f32x2{x - (float)h[0], y - (float)h[1]}, f16x2);
   p1 = __builtin_bit_cast(unsigned, h);
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 // ds_read_b128 (256 B/clk) + the 16 KB DMA fill instead of + 32 KB of ds_write.
 // TM = 32-agent row groups per wave (workgroup tile 128 TM agents x BN): TM = 2 halves the weight traffic (L2 -> LDS
 // fill and ds_read per MFMA) at 2 instead of 3 waves per SIMD.
-template <int BN, int TM>
+template <int BN, int TM, bool ILV>
 __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_kernel(const SplitParams p) {
   constexpr int TN = BN / 32;
   constexpr int STAGE = 2 * BN * 64;                    // bytes per weight stage: two planes of BN rows x 64 B
@@ -490,8 +492,11 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
   const char* const wtb = reinterpret_cast<const char*>(p.wt);
 
   f32x4 fa32[TM][4];
-  // issue the loads of the next slab: weight pieces -> LDS stage `stage`, activation floats -> fa32
-  auto load_slab = [&](int stage) {
+  // loads of the next slab: advance() moves the tap cursor and leaves the addresses in na / nb, load_a(i) fetches row
+  // group i's floats into fa32, dma(i, stage) sends weight piece i to LDS stage `stage`
+  const char* na[TM];
+  const char* nb;
+  auto advance = [&]() {
     const bool main_seg = cur_main;
     const int k0 = cur_ks * BK;
     const char* ab;
@@ -512,39 +517,47 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
       bk = p.kH * p.kW * p.Cin + k0;
       ++cur_ks;
     }
-    const char* bb = wtb + (long long)bk * 2;
+    nb = wtb + (long long)bk * 2;
     const unsigned sel = main_seg ? 0xffffffffu : 0u;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const char* a = ab + (aoff2[i] + ((aoff[i] - aoff2[i]) & sel));
-      fa32[i][0] = *reinterpret_cast<const f32x4*>(a);
-      fa32[i][1] = *reinterpret_cast<const f32x4*>(a + di);
-      fa32[i][2] = *reinterpret_cast<const f32x4*>(a + dks);
-      fa32[i][3] = *reinterpret_cast<const f32x4*>(a + dks + di);
-    }
-    // (the LDS-direct loads go out AFTER the register loads: vmcnt retires in order, so the compiler's waits for the
-    // activation registers - it cannot see the asm loads - never include the weight fill)
+    for (int i = 0; i < TM; ++i) na[i] = ab + (aoff2[i] + ((aoff[i] - aoff2[i]) & sel));
+  };
+  auto load_a = [&](int i) {
+    const char* a = na[i];
+    fa32[i][0] = *reinterpret_cast<const f32x4*>(a);
+    fa32[i][1] = *reinterpret_cast<const f32x4*>(a + di);
+    fa32[i][2] = *reinterpret_cast<const f32x4*>(a + dks);
+    fa32[i][3] = *reinterpret_cast<const f32x4*>(a + dks + di);
+  };
+  // (the LDS-direct loads always go out AFTER the register loads of the slab: vmcnt retires in order, so the compiler's
+  // waits for the activation registers - it cannot see the asm loads - never include the weight fill)
+  auto dma = [&](int i, int stage) {
+    const char* src = nb + boff[i];
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(bm0[i] + (unsigned)stage * (unsigned)STAGE);
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+  };
+  auto load_slab = [&](int stage) {
+    advance();
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const char* src = bb + boff[i];
-      const unsigned m0v = __builtin_amdgcn_readfirstlane(bm0[i] + (unsigned)stage * (unsigned)STAGE);
-      asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
-    }
+    for (int i = 0; i < TM; ++i) load_a(i);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) dma(i, stage);
   };
   u32x4 qa[TM][2][2];                                   // [row group][k step][plane]: the lane's 8 k values as packed f16
+  auto split_half = [&](int i, int ks) {               // row group i, k step ks of the slab held in fa32
+    unsigned h1[4], h2[4];
+    split_pair_f16(fa32[i][2 * ks][0], fa32[i][2 * ks][1], h1[0], h2[0]);
+    split_pair_f16(fa32[i][2 * ks][2], fa32[i][2 * ks][3], h1[1], h2[1]);
+    split_pair_f16(fa32[i][2 * ks + 1][0], fa32[i][2 * ks + 1][1], h1[2], h2[2]);
+    split_pair_f16(fa32[i][2 * ks + 1][2], fa32[i][2 * ks + 1][3], h1[3], h2[3]);
+    qa[i][ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
+    qa[i][ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
+  };
   auto split_regs = [&]() {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        unsigned h1[4], h2[4];
-        split_pair_f16(fa32[i][2 * ks][0], fa32[i][2 * ks][1], h1[0], h2[0]);
-        split_pair_f16(fa32[i][2 * ks][2], fa32[i][2 * ks][3], h1[1], h2[1]);
-        split_pair_f16(fa32[i][2 * ks + 1][0], fa32[i][2 * ks + 1][1], h1[2], h2[2]);
-        split_pair_f16(fa32[i][2 * ks + 1][2], fa32[i][2 * ks + 1][3], h1[3], h2[3]);
-        qa[i][ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
-        qa[i][ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
-      }
+      for (int ks = 0; ks < 2; ++ks) split_half(i, ks);
   };
   auto landed = [&]() {            // this wave's pieces are in LDS; then everybody's
     // (the builtin, not inline asm: the compiler's waitcnt bookkeeping then knows that none of ITS loads is pending
@@ -559,9 +572,14 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
     split_regs();
     landed();
   }
-  for (int s = 0; s < nslab; ++s) {
-    if (s + 1 < nslab) load_slab((s + 1) & 1);
+  // MFMAs of slab s.  IL (slabs that have a successor): the next slab's loads are issued BETWEEN the product groups
+  // instead of ahead of them - a wave issues in order, so a VMEM / LDS-direct instruction that waits for a queue slot
+  // at the top of the body would hold back every MFMA behind it; in the gaps it waits under the wave's own MFMAs.
+  auto compute = [&](int s, auto il_tag) {
+    constexpr bool IL = decltype(il_tag)::value;
     const char* bst = Bs + (s & 1) * STAGE;
+    const int nstage = (s + 1) & 1;
+    if constexpr (IL) advance();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       u32x4 fb[TN][2];
@@ -574,11 +592,11 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
           fb[j][pl] = *reinterpret_cast<const u32x4*>(bst + pl * (BN * 64) + (row * 4 + (c ^ ((row >> 2) & 3))) * 16);
         }
       constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};     // h1g1 h1g2 h2g1 (activation plane, weight plane)
-#pragma unroll
 #ifndef MAGAT_EXP_NQ
 #define MAGAT_EXP_NQ 3
 #endif
-      for (int q = 0; q < MAGAT_EXP_NQ; ++q)
+#pragma unroll
+      for (int q = 0; q < MAGAT_EXP_NQ; ++q) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -586,12 +604,35 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j][PB[q]]),
                                                                __builtin_bit_cast(f16x8, qa[i][ks][PA[q]]), acc[i][j],
                                                                0, 0, 0);
+        if constexpr (IL) {
+          const int g = 3 * ks + q;                     // gap index 0..5: row groups first, then the weight pieces
+          __builtin_amdgcn_sched_barrier(0);            // (pin the order: left alone, the scheduler clusters the loads
+          if (g < TM) load_a(g);                        //  and guards them with vmcnt waits between the MFMAs)
+          constexpr int G0 = TM, NG = 6 - TM, PER = (TN + NG - 1) / NG;
+#pragma unroll
+          for (int e = 0; e < PER; ++e) {
+            const int piece = (g - G0) * PER + e;
+            if (g >= G0 && piece < TN) dma(piece, nstage);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
-    if (s + 1 < nslab) {
+    // (splitting the next slab's k-step-0 floats under k step 1's MFMAs - their registers are free by then - measured
+    // 2-4 % SLOWER on layer 3: the wait for the floats lands inside the MFMA stream)
+    if constexpr (IL) split_regs();
+  };
+  for (int s = 0; s + 1 < nslab; ++s) {
+    if constexpr (ILV) {
+      compute(s, std::true_type{});
+    } else {
+      load_slab((s + 1) & 1);
+      compute(s, std::false_type{});
       split_regs();
-      landed();
     }
+    landed();
   }
+  if (nslab > 0) compute(nslab - 1, std::false_type{});
 
   // epilogue: D[channel][agent]; agent = lane&31, channel = (r&3) + 8*(r>>2) + 4*(lane>>5).  The lane's 4 TN bias quads
   // are fetched as ONE batch of 16-byte loads (per-channel conditional loads cost one L2 round trip per quad).
@@ -716,19 +757,25 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   const int direct = magat_conv_direct_enabled();
   if ((d->in_gl || d->out_gl) && !(d->in_fmt == 4 && d->out_fmt == 0 && direct)) return MAGAT_ERR_UNSUPPORTED;
   if (d->in_fmt == 4 && d->out_fmt == 0 && direct) {
-    static int tm2 = -1;       // MAGAT_CONV_TM=1: one 32-agent row group per wave everywhere
-    if (tm2 < 0) { const char* e = getenv("MAGAT_CONV_TM"); tm2 = e ? atoi(e) : 2; }
+    int tm2 = 2;               // MAGAT_CONV_TM=1: one 32-agent row group per wave everywhere
+    { const char* e = getenv("MAGAT_CONV_TM"); if (e) tm2 = atoi(e); }
     const bool two = tm2 >= 2 && (long long)(p.Mt / 2) * p.npix * p.ntn >= 2048;   // enough 256-agent tiles to fill the chip
     const long long mt = two ? (p.Mt + 1) / 2 : p.Mt;
     const long long g2 = (mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD * p.npix * p.ntn;
     p.Mt = (int)mt;
 #define MAGAT_DIRECT_LAUNCH(BNV)                                                                                     \
   do {                                                                                                              \
-    if (two)                                                                                                        \
-      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2>), dim3((unsigned)g2), dim3(256), 0, st, p);         \
+    if (two && il)                                                                                                  \
+      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2, true>), dim3((unsigned)g2), dim3(256), 0, st, p);   \
+    else if (two)                                                                                                   \
+      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2, false>), dim3((unsigned)g2), dim3(256), 0, st, p);  \
+    else if (il)                                                                                                    \
+      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1, true>), dim3((unsigned)g2), dim3(256), 0, st, p);   \
     else                                                                                                            \
-      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1>), dim3((unsigned)g2), dim3(256), 0, st, p);         \
+      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1, false>), dim3((unsigned)g2), dim3(256), 0, st, p);  \
   } while (0)
+    int il = 1;                // MAGAT_CONV_IL=0: next slab's loads ahead of the MFMAs instead of between the product groups
+    { const char* e = getenv("MAGAT_CONV_IL"); if (e) il = atoi(e); }
     if (BN == 128) MAGAT_DIRECT_LAUNCH(128);
     else if (BN == 64) MAGAT_DIRECT_LAUNCH(64);
     else MAGAT_DIRECT_LAUNCH(32);
