@@ -214,11 +214,21 @@ typedef struct magat_conv_gemm_desc {
    * npix*128*C): everything a workgroup touches is one contiguous ~0.5-2 MB run instead of <= 121 pieces a
    * multi-MB plane stride apart (channel/TLB-aliasing hazard of the plane form on large batches). */
   int64_t in_tile_stride, in2_tile_stride, out_tile_stride;
-  /* Granule-major agent tiles (float32 operands only): inside its 128-agent tile, element (m, c) of a pixel lives at
-   * ((c / 4) * 128 + (m % 128)) * 4 + c % 4 instead of (m % 128) * ld + c - the 16-byte channel quads of the 128
-   * agents are contiguous, which is how one MFMA fragment lane per agent wants to load and store them (512-byte runs
-   * per half wave).  in_gl covers in AND in2; tiles keep their size (ld = channel count).  Taken by the f16x3
-   * direct kernel only (in_fmt 4, out_fmt 0; anything else returns MAGAT_ERR_UNSUPPORTED). */
+  /* Granule-major agent tiles, taken by the f16x3 direct kernel only (in_fmt 4, out_fmt 0; anything else returns
+   * MAGAT_ERR_UNSUPPORTED).  in_gl covers in AND in2; tiles keep their size (ld = channel count C, 128*C*4 bytes per
+   * pixel and tile).
+   *   1: float32 granules - inside its 128-agent tile, element (m, c) of a pixel lives at
+   *      ((c / 4) * 128 + (m % 128)) * 4 + c % 4 instead of (m % 128) * ld + c: the 16-byte channel quads of the 128
+   *      agents are contiguous, which is how one MFMA fragment lane per agent loads and stores them (512-byte runs per
+   *      half wave).
+   *   2: f16 plane granules - the tile holds the two half-precision planes of the f16x3 form (value = plane0 + plane1;
+   *      plane p at byte p*256*C of the pixel's tile), each as 16-byte granules [C/8][128 agents][8 halves]; granule
+   *      (T*2 + ks)*2 + h of a 32-channel tile T holds channels 32T + 16ks + 8(i>>2) + 4h + (i&3) in slot i = 0..7, i.e.
+   *      exactly what MFMA lane (agent, h) of the producing epilogue holds and what the consuming loader feeds to the
+   *      matrix core as its k-step-ks operand.  The CONSUMER's weights must carry the same order: within every 32-wide
+   *      K slab, column 16ks + 8h + i = the weight of channel 16ks + 8(i>>2) + 4h + (i&3) (encoder.fold_resnet packs
+   *      such a copy behind each f16 weight block).  Values are split once by the producer instead of once per tap by
+   *      every consumer. */
   int in_gl, out_gl;
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);

@@ -419,7 +419,10 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 // ds_read_b128 (256 B/clk) + the 16 KB DMA fill instead of + 32 KB of ds_write.
 // TM = 32-agent row groups per wave (workgroup tile 128 TM agents x BN): TM = 2 halves the weight traffic (L2 -> LDS
 // fill and ds_read per MFMA) at 2 instead of 3 waves per SIMD.
-template <int BN, int TM, bool ILV>
+// PIN: in / in2 arrive as f16 PLANE PAIRS in the plane-granule layout (in_gl = 2, magat_hip.h): the producer's epilogue
+// split every value once, the loader here fetches finished 16-byte MFMA operands and does no VALU work at all (with
+// float32 input every value is split once per tap it is used by - 7 times on a 6x6 map).
+template <int BN, int TM, bool PIN>
 __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_kernel(const SplitParams p) {
   constexpr int TN = BN / 32;
   constexpr int STAGE = 2 * BN * 64;                    // bytes per weight stage: two planes of BN rows x 64 B
@@ -453,20 +456,32 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // activation fragment of this lane: row m, floats k = 16 ks + 8 fh .. +7 of every slab (rows past M clamped)
-  // Granule-major tiles (in_gl: [C/4][128 agents][4 floats]) make every one of those 16-byte loads land next to its
-  // neighbour lanes' (32 agents x 16 B = 512 contiguous bytes per half wave) instead of one 64-B line per lane pair.
+  // Activation fragment of this lane: row m and 8 k values per k step of every slab (rows past M clamped).
+  //   float32 row-major tiles:     floats k = 16 ks + 8 fh .. +7            (one 64-B line per lane pair)
+  //   float32 granule-major tiles (in_gl 1, [C/4][128 agents][4 floats]): the same floats, but each 16-byte load sits
+  //                                next to the neighbour lanes' (512 contiguous bytes per half wave)
+  //   f16 plane granules (PIN, in_gl 2): one finished 16-byte operand per plane and k step
+  // Four 16-byte loads per row group and slab in every case, at a + {0, d1, d2, d2 + d1}.
   unsigned aoff[TM], aoff2[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int mrow = min(m0 + 32 * (TM * wave + i) + fr, p.M - 1);
-    aoff[i] = p.in_gl ? (unsigned)(((mrow >> 7) * p.in_tile + (2 * fh * 128 + (mrow & 127)) * 4) * 4)
-                      : (unsigned)((magat_row_off(mrow, p.lda, p.in_tile) + 8 * fh) * 4);
-    aoff2[i] = p.in_gl ? (unsigned)(((mrow >> 7) * p.in2_tile + (2 * fh * 128 + (mrow & 127)) * 4) * 4)
-                       : (unsigned)((magat_row_off(mrow, p.lda2, p.in2_tile) + 8 * fh) * 4);
+    if (PIN) {
+      aoff[i] = (unsigned)((mrow >> 7) * p.in_tile * 4 + fh * 2048 + (mrow & 127) * 16);
+      aoff2[i] = (unsigned)((mrow >> 7) * p.in2_tile * 4 + fh * 2048 + (mrow & 127) * 16);
+    } else if (p.in_gl) {
+      aoff[i] = (unsigned)(((mrow >> 7) * p.in_tile + (2 * fh * 128 + (mrow & 127)) * 4) * 4);
+      aoff2[i] = (unsigned)(((mrow >> 7) * p.in2_tile + (2 * fh * 128 + (mrow & 127)) * 4) * 4);
+    } else {
+      aoff[i] = (unsigned)((magat_row_off(mrow, p.lda, p.in_tile) + 8 * fh) * 4);
+      aoff2[i] = (unsigned)((magat_row_off(mrow, p.lda2, p.in2_tile) + 8 * fh) * 4);
+    }
   }
-  const int kmul = p.in_gl ? 512 : 4;                   // bytes per unit of k0 (k0 % 32 == 0)
-  const int di = p.in_gl ? 2048 : 16, dks = p.in_gl ? 8192 : 64;
+  const int kmul = PIN ? 256 : (p.in_gl ? 512 : 4);     // bytes per unit of k0 (k0 % 32 == 0)
+  // PIN: d1 = k step (+4096), d2 = plane (+256 C bytes: C differs between in and in2);  float32: d1 = second quad,
+  // d2 = k step
+  const int d1 = PIN ? 4096 : (p.in_gl ? 2048 : 16);
+  const int d2m = PIN ? 256 * p.lda : (p.in_gl ? 8192 : 64), d2s = PIN ? 256 * p.lda2 : d2m;
 
   // weight slab pieces (1 KB = 16 rows x 64 B of one plane) this wave copies: piece id = wave + 4 i; lane -> LDS bytes
   // [16 lane, +16) of the piece, i.e. row lane/4, chunk slot lane%4, which holds k chunk slot ^ ((row>>2)&3)
@@ -491,11 +506,12 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
                                 (long long)(oy * p.stride2 * p.W2 + ox * p.stride2) * p.in2_pix_stride * 4;
   const char* const wtb = reinterpret_cast<const char*>(p.wt);
 
-  f32x4 fa32[TM][4];
-  // loads of the next slab: advance() moves the tap cursor and leaves the addresses in na / nb, load_a(i) fetches row
-  // group i's floats into fa32, dma(i, stage) sends weight piece i to LDS stage `stage`
+  u32x4 fa[TM][4];          // the next slab as loaded: float32 quads, or (PIN) the operands [plane][k step] themselves
+  // loads of the next slab: advance() moves the tap cursor and leaves the addresses in na / nb / nd2, load_a(i) fetches
+  // row group i into fa, dma(i, stage) sends weight piece i to LDS stage `stage`
   const char* na[TM];
   const char* nb;
+  int nd2;
   auto advance = [&]() {
     const bool main_seg = cur_main;
     const int k0 = cur_ks * BK;
@@ -518,16 +534,17 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
       ++cur_ks;
     }
     nb = wtb + (long long)bk * 2;
+    nd2 = main_seg ? d2m : d2s;
     const unsigned sel = main_seg ? 0xffffffffu : 0u;
 #pragma unroll
     for (int i = 0; i < TM; ++i) na[i] = ab + (aoff2[i] + ((aoff[i] - aoff2[i]) & sel));
   };
   auto load_a = [&](int i) {
     const char* a = na[i];
-    fa32[i][0] = *reinterpret_cast<const f32x4*>(a);
-    fa32[i][1] = *reinterpret_cast<const f32x4*>(a + di);
-    fa32[i][2] = *reinterpret_cast<const f32x4*>(a + dks);
-    fa32[i][3] = *reinterpret_cast<const f32x4*>(a + dks + di);
+    fa[i][0] = *reinterpret_cast<const u32x4*>(a);
+    fa[i][1] = *reinterpret_cast<const u32x4*>(a + d1);
+    fa[i][2] = *reinterpret_cast<const u32x4*>(a + nd2);
+    fa[i][3] = *reinterpret_cast<const u32x4*>(a + nd2 + d1);
   };
   // (the LDS-direct loads always go out AFTER the register loads of the slab: vmcnt retires in order, so the compiler's
   // waits for the activation registers - it cannot see the asm loads - never include the weight fill)
@@ -536,28 +553,26 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
     const unsigned m0v = __builtin_amdgcn_readfirstlane(bm0[i] + (unsigned)stage * (unsigned)STAGE);
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
   };
-  auto load_slab = [&](int stage) {
-    advance();
-#pragma unroll
-    for (int i = 0; i < TM; ++i) load_a(i);
-#pragma unroll
-    for (int i = 0; i < TN; ++i) dma(i, stage);
-  };
   u32x4 qa[TM][2][2];                                   // [row group][k step][plane]: the lane's 8 k values as packed f16
-  auto split_half = [&](int i, int ks) {               // row group i, k step ks of the slab held in fa32
-    unsigned h1[4], h2[4];
-    split_pair_f16(fa32[i][2 * ks][0], fa32[i][2 * ks][1], h1[0], h2[0]);
-    split_pair_f16(fa32[i][2 * ks][2], fa32[i][2 * ks][3], h1[1], h2[1]);
-    split_pair_f16(fa32[i][2 * ks + 1][0], fa32[i][2 * ks + 1][1], h1[2], h2[2]);
-    split_pair_f16(fa32[i][2 * ks + 1][2], fa32[i][2 * ks + 1][3], h1[3], h2[3]);
-    qa[i][ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
-    qa[i][ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
-  };
-  auto split_regs = [&]() {
+  auto take_regs = [&]() {                              // fa -> qa: split float32 quads, or just take the operands
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+      if constexpr (PIN) {
+        qa[i][0][0] = fa[i][0]; qa[i][1][0] = fa[i][1]; qa[i][0][1] = fa[i][2]; qa[i][1][1] = fa[i][3];
+      } else {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) split_half(i, ks);
+        for (int ks = 0; ks < 2; ++ks) {
+          const f32x4 lo = __builtin_bit_cast(f32x4, fa[i][2 * ks]), hi = __builtin_bit_cast(f32x4, fa[i][2 * ks + 1]);
+          unsigned h1[4], h2[4];
+          split_pair_f16(lo[0], lo[1], h1[0], h2[0]);
+          split_pair_f16(lo[2], lo[3], h1[1], h2[1]);
+          split_pair_f16(hi[0], hi[1], h1[2], h2[2]);
+          split_pair_f16(hi[2], hi[3], h1[3], h2[3]);
+          qa[i][ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
+          qa[i][ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
+        }
+      }
+    }
   };
   auto landed = [&]() {            // this wave's pieces are in LDS; then everybody's
     // (the builtin, not inline asm: the compiler's waitcnt bookkeeping then knows that none of ITS loads is pending
@@ -568,8 +583,12 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
   };
 
   if (nslab > 0) {
-    load_slab(0);
-    split_regs();
+    advance();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) load_a(i);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) dma(i, 0);
+    take_regs();
     landed();
   }
   // MFMAs of slab s.  IL (slabs that have a successor): the next slab's loads are issued BETWEEN the product groups
@@ -592,11 +611,8 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
           fb[j][pl] = *reinterpret_cast<const u32x4*>(bst + pl * (BN * 64) + (row * 4 + (c ^ ((row >> 2) & 3))) * 16);
         }
       constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};     // h1g1 h1g2 h2g1 (activation plane, weight plane)
-#ifndef MAGAT_EXP_NQ
-#define MAGAT_EXP_NQ 3
-#endif
 #pragma unroll
-      for (int q = 0; q < MAGAT_EXP_NQ; ++q) {
+      for (int q = 0; q < 3; ++q) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -618,18 +634,13 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
         }
       }
     }
-    // (splitting the next slab's k-step-0 floats under k step 1's MFMAs - their registers are free by then - measured
-    // 2-4 % SLOWER on layer 3: the wait for the floats lands inside the MFMA stream)
-    if constexpr (IL) split_regs();
+    // (float32 input: splitting the next slab's k-step-0 floats under k step 1's MFMAs - their registers are free by
+    // then - measured 2-4 % SLOWER on layer 3: the wait for the floats lands inside the MFMA stream.  Issuing every
+    // activation load in the first gap and one weight piece per later gap: 2-3 % slower as well.)
+    if constexpr (IL) take_regs();
   };
   for (int s = 0; s + 1 < nslab; ++s) {
-    if constexpr (ILV) {
-      compute(s, std::true_type{});
-    } else {
-      load_slab((s + 1) & 1);
-      compute(s, std::false_type{});
-      split_regs();
-    }
+    compute(s, std::true_type{});
     landed();
   }
   if (nslab > 0) compute(nslab - 1, std::false_type{});
@@ -656,6 +667,35 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + 32 * (TM * wave + i) + fr;
     if (m >= p.M) continue;
+    if (p.out_gl == 2) {
+      // f16 plane granules for the next f16x3 layer: the lane's quads 2 ks, 2 ks + 1 of a 32-channel tile ARE that
+      // layer's k-step-ks operand (its weights are packed in this channel order), one 16-byte store per plane
+      char* const ob = static_cast<char*>(p.out) + ((long long)pix * p.out_pix_stride + (long long)(m >> 7) * p.out_tile) * 4 +
+                       fh * 2048 + (m & 127) * 16;
+      const long long oplane = 256LL * p.Cout;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          unsigned h1[4], h2[4];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int q = 2 * ks + e;
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[c] = acc[i][j][4 * q + c] * acc_scale + bq[j][q][c];
+              if (p.relu) v[c] = fmaxf(v[c], 0.f);
+            }
+            split_pair_f16(v[0], v[1], h1[2 * e], h2[2 * e]);
+            split_pair_f16(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1]);
+          }
+          char* const o = ob + (long long)(((n0 >> 5) + j) * 2 + ks) * 4096;
+          *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+          *reinterpret_cast<u32x4*>(o + oplane) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+        }
+      continue;
+    }
     float* const orow = static_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +
                         (p.out_gl ? (m >> 7) * p.out_tile + (m & 127) * 4 : magat_row_off(m, p.ldc, p.out_tile));
     const int nmul = p.out_gl ? 128 : 1;                // granule-major: channel quad n/4 is 128 agents x 4 floats away
@@ -765,17 +805,16 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
     p.Mt = (int)mt;
 #define MAGAT_DIRECT_LAUNCH(BNV)                                                                                     \
   do {                                                                                                              \
-    if (two && il)                                                                                                  \
+    if (two && pin)                                                                                                 \
       hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2, true>), dim3((unsigned)g2), dim3(256), 0, st, p);   \
     else if (two)                                                                                                   \
       hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2, false>), dim3((unsigned)g2), dim3(256), 0, st, p);  \
-    else if (il)                                                                                                    \
+    else if (pin)                                                                                                   \
       hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1, true>), dim3((unsigned)g2), dim3(256), 0, st, p);   \
     else                                                                                                            \
       hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1, false>), dim3((unsigned)g2), dim3(256), 0, st, p);  \
   } while (0)
-    int il = 1;                // MAGAT_CONV_IL=0: next slab's loads ahead of the MFMAs instead of between the product groups
-    { const char* e = getenv("MAGAT_CONV_IL"); if (e) il = atoi(e); }
+    const bool pin = d->in_gl == 2;
     if (BN == 128) MAGAT_DIRECT_LAUNCH(128);
     else if (BN == 64) MAGAT_DIRECT_LAUNCH(64);
     else MAGAT_DIRECT_LAUNCH(32);

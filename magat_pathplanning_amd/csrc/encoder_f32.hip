@@ -112,6 +112,31 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
       // a sits next to its neighbour agents' -> 512-byte runs per half wave and store
       float* og = out + (long long)pix * out_pix_stride + (long long)(agent >> 7) * out_tile_stride +
                   ((lane >> 5) * 128 + (agent & 127)) * 4;
+      if (out_gl == 2) {
+        // f16 plane granules (magat_hip.h out_gl = 2): quads 2 ks, 2 ks + 1 form the next layer's k-step-ks operand
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        char* ob = reinterpret_cast<char*>(out) + ((long long)pix * out_pix_stride + (long long)(agent >> 7) * out_tile_stride) * 4 +
+                   (lane >> 5) * 2048 + (agent & 127) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          unsigned w1[4], w2[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {        // pairs (2e, 2e+1) of the 8 values of quads 2 ks, 2 ks + 1
+            const int q = 2 * ks + (e >> 1), c = 2 * (e & 1);
+            const float a = __builtin_amdgcn_fmed3f(fmaxf(acc[4 * q + c] + bch[q][c], 0.f), -65504.f, 65504.f);
+            const float b2 = __builtin_amdgcn_fmed3f(fmaxf(acc[4 * q + c + 1] + bch[q][c + 1], 0.f), -65504.f, 65504.f);
+            const h2 h = __builtin_convertvector(f2{a, b2}, h2);
+            const h2 r = __builtin_convertvector(f2{a - (float)h[0], b2 - (float)h[1]}, h2);
+            w1[e] = __builtin_bit_cast(unsigned, h);
+            w2[e] = __builtin_bit_cast(unsigned, r);
+          }
+          *reinterpret_cast<u4*>(ob + ks * 4096) = u4{w1[0], w1[1], w1[2], w1[3]};
+          *reinterpret_cast<u4*>(ob + 256 * 32 + ks * 4096) = u4{w2[0], w2[1], w2[2], w2[3]};
+        }
+        continue;
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 v;
@@ -324,12 +349,24 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   // 512-byte runs.  The last conv2 writes row-major tiles again for the pooled head (fp32 MFMA kernel).
   bool gl = !chain && split == (1 << nblocks) - 1 && magat_conv_direct_enabled();
   for (int l = 0; l < nblocks; ++l) gl = gl && enc_use_f16(d, l);
+  // ... and, when the pack carries the K-permuted weight copies (off[30]), as f16 PLANE granules (in_gl/out_gl = 2): every
+  // activation is split into its two half-precision planes once, by the epilogue that produces it, instead of once per
+  // tap by every consumer's loader.  MAGAT_CONV_PCHAIN=0 keeps float32 granules.
+  int lay = gl ? 1 : 0;
+  if (gl && d->off[30] != 0) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MAGAT_CONV_PCHAIN"); v = e ? atoi(e) : 1; }
+    if (v) lay = 2;
+  }
+  // float offset of the permuted copy behind an f16 weight block of cout x ktot weights (two planes + one scale float,
+  // padded to 4 floats)
+  auto permuted = [&](int cout, int ktot) { return lay == 2 ? (int64_t)(((int64_t)cout * ktot + 1 + 3) & ~3LL) : 0; };
   for (int m0 = 0; m0 < M; m0 += mc) {
     const int mm = (M - m0) < mc ? (M - m0) : mc;
     int rc = conv_first_launch(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W,
                                (long long)MAGAT_TILE_ROWS * 32,
                                chain ? (long long)ptiles(H * W, 32) : (long long)H * W * MAGAT_TILE_ROWS * 32, stream,
-                               chain ? planes(H * W, 32) : 0, gl ? 1 : 0);
+                               chain ? planes(H * W, 32) : 0, lay);
     if (rc != MAGAT_OK) return rc;
     int cur = 0;              // buffer holding the block input
     int hin = H, win = W;
@@ -354,7 +391,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
           g.in_tile_stride = ptiles(hin * win, s.cin); g.out_tile_stride = ptiles(hout * wout, s.cout);
         }
       }
-      g.in_gl = g.out_gl = gl ? 1 : 0;
+      g.in_gl = g.out_gl = lay;
+      if (lay == 2) g.wt += permuted(s.cout, 9 * s.cin);
       rc = magat_conv_gemm_f32(&g, stream);
       if (rc != MAGAT_OK) return rc;
       // conv2 + bn2 + (1x1 strided downsample + bn) + relu
@@ -379,7 +417,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
           if (l + 1 < nblocks) h.out_tile_stride = ptiles(hout * wout, s.cout);
         }
       }
-      h.in_gl = gl ? 1 : 0; h.out_gl = gl && l + 1 < nblocks ? 1 : 0;
+      h.in_gl = lay; h.out_gl = l + 1 < nblocks ? lay : 0;
+      if (lay == 2) h.wt += permuted(s.cout, 9 * s.cout + s.cin);
       rc = magat_conv_gemm_f32(&h, stream);
       if (rc != MAGAT_OK) return rc;
       cur = nxt; hin = hout; win = wout;

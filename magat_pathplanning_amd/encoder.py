@@ -124,16 +124,34 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
             raws.append(planes)
         # ... and as f16x2 planes of the power-of-two-scaled weights followed by the inverse scale ("f16x3" GEMM, in_fmt 4):
         # off[24+2l] = layer(l+1).conv1, off[25+2l] = [conv2|downsample]
-        for slot, src in pairs:
+        # Each f16 block is followed by a second copy with the K columns of every 32-wide slab permuted for activations
+        # stored as f16 plane granules (magat_hip.h in_gl = 2; offs[30] != 0 marks their presence): the producer's MFMA
+        # lane holds channels 4h + 8g + c (g, c = 0..3) of a 32-channel tile, and writes quads g = 2ks, 2ks+1 as ONE
+        # 16-byte operand, so operand slot 16ks + 8h + i carries channel 16ks + 8(i>>2) + 4h + (i&3).
+        perm32 = torch.tensor([16 * (q >> 4) + 8 * ((q & 7) >> 2) + 4 * ((q >> 3) & 1) + (q & 3) for q in range(32)])
+        couts = [32, 32, 64, 64, 128, 128]
+        for (slot, src), cout in zip(pairs, couts):
             nxt = sorted(o for o in offs[:18] if o > offs[src])
             end = nxt[0] if nxt else n_f32
-            blk, _ = split_f16x2(pack[offs[src]:end])
+            w32 = pack[offs[src]:end]
+            blk, _ = split_f16x2(w32)
             pad = (-blk.numel()) % 4
             if pad:
                 blk = torch.cat((blk, torch.zeros(pad)))
             offs[slot + 6] = cursor_f
             cursor_f += blk.numel()
             raws.append(blk)
+            w2d = w32.reshape(cout, -1)
+            assert w2d.shape[1] % 32 == 0
+            idx = (torch.arange(w2d.shape[1]) // 32) * 32
+            idx = idx + perm32.repeat(w2d.shape[1] // 32)
+            blk2, _ = split_f16x2(w2d[:, idx].reshape(-1))
+            if pad:
+                blk2 = torch.cat((blk2, torch.zeros(pad)))
+            assert blk2.numel() == blk.numel()
+            cursor_f += blk2.numel()
+            raws.append(blk2)
+        offs[30] = offs[24] + (offs[25] - offs[24]) // 2      # first permuted copy (non-zero = copies present)
         pack = torch.cat([pack] + raws).contiguous()
     meta = dict(variant=0 if large else 1, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast)
     return pack, offs, meta
