@@ -47,6 +47,7 @@ struct SplitParams {
   int C2, lda2, W2, stride2;
   int Cout, Ktot, ldc, relu;
   int ntn, npix, tag, out_split;
+  int korder;               // direct kernel: 1 = channel slab outer, taps inner (MAGAT_CONV_KORDER)
   int in_gl, out_gl;        // direct kernel: granule-major agent tiles [C/4][128][4] for in/in2 resp. out
   const float* acc_scale;   // NPL == 2: device pointer to 1 / (power-of-two weight scale), applied before the bias
 };
@@ -520,7 +521,21 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
     if (main_seg) {
       ab = cur_tap + (long long)k0 * kmul;
       bk = (cur_ty * p.kW + cur_tx) * p.Cin + k0;
-      if (++cur_ks == spt) {
+      if (p.korder) {
+        // channel slab OUTER, taps inner: the workgroups of an agent tile (one per output pixel, all on one XCD) then sweep
+        // the SAME 32-channel slab of the input map at the same time - the <= 9 re-reads of a (pixel, slab) chunk by
+        // neighbouring output pixels fall into a short window and hit in L2.  Tap-major order spreads them over the
+        // whole K walk, the tile's input (4.7 MB at layer 3) does not fit the 4 MB L2, and every chunk came back from the
+        // fabric 3.6 times (rocprofv3 FETCH_SIZE, profiles/r01f).
+        if (++cur_tx == tx1) {
+          cur_tx = tx0;
+          if (++cur_ty == ty1) {
+            cur_ty = ty0;
+            if (++cur_ks == spt) { cur_ks = 0; cur_main = false; }
+          }
+        }
+        if (cur_main) cur_tap = tap_base(cur_ty, cur_tx);
+      } else if (++cur_ks == spt) {
         cur_ks = 0;
         if (++cur_tx == tx1) {
           cur_tx = tx0;
@@ -635,8 +650,8 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
       }
     }
     // (float32 input: splitting the next slab's k-step-0 floats under k step 1's MFMAs - their registers are free by
-    // then - measured 2-4 % SLOWER on layer 3: the wait for the floats lands inside the MFMA stream.  Issuing every
-    // activation load in the first gap and one weight piece per later gap: 2-3 % slower as well.)
+    // then - measured 2-4 % SLOWER on layer 3: the wait for the floats lands inside the MFMA stream.  Other assignments
+    // of the loads to the gaps (all activation loads first, weight pieces first, two pieces per gap) are within +-3 %.)
     if constexpr (IL) take_regs();
   };
   for (int s = 0; s + 1 < nslab; ++s) {
@@ -765,6 +780,7 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.wt_plane = (long long)p.Cout * p.Ktot;
   p.npix = d->Hout * d->Wout; p.tag = d->tag; p.out_split = d->out_fmt;
   p.in_gl = d->in_gl; p.out_gl = d->out_gl;
+  { const char* e = getenv("MAGAT_CONV_KORDER"); p.korder = e ? atoi(e) : 1; }
   p.Mt = (p.M + BM - 1) / BM;
   p.ntn = p.Cout / BN;
   if (magat_row_off(p.M, p.lda, p.in_tile) * 4 >= 0xffffffffLL ||

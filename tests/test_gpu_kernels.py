@@ -559,7 +559,7 @@ def test_conv_gemm_f16x3_split_mfma_matches_fp64(gpu_device, cin, cout, c2, M, s
 
 
 
-def test_conv_gemm_f16_plane_formats(gpu_device):
+def test_conv_gemm_f16_plane_formats(gpu_device, monkeypatch):
     """in_fmt 5 (activations already as two f16 planes) gives bit-identical results to in_fmt 4 (split on load), and
     out_fmt 3 (epilogue writes the two planes) reproduces the float32 output to 2^-22."""
     from magat_pathplanning_amd.encoder import split_f16x2
@@ -574,6 +574,9 @@ def test_conv_gemm_f16_plane_formats(gpu_device):
     planes = torch.stack((h1, (xp - h1.float()).half())).contiguous()  # [2][36][M][cin]
     ws, bd = split_f16x2(wt)[0].to(gpu_device), b.to(gpu_device)
     outs = {}
+    # (4, 0) runs on the direct kernel, whose default K walk is channel-slab-major; the tap-major walk of the LDS-staged
+    # kernel (the other two cases) gives bit-identical sums only in the same order
+    monkeypatch.setenv("MAGAT_CONV_KORDER", "0")
     for in_fmt, out_fmt in ((4, 0), (5, 0), (4, 3)):
         d = nat.ConvGemmDesc()
         src = planes if in_fmt == 5 else xp
@@ -591,3 +594,85 @@ def test_conv_gemm_f16_plane_formats(gpu_device):
     rec = outs[(4, 3)][0].float() + outs[(4, 3)][1].float()
     ref = outs[(4, 0)]
     assert float((rec - ref).abs().max()) <= 2.0 ** -21 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("korder", [0, 1])
+def test_conv_gemm_f16x3_granule_layouts(gpu_device, monkeypatch, korder):
+    """Direct f16x3 kernel: float32 granule-major tiles (in_gl/out_gl = 1) are bit-identical to row-major tiles; f16
+    plane granules (in_gl/out_gl = 2, K-permuted weights) agree to the rounding of the two output planes and of the
+    MFMA's internal sum order.  Residual 1x1 segment (in2), ragged M (partial last agent tile), both K walks."""
+    from magat_pathplanning_amd.encoder import split_f16x2
+    nat, lib = _nat()
+    monkeypatch.setenv("MAGAT_CONV_KORDER", str(korder))
+    M, cin, cout, c2, npix = 300, 64, 128, 32, 36
+    Mp = (M + 127) // 128 * 128
+    g = torch.Generator().manual_seed(11)
+    x = torch.zeros(npix, Mp, cin); x[:, :M] = torch.relu(torch.randn(npix, M, cin, generator=g))
+    x2 = torch.zeros(npix, Mp, c2); x2[:, :M] = torch.relu(torch.randn(npix, M, c2, generator=g))
+    wt = (torch.randn(cout, 9 * cin + c2, generator=g) / (9 * cin) ** 0.5).contiguous()
+    b = torch.randn(cout, generator=g)
+    perm = torch.tensor([16 * (q >> 4) + 8 * ((q & 7) >> 2) + 4 * ((q >> 3) & 1) + (q & 3) for q in range(32)])
+
+    def kidx(c):
+        return (torch.arange(c) // 32) * 32 + perm.repeat(c // 32)
+
+    def to_gl(t):
+        return t.view(npix, Mp // 128, 128, t.shape[-1] // 4, 4).permute(0, 1, 3, 2, 4).contiguous()
+
+    def from_gl(t, c):
+        return t.view(npix, Mp // 128, c // 4, 128, 4).permute(0, 1, 3, 2, 4).reshape(npix, Mp, c)
+
+    def to_pl(t):
+        c = t.shape[-1]
+        tp = t.clamp(-65504.0, 65504.0)[..., kidx(c)]
+        h1 = tp.half()
+        pl = torch.stack((h1, (tp - h1.float()).half()), dim=1)
+        return pl.view(npix, 2, Mp // 128, 128, c // 8, 8).permute(0, 2, 1, 4, 3, 5).contiguous()
+
+    def from_pl(buf, c):
+        pl = buf.view(torch.float16).view(npix, Mp // 128, 2, c // 8, 128, 8).permute(0, 2, 1, 4, 3, 5)
+        pl = pl.reshape(npix, 2, Mp, c)
+        v = pl[:, 0].float() + pl[:, 1].float()
+        out = torch.empty_like(v)
+        out[..., kidx(c)] = v
+        return out
+
+    ws = split_f16x2(wt)[0].to(gpu_device)
+    wsp = split_f16x2(wt[:, kidx(wt.shape[1])])[0].to(gpu_device)
+    bd = b.to(gpu_device)
+    res = {}
+    for lay in (0, 1, 2):
+        xi, x2i = ((x, x2), (to_gl(x), to_gl(x2)), (to_pl(x), to_pl(x2)))[lay]
+        xi, x2i = xi.to(gpu_device), x2i.to(gpu_device)
+        out = torch.full((npix, Mp, cout), float("nan"), device=gpu_device)
+        d = nat.ConvGemmDesc()
+        d.inp, d.in2, d.bias, d.out = xi.data_ptr(), x2i.data_ptr(), bd.data_ptr(), out.data_ptr()
+        d.wt = (wsp if lay == 2 else ws).data_ptr()
+        d.in_pix_stride, d.in2_pix_stride, d.out_pix_stride = Mp * cin, Mp * c2, Mp * cout
+        d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, 6, 6, 3, 3, 1, 1
+        d.C2, d.lda2, d.W2, d.stride2 = c2, c2, 6, 1
+        d.Hout, d.Wout, d.Cout, d.ldc, d.relu, d.in_fmt, d.in_gl, d.out_gl = 6, 6, cout, cout, 1, 4, lay, lay
+        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)),
+                  "conv_gemm granule layout %d" % lay)
+        torch.cuda.synchronize()
+        got = out.cpu()
+        res[lay] = (got if lay == 0 else (from_gl(got, cout) if lay == 1 else from_pl(got, cout)))[:, :M]
+    # float64 reference
+    ref = torch.zeros(npix, M, cout, dtype=torch.float64)
+    w64 = wt.double()
+    for oy in range(6):
+        for ox in range(6):
+            acc = x2[oy * 6 + ox, :M].double() @ w64[:, 9 * cin:].T
+            for ty in range(3):
+                for tx in range(3):
+                    iy, ix = oy - 1 + ty, ox - 1 + tx
+                    if 0 <= iy < 6 and 0 <= ix < 6:
+                        acc += x[iy * 6 + ix, :M].double() @ w64[:, (ty * 3 + tx) * cin:(ty * 3 + tx + 1) * cin].T
+            ref[oy * 6 + ox] = torch.relu(acc + b.double())
+    scale = float(ref.abs().max())
+    assert not torch.isnan(res[0]).any()
+    assert torch.equal(res[0], res[1])
+    assert float((res[0].double() - ref).abs().max()) <= 3e-6 * scale
+    assert float((res[2].double() - ref).abs().max()) <= 3e-6 * scale
+    assert float((res[2] - res[0]).abs().max()) <= 3e-6 * scale

@@ -12,6 +12,9 @@ from collections import defaultdict
 
 def short(name):
     import re
+    m = re.search(r"conv_gemm_f16x3_direct_kernel<(\d+), (\d+), (true|false)>", name)
+    if m:                                       # f16x3, activations straight into registers
+        return "conv_f16x3_direct<%s,TM%s,%s>" % (m.group(1), m.group(2), "planes-in" if m.group(3) == "true" else "f32-in")
     m = re.search(r"conv_gemm_bf16x6_kernel<true, (\d+), \d+, \d+, 2>", name)
     if m:                                       # NPL = 2: the f16x3 flavour of the split kernel
         return "conv_gemm_f16x3<f32-in,%s>" % m.group(1)
@@ -69,7 +72,8 @@ def main():
     # per-layer split: our library launches a fixed 12-kernel sequence per addGSO+forward step (c3 workload)
     SEQ = ["conv_first", "layer1.conv1", "layer1.conv2+ds", "layer2.conv1", "layer2.conv2+ds", "layer3.conv1",
            "layer3.conv2+ds", "head(avgpool+fc+linear)", "compressMLP", "gat_maps_gemm", "gat_graph", "actionsMLP"]
-    ours = ("conv_gemm_kernel", "conv_gemm_bf16x6_kernel", "conv_first_kernel", "gat_dense_kernel")
+    ours = ("conv_gemm_kernel", "conv_gemm_bf16x6_kernel", "conv_gemm_f16x3_direct_kernel", "conv_first_kernel",
+            "gat_dense_kernel")
     layers = defaultdict(dict)
     tr = find(os.path.join(out, "trace"), "*kernel_trace.csv")
     if tr:
