@@ -363,10 +363,25 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   auto permuted = [&](int cout, int ktot) { return lay == 2 ? (int64_t)(((int64_t)cout * ktot + 1 + 3) & ~3LL) : 0; };
   for (int m0 = 0; m0 < M; m0 += mc) {
     const int mm = (M - m0) < mc ? (M - m0) : mc;
-    int rc = conv_first_launch(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W,
-                               (long long)MAGAT_TILE_ROWS * 32,
-                               chain ? (long long)ptiles(H * W, 32) : (long long)H * W * MAGAT_TILE_ROWS * 32, stream,
-                               chain ? planes(H * W, 32) : 0, lay);
+    // Plane chain: the stem and layer1.conv1 run as ONE kernel (layer1_fused.hip) - the 121-pixel stem output never
+    // reaches HBM; buf[0] receives only its 36 stride-2 pixels, the input of the block's residual 1x1 branch.
+    // MAGAT_L1_FUSED=0 keeps the two launches.
+    bool fused1 = lay == 2 && W >= 4;
+    if (fused1) {
+      static int v = -1;
+      if (v < 0) { const char* e = getenv("MAGAT_L1_FUSED"); v = e ? atoi(e) : 1; }
+      fused1 = v != 0;
+    }
+    int rc;
+    if (fused1)
+      rc = magat_layer1_fused(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1],
+                              pk + d->off[24] + permuted(32, 9 * 32), pk + d->off[3], buf[1], buf[0], mm, H, W,
+                              static_cast<hipStream_t>(stream));
+    else
+      rc = conv_first_launch(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W,
+                             (long long)MAGAT_TILE_ROWS * 32,
+                             chain ? (long long)ptiles(H * W, 32) : (long long)H * W * MAGAT_TILE_ROWS * 32, stream,
+                             chain ? planes(H * W, 32) : 0, lay);
     if (rc != MAGAT_OK) return rc;
     int cur = 0;              // buffer holding the block input
     int hin = H, win = W;
@@ -393,8 +408,10 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       }
       g.in_gl = g.out_gl = lay;
       if (lay == 2) g.wt += permuted(s.cout, 9 * s.cin);
-      rc = magat_conv_gemm_f32(&g, stream);
-      if (rc != MAGAT_OK) return rc;
+      if (!(fused1 && l == 0)) {
+        rc = magat_conv_gemm_f32(&g, stream);
+        if (rc != MAGAT_OK) return rc;
+      }
       // conv2 + bn2 + (1x1 strided downsample + bn) + relu
       magat_conv_gemm_desc h = {};
       h.in = buf[mid]; h.in2 = buf[cur]; h.wt = pk + d->off[4 + 4 * l]; h.bias = pk + d->off[5 + 4 * l];
@@ -419,6 +436,9 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       }
       h.in_gl = lay; h.out_gl = l + 1 < nblocks ? lay : 0;
       if (lay == 2) h.wt += permuted(s.cout, 9 * s.cout + s.cin);
+      if (fused1 && l == 0) {    // the residual branch reads the stem's stride-2 pixels, stored as an Ho x Wo map
+        h.in2_tile_stride = tiles(hout * wout, s.cin); h.W2 = wout; h.stride2 = 1;
+      }
       rc = magat_conv_gemm_f32(&h, stream);
       if (rc != MAGAT_OK) return rc;
       cur = nxt; hin = hout; win = wout;

@@ -23,6 +23,8 @@ void magat_prof_end(int id, hipStream_t st);
 
 // bf16x6 split-MFMA GEMM (conv_gemm_bf16x6.hip), reached through magat_conv_gemm_f32 when desc->in_fmt == 1
 int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st);
+int magat_layer1_fused(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, void* out,
+                       void* ctr, int M, int H, int W, hipStream_t st);   // layer1_fused.hip
 int magat_conv_direct_enabled();   // f16x3 direct kernel on (MAGAT_CONV_DIRECT, default 1)
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of
