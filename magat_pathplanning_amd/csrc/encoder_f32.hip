@@ -366,7 +366,7 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
     // Plane chain: the stem and layer1.conv1 run as ONE kernel (layer1_fused.hip) - the 121-pixel stem output never
     // reaches HBM; buf[0] receives only its 36 stride-2 pixels, the input of the block's residual 1x1 branch.
     // MAGAT_L1_FUSED=0 keeps the two launches.
-    bool fused1 = lay == 2 && W >= 4;
+    bool fused1 = lay == 2 && magat_layer1_fused_lds(W) != 0;
     if (fused1) {
       static int v = -1;
       if (v < 0) { const char* e = getenv("MAGAT_L1_FUSED"); v = e ? atoi(e) : 1; }

@@ -50,33 +50,36 @@ __device__ __forceinline__ void split2(float x, float y, unsigned& p1, unsigned&
 #ifndef L1_EXP
 #define L1_EXP 0
 #endif
-constexpr int WS = 77;              // floats per agent window (75 used): odd stride, agents on distinct LDS banks
 constexpr float W0_SCALE = 256.f;   // stem weights are split as planes of 256 w (both planes normal numbers)
+constexpr int MAXV = 4;             // 16-byte loads per image row: W <= 16
 
-__global__ __launch_bounds__(256, 2) void layer1_fused_kernel(const L1Params p) {
+// Workgroup = (128 agents) x (one OUTPUT ROW of layer1.conv1), 8 waves: wave -> 32 agents x half of the row's pixels.
+// LDS: all nine taps of the layer1.conv1 weights (36 KB) + the agents' 5-row input windows:
+//   per agent  [0] | channel c: 5 rows of (W values, 0)      (stride WSTR floats, odd: agents on distinct banks)
+// the trailing zero of a row is also column -1 of the next row (and [0] that of the first), so the stem's zero padding
+// needs no index tests.  Staging cost is paid once per 128 x Wo output pixels.
+__global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) {
   extern __shared__ __attribute__((aligned(1024))) char l1smem[];
   char* const Ws = l1smem;                                           // layer1.conv1 weights: [tap][plane][32 rows][64 B]
-  float* const win = reinterpret_cast<float*>(l1smem + 9 * 4096);    // input windows [agent][c][5][5]
+  float* const win = reinterpret_cast<float*>(l1smem + 9 * 4096);
 
+  const int RW = p.W + 1, RB = 5 * RW, WSTR = (1 + 3 * RB) | 1;
   const int bid = blockIdx.x;
   const int xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
-  const int npix = p.Ho * p.Wo;
-  const int mtile = xcd + MAGAT_NUM_XCD * (slot / npix);
+  const int mtile = xcd + MAGAT_NUM_XCD * (slot / p.Ho);
   if (mtile >= p.Mt) return;
-  const int pix = slot % npix;
-  const int oy = pix / p.Wo, ox = pix % p.Wo;
+  const int oy = slot % p.Ho;
   const int m0 = mtile * 128;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int fr = lane & 31, fh = lane >> 5;
+  const int npix = p.Ho * p.Wo;
 
   // ---- staging -----------------------------------------------------------------------------------------------------
   // layer1.conv1 weights, every tap: 36 pieces of 1 KB (16 rows x 64 B of one plane and tap), LDS-direct
   {
     const char* wb = reinterpret_cast<const char*>(p.w1);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const int id = wave + 4 * i;                       // (tap * 2 + plane) * 2 + row half
+    for (int id = wave; id < 36; id += 8) {              // (tap * 2 + plane) * 2 + row half
       const int tap = id >> 2, plane = (id >> 1) & 1, row = (id & 1) * 16 + (lane >> 2);
       const int c = (lane & 3) ^ ((row >> 2) & 3);
       const char* src = wb + ((long long)plane * 32 * 288 + row * 288 + tap * 32 + c * 8) * 2;
@@ -84,51 +87,50 @@ __global__ __launch_bounds__(256, 2) void layer1_fused_kernel(const L1Params p) 
       asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
     }
   }
-  // input windows: rows 2 oy - 2 .. + 4, columns 2 ox - 2 .. + 4 of the three channels, zero outside the map.  One work
-  // item = one 5-float window row (agent, channel, row), fetched as ONE 16-byte load (dword-aligned, start clamped into
-  // the image row) + one scalar load: per-element 4-byte gathers cost 2.5x the address-coalescer cycles (the staging
-  // then took longer than all nine taps' arithmetic).
+  // input windows: image rows 2 oy - 2 .. 2 oy + 2 of the three channels.  One work item = one image row (agent,
+  // channel, row): ceil(W/4) 16-byte loads (dword-aligned; the last one clamped back into the row) - per-element
+  // 4-byte gathers cost several times the address-coalescer cycles.
   {
     typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
     const int HW = p.H * p.W;
-    const int wy0 = 2 * oy - 2, wx0 = 2 * ox - 2;
-    const int s0 = min(max(wx0, 0), p.W - 4);            // first column of the 16-byte load
-    const int e0 = min(max(wx0 + 4, 0), p.W - 1);        // column of the scalar load (window column 4)
-    const int shift = wx0 - s0;                          // window column wx sits at vector position wx + shift
-    constexpr int NIT = (128 * 15 + 255) / 256;          // 8 rows per thread
-    f32x4 v4[NIT];
-    float v1[NIT];
+    const int nv = (p.W + 3) / 4;
+    constexpr int NIT = (128 * 15 + 511) / 512;          // 4 rows per thread
+    f32x4 v4[NIT][MAXV];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int item = t + 256 * i;
+      const int item = t + 512 * i;
       const int a = item / 15, r = item - a * 15;
       const int c = r / 5, wy = r - c * 5;
-      const int iy = wy0 + wy;
+      const int iy = 2 * oy - 2 + wy;
       const bool ok = item < 128 * 15 && m0 + a < p.M && iy >= 0 && iy < p.H && L1_EXP != 2;
       const float* row = p.x + (long long)(m0 + a) * 3 * HW + c * HW + iy * p.W;
-      v4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      v1[i] = 0.f;
-      if (ok) {
-        v4[i] = *reinterpret_cast<const f32x4_u*>(row + s0);
-        v1[i] = row[e0];
+#pragma unroll
+      for (int j = 0; j < MAXV; ++j) {
+        v4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok && j < nv) v4[i][j] = *reinterpret_cast<const f32x4_u*>(row + min(4 * j, p.W - 4));
       }
     }
+    for (int i = t; i < 128; i += 512) win[i * WSTR] = 0.f;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int item = t + 256 * i;
+      const int item = t + 512 * i;
       const int a = item / 15, r = item - a * 15;
       if (item < 128 * 15) {
-        float* dst = win + a * WS + r * 5;
+        float* dst = win + a * WSTR + 1 + r * RW;
 #pragma unroll
-        for (int wx = 0; wx < 5; ++wx) {
-          const int ix = wx0 + wx, pos = wx + shift;
-          float val = wx == 4 ? v1[i] : 0.f;
-          if (pos == 0) val = v4[i][0];
-          if (pos == 1) val = v4[i][1];
-          if (pos == 2) val = v4[i][2];
-          if (pos == 3) val = v4[i][3];
-          dst[wx] = (ix >= 0 && ix < p.W) ? val : 0.f;
+        for (int j = 0; j < MAXV; ++j) {
+          const int sh = 4 * j - min(4 * j, p.W - 4);    // the clamped load starts sh columns early (uniform)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int col = 4 * j + e;
+            float val = v4[i][j][e];                     // sh = 0
+            if (sh == 1 && e < 3) val = v4[i][j][e + 1];
+            if (sh == 2 && e < 2) val = v4[i][j][e + 2];
+            if (sh == 3 && e < 1) val = v4[i][j][e + 3];
+            if (j < nv && col < p.W) dst[col] = val;
+          }
         }
+        dst[p.W] = 0.f;
       }
     }
   }
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void layer1_fused_kernel(const L1Params p) 
       const int k = 16 * ks + 8 * fh + i;
       wv[i] = k < 27 ? p.w0[fr * 27 + k] * W0_SCALE : 0.f;
       const int kk = k < 27 ? k : 0;
-      koff[ks][i] = (kk / 9) * 25 + ((kk % 9) / 3) * 5 + (kk % 3);
+      koff[ks][i] = (kk / 9) * RB + ((kk % 9) / 3) * RW + (kk % 3);
     }
     unsigned h1[4], h2[4];
 #pragma unroll
@@ -163,53 +165,105 @@ __global__ __launch_bounds__(256, 2) void layer1_fused_kernel(const L1Params p) 
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
-  // ---- taps ----------------------------------------------------------------------------------------------------------
-  const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;          // tap (ty, tx) reads stem pixel (iy0 + ty, ix0 + tx)
-  const int ty0 = iy0 < 0 ? 1 : 0, tx0 = ix0 < 0 ? 1 : 0;
-  const int ty1 = min(3, p.H - iy0), tx1 = min(3, p.W - ix0);
-  const int agent = 32 * wave + fr;                      // agent inside the tile
-  const float* wbase = win + agent * WS;
+  // ---- pixels of this wave: 32 agents x half of the output row -----------------------------------------------------------
+  const int agent = 32 * (wave & 3) + fr;                // agent inside the tile
   const int m = m0 + agent;
-  // plane-granule address of this lane's operand inside a 32-channel tile: + plane * 256 * 32 + ks * 4096
-  const long long tile_off = ((long long)mtile * npix + pix) * (128 * 32 * 4) + fh * 2048 + agent * 16;
-
-  f32x16 acc1, acc1b;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc1[r] = acc1b[r] = 0.f;
+  const int half = (p.Wo + 1) / 2;
+  const int ox_lo = (wave >> 2) * half, ox_hi = min(p.Wo, ox_lo + half);
+  const float* wbase = win + agent * WSTR;
+  const int iy0 = 2 * oy - 1;                            // tap (ty, tx) reads stem pixel (iy0 + ty, 2 ox - 1 + tx)
+  const int ty0 = iy0 < 0 ? 1 : 0, ty1 = min(3, p.H - iy0);
   constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};     // h1g1 h1g2 h2g1 (activation plane, weight plane)
 
-  for (int ty = ty0; ty < (L1_EXP == 1 ? ty0 : ty1); ++ty)
-    for (int tx = tx0; tx < tx1; ++tx) {
-      const float* wp = wbase + ty * 5 + tx;             // window coordinates of the 3x3 patch's corner = (ty, tx)
-      // 1. im2col row of the tap pixel -> f16 planes
-      u32x4 pb[2][2];
+  for (int ox = ox_lo; ox < ox_hi; ++ox) {
+    const int ix0 = 2 * ox - 1;
+    const int tx0 = ix0 < 0 ? 1 : 0, tx1 = min(3, p.W - ix0);
+    // plane-granule address of this lane's operand inside a 32-channel tile: + plane * 256 * 32 + ks * 4096
+    const long long tile_off = ((long long)mtile * npix + oy * p.Wo + ox) * (128 * 32 * 4) + fh * 2048 + agent * 16;
+    f32x16 acc1, acc1b;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        float pv[8];
+    for (int r = 0; r < 16; ++r) acc1[r] = acc1b[r] = 0.f;
+
+    for (int ty = ty0; ty < (L1_EXP == 1 ? ty0 : ty1); ++ty)
+      for (int tx = tx0; tx < tx1; ++tx) {
+        // window index of the 3x3 patch's corner: row ty (= stem row iy0 + ty - 1), column ix0 + tx - 1 (>= -1)
+        const float* wp = wbase + 1 + ty * RW + (ix0 + tx - 1);
+        // 1. im2col row of the tap pixel -> f16 planes
+        u32x4 pb[2][2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pv[i] = wp[koff[ks][i]];
-        unsigned h1[4], h2[4];
+        for (int ks = 0; ks < 2; ++ks) {
+          float pv[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split2(pv[2 * e], pv[2 * e + 1], h1[e], h2[e]);
-        pb[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
-        pb[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
+          for (int i = 0; i < 8; ++i) pv[i] = wp[koff[ks][i]];
+          unsigned h1[4], h2[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2(pv[2 * e], pv[2 * e + 1], h1[e], h2[e]);
+          pb[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
+          pb[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
+        }
+        // 2. stem: D[channel][agent] (k >= 27 carries zero weights); one accumulator per k step: two chains of three
+        //    dependent MFMAs instead of one of six
+        f32x16 acc0, acc0b;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc0b[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[0][PB[q]]),
+                                                        __builtin_bit_cast(f16x8, pb[0][PA[q]]), acc0, 0, 0, 0);
+          acc0b = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[1][PB[q]]),
+                                                         __builtin_bit_cast(f16x8, pb[1][PA[q]]), acc0b, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] += acc0b[r];
+        // 3. bias + ReLU -> f16 planes = layer1.conv1's operand of this tap (quads 2 ks, 2 ks + 1 -> k step ks)
+        u32x4 qa[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          unsigned h1[4], h2[4];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int g = 2 * ks + e;
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc0[4 * g + c] * (1.f / W0_SCALE) + bq0[g][c], 0.f);
+            split2(v[0], v[1], h1[2 * e], h2[2 * e]);
+            split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1]);
+          }
+          qa[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
+          qa[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
+        }
+        if (ty == 1 && tx == 1 && m < p.M) {             // stem pixel (2 oy, 2 ox): the residual branch's input
+          char* o = static_cast<char*>(p.ctr) + tile_off;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            *reinterpret_cast<u32x4*>(o + ks * 4096) = qa[ks][0];
+            *reinterpret_cast<u32x4*>(o + 256 * 32 + ks * 4096) = qa[ks][1];
+          }
+        }
+        // 4. layer1.conv1 tap product
+        const char* wt = Ws + (ty * 3 + tx) * 4096;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int c = 2 * ks + fh;
+          u32x4 fb[2];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+            fb[pl] = *reinterpret_cast<const u32x4*>(wt + pl * 2048 + (fr * 4 + (c ^ ((fr >> 2) & 3))) * 16);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            if (ks == 0)
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[PB[q]]),
+                                                            __builtin_bit_cast(f16x8, qa[ks][PA[q]]), acc1, 0, 0, 0);
+            else
+              acc1b = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[PB[q]]),
+                                                             __builtin_bit_cast(f16x8, qa[ks][PA[q]]), acc1b, 0, 0, 0);
+          }
+        }
       }
-      // 2. stem: D[channel][agent] (k >= 27 carries zero weights)
-      // (one accumulator per k step: two chains of three dependent MFMAs instead of one of six)
-      f32x16 acc0, acc0b;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[r] = acc0b[r] = 0.f;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[0][PB[q]]),
-                                                      __builtin_bit_cast(f16x8, pb[0][PA[q]]), acc0, 0, 0, 0);
-        acc0b = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[1][PB[q]]),
-                                                       __builtin_bit_cast(f16x8, pb[1][PA[q]]), acc0b, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[r] += acc0b[r];
-      // 3. bias + ReLU -> f16 planes = layer1.conv1's operand of this tap (quads 2 ks, 2 ks + 1 -> k step ks)
-      u32x4 qa[2][2];
+
+    // ---- layer1.conv1 output of this pixel as f16 plane granules ----------------------------------------------------------
+    if (m < p.M) {
+      char* o = static_cast<char*>(p.out) + tile_off;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         unsigned h1[4], h2[4];
@@ -218,65 +272,26 @@ __global__ __launch_bounds__(256, 2) void layer1_fused_kernel(const L1Params p) 
           const int g = 2 * ks + e;
           float v[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc0[4 * g + c] * (1.f / W0_SCALE) + bq0[g][c], 0.f);
+          for (int c = 0; c < 4; ++c) v[c] = fmaxf((acc1[4 * g + c] + acc1b[4 * g + c]) * scale1 + bq1[g][c], 0.f);
           split2(v[0], v[1], h1[2 * e], h2[2 * e]);
           split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1]);
         }
-        qa[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
-        qa[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
-      }
-      if (ty == 1 && tx == 1 && m < p.M) {               // stem pixel (2 oy, 2 ox): the residual branch's input
-        char* o = static_cast<char*>(p.ctr) + tile_off;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          *reinterpret_cast<u32x4*>(o + ks * 4096) = qa[ks][0];
-          *reinterpret_cast<u32x4*>(o + 256 * 32 + ks * 4096) = qa[ks][1];
-        }
-      }
-      // 4. layer1.conv1 tap product
-      const char* wt = Ws + (ty * 3 + tx) * 4096;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int c = 2 * ks + fh;
-        u32x4 fb[2];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-          fb[pl] = *reinterpret_cast<const u32x4*>(wt + pl * 2048 + (fr * 4 + (c ^ ((fr >> 2) & 3))) * 16);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          if (ks == 0)
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[PB[q]]),
-                                                          __builtin_bit_cast(f16x8, qa[ks][PA[q]]), acc1, 0, 0, 0);
-          else
-            acc1b = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[PB[q]]),
-                                                           __builtin_bit_cast(f16x8, qa[ks][PA[q]]), acc1b, 0, 0, 0);
-        }
+        *reinterpret_cast<u32x4*>(o + ks * 4096) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+        *reinterpret_cast<u32x4*>(o + 256 * 32 + ks * 4096) = u32x4{h2[0], h2[1], h2[2], h2[3]};
       }
     }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc1[r] += acc1b[r];
-
-  // ---- epilogue: layer1.conv1 output as f16 plane granules --------------------------------------------------------------
-  if (m >= p.M) return;
-  char* o = static_cast<char*>(p.out) + tile_off;
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    unsigned h1[4], h2[4];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int g = 2 * ks + e;
-      float v[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc1[4 * g + c] * scale1 + bq1[g][c], 0.f);
-      split2(v[0], v[1], h1[2 * e], h2[2 * e]);
-      split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1]);
-    }
-    *reinterpret_cast<u32x4*>(o + ks * 4096) = u32x4{h1[0], h1[1], h1[2], h1[3]};
-    *reinterpret_cast<u32x4*>(o + 256 * 32 + ks * 4096) = u32x4{h2[0], h2[1], h2[2], h2[3]};
   }
 }
 
 }  // namespace
+
+// LDS bytes of the fused kernel for a W-wide input map; 0 = does not fit / not supported (use the two-kernel path)
+size_t magat_layer1_fused_lds(int W) {
+  if (W < 4 || W > 4 * MAXV) return 0;
+  const size_t wstr = (size_t)((1 + 15 * (W + 1)) | 1);
+  const size_t lds = 9 * 4096 + 128 * wstr * sizeof(float);
+  return lds <= 160 * 1024 ? lds : 0;
+}
 
 // x (M,3,H,W) -> out, ctr: [ceil(M/128)][Ho*Wo] plane-granule tiles of 32 channels (128*32*4 bytes each), Ho = (H-1)/2+1.
 // w1 = f16 planes [2][32][288] of layer1.conv1 (K-permuted copy of the encoder pack) followed by the float 2^-e.
@@ -292,18 +307,19 @@ int magat_layer1_fused(const float* x, const float* w0, const float* b0, const f
   p.M = M; p.H = H; p.W = W; p.Ho = (H + 2 - 3) / 2 + 1; p.Wo = (W + 2 - 3) / 2 + 1;
   p.Mt = (M + 127) / 128;
   const long long groups = (p.Mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD;
-  const long long grid = groups * MAGAT_NUM_XCD * p.Ho * p.Wo;
+  const long long grid = groups * MAGAT_NUM_XCD * p.Ho;
   if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
-  constexpr size_t lds = 9 * 4096 + 128 * WS * sizeof(float);       // 76288 B: two workgroups per CU
-  static bool attr_set = false;
-  if (!attr_set) {
+  const size_t lds = magat_layer1_fused_lds(W);                     // 129.6 KB at W = 11: one 8-wave workgroup per CU
+  if (lds == 0) return MAGAT_ERR_UNSUPPORTED;
+  static size_t attr_lds = 0;
+  if (attr_lds < lds) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&layer1_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return MAGAT_ERR_LAUNCH;
-    attr_set = true;
+    attr_lds = lds;
   }
   const int pid = magat_prof_begin(MAGAT_TAG_CONV_FIRST, st);
-  hipLaunchKernelGGL(layer1_fused_kernel, dim3((unsigned)grid), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(layer1_fused_kernel, dim3((unsigned)grid), dim3(512), lds, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
