@@ -47,21 +47,34 @@ __device__ __forceinline__ void split2(float x, float y, unsigned& p1, unsigned&
   p2 = __builtin_bit_cast(unsigned, r);
 }
 
+// non-negative inputs: ReLU and the f16 range clamp are the same v_med3
+__device__ __forceinline__ void split2_relu(float x, float y, unsigned& p1, unsigned& p2) {
+  x = __builtin_amdgcn_fmed3f(x, 0.f, 65504.f);
+  y = __builtin_amdgcn_fmed3f(y, 0.f, 65504.f);
+  const f16x2 h = __builtin_convertvector(f32x2{x, y}, f16x2);
+  const f16x2 r = __builtin_convertvector(f32x2{x - (float)h[0], y - (float)h[1]}, f16x2);
+  p1 = __builtin_bit_cast(unsigned, h);
+  p2 = __builtin_bit_cast(unsigned, r);
+}
+
 #ifndef L1_EXP
 #define L1_EXP 0
 #endif
-constexpr float W0_SCALE = 256.f;   // stem weights are split as planes of 256 w (both planes normal numbers)
+constexpr float W0_SCALE = 16.f;    // stem weights (and bias) are split as planes of 16 w: the stem output is carried 16x
+                                    // too large (exact; saturates beyond 4094) and layer1.conv1's scale undoes it
 constexpr int MAXV = 4;             // 16-byte loads per image row: W <= 16
 
 // Workgroup = (128 agents) x (one OUTPUT ROW of layer1.conv1), 8 waves: wave -> 32 agents x half of the row's pixels.
 // LDS: all nine taps of the layer1.conv1 weights (36 KB) + the agents' 5-row input windows:
-//   per agent  [0] | channel c: 5 rows of (W values, 0)      (stride WSTR floats, odd: agents on distinct banks)
+//   per agent  [0] | channel c: 5 rows of (W values, 0)      (stride WSTR dwords, odd: agents on distinct banks)
 // the trailing zero of a row is also column -1 of the next row (and [0] that of the first), so the stem's zero padding
-// needs no index tests.  Staging cost is paid once per 128 x Wo output pixels.
+// needs no index tests.  Every value is stored SPLIT, as one dword (plane-0 half | plane-1 half << 16): a window value is
+// used by up to nine stem taps of up to three output pixels, so it is split once here, and a tap builds its MFMA operand
+// with one v_perm per two values.  Staging cost is paid once per 128 x Wo output pixels.
 __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) {
   extern __shared__ __attribute__((aligned(1024))) char l1smem[];
   char* const Ws = l1smem;                                           // layer1.conv1 weights: [tap][plane][32 rows][64 B]
-  float* const win = reinterpret_cast<float*>(l1smem + 9 * 4096);
+  unsigned* const win = reinterpret_cast<unsigned*>(l1smem + 9 * 4096);
 
   const int RW = p.W + 1, RB = 5 * RW, WSTR = (1 + 3 * RB) | 1;
   const int bid = blockIdx.x;
@@ -110,27 +123,34 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
         if (ok && j < nv) v4[i][j] = *reinterpret_cast<const f32x4_u*>(row + min(4 * j, p.W - 4));
       }
     }
-    for (int i = t; i < 128; i += 512) win[i * WSTR] = 0.f;
+    for (int i = t; i < 128; i += 512) win[i * WSTR] = 0u;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int item = t + 512 * i;
       const int a = item / 15, r = item - a * 15;
       if (item < 128 * 15) {
-        float* dst = win + a * WSTR + 1 + r * RW;
+        unsigned* dst = win + a * WSTR + 1 + r * RW;
 #pragma unroll
         for (int j = 0; j < MAXV; ++j) {
           const int sh = 4 * j - min(4 * j, p.W - 4);    // the clamped load starts sh columns early (uniform)
+          float val[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
+            val[e] = v4[i][j][e];                        // sh = 0
+            if (sh == 1 && e < 3) val[e] = v4[i][j][e + 1];
+            if (sh == 2 && e < 2) val[e] = v4[i][j][e + 2];
+            if (sh == 3 && e < 1) val[e] = v4[i][j][e + 3];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            unsigned p1, p2;
+            split2(val[e], val[e + 1], p1, p2);          // (h1a | h1b << 16), (h2a | h2b << 16)
             const int col = 4 * j + e;
-            float val = v4[i][j][e];                     // sh = 0
-            if (sh == 1 && e < 3) val = v4[i][j][e + 1];
-            if (sh == 2 && e < 2) val = v4[i][j][e + 2];
-            if (sh == 3 && e < 1) val = v4[i][j][e + 3];
-            if (j < nv && col < p.W) dst[col] = val;
+            if (j < nv && col < p.W) dst[col] = __builtin_amdgcn_perm(p2, p1, 0x05040100u);          // h1a | h2a << 16
+            if (j < nv && col + 1 < p.W) dst[col + 1] = __builtin_amdgcn_perm(p2, p1, 0x07060302u);  // h1b | h2b << 16
           }
         }
-        dst[p.W] = 0.f;
+        dst[p.W] = 0u;
       }
     }
   }
@@ -145,7 +165,7 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int k = 16 * ks + 8 * fh + i;
-      wv[i] = k < 27 ? p.w0[fr * 27 + k] * W0_SCALE : 0.f;
+      wv[i] = k < 27 ? p.w0[fr * 27 + k] * W0_SCALE : (k == 27 ? p.b0[fr] * W0_SCALE : 0.f);   // slot 27: bias x 1.0
       const int kk = k < 27 ? k : 0;
       koff[ks][i] = (kk / 9) * RB + ((kk % 9) / 3) * RW + (kk % 3);
     }
@@ -155,13 +175,11 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
     wa[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
     wa[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
   }
-  f32x4 bq0[4], bq1[4];
+  f32x4 bq1[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    bq0[g] = *reinterpret_cast<const f32x4*>(p.b0 + 8 * g + 4 * fh);
-    bq1[g] = *reinterpret_cast<const f32x4*>(p.b1 + 8 * g + 4 * fh);
-  }
-  const float scale1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.w1) + 2 * 32 * 288 * 2);
+  for (int g = 0; g < 4; ++g) bq1[g] = *reinterpret_cast<const f32x4*>(p.b1 + 8 * g + 4 * fh);
+  const float scale1 =
+      *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.w1) + 2 * 32 * 288 * 2) * (1.f / W0_SCALE);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
@@ -170,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
   const int m = m0 + agent;
   const int half = (p.Wo + 1) / 2;
   const int ox_lo = (wave >> 2) * half, ox_hi = min(p.Wo, ox_lo + half);
-  const float* wbase = win + agent * WSTR;
+  const unsigned* wbase = win + agent * WSTR;
   const int iy0 = 2 * oy - 1;                            // tap (ty, tx) reads stem pixel (iy0 + ty, 2 ox - 1 + tx)
   const int ty0 = iy0 < 0 ? 1 : 0, ty1 = min(3, p.H - iy0);
   constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};     // h1g1 h1g2 h2g1 (activation plane, weight plane)
@@ -187,35 +205,37 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
     for (int ty = ty0; ty < (L1_EXP == 1 ? ty0 : ty1); ++ty)
       for (int tx = tx0; tx < tx1; ++tx) {
         // window index of the 3x3 patch's corner: row ty (= stem row iy0 + ty - 1), column ix0 + tx - 1 (>= -1)
-        const float* wp = wbase + 1 + ty * RW + (ix0 + tx - 1);
-        // 1. im2col row of the tap pixel -> f16 planes
+        const unsigned* wp = wbase + 1 + ty * RW + (ix0 + tx - 1);
+        // 1. im2col row of the tap pixel: 16 packed (plane 0 | plane 1) dwords -> the two f16 operand planes by v_perm;
+        //    slot k = 27 (a zero-weight padding slot of the 27-wide row) carries the constant 1.0 against the bias
         u32x4 pb[2][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          float pv[8];
+          unsigned pv[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) pv[i] = wp[koff[ks][i]];
+          if (ks == 1) pv[3] = fh ? 0x00003C00u : pv[3];
           unsigned h1[4], h2[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) split2(pv[2 * e], pv[2 * e + 1], h1[e], h2[e]);
+          for (int e = 0; e < 4; ++e) {
+            h1[e] = __builtin_amdgcn_perm(pv[2 * e + 1], pv[2 * e], 0x05040100u);
+            h2[e] = __builtin_amdgcn_perm(pv[2 * e + 1], pv[2 * e], 0x07060302u);
+          }
           pb[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
           pb[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
         }
-        // 2. stem: D[channel][agent] (k >= 27 carries zero weights); one accumulator per k step: two chains of three
-        //    dependent MFMAs instead of one of six
-        f32x16 acc0, acc0b;
+        // 2. stem (+ bias): D[channel][agent] = 16 (w . x + b)
+        f32x16 acc0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = acc0b[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[0][PB[q]]),
-                                                        __builtin_bit_cast(f16x8, pb[0][PA[q]]), acc0, 0, 0, 0);
-          acc0b = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[1][PB[q]]),
-                                                         __builtin_bit_cast(f16x8, pb[1][PA[q]]), acc0b, 0, 0, 0);
-        }
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] += acc0b[r];
-        // 3. bias + ReLU -> f16 planes = layer1.conv1's operand of this tap (quads 2 ks, 2 ks + 1 -> k step ks)
+          for (int q = 0; q < 3; ++q)
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[ks][PB[q]]),
+                                                          __builtin_bit_cast(f16x8, pb[ks][PA[q]]), acc0, 0, 0, 0);
+        // 3. ReLU (the lower bound of the f16 clamp) -> f16 planes = layer1.conv1's operand of this tap (quads 2 ks,
+        //    2 ks + 1 -> k step ks), still 16x
         u32x4 qa[2][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -223,21 +243,26 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const int g = 2 * ks + e;
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc0[4 * g + c] * (1.f / W0_SCALE) + bq0[g][c], 0.f);
-            split2(v[0], v[1], h1[2 * e], h2[2 * e]);
-            split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1]);
+            split2_relu(acc0[4 * g], acc0[4 * g + 1], h1[2 * e], h2[2 * e]);
+            split2_relu(acc0[4 * g + 2], acc0[4 * g + 3], h1[2 * e + 1], h2[2 * e + 1]);
           }
           qa[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
           qa[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
         }
-        if (ty == 1 && tx == 1 && m < p.M) {             // stem pixel (2 oy, 2 ox): the residual branch's input
+        if (ty == 1 && tx == 1 && m < p.M) {             // stem pixel (2 oy, 2 ox): the residual branch's input, unscaled
           char* o = static_cast<char*>(p.ctr) + tile_off;
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            *reinterpret_cast<u32x4*>(o + ks * 4096) = qa[ks][0];
-            *reinterpret_cast<u32x4*>(o + 256 * 32 + ks * 4096) = qa[ks][1];
+            unsigned h1[4], h2[4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int g = 2 * ks + e;
+              split2_relu(acc0[4 * g] * (1.f / W0_SCALE), acc0[4 * g + 1] * (1.f / W0_SCALE), h1[2 * e], h2[2 * e]);
+              split2_relu(acc0[4 * g + 2] * (1.f / W0_SCALE), acc0[4 * g + 3] * (1.f / W0_SCALE), h1[2 * e + 1],
+                          h2[2 * e + 1]);
+            }
+            *reinterpret_cast<u32x4*>(o + ks * 4096) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+            *reinterpret_cast<u32x4*>(o + 256 * 32 + ks * 4096) = u32x4{h2[0], h2[1], h2[2], h2[3]};
           }
         }
         // 4. layer1.conv1 tap product
