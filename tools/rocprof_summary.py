@@ -27,6 +27,7 @@ def short(name):
                    ("conv_gemm_kernel<64, 128", "conv_gemm_f32<64,128>"),
                    ("conv_gemm_kernel<128, 128", "conv_gemm_f32<128,128>"), ("conv_gemm_kernel<128, 64", "conv_gemm_f32<128,64>"),
                    ("conv_gemm_kernel<128, 32", "conv_gemm_f32<128,32>"), ("conv_first_kernel", "conv_first"),
+                   ("layer1_fused_kernel", "layer1_fused(stem+layer1.conv1)"),
                    ("gat_dense_kernel", "gat_dense_kernel"), ("head_mean_relu", "head_mean_relu"),
                    ("pack_kernel", "gat_pack"), ("gso_prepare", "gso_prepare")):
         if key in name:
@@ -73,11 +74,13 @@ def main():
     SEQ = ["conv_first", "layer1.conv1", "layer1.conv2+ds", "layer2.conv1", "layer2.conv2+ds", "layer3.conv1",
            "layer3.conv2+ds", "head(avgpool+fc+linear)", "compressMLP", "gat_maps_gemm", "gat_graph", "actionsMLP"]
     ours = ("conv_gemm_kernel", "conv_gemm_bf16x6_kernel", "conv_gemm_f16x3_direct_kernel", "conv_first_kernel",
-            "gat_dense_kernel")
+            "layer1_fused_kernel", "gat_dense_kernel")
     layers = defaultdict(dict)
     tr = find(os.path.join(out, "trace"), "*kernel_trace.csv")
     if tr:
         rows = [r for r in csv.DictReader(open(tr)) if any(o in r["Kernel_Name"] for o in ours)]
+        if any("layer1_fused_kernel" in r["Kernel_Name"] for r in rows):     # stem + layer1.conv1 are one launch
+            SEQ = ["conv_first+layer1.conv1 (fused)"] + SEQ[2:]
         if len(rows) % len(SEQ) == 0:
             dur = defaultdict(list)
             for i, r in enumerate(rows):
