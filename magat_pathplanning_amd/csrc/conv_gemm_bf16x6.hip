@@ -741,9 +741,8 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
 
 // MAGAT_CONV_DIRECT=0 keeps f16x3 (in_fmt 4, out_fmt 0) on the 2x2 LDS-staged kernel
 int magat_conv_direct_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MAGAT_CONV_DIRECT"); v = e ? atoi(e) : 1; }
-  return v;
+  const char* e = getenv("MAGAT_CONV_DIRECT");         // (read per call: the parity tests flip it)
+  return e ? atoi(e) : 1;
 }
 
 // in_fmt 5: like 4, but in/in2 arrive as the two f16 planes already (written by a producer with out_fmt 3): no split work.

@@ -220,11 +220,8 @@ static int conv_first_launch(const float* x, const float* wt, const float* bias,
 // used to be a wash; since the activation split left the barrier section it wins: 351 -> 305 us and 342 -> 264 us);
 // 0 keeps every layer on the fp32 MFMA kernel.
 static int enc_split_mask(const magat_encoder_desc* d) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MAGAT_CONV_SPLIT");
-    v = e ? atoi(e) : 7;
-  }
+  const char* e = getenv("MAGAT_CONV_SPLIT");          // (read per call: the parity tests flip it)
+  const int v = e ? atoi(e) : 7;
   int m = 0;
   for (int l = 0; l < 3; ++l)
     if ((v >> l & 1) && d->off[18 + 2 * l] > 0 && d->off[19 + 2 * l] > 0) m |= 1 << l;
@@ -234,11 +231,8 @@ static int enc_split_mask(const magat_encoder_desc* d) {
 // Split flavour of those layers: f16x3 (two f16 planes, three v_mfma_f32_32x32x16_f16 per product, in_fmt 4) when the
 // pack carries the f16 weight planes, else bf16x6 (in_fmt 2).  MAGAT_CONV_F16=0 forces bf16x6.
 static bool enc_use_f16(const magat_encoder_desc* d, int l) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MAGAT_CONV_F16");
-    v = e ? atoi(e) : 1;
-  }
+  const char* e = getenv("MAGAT_CONV_F16");
+  const int v = e ? atoi(e) : 1;
   return v && d->off[24 + 2 * l] > 0 && d->off[25 + 2 * l] > 0;
 }
 
@@ -354,9 +348,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   // tap by every consumer's loader.  MAGAT_CONV_PCHAIN=0 keeps float32 granules.
   int lay = gl ? 1 : 0;
   if (gl && d->off[30] != 0) {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MAGAT_CONV_PCHAIN"); v = e ? atoi(e) : 1; }
-    if (v) lay = 2;
+    const char* e = getenv("MAGAT_CONV_PCHAIN");       // (read per call: the parity tests flip it)
+    if (!e || atoi(e)) lay = 2;
   }
   // float offset of the permuted copy behind an f16 weight block of cout x ktot weights (two planes + one scale float,
   // padded to 4 floats)
@@ -368,9 +361,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
     // MAGAT_L1_FUSED=0 keeps the two launches.
     bool fused1 = lay == 2 && magat_layer1_fused_lds(W) != 0;
     if (fused1) {
-      static int v = -1;
-      if (v < 0) { const char* e = getenv("MAGAT_L1_FUSED"); v = e ? atoi(e) : 1; }
-      fused1 = v != 0;
+      const char* e = getenv("MAGAT_L1_FUSED");        // (read per call)
+      fused1 = !e || atoi(e) != 0;
     }
     int rc;
     if (fused1)

@@ -880,11 +880,8 @@ int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, in
     use_split = e ? atoi(e) : 1;
   }
   if (use_split && NC % 32 == 0 && G % 32 == 0) {
-    static int use_f16 = -1;
-    if (use_f16 < 0) {
-      const char* e = getenv("MAGAT_CONV_F16");
-      use_f16 = e ? atoi(e) : 1;
-    }
+    const char* ef = getenv("MAGAT_CONV_F16");
+    const int use_f16 = ef ? atoi(ef) : 1;
     magat_conv_gemm_desc d = {};
     d.in = X;
     d.wt = use_f16 ? packed + magat_gat_f16_block_offset(NC, G) : packed + (((size_t)NC * (G + 1) + 3) & ~(size_t)3);

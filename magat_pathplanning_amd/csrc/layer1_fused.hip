@@ -57,9 +57,6 @@ __device__ __forceinline__ void split2_relu(float x, float y, unsigned& p1, unsi
   p2 = __builtin_bit_cast(unsigned, r);
 }
 
-#ifndef L1_EXP
-#define L1_EXP 0
-#endif
 constexpr float W0_SCALE = 16.f;    // stem weights (and bias) are split as planes of 16 w: the stem output is carried 16x
                                     // too large (exact; saturates beyond 4094) and layer1.conv1's scale undoes it
 constexpr int MAXV = 4;             // 16-byte loads per image row: W <= 16
@@ -115,7 +112,7 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
       const int a = item / 15, r = item - a * 15;
       const int c = r / 5, wy = r - c * 5;
       const int iy = 2 * oy - 2 + wy;
-      const bool ok = item < 128 * 15 && m0 + a < p.M && iy >= 0 && iy < p.H && L1_EXP != 2;
+      const bool ok = item < 128 * 15 && m0 + a < p.M && iy >= 0 && iy < p.H;
       const float* row = p.x + (long long)(m0 + a) * 3 * HW + c * HW + iy * p.W;
 #pragma unroll
       for (int j = 0; j < MAXV; ++j) {
@@ -202,7 +199,7 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] = acc1b[r] = 0.f;
 
-    for (int ty = ty0; ty < (L1_EXP == 1 ? ty0 : ty1); ++ty)
+    for (int ty = ty0; ty < ty1; ++ty)
       for (int tx = tx0; tx < tx1; ++tx) {
         // window index of the 3x3 patch's corner: row ty (= stem row iy0 + ty - 1), column ix0 + tx - 1 (>= -1)
         const unsigned* wp = wbase + 1 + ty * RW + (ix0 + tx - 1);

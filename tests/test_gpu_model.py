@@ -179,3 +179,36 @@ def test_model_bf16_gat_storage_config5_shape(gpu_device):
     print("bf16 GAT storage: max|dlogit| = %.3e, argmax agreement = %.4f" % (err, agree))
     assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
     assert agree >= 0.97, agree
+
+
+@pytest.mark.parametrize("cnn", ["ResNetLarge_withMLP", "ResNetSlim_withMLP"])
+def test_encoder_paths_agree(gpu_device, monkeypatch, cnn):
+    """The encoder's kernel paths are interchangeable: fused stem + layer1.conv1 vs two launches, f16 plane-granule vs
+    float32-granule activation tiles, direct vs 2x2 LDS-staged f16x3 GEMM, f16x3 vs bf16x6 vs fp32 MFMA - every
+    combination reproduces the oracle within the 1e-4 gate and the default path within 2e-5.  Ragged agent count
+    (B*N = 150: a partial 128-agent tile) on purpose."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N = 15, 10
+    cfg = make_config(num_agents=N, nGraphFilterTaps=2, nAttentionHeads=2, CNN_mode=cnn)
+    sd = orc.init_state_dict(cfg, seed=13)
+    x = fov_states(B, N, seed=5)
+    S = comm_gso(B, N, 20, seed=6, dtype=torch.float64)
+    ref = orc.planner_forward(x, S.clone(), sd, cfg).numpy()
+    net = _build(cfg, sd, gpu_device)
+    xd = x.to(gpu_device)
+    outs = {}
+    variants = [{}, {"MAGAT_L1_FUSED": "0"}, {"MAGAT_CONV_PCHAIN": "0"}, {"MAGAT_CONV_DIRECT": "0"},
+                {"MAGAT_CONV_KORDER": "0", "MAGAT_CONV_TM": "1"}, {"MAGAT_CONV_F16": "0"}, {"MAGAT_CONV_SPLIT": "0"}]
+    for env in variants:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with torch.no_grad():
+            net.addGSO(S.clone().to(gpu_device))
+            outs[tuple(sorted(env.items()))] = net(xd).cpu().numpy()
+        for k in env:
+            monkeypatch.delenv(k)
+    base = outs[()]
+    for key, got in outs.items():
+        assert np.abs(got - ref).max() <= TOL, (key, np.abs(got - ref).max())
+        assert np.abs(got - base).max() <= 2e-5, (key, np.abs(got - base).max())
