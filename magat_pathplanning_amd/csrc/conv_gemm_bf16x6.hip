@@ -47,6 +47,7 @@ struct SplitParams {
   int C2, lda2, W2, stride2;
   int Cout, Ktot, ldc, relu;
   int ntn, npix, tag, out_split;
+  int tepi;                 // direct kernel: row-major float32 output transposed through LDS (MAGAT_CONV_TEPI)
   int korder;               // direct kernel: 1 = channel slab outer, taps inner (MAGAT_CONV_KORDER)
   int in_gl, out_gl;        // direct kernel: granule-major agent tiles [C/4][128][4] for in/in2 resp. out
   const float* acc_scale;   // NPL == 2: device pointer to 1 / (power-of-two weight scale), applied before the bias
@@ -678,6 +679,48 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
 #pragma unroll
         for (int c = 0; c < 4; ++c) bq[j][q][c] = p.bias ? p.bias[n0 + j * 32 + 4 * fh + 8 * q + c] : 0.f;
   }
+  if (TN >= 2 && p.out_gl == 0 && vec && p.tepi) {
+    // Row-major float32 output (the GAT maps' Z, the last conv's map for the pooled head): the accumulator layout gives a
+    // lane four 16-byte pieces of ONE agent's row per channel tile, i.e. a store instruction scatters 64 pieces over 32
+    // rows.  Transposed through the (now idle) weight stages - one 64 BN-byte region per wave, 16-byte units XOR-swizzled
+    // by the agent - every store instruction writes four agents' BN/2-channel runs (256 B each at BN = 128).
+    constexpr int CP = BN / 2, UP = CP / 4;             // channels / 16-byte units per pass and agent
+    constexpr int JP = CP / 32;                          // channel tiles per pass
+    __syncthreads();                                     // every wave is done reading the weight stages
+    char* const wl = Bs + wave * (64 * BN);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = m0 + 32 * (TM * wave + i);
+#pragma unroll
+      for (int ps = 0; ps < TN / JP; ++ps) {
+#pragma unroll
+        for (int jj = 0; jj < JP; ++jj) {
+          const int j = ps * JP + jj;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[c] = acc[i][j][4 * q + c] * acc_scale + bq[j][q][c];
+              if (p.relu) v[c] = fmaxf(v[c], 0.f);
+            }
+            const int u = jj * 8 + 2 * q + fh;          // 16-byte unit of channels 32 jj + 8 q + 4 fh .. + 3
+            *reinterpret_cast<f32x4*>(wl + fr * (CP * 4) + ((u ^ (fr & (UP - 1))) * 16)) = v;
+          }
+        }
+#pragma unroll
+        for (int st = 0; st < 32 * UP / 64; ++st) {
+          const int r = st * (64 / UP) + lane / UP, u = lane % UP;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * (CP * 4) + ((u ^ (r & (UP - 1))) * 16));
+          const int m = mb + r;
+          if (m < p.M)
+            *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +
+                                      magat_row_off(m, p.ldc, p.out_tile) + n0 + ps * CP + 4 * u) = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + 32 * (TM * wave + i) + fr;
@@ -780,6 +823,7 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.npix = d->Hout * d->Wout; p.tag = d->tag; p.out_split = d->out_fmt;
   p.in_gl = d->in_gl; p.out_gl = d->out_gl;
   { const char* e = getenv("MAGAT_CONV_KORDER"); p.korder = e ? atoi(e) : 1; }
+  { const char* e = getenv("MAGAT_CONV_TEPI"); p.tepi = e ? atoi(e) : 1; }
   p.Mt = (p.M + BM - 1) / BM;
   p.ntn = p.Cout / BN;
   if (magat_row_off(p.M, p.lda, p.in_tile) * 4 >= 0xffffffffLL ||

@@ -29,7 +29,7 @@ def from_pl(buf, npix, c):   # inverse of to_pl on a float32-typed buffer of the
     out = torch.empty_like(v); out[..., idx.to(v.device)] = v
     return out
 
-shapes = (("l1.conv2+ds", 32, 32, 32, 6), ("l2.conv1", 32, 64, 0, 6), ("l2.conv2+ds", 64, 64, 32, 6), ("l3.conv1", 64, 128, 0, 6), ("l3.conv2+ds", 128, 128, 64, 6))
+shapes = (("gat_maps-like (1 pixel, N=2048)", 128, 2048, 0, 1), ("l1.conv2+ds", 32, 32, 32, 6), ("l2.conv1", 32, 64, 0, 6), ("l2.conv2+ds", 64, 64, 32, 6), ("l3.conv1", 64, 128, 0, 6), ("l3.conv2+ds", 128, 128, 64, 6))
 def taps(n):
     one = sum(sum(1 for t in range(3) if 0 <= o - 1 + t < n) for o in range(n)); return one * one
 for name, cin, cout, c2, hw in shapes:
