@@ -855,6 +855,16 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   } while (0)
   const int direct = magat_conv_direct_enabled();
   if ((d->in_gl || d->out_gl) && !(d->in_fmt == 4 && d->out_fmt == 0 && direct)) return MAGAT_ERR_UNSUPPORTED;
+  if (d->in_fmt == 4 && d->out_fmt == 0 && direct && d->in_gl == 2) {
+    // 3x3 / stride-1 layers with 128-channel tiles: two adjacent output pixels per workgroup (conv_gemm_f16x3_pair.hip).
+    // Opt-in (MAGAT_CONV_PAIR=1): bit-identical, 1/3 less activation traffic, but its single 8-wave workgroup per CU runs
+    // all waves in phase behind one barrier and measured 20 % SLOWER than two independent 4-wave workgroups.
+    const char* e = getenv("MAGAT_CONV_PAIR");
+    if (e && atoi(e)) {
+      const int rc = magat_conv_gemm_f16x3_pair(d, st);
+      if (rc != MAGAT_ERR_UNSUPPORTED) return rc;
+    }
+  }
   if (d->in_fmt == 4 && d->out_fmt == 0 && direct) {
     int tm2 = 2;               // MAGAT_CONV_TM=1: one 32-agent row group per wave everywhere
     { const char* e = getenv("MAGAT_CONV_TM"); if (e) tm2 = atoi(e); }
