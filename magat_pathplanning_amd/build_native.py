@@ -6,7 +6,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "libmagat_hip.so")
-SOURCES = ["conv_gemm_f32.hip", "conv_gemm_bf16x6.hip", "conv_gemm_f16x3_pair.hip", "gat_f32.hip", "gat_list_f32.hip", "gat_csr_f32.hip", "encoder_f32.hip", "layer1_fused.hip", "sim_frontend.hip", "profile.hip"]
+SOURCES = ["conv_gemm_f32.hip", "conv_gemm_bf16x6.hip", "conv_gemm_f16x3_pair.hip", "conv_gemm_f16x3_duo.hip", "gat_f32.hip", "gat_list_f32.hip", "gat_csr_f32.hip", "encoder_f32.hip", "layer1_fused.hip", "sim_frontend.hip", "profile.hip"]
 HEADERS = ["magat_common.h", os.path.join("..", "..", "include", "magat_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 

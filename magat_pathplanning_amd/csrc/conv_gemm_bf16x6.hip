@@ -859,6 +859,11 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
     // 3x3 / stride-1 layers with 128-channel tiles: two adjacent output pixels per workgroup (conv_gemm_f16x3_pair.hip).
     // Opt-in (MAGAT_CONV_PAIR=1): bit-identical, 1/3 less activation traffic, but its single 8-wave workgroup per CU runs
     // all waves in phase behind one barrier and measured 20 % SLOWER than two independent 4-wave workgroups.
+    const char* ed = getenv("MAGAT_CONV_DUO");        // two half-a-slab-apart halves per workgroup (conv_gemm_f16x3_duo.hip)
+    if (ed && atoi(ed)) {
+      const int rc = magat_conv_gemm_f16x3_duo(d, st);
+      if (rc != MAGAT_ERR_UNSUPPORTED) return rc;
+    }
     const char* e = getenv("MAGAT_CONV_PAIR");
     if (e && atoi(e)) {
       const int rc = magat_conv_gemm_f16x3_pair(d, st);

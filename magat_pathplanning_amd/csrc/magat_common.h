@@ -27,6 +27,7 @@ int magat_layer1_fused(const float* x, const float* w0, const float* b0, const f
                        void* ctr, int M, int H, int W, hipStream_t st);   // layer1_fused.hip
 size_t magat_layer1_fused_lds(int W);   // 0: the fused kernel does not take this map width
 int magat_conv_gemm_f16x3_pair(const magat_conv_gemm_desc* d, hipStream_t st);   // conv_gemm_f16x3_pair.hip
+int magat_conv_gemm_f16x3_duo(const magat_conv_gemm_desc* d, hipStream_t st);    // conv_gemm_f16x3_duo.hip
 int magat_conv_direct_enabled();   // f16x3 direct kernel on (MAGAT_CONV_DIRECT, default 1)
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of
