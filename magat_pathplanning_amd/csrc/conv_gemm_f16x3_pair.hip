@@ -50,10 +50,18 @@ __device__ __forceinline__ void split2(float x, float y, unsigned& p1, unsigned&
   p2 = __builtin_bit_cast(unsigned, r);
 }
 
-constexpr int BN = 128, TN = 4, BK = 32;
-constexpr int SLAB = 2 * BN * 64;                        // bytes of one weight slab in LDS: two planes of BN rows x 64 B
+constexpr int BK = 32;
 
-__global__ __launch_bounds__(512, 1) void conv_gemm_f16x3_pair_kernel(const PairParams p) {
+// <BN, TM, NW>: channel tile, 32-agent row groups per wave, waves per workgroup (32 TM NW agents per workgroup).
+//   <128, 1, 8>: 256 agents, wave = 32 agents x 128 channels x 2 pixels (opt-in, one 8-wave workgroup per CU)
+//   < 64, 2, 4>: 256 agents, wave = 64 agents x  64 channels x 2 pixels: the same 128 accumulator registers in the
+//                proven shape of two free-running 4-wave workgroups per CU - the default of the 64-channel 3x3 layers
+template <int BN, int TM, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_gemm_f16x3_pair_kernel(const PairParams p) {
+  constexpr int TN = BN / 32;
+  constexpr int SLAB = 2 * BN * 64;                      // bytes of one weight slab in LDS: two planes of BN rows x 64 B
+  constexpr int NPW = BN / 8 / NW;                       // weight pieces (1 KB) per wave and slab
+  static_assert(NPW >= 1 && NPW * NW * 8 == BN, "piece split");
   extern __shared__ __attribute__((aligned(1024))) char Bs[];   // [stage 2][slot 2][SLAB]
 
   const int bid = blockIdx.x;
@@ -65,7 +73,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_f16x3_pair_kernel(const Pair
   const int pair = rem / p.ntn, ntile = rem % p.ntn;
   const int hw = p.Wout >> 1;
   const int oy = pair / hw, x0 = 2 * (pair % hw);
-  const int m0 = mtile * 256, n0 = ntile * BN;
+  const int m0 = mtile * (32 * TM * NW), n0 = ntile * BN;
   const int ty0 = oy - 1 < 0 ? 1 : 0, ty1 = min(3, p.Hin - (oy - 1));
   const int c0 = x0 - 1 < 0 ? 1 : 0, c1 = min(4, p.Win - (x0 - 1));
   const int spt = p.Cin / BK, spt2 = p.C2 / BK;
@@ -75,27 +83,33 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_f16x3_pair_kernel(const Pair
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int fr = lane & 31, fh = lane >> 5;
 
-  f32x16 acc[2][TN];
+  f32x16 acc[2][TM][TN];         // [pixel][row group][channel tile]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int px = 0; px < 2; ++px)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[px][i][j][r] = 0.f;
 
   // plane-granule operand address of this lane (magat_hip.h in_gl = 2): + plane * 256 C + k step * 4096 + k0 * 256
-  const int mrow = min(m0 + 32 * wave + fr, p.M - 1);
-  const unsigned aoff = (unsigned)((mrow >> 7) * p.in_tile * 4 + fh * 2048 + (mrow & 127) * 16);
-  const unsigned aoff2 = (unsigned)((mrow >> 7) * p.in2_tile * 4 + fh * 2048 + (mrow & 127) * 16);
+  unsigned aoff[TM], aoff2[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int mrow = min(m0 + 32 * (TM * wave + i) + fr, p.M - 1);
+    aoff[i] = (unsigned)((mrow >> 7) * p.in_tile * 4 + fh * 2048 + (mrow & 127) * 16);
+    aoff2[i] = (unsigned)((mrow >> 7) * p.in2_tile * 4 + fh * 2048 + (mrow & 127) * 16);
+  }
   const int d2m = 256 * p.Cin, d2s = 256 * p.C2;
 
-  // weight slab pieces (1 KB = 16 rows x 64 B of one plane) this wave copies: piece id = wave + 8 i
-  long long boff[2];
-  unsigned bm0[2];
+  // weight slab pieces (1 KB = 16 rows x 64 B of one plane) this wave copies: piece id = wave + NW i
+  long long boff[NPW];
+  unsigned bm0[NPW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int id = wave + 8 * i;
-    const int plane = id >> 3, row = (id & 7) * 16 + (lane >> 2);
+  for (int i = 0; i < NPW; ++i) {
+    const int id = wave + NW * i;
+    const int plane = id / (BN / 16), row = (id % (BN / 16)) * 16 + (lane >> 2);
     const int c = (lane & 3) ^ ((row >> 2) & 3);
     boff[i] = ((long long)plane * p.wt_plane + (long long)(n0 + row) * p.Ktot + c * 8) * 2;
     bm0[i] = (unsigned)(uintptr_t)Bs + (unsigned)id * 1024u;
@@ -103,12 +117,14 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_f16x3_pair_kernel(const Pair
 
   // ---- step cursor ---------------------------------------------------------------------------------------------------
   int cur_seg = spt * (ty1 - ty0) * (c1 - c0) > 0 ? 0 : 1, cur_ks = 0, cur_ty = ty0, cur_c = c0;
-  const char* na;            // operand address of the next step
+  const char* na[TM];        // operand addresses of the next step
   int nd2, nmode, nbk0, nbk1;   // its plane distance, active slots (0: slot 0 = pixel 0 only; 1: both; 2: slot 1 = pixel 1 only), K offsets
   auto advance = [&]() {
     const int k0 = cur_ks * BK;
     if (cur_seg == 0) {
-      na = p.in + ((long long)((oy - 1 + cur_ty) * p.Win + (x0 - 1 + cur_c)) * p.in_pix) * 4 + (long long)k0 * 256 + aoff;
+      const char* ab = p.in + ((long long)((oy - 1 + cur_ty) * p.Win + (x0 - 1 + cur_c)) * p.in_pix) * 4 + (long long)k0 * 256;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) na[i] = ab + aoff[i];
       nd2 = d2m;
       nmode = cur_c == 0 ? 0 : (cur_c == 3 ? 2 : 1);
       nbk0 = (cur_ty * 3 + cur_c) * p.Cin + k0;
@@ -122,7 +138,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_f16x3_pair_kernel(const Pair
       }
     } else {
       const int px = cur_seg - 1;
-      na = p.in2 + ((long long)(oy * p.W2 + x0 + px) * p.in2_pix) * 4 + (long long)k0 * 256 + aoff2;
+      const char* ab = p.in2 + ((long long)(oy * p.W2 + x0 + px) * p.in2_pix) * 4 + (long long)k0 * 256;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) na[i] = ab + aoff2[i];
       nd2 = d2s;
       nmode = px == 0 ? 0 : 2;
       nbk0 = 9 * p.Cin + k0;
@@ -130,24 +148,27 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_f16x3_pair_kernel(const Pair
       if (++cur_ks == spt2) { cur_ks = 0; ++cur_seg; }
     }
   };
-  u32x4 fa[4];                  // the next step's operands [plane][k step] as loaded
-  auto load_a = [&]() {
-    fa[0] = *reinterpret_cast<const u32x4*>(na);
-    fa[1] = *reinterpret_cast<const u32x4*>(na + 4096);
-    fa[2] = *reinterpret_cast<const u32x4*>(na + nd2);
-    fa[3] = *reinterpret_cast<const u32x4*>(na + nd2 + 4096);
+  u32x4 fa[TM][4];              // the next step's operands [row group][plane * 2 + k step] as loaded
+  auto load_a = [&](int i) {
+    fa[i][0] = *reinterpret_cast<const u32x4*>(na[i]);
+    fa[i][1] = *reinterpret_cast<const u32x4*>(na[i] + 4096);
+    fa[i][2] = *reinterpret_cast<const u32x4*>(na[i] + nd2);
+    fa[i][3] = *reinterpret_cast<const u32x4*>(na[i] + nd2 + 4096);
   };
-  // weight piece e (0, 1: slot 0; 2, 3: slot 1) of the next step into stage `stage`
+  // weight piece e (0 .. NPW-1: slot 0; NPW .. 2 NPW-1: slot 1) of the next step into stage `stage`
   auto dma = [&](int e, int stage) {
-    const int sl = e >> 1, i = e & 1;
+    const int sl = e / NPW, i = e % NPW;
     const char* src = p.wt + (long long)(sl ? nbk1 : nbk0) * 2 + boff[i];
     const unsigned m0v =
         __builtin_amdgcn_readfirstlane(bm0[i] + (unsigned)(stage * 2 + sl) * (unsigned)SLAB);
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
   };
-  u32x4 qa[2][2];               // [k step][plane] of the current step
+  u32x4 qa[TM][2][2];           // [row group][k step][plane] of the current step
   auto take_regs = [&]() {
-    qa[0][0] = fa[0]; qa[1][0] = fa[1]; qa[0][1] = fa[2]; qa[1][1] = fa[3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      qa[i][0][0] = fa[i][0]; qa[i][1][0] = fa[i][1]; qa[i][0][1] = fa[i][2]; qa[i][1][1] = fa[i][3];
+    }
   };
   auto landed = [&]() {
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
@@ -158,9 +179,13 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_f16x3_pair_kernel(const Pair
   if (nsteps > 0) {
     advance();
     cmode = nmode;
-    load_a();
-    if (nmode != 2) { dma(0, 0); dma(1, 0); }
-    if (nmode != 0) { dma(2, 0); dma(3, 0); }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) load_a(i);
+#pragma unroll
+    for (int e = 0; e < NPW; ++e) {
+      if (nmode != 2) dma(e, 0);
+      if (nmode != 0) dma(NPW + e, 0);
+    }
     take_regs();
     landed();
   }
@@ -176,9 +201,21 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_f16x3_pair_kernel(const Pair
     auto gap = [&]() {
       if constexpr (IL) {
         __builtin_amdgcn_sched_barrier(0);
-        if (g == 0) load_a();
-        else if (g <= 2) { if (nmode != 2) dma(g - 1, nstage); }
-        else if (g <= 4) { if (nmode != 0) dma(g - 1, nstage); }
+        // gaps 0 .. TM-1: operand loads; then the slot-0 pieces, then the slot-1 pieces.  The gap counter is a run-time
+        // value (slot blocks are skipped by branches), the array indices must not be: indexed by g, the operand buffers
+        // and piece offsets were demoted to scratch memory (2.5x slower).
+        if constexpr (TM == 1) {
+          if (g == 0) load_a(0);
+          else if (g <= 2) { if (nmode != 2) dma(g - 1, nstage); }
+          else if (g <= 4) { if (nmode != 0) dma(g - 1, nstage); }
+        } else {
+#pragma unroll
+          for (int k = 0; k < TM; ++k)
+            if (g == k) load_a(k);
+#pragma unroll
+          for (int k = 0; k < 2 * NPW; ++k)
+            if (g == TM + k && (k < NPW ? nmode != 2 : nmode != 0)) dma(k, nstage);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       ++g;
@@ -198,10 +235,12 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_f16x3_pair_kernel(const Pair
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[PX][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j][PB[q]]),
-                                                              __builtin_bit_cast(f16x8, qa[ks][PA[q]]), acc[PX][j], 0, 0,
-                                                              0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[PX][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j][PB[q]]),
+                                                                   __builtin_bit_cast(f16x8, qa[i][ks][PA[q]]),
+                                                                   acc[PX][i][j], 0, 0, 0);
         gap();
       }
     };
@@ -230,77 +269,82 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_f16x3_pair_kernel(const Pair
       else bq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  const int m = m0 + 32 * wave + fr;
   if (p.out_gl == 0) {
-    // row-major float32 (the last conv's map for the pooled head): transposed through the idle weight stages, 8 KB per
-    // wave, 16-byte units XOR-swizzled by the agent - every store instruction writes four agents' 64-channel runs
-    __syncthreads();
-    char* const wl = Bs + wave * 8192;
+    if constexpr (BN == 128 && TM == 1) {
+      // row-major float32 (the last conv's map for the pooled head): transposed through the idle weight stages, 8 KB per
+      // wave, 16-byte units XOR-swizzled by the agent - every store instruction writes four agents' 64-channel runs
+      __syncthreads();
+      char* const wl = Bs + wave * 8192;
 #pragma unroll
-    for (int px = 0; px < 2; ++px) {
-      const int pix = oy * p.Wout + x0 + px;
+      for (int px = 0; px < 2; ++px) {
+        const int pix = oy * p.Wout + x0 + px;
 #pragma unroll
-      for (int ps = 0; ps < 2; ++ps) {
+        for (int ps = 0; ps < 2; ++ps) {
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int j = ps * 2 + jj;
-          f32x4 bq[4];
-          bias_of(j, bq);
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = ps * 2 + jj;
+            f32x4 bq[4];
+            bias_of(j, bq);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 v;
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              v[c] = acc[px][j][4 * q + c] * acc_scale + bq[q][c];
-              if (p.relu) v[c] = fmaxf(v[c], 0.f);
+              for (int c = 0; c < 4; ++c) {
+                v[c] = acc[px][0][j][4 * q + c] * acc_scale + bq[q][c];
+                if (p.relu) v[c] = fmaxf(v[c], 0.f);
+              }
+              const int u = jj * 8 + 2 * q + fh;
+              *reinterpret_cast<f32x4*>(wl + fr * 256 + ((u ^ (fr & 15)) * 16)) = v;
             }
-            const int u = jj * 8 + 2 * q + fh;
-            *reinterpret_cast<f32x4*>(wl + fr * 256 + ((u ^ (fr & 15)) * 16)) = v;
           }
-        }
 #pragma unroll
-        for (int st = 0; st < 8; ++st) {
-          const int r = st * 4 + (lane >> 4), u = lane & 15;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 256 + ((u ^ (r & 15)) * 16));
-          const int mm = m0 + 32 * wave + r;
-          if (mm < p.M)
-            *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + (long long)pix * p.out_pix +
-                                      magat_row_off(mm, p.ldc, p.out_tile) + n0 + ps * 64 + 4 * u) = v;
+          for (int st = 0; st < 8; ++st) {
+            const int r = st * 4 + (lane >> 4), u = lane & 15;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 256 + ((u ^ (r & 15)) * 16));
+            const int mm = m0 + 32 * wave + r;
+            if (mm < p.M)
+              *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + (long long)pix * p.out_pix +
+                                        magat_row_off(mm, p.ldc, p.out_tile) + n0 + ps * 64 + 4 * u) = v;
+          }
         }
       }
     }
-    return;
+    return;                     // (the host sends row-major outputs of other shapes to the one-pixel kernel)
   }
-  if (m >= p.M) return;
 #pragma unroll
   for (int px = 0; px < 2; ++px) {
     const int pix = oy * p.Wout + x0 + px;
-    // f16 plane granules for the next f16x3 layer (out_gl = 2)
-    char* const ob = static_cast<char*>(p.out) + ((long long)pix * p.out_pix + (long long)(m >> 7) * p.out_tile) * 4 +
-                     fh * 2048 + (m & 127) * 16;
-    const long long oplane = 256LL * p.Cout;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      f32x4 bq[4];
-      bias_of(j, bq);
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + 32 * (TM * wave + i) + fr;
+      if (m >= p.M) continue;
+      // f16 plane granules for the next f16x3 layer (out_gl = 2)
+      char* const ob = static_cast<char*>(p.out) + ((long long)pix * p.out_pix + (long long)(m >> 7) * p.out_tile) * 4 +
+                       fh * 2048 + (m & 127) * 16;
+      const long long oplane = 256LL * p.Cout;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        unsigned h1[4], h2[4];
+      for (int j = 0; j < TN; ++j) {
+        f32x4 bq[4];
+        bias_of(j, bq);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int q = 2 * ks + e;
-          float v[4];
+        for (int ks = 0; ks < 2; ++ks) {
+          unsigned h1[4], h2[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            v[c] = acc[px][j][4 * q + c] * acc_scale + bq[q][c];
-            if (p.relu) v[c] = fmaxf(v[c], 0.f);
+          for (int e = 0; e < 2; ++e) {
+            const int q = 2 * ks + e;
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[c] = acc[px][i][j][4 * q + c] * acc_scale + bq[q][c];
+              if (p.relu) v[c] = fmaxf(v[c], 0.f);
+            }
+            split2(v[0], v[1], h1[2 * e], h2[2 * e]);
+            split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1]);
           }
-          split2(v[0], v[1], h1[2 * e], h2[2 * e]);
-          split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1]);
+          char* const o = ob + (long long)(((n0 >> 5) + j) * 2 + ks) * 4096;
+          *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+          *reinterpret_cast<u32x4*>(o + oplane) = u32x4{h2[0], h2[1], h2[2], h2[3]};
         }
-        char* const o = ob + (long long)(((n0 >> 5) + j) * 2 + ks) * 4096;
-        *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
-        *reinterpret_cast<u32x4*>(o + oplane) = u32x4{h2[0], h2[1], h2[2], h2[3]};
       }
     }
   }
@@ -316,8 +360,10 @@ int magat_conv_gemm_f16x3_pair(const magat_conv_gemm_desc* d, hipStream_t st) {
   if (d->kH != 3 || d->kW != 3 || d->stride != 1 || d->pad != 1 || d->Hout != d->Hin || d->Wout != d->Win || (d->Wout & 1) ||
       d->pool)
     return MAGAT_ERR_UNSUPPORTED;
-  if ((d->Cout % 128) || (d->Cin % 32) || (d->C2 % 32) || (d->C2 > 0 && (d->stride2 != 1 || d->W2 != d->Wout || !d->in2)))
+  const int bn = d->Cout % 128 == 0 ? 128 : 64;
+  if ((d->Cout % 64) || (d->Cin % 32) || (d->C2 % 32) || (d->C2 > 0 && (d->stride2 != 1 || d->W2 != d->Wout || !d->in2)))
     return MAGAT_ERR_UNSUPPORTED;
+  if (bn == 64 && d->out_gl != 2) return MAGAT_ERR_UNSUPPORTED;
   if (d->out_gl == 0 && ((d->ldc & 3) || (reinterpret_cast<uintptr_t>(d->out) & 15))) return MAGAT_ERR_UNSUPPORTED;
   if (d->bias && (reinterpret_cast<uintptr_t>(d->bias) & 15)) return MAGAT_ERR_UNSUPPORTED;
   PairParams p;
@@ -334,7 +380,7 @@ int magat_conv_gemm_f16x3_pair(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.Cin = d->Cin; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
   p.C2 = d->C2; p.W2 = d->W2; p.Cout = d->Cout; p.Ktot = 9 * d->Cin + d->C2; p.ldc = d->ldc; p.relu = d->relu;
   p.wt_plane = (long long)p.Cout * p.Ktot;
-  p.ntn = p.Cout / BN; p.npair = d->Hout * (d->Wout / 2); p.out_gl = d->out_gl; p.tag = d->tag;
+  p.ntn = p.Cout / bn; p.npair = d->Hout * (d->Wout / 2); p.out_gl = d->out_gl; p.tag = d->tag;
   p.acc_scale = reinterpret_cast<const float*>(p.wt + (size_t)2 * p.Cout * p.Ktot * 2);
   const long long t128 = (d->M + 127) / 128;
   if (t128 * p.in_tile * 4 >= 0xffffffffLL || (p.C2 > 0 && t128 * p.in2_tile * 4 >= 0xffffffffLL))
@@ -342,16 +388,24 @@ int magat_conv_gemm_f16x3_pair(const magat_conv_gemm_desc* d, hipStream_t st) {
   const long long groups = (p.Mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD;
   const long long grid = groups * MAGAT_NUM_XCD * p.npair * p.ntn;
   if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
-  constexpr size_t lds = 2 * 2 * (size_t)SLAB;          // 64 KB
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_f16x3_pair_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return MAGAT_ERR_LAUNCH;
-    attr_set = true;
+  const int pid_dummy = 0; (void)pid_dummy;
+  if (bn == 128) {
+    constexpr size_t lds = 2 * 2 * (size_t)(2 * 128 * 64);          // 64 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_f16x3_pair_kernel<128, 1, 8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return MAGAT_ERR_LAUNCH;
+      attr_set = true;
+    }
+    const int pid = magat_prof_begin(p.tag, st);
+    hipLaunchKernelGGL((conv_gemm_f16x3_pair_kernel<128, 1, 8>), dim3((unsigned)grid), dim3(512), lds, st, p);
+    magat_prof_end(pid, st);
+    return magat_check_launch();
   }
+  constexpr size_t lds64 = 2 * 2 * (size_t)(2 * 64 * 64);            // 32 KB
   const int pid = magat_prof_begin(p.tag, st);
-  hipLaunchKernelGGL(conv_gemm_f16x3_pair_kernel, dim3((unsigned)grid), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((conv_gemm_f16x3_pair_kernel<64, 2, 4>), dim3((unsigned)grid), dim3(256), lds64, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
