@@ -227,6 +227,14 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_f16x3_duo_kernel(const DuoPa
     if (s + 1 < nslab) step(s + 1, Y);
   }
   if (half == 0) seg_barrier();          // half A idles through the last segment
+  // The last load segments' (unused) operand loads may still be in flight: their destination registers must stay reserved
+  // until they have landed - a dead asm output is a free register to the compiler, and a late load return into an
+  // address temporary faulted (odd slab counts).
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(X[i][k]), "v"(Y[i][k]));
 
   // ---- epilogue (as the direct kernel) -------------------------------------------------------------------------------------
   const float acc_scale = *p.acc_scale;

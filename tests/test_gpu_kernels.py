@@ -676,3 +676,59 @@ def test_conv_gemm_f16x3_granule_layouts(gpu_device, monkeypatch, korder):
     assert float((res[0].double() - ref).abs().max()) <= 3e-6 * scale
     assert float((res[2].double() - ref).abs().max()) <= 3e-6 * scale
     assert float((res[2] - res[0]).abs().max()) <= 3e-6 * scale
+
+
+@pytest.mark.gpu
+def test_conv_gemm_f16x3_direct_256_agent_tiles_ragged(gpu_device, monkeypatch):
+    """The 256-agent-tile form of the direct kernel (TM = 2, taken when the grid is large) on a ragged agent count
+    (14700 = 57 full tiles + 108 agents) is bit-identical to the 128-agent form, for float32 granules and f16 plane
+    granules, row-major and granule outputs; so are the opt-in pair / duo kernels."""
+    from magat_pathplanning_amd.encoder import split_f16x2
+    nat, lib = _nat()
+    M, cin, cout, c2, npix = 14700, 32, 128, 32, 36
+    Mp = (M + 127) // 128 * 128
+    g = torch.Generator().manual_seed(21)
+    perm = torch.tensor([16 * (q >> 4) + 8 * ((q & 7) >> 2) + 4 * ((q >> 3) & 1) + (q & 3) for q in range(32)])
+
+    def kidx(c):
+        return (torch.arange(c) // 32) * 32 + perm.repeat(c // 32)
+
+    def to_pl(t):
+        c = t.shape[-1]
+        tp = t.clamp(-65504.0, 65504.0)[..., kidx(c).to(t.device)]
+        h1 = tp.half()
+        pl = torch.stack((h1, (tp - h1.float()).half()), dim=1)
+        return pl.view(npix, 2, Mp // 128, 128, c // 8, 8).permute(0, 2, 1, 4, 3, 5).contiguous()
+
+    x = torch.zeros(npix, Mp, cin, device=gpu_device)
+    x[:, :M] = torch.relu(torch.randn(npix, M, cin, generator=g)).to(gpu_device)
+    x2 = torch.zeros(npix, Mp, c2, device=gpu_device)
+    x2[:, :M] = torch.relu(torch.randn(npix, M, c2, generator=g)).to(gpu_device)
+    wt = (torch.randn(cout, 9 * cin + c2, generator=g) / (9 * cin) ** 0.5).contiguous()
+    wsp = split_f16x2(wt[:, kidx(wt.shape[1])])[0].to(gpu_device)
+    bd = torch.randn(cout, generator=g).to(gpu_device)
+    xi, x2i = to_pl(x), to_pl(x2)
+    outs = {}
+    for out_gl in (0, 2):
+        for env in ({"MAGAT_CONV_TM": "1"}, {}, {"MAGAT_CONV_PAIR": "1"}, {"MAGAT_CONV_DUO": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            out = torch.full((npix, Mp, cout), 7.0, device=gpu_device)
+            d = nat.ConvGemmDesc()
+            d.inp, d.in2, d.wt, d.bias, d.out = xi.data_ptr(), x2i.data_ptr(), wsp.data_ptr(), bd.data_ptr(), out.data_ptr()
+            d.in_pix_stride, d.in2_pix_stride, d.out_pix_stride = Mp * cin, Mp * c2, Mp * cout
+            d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, 6, 6, 3, 3, 1, 1
+            d.C2, d.lda2, d.W2, d.stride2 = c2, c2, 6, 1
+            d.Hout, d.Wout, d.Cout, d.ldc, d.relu, d.in_fmt, d.in_gl, d.out_gl = 6, 6, cout, cout, 1, 4, 2, out_gl
+            nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "direct kernel %s" % env)
+            torch.cuda.synchronize()
+            for k in env:
+                monkeypatch.delenv(k)
+            outs[(out_gl, tuple(env))] = out
+        ref = outs[(out_gl, ("MAGAT_CONV_TM",))]
+        assert not torch.isnan(ref[:, :M]).any()
+        if out_gl == 0:          # rows past M are never written
+            assert bool((ref[:, M:] == 7.0).all())
+        for key, got in outs.items():
+            if key[0] == out_gl:
+                assert torch.equal(got, ref), key
