@@ -59,7 +59,7 @@ __device__ __forceinline__ void split2_relu(float x, float y, unsigned& p1, unsi
 
 constexpr float W0_SCALE = 16.f;    // stem weights (and bias) are split as planes of 16 w: the stem output is carried 16x
                                     // too large (exact; saturates beyond 4094) and layer1.conv1's scale undoes it
-constexpr int MAXV = 4;             // 16-byte loads per image row: W <= 16
+constexpr int MAXV = 4;             // 16-byte loads per image row: W <= 16 (the LDS windows fit up to W = 15)
 
 // Workgroup = (128 agents) x (one OUTPUT ROW of layer1.conv1), 8 waves: wave -> 32 agents x half of the row's pixels.
 // LDS: all nine taps of the layer1.conv1 weights (36 KB) + the agents' 5-row input windows:

@@ -213,3 +213,47 @@ def test_encoder_paths_agree(gpu_device, monkeypatch, cnn):
     for key, got in outs.items():
         assert np.abs(got - ref).max() <= TOL, (key, np.abs(got - ref).max())
         assert np.abs(got - base).max() <= 2e-5, (key, np.abs(got - base).max())
+
+
+@pytest.mark.parametrize("hw,cnn", [(7, "ResNetLarge"), (9, "ResNetLarge"), (12, "ResNetSlim"), (13, "ResNetSlim"),
+                                    (15, "ResNetLarge")])
+def test_encoder_other_map_sizes(gpu_device, monkeypatch, hw, cnn):
+    """The encoder C entry at map sizes other than the reference's 11x11 (its ResNet heads hard-wire 1152 features, so
+    this is below the module level): fused stem + layer1.conv1 (odd / even output widths, maps up to 15 wide: the LDS limit of its windows),
+    plane-granule chain, float32-granule chain and - up to 11x11, the LDS limit of the stand-alone stem kernel - the
+    two-kernel path, against the oracle's conv stack."""
+    import ctypes
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd import _native as nat, encoder as enc
+    from magat_pathplanning_amd.synthetic import make_config
+    lib = nat.lib()
+    M = 150
+    cfg = make_config(CNN_mode=cnn)
+    sd = orc.init_state_dict(cfg, seed=23)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(M, 3, hw, hw, generator=g) < 0.3).float() + 0.25 * torch.rand(M, 3, hw, hw, generator=g)
+    ref = orc.resnet_forward(x.double(), {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}).flatten(1)
+    pack, offs, meta = enc.fold_resnet(sd, hw, hw, "ConvLayers.0", None, None)
+    packd = pack.to(gpu_device)
+    d = nat.EncoderDesc()
+    d.variant, d.H, d.W, d.n_feat, d.n_comp, d.pack = meta["variant"], hw, hw, meta["n_feat"], 0, packd.data_ptr()
+    for i, o in enumerate(offs):
+        d.off[i] = o
+    assert meta["n_feat"] == ref.shape[1]
+    xd = x.to(gpu_device)
+    ws = torch.empty(lib.magat_encoder_workspace_bytes(ctypes.byref(d), M), dtype=torch.uint8, device=gpu_device)
+    scale = float(ref.abs().max())
+    outs = []
+    envs = [{}] + ([{"MAGAT_L1_FUSED": "0"}, {"MAGAT_CONV_PCHAIN": "0"}] if hw <= 11 else [])
+    for env in envs:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        feat = torch.full((M, meta["n_feat"]), float("nan"), device=gpu_device)
+        nat.check(lib.magat_encoder_forward_f32(ctypes.byref(d), nat.ptr(xd), nat.ptr(feat), meta["n_feat"], None, 0,
+                                                nat.ptr(ws), ws.numel(), M, nat.current_stream(gpu_device)), "encoder")
+        torch.cuda.synchronize()
+        for k in env:
+            monkeypatch.delenv(k)
+        got = feat.double().cpu()
+        assert float((got - ref).abs().max()) <= 2e-5 * max(scale, 1.0), (env, float((got - ref).abs().max()), scale)
+        outs.append(got)
