@@ -230,6 +230,11 @@ typedef struct magat_conv_gemm_desc {
    *      such a copy behind each f16 weight block).  Values are split once by the producer instead of once per tap by
    *      every consumer. */
   int in_gl, out_gl;
+  /* Row-major float32 output split into column tiles (f16x3 direct kernel, out_gl = 0 only): when > 0, the 128-channel tile
+   * t of the output lives at out + t * out_ntile_stride (+ pixel offset) with row stride ldc, instead of at column 128 t of
+   * one ldc-wide row - every workgroup then writes ONE contiguous region (the GAT maps' Z: consumed as per-instance
+   * [N][128] tiles).  0 = plain rows. */
+  int64_t out_ntile_stride;
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 

@@ -44,7 +44,7 @@ class ConvGemmDesc(ctypes.Structure):
                 ("out_plane_stride", ctypes.c_int64),
                 ("in_tile_stride", ctypes.c_int64), ("in2_tile_stride", ctypes.c_int64),
                 ("out_tile_stride", ctypes.c_int64),
-                ("in_gl", ctypes.c_int), ("out_gl", ctypes.c_int)]
+                ("in_gl", ctypes.c_int), ("out_gl", ctypes.c_int), ("out_ntile_stride", ctypes.c_int64)]
 
 
 class EncoderDesc(ctypes.Structure):

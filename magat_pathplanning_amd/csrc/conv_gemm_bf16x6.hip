@@ -47,6 +47,7 @@ struct SplitParams {
   int C2, lda2, W2, stride2;
   int Cout, Ktot, ldc, relu;
   int ntn, npix, tag, out_split;
+  long long out_nt;         // direct kernel, row-major output: column tile t at out + t * out_nt (0: column 128 t of the row)
   int tepi;                 // direct kernel: row-major float32 output transposed through LDS (MAGAT_CONV_TEPI)
   int korder;               // direct kernel: 1 = channel slab outer, taps inner (MAGAT_CONV_KORDER)
   int in_gl, out_gl;        // direct kernel: granule-major agent tiles [C/4][128][4] for in/in2 resp. out
@@ -715,7 +716,8 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
           const int m = mb + r;
           if (m < p.M)
             *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +
-                                      magat_row_off(m, p.ldc, p.out_tile) + n0 + ps * CP + 4 * u) = v;
+                                      magat_row_off(m, p.ldc, p.out_tile) + (p.out_nt ? ntile * p.out_nt : n0) + ps * CP +
+                                      4 * u) = v;
         }
       }
     }
@@ -755,7 +757,8 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
       continue;
     }
     float* const orow = static_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +
-                        (p.out_gl ? (m >> 7) * p.out_tile + (m & 127) * 4 : magat_row_off(m, p.ldc, p.out_tile));
+                        (p.out_gl ? (m >> 7) * p.out_tile + (m & 127) * 4 : magat_row_off(m, p.ldc, p.out_tile)) +
+                        (p.out_nt ? ntile * p.out_nt - n0 : 0);
     const int nmul = p.out_gl ? 128 : 1;                // granule-major: channel quad n/4 is 128 agents x 4 floats away
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -822,6 +825,9 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.wt_plane = (long long)p.Cout * p.Ktot;
   p.npix = d->Hout * d->Wout; p.tag = d->tag; p.out_split = d->out_fmt;
   p.in_gl = d->in_gl; p.out_gl = d->out_gl;
+  p.out_nt = d->out_ntile_stride;
+  if (p.out_nt && !(d->in_fmt == 4 && d->out_fmt == 0 && d->out_gl == 0 && BN == 128 && magat_conv_direct_enabled()))
+    return MAGAT_ERR_UNSUPPORTED;
   { const char* e = getenv("MAGAT_CONV_KORDER"); p.korder = e ? atoi(e) : 1; }
   { const char* e = getenv("MAGAT_CONV_TEPI"); p.tepi = e ? atoi(e) : 1; }
   p.Mt = (p.M + BM - 1) / BM;

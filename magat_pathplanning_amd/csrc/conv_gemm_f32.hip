@@ -370,7 +370,7 @@ int launch(ConvGemmParams& p, hipStream_t st) {
 extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) {
   if (!d || !d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
   if (d->in_fmt >= 1 && d->in_fmt <= 5) return magat_conv_gemm_bf16x6(d, static_cast<hipStream_t>(stream));
-  if (d->in_gl || d->out_gl) return MAGAT_ERR_UNSUPPORTED;   // granule-major tiles: f16x3 direct kernel only
+  if (d->in_gl || d->out_gl || d->out_ntile_stride) return MAGAT_ERR_UNSUPPORTED;   // f16x3 direct kernel only
   if (d->in_fmt != 0 || (d->out_fmt != 0 && d->out_fmt != 1)) return MAGAT_ERR_UNSUPPORTED;
   if (d->M <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->kH <= 0 || d->kW <= 0 ||
       d->stride <= 0 || d->pad < 0 || d->C2 < 0)

@@ -42,6 +42,8 @@ struct GatParams {
   int b0;                        // first instance of this chunk
   long long* dbg;                // optional phase timestamps [blocks][8] (instrumentation; null in production)
   int skip;                      // instrumentation: bit0 skip scores, bit1 skip hops (wrong results; for PMC deltas)
+  long long zts;                 // 0: Z rows are NC wide; > 0: Z is split into 128-column tiles zts floats apart (row stride 128):
+                                 // an instance's [N][128] tile is one contiguous run (written so by the maps GEMM)
   const int* over;               // when set: only instances with over[bl] != 0 are processed here (the rest were
                                  // handled by the list kernel, gat_list_f32.hip)
   float* Ymean;                  // fused head-mean (mean merge, hpb == P): final output [B*N, ldym]; Y is unused then
@@ -107,7 +109,10 @@ __global__ void gat_dense_kernel(const GatParams p) {
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   long long* dbg = p.dbg ? p.dbg + (long long)bid * 8 : nullptr;
   if (dbg && t == 0) dbg[0] = clock64();
-  const float* Zb = p.Z + (long long)bl0 * N * p.NC;     // current instance (updated by the instance loop)
+  // Z addressing: row n, column col of the current instance = Zb + n * zrow + zcol(col)
+  const int zrow = p.zts ? 128 : p.NC;
+  auto zcol = [&](int col) -> long long { return p.zts ? (long long)(col >> 7) * p.zts + (col & 127) : (long long)col; };
+  const float* Zb = p.Z + (long long)bl0 * N * zrow;     // current instance (updated by the instance loop)
 
   // ---- phase 0 (once per workgroup): the GSO edge masks, this wave's x_i rows, the first head's tiles.
   // WIDE path: the Q_p and U_{K-1} tiles ([N][128] floats, rows NC floats apart in Z) travel global -> LDS with the
@@ -135,7 +140,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
       const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)dst + (unsigned)g * 1024u);
       if (idx < total) {
         const int n = idx / GC, c = idx % GC;
-        const float* src = zb + (long long)n * p.NC + col_off + 4 * c;
+        const float* src = zb + (long long)n * zrow + zcol(col_off) + 4 * c;
         asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
       }
     }
@@ -149,7 +154,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
 #pragma unroll
     for (int q = 0; q < QG; ++q) {
       const int idx = tl + q * NT, n = idx / GC, c = idx % GC;
-      qst[q] = *reinterpret_cast<const f32x4*>(Zb + (long long)(n < N ? n : 0) * p.NC + qo + 4 * c);
+      qst[q] = *reinterpret_cast<const f32x4*>(Zb + (long long)(n < N ? n : 0) * zrow + zcol(qo) + 4 * c);
     }
   };
   auto issue_u = [&](int head, int tl) {
@@ -157,7 +162,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
 #pragma unroll
     for (int q = 0; q < QF; ++q) {
       const int idx = tl + q * NT, n = idx / FC, c = idx % FC;
-      ust[q] = *reinterpret_cast<const f32x4*>(Zb + (long long)(n < N ? n : 0) * p.NC + uo + 4 * c);
+      ust[q] = *reinterpret_cast<const f32x4*>(Zb + (long long)(n < N ? n : 0) * zrow + zcol(uo) + 4 * c);
     }
   };
   float* Rq = R0;     // LDS buffer holding the current head's Q tile (WIDE: alternates between heads)
@@ -186,7 +191,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
   const int t = ti, lane = ti & 63, wave = ti >> 6;
   long long t_inst = 0;
   if (dbg && t == 0) t_inst = clock64();
-  Zb = p.Z + (long long)bl * N * p.NC;
+  Zb = p.Z + (long long)bl * N * zrow;
   const float* Xb = p.X + (long long)b * N * p.ldx;
   const long long sbase = (long long)b * N * N;
   // WIDE score phase: 8 lanes per graph row (8 rows per wave step, exactly one step per wave since NT >= 8 N); lane es
@@ -287,15 +292,15 @@ __global__ void gat_dense_kernel(const GatParams p) {
   if (dbg && t == 0 && hh == hpb - 1 && hh > 0) dbg[0] = clock64();   // instrumentation follows the LAST head
   if (need_att && !keyquery)
     for (int n = t; n < N; n += NT) {
-      c1s[n] = Zb[(long long)n * p.NC + p.c1off + head];
-      c2s[n] = Zb[(long long)n * p.NC + p.c2off + head];
+      c1s[n] = Zb[(long long)n * zrow + zcol(p.c1off + head)];
+      c2s[n] = Zb[(long long)n * zrow + zcol(p.c2off + head)];
     }
   // U rows of this wave's output rows: one per-lane base pointer, rows nwaves * rpw apart (rows past N re-read row 0
   // of the group: harmless, never stored)
   const int ws_head = __builtin_amdgcn_readfirstlane(wl);
   auto load_urows = [&](fvec (&dst)[HMAX], int kk) {
-    const float* base = Zb + (long long)(ws_head * rpw + grp) * p.NC + p.uoff + (head * K + kk) * F + VEC * sub;
-    const long long step = (long long)nwaves * rpw * p.NC;
+    const float* base = Zb + (long long)(ws_head * rpw + grp) * zrow + zcol(p.uoff + (head * K + kk) * F) + VEC * sub;
+    const long long step = (long long)nwaves * rpw * zrow;
 #pragma unroll
     for (int h = 0; h < HMAX; ++h) {
       const bool ok = (ws_head + h * nwaves) * rpw + grp < N;
@@ -680,7 +685,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
         // into it during the last hop (every register the rows below consume has been settled: nothing waits for it)
         int tk = threadIdx.x;
         asm volatile("" : "+v"(tk));
-        const float* zbn = more_heads ? Zb : p.Z + (long long)(bl + istride) * N * p.NC;
+        const float* zbn = more_heads ? Zb : p.Z + (long long)(bl + istride) * N * zrow;
         const int hn = more_heads ? head + 1 : head0;
         if (keyquery && need_att) dma_tile(Rnew, zbn, p.qoff + hn * G, tk);
         else if (K > 1) dma_tile(Rnew, zbn, p.uoff + (hn * K + (K - 1)) * F, tk);
@@ -873,7 +878,8 @@ static int gat_zpad() {
   }
   return v;
 }
-int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, int G, int NC, int ldz, void* stream) {
+int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, int G, int NC, int ldz, void* stream,
+                        long long ntile_stride) {
   static int use_split = -1;
   if (use_split < 0) {
     const char* e = getenv("MAGAT_GAT_SPLIT");
@@ -889,8 +895,10 @@ int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, in
     d.out = Z;
     d.M = M; d.Cin = G; d.lda = G; d.Hin = d.Win = 1; d.kH = d.kW = 1; d.stride = 1; d.Hout = d.Wout = 1;
     d.Cout = NC; d.ldc = ldz; d.tag = MAGAT_TAG_GAT_MAPS; d.in_fmt = use_f16 ? 4 : 2;
+    if (ntile_stride) { d.ldc = 128; d.out_ntile_stride = ntile_stride; }
     return magat_conv_gemm_f32(&d, stream);
   }
+  if (ntile_stride) return MAGAT_ERR_UNSUPPORTED;
   return magat_linear_tagged_f32(X, G, packed, packed + (size_t)NC * G, Z, ldz, M, NC, G, 0, MAGAT_TAG_GAT_MAPS,
                                  stream);
 }
@@ -986,7 +994,19 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
   for (int b0 = 0; b0 < B && all_fused; b0 += chunk) all_fused = hpb_for((B - b0) < chunk ? (B - b0) : chunk) == P;
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int cb = (B - b0) < chunk ? (B - b0) : chunk;
-    int rc = magat_gat_maps_gemm(X + (size_t)b0 * N * G, packed, Z, cb * N, G, L.NC, ldz, stream);
+    // Z in 128-column tiles ([tile][cb * N][128]: an instance's Q_p / U_pk tile is ONE contiguous N x 128 run for the
+    // LDS-direct loads, and every workgroup of the maps GEMM writes one contiguous region) when the dense kernel with
+    // 128-wide features consumes it and the f16x3 direct GEMM produces it; MAGAT_GAT_ZTILES=0 keeps NC-wide rows.
+    bool ztiles = G == 128 && F == 128 && L.NC % 128 == 0 && !use_list && magat_conv_direct_enabled();
+    {
+      const char* e = getenv("MAGAT_GAT_ZTILES");
+      if (e && !atoi(e)) ztiles = false;
+      const char* es = getenv("MAGAT_GAT_SPLIT");
+      const char* ef = getenv("MAGAT_CONV_F16");
+      if ((es && !atoi(es)) || (ef && !atoi(ef))) ztiles = false;
+    }
+    p.zts = ztiles ? (long long)cb * N * 128 : 0;
+    int rc = magat_gat_maps_gemm(X + (size_t)b0 * N * G, packed, Z, cb * N, G, L.NC, ldz, stream, p.zts);
     if (rc != MAGAT_OK) return rc;
     p.B = cb; p.b0 = b0;
     if (use_list) {     // sparse instances: structure pass + list kernel; dense ones stay flagged for the kernel below

@@ -39,7 +39,8 @@ __host__ __device__ inline size_t magat_gat_f16_block_offset(int NC, int G) {
 
 // hoisted GAT maps Z [M][ldz >= NC] = X [M][G] @ Bt^T + colbias from the packed weights (gat_f32.hip): bf16x6 split when
 // NC % 32 == 0 and G % 32 == 0, else fp32 MFMA
-int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, int G, int NC, int ldz, void* stream);
+int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, int G, int NC, int ldz, void* stream,
+                        long long ntile_stride = 0);   // > 0: Z in 128-column tiles ntile_stride floats apart (row stride 128)
 
 // fp32 -> three bf16 planes (round-to-nearest-even each)
 __device__ __forceinline__ unsigned short magat_bf16_rne(float v) {
