@@ -1,5 +1,5 @@
 """Interleaved A/B timing of the f16x3 direct conv kernel under different runtime switches (GPU only).
-usage: python tools/conv_ab.py "MAGAT_CONV_PRIO=0" "MAGAT_CONV_PRIO=1" ...   (each arg: comma-separated VAR=VALUE list)
+usage: python tools/conv_ab.py "LAYOUT=2,MAGAT_CONV_TM=1" "LAYOUT=2,MAGAT_CONV_TM=2" ...   (each arg: comma-separated VAR=VALUE list)
 Every round times each configuration once (median of 3 launches) - box drift hits all configurations alike."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
