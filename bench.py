@@ -62,9 +62,11 @@ def split_tags(cfg):
     return tags
 
 
-def per_agent_work(cfg, N, S_bytes, deg=None):
+def per_agent_work(cfg, N, S_bytes, deg=None, planned=False):
     """Algorithmic work per AGENT-STEP for each kernel tag: (flops, hbm_bytes, bound).  deg: mean out-degree, given
-    when the layer runs on the CSR kernels (N > 128 or bf16 storage)."""
+    when the layer runs on the CSR kernels (N > 128 or bf16 storage).  planned: the GSO plan (magat_gat_gso_plan, made
+    at addGSO on a side stream) read S instead of the graph kernel, which then reads 16 B of edge mask per agent -
+    the S bytes are priced on the plan kernel (tag 16), not on the graph kernel."""
     G, K, P = cfg.bottleneckFeature, cfg.nGraphFilterTaps, cfg.nAttentionHeads
     F = G
     nfm = cfg.numInputFeatures
@@ -83,7 +85,9 @@ def per_agent_work(cfg, N, S_bytes, deg=None):
     w[10] = (2 * G * NC, 4 * (G + NC), "mfma")
     # graph kernel: SURVEY 8(d) "kernel (ii)" bytes per instance / N
     yw = P * F if cfg.AttentionConcat else F          # head-mean: one merged [N][F] row block is written
-    w[11] = (0, (4 * (N * G + P * N * G + P * K * N * F + N * yw) + S_bytes * N * N) / N, "hbm")
+    w[11] = (0, (4 * (N * G + P * N * G + P * K * N * F + N * yw) + (16 * N if planned else S_bytes * N * N)) / N, "hbm")
+    if planned:
+        w[16] = (0, S_bytes * N + 16 + 8.0 / N, "hbm")
     if deg is not None:
         # CSR kernels: X, the hoisted maps Z and Y in the storage type (4 or 2 bytes), CSR + CSC index arrays, and the
         # attention values written by the score kernel and read once per hop
@@ -243,7 +247,10 @@ def main():
                           "global_batch": B * world, "agents": N, "parallelism": "instance-sharded x%d" % world}}
         if timing:
             csr = N > 128 or cfg.gat_storage == "bf16"
-            work = per_agent_work(cfg, N, 4, float((S != 0).sum().item()) / (B * N) if csr else None)
+            cnt16, tot16 = ctypes.c_longlong(0), ctypes.c_double(0.0)
+            lib.magat_profile_read(16, ctypes.byref(cnt16), ctypes.byref(tot16))
+            work = per_agent_work(cfg, N, 4, float((S != 0).sum().item()) / (B * N) if csr else None,
+                                  planned=cnt16.value > 0 and not csr)
             TAG_OF = {v: k for k, v in nat.TAGS.items()}
             splits = split_tags(cfg)
             kernels, dom = {}, None
@@ -315,7 +322,11 @@ def main():
                 res["roofline"] = roof(dom[0])
             if "gat_graph" in kernels:
                 res["roofline_gat"] = roof("gat_graph")
-            res["kernel_time_ms_per_step"] = round(sum(k["ms_per_step"] for k in kernels.values()), 4)
+            if "gat_prepare" in kernels:
+                kernels["gat_prepare"]["note"] = ("GSO plan, made at addGSO on a side stream: runs under the encoder, "
+                                                  "not part of the main-stream kernel time")
+            res["kernel_time_ms_per_step"] = round(sum(k["ms_per_step"] for n_, k in kernels.items()
+                                                       if n_ != "gat_prepare"), 4)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, net.state_dict(), N, map_w)
         print(json.dumps(res), flush=True)

@@ -75,6 +75,23 @@ int magat_gat_forward_packed_f32(const float* X, const void* S, int s_is_f64, co
                                  const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
                                  size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
                                  int mode, int concat, void* stream);
+
+/* GSO plan for the dense kernel (optional).  The reference hands the GSO over before the forward pass
+ * (addGSO(S), graphs/models/decentralplanner_GAT_bottleneck.py:262-278, then forward(x) :283); everything the
+ * graph kernel derives from S alone - per-row edge bitmasks [B][N][4] and an edge-count-balanced order in which
+ * the persistent workgroups walk the instances - can therefore be made at addGSO time, on a side stream, while
+ * the per-agent CNN runs.  plan: device buffer of magat_gat_gso_plan_bytes(B, N) bytes (0 = shape not
+ * plannable: N > 128 or B > 8192), 256-byte aligned.  A plan is valid for the (S contents, B, N, mode) it was made
+ * from; the caller orders the plan stream before the forward stream (event) and re-plans after changing S.
+ * magat_gat_forward_planned_f32 = magat_gat_forward_packed_f32 plus the plan (NULL = none: identical results either
+ * way - the plan changes where masks come from and the instance order, not the arithmetic). */
+size_t magat_gat_gso_plan_bytes(int B, int N);
+int magat_gat_gso_plan(const void* S, int s_is_f64, int mode, void* plan, size_t plan_bytes, int B, int N,
+                       void* stream);
+int magat_gat_forward_planned_f32(const float* X, const void* S, int s_is_f64, const float* packed,
+                                 const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
+                                 size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
+                                 int mode, int concat, const void* plan, void* stream);
 /* convenience: pack (into the tail of workspace) + forward; workspace must hold
  * magat_gat_workspace_bytes(...) + 4*magat_gat_packed_floats(...) bytes. */
 int magat_gat_forward_dense_f32(const float* X, const void* S, int s_is_f64, const float* weight,
@@ -293,7 +310,8 @@ int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* 
 #define MAGAT_TAG_HEAD_MEAN 13
 #define MAGAT_TAG_GAT_PACK 14
 #define MAGAT_TAG_GSO_PREPARE 15
-#define MAGAT_PROF_TAGS 16
+#define MAGAT_TAG_GAT_PREPARE 16  /* edge masks + edge counts + balanced instance order for the persistent graph kernel */
+#define MAGAT_PROF_TAGS 24
 int magat_gat_set_debug_buffer(long long* dev_buf); /* [grid][8] int64 phase timestamps of gat_dense_kernel; NULL = off */
 int magat_profile_reserve(int spans);   /* pre-create event pairs (keeps hipEventCreate out of a timed region) */
 int magat_profile_enable(int on);

@@ -17,7 +17,7 @@ MODE_GNN = 3
 TAGS = {0: "untagged", 1: "conv_first", 2: "layer1.conv1", 3: "layer1.conv2+ds", 4: "layer2.conv1",
         5: "layer2.conv2+ds", 6: "layer3.conv1", 7: "layer3.conv2+ds", 8: "head(avgpool+fc+linear)",
         9: "compressMLP", 10: "gat_maps_gemm", 11: "gat_graph", 12: "actionsMLP", 13: "head_mean",
-        14: "gat_pack", 15: "gso_prepare"}
+        14: "gat_pack", 15: "gso_prepare", 16: "gat_prepare"}
 TAG_ACTIONS = 12
 
 _lock = threading.Lock()
@@ -62,6 +62,9 @@ _SIGNATURES = {
     "magat_gat_pack_weights": (_I, [_P] * 5 + [_I] * 5 + [_P]),
     "magat_gat_workspace_bytes": (_Z, [_I] * 8),
     "magat_gat_forward_packed_f32": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
+    "magat_gat_forward_planned_f32": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P, _P]),
+    "magat_gat_gso_plan_bytes": (_Z, [_I, _I]),
+    "magat_gat_gso_plan": (_I, [_P, _I, _I, _P, _Z, _I, _I, _P]),
     "magat_gat_forward_dense_f32": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_csr_workspace_bytes": (_Z, [_I, _I, ctypes.c_longlong] + [_I] * 6),
     "magat_gat_forward_csr_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),

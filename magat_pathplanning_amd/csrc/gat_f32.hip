@@ -42,6 +42,8 @@ struct GatParams {
   int b0;                        // first instance of this chunk
   long long* dbg;                // optional phase timestamps [blocks][8] (instrumentation; null in production)
   int skip;                      // instrumentation: bit0 skip scores, bit1 skip hops (wrong results; for PMC deltas)
+  const int* order;              // when set: slot s of the instance walk processes instance order[s] (balanced assignment)
+  const unsigned* rmask_pre;     // when set: [B][N][4] edge masks made by gat_prepare_kernel (the kernel then never reads S)
   long long zts;                 // 0: Z rows are NC wide; > 0: Z is split into 128-column tiles zts floats apart (row stride 128):
                                  // an instance's [N][128] tile is one contiguous run (written so by the maps GEMM)
   const int* over;               // when set: only instances with over[bl] != 0 are processed here (the rest were
@@ -183,7 +185,8 @@ __global__ void gat_dense_kernel(const GatParams p) {
   fvec ysum[HMAX];
 #pragma unroll
   for (int h = 0; h < HMAX; ++h) ysum[h] = zerov;
-  for (int bl = bl0; bl < p.B; bl += istride) {     // ---- instances of this workgroup
+  for (int sl_ = bl0; sl_ < p.B; sl_ += istride) {  // ---- instance slots of this workgroup
+  const int bl = p.order ? p.order[sl_] : sl_;       // (balanced walk: slots -> instances dealt out by edge count)
   if (p.over && !p.over[bl]) continue;               // (host never combines the list path with istride < B)
   const int b = p.b0 + bl;
   int ti = threadIdx.x;              // laundered per instance (see the note at the head loop)
@@ -201,14 +204,14 @@ __global__ void gat_dense_kernel(const GatParams p) {
   f32x4 xi[CP8];
   if constexpr (WIDE) {
     if (keyquery && need_att) {
-      if (bl == bl0) dma_tile(Rq, Zb, p.qoff + head0 * G, t);
+      if (sl_ == bl0) dma_tile(Rq, Zb, p.qoff + head0 * G, t);
       const int es0 = lane & 7, eg0 = lane >> 3, par0 = eg0 & 1;
       const int i = 8 * wave + eg0, ir = i < N ? i : 0;
 #pragma unroll
       for (int q = 0; q < CP8; ++q)
         xi[q] = *reinterpret_cast<const f32x4*>(Xb + (long long)ir * p.ldx + 4 * (es0 + 8 * (q ^ par0)));
     }
-    if (K > 1 && bl == bl0) dma_tile(Ru, Zb, p.uoff + (head0 * K + (K - 1)) * F, t);
+    if (K > 1 && sl_ == bl0) dma_tile(Ru, Zb, p.uoff + (head0 * K + (K - 1)) * F, t);
   } else if (keyquery && need_att) {
     issue_q(head0, t);
 #pragma unroll
@@ -223,7 +226,12 @@ __global__ void gat_dense_kernel(const GatParams p) {
       // every wave owns rows wave, wave + nwaves, ... (at most 8 since NT >= 8 N): all their loads are issued
       // first and the ballots run afterwards - one memory latency per instance instead of one per row
       const float sl = p.mode == MAGAT_MODE_GAT_ORIGIN ? 1.f : 0.f;
+      if (p.rmask_pre) {      // made by gat_prepare_kernel: 16 bytes per row instead of the GSO row
+        const unsigned* src = p.rmask_pre + (long long)b * N * 4;
+        for (int idx = t; idx < 4 * N; idx += NT) rmask[idx] = src[idx];
+      }
       auto stage_masks = [&](auto tag) {
+        if (p.rmask_pre) return;
         typedef decltype(tag) ST;
         const ST* Sp = static_cast<const ST*>(p.S) + sbase;
         for (int hb = 0; hb < 8; hb += 4) {       // two batches of four rows (register budget)
@@ -310,7 +318,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
   // the first hop's U rows travel during the score phase.  For the very first head of a workgroup they are issued
   // before the wait for the tiles (everything is in flight together: short score phases, e.g. N = 20, do not cover a
   // second memory latency); for later heads after it (the wait must not include them).
-  const bool first_head = hh == 0 && bl == bl0;
+  const bool first_head = hh == 0 && sl_ == bl0;
   if (WIDE && first_head) load_urows(ucur, K > 1 ? K - 2 : 0);
   if constexpr (WIDE) {
     // Q tile (prefetched during the previous head's last hop, or above) is in Rq once every wave's loads are done
@@ -318,7 +326,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
     // the previous head's reads of Ru and A
     if (first_head || p.skip) tiles_landed();
     else __syncthreads();
-    if ((hh > 0 || bl != bl0) && keyquery && need_att && K > 1)
+    if ((hh > 0 || sl_ != bl0) && keyquery && need_att && K > 1)
       dma_tile(Ru, Zb, p.uoff + (head * K + (K - 1)) * F, tl);
   } else {
     if (keyquery && need_att) {
@@ -680,12 +688,13 @@ __global__ void gat_dense_kernel(const GatParams p) {
     }
     if constexpr (WIDE) {
       const bool more_heads = hh + 1 < hpb;
-      if (more_heads || bl + istride < p.B) {
+      if (more_heads || sl_ + istride < p.B) {
         // Rnew is not read any more: the first tile of the next head (or of the next instance's first head) streams
         // into it during the last hop (every register the rows below consume has been settled: nothing waits for it)
         int tk = threadIdx.x;
         asm volatile("" : "+v"(tk));
-        const float* zbn = more_heads ? Zb : p.Z + (long long)(bl + istride) * N * zrow;
+        const float* zbn =
+            more_heads ? Zb : p.Z + (long long)(p.order ? p.order[sl_ + istride] : sl_ + istride) * N * zrow;
         const int hn = more_heads ? head + 1 : head0;
         if (keyquery && need_att) dma_tile(Rnew, zbn, p.qoff + hn * G, tk);
         else if (K > 1) dma_tile(Rnew, zbn, p.uoff + (hn * K + (K - 1)) * F, tk);
@@ -935,6 +944,132 @@ bool gat_list_enabled() {
   return v != 0;
 }
 
+// ---- GSO plan (magat_gat_gso_plan): edge masks, edge counts, balanced instance walk for the persistent kernel ----------
+// Made when the GSO is handed over (addGSO), on a side stream, so it overlaps the per-agent CNN that runs before the graph
+// layer (in-stream it costs 29 us at c3 and buys 13-15 us: a loss; hidden under the MFMA-bound encoder it is free).
+// One pass over S (instead of the graph kernel's own): per row the 128-bit edge mask the graph kernel
+// otherwise stages itself, per instance the edge count.  With one workgroup per CU walking B / 256 instances each, a
+// launch ends when the unluckiest workgroup does - at c3 (510 +- 34 edges per instance) the maximum over 256 workgroups of
+// a two-instance sum is 4-13 % above the mean; score and hop phases are per-edge, so the instances are ranked by edge
+// count and dealt out in snake order (round r of workgroup w takes rank r W + w, odd rounds reversed).
+// Without a plan the graph kernel stages the masks from S itself and walks the instances in index order.
+// One 1024-thread workgroup per instance (16 waves, <= 8 rows each: every load of a wave is issued before its first
+// ballot - one memory latency per instance, not one per row); a single-workgroup kernel then ranks the instances (a
+// device-wide "last workgroup ranks" ticket serialised 512 atomics on one address: 3x slower than the second launch).
+template <typename T>
+__global__ __launch_bounds__(1024) void gat_prepare_kernel(const T* __restrict__ S, unsigned* __restrict__ masks,
+                                                           int* __restrict__ cost, int N, int origin) {
+  __shared__ int part[16];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* Sp = S + (long long)b * N * N;
+  T v0[8], v1[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    const int i = wave + 16 * h, ic = i < N ? i : N - 1;
+    v0[h] = Sp[(long long)ic * N + (lane < N ? lane : N - 1)];
+    v1[h] = Sp[(long long)ic * N + (lane + 64 < N ? lane + 64 : N - 1)];
+  }
+  int cnt = 0;
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    const int i = wave + 16 * h;
+    if (i >= N) break;
+    bool f0, f1;
+    if (origin) {      // GAT_origin: |float(S) + I| > 1e-9f
+      f0 = fabsf((float)v0[h] + (lane == i ? 1.f : 0.f)) > 1e-9f;
+      f1 = fabsf((float)v1[h] + (lane + 64 == i ? 1.f : 0.f)) > 1e-9f;
+    } else if (sizeof(T) == 8) {
+      f0 = fabs((double)v0[h]) > 1e-9;
+      f1 = fabs((double)v1[h]) > 1e-9;
+    } else {
+      f0 = fabsf((float)v0[h]) > 1e-9f;
+      f1 = fabsf((float)v1[h]) > 1e-9f;
+    }
+    const unsigned long long k0 = __ballot(f0 && lane < N), k1 = __ballot(f1 && lane + 64 < N);
+    cnt += __popcll(k0) + __popcll(k1);
+    if (lane == 0) {
+      unsigned* m = masks + ((long long)b * N + i) * 4;
+      m[0] = (unsigned)k0; m[1] = (unsigned)(k0 >> 32); m[2] = (unsigned)k1; m[3] = (unsigned)(k1 >> 32);
+    }
+  }
+  if (lane == 0) part[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int w = 0; w < 16; ++w) c += part[w];
+    cost[b] = c;
+  }
+}
+
+// rank by edge count (ties by index), deal out in snake order over W walkers
+__global__ __launch_bounds__(1024) void gat_order_kernel(const int* __restrict__ cost, int* __restrict__ order, int B,
+                                                         int W) {
+  extern __shared__ int cs[];             // B costs (padded to a multiple of 4 with -1), then B partial ranks
+  const int Bp = (B + 3) & ~3;
+  int* pr = cs + Bp;
+  for (int i = threadIdx.x; i < Bp; i += 1024) cs[i] = i < B ? cost[i] : -1;
+  __syncthreads();
+  // PARTS threads per instance, each counting over an interleaved quarter of the list with 16-byte LDS reads
+  const int parts = B <= 256 ? 4 : (B <= 512 ? 2 : 1);
+  for (int i0 = 0; i0 < B; i0 += 1024 / parts) {
+    const int i = i0 + (int)threadIdx.x / parts, part = (int)threadIdx.x % parts;
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    if (i < B) {
+      const int ci = cs[i];
+      for (int j = 4 * part; j < Bp; j += 4 * parts) {
+        const int4 c = *reinterpret_cast<const int4*>(cs + j);
+        r0 += (c.x > ci || (c.x == ci && j < i)) ? 1 : 0;
+        r1 += (c.y > ci || (c.y == ci && j + 1 < i)) ? 1 : 0;
+        r2 += (c.z > ci || (c.z == ci && j + 2 < i)) ? 1 : 0;
+        r3 += (c.w > ci || (c.w == ci && j + 3 < i)) ? 1 : 0;
+      }
+    }
+    int r = r0 + r1 + r2 + r3;
+    for (int o = 1; o < parts; o <<= 1) r += __shfl_xor(r, o, 64);
+    if (i < B && part == 0) pr[i] = r;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < B; i += 1024) {
+    const int rank = pr[i];
+    const int round = rank / W, pos = rank - round * W;
+    const bool rev = (round & 1) && (round + 1) * W <= B;      // a partial last round keeps its order
+    order[round * W + (rev ? W - 1 - pos : pos)] = i;
+  }
+}
+
+constexpr int GAT_PLAN_WALKERS = 256;     // persistent graph-kernel workgroups (one per CU) the walk order is dealt to
+
+extern "C" size_t magat_gat_gso_plan_bytes(int B, int N) {
+  if (B <= 0 || N <= 0 || N > 128 || B > 8192) return 0;
+  return magat_align_up((size_t)B * N * 4 * sizeof(unsigned), 256) + magat_align_up((size_t)(2 * B + 1) * sizeof(int), 256);
+}
+
+extern "C" int magat_gat_gso_plan(const void* S, int s_is_f64, int mode, void* plan, size_t plan_bytes, int B, int N,
+                                  void* stream) {
+  if (!S || !plan) return MAGAT_ERR_NULL;
+  if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GAT_ORIGIN) return MAGAT_ERR_UNSUPPORTED;
+  const size_t need = magat_gat_gso_plan_bytes(B, N);
+  if (!need) return MAGAT_ERR_UNSUPPORTED;
+  if (plan_bytes < need || (reinterpret_cast<uintptr_t>(plan) & 255)) return MAGAT_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = static_cast<char*>(plan);
+  unsigned* masks = reinterpret_cast<unsigned*>(base);
+  int* cost = reinterpret_cast<int*>(base + magat_align_up((size_t)B * N * 4 * sizeof(unsigned), 256));
+  int* order = cost + B;
+  const int origin = mode == MAGAT_MODE_GAT_ORIGIN ? 1 : 0;
+  const int pid = magat_prof_begin(MAGAT_TAG_GAT_PREPARE, st);
+  if (s_is_f64)
+    hipLaunchKernelGGL(gat_prepare_kernel<double>, dim3(B), dim3(1024), 0, st, static_cast<const double*>(S), masks,
+                       cost, N, origin);
+  else
+    hipLaunchKernelGGL(gat_prepare_kernel<float>, dim3(B), dim3(1024), 0, st, static_cast<const float*>(S), masks, cost,
+                       N, origin);
+  hipLaunchKernelGGL(gat_order_kernel, dim3(1), dim3(1024), (size_t)(2 * B + 8) * sizeof(int), st, cost, order, B,
+                     GAT_PLAN_WALKERS);
+  magat_prof_end(pid, st);
+  return hipGetLastError() == hipSuccess ? MAGAT_OK : MAGAT_ERR_LAUNCH;
+}
+
 extern "C" size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, int P, int mode, int concat) {
   if (B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
   const PackLayout L = pack_layout(G, F, K, P, mode);
@@ -946,10 +1081,10 @@ extern "C" size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, i
   return bytes;
 }
 
-extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s_is_f64, const float* packed,
-                                            const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
-                                            size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
-                                            int mode, int concat, void* stream) {
+extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int s_is_f64, const float* packed,
+                                             const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
+                                             size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
+                                             int mode, int concat, const void* plan, void* stream) {
   if (!X || !S || !packed || !Y) return MAGAT_ERR_NULL;
   if (B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
   if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GAT_ORIGIN) return MAGAT_ERR_UNSUPPORTED;
@@ -974,6 +1109,8 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
   const bool use_list = gat_list_enabled() && mode != MAGAT_MODE_GAT_ORIGIN && magat_gat_list_capacity(N, G, F) > 0;
   GatParams p;
   p.over = nullptr;
+  p.order = nullptr;
+  p.rmask_pre = nullptr;
   p.dbg = g_gat_dbg;
   { static int sk = -1; if (sk < 0) { const char* e = getenv("MAGAT_GAT_SKIP"); sk = e ? atoi(e) : 0; } p.skip = sk; }
   p.X = X; p.S = S; p.Z = Z; p.bias = bias; p.A_opt = A_opt;
@@ -1033,8 +1170,16 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
     int inst_slots = (cb + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD;
     static int persist_env = -1;
     if (persist_env < 0) { const char* e = getenv("MAGAT_GAT_PERSIST"); persist_env = e ? atoi(e) : 1; }
-    if (persist_env && hpb == P && hpb > 1 && !use_list && inst_slots > 256) inst_slots = 256;
+    if (persist_env && hpb == P && hpb > 1 && !use_list && inst_slots > GAT_PLAN_WALKERS) inst_slots = GAT_PLAN_WALKERS;
     const int blocks = inst_slots * (P / hpb);
+    p.order = nullptr;
+    p.rmask_pre = nullptr;
+    if (plan && cb == B && !use_list && G >= 64 && N <= 128) {     // made by magat_gat_gso_plan for this S
+      const char* base = static_cast<const char*>(plan);
+      p.rmask_pre = reinterpret_cast<const unsigned*>(base);
+      if (inst_slots == GAT_PLAN_WALKERS && inst_slots < cb)
+        p.order = reinterpret_cast<const int*>(base + magat_align_up((size_t)B * N * 4 * sizeof(unsigned), 256)) + B;
+    }
     switch (G) {
       case 16: rc = launch_gat<16, 16>(p, blocks, threads, lds, st); break;
       case 32: rc = launch_gat<32, 32>(p, blocks, threads, lds, st); break;
@@ -1055,6 +1200,14 @@ extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s
     return magat_check_launch();
   }
   return MAGAT_OK;
+}
+
+extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s_is_f64, const float* packed,
+                                            const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
+                                            size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
+                                            int mode, int concat, void* stream) {
+  return magat_gat_forward_planned_f32(X, S, s_is_f64, packed, bias, Y, ldy, A_opt, workspace, workspace_bytes, B, N, G,
+                                       F, K, P, mode, concat, nullptr, stream);
 }
 
 extern "C" int magat_gat_forward_dense_f32(const float* X, const void* S, int s_is_f64, const float* weight,

@@ -17,7 +17,8 @@ import torch.nn as nn
 
 from . import _native as nat
 from . import encoder as enc
-from .graphml import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin, gat_forward_rows
+from .graphml import (_MODES, GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin, GsoPlan,
+                      gat_forward_rows)
 from .resnet import ResNet, ResNetSlim
 
 _SKIP_FILES = {
@@ -51,6 +52,7 @@ class _Runtime:
         self.act = None
         self.buffers = {}
         self.ws = None
+        self.plan = GsoPlan()          # GSO-derived masks / walk order, made at addGSO on a side stream
 
 
 class DecentralPlannerGATNet(nn.Module):
@@ -152,7 +154,12 @@ class DecentralPlannerGATNet(nn.Module):
                                                           S.numel(), 1 if scrub else 0, gso_mode,
                                                           nat.current_stream(S.device)), "magat_gso_prepare")
             self.S = S.unsqueeze(1)
+            # what the graph kernel needs from S alone is made now, on a side stream, under the per-agent CNN
+            layer = self.GFL[0]
+            if not (self.training or layer.storage_dtype == torch.bfloat16):
+                self._rt.plan.make(S, _MODES[layer.attentionMode])
             return
+        self._rt.plan.key = None
         self.S = S.unsqueeze(1)
         if scrub:
             self.S[torch.isnan(self.S)] = 0
@@ -286,7 +293,8 @@ class DecentralPlannerGATNet(nn.Module):
                                               want_attention=want_att)
                 gat.copy_(gat16)
             else:
-                _, aij = gat_forward_rows(comp.view(B, N, G), self.S, layer, out=gat, want_attention=want_att)
+                _, aij = gat_forward_rows(comp.view(B, N, G), self.S, layer, out=gat, want_attention=want_att,
+                                          plan=rt.plan)
             layer.aij = aij
             # actionsMLP
             nout = rt.act[0].shape[0]
