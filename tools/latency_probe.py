@@ -17,23 +17,18 @@ for (B, N, mw) in ((1, 10, 20), (1, 100, 50), (8, 100, 50)):
         for _ in range(200):
             net.addGSO(S); y = net(x); y.cpu()
         dt = (time.perf_counter() - t0) / 200
-        # graph replay
-        g = torch.cuda.CUDAGraph()
-        sx, sS = x.clone(), S.clone()
-        s = torch.cuda.Stream()
-        with torch.cuda.stream(s):
-            for _ in range(3):
-                net.addGSO(sS); net(sx)
-        torch.cuda.current_stream().wait_stream(s)
+        # the product's own graph mode: enable_hip_graph() (capture on the first call of a shape, then replay)
+        net.enable_hip_graph(True)
         try:
-            with torch.cuda.graph(g):
-                net.addGSO(sS); sy = net(sx)
+            for _ in range(5):
+                net.addGSO(S); sy = net(x)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(200):
-                sx.copy_(x); sS.copy_(S); g.replay(); sy.cpu()
+                net.addGSO(S); sy = net(x); sy.cpu()
             dg = (time.perf_counter() - t0) / 200
             ok = torch.equal(sy, y)
         except Exception as e:
             dg, ok = float("nan"), repr(e)[:120]
-    print("B=%d N=%3d  eager %.1f us/step   graph replay %.1f us/step   same=%s" % (B, N, dt * 1e6, dg * 1e6, ok))
+        net.enable_hip_graph(False)
+    print("B=%d N=%3d  eager %.1f us/step   hipGraph replay %.1f us/step   same=%s" % (B, N, dt * 1e6, dg * 1e6, ok))
