@@ -159,8 +159,8 @@ def cpu_baseline(cfg, sd, N, map_w, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)      # >= 50 timed steps after >= 10 warm-ups
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")

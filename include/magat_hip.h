@@ -252,6 +252,12 @@ typedef struct magat_conv_gemm_desc {
    * one ldc-wide row - every workgroup then writes ONE contiguous region (the GAT maps' Z: consumed as per-instance
    * [N][128] tiles).  0 = plain rows. */
   int64_t out_ntile_stride;
+  /* Per-output-pixel weights (float32 kernel only): output pixel q = oy * Wout + ox uses the weight matrix at
+   * wt + q * wt_pix_stride (floats), rows ldw floats apart (ldw = 0: kH*kW*Cin + C2, the packed row).  With a 1x1 kernel over
+   * a pooled map this turns one long-K GEMM into Hout*Wout independent partial products written to Hout*Wout output pixels
+   * - the split-K form of the encoder head for small agent counts (encoder_f32.hip sums the partials).  0 = shared weights. */
+  int64_t wt_pix_stride;
+  int ldw;
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 

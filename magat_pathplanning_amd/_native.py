@@ -44,7 +44,8 @@ class ConvGemmDesc(ctypes.Structure):
                 ("out_plane_stride", ctypes.c_int64),
                 ("in_tile_stride", ctypes.c_int64), ("in2_tile_stride", ctypes.c_int64),
                 ("out_tile_stride", ctypes.c_int64),
-                ("in_gl", ctypes.c_int), ("out_gl", ctypes.c_int), ("out_ntile_stride", ctypes.c_int64)]
+                ("in_gl", ctypes.c_int), ("out_gl", ctypes.c_int), ("out_ntile_stride", ctypes.c_int64),
+                ("wt_pix_stride", ctypes.c_int64), ("ldw", ctypes.c_int)]
 
 
 class EncoderDesc(ctypes.Structure):

@@ -804,6 +804,7 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   if ((d->Cout % BN) || (d->Cin % BK) || (d->C2 % BK) || (d->lda % 8) || (d->C2 > 0 && (d->lda2 % 8)) || d->pool)
     return MAGAT_ERR_UNSUPPORTED;
   if (d->in_fmt < 1 || d->in_fmt > 5 || d->out_fmt < 0 || d->out_fmt > 3) return MAGAT_ERR_UNSUPPORTED;
+  if (d->wt_pix_stride || d->ldw) return MAGAT_ERR_UNSUPPORTED;     // float32 kernel only
   if (d->in_fmt >= 4 && d->out_fmt != 0 && d->out_fmt != 3) return MAGAT_ERR_UNSUPPORTED;
   if (d->out_fmt == 3 && d->in_fmt < 4) return MAGAT_ERR_UNSUPPORTED;
   SplitParams p;

@@ -41,6 +41,7 @@ struct ConvGemmParams {
   int tag;
   int pool_w;   // POOL: physical input width (input pixel (iy,ix) = sum or max of the 2x2 physical pixels)
   int pool_max; // POOL: 0 = sum (AvgPool2d with 1/4 in the weights), 1 = max (MaxPool2d)
+  long long wt_pix;         // per-output-pixel weight offset (floats); 0 = shared weights
   int out_split;            // epilogue writes three bf16 planes (out_plane elements apart) instead of float32
   long long out_plane;
 };
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
   const int pix = rem / p.ntn, ntile = rem % p.ntn;
   const int m0 = mtile * BM, n0 = ntile * BN;
   const int oy = pix / p.Wout, ox = pix % p.Wout;
+  const float* const wtp = p.wt + (long long)pix * p.wt_pix;
 
   // valid tap window of this output pixel
   const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
     }
     if constexpr (FULL) {
       const char* ab = reinterpret_cast<const char*>(abase);
-      const char* bb = reinterpret_cast<const char*>(p.wt + bk);
+      const char* bb = reinterpret_cast<const char*>(wtp + bk);
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
         const char* src = ab + (main_seg ? aoff[i] : aoff2[i]);
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
     for (int i = 0; i < BI; ++i) {
       const int n = n0 + r0 + 32 * i;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kok && n < p.Cout) v = *reinterpret_cast<const f32x4*>(p.wt + (long long)n * p.Ktot + bk + c4 * 4);
+      if (kok && n < p.Cout) v = *reinterpret_cast<const f32x4*>(wtp + (long long)n * p.Ktot + bk + c4 * 4);
       rb[i] = v;
     }
   };
@@ -391,6 +393,12 @@ extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) 
   p.stride = d->stride; p.pad = d->pad; p.Hout = d->Hout; p.Wout = d->Wout;
   p.C2 = d->C2; p.lda2 = d->lda2; p.W2 = d->W2; p.stride2 = d->stride2;
   p.Cout = d->Cout; p.Ktot = d->kH * d->kW * d->Cin + d->C2; p.ldc = d->ldc; p.relu = d->relu;
+  if (d->ldw) {
+    if (d->ldw < p.Ktot || (d->ldw & 3)) return MAGAT_ERR_BAD_SHAPE;
+    p.Ktot = d->ldw;          // weight row stride
+  }
+  if (d->wt_pix_stride & 3) return MAGAT_ERR_BAD_SHAPE;
+  p.wt_pix = d->wt_pix_stride;
   p.npix = d->Hout * d->Wout;
   p.tag = d->tag;
   p.out_split = d->out_fmt == 1;

@@ -179,6 +179,20 @@ struct BlockShape {
   int cin, cout, stride;
 };
 
+
+// feat[m][n] = bias[n] + sum over the pooled cells (fixed order) of part[c][m][n]: the second half of the split-K head
+__global__ __launch_bounds__(256) void head_sum_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                       float* __restrict__ feat, int ldfeat, int M, int nf, int cells) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int q = nf / 4;
+  if (i >= (long long)M * q) return;
+  const int m = (int)(i / q), n = (int)(i % q) * 4;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(bias + n);
+  const float* src = part + (long long)m * nf + n;
+  for (int c = 0; c < cells; ++c) acc += *reinterpret_cast<const f32x4*>(src + (long long)c * M * nf);
+  *reinterpret_cast<f32x4*>(feat + (long long)m * ldfeat + n) = acc;
+}
+
 }  // namespace
 
 static int conv_first_launch(const float* x, const float* wt, const float* bias, float* out, int M, int H, int W,
@@ -446,7 +460,34 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
     g.kH = hin / 2; g.kW = win / 2; g.stride = 1; g.pad = 0; g.Hout = g.Wout = 1; g.Cout = d->n_feat; g.ldc = ldfeat;
     g.relu = 0; g.pool = 1; g.pool_w = win;
     g.tag = MAGAT_TAG_HEAD;
-    rc = magat_conv_gemm_f32(&g, stream);
+    // Few agents (the closed-loop batch-1 step): one workgroup per 64 agents would walk all (hin/2)(win/2) clast of K alone
+    // (83 us at 100 agents).  Split K by pooled cell instead: every cell is its own 1x1 "output pixel" with its slice of the
+    // weight rows (wt_pix_stride / ldw), the partial products land in a free map buffer, a small kernel sums them in
+    // a fixed order and adds the bias.  MAGAT_HEAD_SPLITK = largest agent count that takes this form (0 = never).
+    const int cells = (hin / 2) * (win / 2);
+    int split_max = 12288;
+    { const char* e = getenv("MAGAT_HEAD_SPLITK"); if (e) split_max = atoi(e); }
+    if (cells > 1 && mm <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
+        (size_t)cells * d->n_feat <= enc_buf_floats_per_agent(d)) {     // the partials must fit one map buffer
+      float* part = buf[(cur + 1) % 3];                 // [cells][mm][n_feat]
+      g.out = part; g.bias = nullptr; g.ldc = d->n_feat;
+      g.out_pix_stride = (long long)mm * d->n_feat;
+      g.kH = g.kW = 1; g.Hout = hin / 2; g.Wout = win / 2;
+      g.wt_pix_stride = clast; g.ldw = cells * clast;
+      const int pid = magat_prof_begin(MAGAT_TAG_HEAD, static_cast<hipStream_t>(stream));
+      g.tag = MAGAT_TAG_UNTAGGED;
+      rc = magat_conv_gemm_f32(&g, stream);
+      if (rc == MAGAT_OK) {
+        const long long total4 = (long long)mm * (d->n_feat / 4);
+        hipLaunchKernelGGL(head_sum_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), part, pk + d->off[15], feat + (size_t)m0 * ldfeat, ldfeat, mm,
+                           d->n_feat, cells);
+        if (hipGetLastError() != hipSuccess) rc = MAGAT_ERR_LAUNCH;
+      }
+      magat_prof_end(pid, static_cast<hipStream_t>(stream));
+    } else {
+      rc = magat_conv_gemm_f32(&g, stream);
+    }
     if (rc != MAGAT_OK) return rc;
     if (d->n_comp > 0) {
       rc = magat_linear_tagged_f32(feat + (size_t)m0 * ldfeat, ldfeat, pk + d->off[16], pk + d->off[17],

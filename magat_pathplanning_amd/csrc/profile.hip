@@ -21,7 +21,7 @@ constexpr size_t kMaxSpans = 1 << 16;
 }  // namespace
 
 int magat_prof_begin(int tag, hipStream_t st) {
-  if (!g_enabled) return -1;
+  if (!g_enabled || tag == MAGAT_TAG_UNTAGGED) return -1;      // untagged launches are not timed (a tagged span may enclose them)
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_used >= kMaxSpans) return -1;
   if (g_used == g_pool.size()) {
