@@ -732,3 +732,48 @@ def test_conv_gemm_f16x3_direct_256_agent_tiles_ragged(gpu_device, monkeypatch):
         for key, got in outs.items():
             if key[0] == out_gl:
                 assert torch.equal(got, ref), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,cin,cout,hp", [(150, 128, 128, 3), (37, 64, 128, 2), (300, 128, 1152, 3)])
+def test_conv_gemm_f32_per_pixel_weights_over_pooled_map(gpu_device, M, cin, cout, hp):
+    """wt_pix_stride / ldw of magat_conv_gemm_desc: output pixel q of a 1x1 conv over the 2x2 sum-pooled map multiplies
+    with its own slice [q*cin, (q+1)*cin) of rows that are hp*hp*cin floats long - the split-K form of the encoder head.
+    The hp*hp partial products, summed, equal the one long-K GEMM of the same call without the split (and fp64)."""
+    nat, lib = _nat()
+    g = torch.Generator().manual_seed(M + cin + cout)
+    hin = 2 * hp + (M & 1)                       # odd physical maps drop their last row / column (AvgPool2d floor)
+    x = torch.relu(torch.randn(M, cin, hin, hin, generator=g))
+    w = torch.randn(cout, hp * hp * cin, generator=g) / (hp * hp * cin) ** 0.5
+    pooled = x[:, :, :2 * hp, :2 * hp].double().reshape(M, cin, hp, 2, hp, 2).sum(dim=(3, 5))       # (M, cin, hp, hp)
+    flat = pooled.permute(0, 2, 3, 1).reshape(M, hp * hp, cin)
+    ref_parts = torch.einsum("mqc,nqc->qmn", flat, w.double().view(cout, hp * hp, cin))
+    xin = _to_pixel_major(x).to(gpu_device)
+    wd = w.contiguous().to(gpu_device)
+    part = torch.full((hp * hp, M, cout), float("nan"), device=gpu_device)
+    d = nat.ConvGemmDesc()
+    d.inp, d.wt, d.out = xin.data_ptr(), wd.data_ptr(), part.data_ptr()
+    d.in_pix_stride, d.out_pix_stride = M * cin, M * cout
+    d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, hp, hp, 1, 1, 1, 0
+    d.Hout, d.Wout, d.Cout, d.ldc, d.relu, d.pool, d.pool_w = hp, hp, cout, cout, 0, 1, hin
+    d.wt_pix_stride, d.ldw = cin, hp * hp * cin
+    nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "conv_gemm per-pixel weights")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(part.cpu().numpy(), ref_parts.float().numpy(), rtol=0, atol=3e-5)
+    # the unsplit call: one output pixel, K = hp*hp*cin
+    whole = torch.full((M, cout), float("nan"), device=gpu_device)
+    d2 = nat.ConvGemmDesc()
+    d2.inp, d2.wt, d2.out = xin.data_ptr(), wd.data_ptr(), whole.data_ptr()
+    d2.in_pix_stride = M * cin
+    d2.M, d2.Cin, d2.lda, d2.Hin, d2.Win, d2.kH, d2.kW, d2.stride, d2.pad = M, cin, cin, hp, hp, hp, hp, 1, 0
+    d2.Hout, d2.Wout, d2.Cout, d2.ldc, d2.relu, d2.pool, d2.pool_w = 1, 1, cout, cout, 0, 1, hin
+    nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d2), nat.current_stream(gpu_device)), "conv_gemm pooled head")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(part.sum(0).cpu().numpy(), whole.cpu().numpy(), rtol=0, atol=3e-5)
+    # misuse is refused: row stride shorter than the row, unaligned offsets, the split-MFMA formats
+    d.ldw = cin - 4
+    assert lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)) == -1      # MAGAT_ERR_BAD_SHAPE
+    d.ldw, d.wt_pix_stride = hp * hp * cin, 6
+    assert lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)) == -1      # MAGAT_ERR_BAD_SHAPE
+    d.wt_pix_stride, d.in_fmt, d.pool = cin, 4, 0
+    assert lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)) == -2      # MAGAT_ERR_UNSUPPORTED
