@@ -88,6 +88,37 @@ def test_shard_equivalence_and_pickle(gpu_device):
         assert torch.equal(clone(x), full)
 
 
+def test_shard_equivalence_across_the_head_split(gpu_device, monkeypatch):
+    """The one size-dependent piece of arithmetic is the encoder head: below MAGAT_HEAD_SPLITK agents (12288) it sums nine
+    per-cell partial products, above it runs one long-K GEMM.  A batch above the threshold cut into shards below it
+    therefore agrees to float32 rounding (1e-5 here, the gate is 1e-4), and bit-for-bit once both sides are pinned to
+    one form (MAGAT_HEAD_SPLITK=0) - what a deployment that needs bit-exact resharding sets."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N = 130, 100                                   # 13000 agents: above the threshold; halves of 6500: below
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat")
+    net = _build(cfg, orc.init_state_dict(cfg, seed=12), gpu_device)
+    x = fov_states(B, N, seed=3).to(gpu_device)
+    S = comm_gso(B, N, 50, seed=4).to(gpu_device)
+    h = B // 2
+
+    def run():
+        with torch.no_grad():
+            net.addGSO(S)
+            full = net(x).clone()
+            net.addGSO(S[:h].contiguous())
+            a = net(x[:h]).clone()
+            net.addGSO(S[h:].contiguous())
+            b = net(x[h:]).clone()
+        return full, torch.cat((a, b))
+    full, parts = run()
+    assert (full - parts).abs().max().item() <= 1e-5
+    monkeypatch.setenv("MAGAT_HEAD_SPLITK", "0")
+    full0, parts0 = run()
+    assert torch.equal(full0, parts0)
+    assert torch.equal(full0, full)                   # above the threshold the default already is the one-GEMM form
+
+
 def test_cpu_tensor_inference_fails_loudly(gpu_device):
     from magat_pathplanning_amd import DecentralPlannerGATNet, _native
     from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
