@@ -151,7 +151,7 @@ class DecentralPlannerGATNet(nn.Module):
         scrub = self.skip in ("only", "legacy")        # only these reference files zero NaNs
         gso_mode = {"dist_GSO_one": 1, "full_GSO": 2}.get(self.config.GSO_mode, 0)
         if S.is_cuda and S.is_contiguous() and S.dtype in (torch.float32, torch.float64) and gso_mode != 2:
-            if scrub or gso_mode:
+            if (scrub or gso_mode) and S.numel() > 0:        # an empty GSO is accepted here, like the reference's addGSO
                 with torch.cuda.device(S.device):
                     nat.check(nat.lib().magat_gso_prepare(nat.ptr(S), 1 if S.dtype == torch.float64 else 0,
                                                           S.numel(), 1 if scrub else 0, gso_mode,
@@ -159,7 +159,7 @@ class DecentralPlannerGATNet(nn.Module):
             self.S = S.unsqueeze(1)
             # what the graph kernel needs from S alone is made now, on a side stream, under the per-agent CNN
             layer = self.GFL[0]
-            if not (self.training or layer.storage_dtype == torch.bfloat16):
+            if S.numel() > 0 and not (self.training or layer.storage_dtype == torch.bfloat16):
                 self._rt.plan.make(S, _MODES[layer.attentionMode])
             return
         self._rt.plan.key = None

@@ -381,3 +381,17 @@ def test_hip_graph_replay_matches_eager(gpu_device, mode):
         net.enable_hip_graph(False)
         net.addGSO(S.clone())
         assert torch.equal(net(x), moved)
+
+
+def test_empty_batch_raises_like_the_reference(gpu_device):
+    """B = 0: the reference's forward dies with a RuntimeError (flattening zero feature maps with `view(size(0), -1)` is ambiguous,
+    decentralplanner_GAT_bottleneck.py:297 - checked against the real module in the build container); here the C ABI
+    refuses M = 0 and the module raises MagatNativeError, a RuntimeError.  Nothing is silently returned."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd.synthetic import make_config
+    cfg = make_config(num_agents=10)
+    net = _build(cfg, orc.init_state_dict(cfg, seed=2), gpu_device)
+    with torch.no_grad():
+        net.addGSO(torch.zeros(0, 10, 10, device=gpu_device))
+        with pytest.raises(RuntimeError):
+            net(torch.zeros(0, 10, 3, 11, 11, device=gpu_device))
