@@ -180,6 +180,12 @@ class DecentralPlannerGATNet(nn.Module):
         x = inputTensor.reshape(B * N, C, W, H).to(dev)
         if self.S is None:
             raise TypeError("addGSO must be called before forward")
+        side = self.config.FOV + 2
+        if (C, W, H) != (3, side, side):
+            # the reference fails in its first Linear (mat1 and mat2 shapes cannot be multiplied); the folded encoder is
+            # built for one map size, so say it up front instead of reading the tensor with the wrong geometry
+            raise RuntimeError("DecentralPlannerGATNet built for (3, %d, %d) state maps (config.FOV + 2), got (%d, %d, %d)"
+                               % (side, side, C, W, H))
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if needs_grad or self.training:
             nat.require_device_or_composite(x, "DecentralPlannerGATNet in training / autograd mode")
@@ -208,6 +214,8 @@ class DecentralPlannerGATNet(nn.Module):
         dev = x.device
         rt = self._refresh(dev)
         layer = self.GFL[0]
+        if self.S.shape[-1] != N or self.S.shape[0] != B:
+            return self._forward_hip(x, B, N)            # padded / mismatched GSO: the eager path decides
         S3 = self.S.reshape(B, N, N)
         want_att = layer.return_attention or bool(getattr(self.config, "return_attentionGSO", False))
         if (want_att or layer.storage_dtype == torch.bfloat16 or S3.device != dev or
@@ -350,7 +358,16 @@ class DecentralPlannerGATNet(nn.Module):
             layer.addGSO(self.S)
             gat = self._buf("gat", (M, self.gat_width), dev)
             want_att = layer.return_attention or bool(getattr(self.config, "return_attentionGSO", False))
-            if layer.storage_dtype == torch.bfloat16:
+            Ns = self.S.shape[-1]
+            if Ns > N:
+                # more GSO nodes than agents: the graph layer zero-pads the signal to the GSO's size and trims its
+                # output (graphML.py:4641-4646, 4670-4671) - rare (never in the published scripts), done with copies
+                rows = torch.zeros(B, Ns, G, dtype=torch.float32, device=dev)
+                rows[:, :N] = comp.view(B, N, G)
+                full, aij = gat_forward_rows(rows.to(layer.storage_dtype) if layer.storage_dtype == torch.bfloat16 else rows,
+                                             self.S, layer, want_attention=want_att)
+                gat.copy_(full.view(B, Ns, -1)[:, :N, :self.gat_width].reshape(M, self.gat_width))
+            elif layer.storage_dtype == torch.bfloat16:
                 # bf16 storage inside the GAT layer (config.gat_storage='bf16', BASELINE config 5): the layer reads
                 # and writes bf16 rows; the CNN/MLP GEMMs around it stay fp32
                 gat16, aij = gat_forward_rows(comp.view(B, N, G).to(torch.bfloat16), self.S, layer,
