@@ -14,6 +14,7 @@ CPU oracle, kind "port", timed on this box's host cores on a bounded sample of t
 """
 import argparse
 import ctypes
+import gc
 import json
 import os
 import sys
@@ -214,12 +215,18 @@ def main():
             lib.magat_profile_reserve(32 * (args.steps + 1))      # event pairs created outside the timed region
             lib.magat_profile_reset()
             lib.magat_profile_enable(1)
+        # One-off 50-90 ms host stalls were seen in about one run in fifteen on these boxes (GPU idle meanwhile): a full
+        # collection of the interpreter's heap (torch + numpy put ~1e6 objects there) triggered by the step loop's small
+        # allocations fits.  Collect now and move the survivors out of the collector's reach; every step still runs in full.
+        gc.collect()
+        gc.freeze()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
         barrier()
         elapsed = time.perf_counter() - t0
+        gc.unfreeze()
     if timing:
         lib.magat_profile_enable(0)
         lib.magat_profile_collect()
