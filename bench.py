@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_F32_TFLOPS = 157.3    # fp32 MFMA (v_mfma_f32_32x32x2_f32) = fp32 vector peak
+PEAK_FP8_TFLOPS = 5000.0   # dense MXFP8 (v_mfma_scale_f32_32x32x64_f8f6f4), MI355X_MICROARCH.md
 PEAK_BF16_TFLOPS = 2500.0  # dense 16-bit MFMA (v_mfma_f32_32x32x16_{f16,bf16}); f16x3 issues 3, bf16x6 6 such flops per fp32 flop
 
 WORKLOADS = {
@@ -61,6 +62,16 @@ def split_tags(cfg):
     if int(os.environ.get("MAGAT_GAT_SPLIT", "1")) and nc % 32 == 0 and G % 32 == 0:
         tags.add(10)
     return tags
+
+
+def mx_tags(cfg):
+    """Kernel tags whose f16x3 GEMM runs as "f16 + MX correction" (encoder_f32.hip: every conv whose input is a block output,
+    i.e. layer2.* and layer3.* of the ResNet encoders, plane-granule chain on, MAGAT_CONV_MX != 0)."""
+    if not cfg.CNN_mode.startswith("ResNet") or not int(os.environ.get("MAGAT_CONV_MX", "1")):
+        return set()
+    if not (int(os.environ.get("MAGAT_CONV_PCHAIN", "1")) and int(os.environ.get("MAGAT_CONV_DIRECT", "1"))):
+        return set()
+    return {4, 5, 6, 7}
 
 
 def per_agent_work(cfg, N, S_bytes, deg=None, planned=False):
@@ -278,9 +289,16 @@ def main():
                         # 16-bit matrix peak with the flops it actually issues, and keep the fp32-equivalent rate
                         nprod = 3 if int(os.environ.get("MAGAT_CONV_F16", "1")) else 6
                         ach = nprod * fl * agent_steps / sec / 1e12
-                        ent.update(bound="mfma", mfma_dtype="f16 (f16x3 split, f32 accumulate)" if nprod == 3 else
-                                   "bf16 (bf16x6 split, f32 accumulate)", achieved=round(ach, 1),
-                                   peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
+                        peak, dt = PEAK_BF16_TFLOPS, ("f16 (f16x3 split, f32 accumulate)" if nprod == 3 else
+                                                      "bf16 (bf16x6 split, f32 accumulate)")
+                        if nprod == 3 and tag in mx_tags(cfg):
+                            # "f16 + MX correction" (layer2 / layer3 convs): of the three products one is issued as f16 MFMAs
+                            # and two inside a block-scaled fp8 MFMA at twice the f16 rate - the peak for the same three
+                            # products is 3 / (1/2500 + 2/5000) TFLOP/s
+                            peak = round(3.0 / (1.0 / PEAK_BF16_TFLOPS + 2.0 / PEAK_FP8_TFLOPS), 1)
+                            dt = "f16 main product + 2 correction products in MXFP8 (e4m3, block-scaled MFMA), f32 accumulate"
+                        ent.update(bound="mfma", mfma_dtype=dt, achieved=round(ach, 1),
+                                   peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                                    f32_equiv_tflops=round(ach / nprod, 2), flops_per_agent_step=fl)
                     elif bound == "mfma":
                         ach = fl * agent_steps / sec / 1e12

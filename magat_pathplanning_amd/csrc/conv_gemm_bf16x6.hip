@@ -28,6 +28,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -425,8 +427,14 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 // PIN: in / in2 arrive as f16 PLANE PAIRS in the plane-granule layout (in_gl = 2, magat_hip.h): the producer's epilogue
 // split every value once, the loader here fetches finished 16-byte MFMA operands and does no VALU work at all (with
 // float32 input every value is split once per tap it is used by - 7 times on a 6x6 map).
-template <int BN, int TM, bool PIN>
+// INF 2 (in_gl = 3, "f16 + MX correction"): plane 0 as above, plane 1 carries, per agent and 32-channel tile, 32 bytes
+// e4m3(h1) and 32 bytes e4m3(h2 * 2^11) instead of the f16 h2; the weights' plane 1 carries [e4m3(g2 * 2^5) | e4m3(g1 * 2^-6)]
+// per row and slab.  Per slab: two f16 MFMAs (h1 g1) and ONE v_mfma_scale_f32_32x32x64_f8f6f4 whose K = 64 is
+// [q(h1) | q(h2)] . [q(g2) ; q(g1)] - lanes 0-31 hold K block 0, lanes 32-63 block 1, one power-of-two scale per block.
+// Same bytes moved as the f16x3 form, half the matrix passes; logits move by 4e-6 (tests/arith_probe.py).
+template <int BN, int TM, int INF>
 __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_kernel(const SplitParams p) {
+  constexpr bool PIN = INF >= 1, MX = INF == 2;
   constexpr int TN = BN / 32;
   constexpr int STAGE = 2 * BN * 64;                    // bytes per weight stage: two planes of BN rows x 64 B
   __shared__ __attribute__((aligned(1024))) char Bs[2 * STAGE];
@@ -560,8 +568,13 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
     const char* a = na[i];
     fa[i][0] = *reinterpret_cast<const u32x4*>(a);
     fa[i][1] = *reinterpret_cast<const u32x4*>(a + d1);
-    fa[i][2] = *reinterpret_cast<const u32x4*>(a + nd2);
-    fa[i][3] = *reinterpret_cast<const u32x4*>(a + nd2 + d1);
+    if constexpr (MX) {     // plane 1: this lane's K block = granules 2 fh, 2 fh + 1 of the tile (aoff already has + 2048 fh)
+      fa[i][2] = *reinterpret_cast<const u32x4*>(a + nd2 + fh * 2048);
+      fa[i][3] = *reinterpret_cast<const u32x4*>(a + nd2 + fh * 2048 + 2048);
+    } else {
+      fa[i][2] = *reinterpret_cast<const u32x4*>(a + nd2);
+      fa[i][3] = *reinterpret_cast<const u32x4*>(a + nd2 + d1);
+    }
   };
   // (the LDS-direct loads always go out AFTER the register loads of the slab: vmcnt retires in order, so the compiler's
   // waits for the activation registers - it cannot see the asm loads - never include the weight fill)
@@ -656,11 +669,77 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
     // of the loads to the gaps (all activation loads first, weight pieces first, two pieces per gap) are within +-3 %.)
     if constexpr (IL) take_regs();
   };
-  for (int s = 0; s + 1 < nslab; ++s) {
-    compute(s, std::true_type{});
-    landed();
+  // e8m0 block scales of the MX instruction (value = stored * 2^(scale - 127)): weights block 0 = g2 * 2^5, block 1 = g1 * 2^-6;
+  // activations block 0 = h1, block 1 = h2 * 2^11
+  const int mx_sa = fh ? 133 : 122, mx_sb = fh ? 116 : 127;
+  auto compute_mx = [&](int s, auto il_tag) {
+    constexpr bool IL = decltype(il_tag)::value;
+    const char* bst = Bs + (s & 1) * STAGE;
+    const int nstage = (s + 1) & 1;
+    if constexpr (IL) advance();
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {           // MFMA groups: h1 g1 (k step 0), h1 g1 (k step 1), the MX correction
+      if (g < 2) {
+        u32x4 fb[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = j * 32 + fr;
+          fb[j] = *reinterpret_cast<const u32x4*>(bst + (row * 4 + ((2 * g + fh) ^ ((row >> 2) & 3))) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]),
+                                                               __builtin_bit_cast(f16x8, qa[i][g][0]), acc[i][j], 0, 0, 0);
+      } else {
+        i32x8 fq[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = j * 32 + fr;
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(bst + BN * 64 + (row * 4 + ((2 * fh) ^ ((row >> 2) & 3))) * 16);
+          const u32x4 hi = *reinterpret_cast<const u32x4*>(bst + BN * 64 + (row * 4 + ((2 * fh + 1) ^ ((row >> 2) & 3))) * 16);
+          fq[j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const u32x4 lo = qa[i][0][1], hi = qa[i][1][1];
+          const i32x8 aq = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fq[j], aq, acc[i][j], 0, 0, 0, mx_sa, 0, mx_sb);
+        }
+      }
+      if constexpr (IL) {                   // the next slab's loads go into the gaps behind the groups
+        __builtin_amdgcn_sched_barrier(0);
+        if (g == 0) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) load_a(i);
+        } else {
+#pragma unroll
+          for (int e = 0; e < (TN + 1) / 2; ++e) {
+            const int piece = (g - 1) * ((TN + 1) / 2) + e;
+            if (piece < TN) dma(piece, nstage);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (IL) take_regs();
+  };
+  if constexpr (MX) {
+    for (int s = 0; s + 1 < nslab; ++s) {
+      compute_mx(s, std::true_type{});
+      landed();
+    }
+    if (nslab > 0) compute_mx(nslab - 1, std::false_type{});
+  } else {
+    for (int s = 0; s + 1 < nslab; ++s) {
+      compute(s, std::true_type{});
+      landed();
+    }
+    if (nslab > 0) compute(nslab - 1, std::false_type{});
   }
-  if (nslab > 0) compute(nslab - 1, std::false_type{});
 
   // epilogue: D[channel][agent]; agent = lane&31, channel = (r&3) + 8*(r>>2) + 4*(lane>>5).  The lane's 4 TN bias quads
   // are fetched as ONE batch of 16-byte loads (per-channel conditional loads cost one L2 round trip per quad).
@@ -727,7 +806,7 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + 32 * (TM * wave + i) + fr;
     if (m >= p.M) continue;
-    if (p.out_gl == 2) {
+    if (p.out_gl >= 2) {
       // f16 plane granules for the next f16x3 layer: the lane's quads 2 ks, 2 ks + 1 of a 32-channel tile ARE that
       // layer's k-step-ks operand (its weights are packed in this channel order), one 16-byte store per plane
       char* const ob = static_cast<char*>(p.out) + ((long long)pix * p.out_pix_stride + (long long)(m >> 7) * p.out_tile) * 4 +
@@ -737,7 +816,7 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          unsigned h1[4], h2[4];
+          unsigned h1[4], h2[4], q1w[2], q2w[2];
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const int q = 2 * ks + e;
@@ -749,10 +828,31 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
             }
             split_pair_f16(v[0], v[1], h1[2 * e], h2[2 * e]);
             split_pair_f16(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1]);
+            if (p.out_gl == 3) {      // MX consumer: e4m3(h1) and e4m3((v - h1) * 2^11), four bytes each
+              float a[4], r[4];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const float vc = __builtin_amdgcn_fmed3f(v[c], -65504.f, 65504.f);
+                const float hf = (float)(_Float16)vc;
+                a[c] = __builtin_amdgcn_fmed3f(hf, -448.f, 448.f);
+                r[c] = __builtin_amdgcn_fmed3f((vc - hf) * 2048.f, -448.f, 448.f);
+              }
+              int w = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], 0, false);
+              q1w[e] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], w, true);
+              w = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], 0, false);
+              q2w[e] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], w, true);
+            }
           }
           char* const o = ob + (long long)(((n0 >> 5) + j) * 2 + ks) * 4096;
           *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
-          *reinterpret_cast<u32x4*>(o + oplane) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+          if (p.out_gl == 3) {
+            // plane 1 of the tile: granule fh = this lane's 16 e4m3(h1) bytes (byte 4 q + c), granule 2 + fh the e4m3(h2) ones
+            char* const ot = ob + (long long)(((n0 >> 5) + j) * 2) * 4096 + oplane + 8 * ks;
+            *reinterpret_cast<u32x2*>(ot) = u32x2{q1w[0], q1w[1]};
+            *reinterpret_cast<u32x2*>(ot + 4096) = u32x2{q2w[0], q2w[1]};
+          } else {
+            *reinterpret_cast<u32x4*>(o + oplane) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+          }
         }
       continue;
     }
@@ -862,6 +962,7 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   } while (0)
   const int direct = magat_conv_direct_enabled();
   if ((d->in_gl || d->out_gl) && !(d->in_fmt == 4 && d->out_fmt == 0 && direct)) return MAGAT_ERR_UNSUPPORTED;
+  if (d->in_gl < 0 || d->in_gl > 3 || d->out_gl < 0 || d->out_gl > 3) return MAGAT_ERR_UNSUPPORTED;
   if (d->in_fmt == 4 && d->out_fmt == 0 && direct && d->in_gl == 2) {
     // 3x3 / stride-1 layers with 128-channel tiles: two adjacent output pixels per workgroup (conv_gemm_f16x3_pair.hip).
     // Opt-in (MAGAT_CONV_PAIR=1): bit-identical, 1/3 less activation traffic, but its single 8-wave workgroup per CU runs
@@ -886,16 +987,20 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
     p.Mt = (int)mt;
 #define MAGAT_DIRECT_LAUNCH(BNV)                                                                                     \
   do {                                                                                                              \
-    if (two && pin)                                                                                                 \
-      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2, true>), dim3((unsigned)g2), dim3(256), 0, st, p);   \
+    if (two && mxin)                                                                                                \
+      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2, 2>), dim3((unsigned)g2), dim3(256), 0, st, p);      \
+    else if (mxin)                                                                                                  \
+      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1, 2>), dim3((unsigned)g2), dim3(256), 0, st, p);      \
+    else if (two && pin)                                                                                            \
+      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2, 1>), dim3((unsigned)g2), dim3(256), 0, st, p);      \
     else if (two)                                                                                                   \
-      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2, false>), dim3((unsigned)g2), dim3(256), 0, st, p);  \
+      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2, 0>), dim3((unsigned)g2), dim3(256), 0, st, p);      \
     else if (pin)                                                                                                   \
-      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1, true>), dim3((unsigned)g2), dim3(256), 0, st, p);   \
+      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1, 1>), dim3((unsigned)g2), dim3(256), 0, st, p);      \
     else                                                                                                            \
-      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1, false>), dim3((unsigned)g2), dim3(256), 0, st, p);  \
+      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1, 0>), dim3((unsigned)g2), dim3(256), 0, st, p);      \
   } while (0)
-    const bool pin = d->in_gl == 2;
+    const bool pin = d->in_gl == 2, mxin = d->in_gl == 3;
     if (BN == 128) MAGAT_DIRECT_LAUNCH(128);
     else if (BN == 64) MAGAT_DIRECT_LAUNCH(64);
     else MAGAT_DIRECT_LAUNCH(32);

@@ -368,6 +368,14 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   // float offset of the permuted copy behind an f16 weight block of cout x ktot weights (two planes + one scale float,
   // padded to 4 floats)
   auto permuted = [&](int cout, int ktot) { return lay == 2 ? (int64_t)(((int64_t)cout * ktot + 1 + 3) & ~3LL) : 0; };
+  // "f16 + MX correction" chain (in_gl / out_gl = 3, third weight copy, off[31]): from block 0's output on, the second
+  // activation plane carries e4m3(h1) | e4m3(h2 * 2^11) and the consumers issue two f16 MFMAs + one block-scaled fp8 MFMA per
+  // slab instead of six f16 ones.  Block 0's own inputs (fused stem + layer1.conv1 output) stay f16 planes.  MAGAT_CONV_MX.
+  bool mx = false;
+  if (lay == 2 && d->off[31] != 0) {
+    const char* e = getenv("MAGAT_CONV_MX");       // (read per call: the parity tests flip it; 0 = f16x3 everywhere)
+    mx = !e || atoi(e);
+  }
   for (int m0 = 0; m0 < M; m0 += mc) {
     const int mm = (M - m0) < mc ? (M - m0) : mc;
     // Plane chain: the stem and layer1.conv1 run as ONE kernel (layer1_fused.hip) - the 121-pixel stem output never
@@ -413,7 +421,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
         }
       }
       g.in_gl = g.out_gl = lay;
-      if (lay == 2) g.wt += permuted(s.cout, 9 * s.cin);
+      if (mx && l >= 1) { g.in_gl = g.out_gl = 3; g.wt += 2 * permuted(s.cout, 9 * s.cin); }
+      else if (lay == 2) g.wt += permuted(s.cout, 9 * s.cin);
       if (!(fused1 && l == 0)) {
         rc = magat_conv_gemm_f32(&g, stream);
         if (rc != MAGAT_OK) return rc;
@@ -441,7 +450,9 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
         }
       }
       h.in_gl = lay; h.out_gl = l + 1 < nblocks ? lay : 0;
-      if (lay == 2) h.wt += permuted(s.cout, 9 * s.cout + s.cin);
+      if (mx && l + 1 < nblocks) h.out_gl = 3;
+      if (mx && l >= 1) { h.in_gl = 3; h.wt += 2 * permuted(s.cout, 9 * s.cout + s.cin); }
+      else if (lay == 2) h.wt += permuted(s.cout, 9 * s.cout + s.cin);
       if (fused1 && l == 0) {    // the residual branch reads the stem's stride-2 pixels, stored as an Ho x Wo map
         h.in2_tile_stride = tiles(hout * wout, s.cin); h.W2 = wout; h.stride2 = 1;
       }

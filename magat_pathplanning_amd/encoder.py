@@ -151,7 +151,18 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
             assert blk2.numel() == blk.numel()
             cursor_f += blk2.numel()
             raws.append(blk2)
-        offs[30] = offs[24] + (offs[25] - offs[24]) // 2      # first permuted copy (non-zero = copies present)
+            # ... and a third copy for the "f16 + MX correction" arithmetic (magat_hip.h in_gl = 3): plane 0 as in the
+            # permuted copy (g1), plane 1 = per row and 32-channel slab 64 bytes [fp8(g2 * 2^5) | fp8(g1 * 2^-6)] (OCP
+            # e4m3), channels in the order the producer's lanes emit their fp8 activation bytes
+            blk3 = _mx_block(w2d, perm32)
+            if pad:
+                blk3 = torch.cat((blk3, torch.zeros(pad)))
+            assert blk3.numel() == blk.numel()
+            cursor_f += blk3.numel()
+            raws.append(blk3)
+            if slot == pairs[0][0]:
+                offs[30] = offs[slot + 6] + blk.numel()        # first permuted copy (non-zero = copies present)
+                offs[31] = offs[slot + 6] + 2 * blk.numel()    # first MX copy
         pack = torch.cat([pack] + raws).contiguous()
     meta = dict(variant=0 if large else 1, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast)
     return pack, offs, meta
@@ -165,6 +176,31 @@ def split_bf16x3(t):
     p1 = r.bfloat16()
     p2 = (r - p1.float()).bfloat16()
     return torch.stack((p0, p1, p2), dim=0).contiguous()
+
+
+MX_PI = [8 * ((q >> 2) & 3) + 4 * (q >> 4) + (q & 3) for q in range(32)]     # byte position -> channel of a 32-channel tile
+
+
+def _mx_block(w2d, perm32):
+    """[Cout][K] float32 weights -> the in_gl = 3 operand block (same size as split_f16x2's): plane 0 = f16 g1 with the K
+    columns of every 32-slab in plane-granule order, plane 1 = per row and slab [e4m3(g2 * 2^5) (32 B) | e4m3(g1 * 2^-6) (32 B)]
+    in MX_PI order, then the float32 inverse weight scale.  g1 + g2 = f16 split of w * 2^e as in split_f16x2."""
+    cout, K = w2d.shape
+    _, e = split_f16x2(w2d.reshape(-1))
+    ts = w2d.detach().float().cpu() * (2.0 ** e)
+    g1 = ts.half()
+    g2 = (ts - g1.float()).half()
+    base = (torch.arange(K) // 32) * 32
+    ip = base + perm32.repeat(K // 32)
+    iq = base + torch.tensor(MX_PI).repeat(K // 32)
+    f8 = lambda t: t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    q2 = f8(g2.float()[:, iq] * 32.0).view(cout, K // 32, 32)
+    q1 = f8(g1.float()[:, iq] / 64.0).view(cout, K // 32, 32)
+    plane1 = torch.stack((q2, q1), dim=2).reshape(cout, 2 * K).contiguous().view(torch.int16)       # [cout][K] as 16-bit
+    planes = torch.cat((g1[:, ip].contiguous().view(torch.int16).reshape(-1), plane1.reshape(-1)))
+    if planes.numel() % 2:
+        planes = torch.cat((planes, torch.zeros(1, dtype=torch.int16)))
+    return torch.cat((planes.view(torch.float32), torch.tensor([2.0 ** (-e)], dtype=torch.float32)))
 
 
 def split_f16x2(t):

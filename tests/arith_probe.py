@@ -80,6 +80,9 @@ def make_conv(mode, cmin):
             y = y + c(q8(h1), q8(g2)) + c(q8(h2), q8(g1))
         elif mode == "drop":
             y = y + c(h1, g2)
+        elif mode == "fp8fixed":  # plain e4m3 with FIXED power-of-two scales (no per-block maxima): h1, h2*2^11, g1*2^-6, g2*2^5
+            f8 = lambda t, k: (t * 2.0 ** k).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * 2.0 ** -k
+            y = y + c(f8(h1, 0), f8(g2, 5)) + c(f8(h2, 11), f8(g1, -6))
         elif mode in MX:          # corrections in a block-scaled MX format (blocks of 32 input channels)
             y = y + c(qmx(h1, mode, 1), qmx(g2, mode, 1)) + c(qmx(h2, mode, 1), qmx(g1, mode, 1))
         y = (y / sc).to(x.dtype)
@@ -95,7 +98,7 @@ def main():
         x, S = fov_states(B, N, seed=1), comm_gso(B, N, 20 if N == 10 else 50, seed=2)
         ref = orc.planner_forward(x, S.clone(), sd, cfg)
         print("B=%d N=%d   |logit| max %.3f, mean %.3f" % (B, N, ref.abs().max(), ref.abs().mean()))
-        for mode in ("f16x3", "fp8corr", "mxfp8", "mxfp6_e2m3", "mxfp6_e3m2", "mxfp4", "drop"):
+        for mode in (sys.argv[1:] or ("f16x3", "fp8corr", "fp8fixed", "mxfp8", "mxfp6_e2m3", "mxfp6_e3m2", "mxfp4", "drop")):
             for cmin, what in ((32, "every BasicBlock 3x3 conv"), (64, "layer2.conv2 + layer3"), (128, "layer3.conv2 only")):
                 orc.tnf.conv2d = make_conv(mode, cmin)
                 try:
