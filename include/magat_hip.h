@@ -245,7 +245,14 @@ typedef struct magat_conv_gemm_desc {
    *      matrix core as its k-step-ks operand.  The CONSUMER's weights must carry the same order: within every 32-wide
    *      K slab, column 16ks + 8h + i = the weight of channel 16ks + 8(i>>2) + 4h + (i&3) (encoder.fold_resnet packs
    *      such a copy behind each f16 weight block).  Values are split once by the producer instead of once per tap by
-   *      every consumer. */
+   *      every consumer.
+   *   3: as 2, but plane 1 carries, per agent and 32-channel tile, 32 bytes OCP e4m3 of the value's f16 part h1 (granules 0, 1
+   *      of the tile's plane-1 region: byte 16 h + 4 g + c = channel 8 g + 4 h + c) and 32 bytes e4m3 of (value - h1) * 2^11
+   *      (granules 2, 3) instead of the f16 remainder: the "f16 + MX correction" form.  The consumer (in_gl = 3, weights =
+   *      the THIRD copy of the pack: plane 1 = per row and slab [e4m3(g2 * 2^5) | e4m3(g1 * 2^-6)] in the same byte order)
+   *      issues, per 32-channel slab, two f16 MFMAs for h1 g1 and one v_mfma_scale_f32_32x32x64_f8f6f4 for both correction
+   *      products (K block 0 = q(h1) q(g2), block 1 = q(h2) q(g1), one power-of-two scale per block).  Same bytes as layout 2,
+   *      half the matrix passes; results differ from the f16x3 form by ~3e-6 of the output scale. */
   int in_gl, out_gl;
   /* Row-major float32 output split into column tiles (f16x3 direct kernel, out_gl = 0 only): when > 0, the 128-channel tile
    * t of the output lives at out + t * out_ntile_stride (+ pixel offset) with row stride ldc, instead of at column 128 t of
