@@ -12,9 +12,10 @@ from collections import defaultdict
 
 def short(name):
     import re
-    m = re.search(r"conv_gemm_f16x3_direct_kernel<(\d+), (\d+), (true|false)>", name)
-    if m:                                       # f16x3, activations straight into registers
-        return "conv_f16x3_direct<%s,TM%s,%s>" % (m.group(1), m.group(2), "planes-in" if m.group(3) == "true" else "f32-in")
+    m = re.search(r"conv_gemm_f16x3_direct_kernel<(\d+), (\d+), (true|false|0|1|2)>", name)
+    if m:                                       # f16x3 / f16 + MX correction, activations straight into registers
+        inf = {"true": "planes-in", "false": "f32-in", "0": "f32-in", "1": "planes-in", "2": "MX planes-in"}[m.group(3)]
+        return "conv_f16x3_direct<%s,TM%s,%s>" % (m.group(1), m.group(2), inf)
     m = re.search(r"conv_gemm_bf16x6_kernel<true, (\d+), \d+, \d+, 2>", name)
     if m:                                       # NPL = 2: the f16x3 flavour of the split kernel
         return "conv_gemm_f16x3<f32-in,%s>" % m.group(1)
