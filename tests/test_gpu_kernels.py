@@ -777,3 +777,54 @@ def test_conv_gemm_f32_per_pixel_weights_over_pooled_map(gpu_device, M, cin, cou
     assert lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)) == -1      # MAGAT_ERR_BAD_SHAPE
     d.wt_pix_stride, d.in_fmt, d.pool = cin, 4, 0
     assert lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)) == -2      # MAGAT_ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,cin,cmid,cout", [(256, 64, 64, 128), (150, 32, 64, 64)])
+def test_conv_gemm_f16_plus_mx_correction_chain(gpu_device, M, cin, cmid, cout):
+    """in_gl / out_gl = 3 at the C ABI: a producer conv writes the "f16 + MX correction" plane granules (plane 1 =
+    e4m3(h1) | e4m3(h2 * 2^11)), a consumer conv reads them with the third weight copy (encoder._mx_block) and issues two
+    f16 MFMAs + one block-scaled fp8 MFMA per slab.  Against float64 of the same two 3x3 convs (+ReLU between): the
+    corrections are only 4 bits wide, yet the result stays within 2e-5 of the output scale (f16x3: 3e-6), ragged agent
+    count included.  The same chain with out_gl / in_gl = 2 (three f16 products) must agree with it to that bound too."""
+    nat, lib = _nat()
+    from magat_pathplanning_amd.encoder import _mx_block, split_f16x2
+    g = torch.Generator().manual_seed(M + cin)
+    hw, Mp = 6, (M + 127) // 128 * 128
+    x = torch.relu(torch.randn(M, cin, hw, hw, generator=g))
+    wa = torch.randn(cmid, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    wb = torch.randn(cout, cmid, 3, 3, generator=g) / (9 * cmid) ** 0.5
+    ba, bb = torch.randn(cmid, generator=g) * 0.1, torch.randn(cout, generator=g) * 0.1
+    ref = tnf.conv2d(tnf.conv2d(x.double(), wa.double(), ba.double(), 1, 1).clamp_min(0), wb.double(), bb.double(), 1, 1)
+    wa2, wb2 = wa.permute(0, 2, 3, 1).reshape(cmid, -1).contiguous(), wb.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    perm32 = torch.tensor([16 * (q >> 4) + 8 * ((q & 7) >> 2) + 4 * ((q >> 3) & 1) + (q & 3) for q in range(32)])
+    kidx = (torch.arange(wb2.shape[1]) // 32) * 32 + perm32.repeat(wb2.shape[1] // 32)
+    wts = {3: _mx_block(wb2, perm32).to(gpu_device), 2: split_f16x2(wb2[:, kidx])[0].to(gpu_device)}
+    wad = split_f16x2(wa2)[0].to(gpu_device)
+    xin = torch.zeros(hw * hw, Mp, cin)
+    xin[:, :M] = _to_pixel_major(x)
+    xin = xin.to(gpu_device)
+    bad, bbd = ba.to(gpu_device), bb.to(gpu_device)
+    st = nat.current_stream(gpu_device)
+    outs = {}
+    for lay in (3, 2):
+        mid = torch.zeros(hw * hw * Mp * cmid, device=gpu_device)            # plane granules: 4 bytes per value
+        out = torch.full((hw * hw, Mp, cout), float("nan"), device=gpu_device)
+        d = nat.ConvGemmDesc()
+        d.inp, d.wt, d.bias, d.out = xin.data_ptr(), wad.data_ptr(), bad.data_ptr(), mid.data_ptr()
+        d.in_pix_stride, d.out_pix_stride = Mp * cin, Mp * cmid
+        d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, hw, hw, 3, 3, 1, 1
+        d.Hout, d.Wout, d.Cout, d.ldc, d.relu, d.in_fmt, d.in_gl, d.out_gl = hw, hw, cmid, cmid, 1, 4, 0, lay
+        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), st), "producer")
+        e = nat.ConvGemmDesc()
+        e.inp, e.wt, e.bias, e.out = mid.data_ptr(), wts[lay].data_ptr(), bbd.data_ptr(), out.data_ptr()
+        e.in_pix_stride, e.out_pix_stride = Mp * cmid, Mp * cout
+        e.M, e.Cin, e.lda, e.Hin, e.Win, e.kH, e.kW, e.stride, e.pad = M, cmid, cmid, hw, hw, 3, 3, 1, 1
+        e.Hout, e.Wout, e.Cout, e.ldc, e.relu, e.in_fmt, e.in_gl, e.out_gl = hw, hw, cout, cout, 0, 4, lay, 0
+        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(e), st), "consumer")
+        torch.cuda.synchronize()
+        outs[lay] = _from_pixel_major(out[:, :M].cpu(), hw, hw).double()
+    scale = float(ref.abs().max())
+    assert float((outs[2] - ref).abs().max()) <= 3e-6 * scale
+    assert float((outs[3] - ref).abs().max()) <= 2e-5 * scale
+    assert float((outs[3] - outs[2]).abs().max()) > 0.0          # really another arithmetic
