@@ -255,9 +255,11 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if cfg.gat_storage == "fp32" else "f32 arithmetic, bf16 storage inside the GAT layer",
                "data": "synthetic (seeded binary FOV states + comm-radius GSO; random-init weights, BN stats perturbed)",
-               "config": {"precision": "float32 in / float32 out, logits within 1e-4 of the reference (observed 1e-6); dense maps on "
-                                       "fp32 MFMA or f16x3 split products (2 f16 planes per value = 22 significand bits, 3 f16 "
-                                       "MFMAs per product, fp32 accumulate: measured error vs float64 equal to the fp32 MFMA kernel)",
+               "config": {"precision": "float32 in / float32 out, logits within 1e-4 of the reference (observed 5e-6..1e-5; 1e-6 with "
+                                       "MAGAT_CONV_MX=0); dense maps on fp32 MFMA or split products with fp32 accumulate: f16x3 (2 f16 "
+                                       "planes per value = 22 significand bits, 3 f16 MFMAs per product) and, for the layer2/layer3 "
+                                       "convolutions, the main product h1*g1 on f16 MFMAs + both 2^-11-sized correction products in one "
+                                       "block-scaled fp8 (e4m3) MFMA per slab",
                           "workload": "%s: N=%d agents, %dx%d map, K=%d, P=%d, F=%d, %s, %s, KeyQuery, %s; batch %d per GPU "
                                       "(global %d); resident inputs, addGSO+forward per step"
                                       % (args.workload, N, map_w, map_w, K, P, G, bmode, cnn,
