@@ -43,6 +43,19 @@ extern "C" {
 int magat_abi_version(void);
 const char* magat_error_string(int code);
 
+/* Options.  Every tunable of the library lives in one table that is seeded from the environment (MAGAT_<NAME>) ONCE, at
+ * first use, and is read / changed through these calls afterwards; nothing on the launch path calls getenv.  `name` with
+ * or without the MAGAT_ prefix.  The ones a deployment may care about (the rest are A/B switches of the kernels, listed in
+ * csrc/options.hip):
+ *   RANGE_GUARD (1)  split-arithmetic range guard of the encoder: see magat_encoder_status
+ *   CONV_MX     (0)  OPT-IN block-scaled fp8 correction planes in layer2 / layer3 (narrower than fp32-class arithmetic)
+ *   CONV_SPLIT  (7)  bit l: BasicBlock l+1 on the f16x3 split kernels; 0 = every convolution on the fp32 MFMA kernel
+ *   HEAD_SPLITK      largest agent count whose encoder head sums per-cell partials (0: one long-K GEMM, bit-exact resharding)
+ * Returns MAGAT_ERR_UNSUPPORTED for an unknown name. */
+int magat_set_option(const char* name, int value);
+int magat_get_option(const char* name, int* value);
+int magat_reset_option(const char* name);   /* back to the built-in default (not the environment's value) */
+
 /* ------------------------------------------------------------------------------------------
  * GAT layer: GraphFilterBatchAttentional.forward  (utils/graphUtils/graphML.py:4636-4671)
  *   = graphAttentionLSIGFBatch_{KeyQuery,modified} (graphML.py:1724-1827)

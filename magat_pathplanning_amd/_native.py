@@ -58,6 +58,9 @@ _I, _P, _Z = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 _SIGNATURES = {
     "magat_abi_version": (ctypes.c_int, []),
     "magat_error_string": (ctypes.c_char_p, [_I]),
+    "magat_set_option": (_I, [ctypes.c_char_p, _I]),
+    "magat_get_option": (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
+    "magat_reset_option": (_I, [ctypes.c_char_p]),
     "magat_gat_dense_supported": (_I, [_I] * 3),
     "magat_gat_packed_floats": (_Z, [_I] * 5),
     "magat_gat_pack_weights": (_I, [_P] * 5 + [_I] * 5 + [_P]),
@@ -117,6 +120,21 @@ def lib():
                     fn.restype, fn.argtypes = res, args
                 _lib = handle
     return _lib
+
+
+def set_option(name, value):
+    """Library tunable (include/magat_hip.h "Options"); the environment variable MAGAT_<NAME> only seeds it at load."""
+    check(lib().magat_set_option(name.encode(), int(value)), "magat_set_option(%s)" % name)
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    check(lib().magat_get_option(name.encode(), ctypes.byref(v)), "magat_get_option(%s)" % name)
+    return v.value
+
+
+def reset_option(name):
+    check(lib().magat_reset_option(name.encode()), "magat_reset_option(%s)" % name)
 
 
 def check(rc, what):

@@ -1,35 +1,62 @@
-"""Builds libmagat_hip.so (gfx950) in-tree with hipcc.  `python -m magat_pathplanning_amd.build_native`."""
+"""Builds libmagat_hip.so (gfx950) in-tree with hipcc.  `python -m magat_pathplanning_amd.build_native [--force] [--debug]`.
+
+Every source is compiled to its own object (only the stale ones, in parallel), then linked.  --debug builds
+lib/libmagat_hip_debug.so with -DMAGAT_DEBUG_HOOKS (phase timestamps / phase skipping of the graph kernel, used by
+tools/gat_phase_probe.py through MAGAT_LIB_PATH); the release library carries no instrumentation."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "libmagat_hip.so")
-SOURCES = ["conv_gemm_f32.hip", "conv_gemm_bf16x6.hip", "conv_gemm_f16x3_pair.hip", "conv_gemm_f16x3_duo.hip", "gat_f32.hip", "gat_list_f32.hip", "gat_csr_f32.hip", "encoder_f32.hip", "layer1_fused.hip", "sim_frontend.hip", "profile.hip"]
+LIB_DEBUG = os.path.join(PKG, "lib", "libmagat_hip_debug.so")
+SOURCES = ["conv_gemm_f32.hip", "conv_gemm_bf16x6.hip", "block_fused.hip", "gat_f32.hip", "gat_fused.hip", "gat_csr_f32.hip",
+           "encoder_f32.hip", "layer1_fused.hip", "sim_frontend.hip", "profile.hip", "options.hip"]
 HEADERS = ["magat_common.h", os.path.join("..", "..", "include", "magat_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
+         "-Wno-inline-asm"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _newer(path, deps):
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    t = os.path.getmtime(path)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
+def build(force=False, verbose=False, debug=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc] + [f for f in FLAGS if f] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    return LIB
+    lib = LIB_DEBUG if debug else LIB
+    objdir = os.path.join(PKG, "lib", "obj_debug" if debug else "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    flags = FLAGS + (["-DMAGAT_DEBUG_HOOKS"] if debug else [])
+    jobs, objs = [], []
+    for s in _sources():
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs):
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+    if not jobs and not _newer(lib, objs):
+        return lib
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, debug="--debug" in sys.argv))

@@ -886,10 +886,7 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
 }  // namespace
 
 // MAGAT_CONV_DIRECT=0 keeps f16x3 (in_fmt 4, out_fmt 0) on the 2x2 LDS-staged kernel
-int magat_conv_direct_enabled() {
-  const char* e = getenv("MAGAT_CONV_DIRECT");         // (read per call: the parity tests flip it)
-  return e ? atoi(e) : 1;
-}
+int magat_conv_direct_enabled() { return magat_opt(MAGAT_OPT_CONV_DIRECT); }
 
 // in_fmt 5: like 4, but in/in2 arrive as the two f16 planes already (written by a producer with out_fmt 3): no split work.
 // in_fmt 4: in/in2 float32 split on load into two f16 planes, wt = [2][Cout][Ktot] f16 planes of (weight * 2^e) followed
@@ -929,8 +926,8 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.out_nt = d->out_ntile_stride;
   if (p.out_nt && !(d->in_fmt == 4 && d->out_fmt == 0 && d->out_gl == 0 && BN == 128 && magat_conv_direct_enabled()))
     return MAGAT_ERR_UNSUPPORTED;
-  { const char* e = getenv("MAGAT_CONV_KORDER"); p.korder = e ? atoi(e) : 1; }
-  { const char* e = getenv("MAGAT_CONV_TEPI"); p.tepi = e ? atoi(e) : 1; }
+  p.korder = magat_opt(MAGAT_OPT_CONV_KORDER);
+  p.tepi = magat_opt(MAGAT_OPT_CONV_TEPI);
   p.Mt = (p.M + BM - 1) / BM;
   p.ntn = p.Cout / BN;
   if (magat_row_off(p.M, p.lda, p.in_tile) * 4 >= 0xffffffffLL ||
@@ -963,24 +960,8 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   const int direct = magat_conv_direct_enabled();
   if ((d->in_gl || d->out_gl) && !(d->in_fmt == 4 && d->out_fmt == 0 && direct)) return MAGAT_ERR_UNSUPPORTED;
   if (d->in_gl < 0 || d->in_gl > 3 || d->out_gl < 0 || d->out_gl > 3) return MAGAT_ERR_UNSUPPORTED;
-  if (d->in_fmt == 4 && d->out_fmt == 0 && direct && d->in_gl == 2) {
-    // 3x3 / stride-1 layers with 128-channel tiles: two adjacent output pixels per workgroup (conv_gemm_f16x3_pair.hip).
-    // Opt-in (MAGAT_CONV_PAIR=1): bit-identical, 1/3 less activation traffic, but its single 8-wave workgroup per CU runs
-    // all waves in phase behind one barrier and measured 20 % SLOWER than two independent 4-wave workgroups.
-    const char* ed = getenv("MAGAT_CONV_DUO");        // two half-a-slab-apart halves per workgroup (conv_gemm_f16x3_duo.hip)
-    if (ed && atoi(ed)) {
-      const int rc = magat_conv_gemm_f16x3_duo(d, st);
-      if (rc != MAGAT_ERR_UNSUPPORTED) return rc;
-    }
-    const char* e = getenv("MAGAT_CONV_PAIR");
-    if (e && atoi(e)) {
-      const int rc = magat_conv_gemm_f16x3_pair(d, st);
-      if (rc != MAGAT_ERR_UNSUPPORTED) return rc;
-    }
-  }
   if (d->in_fmt == 4 && d->out_fmt == 0 && direct) {
-    int tm2 = 2;               // MAGAT_CONV_TM=1: one 32-agent row group per wave everywhere
-    { const char* e = getenv("MAGAT_CONV_TM"); if (e) tm2 = atoi(e); }
+    const int tm2 = magat_opt(MAGAT_OPT_CONV_TM);     // 1: one 32-agent row group per wave everywhere
     const bool two = tm2 >= 2 && (long long)(p.Mt / 2) * p.npix * p.ntn >= 2048;   // enough 256-agent tiles to fill the chip
     const long long mt = two ? (p.Mt + 1) / 2 : p.Mt;
     const long long g2 = (mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD * p.npix * p.ntn;

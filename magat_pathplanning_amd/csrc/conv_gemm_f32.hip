@@ -328,14 +328,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
   }
 }
 
-int conv_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MAGAT_CONV_VARIANT");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
+int conv_variant() { return magat_opt(MAGAT_OPT_CONV_VARIANT); }
 
 template <int BM, int BN, int WGM, int WGN, bool POOL, bool FULL>
 int launch2(ConvGemmParams& p, hipStream_t st, long long grid) {

@@ -168,8 +168,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 }
 
 int enc_chunk_agents(int M) {
-  const char* env = getenv("MAGAT_ENC_CHUNK");
-  long long c = env ? atoll(env) : 65536;
+  long long c = magat_opt(MAGAT_OPT_ENC_CHUNK);
   if (c < 128) c = 128;
   if (c > M) c = M;
   return (int)c;
@@ -234,8 +233,7 @@ static int conv_first_launch(const float* x, const float* wt, const float* bias,
 // used to be a wash; since the activation split left the barrier section it wins: 351 -> 305 us and 342 -> 264 us);
 // 0 keeps every layer on the fp32 MFMA kernel.
 static int enc_split_mask(const magat_encoder_desc* d) {
-  const char* e = getenv("MAGAT_CONV_SPLIT");          // (read per call: the parity tests flip it)
-  const int v = e ? atoi(e) : 7;
+  const int v = magat_opt(MAGAT_OPT_CONV_SPLIT);
   int m = 0;
   for (int l = 0; l < 3; ++l)
     if ((v >> l & 1) && d->off[18 + 2 * l] > 0 && d->off[19 + 2 * l] > 0) m |= 1 << l;
@@ -245,9 +243,7 @@ static int enc_split_mask(const magat_encoder_desc* d) {
 // Split flavour of those layers: f16x3 (two f16 planes, three v_mfma_f32_32x32x16_f16 per product, in_fmt 4) when the
 // pack carries the f16 weight planes, else bf16x6 (in_fmt 2).  MAGAT_CONV_F16=0 forces bf16x6.
 static bool enc_use_f16(const magat_encoder_desc* d, int l) {
-  const char* e = getenv("MAGAT_CONV_F16");
-  const int v = e ? atoi(e) : 1;
-  return v && d->off[24 + 2 * l] > 0 && d->off[25 + 2 * l] > 0;
+  return magat_opt(MAGAT_OPT_CONV_F16) && d->off[24 + 2 * l] > 0 && d->off[25 + 2 * l] > 0;
 }
 
 // floats per agent of one rotating activation buffer
@@ -335,57 +331,30 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
     return MAGAT_OK;
   }
 
-  // f16-plane activation chain (opt-in, MAGAT_CONV_PLANES=1): activations between layers live in HBM as the two f16 planes
-  // the f16x3 kernel consumes (same bytes as float32, bit-identical results): each value is split ONCE by its producer's
-  // epilogue instead of once per tap and slab by every consumer's loader; the last conv2 writes float32 for the pooled
-  // head.  Measured on MI355X: faster for an isolated layer (l3.conv1 1007 -> 847 us) but ~7 % SLOWER end to end (the
-  // epilogues' 8-byte plane stores and the split there cost more than the loaders save: the split-on-load VALU work is
-  // hidden behind the MFMA drain anyway), so float32 activations stay the default.
-  bool chain = split == (1 << nblocks) - 1;
-  for (int l = 0; l < nblocks; ++l) chain = chain && enc_use_f16(d, l);
-  {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MAGAT_CONV_PLANES"); v = e ? atoi(e) : 0; }
-    chain = chain && v;
-  }
-  // plane layout: [agent tile][plane][pixel][128][c] 16-bit elements - the two planes of a tile sit next to each other
-  // (a tensor-sized plane stride measured 10 % slower: everything a workgroup touches should stay one contiguous run)
-  auto planes = [&](int npix, int c) { return (int64_t)npix * MAGAT_TILE_ROWS * c; };
-  auto ptiles = [&](int npix, int c) { return (int64_t)2 * npix * MAGAT_TILE_ROWS * c; };
   // Granule-major activation tiles ([C/4][128 agents][4], magat_hip.h in_gl/out_gl) between the layers when every
   // BasicBlock conv runs on the f16x3 direct kernel: its one-lane-per-agent fragment loads and epilogue stores are then
   // 512-byte runs.  The last conv2 writes row-major tiles again for the pooled head (fp32 MFMA kernel).
-  bool gl = !chain && split == (1 << nblocks) - 1 && magat_conv_direct_enabled();
+  bool gl = split == (1 << nblocks) - 1 && magat_conv_direct_enabled();
   for (int l = 0; l < nblocks; ++l) gl = gl && enc_use_f16(d, l);
   // ... and, when the pack carries the K-permuted weight copies (off[30]), as f16 PLANE granules (in_gl/out_gl = 2): every
   // activation is split into its two half-precision planes once, by the epilogue that produces it, instead of once per
   // tap by every consumer's loader.  MAGAT_CONV_PCHAIN=0 keeps float32 granules.
   int lay = gl ? 1 : 0;
-  if (gl && d->off[30] != 0) {
-    const char* e = getenv("MAGAT_CONV_PCHAIN");       // (read per call: the parity tests flip it)
-    if (!e || atoi(e)) lay = 2;
-  }
+  if (gl && d->off[30] != 0 && magat_opt(MAGAT_OPT_CONV_PCHAIN)) lay = 2;
   // float offset of the permuted copy behind an f16 weight block of cout x ktot weights (two planes + one scale float,
   // padded to 4 floats)
   auto permuted = [&](int cout, int ktot) { return lay == 2 ? (int64_t)(((int64_t)cout * ktot + 1 + 3) & ~3LL) : 0; };
   // "f16 + MX correction" chain (in_gl / out_gl = 3, third weight copy, off[31]): from block 0's output on, the second
   // activation plane carries e4m3(h1) | e4m3(h2 * 2^11) and the consumers issue two f16 MFMAs + one block-scaled fp8 MFMA per
   // slab instead of six f16 ones.  Block 0's own inputs (fused stem + layer1.conv1 output) stay f16 planes.  MAGAT_CONV_MX.
-  bool mx = false;
-  if (lay == 2 && d->off[31] != 0) {
-    const char* e = getenv("MAGAT_CONV_MX");       // (read per call: the parity tests flip it; 0 = f16x3 everywhere)
-    mx = !e || atoi(e);
-  }
+  // OPT-IN (option CONV_MX, default 0): the fp8 correction planes are narrower arithmetic than the reference's fp32.
+  const bool mx = lay == 2 && d->off[31] != 0 && magat_opt(MAGAT_OPT_CONV_MX) != 0;
   for (int m0 = 0; m0 < M; m0 += mc) {
     const int mm = (M - m0) < mc ? (M - m0) : mc;
     // Plane chain: the stem and layer1.conv1 run as ONE kernel (layer1_fused.hip) - the 121-pixel stem output never
     // reaches HBM; buf[0] receives only its 36 stride-2 pixels, the input of the block's residual 1x1 branch.
     // MAGAT_L1_FUSED=0 keeps the two launches.
-    bool fused1 = lay == 2 && magat_layer1_fused_lds(W) != 0;
-    if (fused1) {
-      const char* e = getenv("MAGAT_L1_FUSED");        // (read per call)
-      fused1 = !e || atoi(e) != 0;
-    }
+    const bool fused1 = lay == 2 && magat_layer1_fused_lds(W) != 0 && magat_opt(MAGAT_OPT_L1_FUSED) != 0;
     int rc;
     if (fused1)
       rc = magat_layer1_fused(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1],
@@ -393,9 +362,7 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
                               static_cast<hipStream_t>(stream));
     else
       rc = conv_first_launch(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W,
-                             (long long)MAGAT_TILE_ROWS * 32,
-                             chain ? (long long)ptiles(H * W, 32) : (long long)H * W * MAGAT_TILE_ROWS * 32, stream,
-                             chain ? planes(H * W, 32) : 0, lay);
+                             (long long)MAGAT_TILE_ROWS * 32, (long long)H * W * MAGAT_TILE_ROWS * 32, stream, 0, lay);
     if (rc != MAGAT_OK) return rc;
     int cur = 0;              // buffer holding the block input
     int hin = H, win = W;
@@ -414,11 +381,6 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       if (split >> l & 1) {      // bf16x6 split-MFMA kernel: float32 activations split by its loader, bf16x3 weights
         if (enc_use_f16(d, l)) { g.in_fmt = 4; g.wt = pk + d->off[24 + 2 * l]; }
         else { g.in_fmt = 2; g.wt = pk + d->off[18 + 2 * l]; }
-        if (chain) {
-          g.in_fmt = 5; g.out_fmt = 3;
-          g.in_plane_stride = planes(hin * win, s.cin); g.out_plane_stride = planes(hout * wout, s.cout);
-          g.in_tile_stride = ptiles(hin * win, s.cin); g.out_tile_stride = ptiles(hout * wout, s.cout);
-        }
       }
       g.in_gl = g.out_gl = lay;
       if (mx && l >= 1) { g.in_gl = g.out_gl = 3; g.wt += 2 * permuted(s.cout, 9 * s.cin); }
@@ -441,13 +403,6 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       if (split >> l & 1) {
         if (enc_use_f16(d, l)) { h.in_fmt = 4; h.wt = pk + d->off[25 + 2 * l]; }
         else { h.in_fmt = 2; h.wt = pk + d->off[19 + 2 * l]; }
-        if (chain) {
-          h.in_fmt = 5; h.out_fmt = l + 1 < nblocks ? 3 : 0;
-          h.in_plane_stride = planes(hout * wout, s.cout); h.in2_plane_stride = planes(hin * win, s.cin);
-          h.out_plane_stride = planes(hout * wout, s.cout);
-          h.in_tile_stride = ptiles(hout * wout, s.cout); h.in2_tile_stride = ptiles(hin * win, s.cin);
-          if (l + 1 < nblocks) h.out_tile_stride = ptiles(hout * wout, s.cout);
-        }
       }
       h.in_gl = lay; h.out_gl = l + 1 < nblocks ? lay : 0;
       if (mx && l + 1 < nblocks) h.out_gl = 3;
@@ -476,8 +431,7 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
     // weight rows (wt_pix_stride / ldw), the partial products land in a free map buffer, a small kernel sums them in
     // a fixed order and adds the bias.  MAGAT_HEAD_SPLITK = largest agent count that takes this form (0 = never).
     const int cells = (hin / 2) * (win / 2);
-    int split_max = 12288;
-    { const char* e = getenv("MAGAT_HEAD_SPLITK"); if (e) split_max = atoi(e); }
+    const int split_max = magat_opt(MAGAT_OPT_HEAD_SPLITK);
     if (cells > 1 && mm <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
         (size_t)cells * d->n_feat <= enc_buf_floats_per_agent(d)) {     // the partials must fit one map buffer
       float* part = buf[(cur + 1) % 3];                 // [cells][mm][n_feat]

@@ -29,6 +29,14 @@
 
 namespace {
 
+// Instrumentation (phase timestamps, phase skipping) exists only in builds made with -DMAGAT_DEBUG_HOOKS
+// (python -m magat_pathplanning_amd.build_native --debug -> lib/libmagat_hip_debug.so); the release library has none of it.
+#ifdef MAGAT_DEBUG_HOOKS
+constexpr bool kDebugHooks = true;
+#else
+constexpr bool kDebugHooks = false;
+#endif
+
 struct GatParams {
   const float* X;   // [B*N, ldx]
   const void* S;    // [B,N,N] f32 or f64
@@ -46,8 +54,6 @@ struct GatParams {
   const unsigned* rmask_pre;     // when set: [B][N][4] edge masks made by gat_prepare_kernel (the kernel then never reads S)
   long long zts;                 // 0: Z rows are NC wide; > 0: Z is split into 128-column tiles zts floats apart (row stride 128):
                                  // an instance's [N][128] tile is one contiguous run (written so by the maps GEMM)
-  const int* over;               // when set: only instances with over[bl] != 0 are processed here (the rest were
-                                 // handled by the list kernel, gat_list_f32.hip)
   float* Ymean;                  // fused head-mean (mean merge, hpb == P): final output [B*N, ldym]; Y is unused then
   int ldym;
   int hpb;                       // heads per workgroup (1, or P: the workgroup walks all heads of its instance and
@@ -109,7 +115,8 @@ __global__ void gat_dense_kernel(const GatParams p) {
   const bool keyquery = p.mode == MAGAT_MODE_KEYQUERY;
   const bool need_att = K > 1 || p.A_opt;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  long long* dbg = p.dbg ? p.dbg + (long long)bid * 8 : nullptr;
+  long long* dbg = (kDebugHooks && p.dbg) ? p.dbg + (long long)bid * 8 : nullptr;
+  const int skip = kDebugHooks ? p.skip : 0;
   if (dbg && t == 0) dbg[0] = clock64();
   // Z addressing: row n, column col of the current instance = Zb + n * zrow + zcol(col)
   const int zrow = p.zts ? 128 : p.NC;
@@ -187,7 +194,6 @@ __global__ void gat_dense_kernel(const GatParams p) {
   for (int h = 0; h < HMAX; ++h) ysum[h] = zerov;
   for (int sl_ = bl0; sl_ < p.B; sl_ += istride) {  // ---- instance slots of this workgroup
   const int bl = p.order ? p.order[sl_] : sl_;       // (balanced walk: slots -> instances dealt out by edge count)
-  if (p.over && !p.over[bl]) continue;               // (host never combines the list path with istride < B)
   const int b = p.b0 + bl;
   int ti = threadIdx.x;              // laundered per instance (see the note at the head loop)
   asm volatile("" : "+v"(ti));
@@ -324,7 +330,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
     // Q tile (prefetched during the previous head's last hop, or above) is in Rq once every wave's loads are done
     // (waited for at the end of that hop; only a workgroup's very first head waits here); the barrier also retires
     // the previous head's reads of Ru and A
-    if (first_head || p.skip) tiles_landed();
+    if (first_head || skip) tiles_landed();
     else __syncthreads();
     if ((hh > 0 || sl_ != bl0) && keyquery && need_att && K > 1)
       dma_tile(Ru, Zb, p.uoff + (head * K + (K - 1)) * F, tl);
@@ -350,7 +356,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
   // WIDE (G >= 64): a 16-lane row of the wave owns one graph row (4 rows per wave step); its lanes walk the
   // row's edge bitmask, each edge costing CPL ds_read_b128 + 4*CPL FMA + 4 DPP adds; the masked softmax then
   // runs with lane = neighbour slot (8 slots per lane), reductions again on DPP.  No ds_bpermute anywhere.
-  if (need_att && !(p.skip & 1)) {
+  if (need_att && !(skip & 1)) {
     if constexpr (WIDE) {
       const int es = es8, eg = eg8, par = par8;
       for (int ib = 8 * wave; ib < N; ib += 8 * nwaves) {
@@ -667,7 +673,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
       }
     }
   };
-  if (!(p.skip & 2)) {
+  if (!(skip & 2)) {
     for (int k = K - 2; k >= 1; --k) {      // all hops but the last
       int tk = threadIdx.x;      // laundered per hop: load addresses are computed at the point of use
       asm volatile("" : "+v"(tk));
@@ -835,8 +841,7 @@ int gat_block_threads(int N) {
 // (c3, B=512): one big launch beats Infinity-Cache-sized chunks (2.02 TB/s vs 1.85 @96 MB vs 1.23 @32 MB),
 // so the cap only limits workspace (default 2 GiB).
 int gat_chunk_instances(int B, int N, int NC) {
-  const char* env = getenv("MAGAT_GAT_CHUNK_MB");
-  const double mb = env ? atof(env) : 2048.0;
+  const double mb = (double)magat_opt(MAGAT_OPT_GAT_CHUNK_MB);
   long long per = (long long)N * NC * 4;
   long long c = (long long)(mb * 1048576.0) / (per > 0 ? per : 1);
   if (c < 8) c = 8;
@@ -846,13 +851,10 @@ int gat_chunk_instances(int B, int N, int NC) {
 
 template <int G, int F>
 int launch_gat(const GatParams& p, int blocks, int threads, size_t lds, hipStream_t st) {
-  static size_t configured = 0;
-  if (lds > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gat_dense_kernel<G, F>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return MAGAT_ERR_LAUNCH;
-    configured = lds;
-  }
+  constexpr int slot = G == 16 ? MAGAT_LDS_GAT16 : G == 32 ? MAGAT_LDS_GAT32 : G == 64 ? MAGAT_LDS_GAT64
+                      : G == 128 ? MAGAT_LDS_GAT128 : MAGAT_LDS_GAT256;
+  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&gat_dense_kernel<G, F>), slot, lds) != MAGAT_OK)
+    return MAGAT_ERR_LAUNCH;
   const int pid = magat_prof_begin(MAGAT_TAG_GAT_GRAPH, st);
   hipLaunchKernelGGL((gat_dense_kernel<G, F>), dim3(blocks), dim3(threads), lds, st, p);
   magat_prof_end(pid, st);
@@ -864,9 +866,14 @@ int launch_gat(const GatParams& p, int blocks, int threads, size_t lds, hipStrea
 // Instrumentation only: device buffer of [grid][8] int64 receiving per-workgroup phase timestamps
 // (clock64 at entry / after staging / after scores / after each hop / exit, wall_clock64 at exit).
 extern "C" int magat_gat_set_debug_buffer(long long* dev_buf) {
+  if (!kDebugHooks) return dev_buf ? MAGAT_ERR_UNSUPPORTED : MAGAT_OK;      // release build: no instrumentation
   g_gat_dbg = dev_buf;
   return MAGAT_OK;
 }
+#ifdef MAGAT_DEBUG_HOOKS
+static int g_gat_skip = 0;
+extern "C" int magat_gat_set_debug_skip(int mask) { g_gat_skip = mask; return MAGAT_OK; }
+#endif
 
 extern "C" size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode) {
   if (G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
@@ -879,24 +886,13 @@ extern "C" size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode) 
 // benchmark shapes (2048 -> 8 KB rows): the tiles a workgroup reads are 512-byte row pieces exactly 8 KB apart, which
 // all land in the same HBM channels; a 128-byte skew per row spreads them.
 static int gat_zpad() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MAGAT_GAT_ZPAD");
-    v = e ? atoi(e) : 32;
-    if (v < 0 || (v & 3)) v = 0;
-  }
-  return v;
+  const int v = magat_opt(MAGAT_OPT_GAT_ZPAD);
+  return (v < 0 || (v & 3)) ? 0 : v;
 }
 int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, int G, int NC, int ldz, void* stream,
                         long long ntile_stride) {
-  static int use_split = -1;
-  if (use_split < 0) {
-    const char* e = getenv("MAGAT_GAT_SPLIT");
-    use_split = e ? atoi(e) : 1;
-  }
-  if (use_split && NC % 32 == 0 && G % 32 == 0) {
-    const char* ef = getenv("MAGAT_CONV_F16");
-    const int use_f16 = ef ? atoi(ef) : 1;
+  if (magat_opt(MAGAT_OPT_GAT_SPLIT) && NC % 32 == 0 && G % 32 == 0) {
+    const int use_f16 = magat_opt(MAGAT_OPT_CONV_F16);
     magat_conv_gemm_desc d = {};
     d.in = X;
     d.wt = use_f16 ? packed + magat_gat_f16_block_offset(NC, G) : packed + (((size_t)NC * (G + 1) + 3) & ~(size_t)3);
@@ -933,15 +929,6 @@ extern "C" int magat_gat_pack_weights(const float* weight, const float* weight_b
 extern "C" int magat_gat_dense_supported(int N, int G, int F) {
   if (N <= 0 || N > 128 || G != F || !supported_width(G)) return 0;
   return gat_lds_bytes(N, G, F, gat_block_threads(N) / 64) <= 160 * 1024 ? 1 : 0;
-}
-
-bool gat_list_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MAGAT_GAT_LIST");
-    v = e ? atoi(e) : 0;     // opt-in: see the status note in gat_list_f32.hip
-  }
-  return v != 0;
 }
 
 // ---- GSO plan (magat_gat_gso_plan): edge masks, edge counts, balanced instance walk for the persistent kernel ----------
@@ -1077,7 +1064,6 @@ extern "C" size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, i
   const int chunk = gat_chunk_instances(B, N, ldz);
   size_t bytes = magat_align_up((size_t)chunk * N * ldz * sizeof(float), 256);
   if (!concat) bytes += magat_align_up((size_t)B * N * P * F * sizeof(float), 256);
-  bytes += magat_gat_list_workspace_bytes(chunk, N, G, F);
   return bytes;
 }
 
@@ -1105,57 +1091,40 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
   float* Z = static_cast<float*>(workspace);
   float* Ytmp = reinterpret_cast<float*>(static_cast<char*>(workspace) +
                                          magat_align_up((size_t)chunk * N * ldz * sizeof(float), 256));
-  char* list_ws = reinterpret_cast<char*>(Ytmp) + (concat ? 0 : magat_align_up((size_t)B * N * P * F * sizeof(float), 256));
-  const bool use_list = gat_list_enabled() && mode != MAGAT_MODE_GAT_ORIGIN && magat_gat_list_capacity(N, G, F) > 0;
   GatParams p;
-  p.over = nullptr;
   p.order = nullptr;
   p.rmask_pre = nullptr;
   p.dbg = g_gat_dbg;
-  { static int sk = -1; if (sk < 0) { const char* e = getenv("MAGAT_GAT_SKIP"); sk = e ? atoi(e) : 0; } p.skip = sk; }
+  p.skip = 0;
+#ifdef MAGAT_DEBUG_HOOKS
+  p.skip = g_gat_skip;
+#endif
   p.X = X; p.S = S; p.Z = Z; p.bias = bias; p.A_opt = A_opt;
   p.Y = concat ? Y : Ytmp;
   p.N = N; p.K = K; p.P = P; p.mode = mode; p.concat = concat; p.s_is_f64 = s_is_f64;
   p.ldx = G; p.ldy = concat ? ldy : P * F; p.NC = ldz; p.lda_a = N | 1;
   p.qoff = L.qoff; p.uoff = L.uoff; p.c1off = L.c1off; p.c2off = L.c2off;
 
-  static int hpb_env = -1;
-  if (hpb_env < 0) { const char* e = getenv("MAGAT_GAT_HPB"); hpb_env = e ? atoi(e) : 0; }
+  const int hpb_env = magat_opt(MAGAT_OPT_GAT_HPB);
   auto hpb_for = [&](int cb) {
     int h = 1;
     if (G >= 64 && P > 1 && lds > 80 * 1024 && cb >= 256) h = P;
     if (hpb_env > 0 && G >= 64 && P % hpb_env == 0) h = hpb_env;
     return h;
   };
-  bool all_fused = !concat && G >= 64 && !use_list;
+  bool all_fused = !concat && G >= 64;
   for (int b0 = 0; b0 < B && all_fused; b0 += chunk) all_fused = hpb_for((B - b0) < chunk ? (B - b0) : chunk) == P;
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int cb = (B - b0) < chunk ? (B - b0) : chunk;
     // Z in 128-column tiles ([tile][cb * N][128]: an instance's Q_p / U_pk tile is ONE contiguous N x 128 run for the
     // LDS-direct loads, and every workgroup of the maps GEMM writes one contiguous region) when the dense kernel with
     // 128-wide features consumes it and the f16x3 direct GEMM produces it; MAGAT_GAT_ZTILES=0 keeps NC-wide rows.
-    bool ztiles = G == 128 && F == 128 && L.NC % 128 == 0 && !use_list && magat_conv_direct_enabled();
-    {
-      const char* e = getenv("MAGAT_GAT_ZTILES");
-      if (e && !atoi(e)) ztiles = false;
-      const char* es = getenv("MAGAT_GAT_SPLIT");
-      const char* ef = getenv("MAGAT_CONV_F16");
-      if ((es && !atoi(es)) || (ef && !atoi(ef))) ztiles = false;
-    }
+    const bool ztiles = G == 128 && F == 128 && L.NC % 128 == 0 && magat_conv_direct_enabled() &&
+                        magat_opt(MAGAT_OPT_GAT_ZTILES) && magat_opt(MAGAT_OPT_GAT_SPLIT) && magat_opt(MAGAT_OPT_CONV_F16);
     p.zts = ztiles ? (long long)cb * N * 128 : 0;
     int rc = magat_gat_maps_gemm(X + (size_t)b0 * N * G, packed, Z, cb * N, G, L.NC, ldz, stream, p.zts);
     if (rc != MAGAT_OK) return rc;
     p.B = cb; p.b0 = b0;
-    if (use_list) {     // sparse instances: structure pass + list kernel; dense ones stay flagged for the kernel below
-      if (A_opt &&
-          hipMemsetAsync(A_opt + (size_t)b0 * P * N * N, 0, (size_t)cb * P * N * N * sizeof(float), st) != hipSuccess)
-        return MAGAT_ERR_LAUNCH;
-      int* over = nullptr;
-      rc = magat_gat_list_run(X, S, s_is_f64, Z, bias, p.Y, p.ldy, A_opt, list_ws, cb, b0, N, G, K, P, mode, concat,
-                              ldz, L.qoff, L.uoff, L.c1off, L.c2off, &over, st);
-      if (rc != MAGAT_OK) return rc;
-      p.over = over;
-    }
     // heads per workgroup: when the LDS tiles allow only one workgroup per CU there is nothing to overlap a
     // workgroup's loads with, so one workgroup walks all P heads of its instance and prefetches the next head's
     // Q tile during the current head's compute; needs enough instances to fill the chip.
@@ -1168,13 +1137,11 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     // with one workgroup per CU (hpb == P case) the grid is capped at one workgroup per CU and every workgroup walks
     // several instances, prefetching across the instance boundary as well
     int inst_slots = (cb + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD;
-    static int persist_env = -1;
-    if (persist_env < 0) { const char* e = getenv("MAGAT_GAT_PERSIST"); persist_env = e ? atoi(e) : 1; }
-    if (persist_env && hpb == P && hpb > 1 && !use_list && inst_slots > GAT_PLAN_WALKERS) inst_slots = GAT_PLAN_WALKERS;
+    if (magat_opt(MAGAT_OPT_GAT_PERSIST) && hpb == P && hpb > 1 && inst_slots > GAT_PLAN_WALKERS) inst_slots = GAT_PLAN_WALKERS;
     const int blocks = inst_slots * (P / hpb);
     p.order = nullptr;
     p.rmask_pre = nullptr;
-    if (plan && cb == B && !use_list && G >= 64 && N <= 128) {     // made by magat_gat_gso_plan for this S
+    if (plan && cb == B && G >= 64 && N <= 128) {     // made by magat_gat_gso_plan for this S
       const char* base = static_cast<const char*>(plan);
       p.rmask_pre = reinterpret_cast<const unsigned*>(base);
       if (inst_slots == GAT_PLAN_WALKERS && inst_slots < cb)

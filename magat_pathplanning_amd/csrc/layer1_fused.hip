@@ -333,13 +333,8 @@ int magat_layer1_fused(const float* x, const float* w0, const float* b0, const f
   if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
   const size_t lds = magat_layer1_fused_lds(W);                     // 129.6 KB at W = 11: one 8-wave workgroup per CU
   if (lds == 0) return MAGAT_ERR_UNSUPPORTED;
-  static size_t attr_lds = 0;
-  if (attr_lds < lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&layer1_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return MAGAT_ERR_LAUNCH;
-    attr_lds = lds;
-  }
+  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&layer1_fused_kernel), MAGAT_LDS_L1FUSED, lds) != MAGAT_OK)
+    return MAGAT_ERR_LAUNCH;
   const int pid = magat_prof_begin(MAGAT_TAG_CONV_FIRST, st);
   hipLaunchKernelGGL(layer1_fused_kernel, dim3((unsigned)grid), dim3(512), lds, st, p);
   magat_prof_end(pid, st);

@@ -26,9 +26,26 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st);
 int magat_layer1_fused(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, void* out,
                        void* ctr, int M, int H, int W, hipStream_t st);   // layer1_fused.hip
 size_t magat_layer1_fused_lds(int W);   // 0: the fused kernel does not take this map width
-int magat_conv_gemm_f16x3_pair(const magat_conv_gemm_desc* d, hipStream_t st);   // conv_gemm_f16x3_pair.hip
-int magat_conv_gemm_f16x3_duo(const magat_conv_gemm_desc* d, hipStream_t st);    // conv_gemm_f16x3_duo.hip
-int magat_conv_direct_enabled();   // f16x3 direct kernel on (MAGAT_CONV_DIRECT, default 1)
+int magat_conv_direct_enabled();   // f16x3 direct kernel on (option CONV_DIRECT, default 1)
+
+// Library options (options.hip): read from the environment (MAGAT_<NAME>) ONCE, changed at run time through
+// magat_set_option - nothing on the launch path calls getenv.
+enum MagatOpt {
+  MAGAT_OPT_CONV_DIRECT, MAGAT_OPT_CONV_KORDER, MAGAT_OPT_CONV_TEPI, MAGAT_OPT_CONV_TM, MAGAT_OPT_CONV_VARIANT,
+  MAGAT_OPT_ENC_CHUNK, MAGAT_OPT_CONV_SPLIT, MAGAT_OPT_CONV_F16, MAGAT_OPT_CONV_PCHAIN, MAGAT_OPT_CONV_MX,
+  MAGAT_OPT_L1_FUSED, MAGAT_OPT_HEAD_SPLITK, MAGAT_OPT_GAT_CHUNK_MB, MAGAT_OPT_GAT_ZPAD, MAGAT_OPT_GAT_SPLIT,
+  MAGAT_OPT_GAT_HPB, MAGAT_OPT_GAT_ZTILES, MAGAT_OPT_GAT_PERSIST, MAGAT_OPT_RANGE_GUARD, MAGAT_OPT_BLOCK_FUSED,
+  MAGAT_OPT_GAT_FUSED_MAPS, MAGAT_OPT_COUNT
+};
+int magat_opt(int id);
+// hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)
+#define MAGAT_LDS_SLOTS 32
+int magat_ensure_dyn_lds(const void* func, int slot, size_t bytes);
+enum MagatLdsSlot {
+  MAGAT_LDS_GAT16, MAGAT_LDS_GAT32, MAGAT_LDS_GAT64, MAGAT_LDS_GAT128, MAGAT_LDS_GAT256, MAGAT_LDS_L1FUSED,
+  MAGAT_LDS_SIM_GSO_T, MAGAT_LDS_SIM_GSO_F, MAGAT_LDS_SIM_MOVE, MAGAT_LDS_BLOCK_A, MAGAT_LDS_BLOCK_B, MAGAT_LDS_BLOCK_C,
+  MAGAT_LDS_GATF128, MAGAT_LDS_SIM_CONN
+};
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of
 // Bt * 2^8: 2*NC*G u16][float 2^-8][pad]: float offset of the f16 block
@@ -49,13 +66,6 @@ __device__ __forceinline__ unsigned short magat_bf16_rne(float v) {
   return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float magat_bf16_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
-
-// sparse-structure GAT kernel (gat_list_f32.hip), driven by magat_gat_forward_packed_f32
-int magat_gat_list_capacity(int N, int G, int F);
-size_t magat_gat_list_workspace_bytes(int B, int N, int G, int F);
-int magat_gat_list_run(const float* X, const void* S, int s_is_f64, const float* Z, const float* bias, float* Y,
-                       int ldy, float* A_opt, void* ws, int B, int b0, int N, int G, int K, int P, int mode,
-                       int concat, int NC, int qoff, int uoff, int c1off, int c2off, int** over_out, hipStream_t st);
 
 static inline int magat_check_launch() {
   return hipGetLastError() == hipSuccess ? MAGAT_OK : MAGAT_ERR_LAUNCH;

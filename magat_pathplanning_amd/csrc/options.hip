@@ -1,0 +1,117 @@
+// Library options: every tunable of libmagat_hip.so lives in ONE table that is filled from the environment once (first
+// use) and can be changed at run time through the C ABI (magat_set_option) - the launch path never calls getenv.
+// Also: the per-device cache of kernel attributes (hipFuncSetAttribute is per device) and the encoder status word.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "magat_common.h"
+
+namespace {
+
+struct OptEntry {
+  const char* name;
+  int def;
+};
+
+// order = enum MagatOpt (magat_common.h)
+const OptEntry kOpts[MAGAT_OPT_COUNT] = {
+    {"CONV_DIRECT", 1},      // f16x3 convolutions on the register-direct kernel (0: 2x2 LDS-staged kernel)
+    {"CONV_KORDER", 1},      // direct kernel K walk: 1 = channel slab outer, taps inner
+    {"CONV_TEPI", 1},        // direct kernel: row-major float32 output transposed through LDS
+    {"CONV_TM", 2},          // direct kernel: 32-agent row groups per wave (2 = 256-agent tiles when the chip fills)
+    {"CONV_VARIANT", 0},     // fp32 MFMA kernel variant (9 = double-buffered form)
+    {"ENC_CHUNK", 65536},    // agents per encoder pass (workspace bound)
+    {"CONV_SPLIT", 7},       // bit l: BasicBlock l+1 on the split-MFMA kernels (0 = fp32 MFMA everywhere)
+    {"CONV_F16", 1},         // split flavour: 1 = f16x3, 0 = bf16x6
+    {"CONV_PCHAIN", 1},      // f16 plane-granule activation chain between the BasicBlock convolutions
+    {"CONV_MX", 0},          // OPT-IN: layer2/layer3 correction products in block-scaled fp8 (narrower than fp32-class)
+    {"L1_FUSED", 1},         // stem + layer1.conv1 as one kernel
+    {"HEAD_SPLITK", 12288},  // largest agent count for which the encoder head splits K by pooled cell
+    {"GAT_CHUNK_MB", 2048},  // cap of the hoisted-map intermediate Z
+    {"GAT_ZPAD", 32},        // row skew of Z (floats)
+    {"GAT_SPLIT", 1},        // GAT maps on the split-MFMA GEMM
+    {"GAT_HPB", 0},          // heads per workgroup override (0 = automatic)
+    {"GAT_ZTILES", 1},       // Z in 128-column tiles
+    {"GAT_PERSIST", 1},      // persistent graph-kernel workgroups
+    {"RANGE_GUARD", 1},      // split-arithmetic range guard: overflow flag + stream-ordered fp32 re-run of the encoder
+    {"BLOCK_FUSED", 1},      // BasicBlock chain kernel (conv1 -> conv2 (+downsample) with the 6x6 maps in LDS)
+    {"GAT_FUSED_MAPS", 1},   // hoisted maps computed inside the graph kernel (Z never crosses HBM)
+};
+
+int g_val[MAGAT_OPT_COUNT];
+std::once_flag g_once;
+
+void init_opts() {
+  for (int i = 0; i < MAGAT_OPT_COUNT; ++i) {
+    g_val[i] = kOpts[i].def;
+    char key[64] = "MAGAT_";
+    strncat(key, kOpts[i].name, sizeof(key) - 7);
+    const char* e = getenv(key);
+    if (e && *e) g_val[i] = atoi(e);
+  }
+}
+
+}  // namespace
+
+int magat_opt(int id) {
+  std::call_once(g_once, init_opts);
+  return (id >= 0 && id < MAGAT_OPT_COUNT) ? g_val[id] : 0;
+}
+
+extern "C" int magat_set_option(const char* name, int value) {
+  if (!name) return MAGAT_ERR_NULL;
+  std::call_once(g_once, init_opts);
+  if (!strncmp(name, "MAGAT_", 6)) name += 6;
+  for (int i = 0; i < MAGAT_OPT_COUNT; ++i)
+    if (!strcmp(name, kOpts[i].name)) {
+      g_val[i] = value;
+      return MAGAT_OK;
+    }
+  return MAGAT_ERR_UNSUPPORTED;
+}
+
+extern "C" int magat_get_option(const char* name, int* value) {
+  if (!name || !value) return MAGAT_ERR_NULL;
+  std::call_once(g_once, init_opts);
+  if (!strncmp(name, "MAGAT_", 6)) name += 6;
+  for (int i = 0; i < MAGAT_OPT_COUNT; ++i)
+    if (!strcmp(name, kOpts[i].name)) {
+      *value = g_val[i];
+      return MAGAT_OK;
+    }
+  return MAGAT_ERR_UNSUPPORTED;
+}
+
+extern "C" int magat_reset_option(const char* name) {
+  if (!name) return MAGAT_ERR_NULL;
+  std::call_once(g_once, init_opts);
+  if (!strncmp(name, "MAGAT_", 6)) name += 6;
+  for (int i = 0; i < MAGAT_OPT_COUNT; ++i)
+    if (!strcmp(name, kOpts[i].name)) {
+      g_val[i] = kOpts[i].def;
+      return MAGAT_OK;
+    }
+  return MAGAT_ERR_UNSUPPORTED;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember, per (kernel slot, device), the
+// largest size configured so far.  `slot` is a small integer the caller owns (one per kernel instantiation).
+int magat_ensure_dyn_lds(const void* func, int slot, size_t bytes) {
+  constexpr int kMaxDev = 16;
+  static std::atomic<size_t> configured[MAGAT_LDS_SLOTS][kMaxDev];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return MAGAT_ERR_LAUNCH;
+  if (slot < 0 || slot >= MAGAT_LDS_SLOTS || dev < 0 || dev >= kMaxDev) {
+    return hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess
+               ? MAGAT_OK : MAGAT_ERR_LAUNCH;
+  }
+  if (bytes <= configured[slot][dev].load(std::memory_order_acquire)) return MAGAT_OK;
+  if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+    return MAGAT_ERR_LAUNCH;
+  size_t cur = configured[slot][dev].load(std::memory_order_relaxed);
+  while (cur < bytes && !configured[slot][dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {
+  }
+  return MAGAT_OK;
+}

@@ -401,11 +401,12 @@ extern "C" int magat_sim_gso(const int32_t* pos, double comm_radius, int symmetr
   const size_t lds = gso_lds_bytes(N, mask);
   if (lds > 160 * 1024) return MAGAT_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (lds > 64 * 1024 &&
+      magat_ensure_dyn_lds(mask ? reinterpret_cast<const void*>(&gso_kernel<true>)
+                                : reinterpret_cast<const void*>(&gso_kernel<false>),
+                           mask ? MAGAT_LDS_SIM_GSO_T : MAGAT_LDS_SIM_GSO_F, lds) != MAGAT_OK)
+    return MAGAT_ERR_LAUNCH;
   if (mask) {
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gso_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return MAGAT_ERR_LAUNCH;
     hipLaunchKernelGGL(gso_kernel<true>, dim3(B), dim3(SIM_THREADS), lds, st, pos, comm_radius, symmetric_norm, normalize,
                        S, s_is_f64, lambda_out, N);
   } else {
@@ -434,8 +435,7 @@ extern "C" int magat_sim_move(const float* logits, const int32_t* actions_in, co
   const size_t lds = (size_t)H * W * sizeof(unsigned) + (size_t)4 * N * sizeof(int);
   if (lds > 160 * 1024) return MAGAT_ERR_UNSUPPORTED;
   if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&sim_move_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds) != hipSuccess)
+      magat_ensure_dyn_lds(reinterpret_cast<const void*>(&sim_move_kernel), MAGAT_LDS_SIM_MOVE, lds) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
   int threads = 64;
   while (threads < N && threads < 1024) threads *= 2;

@@ -22,9 +22,14 @@ def sharded_forward(model, x, S, group=None, gather=True):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B, N = x.shape[0], x.shape[1]
     b0, b1 = shard_range(B, rank, world)
-    Sl = S[b0:b1].contiguous()
-    model.addGSO(Sl)
-    local = model(x[b0:b1])
+    if b1 > b0:
+        Sl = S[b0:b1].contiguous()
+        model.addGSO(Sl)
+        local = model(x[b0:b1])
+    else:
+        # fewer instances than ranks: this rank owns nothing, but it still has to enter the all_gather below (a rank that
+        # raised on its empty batch would leave the others blocked in the collective)
+        local = torch.zeros(0, 5, dtype=torch.float32, device=x.device)
     if not gather or world == 1:
         return local
     cap = (B + world - 1) // world * N

@@ -5,10 +5,14 @@ agents/decentralplannerlocal_OnlineExpert_GAT.py:66-83 selects the file).
 
 Same constructor (config object), addGSO(S), forward(x) -> (B*N, 5) logits and state_dict layout.
 Inference (eval / no_grad) runs entirely on the gfx950 kernels behind include/magat_hip.h:
-  ConvLayers + compressMLP  -> magat_encoder_forward_f32   (fp32 MFMA implicit GEMMs, BN folded)
-  GFL                       -> magat_gat_forward_packed_f32 (hoisted MFMA GEMM + LDS/wave-softmax kernel)
+  ConvLayers + compressMLP  -> magat_encoder_forward_f32   (BN folded; fp32-class f16x3 split products on the 16-bit
+                               matrix cores with fp32 accumulation, LDS-resident BasicBlock chains, range-guarded with a
+                               stream-ordered fp32-MFMA re-run; the pooled head and compressMLP on fp32 MFMA)
+  GFL                       -> magat_gat_forward_packed_f32 (per-agent maps on MFMA + LDS / wave-softmax graph kernel; CSR
+                               kernels for N > 128 or bf16 storage)
   actionsMLP (+skip inputs) -> magat_conv_gemm_f32          (skip source as second K segment)
-Training (autograd on) evaluates the same modules with torch ops (backward is SURVEY 8(f) row 1).
+Training (autograd on): the graph layer's forward AND backward run on HIP kernels (graphml._GatTrainFunction,
+_GnnTrainFunction); the CNN / MLP parameter containers train through torch autograd.
 """
 import ctypes
 import os
@@ -120,6 +124,12 @@ class DecentralPlannerGATNet(nn.Module):
 
         width = self.F[-1] * config.nAttentionHeads if config.AttentionConcat else self.F[-1]
         self.gat_width = width
+        if self.skip == "skipAddGNN" and width != bottleneck:
+            # the reference's torch.add of (B*N, G) and (B*N, P*F) raises at the first forward
+            # (decentralplanner_GAT_bottleneck_SkipAddGNN.py:303-307); say so at construction instead of reading the
+            # actionsMLP weights with the wrong K split
+            raise RuntimeError("BottomNeck_skipAddGNN adds the %d-wide bottleneck feature to the %d-wide graph-layer output: "
+                               "needs AttentionConcat=False or nAttentionHeads=1" % (bottleneck, width))
         if self.skip == "skipConcat":
             width += numFeatureMap
         elif self.skip == "skipConcatGNN":

@@ -45,3 +45,33 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+class _LibOpt:
+    """Library options (magat_set_option) changed for one test and restored afterwards - the library reads the
+    environment only once, so tests flip its switches through the C ABI."""
+
+    def __init__(self):
+        from magat_pathplanning_amd import _native
+        self.nat = _native
+        self.touched = set()
+
+    def set(self, name, value):
+        self.nat.set_option(name, int(value))
+        self.touched.add(name)
+
+    def reset(self, name):
+        self.nat.reset_option(name)
+        self.touched.discard(name)
+
+    def restore(self):
+        for n in list(self.touched):
+            self.nat.reset_option(n)
+        self.touched.clear()
+
+
+@pytest.fixture
+def libopt():
+    o = _LibOpt()
+    yield o
+    o.restore()

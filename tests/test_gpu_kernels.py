@@ -559,7 +559,7 @@ def test_conv_gemm_f16x3_split_mfma_matches_fp64(gpu_device, cin, cout, c2, M, s
 
 
 
-def test_conv_gemm_f16_plane_formats(gpu_device, monkeypatch):
+def test_conv_gemm_f16_plane_formats(gpu_device, monkeypatch, libopt):
     """in_fmt 5 (activations already as two f16 planes) gives bit-identical results to in_fmt 4 (split on load), and
     out_fmt 3 (epilogue writes the two planes) reproduces the float32 output to 2^-22."""
     from magat_pathplanning_amd.encoder import split_f16x2
@@ -576,7 +576,7 @@ def test_conv_gemm_f16_plane_formats(gpu_device, monkeypatch):
     outs = {}
     # (4, 0) runs on the direct kernel, whose default K walk is channel-slab-major; the tap-major walk of the LDS-staged
     # kernel (the other two cases) gives bit-identical sums only in the same order
-    monkeypatch.setenv("MAGAT_CONV_KORDER", "0")
+    libopt.set("MAGAT_CONV_KORDER", "0")
     for in_fmt, out_fmt in ((4, 0), (5, 0), (4, 3)):
         d = nat.ConvGemmDesc()
         src = planes if in_fmt == 5 else xp
@@ -598,13 +598,13 @@ def test_conv_gemm_f16_plane_formats(gpu_device, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("korder", [0, 1])
-def test_conv_gemm_f16x3_granule_layouts(gpu_device, monkeypatch, korder):
+def test_conv_gemm_f16x3_granule_layouts(gpu_device, monkeypatch, korder, libopt):
     """Direct f16x3 kernel: float32 granule-major tiles (in_gl/out_gl = 1) are bit-identical to row-major tiles; f16
     plane granules (in_gl/out_gl = 2, K-permuted weights) agree to the rounding of the two output planes and of the
     MFMA's internal sum order.  Residual 1x1 segment (in2), ragged M (partial last agent tile), both K walks."""
     from magat_pathplanning_amd.encoder import split_f16x2
     nat, lib = _nat()
-    monkeypatch.setenv("MAGAT_CONV_KORDER", str(korder))
+    libopt.set("MAGAT_CONV_KORDER", str(korder))
     M, cin, cout, c2, npix = 300, 64, 128, 32, 36
     Mp = (M + 127) // 128 * 128
     g = torch.Generator().manual_seed(11)
@@ -679,10 +679,10 @@ def test_conv_gemm_f16x3_granule_layouts(gpu_device, monkeypatch, korder):
 
 
 @pytest.mark.gpu
-def test_conv_gemm_f16x3_direct_256_agent_tiles_ragged(gpu_device, monkeypatch):
+def test_conv_gemm_f16x3_direct_256_agent_tiles_ragged(gpu_device, monkeypatch, libopt):
     """The 256-agent-tile form of the direct kernel (TM = 2, taken when the grid is large) on a ragged agent count
     (14700 = 57 full tiles + 108 agents) is bit-identical to the 128-agent form, for float32 granules and f16 plane
-    granules, row-major and granule outputs; so are the opt-in pair / duo kernels."""
+    granules, row-major and granule outputs."""
     from magat_pathplanning_amd.encoder import split_f16x2
     nat, lib = _nat()
     M, cin, cout, c2, npix = 14700, 32, 128, 32, 36
@@ -710,9 +710,9 @@ def test_conv_gemm_f16x3_direct_256_agent_tiles_ragged(gpu_device, monkeypatch):
     xi, x2i = to_pl(x), to_pl(x2)
     outs = {}
     for out_gl in (0, 2):
-        for env in ({"MAGAT_CONV_TM": "1"}, {}, {"MAGAT_CONV_PAIR": "1"}, {"MAGAT_CONV_DUO": "1"}):
+        for env in ({"MAGAT_CONV_TM": "1"}, {}):
             for k, v in env.items():
-                monkeypatch.setenv(k, v)
+                libopt.set(k, v)
             out = torch.full((npix, Mp, cout), 7.0, device=gpu_device)
             d = nat.ConvGemmDesc()
             d.inp, d.in2, d.wt, d.bias, d.out = xi.data_ptr(), x2i.data_ptr(), wsp.data_ptr(), bd.data_ptr(), out.data_ptr()
@@ -723,7 +723,7 @@ def test_conv_gemm_f16x3_direct_256_agent_tiles_ragged(gpu_device, monkeypatch):
             nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "direct kernel %s" % env)
             torch.cuda.synchronize()
             for k in env:
-                monkeypatch.delenv(k)
+                libopt.reset(k)
             outs[(out_gl, tuple(env))] = out
         ref = outs[(out_gl, ("MAGAT_CONV_TM",))]
         assert not torch.isnan(ref[:, :M]).any()

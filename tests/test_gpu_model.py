@@ -88,7 +88,7 @@ def test_shard_equivalence_and_pickle(gpu_device):
         assert torch.equal(clone(x), full)
 
 
-def test_shard_equivalence_across_the_head_split(gpu_device, monkeypatch):
+def test_shard_equivalence_across_the_head_split(gpu_device, monkeypatch, libopt):
     """The one size-dependent piece of arithmetic is the encoder head: below MAGAT_HEAD_SPLITK agents (12288) it sums nine
     per-cell partial products, above it runs one long-K GEMM.  A batch above the threshold cut into shards below it
     therefore agrees to float32 rounding (1e-5 here, the gate is 1e-4), and bit-for-bit once both sides are pinned to
@@ -113,7 +113,7 @@ def test_shard_equivalence_across_the_head_split(gpu_device, monkeypatch):
         return full, torch.cat((a, b))
     full, parts = run()
     assert (full - parts).abs().max().item() <= 1e-5
-    monkeypatch.setenv("MAGAT_HEAD_SPLITK", "0")
+    libopt.set("MAGAT_HEAD_SPLITK", "0")
     full0, parts0 = run()
     assert torch.equal(full0, parts0)
     assert torch.equal(full0, full)                   # above the threshold the default already is the one-GEMM form
@@ -213,7 +213,7 @@ def test_model_bf16_gat_storage_config5_shape(gpu_device):
 
 
 @pytest.mark.parametrize("cnn", ["ResNetLarge_withMLP", "ResNetSlim_withMLP"])
-def test_encoder_paths_agree(gpu_device, monkeypatch, cnn):
+def test_encoder_paths_agree(gpu_device, monkeypatch, cnn, libopt):
     """The encoder's kernel paths are interchangeable: fused stem + layer1.conv1 vs two launches, f16 plane-granule vs
     float32-granule activation tiles, direct vs 2x2 LDS-staged f16x3 GEMM, f16x3 vs bf16x6 vs fp32 MFMA - every
     combination reproduces the oracle within the 1e-4 gate and the default path within 2e-5.  Ragged agent count
@@ -230,16 +230,16 @@ def test_encoder_paths_agree(gpu_device, monkeypatch, cnn):
     xd = x.to(gpu_device)
     outs = {}
     variants = [{}, {"MAGAT_L1_FUSED": "0"}, {"MAGAT_CONV_PCHAIN": "0"}, {"MAGAT_CONV_DIRECT": "0"},
-                {"MAGAT_CONV_KORDER": "0", "MAGAT_CONV_TM": "1"}, {"MAGAT_CONV_PAIR": "1"}, {"MAGAT_CONV_DUO": "1"}, {"MAGAT_CONV_F16": "0"},
-                {"MAGAT_CONV_SPLIT": "0"}, {"MAGAT_HEAD_SPLITK": "0"}, {"MAGAT_CONV_MX": "0"}]
+                {"MAGAT_CONV_KORDER": "0", "MAGAT_CONV_TM": "1"}, {"MAGAT_CONV_F16": "0"},
+                {"MAGAT_CONV_SPLIT": "0"}, {"MAGAT_HEAD_SPLITK": "0"}, {"MAGAT_CONV_MX": "1"}]
     for env in variants:
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            libopt.set(k, v)
         with torch.no_grad():
             net.addGSO(S.clone().to(gpu_device))
             outs[tuple(sorted(env.items()))] = net(xd).cpu().numpy()
         for k in env:
-            monkeypatch.delenv(k)
+            libopt.reset(k)
     base = outs[()]
     for key, got in outs.items():
         assert np.abs(got - ref).max() <= TOL, (key, np.abs(got - ref).max())
@@ -248,7 +248,7 @@ def test_encoder_paths_agree(gpu_device, monkeypatch, cnn):
 
 @pytest.mark.parametrize("hw,cnn", [(7, "ResNetLarge"), (9, "ResNetLarge"), (12, "ResNetSlim"), (13, "ResNetSlim"),
                                     (15, "ResNetLarge")])
-def test_encoder_other_map_sizes(gpu_device, monkeypatch, hw, cnn):
+def test_encoder_other_map_sizes(gpu_device, monkeypatch, hw, cnn, libopt):
     """The encoder C entry at map sizes other than the reference's 11x11 (its ResNet heads hard-wire 1152 features, so
     this is below the module level): fused stem + layer1.conv1 (odd / even output widths, maps up to 15 wide: the LDS limit of its windows),
     plane-granule chain, float32-granule chain and - up to 11x11, the LDS limit of the stand-alone stem kernel - the
@@ -278,13 +278,13 @@ def test_encoder_other_map_sizes(gpu_device, monkeypatch, hw, cnn):
     envs = [{}] + ([{"MAGAT_L1_FUSED": "0"}, {"MAGAT_CONV_PCHAIN": "0"}] if hw <= 11 else [])
     for env in envs:
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            libopt.set(k, v)
         feat = torch.full((M, meta["n_feat"]), float("nan"), device=gpu_device)
         nat.check(lib.magat_encoder_forward_f32(ctypes.byref(d), nat.ptr(xd), nat.ptr(feat), meta["n_feat"], None, 0,
                                                 nat.ptr(ws), ws.numel(), M, nat.current_stream(gpu_device)), "encoder")
         torch.cuda.synchronize()
         for k in env:
-            monkeypatch.delenv(k)
+            libopt.reset(k)
         got = feat.double().cpu()
         assert float((got - ref).abs().max()) <= 2e-5 * max(scale, 1.0), (env, float((got - ref).abs().max()), scale)
         outs.append(got)
