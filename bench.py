@@ -84,7 +84,7 @@ def conv_arith(nat, cfg, layer):
     return "f16x3"
 
 
-def kernel_work(nat, cfg, N, S_bytes, deg=None, planned=False):
+def kernel_work(nat, cfg, N, S_bytes, deg=None, planned=False, fused_stem=True):
     """ALGORITHMIC work per AGENT-STEP for each kernel tag name: dict(flops=fp32 multiply-add flops, bytes=HBM bytes every
     kernel must move if it kept nothing it does not have to, arith=key of ARITH or None).  SURVEY.md section 8(d).  deg: mean
     out-degree, given when the layer runs on the CSR kernels (N > 128 or bf16 storage)."""
@@ -100,7 +100,10 @@ def kernel_work(nat, cfg, N, S_bytes, deg=None, planned=False):
         taps = t11 if l == 0 else t6
         hw_in = 121 if l == 0 else 36
         conv[(l, 1)] = (2 * taps * ci * co, 4 * (hw_in * ci + 36 * co))
-        conv[(l, 2)] = (2 * (t6 * co * co + 36 * ci * co), 4 * (36 * co + hw_in * ci + 36 * co))
+        # conv2's residual 1x1 branch reads the block input at the 36 stride-s pixels only; the two-kernel stem path hands it
+        # the full 121-pixel map, the fused stem kernel writes those 36 pixels as their own map
+        hw2 = hw_in if (l == 0 and not fused_stem) else 36
+        conv[(l, 2)] = (2 * (t6 * co * co + 36 * ci * co), 4 * (36 * co + hw2 * ci + 36 * co))
     stem = (2 * 121 * 27 * 32, 4 * (363 + 121 * 32))
     w["conv_first"] = dict(flops=stem[0], bytes=stem[1], arith="f32")
     # stem + layer1.conv1 in one kernel: the (3,H,W) input in, layer1.conv1's map + the stem's stride-2 pixels out
@@ -346,7 +349,8 @@ def main():
         """per-kernel entries: time, algorithmic rate against the roof that binds, issued rate."""
         csr = Nk > 128 or cfg.gat_storage == "bf16"
         deg = float((S != 0).sum().item()) / (Bk * Nk) if csr else None
-        work = kernel_work(nat, cfg, Nk, 4, deg, planned="gat_prepare" in kern and not csr)
+        work = kernel_work(nat, cfg, Nk, 4, deg, planned="gat_prepare" in kern and not csr,
+                           fused_stem="layer1.conv1" not in kern)
         if "conv_first" in kern and "layer1.conv1" not in kern and cfg.CNN_mode.startswith("ResNet"):
             kern = {("conv_first+layer1.conv1 (fused)" if k == "conv_first" else k): v for k, v in kern.items()}
         agent_steps = Bk * Nk * steps
