@@ -84,6 +84,11 @@ int magat_gat_pack_weights(const float* weight, const float* weight_bias, const 
                            const float* taps, float* packed, int G, int F, int K, int P, int mode,
                            void* stream);
 size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, int P, int mode, int concat);
+/* Range guard of the layer's per-agent maps (the f16x3 GEMM X @ [W_p | H_pk]^T; same scheme as magat_encoder_read_status):
+ * the first 256 bytes of the dense AND the csr_f32 workspaces are the status block, int32 [0] = 1 when the last forward had
+ * an |X| > 65504 and the maps were recomputed on the float32 MFMA kernel in the same stream, [1] = number of such re-runs
+ * since the caller zeroed the block.  Synchronises `stream`. */
+int magat_gat_read_status(const void* workspace, int32_t status_host[2], void* stream);
 int magat_gat_forward_packed_f32(const float* X, const void* S, int s_is_f64, const float* packed,
                                  const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
                                  size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
@@ -278,6 +283,13 @@ typedef struct magat_conv_gemm_desc {
    * - the split-K form of the encoder head for small agent counts (encoder_f32.hip sums the partials).  0 = shared weights. */
   int64_t wt_pix_stride;
   int ldw;
+  /* Range guard of the split arithmetic (ABI 2).  range_flag (device int32, may be NULL): the f16x3 / f16+MX kernels OR 1
+   * into it when a value left the range their half-precision planes carry exactly (|v| > 65504 on the way into a plane
+   * pair; > 448 into an fp8 correction plane) - such a value was CLAMPED and the result is not fp32-class.  run_if (device
+   * int32, may be NULL): the float32 kernel (in_fmt 0) does nothing unless *run_if != 0 - the stream-ordered "re-run in
+   * true fp32 if the split path clamped" that magat_encoder_forward_f32 / the GAT maps use. */
+  int32_t* range_flag;
+  const int32_t* run_if;
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 
@@ -315,7 +327,17 @@ typedef struct magat_encoder_desc {
   const float* pack; /* device pointer to the folded parameter pack */
   int64_t off[32];   /* float offsets into pack: see DESIGN.md "encoder pack" */
 } magat_encoder_desc;
+/* Range guard (option RANGE_GUARD, default 1).  The convolutions run as f16x3 split products (two half-precision planes per
+ * value, fp32 accumulate: as accurate as the fp32 MFMA kernel while every activation stays within +-65504; the fused stem
+ * carries its output 16x and needs it below 4094).  Whether a forward stayed inside is checked ON THE DEVICE: every kernel
+ * that forms planes ORs a flag when it had to clamp, and the encoder then re-runs itself on the float32 MFMA kernels in
+ * the same stream, predicated on that flag (about ten launches that return immediately when the flag is clear), so feat /
+ * comp are fp32-class either way.  The first 256 bytes of `workspace` are the status block (int32): [0] = 1 if the LAST
+ * forward clamped and was re-run in float32, [1] = number of re-run forwards since the caller zeroed the block (the caller
+ * zeroes it once, when it allocates the workspace).  magat_encoder_read_status copies both words to the host; it is the one
+ * call that synchronises `stream`. */
 size_t magat_encoder_workspace_bytes(const magat_encoder_desc* desc_host, int M);
+int magat_encoder_read_status(const void* workspace, int32_t status_host[2], void* stream);
 int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* x /*M,3,H,W*/,
                               float* feat, int ldfeat, float* comp, int ldcomp, void* workspace,
                               size_t workspace_bytes, int M, void* stream);
@@ -337,6 +359,9 @@ int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* 
 #define MAGAT_TAG_GAT_PACK 14
 #define MAGAT_TAG_GSO_PREPARE 15
 #define MAGAT_TAG_GAT_PREPARE 16  /* edge masks + edge counts + balanced instance order for the persistent graph kernel */
+#define MAGAT_TAG_RANGE_GUARD 17  /* flag reset + the predicated float32 re-run launches of the range guard (no-ops when clear) */
+#define MAGAT_TAG_BLOCK_CHAIN 18  /* BasicBlock chain kernel (block_fused.hip) */
+#define MAGAT_TAG_GAT_LAYER 19    /* graph kernel with the per-agent maps computed inside (gat_fused.hip) */
 #define MAGAT_PROF_TAGS 24
 int magat_gat_set_debug_buffer(long long* dev_buf); /* [grid][8] int64 phase timestamps of gat_dense_kernel; NULL = off */
 int magat_profile_reserve(int spans);   /* pre-create event pairs (keeps hipEventCreate out of a timed region) */

@@ -45,7 +45,8 @@ class ConvGemmDesc(ctypes.Structure):
                 ("in_tile_stride", ctypes.c_int64), ("in2_tile_stride", ctypes.c_int64),
                 ("out_tile_stride", ctypes.c_int64),
                 ("in_gl", ctypes.c_int), ("out_gl", ctypes.c_int), ("out_ntile_stride", ctypes.c_int64),
-                ("wt_pix_stride", ctypes.c_int64), ("ldw", ctypes.c_int)]
+                ("wt_pix_stride", ctypes.c_int64), ("ldw", ctypes.c_int),
+                ("range_flag", ctypes.c_void_p), ("run_if", ctypes.c_void_p)]
 
 
 class EncoderDesc(ctypes.Structure):
@@ -95,6 +96,8 @@ _SIGNATURES = {
     "magat_conv_first_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "magat_conv_first_tiled_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "magat_encoder_workspace_bytes": (_Z, [ctypes.POINTER(EncoderDesc), _I]),
+    "magat_encoder_read_status": (_I, [_P, ctypes.POINTER(ctypes.c_int32), _P]),
+    "magat_gat_read_status": (_I, [_P, ctypes.POINTER(ctypes.c_int32), _P]),
     "magat_encoder_forward_f32": (_I, [ctypes.POINTER(EncoderDesc), _P, _P, _I, _P, _I, _P, _Z, _I, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -54,7 +54,13 @@ struct SplitParams {
   int korder;               // direct kernel: 1 = channel slab outer, taps inner (MAGAT_CONV_KORDER)
   int in_gl, out_gl;        // direct kernel: granule-major agent tiles [C/4][128][4] for in/in2 resp. out
   const float* acc_scale;   // NPL == 2: device pointer to 1 / (power-of-two weight scale), applied before the bias
+  int* range_flag;          // range guard (magat_hip.h): OR-ed with 1 when a value had to be clamped into its f16 / fp8 planes
 };
+
+// the guard's device-side flag: lanes that clamped (normally none: one skipped branch) OR it
+__device__ __forceinline__ void report_clamped(int* flag, bool clamped) {
+  if (clamped && flag) atomicOr(flag, 1);
+}
 
 __device__ __forceinline__ u16 bf16_rne(float v) { return magat_bf16_rne(v); }
 __device__ __forceinline__ float bf16_f32(u16 h) { return magat_bf16_f32(h); }
@@ -88,6 +94,11 @@ __device__ __forceinline__ void split_pair_f16(float x, float y, unsigned& p1, u
   const f16x2 r = __builtin_convertvector(f32x2{x - (float)h[0], y - (float)h[1]}, f16x2);
   p1 = __builtin_bit_cast(unsigned, h);
   p2 = __builtin_bit_cast(unsigned, r);
+}
+// same, remembering in `clamped` whether a value was outside +-65504 (range guard)
+__device__ __forceinline__ void split_pair_f16(float x, float y, unsigned& p1, unsigned& p2, bool& clamped) {
+  clamped |= (__builtin_fabsf(x) > 65504.f) | (__builtin_fabsf(y) > 65504.f);
+  split_pair_f16(x, y, p1, p2);
 }
 
 // AF32: the activation operands (in, in2) are plain float32 and are split into their three bf16 planes by the
@@ -222,6 +233,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
   // the current slab (the loads landed long ago; the VALU work overlaps the wave's own MFMA drain and the other
   // waves' tails) instead of inside the barrier-to-barrier section, which is then only the LDS writes.
   uint2 qs[NPL][4];
+  bool clamped = false;
   auto split_regs = [&]() {
     if constexpr (AF32 && NPL == 3) {
 #pragma unroll
@@ -237,8 +249,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         unsigned q1[2], q2[2];
-        split_pair_f16(fa32[i][0], fa32[i][1], q1[0], q2[0]);
-        split_pair_f16(fa32[i][2], fa32[i][3], q1[1], q2[1]);
+        split_pair_f16(fa32[i][0], fa32[i][1], q1[0], q2[0], clamped);
+        split_pair_f16(fa32[i][2], fa32[i][3], q1[1], q2[1], clamped);
         qs[0][i] = uint2{q1[0], q1[1]};
         qs[1][i] = uint2{q2[0], q2[1]};
       }
@@ -367,8 +379,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
         } else if (p.out_split == 3) {     // two f16 planes (the operand format of the next f16x3 layer: split once here,
           u16* ob = static_cast<u16*>(p.out);   // not once per tap and slab by every consumer)
           unsigned a1, a2, b1, b2;
-          split_pair_f16(v[0], v[1], a1, a2);
-          split_pair_f16(v[2], v[3], b1, b2);
+          split_pair_f16(v[0], v[1], a1, a2, clamped);
+          split_pair_f16(v[2], v[3], b1, b2, clamped);
           if (vec) {
             *reinterpret_cast<uint2*>(ob + o) = uint2{a1, b1};
             *reinterpret_cast<uint2*>(ob + p.out_plane + o) = uint2{a2, b2};
@@ -412,6 +424,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
       }
     }
   }
+  if constexpr (NPL == 2) report_clamped(p.range_flag, clamped);
 }
 
 // ---- f16x3, activations straight into registers ("direct" flavour; in_fmt 4, out_fmt 0) --------------------------------
@@ -584,6 +597,7 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
   };
   u32x4 qa[TM][2][2];                                   // [row group][k step][plane]: the lane's 8 k values as packed f16
+  bool clamped = false;
   auto take_regs = [&]() {                              // fa -> qa: split float32 quads, or just take the operands
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -594,10 +608,10 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
         for (int ks = 0; ks < 2; ++ks) {
           const f32x4 lo = __builtin_bit_cast(f32x4, fa[i][2 * ks]), hi = __builtin_bit_cast(f32x4, fa[i][2 * ks + 1]);
           unsigned h1[4], h2[4];
-          split_pair_f16(lo[0], lo[1], h1[0], h2[0]);
-          split_pair_f16(lo[2], lo[3], h1[1], h2[1]);
-          split_pair_f16(hi[0], hi[1], h1[2], h2[2]);
-          split_pair_f16(hi[2], hi[3], h1[3], h2[3]);
+          split_pair_f16(lo[0], lo[1], h1[0], h2[0], clamped);
+          split_pair_f16(lo[2], lo[3], h1[1], h2[1], clamped);
+          split_pair_f16(hi[0], hi[1], h1[2], h2[2], clamped);
+          split_pair_f16(hi[2], hi[3], h1[3], h2[3], clamped);
           qa[i][ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
           qa[i][ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
         }
@@ -741,6 +755,8 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
     if (nslab > 0) compute(nslab - 1, std::false_type{});
   }
 
+  if constexpr (!PIN) report_clamped(p.range_flag, clamped);      // float32 input split by the loader
+  clamped = false;
   // epilogue: D[channel][agent]; agent = lane&31, channel = (r&3) + 8*(r>>2) + 4*(lane>>5).  The lane's 4 TN bias quads
   // are fetched as ONE batch of 16-byte loads (per-channel conditional loads cost one L2 round trip per quad).
   const bool vec = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
@@ -826,14 +842,15 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
               v[c] = acc[i][j][4 * q + c] * acc_scale + bq[j][q][c];
               if (p.relu) v[c] = fmaxf(v[c], 0.f);
             }
-            split_pair_f16(v[0], v[1], h1[2 * e], h2[2 * e]);
-            split_pair_f16(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1]);
+            split_pair_f16(v[0], v[1], h1[2 * e], h2[2 * e], clamped);
+            split_pair_f16(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1], clamped);
             if (p.out_gl == 3) {      // MX consumer: e4m3(h1) and e4m3((v - h1) * 2^11), four bytes each
               float a[4], r[4];
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
                 const float vc = __builtin_amdgcn_fmed3f(v[c], -65504.f, 65504.f);
                 const float hf = (float)(_Float16)vc;
+                clamped |= __builtin_fabsf(hf) > 448.f;          // the e4m3 plane of h1 saturates: outside the MX form's range
                 a[c] = __builtin_amdgcn_fmed3f(hf, -448.f, 448.f);
                 r[c] = __builtin_amdgcn_fmed3f((vc - hf) * 2048.f, -448.f, 448.f);
               }
@@ -924,6 +941,7 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.npix = d->Hout * d->Wout; p.tag = d->tag; p.out_split = d->out_fmt;
   p.in_gl = d->in_gl; p.out_gl = d->out_gl;
   p.out_nt = d->out_ntile_stride;
+  p.range_flag = reinterpret_cast<int*>(d->range_flag);
   if (p.out_nt && !(d->in_fmt == 4 && d->out_fmt == 0 && d->out_gl == 0 && BN == 128 && magat_conv_direct_enabled()))
     return MAGAT_ERR_UNSUPPORTED;
   p.korder = magat_opt(MAGAT_OPT_CONV_KORDER);

@@ -44,6 +44,8 @@ struct ConvGemmParams {
   long long wt_pix;         // per-output-pixel weight offset (floats); 0 = shared weights
   int out_split;            // epilogue writes three bf16 planes (out_plane elements apart) instead of float32
   long long out_plane;
+  long long out_nt;         // > 0: 128-column tile t of the row-major output lives at out + t * out_nt (row stride ldc = 128)
+  const int* run_if;        // range-guard re-run: the kernel does nothing unless *run_if != 0 (null: always runs)
 };
 
 // FULL: M % BM == 0, Cout % BN == 0, Cin % 32 == 0, C2 % 32 == 0 -> the loader has no bounds checks and
@@ -62,6 +64,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
   // XCD-aware block -> tile map: the dispatcher places block b on XCD b % 8, so give each XCD
   // whole agent tiles (all pixels x all Cout tiles): the tile's inputs stay in that XCD's L2
   // while its <= 9-fold tap re-reads happen.
+  if (p.run_if && *p.run_if == 0) return;
   const int bid = blockIdx.x;
   const int xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
   const int per_m = p.npix * p.ntn;
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
           v[c] = acc[i][j][4 * q + c] + bq[j][q][c];
           if (p.relu) v[c] = fmaxf(v[c], 0.f);
         }
-        const long long o = magat_row_off(m, p.ldc, p.out_tile) + n;
+        const long long o = magat_row_off(m, p.ldc, p.out_tile) + (p.out_nt ? (long long)(n >> 7) * p.out_nt + (n & 127) : n);
         if (p.out_split) {
           unsigned short h[3][4];
 #pragma unroll
@@ -365,12 +368,14 @@ int launch(ConvGemmParams& p, hipStream_t st) {
 extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) {
   if (!d || !d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
   if (d->in_fmt >= 1 && d->in_fmt <= 5) return magat_conv_gemm_bf16x6(d, static_cast<hipStream_t>(stream));
-  if (d->in_gl || d->out_gl || d->out_ntile_stride) return MAGAT_ERR_UNSUPPORTED;   // f16x3 direct kernel only
+  if (d->in_gl || d->out_gl) return MAGAT_ERR_UNSUPPORTED;   // f16x3 direct kernel only
+  if (d->out_ntile_stride && (d->ldc != 128 || (d->Cout & 127) || d->out_fmt != 0)) return MAGAT_ERR_UNSUPPORTED;
   if (d->in_fmt != 0 || (d->out_fmt != 0 && d->out_fmt != 1)) return MAGAT_ERR_UNSUPPORTED;
   if (d->M <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->kH <= 0 || d->kW <= 0 ||
       d->stride <= 0 || d->pad < 0 || d->C2 < 0)
     return MAGAT_ERR_BAD_SHAPE;
-  if ((d->Cin & 3) || (d->C2 & 3) || (d->lda & 3) || d->lda < d->Cin || d->ldc < d->Cout) return MAGAT_ERR_BAD_SHAPE;
+  if ((d->Cin & 3) || (d->C2 & 3) || (d->lda & 3) || d->lda < d->Cin || (d->ldc < d->Cout && !d->out_ntile_stride))
+    return MAGAT_ERR_BAD_SHAPE;
   if (d->C2 > 0 && (!d->in2 || (d->lda2 & 3) || d->lda2 < d->C2 || d->stride2 <= 0)) return MAGAT_ERR_BAD_SHAPE;
   if ((reinterpret_cast<uintptr_t>(d->in) | reinterpret_cast<uintptr_t>(d->wt) |
        reinterpret_cast<uintptr_t>(d->in2)) & 15)
@@ -396,6 +401,8 @@ extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) 
   p.tag = d->tag;
   p.out_split = d->out_fmt == 1;
   p.out_plane = d->out_plane_stride;
+  p.out_nt = d->out_ntile_stride;
+  p.run_if = reinterpret_cast<const int*>(d->run_if);
   p.pool_w = 0;
   p.pool_max = d->pool == 2;
   if (d->pool) {   // input map is the 2x2 sum- or max-pool of a physical (2*Hin.. x pool_w) map

@@ -21,8 +21,10 @@ template <int HC, int WC>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          int M, int Hr, int Wr, long long out_pix_stride,
-                                                         long long out_tile_stride, long long out_plane, int out_gl) {
+                                                         long long out_tile_stride, long long out_plane, int out_gl,
+                                                         int* range_flag, const int* run_if) {
   extern __shared__ float img[];
+  if (run_if && *run_if == 0) return;        // range-guard re-run: nothing to do unless the split path clamped
   const int H = HC ? HC : Hr, W = WC ? WC : Wr;
   const int PW = W + 2, PHW = (H + 2) * PW;
   const int PS = (3 * PHW) | 1;            // odd per-agent stride
@@ -125,8 +127,10 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 #pragma unroll
           for (int e = 0; e < 4; ++e) {        // pairs (2e, 2e+1) of the 8 values of quads 2 ks, 2 ks + 1
             const int q = 2 * ks + (e >> 1), c = 2 * (e & 1);
-            const float a = __builtin_amdgcn_fmed3f(fmaxf(acc[4 * q + c] + bch[q][c], 0.f), -65504.f, 65504.f);
-            const float b2 = __builtin_amdgcn_fmed3f(fmaxf(acc[4 * q + c + 1] + bch[q][c + 1], 0.f), -65504.f, 65504.f);
+            const float a0 = fmaxf(acc[4 * q + c] + bch[q][c], 0.f), b0 = fmaxf(acc[4 * q + c + 1] + bch[q][c + 1], 0.f);
+            if ((a0 > 65504.f || b0 > 65504.f) && range_flag) atomicOr(range_flag, 1);      // range guard (rare)
+            const float a = __builtin_amdgcn_fmed3f(a0, -65504.f, 65504.f);
+            const float b2 = __builtin_amdgcn_fmed3f(b0, -65504.f, 65504.f);
             const h2 h = __builtin_convertvector(f2{a, b2}, h2);
             const h2 r = __builtin_convertvector(f2{a - (float)h[0], b2 - (float)h[1]}, h2);
             w1[e] = __builtin_bit_cast(unsigned, h);
@@ -181,7 +185,9 @@ struct BlockShape {
 
 // feat[m][n] = bias[n] + sum over the pooled cells (fixed order) of part[c][m][n]: the second half of the split-K head
 __global__ __launch_bounds__(256) void head_sum_kernel(const float* __restrict__ part, const float* __restrict__ bias,
-                                                       float* __restrict__ feat, int ldfeat, int M, int nf, int cells) {
+                                                       float* __restrict__ feat, int ldfeat, int M, int nf, int cells,
+                                                       const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const int q = nf / 4;
   if (i >= (long long)M * q) return;
@@ -192,11 +198,16 @@ __global__ __launch_bounds__(256) void head_sum_kernel(const float* __restrict__
   *reinterpret_cast<f32x4*>(feat + (long long)m * ldfeat + n) = acc;
 }
 
+// range guard bookkeeping: status[0] = flag of this forward, status[1] += 1 when the float32 re-run happened
+__global__ void guard_count_kernel(int* status) {
+  if (status[0] != 0) status[1] += 1;
+}
+
 }  // namespace
 
 static int conv_first_launch(const float* x, const float* wt, const float* bias, float* out, int M, int H, int W,
                              long long pix_stride, long long tile_stride, void* stream, long long out_plane = 0,
-                             int out_gl = 0);
+                             int out_gl = 0, int* range_flag = nullptr, const int* run_if = nullptr, int tag = MAGAT_TAG_CONV_FIRST);
 
 extern "C" int magat_conv_first_f32(const float* x, const float* wt, const float* bias, float* out, int M, int H,
                                     int W, void* stream) {
@@ -210,30 +221,28 @@ extern "C" int magat_conv_first_tiled_f32(const float* x, const float* wt, const
 }
 
 static int conv_first_launch(const float* x, const float* wt, const float* bias, float* out, int M, int H, int W,
-                             long long pix_stride, long long tile_stride, void* stream, long long out_plane, int out_gl) {
+                             long long pix_stride, long long tile_stride, void* stream, long long out_plane, int out_gl,
+                             int* range_flag, const int* run_if, int tag) {
   if (!x || !wt || !bias || !out) return MAGAT_ERR_NULL;
   if (M <= 0 || H <= 0 || W <= 0) return MAGAT_ERR_BAD_SHAPE;
   const size_t lds = sizeof(float) * 32 * (size_t)((3 * (H + 2) * (W + 2)) | 1);
   if (lds > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;
   const int blocks = (M + 31) / 32;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int pid = magat_prof_begin(MAGAT_TAG_CONV_FIRST, st);
+  const int pid = magat_prof_begin(tag, st);
   if (H == 11 && W == 11 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
     hipLaunchKernelGGL((conv_first_kernel<11, 11>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W,
-                       pix_stride, tile_stride, out_plane, out_gl);
+                       pix_stride, tile_stride, out_plane, out_gl, range_flag, run_if);
   else
     hipLaunchKernelGGL((conv_first_kernel<0, 0>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W,
-                       pix_stride, tile_stride, out_plane, out_gl);
+                       pix_stride, tile_stride, out_plane, out_gl, range_flag, run_if);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
 
-// Block convolutions on the bf16x6 split-MFMA kernel (split weights in the pack).  MAGAT_CONV_SPLIT = bit mask of
-// BasicBlocks that use it (bit l = layer l+1); default 7 = all three (layer 1, Cin = Cout = 32 on the 128x32 tiles,
-// used to be a wash; since the activation split left the barrier section it wins: 351 -> 305 us and 342 -> 264 us);
-// 0 keeps every layer on the fp32 MFMA kernel.
-static int enc_split_mask(const magat_encoder_desc* d) {
-  const int v = magat_opt(MAGAT_OPT_CONV_SPLIT);
+// Block convolutions on the split-MFMA kernels (split weights in the pack).  Option CONV_SPLIT = bit mask of
+// BasicBlocks that use them (bit l = layer l+1); default 7 = all three; 0 keeps every layer on the fp32 MFMA kernel.
+static int enc_split_mask(const magat_encoder_desc* d, int v) {
   int m = 0;
   for (int l = 0; l < 3; ++l)
     if ((v >> l & 1) && d->off[18 + 2 * l] > 0 && d->off[19 + 2 * l] > 0) m |= 1 << l;
@@ -241,7 +250,7 @@ static int enc_split_mask(const magat_encoder_desc* d) {
 }
 
 // Split flavour of those layers: f16x3 (two f16 planes, three v_mfma_f32_32x32x16_f16 per product, in_fmt 4) when the
-// pack carries the f16 weight planes, else bf16x6 (in_fmt 2).  MAGAT_CONV_F16=0 forces bf16x6.
+// pack carries the f16 weight planes, else bf16x6 (in_fmt 2).  Option CONV_F16=0 forces bf16x6.
 static bool enc_use_f16(const magat_encoder_desc* d, int l) {
   return magat_opt(MAGAT_OPT_CONV_F16) && d->off[24 + 2 * l] > 0 && d->off[25 + 2 * l] > 0;
 }
@@ -255,10 +264,190 @@ static size_t enc_buf_floats_per_agent(const magat_encoder_desc* d) {
   return a0 > a3 ? a0 : a3;
 }
 
+constexpr size_t ENC_STATUS_BYTES = 256;     // status block at the head of the workspace (magat_hip.h)
+
 extern "C" size_t magat_encoder_workspace_bytes(const magat_encoder_desc* d, int M) {
   if (!d || M <= 0) return 0;
   const int mc = (enc_chunk_agents(M) + MAGAT_TILE_ROWS - 1) / MAGAT_TILE_ROWS * MAGAT_TILE_ROWS;   // whole agent tiles
-  return 3 * magat_align_up(enc_buf_floats_per_agent(d) * (size_t)mc * sizeof(float), 256);
+  return ENC_STATUS_BYTES + 3 * magat_align_up(enc_buf_floats_per_agent(d) * (size_t)mc * sizeof(float), 256);
+}
+
+extern "C" int magat_encoder_read_status(const void* workspace, int32_t status_host[2], void* stream) {
+  if (!workspace || !status_host) return MAGAT_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(status_host, workspace, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return MAGAT_ERR_LAUNCH;
+  return MAGAT_OK;
+}
+
+// y = act(x @ w^T + b) on the float32 kernel with the guard's predicate
+static int enc_linear(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int N, int K,
+                      int relu, int tag, const int32_t* run_if, void* stream) {
+  magat_conv_gemm_desc d = {};
+  d.tag = tag;
+  d.in = x; d.wt = w; d.bias = b; d.out = y;
+  d.M = M; d.Cin = K; d.lda = ldx; d.Hin = d.Win = 1; d.kH = d.kW = 1; d.stride = 1; d.pad = 0;
+  d.Hout = d.Wout = 1; d.Cout = N; d.ldc = ldy; d.relu = relu;
+  d.run_if = run_if;
+  return magat_conv_gemm_f32(&d, stream);
+}
+
+// One pass of the ResNet encoders (variant 0 / 1) over all agents with the BasicBlocks in `split` on the split-MFMA
+// kernels.  range_flag: where those kernels report a clamp (null: not tracked).  run_if: predicate of the float32
+// re-run (every launch of the pass returns immediately unless *run_if != 0; only valid with split == 0).
+static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* feat, int ldfeat, float* comp, int ldcomp,
+                          float* bufbase, int M, void* stream, int split, int32_t* range_flag, const int32_t* run_if) {
+  const int H = d->H, W = d->W;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int mc = enc_chunk_agents(M);
+  const int mcp = (mc + MAGAT_TILE_ROWS - 1) / MAGAT_TILE_ROWS * MAGAT_TILE_ROWS;
+  const size_t bstride = magat_align_up(enc_buf_floats_per_agent(d) * (size_t)mcp * sizeof(float), 256) / sizeof(float);
+  // activations are TILE-major: [agent tile][pixel][128][C]
+  auto pixs = [](int c) { return (int64_t)MAGAT_TILE_ROWS * c; };
+  auto tiles = [](int npix, int c) { return (int64_t)npix * MAGAT_TILE_ROWS * c; };
+  float* buf[3] = {bufbase, bufbase + bstride, bufbase + 2 * bstride};
+  const float* pk = d->pack;
+  const BlockShape shapes[3] = {{32, 32, 2}, {32, 64, 1}, {64, 128, 1}};
+  const int nblocks = d->variant == 0 ? 3 : 2;
+  const bool rerun = run_if != nullptr;
+  auto tagof = [&](int t) { return rerun ? MAGAT_TAG_UNTAGGED : t; };     // the re-run is timed as ONE span by the caller
+  hipStream_t st = static_cast<hipStream_t>(stream);
+
+  // Granule-major activation tiles ([C/4][128 agents][4], magat_hip.h in_gl/out_gl) between the layers when every
+  // BasicBlock conv runs on the f16x3 direct kernel: its one-lane-per-agent fragment loads and epilogue stores are then
+  // 512-byte runs.  The last conv2 writes row-major tiles again for the pooled head (fp32 MFMA kernel).
+  bool gl = split == (1 << nblocks) - 1 && magat_conv_direct_enabled();
+  for (int l = 0; l < nblocks; ++l) gl = gl && enc_use_f16(d, l);
+  // ... and, when the pack carries the K-permuted weight copies (off[30]), as f16 PLANE granules (in_gl/out_gl = 2): every
+  // activation is split into its two half-precision planes once, by the epilogue that produces it, instead of once per
+  // tap by every consumer's loader.  Option CONV_PCHAIN=0 keeps float32 granules.
+  int lay = gl ? 1 : 0;
+  if (gl && d->off[30] != 0 && magat_opt(MAGAT_OPT_CONV_PCHAIN)) lay = 2;
+  // float offset of the permuted copy behind an f16 weight block of cout x ktot weights (two planes + one scale float,
+  // padded to 4 floats)
+  auto permuted = [&](int cout, int ktot) { return lay == 2 ? (int64_t)(((int64_t)cout * ktot + 1 + 3) & ~3LL) : 0; };
+  // "f16 + MX correction" chain (in_gl / out_gl = 3, third weight copy, off[31]): from block 0's output on, the second
+  // activation plane carries e4m3(h1) | e4m3(h2 * 2^11) and the consumers issue two f16 MFMAs + one block-scaled fp8 MFMA per
+  // slab instead of six f16 ones.  Block 0's own inputs (fused stem + layer1.conv1 output) stay f16 planes.
+  // OPT-IN (option CONV_MX, default 0): the fp8 correction planes are narrower arithmetic than the reference's fp32.
+  const bool mx = lay == 2 && d->off[31] != 0 && magat_opt(MAGAT_OPT_CONV_MX) != 0;
+  for (int m0 = 0; m0 < M; m0 += mc) {
+    const int mm = (M - m0) < mc ? (M - m0) : mc;
+    // Plane chain: the stem and layer1.conv1 run as ONE kernel (layer1_fused.hip) - the 121-pixel stem output never
+    // reaches HBM; buf[0] receives only its 36 stride-2 pixels, the input of the block's residual 1x1 branch.
+    // Option L1_FUSED=0 keeps the two launches.
+    const bool fused1 = lay == 2 && magat_layer1_fused_lds(W) != 0 && magat_opt(MAGAT_OPT_L1_FUSED) != 0;
+    int rc;
+    if (fused1)
+      rc = magat_layer1_fused(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1],
+                              pk + d->off[24] + permuted(32, 9 * 32), pk + d->off[3], buf[1], buf[0], mm, H, W, st,
+                              range_flag);
+    else
+      rc = conv_first_launch(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W,
+                             (long long)MAGAT_TILE_ROWS * 32, (long long)H * W * MAGAT_TILE_ROWS * 32, stream, 0, lay,
+                             range_flag, run_if, tagof(MAGAT_TAG_CONV_FIRST));
+    if (rc != MAGAT_OK) return rc;
+    int cur = 0;              // buffer holding the block input
+    int hin = H, win = W;
+    for (int l = 0; l < nblocks; ++l) {
+      const BlockShape s = shapes[l];
+      const int hout = s.stride == 2 ? Ho : hin, wout = s.stride == 2 ? Wo : win;
+      const int mid = (cur + 1) % 3, nxt = (cur + 2) % 3;
+      magat_conv_gemm_desc g = {};
+      // conv1 + bn1 + relu
+      g.in = buf[cur]; g.wt = pk + d->off[2 + 4 * l]; g.bias = pk + d->off[3 + 4 * l]; g.out = buf[mid];
+      g.in_pix_stride = pixs(s.cin); g.out_pix_stride = pixs(s.cout);
+      g.in_tile_stride = tiles(hin * win, s.cin); g.out_tile_stride = tiles(hout * wout, s.cout);
+      g.M = mm; g.Cin = s.cin; g.lda = s.cin; g.Hin = hin; g.Win = win; g.kH = g.kW = 3; g.stride = s.stride;
+      g.pad = 1; g.Hout = hout; g.Wout = wout; g.Cout = s.cout; g.ldc = s.cout; g.relu = 1;
+      g.tag = tagof(MAGAT_TAG_BLOCK_CONV + 2 * l);
+      g.range_flag = range_flag; g.run_if = run_if;
+      if (split >> l & 1) {      // split-MFMA kernel: float32 activations split by its loader, pre-split weights
+        if (enc_use_f16(d, l)) { g.in_fmt = 4; g.wt = pk + d->off[24 + 2 * l]; }
+        else { g.in_fmt = 2; g.wt = pk + d->off[18 + 2 * l]; }
+      }
+      g.in_gl = g.out_gl = lay;
+      if (mx && l >= 1) { g.in_gl = g.out_gl = 3; g.wt += 2 * permuted(s.cout, 9 * s.cin); }
+      else if (lay == 2) g.wt += permuted(s.cout, 9 * s.cin);
+      if (!(fused1 && l == 0)) {
+        rc = magat_conv_gemm_f32(&g, stream);
+        if (rc != MAGAT_OK) return rc;
+      }
+      // conv2 + bn2 + (1x1 strided downsample + bn) + relu
+      magat_conv_gemm_desc h = {};
+      h.in = buf[mid]; h.in2 = buf[cur]; h.wt = pk + d->off[4 + 4 * l]; h.bias = pk + d->off[5 + 4 * l];
+      h.out = buf[nxt];
+      h.in_pix_stride = pixs(s.cout); h.in2_pix_stride = pixs(s.cin); h.out_pix_stride = pixs(s.cout);
+      h.in_tile_stride = tiles(hout * wout, s.cout); h.in2_tile_stride = tiles(hin * win, s.cin);
+      h.out_tile_stride = tiles(hout * wout, s.cout);
+      h.M = mm; h.Cin = s.cout; h.lda = s.cout; h.Hin = hout; h.Win = wout; h.kH = h.kW = 3; h.stride = 1; h.pad = 1;
+      h.Hout = hout; h.Wout = wout; h.C2 = s.cin; h.lda2 = s.cin; h.W2 = win; h.stride2 = s.stride;
+      h.Cout = s.cout; h.ldc = s.cout; h.relu = 1;
+      h.tag = tagof(MAGAT_TAG_BLOCK_CONV + 2 * l + 1);
+      h.range_flag = range_flag; h.run_if = run_if;
+      if (split >> l & 1) {
+        if (enc_use_f16(d, l)) { h.in_fmt = 4; h.wt = pk + d->off[25 + 2 * l]; }
+        else { h.in_fmt = 2; h.wt = pk + d->off[19 + 2 * l]; }
+      }
+      h.in_gl = lay; h.out_gl = l + 1 < nblocks ? lay : 0;
+      if (mx && l + 1 < nblocks) h.out_gl = 3;
+      if (mx && l >= 1) { h.in_gl = 3; h.wt += 2 * permuted(s.cout, 9 * s.cout + s.cin); }
+      else if (lay == 2) h.wt += permuted(s.cout, 9 * s.cout + s.cin);
+      if (fused1 && l == 0) {    // the residual branch reads the stem's stride-2 pixels, stored as an Ho x Wo map
+        h.in2_tile_stride = tiles(hout * wout, s.cin); h.W2 = wout; h.stride2 = 1;
+      }
+      rc = magat_conv_gemm_f32(&h, stream);
+      if (rc != MAGAT_OK) return rc;
+      cur = nxt; hin = hout; win = wout;
+    }
+    // head: AvgPool2d(2) (sum-pool on load, 1/4 in the weights) + fc(+Flatten+Linear) folded into one
+    // (hin/2 x win/2) valid conv over the pooled map -> [mm][n_feat]
+    const int clast = shapes[nblocks - 1].cout;
+    magat_conv_gemm_desc g = {};
+    g.in = buf[cur]; g.wt = pk + d->off[14]; g.bias = pk + d->off[15];
+    g.out = feat + (size_t)m0 * ldfeat;
+    g.in_pix_stride = pixs(clast); g.in_tile_stride = tiles(hin * win, clast);
+    g.M = mm; g.Cin = clast; g.lda = clast; g.Hin = hin / 2; g.Win = win / 2;
+    g.kH = hin / 2; g.kW = win / 2; g.stride = 1; g.pad = 0; g.Hout = g.Wout = 1; g.Cout = d->n_feat; g.ldc = ldfeat;
+    g.relu = 0; g.pool = 1; g.pool_w = win;
+    g.tag = tagof(MAGAT_TAG_HEAD);
+    g.run_if = run_if;
+    // Few agents (the closed-loop batch-1 step): one workgroup per 64 agents would walk all (hin/2)(win/2) clast of K alone
+    // (83 us at 100 agents).  Split K by pooled cell instead: every cell is its own 1x1 "output pixel" with its slice of the
+    // weight rows (wt_pix_stride / ldw), the partial products land in a free map buffer, a small kernel sums them in
+    // a fixed order and adds the bias.  Option HEAD_SPLITK = largest agent count that takes this form (0 = never).
+    const int cells = (hin / 2) * (win / 2);
+    const int split_max = magat_opt(MAGAT_OPT_HEAD_SPLITK);
+    if (cells > 1 && mm <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
+        (size_t)cells * d->n_feat <= enc_buf_floats_per_agent(d)) {     // the partials must fit one map buffer
+      float* part = buf[(cur + 1) % 3];                 // [cells][mm][n_feat]
+      g.out = part; g.bias = nullptr; g.ldc = d->n_feat;
+      g.out_pix_stride = (long long)mm * d->n_feat;
+      g.kH = g.kW = 1; g.Hout = hin / 2; g.Wout = win / 2;
+      g.wt_pix_stride = clast; g.ldw = cells * clast;
+      const int pid = magat_prof_begin(tagof(MAGAT_TAG_HEAD), st);
+      g.tag = MAGAT_TAG_UNTAGGED;
+      rc = magat_conv_gemm_f32(&g, stream);
+      if (rc == MAGAT_OK) {
+        const long long total4 = (long long)mm * (d->n_feat / 4);
+        hipLaunchKernelGGL(head_sum_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, part,
+                           pk + d->off[15], feat + (size_t)m0 * ldfeat, ldfeat, mm, d->n_feat, cells,
+                           reinterpret_cast<const int*>(run_if));
+        if (hipGetLastError() != hipSuccess) rc = MAGAT_ERR_LAUNCH;
+      }
+      magat_prof_end(pid, st);
+    } else {
+      rc = magat_conv_gemm_f32(&g, stream);
+    }
+    if (rc != MAGAT_OK) return rc;
+    if (d->n_comp > 0) {
+      rc = enc_linear(feat + (size_t)m0 * ldfeat, ldfeat, pk + d->off[16], pk + d->off[17], comp + (size_t)m0 * ldcomp,
+                      ldcomp, mm, d->n_comp, d->n_feat, 1, tagof(MAGAT_TAG_COMPRESS), run_if, stream);
+      if (rc != MAGAT_OK) return rc;
+    }
+  }
+  return MAGAT_OK;
 }
 
 extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const float* x, float* feat, int ldfeat,
@@ -272,21 +461,18 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
       workspace_bytes < magat_encoder_workspace_bytes(d, M))
     return MAGAT_ERR_WORKSPACE;
   const int H = d->H, W = d->W;
-  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int mc = enc_chunk_agents(M);
   const int mcp = (mc + MAGAT_TILE_ROWS - 1) / MAGAT_TILE_ROWS * MAGAT_TILE_ROWS;
   const size_t bstride = magat_align_up(enc_buf_floats_per_agent(d) * (size_t)mcp * sizeof(float), 256) / sizeof(float);
-  // activations are TILE-major: [agent tile][pixel][128][C]
+  int32_t* status = static_cast<int32_t*>(workspace);
+  float* bufbase = reinterpret_cast<float*>(static_cast<char*>(workspace) + ENC_STATUS_BYTES);
   auto pixs = [](int c) { return (int64_t)MAGAT_TILE_ROWS * c; };
   auto tiles = [](int npix, int c) { return (int64_t)npix * MAGAT_TILE_ROWS * c; };
-  float* buf[3] = {static_cast<float*>(workspace), static_cast<float*>(workspace) + bstride,
-                   static_cast<float*>(workspace) + 2 * bstride};
+  float* buf[3] = {bufbase, bufbase + bstride, bufbase + 2 * bstride};
   const float* pk = d->pack;
-  const BlockShape shapes[3] = {{32, 32, 2}, {32, 64, 1}, {64, 128, 1}};
-  const int nblocks = d->variant == 0 ? 3 : 2;
-  const int split = enc_split_mask(d);
+  hipStream_t st = static_cast<hipStream_t>(stream);
 
-  if (d->variant == 2) {     // CNN_mode Default: conv-BN-ReLU x5 with MaxPool2d(2) after layers 0, 2, 4
+  if (d->variant == 2) {     // CNN_mode Default: conv-BN-ReLU x5 with MaxPool2d(2) after layers 0, 2, 4 (float32 kernels only)
     if (d->n_feat != 128) return MAGAT_ERR_BAD_SHAPE;
     const int chans[6] = {3, 32, 32, 64, 64, 128};
     for (int m0 = 0; m0 < M; m0 += mc) {
@@ -331,135 +517,26 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
     return MAGAT_OK;
   }
 
-  // Granule-major activation tiles ([C/4][128 agents][4], magat_hip.h in_gl/out_gl) between the layers when every
-  // BasicBlock conv runs on the f16x3 direct kernel: its one-lane-per-agent fragment loads and epilogue stores are then
-  // 512-byte runs.  The last conv2 writes row-major tiles again for the pooled head (fp32 MFMA kernel).
-  bool gl = split == (1 << nblocks) - 1 && magat_conv_direct_enabled();
-  for (int l = 0; l < nblocks; ++l) gl = gl && enc_use_f16(d, l);
-  // ... and, when the pack carries the K-permuted weight copies (off[30]), as f16 PLANE granules (in_gl/out_gl = 2): every
-  // activation is split into its two half-precision planes once, by the epilogue that produces it, instead of once per
-  // tap by every consumer's loader.  MAGAT_CONV_PCHAIN=0 keeps float32 granules.
-  int lay = gl ? 1 : 0;
-  if (gl && d->off[30] != 0 && magat_opt(MAGAT_OPT_CONV_PCHAIN)) lay = 2;
-  // float offset of the permuted copy behind an f16 weight block of cout x ktot weights (two planes + one scale float,
-  // padded to 4 floats)
-  auto permuted = [&](int cout, int ktot) { return lay == 2 ? (int64_t)(((int64_t)cout * ktot + 1 + 3) & ~3LL) : 0; };
-  // "f16 + MX correction" chain (in_gl / out_gl = 3, third weight copy, off[31]): from block 0's output on, the second
-  // activation plane carries e4m3(h1) | e4m3(h2 * 2^11) and the consumers issue two f16 MFMAs + one block-scaled fp8 MFMA per
-  // slab instead of six f16 ones.  Block 0's own inputs (fused stem + layer1.conv1 output) stay f16 planes.  MAGAT_CONV_MX.
-  // OPT-IN (option CONV_MX, default 0): the fp8 correction planes are narrower arithmetic than the reference's fp32.
-  const bool mx = lay == 2 && d->off[31] != 0 && magat_opt(MAGAT_OPT_CONV_MX) != 0;
-  for (int m0 = 0; m0 < M; m0 += mc) {
-    const int mm = (M - m0) < mc ? (M - m0) : mc;
-    // Plane chain: the stem and layer1.conv1 run as ONE kernel (layer1_fused.hip) - the 121-pixel stem output never
-    // reaches HBM; buf[0] receives only its 36 stride-2 pixels, the input of the block's residual 1x1 branch.
-    // MAGAT_L1_FUSED=0 keeps the two launches.
-    const bool fused1 = lay == 2 && magat_layer1_fused_lds(W) != 0 && magat_opt(MAGAT_OPT_L1_FUSED) != 0;
-    int rc;
-    if (fused1)
-      rc = magat_layer1_fused(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1],
-                              pk + d->off[24] + permuted(32, 9 * 32), pk + d->off[3], buf[1], buf[0], mm, H, W,
-                              static_cast<hipStream_t>(stream));
-    else
-      rc = conv_first_launch(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W,
-                             (long long)MAGAT_TILE_ROWS * 32, (long long)H * W * MAGAT_TILE_ROWS * 32, stream, 0, lay);
-    if (rc != MAGAT_OK) return rc;
-    int cur = 0;              // buffer holding the block input
-    int hin = H, win = W;
-    for (int l = 0; l < nblocks; ++l) {
-      const BlockShape s = shapes[l];
-      const int hout = s.stride == 2 ? Ho : hin, wout = s.stride == 2 ? Wo : win;
-      const int mid = (cur + 1) % 3, nxt = (cur + 2) % 3;
-      magat_conv_gemm_desc g = {};
-      // conv1 + bn1 + relu
-      g.in = buf[cur]; g.wt = pk + d->off[2 + 4 * l]; g.bias = pk + d->off[3 + 4 * l]; g.out = buf[mid];
-      g.in_pix_stride = pixs(s.cin); g.out_pix_stride = pixs(s.cout);
-      g.in_tile_stride = tiles(hin * win, s.cin); g.out_tile_stride = tiles(hout * wout, s.cout);
-      g.M = mm; g.Cin = s.cin; g.lda = s.cin; g.Hin = hin; g.Win = win; g.kH = g.kW = 3; g.stride = s.stride;
-      g.pad = 1; g.Hout = hout; g.Wout = wout; g.Cout = s.cout; g.ldc = s.cout; g.relu = 1;
-      g.tag = MAGAT_TAG_BLOCK_CONV + 2 * l;
-      if (split >> l & 1) {      // bf16x6 split-MFMA kernel: float32 activations split by its loader, bf16x3 weights
-        if (enc_use_f16(d, l)) { g.in_fmt = 4; g.wt = pk + d->off[24 + 2 * l]; }
-        else { g.in_fmt = 2; g.wt = pk + d->off[18 + 2 * l]; }
-      }
-      g.in_gl = g.out_gl = lay;
-      if (mx && l >= 1) { g.in_gl = g.out_gl = 3; g.wt += 2 * permuted(s.cout, 9 * s.cin); }
-      else if (lay == 2) g.wt += permuted(s.cout, 9 * s.cin);
-      if (!(fused1 && l == 0)) {
-        rc = magat_conv_gemm_f32(&g, stream);
-        if (rc != MAGAT_OK) return rc;
-      }
-      // conv2 + bn2 + (1x1 strided downsample + bn) + relu
-      magat_conv_gemm_desc h = {};
-      h.in = buf[mid]; h.in2 = buf[cur]; h.wt = pk + d->off[4 + 4 * l]; h.bias = pk + d->off[5 + 4 * l];
-      h.out = buf[nxt];
-      h.in_pix_stride = pixs(s.cout); h.in2_pix_stride = pixs(s.cin); h.out_pix_stride = pixs(s.cout);
-      h.in_tile_stride = tiles(hout * wout, s.cout); h.in2_tile_stride = tiles(hin * win, s.cin);
-      h.out_tile_stride = tiles(hout * wout, s.cout);
-      h.M = mm; h.Cin = s.cout; h.lda = s.cout; h.Hin = hout; h.Win = wout; h.kH = h.kW = 3; h.stride = 1; h.pad = 1;
-      h.Hout = hout; h.Wout = wout; h.C2 = s.cin; h.lda2 = s.cin; h.W2 = win; h.stride2 = s.stride;
-      h.Cout = s.cout; h.ldc = s.cout; h.relu = 1;
-      h.tag = MAGAT_TAG_BLOCK_CONV + 2 * l + 1;
-      if (split >> l & 1) {
-        if (enc_use_f16(d, l)) { h.in_fmt = 4; h.wt = pk + d->off[25 + 2 * l]; }
-        else { h.in_fmt = 2; h.wt = pk + d->off[19 + 2 * l]; }
-      }
-      h.in_gl = lay; h.out_gl = l + 1 < nblocks ? lay : 0;
-      if (mx && l + 1 < nblocks) h.out_gl = 3;
-      if (mx && l >= 1) { h.in_gl = 3; h.wt += 2 * permuted(s.cout, 9 * s.cout + s.cin); }
-      else if (lay == 2) h.wt += permuted(s.cout, 9 * s.cout + s.cin);
-      if (fused1 && l == 0) {    // the residual branch reads the stem's stride-2 pixels, stored as an Ho x Wo map
-        h.in2_tile_stride = tiles(hout * wout, s.cin); h.W2 = wout; h.stride2 = 1;
-      }
-      rc = magat_conv_gemm_f32(&h, stream);
-      if (rc != MAGAT_OK) return rc;
-      cur = nxt; hin = hout; win = wout;
-    }
-    // head: AvgPool2d(2) (sum-pool on load, 1/4 in the weights) + fc(+Flatten+Linear) folded into one
-    // (hin/2 x win/2) valid conv over the pooled map -> [mm][n_feat]
-    const int clast = shapes[nblocks - 1].cout;
-    magat_conv_gemm_desc g = {};
-    g.in = buf[cur]; g.wt = pk + d->off[14]; g.bias = pk + d->off[15];
-    g.out = feat + (size_t)m0 * ldfeat;
-    g.in_pix_stride = pixs(clast); g.in_tile_stride = tiles(hin * win, clast);
-    g.M = mm; g.Cin = clast; g.lda = clast; g.Hin = hin / 2; g.Win = win / 2;
-    g.kH = hin / 2; g.kW = win / 2; g.stride = 1; g.pad = 0; g.Hout = g.Wout = 1; g.Cout = d->n_feat; g.ldc = ldfeat;
-    g.relu = 0; g.pool = 1; g.pool_w = win;
-    g.tag = MAGAT_TAG_HEAD;
-    // Few agents (the closed-loop batch-1 step): one workgroup per 64 agents would walk all (hin/2)(win/2) clast of K alone
-    // (83 us at 100 agents).  Split K by pooled cell instead: every cell is its own 1x1 "output pixel" with its slice of the
-    // weight rows (wt_pix_stride / ldw), the partial products land in a free map buffer, a small kernel sums them in
-    // a fixed order and adds the bias.  MAGAT_HEAD_SPLITK = largest agent count that takes this form (0 = never).
-    const int cells = (hin / 2) * (win / 2);
-    const int split_max = magat_opt(MAGAT_OPT_HEAD_SPLITK);
-    if (cells > 1 && mm <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
-        (size_t)cells * d->n_feat <= enc_buf_floats_per_agent(d)) {     // the partials must fit one map buffer
-      float* part = buf[(cur + 1) % 3];                 // [cells][mm][n_feat]
-      g.out = part; g.bias = nullptr; g.ldc = d->n_feat;
-      g.out_pix_stride = (long long)mm * d->n_feat;
-      g.kH = g.kW = 1; g.Hout = hin / 2; g.Wout = win / 2;
-      g.wt_pix_stride = clast; g.ldw = cells * clast;
-      const int pid = magat_prof_begin(MAGAT_TAG_HEAD, static_cast<hipStream_t>(stream));
-      g.tag = MAGAT_TAG_UNTAGGED;
-      rc = magat_conv_gemm_f32(&g, stream);
-      if (rc == MAGAT_OK) {
-        const long long total4 = (long long)mm * (d->n_feat / 4);
-        hipLaunchKernelGGL(head_sum_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), part, pk + d->off[15], feat + (size_t)m0 * ldfeat, ldfeat, mm,
-                           d->n_feat, cells);
-        if (hipGetLastError() != hipSuccess) rc = MAGAT_ERR_LAUNCH;
-      }
-      magat_prof_end(pid, static_cast<hipStream_t>(stream));
-    } else {
-      rc = magat_conv_gemm_f32(&g, stream);
-    }
-    if (rc != MAGAT_OK) return rc;
-    if (d->n_comp > 0) {
-      rc = magat_linear_tagged_f32(feat + (size_t)m0 * ldfeat, ldfeat, pk + d->off[16], pk + d->off[17],
-                                   comp + (size_t)m0 * ldcomp, ldcomp, mm, d->n_comp, d->n_feat, 1,
-                                   MAGAT_TAG_COMPRESS, stream);
-      if (rc != MAGAT_OK) return rc;
-    }
+  // ResNet encoders.  With the range guard on (default) the split-arithmetic pass reports clamps into status[0] and a
+  // float32-MFMA pass of the whole encoder follows in the same stream, every launch of it predicated on that flag: when no
+  // value left the f16 planes' range (always, for sane checkpoints) those launches return at once; when one did, feat / comp
+  // are recomputed in true fp32 before anything downstream reads them.
+  const int split = enc_split_mask(d, magat_opt(MAGAT_OPT_CONV_SPLIT));
+  const bool guard = split != 0 && magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
+  if (guard) {
+    const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);
+    const hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), st);
+    magat_prof_end(pid, st);
+    if (e != hipSuccess) return MAGAT_ERR_LAUNCH;
   }
-  return MAGAT_OK;
+  int rc = enc_run_resnet(d, x, feat, ldfeat, comp, ldcomp, bufbase, M, stream, split, guard ? status : nullptr, nullptr);
+  if (rc != MAGAT_OK || !guard) return rc;
+  const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);
+  rc = enc_run_resnet(d, x, feat, ldfeat, comp, ldcomp, bufbase, M, stream, 0, nullptr, status);
+  if (rc == MAGAT_OK) {
+    hipLaunchKernelGGL(guard_count_kernel, dim3(1), dim3(1), 0, st, status);
+    if (hipGetLastError() != hipSuccess) rc = MAGAT_ERR_LAUNCH;
+  }
+  magat_prof_end(pid, st);
+  return rc;
 }

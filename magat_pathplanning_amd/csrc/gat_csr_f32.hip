@@ -325,7 +325,7 @@ Layout layout(int G, int F, int K, int P, int mode) {   // must match pack_layou
 }
 
 struct WsLayout {
-  size_t z, cscptr, cscsrc, cscpos, csctmp, att, t0, t1, ytmp, total;
+  size_t status, z, cscptr, cscsrc, cscpos, csctmp, att, t0, t1, ytmp, total;
 };
 WsLayout ws_layout(int B, int N, long long nnz, int G, int F, int K, int P, int mode, int concat,
                    size_t esz = sizeof(float)) {
@@ -333,6 +333,7 @@ WsLayout ws_layout(int B, int N, long long nnz, int G, int F, int K, int P, int 
   WsLayout w;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += magat_align_up(bytes, 256); return at; };
+  w.status = take(256);              // range-guard status words of the maps GEMM (first bytes of the workspace)
   w.z = take((size_t)B * N * L.NC * esz);
   w.cscptr = take((size_t)B * (N + 1) * sizeof(int));
   w.cscsrc = take((size_t)nnz * sizeof(int));
@@ -411,13 +412,14 @@ __global__ void head_mean_relu_csr_kernel(const ST* __restrict__ ytmp, ST* __res
 // maps GEMM Z = X @ Bt^T + colbias in the storage type: fp32 (fp32 MFMA / bf16x6 split) or bf16 in, bf16 out
 // (one bf16 MFMA product per element pair, fp32 accumulate; weights = plane 0 of the packed bf16x3 block)
 template <typename ST>
-int csr_maps_gemm(const ST* X, const float* packed, ST* Z, int M, int G, const Layout& L, void* stream);
+int csr_maps_gemm(const ST* X, const float* packed, ST* Z, int M, int G, const Layout& L, void* stream, int32_t* status);
 template <>
-int csr_maps_gemm<float>(const float* X, const float* packed, float* Z, int M, int G, const Layout& L, void* stream) {
-  return magat_gat_maps_gemm(X, packed, Z, M, G, L.NC, L.NC, stream);
+int csr_maps_gemm<float>(const float* X, const float* packed, float* Z, int M, int G, const Layout& L, void* stream,
+                         int32_t* status) {
+  return magat_gat_maps_gemm(X, packed, Z, M, G, L.NC, L.NC, stream, 0, status);
 }
 template <>
-int csr_maps_gemm<u16>(const u16* X, const float* packed, u16* Z, int M, int G, const Layout& L, void* stream) {
+int csr_maps_gemm<u16>(const u16* X, const float* packed, u16* Z, int M, int G, const Layout& L, void* stream, int32_t*) {
   if ((L.NC % 32) || (G % 32)) return MAGAT_ERR_UNSUPPORTED;
   magat_conv_gemm_desc d = {};
   d.in = reinterpret_cast<const float*>(X);
@@ -457,7 +459,7 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
   ST* tbuf[2] = {reinterpret_cast<ST*>(ws + w.t0), reinterpret_cast<ST*>(ws + w.t1)};
   ST* Ytmp = reinterpret_cast<ST*>(ws + w.ytmp);
 
-  int rc = csr_maps_gemm<ST>(X, packed, Z, B * N, G, L, stream);
+  int rc = csr_maps_gemm<ST>(X, packed, Z, B * N, G, L, stream, reinterpret_cast<int32_t*>(ws + w.status));
   if (rc != MAGAT_OK) return rc;
 
   CsrParams p = {};
@@ -858,7 +860,9 @@ extern "C" int magat_gat_train_forward_f32(const float* X, const int* rowptr, co
   hipStream_t st = static_cast<hipStream_t>(stream);
   const Layout L = layout(G, F, K, P, mode);
   const long long M = (long long)B * N;
-  int rc = magat_gat_maps_gemm(X, packed, Z, (int)M, G, L.NC, L.NC, stream);
+  // float32 MFMA maps: Z is kept for the backward, and with caller-owned buffers there is no status word for a guarded
+  // split GEMM (the maps are 5 % of a training step either way)
+  int rc = magat_gat_maps_gemm(X, packed, Z, (int)M, G, L.NC, L.NC, stream, 0, nullptr, 1);
   if (rc != MAGAT_OK) return rc;
   CsrParams p = {};
   p.X = X; p.Z = Z; p.rowptr = rowptr; p.colidx = colidx; p.cscptr = cscptr; p.cscsrc = cscsrc; p.cscpos = cscpos;

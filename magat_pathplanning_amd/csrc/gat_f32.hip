@@ -889,10 +889,38 @@ static int gat_zpad() {
   const int v = magat_opt(MAGAT_OPT_GAT_ZPAD);
   return (v < 0 || (v & 3)) ? 0 : v;
 }
+// float32-MFMA form of the maps (exact fp32 products): the guard's re-run, and the training path
+static int gat_maps_gemm_f32(const float* X, const float* packed, float* Z, int M, int G, int NC, int ldz, void* stream,
+                             long long ntile_stride, const int32_t* run_if, int tag) {
+  magat_conv_gemm_desc d = {};
+  d.tag = tag;
+  d.in = X; d.wt = packed; d.bias = packed + (size_t)NC * G; d.out = Z;
+  d.M = M; d.Cin = G; d.lda = G; d.Hin = d.Win = 1; d.kH = d.kW = 1; d.stride = 1; d.pad = 0;
+  d.Hout = d.Wout = 1; d.Cout = NC; d.ldc = ldz;
+  if (ntile_stride) { d.ldc = 128; d.out_ntile_stride = ntile_stride; }
+  d.run_if = run_if;
+  return magat_conv_gemm_f32(&d, stream);
+}
+
+__global__ void gat_guard_count_kernel(int* status) {
+  if (status[0] != 0) status[1] += 1;
+}
+
+// status (device int32[2], may be null): range guard of the f16x3 form - [0] is cleared, OR-ed by the split GEMM when it had
+// to clamp an X value into its f16 planes, and a float32-MFMA GEMM predicated on it re-writes Z in the same stream
+// ([1] counts such re-runs).  force_f32: skip the split form altogether.
 int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, int G, int NC, int ldz, void* stream,
-                        long long ntile_stride) {
-  if (magat_opt(MAGAT_OPT_GAT_SPLIT) && NC % 32 == 0 && G % 32 == 0) {
+                        long long ntile_stride, int32_t* status, int force_f32) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!force_f32 && magat_opt(MAGAT_OPT_GAT_SPLIT) && NC % 32 == 0 && G % 32 == 0) {
     const int use_f16 = magat_opt(MAGAT_OPT_CONV_F16);
+    const bool guard = status && use_f16 && magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
+    if (guard) {
+      const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);
+      const hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), st);
+      magat_prof_end(pid, st);
+      if (e != hipSuccess) return MAGAT_ERR_LAUNCH;
+    }
     magat_conv_gemm_desc d = {};
     d.in = X;
     d.wt = use_f16 ? packed + magat_gat_f16_block_offset(NC, G) : packed + (((size_t)NC * (G + 1) + 3) & ~(size_t)3);
@@ -901,11 +929,20 @@ int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, in
     d.M = M; d.Cin = G; d.lda = G; d.Hin = d.Win = 1; d.kH = d.kW = 1; d.stride = 1; d.Hout = d.Wout = 1;
     d.Cout = NC; d.ldc = ldz; d.tag = MAGAT_TAG_GAT_MAPS; d.in_fmt = use_f16 ? 4 : 2;
     if (ntile_stride) { d.ldc = 128; d.out_ntile_stride = ntile_stride; }
-    return magat_conv_gemm_f32(&d, stream);
+    d.range_flag = guard ? status : nullptr;
+    int rc = magat_conv_gemm_f32(&d, stream);
+    if (rc != MAGAT_OK || !guard) return rc;
+    const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);
+    rc = gat_maps_gemm_f32(X, packed, Z, M, G, NC, ldz, stream, ntile_stride, status, MAGAT_TAG_UNTAGGED);
+    if (rc == MAGAT_OK) {
+      hipLaunchKernelGGL(gat_guard_count_kernel, dim3(1), dim3(1), 0, st, status);
+      if (hipGetLastError() != hipSuccess) rc = MAGAT_ERR_LAUNCH;
+    }
+    magat_prof_end(pid, st);
+    return rc;
   }
-  if (ntile_stride) return MAGAT_ERR_UNSUPPORTED;
-  return magat_linear_tagged_f32(X, G, packed, packed + (size_t)NC * G, Z, ldz, M, NC, G, 0, MAGAT_TAG_GAT_MAPS,
-                                 stream);
+  if (ntile_stride && (NC & 127)) return MAGAT_ERR_UNSUPPORTED;
+  return gat_maps_gemm_f32(X, packed, Z, M, G, NC, ldz, stream, ntile_stride, nullptr, MAGAT_TAG_GAT_MAPS);
 }
 
 extern "C" int magat_gat_pack_weights(const float* weight, const float* weight_bias, const float* mixer,
@@ -1057,12 +1094,23 @@ extern "C" int magat_gat_gso_plan(const void* S, int s_is_f64, int mode, void* p
   return hipGetLastError() == hipSuccess ? MAGAT_OK : MAGAT_ERR_LAUNCH;
 }
 
+constexpr size_t GAT_STATUS_BYTES = 256;   // status block (range guard of the maps GEMM) at the head of the workspace
+
+extern "C" int magat_gat_read_status(const void* workspace, int32_t status_host[2], void* stream) {
+  if (!workspace || !status_host) return MAGAT_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(status_host, workspace, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return MAGAT_ERR_LAUNCH;
+  return MAGAT_OK;
+}
+
 extern "C" size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, int P, int mode, int concat) {
   if (B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
   const PackLayout L = pack_layout(G, F, K, P, mode);
   const int ldz = L.NC + gat_zpad();
   const int chunk = gat_chunk_instances(B, N, ldz);
-  size_t bytes = magat_align_up((size_t)chunk * N * ldz * sizeof(float), 256);
+  size_t bytes = GAT_STATUS_BYTES + magat_align_up((size_t)chunk * N * ldz * sizeof(float), 256);
   if (!concat) bytes += magat_align_up((size_t)B * N * P * F * sizeof(float), 256);
   return bytes;
 }
@@ -1088,8 +1136,9 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
   const PackLayout L = pack_layout(G, F, K, P, mode);
   const int ldz = L.NC + gat_zpad();
   const int chunk = gat_chunk_instances(B, N, ldz);
-  float* Z = static_cast<float*>(workspace);
-  float* Ytmp = reinterpret_cast<float*>(static_cast<char*>(workspace) +
+  int32_t* status = static_cast<int32_t*>(workspace);
+  float* Z = reinterpret_cast<float*>(static_cast<char*>(workspace) + GAT_STATUS_BYTES);
+  float* Ytmp = reinterpret_cast<float*>(static_cast<char*>(workspace) + GAT_STATUS_BYTES +
                                          magat_align_up((size_t)chunk * N * ldz * sizeof(float), 256));
   GatParams p;
   p.order = nullptr;
@@ -1122,7 +1171,9 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     const bool ztiles = G == 128 && F == 128 && L.NC % 128 == 0 && magat_conv_direct_enabled() &&
                         magat_opt(MAGAT_OPT_GAT_ZTILES) && magat_opt(MAGAT_OPT_GAT_SPLIT) && magat_opt(MAGAT_OPT_CONV_F16);
     p.zts = ztiles ? (long long)cb * N * 128 : 0;
-    int rc = magat_gat_maps_gemm(X + (size_t)b0 * N * G, packed, Z, cb * N, G, L.NC, ldz, stream, p.zts);
+    // (one chunk is the rule; with several, a clamp in an earlier chunk leaves the flag set only until the next chunk's
+    // own GEMM clears it - status[1] still counts every re-run)
+    int rc = magat_gat_maps_gemm(X + (size_t)b0 * N * G, packed, Z, cb * N, G, L.NC, ldz, stream, p.zts, status);
     if (rc != MAGAT_OK) return rc;
     p.B = cb; p.b0 = b0;
     // heads per workgroup: when the LDS tiles allow only one workgroup per CU there is nothing to overlap a
@@ -1220,7 +1271,7 @@ extern "C" int magat_gso_prepare(void* S, int s_is_f64, size_t count, int scrub_
   return magat_check_launch();
 }
 
-extern "C" int magat_abi_version(void) { return 1; }
+extern "C" int magat_abi_version(void) { return 2; }
 
 extern "C" const char* magat_error_string(int code) {
   switch (code) {

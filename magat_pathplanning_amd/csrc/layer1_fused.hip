@@ -36,6 +36,7 @@ struct L1Params {
   void* out;                 // [tile][Ho*Wo] plane-granule tiles of 32 channels (layer1.conv1 output)
   void* ctr;                 // same geometry: stem output at pixels (2 oy, 2 ox)
   int M, H, W, Ho, Wo, Mt;
+  int* range_flag;           // range guard: OR-ed with 1 when the 16x stem output or the layer1.conv1 output had to be clamped
 };
 
 __device__ __forceinline__ void split2(float x, float y, unsigned& p1, unsigned& p2) {
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
     f32x16 acc1, acc1b;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] = acc1b[r] = 0.f;
+    bool clamped = false;
 
     for (int ty = ty0; ty < ty1; ++ty)
       for (int tx = tx0; tx < tx1; ++tx) {
@@ -233,6 +235,12 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
                                                           __builtin_bit_cast(f16x8, pb[ks][PA[q]]), acc0, 0, 0, 0);
         // 3. ReLU (the lower bound of the f16 clamp) -> f16 planes = layer1.conv1's operand of this tap (quads 2 ks,
         //    2 ks + 1 -> k step ks), still 16x
+        {
+          float mx = acc0[0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc0[r]);
+          clamped |= mx > 65504.f;                       // stem output beyond 4094: outside what the 16x form carries
+        }
         u32x4 qa[2][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -294,7 +302,10 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
           const int g = 2 * ks + e;
           float v[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = fmaxf((acc1[4 * g + c] + acc1b[4 * g + c]) * scale1 + bq1[g][c], 0.f);
+          for (int c = 0; c < 4; ++c) {
+            v[c] = fmaxf((acc1[4 * g + c] + acc1b[4 * g + c]) * scale1 + bq1[g][c], 0.f);
+            clamped |= v[c] > 65504.f;
+          }
           split2(v[0], v[1], h1[2 * e], h2[2 * e]);
           split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1]);
         }
@@ -302,6 +313,7 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
         *reinterpret_cast<u32x4*>(o + 256 * 32 + ks * 4096) = u32x4{h2[0], h2[1], h2[2], h2[3]};
       }
     }
+    if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
   }
 }
 
@@ -318,7 +330,7 @@ size_t magat_layer1_fused_lds(int W) {
 // x (M,3,H,W) -> out, ctr: [ceil(M/128)][Ho*Wo] plane-granule tiles of 32 channels (128*32*4 bytes each), Ho = (H-1)/2+1.
 // w1 = f16 planes [2][32][288] of layer1.conv1 (K-permuted copy of the encoder pack) followed by the float 2^-e.
 int magat_layer1_fused(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, void* out,
-                       void* ctr, int M, int H, int W, hipStream_t st) {
+                       void* ctr, int M, int H, int W, hipStream_t st, int* range_flag) {
   if (!x || !w0 || !b0 || !w1 || !b1 || !out || !ctr) return MAGAT_ERR_NULL;
   if (M <= 0 || H < 3 || W < 4) return MAGAT_ERR_BAD_SHAPE;
   if ((reinterpret_cast<uintptr_t>(b0) & 15) || (reinterpret_cast<uintptr_t>(b1) & 15) ||
@@ -328,6 +340,7 @@ int magat_layer1_fused(const float* x, const float* w0, const float* b0, const f
   p.x = x; p.w0 = w0; p.b0 = b0; p.w1 = reinterpret_cast<const unsigned short*>(w1); p.b1 = b1; p.out = out; p.ctr = ctr;
   p.M = M; p.H = H; p.W = W; p.Ho = (H + 2 - 3) / 2 + 1; p.Wo = (W + 2 - 3) / 2 + 1;
   p.Mt = (M + 127) / 128;
+  p.range_flag = range_flag;
   const long long groups = (p.Mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD;
   const long long grid = groups * MAGAT_NUM_XCD * p.Ho;
   if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;

@@ -24,7 +24,7 @@ void magat_prof_end(int id, hipStream_t st);
 // bf16x6 split-MFMA GEMM (conv_gemm_bf16x6.hip), reached through magat_conv_gemm_f32 when desc->in_fmt == 1
 int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st);
 int magat_layer1_fused(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, void* out,
-                       void* ctr, int M, int H, int W, hipStream_t st);   // layer1_fused.hip
+                       void* ctr, int M, int H, int W, hipStream_t st, int* range_flag = nullptr);   // layer1_fused.hip
 size_t magat_layer1_fused_lds(int W);   // 0: the fused kernel does not take this map width
 int magat_conv_direct_enabled();   // f16x3 direct kernel on (option CONV_DIRECT, default 1)
 
@@ -57,7 +57,9 @@ __host__ __device__ inline size_t magat_gat_f16_block_offset(int NC, int G) {
 // hoisted GAT maps Z [M][ldz >= NC] = X [M][G] @ Bt^T + colbias from the packed weights (gat_f32.hip): bf16x6 split when
 // NC % 32 == 0 and G % 32 == 0, else fp32 MFMA
 int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, int G, int NC, int ldz, void* stream,
-                        long long ntile_stride = 0);   // > 0: Z in 128-column tiles ntile_stride floats apart (row stride 128)
+                        long long ntile_stride = 0,    // > 0: Z in 128-column tiles ntile_stride floats apart (row stride 128)
+                        int32_t* status = nullptr,     // range guard status words (device int32[2]) or null: unguarded
+                        int force_f32 = 0);            // 1: float32 MFMA kernel (training: Z feeds the backward)
 
 // fp32 -> three bf16 planes (round-to-nearest-even each)
 __device__ __forceinline__ unsigned short magat_bf16_rne(float v) {

@@ -30,6 +30,15 @@ class _Scratch:
         self.workspace = None
 
 
+def _workspace(sc, need, dev):
+    """Caller-owned workspace of a layer.  Its first 256 bytes are the range-guard status block (magat_gat_read_status):
+    zeroed once, here, when the buffer is (re)allocated."""
+    if sc.workspace is None or sc.workspace.numel() < need or sc.workspace.device != dev:
+        sc.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        sc.workspace[:256].zero_()
+    return sc.workspace
+
+
 def _param_key(*tensors):
     return tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
 
@@ -101,8 +110,7 @@ def gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=None, want_attention
         stream = nat.current_stream(dev)
         packed = _packed_weights(layer, dev, stream, G, F, K, P, mode)
         need = ws_fn(B, N, nnz, G, F, K, P, mode, concat)
-        if sc.workspace is None or sc.workspace.numel() < need or sc.workspace.device != dev:
-            sc.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        _workspace(sc, need, dev)
         if out is None:
             out = torch.empty(B * N, width, dtype=sdt, device=dev)
         elif out.dtype != sdt:
@@ -209,8 +217,7 @@ def gat_forward_rows(X, S, layer, out=None, want_attention=False, plan=None):
         stream = nat.current_stream(dev)
         _packed_weights(layer, dev, stream, G, F, K, P, mode)
         need = lib.magat_gat_workspace_bytes(B, N, G, F, K, P, mode, concat)
-        if sc.workspace is None or sc.workspace.numel() < need or sc.workspace.device != dev:
-            sc.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        _workspace(sc, need, dev)
         if out is None:
             out = torch.empty(B * N, width, dtype=torch.float32, device=dev)
         ldy = out.stride(0)
@@ -607,8 +614,7 @@ class GraphFilterBatch(nn.Module):
                                                          self.K, 1, nat.MODE_GNN, stream), "magat_gat_pack_weights")
                     sc.packed_key = key
                 need = lib.magat_gat_csr_workspace_bytes(B, N, nnz, self.G, self.F, self.K, 1, nat.MODE_GNN, 1)
-                if sc.workspace is None or sc.workspace.numel() < need or sc.workspace.device != dev:
-                    sc.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+                _workspace(sc, need, dev)
                 out = torch.empty(B * N, self.F, dtype=torch.float32, device=dev)
                 bias = None if self.bias is None else self.bias.detach().to(dev, torch.float32).reshape(-1).contiguous()
                 nat.check(lib.magat_gnn_forward_csr_f32(

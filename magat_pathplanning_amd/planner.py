@@ -184,6 +184,27 @@ class DecentralPlannerGATNet(nn.Module):
     def returnAttentionGSO(self):
         return self.GFL[0].returnAttentionGSO()
 
+    def range_status(self):
+        """Range guard of the split arithmetic (include/magat_hip.h): did the LAST inference forward leave the range the
+        f16 planes carry exactly, so that the encoder / the graph layer's maps were re-run on the float32 MFMA kernels
+        (same stream, automatic), and how often has that happened since the workspaces were allocated.  Synchronises."""
+        out = {"encoder_rerun": False, "encoder_reruns": 0, "gat_rerun": False, "gat_reruns": 0}
+        lib = nat.lib()
+        st = (ctypes.c_int32 * 2)()
+        rt = self._rt
+        if rt is not None and rt.ws is not None:
+            with torch.cuda.device(rt.ws.device):
+                nat.check(lib.magat_encoder_read_status(nat.ptr(rt.ws), st, nat.current_stream(rt.ws.device)),
+                          "magat_encoder_read_status")
+            out["encoder_rerun"], out["encoder_reruns"] = bool(st[0]), int(st[1])
+        ws = self.GFL[0]._scratch.workspace
+        if ws is not None and self.GFL[0].storage_dtype != torch.bfloat16:
+            with torch.cuda.device(ws.device):
+                nat.check(lib.magat_gat_read_status(nat.ptr(ws), st, nat.current_stream(ws.device)),
+                          "magat_gat_read_status")
+            out["gat_rerun"], out["gat_reruns"] = bool(st[0]), int(st[1])
+        return out
+
     def forward(self, inputTensor):
         (B, N, C, W, H) = inputTensor.shape
         dev = torch.device(self.config.device)
@@ -354,6 +375,7 @@ class DecentralPlannerGATNet(nn.Module):
                 need = lib.magat_encoder_workspace_bytes(ctypes.byref(rt.desc), M)
                 if rt.ws is None or rt.ws.numel() < need or rt.ws.device != dev:
                     rt.ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                    rt.ws[:256].zero_()          # range-guard status block (magat_encoder_read_status)
                 nat.check(lib.magat_encoder_forward_f32(ctypes.byref(rt.desc), nat.ptr(x), nat.ptr(feat), nfm,
                                                         nat.ptr(comp), G, nat.ptr(rt.ws), rt.ws.numel(), M, stream),
                           "magat_encoder_forward_f32")

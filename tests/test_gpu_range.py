@@ -1,0 +1,144 @@
+"""Range guard of the split arithmetic (include/magat_hip.h "Range guard"): the f16x3 convolutions / maps carry every value
+as two half-precision planes, exact within +-65504 (the fused stem: 4094); a checkpoint whose activations leave that range
+must not silently lose the 1e-4 parity.  The guard is on the device: the split kernels OR a flag when they clamp, the
+encoder / the graph layer's maps re-run on the float32 MFMA kernels in the same stream predicated on it, and a status
+word says so.  Tolerances are RELATIVE to the logit scale with the north star's absolute 1e-4 as the floor:
+|hip - oracle| <= 1e-4 * max(1, max|oracle logits|)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scaled_model(device, scale, N=20, K=3, P=4, seed=11, where="stem"):
+    """Reference-initialised weights with one BatchNorm's gamma / beta scaled: every activation behind it scales with
+    it (eval-mode BN does not renormalise), like a trained checkpoint with a small running_var / large gamma would."""
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    from magat_pathplanning_amd.synthetic import make_config
+    from oracle import magat_oracle as orc
+    cfg = make_config(num_agents=N, nGraphFilterTaps=K, nAttentionHeads=P, bottleneckMode="BottomNeck_skipConcat",
+                      device=str(device))
+    sd = orc.init_state_dict(cfg, seed=seed)
+    key = {"stem": "ConvLayers.0.bn1", "layer2": "ConvLayers.0.layer2.0.bn1",
+           "compress": None}[where]
+    if key is not None:
+        sd[key + ".weight"] = sd[key + ".weight"] * scale
+        sd[key + ".bias"] = sd[key + ".bias"] * scale
+    else:       # the compressMLP output X feeds the graph layer's f16x3 maps
+        sd["compressMLP.0.weight"] = sd["compressMLP.0.weight"] * scale
+        sd["compressMLP.0.bias"] = sd["compressMLP.0.bias"] * scale
+    net = DecentralPlannerGATNet(cfg)
+    net.load_state_dict(sd)
+    return cfg, sd, net.to(device).eval()
+
+
+def _run(net, cfg, sd, device, B=4, N=20):
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states
+    from oracle import magat_oracle as orc
+    x, S = fov_states(B, N, seed=5), comm_gso(B, N, 28, seed=6)
+    ref = orc.planner_forward(x.double(), S.clone().double(), {k: (v.double() if v.is_floating_point() else v)
+                                                                for k, v in sd.items()}, cfg).float()
+    with torch.no_grad():
+        net.addGSO(S.clone().to(device))
+        got = net(x.to(device)).cpu()
+    return got, ref
+
+
+@pytest.mark.parametrize("where,scale,expect_enc,expect_gat", [
+    ("stem", 1.0, False, False),          # the reference's init: nothing near the range limits
+    ("stem", 3.0e3, False, False),        # activations up to ~3e3 everywhere: inside the planes' range, no re-run
+    ("stem", 1.0e4, True, None),          # stem output ~1e4 > 4094 (the fused stem carries it 16x): re-run in fp32
+    ("layer2", 2.0e3, False, False),      # block-internal BN, maps up to ~3e3: in range
+    ("layer2", 1.0e5, True, None),        # layer2 / layer3 maps ~1e5 > 65504: re-run in fp32
+    ("stem", 1.0e-4, False, False),       # tiny activations: absolute error floor of the f16 planes (3e-8 per value)
+    ("compress", 1.0e4, False, False),    # graph-layer input X ~1.7e4: in range
+    ("compress", 1.0e5, False, True),     # X ~1.7e5 > 65504: encoder fine, the layer's maps re-run in fp32
+])
+def test_scaled_checkpoints_keep_parity(gpu_device, where, scale, expect_enc, expect_gat):
+    cfg, sd, net = _scaled_model(gpu_device, scale, where=where)
+    got, ref = _run(net, cfg, sd, gpu_device)
+    st = net.range_status()
+    lim = 1e-4 * max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    print("range case %s x%g: max|logit| %.3g, err %.3g (limit %.3g), status %s" % (where, scale, float(ref.abs().max()), err, lim, st))
+    assert torch.isfinite(got).all()
+    assert err <= lim, (where, scale, err, lim, st)
+    assert st["encoder_rerun"] == expect_enc, st
+    if expect_gat is not None:
+        assert st["gat_rerun"] == expect_gat, st
+
+
+def test_guard_off_shows_what_it_protects_from(gpu_device, libopt):
+    """With the guard disabled the same out-of-range checkpoint silently loses parity (the clamp is real) - and the status
+    stays clear because nothing is tracked."""
+    cfg, sd, net = _scaled_model(gpu_device, 1.0e4, where="stem")
+    libopt.set("MAGAT_RANGE_GUARD", 0)
+    got, ref = _run(net, cfg, sd, gpu_device)
+    lim = 1e-4 * max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) > lim
+    libopt.reset("MAGAT_RANGE_GUARD")
+    got, ref = _run(net, cfg, sd, gpu_device)
+    assert float((got - ref).abs().max()) <= lim
+    assert net.range_status()["encoder_rerun"]
+
+
+def test_mx_opt_in_is_guarded_too(gpu_device, libopt):
+    """OPT-IN f16 + block-scaled-fp8 correction form: its e4m3 planes saturate beyond +-448.  Activations in the thousands
+    (fine for f16x3) trip the flag there and the float32 re-run restores parity."""
+    libopt.set("MAGAT_CONV_MX", 1)
+    cfg, sd, net = _scaled_model(gpu_device, 1000.0, where="layer2")
+    got, ref = _run(net, cfg, sd, gpu_device)
+    st = net.range_status()
+    lim = 1e-4 * max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) <= lim, (float((got - ref).abs().max()), lim, st)
+    assert st["encoder_rerun"], st
+    # the same checkpoint on the default f16x3 arithmetic stays inside the planes' range: no re-run
+    libopt.reset("MAGAT_CONV_MX")
+    got, ref = _run(net, cfg, sd, gpu_device)
+    assert float((got - ref).abs().max()) <= lim
+    assert not net.range_status()["encoder_rerun"]
+
+
+def test_split_gemm_reports_clamps_through_the_c_abi(gpu_device):
+    """magat_conv_gemm_desc.range_flag / run_if: the f16x3 GEMM ORs the flag exactly when an input left +-65504, and the
+    float32 kernel with run_if pointing at a zero word does not touch its output."""
+    from magat_pathplanning_amd import _native as nat
+    from magat_pathplanning_amd.encoder import split_f16x2
+    lib = nat.lib()
+    M, K, Nc = 256, 128, 128
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(Nc, K, generator=g) / K ** 0.5).contiguous()
+    ws = split_f16x2(w)[0].to(gpu_device)
+    wd, bd = w.to(gpu_device), torch.zeros(Nc, device=gpu_device)
+    for big in (False, True):
+        x = torch.randn(M, K, generator=g)
+        if big:
+            x[17, 5] = 7.0e4
+        xd = x.to(gpu_device)
+        flag = torch.zeros(2, dtype=torch.int32, device=gpu_device)
+        out = torch.empty(M, Nc, device=gpu_device)
+        d = nat.ConvGemmDesc()
+        d.inp, d.wt, d.bias, d.out = xd.data_ptr(), ws.data_ptr(), bd.data_ptr(), out.data_ptr()
+        d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, K, K, 1, 1, 1, 1, 1, 0
+        d.Hout, d.Wout, d.Cout, d.ldc, d.in_fmt = 1, 1, Nc, Nc, 4
+        d.range_flag = flag.data_ptr()
+        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "f16x3 gemm")
+        torch.cuda.synchronize()
+        assert int(flag[0]) == (1 if big else 0)
+        # predicated float32 kernel: runs iff the flag is set
+        out2 = torch.full((M, Nc), -7.0, device=gpu_device)
+        d2 = nat.ConvGemmDesc()
+        d2.inp, d2.wt, d2.bias, d2.out = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out2.data_ptr()
+        d2.M, d2.Cin, d2.lda, d2.Hin, d2.Win, d2.kH, d2.kW, d2.stride, d2.pad = M, K, K, 1, 1, 1, 1, 1, 0
+        d2.Hout, d2.Wout, d2.Cout, d2.ldc = 1, 1, Nc, Nc
+        d2.run_if = flag.data_ptr()
+        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d2), nat.current_stream(gpu_device)), "predicated f32 gemm")
+        torch.cuda.synchronize()
+        if big:
+            ref = x.double() @ w.double().t()
+            assert float((out2.cpu().double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+        else:
+            assert bool((out2 == -7.0).all())
