@@ -871,6 +871,8 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
             *reinterpret_cast<u32x4*>(o + oplane) = u32x4{h2[0], h2[1], h2[2], h2[3]};
           }
         }
+      report_clamped(p.range_flag, clamped);
+      clamped = false;
       continue;
     }
     float* const orow = static_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +

@@ -46,14 +46,15 @@ struct ConvGemmParams {
   long long out_plane;
   long long out_nt;         // > 0: 128-column tile t of the row-major output lives at out + t * out_nt (row stride ldc = 128)
   const int* run_if;        // range-guard re-run: the kernel does nothing unless *run_if != 0 (null: always runs)
+  int vgrid;                // number of tiles (virtual workgroups); the launch grid is smaller only for predicated re-runs
 };
 
 // FULL: M % BM == 0, Cout % BN == 0, Cin % 32 == 0, C2 % 32 == 0 -> the loader has no bounds checks and
 // addresses every 16-byte load as (wave-uniform 64-bit base) + (per-thread 32-bit byte offset).
 // NBUF = 2: register-staged double buffer, one barrier per slab.  NBUF = 1: single LDS buffer, two barriers
 // per slab, half the LDS -> one more workgroup per CU.
-template <int BM, int BN, int WGM, int WGN, bool POOL, bool FULL, int NBUF, int MINW = 1>
-__global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmParams p) {
+template <int BM, int BN, int WGM, int WGN, bool POOL, bool FULL, int NBUF>
+__device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, const int bid) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int AI = BM / 32, BI = BN / 32;  // float4 loads per thread per slab
@@ -64,8 +65,6 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
   // XCD-aware block -> tile map: the dispatcher places block b on XCD b % 8, so give each XCD
   // whole agent tiles (all pixels x all Cout tiles): the tile's inputs stay in that XCD's L2
   // while its <= 9-fold tap re-reads happen.
-  if (p.run_if && *p.run_if == 0) return;
-  const int bid = blockIdx.x;
   const int xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
   const int per_m = p.npix * p.ntn;
   const int mtile = xcd + MAGAT_NUM_XCD * (slot / per_m);
@@ -331,6 +330,18 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
   }
 }
 
+// Normal launches: one workgroup per tile (gridDim.x == vgrid: the loop runs once).  The range guard's predicated re-run
+// (run_if set) is launched with a SMALL grid whose workgroups walk the tiles - when the flag is clear, which is the rule,
+// a few hundred workgroups return at once instead of tens of thousands being dispatched for nothing.
+template <int BM, int BN, int WGM, int WGN, bool POOL, bool FULL, int NBUF, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmParams p) {
+  if (p.run_if && *p.run_if == 0) return;
+  for (int bid = blockIdx.x; bid < p.vgrid; bid += gridDim.x) {
+    conv_gemm_tile<BM, BN, WGM, WGN, POOL, FULL, NBUF>(p, bid);
+    if (bid + (int)gridDim.x < p.vgrid) __syncthreads();     // the next tile reuses the LDS stages
+  }
+}
+
 int conv_variant() { return magat_opt(MAGAT_OPT_CONV_VARIANT); }
 
 template <int BM, int BN, int WGM, int WGN, bool POOL, bool FULL>
@@ -341,10 +352,12 @@ int launch2(ConvGemmParams& p, hipStream_t st, long long grid) {
   // (4 waves/SIMD, 11 spilled VGPRs) adds another 2-3 % (131.6 TF).  MAGAT_CONV_VARIANT=9 keeps the
   // double-buffered kernel selectable for A/B runs.
   constexpr int MINW = (BM == 128 && BN == 128) ? 4 : 1;
+  p.vgrid = (int)grid;
+  const unsigned launch_grid = (unsigned)((p.run_if && grid > 512) ? 512 : grid);
   if (conv_variant() != 9)
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, POOL, FULL, 1, MINW>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, POOL, FULL, 1, MINW>), dim3(launch_grid), dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, POOL, FULL, 2>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, POOL, FULL, 2>), dim3(launch_grid), dim3(256), 0, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }

@@ -198,9 +198,13 @@ __global__ __launch_bounds__(256) void head_sum_kernel(const float* __restrict__
   *reinterpret_cast<f32x4*>(feat + (long long)m * ldfeat + n) = acc;
 }
 
-// range guard bookkeeping: status[0] = flag of this forward, status[1] += 1 when the float32 re-run happened
+// range guard bookkeeping at the end of a forward: status[2] = this forward's flag, status[1] += 1 when the float32 re-run
+// happened, and the working flag status[0] is cleared for the next forward (no memset launch per forward)
 __global__ void guard_count_kernel(int* status) {
-  if (status[0] != 0) status[1] += 1;
+  const int f = status[0];
+  status[2] = f;
+  if (f != 0) status[1] += 1;
+  status[0] = 0;
 }
 
 }  // namespace
@@ -226,11 +230,17 @@ static int conv_first_launch(const float* x, const float* wt, const float* bias,
   if (!x || !wt || !bias || !out) return MAGAT_ERR_NULL;
   if (M <= 0 || H <= 0 || W <= 0) return MAGAT_ERR_BAD_SHAPE;
   const size_t lds = sizeof(float) * 32 * (size_t)((3 * (H + 2) * (W + 2)) | 1);
-  if (lds > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  if (lds > 160 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  const bool c11 = H == 11 && W == 11 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  if (lds > 64 * 1024 &&
+      magat_ensure_dyn_lds(c11 ? reinterpret_cast<const void*>(&conv_first_kernel<11, 11>)
+                               : reinterpret_cast<const void*>(&conv_first_kernel<0, 0>),
+                           c11 ? MAGAT_LDS_CONV_FIRST11 : MAGAT_LDS_CONV_FIRST, lds) != MAGAT_OK)
+    return MAGAT_ERR_LAUNCH;
   const int blocks = (M + 31) / 32;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int pid = magat_prof_begin(tag, st);
-  if (H == 11 && W == 11 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+  if (c11)
     hipLaunchKernelGGL((conv_first_kernel<11, 11>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W,
                        pix_stride, tile_stride, out_plane, out_gl, range_flag, run_if);
   else
@@ -275,9 +285,12 @@ extern "C" size_t magat_encoder_workspace_bytes(const magat_encoder_desc* d, int
 extern "C" int magat_encoder_read_status(const void* workspace, int32_t status_host[2], void* stream) {
   if (!workspace || !status_host) return MAGAT_ERR_NULL;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemcpyAsync(status_host, workspace, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+  int32_t w[3];
+  if (hipMemcpyAsync(w, workspace, sizeof(w), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)
     return MAGAT_ERR_LAUNCH;
+  status_host[0] = w[2];      // the last forward's flag
+  status_host[1] = w[1];      // re-run count
   return MAGAT_OK;
 }
 
@@ -523,12 +536,6 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   // are recomputed in true fp32 before anything downstream reads them.
   const int split = enc_split_mask(d, magat_opt(MAGAT_OPT_CONV_SPLIT));
   const bool guard = split != 0 && magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
-  if (guard) {
-    const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);
-    const hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), st);
-    magat_prof_end(pid, st);
-    if (e != hipSuccess) return MAGAT_ERR_LAUNCH;
-  }
   int rc = enc_run_resnet(d, x, feat, ldfeat, comp, ldcomp, bufbase, M, stream, split, guard ? status : nullptr, nullptr);
   if (rc != MAGAT_OK || !guard) return rc;
   const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);

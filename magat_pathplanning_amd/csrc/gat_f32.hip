@@ -902,25 +902,22 @@ static int gat_maps_gemm_f32(const float* X, const float* packed, float* Z, int 
   return magat_conv_gemm_f32(&d, stream);
 }
 
-__global__ void gat_guard_count_kernel(int* status) {
-  if (status[0] != 0) status[1] += 1;
+__global__ void gat_guard_count_kernel(int* status) {     // see guard_count_kernel (encoder_f32.hip)
+  const int f = status[0];
+  status[2] = f;
+  if (f != 0) status[1] += 1;
+  status[0] = 0;
 }
 
-// status (device int32[2], may be null): range guard of the f16x3 form - [0] is cleared, OR-ed by the split GEMM when it had
-// to clamp an X value into its f16 planes, and a float32-MFMA GEMM predicated on it re-writes Z in the same stream
-// ([1] counts such re-runs).  force_f32: skip the split form altogether.
+// status (device int32[3], may be null): range guard of the f16x3 form - the working flag [0] (zero between forwards) is
+// OR-ed by the split GEMM when it had to clamp an X value into its f16 planes, a float32-MFMA GEMM predicated on it re-writes
+// Z in the same stream, and a one-thread kernel moves the flag to [2], counts re-runs in [1] and clears [0].  force_f32: skip the split form altogether.
 int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, int G, int NC, int ldz, void* stream,
                         long long ntile_stride, int32_t* status, int force_f32) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!force_f32 && magat_opt(MAGAT_OPT_GAT_SPLIT) && NC % 32 == 0 && G % 32 == 0) {
     const int use_f16 = magat_opt(MAGAT_OPT_CONV_F16);
     const bool guard = status && use_f16 && magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
-    if (guard) {
-      const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);
-      const hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), st);
-      magat_prof_end(pid, st);
-      if (e != hipSuccess) return MAGAT_ERR_LAUNCH;
-    }
     magat_conv_gemm_desc d = {};
     d.in = X;
     d.wt = use_f16 ? packed + magat_gat_f16_block_offset(NC, G) : packed + (((size_t)NC * (G + 1) + 3) & ~(size_t)3);
@@ -1099,9 +1096,12 @@ constexpr size_t GAT_STATUS_BYTES = 256;   // status block (range guard of the m
 extern "C" int magat_gat_read_status(const void* workspace, int32_t status_host[2], void* stream) {
   if (!workspace || !status_host) return MAGAT_ERR_NULL;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemcpyAsync(status_host, workspace, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+  int32_t w[3];
+  if (hipMemcpyAsync(w, workspace, sizeof(w), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)
     return MAGAT_ERR_LAUNCH;
+  status_host[0] = w[2];
+  status_host[1] = w[1];
   return MAGAT_OK;
 }
 

@@ -251,7 +251,7 @@ def test_encoder_paths_agree(gpu_device, monkeypatch, cnn, libopt):
 def test_encoder_other_map_sizes(gpu_device, monkeypatch, hw, cnn, libopt):
     """The encoder C entry at map sizes other than the reference's 11x11 (its ResNet heads hard-wire 1152 features, so
     this is below the module level): fused stem + layer1.conv1 (odd / even output widths, maps up to 15 wide: the LDS limit of its windows),
-    plane-granule chain, float32-granule chain and - up to 11x11, the LDS limit of the stand-alone stem kernel - the
+    plane-granule chain, float32-granule chain and the
     two-kernel path, against the oracle's conv stack."""
     import ctypes
     from oracle import magat_oracle as orc
@@ -275,7 +275,7 @@ def test_encoder_other_map_sizes(gpu_device, monkeypatch, hw, cnn, libopt):
     ws = torch.empty(lib.magat_encoder_workspace_bytes(ctypes.byref(d), M), dtype=torch.uint8, device=gpu_device)
     scale = float(ref.abs().max())
     outs = []
-    envs = [{}] + ([{"MAGAT_L1_FUSED": "0"}, {"MAGAT_CONV_PCHAIN": "0"}] if hw <= 11 else [])
+    envs = [{}, {"MAGAT_L1_FUSED": "0"}, {"MAGAT_CONV_PCHAIN": "0"}]
     for env in envs:
         for k, v in env.items():
             libopt.set(k, v)
