@@ -190,6 +190,28 @@ int magat_sim_move(const float* logits, const int32_t* actions_in, const uint8_t
                    int32_t* pos, const int32_t* goal, int32_t* actions_out, int8_t* moves_out, uint8_t* reached_out,
                    int32_t* flags_out, int B, int N, void* stream);
 
+/* Dense GSO -> everything the CSR kernels need, for N <= 1024, in ONE streaming pass over S plus one small kernel, with no
+ * host synchronisation: addGSO's in-place scrub (scrub_nan / gso_mode 0|1 as magat_gso_prepare; values are written back only
+ * where they change), the edge test (edge_rule: 0 |S| > 1e-9 in S's dtype, 1 GAT_origin |float(S) + I| > 1e-9, 2 float(S) != 0)
+ * -> rowptr [B*(N+1)] absolute offsets, colidx (ascending j per row), cscptr [B*(N+1)], cscsrc / cscpos (per in-edge, ascending
+ * source row: source and CSR position).  cap = capacity of colidx / cscsrc / cscpos in entries (B*N*N can never overflow;
+ * entries beyond cap are dropped and *nnz_dev, the device-side edge total, tells).  The forward entry points take `nnz` only
+ * as the stride of their per-head attention buffers and for sizing: pass the same cap there.  Workspace: magat_gso_csr_
+ * workspace_bytes (bit matrix, N*N/8 bytes per instance; 0 = N too large, use the two calls below). */
+size_t magat_gso_csr_workspace_bytes(int B, int N);
+int magat_gso_csr_build(void* S, int s_is_f64, int scrub_nan, int gso_mode, int edge_rule, int* rowptr, int* colidx,
+                        int* cscptr, int* cscsrc, int* cscpos, long long cap, long long* nnz_dev, void* workspace,
+                        size_t workspace_bytes, int B, int N, void* stream);
+/* magat_gat_forward_csr_{f32,bf16} with the CSC view from magat_gso_csr_build (no per-call transpose) */
+int magat_gat_forward_csc_f32(const float* X, const int* rowptr, const int* colidx, const int* cscptr, const int* cscsrc,
+                              const int* cscpos, long long nnz, const float* packed, const float* bias, float* Y, int ldy,
+                              float* att_opt, void* workspace, size_t workspace_bytes, int B, int N, int G, int F, int K,
+                              int P, int mode, int concat, void* stream);
+int magat_gat_forward_csc_bf16(const uint16_t* X, const int* rowptr, const int* colidx, const int* cscptr,
+                               const int* cscsrc, const int* cscpos, long long nnz, const float* packed, const float* bias,
+                               uint16_t* Y, int ldy, float* att_opt, void* workspace, size_t workspace_bytes, int B, int N,
+                               int G, int F, int K, int P, int mode, int concat, void* stream);
+
 /* dense GSO -> CSR in two steps (the caller prefix-sums the degrees in between): per-row edge counts, then column fill */
 int magat_gso_row_degrees(const void* S, int s_is_f64, int self_loops /*edge rule: 0 |S|>1e-9, 1 GAT_origin |float(S)+I|>1e-9, 2 float(S)!=0*/, int* deg /*B*N*/, int B,
                           int N, void* stream);
@@ -363,6 +385,7 @@ int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* 
 #define MAGAT_TAG_RANGE_GUARD 17  /* flag reset + the predicated float32 re-run launches of the range guard (no-ops when clear) */
 #define MAGAT_TAG_BLOCK_CHAIN 18  /* BasicBlock chain kernel (block_fused.hip) */
 #define MAGAT_TAG_GAT_LAYER 19    /* graph kernel with the per-agent maps computed inside (gat_fused.hip) */
+#define MAGAT_TAG_GSO_CSR 20      /* dense GSO -> CSR + CSC structure (magat_gso_csr_build, or the transpose inside *_csr_*) */
 #define MAGAT_PROF_TAGS 24
 int magat_gat_set_debug_buffer(long long* dev_buf); /* [grid][8] int64 phase timestamps of gat_dense_kernel; NULL = off */
 int magat_profile_reserve(int spans);   /* pre-create event pairs (keeps hipEventCreate out of a timed region) */

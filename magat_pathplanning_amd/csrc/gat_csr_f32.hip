@@ -435,7 +435,8 @@ template <typename ST>
 int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz, const float* packed,
                 const float* bias, ST* Y, int ldy, float* att_opt, void* workspace, size_t workspace_bytes, int B,
                 int N, int G, int F, int K, int P, int mode, int concat, void* stream,
-                const float* edge_vals = nullptr) {
+                const float* edge_vals = nullptr, const int* pre_cscptr = nullptr, const int* pre_cscsrc = nullptr,
+                const int* pre_cscpos = nullptr) {
   if (!X || !rowptr || !packed || !Y || (nnz > 0 && !colidx)) return MAGAT_ERR_NULL;
   if (B <= 0 || N <= 0 || nnz < 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
   if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GNN) return MAGAT_ERR_UNSUPPORTED;
@@ -452,9 +453,10 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
   char* ws = static_cast<char*>(workspace);
   const Layout L = layout(G, F, K, P, mode);
   ST* Z = reinterpret_cast<ST*>(ws + w.z);
-  int* cscptr = reinterpret_cast<int*>(ws + w.cscptr);
-  int* cscsrc = reinterpret_cast<int*>(ws + w.cscsrc);
-  int* cscpos = reinterpret_cast<int*>(ws + w.cscpos);
+  const bool have_csc = pre_cscptr && pre_cscsrc && pre_cscpos;     // made by magat_gso_csr_build (once per GSO)
+  int* cscptr = have_csc ? const_cast<int*>(pre_cscptr) : reinterpret_cast<int*>(ws + w.cscptr);
+  int* cscsrc = have_csc ? const_cast<int*>(pre_cscsrc) : reinterpret_cast<int*>(ws + w.cscsrc);
+  int* cscpos = have_csc ? const_cast<int*>(pre_cscpos) : reinterpret_cast<int*>(ws + w.cscpos);
   float* att = gnn ? const_cast<float*>(edge_vals) : (att_opt ? att_opt : reinterpret_cast<float*>(ws + w.att));
   ST* tbuf[2] = {reinterpret_cast<ST*>(ws + w.t0), reinterpret_cast<ST*>(ws + w.t1)};
   ST* Ytmp = reinterpret_cast<ST*>(ws + w.ytmp);
@@ -473,8 +475,8 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
     MAGAT_CSR_DISPATCH(F, run_k1, ST)
     if (rc != MAGAT_OK) return rc;
   } else {
-    if (K > 1) {
-      const int pid = magat_prof_begin(MAGAT_TAG_GAT_PACK, st);
+    if (K > 1 && !have_csc) {
+      const int pid = magat_prof_begin(MAGAT_TAG_GSO_CSR, st);
       int* csctmp = reinterpret_cast<int*>(ws + w.csctmp);
       hipLaunchKernelGGL(csr_transpose_kernel, dim3(B), dim3(256), (size_t)(2 * N + 2) * sizeof(int), st, rowptr, colidx,
                          cscptr, csctmp, N);
@@ -635,6 +637,208 @@ extern "C" int magat_gso_fill_csr(const void* S, int s_is_f64, int self_loops, c
     hipLaunchKernelGGL(gso_fill_csr_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(S),
                        rowstart, colidx, N, rows, self_loops);
   return magat_check_launch();
+}
+
+namespace {
+// ---- GSO -> CSR + CSC in ONE pass over the dense tensor (magat_gso_csr_build) ------------------------------------------
+// The dense (B,N,N) GSO of a large instance is big (4 MB per instance at N = 1000): addGSO's in-place scrub, the edge test
+// and the row degrees are one streaming read of it (written back only where a value changes), leaving a bit matrix
+// (N^2/8 bytes per instance).  A second kernel - one workgroup per instance, the bit matrix in LDS - then produces
+// everything the CSR kernels need, deterministically and without atomics: rowptr / colidx (ascending j per row), cscptr,
+// and per in-edge its source row and CSR position (ascending i per column).
+constexpr int GSO_W64_MAX = 16;          // N <= 1024
+
+template <typename T>
+__global__ __launch_bounds__(256) void gso_mask_kernel(T* __restrict__ S, unsigned long long* __restrict__ masks,
+                                                       int* __restrict__ inst_tot, int N, int W64, long long rows,
+                                                       int scrub_nan, int gso_mode, int rule) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  T* r = S + row * N;
+  const int i = (int)(row % N);
+  int cnt = 0;
+  for (int w = 0; w < W64; ++w) {
+    const int j = w * 64 + lane;
+    bool f = false;
+    if (j < N) {
+      T v = r[j];
+      const T v0 = v;
+      bool dirty = false;
+      if (scrub_nan && v != v) { v = (T)0; dirty = true; }
+      if (gso_mode == 1 && v > (T)0 && v != (T)1) { v = (T)1; dirty = true; }
+      if (dirty) r[j] = v;
+      (void)v0;
+      f = gso_edge(v, j == i, rule);
+    }
+    const unsigned long long m = __ballot(f);
+    cnt += __popcll(m);
+    if (lane == 0) masks[row * W64 + w] = m;
+  }
+  if (lane == 0 && cnt) atomicAdd(&inst_tot[row / N], cnt);
+}
+
+__global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long long* __restrict__ masks,
+                                                             int* __restrict__ inst_tot, int* __restrict__ rowptr,
+                                                             int* __restrict__ colidx, int* __restrict__ cscptr,
+                                                             int* __restrict__ cscsrc, int* __restrict__ cscpos,
+                                                             long long cap, long long* __restrict__ nnz_out, int B, int N,
+                                                             int W64) {
+  extern __shared__ __align__(16) unsigned long long gsm[];
+  unsigned long long* M = gsm;                                   // [N][W64]
+  int* roff = reinterpret_cast<int*>(M + (size_t)N * W64);       // [N+1] exclusive row offsets (local)
+  int* coff = roff + (N + 1);                                    // [N+1] exclusive column offsets (local)
+  __shared__ int part[17];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // absolute offset of this instance = edges of all earlier instances (inst_tot was accumulated by the mask pass)
+  int before = 0;
+  for (int q = t; q < b; q += 1024) before += inst_tot[q];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  if (lane == 0) part[wave] = before;
+  const unsigned long long* src = masks + (size_t)b * N * W64;
+  for (int q = t; q < N * W64; q += 1024) M[q] = src[q];
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < 16; ++w) base += part[w];
+  __syncthreads();
+  // block-wide exclusive scan helper over up to 1024 values (one per thread)
+  auto block_scan = [&](int v, int* out_total) -> int {
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) part[wave] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += part[w];
+    int tot = 0;
+    for (int w = 0; w < 16; ++w) tot += part[w];
+    __syncthreads();
+    *out_total = tot;
+    return wbase + inc - v;
+  };
+  // rows: degrees -> offsets
+  int rdeg = 0;
+  if (t < N)
+    for (int w = 0; w < W64; ++w) rdeg += __popcll(M[t * W64 + w]);
+  int total = 0;
+  const int rex = block_scan(rdeg, &total);
+  if (t < N) roff[t] = rex;
+  if (t == 0) roff[N] = total;
+  // columns: degrees (thread per column walks the rows; a wave reads one broadcast word per row) -> offsets
+  int cdeg = 0;
+  if (t < N) {
+    const int w = t >> 6;
+    const unsigned long long bit = 1ull << (t & 63);
+    for (int i = 0; i < N; ++i) cdeg += (M[i * W64 + w] & bit) ? 1 : 0;
+  }
+  int total2 = 0;
+  const int cex = block_scan(cdeg, &total2);
+  if (t < N) coff[t] = cex;
+  if (t == 0) coff[N] = total;
+  __syncthreads();
+  int* rp = rowptr + (size_t)b * (N + 1);
+  int* cp = cscptr + (size_t)b * (N + 1);
+  for (int q = t; q <= N; q += 1024) {
+    rp[q] = base + roff[q];
+    cp[q] = base + coff[q];
+  }
+  if (b == B - 1 && t == 0 && nnz_out) *nnz_out = (long long)base + total;
+  // colidx: thread per (row, 64-bit word)
+  for (int q = t; q < N * W64; q += 1024) {
+    const int i = q / W64, w = q - i * W64;
+    unsigned long long m = M[q];
+    if (!m) continue;
+    int pos = base + roff[i];
+    for (int u = 0; u < w; ++u) pos += __popcll(M[i * W64 + u]);
+    while (m) {
+      const int bit = __builtin_ctzll(m);
+      m &= m - 1;
+      if (pos < cap) colidx[pos] = w * 64 + bit;
+      ++pos;
+    }
+  }
+  // CSC: thread per column, rows ascending
+  if (t < N) {
+    const int w = t >> 6;
+    const unsigned long long bit = 1ull << (t & 63), below = bit - 1ull;
+    int k = base + coff[t];
+    for (int i = 0; i < N; ++i) {
+      const unsigned long long mw = M[i * W64 + w];
+      if (mw & bit) {
+        int pos = base + roff[i] + __popcll(mw & below);
+        for (int u = 0; u < w; ++u) pos += __popcll(M[i * W64 + u]);
+        if (k < cap) { cscsrc[k] = i; cscpos[k] = pos; }
+        ++k;
+      }
+    }
+  }
+  // leave inst_tot clear for the next build (every workgroup has read what it needs only after ALL of them pass this
+  // point is not guaranteed - so the clearing is done by the NEXT build's memset, see the host code)
+}
+
+}  // namespace
+
+extern "C" size_t magat_gso_csr_workspace_bytes(int B, int N) {
+  if (B <= 0 || N <= 0 || N > 64 * GSO_W64_MAX) return 0;
+  const size_t w64 = (size_t)(N + 63) / 64;
+  return magat_align_up((size_t)B * N * w64 * 8, 256) + magat_align_up((size_t)B * sizeof(int), 256);
+}
+
+extern "C" int magat_gso_csr_build(void* S, int s_is_f64, int scrub_nan, int gso_mode, int edge_rule, int* rowptr,
+                                   int* colidx, int* cscptr, int* cscsrc, int* cscpos, long long cap, long long* nnz_dev,
+                                   void* workspace, size_t workspace_bytes, int B, int N, void* stream) {
+  if (!S || !rowptr || !colidx || !cscptr || !cscsrc || !cscpos) return MAGAT_ERR_NULL;
+  if (B <= 0 || N <= 0 || cap < 0 || edge_rule < 0 || edge_rule > 2 || gso_mode < 0 || gso_mode > 1)
+    return MAGAT_ERR_BAD_SHAPE;
+  const size_t need = magat_gso_csr_workspace_bytes(B, N);
+  if (!need) return MAGAT_ERR_UNSUPPORTED;                      // N > 1024: magat_gso_row_degrees / magat_gso_fill_csr
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < need) return MAGAT_ERR_WORKSPACE;
+  const int W64 = (N + 63) / 64;
+  const size_t lds = (size_t)N * W64 * 8 + (size_t)2 * (N + 1) * sizeof(int);
+  if (lds > 160 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned long long* masks = static_cast<unsigned long long*>(workspace);
+  int* inst_tot = reinterpret_cast<int*>(static_cast<char*>(workspace) + magat_align_up((size_t)B * N * W64 * 8, 256));
+  const long long rows = (long long)B * N;
+  const int pid = magat_prof_begin(MAGAT_TAG_GSO_CSR, st);
+  if (hipMemsetAsync(inst_tot, 0, (size_t)B * sizeof(int), st) != hipSuccess) return MAGAT_ERR_LAUNCH;
+  const unsigned blocks = (unsigned)((rows + 3) / 4);
+  if (s_is_f64)
+    hipLaunchKernelGGL(gso_mask_kernel<double>, dim3(blocks), dim3(256), 0, st, static_cast<double*>(S), masks, inst_tot,
+                       N, W64, rows, scrub_nan, gso_mode, edge_rule);
+  else
+    hipLaunchKernelGGL(gso_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<float*>(S), masks, inst_tot, N,
+                       W64, rows, scrub_nan, gso_mode, edge_rule);
+  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&gso_structure_kernel), MAGAT_LDS_GSO_STRUCT, lds) != MAGAT_OK)
+    return MAGAT_ERR_LAUNCH;
+  hipLaunchKernelGGL(gso_structure_kernel, dim3(B), dim3(1024), lds, st, masks, inst_tot, rowptr, colidx, cscptr, cscsrc,
+                     cscpos, cap, nnz_dev, B, N, W64);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
+}
+
+// forward with the CSC view made by magat_gso_csr_build (skips the per-call transpose)
+extern "C" int magat_gat_forward_csc_f32(const float* X, const int* rowptr, const int* colidx, const int* cscptr,
+                                         const int* cscsrc, const int* cscpos, long long nnz, const float* packed,
+                                         const float* bias, float* Y, int ldy, float* att_opt, void* workspace,
+                                         size_t workspace_bytes, int B, int N, int G, int F, int K, int P, int mode,
+                                         int concat, void* stream) {
+  if (!cscptr || !cscsrc || !cscpos) return MAGAT_ERR_NULL;
+  return csr_forward<float>(X, rowptr, colidx, nnz, packed, bias, Y, ldy, att_opt, workspace, workspace_bytes, B, N, G,
+                            F, K, P, mode, concat, stream, nullptr, cscptr, cscsrc, cscpos);
+}
+extern "C" int magat_gat_forward_csc_bf16(const uint16_t* X, const int* rowptr, const int* colidx, const int* cscptr,
+                                          const int* cscsrc, const int* cscpos, long long nnz, const float* packed,
+                                          const float* bias, uint16_t* Y, int ldy, float* att_opt, void* workspace,
+                                          size_t workspace_bytes, int B, int N, int G, int F, int K, int P, int mode,
+                                          int concat, void* stream) {
+  if (!cscptr || !cscsrc || !cscpos) return MAGAT_ERR_NULL;
+  return csr_forward<u16>(X, rowptr, colidx, nnz, packed, bias, Y, ldy, att_opt, workspace, workspace_bytes, B, N, G, F,
+                          K, P, mode, concat, stream, nullptr, cscptr, cscsrc, cscpos);
 }
 
 // =====================================================================================================

@@ -28,6 +28,7 @@ class _Scratch:
         self.packed = None
         self.packed_key = None
         self.workspace = None
+        self.csr = None              # CsrStructure built in the forward when addGSO did not hand one over
 
 
 def _workspace(sc, need, dev):
@@ -73,9 +74,12 @@ def dense_gso_to_csr(S3, self_loops=False):
         deg = torch.empty(B * N, dtype=torch.int32, device=dev)
         sl = int(self_loops)          # edge rule: 0 |S|>1e-9, 1 GAT_origin (S + I), 2 float(S) != 0 (GraphFilterBatch)
         nat.check(lib.magat_gso_row_degrees(nat.ptr(S3), f64, sl, nat.ptr(deg), B, N, stream), "magat_gso_row_degrees")
-        ends = torch.cumsum(deg, 0, dtype=torch.int32)
+        ends64 = torch.cumsum(deg, 0, dtype=torch.int64)
+        nnz = int(ends64[-1].item())
+        if nnz >= 2 ** 31:
+            raise nat.MagatNativeError("GSO with %d edges: the CSR index arrays are int32" % nnz)
+        ends = ends64.to(torch.int32)
         starts = (ends - deg).contiguous()
-        nnz = int(ends[-1].item())
         colidx = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
         nat.check(lib.magat_gso_fill_csr(nat.ptr(S3), f64, sl, nat.ptr(starts), nat.ptr(colidx), B, N, stream),
                   "magat_gso_fill_csr")
@@ -85,10 +89,59 @@ def dense_gso_to_csr(S3, self_loops=False):
     return rowptr.reshape(-1).contiguous(), colidx, nnz
 
 
-def gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=None, want_attention=False):
+class CsrStructure:
+    """CSR + CSC edge structure of one GSO tensor, made on the device by magat_gso_csr_build (N <= 1024): one streaming
+    pass over S (with addGSO's scrub fused in) + one small kernel, no host synchronisation.  `cap` is the capacity the index
+    arrays were allocated with (B*N*N: cannot overflow) and what the forward kernels receive as `nnz` (they use it only as
+    a stride); the true edge count lives on the device in `nnz_dev`."""
+
+    _CAP_LIMIT = 1 << 28          # entries; above it the exact (synchronising) path is used
+
+    def __init__(self):
+        self.key = None
+        self.rowptr = self.colidx = self.cscptr = self.csc = self.nnz_dev = self.ws = None
+        self.cap = 0
+
+    @staticmethod
+    def supported(B, N):
+        return nat.lib().magat_gso_csr_workspace_bytes(B, N) > 0 and B * N * N <= CsrStructure._CAP_LIMIT
+
+    def build(self, S3, rule, scrub_nan=0, gso_mode=0):
+        """S3 (B,N,N) contiguous f32|f64 device tensor (scrubbed IN PLACE when asked to)."""
+        lib = nat.lib()
+        B, N, _ = S3.shape
+        dev = S3.device
+        cap = B * N * N
+        with torch.cuda.device(dev):
+            if self.rowptr is None or self.rowptr.numel() != B * (N + 1) or self.cap != cap or self.rowptr.device != dev:
+                self.rowptr = torch.empty(B * (N + 1), dtype=torch.int32, device=dev)
+                self.cscptr = torch.empty(B * (N + 1), dtype=torch.int32, device=dev)
+                self.colidx = torch.empty(cap, dtype=torch.int32, device=dev)
+                self.csc = torch.empty(2, cap, dtype=torch.int32, device=dev)
+                self.nnz_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+                self.ws = torch.empty(lib.magat_gso_csr_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
+                self.cap = cap
+            nat.check(lib.magat_gso_csr_build(
+                nat.ptr(S3), 1 if S3.dtype == torch.float64 else 0, int(scrub_nan), int(gso_mode), int(rule),
+                nat.ptr(self.rowptr), nat.ptr(self.colidx), nat.ptr(self.cscptr), nat.ptr(self.csc[0]),
+                nat.ptr(self.csc[1]), cap, nat.ptr(self.nnz_dev), nat.ptr(self.ws), self.ws.numel(), B, N,
+                nat.current_stream(dev)), "magat_gso_csr_build")
+        self.key = (S3.data_ptr(), B, N, S3.dtype, int(rule), str(dev))
+        return self
+
+    def matches(self, S3, rule):
+        return self.key == (S3.data_ptr(), S3.shape[0], S3.shape[1], S3.dtype, int(rule), str(S3.device))
+
+    def exact_nnz(self):
+        return int(self.nnz_dev.item())
+
+
+def gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=None, want_attention=False, csc=None):
     """CSR / large-graph form (any N).  X (B,N,G) device rows; rowptr int32 [B*(N+1)] absolute offsets; colidx int32.
     X float32 -> fp32 kernels; X bfloat16 -> the bf16-STORAGE kernels (BASELINE config 5: X, maps, hop states and the
-    result are bf16 in HBM, fp32 arithmetic; `out`, if given, must be bfloat16 too).
+    result are bf16 in HBM, fp32 arithmetic; `out`, if given, must be bfloat16 too).  nnz: edge count, or any upper bound
+    the index arrays were allocated with (the kernels use it as a stride / for sizing only).  csc: optional
+    (cscptr, cscsrc, cscpos) made by magat_gso_csr_build - skips the per-call transpose.
     Returns (out (B*N, ld), att (P, nnz) CSR-ordered fp32 attention or None)."""
     if not X.is_cuda:
         raise nat.MagatNativeError("the HIP GAT path needs device tensors; got %s (no CPU fallback)" % X.device)
@@ -102,8 +155,6 @@ def gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=None, want_attention
     X = X.contiguous() if bf16 else X.contiguous().float()
     sdt = torch.bfloat16 if bf16 else torch.float32
     ws_fn = lib.magat_gat_csr_bf16_workspace_bytes if bf16 else lib.magat_gat_csr_workspace_bytes
-    fwd_fn, fwd_name = ((lib.magat_gat_forward_csr_bf16, "magat_gat_forward_csr_bf16") if bf16 else
-                        (lib.magat_gat_forward_csr_f32, "magat_gat_forward_csr_f32"))
     dev = X.device
     sc = layer._scratch
     with torch.cuda.device(dev):
@@ -117,10 +168,16 @@ def gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=None, want_attention
             raise TypeError("out must be %s for %s rows" % (sdt, X.dtype))
         att = torch.empty(P, max(nnz, 1), dtype=torch.float32, device=dev) if want_attention else None
         bias = None if layer.bias is None else layer.bias.detach().to(dev, torch.float32).reshape(-1).contiguous()
-        nat.check(fwd_fn(
-            nat.ptr(X), nat.ptr(rowptr), nat.ptr(colidx), nnz, nat.ptr(packed), nat.ptr(bias), nat.ptr(out),
-            out.stride(0), nat.ptr(att), nat.ptr(sc.workspace), sc.workspace.numel(), B, N, G, F, K, P, mode, concat,
-            stream), fwd_name)
+        tail = (nnz, nat.ptr(packed), nat.ptr(bias), nat.ptr(out), out.stride(0), nat.ptr(att), nat.ptr(sc.workspace),
+                sc.workspace.numel(), B, N, G, F, K, P, mode, concat, stream)
+        if csc is not None:
+            fn = lib.magat_gat_forward_csc_bf16 if bf16 else lib.magat_gat_forward_csc_f32
+            nat.check(fn(nat.ptr(X), nat.ptr(rowptr), nat.ptr(colidx), nat.ptr(csc[0]), nat.ptr(csc[1]), nat.ptr(csc[2]),
+                         *tail), "magat_gat_forward_csc_%s" % ("bf16" if bf16 else "f32"))
+        else:
+            fn = lib.magat_gat_forward_csr_bf16 if bf16 else lib.magat_gat_forward_csr_f32
+            nat.check(fn(nat.ptr(X), nat.ptr(rowptr), nat.ptr(colidx), *tail),
+                      "magat_gat_forward_csr_%s" % ("bf16" if bf16 else "f32"))
     return out, att
 
 
@@ -181,10 +238,11 @@ class GsoPlan:
         return nat.ptr(self.buf)
 
 
-def gat_forward_rows(X, S, layer, out=None, want_attention=False, plan=None):
+def gat_forward_rows(X, S, layer, out=None, want_attention=False, plan=None, csr=None):
     """Kernel-facing form.  X (B,N,G) f32 contiguous device rows; S (B,N,N) or (B,1,N,N) f32|f64;
     out: optional (B*N, ld) float32 view whose first P*F|F columns receive the result.
     plan: optional GsoPlan made from this S (ignored when it was made for another tensor / shape / mode).
+    csr: optional CsrStructure made from this S at addGSO time (large-graph / bf16-storage path).
     Returns (out (B*N, ld) with the result in columns [0, width), aij (B,P,1,N,N) device tensor or None)."""
     if not X.is_cuda:
         raise nat.MagatNativeError("the HIP GAT path needs device tensors; got %s (no CPU fallback)" % X.device)
@@ -208,7 +266,20 @@ def gat_forward_rows(X, S, layer, out=None, want_attention=False, plan=None):
     dev = X.device
     sc = layer._scratch
     if bf16 or not lib.magat_gat_dense_supported(N, G, F):
-        # graph too large for the LDS-resident kernel: same layer through the CSR kernels
+        # graph too large for the LDS-resident kernel (or bf16 storage): same layer through the CSR kernels
+        rule = 1 if layer.attentionMode == "GAT_origin" else 0
+        if CsrStructure.supported(B, N):
+            # structure made on the device, no host synchronisation: at addGSO time (csr), or here
+            if csr is None or not csr.matches(S3, rule):
+                if layer._scratch.csr is None:
+                    layer._scratch.csr = CsrStructure()
+                csr = layer._scratch.csr.build(S3, rule)
+            out, att = gat_forward_rows_csr(X, csr.rowptr, csr.colidx, csr.cap, layer, out=out,
+                                            want_attention=want_attention, csc=(csr.cscptr, csr.csc[0], csr.csc[1]))
+            aij = None
+            if want_attention:       # (only returnAttentionGSO callers: the one place the exact count is needed)
+                aij = _csr_attention_to_dense(att, csr.rowptr, csr.colidx, csr.exact_nnz(), B, N, P)
+            return out, aij
         rowptr, colidx, nnz = dense_gso_to_csr(S3, self_loops=layer.attentionMode == "GAT_origin")
         out, att = gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=out, want_attention=want_attention)
         aij = _csr_attention_to_dense(att, rowptr, colidx, nnz, B, N, P) if want_attention else None

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import _native as nat
 from . import encoder as enc
-from .graphml import (_MODES, GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin, GsoPlan,
+from .graphml import (_MODES, CsrStructure, GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin, GsoPlan,
                       gat_forward_rows)
 from .resnet import ResNet, ResNetSlim
 
@@ -58,6 +58,7 @@ class _Runtime:
         self.buffers = {}
         self.ws = None
         self.plan = GsoPlan()          # GSO-derived masks / walk order, made at addGSO on a side stream
+        self.csr = CsrStructure()      # CSR + CSC structure of the GSO (large graphs / bf16 storage), made at addGSO
         self.graphs = {}               # (shape key) -> captured hipGraph of one forward (enable_hip_graph)
         self.graph_on = None           # None: follow MAGAT_HIP_GRAPH
 
@@ -161,6 +162,18 @@ class DecentralPlannerGATNet(nn.Module):
         scrub = self.skip in ("only", "legacy")        # only these reference files zero NaNs
         gso_mode = {"dist_GSO_one": 1, "full_GSO": 2}.get(self.config.GSO_mode, 0)
         if S.is_cuda and S.is_contiguous() and S.dtype in (torch.float32, torch.float64) and gso_mode != 2:
+            layer = self.GFL[0]
+            B_, N_ = S.shape[0], S.shape[1]
+            if (S.numel() > 0 and S.shape[1] == S.shape[2] and not self.training and
+                    (layer.storage_dtype == torch.bfloat16 or
+                     not nat.lib().magat_gat_dense_supported(N_, layer.G, layer.F)) and CsrStructure.supported(B_, N_)):
+                # large graph / bf16 storage: the layer runs on the CSR kernels.  ONE pass over S does the scrub and leaves
+                # the bit matrix the CSR + CSC structure is built from (no host synchronisation, nothing re-read later)
+                self._rt.csr.build(S, 1 if layer.attentionMode == "GAT_origin" else 0, scrub_nan=scrub, gso_mode=gso_mode)
+                self._rt.plan.key = None
+                self.S = S.unsqueeze(1)
+                return
+            self._rt.csr.key = None
             if (scrub or gso_mode) and S.numel() > 0:        # an empty GSO is accepted here, like the reference's addGSO
                 with torch.cuda.device(S.device):
                     nat.check(nat.lib().magat_gso_prepare(nat.ptr(S), 1 if S.dtype == torch.float64 else 0,
@@ -403,11 +416,11 @@ class DecentralPlannerGATNet(nn.Module):
                 # bf16 storage inside the GAT layer (config.gat_storage='bf16', BASELINE config 5): the layer reads
                 # and writes bf16 rows; the CNN/MLP GEMMs around it stay fp32
                 gat16, aij = gat_forward_rows(comp.view(B, N, G).to(torch.bfloat16), self.S, layer,
-                                              want_attention=want_att)
+                                              want_attention=want_att, csr=rt.csr)
                 gat.copy_(gat16)
             else:
                 _, aij = gat_forward_rows(comp.view(B, N, G), self.S, layer, out=gat, want_attention=want_att,
-                                          plan=rt.plan)
+                                          plan=rt.plan, csr=rt.csr)
             layer.aij = aij
             # actionsMLP
             nout = rt.act[0].shape[0]
