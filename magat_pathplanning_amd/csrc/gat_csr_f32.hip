@@ -348,6 +348,255 @@ WsLayout ws_layout(int B, int N, long long nnz, int G, int F, int K, int P, int 
   return w;
 }
 
+// ---- LDS-tiled forms of the score and hop kernels for N <= 1024 (BASELINE config 5: N = 1000) ------------------------------
+// The per-edge gathers above read every neighbour row from L2 (256-512 B per edge and head: 3.6 GB per c5 step, the
+// kernels sat at 13 % of the HBM roof).  Here one workgroup owns an (instance, head) pair and walks the feature axis in
+// passes of 128 BYTES per row (32 fp32 or 64 bf16 features): the pass's [N][128 B] slice of the gathered tensor (Q_p for
+// the scores, the hop input for a hop) is streamed into LDS once (LDS-direct loads), and every edge then gathers its
+// 16 bytes per lane from LDS.  8 lanes per graph row, 8 rows per wave step.  Partial scores of the passes are accumulated
+// in att[] by the lane that owns the edge (edge k of a row belongs to lane k & 7 of the row's group: same-thread
+// read-after-write, always coherent); owners prefetch their previous partials as one batch before the edge loop, and the
+// value enters the 8-lane reduction of the dot product as an extra term of its owner - no dependent load in the loop.
+constexpr int TILE_ROW_BYTES = 128;
+constexpr int TILED_ROUNDS = 4;          // edges of a row handled by the batched path: 8 * TILED_ROUNDS (the rest: slow path)
+
+template <typename ST>
+__device__ __forceinline__ void tile_dma(char* tile, const ST* src_base, long long row_stride_elems, int N, int t) {
+  // rows n = 0..N-1, 128 bytes each from src_base + n * row_stride: one wave instruction moves 8 rows (1 KB)
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), nw = (int)(blockDim.x >> 6);
+  for (int g = wave; g * 8 < N; g += nw) {
+    const int n = g * 8 + (lane >> 3);
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile + (unsigned)g * 1024u);
+    if (n < N) {
+      const char* src = reinterpret_cast<const char*>(src_base + (long long)n * row_stride_elems) + (lane & 7) * 16;
+      asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+    }
+  }
+}
+
+template <typename ST> struct TileVec;            // the 16 bytes a lane owns of a tile row, as floats
+template <> struct TileVec<float> {
+  static constexpr int E = 4;
+  static __device__ __forceinline__ void load(const void* p, float (&o)[4]) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  }
+};
+template <> struct TileVec<u16> {
+  static constexpr int E = 8;
+  static __device__ __forceinline__ void load(const void* p, float (&o)[8]) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ v = *reinterpret_cast<const u32x4_*>(p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      o[2 * q] = __builtin_bit_cast(float, v[q] << 16);
+      o[2 * q + 1] = __builtin_bit_cast(float, v[q] & 0xffff0000u);
+    }
+  }
+};
+
+template <typename ST>
+__global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams p, int G) {
+  extern __shared__ __attribute__((aligned(1024))) char tile[];
+  constexpr int E = TileVec<ST>::E;                 // features per lane and pass
+  constexpr int FPP = TILE_ROW_BYTES / (int)sizeof(ST);   // features per pass
+  const int N = p.N, NP = G / FPP;
+  const int bid = blockIdx.x, xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
+  const int b = xcd + MAGAT_NUM_XCD * (slot / p.P), head = slot % p.P;
+  if (b >= p.B) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, es = lane & 7, eg = lane >> 3;
+  const int* rp = p.rowptr + (long long)b * (N + 1);
+  const ST* Zb = static_cast<const ST*>(p.Z) + (long long)b * N * p.NC + p.qoff + head * G;
+  const ST* Xb = static_cast<const ST*>(p.X) + (long long)b * N * G;
+  float* att = p.att + (long long)head * p.nnz;
+  for (int h = 0; h < NP; ++h) {
+    const bool first = h == 0, last = h == NP - 1;
+    if (h > 0) __syncthreads();                       // every wave is done with the previous slice
+    tile_dma<ST>(tile, Zb + h * FPP, p.NC, N, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ib = 8 * wave; ib < N; ib += 8 * (int)(blockDim.x >> 6)) {
+      const int i = ib + eg;
+      const bool iok = i < N;
+      const int ir = iok ? i : 0;
+      const int e0 = rp[ir], e1 = iok ? rp[ir + 1] : e0;
+      const int deg = e1 - e0;
+      float xv[E];
+      TileVec<ST>::load(Xb + (long long)ir * G + h * FPP + es * E, xv);
+      // this lane's edges: e0 + es + 8 r.  Previous partial scores, fetched as one batch
+      float pre[TILED_ROUNDS], mine[TILED_ROUNDS];
+#pragma unroll
+      for (int r = 0; r < TILED_ROUNDS; ++r) {
+        pre[r] = 0.f;
+        mine[r] = 0.f;
+        if (!first && es + 8 * r < deg) pre[r] = att[e0 + es + 8 * r];
+      }
+      float mx = -__builtin_inff(), sum = 0.f;
+      auto online = [&](float d) {
+        const float m2 = fmaxf(mx, d);
+        sum = sum * __expf(mx - m2) + __expf(d - m2);
+        mx = m2;
+      };
+      auto edge_dot = [&](int j) -> float {
+        float qv[E];
+        TileVec<ST>::load(tile + j * TILE_ROW_BYTES + es * 16, qv);
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < E; ++c) d = fmaf(xv[c], qv[c], d);
+        return d;
+      };
+      // the wave walks max-degree-of-its-8-rows edges; rows that ran out keep issuing harmless work on row 0 of the tile
+      const int wdeg = deg;
+#pragma unroll
+      for (int r = 0; r < TILED_ROUNDS; ++r) {
+        if (__builtin_amdgcn_ballot_w64(8 * r < wdeg) == 0ull) break;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          const int ka = 8 * r + k, kb = ka + 1;
+          const bool va = ka < deg, vb = kb < deg;
+          const int ja = va ? p.colidx[e0 + ka] : 0, jb = vb ? p.colidx[e0 + kb] : 0;
+          float da = edge_dot(ja), db = edge_dot(jb);
+          if (es == k) da += pre[r];
+          if (es == k + 1) db += pre[r];
+          da = oct_sum(da);
+          db = oct_sum(db);
+          if (es == k && va) mine[r] = da;
+          if (es == k + 1 && vb) mine[r] = db;
+          if (last) {
+            if (va) online(da);
+            if (vb) online(db);
+          }
+        }
+      }
+      // rows with more than 8 * TILED_ROUNDS edges: the rest one by one, owner = lane 0 (dependent loads: rare)
+      for (int k = 8 * TILED_ROUNDS; k < deg; ++k) {
+        float d = edge_dot(p.colidx[e0 + k]);
+        if (es == 0 && !first) d += att[e0 + k];
+        d = oct_sum(d);
+        if (es == 0) att[e0 + k] = d;
+        if (last) online(d);
+      }
+      if (!last) {
+#pragma unroll
+        for (int r = 0; r < TILED_ROUNDS; ++r)
+          if (es + 8 * r < deg) att[e0 + es + 8 * r] = mine[r];
+      } else {
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;
+#pragma unroll
+        for (int r = 0; r < TILED_ROUNDS; ++r)
+          if (es + 8 * r < deg) att[e0 + es + 8 * r] = __expf(mine[r] - mx) * inv;
+        if (es == 0)
+          for (int k = 8 * TILED_ROUNDS; k < deg; ++k) att[e0 + k] = __expf(att[e0 + k] - mx) * inv;
+      }
+    }
+  }
+}
+
+// one Horner hop out[j] = U_k[j] + sum over in-edges (i -> j) of att * Told[i], Told slice in LDS
+template <typename ST>
+__global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, int F) {
+  extern __shared__ __attribute__((aligned(1024))) char tile[];
+  constexpr int E = TileVec<ST>::E;
+  constexpr int FPP = TILE_ROW_BYTES / (int)sizeof(ST);
+  const int N = p.N, NP = F / FPP;
+  const int bid = blockIdx.x, xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
+  const int b = xcd + MAGAT_NUM_XCD * (slot / p.P), head = slot % p.P;
+  if (b >= p.B) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, es = lane & 7, eg = lane >> 3;
+  const int* cp = p.cscptr + (long long)b * (N + 1);
+  const float* att = p.att + (long long)head * p.nnz;
+  const ST* Tb = static_cast<const ST*>(p.Told) + p.told_off + (long long)b * N * p.told_ld +
+                 (long long)head * p.told_head_stride;
+  const ST* Ub = static_cast<const ST*>(p.Z) + (long long)b * N * p.NC + p.uoff + (head * p.K + p.k) * F;
+  for (int h = 0; h < NP; ++h) {
+    if (h > 0) __syncthreads();
+    tile_dma<ST>(tile, Tb + h * FPP, p.told_ld, N, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int jb = 8 * wave; jb < N; jb += 8 * (int)(blockDim.x >> 6)) {
+      const int j = jb + eg;
+      const bool jok = j < N;
+      const int jr = jok ? j : 0;
+      const int s0 = cp[jr], s1 = jok ? cp[jr + 1] : s0;
+      const int deg = s1 - s0;
+      float acc[E];
+      TileVec<ST>::load(Ub + (long long)jr * p.NC + h * FPP + es * E, acc);
+      // this lane's in-edges s0 + es + 8 r: source row and weight, one batch of loads
+      int src[TILED_ROUNDS];
+      float wgt[TILED_ROUNDS];
+#pragma unroll
+      for (int r = 0; r < TILED_ROUNDS; ++r) {
+        src[r] = 0;
+        wgt[r] = 0.f;
+        if (es + 8 * r < deg) {
+          src[r] = p.cscsrc[s0 + es + 8 * r];
+          wgt[r] = att[p.cscpos[s0 + es + 8 * r]];
+        }
+      }
+      const int gbase = lane & ~7;
+#pragma unroll
+      for (int r = 0; r < TILED_ROUNDS; ++r) {
+        if (__builtin_amdgcn_ballot_w64(8 * r < deg) == 0ull) break;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          // (i, a) of edge 8 r + k from its owner lane; edges past the row's degree carry weight 0 and row 0
+          const int i = __shfl(src[r], gbase + k, 64);
+          const float a = __shfl(wgt[r], gbase + k, 64);
+          float tv[E];
+          TileVec<ST>::load(tile + i * TILE_ROW_BYTES + es * 16, tv);
+#pragma unroll
+          for (int c = 0; c < E; ++c) acc[c] = fmaf(a, tv[c], acc[c]);
+        }
+      }
+      for (int k = 8 * TILED_ROUNDS; k < deg; ++k) {
+        const int i = p.cscsrc[s0 + k];
+        const float a = att[p.cscpos[s0 + k]];
+        float tv[E];
+        TileVec<ST>::load(tile + i * TILE_ROW_BYTES + es * 16, tv);
+#pragma unroll
+        for (int c = 0; c < E; ++c) acc[c] = fmaf(a, tv[c], acc[c]);
+      }
+      if (!jok) continue;
+      const int col = h * FPP + es * E;
+      if (p.last) {
+        if (p.bias) {
+#pragma unroll
+          for (int c = 0; c < E; ++c) acc[c] += p.bias[col + c];
+        }
+        if (p.act_relu) {
+#pragma unroll
+          for (int c = 0; c < E; ++c) acc[c] = fmaxf(acc[c], 0.f);
+        }
+        store_vec<E, ST>(static_cast<ST*>(p.Y) + ((long long)b * N + j) * p.ldy + head * F + col, acc);
+      } else {
+        store_vec<E, ST>(static_cast<ST*>(p.Tnew) + (((long long)b * N + j) * p.P + head) * F + col, acc);
+      }
+    }
+  }
+}
+
+template <typename ST>
+bool csr_tiled_ok(const CsrParams& p, int width) {
+  return magat_opt(MAGAT_OPT_CSR_TILED) && p.N <= 1024 && p.N >= 8 && (width * (int)sizeof(ST)) % TILE_ROW_BYTES == 0;
+}
+template <typename ST>
+int run_tiled(const CsrParams& p, int width, bool scores, hipStream_t st) {
+  const long long grid = (long long)((p.B + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD) * MAGAT_NUM_XCD * p.P;
+  if (grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
+  const size_t lds = (size_t)((p.N + 7) / 8) * 8 * TILE_ROW_BYTES;
+  const void* fn = scores ? reinterpret_cast<const void*>(&csr_tiled_scores_kernel<ST>)
+                          : reinterpret_cast<const void*>(&csr_tiled_hop_kernel<ST>);
+  const int slot = (scores ? MAGAT_LDS_CSR_TILED_A : MAGAT_LDS_CSR_TILED_B) + (sizeof(ST) == 2 ? 2 : 0);
+  if (magat_ensure_dyn_lds(fn, slot, lds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
+  const int pid = magat_prof_begin(MAGAT_TAG_GAT_GRAPH, st);
+  if (scores)
+    hipLaunchKernelGGL((csr_tiled_scores_kernel<ST>), dim3((unsigned)grid), dim3(1024), lds, st, p, width);
+  else
+    hipLaunchKernelGGL((csr_tiled_hop_kernel<ST>), dim3((unsigned)grid), dim3(1024), lds, st, p, width);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
+}
+
 template <int G, typename ST = float>
 int run_scores(const CsrParams& p, hipStream_t st) {
   constexpr int LE = (G / 4) < 8 ? (G / 4) : 8;
@@ -487,7 +736,8 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
       if ((rc = magat_check_launch()) != MAGAT_OK) return rc;
     }
     if (!gnn) {
-      MAGAT_CSR_DISPATCH(G, run_scores, ST)
+      if (mode == MAGAT_MODE_KEYQUERY && csr_tiled_ok<ST>(p, G)) rc = run_tiled<ST>(p, G, true, st);
+      else { MAGAT_CSR_DISPATCH(G, run_scores, ST) }
       if (rc != MAGAT_OK) return rc;
     }
     if (K == 1) {
@@ -510,7 +760,8 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
         p.told_head_stride = F;
       }
       p.Tnew = tbuf[h & 1];
-      MAGAT_CSR_DISPATCH(F, run_hop, ST)
+      if (csr_tiled_ok<ST>(p, F)) rc = run_tiled<ST>(p, F, false, st);
+      else { MAGAT_CSR_DISPATCH(F, run_hop, ST) }
       if (rc != MAGAT_OK) return rc;
     }
   }
@@ -657,25 +908,49 @@ __global__ __launch_bounds__(256) void gso_mask_kernel(T* __restrict__ S, unsign
   if (row >= rows) return;
   T* r = S + row * N;
   const int i = (int)(row % N);
+  // the whole row (<= 1024 values) is requested before anything is looked at: one memory latency per row, not one per
+  // 64-value piece (the conditional write-back below would otherwise keep the compiler from hoisting the loads)
+  T v[GSO_W64_MAX];
+#pragma unroll
+  for (int w = 0; w < GSO_W64_MAX; ++w) {
+    const int j = w * 64 + lane;
+    v[w] = (T)0;
+    if (w < W64 && j < N) v[w] = r[j];
+  }
   int cnt = 0;
-  for (int w = 0; w < W64; ++w) {
+  unsigned long long mine = 0ull;        // lane w keeps word w of the row: one 128-byte store per row
+#pragma unroll
+  for (int w = 0; w < GSO_W64_MAX; ++w) {
+    if (w >= W64) break;
     const int j = w * 64 + lane;
     bool f = false;
     if (j < N) {
-      T v = r[j];
-      const T v0 = v;
+      T x = v[w];
       bool dirty = false;
-      if (scrub_nan && v != v) { v = (T)0; dirty = true; }
-      if (gso_mode == 1 && v > (T)0 && v != (T)1) { v = (T)1; dirty = true; }
-      if (dirty) r[j] = v;
-      (void)v0;
-      f = gso_edge(v, j == i, rule);
+      if (scrub_nan && x != x) { x = (T)0; dirty = true; }
+      if (gso_mode == 1 && x > (T)0 && x != (T)1) { x = (T)1; dirty = true; }
+      if (dirty) r[j] = x;
+      f = gso_edge(x, j == i, rule);
     }
     const unsigned long long m = __ballot(f);
     cnt += __popcll(m);
-    if (lane == 0) masks[row * W64 + w] = m;
+    if (lane == w) mine = m;
   }
-  if (lane == 0 && cnt) atomicAdd(&inst_tot[row / N], cnt);
+  if (lane < W64) masks[row * W64 + lane] = mine;
+  if (lane == 0) inst_tot[row] = cnt;      // per-ROW degree (summed per instance by gso_totals_kernel: 128 k same-line atomics
+}                                          // serialised on one L2 channel took 1 ms)
+
+// edge total of every instance: one workgroup per instance over its N row degrees
+__global__ __launch_bounds__(256) void gso_totals_kernel(const int* __restrict__ rowdeg, int* __restrict__ inst_tot, int N) {
+  __shared__ int part[4];
+  const int b = blockIdx.x, t = threadIdx.x;
+  int s = 0;
+  for (int i = t; i < N; i += 256) s += rowdeg[(size_t)b * N + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((t & 63) == 0) part[t >> 6] = s;
+  __syncthreads();
+  if (t == 0) inst_tot[b] = part[0] + part[1] + part[2] + part[3];
 }
 
 __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long long* __restrict__ masks,
@@ -687,7 +962,8 @@ __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long
   extern __shared__ __align__(16) unsigned long long gsm[];
   unsigned long long* M = gsm;                                   // [N][W64]
   int* roff = reinterpret_cast<int*>(M + (size_t)N * W64);       // [N+1] exclusive row offsets (local)
-  int* coff = roff + (N + 1);                                    // [N+1] exclusive column offsets (local)
+  const int W2 = (W64 + 1) / 2;
+  unsigned short* pre2 = reinterpret_cast<unsigned short*>(roff + (N + 2));   // [N][W2]: edges of row i in words < 2 q
   __shared__ int part[17];
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // absolute offset of this instance = edges of all earlier instances (inst_tot was accumulated by the mask pass)
@@ -737,23 +1013,33 @@ __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long
   }
   int total2 = 0;
   const int cex = block_scan(cdeg, &total2);
-  if (t < N) coff[t] = cex;
-  if (t == 0) coff[N] = total;
+  // per row: edge count in front of every EVEN word (the odd ones add one popcount): position of an edge inside its row
+  if (t < N) {
+    int run = 0;
+    for (int q = 0; q < W2; ++q) {
+      pre2[t * W2 + q] = (unsigned short)run;
+      run += __popcll(M[t * W64 + 2 * q]);
+      if (2 * q + 1 < W64) run += __popcll(M[t * W64 + 2 * q + 1]);
+    }
+  }
   __syncthreads();
   int* rp = rowptr + (size_t)b * (N + 1);
   int* cp = cscptr + (size_t)b * (N + 1);
-  for (int q = t; q <= N; q += 1024) {
-    rp[q] = base + roff[q];
-    cp[q] = base + coff[q];
-  }
+  for (int q = t; q <= N; q += 1024) rp[q] = base + roff[q];
+  if (t < N) cp[t] = base + cex;
+  if (t == 0) cp[N] = base + total;
+  auto row_prefix = [&](int i, int w) -> int {      // edges of row i in words < w
+    int p = pre2[i * W2 + (w >> 1)];
+    if (w & 1) p += __popcll(M[i * W64 + w - 1]);
+    return p;
+  };
   if (b == B - 1 && t == 0 && nnz_out) *nnz_out = (long long)base + total;
   // colidx: thread per (row, 64-bit word)
   for (int q = t; q < N * W64; q += 1024) {
     const int i = q / W64, w = q - i * W64;
     unsigned long long m = M[q];
     if (!m) continue;
-    int pos = base + roff[i];
-    for (int u = 0; u < w; ++u) pos += __popcll(M[i * W64 + u]);
+    int pos = base + roff[i] + row_prefix(i, w);
     while (m) {
       const int bit = __builtin_ctzll(m);
       m &= m - 1;
@@ -765,12 +1051,11 @@ __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long
   if (t < N) {
     const int w = t >> 6;
     const unsigned long long bit = 1ull << (t & 63), below = bit - 1ull;
-    int k = base + coff[t];
+    int k = base + cex;
     for (int i = 0; i < N; ++i) {
       const unsigned long long mw = M[i * W64 + w];
       if (mw & bit) {
-        int pos = base + roff[i] + __popcll(mw & below);
-        for (int u = 0; u < w; ++u) pos += __popcll(M[i * W64 + u]);
+        const int pos = base + roff[i] + row_prefix(i, w) + __popcll(mw & below);
         if (k < cap) { cscsrc[k] = i; cscpos[k] = pos; }
         ++k;
       }
@@ -785,7 +1070,8 @@ __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long
 extern "C" size_t magat_gso_csr_workspace_bytes(int B, int N) {
   if (B <= 0 || N <= 0 || N > 64 * GSO_W64_MAX) return 0;
   const size_t w64 = (size_t)(N + 63) / 64;
-  return magat_align_up((size_t)B * N * w64 * 8, 256) + magat_align_up((size_t)B * sizeof(int), 256);
+  return magat_align_up((size_t)B * N * w64 * 8, 256) + magat_align_up((size_t)B * sizeof(int), 256) +
+         magat_align_up((size_t)B * N * sizeof(int), 256);
 }
 
 extern "C" int magat_gso_csr_build(void* S, int s_is_f64, int scrub_nan, int gso_mode, int edge_rule, int* rowptr,
@@ -798,21 +1084,22 @@ extern "C" int magat_gso_csr_build(void* S, int s_is_f64, int scrub_nan, int gso
   if (!need) return MAGAT_ERR_UNSUPPORTED;                      // N > 1024: magat_gso_row_degrees / magat_gso_fill_csr
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < need) return MAGAT_ERR_WORKSPACE;
   const int W64 = (N + 63) / 64;
-  const size_t lds = (size_t)N * W64 * 8 + (size_t)2 * (N + 1) * sizeof(int);
+  const size_t lds = (size_t)N * W64 * 8 + (size_t)(N + 2) * sizeof(int) + (size_t)N * ((W64 + 1) / 2) * sizeof(unsigned short);
   if (lds > 160 * 1024) return MAGAT_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned long long* masks = static_cast<unsigned long long*>(workspace);
   int* inst_tot = reinterpret_cast<int*>(static_cast<char*>(workspace) + magat_align_up((size_t)B * N * W64 * 8, 256));
+  int* rowdeg = reinterpret_cast<int*>(reinterpret_cast<char*>(inst_tot) + magat_align_up((size_t)B * sizeof(int), 256));
   const long long rows = (long long)B * N;
   const int pid = magat_prof_begin(MAGAT_TAG_GSO_CSR, st);
-  if (hipMemsetAsync(inst_tot, 0, (size_t)B * sizeof(int), st) != hipSuccess) return MAGAT_ERR_LAUNCH;
   const unsigned blocks = (unsigned)((rows + 3) / 4);
   if (s_is_f64)
-    hipLaunchKernelGGL(gso_mask_kernel<double>, dim3(blocks), dim3(256), 0, st, static_cast<double*>(S), masks, inst_tot,
+    hipLaunchKernelGGL(gso_mask_kernel<double>, dim3(blocks), dim3(256), 0, st, static_cast<double*>(S), masks, rowdeg,
                        N, W64, rows, scrub_nan, gso_mode, edge_rule);
   else
-    hipLaunchKernelGGL(gso_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<float*>(S), masks, inst_tot, N,
+    hipLaunchKernelGGL(gso_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<float*>(S), masks, rowdeg, N,
                        W64, rows, scrub_nan, gso_mode, edge_rule);
+  hipLaunchKernelGGL(gso_totals_kernel, dim3(B), dim3(256), 0, st, rowdeg, inst_tot, N);
   if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&gso_structure_kernel), MAGAT_LDS_GSO_STRUCT, lds) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
   hipLaunchKernelGGL(gso_structure_kernel, dim3(B), dim3(1024), lds, st, masks, inst_tot, rowptr, colidx, cscptr, cscsrc,
