@@ -146,6 +146,9 @@ int magat_gat_forward_csr_bf16(const uint16_t* X, const int* rowptr, const int* 
                                const float* packed, const float* bias, uint16_t* Y, int ldy, float* att_opt,
                                void* workspace, size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
                                int mode, int concat, void* stream);
+/* Row-block casts around the bf16-storage layer: src [M][ld_src] -> dst [M][ld_dst], `width` columns (multiples of 4);
+ * to_bf16 != 0: float32 -> bf16 bits (RNE), else bf16 bits -> float32. */
+int magat_cast_rows(const void* src, void* dst, int to_bf16, long long M, int width, int ld_src, int ld_dst, void* stream);
 /* Training support (caller: loss.backward() at agents/decentralplannerlocal_OnlineExpert_GAT.py:564).
  * Forward that keeps what the backward needs: Ypre [M][P*F] = per-head filter outputs + bias BEFORE ReLU / head merge
  * (the caller's autograd owns those), att [P][nnz] (CSR order), Z [M][NC], T [(K-2)][M][P*F] (intermediate hop
@@ -386,6 +389,7 @@ int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* 
 #define MAGAT_TAG_BLOCK_CHAIN 18  /* BasicBlock chain kernel (block_fused.hip) */
 #define MAGAT_TAG_GAT_LAYER 19    /* graph kernel with the per-agent maps computed inside (gat_fused.hip) */
 #define MAGAT_TAG_GSO_CSR 20      /* dense GSO -> CSR + CSC structure (magat_gso_csr_build, or the transpose inside *_csr_*) */
+#define MAGAT_TAG_GAT_CAST 21     /* float32 <-> bf16 row casts around the bf16-storage graph layer */
 #define MAGAT_PROF_TAGS 24
 int magat_gat_set_debug_buffer(long long* dev_buf); /* [grid][8] int64 phase timestamps of gat_dense_kernel; NULL = off */
 int magat_profile_reserve(int spans);   /* pre-create event pairs (keeps hipEventCreate out of a timed region) */

@@ -17,7 +17,7 @@ MODE_GNN = 3
 TAGS = {0: "untagged", 1: "conv_first", 2: "layer1.conv1", 3: "layer1.conv2+ds", 4: "layer2.conv1",
         5: "layer2.conv2+ds", 6: "layer3.conv1", 7: "layer3.conv2+ds", 8: "head(avgpool+fc+linear)",
         9: "compressMLP", 10: "gat_maps_gemm", 11: "gat_graph", 12: "actionsMLP", 13: "head_mean",
-        14: "gat_pack", 15: "gso_prepare", 16: "gat_prepare", 17: "range_guard", 18: "block_chain", 19: "gat_layer (fused maps)", 20: "gso_to_csr"}
+        14: "gat_pack", 15: "gso_prepare", 16: "gat_prepare", 17: "range_guard", 18: "block_chain", 19: "gat_layer (fused maps)", 20: "gso_to_csr", 21: "gat_cast"}
 TAG_ACTIONS = 12
 
 _lock = threading.Lock()
@@ -82,6 +82,7 @@ _SIGNATURES = {
     "magat_gso_csr_build": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, ctypes.c_longlong, _P, _P, _Z, _I, _I, _P]),
     "magat_gat_forward_csc_f32": (_I, [_P] * 6 + [ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_forward_csc_bf16": (_I, [_P] * 6 + [ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
+    "magat_cast_rows": (_I, [_P, _P, _I, ctypes.c_longlong, _I, _I, _I, _P]),
     "magat_gso_row_degrees": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "magat_gso_fill_csr": (_I, [_P, _I, _I, _P, _P, _I, _I, _P]),
     "magat_sim_gso": (_I, [_P, ctypes.c_double, _I, _I, _P, _I, _P, _I, _I, _P]),

@@ -374,9 +374,17 @@ __device__ __forceinline__ void tile_dma(char* tile, const ST* src_base, long lo
   }
 }
 
+typedef unsigned tv_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 tv_bf2 __attribute__((ext_vector_type(2)));
 template <typename ST> struct TileVec;            // the 16 bytes a lane owns of a tile row, as floats
 template <> struct TileVec<float> {
   static constexpr int E = 4;
+  static __device__ __forceinline__ float dot(const unsigned (&a)[4], const unsigned (&b)[4]) {     // raw 16-byte pieces
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d = fmaf(__builtin_bit_cast(float, a[c]), __builtin_bit_cast(float, b[c]), d);
+    return d;
+  }
   static __device__ __forceinline__ void load(const void* p, float (&o)[4]) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(p);
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
@@ -384,6 +392,13 @@ template <> struct TileVec<float> {
 };
 template <> struct TileVec<u16> {
   static constexpr int E = 8;
+  static __device__ __forceinline__ float dot(const unsigned (&a)[4], const unsigned (&b)[4]) {   // v_dot2c_f32_bf16: exact
+    float d = 0.f;                                                                               // products, fp32 accumulation
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tv_bf2, a[c]), __builtin_bit_cast(tv_bf2, b[c]), d, false);
+    return d;
+  }
   static __device__ __forceinline__ void load(const void* p, float (&o)[8]) {
     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
     const u32x4_ v = *reinterpret_cast<const u32x4_*>(p);
@@ -400,37 +415,59 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
   extern __shared__ __attribute__((aligned(1024))) char tile[];
   constexpr int E = TileVec<ST>::E;                 // features per lane and pass
   constexpr int FPP = TILE_ROW_BYTES / (int)sizeof(ST);   // features per pass
+  constexpr int R = TILED_ROUNDS;
   const int N = p.N, NP = G / FPP;
   const int bid = blockIdx.x, xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
   const int b = xcd + MAGAT_NUM_XCD * (slot / p.P), head = slot % p.P;
   if (b >= p.B) return;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, es = lane & 7, eg = lane >> 3;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, es = lane & 7, eg = lane >> 3, gbase = lane & ~7;
+  const int rstep = 8 * (int)(blockDim.x >> 6);
   const int* rp = p.rowptr + (long long)b * (N + 1);
   const ST* Zb = static_cast<const ST*>(p.Z) + (long long)b * N * p.NC + p.qoff + head * G;
   const ST* Xb = static_cast<const ST*>(p.X) + (long long)b * N * G;
   float* att = p.att + (long long)head * p.nnz;
+  // everything a row step needs from global memory, requested one step ahead (the loop body then only touches LDS)
+  struct Row {
+    int e0, deg;
+    bool ok;
+    unsigned xv[4];          // the lane's 16 bytes of x_i, raw
+    int cj[R];
+    float pre[R];
+  };
   for (int h = 0; h < NP; ++h) {
     const bool first = h == 0, last = h == NP - 1;
+    auto fetch = [&](int ib, Row& w) {
+      const int i = ib + eg;
+      w.ok = i < N;
+      const int ir = w.ok ? i : 0;
+      w.e0 = rp[ir];
+      w.deg = w.ok ? rp[ir + 1] - w.e0 : 0;
+      {
+        const tv_u32x4 v = *reinterpret_cast<const tv_u32x4*>(Xb + (long long)ir * G + h * FPP + es * E);
+        w.xv[0] = v[0]; w.xv[1] = v[1]; w.xv[2] = v[2]; w.xv[3] = v[3];
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool mine_ok = es + 8 * r < w.deg;
+        w.cj[r] = mine_ok ? p.colidx[w.e0 + es + 8 * r] : 0;
+        // (agent-scope load: served by L2.  The value was stored by THIS thread in the previous pass, but a plain load may
+        //  hit the copy of the line this CU's L1 still holds from the pass before that)
+        w.pre[r] = (!first && mine_ok)
+                       ? __hip_atomic_load(att + w.e0 + es + 8 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+      }
+    };
+    Row cur, nxt;
+    if (8 * wave < N) fetch(8 * wave, cur);           // in flight together with the slice
     if (h > 0) __syncthreads();                       // every wave is done with the previous slice
     tile_dma<ST>(tile, Zb + h * FPP, p.NC, N, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int ib = 8 * wave; ib < N; ib += 8 * (int)(blockDim.x >> 6)) {
-      const int i = ib + eg;
-      const bool iok = i < N;
-      const int ir = iok ? i : 0;
-      const int e0 = rp[ir], e1 = iok ? rp[ir + 1] : e0;
-      const int deg = e1 - e0;
-      float xv[E];
-      TileVec<ST>::load(Xb + (long long)ir * G + h * FPP + es * E, xv);
-      // this lane's edges: e0 + es + 8 r.  Previous partial scores, fetched as one batch
-      float pre[TILED_ROUNDS], mine[TILED_ROUNDS];
+    for (int ib = 8 * wave; ib < N; ib += rstep) {
+      if (ib + rstep < N) fetch(ib + rstep, nxt);
+      const int e0 = cur.e0, deg = cur.deg;
+      float mine[R];
 #pragma unroll
-      for (int r = 0; r < TILED_ROUNDS; ++r) {
-        pre[r] = 0.f;
-        mine[r] = 0.f;
-        if (!first && es + 8 * r < deg) pre[r] = att[e0 + es + 8 * r];
-      }
+      for (int r = 0; r < R; ++r) mine[r] = 0.f;
       float mx = -__builtin_inff(), sum = 0.f;
       auto online = [&](float d) {
         const float m2 = fmaxf(mx, d);
@@ -438,26 +475,22 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
         mx = m2;
       };
       auto edge_dot = [&](int j) -> float {
-        float qv[E];
-        TileVec<ST>::load(tile + j * TILE_ROW_BYTES + es * 16, qv);
-        float d = 0.f;
-#pragma unroll
-        for (int c = 0; c < E; ++c) d = fmaf(xv[c], qv[c], d);
-        return d;
+        const tv_u32x4 v = *reinterpret_cast<const tv_u32x4*>(tile + j * TILE_ROW_BYTES + es * 16);
+        const unsigned q[4] = {v[0], v[1], v[2], v[3]};
+        return TileVec<ST>::dot(cur.xv, q);
       };
-      // the wave walks max-degree-of-its-8-rows edges; rows that ran out keep issuing harmless work on row 0 of the tile
-      const int wdeg = deg;
 #pragma unroll
-      for (int r = 0; r < TILED_ROUNDS; ++r) {
-        if (__builtin_amdgcn_ballot_w64(8 * r < wdeg) == 0ull) break;
+      for (int r = 0; r < R; ++r) {
+        if (__builtin_amdgcn_ballot_w64(8 * r < deg) == 0ull) break;
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
           const int ka = 8 * r + k, kb = ka + 1;
           const bool va = ka < deg, vb = kb < deg;
-          const int ja = va ? p.colidx[e0 + ka] : 0, jb = vb ? p.colidx[e0 + kb] : 0;
+          // neighbour index of edge k from its owner lane (past the row's degree: row 0 of the slice, never used)
+          const int ja = __shfl(cur.cj[r], gbase + k, 64), jb = __shfl(cur.cj[r], gbase + k + 1, 64);
           float da = edge_dot(ja), db = edge_dot(jb);
-          if (es == k) da += pre[r];
-          if (es == k + 1) db += pre[r];
+          if (es == k) da += cur.pre[r];
+          if (es == k + 1) db += cur.pre[r];
           da = oct_sum(da);
           db = oct_sum(db);
           if (es == k && va) mine[r] = da;
@@ -468,26 +501,28 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
           }
         }
       }
-      // rows with more than 8 * TILED_ROUNDS edges: the rest one by one, owner = lane 0 (dependent loads: rare)
-      for (int k = 8 * TILED_ROUNDS; k < deg; ++k) {
+      // rows with more than 8 R edges: the rest one by one, owner = lane 0 (dependent loads: rare)
+      for (int k = 8 * R; k < deg; ++k) {
         float d = edge_dot(p.colidx[e0 + k]);
-        if (es == 0 && !first) d += att[e0 + k];
+        if (es == 0 && !first) d += __hip_atomic_load(att + e0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         d = oct_sum(d);
         if (es == 0) att[e0 + k] = d;
         if (last) online(d);
       }
       if (!last) {
 #pragma unroll
-        for (int r = 0; r < TILED_ROUNDS; ++r)
+        for (int r = 0; r < R; ++r)
           if (es + 8 * r < deg) att[e0 + es + 8 * r] = mine[r];
       } else {
         const float inv = sum > 0.f ? 1.f / sum : 0.f;
 #pragma unroll
-        for (int r = 0; r < TILED_ROUNDS; ++r)
+        for (int r = 0; r < R; ++r)
           if (es + 8 * r < deg) att[e0 + es + 8 * r] = __expf(mine[r] - mx) * inv;
         if (es == 0)
-          for (int k = 8 * TILED_ROUNDS; k < deg; ++k) att[e0 + k] = __expf(att[e0 + k] - mx) * inv;
+          for (int k = 8 * R; k < deg; ++k)
+            att[e0 + k] = __expf(__hip_atomic_load(att + e0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mx) * inv;
       }
+      cur = nxt;
     }
   }
 }
@@ -498,86 +533,98 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
   extern __shared__ __attribute__((aligned(1024))) char tile[];
   constexpr int E = TileVec<ST>::E;
   constexpr int FPP = TILE_ROW_BYTES / (int)sizeof(ST);
+  constexpr int R = TILED_ROUNDS;
   const int N = p.N, NP = F / FPP;
   const int bid = blockIdx.x, xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
   const int b = xcd + MAGAT_NUM_XCD * (slot / p.P), head = slot % p.P;
   if (b >= p.B) return;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, es = lane & 7, eg = lane >> 3;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, es = lane & 7, eg = lane >> 3, gbase = lane & ~7;
+  const int rstep = 8 * (int)(blockDim.x >> 6);
   const int* cp = p.cscptr + (long long)b * (N + 1);
   const float* att = p.att + (long long)head * p.nnz;
   const ST* Tb = static_cast<const ST*>(p.Told) + p.told_off + (long long)b * N * p.told_ld +
                  (long long)head * p.told_head_stride;
   const ST* Ub = static_cast<const ST*>(p.Z) + (long long)b * N * p.NC + p.uoff + (head * p.K + p.k) * F;
+  struct Row {
+    int s0, deg;
+    bool ok;
+    float acc[E];
+    int src[R];
+    float wgt[R];
+  };
   for (int h = 0; h < NP; ++h) {
+    auto fetch = [&](int jb, Row& w) {
+      const int j = jb + eg;
+      w.ok = j < N;
+      const int jr = w.ok ? j : 0;
+      w.s0 = cp[jr];
+      w.deg = w.ok ? cp[jr + 1] - w.s0 : 0;
+      TileVec<ST>::load(Ub + (long long)jr * p.NC + h * FPP + es * E, w.acc);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool mine_ok = es + 8 * r < w.deg;
+        w.src[r] = mine_ok ? p.cscsrc[w.s0 + es + 8 * r] : 0;
+        w.wgt[r] = mine_ok ? att[p.cscpos[w.s0 + es + 8 * r]] : 0.f;
+      }
+    };
+    Row cur, nxt;
+    if (8 * wave < N) fetch(8 * wave, cur);
     if (h > 0) __syncthreads();
     tile_dma<ST>(tile, Tb + h * FPP, p.told_ld, N, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int jb = 8 * wave; jb < N; jb += 8 * (int)(blockDim.x >> 6)) {
-      const int j = jb + eg;
-      const bool jok = j < N;
-      const int jr = jok ? j : 0;
-      const int s0 = cp[jr], s1 = jok ? cp[jr + 1] : s0;
-      const int deg = s1 - s0;
+    for (int jb = 8 * wave; jb < N; jb += rstep) {
+      if (jb + rstep < N) fetch(jb + rstep, nxt);
+      const int j = jb + eg, deg = cur.deg;
       float acc[E];
-      TileVec<ST>::load(Ub + (long long)jr * p.NC + h * FPP + es * E, acc);
-      // this lane's in-edges s0 + es + 8 r: source row and weight, one batch of loads
-      int src[TILED_ROUNDS];
-      float wgt[TILED_ROUNDS];
 #pragma unroll
-      for (int r = 0; r < TILED_ROUNDS; ++r) {
-        src[r] = 0;
-        wgt[r] = 0.f;
-        if (es + 8 * r < deg) {
-          src[r] = p.cscsrc[s0 + es + 8 * r];
-          wgt[r] = att[p.cscpos[s0 + es + 8 * r]];
-        }
-      }
-      const int gbase = lane & ~7;
+      for (int c = 0; c < E; ++c) acc[c] = cur.acc[c];
 #pragma unroll
-      for (int r = 0; r < TILED_ROUNDS; ++r) {
+      for (int r = 0; r < R; ++r) {
         if (__builtin_amdgcn_ballot_w64(8 * r < deg) == 0ull) break;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           // (i, a) of edge 8 r + k from its owner lane; edges past the row's degree carry weight 0 and row 0
-          const int i = __shfl(src[r], gbase + k, 64);
-          const float a = __shfl(wgt[r], gbase + k, 64);
+          const int i = __shfl(cur.src[r], gbase + k, 64);
+          const float a = __shfl(cur.wgt[r], gbase + k, 64);
           float tv[E];
           TileVec<ST>::load(tile + i * TILE_ROW_BYTES + es * 16, tv);
 #pragma unroll
           for (int c = 0; c < E; ++c) acc[c] = fmaf(a, tv[c], acc[c]);
         }
       }
-      for (int k = 8 * TILED_ROUNDS; k < deg; ++k) {
-        const int i = p.cscsrc[s0 + k];
-        const float a = att[p.cscpos[s0 + k]];
+      for (int k = 8 * R; k < deg; ++k) {
+        const int i = p.cscsrc[cur.s0 + k];
+        const float a = att[p.cscpos[cur.s0 + k]];
         float tv[E];
         TileVec<ST>::load(tile + i * TILE_ROW_BYTES + es * 16, tv);
 #pragma unroll
         for (int c = 0; c < E; ++c) acc[c] = fmaf(a, tv[c], acc[c]);
       }
-      if (!jok) continue;
-      const int col = h * FPP + es * E;
-      if (p.last) {
-        if (p.bias) {
+      if (cur.ok) {
+        const int col = h * FPP + es * E;
+        if (p.last) {
+          if (p.bias) {
 #pragma unroll
-          for (int c = 0; c < E; ++c) acc[c] += p.bias[col + c];
-        }
-        if (p.act_relu) {
+            for (int c = 0; c < E; ++c) acc[c] += p.bias[col + c];
+          }
+          if (p.act_relu) {
 #pragma unroll
-          for (int c = 0; c < E; ++c) acc[c] = fmaxf(acc[c], 0.f);
+            for (int c = 0; c < E; ++c) acc[c] = fmaxf(acc[c], 0.f);
+          }
+          store_vec<E, ST>(static_cast<ST*>(p.Y) + ((long long)b * N + j) * p.ldy + head * F + col, acc);
+        } else {
+          store_vec<E, ST>(static_cast<ST*>(p.Tnew) + (((long long)b * N + j) * p.P + head) * F + col, acc);
         }
-        store_vec<E, ST>(static_cast<ST*>(p.Y) + ((long long)b * N + j) * p.ldy + head * F + col, acc);
-      } else {
-        store_vec<E, ST>(static_cast<ST*>(p.Tnew) + (((long long)b * N + j) * p.P + head) * F + col, acc);
       }
+      cur = nxt;
     }
   }
 }
 
 template <typename ST>
-bool csr_tiled_ok(const CsrParams& p, int width) {
-  return magat_opt(MAGAT_OPT_CSR_TILED) && p.N <= 1024 && p.N >= 8 && (width * (int)sizeof(ST)) % TILE_ROW_BYTES == 0;
+bool csr_tiled_ok(const CsrParams& p, int width, int which) {      // which: 1 = scores, 2 = hop (option CSR_TILED = bit mask)
+  return (magat_opt(MAGAT_OPT_CSR_TILED) & which) && p.N <= 1024 && p.N >= 8 && (width * (int)sizeof(ST)) % TILE_ROW_BYTES == 0;
 }
 template <typename ST>
 int run_tiled(const CsrParams& p, int width, bool scores, hipStream_t st) {
@@ -736,7 +783,7 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
       if ((rc = magat_check_launch()) != MAGAT_OK) return rc;
     }
     if (!gnn) {
-      if (mode == MAGAT_MODE_KEYQUERY && csr_tiled_ok<ST>(p, G)) rc = run_tiled<ST>(p, G, true, st);
+      if (mode == MAGAT_MODE_KEYQUERY && csr_tiled_ok<ST>(p, G, 1)) rc = run_tiled<ST>(p, G, true, st);
       else { MAGAT_CSR_DISPATCH(G, run_scores, ST) }
       if (rc != MAGAT_OK) return rc;
     }
@@ -760,7 +807,7 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
         p.told_head_stride = F;
       }
       p.Tnew = tbuf[h & 1];
-      if (csr_tiled_ok<ST>(p, F)) rc = run_tiled<ST>(p, F, false, st);
+      if (csr_tiled_ok<ST>(p, F, 2)) rc = run_tiled<ST>(p, F, false, st);
       else { MAGAT_CSR_DISPATCH(F, run_hop, ST) }
       if (rc != MAGAT_OK) return rc;
     }
@@ -778,6 +825,58 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
 }
 
 }  // namespace
+
+// float32 <-> bf16 (RNE) row blocks around the bf16-storage layer: src [M][ld_src] -> dst [M][ld_dst], `width` columns
+namespace {
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, long long M, int width,
+                                     int ld_src, int ld_dst) {
+  const int wq = width / 4;
+  const long long total = M * wq;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long m = idx / wq;
+    const int c = (int)(idx - m * wq) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + m * ld_src + c);
+    uint2 o;
+    o.x = (unsigned)magat_bf16_rne(v[0]) | ((unsigned)magat_bf16_rne(v[1]) << 16);
+    o.y = (unsigned)magat_bf16_rne(v[2]) | ((unsigned)magat_bf16_rne(v[3]) << 16);
+    *reinterpret_cast<uint2*>(dst + m * ld_dst + c) = o;
+  }
+}
+__global__ void cast_bf16_f32_kernel(const u16* __restrict__ src, float* __restrict__ dst, long long M, int width,
+                                     int ld_src, int ld_dst) {
+  const int wq = width / 4;
+  const long long total = M * wq;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long m = idx / wq;
+    const int c = (int)(idx - m * wq) * 4;
+    const uint2 v = *reinterpret_cast<const uint2*>(src + m * ld_src + c);
+    *reinterpret_cast<f32x4*>(dst + m * ld_dst + c) =
+        f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
+              __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u)};
+  }
+}
+}  // namespace
+
+extern "C" int magat_cast_rows(const void* src, void* dst, int to_bf16, long long M, int width, int ld_src, int ld_dst,
+                               void* stream) {
+  if (!src || !dst) return MAGAT_ERR_NULL;
+  if (M <= 0 || width <= 0 || (width & 3) || (ld_src & 3) || (ld_dst & 3) || ld_src < width || ld_dst < width)
+    return MAGAT_ERR_BAD_SHAPE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  long long blocks = (M * (width / 4) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  const int pid = magat_prof_begin(MAGAT_TAG_GAT_CAST, st);
+  if (to_bf16)
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float*>(src),
+                       static_cast<u16*>(dst), M, width, ld_src, ld_dst);
+  else
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const u16*>(src),
+                       static_cast<float*>(dst), M, width, ld_src, ld_dst);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
+}
 
 extern "C" size_t magat_gat_csr_workspace_bytes(int B, int N, long long nnz, int G, int F, int K, int P, int mode,
                                                 int concat) {
@@ -908,24 +1007,14 @@ __global__ __launch_bounds__(256) void gso_mask_kernel(T* __restrict__ S, unsign
   if (row >= rows) return;
   T* r = S + row * N;
   const int i = (int)(row % N);
-  // the whole row (<= 1024 values) is requested before anything is looked at: one memory latency per row, not one per
-  // 64-value piece (the conditional write-back below would otherwise keep the compiler from hoisting the loads)
-  T v[GSO_W64_MAX];
-#pragma unroll
-  for (int w = 0; w < GSO_W64_MAX; ++w) {
-    const int j = w * 64 + lane;
-    v[w] = (T)0;
-    if (w < W64 && j < N) v[w] = r[j];
-  }
+  // plain 64-column steps at full occupancy (8 waves per SIMD hide the latency; a 16-register batched form compiled to
+  // 236 VGPRs and ran 7x slower)
   int cnt = 0;
-  unsigned long long mine = 0ull;        // lane w keeps word w of the row: one 128-byte store per row
-#pragma unroll
-  for (int w = 0; w < GSO_W64_MAX; ++w) {
-    if (w >= W64) break;
+  for (int w = 0; w < W64; ++w) {
     const int j = w * 64 + lane;
     bool f = false;
     if (j < N) {
-      T x = v[w];
+      T x = r[j];
       bool dirty = false;
       if (scrub_nan && x != x) { x = (T)0; dirty = true; }
       if (gso_mode == 1 && x > (T)0 && x != (T)1) { x = (T)1; dirty = true; }
@@ -934,9 +1023,8 @@ __global__ __launch_bounds__(256) void gso_mask_kernel(T* __restrict__ S, unsign
     }
     const unsigned long long m = __ballot(f);
     cnt += __popcll(m);
-    if (lane == w) mine = m;
+    if (lane == 0) masks[row * W64 + w] = m;
   }
-  if (lane < W64) masks[row * W64 + lane] = mine;
   if (lane == 0) inst_tot[row] = cnt;      // per-ROW degree (summed per instance by gso_totals_kernel: 128 k same-line atomics
 }                                          // serialised on one L2 channel took 1 ms)
 

@@ -38,7 +38,7 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
     {"RANGE_GUARD", 1},      // split-arithmetic range guard: overflow flag + stream-ordered fp32 re-run of the encoder
     {"BLOCK_FUSED", 1},      // BasicBlock chain kernel (conv1 -> conv2 (+downsample) with the 6x6 maps in LDS)
     {"GAT_FUSED_MAPS", 1},   // hoisted maps computed inside the graph kernel (Z never crosses HBM)
-    {"CSR_TILED", 1},        // CSR path, N <= 1024: LDS-tiled score / hop kernels (gathers from LDS instead of L2)
+    {"CSR_TILED", 3},        // CSR path, N <= 1024: LDS-tiled kernels (bit 0 scores, bit 1 hops) instead of L2 gathers
 };
 
 int g_val[MAGAT_OPT_COUNT];

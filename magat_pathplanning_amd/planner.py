@@ -368,6 +368,13 @@ class DecentralPlannerGATNet(nn.Module):
             self._rt.buffers[name] = t
         return t
 
+    def _buf16(self, name, shape, dev):
+        t = self._rt.buffers.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != dev:
+            t = torch.empty(shape, dtype=torch.bfloat16, device=dev)
+            self._rt.buffers[name] = t
+        return t
+
     @torch.no_grad()
     def _forward_hip(self, x, B, N):
         if not x.is_cuda:
@@ -415,9 +422,13 @@ class DecentralPlannerGATNet(nn.Module):
             elif layer.storage_dtype == torch.bfloat16:
                 # bf16 storage inside the GAT layer (config.gat_storage='bf16', BASELINE config 5): the layer reads
                 # and writes bf16 rows; the CNN/MLP GEMMs around it stay fp32
-                gat16, aij = gat_forward_rows(comp.view(B, N, G).to(torch.bfloat16), self.S, layer,
-                                              want_attention=want_att, csr=rt.csr)
-                gat.copy_(gat16)
+                comp16 = self._buf16("comp16", (M, G), dev)
+                gat16 = self._buf16("gat16", (M, self.gat_width), dev)
+                nat.check(lib.magat_cast_rows(nat.ptr(comp), nat.ptr(comp16), 1, M, G, G, G, stream), "magat_cast_rows")
+                _, aij = gat_forward_rows(comp16.view(B, N, G), self.S, layer, out=gat16, want_attention=want_att,
+                                          csr=rt.csr)
+                nat.check(lib.magat_cast_rows(nat.ptr(gat16), nat.ptr(gat), 0, M, self.gat_width, self.gat_width,
+                                              self.gat_width, stream), "magat_cast_rows")
             else:
                 _, aij = gat_forward_rows(comp.view(B, N, G), self.S, layer, out=gat, want_attention=want_att,
                                           plan=rt.plan, csr=rt.csr)

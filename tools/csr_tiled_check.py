@@ -1,0 +1,37 @@
+"""tiled vs untiled CSR kernels (bf16 and fp32 storage) on the same inputs: attention and outputs."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from magat_pathplanning_amd import GraphFilterBatchAttentional, _native as nat
+from magat_pathplanning_amd.graphml import CsrStructure, gat_forward_rows_csr
+from magat_pathplanning_amd.synthetic import comm_gso
+dev = torch.device("cuda:0")
+B, N, G, K, P = 2, 1000, 128, 2, 4
+g = torch.Generator().manual_seed(15)
+layer = GraphFilterBatchAttentional(G, G, K, P, attentionMode="KeyQuery").to(dev).eval()
+S = comm_gso(B, N, 160, seed=8).to(dev)
+st = CsrStructure().build(S, 0)
+for dt in (torch.float32, torch.bfloat16):
+    X = (torch.randn(B, N, G, generator=g) * 0.5).to(dev).to(dt)
+    res = {}
+    for tiled in (0, 3):
+        nat.set_option("CSR_TILED", tiled)
+        out, att = gat_forward_rows_csr(X, st.rowptr, st.colidx, st.cap, layer, want_attention=True,
+                                        csc=(st.cscptr, st.csc[0], st.csc[1]))
+        torch.cuda.synchronize()
+        nnz = st.exact_nnz()
+        res[tiled] = (out.float().clone(), att[:, :nnz].clone())
+    print(dt, "out diff %.3g (scale %.3g)  att diff %.3g" % (float((res[0][0] - res[3][0]).abs().max()), float(res[0][0].abs().max()),
+                                                            float((res[0][1] - res[3][1]).abs().max())))
+# which one is right? the pinned oracle
+from oracle import magat_oracle as orc
+X = (torch.randn(B, N, G, generator=g) * 0.5)
+params = {k: v.detach().cpu() for k, v in layer.state_dict().items()}
+y_ref, a_ref = orc.gat_layer_forward(X.permute(0, 2, 1).contiguous(), S.cpu().unsqueeze(1), params, "KeyQuery", True)
+y_ref = y_ref.permute(0, 2, 1).reshape(B * N, -1)
+for tiled in (0, 1, 2, 3):
+    nat.set_option("CSR_TILED", tiled)
+    out, att = gat_forward_rows_csr(X.to(dev), st.rowptr, st.colidx, st.cap, layer, want_attention=False,
+                                    csc=(st.cscptr, st.csc[0], st.csc[1]))
+    torch.cuda.synchronize()
+    print("tiled=%d vs oracle: %.3g" % (tiled, float((out.cpu() - y_ref).abs().max())))
