@@ -351,6 +351,8 @@ typedef struct magat_encoder_desc {
   int n_comp;      /* bottleneckFeature G (0: skip compressMLP) */
   const float* pack; /* device pointer to the folded parameter pack */
   int64_t off[32];   /* float offsets into pack: see DESIGN.md "encoder pack" */
+  int64_t chain_off; /* float offset of the BasicBlock chain kernel's fragment-major weights (encoder.pack_chain_weights: layer1.
+                        conv2+downsample, layer2.conv1, layer2.conv2+downsample), 0 = absent -> layer-by-layer kernels (ABI 2) */
 } magat_encoder_desc;
 /* Range guard (option RANGE_GUARD, default 1).  The convolutions run as f16x3 split products (two half-precision planes per
  * value, fp32 accumulate: as accurate as the fp32 MFMA kernel while every activation stays within +-65504; the fused stem

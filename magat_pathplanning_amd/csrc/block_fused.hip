@@ -1,0 +1,315 @@
+// BasicBlock chain kernel: layer1.conv2(+downsample) -> layer2.conv1 -> layer2.conv2(+downsample) of the ResNet encoders
+// (reference graphs/models/resnet_pytorch.py:40-73 BasicBlock, :495-524 forward) in ONE launch, with every intermediate
+// 6x6 map of a small agent group resident in LDS.  f16x3 arithmetic (conv_gemm_bf16x6.hip): every value is two
+// half-precision planes, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation.
+//
+// Layer by layer these three convolutions moved 3.35 GB through HBM per 51 200-agent step (every map written by one kernel and
+// read back - up to nine times - by the next) and ran at 18-33 % of the matrix peak.  Here a workgroup owns EIGHT agents:
+//   rows of the implicit GEMMs = (pixel, agent) pairs, 36 x 8 = 288 rows = 9 MFMA row tiles of 32.  The tiles are formed by
+//   tap-validity class - 4 x interior (all 9 taps), top / bottom / left / right edge (6 taps each), the 4 corners (9 taps,
+//   invalid ones read a zero pixel) - so that a tile skips a tap outright when it falls into the zero padding for all of
+//   its pixels: 69 tile-taps are executed per channel tile where 64 are useful (exact skipping needs 32 agents per pixel,
+//   whose maps do not fit LDS).
+//   LDS map layout [plane][8-channel chunk][pixel slot 0..36][agent][8 halves]: a row's MFMA operand for any tap is one
+//   ds_read_b128 at (lane base + compile-time offset); pixel slot 36 is a zero pixel.  Maps: the two 32-channel inputs
+//   (layer1.conv1 output, stem stride-2 pixels), layer1's output, layer2.conv1's output (aliasing the dead inputs): 111 KB.
+//   Weights are pre-packed fragment-major (encoder.pack_chain_weights): the MFMA row operand of (channel tile, tap, k step,
+//   plane) is one contiguous 1 KB block, fetched global -> registers one tap ahead.  No barrier inside a convolution: the
+//   maps are read-only while a stage runs, the eight waves drift freely (wave = channel tile x group of row tiles with
+//   balanced tap counts); three workgroup barriers per launch.
+// Output: layer2's map as f16 plane granules (magat_hip.h in_gl = 2) for layer3.conv1, or float32 row-major tiles for the
+// pooled head (ResNetSlim).
+#include "magat_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int AG = 8;                       // agents per workgroup
+constexpr int NPIX = 36, ZPIX = 36;         // 6 x 6 map; pixel slot 36 = zeros
+constexpr int PIXB = AG * 16;               // bytes per pixel slot of one (plane, chunk) block: 8 agents x 16 B
+constexpr int BLK = (NPIX + 1) * PIXB;      // 4736 bytes per (plane, chunk) block
+constexpr int MAP32 = 8 * BLK;              // 32-channel map: 2 planes x 4 chunks
+constexpr int MAP64 = 16 * BLK;             // 64-channel map: 2 planes x 8 chunks
+constexpr int LDS_X1 = 0, LDS_X2 = MAP32, LDS_Z = 0, LDS_Y = MAP64, LDS_TOTAL = MAP64 + MAP32;
+constexpr int TAPBIAS = 7 * PIXB;           // tap shifts are (6 dy + dx) pixel slots in [-7, 7]: biased to stay non-negative
+
+// row tiles by tap-validity class: pixel = 6 y + x
+__device__ constexpr int TILE_PIX[9][4] = {{7, 8, 9, 10},    {13, 14, 15, 16}, {19, 20, 21, 22}, {25, 26, 27, 28},
+                                           {1, 2, 3, 4},     {31, 32, 33, 34}, {6, 12, 18, 24},  {11, 17, 23, 29},
+                                           {0, 5, 30, 35}};
+// valid taps t = 3 (dy + 1) + (dx + 1) of every pixel of the tile (corners: union; per-lane validity handled by address)
+__device__ constexpr int TILE_TAPS[9] = {0x1FF, 0x1FF, 0x1FF, 0x1FF, 0x1F8, 0x03F, 0x1B6, 0x0DB, 0x1FF};
+constexpr int T_I0 = 0, T_I1 = 1, T_I2 = 2, T_I3 = 3, T_ET = 4, T_EB = 5, T_EL = 6, T_ER = 7, T_C = 8;
+// wave -> row tiles.  32 output channels: one channel tile, waves split the nine row tiles; 64: wave = (channel tile w & 1,
+// row group w >> 1) - waves w and w + 4 share a SIMD: their tap counts add up to 33 / 36 per SIMD
+__device__ constexpr int WT32[8][3] = {{T_I0, -1, -1}, {T_I1, -1, -1}, {T_I2, -1, -1},    {T_I3, -1, -1},
+                                       {T_C, -1, -1},  {T_ET, T_EB, -1}, {T_EL, -1, -1}, {T_ER, -1, -1}};
+__device__ constexpr int WG64[4][3] = {{T_I0, T_I1, -1}, {T_I2, T_I3, -1}, {T_C, T_ET, -1}, {T_EB, T_EL, T_ER}};
+
+struct ChainParams {
+  const char* in1;        // layer1.conv1 output, f16 plane granules, 32 channels: [agent tile][pixel][128 agents x 128 B]
+  const char* in2;        // stem output at the stride-2 pixels, same geometry
+  char* out;              // layer2 output
+  int out_gl;             // 2: f16 plane granules (64 channels); 0: float32 row-major agent tiles
+  long long out_pix_stride, out_tile;     // floats
+  const char* wA; const char* wB; const char* wC;      // fragment-major f16 weight planes (+ float 2^-e at the end of each)
+  const float* bA; const float* bB; const float* bC;   // biases (conv2 + downsample already added)
+  const float* sA; const float* sB; const float* sC;     // 2^-e of each weight block (one float behind it)
+  int M, groups;
+  int* range_flag;
+};
+
+__device__ __forceinline__ void split2(float x, float y, unsigned& p1, unsigned& p2, bool& clamped) {
+  clamped |= (x > 65504.f) | (y > 65504.f);              // (post-ReLU values)
+  x = __builtin_amdgcn_fmed3f(x, 0.f, 65504.f);
+  y = __builtin_amdgcn_fmed3f(y, 0.f, 65504.f);
+  const f16x2 h = __builtin_convertvector(f32x2{x, y}, f16x2);
+  const f16x2 r = __builtin_convertvector(f32x2{x - (float)h[0], y - (float)h[1]}, f16x2);
+  p1 = __builtin_bit_cast(unsigned, h);
+  p2 = __builtin_bit_cast(unsigned, r);
+}
+
+// One convolution stage: out = relu(conv3x3(in, CIN -> COUT) + conv1x1(in2, C2 -> COUT) + bias).
+// in / in2 / out are LDS maps (LAST: out goes to global memory).  wts: this stage's fragment-major weights.
+template <int CIN, int C2, int COUT, bool LAST>
+__device__ __forceinline__ void chain_stage(const ChainParams& p, char* lds, int in_off, int in2_off, int out_off,
+                                            const char* wts, const float* bias, float scale, int group, bool& clamped) {
+  constexpr int KSM = CIN / 16, KS2 = C2 / 16;
+  constexpr int BPT = (9 * KSM + KS2) * 2;                  // 1 KB weight blocks per channel tile
+  constexpr int PS_IN = (CIN / 8) * BLK, PS_IN2 = (C2 / 8) * BLK, PS_OUT = (COUT / 8) * BLK;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int agent = fr & 7, psl = fr >> 3;                  // row of the tile = (pixel slot of the tile, agent)
+  int ct, tl[3];
+  if (COUT == 32) {
+    ct = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) tl[s] = WT32[wave][s];
+  } else {
+    ct = wave & 1;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) tl[s] = WG64[wave >> 1][s];
+  }
+  int umask = 0;
+  unsigned ab[3], az[3];        // lane base of its pixel in plane 0 / of the zero pixel (both minus nothing: offsets carry TAPBIAS)
+  int lmask[3];                 // per-lane valid taps of the slot's pixel
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int tile = tl[s] < 0 ? 0 : tl[s];
+    if (tl[s] >= 0) umask |= TILE_TAPS[tile];
+    const int pix = TILE_PIX[tile][psl];
+    const int y = pix / 6, x = pix - 6 * y;
+    int m = 0;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+      if (y + dy >= 0 && y + dy < 6 && x + dx >= 0 && x + dx < 6) m |= 1 << tp;
+    }
+    lmask[s] = m;
+    ab[s] = (unsigned)(pix * PIXB + agent * 16 + fh * BLK);
+    az[s] = (unsigned)(ZPIX * PIXB + agent * 16 + fh * BLK);
+  }
+  f32x16 acc[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+  // weights of one tap (index u = 0..8, 9 = the 1x1 residual segment): KSM (KS2) k steps x 2 planes, 16 bytes per lane each
+  const char* wl = wts + (size_t)ct * BPT * 1024 + lane * 16;
+  u32x4 bcur[KSM][2], bnxt[KSM][2];
+  auto load_b = [&](int u, u32x4 (&b)[KSM][2]) {
+    const char* src = wl + (size_t)(u < 9 ? u * KSM : 9 * KSM) * 2048;
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks)
+      if (u < 9 || ks < KS2) {
+        b[ks][0] = *reinterpret_cast<const u32x4*>(src + ks * 2048);
+        b[ks][1] = *reinterpret_cast<const u32x4*>(src + ks * 2048 + 1024);
+      }
+  };
+  const int walk = umask | (KS2 > 0 ? 0x200 : 0);           // taps this wave visits (+ the residual segment)
+  load_b(__builtin_ctz(walk), bcur);
+  constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};        // h1g1 h1g2 h2g1 (activation plane, weight plane)
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+    if (!(umask >> tp & 1)) continue;                         // wave-uniform
+    const int rest = walk >> (tp + 1);
+    if (rest) load_b(tp + 1 + __builtin_ctz(rest), bnxt);     // next visited tap: in flight under this tap's MFMAs
+    const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+    const int shift = (6 * dy + dx) * PIXB + TAPBIAS;         // >= 0
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      if (tl[s] < 0 || !(TILE_TAPS[tl[s] < 0 ? 0 : tl[s]] >> tp & 1)) continue;     // wave-uniform
+      // lanes whose pixel has no neighbour at this tap (corner tile only) read the zero pixel instead
+      const unsigned a0 = ((lmask[s] >> tp & 1) ? ab[s] + (unsigned)shift : az[s] + (unsigned)TAPBIAS) + (unsigned)in_off -
+                          (unsigned)TAPBIAS;
+#pragma unroll
+      for (int ks = 0; ks < KSM; ++ks) {
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK);
+        const u32x4 a2 = *reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK + PS_IN);
+        const u32x4 av[2] = {a1, a2};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bcur[ks][PB[q]]),
+                                                          __builtin_bit_cast(f16x8, av[PA[q]]), acc[s], 0, 0, 0);
+      }
+    }
+    if (rest) {
+#pragma unroll
+      for (int ks = 0; ks < KSM; ++ks) { bcur[ks][0] = bnxt[ks][0]; bcur[ks][1] = bnxt[ks][1]; }
+    }
+  }
+  if (KS2 > 0) {     // residual 1x1 branch: the block input at the same pixel
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      if (tl[s] < 0) continue;
+      const unsigned a0 = ab[s] + (unsigned)in2_off;
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK);
+        const u32x4 a2 = *reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK + PS_IN2);
+        const u32x4 av[2] = {a1, a2};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bcur[ks][PB[q]]),
+                                                          __builtin_bit_cast(f16x8, av[PA[q]]), acc[s], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: D[channel][row]; channel = 32 ct + (r & 3) + 8 (r >> 2) + 4 fh.  Quads 2 ks, 2 ks + 1 of the lane are the next
+  // layer's k-step-ks operand (plane-granule order): chunk (ct * 2 + ks) * 2 + fh of the output map
+  f32x4 bq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bias + 32 * ct + 8 * q + 4 * fh);
+  const int m = group * AG + agent;
+  const bool mok = m < p.M;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    if (tl[s] < 0) continue;
+    const int pix = TILE_PIX[tl[s]][psl];
+    if (LAST && p.out_gl == 0) {         // float32 row-major agent tiles [tile][pixel][128][COUT]
+      if (mok) {
+        float* orow = reinterpret_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +
+                      magat_row_off(m, COUT, p.out_tile) + 32 * ct + 4 * fh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * scale + bq[q][c], 0.f);
+          *reinterpret_cast<f32x4*>(orow + 8 * q) = v;
+        }
+      }
+      continue;
+    }
+    bool cl = false;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      unsigned h1[4], h2[4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int q = 2 * ks + e;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * scale + bq[q][c], 0.f);
+        split2(v[0], v[1], h1[2 * e], h2[2 * e], cl);
+        split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1], cl);
+      }
+      const int chunk = (ct * 2 + ks) * 2 + fh;
+      if (LAST) {
+        if (mok) {
+          char* o = p.out + ((long long)pix * p.out_pix_stride + (long long)(m >> 7) * p.out_tile) * 4 + (m & 127) * 16 +
+                    (long long)chunk * 2048;
+          *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+          *reinterpret_cast<u32x4*>(o + 256 * COUT) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+        }
+      } else {
+        char* o = lds + out_off + chunk * BLK + pix * PIXB + agent * 16;
+        *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+        *reinterpret_cast<u32x4*>(o + PS_OUT) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+      }
+    }
+    clamped |= cl && mok;      // (rows of agents past M compute on whatever the padded tile holds)
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void block_chain_kernel(const ChainParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int group = blockIdx.x;
+  if (group >= p.groups) return;
+  // zero pixel of every (plane, chunk) block (24 blocks)
+  for (int i = t; i < 24 * (PIXB / 4); i += 512)
+    *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
+  // inputs: for (map, plane, chunk) the 36 pixels x 128 B of this agent group, 8 pixels per LDS-direct instruction
+  {
+    const int m0 = group * AG;
+    const long long tile_b = (long long)(m0 >> 7) * NPIX * (128 * 32 * 4) + (m0 & 127) * 16;    // bytes: agent tile, agents
+    for (int item = wave; item < 2 * 8 * 5; item += 8) {
+      const int map = item / 40, r = item % 40, blk = r / 5, part = r % 5;      // blk = plane * 4 + chunk
+      const int pix = part * 8 + (lane >> 3);
+      const char* base = map ? p.in2 : p.in1;
+      const char* src = base + tile_b + (long long)pix * (128 * 32 * 4) + (blk >> 2) * (256 * 32) + (blk & 3) * 2048 +
+                        (lane & 7) * 16;
+      const unsigned dst = (unsigned)(uintptr_t)lds + (unsigned)((map ? LDS_X2 : LDS_X1) + blk * BLK + part * 8 * PIXB);
+      const unsigned m0v = __builtin_amdgcn_readfirstlane(dst);
+      if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  bool clamped = false;
+  const float sA = *p.sA, sB = *p.sB, sC = *p.sC;
+  // A: layer1.conv2 (32 -> 32) + downsample(stem stride-2 pixels)      X1, X2 -> Y
+  chain_stage<32, 32, 32, false>(p, lds, LDS_X1, LDS_X2, LDS_Y, p.wA, p.bA, sA, group, clamped);
+  __syncthreads();
+  // B: layer2.conv1 (32 -> 64)                                          Y -> Z (over the dead inputs)
+  chain_stage<32, 0, 64, false>(p, lds, LDS_Y, 0, LDS_Z, p.wB, p.bB, sB, group, clamped);
+  __syncthreads();
+  // C: layer2.conv2 (64 -> 64) + downsample(Y)                          Z, Y -> global
+  chain_stage<64, 32, 64, true>(p, lds, LDS_Z, LDS_Y, 0, p.wC, p.bC, sC, group, clamped);
+  if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
+}
+
+}  // namespace
+
+// bytes of one stage's fragment-major weight block (without the trailing scale float)
+static size_t chain_block_bytes(int cin, int c2, int cout) { return (size_t)(cout / 32) * (9 * (cin / 16) + c2 / 16) * 2 * 1024; }
+
+size_t magat_block_chain_weight_floats() {      // three blocks, each followed by [2^-e, pad x3]
+  return (chain_block_bytes(32, 32, 32) + chain_block_bytes(32, 0, 64) + chain_block_bytes(64, 32, 64)) / 4 + 12;
+}
+
+// in1 / in2: [ceil(M/128)][36] plane-granule tiles of 32 channels.  w: the three fragment-major weight blocks of
+// encoder.pack_chain_weights, each followed by 4 floats [2^-e, 0, 0, 0].  bA / bB / bC: biases of layer1.conv2+downsample,
+// layer2.conv1, layer2.conv2+downsample.
+// out_gl 2: [ceil(M/128)][36] plane-granule tiles of 64 channels (out_pix_stride = 128*64, out_tile = 36*128*64 floats);
+// out_gl 0: float32 row-major tiles with the same strides.
+int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, long long out_pix_stride, long long out_tile,
+                      const float* w, const float* bA, const float* bB, const float* bC, int M, int* range_flag,
+                      hipStream_t st) {
+  if (!in1 || !in2 || !out || !w || !bA || !bB || !bC) return MAGAT_ERR_NULL;
+  if (M <= 0 || (out_gl != 0 && out_gl != 2)) return MAGAT_ERR_BAD_SHAPE;
+  ChainParams p;
+  p.in1 = static_cast<const char*>(in1); p.in2 = static_cast<const char*>(in2); p.out = static_cast<char*>(out);
+  p.out_gl = out_gl; p.out_pix_stride = out_pix_stride; p.out_tile = out_tile;
+  const char* wb = reinterpret_cast<const char*>(w);
+  const size_t nA = chain_block_bytes(32, 32, 32), nB = chain_block_bytes(32, 0, 64), nC = chain_block_bytes(64, 32, 64);
+  p.wA = wb; p.wB = wb + nA + 16; p.wC = wb + nA + 16 + nB + 16;
+  p.bA = bA; p.bB = bB; p.bC = bC;
+  p.sA = reinterpret_cast<const float*>(p.wA + nA);
+  p.sB = reinterpret_cast<const float*>(p.wB + nB);
+  p.sC = reinterpret_cast<const float*>(p.wC + nC);
+  p.M = M; p.groups = (M + AG - 1) / AG;
+  p.range_flag = range_flag;
+  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block_chain_kernel), MAGAT_LDS_BLOCK_A, LDS_TOTAL) != MAGAT_OK)
+    return MAGAT_ERR_LAUNCH;
+  const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_CHAIN, st);
+  hipLaunchKernelGGL(block_chain_kernel, dim3((unsigned)p.groups), dim3(512), LDS_TOTAL, st, p);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
+}

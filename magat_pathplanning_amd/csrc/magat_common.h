@@ -26,6 +26,11 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st);
 int magat_layer1_fused(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, void* out,
                        void* ctr, int M, int H, int W, hipStream_t st, int* range_flag = nullptr);   // layer1_fused.hip
 size_t magat_layer1_fused_lds(int W);   // 0: the fused kernel does not take this map width
+// BasicBlock chain kernel (block_fused.hip): layer1.conv2+ds -> layer2.conv1 -> layer2.conv2+ds on 6x6 maps, maps in LDS
+size_t magat_block_chain_weight_floats();
+int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, long long out_pix_stride, long long out_tile,
+                      const float* w, const float* bA, const float* bB, const float* bC, int M, int* range_flag,
+                      hipStream_t st);
 int magat_conv_direct_enabled();   // f16x3 direct kernel on (option CONV_DIRECT, default 1)
 
 // Library options (options.hip): read from the environment (MAGAT_<NAME>) ONCE, changed at run time through

@@ -164,8 +164,57 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
                 offs[30] = offs[slot + 6] + blk.numel()        # first permuted copy (non-zero = copies present)
                 offs[31] = offs[slot + 6] + 2 * blk.numel()    # first MX copy
         pack = torch.cat([pack] + raws).contiguous()
-    meta = dict(variant=0 if large else 1, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast)
+    # BasicBlock chain kernel (csrc/block_fused.hip; 6x6 maps only, i.e. the reference's 11x11 input): layer1.conv2+ds,
+    # layer2.conv1, layer2.conv2+ds as fragment-major f16 planes, appended to the pack; its float offset goes to meta["chain"]
+    chain_off = 0
+    if Ho == 6 and Wo == 6 and nblocks >= 2:
+        def rows(slot, cout):
+            nxt = sorted(o for o in offs[:18] if o > offs[slot])
+            return pack[offs[slot]:(nxt[0] if nxt else n_f32)].reshape(cout, -1)
+        blocks = [pack_chain_weights(rows(4, 32)[:, :9 * 32 + 32], 32, 32),
+                  pack_chain_weights(rows(6, 64)[:, :9 * 32], 32, 0),
+                  pack_chain_weights(rows(8, 64)[:, :9 * 64 + 32], 64, 32)]
+        chain_off = pack.numel()
+        pack = torch.cat([pack] + blocks).contiguous()
+    meta = dict(variant=0 if large else 1, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast, chain=chain_off)
     return pack, offs, meta
+
+
+def chain_channel(ks, fh, i):
+    """channel carried by element i of MFMA lane half fh in k step ks of a plane-granule map (magat_hip.h in_gl = 2)."""
+    return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (i >> 2) + 4 * fh + (i & 3)
+
+
+def pack_chain_weights(w, cin, c2):
+    """[Cout][9*cin + c2] float32 BN-folded rows ((ty, tx, c) order, then the 1x1 residual columns) -> the fragment-major
+    operand block of csrc/block_fused.hip: for channel tile ct, tap u = 0..8 (9 = residual segment), k step ks, plane pl
+    one 1 KB block [64 lanes][8 halves]: lane l holds, for output channel 32 ct + (l & 31), the weights of the channels
+    chain_channel(ks, l >> 5, i), i = 0..7, of that tap - the order in which the activation lanes hold their operand.
+    Values are f16 planes of w * 2^e (split_f16x2's scale); 4 floats [2^-e, 0, 0, 0] follow."""
+    w = w.detach().float().cpu()
+    cout = w.shape[0]
+    assert w.shape[1] == 9 * cin + c2 and cout % 32 == 0 and cin % 16 == 0 and c2 % 16 == 0
+    mx = float(w.abs().max())
+    e = 0 if mx == 0.0 else 13 - int(math.floor(math.log2(mx)))
+    e = max(-14, min(e, 24))
+    ws = w * (2.0 ** e)
+    h1 = ws.half()
+    h2 = (ws - h1.float()).half()
+    lane = torch.arange(64)
+    n_in, fh = lane & 31, lane >> 5
+    i8 = torch.arange(8)
+    out = []
+    for ct in range(cout // 32):
+        segs = [(u, cin // 16, u * cin) for u in range(9)] + ([(9, c2 // 16, 9 * cin)] if c2 else [])
+        for u, nks, base in segs:
+            for ks in range(nks):
+                ch = (32 * (ks >> 1) + 16 * (ks & 1) + 8 * (i8.view(1, 8) >> 2) + 4 * fh.view(64, 1) + (i8.view(1, 8) & 3))
+                col = base + ch                                          # [64][8]
+                row = (32 * ct + n_in).view(64, 1).expand(64, 8)
+                for plane in (h1, h2):
+                    out.append(plane[row, col].reshape(-1))
+    blk = torch.cat(out).view(torch.int16)
+    return torch.cat((blk.view(torch.float32), torch.tensor([2.0 ** (-e), 0.0, 0.0, 0.0], dtype=torch.float32)))
 
 
 def split_bf16x3(t):

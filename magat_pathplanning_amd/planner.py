@@ -336,6 +336,7 @@ class DecentralPlannerGATNet(nn.Module):
             d.pack = rt.pack.data_ptr()
             for i, o in enumerate(offs):
                 d.off[i] = o
+            d.chain_off = meta.get("chain", 0)
             rt.desc = d
         elif self.config.FOV + 2 == 11:
             pack, offs, meta = enc.fold_default_cnn(sd, 11, 11, "ConvLayers",
