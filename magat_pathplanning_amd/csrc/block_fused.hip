@@ -33,7 +33,8 @@ constexpr int PIXB = AG * 16;               // bytes per pixel slot of one (plan
 constexpr int BLK = (NPIX + 1) * PIXB;      // 4736 bytes per (plane, chunk) block
 constexpr int MAP32 = 8 * BLK;              // 32-channel map: 2 planes x 4 chunks
 constexpr int MAP64 = 16 * BLK;             // 64-channel map: 2 planes x 8 chunks
-constexpr int LDS_X1 = 0, LDS_X2 = MAP32, LDS_Z = 0, LDS_Y = MAP64, LDS_TOTAL = MAP64 + MAP32;
+// regions: [0, MAP64) Z (stage B output), its second half doubling as the residual input X2 of stage A; Y; the main input X1
+constexpr int LDS_X2 = MAP32, LDS_Z = 0, LDS_Y = MAP64, LDS_X1N = MAP64 + MAP32, LDS_TOTAL = MAP64 + 2 * MAP32;
 constexpr int TAPBIAS = 7 * PIXB;           // tap shifts are (6 dy + dx) pixel slots in [-7, 7]: biased to stay non-negative
 
 // row tiles by tap-validity class: pixel = 6 y + x
@@ -45,8 +46,9 @@ __device__ constexpr int TILE_TAPS[9] = {0x1FF, 0x1FF, 0x1FF, 0x1FF, 0x1F8, 0x03
 constexpr int T_I0 = 0, T_I1 = 1, T_I2 = 2, T_I3 = 3, T_ET = 4, T_EB = 5, T_EL = 6, T_ER = 7, T_C = 8;
 // wave -> row tiles.  32 output channels: one channel tile, waves split the nine row tiles; 64: wave = (channel tile w & 1,
 // row group w >> 1) - waves w and w + 4 share a SIMD: their tap counts add up to 33 / 36 per SIMD
-__device__ constexpr int WT32[8][3] = {{T_I0, -1, -1}, {T_I1, -1, -1}, {T_I2, -1, -1},    {T_I3, -1, -1},
-                                       {T_C, -1, -1},  {T_ET, T_EB, -1}, {T_EL, -1, -1}, {T_ER, -1, -1}};
+// (SIMD sums of MFMAs for 32 -> 32 + residual: 120, 120, 102, 126)
+__device__ constexpr int WT32[8][3] = {{T_I0, -1, -1}, {T_I2, -1, -1}, {T_C, -1, -1},  {T_EB, T_EL, -1},
+                                       {T_I1, -1, -1}, {T_I3, -1, -1}, {T_ET, -1, -1}, {T_ER, -1, -1}};
 __device__ constexpr int WG64[4][3] = {{T_I0, T_I1, -1}, {T_I2, T_I3, -1}, {T_C, T_ET, -1}, {T_EB, T_EL, T_ER}};
 
 struct ChainParams {
@@ -60,7 +62,15 @@ struct ChainParams {
   const float* sA; const float* sB; const float* sC;     // 2^-e of each weight block (one float behind it)
   int M, groups;
   int* range_flag;
+  long long* dbg;         // MAGAT_DEBUG_HOOKS builds only: [groups][8] phase timestamps of wave 0
 };
+
+#ifdef MAGAT_DEBUG_HOOKS
+#define CHAIN_STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(long long)blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+long long* g_chain_dbg = nullptr;
+#else
+#define CHAIN_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ void split2(float x, float y, unsigned& p1, unsigned& p2, bool& clamped) {
   clamped |= (x > 65504.f) | (y > 65504.f);              // (post-ReLU values)
@@ -236,42 +246,56 @@ __device__ __forceinline__ void chain_stage(const ChainParams& p, char* lds, int
   }
 }
 
+// PERSISTENT workgroups (one per CU), each walking agent groups g, g + grid, ...  The main input map of the NEXT group
+// (layer1.conv1's output, 37 KB) streams into a fourth LDS region with LDS-direct loads while stages B and C of the current
+// group run; only the 32-channel residual input is fetched at the top of an iteration (half of the 8.4 k-cycle prologue a
+// one-group-per-workgroup launch pays with nothing to overlap it; the other half does not fit: 5 x 37 KB > 160 KB).
 __global__ __launch_bounds__(512, 2) void block_chain_kernel(const ChainParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int group = blockIdx.x;
-  if (group >= p.groups) return;
-  // zero pixel of every (plane, chunk) block (24 blocks)
-  for (int i = t; i < 24 * (PIXB / 4); i += 512)
+  // zero pixel of every (plane, chunk) block (32 blocks): written once, never overwritten
+  for (int i = t; i < 32 * (PIXB / 4); i += 512)
     *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
-  // inputs: for (map, plane, chunk) the 36 pixels x 128 B of this agent group, 8 pixels per LDS-direct instruction
-  {
+  // one 32-channel input map of an agent group: for (plane, chunk) the 36 pixels x 128 B, 8 pixels per LDS-direct instruction
+  auto dma_map = [&](const char* base, int group, int lds_off) {
     const int m0 = group * AG;
     const long long tile_b = (long long)(m0 >> 7) * NPIX * (128 * 32 * 4) + (m0 & 127) * 16;    // bytes: agent tile, agents
-    for (int item = wave; item < 2 * 8 * 5; item += 8) {
-      const int map = item / 40, r = item % 40, blk = r / 5, part = r % 5;      // blk = plane * 4 + chunk
+    for (int item = wave; item < 8 * 5; item += 8) {
+      const int blk = item / 5, part = item % 5;             // blk = plane * 4 + chunk
       const int pix = part * 8 + (lane >> 3);
-      const char* base = map ? p.in2 : p.in1;
       const char* src = base + tile_b + (long long)pix * (128 * 32 * 4) + (blk >> 2) * (256 * 32) + (blk & 3) * 2048 +
                         (lane & 7) * 16;
-      const unsigned dst = (unsigned)(uintptr_t)lds + (unsigned)((map ? LDS_X2 : LDS_X1) + blk * BLK + part * 8 * PIXB);
-      const unsigned m0v = __builtin_amdgcn_readfirstlane(dst);
+      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(lds_off + blk * BLK + part * 8 * PIXB));
       if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
     }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  bool clamped = false;
+  };
   const float sA = *p.sA, sB = *p.sB, sC = *p.sC;
-  // A: layer1.conv2 (32 -> 32) + downsample(stem stride-2 pixels)      X1, X2 -> Y
-  chain_stage<32, 32, 32, false>(p, lds, LDS_X1, LDS_X2, LDS_Y, p.wA, p.bA, sA, group, clamped);
-  __syncthreads();
-  // B: layer2.conv1 (32 -> 64)                                          Y -> Z (over the dead inputs)
-  chain_stage<32, 0, 64, false>(p, lds, LDS_Y, 0, LDS_Z, p.wB, p.bB, sB, group, clamped);
-  __syncthreads();
-  // C: layer2.conv2 (64 -> 64) + downsample(Y)                          Z, Y -> global
-  chain_stage<64, 32, 64, true>(p, lds, LDS_Z, LDS_Y, 0, p.wC, p.bC, sC, group, clamped);
+  bool clamped = false;
+  int group = blockIdx.x;
+  if (group < p.groups) dma_map(p.in1, group, LDS_X1N);
+  for (; group < p.groups; group += (int)gridDim.x) {
+    CHAIN_STAMP(0);
+    __syncthreads();            // every wave is done reading the previous group's maps (and the zero pixels are written)
+    dma_map(p.in2, group, LDS_X2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this group's main input (issued an iteration ago) + the residual input
+    __syncthreads();
+    CHAIN_STAMP(1);
+    // A: layer1.conv2 (32 -> 32) + downsample(stem stride-2 pixels)      X1 (prefetch region), X2 -> Y
+    chain_stage<32, 32, 32, false>(p, lds, LDS_X1N, LDS_X2, LDS_Y, p.wA, p.bA, sA, group, clamped);
+    CHAIN_STAMP(2);
+    __syncthreads();
+    CHAIN_STAMP(3);
+    if (group + (int)gridDim.x < p.groups) dma_map(p.in1, group + (int)gridDim.x, LDS_X1N);      // lands under stages B and C
+    // B: layer2.conv1 (32 -> 64)                                          Y -> Z
+    chain_stage<32, 0, 64, false>(p, lds, LDS_Y, 0, LDS_Z, p.wB, p.bB, sB, group, clamped);
+    CHAIN_STAMP(4);
+    __syncthreads();
+    CHAIN_STAMP(5);
+    // C: layer2.conv2 (64 -> 64) + downsample(Y)                          Z, Y -> global
+    chain_stage<64, 32, 64, true>(p, lds, LDS_Z, LDS_Y, 0, p.wC, p.bC, sC, group, clamped);
+    CHAIN_STAMP(6);
+  }
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
@@ -306,10 +330,24 @@ int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, l
   p.sC = reinterpret_cast<const float*>(p.wC + nC);
   p.M = M; p.groups = (M + AG - 1) / AG;
   p.range_flag = range_flag;
+  p.dbg = nullptr;
+#ifdef MAGAT_DEBUG_HOOKS
+  p.dbg = g_chain_dbg;
+#endif
   if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block_chain_kernel), MAGAT_LDS_BLOCK_A, LDS_TOTAL) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const int grid = p.groups < cus ? p.groups : cus;
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_CHAIN, st);
-  hipLaunchKernelGGL(block_chain_kernel, dim3((unsigned)p.groups), dim3(512), LDS_TOTAL, st, p);
+  hipLaunchKernelGGL(block_chain_kernel, dim3((unsigned)grid), dim3(512), LDS_TOTAL, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
+
+#ifdef MAGAT_DEBUG_HOOKS
+extern "C" int magat_chain_set_debug_buffer(long long* dev_buf) { g_chain_dbg = dev_buf; return MAGAT_OK; }
+#endif

@@ -1,0 +1,31 @@
+"""Phase timing of the BasicBlock chain kernel (debug build: python -m magat_pathplanning_amd.build_native --debug;
+run with MAGAT_LIB_PATH=magat_pathplanning_amd/lib/libmagat_hip_debug.so)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import numpy as np
+from magat_pathplanning_amd import DecentralPlannerGATNet, _native as nat
+from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+dev = torch.device("cuda:0")
+B, N = 512, 100
+cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat", device="cuda:0")
+net = DecentralPlannerGATNet(cfg).to(dev).eval()
+x, S = fov_states(B, N).to(dev), comm_gso(B, N, 50).to(dev)
+groups = 256          # persistent grid: one workgroup per CU; the stamps are those of its LAST agent group
+buf = torch.zeros(groups, 8, dtype=torch.int64, device=dev)
+h = ctypes.CDLL(nat.LIB_PATH)
+h.magat_chain_set_debug_buffer.argtypes = [ctypes.c_void_p]
+with torch.no_grad():
+    for _ in range(3):
+        net.addGSO(S); net(x)
+    h.magat_chain_set_debug_buffer(ctypes.c_void_p(buf.data_ptr()))
+    net.addGSO(S); net(x)
+    torch.cuda.synchronize()
+    h.magat_chain_set_debug_buffer(None)
+t = buf.cpu().numpy().astype(np.float64)
+names = ["prologue (barrier + LDS write of the prefetched inputs)", "stage A", "barrier A", "stage B", "barrier B", "stage C (+ stores)"]
+d = t[:, 1:7] - t[:, 0:6]
+tot = t[:, 6] - t[:, 0]
+print("per-workgroup cycles (wave 0), mean / p90:  total %.0f / %.0f" % (tot.mean(), np.percentile(tot, 90)))
+for i, n in enumerate(names):
+    print("  %-30s %8.0f / %8.0f   (%.1f %%)" % (n, d[:, i].mean(), np.percentile(d[:, i], 90), 100 * d[:, i].mean() / tot.mean()))
