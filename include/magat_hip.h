@@ -353,6 +353,7 @@ typedef struct magat_encoder_desc {
   int64_t off[32];   /* float offsets into pack: see DESIGN.md "encoder pack" */
   int64_t chain_off; /* float offset of the BasicBlock chain kernel's fragment-major weights (encoder.pack_chain_weights: layer1.
                         conv2+downsample, layer2.conv1, layer2.conv2+downsample), 0 = absent -> layer-by-layer kernels (ABI 2) */
+  int64_t chain3_off; /* float offset of the layer3 kernel's weights (encoder.pack_block3_weights), 0 = absent (ABI 2) */
 } magat_encoder_desc;
 /* Range guard (option RANGE_GUARD, default 1).  The convolutions run as f16x3 split products (two half-precision planes per
  * value, fp32 accumulate: as accurate as the fp32 MFMA kernel while every activation stays within +-65504; the fused stem
@@ -392,6 +393,7 @@ int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* 
 #define MAGAT_TAG_GAT_LAYER 19    /* graph kernel with the per-agent maps computed inside (gat_fused.hip) */
 #define MAGAT_TAG_GSO_CSR 20      /* dense GSO -> CSR + CSC structure (magat_gso_csr_build, or the transpose inside *_csr_*) */
 #define MAGAT_TAG_GAT_CAST 21     /* float32 <-> bf16 row casts around the bf16-storage graph layer */
+#define MAGAT_TAG_BLOCK3 22       /* layer3 + ReLU + 2x2 pool in one launch (block_fused.hip) */
 #define MAGAT_PROF_TAGS 24
 int magat_gat_set_debug_buffer(long long* dev_buf); /* [grid][8] int64 phase timestamps of gat_dense_kernel; NULL = off */
 int magat_profile_reserve(int spans);   /* pre-create event pairs (keeps hipEventCreate out of a timed region) */

@@ -17,7 +17,7 @@ MODE_GNN = 3
 TAGS = {0: "untagged", 1: "conv_first", 2: "layer1.conv1", 3: "layer1.conv2+ds", 4: "layer2.conv1",
         5: "layer2.conv2+ds", 6: "layer3.conv1", 7: "layer3.conv2+ds", 8: "head(avgpool+fc+linear)",
         9: "compressMLP", 10: "gat_maps_gemm", 11: "gat_graph", 12: "actionsMLP", 13: "head_mean",
-        14: "gat_pack", 15: "gso_prepare", 16: "gat_prepare", 17: "range_guard", 18: "layer1.conv2+layer2 (fused)", 19: "gat_layer (fused maps)", 20: "gso_to_csr", 21: "gat_cast"}
+        14: "gat_pack", 15: "gso_prepare", 16: "gat_prepare", 17: "range_guard", 18: "layer1.conv2+layer2 (fused)", 19: "gat_layer (fused maps)", 20: "gso_to_csr", 21: "gat_cast", 22: "layer3 (fused, pooled)"}
 TAG_ACTIONS = 12
 
 _lock = threading.Lock()
@@ -52,7 +52,7 @@ class ConvGemmDesc(ctypes.Structure):
 class EncoderDesc(ctypes.Structure):
     _fields_ = [("variant", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
                 ("n_feat", ctypes.c_int), ("n_comp", ctypes.c_int), ("pack", ctypes.c_void_p),
-                ("off", ctypes.c_int64 * 32), ("chain_off", ctypes.c_int64)]
+                ("off", ctypes.c_int64 * 32), ("chain_off", ctypes.c_int64), ("chain3_off", ctypes.c_int64)]
 
 
 _I, _P, _Z = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t

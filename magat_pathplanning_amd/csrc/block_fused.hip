@@ -246,6 +246,255 @@ __device__ __forceinline__ void chain_stage(const ChainParams& p, char* lds, int
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// layer3 of ResNetLarge in one launch: conv1 (64 -> 128) -> conv2 (128 -> 128) + downsample(64 -> 128) -> ReLU -> 2x2 sum-pool.
+// Same row tiling as above, 8 agents per workgroup.  The 128-channel intermediate map (148 KB for 8 agents) does not fit LDS
+// next to the input, so it is produced and consumed in two 64-channel HALVES: conv1 half h -> LDS, conv2 accumulates its K
+// segment over those 64 channels into register accumulators that live across both halves (wave = output channel tile x one
+// of two row-tile groups: 69 tile-taps on every SIMD, 80 accumulator registers).  The output never reaches HBM un-pooled:
+// ReLU'd values go to an LDS scratch (the two map regions, dead by then) and the AvgPool2d(2) sums - the 1/4 lives in the
+// head's weights - are written as [cell 9][agent][128] float32: 0.24 GB per 51 200 agents instead of 0.94 GB written by the
+// convolution and 0.94 GB read back by the head.
+struct L3Params {
+  const char* in;         // layer2 output, f16 plane granules, 64 channels: [agent tile][pixel][128 agents x 256 B]
+  float* out;             // pooled float32 [agent tile][cell 9][128 agents][128]
+  const char* w1;         // conv1: [ct 4][tap 9][ks 4][plane 2] 1 KB blocks, then float 2^-e
+  const char* w2a;        // conv2, K over intermediate channels 0..63:   [ct 4][tap 9][ks 4][plane 2]
+  const char* w2b;        // conv2, K over channels 64..127 + residual:   [ct 4][tap 9 | residual][ks 4][plane 2], then float 2^-e
+  const float* b1; const float* b2;
+  const float* s1; const float* s2;
+  int M, groups;
+  int* range_flag;
+};
+
+// row-tile groups of the conv2 waves: 33 + 36 tile-taps
+__device__ constexpr int L3_RG[2][5] = {{T_I0, T_I1, T_I2, T_ET, -1}, {T_I3, T_C, T_EB, T_EL, T_ER}};
+
+// K walk of one wave over its row tiles (run-time list, -1 = none): acc[s] += conv taps (KSM k steps each) [+ residual segment].
+// Register-lean form for the layer3 kernel, whose conv2 accumulators (80 registers) stay live across everything: the weight
+// ring holds ONE k step (two planes, 8 registers) per slot and is fetched one k step ahead - a k step is 3 MFMAs per row
+// tile, 6-15 MFMAs per wave, about an L2 round trip.
+template <int KSM, int KS2, int NS>
+__device__ __forceinline__ void conv_walk(char* lds, int in_off, int in2_off, const char* wl, const int (&tl)[NS],
+                                          f32x16 (&acc)[NS]) {
+  constexpr int PS_IN = 2 * KSM * BLK, PS_IN2 = 2 * KS2 * BLK;
+  constexpr int NSTEP = 9 * KSM + KS2;                 // k steps of the whole walk, in weight-stream order
+  // (laundered thread index: the per-tap LDS addresses below are recomputed in every call - left alone, the compiler hoists
+  //  all 9 x NS of them out of the caller's loop over the channel halves and spills them: 1.3 KB of scratch per lane)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int agent = fr & 7, psl = fr >> 3;
+  int umask = 0;
+  unsigned ab[NS];
+  int lmask[NS];
+  const unsigned az = (unsigned)(ZPIX * PIXB + agent * 16 + fh * BLK);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int tile = tl[s] < 0 ? 0 : tl[s];
+    if (tl[s] >= 0) umask |= TILE_TAPS[tile];
+    const int pix = TILE_PIX[tile][psl];
+    const int y = pix / 6, x = pix - 6 * y;
+    int m = 0;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+      if (y + dy >= 0 && y + dy < 6 && x + dx >= 0 && x + dx < 6) m |= 1 << tp;
+    }
+    lmask[s] = m;
+    ab[s] = (unsigned)(pix * PIXB + agent * 16 + fh * BLK);
+  }
+  u32x4 bw[2][2];
+  auto load_b = [&](int step, u32x4 (&b)[2]) {
+    b[0] = *reinterpret_cast<const u32x4*>(wl + (size_t)step * 2048);
+    b[1] = *reinterpret_cast<const u32x4*>(wl + (size_t)step * 2048 + 1024);
+  };
+  load_b(0, bw[0]);
+  constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
+  static_assert(KSM % 2 == 0, "the ring slot of a k step must not depend on the tap");
+  // (run-time loop over the taps: unrolled, the scheduler computes all 9 x NS tap addresses up front and spills)
+#pragma unroll 1
+  for (int tp = 0; tp < 9; ++tp) {
+    const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+    const int shift = (6 * dy + dx) * PIXB + TAPBIAS;
+    unsigned a0[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      a0[s] = ((lmask[s] >> tp & 1) ? ab[s] + (unsigned)shift : az + (unsigned)TAPBIAS) + (unsigned)in_off - (unsigned)TAPBIAS;
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks) {
+      const int step = tp * KSM + ks;
+      if (step + 1 < NSTEP) load_b(step + 1, bw[(step + 1) & 1]);
+      if (!(umask >> tp & 1)) continue;                 // wave-uniform (the fetch above keeps the ring in step)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (tl[s] < 0 || !(TILE_TAPS[tl[s] < 0 ? 0 : tl[s]] >> tp & 1)) continue;
+        const u32x4 av[2] = {*reinterpret_cast<const u32x4*>(lds + a0[s] + ks * 2 * BLK),
+                             *reinterpret_cast<const u32x4*>(lds + a0[s] + ks * 2 * BLK + PS_IN)};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bw[step & 1][PB[q]]),
+                                                          __builtin_bit_cast(f16x8, av[PA[q]]), acc[s], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS2; ++ks) {
+    const int step = 9 * KSM + ks;
+    if (step + 1 < NSTEP) load_b(step + 1, bw[(step + 1) & 1]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (tl[s] < 0) continue;
+      const unsigned a0 = ab[s] + (unsigned)in2_off;
+      const u32x4 av[2] = {*reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK),
+                           *reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK + PS_IN2)};
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bw[step & 1][PB[q]]),
+                                                        __builtin_bit_cast(f16x8, av[PA[q]]), acc[s], 0, 0, 0);
+    }
+  }
+}
+
+// relu(acc * scale + bias) of a wave's row tiles as f16 plane chunks of an LDS map with COUT channels (channel tile ct)
+template <int COUT, int NS>
+__device__ __forceinline__ void epi_to_lds(char* lds, int out_off, const int (&tl)[NS], const f32x16 (&acc)[NS], int ct,
+                                           const float* bias, float scale, bool rows_ok, bool& clamped) {
+  constexpr int PS_OUT = (COUT / 8) * BLK;
+  const int lane = threadIdx.x & 63;
+  const int fr = lane & 31, fh = lane >> 5, agent = fr & 7, psl = fr >> 3;
+  f32x4 bq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bias + 32 * ct + 8 * q + 4 * fh);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    if (tl[s] < 0) continue;
+    const int pix = TILE_PIX[tl[s]][psl];
+    bool cl = false;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      unsigned h1[4], h2[4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int q = 2 * ks + e;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * scale + bq[q][c], 0.f);
+        split2(v[0], v[1], h1[2 * e], h2[2 * e], cl);
+        split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1], cl);
+      }
+      char* o = lds + out_off + ((ct * 2 + ks) * 2 + fh) * BLK + pix * PIXB + agent * 16;
+      *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+      *reinterpret_cast<u32x4*>(o + PS_OUT) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+    }
+    clamped |= cl && rows_ok;
+  }
+}
+
+// row-tile groups of the 64-output-channel conv1 halves (as the chain kernel's stage B): 18 / 18 / 15 / 18 tile-taps
+__device__ constexpr int L3_G1[4][3] = {{T_I0, T_I1, -1}, {T_I2, T_I3, -1}, {T_C, T_ET, -1}, {T_EB, T_EL, T_ER}};
+
+__global__ __launch_bounds__(512, 2) void block3_kernel(const L3Params p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  constexpr int L_IN = 0, L_MID = MAP64;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int group = blockIdx.x;
+  if (group >= p.groups) return;
+  for (int i = t; i < 32 * (PIXB / 4); i += 512)
+    *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
+  {   // input map: 16 (plane, chunk) blocks x 36 pixels x 128 B of this agent group
+    const int m0 = group * AG;
+    const long long tile_b = (long long)(m0 >> 7) * NPIX * (128 * 64 * 4) + (m0 & 127) * 16;
+    for (int item = wave; item < 16 * 5; item += 8) {
+      const int blk = item / 5, part = item % 5;             // blk = plane * 8 + chunk
+      const int pix = part * 8 + (lane >> 3);
+      const char* src = p.in + tile_b + (long long)pix * (128 * 64 * 4) + (blk >> 3) * (256 * 64) + (blk & 7) * 2048 +
+                        (lane & 7) * 16;
+      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(L_IN + blk * BLK + part * 8 * PIXB));
+      if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+    }
+  }
+  const float s1 = *p.s1, s2 = *p.s2;
+  bool clamped = false;
+  const bool rows_ok = group * AG + ((lane & 31) & 7) < p.M;
+  // conv1 role of this wave (per half): channel tile ct1 of the half, row-tile group; conv2 role: output channel tile ct2,
+  // one of two row-tile groups
+  const int ct1 = wave & 1;
+  int tl1[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) tl1[s] = L3_G1[wave >> 1][s];
+  const int ct2 = wave & 3, rg = wave >> 2;
+  int tl2[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) tl2[s] = L3_RG[rg][s];
+  f32x16 acc[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  constexpr int BPT1 = 9 * 4 * 2, BPT2A = 9 * 4 * 2, BPT2B = (9 * 4 + 4) * 2;      // 1 KB blocks per channel tile
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    {   // conv1, output channels 64 h .. 64 h + 63 -> MID (channel tiles 2 h, 2 h + 1 of the weight block)
+      f32x16 a1[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
+      conv_walk<4, 0, 3>(lds, L_IN, 0, p.w1 + (size_t)(2 * h + ct1) * BPT1 * 1024 + lane * 16, tl1, a1);
+      epi_to_lds<64, 3>(lds, L_MID, tl1, a1, ct1, p.b1 + 64 * h, s1, rows_ok, clamped);
+    }
+    __syncthreads();
+    // conv2: K over these 64 intermediate channels (second half: + the residual 1x1 over the 64 input channels)
+    if (h == 0) conv_walk<4, 0, 5>(lds, L_MID, 0, p.w2a + (size_t)ct2 * BPT2A * 1024 + lane * 16, tl2, acc);
+    else conv_walk<4, 4, 5>(lds, L_MID, L_IN, p.w2b + (size_t)ct2 * BPT2B * 1024 + lane * 16, tl2, acc);
+    __syncthreads();          // MID is rewritten by the next half / becomes scratch
+  }
+  // ReLU'd output -> LDS scratch [pixel][agent][128 floats] (16-byte quads XOR-swizzled by the row: the 32 lanes that hold the
+  // same quad index then hit 32 different bank groups), then the 2x2 sums
+  float* S = reinterpret_cast<float*>(lds);
+  {
+    const int fr = lane & 31, fh = lane >> 5, agent = fr & 7, psl = fr >> 3;
+    f32x4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(p.b2 + 32 * ct2 + 8 * q + 4 * fh);
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      if (tl2[s] < 0) continue;
+      const int pix = TILE_PIX[tl2[s]][psl];
+      const int row = pix * AG + agent;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * s2 + bq[q][c], 0.f);
+        const int Q = 8 * ct2 + 2 * q + fh;
+        *reinterpret_cast<f32x4*>(S + row * 128 + ((Q ^ (row & 31)) << 2)) = v;
+      }
+    }
+  }
+  __syncthreads();
+  for (int o = t; o < 9 * AG * 32; o += 512) {
+    const int Q = o & 31, agent = (o >> 5) & 7, cell = o >> 8;
+    const int cy = cell / 3, cx = cell - 3 * cy;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pix = (2 * cy + (e >> 1)) * 6 + 2 * cx + (e & 1);
+      const int row = pix * AG + agent;
+      sum += *reinterpret_cast<const f32x4*>(S + row * 128 + ((Q ^ (row & 31)) << 2));
+    }
+    const int m = group * AG + agent;
+    if (m < p.M)
+      *reinterpret_cast<f32x4*>(p.out + ((long long)(m >> 7) * 9 + cell) * (128 * 128) + (m & 127) * 128 + 4 * Q) = sum;
+  }
+  if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
+}
+
 // PERSISTENT workgroups (one per CU), each walking agent groups g, g + grid, ...  The main input map of the NEXT group
 // (layer1.conv1's output, 37 KB) streams into a fourth LDS region with LDS-direct loads while stages B and C of the current
 // group run; only the 32-channel residual input is fetched at the top of an iteration (half of the 8.4 k-cycle prologue a
@@ -344,6 +593,34 @@ int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, l
   const int grid = p.groups < cus ? p.groups : cus;
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_CHAIN, st);
   hipLaunchKernelGGL(block_chain_kernel, dim3((unsigned)grid), dim3(512), LDS_TOTAL, st, p);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
+}
+
+size_t magat_block3_weight_floats() { return ((size_t)(4 * 72 + 4 * 72 + 4 * 80) * 1024) / 4 + 12; }
+
+// layer3 (+ ReLU + 2x2 sum-pool) of ResNetLarge.  in: [ceil(M/128)][36] plane-granule tiles of 64 channels (layer2's output);
+// out: pooled float32 [ceil(M/128)][9][128][128].  w: conv1 block, conv2 first-half block, conv2 second-half block
+// (encoder.pack_block3_weights), each followed by 4 floats [2^-e, 0, 0, 0]; b1 / b2: biases of conv1, conv2 + downsample.
+int magat_block3(const void* in, float* out, const float* w, const float* b1, const float* b2, int M, int* range_flag,
+                 hipStream_t st) {
+  if (!in || !out || !w || !b1 || !b2) return MAGAT_ERR_NULL;
+  if (M <= 0) return MAGAT_ERR_BAD_SHAPE;
+  L3Params p;
+  p.in = static_cast<const char*>(in); p.out = out;
+  const char* wb = reinterpret_cast<const char*>(w);
+  const size_t n1 = (size_t)4 * 72 * 1024, n2a = (size_t)4 * 72 * 1024, n2b = (size_t)4 * 80 * 1024;
+  p.w1 = wb; p.w2a = wb + n1 + 16; p.w2b = wb + n1 + 16 + n2a + 16;
+  p.s1 = reinterpret_cast<const float*>(p.w1 + n1);
+  p.s2 = reinterpret_cast<const float*>(p.w2b + n2b);
+  p.b1 = b1; p.b2 = b2;
+  p.M = M; p.groups = (M + AG - 1) / AG;
+  p.range_flag = range_flag;
+  constexpr size_t lds = 2 * MAP64;
+  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block3_kernel), MAGAT_LDS_BLOCK_B, lds) != MAGAT_OK)
+    return MAGAT_ERR_LAUNCH;
+  const int pid = magat_prof_begin(MAGAT_TAG_BLOCK3, st);
+  hipLaunchKernelGGL(block3_kernel, dim3((unsigned)p.groups), dim3(512), lds, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }

@@ -364,6 +364,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     int cur = 0;              // buffer holding the block input
     int hin = H, win = W;
     int lstart = 0;
+    bool pooled_in = false;     // buf[cur] already holds the 2x2-pooled map [tile][(hin/2)(win/2)][128][clast]
     // BasicBlock chain kernel (block_fused.hip): layer1.conv2+downsample -> layer2.conv1 -> layer2.conv2+downsample in one
     // launch with the 6x6 maps of an 8-agent group in LDS (3.35 GB of HBM traffic per 51 200 agents become 0.94 GB).
     // Needs the fused stem's plane-granule outputs; option BLOCK_FUSED=0 keeps the layer-by-layer kernels.
@@ -372,6 +373,13 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
                              pk + d->off[5], pk + d->off[7], pk + d->off[9], mm, reinterpret_cast<int*>(range_flag), st);
       if (rc != MAGAT_OK) return rc;
       cur = 2; hin = Ho; win = Wo; lstart = 2;
+      // ... and layer3 + ReLU + AvgPool2d(2) as one more launch: the head then reads 9 pooled cells instead of 36 pixels
+      if (nblocks == 3 && d->chain3_off > 0 && magat_opt(MAGAT_OPT_BLOCK3_FUSED)) {
+        rc = magat_block3(buf[2], buf[0], pk + d->chain3_off, pk + d->off[11], pk + d->off[13], mm,
+                          reinterpret_cast<int*>(range_flag), st);
+        if (rc != MAGAT_OK) return rc;
+        cur = 0; lstart = 3; pooled_in = true;
+      }
     }
     for (int l = lstart; l < nblocks; ++l) {
       const BlockShape s = shapes[l];
@@ -430,10 +438,11 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     magat_conv_gemm_desc g = {};
     g.in = buf[cur]; g.wt = pk + d->off[14]; g.bias = pk + d->off[15];
     g.out = feat + (size_t)m0 * ldfeat;
-    g.in_pix_stride = pixs(clast); g.in_tile_stride = tiles(hin * win, clast);
+    g.in_pix_stride = pixs(clast); g.in_tile_stride = tiles(pooled_in ? (hin / 2) * (win / 2) : hin * win, clast);
     g.M = mm; g.Cin = clast; g.lda = clast; g.Hin = hin / 2; g.Win = win / 2;
     g.kH = hin / 2; g.kW = win / 2; g.stride = 1; g.pad = 0; g.Hout = g.Wout = 1; g.Cout = d->n_feat; g.ldc = ldfeat;
-    g.relu = 0; g.pool = 1; g.pool_w = win;
+    g.relu = 0;
+    if (!pooled_in) { g.pool = 1; g.pool_w = win; }
     g.tag = tagof(MAGAT_TAG_HEAD);
     g.run_if = run_if;
     // Few agents (the closed-loop batch-1 step): one workgroup per 64 agents would walk all (hin/2)(win/2) clast of K alone

@@ -28,6 +28,9 @@ int magat_layer1_fused(const float* x, const float* w0, const float* b0, const f
 size_t magat_layer1_fused_lds(int W);   // 0: the fused kernel does not take this map width
 // BasicBlock chain kernel (block_fused.hip): layer1.conv2+ds -> layer2.conv1 -> layer2.conv2+ds on 6x6 maps, maps in LDS
 size_t magat_block_chain_weight_floats();
+size_t magat_block3_weight_floats();
+int magat_block3(const void* in, float* out, const float* w, const float* b1, const float* b2, int M, int* range_flag,
+                 hipStream_t st);
 int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, long long out_pix_stride, long long out_tile,
                       const float* w, const float* bA, const float* bB, const float* bC, int M, int* range_flag,
                       hipStream_t st);
@@ -40,7 +43,7 @@ enum MagatOpt {
   MAGAT_OPT_ENC_CHUNK, MAGAT_OPT_CONV_SPLIT, MAGAT_OPT_CONV_F16, MAGAT_OPT_CONV_PCHAIN, MAGAT_OPT_CONV_MX,
   MAGAT_OPT_L1_FUSED, MAGAT_OPT_HEAD_SPLITK, MAGAT_OPT_GAT_CHUNK_MB, MAGAT_OPT_GAT_ZPAD, MAGAT_OPT_GAT_SPLIT,
   MAGAT_OPT_GAT_HPB, MAGAT_OPT_GAT_ZTILES, MAGAT_OPT_GAT_PERSIST, MAGAT_OPT_RANGE_GUARD, MAGAT_OPT_BLOCK_FUSED,
-  MAGAT_OPT_GAT_FUSED_MAPS, MAGAT_OPT_CSR_TILED, MAGAT_OPT_COUNT
+  MAGAT_OPT_GAT_FUSED_MAPS, MAGAT_OPT_CSR_TILED, MAGAT_OPT_BLOCK3_FUSED, MAGAT_OPT_COUNT
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)

@@ -39,6 +39,7 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
     {"BLOCK_FUSED", 1},      // BasicBlock chain kernel (conv1 -> conv2 (+downsample) with the 6x6 maps in LDS)
     {"GAT_FUSED_MAPS", 1},   // hoisted maps computed inside the graph kernel (Z never crosses HBM)
     {"CSR_TILED", 3},        // CSR path, N <= 1024: LDS-tiled kernels (bit 0 scores, bit 1 hops) instead of L2 gathers
+    {"BLOCK3_FUSED", 1},     // layer3 + ReLU + pool as one launch (two-half intermediate in LDS); needs BLOCK_FUSED
 };
 
 int g_val[MAGAT_OPT_COUNT];

@@ -176,8 +176,31 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
                   pack_chain_weights(rows(8, 64)[:, :9 * 64 + 32], 64, 32)]
         chain_off = pack.numel()
         pack = torch.cat([pack] + blocks).contiguous()
-    meta = dict(variant=0 if large else 1, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast, chain=chain_off)
+    chain3_off = 0
+    if chain_off and large:
+        def rows3(slot):
+            nxt = sorted(o for o in offs[:18] if o > offs[slot])
+            return pack[offs[slot]:(nxt[0] if nxt else n_f32)].reshape(128, -1)
+        chain3_off = pack.numel()
+        pack = torch.cat([pack] + pack_block3_weights(rows3(10)[:, :9 * 64], rows3(12)[:, :9 * 128 + 64])).contiguous()
+    meta = dict(variant=0 if large else 1, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast, chain=chain_off,
+                chain3=chain3_off)
     return pack, offs, meta
+
+
+def pack_block3_weights(w1, w2):
+    """layer3 kernel (csrc/block_fused.hip block3_kernel): conv1 rows [128][9*64] and [conv2 | downsample] rows
+    [128][9*128 + 64] -> three fragment-major blocks: conv1; conv2 over intermediate channels 0..63; conv2 over channels
+    64..127 followed by the residual columns.  The two conv2 blocks share one power-of-two scale (they feed the same
+    accumulators)."""
+    w2 = w2.detach().float().cpu()
+    taps = w2[:, :9 * 128].reshape(128, 9, 128)
+    lo = taps[:, :, :64].reshape(128, 9 * 64)
+    hi = torch.cat((taps[:, :, 64:].reshape(128, 9 * 64), w2[:, 9 * 128:]), dim=1)
+    mx = float(w2.abs().max())
+    e = 0 if mx == 0.0 else 13 - int(math.floor(math.log2(mx)))
+    e = max(-14, min(e, 24))
+    return [pack_chain_weights(w1, 64, 0), pack_chain_weights(lo, 64, 0, e=e), pack_chain_weights(hi, 64, 64, e=e)]
 
 
 def chain_channel(ks, fh, i):
@@ -185,7 +208,7 @@ def chain_channel(ks, fh, i):
     return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (i >> 2) + 4 * fh + (i & 3)
 
 
-def pack_chain_weights(w, cin, c2):
+def pack_chain_weights(w, cin, c2, e=None):
     """[Cout][9*cin + c2] float32 BN-folded rows ((ty, tx, c) order, then the 1x1 residual columns) -> the fragment-major
     operand block of csrc/block_fused.hip: for channel tile ct, tap u = 0..8 (9 = residual segment), k step ks, plane pl
     one 1 KB block [64 lanes][8 halves]: lane l holds, for output channel 32 ct + (l & 31), the weights of the channels
@@ -194,9 +217,10 @@ def pack_chain_weights(w, cin, c2):
     w = w.detach().float().cpu()
     cout = w.shape[0]
     assert w.shape[1] == 9 * cin + c2 and cout % 32 == 0 and cin % 16 == 0 and c2 % 16 == 0
-    mx = float(w.abs().max())
-    e = 0 if mx == 0.0 else 13 - int(math.floor(math.log2(mx)))
-    e = max(-14, min(e, 24))
+    if e is None:
+        mx = float(w.abs().max())
+        e = 0 if mx == 0.0 else 13 - int(math.floor(math.log2(mx)))
+        e = max(-14, min(e, 24))
     ws = w * (2.0 ** e)
     h1 = ws.half()
     h2 = (ws - h1.float()).half()
