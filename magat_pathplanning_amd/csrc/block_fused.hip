@@ -68,6 +68,7 @@ struct ChainParams {
 #ifdef MAGAT_DEBUG_HOOKS
 #define CHAIN_STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(long long)blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 long long* g_chain_dbg = nullptr;
+long long* g_block3_dbg = nullptr;
 #else
 #define CHAIN_STAMP(i) do { } while (0)
 #endif
@@ -265,6 +266,7 @@ struct L3Params {
   const float* s1; const float* s2;
   int M, groups;
   int* range_flag;
+  long long* dbg;
 };
 
 // row-tile groups of the conv2 waves: 33 + 36 tile-taps
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(512, 2) void block3_kernel(const L3Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int group = blockIdx.x;
   if (group >= p.groups) return;
+  CHAIN_STAMP(0);
   for (int i = t; i < 32 * (PIXB / 4); i += 512)
     *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
   {   // input map: 16 (plane, chunk) blocks x 36 pixels x 128 B of this agent group
@@ -437,6 +440,7 @@ __global__ __launch_bounds__(512, 2) void block3_kernel(const L3Params p) {
   constexpr int BPT1 = 9 * 4 * 2, BPT2A = 9 * 4 * 2, BPT2B = (9 * 4 + 4) * 2;      // 1 KB blocks per channel tile
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  CHAIN_STAMP(1);
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     {   // conv1, output channels 64 h .. 64 h + 63 -> MID (channel tiles 2 h, 2 h + 1 of the weight block)
@@ -449,10 +453,12 @@ __global__ __launch_bounds__(512, 2) void block3_kernel(const L3Params p) {
       epi_to_lds<64, 3>(lds, L_MID, tl1, a1, ct1, p.b1 + 64 * h, s1, rows_ok, clamped);
     }
     __syncthreads();
+    CHAIN_STAMP(2 + 2 * h);
     // conv2: K over these 64 intermediate channels (second half: + the residual 1x1 over the 64 input channels)
     if (h == 0) conv_walk<4, 0, 5>(lds, L_MID, 0, p.w2a + (size_t)ct2 * BPT2A * 1024 + lane * 16, tl2, acc);
     else conv_walk<4, 4, 5>(lds, L_MID, L_IN, p.w2b + (size_t)ct2 * BPT2B * 1024 + lane * 16, tl2, acc);
     __syncthreads();          // MID is rewritten by the next half / becomes scratch
+    CHAIN_STAMP(3 + 2 * h);
   }
   // ReLU'd output -> LDS scratch [pixel][agent][128 floats] (16-byte quads XOR-swizzled by the row: the 32 lanes that hold the
   // same quad index then hit 32 different bank groups), then the 2x2 sums
@@ -492,6 +498,7 @@ __global__ __launch_bounds__(512, 2) void block3_kernel(const L3Params p) {
     if (m < p.M)
       *reinterpret_cast<f32x4*>(p.out + ((long long)(m >> 7) * 9 + cell) * (128 * 128) + (m & 127) * 128 + 4 * Q) = sum;
   }
+  CHAIN_STAMP(6);
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
@@ -616,6 +623,10 @@ int magat_block3(const void* in, float* out, const float* w, const float* b1, co
   p.b1 = b1; p.b2 = b2;
   p.M = M; p.groups = (M + AG - 1) / AG;
   p.range_flag = range_flag;
+  p.dbg = nullptr;
+#ifdef MAGAT_DEBUG_HOOKS
+  p.dbg = g_block3_dbg;
+#endif
   constexpr size_t lds = 2 * MAP64;
   if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block3_kernel), MAGAT_LDS_BLOCK_B, lds) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
@@ -627,4 +638,5 @@ int magat_block3(const void* in, float* out, const float* w, const float* b1, co
 
 #ifdef MAGAT_DEBUG_HOOKS
 extern "C" int magat_chain_set_debug_buffer(long long* dev_buf) { g_chain_dbg = dev_buf; return MAGAT_OK; }
+extern "C" int magat_block3_set_debug_buffer(long long* dev_buf) { g_block3_dbg = dev_buf; return MAGAT_OK; }
 #endif
