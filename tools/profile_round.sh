@@ -9,9 +9,9 @@ R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing"
+BENCH="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-extra-legs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o c3 -- $BENCH > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o c3 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o c3 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o c3 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-extra-legs > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o c3 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-extra-legs > $OUT/pmc_write.log 2>&1
 cd $R
 python tools/rocprof_summary.py $OUT $TAG

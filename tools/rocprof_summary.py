@@ -29,6 +29,9 @@ def short(name):
                    ("conv_gemm_kernel<128, 128", "conv_gemm_f32<128,128>"), ("conv_gemm_kernel<128, 64", "conv_gemm_f32<128,64>"),
                    ("conv_gemm_kernel<128, 32", "conv_gemm_f32<128,32>"), ("conv_first_kernel", "conv_first"),
                    ("layer1_fused_kernel", "layer1_fused(stem+layer1.conv1)"),
+                   ("block_chain_kernel", "block_chain(layer1.conv2+layer2)"), ("block3_kernel", "block3(layer3+pool)"),
+                   ("gat_guard_count_kernel", "guard_count(gat)"), ("guard_count_kernel", "guard_count(encoder)"),
+                   ("gat_fused_kernel", "gat_fused_kernel"),
                    ("gat_dense_kernel", "gat_dense_kernel"), ("head_mean_relu", "head_mean_relu"),
                    ("pack_kernel", "gat_pack"), ("gso_prepare", "gso_prepare")):
         if key in name:
@@ -71,17 +74,21 @@ def main():
         for k, (n, tot) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
             lines.append("%-28s launches=%5d avg_KiB=%14.1f" % (k, n, tot / n))
             res["kernels"].setdefault(k, {})[ctr + "_KiB_per_launch"] = tot / n
-    # per-layer split: our library launches a fixed 12-kernel sequence per addGSO+forward step (c3 workload)
-    SEQ = ["conv_first", "layer1.conv1", "layer1.conv2+ds", "layer2.conv1", "layer2.conv2+ds", "layer3.conv1",
-           "layer3.conv2+ds", "head(avgpool+fc+linear)", "compressMLP", "gat_maps_gemm", "gat_graph", "actionsMLP"]
+    # per-layer split: the library launches a fixed kernel sequence per addGSO+forward step (c3 workload, default options:
+    # fused stem, BasicBlock chain kernel, layer3 kernel, range guard on).  "guard:*" entries are the predicated float32 re-run
+    # launches of the range guard (no-ops while nothing clamps).
+    SEQ = ["conv_first+layer1.conv1 (fused)", "layer1.conv2+layer2 (fused)", "layer3 (fused, pooled)",
+           "head(avgpool+fc+linear)", "compressMLP",
+           "guard:conv_first", "guard:layer1.conv1", "guard:layer1.conv2", "guard:layer2.conv1", "guard:layer2.conv2",
+           "guard:layer3.conv1", "guard:layer3.conv2", "guard:head", "guard:compress", "guard:count",
+           "gat_maps_gemm", "guard:gat_maps", "guard:gat_count", "gat_graph", "actionsMLP"]
     ours = ("conv_gemm_kernel", "conv_gemm_bf16x6_kernel", "conv_gemm_f16x3_direct_kernel", "conv_first_kernel",
-            "layer1_fused_kernel", "gat_dense_kernel")
+            "layer1_fused_kernel", "gat_dense_kernel", "block_chain_kernel", "block3_kernel", "guard_count_kernel",
+            "gat_fused_kernel")
     layers = defaultdict(dict)
     tr = find(os.path.join(out, "trace"), "*kernel_trace.csv")
     if tr:
         rows = [r for r in csv.DictReader(open(tr)) if any(o in r["Kernel_Name"] for o in ours)]
-        if any("layer1_fused_kernel" in r["Kernel_Name"] for r in rows):     # stem + layer1.conv1 are one launch
-            SEQ = ["conv_first+layer1.conv1 (fused)"] + SEQ[2:]
         if len(rows) % len(SEQ) == 0:
             dur = defaultdict(list)
             for i, r in enumerate(rows):
@@ -89,6 +96,9 @@ def main():
             for k, v in dur.items():
                 layers[k]["avg_us"] = sum(v) / len(v)
                 layers[k]["launches"] = len(v)
+        else:
+            lines.append("(per-layer view skipped: %d library launches are not a multiple of the %d-launch step sequence)"
+                         % (len(rows), len(SEQ)))
     for ctr, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         cc = find(os.path.join(out, sub), "*counter_collection.csv")
         if not cc:
