@@ -170,13 +170,22 @@ int magat_gat_train_backward_f32(const float* dYpre, const float* X, const float
  *   diagonal, optional D^-1/2 W D^-1/2 (config.symmetric_norm), then W / lambda_max(W) when `normalize` (an edgeless
  *   instance stays zero).  Edge structure is bit-exact; lambda_max (-> lambda_out [B], may be NULL) comes from Lanczos +
  *   Sturm bisection in float64 (the reference: numpy.linalg.eigvalsh on the host), values agree to ~1e-12 relative.
- *   The step-0 radius growth loop (grow R by 10 % until the graph is connected, :761-768) stays with the caller.
+ *   magat_sim_gso_radii: the same with one radius per instance (radii [B] float64 on the device).
+ * magat_sim_connect_radius: the step-0 branch of computeAdjacencyMatrix (:759-768): r = R / 1.1, then r *= 1.1 until the
+ *   graph (distance < r) is connected - the radius the episode keeps.  radii_out [B] float64 (the same float64 products as
+ *   the reference, bit-exact), steps_out [B] (may be NULL) = number of growth steps, negative if still disconnected after
+ *   max_steps.  Connectivity is tested by reachability from agent 0 (the reference: multiplicity of the Laplacian's zero
+ *   eigenvalue, graphTools.isConnected :562-589 - the same predicate).  N <= 5461.
  * magat_sim_fov_states: AgentState.toInputTensor for guidance 'Project_G' (dataloader/statetransformer_Guidance.py:
  *   88-124, 185-239): obstacle map [B or 1][H][W] uint8 (non-zero = obstacle; outside the map counts as obstacle),
  *   pos / goal [B][N][2] int32 -> x [B][N][3][FOV+2][FOV+2] float32 in {0,1}: channel 0 obstacles, 1 goal or projected
  *   goal, 2 agents (self included); bit-exact. */
 int magat_sim_gso(const int32_t* pos, double comm_radius, int symmetric_norm, int normalize, void* S, int s_is_f64,
                   double* lambda_out, int B, int N, void* stream);
+int magat_sim_gso_radii(const int32_t* pos, const double* radii, int symmetric_norm, int normalize, void* S, int s_is_f64,
+                        double* lambda_out, int B, int N, void* stream);
+int magat_sim_connect_radius(const int32_t* pos, double comm_radius, double* radii_out, int32_t* steps_out, int B, int N,
+                             int max_steps, void* stream);
 int magat_sim_fov_states(const uint8_t* map, int map_batched, int H, int W, const int32_t* pos, const int32_t* goal,
                          float* x, int FOV, int B, int N, void* stream);
 
@@ -187,11 +196,49 @@ int magat_sim_fov_states(const uint8_t* map, int map_batched, int H, int W, cons
  *   reference lets random.choice pick among several MOVING claimants of a cell, the lowest agent index wins (equal to
  *   the reference run with random.choice := first; a stationary claimant always wins, as in the reference).
  *   Outputs (each may be NULL): actions_out [B*N], moves_out [B][N][2] int8, reached_out [B][N] (new pos == goal),
- *   flags_out [B] bit0 out-of-arena, bit1 swap, bit2 obstacle, bit3 cell conflict.  One workgroup per instance,
+ *   flags_out [B] bit0 out-of-arena, bit1 swap, bit2 obstacle, bit3 cell conflict, bit4 a position outside the map (that
+ *   agent is left alone).  One workgroup per instance,
  *   H*W*4 + 16 N bytes of LDS <= 160 KB, N <= 65535. */
 int magat_sim_move(const float* logits, const int32_t* actions_in, const uint8_t* map, int map_batched, int H, int W,
                    int32_t* pos, const int32_t* goal, int32_t* actions_out, int8_t* moves_out, uint8_t* reached_out,
                    int32_t* flags_out, int B, int N, void* stream);
+
+/* magat_sim_step: one full multiRobotSimNew.move (utils/new_simulator.py:471-549) per instance with the episode state on
+ * the device.  On top of magat_sim_move:
+ *   - policy 0 = convectToActionKey_softmax (argmax), 1 = convectToActionKey_sum_multinorm, 2 = convectToActionKey_
+ *     exp_multinorm (:863-883).  The multinomial draw is defined by caller-supplied uniforms [B*N] float64 in [0, 1)
+ *     (e.g. torch.rand on the device, seeded): inverse CDF over the float32 weights (x / sum(x), or exp(x)) in index
+ *     order, accumulated in float64 - the first k with w_0 + .. + w_k > u * sum.  torch.multinomial's own stream cannot be
+ *     replayed on the device; the reference run with torch.multinomial patched to this rule gives identical keys
+ *     (tests/golden/sim_episode_*.npz).  A row that torch.multinomial would reject (negative / inf / nan / zero sum)
+ *     falls back to the argmax key and sets flag bit 5.
+ *   - bookkeeping, all int32 / uint8 and updated in place: reach_goal [B][N] (sticky), first_move [B][N] (first step with a
+ *     non-stop PROPOSED key, with the reference's own "== 0 means unset" test), end_step [B][N]; the step is skipped when
+ *     every agent had arrived before the call or currentstep >= maxstep, and then end_step == 0 entries become
+ *     currentstep - 1 and flowtime_out / makespan_out [B] are written (:528-547).  done_out [B] = allReachGoal (evaluated
+ *     before the move, as the reference returns it).  flags_out != 0 (bits 0-3) is the reference's check_predictCollsion.
+ *   - flag bit 4: an agent position outside the map (the agent is left where it is and takes no part in the step). */
+typedef struct magat_sim_step_desc {
+  const float* logits;       /* [B][N][5] or NULL */
+  const int32_t* actions_in; /* [B][N] keys when logits is NULL */
+  const uint8_t* map;        /* [B or 1][H][W] */
+  int32_t map_batched, H, W, B, N;
+  int32_t policy;            /* 0 argmax, 1 sum_multinorm, 2 exp_multinorm */
+  const double* uniforms;    /* [B][N], policies 1 and 2 */
+  int32_t* pos;              /* [B][N][2] in/out */
+  const int32_t* goal;       /* [B][N][2] */
+  uint8_t* reach_goal;       /* [B][N] in/out */
+  int32_t* first_move;       /* [B][N] in/out */
+  int32_t* end_step;         /* [B][N] in/out */
+  int32_t currentstep, maxstep;
+  int32_t* actions_out;      /* [B][N] or NULL */
+  int8_t* moves_out;         /* [B][N][2] or NULL */
+  int32_t* flags_out;        /* [B] or NULL */
+  int32_t* done_out;         /* [B] or NULL */
+  int32_t* flowtime_out;     /* [B] or NULL */
+  int32_t* makespan_out;     /* [B] or NULL */
+} magat_sim_step_desc;
+int magat_sim_step(const magat_sim_step_desc* d, void* stream);
 
 /* Dense GSO -> everything the CSR kernels need, for N <= 1024, in ONE streaming pass over S plus one small kernel, with no
  * host synchronisation: addGSO's in-place scrub (scrub_nan / gso_mode 0|1 as magat_gso_prepare; values are written back only

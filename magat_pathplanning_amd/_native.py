@@ -55,6 +55,17 @@ class EncoderDesc(ctypes.Structure):
                 ("off", ctypes.c_int64 * 32), ("chain_off", ctypes.c_int64), ("chain3_off", ctypes.c_int64)]
 
 
+class SimStepDesc(ctypes.Structure):
+    """magat_sim_step_desc (include/magat_hip.h)."""
+    _fields_ = [("logits", ctypes.c_void_p), ("actions_in", ctypes.c_void_p), ("map", ctypes.c_void_p),
+                ("map_batched", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("B", ctypes.c_int32),
+                ("N", ctypes.c_int32), ("policy", ctypes.c_int32), ("uniforms", ctypes.c_void_p), ("pos", ctypes.c_void_p),
+                ("goal", ctypes.c_void_p), ("reach_goal", ctypes.c_void_p), ("first_move", ctypes.c_void_p),
+                ("end_step", ctypes.c_void_p), ("currentstep", ctypes.c_int32), ("maxstep", ctypes.c_int32),
+                ("actions_out", ctypes.c_void_p), ("moves_out", ctypes.c_void_p), ("flags_out", ctypes.c_void_p),
+                ("done_out", ctypes.c_void_p), ("flowtime_out", ctypes.c_void_p), ("makespan_out", ctypes.c_void_p)]
+
+
 _I, _P, _Z = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 _SIGNATURES = {
     "magat_abi_version": (ctypes.c_int, []),
@@ -86,6 +97,9 @@ _SIGNATURES = {
     "magat_gso_row_degrees": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "magat_gso_fill_csr": (_I, [_P, _I, _I, _P, _P, _I, _I, _P]),
     "magat_sim_gso": (_I, [_P, ctypes.c_double, _I, _I, _P, _I, _P, _I, _I, _P]),
+    "magat_sim_gso_radii": (_I, [_P, _P, _I, _I, _P, _I, _P, _I, _I, _P]),
+    "magat_sim_connect_radius": (_I, [_P, ctypes.c_double, _P, _P, _I, _I, _I, _P]),
+    "magat_sim_step": (_I, [ctypes.POINTER(SimStepDesc), _P]),
     "magat_sim_fov_states": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "magat_sim_move": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "magat_gso_prepare": (_I, [_P, _I, _Z, _I, _I, _P]),

@@ -29,11 +29,13 @@ __device__ __forceinline__ double block_sum(double v, double* red, int t, int nt
 // rows of W as bit masks in LDS while they fit (N <= ~1000: 128 KB); larger instances evaluate the distance test on
 // the fly (N <= 2048)
 template <bool MASK>
-__global__ __launch_bounds__(SIM_THREADS) void gso_kernel(const int* __restrict__ pos, double R, int symmetric_norm,
+__global__ __launch_bounds__(SIM_THREADS) void gso_kernel(const int* __restrict__ pos, double Rscalar,
+                                                          const double* __restrict__ radii, int symmetric_norm,
                                                           int normalize, void* __restrict__ S, int s_is_f64,
                                                           double* __restrict__ lambda_out, int N) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  const double R = radii ? radii[b] : Rscalar;       // per-instance radius (grown at step 0 by sim_radius_kernel) or one for all
   const int words = (N + 31) / 32;
   int* px = reinterpret_cast<int*>(smem_raw);
   int* py = px + N;
@@ -267,19 +269,112 @@ __global__ __launch_bounds__(SIM_THREADS) void fov_states_kernel(const uint8_t* 
 }
 
 
+// ---- step-0 communication radius (multiRobotSimNew.computeAdjacencyMatrix, step == 0 branch, new_simulator.py:759-768):
+// r = R0 / 1.1;  do { r = r * 1.1;  W = (distance < r) } while (!isConnected(W)).  The reference tests connectivity through
+// the Laplacian's spectrum (graphTools.isConnected: exactly one eigenvalue below 1e-9); here it is a reachability sweep
+// from agent 0 over the same float64 distance test - the same predicate, evaluated exactly.  One workgroup per instance.
+__global__ __launch_bounds__(SIM_THREADS) void sim_radius_kernel(const int* __restrict__ pos, double R0,
+                                                                 double* __restrict__ radii_out, int* __restrict__ steps_out,
+                                                                 int N, int max_steps) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  int* px = reinterpret_cast<int*>(smem_raw);
+  int* py = px + N;
+  int* seen = py + N;                  // 0 / 1 per agent
+  __shared__ int changed, count;
+  for (int n = t; n < N; n += nt) {
+    px[n] = pos[((long long)b * N + n) * 2 + 0];
+    py[n] = pos[((long long)b * N + n) * 2 + 1];
+  }
+  double r = R0 / 1.1;
+  int steps = 0;
+  bool connected = false;
+  while (!connected && steps < max_steps) {
+    r = r * 1.1;
+    ++steps;
+    __syncthreads();
+    for (int n = t; n < N; n += nt) seen[n] = n == 0 ? 1 : 0;
+    while (true) {
+      __syncthreads();
+      if (t == 0) changed = 0;
+      __syncthreads();
+      for (int i = t; i < N; i += nt) {
+        if (seen[i]) continue;
+        bool hit = false;
+        for (int j = 0; j < N && !hit; ++j) {
+          if (!seen[j] || j == i) continue;
+          const long long dx = px[i] - px[j], dy = py[i] - py[j];
+          hit = sqrt((double)(dx * dx + dy * dy)) < r;
+        }
+        if (hit) { seen[i] = 1; changed = 1; }
+      }
+      __syncthreads();
+      if (!changed) break;
+    }
+    if (t == 0) count = 0;
+    __syncthreads();
+    int c = 0;
+    for (int n = t; n < N; n += nt) c += seen[n];
+    if (c) atomicAdd(&count, c);
+    __syncthreads();
+    connected = count == N;
+  }
+  if (t == 0) {
+    radii_out[b] = r;
+    if (steps_out) steps_out[b] = connected ? steps : -steps;     // negative: still disconnected after max_steps
+  }
+}
+
 // ---- action decode + collision shielding + position update (new_simulator.py:334-454, 471-520).
 // One workgroup per instance; a single int32 cell grid in LDS is reused for the three lookups the reference does with
 // Python dicts: occupant of a cell (swap test), claimants of a target cell (atomicMin of a priority key), and the
 // "forced to stay" cells of the backward cascade.
+struct SimBook {
+  uint8_t* reach;          // [B][N] sticky reach-goal flags (null: no bookkeeping)
+  int* first_move;         // [B][N]
+  int* end_step;           // [B][N]
+  int step, maxstep;
+  int* done_out;           // [B] all agents had reached their goals BEFORE this call
+  int* flowtime_out;       // [B] written when the episode is over
+  int* makespan_out;       // [B]
+};
+
 __global__ __launch_bounds__(1024) void sim_move_kernel(const float* __restrict__ logits, const int* __restrict__ actions_in,
                                                         const uint8_t* __restrict__ map, long long map_stride, int H, int Wm,
                                                         int* __restrict__ pos, const int* __restrict__ goal,
                                                         int* __restrict__ actions_out, signed char* __restrict__ moves_out,
                                                         uint8_t* __restrict__ reached_out, int* __restrict__ flags_out,
-                                                        int N) {
+                                                        int N, int policy, const double* __restrict__ uniforms,
+                                                        SimBook bk) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   const int cells = H * Wm;
+  // episode bookkeeping of multiRobotSimNew.move (new_simulator.py:471-549), when the caller keeps its state on the device
+  __shared__ int n_reached;
+  bool active = true, finalize = false;
+  if (bk.reach) {
+    if (t == 0) n_reached = 0;
+    __syncthreads();
+    int c = 0;
+    for (int n = t; n < N; n += nt) c += bk.reach[(long long)b * N + n] ? 1 : 0;
+    if (c) atomicAdd(&n_reached, c);
+    __syncthreads();
+    const bool all_reached = n_reached == N;                 // evaluated BEFORE this step's move, like the reference
+    active = !all_reached && bk.step < bk.maxstep;
+    finalize = all_reached || bk.step >= bk.maxstep;
+    if (t == 0 && bk.done_out) bk.done_out[b] = all_reached ? 1 : 0;
+    __syncthreads();
+  }
+  if (!active) {
+    for (int n = t; n < N; n += nt) {
+      const long long a = (long long)b * N + n;
+      if (actions_out) actions_out[a] = 4;
+      if (moves_out) { moves_out[2 * a] = 0; moves_out[2 * a + 1] = 0; }
+      if (reached_out && goal) reached_out[a] = (pos[2 * a] == goal[2 * a] && pos[2 * a + 1] == goal[2 * a + 1]) ? 1 : 0;
+    }
+    if (flags_out && t == 0) flags_out[b] = 0;
+  }
+  if (active) {
   unsigned* grid = reinterpret_cast<unsigned*>(smem_raw);            // [cells]
   int* px = reinterpret_cast<int*>(grid + cells);                    // [N]
   int* py = px + N;
@@ -295,17 +390,54 @@ __global__ __launch_bounds__(1024) void sim_move_kernel(const float* __restrict_
     const long long a = (long long)b * N + n;
     const int x = pos[2 * a], y = pos[2 * a + 1];
     int key;
-    if (logits) {                       // convectToActionKey_softmax: argmax, first maximum wins
+    if (logits) {
       const float* l = logits + a * 5;
-      key = 0;
+      key = 0;                          // convectToActionKey_softmax (:863-869): argmax, first maximum wins
       float best = l[0];
       for (int q = 1; q < 5; ++q)
         if (l[q] > best) { best = l[q]; key = q; }
+      if (policy != 0 && uniforms) {
+        // convectToActionKey_{sum,exp}_multinorm (:871-883): one draw from the categorical distribution with weights
+        // x / sum(x) (sum) or exp(x) (exp), float32.  torch.multinomial's generator cannot be replayed on the device, so the draw
+        // is defined by a caller-supplied uniform u in [0, 1): inverse CDF over the float32 weights in index order,
+        // accumulated in float64 - the first k with w_0 + .. + w_k > u * sum.  (tests: the reference run with
+        // torch.multinomial patched to this rule and the same u gives the same keys.)
+        double w[5], tot = 0.0;
+        bool bad = false;
+        const float lsum = (((l[0] + l[1]) + l[2]) + l[3]) + l[4];   // sum_multinorm draws from normalize(x) = x / sum(x) (:857-861)
+        for (int q = 0; q < 5; ++q) {
+          const float wf = policy == 2 ? (float)exp((double)l[q]) : l[q] / lsum;
+          bad |= !(wf >= 0.f) || wf == __builtin_inff();
+          w[q] = (double)wf;
+          tot += w[q];
+        }
+        if (bad || !(tot > 0.0)) {
+          atomicOr(&flags, 32);         // invalid distribution (torch.multinomial raises): the greedy key stands
+        } else {
+          const double thr = uniforms[a] * tot;
+          double c = 0.0;
+          int pick = -1, lastpos = 0;
+          for (int q = 0; q < 5; ++q) {
+            c += w[q];
+            if (w[q] > 0.0) lastpos = q;
+            if (pick < 0 && c > thr) pick = q;
+          }
+          key = pick < 0 ? lastpos : pick;
+        }
+      }
     } else {
       key = actions_in[a];
       if (key < 0 || key > 4) key = 4;
     }
     if (actions_out) actions_out[a] = key;
+    // first step at which the agent proposes a move (:489-490; the reference's own "== 0" test cannot tell "never" from
+    // "at step 0" - reproduced as is)
+    if (bk.first_move && key != 4 && bk.first_move[a] == 0) bk.first_move[a] = bk.step;
+    if (x < 0 || y < 0 || x >= H || y >= Wm) {                       // a position outside the map: flagged, the agent is left alone
+      atomicOr(&flags, 16);
+      px[n] = -1; py[n] = 0; mc[n] = 4; aux[n] = 0;                   // px < 0: takes no part in the cell claims
+      continue;
+    }
     const int nx = x + DX[key], ny = y + DY[key];
     if (nx < 0 || ny < 0 || nx >= H || ny >= Wm) {                   // out of the arena -> stop (:354-357)
       key = 4;
@@ -346,6 +478,7 @@ __global__ __launch_bounds__(1024) void sim_move_kernel(const float* __restrict_
   // random.choice here, :416 - the one documented deviation)
   for (int n = t; n < N; n += nt) {
     const int k = mc[n];
+    if (px[n] < 0) continue;
     atomicMin(&grid[(px[n] + DX[k]) * Wm + py[n] + DY[k]], (unsigned)((k == 4 ? 0 : 1) << 16 | n));
   }
   __syncthreads();
@@ -381,21 +514,50 @@ __global__ __launch_bounds__(1024) void sim_move_kernel(const float* __restrict_
   for (int n = t; n < N; n += nt) {
     const long long a = (long long)b * N + n;
     const int k = mc[n];
-    const int nx = px[n] + DX[k], ny = py[n] + DY[k];
+    const bool inside = pos[2 * a] >= 0 && pos[2 * a + 1] >= 0 && pos[2 * a] < H && pos[2 * a + 1] < Wm;
+    const int nx = inside ? px[n] + DX[k] : pos[2 * a], ny = inside ? py[n] + DY[k] : pos[2 * a + 1];
     pos[2 * a] = nx;
     pos[2 * a + 1] = ny;
-    if (moves_out) { moves_out[2 * a] = (signed char)DX[k]; moves_out[2 * a + 1] = (signed char)DY[k]; }
-    if (reached_out && goal) reached_out[a] = (nx == goal[2 * a] && ny == goal[2 * a + 1]) ? 1 : 0;
+    if (moves_out) { moves_out[2 * a] = (signed char)(inside ? DX[k] : 0); moves_out[2 * a + 1] = (signed char)(inside ? DY[k] : 0); }
+    const bool at_goal = goal && nx == goal[2 * a] && ny == goal[2 * a + 1];
+    if (reached_out && goal) reached_out[a] = at_goal ? 1 : 0;
+    if (bk.reach && at_goal) {                                      // sticky reach flag, first arrival step (:521-526)
+      bk.reach[a] = 1;
+      if (bk.end_step && bk.end_step[a] == 0) bk.end_step[a] = bk.step;
+    }
   }
   if (flags_out && t == 0) flags_out[b] = flags;
+  }
+  if (finalize && bk.end_step && bk.first_move) {
+    // episode over (everybody arrived before this call, or the step budget is spent): :528-547
+    __shared__ int flow, emax, fmin;
+    __syncthreads();
+    if (t == 0) { flow = 0; emax = -2147483647; fmin = 2147483647; }
+    __syncthreads();
+    for (int n = t; n < N; n += nt) {
+      const long long a = (long long)b * N + n;
+      int e = bk.end_step[a];
+      if (e == 0) { e = bk.step - 1; bk.end_step[a] = e; }
+      const int f = bk.first_move[a];
+      atomicAdd(&flow, e - f + 1);
+      atomicMax(&emax, e);
+      atomicMin(&fmin, f);
+    }
+    __syncthreads();
+    if (t == 0) {
+      if (bk.flowtime_out) bk.flowtime_out[b] = flow;
+      if (bk.makespan_out) bk.makespan_out[b] = emax - fmin + 1;
+    }
+  }
 }
 
 }  // namespace
 
-extern "C" int magat_sim_gso(const int32_t* pos, double comm_radius, int symmetric_norm, int normalize, void* S,
-                             int s_is_f64, double* lambda_out, int B, int N, void* stream) {
+namespace {
+int sim_gso_launch(const int32_t* pos, double comm_radius, const double* radii, int symmetric_norm, int normalize, void* S,
+                   int s_is_f64, double* lambda_out, int B, int N, void* stream) {
   if (!pos || !S) return MAGAT_ERR_NULL;
-  if (B <= 0 || N <= 0 || !(comm_radius > 0.0)) return MAGAT_ERR_BAD_SHAPE;
+  if (B <= 0 || N <= 0 || (!radii && !(comm_radius > 0.0))) return MAGAT_ERR_BAD_SHAPE;
   if (N > 2048) return MAGAT_ERR_UNSUPPORTED;
   const bool mask = gso_lds_bytes(N, true) <= 160 * 1024;          // bit rows of W in LDS (N <= ~1000), else on the fly
   const size_t lds = gso_lds_bytes(N, mask);
@@ -407,12 +569,35 @@ extern "C" int magat_sim_gso(const int32_t* pos, double comm_radius, int symmetr
                            mask ? MAGAT_LDS_SIM_GSO_T : MAGAT_LDS_SIM_GSO_F, lds) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
   if (mask) {
-    hipLaunchKernelGGL(gso_kernel<true>, dim3(B), dim3(SIM_THREADS), lds, st, pos, comm_radius, symmetric_norm, normalize,
-                       S, s_is_f64, lambda_out, N);
+    hipLaunchKernelGGL(gso_kernel<true>, dim3(B), dim3(SIM_THREADS), lds, st, pos, comm_radius, radii, symmetric_norm,
+                       normalize, S, s_is_f64, lambda_out, N);
   } else {
-    hipLaunchKernelGGL(gso_kernel<false>, dim3(B), dim3(SIM_THREADS), lds, st, pos, comm_radius, symmetric_norm, normalize,
-                       S, s_is_f64, lambda_out, N);
+    hipLaunchKernelGGL(gso_kernel<false>, dim3(B), dim3(SIM_THREADS), lds, st, pos, comm_radius, radii, symmetric_norm,
+                       normalize, S, s_is_f64, lambda_out, N);
   }
+  return magat_check_launch();
+}
+}  // namespace
+
+extern "C" int magat_sim_gso(const int32_t* pos, double comm_radius, int symmetric_norm, int normalize, void* S,
+                             int s_is_f64, double* lambda_out, int B, int N, void* stream) {
+  return sim_gso_launch(pos, comm_radius, nullptr, symmetric_norm, normalize, S, s_is_f64, lambda_out, B, N, stream);
+}
+
+extern "C" int magat_sim_gso_radii(const int32_t* pos, const double* radii, int symmetric_norm, int normalize, void* S,
+                                   int s_is_f64, double* lambda_out, int B, int N, void* stream) {
+  if (!radii) return MAGAT_ERR_NULL;
+  return sim_gso_launch(pos, 0.0, radii, symmetric_norm, normalize, S, s_is_f64, lambda_out, B, N, stream);
+}
+
+extern "C" int magat_sim_connect_radius(const int32_t* pos, double comm_radius, double* radii_out, int32_t* steps_out,
+                                        int B, int N, int max_steps, void* stream) {
+  if (!pos || !radii_out) return MAGAT_ERR_NULL;
+  if (B <= 0 || N <= 0 || !(comm_radius > 0.0) || max_steps <= 0) return MAGAT_ERR_BAD_SHAPE;
+  const size_t lds = (size_t)3 * N * sizeof(int);
+  if (lds > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(sim_radius_kernel, dim3(B), dim3(SIM_THREADS), lds, static_cast<hipStream_t>(stream), pos, comm_radius,
+                     radii_out, steps_out, N, max_steps);
   return magat_check_launch();
 }
 
@@ -427,11 +612,14 @@ extern "C" int magat_sim_fov_states(const uint8_t* map, int map_batched, int H, 
   return magat_check_launch();
 }
 
-extern "C" int magat_sim_move(const float* logits, const int32_t* actions_in, const uint8_t* map, int map_batched, int H,
-                              int W, int32_t* pos, const int32_t* goal, int32_t* actions_out, int8_t* moves_out,
-                              uint8_t* reached_out, int32_t* flags_out, int B, int N, void* stream) {
+namespace {
+int sim_move_launch(const float* logits, const int32_t* actions_in, const uint8_t* map, int map_batched, int H, int W,
+                    int32_t* pos, const int32_t* goal, int32_t* actions_out, int8_t* moves_out, uint8_t* reached_out,
+                    int32_t* flags_out, int B, int N, int policy, const double* uniforms, const SimBook& bk, void* stream) {
   if ((!logits && !actions_in) || !map || !pos) return MAGAT_ERR_NULL;
   if (B <= 0 || N <= 0 || N > 65535 || H <= 0 || W <= 0) return MAGAT_ERR_BAD_SHAPE;
+  if (policy < 0 || policy > 2) return MAGAT_ERR_UNSUPPORTED;
+  if (policy != 0 && (!logits || !uniforms)) return MAGAT_ERR_NULL;
   const size_t lds = (size_t)H * W * sizeof(unsigned) + (size_t)4 * N * sizeof(int);
   if (lds > 160 * 1024) return MAGAT_ERR_UNSUPPORTED;
   if (lds > 64 * 1024 &&
@@ -441,6 +629,30 @@ extern "C" int magat_sim_move(const float* logits, const int32_t* actions_in, co
   while (threads < N && threads < 1024) threads *= 2;
   hipLaunchKernelGGL(sim_move_kernel, dim3(B), dim3(threads), lds, static_cast<hipStream_t>(stream), logits, actions_in,
                      map, map_batched ? (long long)H * W : 0LL, H, W, pos, goal, actions_out,
-                     reinterpret_cast<signed char*>(moves_out), reached_out, flags_out, N);
+                     reinterpret_cast<signed char*>(moves_out), reached_out, flags_out, N, policy, uniforms, bk);
   return magat_check_launch();
+}
+}  // namespace
+
+extern "C" int magat_sim_move(const float* logits, const int32_t* actions_in, const uint8_t* map, int map_batched, int H,
+                              int W, int32_t* pos, const int32_t* goal, int32_t* actions_out, int8_t* moves_out,
+                              uint8_t* reached_out, int32_t* flags_out, int B, int N, void* stream) {
+  return sim_move_launch(logits, actions_in, map, map_batched, H, W, pos, goal, actions_out, moves_out, reached_out,
+                         flags_out, B, N, 0, nullptr, SimBook{}, stream);
+}
+
+extern "C" int magat_sim_step(const magat_sim_step_desc* d, void* stream) {
+  if (!d) return MAGAT_ERR_NULL;
+  if (!d->goal || !d->reach_goal || !d->first_move || !d->end_step) return MAGAT_ERR_NULL;
+  SimBook bk{};
+  bk.reach = d->reach_goal;
+  bk.first_move = d->first_move;
+  bk.end_step = d->end_step;
+  bk.step = d->currentstep;
+  bk.maxstep = d->maxstep;
+  bk.done_out = d->done_out;
+  bk.flowtime_out = d->flowtime_out;
+  bk.makespan_out = d->makespan_out;
+  return sim_move_launch(d->logits, d->actions_in, d->map, d->map_batched, d->H, d->W, d->pos, d->goal, d->actions_out,
+                         d->moves_out, nullptr, d->flags_out, d->B, d->N, d->policy, d->uniforms, bk, stream);
 }

@@ -166,3 +166,98 @@ def move_step(obstacle_map, pos, goal, logits):
     new_pos = np.asarray(pos, np.int64) + new_move
     reached = np.abs(new_pos - np.asarray(goal, np.int64)).sum(axis=1) == 0
     return new_pos, actions, reached
+
+
+# ------------------------------------------------------------------ policies, episode
+# bookkeeping, step-0 communication radius
+def sample_actions(logits, policy, uniforms):
+    """The three action policies (new_simulator.py:863-883).  policy 0: convectToActionKey_softmax (argmax); 1:
+    convectToActionKey_sum_multinorm, one draw with weights normalize(x) = x / sum(x) (float32, :857-861); 2:
+    convectToActionKey_exp_multinorm, weights exp(x) (float32).  The draw of torch.multinomial is pinned to the inverse
+    CDF with the given uniforms: first k with  w_0 + .. + w_k > u * sum(w), float64 running sum over the float32 weights
+    (the reference run with torch.multinomial patched to this rule: oracle/make_golden_sim_episode.py)."""
+    logits = np.asarray(logits, np.float32)
+    if policy == 0:
+        return decode_actions(logits)
+    keys = np.zeros(len(logits), np.int64)
+    for i, l in enumerate(logits):
+        if policy == 1:
+            s = np.float32(0)
+            for q in range(5):
+                s = np.float32(s + l[q])
+            w = (l / s).astype(np.float32)
+        else:
+            w = np.exp(l.astype(np.float64)).astype(np.float32)
+        c = np.cumsum(w.astype(np.float64))
+        keys[i] = int(np.nonzero(c > uniforms[i] * c[-1])[0][0])
+    return keys
+
+
+class EpisodeState:
+    """The per-case state multiRobotSimNew keeps across move() calls (new_simulator.py:191-221)."""
+
+    def __init__(self, obstacle_map, pos, goal, maxstep):
+        n = len(pos)
+        self.map = np.asarray(obstacle_map)
+        self.pos = np.array(pos, np.int64)
+        self.goal = np.asarray(goal, np.int64)
+        self.maxstep = int(maxstep)
+        self.reach_goal = np.zeros(n, np.uint8)
+        self.first_move = np.zeros(n, np.int64)
+        self.end_step = np.zeros(n, np.int64)
+        self.flowtime = self.maxstep * n
+        self.makespan = self.maxstep
+
+
+def episode_step(st, logits, currentstep, policy=0, uniforms=None):
+    """multiRobotSimNew.move (new_simulator.py:471-549), complete: returns (allReachGoal, check_predictCollsion, keys)."""
+    n = len(st.pos)
+    all_reached = int(np.count_nonzero(st.reach_goal)) == n
+    predict_collision = False
+    keys = None
+    if (not all_reached) and currentstep < st.maxstep:
+        keys = sample_actions(logits, policy, uniforms)
+        st.first_move[(keys != 4) & (st.first_move == 0)] = currentstep
+        new_move, fl = shield_moves(st.map, st.pos, MOVES[keys])
+        predict_collision = bool(fl["out_boundary"].any() or fl["wall"] or fl["swap"] or fl["collide"])
+        st.pos = st.pos + new_move
+        at = np.abs(st.pos - st.goal).sum(axis=1) == 0
+        st.reach_goal[at] = 1
+        st.end_step[at & (st.end_step == 0)] = currentstep
+    if all_reached or currentstep >= st.maxstep:
+        st.end_step[st.end_step == 0] = currentstep - 1
+        st.flowtime = int(np.sum(st.end_step - st.first_move + 1))
+        st.makespan = int(st.end_step.max() - st.first_move.min() + 1)
+    return all_reached, predict_collision, keys
+
+
+def is_connected(W):
+    """graphTools.isConnected (utils/graphUtils/graphTools.py:562-589) decides by the multiplicity of the Laplacian's zero
+    eigenvalue (== 1); for an undirected graph that is reachability of every node from node 0, tested here exactly."""
+    n = len(W)
+    seen = np.zeros(n, bool)
+    seen[0] = True
+    front = [0]
+    while front:
+        i = front.pop()
+        for j in np.nonzero(W[i])[0]:
+            if not seen[j]:
+                seen[j] = True
+                front.append(int(j))
+    return bool(seen.all())
+
+
+def connect_radius(pos, comm_radius):
+    """Step-0 branch of computeAdjacencyMatrix (new_simulator.py:759-768): r = R / 1.1; repeat r *= 1.1 until the graph
+    (distance < r, zero diagonal) is connected.  Returns (r, growth steps)."""
+    pos = np.asarray(pos, np.float64)
+    d = np.sqrt(((pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1))
+    r = comm_radius / 1.1
+    steps = 0
+    while True:
+        r = r * 1.1
+        steps += 1
+        W = (d < r).astype(np.float64)
+        np.fill_diagonal(W, 0.0)
+        if is_connected(W):
+            return r, steps
