@@ -164,6 +164,14 @@ int magat_gat_train_backward_f32(const float* dYpre, const float* X, const float
                                  const int* cscpos, long long nnz, float* dZ, float* dXd, float* datt, int B, int N,
                                  int G, int F, int K, int P, int mode, void* stream);
 
+/* Backward of the non-attentional graph filter (GraphFilterBatch / BatchLSIGF, graphML.py:5485-5700).  The layer is linear in
+ * x and in the taps:  Y = b + sum_k A^k X H_k^T  (A = row operator of "x @ S"), so  dU_k = (A^T)^k dY  is the forward hop
+ * run over the CSR rows of S.  dY [M][F] -> dZ [M][K*F], slice k = dU_k.  The caller finishes with two plain GEMMs:
+ * dX = dZ @ Bt (Bt [K*F][G], row k*F+f = weight[f,0,k,:]),  dweight[f,0,k,:] = (dZ^T X)[k*F+f],  dbias = column sums of dY.
+ * rowptr / colidx / vals: the CSR arrays magat_gnn_forward_csr_f32 takes. */
+int magat_gnn_backward_csr_f32(const float* dY, const int* rowptr, const int* colidx, const float* vals, long long nnz,
+                               float* dZ, int B, int N, int F, int K, void* stream);
+
 /* ---- Batched on-device simulator front-end: the two per-step host loops in front of the model.
  * magat_sim_gso: multiRobotSimNew.computeAdjacencyMatrix, fixed-radius branch (utils/new_simulator.py:783-804, called by
  *   getGSO :301-321): pos [B][N][2] int32 (row, col) -> S [B][N][N] float32|float64,  W = (euclidean distance < R) with zero

@@ -96,6 +96,7 @@ _SIGNATURES = {
     "magat_cast_rows": (_I, [_P, _P, _I, ctypes.c_longlong, _I, _I, _I, _P]),
     "magat_gso_row_degrees": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "magat_gso_fill_csr": (_I, [_P, _I, _I, _P, _P, _I, _I, _P]),
+    "magat_gnn_backward_csr_f32": (_I, [_P, _P, _P, _P, ctypes.c_longlong, _P, _I, _I, _I, _I, _P]),
     "magat_sim_gso": (_I, [_P, ctypes.c_double, _I, _I, _P, _I, _P, _I, _I, _P]),
     "magat_sim_gso_radii": (_I, [_P, _P, _I, _I, _P, _I, _P, _I, _I, _P]),
     "magat_sim_connect_radius": (_I, [_P, ctypes.c_double, _P, _P, _I, _I, _I, _P]),

@@ -1405,6 +1405,51 @@ __global__ void bwd_seed_kernel(const float* __restrict__ dY, float* __restrict_
   }
 }
 
+
+// ---- GraphFilterBatch backward (graphML.py:5485-5579 differentiated).  The layer is linear:  Y = b + sum_k A^k X H_k^T
+// with A the row operator of "x @ S" (row n gathers S[m][n] X[m]: the CSC view in the forward).  Hence  dU_k = (A^T)^k dY
+// - the same hop with the CSR rows of S as gather lists - and the rest is two plain GEMMs of the caller:
+// dX = [dU_0 .. dU_{K-1}] Bt,  dH = dU^T X.   dZ [M][K*F]: slice k = dU_k.  One wave per agent row, 4 rows per workgroup.
+template <int F>
+__global__ __launch_bounds__(256) void gnn_bwd_hop_kernel(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                                          const float* __restrict__ vals, float* __restrict__ dZ, int B,
+                                                          int N, int K, int k) {
+  constexpr int VEC = F >= 64 ? F / 64 : 1, LANES = F >= 64 ? 64 : F;
+  typedef float fvec __attribute__((ext_vector_type(VEC)));
+  const int tiles = (N + 3) / 4;
+  const int bid = blockIdx.x, xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
+  const int b = xcd + MAGAT_NUM_XCD * (slot / tiles);
+  if (b >= B) return;
+  const int tile = slot % tiles, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = tile * 4 + wave;
+  if (i >= N || lane >= LANES) return;
+  const int* rp = rowptr + (long long)b * (N + 1);
+  const int e0 = rp[i], e1 = rp[i + 1];
+  const long long row0 = (long long)b * N, ld = (long long)K * F;
+  const float* src = dZ + (long long)(k - 1) * F + VEC * lane;
+  fvec acc;
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
+  for (int e = e0; e < e1; ++e) {
+    const float a = vals[e];
+    const fvec d = *reinterpret_cast<const fvec*>(src + (row0 + colidx[e]) * ld);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[c] = fmaf(a, d[c], acc[c]);
+  }
+  *reinterpret_cast<fvec*>(dZ + (row0 + i) * ld + (long long)k * F + VEC * lane) = acc;
+}
+
+__global__ void gnn_bwd_seed_kernel(const float* __restrict__ dY, float* __restrict__ dZ, long long M, int F, int K) {
+  const int FC = F / 4;
+  const long long total = M * FC;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % FC);
+    const long long m = idx / FC;
+    *reinterpret_cast<f32x4*>(dZ + m * K * F + 4 * c) = *reinterpret_cast<const f32x4*>(dY + m * F + 4 * c);
+  }
+}
+
 template <int W, typename KFn>
 int launch_rows(KFn kern, const TrainParams& p, int per_instance_factor, hipStream_t st) {
   const int tiles = (p.N + 3) / 4;
@@ -1508,5 +1553,28 @@ extern "C" int magat_gat_train_backward_f32(const float* dYpre, const float* X, 
   MAGAT_WIDTH_SWITCH(G, rc = launch_rows<WW>(bwd_scores_rows_kernel<WW>, p, 1, st));
   if (rc != MAGAT_OK) return rc;
   MAGAT_WIDTH_SWITCH(G, rc = launch_rows<WW>(bwd_scores_cols_kernel<WW>, p, 1, st));
+  return rc;
+}
+
+extern "C" int magat_gnn_backward_csr_f32(const float* dY, const int* rowptr, const int* colidx, const float* vals,
+                                          long long nnz, float* dZ, int B, int N, int F, int K, void* stream) {
+  if (!dY || !rowptr || !dZ) return MAGAT_ERR_NULL;
+  if (nnz > 0 && K > 1 && (!colidx || !vals)) return MAGAT_ERR_NULL;
+  if (B <= 0 || N <= 0 || nnz < 0 || K <= 0) return MAGAT_ERR_BAD_SHAPE;
+  if (!(F == 16 || F == 32 || F == 64 || F == 128 || F == 256)) return MAGAT_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long M = (long long)B * N;
+  long long blocks = (M * (F / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gnn_bwd_seed_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dY, dZ, M, F, K);
+  int rc = magat_check_launch();
+  const int tiles = (N + 3) / 4;
+  const long long grid = (long long)((B + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD) * MAGAT_NUM_XCD * tiles;
+  if (grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
+  for (int k = 1; k < K && rc == MAGAT_OK; ++k) {
+    MAGAT_WIDTH_SWITCH(F, hipLaunchKernelGGL(gnn_bwd_hop_kernel<WW>, dim3((unsigned)grid), dim3(256), 0, st, rowptr, colidx,
+                                             vals, dZ, B, N, K, k));
+    rc = magat_check_launch();
+  }
   return rc;
 }

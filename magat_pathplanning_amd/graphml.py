@@ -604,11 +604,48 @@ class GraphFilterBatchAttentional_Origin(GraphFilterBatchAttentional):
                 self.bias.uniform_(-stdv, stdv)
 
 
+class _GnnTrainFunction(torch.autograd.Function):
+    """HIP forward + backward of GraphFilterBatch for training.  The layer is linear, so nothing but the input rows and the
+    CSR arrays is kept:  dU_k = (A^T)^k dY  by the HIP hop kernel (magat_gnn_backward_csr_f32), then two library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, layer):
+        y, X, (rowptr, colidx, vals, nnz) = layer._forward_hip(x)
+        ctx.layer, ctx.nnz, ctx.shape = layer, nnz, tuple(x.shape)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(X, rowptr, colidx, vals, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        X, rowptr, colidx, vals, weight = ctx.saved_tensors
+        layer = ctx.layer
+        B, G, N = ctx.shape
+        F, K = layer.F, layer.K
+        dev, M = X.device, B * N
+        dY = dy.permute(0, 2, 1).contiguous().float().view(M, F)
+        dZ = torch.empty(M, K * F, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(nat.lib().magat_gnn_backward_csr_f32(nat.ptr(dY), nat.ptr(rowptr), nat.ptr(colidx), nat.ptr(vals),
+                                                           ctx.nnz, nat.ptr(dZ), B, N, F, K, nat.current_stream(dev)),
+                      "magat_gnn_backward_csr_f32")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            Bt = weight.detach()[:, 0].permute(1, 0, 2).reshape(K * F, G).float()        # row k*F+f = weight[f,0,k,:]
+            dx = (dZ @ Bt).view(B, N, G).permute(0, 2, 1)
+        if ctx.needs_input_grad[1]:
+            dw = (dZ.t() @ X).view(K, F, G).permute(1, 0, 2).reshape(F, 1, K, G).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dY.sum(dim=0).view(F, 1)
+        return dx, dw, db, None
+
+
 class GraphFilterBatch(nn.Module):
     """Drop-in for the reference's non-attentional graph filter (graphML.py:5581-5700; BatchLSIGF :5485-5579), the GNN
     baseline of the paper:  y = bias + sum_k (x S^k) h_k  with the GSO VALUES as edge weights (`x @ S.float()`), no
     nonlinearity inside.  Parameters: weight (F,E,K,G), bias (F,1); init U(+-1/sqrt(G K)).  Inference on the HIP CSR kernels
-    (magat_gnn_forward_csr_f32); with autograd on, the torch composite below."""
+    (magat_gnn_forward_csr_f32); with autograd on, the same forward plus the HIP backward (_GnnTrainFunction) on device
+    tensors, and a torch composite for CPU tensors (host / gloo tests)."""
 
     def __init__(self, G, F, K, E=1, bias=True):
         super().__init__()
@@ -648,8 +685,8 @@ class GraphFilterBatch(nn.Module):
         if Nin < N:
             x = torch.cat((x, torch.zeros(B, Gin, N - Nin, dtype=x.dtype, device=x.device)), dim=2)
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if needs_grad:
-            nat.require_device_or_composite(x, "GraphFilterBatch under autograd")
+        if needs_grad and not x.is_cuda:
+            nat.require_device_or_composite(x, "GraphFilterBatch under autograd")     # CPU tensors: the torch composite
             Sf = self.S.to(x.device)[:, 0].float()
             z = x
             y = torch.einsum("bgn,fg->bfn", z, self.weight[:, 0, 0])
@@ -658,44 +695,57 @@ class GraphFilterBatch(nn.Module):
                 y = y + torch.einsum("bgn,fg->bfn", z, self.weight[:, 0, k])
             if self.bias is not None:
                 y = y + self.bias
+        elif needs_grad:
+            y = _GnnTrainFunction.apply(x, self.weight, self.bias, self)
         else:
-            if not x.is_cuda:
-                raise nat.MagatNativeError("the HIP path needs device tensors; got %s (no CPU fallback)" % x.device)
-            lib = nat.lib()
-            dev = x.device
-            X = x.permute(0, 2, 1).contiguous().float()
-            S3 = self.S.reshape(B, N, N).to(dev)
-            if S3.dtype not in (torch.float32, torch.float64):
-                S3 = S3.float()
-            S3 = S3.contiguous()
-            rowptr, colidx, nnz = dense_gso_to_csr(S3, self_loops=2)          # rule 2: every non-zero float(S)
-            rp = rowptr.view(B, N + 1).long()
-            rows = torch.repeat_interleave(torch.arange(B * N, device=dev), (rp[:, 1:] - rp[:, :-1]).reshape(-1))
-            vals = S3.reshape(B * N, N)[rows, colidx[:nnz].long()].float().contiguous() if nnz else \
-                torch.zeros(1, dtype=torch.float32, device=dev)
-            sc = self._scratch
-            with torch.cuda.device(dev):
-                stream = nat.current_stream(dev)
-                key = _param_key(self.weight) + (str(dev),)
-                if sc.packed is None or sc.packed_key != key:
-                    nfl = lib.magat_gat_packed_floats(self.G, self.F, self.K, 1, nat.MODE_GNN)
-                    sc.packed = torch.empty(nfl, dtype=torch.float32, device=dev)
-                    w = self.weight.detach().to(dev, torch.float32).contiguous()
-                    nat.check(lib.magat_gat_pack_weights(None, None, None, nat.ptr(w), nat.ptr(sc.packed), self.G, self.F,
-                                                         self.K, 1, nat.MODE_GNN, stream), "magat_gat_pack_weights")
-                    sc.packed_key = key
-                need = lib.magat_gat_csr_workspace_bytes(B, N, nnz, self.G, self.F, self.K, 1, nat.MODE_GNN, 1)
-                _workspace(sc, need, dev)
-                out = torch.empty(B * N, self.F, dtype=torch.float32, device=dev)
-                bias = None if self.bias is None else self.bias.detach().to(dev, torch.float32).reshape(-1).contiguous()
-                nat.check(lib.magat_gnn_forward_csr_f32(
-                    nat.ptr(X), nat.ptr(rowptr), nat.ptr(colidx), nat.ptr(vals), nnz, nat.ptr(sc.packed), nat.ptr(bias),
-                    nat.ptr(out), out.stride(0), nat.ptr(sc.workspace), sc.workspace.numel(), B, N, self.G, self.F,
-                    self.K, stream), "magat_gnn_forward_csr_f32")
-            y = out.view(B, N, self.F).permute(0, 2, 1)
+            y = self._forward_hip(x)[0]
         if Nin < N:
             y = y[:, :, :Nin]
         return y
+
+    def _csr(self, dev, B):
+        """CSR arrays of float(S) (every non-zero entry, values kept) for the HIP kernels."""
+        N = self.N
+        S3 = self.S.reshape(B, N, N).to(dev)
+        if S3.dtype not in (torch.float32, torch.float64):
+            S3 = S3.float()
+        S3 = S3.contiguous()
+        rowptr, colidx, nnz = dense_gso_to_csr(S3, self_loops=2)          # rule 2: every non-zero float(S)
+        rp = rowptr.view(B, N + 1).long()
+        rows = torch.repeat_interleave(torch.arange(B * N, device=dev), (rp[:, 1:] - rp[:, :-1]).reshape(-1))
+        vals = S3.reshape(B * N, N)[rows, colidx[:nnz].long()].float().contiguous() if nnz else \
+            torch.zeros(1, dtype=torch.float32, device=dev)
+        return rowptr, colidx, vals, nnz
+
+    def _forward_hip(self, x):
+        """x (B,G,N) device tensor -> (y (B,F,N) view, X rows (M,G), csr) on the HIP CSR kernels."""
+        if not x.is_cuda:
+            raise nat.MagatNativeError("the HIP path needs device tensors; got %s (no CPU fallback)" % x.device)
+        lib = nat.lib()
+        dev = x.device
+        B, _, N = x.shape
+        X = x.detach().permute(0, 2, 1).contiguous().float()
+        rowptr, colidx, vals, nnz = csr = self._csr(dev, B)
+        sc = self._scratch
+        with torch.cuda.device(dev):
+            stream = nat.current_stream(dev)
+            key = _param_key(self.weight) + (str(dev),)
+            if sc.packed is None or sc.packed_key != key:
+                nfl = lib.magat_gat_packed_floats(self.G, self.F, self.K, 1, nat.MODE_GNN)
+                sc.packed = torch.empty(nfl, dtype=torch.float32, device=dev)
+                w = self.weight.detach().to(dev, torch.float32).contiguous()
+                nat.check(lib.magat_gat_pack_weights(None, None, None, nat.ptr(w), nat.ptr(sc.packed), self.G, self.F,
+                                                     self.K, 1, nat.MODE_GNN, stream), "magat_gat_pack_weights")
+                sc.packed_key = key
+            need = lib.magat_gat_csr_workspace_bytes(B, N, nnz, self.G, self.F, self.K, 1, nat.MODE_GNN, 1)
+            _workspace(sc, need, dev)
+            out = torch.empty(B * N, self.F, dtype=torch.float32, device=dev)
+            bias = None if self.bias is None else self.bias.detach().to(dev, torch.float32).reshape(-1).contiguous()
+            nat.check(lib.magat_gnn_forward_csr_f32(
+                nat.ptr(X), nat.ptr(rowptr), nat.ptr(colidx), nat.ptr(vals), nnz, nat.ptr(sc.packed), nat.ptr(bias),
+                nat.ptr(out), out.stride(0), nat.ptr(sc.workspace), sc.workspace.numel(), B, N, self.G, self.F,
+                self.K, stream), "magat_gnn_forward_csr_f32")
+        return out.view(B, N, self.F).permute(0, 2, 1), X.view(B * N, self.G), csr
 
     def extra_repr(self):
         return "in_features=%d, out_features=%d, filter_taps=%d, edge_features=%d, bias=%s, GSO stored: %s" % (

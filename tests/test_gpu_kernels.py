@@ -373,6 +373,57 @@ def test_gat_training_backward_matches_autograd(gpu_device, mode, concat, N, G, 
         close(getattr(layer, n_).grad, getattr(ref, n_).grad, n_)
 
 
+@pytest.mark.parametrize("N,G,F,K", [(12, 64, 32, 3), (20, 128, 128, 2), (9, 32, 16, 4), (30, 16, 64, 1), (100, 128, 128, 3)])
+def test_graph_filter_batch_backward_matches_autograd(gpu_device, N, G, F, K):
+    """HIP training forward/backward of GraphFilterBatch (magat_gnn_backward_csr_f32 + two GEMMs) vs float64 autograd
+    of the reference algebra (x @ S per hop, graphML.py:5485-5579) on CPU: y, dx, dweight, dbias.  The GSO has directed
+    (asymmetric) entries, an isolated node and negative values, so the direction of the gradient hop is exercised."""
+    from magat_pathplanning_amd import GraphFilterBatch
+    from magat_pathplanning_amd.synthetic import comm_gso
+    from oracle import magat_oracle as orc
+    B = 3
+    g = torch.Generator().manual_seed(N * 5 + F)
+    ref = GraphFilterBatch(G, F, K).double()
+    x = (torch.randn(B, G, N, generator=g) * 0.6).double().requires_grad_(True)
+    S = comm_gso(B, N, max(6, int(4 * N ** 0.5)), seed=N, dtype=torch.float64)
+    S[0, 2, :] = 0
+    S[0, :, 2] = 0
+    S[1, 3, 5], S[1, 5, 3] = 0.7, 0.0
+    S[2, 1, 4], S[2, 4, 1] = -0.4, 0.2
+    wgt = torch.randn(B, F, N, generator=g).double()
+    Sd = S.float().double()                      # the layer multiplies by S.float() (:5562)
+    z, y_ref = x, torch.einsum("bgn,fg->bfn", x, ref.weight[:, 0, 0])
+    for k in range(1, K):
+        z = torch.matmul(z, Sd)
+        y_ref = y_ref + torch.einsum("bgn,fg->bfn", z, ref.weight[:, 0, k])
+    y_ref = y_ref + ref.bias
+    if K <= 3 and N <= 30:                       # the same algebra as the pinned oracle
+        with torch.no_grad():
+            want = orc.graph_filter_batch_forward(x.float(), S.unsqueeze(1), ref.weight.float(), ref.bias.float())
+        assert float((want.double() - y_ref).abs().max()) < 1e-4
+    (y_ref * wgt).sum().backward()
+    layer = GraphFilterBatch(G, F, K)
+    layer.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    layer = layer.to(gpu_device).train()
+    xg = x.detach().float().to(gpu_device).requires_grad_(True)
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    y = layer(xg)
+    assert type(y.grad_fn).__name__ == "_GnnTrainFunctionBackward"          # the HIP function, not the composite
+    (y * wgt.float().to(gpu_device)).sum().backward()
+    torch.cuda.synchronize()
+    for a, b, what in ((y, y_ref, "y"), (xg.grad, x.grad, "dx"), (layer.weight.grad, ref.weight.grad, "dweight"),
+                       (layer.bias.grad, ref.bias.grad, "dbias")):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 2e-4 * scale, (what, float((a - b).abs().max()), scale)
+    # parameters only (input without grad), Nin < N padding
+    layer.zero_grad()
+    y2 = layer(x.detach().float().to(gpu_device)[:, :, :N - 2].contiguous())
+    assert y2.shape == (B, F, N - 2)
+    y2.sum().backward()
+    assert layer.weight.grad is not None and float(layer.weight.grad.abs().sum()) > 0
+
+
 def test_model_training_step_runs_on_gpu(gpu_device):
     """loss.backward() + optimizer step through DecentralPlannerGATNet in train() mode on the GPU: the GAT layer's
     forward/backward are the HIP kernels, CNN/MLPs are torch autograd; the loss must drop."""
