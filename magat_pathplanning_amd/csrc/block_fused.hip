@@ -72,6 +72,12 @@ long long* g_block3_dbg = nullptr;
 #else
 #define CHAIN_STAMP(i) do { } while (0)
 #endif
+// per-wave phase stamps of the layer3 kernel (debug build): [workgroup][wave 8][16], before and after every barrier
+#ifdef MAGAT_DEBUG_HOOKS
+#define L3_STAMP(i) do { if (p.dbg && (threadIdx.x & 63) == 0) p.dbg[((long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define L3_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ void split2(float x, float y, unsigned& p1, unsigned& p2, bool& clamped) {
   clamped |= (x > 65504.f) | (y > 65504.f);              // (post-ReLU values)
@@ -308,7 +314,12 @@ __device__ __forceinline__ void conv_walk(char* lds, int in_off, int in2_off, co
     ab[s] = (unsigned)(pix * PIXB + agent * 16 + fh * BLK);
   }
   u32x4 bw[2][2];
+  // MAGAT_WHATIF_NO_W / MAGAT_WHATIF_NO_LDS (tools/whatif_block3.sh): timing experiments, results are WRONG - the walk
+  // without its weight stream / without its operand reads, to see in CYCLES which supply path the MFMAs wait for
   auto load_b = [&](int step, u32x4 (&b)[2]) {
+#ifdef MAGAT_WHATIF_NO_W
+    if (step != 0) return;
+#endif
     b[0] = *reinterpret_cast<const u32x4*>(wl + (size_t)step * 2048);
     b[1] = *reinterpret_cast<const u32x4*>(wl + (size_t)step * 2048 + 1024);
   };
@@ -332,8 +343,12 @@ __device__ __forceinline__ void conv_walk(char* lds, int in_off, int in2_off, co
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         if (tl[s] < 0 || !(TILE_TAPS[tl[s] < 0 ? 0 : tl[s]] >> tp & 1)) continue;
+#ifdef MAGAT_WHATIF_NO_LDS
+        const u32x4 av[2] = {bw[step & 1][1], bw[step & 1][0]};
+#else
         const u32x4 av[2] = {*reinterpret_cast<const u32x4*>(lds + a0[s] + ks * 2 * BLK),
                              *reinterpret_cast<const u32x4*>(lds + a0[s] + ks * 2 * BLK + PS_IN)};
+#endif
 #pragma unroll
         for (int q = 0; q < 3; ++q)
           acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bw[step & 1][PB[q]]),
@@ -349,8 +364,12 @@ __device__ __forceinline__ void conv_walk(char* lds, int in_off, int in2_off, co
     for (int s = 0; s < NS; ++s) {
       if (tl[s] < 0) continue;
       const unsigned a0 = ab[s] + (unsigned)in2_off;
+#ifdef MAGAT_WHATIF_NO_LDS
+      const u32x4 av[2] = {bw[step & 1][1], bw[step & 1][0]};
+#else
       const u32x4 av[2] = {*reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK),
                            *reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK + PS_IN2)};
+#endif
 #pragma unroll
       for (int q = 0; q < 3; ++q)
         acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bw[step & 1][PB[q]]),
@@ -404,7 +423,7 @@ __global__ __launch_bounds__(512, 2) void block3_kernel(const L3Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int group = blockIdx.x;
   if (group >= p.groups) return;
-  CHAIN_STAMP(0);
+  L3_STAMP(0);
   for (int i = t; i < 32 * (PIXB / 4); i += 512)
     *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
   {   // input map: 16 (plane, chunk) blocks x 36 pixels x 128 B of this agent group
@@ -440,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void block3_kernel(const L3Params p) {
   constexpr int BPT1 = 9 * 4 * 2, BPT2A = 9 * 4 * 2, BPT2B = (9 * 4 + 4) * 2;      // 1 KB blocks per channel tile
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  CHAIN_STAMP(1);
+  L3_STAMP(1);
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     {   // conv1, output channels 64 h .. 64 h + 63 -> MID (channel tiles 2 h, 2 h + 1 of the weight block)
@@ -452,13 +471,15 @@ __global__ __launch_bounds__(512, 2) void block3_kernel(const L3Params p) {
       conv_walk<4, 0, 3>(lds, L_IN, 0, p.w1 + (size_t)(2 * h + ct1) * BPT1 * 1024 + lane * 16, tl1, a1);
       epi_to_lds<64, 3>(lds, L_MID, tl1, a1, ct1, p.b1 + 64 * h, s1, rows_ok, clamped);
     }
+    L3_STAMP(2 + 4 * h);
     __syncthreads();
-    CHAIN_STAMP(2 + 2 * h);
+    L3_STAMP(3 + 4 * h);
     // conv2: K over these 64 intermediate channels (second half: + the residual 1x1 over the 64 input channels)
     if (h == 0) conv_walk<4, 0, 5>(lds, L_MID, 0, p.w2a + (size_t)ct2 * BPT2A * 1024 + lane * 16, tl2, acc);
     else conv_walk<4, 4, 5>(lds, L_MID, L_IN, p.w2b + (size_t)ct2 * BPT2B * 1024 + lane * 16, tl2, acc);
+    L3_STAMP(4 + 4 * h);
     __syncthreads();          // MID is rewritten by the next half / becomes scratch
-    CHAIN_STAMP(3 + 2 * h);
+    L3_STAMP(5 + 4 * h);
   }
   // ReLU'd output -> LDS scratch [pixel][agent][128 floats] (16-byte quads XOR-swizzled by the row: the 32 lanes that hold the
   // same quad index then hit 32 different bank groups), then the 2x2 sums
@@ -498,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void block3_kernel(const L3Params p) {
     if (m < p.M)
       *reinterpret_cast<f32x4*>(p.out + ((long long)(m >> 7) * 9 + cell) * (128 * 128) + (m & 127) * 128 + 4 * Q) = sum;
   }
-  CHAIN_STAMP(6);
+  L3_STAMP(10);
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 

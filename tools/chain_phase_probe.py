@@ -30,9 +30,9 @@ print("per-workgroup cycles (wave 0), mean / p90:  total %.0f / %.0f" % (tot.mea
 for i, n in enumerate(names):
     print("  %-30s %8.0f / %8.0f   (%.1f %%)" % (n, d[:, i].mean(), np.percentile(d[:, i], 90), 100 * d[:, i].mean() / tot.mean()))
 
-# layer3 kernel (one workgroup per agent group)
+# layer3 kernel (one workgroup per agent group): per-WAVE stamps before and after every barrier
 g3 = B * N // 8
-buf3 = torch.zeros(g3, 8, dtype=torch.int64, device=dev)
+buf3 = torch.zeros(g3, 8, 16, dtype=torch.int64, device=dev)
 h.magat_block3_set_debug_buffer.argtypes = [ctypes.c_void_p]
 with torch.no_grad():
     h.magat_block3_set_debug_buffer(ctypes.c_void_p(buf3.data_ptr()))
@@ -40,10 +40,11 @@ with torch.no_grad():
     torch.cuda.synchronize()
     h.magat_block3_set_debug_buffer(None)
 t = buf3.cpu().numpy().astype(np.float64)
-names = ["prologue (input DMA)", "conv1 half 0 (+barrier)", "conv2 half 0 (+barrier)", "conv1 half 1 (+barrier)",
-         "conv2 half 1 + residual (+barrier)", "relu + pool + store"]
-d = t[:, 1:7] - t[:, 0:6]
-tot = t[:, 6] - t[:, 0]
-print("layer3 kernel, per-workgroup cycles (wave 0), mean / p90:  total %.0f / %.0f" % (tot.mean(), np.percentile(tot, 90)))
+names = ["prologue (input DMA + barrier)", "conv1 half 0", "  barrier", "conv2 half 0", "  barrier", "conv1 half 1", "  barrier",
+         "conv2 half 1 + residual", "  barrier", "relu + pool + store"]
+d = t[:, :, 1:11] - t[:, :, 0:10]                 # [wg][wave][phase]
+tot = (t[:, :, 10] - t[:, :, 0]).mean()
+print("layer3 kernel, cycles per agent group (mean over workgroups), by wave; total %.0f" % tot)
+print("  %-32s" % "phase" + "".join("   wave%d" % w for w in range(8)))
 for i, n in enumerate(names):
-    print("  %-38s %8.0f / %8.0f   (%.1f %%)" % (n, d[:, i].mean(), np.percentile(d[:, i], 90), 100 * d[:, i].mean() / tot.mean()))
+    print("  %-32s" % n + "".join("%8.0f" % d[:, w, i].mean() for w in range(8)))
