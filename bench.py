@@ -118,7 +118,8 @@ def kernel_work(nat, cfg, N, S_bytes, deg=None, planned=False, fused_stem=True, 
     w["layer2 (fused)"] = dict(flops=conv[(1, 1)][0] + conv[(1, 2)][0], bytes=4 * (36 * 32 + 36 * 64), arith="f16x3")
     # layer3 + ReLU + 2x2 pool in one launch: layer2's map in, the 9 pooled cells out
     w["layer3 (fused, pooled)"] = dict(flops=conv[(2, 1)][0] + conv[(2, 2)][0], bytes=4 * (36 * 64 + 9 * 128), arith="f16x3")
-    w["head(avgpool+fc+linear)"] = dict(flops=2 * 9 * 128 * nfm, bytes=4 * ((9 if pooled_head else 36) * 128 + nfm), arith="f32")
+    head_a = "f16x3" if (pooled_head and lib_opt(nat, "HEAD_F16") and conv_arith(nat, cfg, 2) == "f16x3") else "f32"
+    w["head(avgpool+fc+linear)"] = dict(flops=2 * 9 * 128 * nfm, bytes=4 * ((9 if pooled_head else 36) * 128 + nfm), arith=head_a)
     w["compressMLP"] = dict(flops=2 * nfm * G, bytes=4 * (nfm + G), arith="f32")
     gat_a = "f32"
     if lib_opt(nat, "GAT_SPLIT") and NC % 32 == 0 and G % 32 == 0:
@@ -415,7 +416,8 @@ def main():
                "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32 in/out, fp32-class arithmetic: convolutions + GAT maps as %s split products on the 16-bit matrix "
-                        "cores with f32 accumulation, head / MLPs on f32 MFMA, graph kernel f32 VALU%s"
+                        "cores with f32 accumulation (the encoder head too, on the layer3 kernel's pooled map), MLPs on f32 MFMA, graph "
+                        "kernel f32 VALU%s"
                         % ("/".join(ariths), "" if cfg.gat_storage == "fp32" else "; bf16 STORAGE inside the GAT layer"),
                "data": "synthetic (seeded binary FOV states + comm-radius GSO; random-init weights, BN stats perturbed)",
                "config": {"workload": "%s: N=%d agents, %dx%d map, K=%d, P=%d, F=%d, %s, %s, KeyQuery, %s; batch %d per GPU "

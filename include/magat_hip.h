@@ -51,6 +51,7 @@ const char* magat_error_string(int code);
  *   CONV_MX     (0)  OPT-IN block-scaled fp8 correction planes in layer2 / layer3 (narrower than fp32-class arithmetic)
  *   CONV_SPLIT  (7)  bit l: BasicBlock l+1 on the f16x3 split kernels; 0 = every convolution on the fp32 MFMA kernel
  *   HEAD_SPLITK      largest agent count whose encoder head sums per-cell partials (0: one long-K GEMM, bit-exact resharding)
+ *   HEAD_F16    (1)  encoder head as f16x3 split products when its input is the layer3 kernel's pooled map (large batches)
  * Returns MAGAT_ERR_UNSUPPORTED for an unknown name. */
 int magat_set_option(const char* name, int value);
 int magat_get_option(const char* name, int* value);
@@ -409,6 +410,8 @@ typedef struct magat_encoder_desc {
   int64_t chain_off; /* float offset of the BasicBlock chain kernel's fragment-major weights (encoder.pack_chain_weights: layer1.
                         conv2+downsample, layer2.conv1, layer2.conv2+downsample), 0 = absent -> layer-by-layer kernels (ABI 2) */
   int64_t chain3_off; /* float offset of the layer3 kernel's weights (encoder.pack_block3_weights), 0 = absent (ABI 2) */
+  int64_t head16_off; /* float offset of the head weight as f16x2 planes + 2^-e (in_fmt 4), 0 = absent: the head runs as
+                         f16x3 split products when its input is the layer3 kernel's pooled map (ABI 2) */
 } magat_encoder_desc;
 /* Range guard (option RANGE_GUARD, default 1).  The convolutions run as f16x3 split products (two half-precision planes per
  * value, fp32 accumulate: as accurate as the fp32 MFMA kernel while every activation stays within +-65504; the fused stem

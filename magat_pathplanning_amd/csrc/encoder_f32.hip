@@ -470,6 +470,11 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
       }
       magat_prof_end(pid, st);
     } else {
+      // many agents, pooled input (no pooling on load): a plain valid convolution - f16x3 split products like the blocks
+      if (pooled_in && split && d->head16_off > 0 && (clast % 32) == 0 && (d->n_feat % 32) == 0 &&
+          magat_opt(MAGAT_OPT_HEAD_F16)) {
+        g.in_fmt = 4; g.wt = pk + d->head16_off; g.range_flag = range_flag; g.run_if = nullptr;
+      }
       rc = magat_conv_gemm_f32(&g, stream);
     }
     if (rc != MAGAT_OK) return rc;

@@ -40,6 +40,7 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
     {"GAT_FUSED_MAPS", 1},   // hoisted maps computed inside the graph kernel (Z never crosses HBM)
     {"CSR_TILED", 3},        // CSR path, N <= 1024: LDS-tiled kernels (bit 0 scores, bit 1 hops) instead of L2 gathers
     {"BLOCK3_FUSED", 1},     // layer3 + ReLU + pool as one launch (two-half intermediate in LDS); needs BLOCK_FUSED
+    {"HEAD_F16", 1},         // encoder head on the f16x3 split kernel when its input is the pooled map of the layer3 kernel
 };
 
 int g_val[MAGAT_OPT_COUNT];

@@ -183,8 +183,17 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
             return pack[offs[slot]:(nxt[0] if nxt else n_f32)].reshape(128, -1)
         chain3_off = pack.numel()
         pack = torch.cat([pack] + pack_block3_weights(rows3(10)[:, :9 * 64], rows3(12)[:, :9 * 128 + 64])).contiguous()
+    # the head once more as f16x2 planes (in_fmt 4): with the layer3 kernel's pooled output the head is a plain valid conv
+    # over the pooled map, 5x faster on the split-MFMA kernel than on the float32 matrix cores
+    nxt = sorted(o for o in offs[:18] if o > offs[14])
+    head16, _ = split_f16x2(pack[offs[14]:(nxt[0] if nxt else n_f32)])
+    pad = (-head16.numel()) % 4
+    if pad:
+        head16 = torch.cat((head16, torch.zeros(pad)))
+    head16_off = pack.numel()
+    pack = torch.cat([pack, head16]).contiguous()
     meta = dict(variant=0 if large else 1, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast, chain=chain_off,
-                chain3=chain3_off)
+                chain3=chain3_off, head16=head16_off)
     return pack, offs, meta
 
 
