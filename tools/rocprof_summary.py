@@ -89,6 +89,7 @@ def main():
     tr = find(os.path.join(out, "trace"), "*kernel_trace.csv")
     if tr:
         rows = [r for r in csv.DictReader(open(tr)) if any(o in r["Kernel_Name"] for o in ours)]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))          # the CSV is not in dispatch order
         if len(rows) % len(SEQ) == 0:
             dur = defaultdict(list)
             for i, r in enumerate(rows):
@@ -105,6 +106,9 @@ def main():
             continue
         rows = [r for r in csv.DictReader(open(cc)) if r.get("Counter_Name") == ctr and
                 any(o in r["Kernel_Name"] for o in ours)]
+        key = "Dispatch_Id" if rows and "Dispatch_Id" in rows[0] else None
+        if key:
+            rows.sort(key=lambda r: int(r[key]))
         if len(rows) % len(SEQ) == 0:
             acc2 = defaultdict(list)
             for i, r in enumerate(rows):
