@@ -140,6 +140,9 @@ __device__ __forceinline__ void chain_stage(const ChainParams& p, char* lds, int
   const char* wl = wts + (size_t)ct * BPT * 1024 + lane * 16;
   u32x4 bcur[KSM][2], bnxt[KSM][2];
   auto load_b = [&](int u, u32x4 (&b)[KSM][2]) {
+#ifdef MAGAT_WHATIF_NO_W       // timing experiment (wrong results; tools/whatif_block3.sh): one weight fetch per stage
+    if (u != __builtin_ctz(umask | (KS2 > 0 ? 0x200 : 0))) return;
+#endif
     const char* src = wl + (size_t)(u < 9 ? u * KSM : 9 * KSM) * 2048;
 #pragma unroll
     for (int ks = 0; ks < KSM; ++ks)
