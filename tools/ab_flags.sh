@@ -4,7 +4,7 @@
 #   SRC=block_fused.hip KERNELS="layer1.conv2+layer2" FLAG_LIST="-DX" bash tools/ab_flags.sh
 cd $(dirname $0)/..
 SRC=${SRC:-block_fused.hip}
-IFS='|' read -ra VARS <<< "|${FLAG_LIST}|"
+IFS="|" read -ra VARS <<< "|${FLAG_LIST}|x"; unset "VARS[${#VARS[@]}-1]"; VARS+=("")
 for F in "${VARS[@]}"; do
   touch magat_pathplanning_amd/csrc/$SRC
   MAGAT_EXTRA_FLAGS="$F" python -m magat_pathplanning_amd.build_native > /dev/null 2>&1 || { echo "build failed: $F"; continue; }
