@@ -152,7 +152,9 @@ def load_pmc_traffic():
     tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction).  PMC counters
     cannot be collected from inside this process, so the latest committed summary of the same workload is used."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary_*.json")), key=os.path.getmtime)
+    # the latest round by directory name (r02h > r02f > r01h): file times do not survive a checkout
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary_*.json")),
+                   key=lambda q: os.path.basename(os.path.dirname(q)))
     if not paths:
         return {}
     try:
