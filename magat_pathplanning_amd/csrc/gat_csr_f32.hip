@@ -357,18 +357,27 @@ WsLayout ws_layout(int B, int N, long long nnz, int G, int F, int K, int P, int 
 // in att[] by the lane that owns the edge (edge k of a row belongs to lane k & 7 of the row's group: same-thread
 // read-after-write, always coherent); owners prefetch their previous partials as one batch before the edge loop, and the
 // value enters the 8-lane reduction of the dot product as an extra term of its owner - no dependent load in the loop.
-constexpr int TILE_ROW_BYTES = 128;
-constexpr int TILED_ROUNDS = 4;          // edges of a row handled by the batched path: 8 * TILED_ROUNDS (the rest: slow path)
+// LPR = lanes per graph row (8: 128-byte slices, one 1024-thread workgroup per CU at N = 1000; 4: 64-byte slices, 512-thread
+// workgroups, two per CU - one streams its slice in while the other computes).  32 edges of a row take the batched path.
+constexpr int TILED_EDGES = 32;
+template <int LPR>
+__device__ __forceinline__ float grp_sum(float d) {
+  if (LPR == 8) return oct_sum(d);
+  d += __shfl_xor(d, 1, 64);
+  d += __shfl_xor(d, 2, 64);
+  return d;
+}
 
-template <typename ST>
+template <typename ST, int LPR>
 __device__ __forceinline__ void tile_dma(char* tile, const ST* src_base, long long row_stride_elems, int N, int t) {
-  // rows n = 0..N-1, 128 bytes each from src_base + n * row_stride: one wave instruction moves 8 rows (1 KB)
+  // rows n = 0..N-1, 16 LPR bytes each from src_base + n * row_stride: one wave instruction moves 64 / LPR rows (1 KB)
+  constexpr int RPI = 64 / LPR;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), nw = (int)(blockDim.x >> 6);
-  for (int g = wave; g * 8 < N; g += nw) {
-    const int n = g * 8 + (lane >> 3);
+  for (int g = wave; g * RPI < N; g += nw) {
+    const int n = g * RPI + lane / LPR;
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile + (unsigned)g * 1024u);
     if (n < N) {
-      const char* src = reinterpret_cast<const char*>(src_base + (long long)n * row_stride_elems) + (lane & 7) * 16;
+      const char* src = reinterpret_cast<const char*>(src_base + (long long)n * row_stride_elems) + (lane & (LPR - 1)) * 16;
       asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
     }
   }
@@ -410,18 +419,19 @@ template <> struct TileVec<u16> {
   }
 };
 
-template <typename ST>
+template <typename ST, int LPR>
 __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams p, int G) {
   extern __shared__ __attribute__((aligned(1024))) char tile[];
   constexpr int E = TileVec<ST>::E;                 // features per lane and pass
+  constexpr int TILE_ROW_BYTES = 16 * LPR, RPS = 64 / LPR;          // bytes of a row slice; graph rows per wave step
   constexpr int FPP = TILE_ROW_BYTES / (int)sizeof(ST);   // features per pass
-  constexpr int R = TILED_ROUNDS;
+  constexpr int R = TILED_EDGES / LPR;
   const int N = p.N, NP = G / FPP;
   const int bid = blockIdx.x, xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
   const int b = xcd + MAGAT_NUM_XCD * (slot / p.P), head = slot % p.P;
   if (b >= p.B) return;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, es = lane & 7, eg = lane >> 3, gbase = lane & ~7;
-  const int rstep = 8 * (int)(blockDim.x >> 6);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, es = lane & (LPR - 1), eg = lane / LPR, gbase = lane & ~(LPR - 1);
+  const int rstep = RPS * (int)(blockDim.x >> 6);
   const int* rp = p.rowptr + (long long)b * (N + 1);
   const ST* Zb = static_cast<const ST*>(p.Z) + (long long)b * N * p.NC + p.qoff + head * G;
   const ST* Xb = static_cast<const ST*>(p.X) + (long long)b * N * G;
@@ -448,21 +458,21 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const bool mine_ok = es + 8 * r < w.deg;
-        w.cj[r] = mine_ok ? p.colidx[w.e0 + es + 8 * r] : 0;
+        const bool mine_ok = es + LPR * r < w.deg;
+        w.cj[r] = mine_ok ? p.colidx[w.e0 + es + LPR * r] : 0;
         // (agent-scope load: served by L2.  The value was stored by THIS thread in the previous pass, but a plain load may
         //  hit the copy of the line this CU's L1 still holds from the pass before that)
         w.pre[r] = (!first && mine_ok)
-                       ? __hip_atomic_load(att + w.e0 + es + 8 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                       ? __hip_atomic_load(att + w.e0 + es + LPR * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
       }
     };
     Row cur, nxt;
-    if (8 * wave < N) fetch(8 * wave, cur);           // in flight together with the slice
+    if (RPS * wave < N) fetch(RPS * wave, cur);           // in flight together with the slice
     if (h > 0) __syncthreads();                       // every wave is done with the previous slice
-    tile_dma<ST>(tile, Zb + h * FPP, p.NC, N, t);
+    tile_dma<ST, LPR>(tile, Zb + h * FPP, p.NC, N, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int ib = 8 * wave; ib < N; ib += rstep) {
+    for (int ib = RPS * wave; ib < N; ib += rstep) {
       if (ib + rstep < N) fetch(ib + rstep, nxt);
       const int e0 = cur.e0, deg = cur.deg;
       float mine[R];
@@ -481,18 +491,18 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
       };
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        if (__builtin_amdgcn_ballot_w64(8 * r < deg) == 0ull) break;
+        if (__builtin_amdgcn_ballot_w64(LPR * r < deg) == 0ull) break;
 #pragma unroll
-        for (int k = 0; k < 8; k += 2) {
-          const int ka = 8 * r + k, kb = ka + 1;
+        for (int k = 0; k < LPR; k += 2) {
+          const int ka = LPR * r + k, kb = ka + 1;
           const bool va = ka < deg, vb = kb < deg;
           // neighbour index of edge k from its owner lane (past the row's degree: row 0 of the slice, never used)
           const int ja = __shfl(cur.cj[r], gbase + k, 64), jb = __shfl(cur.cj[r], gbase + k + 1, 64);
           float da = edge_dot(ja), db = edge_dot(jb);
           if (es == k) da += cur.pre[r];
           if (es == k + 1) db += cur.pre[r];
-          da = oct_sum(da);
-          db = oct_sum(db);
+          da = grp_sum<LPR>(da);
+          db = grp_sum<LPR>(db);
           if (es == k && va) mine[r] = da;
           if (es == k + 1 && vb) mine[r] = db;
           if (last) {
@@ -502,24 +512,24 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
         }
       }
       // rows with more than 8 R edges: the rest one by one, owner = lane 0 (dependent loads: rare)
-      for (int k = 8 * R; k < deg; ++k) {
+      for (int k = LPR * R; k < deg; ++k) {
         float d = edge_dot(p.colidx[e0 + k]);
         if (es == 0 && !first) d += __hip_atomic_load(att + e0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        d = oct_sum(d);
+        d = grp_sum<LPR>(d);
         if (es == 0) att[e0 + k] = d;
         if (last) online(d);
       }
       if (!last) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
-          if (es + 8 * r < deg) att[e0 + es + 8 * r] = mine[r];
+          if (es + LPR * r < deg) att[e0 + es + LPR * r] = mine[r];
       } else {
         const float inv = sum > 0.f ? 1.f / sum : 0.f;
 #pragma unroll
         for (int r = 0; r < R; ++r)
-          if (es + 8 * r < deg) att[e0 + es + 8 * r] = __expf(mine[r] - mx) * inv;
+          if (es + LPR * r < deg) att[e0 + es + LPR * r] = __expf(mine[r] - mx) * inv;
         if (es == 0)
-          for (int k = 8 * R; k < deg; ++k)
+          for (int k = LPR * R; k < deg; ++k)
             att[e0 + k] = __expf(__hip_atomic_load(att + e0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mx) * inv;
       }
       cur = nxt;
@@ -528,18 +538,19 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
 }
 
 // one Horner hop out[j] = U_k[j] + sum over in-edges (i -> j) of att * Told[i], Told slice in LDS
-template <typename ST>
+template <typename ST, int LPR>
 __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, int F) {
   extern __shared__ __attribute__((aligned(1024))) char tile[];
   constexpr int E = TileVec<ST>::E;
+  constexpr int TILE_ROW_BYTES = 16 * LPR, RPS = 64 / LPR;
   constexpr int FPP = TILE_ROW_BYTES / (int)sizeof(ST);
-  constexpr int R = TILED_ROUNDS;
+  constexpr int R = TILED_EDGES / LPR;
   const int N = p.N, NP = F / FPP;
   const int bid = blockIdx.x, xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
   const int b = xcd + MAGAT_NUM_XCD * (slot / p.P), head = slot % p.P;
   if (b >= p.B) return;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, es = lane & 7, eg = lane >> 3, gbase = lane & ~7;
-  const int rstep = 8 * (int)(blockDim.x >> 6);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, es = lane & (LPR - 1), eg = lane / LPR, gbase = lane & ~(LPR - 1);
+  const int rstep = RPS * (int)(blockDim.x >> 6);
   const int* cp = p.cscptr + (long long)b * (N + 1);
   const float* att = p.att + (long long)head * p.nnz;
   const ST* Tb = static_cast<const ST*>(p.Told) + p.told_off + (long long)b * N * p.told_ld +
@@ -562,18 +573,18 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
       TileVec<ST>::load(Ub + (long long)jr * p.NC + h * FPP + es * E, w.acc);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const bool mine_ok = es + 8 * r < w.deg;
-        w.src[r] = mine_ok ? p.cscsrc[w.s0 + es + 8 * r] : 0;
-        w.wgt[r] = mine_ok ? att[p.cscpos[w.s0 + es + 8 * r]] : 0.f;
+        const bool mine_ok = es + LPR * r < w.deg;
+        w.src[r] = mine_ok ? p.cscsrc[w.s0 + es + LPR * r] : 0;
+        w.wgt[r] = mine_ok ? att[p.cscpos[w.s0 + es + LPR * r]] : 0.f;
       }
     };
     Row cur, nxt;
-    if (8 * wave < N) fetch(8 * wave, cur);
+    if (RPS * wave < N) fetch(RPS * wave, cur);
     if (h > 0) __syncthreads();
-    tile_dma<ST>(tile, Tb + h * FPP, p.told_ld, N, t);
+    tile_dma<ST, LPR>(tile, Tb + h * FPP, p.told_ld, N, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int jb = 8 * wave; jb < N; jb += rstep) {
+    for (int jb = RPS * wave; jb < N; jb += rstep) {
       if (jb + rstep < N) fetch(jb + rstep, nxt);
       const int j = jb + eg, deg = cur.deg;
       float acc[E];
@@ -581,10 +592,10 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
       for (int c = 0; c < E; ++c) acc[c] = cur.acc[c];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        if (__builtin_amdgcn_ballot_w64(8 * r < deg) == 0ull) break;
+        if (__builtin_amdgcn_ballot_w64(LPR * r < deg) == 0ull) break;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          // (i, a) of edge 8 r + k from its owner lane; edges past the row's degree carry weight 0 and row 0
+        for (int k = 0; k < LPR; ++k) {
+          // (i, a) of edge LPR r + k from its owner lane; edges past the row's degree carry weight 0 and row 0
           const int i = __shfl(cur.src[r], gbase + k, 64);
           const float a = __shfl(cur.wgt[r], gbase + k, 64);
           float tv[E];
@@ -593,7 +604,7 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
           for (int c = 0; c < E; ++c) acc[c] = fmaf(a, tv[c], acc[c]);
         }
       }
-      for (int k = 8 * R; k < deg; ++k) {
+      for (int k = LPR * R; k < deg; ++k) {
         const int i = p.cscsrc[cur.s0 + k];
         const float a = att[p.cscpos[cur.s0 + k]];
         float tv[E];
@@ -624,24 +635,32 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
 
 template <typename ST>
 bool csr_tiled_ok(const CsrParams& p, int width, int which) {      // which: 1 = scores, 2 = hop (option CSR_TILED = bit mask)
-  return (magat_opt(MAGAT_OPT_CSR_TILED) & which) && p.N <= 1024 && p.N >= 8 && (width * (int)sizeof(ST)) % TILE_ROW_BYTES == 0;
+  return (magat_opt(MAGAT_OPT_CSR_TILED) & which) && p.N <= 1024 && p.N >= 8 && (width * (int)sizeof(ST)) % 128 == 0;
+}
+template <typename ST, int LPR>
+int launch_tiled(const CsrParams& p, int width, bool scores, hipStream_t st) {
+  constexpr int RPS = 64 / LPR;
+  const long long grid = (long long)((p.B + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD) * MAGAT_NUM_XCD * p.P;
+  if (grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
+  const size_t lds = (size_t)((p.N + RPS - 1) / RPS) * 1024;
+  const void* fn = scores ? reinterpret_cast<const void*>(&csr_tiled_scores_kernel<ST, LPR>)
+                          : reinterpret_cast<const void*>(&csr_tiled_hop_kernel<ST, LPR>);
+  const int slot = (scores ? MAGAT_LDS_CSR_TILED_A : MAGAT_LDS_CSR_TILED_B) + (sizeof(ST) == 2 ? 2 : 0) + (LPR == 4 ? 4 : 0);
+  if (magat_ensure_dyn_lds(fn, slot, lds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
+  const int threads = LPR == 4 ? 512 : 1024;
+  const int pid = magat_prof_begin(MAGAT_TAG_GAT_GRAPH, st);
+  if (scores)
+    hipLaunchKernelGGL((csr_tiled_scores_kernel<ST, LPR>), dim3((unsigned)grid), dim3(threads), lds, st, p, width);
+  else
+    hipLaunchKernelGGL((csr_tiled_hop_kernel<ST, LPR>), dim3((unsigned)grid), dim3(threads), lds, st, p, width);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
 }
 template <typename ST>
 int run_tiled(const CsrParams& p, int width, bool scores, hipStream_t st) {
-  const long long grid = (long long)((p.B + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD) * MAGAT_NUM_XCD * p.P;
-  if (grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
-  const size_t lds = (size_t)((p.N + 7) / 8) * 8 * TILE_ROW_BYTES;
-  const void* fn = scores ? reinterpret_cast<const void*>(&csr_tiled_scores_kernel<ST>)
-                          : reinterpret_cast<const void*>(&csr_tiled_hop_kernel<ST>);
-  const int slot = (scores ? MAGAT_LDS_CSR_TILED_A : MAGAT_LDS_CSR_TILED_B) + (sizeof(ST) == 2 ? 2 : 0);
-  if (magat_ensure_dyn_lds(fn, slot, lds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
-  const int pid = magat_prof_begin(MAGAT_TAG_GAT_GRAPH, st);
-  if (scores)
-    hipLaunchKernelGGL((csr_tiled_scores_kernel<ST>), dim3((unsigned)grid), dim3(1024), lds, st, p, width);
-  else
-    hipLaunchKernelGGL((csr_tiled_hop_kernel<ST>), dim3((unsigned)grid), dim3(1024), lds, st, p, width);
-  magat_prof_end(pid, st);
-  return magat_check_launch();
+  // option CSR_TILED bit 2: 64-byte slices in 512-thread workgroups (two per CU) when a 128-byte slice leaves room for one
+  const bool half = (magat_opt(MAGAT_OPT_CSR_TILED) & 4) && (size_t)((p.N + 7) / 8) * 1024 > 80 * 1024;
+  return half ? launch_tiled<ST, 4>(p, width, scores, st) : launch_tiled<ST, 8>(p, width, scores, st);
 }
 
 template <int G, typename ST = float>

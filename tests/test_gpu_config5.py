@@ -73,14 +73,16 @@ def test_gso_csr_build_matches_the_definition(gpu_device, N, dtype, rule):
     assert torch.equal(Sd2.cpu(), w2)
 
 
+@pytest.mark.parametrize("tiled", [3, 7, 0])
 @pytest.mark.parametrize("storage", ["bf16", "fp32"])
-def test_config5_layer_at_1000_agents(gpu_device, storage):
+def test_config5_layer_at_1000_agents(gpu_device, storage, tiled, libopt):
     """GraphFilterBatchAttentional at N=1000, K=2, P=4, G=F=128 on the CSR kernels with the device-built structure:
     fp32 storage against the pinned oracle (1e-4 of the output scale), bf16 storage against the oracle's bf16-storage
     emulation (same rounding points, ~1 bf16 ulp of the output scale) and within the bf16 budget of the fp32 oracle."""
     from magat_pathplanning_amd import GraphFilterBatchAttentional
     from magat_pathplanning_amd.synthetic import comm_gso
     from oracle import magat_oracle as orc
+    libopt.set("CSR_TILED", tiled)  # 3: LDS-tiled kernels (default), 7: their 64-byte-slice form, 0: the L2-gather kernels
     B = 2
     g = torch.Generator().manual_seed(15)
     layer = GraphFilterBatchAttentional(G5, G5, K5, P5, attentionMode="KeyQuery")
