@@ -74,3 +74,34 @@ torch.cuda.synchronize()
 loop2 = (time.perf_counter() - t0) / T
 print("with the 0/1 adjacency as GSO (logits identical: %s): closed loop %.3f ms/step = %.2f M agent-steps/s"
       % (bool(torch.equal(y_norm, y_adj)), loop2 * 1e3, B * N / loop2 / 1e6))
+
+# The same loop through BatchedEpisode: the reference's whole per-case state on the device (step-0 radius growth, reach_goal /
+# first_move / end_step, flowtime / makespan), exp_multinorm action sampling from a seeded device generator.
+from magat_pathplanning_amd.simulator import BatchedEpisode
+gen = torch.Generator(device=dev).manual_seed(11)
+ep = BatchedEpisode(dm, torch.from_numpy(pos).to(dev), dgoal, maxstep=10 ** 6, comm_radius=7.0, action_select="exp_multinorm",
+                    generator=gen)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+S0 = ep.gso()                      # includes the radius growth of step 0
+torch.cuda.synchronize()
+t_first = time.perf_counter() - t0
+
+
+def ep_step():
+    with torch.no_grad():
+        net.addGSO(ep.gso())
+        return ep.step(net(ep.states()))
+
+
+for _ in range(3):
+    ep_step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(T):
+    ep_step()
+torch.cuda.synchronize()
+loop3 = (time.perf_counter() - t0) / T
+print("BatchedEpisode (exp_multinorm, bookkeeping on device): %.3f ms/step = %.2f M agent-steps/s; first getGSO with radius growth %.2f ms "
+      "(radii %.2f..%.2f); agents at their goals after %d steps: %d"
+      % (loop3 * 1e3, B * N / loop3 / 1e6, t_first * 1e3, float(ep.radii.min()), float(ep.radii.max()), T + 3, int(ep.reach_goal.sum())))
