@@ -526,6 +526,238 @@ __global__ __launch_bounds__(512, 2) void block3_kernel(const L3Params p) {
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// layer3, "w4" form: FOUR waves per workgroup, one per SIMD, each with the whole 512-entry register budget (256 arch + 256
+// accumulation registers).  conv2: wave = one 32-channel output tile x ALL nine row tiles (144 accumulator registers, live
+// across both halves) - every weight fragment is fetched by exactly one wave of the workgroup (the 8-wave form fetches it
+// twice for conv2, four times for conv1: the vector-memory return path was 72 % busy).  conv1: wave = (channel tile of the
+// half, one of two row-tile groups).  Every wave role is a compile-time list of (tap, k step, row tile) items, so the K walk is
+// straight-line code with immediate LDS offsets: no tap loop, no branches, no address arithmetic except for the corner tile;
+// the operand reads of item i + 2 sit between the MFMAs of item i (measured, tools/exp/mfma_lds.hip: one wave per SIMD sustains
+// 1.9 PF that way, 1.67 PF with the reads in front of the MFMA run), weights come 3 k steps ahead.
+struct W4Item { signed char tp, ks, s, first; };           // tp = 9: the residual 1x1 segment over in2
+struct W4All { static constexpr int NT = 9; static constexpr int t[9] = {T_I0, T_I1, T_I2, T_I3, T_C, T_ET, T_EB, T_EL, T_ER}; };
+struct W4A { static constexpr int NT = 4; static constexpr int t[4] = {T_I0, T_I1, T_I2, T_ET}; };           // 33 tile-taps
+struct W4B { static constexpr int NT = 5; static constexpr int t[5] = {T_I3, T_C, T_EB, T_EL, T_ER}; };      // 36 tile-taps
+constexpr int W4_TAPS[9] = {0x1FF, 0x1FF, 0x1FF, 0x1FF, 0x1F8, 0x03F, 0x1B6, 0x0DB, 0x1FF};     // = TILE_TAPS, host-visible
+template <int NMAX> struct W4Seq { W4Item it[NMAX]; int n, nmain; };
+template <typename TL, int KS2>
+constexpr W4Seq<(36 + KS2) * TL::NT + 1> w4_seq() {
+  W4Seq<(36 + KS2) * TL::NT + 1> q{};
+  int n = 0;
+  for (int tp = 0; tp < 9; ++tp)
+    for (int ks = 0; ks < 4; ++ks) {
+      bool first = true;
+      for (int s = 0; s < TL::NT; ++s)
+        if (W4_TAPS[TL::t[s]] >> tp & 1) {
+          q.it[n].tp = (signed char)tp; q.it[n].ks = (signed char)ks; q.it[n].s = (signed char)s; q.it[n].first = first;
+          first = false;
+          ++n;
+        }
+    }
+  q.nmain = n;
+  for (int ks = 0; ks < KS2; ++ks)
+    for (int s = 0; s < TL::NT; ++s) {
+      q.it[n].tp = 9; q.it[n].ks = (signed char)ks; q.it[n].s = (signed char)s; q.it[n].first = s == 0;
+      ++n;
+    }
+  q.n = n;
+  return q;
+}
+// smallest pixel shift (6 dy + dx) over the active taps of a tile: the tile's base address points at that neighbour, so that
+// every immediate offset is non-negative
+constexpr int w4_minshift(int tile) {
+  int m = 99;
+  for (int tp = 0; tp < 9; ++tp)
+    if (W4_TAPS[tile] >> tp & 1) {
+      const int sh = 6 * (tp / 3 - 1) + (tp % 3 - 1);
+      if (sh < m) m = sh;
+    }
+  return m;
+}
+
+template <typename TL, int KS2>
+__device__ __forceinline__ void walk4(char* lds, int in_off, int in2_off, const char* wbase, f32x16 (&acc)[TL::NT], bool with_res) {
+  constexpr int NT = TL::NT, D = 4;
+  constexpr int PS_IN = 8 * BLK, PS_IN2 = 8 * BLK;             // both inputs are 64-channel maps
+  constexpr auto SQ = w4_seq<TL, KS2>();
+  constexpr int NSTEP = 36 + KS2;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));        // (keeps the address set-up inside the caller's loop over the halves)
+  const int lane = tid & 63;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int fr = lane & 31, fh = lane >> 5, agent = fr & 7, psl = fr >> 3;
+  unsigned ab[NT], b0[NT];
+  int cmask = 0;                         // corner tile: the lane's valid taps
+  unsigned cab = 0;
+#pragma unroll
+  for (int s = 0; s < NT; ++s) {
+    const int pix = TILE_PIX[TL::t[s]][psl];
+    ab[s] = (unsigned)(pix * PIXB + agent * 16 + fh * BLK);
+    b0[s] = ab[s] + (unsigned)(in_off + w4_minshift(TL::t[s]) * PIXB);
+    if (TL::t[s] == T_C) {
+      const int y = pix / 6, x = pix - 6 * y;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+        if (y + dy >= 0 && y + dy < 6 && x + dx >= 0 && x + dx < 6) cmask |= 1 << tp;
+      }
+      cab = ab[s];
+    }
+  }
+  const unsigned az = (unsigned)(ZPIX * PIXB + agent * 16 + fh * BLK + in_off);
+  u32x4 w[D][2];
+  auto load_w = [&](int step, u32x4 (&b)[2]) {
+    b[0] = *reinterpret_cast<const u32x4*>(wbase + (size_t)step * 2048 + lane16);
+    b[1] = *reinterpret_cast<const u32x4*>(wbase + (size_t)step * 2048 + (lane16 + 1024u));
+  };
+  u32x4 av[3][2];
+  auto rd = [&](const W4Item it, int pl, u32x4& dst) {
+    const int tile = TL::t[it.s];
+    if (it.tp == 9) {                                    // residual: the block input at the same pixel
+      dst = *reinterpret_cast<const u32x4*>(lds + (ab[it.s] + (unsigned)in2_off) + (pl * PS_IN2 + it.ks * 2 * BLK));
+    } else if (tile == T_C) {                            // corner pixels: per-lane validity, the others read the zero pixel
+      const int sh = 6 * (it.tp / 3 - 1) + (it.tp % 3 - 1);
+      const unsigned a = (cmask >> it.tp & 1) ? cab + (unsigned)(in_off + sh * PIXB) : az;
+      dst = *reinterpret_cast<const u32x4*>(lds + a + (pl * PS_IN + it.ks * 2 * BLK));
+    } else {
+      const int sh = 6 * (it.tp / 3 - 1) + (it.tp % 3 - 1) - w4_minshift(tile);
+      dst = *reinterpret_cast<const u32x4*>(lds + b0[it.s] + (sh * PIXB + pl * PS_IN + it.ks * 2 * BLK));
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < D - 1; ++j) load_w(j, w[j]);
+  rd(SQ.it[0], 0, av[0][0]);
+  rd(SQ.it[0], 1, av[0][1]);
+  rd(SQ.it[1], 0, av[1][0]);
+  rd(SQ.it[1], 1, av[1][1]);
+  const int nrun = with_res ? SQ.n : SQ.nmain;
+  const int nstep = with_res ? NSTEP : 36;
+#pragma clang loop unroll(full)
+  for (int i = 0; i < SQ.n; ++i) {
+    constexpr int dummy = 0; (void)dummy;
+    const W4Item it = SQ.it[i];
+    if (KS2 > 0 && i == SQ.nmain && !with_res) break;            // (uniform; the first half of conv2 has no residual)
+    const int step = it.tp * 4 + it.ks;
+    if (it.first && step + D - 1 < NSTEP) {
+      if (step + D - 1 < 36 || with_res) load_w(step + D - 1, w[(step + D - 1) % D]);
+    }
+    const bool more = i + 2 < SQ.n;
+    const bool more_ok = more && (i + 2 < SQ.nmain || with_res);
+    acc[it.s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[step % D][0]),
+                                                       __builtin_bit_cast(f16x8, av[i % 3][0]), acc[it.s], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) { if (more_ok) rd(SQ.it[more ? i + 2 : i], 0, av[(i + 2) % 3][0]); __builtin_amdgcn_sched_barrier(0); }
+    acc[it.s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[step % D][1]),
+                                                       __builtin_bit_cast(f16x8, av[i % 3][0]), acc[it.s], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) { if (more_ok) rd(SQ.it[more ? i + 2 : i], 1, av[(i + 2) % 3][1]); __builtin_amdgcn_sched_barrier(0); }
+    acc[it.s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[step % D][0]),
+                                                       __builtin_bit_cast(f16x8, av[i % 3][1]), acc[it.s], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  (void)nrun; (void)nstep;
+}
+
+__global__ __launch_bounds__(256, 1) void block3_w4_kernel(const L3Params p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  constexpr int L_IN = 0, L_MID = MAP64;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int group = blockIdx.x;
+  if (group >= p.groups) return;
+  for (int i = t; i < 32 * (PIXB / 4); i += 256)
+    *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
+  {   // input map: 16 (plane, chunk) blocks x 36 pixels x 128 B of this agent group
+    const int m0 = group * AG;
+    const long long tile_b = (long long)(m0 >> 7) * NPIX * (128 * 64 * 4) + (m0 & 127) * 16;
+    for (int item = wave; item < 16 * 5; item += 4) {
+      const int blk = item / 5, part = item % 5;             // blk = plane * 8 + chunk
+      const int pix = part * 8 + (lane >> 3);
+      const char* src = p.in + tile_b + (long long)pix * (128 * 64 * 4) + (blk >> 3) * (256 * 64) + (blk & 7) * 2048 +
+                        (lane & 7) * 16;
+      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(L_IN + blk * BLK + part * 8 * PIXB));
+      if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+    }
+  }
+  const float s1 = *p.s1, s2 = *p.s2;
+  bool clamped = false;
+  const bool rows_ok = group * AG + ((lane & 31) & 7) < p.M;
+  const int ct1 = wave & 1, rg1 = wave >> 1, ct2 = wave;
+  f32x16 acc[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  constexpr int BPT1 = 9 * 4 * 2, BPT2A = 9 * 4 * 2, BPT2B = (9 * 4 + 4) * 2;      // 1 KB blocks per channel tile
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    const char* w1 = p.w1 + (size_t)(2 * h + ct1) * BPT1 * 1024;
+    if (rg1 == 0) {
+      f32x16 a1[W4A::NT];
+#pragma unroll
+      for (int s = 0; s < W4A::NT; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
+      walk4<W4A, 0>(lds, L_IN, 0, w1, a1, false);
+      const int tl[W4A::NT] = {W4A::t[0], W4A::t[1], W4A::t[2], W4A::t[3]};
+      epi_to_lds<64, W4A::NT>(lds, L_MID, tl, a1, ct1, p.b1 + 64 * h, s1, rows_ok, clamped);
+    } else {
+      f32x16 a1[W4B::NT];
+#pragma unroll
+      for (int s = 0; s < W4B::NT; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
+      walk4<W4B, 0>(lds, L_IN, 0, w1, a1, false);
+      const int tl[W4B::NT] = {W4B::t[0], W4B::t[1], W4B::t[2], W4B::t[3], W4B::t[4]};
+      epi_to_lds<64, W4B::NT>(lds, L_MID, tl, a1, ct1, p.b1 + 64 * h, s1, rows_ok, clamped);
+    }
+    __syncthreads();
+    // conv2: K over these 64 intermediate channels (second half: + the residual 1x1 over the 64 input channels)
+    walk4<W4All, 4>(lds, L_MID, L_IN, (h == 0 ? p.w2a + (size_t)ct2 * BPT2A * 1024 : p.w2b + (size_t)ct2 * BPT2B * 1024), acc, h == 1);
+    __syncthreads();          // MID is rewritten by the next half / becomes scratch
+  }
+  // ReLU'd output -> LDS scratch [pixel][agent][128 floats] (quads XOR-swizzled by the row), then the 2x2 sums
+  float* S = reinterpret_cast<float*>(lds);
+  {
+    const int fr = lane & 31, fh = lane >> 5, agent = fr & 7, psl = fr >> 3;
+    f32x4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(p.b2 + 32 * ct2 + 8 * q + 4 * fh);
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+      const int pix = TILE_PIX[W4All::t[s]][psl];
+      const int row = pix * AG + agent;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * s2 + bq[q][c], 0.f);
+        const int Q = 8 * ct2 + 2 * q + fh;
+        *reinterpret_cast<f32x4*>(S + row * 128 + ((Q ^ (row & 31)) << 2)) = v;
+      }
+    }
+  }
+  __syncthreads();
+  for (int o = t; o < 9 * AG * 32; o += 256) {
+    const int Q = o & 31, agent = (o >> 5) & 7, cell = o >> 8;
+    const int cy = cell / 3, cx = cell - 3 * cy;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pix = (2 * cy + (e >> 1)) * 6 + 2 * cx + (e & 1);
+      const int row = pix * AG + agent;
+      sum += *reinterpret_cast<const f32x4*>(S + row * 128 + ((Q ^ (row & 31)) << 2));
+    }
+    const int m = group * AG + agent;
+    if (m < p.M)
+      *reinterpret_cast<f32x4*>(p.out + ((long long)(m >> 7) * 9 + cell) * (128 * 128) + (m & 127) * 128 + 4 * Q) = sum;
+  }
+  if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
+}
+
 // PERSISTENT workgroups (one per CU), each walking agent groups g, g + grid, ...  The main input map of the NEXT group
 // (layer1.conv1's output, 37 KB) streams into a fourth LDS region with LDS-direct loads while stages B and C of the current
 // group run; only the 32-channel residual input is fetched at the top of an iteration (half of the 8.4 k-cycle prologue a
@@ -654,8 +886,12 @@ int magat_block3(const void* in, float* out, const float* w, const float* b1, co
   constexpr size_t lds = 2 * MAP64;
   if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block3_kernel), MAGAT_LDS_BLOCK_B, lds) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
+  const bool w4 = magat_opt(MAGAT_OPT_BLOCK3_FUSED) >= 2;      // 2: four waves x 512 registers; 1: eight waves x 256
+  if (w4 && magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block3_w4_kernel), MAGAT_LDS_BLOCK_C, lds) != MAGAT_OK)
+    return MAGAT_ERR_LAUNCH;
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK3, st);
-  hipLaunchKernelGGL(block3_kernel, dim3((unsigned)p.groups), dim3(512), lds, st, p);
+  if (w4) hipLaunchKernelGGL(block3_w4_kernel, dim3((unsigned)p.groups), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(block3_kernel, dim3((unsigned)p.groups), dim3(512), lds, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }

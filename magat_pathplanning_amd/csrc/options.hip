@@ -40,7 +40,8 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
     {"GAT_FUSED_MAPS", 1},   // hoisted maps computed inside the graph kernel (Z never crosses HBM)
     {"CSR_TILED", 3},        // CSR path, N <= 1024: LDS-tiled kernels (bit 0 scores, bit 1 hops) instead of L2 gathers; bit 2 (opt-in,
                              // measured slower): 64-byte slices in 512-thread workgroups, two per CU
-    {"BLOCK3_FUSED", 1},     // layer3 + ReLU + pool as one launch (two-half intermediate in LDS); needs BLOCK_FUSED
+    {"BLOCK3_FUSED", 2},     // layer3 + ReLU + pool as one launch (two-half intermediate in LDS); needs BLOCK_FUSED.
+                             // 2 = four waves x 512 registers, static K walk; 1 = eight waves x 256 registers; 0 = layer by layer
     {"HEAD_F16", 1},         // encoder head on the f16x3 split kernel when its input is the pooled map of the layer3 kernel
 };
 

@@ -114,5 +114,9 @@ int main() {
   run<4, 5, 3>(512, 16, "between + weights, 5 acc");
   run<4, 1, 3>(512, 16, "between + weights, 1 acc");
   run<0, 5, 3>(512, 16, "weights only, 5 acc");
+  run<4, 5, 3>(256, 16, "1 wave/SIMD: between + weights, 5 acc");
+  run<4, 1, 2>(256, 16, "1 wave/SIMD: reads between, 1 acc");
+  run<4, 2, 2>(256, 16, "1 wave/SIMD: reads between, 2 acc");
+  run<4, 1, 0>(256, 16, "1 wave/SIMD: reads in front");
   return 0;
 }
