@@ -72,6 +72,9 @@ long long* g_block3_dbg = nullptr;
 #else
 #define CHAIN_STAMP(i) do { } while (0)
 #endif
+// barrier for LDS hand-overs only: __syncthreads() carries s_waitcnt vmcnt(0) in its release fence and would wait for every
+// global load in flight (weight prefetches, the next group's input)
+#define L3_LDS_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
 // per-wave phase stamps of the layer3 kernel (debug build): [workgroup][wave 8][16], before and after every barrier
 #ifdef MAGAT_DEBUG_HOOKS
 #define L3_STAMP(i) do { if (p.dbg && (threadIdx.x & 63) == 0) p.dbg[((long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -541,12 +544,12 @@ struct W4A { static constexpr int NT = 4; static constexpr int t[4] = {T_I0, T_I
 struct W4B { static constexpr int NT = 5; static constexpr int t[5] = {T_I3, T_C, T_EB, T_EL, T_ER}; };      // 36 tile-taps
 constexpr int W4_TAPS[9] = {0x1FF, 0x1FF, 0x1FF, 0x1FF, 0x1F8, 0x03F, 0x1B6, 0x0DB, 0x1FF};     // = TILE_TAPS, host-visible
 template <int NMAX> struct W4Seq { W4Item it[NMAX]; int n, nmain; };
-template <typename TL, int KS2>
-constexpr W4Seq<(36 + KS2) * TL::NT + 1> w4_seq() {
-  W4Seq<(36 + KS2) * TL::NT + 1> q{};
+template <typename TL, int KSM, int KS2>
+constexpr W4Seq<(9 * KSM + KS2) * TL::NT + 1> w4_seq() {
+  W4Seq<(9 * KSM + KS2) * TL::NT + 1> q{};
   int n = 0;
   for (int tp = 0; tp < 9; ++tp)
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KSM; ++ks) {
       bool first = true;
       for (int s = 0; s < TL::NT; ++s)
         if (W4_TAPS[TL::t[s]] >> tp & 1) {
@@ -576,12 +579,39 @@ constexpr int w4_minshift(int tile) {
   return m;
 }
 
-template <typename TL, int KS2>
+// KSM / KS2: k steps (16 channels) per tap of the main input / of the residual input; PS_IN / PS_IN2: plane strides of the two
+// LDS maps; D: weight ring (fetched D - 1 k steps ahead).
+#ifndef MAGAT_W4_D
+#define MAGAT_W4_D 4
+#endif
+#ifndef MAGAT_W4_AV
+#define MAGAT_W4_AV 3
+#endif
+#ifdef MAGAT_W4_NOPIN
+#define W4_PIN() do { } while (0)
+#else
+#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
+constexpr int w4_depth(int nt, int ksm) { return nt * ksm <= 8 ? 8 : MAGAT_W4_D; }    // short k steps (few MFMAs): deeper weight ring
+// first D - 1 k steps of a weight stream into the ring
+template <int NSTEP, int D>
+__device__ __forceinline__ void w4_fill(const char* wbase, u32x4 (&w)[D][2]) {
+  const unsigned lane16 = (threadIdx.x & 63u) * 16u;
+#pragma unroll
+  for (int j = 0; j < D - 1; ++j)
+    if (j < NSTEP) {
+      w[j][0] = *reinterpret_cast<const u32x4*>(wbase + (size_t)j * 2048 + lane16);
+      w[j][1] = *reinterpret_cast<const u32x4*>(wbase + (size_t)j * 2048 + (lane16 + 1024u));
+    }
+}
+// (Filling the ring one stage ahead - before the previous stage's epilogue and an LDS-only barrier - was measured and is
+//  slower: chain 608-624 -> 659 us, layer3 1.50-1.52 -> 1.53 ms same-box; the rings of two stages then overlap in registers.)
+template <typename TL, int KSM, int KS2, int PS_IN, int PS_IN2, int D>
 __device__ __forceinline__ void walk4(char* lds, int in_off, int in2_off, const char* wbase, f32x16 (&acc)[TL::NT], bool with_res) {
-  constexpr int NT = TL::NT, D = 4;
-  constexpr int PS_IN = 8 * BLK, PS_IN2 = 8 * BLK;             // both inputs are 64-channel maps
-  constexpr auto SQ = w4_seq<TL, KS2>();
-  constexpr int NSTEP = 36 + KS2;
+  u32x4 w[D][2];
+  constexpr int NT = TL::NT;
+  constexpr auto SQ = w4_seq<TL, KSM, KS2>();
+  constexpr int NMAIN = 9 * KSM, NSTEP = NMAIN + KS2;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));        // (keeps the address set-up inside the caller's loop over the halves)
   const int lane = tid & 63;
@@ -606,12 +636,12 @@ __device__ __forceinline__ void walk4(char* lds, int in_off, int in2_off, const 
     }
   }
   const unsigned az = (unsigned)(ZPIX * PIXB + agent * 16 + fh * BLK + in_off);
-  u32x4 w[D][2];
   auto load_w = [&](int step, u32x4 (&b)[2]) {
     b[0] = *reinterpret_cast<const u32x4*>(wbase + (size_t)step * 2048 + lane16);
     b[1] = *reinterpret_cast<const u32x4*>(wbase + (size_t)step * 2048 + (lane16 + 1024u));
   };
-  u32x4 av[3][2];
+  constexpr int AV = MAGAT_W4_AV;         // operand ring: reads run AV - 1 items ahead of the MFMAs
+  u32x4 av[AV][2];
   auto rd = [&](const W4Item it, int pl, u32x4& dst) {
     const int tile = TL::t[it.s];
     if (it.tp == 9) {                                    // residual: the block input at the same pixel
@@ -625,38 +655,35 @@ __device__ __forceinline__ void walk4(char* lds, int in_off, int in2_off, const 
       dst = *reinterpret_cast<const u32x4*>(lds + b0[it.s] + (sh * PIXB + pl * PS_IN + it.ks * 2 * BLK));
     }
   };
+  w4_fill<NSTEP, D>(wbase, w);
 #pragma unroll
-  for (int j = 0; j < D - 1; ++j) load_w(j, w[j]);
-  rd(SQ.it[0], 0, av[0][0]);
-  rd(SQ.it[0], 1, av[0][1]);
-  rd(SQ.it[1], 0, av[1][0]);
-  rd(SQ.it[1], 1, av[1][1]);
-  const int nrun = with_res ? SQ.n : SQ.nmain;
-  const int nstep = with_res ? NSTEP : 36;
+  for (int j = 0; j < AV - 1; ++j) {
+    rd(SQ.it[j], 0, av[j][0]);
+    rd(SQ.it[j], 1, av[j][1]);
+  }
 #pragma clang loop unroll(full)
   for (int i = 0; i < SQ.n; ++i) {
-    constexpr int dummy = 0; (void)dummy;
     const W4Item it = SQ.it[i];
     if (KS2 > 0 && i == SQ.nmain && !with_res) break;            // (uniform; the first half of conv2 has no residual)
-    const int step = it.tp * 4 + it.ks;
+    const int step = it.tp * KSM + it.ks;              // (residual items: tp = 9)
     if (it.first && step + D - 1 < NSTEP) {
-      if (step + D - 1 < 36 || with_res) load_w(step + D - 1, w[(step + D - 1) % D]);
+      if (step + D - 1 < NMAIN || with_res) load_w(step + D - 1, w[(step + D - 1) % D]);
     }
-    const bool more = i + 2 < SQ.n;
-    const bool more_ok = more && (i + 2 < SQ.nmain || with_res);
+    constexpr int LA = AV - 1;
+    const bool more = i + LA < SQ.n;
+    const bool more_ok = more && (i + LA < SQ.nmain || with_res);
     acc[it.s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[step % D][0]),
-                                                       __builtin_bit_cast(f16x8, av[i % 3][0]), acc[it.s], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) { if (more_ok) rd(SQ.it[more ? i + 2 : i], 0, av[(i + 2) % 3][0]); __builtin_amdgcn_sched_barrier(0); }
+                                                       __builtin_bit_cast(f16x8, av[i % AV][0]), acc[it.s], 0, 0, 0);
+    W4_PIN();
+    if (more) { if (more_ok) rd(SQ.it[more ? i + LA : i], 0, av[(i + LA) % AV][0]); W4_PIN(); }
     acc[it.s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[step % D][1]),
-                                                       __builtin_bit_cast(f16x8, av[i % 3][0]), acc[it.s], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) { if (more_ok) rd(SQ.it[more ? i + 2 : i], 1, av[(i + 2) % 3][1]); __builtin_amdgcn_sched_barrier(0); }
+                                                       __builtin_bit_cast(f16x8, av[i % AV][0]), acc[it.s], 0, 0, 0);
+    W4_PIN();
+    if (more) { if (more_ok) rd(SQ.it[more ? i + LA : i], 1, av[(i + LA) % AV][1]); W4_PIN(); }
     acc[it.s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[step % D][0]),
-                                                       __builtin_bit_cast(f16x8, av[i % 3][1]), acc[it.s], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+                                                       __builtin_bit_cast(f16x8, av[i % AV][1]), acc[it.s], 0, 0, 0);
+    W4_PIN();
   }
-  (void)nrun; (void)nstep;
 }
 
 __global__ __launch_bounds__(256, 1) void block3_w4_kernel(const L3Params p) {
@@ -666,6 +693,7 @@ __global__ __launch_bounds__(256, 1) void block3_w4_kernel(const L3Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int group = blockIdx.x;
   if (group >= p.groups) return;
+  L3_STAMP(0);
   for (int i = t; i < 32 * (PIXB / 4); i += 256)
     *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
   {   // input map: 16 (plane, chunk) blocks x 36 pixels x 128 B of this agent group
@@ -692,16 +720,18 @@ __global__ __launch_bounds__(256, 1) void block3_w4_kernel(const L3Params p) {
   constexpr int BPT1 = 9 * 4 * 2, BPT2A = 9 * 4 * 2, BPT2B = (9 * 4 + 4) * 2;      // 1 KB blocks per channel tile
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  L3_STAMP(1);
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     const char* w1 = p.w1 + (size_t)(2 * h + ct1) * BPT1 * 1024;
+    const char* w2 = h == 0 ? p.w2a + (size_t)ct2 * BPT2A * 1024 : p.w2b + (size_t)ct2 * BPT2B * 1024;
     if (rg1 == 0) {
       f32x16 a1[W4A::NT];
 #pragma unroll
       for (int s = 0; s < W4A::NT; ++s)
 #pragma unroll
         for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
-      walk4<W4A, 0>(lds, L_IN, 0, w1, a1, false);
+      walk4<W4A, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1, a1, false);
       const int tl[W4A::NT] = {W4A::t[0], W4A::t[1], W4A::t[2], W4A::t[3]};
       epi_to_lds<64, W4A::NT>(lds, L_MID, tl, a1, ct1, p.b1 + 64 * h, s1, rows_ok, clamped);
     } else {
@@ -710,14 +740,18 @@ __global__ __launch_bounds__(256, 1) void block3_w4_kernel(const L3Params p) {
       for (int s = 0; s < W4B::NT; ++s)
 #pragma unroll
         for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
-      walk4<W4B, 0>(lds, L_IN, 0, w1, a1, false);
+      walk4<W4B, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1, a1, false);
       const int tl[W4B::NT] = {W4B::t[0], W4B::t[1], W4B::t[2], W4B::t[3], W4B::t[4]};
       epi_to_lds<64, W4B::NT>(lds, L_MID, tl, a1, ct1, p.b1 + 64 * h, s1, rows_ok, clamped);
     }
+    L3_STAMP(2 + 4 * h);
     __syncthreads();
+    L3_STAMP(3 + 4 * h);
     // conv2: K over these 64 intermediate channels (second half: + the residual 1x1 over the 64 input channels)
-    walk4<W4All, 4>(lds, L_MID, L_IN, (h == 0 ? p.w2a + (size_t)ct2 * BPT2A * 1024 : p.w2b + (size_t)ct2 * BPT2B * 1024), acc, h == 1);
+    walk4<W4All, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_MID, L_IN, w2, acc, h == 1);
+    L3_STAMP(4 + 4 * h);
     __syncthreads();          // MID is rewritten by the next half / becomes scratch
+    L3_STAMP(5 + 4 * h);
   }
   // ReLU'd output -> LDS scratch [pixel][agent][128 floats] (quads XOR-swizzled by the row), then the 2x2 sums
   float* S = reinterpret_cast<float*>(lds);
@@ -755,6 +789,7 @@ __global__ __launch_bounds__(256, 1) void block3_w4_kernel(const L3Params p) {
     if (m < p.M)
       *reinterpret_cast<f32x4*>(p.out + ((long long)(m >> 7) * 9 + cell) * (128 * 128) + (m & 127) * 128 + 4 * Q) = sum;
   }
+  L3_STAMP(10);
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
@@ -811,6 +846,138 @@ __global__ __launch_bounds__(512, 2) void block_chain_kernel(const ChainParams p
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
+// ---- the chain kernel in the four-wave form (see walk4): stage A = one channel tile, the nine row tiles dealt to the four
+// waves; stages B and C = (channel tile, one of two row-tile groups) per wave
+struct W4P0 { static constexpr int NT = 2; static constexpr int t[2] = {T_I0, T_I1}; };
+struct W4P1 { static constexpr int NT = 2; static constexpr int t[2] = {T_I2, T_I3}; };
+struct W4P2 { static constexpr int NT = 2; static constexpr int t[2] = {T_C, T_ET}; };
+struct W4P3 { static constexpr int NT = 3; static constexpr int t[3] = {T_EB, T_EL, T_ER}; };
+
+template <typename TL, int CIN, int C2, int COUT, bool LAST>
+__device__ __forceinline__ void chain_stage4(const ChainParams& p, char* lds, int in_off, int in2_off, int out_off,
+                                             const char* wts, int ct, const float* bias, float scale, int group, bool& clamped) {
+  constexpr int KSM = CIN / 16, KS2 = C2 / 16, NT = TL::NT;
+  constexpr int BPT = (9 * KSM + KS2) * 2;                  // 1 KB weight blocks per channel tile
+  constexpr int PS_OUT = (COUT / 8) * BLK;
+  const int lane = threadIdx.x & 63;
+  const int fr = lane & 31, fh = lane >> 5, agent = fr & 7, psl = fr >> 3;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int s = 0; s < NT; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  walk4<TL, KSM, KS2, (CIN / 8) * BLK, (C2 > 0 ? C2 / 8 : 1) * BLK, w4_depth(NT, KSM)>(
+      lds, in_off, in2_off, wts + (size_t)ct * BPT * 1024, acc, true);
+  // epilogue: as chain_stage
+  f32x4 bq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bias + 32 * ct + 8 * q + 4 * fh);
+  const int m = group * AG + agent;
+  const bool mok = m < p.M;
+#pragma unroll
+  for (int s = 0; s < NT; ++s) {
+    const int pix = TILE_PIX[TL::t[s]][psl];
+    if (LAST && p.out_gl == 0) {         // float32 row-major agent tiles [tile][pixel][128][COUT]
+      if (mok) {
+        float* orow = reinterpret_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +
+                      magat_row_off(m, COUT, p.out_tile) + 32 * ct + 4 * fh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * scale + bq[q][c], 0.f);
+          *reinterpret_cast<f32x4*>(orow + 8 * q) = v;
+        }
+      }
+      continue;
+    }
+    bool cl = false;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      unsigned h1[4], h2[4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int q = 2 * ks + e;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * scale + bq[q][c], 0.f);
+        split2(v[0], v[1], h1[2 * e], h2[2 * e], cl);
+        split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1], cl);
+      }
+      const int chunk = (ct * 2 + ks) * 2 + fh;
+      if (LAST) {
+        if (mok) {
+          char* o = p.out + ((long long)pix * p.out_pix_stride + (long long)(m >> 7) * p.out_tile) * 4 + (m & 127) * 16 +
+                    (long long)chunk * 2048;
+          *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+          *reinterpret_cast<u32x4*>(o + 256 * COUT) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+        }
+      } else {
+        char* o = lds + out_off + chunk * BLK + pix * PIXB + agent * 16;
+        *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+        *reinterpret_cast<u32x4*>(o + PS_OUT) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+      }
+    }
+    clamped |= cl && mok;
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void block_chain_w4_kernel(const ChainParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  for (int i = t; i < 32 * (PIXB / 4); i += 256)
+    *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
+  auto dma_map = [&](const char* base, int group, int lds_off) {
+    const int m0 = group * AG;
+    const long long tile_b = (long long)(m0 >> 7) * NPIX * (128 * 32 * 4) + (m0 & 127) * 16;    // bytes: agent tile, agents
+    for (int item = wave; item < 8 * 5; item += 4) {
+      const int blk = item / 5, part = item % 5;             // blk = plane * 4 + chunk
+      const int pix = part * 8 + (lane >> 3);
+      const char* src = base + tile_b + (long long)pix * (128 * 32 * 4) + (blk >> 2) * (256 * 32) + (blk & 3) * 2048 +
+                        (lane & 7) * 16;
+      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(lds_off + blk * BLK + part * 8 * PIXB));
+      if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+    }
+  };
+  const float sA = *p.sA, sB = *p.sB, sC = *p.sC;
+  bool clamped = false;
+  const int ct = wave & 1, rg = wave >> 1;
+  int group = blockIdx.x;
+  if (group < p.groups) dma_map(p.in1, group, LDS_X1N);
+  for (; group < p.groups; group += (int)gridDim.x) {
+    const bool more = group + (int)gridDim.x < p.groups;
+    CHAIN_STAMP(0);
+    __syncthreads();            // every wave is done reading the previous group's maps (and the zero pixels are written)
+    dma_map(p.in2, group, LDS_X2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this group's main input (issued an iteration ago) + the residual input
+    __syncthreads();
+    CHAIN_STAMP(1);
+    // A: layer1.conv2 (32 -> 32) + downsample(stem stride-2 pixels)      X1 (prefetch region), X2 -> Y
+    switch (wave) {
+      case 0: chain_stage4<W4P0, 32, 32, 32, false>(p, lds, LDS_X1N, LDS_X2, LDS_Y, p.wA, 0, p.bA, sA, group, clamped); break;
+      case 1: chain_stage4<W4P1, 32, 32, 32, false>(p, lds, LDS_X1N, LDS_X2, LDS_Y, p.wA, 0, p.bA, sA, group, clamped); break;
+      case 2: chain_stage4<W4P2, 32, 32, 32, false>(p, lds, LDS_X1N, LDS_X2, LDS_Y, p.wA, 0, p.bA, sA, group, clamped); break;
+      default: chain_stage4<W4P3, 32, 32, 32, false>(p, lds, LDS_X1N, LDS_X2, LDS_Y, p.wA, 0, p.bA, sA, group, clamped); break;
+    }
+    CHAIN_STAMP(2);
+    __syncthreads();
+    CHAIN_STAMP(3);
+    if (more) dma_map(p.in1, group + (int)gridDim.x, LDS_X1N);      // lands under stages B and C
+    // B: layer2.conv1 (32 -> 64)                                          Y -> Z
+    if (rg == 0) chain_stage4<W4A, 32, 0, 64, false>(p, lds, LDS_Y, 0, LDS_Z, p.wB, ct, p.bB, sB, group, clamped);
+    else chain_stage4<W4B, 32, 0, 64, false>(p, lds, LDS_Y, 0, LDS_Z, p.wB, ct, p.bB, sB, group, clamped);
+    CHAIN_STAMP(4);
+    __syncthreads();
+    CHAIN_STAMP(5);
+    // C: layer2.conv2 (64 -> 64) + downsample(Y)                          Z, Y -> global
+    if (rg == 0) chain_stage4<W4A, 64, 32, 64, true>(p, lds, LDS_Z, LDS_Y, 0, p.wC, ct, p.bC, sC, group, clamped);
+    else chain_stage4<W4B, 64, 32, 64, true>(p, lds, LDS_Z, LDS_Y, 0, p.wC, ct, p.bC, sC, group, clamped);
+    CHAIN_STAMP(6);
+  }
+  if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
+}
+
 }  // namespace
 
 // bytes of one stage's fragment-major weight block (without the trailing scale float)
@@ -846,7 +1013,10 @@ int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, l
 #ifdef MAGAT_DEBUG_HOOKS
   p.dbg = g_chain_dbg;
 #endif
-  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block_chain_kernel), MAGAT_LDS_BLOCK_A, LDS_TOTAL) != MAGAT_OK)
+  const bool w4 = magat_opt(MAGAT_OPT_BLOCK_FUSED) >= 2;       // 2: four waves x 512 registers; 1: eight waves x 256
+  if (magat_ensure_dyn_lds(w4 ? reinterpret_cast<const void*>(&block_chain_w4_kernel)
+                              : reinterpret_cast<const void*>(&block_chain_kernel),
+                           w4 ? MAGAT_LDS_BLOCK_B4 : MAGAT_LDS_BLOCK_A, LDS_TOTAL) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -855,7 +1025,8 @@ int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, l
   }
   const int grid = p.groups < cus ? p.groups : cus;
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_CHAIN, st);
-  hipLaunchKernelGGL(block_chain_kernel, dim3((unsigned)grid), dim3(512), LDS_TOTAL, st, p);
+  if (w4) hipLaunchKernelGGL(block_chain_w4_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, p);
+  else hipLaunchKernelGGL(block_chain_kernel, dim3((unsigned)grid), dim3(512), LDS_TOTAL, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
