@@ -691,15 +691,15 @@ __global__ __launch_bounds__(256, 1) void block3_w4_kernel(const L3Params p) {
   constexpr int L_IN = 0, L_MID = MAP64;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int group = blockIdx.x;
-  if (group >= p.groups) return;
-  L3_STAMP(0);
+  L3_STAMP(11);
   for (int i = t; i < 32 * (PIXB / 4); i += 256)
     *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
-  {   // input map: 16 (plane, chunk) blocks x 36 pixels x 128 B of this agent group
+  // input map: 16 (plane, chunk) blocks x 36 pixels x 128 B of an agent group = 80 LDS-direct instructions (an expensive
+  // instruction to issue, ~150 cycles each): items first, first + step, ... < last
+  auto dma_in = [&](int group, int first, int step, int last) {
     const int m0 = group * AG;
     const long long tile_b = (long long)(m0 >> 7) * NPIX * (128 * 64 * 4) + (m0 & 127) * 16;
-    for (int item = wave; item < 16 * 5; item += 4) {
+    for (int item = first; item < last; item += step) {
       const int blk = item / 5, part = item % 5;             // blk = plane * 8 + chunk
       const int pix = part * 8 + (lane >> 3);
       const char* src = p.in + tile_b + (long long)pix * (128 * 64 * 4) + (blk >> 3) * (256 * 64) + (blk & 7) * 2048 +
@@ -707,89 +707,119 @@ __global__ __launch_bounds__(256, 1) void block3_w4_kernel(const L3Params p) {
       const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(L_IN + blk * BLK + part * 8 * PIXB));
       if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
     }
-  }
+  };
   const float s1 = *p.s1, s2 = *p.s2;
   bool clamped = false;
-  const bool rows_ok = group * AG + ((lane & 31) & 7) < p.M;
   const int ct1 = wave & 1, rg1 = wave >> 1, ct2 = wave;
-  f32x16 acc[9];
-#pragma unroll
-  for (int s = 0; s < 9; ++s)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
   constexpr int BPT1 = 9 * 4 * 2, BPT2A = 9 * 4 * 2, BPT2B = (9 * 4 + 4) * 2;      // 1 KB blocks per channel tile
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  L3_STAMP(1);
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    const char* w1 = p.w1 + (size_t)(2 * h + ct1) * BPT1 * 1024;
-    const char* w2 = h == 0 ? p.w2a + (size_t)ct2 * BPT2A * 1024 : p.w2b + (size_t)ct2 * BPT2B * 1024;
-    if (rg1 == 0) {
-      f32x16 a1[W4A::NT];
-#pragma unroll
-      for (int s = 0; s < W4A::NT; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
-      walk4<W4A, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1, a1, false);
-      const int tl[W4A::NT] = {W4A::t[0], W4A::t[1], W4A::t[2], W4A::t[3]};
-      epi_to_lds<64, W4A::NT>(lds, L_MID, tl, a1, ct1, p.b1 + 64 * h, s1, rows_ok, clamped);
-    } else {
-      f32x16 a1[W4B::NT];
-#pragma unroll
-      for (int s = 0; s < W4B::NT; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
-      walk4<W4B, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1, a1, false);
-      const int tl[W4B::NT] = {W4B::t[0], W4B::t[1], W4B::t[2], W4B::t[3], W4B::t[4]};
-      epi_to_lds<64, W4B::NT>(lds, L_MID, tl, a1, ct1, p.b1 + 64 * h, s1, rows_ok, clamped);
-    }
-    L3_STAMP(2 + 4 * h);
-    __syncthreads();
-    L3_STAMP(3 + 4 * h);
-    // conv2: K over these 64 intermediate channels (second half: + the residual 1x1 over the 64 input channels)
-    walk4<W4All, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_MID, L_IN, w2, acc, h == 1);
-    L3_STAMP(4 + 4 * h);
-    __syncthreads();          // MID is rewritten by the next half / becomes scratch
-    L3_STAMP(5 + 4 * h);
-  }
-  // ReLU'd output -> LDS scratch [pixel][agent][128 floats] (quads XOR-swizzled by the row), then the 2x2 sums
-  float* S = reinterpret_cast<float*>(lds);
+#ifdef MAGAT_B3W4_ONESHOT
+  const int gstride = 1 << 30;
+#else
+  const int gstride = (int)gridDim.x;       // PERSISTENT: the next group's input streams in under the output phase
+#endif
+  // conv2's bias: loaded once (a load issued behind the 76 KB input DMA of the output phase would wait for it to land)
+  f32x4 bq[4];
   {
-    const int fr = lane & 31, fh = lane >> 5, agent = fr & 7, psl = fr >> 3;
-    f32x4 bq[4];
+    const int fh = lane >> 5;
 #pragma unroll
     for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(p.b2 + 32 * ct2 + 8 * q + 4 * fh);
+  }
+  if ((int)blockIdx.x < p.groups) dma_in(blockIdx.x, wave, 4, 80);
+#pragma unroll 1
+  for (int group = blockIdx.x; group < p.groups; group += gstride) {
+    const bool rows_ok = group * AG + ((lane & 31) & 7) < p.M;
+    f32x16 acc[9];
 #pragma unroll
-    for (int s = 0; s < 9; ++s) {
-      const int pix = TILE_PIX[W4All::t[s]][psl];
-      const int row = pix * AG + agent;
+    for (int s = 0; s < 9; ++s)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 v;
+      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+    L3_STAMP(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    L3_STAMP(1);
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      const char* w1 = p.w1 + (size_t)(2 * h + ct1) * BPT1 * 1024;
+      const char* w2 = h == 0 ? p.w2a + (size_t)ct2 * BPT2A * 1024 : p.w2b + (size_t)ct2 * BPT2B * 1024;
+      if (rg1 == 0) {
+        f32x16 a1[W4A::NT];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * s2 + bq[q][c], 0.f);
-        const int Q = 8 * ct2 + 2 * q + fh;
-        *reinterpret_cast<f32x4*>(S + row * 128 + ((Q ^ (row & 31)) << 2)) = v;
+        for (int s = 0; s < W4A::NT; ++s)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
+        walk4<W4A, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1, a1, false);
+        const int tl[W4A::NT] = {W4A::t[0], W4A::t[1], W4A::t[2], W4A::t[3]};
+        epi_to_lds<64, W4A::NT>(lds, L_MID, tl, a1, ct1, p.b1 + 64 * h, s1, rows_ok, clamped);
+      } else {
+        f32x16 a1[W4B::NT];
+#pragma unroll
+        for (int s = 0; s < W4B::NT; ++s)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
+        walk4<W4B, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1, a1, false);
+        const int tl[W4B::NT] = {W4B::t[0], W4B::t[1], W4B::t[2], W4B::t[3], W4B::t[4]};
+        epi_to_lds<64, W4B::NT>(lds, L_MID, tl, a1, ct1, p.b1 + 64 * h, s1, rows_ok, clamped);
       }
+      L3_STAMP(2 + 4 * h);
+      __syncthreads();
+      L3_STAMP(3 + 4 * h);
+      // conv2: K over these 64 intermediate channels (second half: + the residual 1x1 over the 64 input channels)
+      walk4<W4All, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_MID, L_IN, w2, acc, h == 1);
+      L3_STAMP(4 + 4 * h);
+      __syncthreads();          // MID is rewritten by the next half / becomes scratch; after the second half IN is dead too
+      L3_STAMP(5 + 4 * h);
     }
-  }
-  __syncthreads();
-  for (int o = t; o < 9 * AG * 32; o += 256) {
-    const int Q = o & 31, agent = (o >> 5) & 7, cell = o >> 8;
-    const int cy = cell / 3, cx = cell - 3 * cy;
-    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    const bool more = group + gstride < p.groups;
+    // ReLU'd output, 64 channels per pass (waves 0-1, then 2-3) -> scratch in the MID region [pixel][agent][64 floats] (quads
+    // XOR-swizzled by the row), then the 2x2 sums.  LDS-only barriers: __syncthreads() would wait for the DMA in flight.
+    float* S = reinterpret_cast<float*>(lds + L_MID);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      if ((ct2 >> 1) != half) {
+        // the two waves with nothing to write in this pass request half of the NEXT group's input instead
+        if (more) dma_in(group + gstride, 40 * half + (wave & 1), 2, 40 * half + 40);
+      } else {
+        const int fr = lane & 31, fh = lane >> 5, agent = fr & 7, psl = fr >> 3;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int pix = (2 * cy + (e >> 1)) * 6 + 2 * cx + (e & 1);
-      const int row = pix * AG + agent;
-      sum += *reinterpret_cast<const f32x4*>(S + row * 128 + ((Q ^ (row & 31)) << 2));
+        for (int s = 0; s < 9; ++s) {
+          const int pix = TILE_PIX[W4All::t[s]][psl];
+          const int row = pix * AG + agent;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * s2 + bq[q][c], 0.f);
+            const int Q = 8 * (ct2 & 1) + 2 * q + fh;
+            *reinterpret_cast<f32x4*>(S + row * 64 + ((Q ^ (row & 15)) << 2)) = v;
+          }
+        }
+      }
+      L3_LDS_SYNC();
+      if (half == 0) L3_STAMP(13); else L3_STAMP(15);
+      for (int o = t; o < 9 * AG * 16; o += 256) {
+        const int Q = o & 15, agent = (o >> 4) & 7, cell = o >> 7;
+        const int cy = cell / 3, cx = cell - 3 * cy;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pix = (2 * cy + (e >> 1)) * 6 + 2 * cx + (e & 1);
+          const int row = pix * AG + agent;
+          sum += *reinterpret_cast<const f32x4*>(S + row * 64 + ((Q ^ (row & 15)) << 2));
+        }
+        const int m = group * AG + agent;
+        if (m < p.M)
+          *reinterpret_cast<f32x4*>(p.out + ((long long)(m >> 7) * 9 + cell) * (128 * 128) + (m & 127) * 128 + 64 * half +
+                                    4 * Q) = sum;
+      }
+      L3_LDS_SYNC();
+      if (half == 0) L3_STAMP(14);
     }
-    const int m = group * AG + agent;
-    if (m < p.M)
-      *reinterpret_cast<f32x4*>(p.out + ((long long)(m >> 7) * 9 + cell) * (128 * 128) + (m & 127) * 128 + 4 * Q) = sum;
+    // the scratch ran over the zero pixel slots of the MID blocks
+    for (int i = t; i < 16 * (PIXB / 4); i += 256)
+      *reinterpret_cast<unsigned*>(lds + L_MID + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
+    L3_STAMP(10);
   }
-  L3_STAMP(10);
+  L3_STAMP(12);
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
@@ -1061,7 +1091,19 @@ int magat_block3(const void* in, float* out, const float* w, const float* b1, co
   if (w4 && magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block3_w4_kernel), MAGAT_LDS_BLOCK_C, lds) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK3, st);
-  if (w4) hipLaunchKernelGGL(block3_w4_kernel, dim3((unsigned)p.groups), dim3(256), lds, st, p);
+  if (w4) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+#ifdef MAGAT_B3W4_ONESHOT
+    const int grid = p.groups;
+#else
+    const int grid = p.groups < cus ? p.groups : cus;
+#endif
+    hipLaunchKernelGGL(block3_w4_kernel, dim3((unsigned)grid), dim3(256), lds, st, p);
+  }
   else hipLaunchKernelGGL(block3_kernel, dim3((unsigned)p.groups), dim3(512), lds, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();

@@ -31,7 +31,7 @@ for i, n in enumerate(names):
     print("  %-30s %8.0f / %8.0f   (%.1f %%)" % (n, d[:, i].mean(), np.percentile(d[:, i], 90), 100 * d[:, i].mean() / tot.mean()))
 
 # layer3 kernel (one workgroup per agent group): per-WAVE stamps before and after every barrier
-g3 = B * N // 8
+g3 = 256               # persistent: one workgroup per CU, the stamps are those of its LAST agent group
 buf3 = torch.zeros(g3, 8, 16, dtype=torch.int64, device=dev)
 h.magat_block3_set_debug_buffer.argtypes = [ctypes.c_void_p]
 with torch.no_grad():
@@ -49,3 +49,8 @@ nw = 8 if t[:, 4:, 10].any() else 4          # the four-wave form of the kernel 
 print("  %-32s" % "phase" + "".join("   wave%d" % w for w in range(nw)))
 for i, n in enumerate(names):
     print("  %-32s" % n + "".join("%8.0f" % d[:, w, i].mean() for w in range(nw)))
+if t[:, 0, 13].any():
+    o = t[:, :4, :]
+    print("  output phase: S write 0 %.0f | pool+store 0 %.0f | S write 1 %.0f | pool+store 1 + zero fill %.0f" % (
+        (o[:, :, 13] - o[:, :, 9]).mean(), (o[:, :, 14] - o[:, :, 13]).mean(), (o[:, :, 15] - o[:, :, 14]).mean(),
+        (o[:, :, 10] - o[:, :, 15]).mean()))
