@@ -30,6 +30,7 @@ def short(name):
                    ("conv_gemm_kernel<128, 32", "conv_gemm_f32<128,32>"), ("conv_first_kernel", "conv_first"),
                    ("layer1_fused_kernel", "layer1_fused(stem+layer1.conv1)"),
                    ("block_chain_kernel", "block_chain(layer1.conv2+layer2)"), ("block3_kernel", "block3(layer3+pool)"),
+                   ("block_chain_w4_kernel", "block_chain_w4(layer1.conv2+layer2)"), ("block3_w4_kernel", "block3_w4(layer3+pool)"),
                    ("gat_guard_count_kernel", "guard_count(gat)"), ("guard_count_kernel", "guard_count(encoder)"),
                    ("gat_fused_kernel", "gat_fused_kernel"),
                    ("gat_dense_kernel", "gat_dense_kernel"), ("head_mean_relu", "head_mean_relu"),
@@ -83,7 +84,8 @@ def main():
            "guard:layer3.conv1", "guard:layer3.conv2", "guard:head", "guard:compress", "guard:count",
            "gat_maps_gemm", "guard:gat_maps", "guard:gat_count", "gat_graph", "actionsMLP"]
     ours = ("conv_gemm_kernel", "conv_gemm_bf16x6_kernel", "conv_gemm_f16x3_direct_kernel", "conv_first_kernel",
-            "layer1_fused_kernel", "gat_dense_kernel", "block_chain_kernel", "block3_kernel", "guard_count_kernel",
+            "layer1_fused_kernel", "gat_dense_kernel", "block_chain_kernel", "block3_kernel", "block_chain_w4_kernel",
+            "block3_w4_kernel", "guard_count_kernel",
             "gat_fused_kernel")
     layers = defaultdict(dict)
     tr = find(os.path.join(out, "trace"), "*kernel_trace.csv")
