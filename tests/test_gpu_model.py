@@ -431,3 +431,28 @@ def test_unusual_inputs_behave_like_the_reference(gpu_device):
             net(torch.zeros(2, 10, 3, 9, 9, device=gpu_device))
         with pytest.raises(AssertionError):
             net.addGSO(torch.zeros(10, 10, device=gpu_device))
+
+
+@pytest.mark.parametrize("N,B", [(13, 7), (10, 64), (100, 33), (100, 300)])
+def test_forward_is_deterministic_and_independent_of_batch_composition(gpu_device, N, B):
+    """The chain kernels keep an 8-agent group's maps in LDS, run persistent workgroups that prefetch the NEXT group's input and
+    hand maps between stages through LDS barriers: the same batch twice must give bit-identical logits (partial groups, fewer and
+    more groups than CUs), and an instance's logits must not depend on its neighbours in the batch."""
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat",
+                      device=str(gpu_device))
+    torch.manual_seed(N + B)
+    net = DecentralPlannerGATNet(cfg).to(gpu_device).eval()
+    x, S = fov_states(B, N, seed=B).to(gpu_device), comm_gso(B, N, max(8, N // 2), seed=B + 1).to(gpu_device)
+    with torch.no_grad():
+        net.addGSO(S)
+        ref = net(x).clone()
+        for _ in range(3):
+            net.addGSO(S)
+            assert torch.equal(net(x), ref)
+        for b in (0, B // 2, B - 1):
+            net.addGSO(S[b:b + 1].contiguous())
+            alone = net(x[b:b + 1].contiguous())
+            # (the encoder head changes its summation form with the agent count: float32 rounding, not bit equality)
+            assert float((alone - ref[b * N:(b + 1) * N]).abs().max()) <= 2e-5
