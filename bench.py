@@ -118,6 +118,10 @@ def kernel_work(nat, cfg, N, S_bytes, deg=None, planned=False, fused_stem=True, 
     w["layer2 (fused)"] = dict(flops=conv[(1, 1)][0] + conv[(1, 2)][0], bytes=4 * (36 * 32 + 36 * 64), arith="f16x3")
     # layer3 + ReLU + 2x2 pool in one launch: layer2's map in, the 9 pooled cells out
     w["layer3 (fused, pooled)"] = dict(flops=conv[(2, 1)][0] + conv[(2, 2)][0], bytes=4 * (36 * 64 + 9 * 128), arith="f16x3")
+    # both chain kernels as one launch: layer1.conv1's map + the stem's stride-2 pixels in, the 9 pooled cells out
+    w["layer1.conv2+layer2+layer3 (fused, pooled)"] = dict(
+        flops=conv[(0, 2)][0] + conv[(1, 1)][0] + conv[(1, 2)][0] + conv[(2, 1)][0] + conv[(2, 2)][0],
+        bytes=4 * (2 * 36 * 32 + 9 * 128), arith="f16x3")
     head_a = "f16x3" if (pooled_head and lib_opt(nat, "HEAD_F16") and conv_arith(nat, cfg, 2) == "f16x3") else "f32"
     w["head(avgpool+fc+linear)"] = dict(flops=2 * 9 * 128 * nfm, bytes=4 * ((9 if pooled_head else 36) * 128 + nfm), arith=head_a)
     w["compressMLP"] = dict(flops=2 * nfm * G, bytes=4 * (nfm + G), arith="f32")
@@ -354,7 +358,7 @@ def main():
         csr = Nk > 128 or cfg.gat_storage == "bf16"
         deg = float((S != 0).sum().item()) / (Bk * Nk) if csr else None
         work = kernel_work(nat, cfg, Nk, 4, deg, planned="gat_prepare" in kern and not csr,
-                           fused_stem="layer1.conv1" not in kern, pooled_head="layer3 (fused, pooled)" in kern)
+                           fused_stem="layer1.conv1" not in kern, pooled_head=("layer3 (fused, pooled)" in kern or "layer1.conv2+layer2+layer3 (fused, pooled)" in kern))
         if "conv_first" in kern and "layer1.conv1" not in kern and cfg.CNN_mode.startswith("ResNet"):
             kern = {("conv_first+layer1.conv1 (fused)" if k == "conv_first" else k): v for k, v in kern.items()}
         agent_steps = Bk * Nk * steps
@@ -429,7 +433,7 @@ def main():
                           "arithmetic": {a: ARITH[a][1] for a in ariths},
                           "parity": "logits within 1e-4 of the reference (gate; observed ~1e-6 with this arithmetic)",
                           "options": {k: lib_opt(nat, k) for k in ("CONV_MX", "CONV_SPLIT", "CONV_F16", "RANGE_GUARD",
-                                                                    "BLOCK_FUSED", "BLOCK3_FUSED", "GAT_FUSED_MAPS")},
+                                                                    "BLOCK_FUSED", "BLOCK3_FUSED", "BLOCK_FULL", "GAT_FUSED_MAPS")},
                           "global_batch": B * world, "agents": N, "parallelism": "instance-sharded x%d" % world}}
         if timing:
             pmc = load_pmc_traffic() if args.workload == "c3" and not args.batch else {}

@@ -53,6 +53,7 @@ const char* magat_error_string(int code);
  *   HEAD_SPLITK      largest agent count whose encoder head sums per-cell partials (0: one long-K GEMM, bit-exact resharding)
  *   BLOCK_FUSED (1), BLOCK3_FUSED (2)  BasicBlock chain kernels (maps of an 8-agent group in LDS); BLOCK3_FUSED 2 = the four-wave,
  *                    512-register form of the layer3 kernel, 1 = the eight-wave form, 0 = one launch per convolution
+ *   BLOCK_FULL  (1)  both chain kernels as ONE launch (layer2's output never leaves the CU); needs BLOCK_FUSED 2, BLOCK3_FUSED 2
  *   HEAD_F16    (1)  encoder head as f16x3 split products when its input is the layer3 kernel's pooled map (large batches)
  * Returns MAGAT_ERR_UNSUPPORTED for an unknown name. */
 int magat_set_option(const char* name, int value);
@@ -454,6 +455,7 @@ int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* 
 #define MAGAT_TAG_GSO_CSR 20      /* dense GSO -> CSR + CSC structure (magat_gso_csr_build, or the transpose inside *_csr_*) */
 #define MAGAT_TAG_GAT_CAST 21     /* float32 <-> bf16 row casts around the bf16-storage graph layer */
 #define MAGAT_TAG_BLOCK3 22       /* layer3 + ReLU + 2x2 pool in one launch (block_fused.hip) */
+#define MAGAT_TAG_BLOCK_FULL 23   /* layer1.conv2 -> layer2 -> layer3 -> pool in one launch (block_fused.hip) */
 #define MAGAT_PROF_TAGS 24
 int magat_gat_set_debug_buffer(long long* dev_buf); /* [grid][8] int64 phase timestamps of gat_dense_kernel; NULL = off */
 int magat_profile_reserve(int spans);   /* pre-create event pairs (keeps hipEventCreate out of a timed region) */

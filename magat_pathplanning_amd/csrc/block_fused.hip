@@ -883,7 +883,7 @@ struct W4P1 { static constexpr int NT = 2; static constexpr int t[2] = {T_I2, T_
 struct W4P2 { static constexpr int NT = 2; static constexpr int t[2] = {T_C, T_ET}; };
 struct W4P3 { static constexpr int NT = 3; static constexpr int t[3] = {T_EB, T_EL, T_ER}; };
 
-template <typename TL, int CIN, int C2, int COUT, bool LAST>
+template <typename TL, int CIN, int C2, int COUT, bool LAST, bool SYNC_BEFORE_EPI = false>
 __device__ __forceinline__ void chain_stage4(const ChainParams& p, char* lds, int in_off, int in2_off, int out_off,
                                              const char* wts, int ct, const float* bias, float scale, int group, bool& clamped) {
   constexpr int KSM = CIN / 16, KS2 = C2 / 16, NT = TL::NT;
@@ -898,6 +898,7 @@ __device__ __forceinline__ void chain_stage4(const ChainParams& p, char* lds, in
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
   walk4<TL, KSM, KS2, (CIN / 8) * BLK, (C2 > 0 ? C2 / 8 : 1) * BLK, w4_depth(NT, KSM)>(
       lds, in_off, in2_off, wts + (size_t)ct * BPT * 1024, acc, true);
+  if (SYNC_BEFORE_EPI) __syncthreads();       // the output overwrites a map that other waves read until their walks end
   // epilogue: as chain_stage
   f32x4 bq[4];
 #pragma unroll
@@ -1008,6 +1009,160 @@ __global__ __launch_bounds__(256, 1) void block_chain_w4_kernel(const ChainParam
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
+// ---- layer1.conv2 -> layer2 -> layer3 -> ReLU -> pool in ONE persistent four-wave kernel: layer2's output map never leaves the
+// CU (no 0.47 GB written and 0.6 GB read back per step, no input phase for layer3, no store epilogue for layer2.conv2), and
+// both inputs of the NEXT group are requested a whole layer3 ahead (the chain kernel alone waits out an HBM round trip for its
+// residual input at the top of every group).  LDS = four 37.9 KB units U0..U3; their roles alternate with the group parity:
+//   X1 @ U3', X2 @ U2'   -A->  Y @ U1'   -B->  Z @ (U2', U3')   -C->  layer3's IN @ (U0', U1')     [' = rotated by 2 on odd groups]
+//   layer3: IN (U0', U1'), MID (U2', U3'); pooled epilogue scratch in MID; meanwhile the next X1 -> U1', X2 -> U0' (= its U3'', U2'').
+struct FullParams { ChainParams c; L3Params l; };
+
+__global__ __launch_bounds__(256, 1) void block_full_w4_kernel(const FullParams q) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const ChainParams& p = q.c;
+  const L3Params& l3 = q.l;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  for (int i = t; i < 32 * (PIXB / 4); i += 256)
+    *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
+  // items first, first + step, ... < last of the 40 LDS-direct instructions of one 32-channel input map
+  auto dma_map = [&](const char* base, int group, int lds_off, int first, int step, int last) {
+    const int m0 = group * AG;
+    const long long tile_b = (long long)(m0 >> 7) * NPIX * (128 * 32 * 4) + (m0 & 127) * 16;    // bytes: agent tile, agents
+    for (int item = first; item < last; item += step) {
+      const int blk = item / 5, part = item % 5;             // blk = plane * 4 + chunk
+      const int pix = part * 8 + (lane >> 3);
+      const char* src = base + tile_b + (long long)pix * (128 * 32 * 4) + (blk >> 2) * (256 * 32) + (blk & 3) * 2048 +
+                        (lane & 7) * 16;
+      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(lds_off + blk * BLK + part * 8 * PIXB));
+      if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+    }
+  };
+  const float sA = *p.sA, sB = *p.sB, sC = *p.sC, s1 = *l3.s1, s2 = *l3.s2;
+  bool clamped = false;
+  const int ct = wave & 1, rg = wave >> 1, ct2 = wave;
+  constexpr int BPT1 = 9 * 4 * 2, BPT2A = 9 * 4 * 2, BPT2B = (9 * 4 + 4) * 2;      // 1 KB blocks per channel tile (layer3)
+  f32x4 bq[4];                      // conv2's bias (loaded once: a load behind the input DMA would wait for it)
+  {
+    const int fh = lane >> 5;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const f32x4*>(l3.b2 + 32 * ct2 + 8 * qd + 4 * fh);
+  }
+  const int gstride = (int)gridDim.x;
+  int parity = 0;
+  if ((int)blockIdx.x < p.groups) {
+    dma_map(p.in1, blockIdx.x, 3 * MAP32, wave, 4, 40);
+    dma_map(p.in2, blockIdx.x, 2 * MAP32, wave, 4, 40);
+  }
+#pragma unroll 1
+  for (int group = blockIdx.x; group < p.groups; group += gstride, parity ^= 1) {
+    const int U0 = parity ? 2 * MAP32 : 0, U1 = U0 + MAP32, U2 = parity ? 0 : 2 * MAP32, U3 = U2 + MAP32;
+    const bool rows_ok = group * AG + ((lane & 31) & 7) < p.M;
+    const bool more = group + gstride < p.groups;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this group's inputs (requested during the previous group's epilogue)
+    __syncthreads();
+    // A: layer1.conv2 (32 -> 32) + downsample(stem stride-2 pixels)      X1 @ U3, X2 @ U2 -> Y @ U1
+    switch (wave) {
+      case 0: chain_stage4<W4P0, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
+      case 1: chain_stage4<W4P1, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
+      case 2: chain_stage4<W4P2, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
+      default: chain_stage4<W4P3, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
+    }
+    __syncthreads();
+    // B: layer2.conv1 (32 -> 64)                                          Y @ U1 -> Z @ (U2, U3)
+    if (rg == 0) chain_stage4<W4A, 32, 0, 64, false>(p, lds, U1, 0, U2, p.wB, ct, p.bB, sB, group, clamped);
+    else chain_stage4<W4B, 32, 0, 64, false>(p, lds, U1, 0, U2, p.wB, ct, p.bB, sB, group, clamped);
+    __syncthreads();
+    // C: layer2.conv2 (64 -> 64) + downsample(Y)                          Z @ (U2, U3), Y @ U1 -> layer3's input @ (U0, U1)
+    if (rg == 0) chain_stage4<W4A, 64, 32, 64, false, true>(p, lds, U2, U1, U0, p.wC, ct, p.bC, sC, group, clamped);
+    else chain_stage4<W4B, 64, 32, 64, false, true>(p, lds, U2, U1, U0, p.wC, ct, p.bC, sC, group, clamped);
+    __syncthreads();
+    // layer3: IN = (U0, U1), MID = (U2, U3)
+    const int L_IN = U0, L_MID = U2;
+    const int ct1 = ct, rg1 = rg;
+    f32x16 acc[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      const char* w1 = l3.w1 + (size_t)(2 * h + ct1) * BPT1 * 1024;
+      const char* w2 = h == 0 ? l3.w2a + (size_t)ct2 * BPT2A * 1024 : l3.w2b + (size_t)ct2 * BPT2B * 1024;
+      if (rg1 == 0) {
+        f32x16 a1[W4A::NT];
+#pragma unroll
+        for (int s = 0; s < W4A::NT; ++s)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
+        walk4<W4A, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1, a1, false);
+        const int tl[W4A::NT] = {W4A::t[0], W4A::t[1], W4A::t[2], W4A::t[3]};
+        epi_to_lds<64, W4A::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
+      } else {
+        f32x16 a1[W4B::NT];
+#pragma unroll
+        for (int s = 0; s < W4B::NT; ++s)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
+        walk4<W4B, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1, a1, false);
+        const int tl[W4B::NT] = {W4B::t[0], W4B::t[1], W4B::t[2], W4B::t[3], W4B::t[4]};
+        epi_to_lds<64, W4B::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
+      }
+      __syncthreads();
+      walk4<W4All, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_MID, L_IN, w2, acc, h == 1);
+      __syncthreads();          // MID is rewritten by the next half / becomes scratch; after the second half IN is dead too
+    }
+    // pooled epilogue, 64 channels per pass in the MID region; the two waves with nothing to write in a pass request the NEXT
+    // group's inputs into the dead IN region: X1 -> U1 (its U3 after the rotation), X2 -> U0 (its U2)
+    float* S = reinterpret_cast<float*>(lds + L_MID);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      if ((ct2 >> 1) != half) {
+        if (more) {
+          if (half == 0) dma_map(p.in1, group + gstride, U1, wave & 1, 2, 40);
+          else dma_map(p.in2, group + gstride, U0, wave & 1, 2, 40);
+        }
+      } else {
+        const int fr = lane & 31, fh = lane >> 5, agent = fr & 7, psl = fr >> 3;
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+          const int pix = TILE_PIX[W4All::t[s]][psl];
+          const int row = pix * AG + agent;
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * qd + c] * s2 + bq[qd][c], 0.f);
+            const int Q = 8 * (ct2 & 1) + 2 * qd + fh;
+            *reinterpret_cast<f32x4*>(S + row * 64 + ((Q ^ (row & 15)) << 2)) = v;
+          }
+        }
+      }
+      L3_LDS_SYNC();
+      for (int o = t; o < 9 * AG * 16; o += 256) {
+        const int Q = o & 15, agent = (o >> 4) & 7, cell = o >> 7;
+        const int cy = cell / 3, cx = cell - 3 * cy;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pix = (2 * cy + (e >> 1)) * 6 + 2 * cx + (e & 1);
+          const int row = pix * AG + agent;
+          sum += *reinterpret_cast<const f32x4*>(S + row * 64 + ((Q ^ (row & 15)) << 2));
+        }
+        const int m = group * AG + agent;
+        if (m < p.M)
+          *reinterpret_cast<f32x4*>(l3.out + ((long long)(m >> 7) * 9 + cell) * (128 * 128) + (m & 127) * 128 + 64 * half +
+                                    4 * Q) = sum;
+      }
+      L3_LDS_SYNC();
+    }
+    // the scratch ran over the zero pixel slots of the MID blocks
+    for (int i = t; i < 16 * (PIXB / 4); i += 256)
+      *reinterpret_cast<unsigned*>(lds + L_MID + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
+  }
+  if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
+}
+
 }  // namespace
 
 // bytes of one stage's fragment-major weight block (without the trailing scale float)
@@ -1113,3 +1268,48 @@ int magat_block3(const void* in, float* out, const float* w, const float* b1, co
 extern "C" int magat_chain_set_debug_buffer(long long* dev_buf) { g_chain_dbg = dev_buf; return MAGAT_OK; }
 extern "C" int magat_block3_set_debug_buffer(long long* dev_buf) { g_block3_dbg = dev_buf; return MAGAT_OK; }
 #endif
+
+// layer1.conv2 -> layer2 -> layer3 -> pool as ONE launch (block_full_w4_kernel).  Arguments: those of magat_block_chain (without
+// its output) and of magat_block3 (without its input).
+int magat_block_full(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
+                     float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st) {
+  if (!in1 || !in2 || !wchain || !bA || !bB || !bC || !out || !w3 || !b1 || !b2) return MAGAT_ERR_NULL;
+  if (M <= 0) return MAGAT_ERR_BAD_SHAPE;
+  FullParams q;
+  ChainParams& p = q.c;
+  p.in1 = static_cast<const char*>(in1); p.in2 = static_cast<const char*>(in2); p.out = nullptr;
+  p.out_gl = 2; p.out_pix_stride = 0; p.out_tile = 0;
+  const char* wb = reinterpret_cast<const char*>(wchain);
+  const size_t nA = chain_block_bytes(32, 32, 32), nB = chain_block_bytes(32, 0, 64), nC = chain_block_bytes(64, 32, 64);
+  p.wA = wb; p.wB = wb + nA + 16; p.wC = wb + nA + 16 + nB + 16;
+  p.bA = bA; p.bB = bB; p.bC = bC;
+  p.sA = reinterpret_cast<const float*>(p.wA + nA);
+  p.sB = reinterpret_cast<const float*>(p.wB + nB);
+  p.sC = reinterpret_cast<const float*>(p.wC + nC);
+  p.M = M; p.groups = (M + AG - 1) / AG;
+  p.range_flag = range_flag;
+  p.dbg = nullptr;
+  L3Params& l = q.l;
+  l.in = nullptr; l.out = out;
+  const char* w3b = reinterpret_cast<const char*>(w3);
+  const size_t n1 = (size_t)4 * 72 * 1024, n2a = (size_t)4 * 72 * 1024, n2b = (size_t)4 * 80 * 1024;
+  l.w1 = w3b; l.w2a = w3b + n1 + 16; l.w2b = w3b + n1 + 16 + n2a + 16;
+  l.s1 = reinterpret_cast<const float*>(l.w1 + n1);
+  l.s2 = reinterpret_cast<const float*>(l.w2b + n2b);
+  l.b1 = b1; l.b2 = b2;
+  l.M = M; l.groups = p.groups;
+  l.range_flag = range_flag;
+  l.dbg = nullptr;
+  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block_full_w4_kernel), MAGAT_LDS_BLOCK_FULL, LDS_TOTAL) != MAGAT_OK)
+    return MAGAT_ERR_LAUNCH;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const int grid = p.groups < cus ? p.groups : cus;
+  const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_FULL, st);
+  hipLaunchKernelGGL(block_full_w4_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
+}

@@ -368,7 +368,14 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // BasicBlock chain kernel (block_fused.hip): layer1.conv2+downsample -> layer2.conv1 -> layer2.conv2+downsample in one
     // launch with the 6x6 maps of an 8-agent group in LDS (3.35 GB of HBM traffic per 51 200 agents become 0.94 GB).
     // Needs the fused stem's plane-granule outputs; option BLOCK_FUSED=0 keeps the layer-by-layer kernels.
-    if (fused1 && !mx && d->chain_off > 0 && Ho == 6 && Wo == 6 && nblocks >= 2 && magat_opt(MAGAT_OPT_BLOCK_FUSED)) {
+    if (fused1 && !mx && d->chain_off > 0 && Ho == 6 && Wo == 6 && nblocks == 3 && d->chain3_off > 0 &&
+        magat_opt(MAGAT_OPT_BLOCK_FUSED) >= 2 && magat_opt(MAGAT_OPT_BLOCK3_FUSED) >= 2 && magat_opt(MAGAT_OPT_BLOCK_FULL)) {
+      // both chain kernels as ONE launch: layer2's output map stays in LDS as layer3's input
+      rc = magat_block_full(buf[1], buf[0], pk + d->chain_off, pk + d->off[5], pk + d->off[7], pk + d->off[9], buf[2],
+                            pk + d->chain3_off, pk + d->off[11], pk + d->off[13], mm, reinterpret_cast<int*>(range_flag), st);
+      if (rc != MAGAT_OK) return rc;
+      cur = 2; hin = Ho; win = Wo; lstart = 3; pooled_in = true;
+    } else if (fused1 && !mx && d->chain_off > 0 && Ho == 6 && Wo == 6 && nblocks >= 2 && magat_opt(MAGAT_OPT_BLOCK_FUSED)) {
       rc = magat_block_chain(buf[1], buf[0], buf[2], nblocks == 2 ? 0 : 2, pixs(64), tiles(Ho * Wo, 64), pk + d->chain_off,
                              pk + d->off[5], pk + d->off[7], pk + d->off[9], mm, reinterpret_cast<int*>(range_flag), st);
       if (rc != MAGAT_OK) return rc;

@@ -29,6 +29,8 @@ size_t magat_layer1_fused_lds(int W);   // 0: the fused kernel does not take thi
 // BasicBlock chain kernel (block_fused.hip): layer1.conv2+ds -> layer2.conv1 -> layer2.conv2+ds on 6x6 maps, maps in LDS
 size_t magat_block_chain_weight_floats();
 size_t magat_block3_weight_floats();
+int magat_block_full(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
+                     float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st);
 int magat_block3(const void* in, float* out, const float* w, const float* b1, const float* b2, int M, int* range_flag,
                  hipStream_t st);
 int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, long long out_pix_stride, long long out_tile,
@@ -44,7 +46,7 @@ enum MagatOpt {
   MAGAT_OPT_L1_FUSED, MAGAT_OPT_HEAD_SPLITK, MAGAT_OPT_GAT_CHUNK_MB, MAGAT_OPT_GAT_ZPAD, MAGAT_OPT_GAT_SPLIT,
   MAGAT_OPT_GAT_HPB, MAGAT_OPT_GAT_ZTILES, MAGAT_OPT_GAT_PERSIST, MAGAT_OPT_RANGE_GUARD, MAGAT_OPT_BLOCK_FUSED,
   MAGAT_OPT_GAT_FUSED_MAPS, MAGAT_OPT_CSR_TILED, MAGAT_OPT_BLOCK3_FUSED,
-  MAGAT_OPT_HEAD_F16, MAGAT_OPT_COUNT
+  MAGAT_OPT_HEAD_F16, MAGAT_OPT_BLOCK_FULL, MAGAT_OPT_COUNT
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)
@@ -54,7 +56,7 @@ enum MagatLdsSlot {
   MAGAT_LDS_GAT16, MAGAT_LDS_GAT32, MAGAT_LDS_GAT64, MAGAT_LDS_GAT128, MAGAT_LDS_GAT256, MAGAT_LDS_L1FUSED,
   MAGAT_LDS_SIM_GSO_T, MAGAT_LDS_SIM_GSO_F, MAGAT_LDS_SIM_MOVE, MAGAT_LDS_BLOCK_A, MAGAT_LDS_BLOCK_B, MAGAT_LDS_BLOCK_C,
   MAGAT_LDS_GATF128, MAGAT_LDS_SIM_CONN, MAGAT_LDS_CONV_FIRST, MAGAT_LDS_CONV_FIRST11, MAGAT_LDS_GSO_STRUCT, MAGAT_LDS_CSR_TILED_A, MAGAT_LDS_CSR_TILED_B, MAGAT_LDS_CSR_TILED_A16, MAGAT_LDS_CSR_TILED_B16,
-  MAGAT_LDS_CSR_TILED_A4, MAGAT_LDS_CSR_TILED_B4, MAGAT_LDS_CSR_TILED_A16_4, MAGAT_LDS_CSR_TILED_B16_4, MAGAT_LDS_BLOCK_B4
+  MAGAT_LDS_CSR_TILED_A4, MAGAT_LDS_CSR_TILED_B4, MAGAT_LDS_CSR_TILED_A16_4, MAGAT_LDS_CSR_TILED_B16_4, MAGAT_LDS_BLOCK_B4, MAGAT_LDS_BLOCK_FULL
 };
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of
