@@ -72,6 +72,11 @@ long long* g_block3_dbg = nullptr;
 #else
 #define CHAIN_STAMP(i) do { } while (0)
 #endif
+#ifdef MAGAT_DEBUG_HOOKS
+#define FULL_STAMP(i) do { if (l3.dbg && (threadIdx.x & 63) == 0) l3.dbg[((long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define FULL_STAMP(i) do { } while (0)
+#endif
 // barrier for LDS hand-overs only: __syncthreads() carries s_waitcnt vmcnt(0) in its release fence and would wait for every
 // global load in flight (weight prefetches, the next group's input)
 #define L3_LDS_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
@@ -1059,8 +1064,10 @@ __global__ __launch_bounds__(256, 1) void block_full_w4_kernel(const FullParams 
     const int U0 = parity ? 2 * MAP32 : 0, U1 = U0 + MAP32, U2 = parity ? 0 : 2 * MAP32, U3 = U2 + MAP32;
     const bool rows_ok = group * AG + ((lane & 31) & 7) < p.M;
     const bool more = group + gstride < p.groups;
+    FULL_STAMP(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this group's inputs (requested during the previous group's epilogue)
     __syncthreads();
+    FULL_STAMP(1);
     // A: layer1.conv2 (32 -> 32) + downsample(stem stride-2 pixels)      X1 @ U3, X2 @ U2 -> Y @ U1
     switch (wave) {
       case 0: chain_stage4<W4P0, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
@@ -1069,14 +1076,17 @@ __global__ __launch_bounds__(256, 1) void block_full_w4_kernel(const FullParams 
       default: chain_stage4<W4P3, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
     }
     __syncthreads();
+    FULL_STAMP(2);
     // B: layer2.conv1 (32 -> 64)                                          Y @ U1 -> Z @ (U2, U3)
     if (rg == 0) chain_stage4<W4A, 32, 0, 64, false>(p, lds, U1, 0, U2, p.wB, ct, p.bB, sB, group, clamped);
     else chain_stage4<W4B, 32, 0, 64, false>(p, lds, U1, 0, U2, p.wB, ct, p.bB, sB, group, clamped);
     __syncthreads();
+    FULL_STAMP(3);
     // C: layer2.conv2 (64 -> 64) + downsample(Y)                          Z @ (U2, U3), Y @ U1 -> layer3's input @ (U0, U1)
     if (rg == 0) chain_stage4<W4A, 64, 32, 64, false, true>(p, lds, U2, U1, U0, p.wC, ct, p.bC, sC, group, clamped);
     else chain_stage4<W4B, 64, 32, 64, false, true>(p, lds, U2, U1, U0, p.wC, ct, p.bC, sC, group, clamped);
     __syncthreads();
+    FULL_STAMP(4);
     // layer3: IN = (U0, U1), MID = (U2, U3)
     const int L_IN = U0, L_MID = U2;
     const int ct1 = ct, rg1 = rg;
@@ -1109,8 +1119,10 @@ __global__ __launch_bounds__(256, 1) void block_full_w4_kernel(const FullParams 
         epi_to_lds<64, W4B::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
       }
       __syncthreads();
+      FULL_STAMP(5 + 2 * h);
       walk4<W4All, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_MID, L_IN, w2, acc, h == 1);
       __syncthreads();          // MID is rewritten by the next half / becomes scratch; after the second half IN is dead too
+      FULL_STAMP(6 + 2 * h);
     }
     // pooled epilogue, 64 channels per pass in the MID region; the two waves with nothing to write in a pass request the NEXT
     // group's inputs into the dead IN region: X1 -> U1 (its U3 after the rotation), X2 -> U0 (its U2)
@@ -1155,10 +1167,12 @@ __global__ __launch_bounds__(256, 1) void block_full_w4_kernel(const FullParams 
                                     4 * Q) = sum;
       }
       L3_LDS_SYNC();
+      if (half == 0) FULL_STAMP(9);
     }
     // the scratch ran over the zero pixel slots of the MID blocks
     for (int i = t; i < 16 * (PIXB / 4); i += 256)
       *reinterpret_cast<unsigned*>(lds + L_MID + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
+    FULL_STAMP(10);
   }
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
@@ -1300,6 +1314,9 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
   l.M = M; l.groups = p.groups;
   l.range_flag = range_flag;
   l.dbg = nullptr;
+#ifdef MAGAT_DEBUG_HOOKS
+  l.dbg = g_block3_dbg;
+#endif
   if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block_full_w4_kernel), MAGAT_LDS_BLOCK_FULL, LDS_TOTAL) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
   int dev = 0, cus = 256;

@@ -54,3 +54,13 @@ if t[:, 0, 13].any():
     print("  output phase: S write 0 %.0f | pool+store 0 %.0f | S write 1 %.0f | pool+store 1 + zero fill %.0f" % (
         (o[:, :, 13] - o[:, :, 9]).mean(), (o[:, :, 14] - o[:, :, 13]).mean(), (o[:, :, 15] - o[:, :, 14]).mean(),
         (o[:, :, 10] - o[:, :, 15]).mean()))
+
+# the merged kernel (option BLOCK_FULL, default): stamps 0..10 of block_full_w4_kernel, per wave, LAST group of a workgroup
+if net is not None and nat.get_option("BLOCK_FULL") and nat.get_option("BLOCK_FUSED") >= 2 and nat.get_option("BLOCK3_FUSED") >= 2:
+    names = ["wait inputs + barrier", "stage A (layer1.conv2)", "stage B (layer2.conv1)", "stage C (layer2.conv2)",
+             "layer3.conv1 half 0", "layer3.conv2 half 0", "layer3.conv1 half 1", "layer3.conv2 half 1 + residual",
+             "pooled epilogue pass 0", "pass 1 + zero fill"]
+    d = t[:, :4, 1:11] - t[:, :4, 0:10]
+    print("merged kernel, cycles per agent group incl. the barrier behind each phase; total %.0f" % (t[:, :4, 10] - t[:, :4, 0]).mean())
+    for i, n in enumerate(names):
+        print("  %-34s" % n + "".join("%8.0f" % d[:, w, i].mean() for w in range(4)))
