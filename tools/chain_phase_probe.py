@@ -23,12 +23,13 @@ with torch.no_grad():
     torch.cuda.synchronize()
     h.magat_chain_set_debug_buffer(None)
 t = buf.cpu().numpy().astype(np.float64)
-names = ["prologue (barrier + LDS write of the prefetched inputs)", "stage A", "barrier A", "stage B", "barrier B", "stage C (+ stores)"]
-d = t[:, 1:7] - t[:, 0:6]
-tot = t[:, 6] - t[:, 0]
-print("per-workgroup cycles (wave 0), mean / p90:  total %.0f / %.0f" % (tot.mean(), np.percentile(tot, 90)))
-for i, n in enumerate(names):
-    print("  %-30s %8.0f / %8.0f   (%.1f %%)" % (n, d[:, i].mean(), np.percentile(d[:, i], 90), 100 * d[:, i].mean() / tot.mean()))
+if t.any():          # (not launched when the chain kernels run as one launch, option BLOCK_FULL)
+    names = ["prologue (barrier + LDS write of the prefetched inputs)", "stage A", "barrier A", "stage B", "barrier B", "stage C (+ stores)"]
+    d = t[:, 1:7] - t[:, 0:6]
+    tot = t[:, 6] - t[:, 0]
+    print("chain kernel, per-workgroup cycles (wave 0, last group), mean / p90:  total %.0f / %.0f" % (tot.mean(), np.percentile(tot, 90)))
+    for i, n in enumerate(names):
+        print("  %-30s %8.0f / %8.0f   (%.1f %%)" % (n, d[:, i].mean(), np.percentile(d[:, i], 90), 100 * d[:, i].mean() / tot.mean()))
 
 # layer3 kernel (one workgroup per agent group): per-WAVE stamps before and after every barrier
 g3 = 256               # persistent: one workgroup per CU, the stamps are those of its LAST agent group
@@ -40,23 +41,26 @@ with torch.no_grad():
     torch.cuda.synchronize()
     h.magat_block3_set_debug_buffer(None)
 t = buf3.cpu().numpy().astype(np.float64)
+full = bool(nat.get_option("BLOCK_FULL") and nat.get_option("BLOCK_FUSED") >= 2 and nat.get_option("BLOCK3_FUSED") >= 2)
 names = ["prologue (input DMA + barrier)", "conv1 half 0", "  barrier", "conv2 half 0", "  barrier", "conv1 half 1", "  barrier",
          "conv2 half 1 + residual", "  barrier", "relu + pool + store"]
 d = t[:, :, 1:11] - t[:, :, 0:10]                 # [wg][wave][phase]
 tot = (t[:, :4, 10] - t[:, :4, 0]).mean()
-print("layer3 kernel, cycles per agent group (mean over workgroups), by wave; total %.0f" % tot)
+if not full:
+    print("layer3 kernel, cycles per agent group (mean over workgroups), by wave; total %.0f" % tot)
 nw = 8 if t[:, 4:, 10].any() else 4          # the four-wave form of the kernel leaves waves 4..7 unstamped
 print("  %-32s" % "phase" + "".join("   wave%d" % w for w in range(nw)))
 for i, n in enumerate(names):
-    print("  %-32s" % n + "".join("%8.0f" % d[:, w, i].mean() for w in range(nw)))
-if t[:, 0, 13].any():
+    if not full:
+        print("  %-32s" % n + "".join("%8.0f" % d[:, w, i].mean() for w in range(nw)))
+if not full and t[:, 0, 13].any():
     o = t[:, :4, :]
     print("  output phase: S write 0 %.0f | pool+store 0 %.0f | S write 1 %.0f | pool+store 1 + zero fill %.0f" % (
         (o[:, :, 13] - o[:, :, 9]).mean(), (o[:, :, 14] - o[:, :, 13]).mean(), (o[:, :, 15] - o[:, :, 14]).mean(),
         (o[:, :, 10] - o[:, :, 15]).mean()))
 
 # the merged kernel (option BLOCK_FULL, default): stamps 0..10 of block_full_w4_kernel, per wave, LAST group of a workgroup
-if net is not None and nat.get_option("BLOCK_FULL") and nat.get_option("BLOCK_FUSED") >= 2 and nat.get_option("BLOCK3_FUSED") >= 2:
+if full:
     names = ["wait inputs + barrier", "stage A (layer1.conv2)", "stage B (layer2.conv1)", "stage C (layer2.conv2)",
              "layer3.conv1 half 0", "layer3.conv2 half 0", "layer3.conv1 half 1", "layer3.conv2 half 1 + residual",
              "pooled epilogue pass 0", "pass 1 + zero fill"]
