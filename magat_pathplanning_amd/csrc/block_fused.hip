@@ -87,8 +87,10 @@ long long* g_block3_dbg = nullptr;
 #define L3_STAMP(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ void split2(float x, float y, unsigned& p1, unsigned& p2, bool& clamped) {
-  clamped |= (x > 65504.f) | (y > 65504.f);              // (post-ReLU values)
+// value pair -> its two f16 planes; ReLU and the f16 range clamp are the same v_med3.  `vmax` keeps the running maximum of the
+// UNclamped values (one v_max3 per pair; the caller compares it with 65504 once per tile for the range guard).
+__device__ __forceinline__ void split2(float x, float y, unsigned& p1, unsigned& p2, float& vmax) {
+  vmax = fmaxf(fmaxf(vmax, x), y);
   x = __builtin_amdgcn_fmed3f(x, 0.f, 65504.f);
   y = __builtin_amdgcn_fmed3f(y, 0.f, 65504.f);
   const f16x2 h = __builtin_convertvector(f32x2{x, y}, f16x2);
@@ -233,7 +235,7 @@ __device__ __forceinline__ void chain_stage(const ChainParams& p, char* lds, int
       }
       continue;
     }
-    bool cl = false;
+    float cl = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       unsigned h1[4], h2[4];
@@ -242,7 +244,7 @@ __device__ __forceinline__ void chain_stage(const ChainParams& p, char* lds, int
         const int q = 2 * ks + e;
         float v[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * scale + bq[q][c], 0.f);
+        for (int c = 0; c < 4; ++c) v[c] = acc[s][4 * q + c] * scale + bq[q][c];       // (ReLU: the clamp of split2)
         split2(v[0], v[1], h1[2 * e], h2[2 * e], cl);
         split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1], cl);
       }
@@ -260,7 +262,7 @@ __device__ __forceinline__ void chain_stage(const ChainParams& p, char* lds, int
         *reinterpret_cast<u32x4*>(o + PS_OUT) = u32x4{h2[0], h2[1], h2[2], h2[3]};
       }
     }
-    clamped |= cl && mok;      // (rows of agents past M compute on whatever the padded tile holds)
+    clamped |= cl > 65504.f && mok;      // (rows of agents past M compute on whatever the padded tile holds)
   }
 }
 
@@ -403,7 +405,7 @@ __device__ __forceinline__ void epi_to_lds(char* lds, int out_off, const int (&t
   for (int s = 0; s < NS; ++s) {
     if (tl[s] < 0) continue;
     const int pix = TILE_PIX[tl[s]][psl];
-    bool cl = false;
+    float cl = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       unsigned h1[4], h2[4];
@@ -412,7 +414,7 @@ __device__ __forceinline__ void epi_to_lds(char* lds, int out_off, const int (&t
         const int q = 2 * ks + e;
         float v[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * scale + bq[q][c], 0.f);
+        for (int c = 0; c < 4; ++c) v[c] = acc[s][4 * q + c] * scale + bq[q][c];       // (ReLU: the clamp of split2)
         split2(v[0], v[1], h1[2 * e], h2[2 * e], cl);
         split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1], cl);
       }
@@ -420,7 +422,7 @@ __device__ __forceinline__ void epi_to_lds(char* lds, int out_off, const int (&t
       *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
       *reinterpret_cast<u32x4*>(o + PS_OUT) = u32x4{h2[0], h2[1], h2[2], h2[3]};
     }
-    clamped |= cl && rows_ok;
+    clamped |= cl > 65504.f && rows_ok;
   }
 }
 
@@ -927,7 +929,7 @@ __device__ __forceinline__ void chain_stage4(const ChainParams& p, char* lds, in
       }
       continue;
     }
-    bool cl = false;
+    float cl = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       unsigned h1[4], h2[4];
@@ -936,7 +938,7 @@ __device__ __forceinline__ void chain_stage4(const ChainParams& p, char* lds, in
         const int q = 2 * ks + e;
         float v[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * scale + bq[q][c], 0.f);
+        for (int c = 0; c < 4; ++c) v[c] = acc[s][4 * q + c] * scale + bq[q][c];       // (ReLU: the clamp of split2)
         split2(v[0], v[1], h1[2 * e], h2[2 * e], cl);
         split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1], cl);
       }
@@ -954,7 +956,7 @@ __device__ __forceinline__ void chain_stage4(const ChainParams& p, char* lds, in
         *reinterpret_cast<u32x4*>(o + PS_OUT) = u32x4{h2[0], h2[1], h2[2], h2[3]};
       }
     }
-    clamped |= cl && mok;
+    clamped |= cl > 65504.f && mok;
   }
 }
 
@@ -1106,6 +1108,7 @@ __global__ __launch_bounds__(256, 1) void block_full_w4_kernel(const FullParams 
 #pragma unroll
           for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
         walk4<W4A, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1, a1, false);
+        if (h == 0) FULL_STAMP(11);
         const int tl[W4A::NT] = {W4A::t[0], W4A::t[1], W4A::t[2], W4A::t[3]};
         epi_to_lds<64, W4A::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
       } else {
@@ -1115,9 +1118,11 @@ __global__ __launch_bounds__(256, 1) void block_full_w4_kernel(const FullParams 
 #pragma unroll
           for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
         walk4<W4B, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1, a1, false);
+        if (h == 0) FULL_STAMP(11);
         const int tl[W4B::NT] = {W4B::t[0], W4B::t[1], W4B::t[2], W4B::t[3], W4B::t[4]};
         epi_to_lds<64, W4B::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
       }
+      if (h == 0) FULL_STAMP(12);
       __syncthreads();
       FULL_STAMP(5 + 2 * h);
       walk4<W4All, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_MID, L_IN, w2, acc, h == 1);

@@ -68,3 +68,7 @@ if full:
     print("merged kernel, cycles per agent group incl. the barrier behind each phase; total %.0f" % (t[:, :4, 10] - t[:, :4, 0]).mean())
     for i, n in enumerate(names):
         print("  %-34s" % n + "".join("%8.0f" % d[:, w, i].mean() for w in range(4)))
+    if t[:, 0, 11].any():
+        print("  layer3.conv1 half 0 by wave: walk " + " ".join("%.0f" % (t[:, w, 11] - t[:, w, 4]).mean() for w in range(4)) +
+              " | epilogue " + " ".join("%.0f" % (t[:, w, 12] - t[:, w, 11]).mean() for w in range(4)) +
+              " | barrier wait " + " ".join("%.0f" % (t[:, w, 5] - t[:, w, 12]).mean() for w in range(4)))
