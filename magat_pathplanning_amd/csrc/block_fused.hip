@@ -1155,7 +1155,9 @@ __global__ __launch_bounds__(256, 1) void block_full_w4_kernel(const FullParams 
           }
         }
       }
+      if (half == 0) FULL_STAMP(13);
       L3_LDS_SYNC();
+      if (half == 0) FULL_STAMP(14);
       for (int o = t; o < 9 * AG * 16; o += 256) {
         const int Q = o & 15, agent = (o >> 4) & 7, cell = o >> 7;
         const int cy = cell / 3, cx = cell - 3 * cy;
@@ -1171,6 +1173,7 @@ __global__ __launch_bounds__(256, 1) void block_full_w4_kernel(const FullParams 
           *reinterpret_cast<f32x4*>(l3.out + ((long long)(m >> 7) * 9 + cell) * (128 * 128) + (m & 127) * 128 + 64 * half +
                                     4 * Q) = sum;
       }
+      if (half == 0) FULL_STAMP(15);
       L3_LDS_SYNC();
       if (half == 0) FULL_STAMP(9);
     }
