@@ -433,7 +433,7 @@ def main():
                           "arithmetic": {a: ARITH[a][1] for a in ariths},
                           "parity": "logits within 1e-4 of the reference (gate; observed ~1e-6 with this arithmetic)",
                           "options": {k: lib_opt(nat, k) for k in ("CONV_MX", "CONV_SPLIT", "CONV_F16", "RANGE_GUARD",
-                                                                    "BLOCK_FUSED", "BLOCK3_FUSED", "BLOCK_FULL", "GAT_FUSED_MAPS")},
+                                                                    "BLOCK_FUSED", "BLOCK3_FUSED", "BLOCK_FULL", "HEAD_F16")},
                           "global_batch": B * world, "agents": N, "parallelism": "instance-sharded x%d" % world}}
         if timing:
             pmc = load_pmc_traffic() if args.workload == "c3" and not args.batch else {}

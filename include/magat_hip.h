@@ -451,7 +451,7 @@ int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* 
 #define MAGAT_TAG_GAT_PREPARE 16  /* edge masks + edge counts + balanced instance order for the persistent graph kernel */
 #define MAGAT_TAG_RANGE_GUARD 17  /* flag reset + the predicated float32 re-run launches of the range guard (no-ops when clear) */
 #define MAGAT_TAG_BLOCK_CHAIN 18  /* BasicBlock chain kernel (block_fused.hip) */
-#define MAGAT_TAG_GAT_LAYER 19    /* graph kernel with the per-agent maps computed inside (gat_fused.hip) */
+#define MAGAT_TAG_GAT_LAYER 19    /* (reserved: a graph kernel with the per-agent maps computed inside) */
 #define MAGAT_TAG_GSO_CSR 20      /* dense GSO -> CSR + CSC structure (magat_gso_csr_build, or the transpose inside *_csr_*) */
 #define MAGAT_TAG_GAT_CAST 21     /* float32 <-> bf16 row casts around the bf16-storage graph layer */
 #define MAGAT_TAG_BLOCK3 22       /* layer3 + ReLU + 2x2 pool in one launch (block_fused.hip) */

@@ -45,7 +45,7 @@ enum MagatOpt {
   MAGAT_OPT_ENC_CHUNK, MAGAT_OPT_CONV_SPLIT, MAGAT_OPT_CONV_F16, MAGAT_OPT_CONV_PCHAIN, MAGAT_OPT_CONV_MX,
   MAGAT_OPT_L1_FUSED, MAGAT_OPT_HEAD_SPLITK, MAGAT_OPT_GAT_CHUNK_MB, MAGAT_OPT_GAT_ZPAD, MAGAT_OPT_GAT_SPLIT,
   MAGAT_OPT_GAT_HPB, MAGAT_OPT_GAT_ZTILES, MAGAT_OPT_GAT_PERSIST, MAGAT_OPT_RANGE_GUARD, MAGAT_OPT_BLOCK_FUSED,
-  MAGAT_OPT_GAT_FUSED_MAPS, MAGAT_OPT_CSR_TILED, MAGAT_OPT_BLOCK3_FUSED,
+  MAGAT_OPT_CSR_TILED, MAGAT_OPT_BLOCK3_FUSED,
   MAGAT_OPT_HEAD_F16, MAGAT_OPT_BLOCK_FULL, MAGAT_OPT_COUNT
 };
 int magat_opt(int id);
@@ -55,7 +55,7 @@ int magat_ensure_dyn_lds(const void* func, int slot, size_t bytes);
 enum MagatLdsSlot {
   MAGAT_LDS_GAT16, MAGAT_LDS_GAT32, MAGAT_LDS_GAT64, MAGAT_LDS_GAT128, MAGAT_LDS_GAT256, MAGAT_LDS_L1FUSED,
   MAGAT_LDS_SIM_GSO_T, MAGAT_LDS_SIM_GSO_F, MAGAT_LDS_SIM_MOVE, MAGAT_LDS_BLOCK_A, MAGAT_LDS_BLOCK_B, MAGAT_LDS_BLOCK_C,
-  MAGAT_LDS_GATF128, MAGAT_LDS_SIM_CONN, MAGAT_LDS_CONV_FIRST, MAGAT_LDS_CONV_FIRST11, MAGAT_LDS_GSO_STRUCT, MAGAT_LDS_CSR_TILED_A, MAGAT_LDS_CSR_TILED_B, MAGAT_LDS_CSR_TILED_A16, MAGAT_LDS_CSR_TILED_B16,
+  MAGAT_LDS_SIM_CONN, MAGAT_LDS_CONV_FIRST, MAGAT_LDS_CONV_FIRST11, MAGAT_LDS_GSO_STRUCT, MAGAT_LDS_CSR_TILED_A, MAGAT_LDS_CSR_TILED_B, MAGAT_LDS_CSR_TILED_A16, MAGAT_LDS_CSR_TILED_B16,
   MAGAT_LDS_CSR_TILED_A4, MAGAT_LDS_CSR_TILED_B4, MAGAT_LDS_CSR_TILED_A16_4, MAGAT_LDS_CSR_TILED_B16_4, MAGAT_LDS_BLOCK_B4, MAGAT_LDS_BLOCK_FULL
 };
 

@@ -38,7 +38,6 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
     {"RANGE_GUARD", 1},      // split-arithmetic range guard: overflow flag + stream-ordered fp32 re-run of the encoder
     {"BLOCK_FUSED", 2},      // BasicBlock chain kernel (conv1 -> conv2 (+downsample) with the 6x6 maps in LDS): 2 = four waves x 512
                              // registers (static K walk), 1 = eight waves x 256, 0 = one launch per convolution
-    {"GAT_FUSED_MAPS", 1},   // hoisted maps computed inside the graph kernel (Z never crosses HBM)
     {"CSR_TILED", 3},        // CSR path, N <= 1024: LDS-tiled kernels (bit 0 scores, bit 1 hops) instead of L2 gathers; bit 2 (opt-in,
                              // measured slower): 64-byte slices in 512-thread workgroups, two per CU
     {"BLOCK3_FUSED", 2},     // layer3 + ReLU + pool as one launch (two-half intermediate in LDS); needs BLOCK_FUSED.

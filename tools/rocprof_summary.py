@@ -33,7 +33,6 @@ def short(name):
                    ("block_chain_w4_kernel", "block_chain_w4(layer1.conv2+layer2)"), ("block3_w4_kernel", "block3_w4(layer3+pool)"),
                    ("block_full_w4_kernel", "block_full_w4(layer1.conv2+layer2+layer3+pool)"),
                    ("gat_guard_count_kernel", "guard_count(gat)"), ("guard_count_kernel", "guard_count(encoder)"),
-                   ("gat_fused_kernel", "gat_fused_kernel"),
                    ("gat_dense_kernel", "gat_dense_kernel"), ("head_mean_relu", "head_mean_relu"),
                    ("pack_kernel", "gat_pack"), ("gso_prepare", "gso_prepare")):
         if key in name:
@@ -86,8 +85,7 @@ def main():
            "gat_maps_gemm", "guard:gat_maps", "guard:gat_count", "gat_graph", "actionsMLP"]
     ours = ("conv_gemm_kernel", "conv_gemm_bf16x6_kernel", "conv_gemm_f16x3_direct_kernel", "conv_first_kernel",
             "layer1_fused_kernel", "gat_dense_kernel", "block_chain_kernel", "block3_kernel", "block_chain_w4_kernel",
-            "block3_w4_kernel", "block_full_w4_kernel", "guard_count_kernel",
-            "gat_fused_kernel")
+            "block3_w4_kernel", "block_full_w4_kernel", "guard_count_kernel")
     layers = defaultdict(dict)
     tr = find(os.path.join(out, "trace"), "*kernel_trace.csv")
     if tr:
