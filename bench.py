@@ -135,8 +135,10 @@ def kernel_work(nat, cfg, N, S_bytes, deg=None, planned=False, fused_stem=True, 
     # graph kernel: SURVEY 8(d) "kernel (ii)" bytes per instance / N (Q, U cross HBM once)
     w["gat_graph"] = dict(flops=0, arith=None, bytes=(4 * (N * G + P * N * G + P * K * N * F + N * yw) +
                                                       (16 * N if planned else S_bytes * N * N)) / N)
-    # maps computed inside the graph kernel: the LAYER-level bytes of SURVEY 8(d) - X, S, Y
-    w["gat_layer (fused maps)"] = dict(flops=2 * G * NC, arith="f16x3", bytes=(4 * (N * G + N * yw) + S_bytes * N * N) / N)
+    # the whole layer as one launch of matrix-core products (gat_mfma.hip): the LAYER-level bytes of SURVEY 8(d) - X, S, Y -
+    # and, per agent-step, the maps (2 G NC) + the dense score product (2 N G per head) + K - 1 dense hops (2 N F per head)
+    w["gat_layer (one launch)"] = dict(flops=2 * G * NC + 2 * N * G * P + 2 * (K - 1) * N * F * P, arith="f16x3",
+                                       bytes=(4 * (N * G + N * yw) + S_bytes * N * N) / N)
     if planned:
         w["gat_prepare"] = dict(flops=0, arith=None, bytes=S_bytes * N + 16 + 8.0 / N)
     if deg is not None:
@@ -422,8 +424,8 @@ def main():
                "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32 in/out, fp32-class arithmetic: convolutions + GAT maps as %s split products on the 16-bit matrix "
-                        "cores with f32 accumulation (the encoder head too, on the layer3 kernel's pooled map), MLPs on f32 MFMA, graph "
-                        "kernel f32 VALU%s"
+                        "cores with f32 accumulation (the encoder head too, on the layer3 kernel's pooled map; with GAT_MFMA the attention "
+                        "scores and the K-hop aggregation as well), MLPs on f32 MFMA%s"
                         % ("/".join(ariths), "" if cfg.gat_storage == "fp32" else "; bf16 STORAGE inside the GAT layer"),
                "data": "synthetic (seeded binary FOV states + comm-radius GSO; random-init weights, BN stats perturbed)",
                "config": {"workload": "%s: N=%d agents, %dx%d map, K=%d, P=%d, F=%d, %s, %s, KeyQuery, %s; batch %d per GPU "
@@ -433,7 +435,7 @@ def main():
                           "arithmetic": {a: ARITH[a][1] for a in ariths},
                           "parity": "logits within 1e-4 of the reference (gate; observed ~1e-6 with this arithmetic)",
                           "options": {k: lib_opt(nat, k) for k in ("CONV_MX", "CONV_SPLIT", "CONV_F16", "RANGE_GUARD",
-                                                                    "BLOCK_FUSED", "BLOCK3_FUSED", "BLOCK_FULL", "HEAD_F16")},
+                                                                    "BLOCK_FUSED", "BLOCK3_FUSED", "BLOCK_FULL", "HEAD_F16", "GAT_MFMA")},
                           "global_batch": B * world, "agents": N, "parallelism": "instance-sharded x%d" % world}}
         if timing:
             pmc = load_pmc_traffic() if args.workload == "c3" and not args.batch else {}
@@ -443,7 +445,7 @@ def main():
             if bounded:
                 dom = max(bounded, key=lambda k: table[k]["ms_per_step"])
                 res["roofline"] = roof(table, dom, B, N, pmc)
-            for gk in ("gat_graph", "gat_layer (fused maps)"):
+            for gk in ("gat_graph", "gat_layer (one launch)"):
                 if gk in table:
                     res["roofline_gat"] = roof(table, gk, B, N, pmc)
             res["kernel_time_ms_per_step"] = round(sum(v["ms_per_step"] for k, v in table.items() if k != "gat_prepare"), 4)
@@ -462,7 +464,7 @@ def main():
               "value": round(Bn * N * esteps / el, 1), "unit": "agent-steps/s", "ms_per_step": round(el / esteps * 1e3, 4)}
         if timing:
             tn = kernel_table(kn, esteps, Bn, N, Sn, {})
-            for gk in ("gat_graph", "gat_layer (fused maps)"):
+            for gk in ("gat_graph", "gat_layer (one launch)"):
                 if gk in tn:
                     ns["gat_kernel"] = {k: tn[gk][k] for k in ("avg_us", "bound", "achieved", "peak", "unit", "frac",
                                                                 "bytes_per_agent_step") if k in tn[gk]}

@@ -55,6 +55,8 @@ const char* magat_error_string(int code);
  *                    512-register form of the layer3 kernel, 1 = the eight-wave form, 0 = one launch per convolution
  *   BLOCK_FULL  (1)  both chain kernels as ONE launch (layer2's output never leaves the CU); needs BLOCK_FUSED 2, BLOCK3_FUSED 2
  *   HEAD_F16    (1)  encoder head as f16x3 split products when its input is the layer3 kernel's pooled map (large batches)
+ *   GAT_MFMA    (1)  magat_gat_forward_*: KeyQuery, G = F = 128, N <= 101, K = 2 | 3, A_opt == NULL run as ONE launch of matrix-core
+ *                    products (maps, scores, softmax, hops; csrc/gat_mfma.hip); 0 = maps GEMM + graph kernel
  * Returns MAGAT_ERR_UNSUPPORTED for an unknown name. */
 int magat_set_option(const char* name, int value);
 int magat_get_option(const char* name, int* value);
@@ -451,7 +453,7 @@ int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* 
 #define MAGAT_TAG_GAT_PREPARE 16  /* edge masks + edge counts + balanced instance order for the persistent graph kernel */
 #define MAGAT_TAG_RANGE_GUARD 17  /* flag reset + the predicated float32 re-run launches of the range guard (no-ops when clear) */
 #define MAGAT_TAG_BLOCK_CHAIN 18  /* BasicBlock chain kernel (block_fused.hip) */
-#define MAGAT_TAG_GAT_LAYER 19    /* (reserved: a graph kernel with the per-agent maps computed inside) */
+#define MAGAT_TAG_GAT_LAYER 19    /* the KeyQuery layer as one launch of matrix-core products (gat_mfma.hip) */
 #define MAGAT_TAG_GSO_CSR 20      /* dense GSO -> CSR + CSC structure (magat_gso_csr_build, or the transpose inside *_csr_*) */
 #define MAGAT_TAG_GAT_CAST 21     /* float32 <-> bf16 row casts around the bf16-storage graph layer */
 #define MAGAT_TAG_BLOCK3 22       /* layer3 + ReLU + 2x2 pool in one launch (block_fused.hip) */

@@ -17,7 +17,7 @@ MODE_GNN = 3
 TAGS = {0: "untagged", 1: "conv_first", 2: "layer1.conv1", 3: "layer1.conv2+ds", 4: "layer2.conv1",
         5: "layer2.conv2+ds", 6: "layer3.conv1", 7: "layer3.conv2+ds", 8: "head(avgpool+fc+linear)",
         9: "compressMLP", 10: "gat_maps_gemm", 11: "gat_graph", 12: "actionsMLP", 13: "head_mean",
-        14: "gat_pack", 15: "gso_prepare", 16: "gat_prepare", 17: "range_guard", 18: "layer1.conv2+layer2 (fused)", 19: "gat_layer (fused maps)", 20: "gso_to_csr", 21: "gat_cast", 22: "layer3 (fused, pooled)", 23: "layer1.conv2+layer2+layer3 (fused, pooled)"}
+        14: "gat_pack", 15: "gso_prepare", 16: "gat_prepare", 17: "range_guard", 18: "layer1.conv2+layer2 (fused)", 19: "gat_layer (one launch)", 20: "gso_to_csr", 21: "gat_cast", 22: "layer3 (fused, pooled)", 23: "layer1.conv2+layer2+layer3 (fused, pooled)"}
 TAG_ACTIONS = 12
 
 _lock = threading.Lock()

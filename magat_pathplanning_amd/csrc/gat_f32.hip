@@ -58,6 +58,7 @@ struct GatParams {
   int ldym;
   int hpb;                       // heads per workgroup (1, or P: the workgroup walks all heads of its instance and
                                  // loads the next head's Q tile while the current head computes)
+  const int* run_if;             // when set: the launch is a no-op unless *run_if != 0 (range-guard re-run of gat_mfma.hip)
 };
 
 // diag: 1 on the diagonal when the mode adds self-loops (GAT_origin: S.float() + I, graphML.py:1018)
@@ -100,6 +101,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
   const int istride = MAGAT_NUM_XCD * ((int)gridDim.x / MAGAT_NUM_XCD / hgroups);
   const int head0 = (slot % hgroups) * hpb;
   if (bl0 >= p.B) return;
+  if (p.run_if && *p.run_if == 0) return;
 
   float* R0 = smem;                      // Q_p, later hop buffer
   float* R1 = R0 + N * RW;               // X_b during the score phase, then U_{K-1} / hop buffer
@@ -722,7 +724,8 @@ __global__ void gat_dense_kernel(const GatParams p) {
 
 // mean over heads then ReLU (graphML.py:4663-4667)
 __global__ void head_mean_relu_kernel(const float* __restrict__ ytmp, float* __restrict__ y, long long M, int P,
-                                      int F, int ldy) {
+                                      int F, int ldy, const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
   const int FC = F / 4;
   const long long total = M * FC;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -771,6 +774,10 @@ __global__ void pack_kernel(const float* __restrict__ weight, const float* __res
   // bf16x3 planes of Bt for the split-MFMA GEMM (raw bf16 bits), 16-byte aligned behind the column bias
   unsigned short* Bs = reinterpret_cast<unsigned short*>(packed + (((long long)L.NC * (G + 1) + 3) & ~3LL));
   unsigned short* Hs = reinterpret_cast<unsigned short*>(packed + magat_gat_f16_block_offset(L.NC, G));
+  // the same two planes once more in MFMA-fragment order for gat_mfma.hip (G = 128): 128-row blocks of Bt, per block
+  // [32-row tile 4][k step 8][plane 2][lane 64][8 halfs], lane = row % 32 + 32 * (k % 16 / 8)
+  unsigned short* Fs = (G == 128 && (L.NC & 127) == 0)
+                           ? reinterpret_cast<unsigned short*>(packed + magat_gat_frag_offset(L.NC, G)) : nullptr;
   const long long total = (long long)L.NC * G;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total + L.NC;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -815,6 +822,13 @@ __global__ void pack_kernel(const float* __restrict__ weight, const float* __res
     const _Float16 g2 = (_Float16)(vs - (float)g1);
     Hs[idx] = __builtin_bit_cast(unsigned short, g1);
     Hs[total + idx] = __builtin_bit_cast(unsigned short, g2);
+    if (Fs) {
+      const int r = col & 127;
+      const long long fo = (long long)(col >> 7) * 32768 + (((r >> 5) * 8 + (g >> 4)) * 2) * 512 +
+                           ((r & 31) + 32 * ((g & 15) >> 3)) * 8 + (g & 7);
+      Fs[fo] = __builtin_bit_cast(unsigned short, g1);
+      Fs[fo + 512] = __builtin_bit_cast(unsigned short, g2);
+    }
     if (idx == 0) *reinterpret_cast<float*>(Hs + 2 * total) = 1.f / 256.f;
   }
 }
@@ -850,12 +864,12 @@ int gat_chunk_instances(int B, int N, int NC) {
 }
 
 template <int G, int F>
-int launch_gat(const GatParams& p, int blocks, int threads, size_t lds, hipStream_t st) {
+int launch_gat(const GatParams& p, int blocks, int threads, size_t lds, hipStream_t st, int tag) {
   constexpr int slot = G == 16 ? MAGAT_LDS_GAT16 : G == 32 ? MAGAT_LDS_GAT32 : G == 64 ? MAGAT_LDS_GAT64
                       : G == 128 ? MAGAT_LDS_GAT128 : MAGAT_LDS_GAT256;
   if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&gat_dense_kernel<G, F>), slot, lds) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
-  const int pid = magat_prof_begin(MAGAT_TAG_GAT_GRAPH, st);
+  const int pid = magat_prof_begin(tag, st);
   hipLaunchKernelGGL((gat_dense_kernel<G, F>), dim3(blocks), dim3(threads), lds, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
@@ -878,6 +892,7 @@ extern "C" int magat_gat_set_debug_skip(int mask) { g_gat_skip = mask; return MA
 extern "C" size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode) {
   if (G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
   const PackLayout L = pack_layout(G, F, K, P, mode);
+  if (G == 128 && (L.NC & 127) == 0) return magat_gat_frag_offset(L.NC, G) + (size_t)L.NC * G;
   return magat_gat_f16_block_offset(L.NC, G) + (size_t)L.NC * G + 4;
 }
 
@@ -1143,6 +1158,7 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
   GatParams p;
   p.order = nullptr;
   p.rmask_pre = nullptr;
+  p.run_if = nullptr;
   p.dbg = g_gat_dbg;
   p.skip = 0;
 #ifdef MAGAT_DEBUG_HOOKS
@@ -1154,6 +1170,19 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
   p.ldx = G; p.ldy = concat ? ldy : P * F; p.NC = ldz; p.lda_a = N | 1;
   p.qoff = L.qoff; p.uoff = L.uoff; p.c1off = L.c1off; p.c2off = L.c2off;
 
+  // One launch of matrix-core products (gat_mfma.hip) when the shape allows; with the range guard on, the two-launch float32
+  // form below follows in the same stream, every launch of it predicated on the flag the fused kernel raises.
+  bool rerun_only = false;
+  if (magat_opt(MAGAT_OPT_GAT_MFMA) && magat_opt(MAGAT_OPT_GAT_SPLIT) && magat_opt(MAGAT_OPT_CONV_F16) && !A_opt &&
+      magat_gat_mfma_supported(N, G, F, K, mode)) {
+    const bool guard = magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
+    const unsigned* masks = (plan && N <= 128) ? static_cast<const unsigned*>(plan) : nullptr;
+    const int rc = magat_gat_mfma_forward(X, G, S, s_is_f64, masks, packed + magat_gat_frag_offset(L.NC, G), bias, Y, ldy, B,
+                                          N, K, P, concat, guard ? status : nullptr, st);
+    if (rc != MAGAT_OK || !guard) return rc;
+    rerun_only = true;
+    p.run_if = status;
+  }
   const int hpb_env = magat_opt(MAGAT_OPT_GAT_HPB);
   auto hpb_for = [&](int cb) {
     int h = 1;
@@ -1173,7 +1202,9 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     p.zts = ztiles ? (long long)cb * N * 128 : 0;
     // (one chunk is the rule; with several, a clamp in an earlier chunk leaves the flag set only until the next chunk's
     // own GEMM clears it - status[1] still counts every re-run)
-    int rc = magat_gat_maps_gemm(X + (size_t)b0 * N * G, packed, Z, cb * N, G, L.NC, ldz, stream, p.zts, status);
+    int rc = rerun_only ? gat_maps_gemm_f32(X + (size_t)b0 * N * G, packed, Z, cb * N, G, L.NC, ldz, stream, p.zts, status,
+                                            MAGAT_TAG_RANGE_GUARD)
+                        : magat_gat_maps_gemm(X + (size_t)b0 * N * G, packed, Z, cb * N, G, L.NC, ldz, stream, p.zts, status);
     if (rc != MAGAT_OK) return rc;
     p.B = cb; p.b0 = b0;
     // heads per workgroup: when the LDS tiles allow only one workgroup per CU there is nothing to overlap a
@@ -1198,12 +1229,13 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
       if (inst_slots == GAT_PLAN_WALKERS && inst_slots < cb)
         p.order = reinterpret_cast<const int*>(base + magat_align_up((size_t)B * N * 4 * sizeof(unsigned), 256)) + B;
     }
+    const int gtag = rerun_only ? MAGAT_TAG_RANGE_GUARD : MAGAT_TAG_GAT_GRAPH;
     switch (G) {
-      case 16: rc = launch_gat<16, 16>(p, blocks, threads, lds, st); break;
-      case 32: rc = launch_gat<32, 32>(p, blocks, threads, lds, st); break;
-      case 64: rc = launch_gat<64, 64>(p, blocks, threads, lds, st); break;
-      case 128: rc = launch_gat<128, 128>(p, blocks, threads, lds, st); break;
-      case 256: rc = launch_gat<256, 256>(p, blocks, threads, lds, st); break;
+      case 16: rc = launch_gat<16, 16>(p, blocks, threads, lds, st, gtag); break;
+      case 32: rc = launch_gat<32, 32>(p, blocks, threads, lds, st, gtag); break;
+      case 64: rc = launch_gat<64, 64>(p, blocks, threads, lds, st, gtag); break;
+      case 128: rc = launch_gat<128, 128>(p, blocks, threads, lds, st, gtag); break;
+      case 256: rc = launch_gat<256, 256>(p, blocks, threads, lds, st, gtag); break;
       default: rc = MAGAT_ERR_UNSUPPORTED;
     }
     if (rc != MAGAT_OK) return rc;
@@ -1212,8 +1244,14 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     const long long M = (long long)B * N;
     long long blocks = (M * (F / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    const int pid = magat_prof_begin(MAGAT_TAG_HEAD_MEAN, st);
-    hipLaunchKernelGGL(head_mean_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Ytmp, Y, M, P, F, ldy);
+    const int pid = magat_prof_begin(rerun_only ? MAGAT_TAG_RANGE_GUARD : MAGAT_TAG_HEAD_MEAN, st);
+    hipLaunchKernelGGL(head_mean_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Ytmp, Y, M, P, F, ldy, p.run_if);
+    magat_prof_end(pid, st);
+    if (magat_check_launch() != MAGAT_OK) return MAGAT_ERR_LAUNCH;
+  }
+  if (rerun_only) {      // flag -> status[2], re-run count, flag cleared (after the predicated launches have read it)
+    const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);
+    hipLaunchKernelGGL(gat_guard_count_kernel, dim3(1), dim3(1), 0, st, status);
     magat_prof_end(pid, st);
     return magat_check_launch();
   }

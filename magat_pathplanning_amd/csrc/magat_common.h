@@ -46,17 +46,19 @@ enum MagatOpt {
   MAGAT_OPT_L1_FUSED, MAGAT_OPT_HEAD_SPLITK, MAGAT_OPT_GAT_CHUNK_MB, MAGAT_OPT_GAT_ZPAD, MAGAT_OPT_GAT_SPLIT,
   MAGAT_OPT_GAT_HPB, MAGAT_OPT_GAT_ZTILES, MAGAT_OPT_GAT_PERSIST, MAGAT_OPT_RANGE_GUARD, MAGAT_OPT_BLOCK_FUSED,
   MAGAT_OPT_CSR_TILED, MAGAT_OPT_BLOCK3_FUSED,
-  MAGAT_OPT_HEAD_F16, MAGAT_OPT_BLOCK_FULL, MAGAT_OPT_COUNT
+  MAGAT_OPT_HEAD_F16, MAGAT_OPT_BLOCK_FULL, MAGAT_OPT_GAT_MFMA, MAGAT_OPT_COUNT
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)
-#define MAGAT_LDS_SLOTS 32
+#define MAGAT_LDS_SLOTS 48
 int magat_ensure_dyn_lds(const void* func, int slot, size_t bytes);
 enum MagatLdsSlot {
   MAGAT_LDS_GAT16, MAGAT_LDS_GAT32, MAGAT_LDS_GAT64, MAGAT_LDS_GAT128, MAGAT_LDS_GAT256, MAGAT_LDS_L1FUSED,
   MAGAT_LDS_SIM_GSO_T, MAGAT_LDS_SIM_GSO_F, MAGAT_LDS_SIM_MOVE, MAGAT_LDS_BLOCK_A, MAGAT_LDS_BLOCK_B, MAGAT_LDS_BLOCK_C,
   MAGAT_LDS_SIM_CONN, MAGAT_LDS_CONV_FIRST, MAGAT_LDS_CONV_FIRST11, MAGAT_LDS_GSO_STRUCT, MAGAT_LDS_CSR_TILED_A, MAGAT_LDS_CSR_TILED_B, MAGAT_LDS_CSR_TILED_A16, MAGAT_LDS_CSR_TILED_B16,
-  MAGAT_LDS_CSR_TILED_A4, MAGAT_LDS_CSR_TILED_B4, MAGAT_LDS_CSR_TILED_A16_4, MAGAT_LDS_CSR_TILED_B16_4, MAGAT_LDS_BLOCK_B4, MAGAT_LDS_BLOCK_FULL
+  MAGAT_LDS_CSR_TILED_A4, MAGAT_LDS_CSR_TILED_B4, MAGAT_LDS_CSR_TILED_A16_4, MAGAT_LDS_CSR_TILED_B16_4, MAGAT_LDS_BLOCK_B4, MAGAT_LDS_BLOCK_FULL,
+  MAGAT_LDS_GATM_0,      // gat_mfma.hip: 12 slots (shape class x taps x merge)
+  MAGAT_LDS_GATM_END = MAGAT_LDS_GATM_0 + 12
 };
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of
@@ -65,6 +67,17 @@ __host__ __device__ inline size_t magat_gat_f16_block_offset(int NC, int G) {
   const size_t a = (((size_t)NC * (G + 1) + 3) & ~(size_t)3) + ((size_t)3 * NC * G + 1) / 2;
   return (a + 3) & ~(size_t)3;
 }
+
+// fragment-major f16x2 planes of Bt * 2^8 in 128-row blocks (G = 128, NC % 128 == 0; gat_mfma.hip): float offset behind the
+// row-major planes; NC * G more floats
+__host__ __device__ inline size_t magat_gat_frag_offset(int NC, int G) {
+  return (magat_gat_f16_block_offset(NC, G) + (size_t)NC * G + 4 + 3) & ~(size_t)3;
+}
+// one-launch KeyQuery layer on the matrix cores (gat_mfma.hip)
+int magat_gat_mfma_supported(int N, int G, int F, int K, int mode);
+int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre,
+                           const float* packed_frag, const float* bias, float* Y, int ldy, int B, int N, int K, int P,
+                           int concat, int* range_flag, hipStream_t st);
 
 // hoisted GAT maps Z [M][ldz >= NC] = X [M][G] @ Bt^T + colbias from the packed weights (gat_f32.hip): bf16x6 split when
 // NC % 32 == 0 and G % 32 == 0, else fp32 MFMA

@@ -44,6 +44,7 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
                              // 2 = four waves x 512 registers, static K walk; 1 = eight waves x 256 registers; 0 = layer by layer
     {"HEAD_F16", 1},         // encoder head on the f16x3 split kernel when its input is the pooled map of the layer3 kernel
     {"BLOCK_FULL", 1},       // layer1.conv2 -> layer2 -> layer3 -> pool as ONE launch (needs BLOCK_FUSED 2 and BLOCK3_FUSED 2)
+    {"GAT_MFMA", 1},         // KeyQuery layer with 128 features, N <= 101, K = 2 | 3 as ONE launch of matrix-core products (gat_mfma.hip)
 };
 
 int g_val[MAGAT_OPT_COUNT];

@@ -1,0 +1,98 @@
+"""The one-launch matrix-core form of the KeyQuery graph-attention layer (csrc/gat_mfma.hip) against the oracle
+(oracle/magat_oracle.py, restating utils/graphUtils/graphML.py:4636-4671 / 1724-1827), and against the two-launch form."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer_and_inputs(B, N, K, P, concat, seed, density=None, bias=True):
+    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from magat_pathplanning_amd.synthetic import comm_gso, random_gso
+    g = torch.Generator().manual_seed(seed)
+    G = 128
+    layer = GraphFilterBatchAttentional(G, G, K, P, bias=bias, concatenate=concat, attentionMode="KeyQuery")
+    if density is None:
+        S = comm_gso(B, N, {100: 50, 20: 28, 10: 20}.get(N, 40), seed=seed)
+    else:
+        S = random_gso(B, N, density, seed=seed)
+    x = torch.randn(B, G, N, generator=g) * 0.7
+    return layer, S, x
+
+
+@pytest.mark.parametrize("N,K,P,concat,dt", [(100, 3, 4, True, torch.float64), (100, 3, 4, False, torch.float32),
+                                              (101, 2, 2, True, torch.float32), (97, 3, 1, True, torch.float64),
+                                              (64, 3, 4, True, torch.float32), (50, 2, 4, False, torch.float64),
+                                              (33, 3, 2, True, torch.float32), (32, 3, 4, True, torch.float32),
+                                              (20, 3, 4, True, torch.float64), (10, 2, 1, True, torch.float32),
+                                              (1, 3, 2, True, torch.float32), (17, 3, 4, False, torch.float32),
+                                              (70, 3, 4, True, torch.float32)])
+def test_gat_mfma_vs_oracle(gpu_device, libopt, N, K, P, concat, dt):
+    from oracle import magat_oracle as orc
+    B = 5
+    layer, S, x = _layer_and_inputs(B, N, K, P, concat, seed=100 + N)
+    S = S.to(dt)
+    y_ref, _ = orc.gat_layer_forward(x, S.unsqueeze(1).float(), {k: v.detach() for k, v in layer.state_dict().items()},
+                                     "KeyQuery", concat)
+    layer = layer.to(gpu_device).eval()
+    out = {}
+    for fused in (1, 0):
+        libopt.set("GAT_MFMA", fused)
+        layer.addGSO(S.unsqueeze(1).to(gpu_device))
+        with torch.no_grad():
+            out[fused] = layer(x.to(gpu_device)).cpu()
+    np.testing.assert_allclose(out[1].numpy(), y_ref.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out[1].numpy(), out[0].numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("density", [0.0, 1.0, 0.3])
+def test_gat_mfma_dense_empty_and_mixed_graphs(gpu_device, density):
+    """Fully connected graphs (every softmax row has N entries), empty graphs (rows without edges are exact zeros, not NaN:
+    the output is relu(U_0 + bias)) and random ones."""
+    from oracle import magat_oracle as orc
+    B, N, K, P = 3, 100, 3, 4
+    layer, S, x = _layer_and_inputs(B, N, K, P, True, seed=7, density=density)
+    y_ref, _ = orc.gat_layer_forward(x, S.unsqueeze(1), {k: v.detach() for k, v in layer.state_dict().items()},
+                                     "KeyQuery", True)
+    layer = layer.to(gpu_device).eval()
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    with torch.no_grad():
+        y = layer(x.to(gpu_device)).cpu()
+    assert torch.isfinite(y).all()
+    np.testing.assert_allclose(y.numpy(), y_ref.numpy(), rtol=0, atol=3e-5)
+
+
+def test_gat_mfma_many_instances_per_workgroup(gpu_device):
+    """More instances than compute units: every workgroup walks several instances (the X planes, masks and the Q / U^T
+    region are rebuilt per instance); results must not depend on the position in the walk."""
+    B, N, K, P = 700, 20, 3, 4
+    layer, S, x = _layer_and_inputs(B, N, K, P, True, seed=3)
+    S[350:] = S[:350]
+    x[350:] = x[:350]
+    layer = layer.to(gpu_device).eval()
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    with torch.no_grad():
+        y = layer(x.to(gpu_device)).cpu()
+    assert torch.equal(y[:350], y[350:])
+
+
+def test_gat_mfma_range_guard_reruns_in_float32(gpu_device):
+    """Features beyond the f16 range: the fused kernel clamps and raises the flag, the predicated float32 two-launch form
+    re-writes Y in the same stream (magat_hip.h, range guard)."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd.graphml import gat_forward_rows
+    B, N, K, P = 4, 100, 3, 4
+    layer, S, x = _layer_and_inputs(B, N, K, P, True, seed=21)
+    x[1, 5, 7] = 9.0e4
+    with torch.no_grad():
+        for prm in layer.parameters():
+            prm.mul_(0.05)
+    y_ref, _ = orc.gat_layer_forward(x, S.unsqueeze(1), {k: v.detach() for k, v in layer.state_dict().items()},
+                                     "KeyQuery", True)
+    layer = layer.to(gpu_device).eval()
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    with torch.no_grad():
+        y = layer(x.to(gpu_device)).cpu()
+    scale = float(y_ref.abs().max())
+    np.testing.assert_allclose(y.numpy(), y_ref.numpy(), rtol=0, atol=2e-6 * max(scale, 1.0))
