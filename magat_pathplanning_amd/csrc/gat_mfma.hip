@@ -19,11 +19,13 @@
 // and of the hops (the U^T rows a wave writes are the rows it reads back).  Weights travel global -> registers as
 // fragment-major f16 planes (packed by magat_gat_pack_weights), one 1 KB fragment per (32-row tile, 16-wide k step,
 // plane): 2 KB per 3 MT MFMAs per wave.
-// LDS (N = 100: 162,240 of 163,840 bytes): X planes [N][2][256 B] (16-byte chunks XOR-swizzled by row), A planes [N][SA],
+// LDS (N = 100: 162,560 of 163,840 bytes): X planes [N][2][256 B] (16-byte chunks XOR-swizzled by row), A planes [N][SA],
 // U^T planes [128][SA] with SA = 2 KI + 16 (KI = 16 KSI >= N columns; rows 60 or 68 banks apart: conflict-free b128 reads);
-// the Q planes live in the U^T region (dead before U^T is written).  That is what bounds N: N <= 101.
+// the Q planes live in the U^T region (dead before U^T is written).  That is what bounds N: N <= 102.
 // Values outside the f16 range are clamped and reported in range_flag (magat_hip.h "range guard"): the caller re-runs
 // the two-launch float32 form when it is set.
+#include <type_traits>
+
 #include "magat_common.h"
 
 namespace {
@@ -67,6 +69,10 @@ long long* g_gat_mfma_dbg = nullptr;
 #else
 #define GM_YST(ptr, val) *reinterpret_cast<float*>(ptr) = (val)
 #endif
+
+// A lone wave issues in order: vector work only runs under the matrix pipe when MFMAs and vector instructions ALTERNATE in
+// the instruction stream.  GM_PIN fences the scheduler: what is written between two fences stays between them.
+#define GM_PIN() __builtin_amdgcn_sched_barrier(0)
 
 // LDS hand-over barrier without the vmcnt(0) of __syncthreads(): weight fragments and Y stores stay in flight
 #define GM_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
@@ -112,6 +118,11 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned& p1, unsig
   const f16x2 r = __builtin_convertvector(f32x2{rx, ry}, f16x2);
   p2 = __builtin_bit_cast(unsigned, r);
 }
+__device__ __forceinline__ float mul1(float a, float b) {      // one v_mul_f32 the vectorizer cannot pair into a packed op
+  float r;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ void split2v(float x, float y, unsigned& p1, unsigned& p2, float& vmax) {
   vmax = fmaxf(fmaxf(vmax, fabsf(x)), fabsf(y));
   split_pair(x, y, p1, p2);
@@ -132,71 +143,112 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
   const int N = p.N;
   // LDS map.  X / Q planes: row r at 512 r, hi plane then lo plane (256 B each), 16-byte chunk c of a plane at
   // (c ^ (r & 15)) << 4.  A / U^T planes: rows SA bytes apart, lo plane behind the hi plane.
-  const unsigned AO = 512u * N, AP = (unsigned)N * SA;      // A planes [N][SA]
-  const unsigned UO = AO + 2 * AP;                          // U^T planes [128][SA]; the Q planes share the region
+  const int R8 = (N + 7) & ~7;                              // rows of the Q / A planes: whole groups of 8 are stored
+  const unsigned AO = 512u * N, AP = (unsigned)R8 * SA;     // A planes [R8][SA]
+  const unsigned UO = AO + 2 * AP;                          // U^T planes [128][SA]; the Q planes [R8][512] share the region
   constexpr unsigned UP = 128 * SA;
-  const unsigned MO = UO + 2 * UP;                          // edge masks [N][4] (staged here when there is no plan)
+  const unsigned MO = AO;      // edge masks [N][4], staged when there is no plan: read into registers behind the prologue
+                               // barrier, dead before the first A plane is written (two barriers later)
 
   // per-lane fragment bases.  Row tiles of the agents (A operand of G1 / G2 / G3 and of the hops; rows past N re-read row
   // N - 1: finite values whose products land in rows nobody stores or in columns the zero entries of A annihilate)
-  unsigned rsw_[MT], xsw_[MT], rpa_[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int row = min(32 * mt + fr, N - 1);
-    rsw_[mt] = row * 512;
-    xsw_[mt] = (h_ ^ (row & 15)) << 4;
-    rpa_[mt] = AO + row * SA + h_ * 16;
-  }
-  // fresh copies per phase (laundered: fragment addresses are formed next to their reads, not hoisted per (tile, k step))
-#define GM_FRESH(dst, src) unsigned dst[MT]; _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) { dst[mt_] = src[mt_]; asm volatile("" : "+v"(dst[mt_])); }
-  const int rowb = min(32 * w + fr, N - 1);        // this wave's i tile as B operand (G2)
-  const unsigned rswb_ = rowb * 512, xswb_ = (h_ ^ (rowb & 15)) << 4;
+  // Formed afresh from the (laundered) lane number wherever a phase needs them - a handful of vector instructions per phase
+  // instead of 3 MT registers that live across the whole kernel (and were spilled):
+  //   GM_ROWS(rsw, xsw): byte offset of row min(32 mt + lane % 32, N - 1) in the X / Q planes and its swizzle term
+  //   GM_AROWS(rpa):     the same row in the A planes (+ 16 bytes for the upper lane half)
+#define GM_ROWS(rsw, xsw) unsigned rsw[MT], xsw[MT]; { int l_ = lane; asm volatile("" : "+v"(l_)); _Pragma("unroll") \
+    for (int mt_ = 0; mt_ < MT; ++mt_) { const int row_ = min(32 * mt_ + (l_ & 31), N - 1); rsw[mt_] = row_ * 512; \
+      xsw[mt_] = ((l_ >> 5) ^ (row_ & 15)) << 4; } }
+#define GM_AROWS(rpa) unsigned rpa[MT]; { int l_ = lane; asm volatile("" : "+v"(l_)); _Pragma("unroll") \
+    for (int mt_ = 0; mt_ < MT; ++mt_) rpa[mt_] = AO + min(32 * mt_ + (l_ & 31), N - 1) * SA + (l_ >> 5) * 16; }
   const int cw_ = 32 * w + fr;                     // this lane's output column (g in G1, i in G2, c in G3 / hops)
   const char* wl = p.wfrag + (size_t)w * 16384 + lane * 16;   // this wave's 32-row tile of a weight block
   const float biasv = p.bias ? p.bias[cw_] : 0.f;
   const bool g2_active = 32 * w < KI;              // waves whose i tile holds columns of A
   float vmax = 0.f;                                // running maximum of |values written to f16 planes|
 
+  // Weight fragments: ONE ring of four register pairs over the static stream of a head - W_p k steps 0..7, then the eight
+  // fragments of tap K - 1, tap K - 2 (, tap 0) - continued into the next head (the stream is the same for every instance:
+  // the last head prefetches head 0's).  A fragment is requested when the k step four ahead of it retires its slot: three
+  // k steps (>= 1100 cycles) of slack for an L2 hit, 8 registers per fragment instead of a whole tap held a phase ahead.
+  constexpr int FPH = 8 * (1 + KT);      // fragments per head (a multiple of the ring depth)
+  uint4 wr[4][2];
+  auto wr_load = [&](int hd_, int f) {      // f: static position in the stream of head hd_ (f >= FPH: the next head's)
+    int hh = hd_;
+    if (f >= FPH) { hh = hd_ + 1 == p.P ? 0 : hd_ + 1; f -= FPH; }
+    const int ks = f & 7;
+    const char* s = f < 8 ? wl + (size_t)hh * 65536
+                          : wl + (size_t)(p.P + hh * KT + (KT - 1 - (f - 8) / 8)) * 65536;
+    wr[f & 3][0] = *reinterpret_cast<const uint4*>(s + ks * 2048);
+    wr[f & 3][1] = *reinterpret_cast<const uint4*>(s + ks * 2048 + 1024);
+  };
+#pragma unroll
+  for (int f = 0; f < 4; ++f) wr_load(0, f);
+
   for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
     // ---- instance prologue: X rows -> f16 planes; edge masks
+    GM_STAMP(14);
+    if (b != (int)blockIdx.x) GM_SYNC();      // (the previous instance's last hops still read the X planes: tap 0 runs under them)
     {
+      // (all of a thread's loads first - at most 7 x 32 bytes for N <= 112 - then the conversions: one memory latency)
       const float* Xb = p.X + (long long)b * N * p.ldx;
-      for (int idx = t; idx < N * 16; idx += 256) {
-        const int row = idx >> 4, ch = idx & 15;
-        const float* src = Xb + (long long)row * p.ldx + 8 * ch;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
-        uint4 hi, lo;
-        split2v(v0[0], v0[1], hi.x, lo.x, vmax);
-        split2v(v0[2], v0[3], hi.y, lo.y, vmax);
-        split2v(v1[0], v1[1], hi.z, lo.z, vmax);
-        split2v(v1[2], v1[3], hi.w, lo.w, vmax);
-        char* dst = lds + (row * 512 + ((ch ^ (row & 15)) << 4));
-        *reinterpret_cast<uint4*>(dst) = hi;
-        *reinterpret_cast<uint4*>(dst + 256) = lo;
+      f32x4 xv[7][2];
+#pragma unroll
+      for (int it = 0; it < 7; ++it) {
+        const int idx = t + 256 * it, row = idx >> 4, ch = idx & 15;
+        if (idx < N * 16) {
+          const float* src = Xb + (long long)row * p.ldx + 8 * ch;
+          xv[it][0] = *reinterpret_cast<const f32x4*>(src);
+          xv[it][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 7; ++it) {
+        const int idx = t + 256 * it, row = idx >> 4, ch = idx & 15;
+        if (idx < N * 16) {
+          uint4 hi, lo;
+          split2v(xv[it][0][0], xv[it][0][1], hi.x, lo.x, vmax);
+          split2v(xv[it][0][2], xv[it][0][3], hi.y, lo.y, vmax);
+          split2v(xv[it][1][0], xv[it][1][1], hi.z, lo.z, vmax);
+          split2v(xv[it][1][2], xv[it][1][3], hi.w, lo.w, vmax);
+          char* dst = lds + (row * 512 + ((ch ^ (row & 15)) << 4));
+          *reinterpret_cast<uint4*>(dst) = hi;
+          *reinterpret_cast<uint4*>(dst + 256) = lo;
+        }
       }
       if (!p.rmask_pre) {        // GSO rows -> 128-bit edge masks (one wave per row, ballot; |S| > 1e-9 as in gat_f32.hip)
-        const long long sbase = (long long)b * N * N;
-        for (int i = w; i < N; i += 4) {
-          bool f0, f1;
+        // rows w, w + 4, ...: eight rows' loads are issued before the first ballot (one memory latency per batch, not per row)
+        auto stage = [&](auto tag) {
+          typedef decltype(tag) ST;
+          const ST* Sp = static_cast<const ST*>(p.S) + (long long)b * N * N;
           const int j0 = lane < N ? lane : N - 1, j1 = lane + 64 < N ? lane + 64 : N - 1;
-          if (p.s_is_f64) {
-            const double* Sp = static_cast<const double*>(p.S) + sbase + (long long)i * N;
-            f0 = fabs(Sp[j0]) > 1e-9;
-            f1 = fabs(Sp[j1]) > 1e-9;
-          } else {
-            const float* Sp = static_cast<const float*>(p.S) + sbase + (long long)i * N;
-            f0 = fabsf(Sp[j0]) > 1e-9f;
-            f1 = fabsf(Sp[j1]) > 1e-9f;
+          for (int i0 = w; i0 < N; i0 += 32) {
+            ST v0[8], v1[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const int i = i0 + 4 * r < N ? i0 + 4 * r : N - 1;
+              v0[r] = Sp[(long long)i * N + j0];
+              v1[r] = Sp[(long long)i * N + j1];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const int i = i0 + 4 * r;
+              const bool f0 = sizeof(ST) == 8 ? fabs((double)v0[r]) > 1e-9 : fabsf((float)v0[r]) > 1e-9f;
+              const bool f1 = sizeof(ST) == 8 ? fabs((double)v1[r]) > 1e-9 : fabsf((float)v1[r]) > 1e-9f;
+              const unsigned long long k0 = __ballot(f0 && lane < N), k1 = __ballot(f1 && lane + 64 < N);
+              if (lane == 0 && i < N) {
+                unsigned* m = reinterpret_cast<unsigned*>(lds + MO) + 4 * i;
+                m[0] = (unsigned)k0; m[1] = (unsigned)(k0 >> 32); m[2] = (unsigned)k1; m[3] = (unsigned)(k1 >> 32);
+              }
+            }
           }
-          const unsigned long long k0 = __ballot(f0 && lane < N), k1 = __ballot(f1 && lane + 64 < N);
-          if (lane == 0) {
-            unsigned* m = reinterpret_cast<unsigned*>(lds + MO) + 4 * i;
-            m[0] = (unsigned)k0; m[1] = (unsigned)(k0 >> 32); m[2] = (unsigned)k1; m[3] = (unsigned)(k1 >> 32);
-          }
-        }
+        };
+        if (p.s_is_f64) stage(double{});
+        else stage(float{});
       }
     }
     GM_SYNC();
+    GM_STAMP(15);
     // edge mask of this lane's row i = cw (bits j), shifted so that bit (8 (r / 4) + r % 4) is row 32 mt + ... of the tile
     unsigned mk[4] = {0u, 0u, 0u, 0u};
     if (cw_ < N) {
@@ -219,46 +271,76 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
       // used (a few VALU ops) instead of being hoisted out of the head loop into hundreds of long-lived registers
       int cw = cw_, h = h_;
       asm volatile("" : "+v"(cw), "+v"(h));
-      // W_p fragments of this wave's g tile: all eight k steps, in flight across the barrier
-      uint4 wq[8][2];
-      {
-        const char* s = wl + (size_t)hd * 65536;
+      // ---- G3 state.  U_k[i][c] for the K taps needs nothing but the X planes and the weights, so its MFMAs are issued
+      // in slices BETWEEN the vector instructions that turn accumulators into planes (a lone wave per SIMD issues in order:
+      // the conversions hide under the matrix pipe only when the two streams alternate).  One tap at a time (the
+      // accumulator file holds 256 registers: all K taps next to the G1 / G2 tiles do not fit): tap K - 1 under the Q
+      // planes, tap K - 2 under the softmax and the A planes, tap 0 (K = 3) under the U^T planes of the hops.
+      f32x16 acc[KT][MT];      // (a tap's tiles are zeroed by its first slice: they occupy registers from there on only)
+      uint4 a3[MT][2];
+      GM_ROWS(rsw3, xsw3)
+      constexpr int TAP_PER = 3 * MT, TAP_ALL = 8 * TAP_PER;
+      // X fragments of a tap: ONE register set.  Within a k step the products run hi*hi, hi*lo, lo*hi over the row tiles, so
+      // tile mt's hi plane is free after the second product and its lo plane after the third: each is re-loaded for the
+      // next k step right behind its last MFMA (a whole product, >= 128 cycles, ahead of its next use).
+      auto tap_load_a1 = [&](int ks, int mt, int pl) {
+        const char* ap = lds + (rsw3[mt] + (xsw3[mt] ^ (unsigned)(ks << 5)));
+        a3[mt][pl] = lds128(ap, 256 * pl);
+      };
+      // item i of tap k's static MFMA sequence (k step, product, row tile); i is a constant wherever this is called
+      auto tap_one = [&](int k, int i) {
+        const int ks = i / TAP_PER, r = i % TAP_PER;
+        const int f = 8 + 8 * (KT - 1 - k) + ks;      // this k step's fragment in the weight stream
+        if (i == 0) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          wq[ks][0] = *reinterpret_cast<const uint4*>(s + ks * 2048);
-          wq[ks][1] = *reinterpret_cast<const uint4*>(s + ks * 2048 + 1024);
+          for (int mt = 0; mt < MT; ++mt) {
+            tap_load_a1(0, mt, 0);
+            tap_load_a1(0, mt, 1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[k][mt][e] = 0.f;
+          }
         }
-      }
+        const int q = r / MT, mt = r % MT;
+        const int pa = q == 2 ? 1 : 0, pb = q == 1 ? 1 : 0;
+        acc[k][mt] = mfma16(a3[mt][pa], wr[f & 3][pb], acc[k][mt]);
+        if (ks + 1 < 8 && q >= 1) tap_load_a1(ks + 1, mt, q - 1);
+        if (r == TAP_PER - 1) wr_load(hd, f + 4);      // (the k step's last MFMA: its slot takes the fragment four ahead)
+      };
+      auto tap_upto4 = [&](int k, int lo, int hi) {      // items lo .. hi - 1, hi - lo <= 4
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (lo + j < hi) tap_one(k, lo + j);
+      };
       if (hd > 0) GM_SYNC();      // the previous head's reads of the U^T / A planes are done
       GM_STAMP(1);
       // ---- G1: Q[j][g]
       {
-        GM_FRESH(rsw, rsw_) GM_FRESH(xsw, xsw_)
-        f32x16 acc[1][MT];
+        GM_ROWS(rsw, xsw)
+        f32x16 accq[1][MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[0][mt][r] = 0.f;
-        uint4 a[2][MT][2];
+          for (int r = 0; r < 16; ++r) accq[0][mt][r] = 0.f;
+        // (X fragments single-buffered like the taps': a plane is re-loaded for the next k step behind its last MFMA)
+        uint4 a[MT][2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const char* ap = lds + (rsw[mt] + xsw[mt]);
-          a[0][mt][0] = lds128(ap, 0);
-          a[0][mt][1] = lds128(ap, 256);
+          a[mt][0] = lds128(ap, 0);
+          a[mt][1] = lds128(ap, 256);
         }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          if (ks + 1 < 8) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-              const char* ap = lds + (rsw[mt] + (xsw[mt] ^ ((ks + 1) << 5)));
-              a[(ks + 1) & 1][mt][0] = lds128(ap, 0);
-              a[(ks + 1) & 1][mt][1] = lds128(ap, 256);
+              accq[0][mt] = mfma16(a[mt][q == 2 ? 1 : 0], wr[ks & 3][q == 1 ? 1 : 0], accq[0][mt]);
+              if (ks + 1 < 8 && q >= 1)
+                a[mt][q - 1] = lds128(lds + (rsw[mt] + (xsw[mt] ^ (unsigned)((ks + 1) << 5))), 256 * (q - 1));
             }
-          }
-          const uint4 bb[1][2] = {{wq[ks][0], wq[ks][1]}};
-          mma_step<MT, 1>(acc, a[ks & 1], bb);
-          __builtin_amdgcn_sched_barrier(0);
+          wr_load(hd, ks + 4);
+          GM_PIN();
         }
         GM_STAMP(11);
         // Q planes [j][g] (chunks swizzled by row): a lane holds column g = cw, rows j = 32 mt + 8 q + 4 h + e.  The swizzle
@@ -273,44 +355,45 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
             asm volatile("" : "+v"(qo));      // (kept as 8 registers: not re-formed from its parts at every write)
             qa[c] = lds + qo;
           }
-          const f32x2 sc = {kInvScale, kInvScale};
-          // all the arithmetic first, as one straight-line block (rows past N: harmless values nobody stores) ...
-          unsigned hq[MT][4][2], lq[MT][4][2];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const f32x2 v01 = f32x2{acc[0][mt][4 * q], acc[0][mt][4 * q + 1]} * sc;
-              const f32x2 v23 = f32x2{acc[0][mt][4 * q + 2], acc[0][mt][4 * q + 3]} * sc;
-              split2v(v01[0], v01[1], hq[mt][q][0], lq[mt][q][0], vmax);
-              split2v(v23[0], v23[1], hq[mt][q][1], lq[mt][q][1], vmax);
-            }
-          // ... then the stores, row groups of 8 (4 registers x the two 4-row halves)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
+              // this row group's arithmetic (rows past N: harmless values; the planes hold whole groups of 8 rows, the rows
+              // past N are never read) alternating with the six MFMAs of tap K - 1 that fall to it; the stores follow under
+              // a wave-uniform branch
+              constexpr int TPG = TAP_ALL / (MT * 4);      // = 6
+              const int t0 = (mt * 4 + q) * TPG;
+              unsigned hq[2], lq[2];
+              tap_one(KT - 1, t0);
+              // (the weights' 2^8 leaves here; single multiplies on purpose: v_pk_mul_f32 does not run under an MFMA of the same
+              // wave - tools/exp/mfma_valu.hip)
+              const float v01[2] = {mul1(accq[0][mt][4 * q], kInvScale), mul1(accq[0][mt][4 * q + 1], kInvScale)};
+              GM_PIN();
+              tap_one(KT - 1, t0 + 1);
+              split2v(v01[0], v01[1], hq[0], lq[0], vmax);
+              GM_PIN();
+              tap_one(KT - 1, t0 + 2);
+              const float v23[2] = {mul1(accq[0][mt][4 * q + 2], kInvScale), mul1(accq[0][mt][4 * q + 3], kInvScale)};
+              GM_PIN();
+              tap_one(KT - 1, t0 + 3);
+              split2v(v23[0], v23[1], hq[1], lq[1], vmax);
+              GM_PIN();
+              tap_one(KT - 1, t0 + 4);
               const int jg = 32 * mt + 8 * q;
-              if (jg >= N) break;                                   // (wave-uniform)
-              const unsigned short hv[4] = {(unsigned short)hq[mt][q][0], (unsigned short)(hq[mt][q][0] >> 16),
-                                            (unsigned short)hq[mt][q][1], (unsigned short)(hq[mt][q][1] >> 16)};
-              const unsigned short lv[4] = {(unsigned short)lq[mt][q][0], (unsigned short)(lq[mt][q][0] >> 16),
-                                            (unsigned short)lq[mt][q][1], (unsigned short)(lq[mt][q][1] >> 16)};
-              if (jg + 8 <= N) {                                    // (wave-uniform: all 8 rows of the group exist)
+              const unsigned short hv[4] = {(unsigned short)hq[0], (unsigned short)(hq[0] >> 16), (unsigned short)hq[1],
+                                            (unsigned short)(hq[1] >> 16)};
+              const unsigned short lv[4] = {(unsigned short)lq[0], (unsigned short)(lq[0] >> 16), (unsigned short)lq[1],
+                                            (unsigned short)(lq[1] >> 16)};
+              GM_PIN();
+              tap_one(KT - 1, t0 + 5);
+              GM_PIN();
+              if (jg < N) {                                         // (wave-uniform)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   char* o = qa[(q & 1) * 4 + e] + (jg + e) * 512;
                   GM_QW(o, hv[e]);
                   GM_QW(o + 256, lv[e]);
-                }
-              } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  char* o = qa[(q & 1) * 4 + e] + (jg + e) * 512;
-                  if (jg + 4 * h + e < N) {
-                    *reinterpret_cast<unsigned short*>(o) = hv[e];
-                    *reinterpret_cast<unsigned short*>(o + 256) = lv[e];
-                  }
                 }
               }
             }
@@ -321,60 +404,68 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
       GM_STAMP(3);
       // ---- G2: E^T[j][i], softmax over j per column i, A planes [j][i] * 2^8
       if (g2_active) {
-        GM_FRESH(rsw, rsw_) GM_FRESH(xsw, xsw_)
-        f32x16 acc[1][MT];
+        GM_ROWS(rsw, xsw)
+        f32x16 acce[1][MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[0][mt][r] = 0.f;
-        unsigned rswb = rswb_, xswb = xswb_;
-        asm volatile("" : "+v"(rswb), "+v"(xswb));
+          for (int r = 0; r < 16; ++r) acce[0][mt][r] = 0.f;
+        const int rowb = min(32 * w + (cw & 31), N - 1);      // this wave's i tile as B operand
+        const unsigned rswb = rowb * 512, xswb = (h ^ (rowb & 15)) << 4;
         const char* qbase = lds + UO;
-        uint4 a[2][MT][2], bq[2][1][2];
+        uint4 a[MT][2], bq[2][2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const char* ap = qbase + (rsw[mt] + xsw[mt]);
-          a[0][mt][0] = lds128(ap, 0);
-          a[0][mt][1] = lds128(ap, 256);
+          a[mt][0] = lds128(ap, 0);
+          a[mt][1] = lds128(ap, 256);
         }
         {
           const char* bp = lds + (rswb + xswb);
-          bq[0][0][0] = lds128(bp, 0);
-          bq[0][0][1] = lds128(bp, 256);
+          bq[0][0] = lds128(bp, 0);
+          bq[0][1] = lds128(bp, 256);
         }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
           if (ks + 1 < 8) {
+            const char* bp = lds + (rswb + (xswb ^ (unsigned)((ks + 1) << 5)));
+            bq[(ks + 1) & 1][0] = lds128(bp, 0);
+            bq[(ks + 1) & 1][1] = lds128(bp, 256);
+          }
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-              const char* ap = qbase + (rsw[mt] + (xsw[mt] ^ ((ks + 1) << 5)));
-              a[(ks + 1) & 1][mt][0] = lds128(ap, 0);
-              a[(ks + 1) & 1][mt][1] = lds128(ap, 256);
+              acce[0][mt] = mfma16(a[mt][q == 2 ? 1 : 0], bq[ks & 1][q == 1 ? 1 : 0], acce[0][mt]);
+              if (ks + 1 < 8 && q >= 1)
+                a[mt][q - 1] = lds128(qbase + (rsw[mt] + (xsw[mt] ^ (unsigned)((ks + 1) << 5))), 256 * (q - 1));
             }
-            const char* bp = lds + (rswb + (xswb ^ ((ks + 1) << 5)));
-            bq[(ks + 1) & 1][0][0] = lds128(bp, 0);
-            bq[(ks + 1) & 1][0][1] = lds128(bp, 256);
-          }
-          mma_step<MT, 1>(acc, a[ks & 1], bq[ks & 1]);
-          __builtin_amdgcn_sched_barrier(0);
+          GM_PIN();
         }
         GM_STAMP(12);
         // masked softmax of row i = cw over its edges j (graphML.py:1771-1776): in-lane over the MT * 16 accumulator
         // registers, one exchange with the partner lane (the other 4-row halves of the same column).  Entries without an
         // edge become -inf by a bit-field insert under the sign-extended mask bit; exp2(-inf) = 0 needs no select.
+        // tap K - 2 under the softmax: TAP_ALL = 24 MT MFMAs = one per four entries of the two passes + four per row group
         float mx = -__builtin_inff();
         unsigned mkl[4] = {mk[0], mk[1], mk[2], mk[3]};      // (laundered: the per-entry masks are formed here, per head)
         asm volatile("" : "+v"(mkl[0]), "+v"(mkl[1]), "+v"(mkl[2]), "+v"(mkl[3]));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)mkl[mt], 8 * (r >> 2) + (r & 3), 1);
-            const float ev = acc[0][mt][r];      // (a scalar copy: bit-casting the vector element itself reads element 0)
-            const unsigned u = (__builtin_bit_cast(unsigned, ev) & m) | (0xff800000u & ~m);
-            const float em = __builtin_bit_cast(float, u);
-            acc[0][mt][r] = em;
-            mx = fmaxf(mx, em);
+          for (int q = 0; q < 4; ++q) {      // (one MFMA of tap K - 2 per four entries)
+            tap_one(KT - 2, (mt * 4 + q) * TAP_ALL / (24 * MT));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * q + e;
+              const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)mkl[mt], 8 * (r >> 2) + (r & 3), 1);
+              const float ev = acce[0][mt][r];      // (a scalar copy: bit-casting the vector element itself reads element 0)
+              const unsigned u = (__builtin_bit_cast(unsigned, ev) & m) | (0xff800000u & ~m);
+              const float em = __builtin_bit_cast(float, u);
+              acce[0][mt][r] = em;
+              mx = fmaxf(mx, em);
+            }
+            GM_PIN();
           }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         constexpr float kLog2e = 1.4426950408889634f;
@@ -383,103 +474,67 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            acc[0][mt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[0][mt][r], kLog2e, cexp));
-            sum += acc[0][mt][r];
+          for (int q = 0; q < 4; ++q) {
+            tap_one(KT - 2, (4 * MT + mt * 4 + q) * TAP_ALL / (24 * MT));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * q + e;
+              acce[0][mt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(acce[0][mt][r], kLog2e, cexp));
+              sum += acce[0][mt][r];
+            }
+            GM_PIN();
           }
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = sum > 0.f ? 256.f / sum : 0.f;
+        const float inv = sum > 0.f ? 256.f / sum : 0.f;      // (A planes carry 2^8: the hops add to accumulators that hold 2^8 U_k)
         GM_STAMP(13);
-        if (cw < KI) {
-          char* ab = lds + (AO + 4 * h * SA + cw * 2);
-          char* al = ab + AP;
-          const f32x2 sc = {inv, inv};
-          unsigned ha[MT][4][2], la[MT][4][2];
+        {
+          // (lanes past the KI columns of A store into the 8 pad columns of the row: nothing reads them)
+          char* abp = lds + (AO + 4 * h * SA + min(cw, KI + 7) * 2);
+          char* alp = abp + AP;
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const f32x2 v01 = f32x2{acc[0][mt][4 * q], acc[0][mt][4 * q + 1]} * sc;
-              const f32x2 v23 = f32x2{acc[0][mt][4 * q + 2], acc[0][mt][4 * q + 3]} * sc;
-              split_pair(v01[0], v01[1], ha[mt][q][0], la[mt][q][0]);
-              split_pair(v23[0], v23[1], ha[mt][q][1], la[mt][q][1]);
-            }
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
+              const int t0 = (8 * MT + (mt * 4 + q) * 4) * TAP_ALL / (24 * MT);      // four MFMAs of tap K - 2 per row group
+              unsigned ha[2], la[2];
+              tap_one(KT - 2, t0);
+              // (single multiplies on purpose: v_pk_mul_f32 does not run under an MFMA of the same wave - tools/exp/mfma_valu.hip)
+              const float v01[2] = {mul1(acce[0][mt][4 * q], inv), mul1(acce[0][mt][4 * q + 1], inv)};
+              const float v23[2] = {mul1(acce[0][mt][4 * q + 2], inv), mul1(acce[0][mt][4 * q + 3], inv)};
+              GM_PIN();
+              tap_one(KT - 2, t0 + 1);
+              split_pair(v01[0], v01[1], ha[0], la[0]);
+              GM_PIN();
+              tap_one(KT - 2, t0 + 2);
+              split_pair(v23[0], v23[1], ha[1], la[1]);
+              GM_PIN();
+              tap_one(KT - 2, t0 + 3);
               const int jg = 32 * mt + 8 * q;
-              if (jg >= N) break;
-              const unsigned short hv[4] = {(unsigned short)ha[mt][q][0], (unsigned short)(ha[mt][q][0] >> 16),
-                                            (unsigned short)ha[mt][q][1], (unsigned short)(ha[mt][q][1] >> 16)};
-              const unsigned short lv[4] = {(unsigned short)la[mt][q][0], (unsigned short)(la[mt][q][0] >> 16),
-                                            (unsigned short)la[mt][q][1], (unsigned short)(la[mt][q][1] >> 16)};
-              if (jg + 8 <= N) {
+              const unsigned short hv[4] = {(unsigned short)ha[0], (unsigned short)(ha[0] >> 16), (unsigned short)ha[1],
+                                            (unsigned short)(ha[1] >> 16)};
+              const unsigned short lv[4] = {(unsigned short)la[0], (unsigned short)(la[0] >> 16), (unsigned short)la[1],
+                                            (unsigned short)(la[1] >> 16)};
+              GM_PIN();
+              if (jg < N) {                                         // (wave-uniform)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  GM_AW(ab + (jg + e) * SA, hv[e]);
-                  GM_AW(al + (jg + e) * SA, lv[e]);
+                  GM_AW(abp + (jg + e) * SA, hv[e]);
+                  GM_AW(alp + (jg + e) * SA, lv[e]);
                 }
-              } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  if (jg + 4 * h + e < N) {
-                    *reinterpret_cast<unsigned short*>(ab + (jg + e) * SA) = hv[e];
-                    *reinterpret_cast<unsigned short*>(al + (jg + e) * SA) = lv[e];
-                  }
               }
             }
         }
+      } else {      // (a wave without columns of A: the second half of G3 on its own)
+#pragma unroll
+        for (int i = 0; i < TAP_ALL; ++i) tap_one(KT - 2, i);
       }
       GM_STAMP(4);
-      // ---- G3: U_k[i][c] for the K taps, weights H_pk streamed one k step ahead
-      f32x16 acc[KT][MT];
-#pragma unroll
-      for (int k = 0; k < KT; ++k)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[k][mt][r] = 0.f;
-      {
-        GM_FRESH(rsw, rsw_) GM_FRESH(xsw, xsw_)
-        const char* s = wl + (size_t)(p.P + hd * KT) * 65536;
-        uint4 a[2][MT][2], bw[2][KT][2];
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-          bw[0][k][0] = *reinterpret_cast<const uint4*>(s + (size_t)k * 65536);
-          bw[0][k][1] = *reinterpret_cast<const uint4*>(s + (size_t)k * 65536 + 1024);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const char* ap = lds + (rsw[mt] + xsw[mt]);
-          a[0][mt][0] = lds128(ap, 0);
-          a[0][mt][1] = lds128(ap, 256);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          if (ks + 1 < 8) {
-#pragma unroll
-            for (int k = 0; k < KT; ++k) {
-              bw[(ks + 1) & 1][k][0] = *reinterpret_cast<const uint4*>(s + (size_t)k * 65536 + (ks + 1) * 2048);
-              bw[(ks + 1) & 1][k][1] = *reinterpret_cast<const uint4*>(s + (size_t)k * 65536 + (ks + 1) * 2048 + 1024);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              const char* ap = lds + (rsw[mt] + (xsw[mt] ^ ((ks + 1) << 5)));
-              a[(ks + 1) & 1][mt][0] = lds128(ap, 0);
-              a[(ks + 1) & 1][mt][1] = lds128(ap, 256);
-            }
-          }
-          mma_step<MT, KT>(acc, a[ks & 1], bw[ks & 1]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
       GM_STAMP(5);
       GM_SYNC();      // Q is dead everywhere, the A planes are complete
       GM_STAMP(6);
       // ---- hops: acc_k += A^T U_{k+1}; the U^T rows of this wave's c tile are written and read by this wave only
-#pragma unroll
-      for (int k = KT - 2; k >= 0; --k) {
+      auto hop = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
         // U^T planes [c][i] <- acc_{k+1} 2^-8: a lane holds column c = cw, 4 consecutive i per register quad
         char* ub = lds + (UO + cw * SA + h * 8);       // (+ 4 h rows of the quad: 8 bytes)
 #pragma unroll
@@ -488,18 +543,25 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
           for (int q = 0; q < 4; ++q) {
             const int i0 = 32 * mt + 8 * q;      // + 4 h
             if (i0 < KI) {                        // (KI is a multiple of 16: both 4-row halves are inside or outside)
+              // (K = 3: tap 0, half under each hop's plane conversion; the last hop's product needs it complete)
+              constexpr int NG2 = KI / 4;      // row groups of both hops
+              const int gi = (k == 1 ? 0 : KI / 8) + mt * 4 + q;
+              const int u0 = TAP_ALL * gi / NG2, u1 = TAP_ALL * (gi + 1) / NG2, um = (u0 + u1) / 2;
               uint2 hi, lo;
-              const f32x2 sc = {kInvScale, kInvScale};
-              const f32x2 v01 = f32x2{acc[k + 1][mt][4 * q], acc[k + 1][mt][4 * q + 1]} * sc;
-              const f32x2 v23 = f32x2{acc[k + 1][mt][4 * q + 2], acc[k + 1][mt][4 * q + 3]} * sc;
+              if constexpr (KT == 3) tap_upto4(0, u0, um);
+              const float v01[2] = {mul1(acc[k + 1][mt][4 * q], kInvScale), mul1(acc[k + 1][mt][4 * q + 1], kInvScale)};
               split2v(v01[0], v01[1], hi.x, lo.x, vmax);
+              GM_PIN();
+              if constexpr (KT == 3) tap_upto4(0, um, u1);
+              const float v23[2] = {mul1(acc[k + 1][mt][4 * q + 2], kInvScale), mul1(acc[k + 1][mt][4 * q + 3], kInvScale)};
               split2v(v23[0], v23[1], hi.y, lo.y, vmax);
+              GM_PIN();
               *reinterpret_cast<uint2*>(ub + i0 * 2) = hi;
               *reinterpret_cast<uint2*>(ub + (i0 * 2 + UP)) = lo;
             }
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's own rows: no barrier
-        GM_FRESH(rpa, rpa_)
+        GM_AROWS(rpa)
         const char* up = lds + (UO + cw * SA + h * 16);
         const char* apl[MT];
 #pragma unroll
@@ -527,7 +589,9 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
           __builtin_amdgcn_sched_barrier(0);
         }
         GM_STAMP(7 + (KT - 2 - k));
-      }
+      };
+      if constexpr (KT == 3) hop(std::integral_constant<int, 1>{});
+      hop(std::integral_constant<int, 0>{});
       // ---- epilogue: Y rows j = 32 mt + 8 q + 4 h + e, column c = cw: a wave-uniform row pointer per register and ONE
       // per-lane byte offset (scalar base + 32-bit vector offset addressing)
       {
@@ -574,11 +638,11 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
 }
 
 size_t gat_mfma_lds(int N, int ksi) {
-  const size_t sa = 2 * 16 * (size_t)ksi + 16;
-  return 2 * (size_t)N * 256 + 2 * (size_t)N * sa + 2 * 128 * sa + 16 * (size_t)N;
+  const size_t sa = 2 * 16 * (size_t)ksi + 16, r8 = ((size_t)N + 7) & ~(size_t)7;
+  return 2 * (size_t)N * 256 + 2 * r8 * sa + 2 * 128 * sa;
 }
 
-// shape classes: (MT, KSI) = (1, 2) N <= 32, (2, 4) N <= 64, (4, 7) N <= 101 (the LDS bound)
+// shape classes: (MT, KSI) = (1, 2) N <= 32, (2, 4) N <= 64, (4, 7) N <= 102 (the LDS bound)
 int gat_mfma_class(int N) {
   if (N <= 0) return -1;
   const int c = N <= 32 ? 0 : (N <= 64 ? 1 : 2);

@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 def _layer_and_inputs(B, N, K, P, concat, seed, density=None, bias=True):
     from magat_pathplanning_amd import GraphFilterBatchAttentional
     from magat_pathplanning_amd.synthetic import comm_gso, random_gso
+    torch.manual_seed(1000 + seed)          # (the layer's initialisation draws from the global generator)
     g = torch.Generator().manual_seed(seed)
     G = 128
     layer = GraphFilterBatchAttentional(G, G, K, P, bias=bias, concatenate=concat, attentionMode="KeyQuery")
@@ -78,7 +79,7 @@ def test_gat_mfma_many_instances_per_workgroup(gpu_device):
 
 
 def test_gat_mfma_range_guard_reruns_in_float32(gpu_device):
-    """Features beyond the f16 range: the fused kernel clamps and raises the flag, the predicated float32 two-launch form
+    """Features beyond the f16 range: the fused kernel raises the flag, the predicated float32 two-launch form
     re-writes Y in the same stream (magat_hip.h, range guard)."""
     from oracle import magat_oracle as orc
     from magat_pathplanning_amd.graphml import gat_forward_rows
@@ -86,8 +87,12 @@ def test_gat_mfma_range_guard_reruns_in_float32(gpu_device):
     layer, S, x = _layer_and_inputs(B, N, K, P, True, seed=21)
     x[1, 5, 7] = 9.0e4
     with torch.no_grad():
+        # scores through a 9e4 feature are ill-conditioned in float32 on ANY path (their differences sit below the float32
+        # resolution at that magnitude): the key / query weights are scaled far down so that the comparison tests the
+        # re-run, not the conditioning of the softmax
         for prm in layer.parameters():
             prm.mul_(0.05)
+        layer.weight.mul_(1e-6)
     y_ref, _ = orc.gat_layer_forward(x, S.unsqueeze(1), {k: v.detach() for k, v in layer.state_dict().items()},
                                      "KeyQuery", True)
     layer = layer.to(gpu_device).eval()

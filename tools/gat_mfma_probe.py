@@ -42,6 +42,7 @@ for wv in range(4):
         seg = dd[:, b_] - dd[:, a]
         print("   %-30s mean %8.0f  p10 %8.0f  p90 %8.0f" % (names[b_], seg.mean().item(), seg.quantile(0.1).item(), seg.quantile(0.9).item()))
     if wv == 0:
+        print("   instance prologue (X planes, masks, barrier): %.0f cycles" % (dd[:, 15] - dd[:, 14]).mean().item())
         print("   (G1 product %.0f | Q planes %.0f;  G2 product %.0f | softmax %.0f | A planes %.0f)" % (
             (dd[:, 11] - dd[:, 1]).mean().item(), (dd[:, 2] - dd[:, 11]).mean().item(), (dd[:, 12] - dd[:, 3]).mean().item(),
             (dd[:, 13] - dd[:, 12]).mean().item(), (dd[:, 4] - dd[:, 13]).mean().item()))
