@@ -33,7 +33,7 @@ def short(name):
                    ("block_chain_w4_kernel", "block_chain_w4(layer1.conv2+layer2)"), ("block3_w4_kernel", "block3_w4(layer3+pool)"),
                    ("block_full_w4_kernel", "block_full_w4(layer1.conv2+layer2+layer3+pool)"),
                    ("gat_guard_count_kernel", "guard_count(gat)"), ("guard_count_kernel", "guard_count(encoder)"),
-                   ("gat_dense_kernel", "gat_dense_kernel"), ("head_mean_relu", "head_mean_relu"),
+                   ("gat_mfma_kernel", "gat_mfma(one-launch KeyQuery layer)"), ("gat_dense_kernel", "gat_dense_kernel"), ("head_mean_relu", "head_mean_relu"),
                    ("pack_kernel", "gat_pack"), ("gso_prepare", "gso_prepare")):
         if key in name:
             return s
@@ -76,16 +76,16 @@ def main():
             lines.append("%-28s launches=%5d avg_KiB=%14.1f" % (k, n, tot / n))
             res["kernels"].setdefault(k, {})[ctr + "_KiB_per_launch"] = tot / n
     # per-layer split: the library launches a fixed kernel sequence per addGSO+forward step (c3 workload, default options:
-    # fused stem, the chain kernels as one launch, range guard on).  "guard:*" entries are the predicated float32 re-run
-    # launches of the range guard (no-ops while nothing clamps).
+    # fused stem, the chain kernels as one launch, the GAT layer as one launch, range guard on).  "guard:*" entries are the
+    # predicated float32 re-run launches of the range guard (no-ops while nothing clamps).
     SEQ = ["conv_first+layer1.conv1 (fused)", "layer1.conv2+layer2+layer3 (fused, pooled)",
            "head(avgpool+fc+linear)", "compressMLP",
            "guard:conv_first", "guard:layer1.conv1", "guard:layer1.conv2", "guard:layer2.conv1", "guard:layer2.conv2",
            "guard:layer3.conv1", "guard:layer3.conv2", "guard:head", "guard:compress", "guard:count",
-           "gat_maps_gemm", "guard:gat_maps", "guard:gat_count", "gat_graph", "actionsMLP"]
+           "gat_layer (one launch)", "guard:gat_maps", "guard:gat_graph", "guard:gat_count", "actionsMLP"]
     ours = ("conv_gemm_kernel", "conv_gemm_bf16x6_kernel", "conv_gemm_f16x3_direct_kernel", "conv_first_kernel",
             "layer1_fused_kernel", "gat_dense_kernel", "block_chain_kernel", "block3_kernel", "block_chain_w4_kernel",
-            "block3_w4_kernel", "block_full_w4_kernel", "guard_count_kernel")
+            "block3_w4_kernel", "block_full_w4_kernel", "guard_count_kernel", "gat_mfma_kernel")
     layers = defaultdict(dict)
     tr = find(os.path.join(out, "trace"), "*kernel_trace.csv")
     if tr:
