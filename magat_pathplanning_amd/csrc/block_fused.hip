@@ -94,8 +94,13 @@ __device__ __forceinline__ void split2(float x, float y, unsigned& p1, unsigned&
   x = __builtin_amdgcn_fmed3f(x, 0.f, 65504.f);
   y = __builtin_amdgcn_fmed3f(y, 0.f, 65504.f);
   const f16x2 h = __builtin_convertvector(f32x2{x, y}, f16x2);
-  const f16x2 r = __builtin_convertvector(f32x2{x - (float)h[0], y - (float)h[1]}, f16x2);
   p1 = __builtin_bit_cast(unsigned, h);
+  // residual x - hi: one mixed-precision fma per value (fma(hi, -1, x), exact; the f16 operand read from its half of the
+  // packed register) instead of two conversions and a packed subtract
+  float rx, ry;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rx) : "v"(p1), "v"(x));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ry) : "v"(p1), "v"(y));
+  const f16x2 r = __builtin_convertvector(f32x2{rx, ry}, f16x2);
   p2 = __builtin_bit_cast(unsigned, r);
 }
 
