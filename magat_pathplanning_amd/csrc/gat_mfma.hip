@@ -41,6 +41,7 @@ struct GatMfmaParams {
   const float* bias;          // [128] or null
   float* Y;                   // [B*N][ldy]; concat: head p at column 128 p
   int B, N, P, ldx, ldy, concat, s_is_f64;
+  int hsplit;                 // 1, or P (small batches, concat): a workgroup per (instance, head) instead of per instance
   int* range_flag;
   long long* dbg;             // MAGAT_DEBUG_HOOKS builds: [grid][4 waves][16] cycle stamps of the last head walked
 };
@@ -172,10 +173,14 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
   // the last head prefetches head 0's).  A fragment is requested when the k step four ahead of it retires its slot: three
   // k steps (>= 1100 cycles) of slack for an L2 hit, 8 registers per fragment instead of a whole tap held a phase ahead.
   constexpr int FPH = 8 * (1 + KT);      // fragments per head (a multiple of the ring depth)
+  // this workgroup's heads [hlo, hhi) and instances b0, b0 + bstride, ... (hsplit = P: one head, for batches that would
+  // leave most of the chip idle - the closed-loop step of a single planning instance)
+  const int hpw = p.P / p.hsplit, hlo = ((int)blockIdx.x % p.hsplit) * hpw, hhi = hlo + hpw;
+  const int b0 = (int)blockIdx.x / p.hsplit, bstride = (int)gridDim.x / p.hsplit;
   uint4 wr[4][2];
   auto wr_load = [&](int hd_, int f) {      // f: static position in the stream of head hd_ (f >= FPH: the next head's)
     int hh = hd_;
-    if (f >= FPH) { hh = hd_ + 1 == p.P ? 0 : hd_ + 1; f -= FPH; }
+    if (f >= FPH) { hh = hd_ + 1 == hhi ? hlo : hd_ + 1; f -= FPH; }
     const int ks = f & 7;
     const char* s = f < 8 ? wl + (size_t)hh * 65536
                           : wl + (size_t)(p.P + hh * KT + (KT - 1 - (f - 8) / 8)) * 65536;
@@ -183,12 +188,12 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
     wr[f & 3][1] = *reinterpret_cast<const uint4*>(s + ks * 2048 + 1024);
   };
 #pragma unroll
-  for (int f = 0; f < 4; ++f) wr_load(0, f);
+  for (int f = 0; f < 4; ++f) wr_load(hlo, f);
 
-  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+  for (int b = b0; b < p.B; b += bstride) {
     // ---- instance prologue: X rows -> f16 planes; edge masks
     GM_STAMP(14);
-    if (b != (int)blockIdx.x) GM_SYNC();      // (the previous instance's last hops still read the X planes: tap 0 runs under them)
+    if (b != b0) GM_SYNC();      // (the previous instance's last hops still read the X planes: tap 0 runs under them)
     {
       // (all of a thread's loads first - at most 7 x 32 bytes for N <= 112 - then the conversions: one memory latency)
       const float* Xb = p.X + (long long)b * N * p.ldx;
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
     }
 
 #pragma unroll 1
-    for (int hd = 0; hd < p.P; ++hd) {
+    for (int hd = hlo; hd < hhi; ++hd) {
       GM_STAMP(0);
       // lane-derived values are laundered per head: the per-element plane addresses below are recomputed where they are
       // used (a few VALU ops) instead of being hoisted out of the head loop into hundreds of long-lived registers
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
         for (int j = 0; j < 4; ++j)
           if (lo + j < hi) tap_one(k, lo + j);
       };
-      if (hd > 0) GM_SYNC();      // the previous head's reads of the U^T / A planes are done
+      if (hd > hlo) GM_SYNC();      // the previous head's reads of the U^T / A planes are done
       GM_STAMP(1);
       // ---- G1: Q[j][g]
       {
@@ -667,10 +672,12 @@ int launch(const GatMfmaParams& p, int slot, hipStream_t st) {
       cached_cus = 256;
   }
   cus = cached_cus;
-  const int blocks = p.B < cus ? p.B : cus;
+  GatMfmaParams q = p;
+  q.hsplit = (p.concat && p.B * p.P <= cus) ? p.P : 1;      // (the head mean is summed in one workgroup's registers: no split)
+  const int blocks = q.hsplit > 1 ? p.B * p.P : (p.B < cus ? p.B : cus);
   const int pid = magat_prof_begin(MAGAT_TAG_GAT_LAYER, st);
-  if (p.concat) hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, true>), dim3(blocks), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, false>), dim3(blocks), dim3(256), lds, st, p);
+  if (p.concat) hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, true>), dim3(blocks), dim3(256), lds, st, q);
+  else hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, false>), dim3(blocks), dim3(256), lds, st, q);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
@@ -694,6 +701,7 @@ int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64,
   p.wfrag = reinterpret_cast<const char*>(packed_frag);
   p.bias = bias; p.Y = Y; p.ldy = ldy; p.B = B; p.N = N; p.P = P; p.concat = concat; p.range_flag = range_flag;
   p.dbg = nullptr;
+  p.hsplit = 1;
 #ifdef MAGAT_DEBUG_HOOKS
   p.dbg = g_gat_mfma_dbg;
 #endif
