@@ -661,17 +661,11 @@ int launch(const GatMfmaParams& p, int slot, hipStream_t st) {
   const void* fn = p.concat ? reinterpret_cast<const void*>(&gat_mfma_kernel<MT, KSI, KT, true>)
                             : reinterpret_cast<const void*>(&gat_mfma_kernel<MT, KSI, KT, false>);
   if (magat_ensure_dyn_lds(fn, slot + (p.concat ? 0 : 6), lds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
-  int cus = 256;
-  hipDeviceProp_t prop;
-  int dev = 0;
-  static int cached_cus = 0;
-  if (!cached_cus) {
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      cached_cus = prop.multiProcessorCount;
-    else
-      cached_cus = 256;
-  }
-  cus = cached_cus;
+  // compute units of the CURRENT device (a cheap attribute query, no cached process-wide value: one process may drive several)
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
   GatMfmaParams q = p;
   q.hsplit = (p.concat && p.B * p.P <= cus) ? p.P : 1;      // (the head mean is summed in one workgroup's registers: no split)
   const int blocks = q.hsplit > 1 ? p.B * p.P : (p.B < cus ? p.B : cus);
