@@ -203,6 +203,7 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
   const int ty0 = iy0 < 0 ? 1 : 0, ty1 = min(3, p.H - iy0);
   constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};     // h1g1 h1g2 h2g1 (activation plane, weight plane)
 
+  u32x4 qkeep[3][2][2];      // stem column 2 ox + 1 (rows iy0 .. iy0 + 2) as layer1.conv1 operand planes: next pixel's tap column 0
   for (int ox = ox_lo; ox < ox_hi; ++ox) {
     const int ix0 = 2 * ox - 1;
     const int tx0 = ix0 < 0 ? 1 : 0, tx1 = min(3, p.W - ix0);
@@ -213,74 +214,90 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
     for (int r = 0; r < 16; ++r) acc1[r] = acc1b[r] = 0.f;
     bool clamped = false;
 
-    for (int ty = ty0; ty < ty1; ++ty)
-      for (int tx = tx0; tx < tx1; ++tx) {
-        // window index of the 3x3 patch's corner: row ty (= stem row iy0 + ty - 1), column ix0 + tx - 1 (>= -1)
-        const unsigned* wp = wbase + 1 + ty * RW + (ix0 + tx - 1);
-        // 1. im2col row of the tap pixel: 16 packed (plane 0 | plane 1) dwords -> the two f16 operand planes by v_perm;
-        //    slot k = 27 (a zero-weight padding slot of the 27-wide row) carries the constant 1.0 against the bias
-        u32x4 pb[2][2];
+    // Taps (ty, tx) of the stride-2 window, fully unrolled with wave-uniform validity tests.  Consecutive output pixels of a
+    // wave share a stem column (2 ox + 1 is tap column 2 of pixel ox and tap column 0 of pixel ox + 1): its three stem
+    // pixels' operand planes are kept in registers (`qkeep`) instead of being recomputed - 6 of a wave's 27 stem products.
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          unsigned pv[8];
+    for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) pv[i] = wp[koff[ks][i]];
-          if (ks == 1) pv[3] = fh ? 0x00003C00u : pv[3];
-          unsigned h1[4], h2[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            h1[e] = __builtin_amdgcn_perm(pv[2 * e + 1], pv[2 * e], 0x05040100u);
-            h2[e] = __builtin_amdgcn_perm(pv[2 * e + 1], pv[2 * e], 0x07060302u);
-          }
-          pb[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
-          pb[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
-        }
-        // 2. stem (+ bias): D[channel][agent] = 16 (w . x + b)
-        f32x16 acc0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[ks][PB[q]]),
-                                                          __builtin_bit_cast(f16x8, pb[ks][PA[q]]), acc0, 0, 0, 0);
-        // 3. ReLU (the lower bound of the f16 clamp) -> f16 planes = layer1.conv1's operand of this tap (quads 2 ks,
-        //    2 ks + 1 -> k step ks), still 16x
-        {
-          float mx = acc0[0];
-#pragma unroll
-          for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc0[r]);
-          clamped |= mx > 65504.f;                       // stem output beyond 4094: outside what the 16x form carries
-        }
+      for (int tx = 0; tx < 3; ++tx) {
+        if (ty < ty0 || ty >= ty1 || tx < tx0 || tx >= tx1) continue;      // (wave-uniform)
         u32x4 qa[2][2];
+        const bool reuse = tx == 0 && ox > ox_lo;                            // (wave-uniform; ox > ox_lo implies ix0 >= 1)
+        if (reuse) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          unsigned h1[4], h2[4];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int g = 2 * ks + e;
-            split2_relu(acc0[4 * g], acc0[4 * g + 1], h1[2 * e], h2[2 * e]);
-            split2_relu(acc0[4 * g + 2], acc0[4 * g + 3], h1[2 * e + 1], h2[2 * e + 1]);
+          for (int ks = 0; ks < 2; ++ks) { qa[ks][0] = qkeep[ty][ks][0]; qa[ks][1] = qkeep[ty][ks][1]; }
+        } else {
+          // window index of the 3x3 patch's corner: row ty (= stem row iy0 + ty - 1), column ix0 + tx - 1 (>= -1)
+          const unsigned* wp = wbase + 1 + ty * RW + (ix0 + tx - 1);
+          // 1. im2col row of the tap pixel: 16 packed (plane 0 | plane 1) dwords -> the two f16 operand planes by v_perm;
+          //    slot k = 27 (a zero-weight padding slot of the 27-wide row) carries the constant 1.0 against the bias
+          u32x4 pb[2][2];
+  #pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            unsigned pv[8];
+  #pragma unroll
+            for (int i = 0; i < 8; ++i) pv[i] = wp[koff[ks][i]];
+            if (ks == 1) pv[3] = fh ? 0x00003C00u : pv[3];
+            unsigned h1[4], h2[4];
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              h1[e] = __builtin_amdgcn_perm(pv[2 * e + 1], pv[2 * e], 0x05040100u);
+              h2[e] = __builtin_amdgcn_perm(pv[2 * e + 1], pv[2 * e], 0x07060302u);
+            }
+            pb[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
+            pb[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
           }
-          qa[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
-          qa[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
-        }
-        if (ty == 1 && tx == 1 && m < p.M) {             // stem pixel (2 oy, 2 ox): the residual branch's input, unscaled
-          char* o = static_cast<char*>(p.ctr) + tile_off;
-#pragma unroll
+          // 2. stem (+ bias): D[channel][agent] = 16 (w . x + b)
+          f32x16 acc0;
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+  #pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+  #pragma unroll
+            for (int q = 0; q < 3; ++q)
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[ks][PB[q]]),
+                                                            __builtin_bit_cast(f16x8, pb[ks][PA[q]]), acc0, 0, 0, 0);
+          // 3. ReLU (the lower bound of the f16 clamp) -> f16 planes = layer1.conv1's operand of this tap (quads 2 ks,
+          //    2 ks + 1 -> k step ks), still 16x
+          {
+            float mx = acc0[0];
+  #pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc0[r]);
+            clamped |= mx > 65504.f;                       // stem output beyond 4094: outside what the 16x form carries
+          }
+  #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             unsigned h1[4], h2[4];
-#pragma unroll
+  #pragma unroll
             for (int e = 0; e < 2; ++e) {
               const int g = 2 * ks + e;
-              split2_relu(acc0[4 * g] * (1.f / W0_SCALE), acc0[4 * g + 1] * (1.f / W0_SCALE), h1[2 * e], h2[2 * e]);
-              split2_relu(acc0[4 * g + 2] * (1.f / W0_SCALE), acc0[4 * g + 3] * (1.f / W0_SCALE), h1[2 * e + 1],
-                          h2[2 * e + 1]);
+              split2_relu(acc0[4 * g], acc0[4 * g + 1], h1[2 * e], h2[2 * e]);
+              split2_relu(acc0[4 * g + 2], acc0[4 * g + 3], h1[2 * e + 1], h2[2 * e + 1]);
             }
-            *reinterpret_cast<u32x4*>(o + ks * 4096) = u32x4{h1[0], h1[1], h1[2], h1[3]};
-            *reinterpret_cast<u32x4*>(o + 256 * 32 + ks * 4096) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+            qa[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
+            qa[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
           }
+          if (ty == 1 && tx == 1 && m < p.M) {             // stem pixel (2 oy, 2 ox): the residual branch's input, unscaled
+            char* o = static_cast<char*>(p.ctr) + tile_off;
+  #pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              unsigned h1[4], h2[4];
+  #pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const int g = 2 * ks + e;
+                split2_relu(acc0[4 * g] * (1.f / W0_SCALE), acc0[4 * g + 1] * (1.f / W0_SCALE), h1[2 * e], h2[2 * e]);
+                split2_relu(acc0[4 * g + 2] * (1.f / W0_SCALE), acc0[4 * g + 3] * (1.f / W0_SCALE), h1[2 * e + 1],
+                            h2[2 * e + 1]);
+              }
+              *reinterpret_cast<u32x4*>(o + ks * 4096) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+              *reinterpret_cast<u32x4*>(o + 256 * 32 + ks * 4096) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+            }
+          }
+        }
+        if (tx == 2) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) { qkeep[ty][ks][0] = qa[ks][0]; qkeep[ty][ks][1] = qa[ks][1]; }
         }
         // 4. layer1.conv1 tap product
         const char* wt = Ws + (ty * 3 + tx) * 4096;
