@@ -74,25 +74,30 @@ constexpr float W0_SCALE = 16.f;    // stem weights (and bias) are split as plan
                                     // too large (exact; saturates beyond 4094) and layer1.conv1's scale undoes it
 constexpr int MAXV = 4;             // 16-byte loads per image row: W <= 16 (the LDS windows fit up to W = 15)
 
-// Workgroup = (128 agents) x (one OUTPUT ROW of layer1.conv1), 8 waves: wave -> 32 agents x half of the row's pixels.
-// LDS: all nine taps of the layer1.conv1 weights (36 KB) + the agents' 5-row input windows:
+// Workgroup = (64 agents) x (one OUTPUT ROW of layer1.conv1), 4 waves: wave -> 32 agents x half of the row's pixels; TWO
+// workgroups per CU (78 KB of LDS each at W = 11), so that one stages its windows - an HBM round trip, 70 of the kernel's
+// 290 us when exposed - while the other computes (the 128-agent / 8-wave form fitted once per CU).
+// LDS: eight taps of the layer1.conv1 weights (32 KB; the centre tap's fragments stay in registers: with all nine the two
+// workgroups miss the CU's 160 KB by 4.6 KB) + the agents' 5-row input windows:
 //   per agent  [0] | channel c: 5 rows of (W values, 0)      (stride WSTR dwords, odd: agents on distinct banks)
 // the trailing zero of a row is also column -1 of the next row (and [0] that of the first), so the stem's zero padding
 // needs no index tests.  Every value is stored SPLIT, as one dword (plane-0 half | plane-1 half << 16): a window value is
 // used by up to nine stem taps of up to three output pixels, so it is split once here, and a tap builds its MFMA operand
 // with one v_perm per two values.  Staging cost is paid once per 128 x Wo output pixels.
-__global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) {
+constexpr int L1_AG = 64;           // agents per workgroup
+__global__ __launch_bounds__(256, 2) void layer1_fused_kernel(const L1Params p) {
   extern __shared__ __attribute__((aligned(1024))) char l1smem[];
   char* const Ws = l1smem;                                           // layer1.conv1 weights: [tap][plane][32 rows][64 B]
-  unsigned* const win = reinterpret_cast<unsigned*>(l1smem + 9 * 4096);
+  unsigned* const win = reinterpret_cast<unsigned*>(l1smem + 8 * 4096);
 
   const int RW = p.W + 1, RB = 5 * RW, WSTR = (1 + 3 * RB) | 1;
   const int bid = blockIdx.x;
   const int xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
-  const int mtile = xcd + MAGAT_NUM_XCD * (slot / p.Ho);
+  const int mtile = xcd + MAGAT_NUM_XCD * (slot / (2 * p.Ho));      // 128-agent tile of the output layout
   if (mtile >= p.Mt) return;
+  const int sub = (slot / p.Ho) & 1;                                 // which 64 agents of the tile
   const int oy = slot % p.Ho;
-  const int m0 = mtile * 128;
+  const int m0 = mtile * 128 + sub * L1_AG;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int fr = lane & 31, fh = lane >> 5;
@@ -102,8 +107,8 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
   // layer1.conv1 weights, every tap: 36 pieces of 1 KB (16 rows x 64 B of one plane and tap), LDS-direct
   {
     const char* wb = reinterpret_cast<const char*>(p.w1);
-    for (int id = wave; id < 36; id += 8) {              // (tap * 2 + plane) * 2 + row half
-      const int tap = id >> 2, plane = (id >> 1) & 1, row = (id & 1) * 16 + (lane >> 2);
+    for (int id = wave; id < 32; id += 4) {              // (slot * 2 + plane) * 2 + row half; slot = tap, skipping tap 4
+      const int tap = (id >> 2) + ((id >> 2) >= 4 ? 1 : 0), plane = (id >> 1) & 1, row = (id & 1) * 16 + (lane >> 2);
       const int c = (lane & 3) ^ ((row >> 2) & 3);
       const char* src = wb + ((long long)plane * 32 * 288 + row * 288 + tap * 32 + c * 8) * 2;
       const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Ws + (unsigned)id * 1024u);
@@ -117,15 +122,15 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
     typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
     const int HW = p.H * p.W;
     const int nv = (p.W + 3) / 4;
-    constexpr int NIT = (128 * 15 + 511) / 512;          // 4 rows per thread
+    constexpr int NIT = (L1_AG * 15 + 255) / 256;        // 4 rows per thread
     f32x4 v4[NIT][MAXV];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int item = t + 512 * i;
+      const int item = t + 256 * i;
       const int a = item / 15, r = item - a * 15;
       const int c = r / 5, wy = r - c * 5;
       const int iy = 2 * oy - 2 + wy;
-      const bool ok = item < 128 * 15 && m0 + a < p.M && iy >= 0 && iy < p.H;
+      const bool ok = item < L1_AG * 15 && m0 + a < p.M && iy >= 0 && iy < p.H;
       const float* row = p.x + (long long)(m0 + a) * 3 * HW + c * HW + iy * p.W;
 #pragma unroll
       for (int j = 0; j < MAXV; ++j) {
@@ -133,12 +138,12 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
         if (ok && j < nv) v4[i][j] = *reinterpret_cast<const f32x4_u*>(row + min(4 * j, p.W - 4));
       }
     }
-    for (int i = t; i < 128; i += 512) win[i * WSTR] = 0u;
+    for (int i = t; i < L1_AG; i += 256) win[i * WSTR] = 0u;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int item = t + 512 * i;
+      const int item = t + 256 * i;
       const int a = item / 15, r = item - a * 15;
-      if (item < 128 * 15) {
+      if (item < L1_AG * 15) {
         unsigned* dst = win + a * WSTR + 1 + r * RW;
 #pragma unroll
         for (int j = 0; j < MAXV; ++j) {
@@ -185,19 +190,25 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
     wa[ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
     wa[ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
   }
-  f32x4 bq1[4];
+  // centre tap (ty = tx = 1) of layer1.conv1: this lane's weight fragments straight from global memory (the LDS copy's layout:
+  // row fr of the 32 x 288 plane, 16-byte chunk 2 ks + fh of the tap's 32 columns)
+  u32x4 fbc[2][2];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) bq1[g] = *reinterpret_cast<const f32x4*>(p.b1 + 8 * g + 4 * fh);
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+      fbc[ks][pl] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.w1) +
+                                                    ((long long)pl * 32 * 288 + fr * 288 + 4 * 32 + (2 * ks + fh) * 8) * 2);
   const float scale1 =
       *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.w1) + 2 * 32 * 288 * 2) * (1.f / W0_SCALE);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
   // ---- pixels of this wave: 32 agents x half of the output row -----------------------------------------------------------
-  const int agent = 32 * (wave & 3) + fr;                // agent inside the tile
+  const int agent = 32 * (wave & 1) + fr;                // agent inside the workgroup's 64
   const int m = m0 + agent;
   const int half = (p.Wo + 1) / 2;
-  const int ox_lo = (wave >> 2) * half, ox_hi = min(p.Wo, ox_lo + half);
+  const int ox_lo = (wave >> 1) * half, ox_hi = min(p.Wo, ox_lo + half);
   const unsigned* wbase = win + agent * WSTR;
   const int iy0 = 2 * oy - 1;                            // tap (ty, tx) reads stem pixel (iy0 + ty, 2 ox - 1 + tx)
   const int ty0 = iy0 < 0 ? 1 : 0, ty1 = min(3, p.H - iy0);
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
     const int ix0 = 2 * ox - 1;
     const int tx0 = ix0 < 0 ? 1 : 0, tx1 = min(3, p.W - ix0);
     // plane-granule address of this lane's operand inside a 32-channel tile: + plane * 256 * 32 + ks * 4096
-    const long long tile_off = ((long long)mtile * npix + oy * p.Wo + ox) * (128 * 32 * 4) + fh * 2048 + agent * 16;
+    const long long tile_off = ((long long)mtile * npix + oy * p.Wo + ox) * (128 * 32 * 4) + fh * 2048 + (sub * L1_AG + agent) * 16;
     f32x16 acc1, acc1b;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] = acc1b[r] = 0.f;
@@ -300,14 +311,16 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
           for (int ks = 0; ks < 2; ++ks) { qkeep[ty][ks][0] = qa[ks][0]; qkeep[ty][ks][1] = qa[ks][1]; }
         }
         // 4. layer1.conv1 tap product
-        const char* wt = Ws + (ty * 3 + tx) * 4096;
+        const int tap = ty * 3 + tx;
+        const char* wt = Ws + (tap - (tap > 4 ? 1 : 0)) * 4096;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const int c = 2 * ks + fh;
           u32x4 fb[2];
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl)
-            fb[pl] = *reinterpret_cast<const u32x4*>(wt + pl * 2048 + (fr * 4 + (c ^ ((fr >> 2) & 3))) * 16);
+            fb[pl] = tap == 4 ? fbc[ks][pl]
+                              : *reinterpret_cast<const u32x4*>(wt + pl * 2048 + (fr * 4 + (c ^ ((fr >> 2) & 3))) * 16);
 #pragma unroll
           for (int q = 0; q < 3; ++q) {
             if (ks == 0)
@@ -323,6 +336,9 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
     // ---- layer1.conv1 output of this pixel as f16 plane granules ----------------------------------------------------------
     if (m < p.M) {
       char* o = static_cast<char*>(p.out) + tile_off;
+      f32x4 bq1[4];      // (re-read per pixel, an L1 hit: its 16 registers hold the centre tap's weight fragments instead)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bq1[g] = *reinterpret_cast<const f32x4*>(p.b1 + 8 * g + 4 * fh);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         unsigned h1[4], h2[4];
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(512, 1) void layer1_fused_kernel(const L1Params p) 
 size_t magat_layer1_fused_lds(int W) {
   if (W < 4 || W > 4 * MAXV) return 0;
   const size_t wstr = (size_t)((1 + 15 * (W + 1)) | 1);
-  const size_t lds = 9 * 4096 + 128 * wstr * sizeof(float);
+  const size_t lds = 8 * 4096 + (size_t)L1_AG * wstr * sizeof(float);
   return lds <= 160 * 1024 ? lds : 0;
 }
 
@@ -371,14 +387,14 @@ int magat_layer1_fused(const float* x, const float* w0, const float* b0, const f
   p.Mt = (M + 127) / 128;
   p.range_flag = range_flag;
   const long long groups = (p.Mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD;
-  const long long grid = groups * MAGAT_NUM_XCD * p.Ho;
+  const long long grid = groups * MAGAT_NUM_XCD * p.Ho * 2;      // two 64-agent workgroups per 128-agent tile and output row
   if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
-  const size_t lds = magat_layer1_fused_lds(W);                     // 129.6 KB at W = 11: one 8-wave workgroup per CU
+  const size_t lds = magat_layer1_fused_lds(W);                     // 79.1 KB at W = 11: two 4-wave workgroups per CU
   if (lds == 0) return MAGAT_ERR_UNSUPPORTED;
   if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&layer1_fused_kernel), MAGAT_LDS_L1FUSED, lds) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
   const int pid = magat_prof_begin(MAGAT_TAG_CONV_FIRST, st);
-  hipLaunchKernelGGL(layer1_fused_kernel, dim3((unsigned)grid), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(layer1_fused_kernel, dim3((unsigned)grid), dim3(256), lds, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
