@@ -124,7 +124,7 @@ def kernel_work(nat, cfg, N, S_bytes, deg=None, planned=False, fused_stem=True, 
         bytes=4 * (2 * 36 * 32 + 9 * 128), arith="f16x3")
     head_a = "f16x3" if (pooled_head and lib_opt(nat, "HEAD_F16") and conv_arith(nat, cfg, 2) == "f16x3") else "f32"
     w["head(avgpool+fc+linear)"] = dict(flops=2 * 9 * 128 * nfm, bytes=4 * ((9 if pooled_head else 36) * 128 + nfm), arith=head_a)
-    w["compressMLP"] = dict(flops=2 * nfm * G, bytes=4 * (nfm + G), arith="f32")
+    w["compressMLP"] = dict(flops=2 * nfm * G, bytes=4 * (nfm + G), arith=head_a)     # (follows the head's arithmetic)
     gat_a = "f32"
     if lib_opt(nat, "GAT_SPLIT") and NC % 32 == 0 and G % 32 == 0:
         gat_a = "f16x3" if lib_opt(nat, "CONV_F16") else "bf16x6"

@@ -54,7 +54,7 @@ const char* magat_error_string(int code);
  *   BLOCK_FUSED (1), BLOCK3_FUSED (2)  BasicBlock chain kernels (maps of an 8-agent group in LDS); BLOCK3_FUSED 2 = the four-wave,
  *                    512-register form of the layer3 kernel, 1 = the eight-wave form, 0 = one launch per convolution
  *   BLOCK_FULL  (1)  both chain kernels as ONE launch (layer2's output never leaves the CU); needs BLOCK_FUSED 2, BLOCK3_FUSED 2
- *   HEAD_F16    (1)  encoder head as f16x3 split products when its input is the layer3 kernel's pooled map (large batches)
+ *   HEAD_F16    (1)  encoder head (and compressMLP behind it) as f16x3 split products when its input is the layer3 kernel's pooled map
  *   GAT_MFMA    (1)  magat_gat_forward_*: KeyQuery, G = F = 128, N <= 101, K = 2 | 3, A_opt == NULL run as ONE launch of matrix-core
  *                    products (maps, scores, softmax, hops; csrc/gat_mfma.hip); 0 = maps GEMM + graph kernel
  * Returns MAGAT_ERR_UNSUPPORTED for an unknown name. */
@@ -417,6 +417,7 @@ typedef struct magat_encoder_desc {
   int64_t chain3_off; /* float offset of the layer3 kernel's weights (encoder.pack_block3_weights), 0 = absent (ABI 2) */
   int64_t head16_off; /* float offset of the head weight as f16x2 planes + 2^-e (in_fmt 4), 0 = absent: the head runs as
                          f16x3 split products when its input is the layer3 kernel's pooled map (ABI 2) */
+  int64_t comp16_off; /* the same for the compressMLP weight: 0 = absent (float32 MFMA); used together with head16_off (ABI 2) */
 } magat_encoder_desc;
 /* Range guard (option RANGE_GUARD, default 1).  The convolutions run as f16x3 split products (two half-precision planes per
  * value, fp32 accumulate: as accurate as the fp32 MFMA kernel while every activation stays within +-65504; the fused stem

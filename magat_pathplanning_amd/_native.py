@@ -53,7 +53,7 @@ class EncoderDesc(ctypes.Structure):
     _fields_ = [("variant", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
                 ("n_feat", ctypes.c_int), ("n_comp", ctypes.c_int), ("pack", ctypes.c_void_p),
                 ("off", ctypes.c_int64 * 32), ("chain_off", ctypes.c_int64), ("chain3_off", ctypes.c_int64),
-                ("head16_off", ctypes.c_int64)]
+                ("head16_off", ctypes.c_int64), ("comp16_off", ctypes.c_int64)]
 
 
 class SimStepDesc(ctypes.Structure):

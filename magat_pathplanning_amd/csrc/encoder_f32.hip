@@ -486,8 +486,22 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     }
     if (rc != MAGAT_OK) return rc;
     if (d->n_comp > 0) {
-      rc = enc_linear(feat + (size_t)m0 * ldfeat, ldfeat, pk + d->off[16], pk + d->off[17], comp + (size_t)m0 * ldcomp,
-                      ldcomp, mm, d->n_comp, d->n_feat, 1, tagof(MAGAT_TAG_COMPRESS), run_if, stream);
+      // compressMLP: f16x3 split products on the direct kernel when the head ran that way (large pooled batches), else
+      // float32 MFMA (and always in the guard's re-run)
+      if (!rerun && pooled_in && split && d->comp16_off > 0 && (d->n_feat % 32) == 0 && (d->n_comp % 32) == 0 &&
+          magat_opt(MAGAT_OPT_HEAD_F16)) {
+        magat_conv_gemm_desc c = {};
+        c.tag = tagof(MAGAT_TAG_COMPRESS);
+        c.in = feat + (size_t)m0 * ldfeat; c.wt = pk + d->comp16_off; c.bias = pk + d->off[17];
+        c.out = comp + (size_t)m0 * ldcomp;
+        c.M = mm; c.Cin = d->n_feat; c.lda = ldfeat; c.Hin = c.Win = 1; c.kH = c.kW = 1; c.stride = 1; c.pad = 0;
+        c.Hout = c.Wout = 1; c.Cout = d->n_comp; c.ldc = ldcomp; c.relu = 1;
+        c.in_fmt = 4; c.range_flag = range_flag;
+        rc = magat_conv_gemm_f32(&c, stream);
+      } else {
+        rc = enc_linear(feat + (size_t)m0 * ldfeat, ldfeat, pk + d->off[16], pk + d->off[17], comp + (size_t)m0 * ldcomp,
+                        ldcomp, mm, d->n_comp, d->n_feat, 1, tagof(MAGAT_TAG_COMPRESS), run_if, stream);
+      }
       if (rc != MAGAT_OK) return rc;
     }
   }

@@ -192,8 +192,17 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
         head16 = torch.cat((head16, torch.zeros(pad)))
     head16_off = pack.numel()
     pack = torch.cat([pack, head16]).contiguous()
+    # ... and compressMLP's weight the same way (it follows the head on the same kernel)
+    comp16_off = 0
+    if n_comp > 0:
+        comp16, _ = split_f16x2(pack[offs[16]:offs[16] + n_comp * n_feat])
+        pad = (-comp16.numel()) % 4
+        if pad:
+            comp16 = torch.cat((comp16, torch.zeros(pad)))
+        comp16_off = pack.numel()
+        pack = torch.cat([pack, comp16]).contiguous()
     meta = dict(variant=0 if large else 1, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast, chain=chain_off,
-                chain3=chain3_off, head16=head16_off)
+                chain3=chain3_off, head16=head16_off, comp16=comp16_off)
     return pack, offs, meta
 
 

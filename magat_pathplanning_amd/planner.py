@@ -339,6 +339,7 @@ class DecentralPlannerGATNet(nn.Module):
             d.chain_off = meta.get("chain", 0)
             d.chain3_off = meta.get("chain3", 0)
             d.head16_off = meta.get("head16", 0)
+            d.comp16_off = meta.get("comp16", 0)
             rt.desc = d
         elif self.config.FOV + 2 == 11:
             pack, offs, meta = enc.fold_default_cnn(sd, 11, 11, "ConvLayers",
