@@ -22,8 +22,10 @@
 // LDS (N = 100: 162,560 of 163,840 bytes): X planes [N][2][256 B] (16-byte chunks XOR-swizzled by row), A planes [N][SA],
 // U^T planes [128][SA] with SA = 2 KI + 16 (KI = 16 KSI >= N columns; rows 60 or 68 banks apart: conflict-free b128 reads);
 // the Q planes live in the U^T region (dead before U^T is written).  That is what bounds N: N <= 102.
-// Values outside the f16 range are clamped and reported in range_flag (magat_hip.h "range guard"): the caller re-runs
-// the two-launch float32 form when it is set.
+// G3's tap products are not a phase of their own: their MFMAs are issued between the vector instructions that turn the G1 /
+// G2 / hop accumulators into planes (see the kernel).  Values outside the f16 range are NOT clamped: the planes turn to
+// inf / nan, the running maximum raises range_flag (magat_hip.h "range guard"), and the caller's predicated two-launch
+// float32 form re-writes every output of the launch.
 #include <type_traits>
 
 #include "magat_common.h"
@@ -82,20 +84,8 @@ __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, const f
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// one 16-wide k step of NB x MT tiles: the three split products, tile after tile (no two consecutive MFMAs on one accumulator
-// when there is more than one tile)
-template <int MT, int NB>
-__device__ __forceinline__ void mma_step(f32x16 (&acc)[NB][MT], const uint4 (&a)[MT][2], const uint4 (&b)[NB][2]) {
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int pa = q == 2 ? 1 : 0, pb = q == 1 ? 1 : 0;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[nb][mt] = mfma16(a[mt][pa], b[nb][pb], acc[nb][mt]);
-  }
-}
-
+// one 16-wide k step of a row of MT tiles: the three split products, tile after tile (no two consecutive MFMAs on one
+// accumulator when there is more than one tile)
 template <int MT>
 __device__ __forceinline__ void mma_step_row(f32x16 (&acc)[MT], const uint4 (&a)[MT][2], const uint4 (&b)[2]) {
 #pragma unroll
@@ -261,14 +251,6 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
                                   : *reinterpret_cast<const uint4*>(lds + MO + 16 * cw_);
       mk[0] = m.x >> (4 * h_); mk[1] = m.y >> (4 * h_); mk[2] = m.z >> (4 * h_); mk[3] = m.w >> (4 * h_);
     }
-    f32x16 ysum[CONCAT ? 1 : MT];      // mean merge: sum over the heads of (Y_p + bias), carried in registers
-    if constexpr (!CONCAT) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ysum[mt][r] = 0.f;
-    }
-
 #pragma unroll 1
     for (int hd = hlo; hd < hhi; ++hd) {
       GM_STAMP(0);
@@ -605,34 +587,33 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
         const long long rowb = (long long)p.ldy * 4;
         const bool last = hd == p.P - 1;
         const float fp = (float)p.P;
-        auto out = [&](int mt, int r) -> float {      // relu as one v_med3 (fmaxf semantics: a NaN gives 0)
-          const float v = acc[0][mt][r] * kInvScale + biasv;
-          if constexpr (CONCAT) return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());
-          ysum[mt][r] = hd == 0 ? v : ysum[mt][r] + v;
-          return __builtin_amdgcn_fmed3f(ysum[mt][r] / fp, 0.f, __builtin_inff());
-        };
-        float oy[MT][16];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oy[mt][r] = out(mt, r);
+        // concat: relu as one v_med3 (fmaxf semantics: a NaN gives 0).  Head mean: the running sum over the heads of
+        // (Y_p + bias) lives in Y itself - every element is owned by one lane of one workgroup, so it is a plain
+        // read-add-write of an L2-resident row (64 registers of running sums next to the taps' accumulators spilled) -
+        // and the last head stores relu(sum / P)      (graphML.py:4663-4667; the same summation order as before)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int jg = 32 * mt + 8 * q;
             if (jg >= N) break;
-            const float* o = &oy[mt][4 * q];
-            if (CONCAT || last) {
-              if (jg + 8 <= N) {
+            const bool whole = jg + 8 <= N;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) GM_YST(const_cast<char*>(ybase + (jg + e) * rowb) + lbyte, o[e]);
+            for (int e = 0; e < 4; ++e) {
+              if (!whole && !(jg + 4 * h + e < N)) continue;
+              float* dst = reinterpret_cast<float*>(const_cast<char*>(ybase + (jg + e) * rowb) + lbyte);
+              float v = acc[0][mt][4 * q + e] * kInvScale + biasv;
+              if constexpr (CONCAT) {
+                v = __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());
               } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  if (jg + 4 * h + e < N)
-                    *reinterpret_cast<float*>(const_cast<char*>(ybase + (jg + e) * rowb) + lbyte) = o[e];
+                if (hd > 0) v = *dst + v;
+                if (last) v = __builtin_amdgcn_fmed3f(v / fp, 0.f, __builtin_inff());
               }
+#ifdef GM_WHATIF_NOYST
+              GM_SINK(v);
+#else
+              *dst = v;
+#endif
             }
           }
       }
