@@ -648,8 +648,14 @@ int launch(const GatMfmaParams& p, int slot, hipStream_t st) {
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     cus = 256;
   GatMfmaParams q = p;
-  q.hsplit = (p.concat && p.B * p.P <= cus) ? p.P : 1;      // (the head mean is summed in one workgroup's registers: no split)
-  const int blocks = q.hsplit > 1 ? p.B * p.P : (p.B < cus ? p.B : cus);
+  // A workgroup per (instance, head) pays the instance prologue once per head (22 k + 36 k cycles per unit against 22 k + 36 k P
+  // per instance), but fills a chip that B instances alone leave idle: the cheaper of the two round counts (concat only: the
+  // head mean accumulates in one workgroup's own rows of Y).
+  const long long unsplit = (long long)((p.B + cus - 1) / cus) * (22 + 36 * p.P);
+  const long long split = (long long)(((long long)p.B * p.P + cus - 1) / cus) * (22 + 36);
+  q.hsplit = (p.concat && p.P > 1 && split < unsplit) ? p.P : 1;
+  const long long units = q.hsplit > 1 ? (long long)p.B * p.P : p.B;
+  const int blocks = (int)(units < (long long)cus * q.hsplit ? units : (long long)cus * q.hsplit);
   const int pid = magat_prof_begin(MAGAT_TAG_GAT_LAYER, st);
   if (p.concat) hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, true>), dim3(blocks), dim3(256), lds, st, q);
   else hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, false>), dim3(blocks), dim3(256), lds, st, q);
