@@ -185,38 +185,28 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
     GM_STAMP(14);
     if (b != b0) GM_SYNC();      // (the previous instance's last hops still read the X planes: tap 0 runs under them)
     {
-      // (all of a thread's loads first - at most 7 x 32 bytes for N <= 112 - then the conversions: one memory latency)
+      // The X rows travel global -> LDS with LDS-direct loads (no destination registers: every request of the instance is in
+      // flight at once; as register loads the compiler spilled each value as it arrived - the register file holds the whole
+      // kernel's long-lived state here - and the loads ran one memory round trip at a time: 22 k cycles per instance), into
+      // the A / U^T regions that nothing uses yet, 2 KB behind the masks; then float32 -> planes out of LDS.
+      int t = threadIdx.x;
+      asm volatile("" : "+v"(t));      // (per instance: the address arithmetic below is not hoisted into long-lived registers)
+      const int lane_ = t & 63;
       const float* Xb = p.X + (long long)b * N * p.ldx;
-      f32x4 xv[7][2];
-#pragma unroll
-      for (int it = 0; it < 7; ++it) {
-        const int idx = t + 256 * it, row = idx >> 4, ch = idx & 15;
-        if (idx < N * 16) {
-          const float* src = Xb + (long long)row * p.ldx + 8 * ch;
-          xv[it][0] = *reinterpret_cast<const f32x4*>(src);
-          xv[it][1] = *reinterpret_cast<const f32x4*>(src + 4);
-        }
+      const unsigned xst = AO + 2048;
+      for (int c = w; c * 64 < N * 32; c += 4) {           // 64 chunks of 16 bytes per wave instruction; 32 chunks per row
+        const int ch = c * 64 + lane_;
+        const float* src = Xb + (long long)(ch >> 5) * p.ldx + (ch & 31) * 4;
+        const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + xst + (unsigned)c * 1024u);
+        if (ch < N * 32) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
       }
-#pragma unroll
-      for (int it = 0; it < 7; ++it) {
-        const int idx = t + 256 * it, row = idx >> 4, ch = idx & 15;
-        if (idx < N * 16) {
-          uint4 hi, lo;
-          split2v(xv[it][0][0], xv[it][0][1], hi.x, lo.x, vmax);
-          split2v(xv[it][0][2], xv[it][0][3], hi.y, lo.y, vmax);
-          split2v(xv[it][1][0], xv[it][1][1], hi.z, lo.z, vmax);
-          split2v(xv[it][1][2], xv[it][1][3], hi.w, lo.w, vmax);
-          char* dst = lds + (row * 512 + ((ch ^ (row & 15)) << 4));
-          *reinterpret_cast<uint4*>(dst) = hi;
-          *reinterpret_cast<uint4*>(dst + 256) = lo;
-        }
-      }
+      // (the masks are formed while the X rows are in flight: their first batch of GSO rows shares that round trip)
       if (!p.rmask_pre) {        // GSO rows -> 128-bit edge masks (one wave per row, ballot; |S| > 1e-9 as in gat_f32.hip)
         // rows w, w + 4, ...: eight rows' loads are issued before the first ballot (one memory latency per batch, not per row)
         auto stage = [&](auto tag) {
           typedef decltype(tag) ST;
           const ST* Sp = static_cast<const ST*>(p.S) + (long long)b * N * N;
-          const int j0 = lane < N ? lane : N - 1, j1 = lane + 64 < N ? lane + 64 : N - 1;
+          const int j0 = lane_ < N ? lane_ : N - 1, j1 = lane_ + 64 < N ? lane_ + 64 : N - 1;
           for (int i0 = w; i0 < N; i0 += 32) {
             ST v0[8], v1[8];
 #pragma unroll
@@ -230,8 +220,8 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
               const int i = i0 + 4 * r;
               const bool f0 = sizeof(ST) == 8 ? fabs((double)v0[r]) > 1e-9 : fabsf((float)v0[r]) > 1e-9f;
               const bool f1 = sizeof(ST) == 8 ? fabs((double)v1[r]) > 1e-9 : fabsf((float)v1[r]) > 1e-9f;
-              const unsigned long long k0 = __ballot(f0 && lane < N), k1 = __ballot(f1 && lane + 64 < N);
-              if (lane == 0 && i < N) {
+              const unsigned long long k0 = __ballot(f0 && lane_ < N), k1 = __ballot(f1 && lane_ + 64 < N);
+              if (lane_ == 0 && i < N) {
                 unsigned* m = reinterpret_cast<unsigned*>(lds + MO) + 4 * i;
                 m[0] = (unsigned)k0; m[1] = (unsigned)(k0 >> 32); m[2] = (unsigned)k1; m[3] = (unsigned)(k1 >> 32);
               }
@@ -240,6 +230,21 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
         };
         if (p.s_is_f64) stage(double{});
         else stage(float{});
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      GM_SYNC();
+      for (int idx = t; idx < N * 16; idx += 256) {
+        const int row = idx >> 4, ch = idx & 15;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + xst + idx * 32);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + xst + idx * 32 + 16);
+        uint4 hi, lo;
+        split2v(v0[0], v0[1], hi.x, lo.x, vmax);
+        split2v(v0[2], v0[3], hi.y, lo.y, vmax);
+        split2v(v1[0], v1[1], hi.z, lo.z, vmax);
+        split2v(v1[2], v1[3], hi.w, lo.w, vmax);
+        char* dst = lds + (row * 512 + ((ch ^ (row & 15)) << 4));
+        *reinterpret_cast<uint4*>(dst) = hi;
+        *reinterpret_cast<uint4*>(dst + 256) = lo;
       }
     }
     GM_SYNC();
@@ -648,11 +653,11 @@ int launch(const GatMfmaParams& p, int slot, hipStream_t st) {
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     cus = 256;
   GatMfmaParams q = p;
-  // A workgroup per (instance, head) pays the instance prologue once per head (22 k + 36 k cycles per unit against 22 k + 36 k P
+  // A workgroup per (instance, head) pays the instance prologue once per head (12 k + 36 k cycles per unit against 12 k + 36 k P
   // per instance), but fills a chip that B instances alone leave idle: the cheaper of the two round counts (concat only: the
   // head mean accumulates in one workgroup's own rows of Y).
-  const long long unsplit = (long long)((p.B + cus - 1) / cus) * (22 + 36 * p.P);
-  const long long split = (long long)(((long long)p.B * p.P + cus - 1) / cus) * (22 + 36);
+  const long long unsplit = (long long)((p.B + cus - 1) / cus) * (12 + 36 * p.P);
+  const long long split = (long long)(((long long)p.B * p.P + cus - 1) / cus) * (12 + 36);
   q.hsplit = (p.concat && p.P > 1 && split < unsplit) ? p.P : 1;
   const long long units = q.hsplit > 1 ? (long long)p.B * p.P : p.B;
   const int blocks = (int)(units < (long long)cus * q.hsplit ? units : (long long)cus * q.hsplit);
