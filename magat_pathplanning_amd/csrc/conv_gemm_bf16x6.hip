@@ -515,15 +515,17 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
 
   // weight slab pieces (1 KB = 16 rows x 64 B of one plane) this wave copies: piece id = wave + 4 i; lane -> LDS bytes
   // [16 lane, +16) of the piece, i.e. row lane/4, chunk slot lane%4, which holds k chunk slot ^ ((row>>2)&3)
-  long long boff[TN];
-  unsigned bm0[TN];
+  // (32-bit byte offsets - the launcher refuses weight tensors of 4 GB - and the LDS address formed from the wave number at
+  // the point of use: the 64-bit offsets + LDS addresses were 12 registers, the kernel sits at the 168-register limit of
+  // three waves per SIMD, and what the compiler spilled was re-loaded from scratch inside the K loop: a vector-memory load
+  // whose wait also sat out the activation loads in flight)
+  unsigned boff[TN];
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     const int id = wave + 4 * i;
     const int plane = id / (BN / 16), row = (id % (BN / 16)) * 16 + (lane >> 2);
     const int c = (lane & 3) ^ ((row >> 2) & 3);
-    boff[i] = ((long long)plane * p.wt_plane + (long long)(n0 + row) * p.Ktot + c * 8) * 2;
-    bm0[i] = (unsigned)(uintptr_t)Bs + (unsigned)id * 1024u;
+    boff[i] = (unsigned)(((long long)plane * p.wt_plane + (long long)(n0 + row) * p.Ktot + c * 8) * 2);
   }
 
   int cur_ty = ty0, cur_tx = tx0, cur_ks = 0;
@@ -578,8 +580,11 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
       ++cur_ks;
     }
     nb = wtb + (long long)bk * 2;
-    nd2 = main_seg ? d2m : d2s;
     const unsigned sel = main_seg ? 0xffffffffu : 0u;
+    // (mask arithmetic, not `main_seg ? d2m : d2s`: the compiler turned that select of two by-reference captures into a
+    // select of their ADDRESSES - both values went to scratch, and every slab paid a scratch load of the pointer and a flat
+    // load of the value, vector-memory loads whose waits also sat out the activation loads in flight)
+    nd2 = d2s + (int)((unsigned)(d2m - d2s) & sel);
 #pragma unroll
     for (int i = 0; i < TM; ++i) na[i] = ab + (aoff2[i] + ((aoff[i] - aoff2[i]) & sel));
   };
@@ -599,7 +604,8 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
   // waits for the activation registers - it cannot see the asm loads - never include the weight fill)
   auto dma = [&](int i, int stage) {
     const char* src = nb + boff[i];
-    const unsigned m0v = __builtin_amdgcn_readfirstlane(bm0[i] + (unsigned)stage * (unsigned)STAGE);
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Bs + (unsigned)(wave + 4 * i) * 1024u +
+                                                        (unsigned)stage * (unsigned)STAGE);
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
   };
   u32x4 qa[TM][2][2];                                   // [row group][k step][plane]: the lane's 8 k values as packed f16
