@@ -606,9 +606,11 @@ constexpr int w4_minshift(int tile) {
 #endif
 constexpr int w4_depth(int nt, int ksm) { return nt * ksm <= 8 ? 8 : MAGAT_W4_D; }    // short k steps (few MFMAs): deeper weight ring
 // first D - 1 k steps of a weight stream into the ring
+// (lane16 comes from the caller's laundered thread index: formed from threadIdx here, the D - 1 fragment addresses are
+//  invariant in the persistent group loop, get hoisted into 64-bit register pairs, spilled, and re-loaded from scratch in
+//  the middle of the fill - each reload's wait sits out the fill's earlier loads)
 template <int NSTEP, int D>
-__device__ __forceinline__ void w4_fill(const char* wbase, u32x4 (&w)[D][2]) {
-  const unsigned lane16 = (threadIdx.x & 63u) * 16u;
+__device__ __forceinline__ void w4_fill(const char* wbase, unsigned lane16, u32x4 (&w)[D][2]) {
 #pragma unroll
   for (int j = 0; j < D - 1; ++j)
     if (j < NSTEP) {
@@ -667,7 +669,7 @@ __device__ __forceinline__ void walk4(char* lds, int in_off, int in2_off, const 
       dst = *reinterpret_cast<const u32x4*>(lds + b0[it.s] + (sh * PIXB + pl * PS_IN + it.ks * 2 * BLK));
     }
   };
-  w4_fill<NSTEP, D>(wbase, w);
+  w4_fill<NSTEP, D>(wbase, lane16, w);
 #pragma unroll
   for (int j = 0; j < AV - 1; ++j) {
     rd(SQ.it[j], 0, av[j][0]);
