@@ -85,6 +85,10 @@ int magat_reset_option(const char* name);   /* back to the built-in default (not
  * Supported: G,F in {16,32,64,128,256}, 1 <= N <= 128 (dense mask path), K >= 1, P >= 1.
  */
 int magat_gat_dense_supported(int N, int G, int F); /* 1: dense-GSO kernel covers it; 0: use the *_csr_* entry point */
+/* 1 when magat_gat_forward_{packed,planned}_f32 with A_opt == NULL runs this shape as ONE launch of matrix-core products
+ * (gat_mfma.hip; profiling tag MAGAT_TAG_GAT_LAYER) under the current options, 0 when it takes the two-launch form (maps GEMM
+ * + graph kernel).  Same results either way; tests use it to assert which kernel produced the numbers they compared. */
+int magat_gat_one_launch_supported(int N, int G, int F, int K, int mode, int concat);
 size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode);
 int magat_gat_pack_weights(const float* weight, const float* weight_bias, const float* mixer,
                            const float* taps, float* packed, int G, int F, int K, int P, int mode,

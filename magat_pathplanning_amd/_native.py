@@ -14,6 +14,7 @@ MODE_KEYQUERY = 0
 MODE_GAT_MODIFIED = 1
 MODE_GAT_ORIGIN = 2
 MODE_GNN = 3
+_MODE_IDS = {"KeyQuery": MODE_KEYQUERY, "GAT_modified": MODE_GAT_MODIFIED, "GAT_origin": MODE_GAT_ORIGIN}
 TAGS = {0: "untagged", 1: "conv_first", 2: "layer1.conv1", 3: "layer1.conv2+ds", 4: "layer2.conv1",
         5: "layer2.conv2+ds", 6: "layer3.conv1", 7: "layer3.conv2+ds", 8: "head(avgpool+fc+linear)",
         9: "compressMLP", 10: "gat_maps_gemm", 11: "gat_graph", 12: "actionsMLP", 13: "head_mean",
@@ -75,6 +76,7 @@ _SIGNATURES = {
     "magat_get_option": (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
     "magat_reset_option": (_I, [ctypes.c_char_p]),
     "magat_gat_dense_supported": (_I, [_I] * 3),
+    "magat_gat_one_launch_supported": (_I, [_I] * 6),
     "magat_gat_packed_floats": (_Z, [_I] * 5),
     "magat_gat_pack_weights": (_I, [_P] * 5 + [_I] * 5 + [_P]),
     "magat_gat_workspace_bytes": (_Z, [_I] * 8),

@@ -531,7 +531,7 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   hipStream_t st = static_cast<hipStream_t>(stream);
 
   if (d->variant == 2) {     // CNN_mode Default: conv-BN-ReLU x5 with MaxPool2d(2) after layers 0, 2, 4 (float32 kernels only)
-    if (d->n_feat != 128) return MAGAT_ERR_BAD_SHAPE;
+    if (d->n_feat <= 0 || d->n_feat % 128) return MAGAT_ERR_BAD_SHAPE;
     const int chans[6] = {3, 32, 32, 64, 64, 128};
     for (int m0 = 0; m0 < M; m0 += mc) {
       const int mm = (M - m0) < mc ? (M - m0) : mc;
@@ -555,14 +555,19 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
         if (rc != MAGAT_OK) return rc;
         cur = (cur + 1) % 3; hp = hin; wp = win;
       }
-      // final MaxPool2d(2) -> [mm][128]: pooled 1x1 GEMM with identity weights
+      // final MaxPool2d(2) -> feat [mm][(hp/2)(wp/2)][128]: a pooled 1x1 GEMM with identity weights, one output pixel per
+      // pooled cell.  At the reference's FOV = 9 (11 x 11 maps) that is one cell; at other map sizes the features are
+      // (cell, channel)-ordered here where the reference's Flatten is (channel, cell)-ordered - encoder.fold_default_cnn
+      // permutes the columns of every weight that reads them (compressMLP, the skip-concat half of actionsMLP) to match
+      const int hf = hp / 2, wf = wp / 2;
+      if (hf < 1 || wf < 1 || d->n_feat != 128 * hf * wf) return MAGAT_ERR_BAD_SHAPE;
       magat_conv_gemm_desc g = {};
       g.in = buf[cur]; g.wt = pk + d->off[14]; g.out = feat + (size_t)m0 * ldfeat;
       g.in_pix_stride = pixs(128); g.in_tile_stride = tiles(hp * wp, 128);
-      g.M = mm; g.Cin = 128; g.lda = 128; g.Hin = hp / 2; g.Win = wp / 2;
-      g.kH = hp / 2; g.kW = wp / 2; g.stride = 1; g.pad = 0; g.Hout = g.Wout = 1; g.Cout = 128; g.ldc = ldfeat;
+      g.M = mm; g.Cin = 128; g.lda = 128; g.Hin = hf; g.Win = wf;
+      g.kH = 1; g.kW = 1; g.stride = 1; g.pad = 0; g.Hout = hf; g.Wout = wf; g.Cout = 128; g.ldc = ldfeat;
+      g.out_pix_stride = 128;
       g.pool = 2; g.pool_w = wp; g.tag = MAGAT_TAG_HEAD;
-      if (hp / 2 != 1 || wp / 2 != 1) return MAGAT_ERR_UNSUPPORTED;   // FOV 9 (11x11 input) geometry
       rc = magat_conv_gemm_f32(&g, stream);
       if (rc != MAGAT_OK) return rc;
       if (d->n_comp > 0) {

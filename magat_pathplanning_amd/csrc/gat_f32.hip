@@ -1130,6 +1130,17 @@ extern "C" size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, i
   return bytes;
 }
 
+static bool gat_one_launch(int N, int G, int F, int K, int mode, int concat) {
+  (void)concat;
+  return magat_opt(MAGAT_OPT_GAT_MFMA) && magat_opt(MAGAT_OPT_GAT_SPLIT) && magat_opt(MAGAT_OPT_CONV_F16) &&
+         magat_gat_mfma_supported(N, G, F, K, mode);
+}
+
+extern "C" int magat_gat_one_launch_supported(int N, int G, int F, int K, int mode, int concat) {
+  if (N <= 0 || G != F || !supported_width(G) || N > 128) return 0;
+  return gat_one_launch(N, G, F, K, mode, concat) ? 1 : 0;
+}
+
 extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int s_is_f64, const float* packed,
                                              const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
                                              size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
@@ -1173,8 +1184,7 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
   // One launch of matrix-core products (gat_mfma.hip) when the shape allows; with the range guard on, the two-launch float32
   // form below follows in the same stream, every launch of it predicated on the flag the fused kernel raises.
   bool rerun_only = false;
-  if (magat_opt(MAGAT_OPT_GAT_MFMA) && magat_opt(MAGAT_OPT_GAT_SPLIT) && magat_opt(MAGAT_OPT_CONV_F16) && !A_opt &&
-      magat_gat_mfma_supported(N, G, F, K, mode)) {
+  if (!A_opt && gat_one_launch(N, G, F, K, mode, concat)) {
     const bool guard = magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
     const unsigned* masks = (plan && N <= 128) ? static_cast<const unsigned*>(plan) : nullptr;
     const int rc = magat_gat_mfma_forward(X, G, S, s_is_f64, masks, packed + magat_gat_frag_offset(L.NC, G), bias, Y, ldy, B,
@@ -1309,7 +1319,7 @@ extern "C" int magat_gso_prepare(void* S, int s_is_f64, size_t count, int scrub_
   return magat_check_launch();
 }
 
-extern "C" int magat_abi_version(void) { return 2; }
+extern "C" int magat_abi_version(void) { return 3; }
 
 extern "C" const char* magat_error_string(int code) {
   switch (code) {

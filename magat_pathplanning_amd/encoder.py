@@ -312,13 +312,33 @@ def split_f16x2(t):
     return out, e
 
 
+def default_cnn_cells(H, W):
+    """Map size after the three MaxPool2d(2) of CNN_mode "Default" (floor mode: w -> w // 2;
+    decentralplanner_GAT_bottleneck.py:118-147)."""
+    for _ in range(3):
+        H, W = H // 2, W // 2
+    return H, W
+
+
+def cell_major_columns(w, hf, wf, c=128):
+    """Weight whose columns index the reference's Flatten of a (c, hf, wf) map -> the same weight over features stored
+    (cell, channel)-ordered, the layout the HIP encoder writes the Default CNN's features in."""
+    lead = w.shape[0]
+    return w.reshape(lead, c, hf, wf).permute(0, 2, 3, 1).reshape(lead, hf * wf * c)
+
+
 def fold_default_cnn(sd, H=11, W=11, pre="ConvLayers", compress=None):
     """CNN_mode "Default" (decentralplanner_GAT_bottleneck.py:118-147): 5 x [Conv2d(bias) + BatchNorm2d + ReLU] with
     MaxPool2d(2) after layers 0, 2, 4.  Sequential indices: conv at 0, 4, 7, 11, 14 (bn = conv+1).  Pack (variant 2):
     off[0..1] conv0 [32][27] / bias, off[2+2i], off[3+2i] conv i+1 weight [Cout][9*Cin] / bias, off[14] identity
-    [128][128] (the last max-pool runs as a pooled 1x1 GEMM), off[16..17] compressMLP."""
+    [128][128] (the last max-pool runs as a pooled 1x1 GEMM), off[16..17] compressMLP.  Any map size whose last pool
+    leaves at least one cell (H, W >= 8): the features are 128 * hf * wf wide, (cell, channel)-ordered in the kernels'
+    buffers, and the compressMLP columns are permuted here to read them (meta["cells"] = (hf, wf) for other readers)."""
     sd = {k: v.detach().cpu() for k, v in sd.items() if k.startswith(pre)}
     parts, offs, cursor = [], [0] * 32, [0]
+    hf, wf = default_cnn_cells(H, W)
+    if hf < 1 or wf < 1:
+        raise ValueError("CNN_mode Default needs maps of at least 8 x 8 (three MaxPool2d(2)); got %d x %d" % (H, W))
 
     def put(slot, t):
         t = t.reshape(-1).double()
@@ -345,9 +365,12 @@ def fold_default_cnn(sd, H=11, W=11, pre="ConvLayers", compress=None):
             put(3 + 2 * (l - 1), bias)
     put(14, torch.eye(128, dtype=torch.float64))
     n_comp = 0
+    n_feat = 128 * hf * wf
     if compress is not None:
-        put(16, compress[0].detach().cpu().double())
+        cw = compress[0].detach().cpu().double()
+        assert cw.shape[1] == n_feat, "compressMLP in_features must equal 128 * pooled cells"
+        put(16, cell_major_columns(cw, hf, wf))
         put(17, compress[1].detach().cpu().double())
         n_comp = compress[0].shape[0]
     pack = torch.cat(parts).to(torch.float32).contiguous()
-    return pack, offs, dict(variant=2, H=H, W=W, n_feat=128, n_comp=n_comp, clast=128)
+    return pack, offs, dict(variant=2, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=128, cells=(hf, wf))

@@ -324,6 +324,7 @@ class DecentralPlannerGATNet(nn.Module):
             return rt
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         rt.pack = rt.desc = None
+        cells = None                   # CNN_mode Default: pooled cells of the last map (feature order, see below)
         rt.graphs.clear()              # captured graphs point into the old packs
         if self.cnn_mode.startswith("ResNet"):
             lin = (sd["ConvLayers.3.weight"], sd["ConvLayers.3.bias"]) if self.cnn_mode.endswith("_withMLP") else None
@@ -341,8 +342,9 @@ class DecentralPlannerGATNet(nn.Module):
             d.head16_off = meta.get("head16", 0)
             d.comp16_off = meta.get("comp16", 0)
             rt.desc = d
-        elif self.config.FOV + 2 == 11:
-            pack, offs, meta = enc.fold_default_cnn(sd, 11, 11, "ConvLayers",
+        else:
+            side = self.config.FOV + 2
+            pack, offs, meta = enc.fold_default_cnn(sd, side, side, "ConvLayers",
                                                     (sd["compressMLP.0.weight"], sd["compressMLP.0.bias"]))
             rt.pack = pack.to(dev)
             d = nat.EncoderDesc()
@@ -352,8 +354,14 @@ class DecentralPlannerGATNet(nn.Module):
             for i, o in enumerate(offs):
                 d.off[i] = o
             rt.desc = d
+            cells = meta["cells"]
         # actionsMLP first layer: [w_skip | w_gat] -> in (skip source) + in2 (GAT output) K segments
         w0 = sd["actionsMLP.0.weight"].to(dev, torch.float32)
+        if cells is not None and cells != (1, 1) and self.skip == "skipConcat":
+            # Default CNN at a map size with several pooled cells: the HIP encoder stores the feature map (cell, channel)-
+            # ordered, the skip-concat half of actionsMLP reads it through permuted columns (encoder.fold_default_cnn)
+            nfm = self.numFeatureMap
+            w0 = torch.cat((enc.cell_major_columns(w0[:, :nfm], *cells), w0[:, nfm:]), dim=1)
         if self.skip == "skipAddGNN":
             w0 = torch.cat((w0, w0), dim=1)
         rt.act = [w0.contiguous(), sd["actionsMLP.0.bias"].to(dev, torch.float32).contiguous()]
@@ -395,21 +403,13 @@ class DecentralPlannerGATNet(nn.Module):
             stream = nat.current_stream(dev)
             feat = self._buf("feat", (M, nfm), dev)
             comp = self._buf("comp", (M, G), dev)
-            if rt.desc is not None:
-                need = lib.magat_encoder_workspace_bytes(ctypes.byref(rt.desc), M)
-                if rt.ws is None or rt.ws.numel() < need or rt.ws.device != dev:
-                    rt.ws = torch.empty(need, dtype=torch.uint8, device=dev)
-                    rt.ws[:256].zero_()          # range-guard status block (magat_encoder_read_status)
-                nat.check(lib.magat_encoder_forward_f32(ctypes.byref(rt.desc), nat.ptr(x), nat.ptr(feat), nfm,
-                                                        nat.ptr(comp), G, nat.ptr(rt.ws), rt.ws.numel(), M, stream),
-                          "magat_encoder_forward_f32")
-            else:
-                # CNN_mode=Default at a FOV other than 9 (the max-pool-on-load HIP path assumes the 11x11 geometry):
-                # torch/MIOpen convs, then our compressMLP GEMM
-                f = self.ConvLayers(x)
-                feat.copy_(f.view(M, -1))
-                nat.check(lib.magat_linear_f32(nat.ptr(feat), nfm, nat.ptr(rt.cw), nat.ptr(rt.cb), nat.ptr(comp), G,
-                                               M, G, nfm, 1, stream), "magat_linear_f32")
+            need = lib.magat_encoder_workspace_bytes(ctypes.byref(rt.desc), M)
+            if rt.ws is None or rt.ws.numel() < need or rt.ws.device != dev:
+                rt.ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                rt.ws[:256].zero_()          # range-guard status block (magat_encoder_read_status)
+            nat.check(lib.magat_encoder_forward_f32(ctypes.byref(rt.desc), nat.ptr(x), nat.ptr(feat), nfm,
+                                                    nat.ptr(comp), G, nat.ptr(rt.ws), rt.ws.numel(), M, stream),
+                      "magat_encoder_forward_f32")
             layer = self.GFL[0]
             layer.addGSO(self.S)
             gat = self._buf("gat", (M, self.gat_width), dev)

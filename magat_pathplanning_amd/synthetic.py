@@ -51,3 +51,34 @@ def random_gso(B, N, density, seed=1337, dtype=torch.float32):
     Wm = (torch.rand(B, N, N, generator=g) < density).float()
     Wm = torch.triu(Wm, 1)
     return (Wm + Wm.transpose(1, 2)).to(dtype)
+
+
+def directed_gso(B, N, density, seed=1337, dtype=torch.float64):
+    """DIRECTED random GSO (M != M^T: every ordered pair drawn independently) carrying the entries the reference's mask rule
+    `|S| > 1e-9` (graphML.py:1274-1276) has to get right: values at 5e-10 (no edge) and -3e-9 (an edge), one NaN (no edge),
+    an isolated node, a node whose ONLY incident edge is one-way INTO it (its softmax row is empty, its column is not:
+    the row-softmax / column-aggregate orientation of graphML.py:1757), and one that only sends; float64 entries are
+    1 / lambda_max-scaled like new_simulator.py:820-846 hands them over."""
+    g = torch.Generator().manual_seed(seed)
+    W = (torch.rand(B, N, N, generator=g) < density).double()
+    idx = torch.arange(N)
+    W[:, idx, idx] = 0.0
+    for b in range(B):
+        if N >= 6:
+            iso, sink, src = (3 + b) % N, (4 + b) % N, (5 + b) % N
+            peer = (iso + 3) % N
+            for n in (iso, sink, src):
+                W[b, n, :] = 0
+                W[b, :, n] = 0
+            if peer not in (iso, sink, src):
+                W[b, peer, sink] = 1.0       # edge peer -> sink only: row `sink` has no edges, column `sink` has one
+                W[b, src, peer] = 1.0        # edge src -> peer only: column `src` has none
+        lam = float(np.abs(np.linalg.eigvals(W[b].numpy())).max()) or 1.0
+        W[b] = W[b] / max(lam, 1e-6)
+        if N >= 12:
+            k, l = (8 + b) % N, (10 + b) % N
+            W[b, k, l] = 5e-10
+            W[b, l, k] = -3e-9
+    if N >= 2:
+        W[0, 0, N - 1] = float("nan")
+    return W.to(dtype)

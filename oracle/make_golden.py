@@ -48,7 +48,7 @@ def tricky_gso(gen, B, N, density, f64):
     return W if f64 else W.float()
 
 
-def layer_fixture(gml, mode, N, G, K, P, seed, density, f64):
+def layer_fixture(gml, mode, N, G, K, P, seed, density, f64, gso=None):
     gen = torch.Generator().manual_seed(seed)
     B, F = 2, G
     layers = {}
@@ -62,7 +62,7 @@ def layer_fixture(gml, mode, N, G, K, P, seed, density, f64):
             ref.weight_bias.uniform_(-0.3, 0.3, generator=gen)   # reference init is 0; exercise it
         layers[False].load_state_dict(ref.state_dict())
     x = torch.randn(B, G, N, generator=gen) * 0.7
-    S = tricky_gso(gen, B, N, density, f64).unsqueeze(1)
+    S = (tricky_gso(gen, B, N, density, f64) if gso is None else gso(B, N)).unsqueeze(1)
     out = {}
     with torch.no_grad():
         for concat, lay in layers.items():
@@ -203,8 +203,33 @@ def main_gnn():
         print("wrote", path, os.path.getsize(path) // 1024, "KB")
 
 
+def main_directed():
+    """Round 3: layer and model fixtures over fully DIRECTED GSOs (magat_pathplanning_amd.synthetic.directed_gso: every
+    ordered pair drawn independently, a one-way edge into an otherwise isolated node, threshold entries, a NaN, float64
+    1/lambda_max values) at the shapes the one-launch kernel covers and at its hand-over (N = 102 | 103 | 128), plus the
+    published B32-P4 / head-mean settings (scripts/train_DMap.sh).  Generated separately: the earlier files stay
+    byte-identical."""
+    from magat_pathplanning_amd.synthetic import directed_gso
+    gml, classes = import_reference()
+    cases = [("KeyQuery", 100, 128, 3, 4, 0.05, True), ("KeyQuery", 102, 128, 2, 2, 0.3, False),
+             ("KeyQuery", 103, 128, 3, 4, 0.05, True), ("KeyQuery", 128, 128, 3, 4, 0.04, False),
+             ("KeyQuery", 64, 128, 3, 4, 0.1, True), ("KeyQuery", 100, 32, 2, 4, 0.05, True),
+             ("KeyQuery", 100, 64, 3, 4, 0.05, False), ("GAT_modified", 100, 128, 3, 4, 0.05, True),
+             ("GAT_modified", 100, 32, 2, 4, 0.08, False)]
+    for si, (mode, N, G, K, P, dens, f64) in enumerate(cases):
+        seed = 6337 + 19 * si
+        fx = layer_fixture(gml, mode, N, G, K, P, seed=seed, density=dens, f64=f64,
+                           gso=lambda B, N_: directed_gso(B, N_, dens, seed=seed + 1,
+                                                          dtype=torch.float64 if f64 else torch.float32))
+        path = os.path.join(OUT, "gat_%s_directed_N%d_G%d_K%d_P%d.npz" % (mode, N, G, K, P))
+        np.savez_compressed(path, **fx)
+        print("wrote", path, os.path.getsize(path) // 1024, "KB")
+
+
 if __name__ == "__main__":
-    if "--gnn" in sys.argv:
+    if "--directed" in sys.argv:
+        main_directed()
+    elif "--gnn" in sys.argv:
         main_gnn()
     elif "--origin" in sys.argv:
         main_origin()

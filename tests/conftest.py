@@ -75,3 +75,45 @@ def libopt():
     o = _LibOpt()
     yield o
     o.restore()
+
+
+class _TagCounts:
+    """Launch counts per profiling tag (magat_profile_*; tags in _native.TAGS) over a `with` block: lets a parity test assert
+    WHICH kernel produced the numbers it compared (e.g. the one-launch graph layer, tag 19), so that a silent hand-over to
+    another form of the same layer cannot keep a test green."""
+
+    def __init__(self):
+        from magat_pathplanning_amd import _native
+        self.nat = _native
+        self.counts = {}
+
+    def __enter__(self):
+        lib = self.nat.lib()
+        lib.magat_profile_reset()
+        lib.magat_profile_enable(1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        import torch
+        lib = self.nat.lib()
+        torch.cuda.synchronize()
+        lib.magat_profile_enable(0)
+        lib.magat_profile_collect()
+        self.counts = {}
+        for tag, name in self.nat.TAGS.items():
+            c, ms = ctypes.c_longlong(0), ctypes.c_double(0)
+            lib.magat_profile_read(tag, ctypes.byref(c), ctypes.byref(ms))
+            if c.value:
+                self.counts[name] = c.value
+        lib.magat_profile_reset()
+        return False
+
+    def __getitem__(self, name):
+        return self.counts.get(name, 0)
+
+
+@pytest.fixture
+def tag_counts():
+    """Factory: `with tag_counts() as tc: ...; tc["gat_layer (one launch)"]`."""
+    return _TagCounts

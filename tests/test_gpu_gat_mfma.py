@@ -101,3 +101,68 @@ def test_gat_mfma_range_guard_reruns_in_float32(gpu_device):
         y = layer(x.to(gpu_device)).cpu()
     scale = float(y_ref.abs().max())
     np.testing.assert_allclose(y.numpy(), y_ref.numpy(), rtol=0, atol=2e-6 * max(scale, 1.0))
+
+
+ONE_LAUNCH = "gat_layer (one launch)"
+
+
+@pytest.mark.parametrize("N,K,P,concat,dt,density", [
+    (100, 3, 4, True, torch.float64, 0.05), (100, 3, 4, False, torch.float32, 0.08), (102, 3, 4, True, torch.float64, 0.05),
+    (102, 2, 2, False, torch.float64, 0.3), (103, 3, 4, True, torch.float64, 0.05), (64, 3, 4, True, torch.float32, 0.1),
+    (65, 2, 3, True, torch.float64, 0.1), (33, 3, 2, False, torch.float64, 0.2), (20, 3, 4, True, torch.float64, 0.25),
+    (12, 3, 4, True, torch.float32, 0.3), (6, 2, 1, True, torch.float64, 0.5)])
+def test_gat_mfma_directed_graphs_vs_oracle(gpu_device, tag_counts, N, K, P, concat, dt, density):
+    """Directed masks (M != M^T) through the DEFAULT kernel: the attention is a row softmax (row i over its out-edges j) that
+    the hops apply column-wise (z_k[j] = sum_i a_ij z_{k-1}[i], graphML.py:1757, 1274-1286) - a transposed mask or hop would
+    pass every symmetric-GSO test.  synthetic.directed_gso adds a one-way edge into an otherwise isolated node, threshold
+    entries (5e-10 / -3e-9), a NaN and float64 1/lambda_max values.  The profiling tag asserts which kernel ran: the
+    one-launch matrix-core kernel up to N = 102, the two-launch form from N = 103 (the hand-over)."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd import _native as nat
+    from magat_pathplanning_amd.synthetic import directed_gso
+    B = 4
+    layer, _, x = _layer_and_inputs(B, N, K, P, concat, seed=300 + N)
+    S = directed_gso(B, N, density, seed=17 + N, dtype=dt)
+    assert N < 6 or not torch.equal(torch.nan_to_num(S) != 0, torch.nan_to_num(S).transpose(1, 2) != 0)
+    y_ref, a_ref = orc.gat_layer_forward(x, S.unsqueeze(1), {k: v.detach() for k, v in layer.state_dict().items()},
+                                         "KeyQuery", concat)
+    layer = layer.to(gpu_device).eval()
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    with tag_counts() as tc, torch.no_grad():
+        y = layer(x.to(gpu_device)).cpu()
+    expect_one = bool(nat.lib().magat_gat_one_launch_supported(N, 128, 128, K, nat.MODE_KEYQUERY, int(concat)))
+    assert expect_one == (N <= 102)
+    assert (tc[ONE_LAUNCH] > 0) == expect_one, tc.counts
+    assert tc["gat_graph"] == (0 if expect_one else 1), tc.counts
+    np.testing.assert_allclose(y.numpy(), y_ref.numpy(), rtol=0, atol=2e-5)
+    # and the attention tensor of the two-launch form for the same directed graph (incl. the empty row of the sink node)
+    layer.return_attention = True
+    with tag_counts() as tc, torch.no_grad():
+        y2 = layer(x.to(gpu_device)).cpu()
+    assert tc[ONE_LAUNCH] == 0
+    np.testing.assert_allclose(y2.numpy(), y_ref.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(layer.aij.cpu().numpy(), a_ref.numpy(), rtol=0, atol=2e-6)
+
+
+def test_gat_mfma_orientation_is_observable(gpu_device, tag_counts):
+    """A graph with ONE directed edge i -> j: under the reference's orientation only node j's output differs from the
+    edge-free result (it aggregates x_i with weight a_ij = 1); node i's does not.  Checked against the oracle AND as a
+    property, on the one-launch kernel."""
+    from oracle import magat_oracle as orc
+    B, N, K, P = 2, 40, 3, 4
+    layer, _, x = _layer_and_inputs(B, N, K, P, True, seed=9)
+    S = torch.zeros(B, N, N, dtype=torch.float64)
+    S[0, 7, 31] = 0.4
+    S[1, 31, 7] = -2e-9
+    sd = {k: v.detach() for k, v in layer.state_dict().items()}
+    y_ref, _ = orc.gat_layer_forward(x, S.unsqueeze(1), sd, "KeyQuery", True)
+    y_empty, _ = orc.gat_layer_forward(x, torch.zeros_like(S).unsqueeze(1), sd, "KeyQuery", True)
+    layer = layer.to(gpu_device).eval()
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    with tag_counts() as tc, torch.no_grad():
+        y = layer(x.to(gpu_device)).cpu()
+    assert tc[ONE_LAUNCH] == 1, tc.counts
+    np.testing.assert_allclose(y.numpy(), y_ref.numpy(), rtol=0, atol=2e-5)
+    changed = (y - y_empty).abs().amax(dim=1) > 1e-4            # (B, N): nodes whose output the edge changed
+    assert changed[0].nonzero().flatten().tolist() == [31]
+    assert changed[1].nonzero().flatten().tolist() == [7]

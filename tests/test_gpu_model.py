@@ -22,14 +22,19 @@ def _build(cfg, sd, device):
     return net.to(device).eval()
 
 
+@pytest.mark.parametrize("want_att", [False, True], ids=["default_kernels", "with_attention"])
 @pytest.mark.parametrize("path", MODEL, ids=[os.path.basename(p)[:-4] for p in MODEL])
-def test_model_vs_reference_golden(gpu_device, path):
+def test_model_vs_reference_golden(gpu_device, tag_counts, path, want_att):
+    """want_att=False: the launch sequence inference runs by default (for KeyQuery models the graph layer is the one-launch
+    matrix-core kernel - asserted through the profiling tags); want_att=True: config.return_attentionGSO, which
+    materialises the attention tensor (two-launch form) and checks it as well."""
+    from magat_pathplanning_amd import _native as nat
     z, sd, cfg = load_model_fixture(path)
     net = _build(cfg, sd, gpu_device)
     x = torch.from_numpy(z["x"].astype(np.float32)).to(gpu_device)
     S = torch.from_numpy(z["S"].copy()).to(gpu_device)
-    cfg.return_attentionGSO = True
-    with torch.no_grad():
+    cfg.return_attentionGSO = want_att
+    with tag_counts() as tc, torch.no_grad():
         net.addGSO(S)
         logits = net(x)
     torch.cuda.synchronize()
@@ -38,7 +43,16 @@ def test_model_vs_reference_golden(gpu_device, path):
     assert err <= TOL, err
     # addGSO mutates the caller's tensor exactly like the reference
     np.testing.assert_array_equal(np.nan_to_num(S.cpu().numpy(), nan=-7.0), np.nan_to_num(z["S_after"], nan=-7.0))
-    np.testing.assert_allclose(net.returnAttentionGSO(), z["aij"].mean(axis=1), rtol=0, atol=5e-6)
+    layer = net.GFL[0]
+    one_launch = bool(nat.lib().magat_gat_one_launch_supported(S.shape[1], layer.G, layer.F, layer.K,
+                                                               nat._MODE_IDS[layer.attentionMode], int(layer.concatenate)))
+    if want_att:
+        assert tc["gat_layer (one launch)"] == 0
+        np.testing.assert_allclose(net.returnAttentionGSO(), z["aij"].mean(axis=1), rtol=0, atol=5e-6)
+    else:
+        assert (tc["gat_layer (one launch)"] > 0) == one_launch, (tc.counts, one_launch)
+        st = net.range_status()
+        assert not st["encoder_rerun"] and not st["gat_rerun"], st       # the fast pass produced these logits, not the re-run
 
 
 @pytest.mark.parametrize("B,N,K,P,mode,concat,skip", [

@@ -13,7 +13,7 @@ MODEL = golden_paths("model_")
 
 
 def test_fixtures_present():
-    assert len(LAYER) == 14 and len(MODEL) == 7
+    assert len(LAYER) == 23 and len(MODEL) == 7      # 14 + the 9 directed-GSO layer fixtures of round 3
 
 
 @pytest.mark.parametrize("path", LAYER, ids=[os.path.basename(p)[:-4] for p in LAYER])
@@ -30,7 +30,14 @@ def test_layer_oracle_matches_reference(path):
     np.testing.assert_allclose(y.numpy(), z["y_concat_nin"], rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("path", [p for p in LAYER if "_N100_G128" not in p],
+def _small_enough_for_loops(path):
+    """(the edge-by-edge restatement is pure Python: the N >= 100, G = 128 fixtures would take minutes)"""
+    import re
+    n, g = map(int, re.search(r"_N(\d+)_G(\d+)_", os.path.basename(path)).groups())
+    return n * g < 100 * 128
+
+
+@pytest.mark.parametrize("path", [p for p in LAYER if _small_enough_for_loops(p)],
                          ids=lambda p: os.path.basename(p)[:-4])
 def test_loop_oracle_matches_reference(path):
     """The edge-by-edge float64 restatement agrees too (independent derivation)."""
