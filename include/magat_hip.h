@@ -262,15 +262,19 @@ int magat_sim_step(const magat_sim_step_desc* d, void* stream);
  * host synchronisation: addGSO's in-place scrub (scrub_nan / gso_mode 0|1 as magat_gso_prepare; values are written back only
  * where they change), the edge test (edge_rule: 0 |S| > 1e-9 in S's dtype, 1 GAT_origin |float(S) + I| > 1e-9, 2 float(S) != 0)
  * -> rowptr [B*(N+1)] absolute offsets, colidx (ascending j per row), cscptr [B*(N+1)], cscsrc / cscpos (per in-edge, ascending
- * source row: source and CSR position).  cap = capacity of colidx / cscsrc / cscpos in entries (B*N*N can never overflow;
- * entries beyond cap are dropped and *nnz_dev, the device-side edge total, tells).  The forward entry points take `nnz` only
- * as the stride of their per-head attention buffers and for sizing: pass the same cap there.  Workspace: magat_gso_csr_
+ * source row: source and CSR position).  cap = capacity of colidx / cscsrc / cscpos in entries: entries beyond cap are
+ * DROPPED (rowptr / cscptr still hold the true offsets) and *nnz_dev, the device-side edge total, tells - the caller reads it
+ * (e.g. an asynchronous copy it waits for before the graph layer, by which time the per-agent CNN is already queued), and
+ * re-builds with a larger capacity when nnz > cap; B*N*N can never overflow.  The forward entry points take `nnz` as the
+ * stride of their per-head attention buffers and for sizing: any value >= the true count.  Workspace: magat_gso_csr_
  * workspace_bytes (bit matrix, N*N/8 bytes per instance; 0 = N too large, use the two calls below). */
 size_t magat_gso_csr_workspace_bytes(int B, int N);
 int magat_gso_csr_build(void* S, int s_is_f64, int scrub_nan, int gso_mode, int edge_rule, int* rowptr, int* colidx,
                         int* cscptr, int* cscsrc, int* cscpos, long long cap, long long* nnz_dev, void* workspace,
                         size_t workspace_bytes, int B, int N, void* stream);
-/* magat_gat_forward_csr_{f32,bf16} with the CSC view from magat_gso_csr_build (no per-call transpose) */
+/* magat_gat_forward_csr_{f32,bf16} with the CSC view from magat_gso_csr_build (no per-call transpose; workspace:
+ * magat_gat_csc_workspace_bytes - the csr_* figure minus the transpose scratch, 3 * nnz ints) */
+size_t magat_gat_csc_workspace_bytes(int B, int N, long long nnz, int G, int F, int K, int P, int mode, int concat, int bf16);
 int magat_gat_forward_csc_f32(const float* X, const int* rowptr, const int* colidx, const int* cscptr, const int* cscsrc,
                               const int* cscpos, long long nnz, const float* packed, const float* bias, float* Y, int ldy,
                               float* att_opt, void* workspace, size_t workspace_bytes, int B, int N, int G, int F, int K,

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "magat_gat_forward_csr_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gnn_forward_csr_f32": (_I, [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P, _Z] + [_I] * 5 + [_P]),
     "magat_gat_csr_bf16_workspace_bytes": (_Z, [_I, _I, ctypes.c_longlong] + [_I] * 6),
+    "magat_gat_csc_workspace_bytes": (_Z, [_I, _I, ctypes.c_longlong] + [_I] * 7),
     "magat_gat_forward_csr_bf16": (_I, [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_train_forward_f32": (_I, [_P, _P, _P, ctypes.c_longlong] + [_P] * 10 + [_I] * 7 + [_P]),
     "magat_gat_train_backward_f32": (_I, [_P] * 10 + [ctypes.c_longlong] + [_P] * 3 + [_I] * 7 + [_P]),

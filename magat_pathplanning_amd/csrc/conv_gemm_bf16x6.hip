@@ -103,7 +103,9 @@ __device__ __forceinline__ void split_pair_f16(float x, float y, unsigned& p1, u
 }
 // same, remembering in `clamped` whether a value was outside +-65504 (range guard)
 __device__ __forceinline__ void split_pair_f16(float x, float y, unsigned& p1, unsigned& p2, bool& clamped) {
-  clamped |= (__builtin_fabsf(x) > 65504.f) | (__builtin_fabsf(y) > 65504.f);
+  // (negated compares: true for NaN as well - a NaN activation must take the float32 re-run, which hands it on like the
+  // reference does, not come out of the v_med3 clamp as a finite number)
+  clamped |= !(__builtin_fabsf(x) <= 65504.f) | !(__builtin_fabsf(y) <= 65504.f);
   split_pair_f16(x, y, p1, p2);
 }
 
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
           float av = acc[i][j][4 * q + c];
           if constexpr (NPL == 2) av *= acc_scale;
           v[c] = av + bq[j][q][c];
-          if (p.relu) v[c] = fmaxf(v[c], 0.f);
+          if (p.relu) v[c] = magat_relu(v[c]);
         }
         const long long o = (long long)pix * p.out_pix_stride + magat_row_off(m, p.ldc, p.out_tile) + n;
         if (p.out_split == 2) {            // one RNE bf16 plane
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               v[c] = acc[i][j][4 * q + c] * acc_scale + bq[j][q][c];
-              if (p.relu) v[c] = fmaxf(v[c], 0.f);
+              if (p.relu) v[c] = magat_relu(v[c]);
             }
             const int u = jj * 8 + 2 * q + fh;          // 16-byte unit of channels 32 jj + 8 q + 4 fh .. + 3
             *reinterpret_cast<f32x4*>(wl + fr * (CP * 4) + ((u ^ (fr & (UP - 1))) * 16)) = v;
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               v[c] = acc[i][j][4 * q + c] * acc_scale + bq[j][q][c];
-              if (p.relu) v[c] = fmaxf(v[c], 0.f);
+              if (p.relu) v[c] = magat_relu(v[c]);
             }
             split_pair_f16(v[0], v[1], h1[2 * e], h2[2 * e], clamped);
             split_pair_f16(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1], clamped);
@@ -901,7 +903,7 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           v[c] = acc[i][j][4 * q + c] * acc_scale + bq[j][q][c];
-          if (p.relu) v[c] = fmaxf(v[c], 0.f);
+          if (p.relu) v[c] = magat_relu(v[c]);
         }
         if (vec) {
           *reinterpret_cast<f32x4*>(orow + (long long)n * nmul) = f32x4{v[0], v[1], v[2], v[3]};

@@ -292,7 +292,7 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, const in
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           v[c] = acc[i][j][4 * q + c] + bq[j][q][c];
-          if (p.relu) v[c] = fmaxf(v[c], 0.f);
+          if (p.relu) v[c] = magat_relu(v[c]);
         }
         const long long o = magat_row_off(m, p.ldc, p.out_tile) + (p.out_nt ? (long long)(n >> 7) * p.out_nt + (n & 127) : n);
         if (p.out_split) {

@@ -22,11 +22,16 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          int M, int Hr, int Wr, long long out_pix_stride,
                                                          long long out_tile_stride, long long out_plane, int out_gl,
-                                                         int* range_flag, const int* run_if) {
+                                                         int* range_flag, const int* run_if, int BH) {
   extern __shared__ float img[];
   if (run_if && *run_if == 0) return;        // range-guard re-run: nothing to do unless the split path clamped
   const int H = HC ? HC : Hr, W = WC ? WC : Wr;
-  const int PW = W + 2, PHW = (H + 2) * PW;
+  // Row bands (maps whose 32 padded images do not fit the LDS, e.g. 19 x 19 at FOV 17): blockIdx.y owns output rows
+  // [ybase, ybase + bh) and stages input rows ybase - 1 .. ybase + bh only.  BH = H (one band) for the usual sizes.
+  const int BHe = HC ? HC : BH;
+  const int ybase = HC ? 0 : (int)blockIdx.y * BHe;
+  const int bh = min(BHe, H - ybase);
+  const int PW = W + 2, PHW = (BHe + 2) * PW;
   const int PS = (3 * PHW) | 1;            // odd per-agent stride
   const int HW = H * W;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -69,11 +74,14 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
       img[a * PS + c * PHW + (y + 1) * PW + xx + 1] = x[(long long)m0 * per + f];
     }
   } else {
-    for (int i = t; i < 32 * per; i += 256) {
-      const int a = i / per, r = i - a * per;
-      const int c = r / HW, q = r - c * HW;
-      const int y = q / W, xx = q - y * W;
-      if (m0 + a < M) img[a * PS + c * PHW + (y + 1) * PW + xx + 1] = x[(long long)(m0 + a) * per + r];
+    const int brows = bh + 2, bper = 3 * brows * W;      // staged rows per channel: global rows ybase - 1 + ry
+    for (int i = t; i < 32 * bper; i += 256) {
+      const int a = i / bper, r = i - a * bper;
+      const int c = r / (brows * W), q = r - c * brows * W;
+      const int ry = q / W, xx = q - ry * W;
+      const int y = ybase - 1 + ry;
+      if (m0 + a < M && y >= 0 && y < H)
+        img[a * PS + c * PHW + ry * PW + xx + 1] = x[(long long)(m0 + a) * per + c * HW + y * W + xx];
     }
   }
   // B operand (weights) and per-k LDS tap offsets for this lane half: k = s + 16*(lane>>5)
@@ -93,9 +101,10 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
   for (int q = 0; q < 4; ++q) bch[q] = *reinterpret_cast<const f32x4*>(bias + 8 * q + 4 * (lane >> 5));
   __syncthreads();
   const int abase = (lane & 31) * PS;
-  for (int pix = wave; pix < HW; pix += 4) {
-    const int oy = pix / W, ox = pix - oy * W;
+  for (int lpix = wave; lpix < bh * W; lpix += 4) {
+    const int oy = lpix / W, ox = lpix - oy * W;
     const int base = abase + oy * PW + ox;
+    const int pix = (ybase + oy) * W + ox;      // the output pixel in the whole map
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -127,8 +136,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 #pragma unroll
           for (int e = 0; e < 4; ++e) {        // pairs (2e, 2e+1) of the 8 values of quads 2 ks, 2 ks + 1
             const int q = 2 * ks + (e >> 1), c = 2 * (e & 1);
-            const float a0 = fmaxf(acc[4 * q + c] + bch[q][c], 0.f), b0 = fmaxf(acc[4 * q + c + 1] + bch[q][c + 1], 0.f);
-            if ((a0 > 65504.f || b0 > 65504.f) && range_flag) atomicOr(range_flag, 1);      // range guard (rare)
+            const float a0 = magat_relu(acc[4 * q + c] + bch[q][c]), b0 = magat_relu(acc[4 * q + c + 1] + bch[q][c + 1]);
+            if ((!(a0 <= 65504.f) || !(b0 <= 65504.f)) && range_flag) atomicOr(range_flag, 1);      // range guard (rare)
             const float a = __builtin_amdgcn_fmed3f(a0, -65504.f, 65504.f);
             const float b2 = __builtin_amdgcn_fmed3f(b0, -65504.f, 65504.f);
             const h2 h = __builtin_convertvector(f2{a, b2}, h2);
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
       for (int q = 0; q < 4; ++q) {
         f32x4 v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[4 * q + c] + bch[q][c], 0.f);
+        for (int c = 0; c < 4; ++c) v[c] = magat_relu(acc[4 * q + c] + bch[q][c]);
         if (out_gl) {
           *reinterpret_cast<f32x4*>(og + q * 1024) = v;
         } else if (out_plane == 0) {
@@ -229,8 +238,12 @@ static int conv_first_launch(const float* x, const float* wt, const float* bias,
                              int* range_flag, const int* run_if, int tag) {
   if (!x || !wt || !bias || !out) return MAGAT_ERR_NULL;
   if (M <= 0 || H <= 0 || W <= 0) return MAGAT_ERR_BAD_SHAPE;
-  const size_t lds = sizeof(float) * 32 * (size_t)((3 * (H + 2) * (W + 2)) | 1);
+  int BH = H;      // rows per band: the whole map when its 32 padded images fit the LDS
+  auto lds_for = [&](int bh) { return sizeof(float) * 32 * (size_t)((3 * (bh + 2) * (W + 2)) | 1); };
+  while (BH > 1 && lds_for(BH) > 160 * 1024) BH = (BH + 1) / 2;
+  const size_t lds = lds_for(BH);
   if (lds > 160 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  const int bands = (H + BH - 1) / BH;
   const bool c11 = H == 11 && W == 11 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
   if (lds > 64 * 1024 &&
       magat_ensure_dyn_lds(c11 ? reinterpret_cast<const void*>(&conv_first_kernel<11, 11>)
@@ -242,10 +255,10 @@ static int conv_first_launch(const float* x, const float* wt, const float* bias,
   const int pid = magat_prof_begin(tag, st);
   if (c11)
     hipLaunchKernelGGL((conv_first_kernel<11, 11>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W,
-                       pix_stride, tile_stride, out_plane, out_gl, range_flag, run_if);
+                       pix_stride, tile_stride, out_plane, out_gl, range_flag, run_if, H);
   else
-    hipLaunchKernelGGL((conv_first_kernel<0, 0>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W,
-                       pix_stride, tile_stride, out_plane, out_gl, range_flag, run_if);
+    hipLaunchKernelGGL((conv_first_kernel<0, 0>), dim3(blocks, bands), dim3(256), lds, st, x, wt, bias, out, M, H, W,
+                       pix_stride, tile_stride, out_plane, out_gl, range_flag, run_if, BH);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }

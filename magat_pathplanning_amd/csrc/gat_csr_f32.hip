@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void csr_hop_kernel(const CsrParams p) {
     }
     if (p.act_relu) {
 #pragma unroll
-      for (int c = 0; c < VEC; ++c) acc[c] = fmaxf(acc[c], 0.f);
+      for (int c = 0; c < VEC; ++c) acc[c] = magat_relu(acc[c]);
     }
     store_vec<VEC, ST>(static_cast<ST*>(p.Y) + ((long long)b * N + j) * p.ldy + head * F + VEC * lane, acc);
   } else {
@@ -303,7 +303,7 @@ __global__ void csr_k1_kernel(const CsrParams p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (p.bias) v[q] += p.bias[4 * c + q];
-      if (p.act_relu) v[q] = fmaxf(v[q], 0.f);
+      if (p.act_relu) v[q] = magat_relu(v[q]);
     }
     store_vec<4, ST>(static_cast<ST*>(p.Y) + m * p.ldy + head * F + 4 * c, v);
   }
@@ -328,17 +328,18 @@ struct WsLayout {
   size_t status, z, cscptr, cscsrc, cscpos, csctmp, att, t0, t1, ytmp, total;
 };
 WsLayout ws_layout(int B, int N, long long nnz, int G, int F, int K, int P, int mode, int concat,
-                   size_t esz = sizeof(float)) {
+                   size_t esz = sizeof(float), bool have_csc = false) {
   const Layout L = layout(G, F, K, P, mode);
   WsLayout w;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += magat_align_up(bytes, 256); return at; };
   w.status = take(256);              // range-guard status words of the maps GEMM (first bytes of the workspace)
   w.z = take((size_t)B * N * L.NC * esz);
-  w.cscptr = take((size_t)B * (N + 1) * sizeof(int));
-  w.cscsrc = take((size_t)nnz * sizeof(int));
-  w.cscpos = take((size_t)nnz * sizeof(int));
-  w.csctmp = take((size_t)nnz * sizeof(int));
+  // (the column view: nothing is reserved for it when the caller brings the one magat_gso_csr_build made)
+  w.cscptr = take(have_csc ? 0 : (size_t)B * (N + 1) * sizeof(int));
+  w.cscsrc = take(have_csc ? 0 : (size_t)nnz * sizeof(int));
+  w.cscpos = take(have_csc ? 0 : (size_t)nnz * sizeof(int));
+  w.csctmp = take(have_csc ? 0 : (size_t)nnz * sizeof(int));
   w.att = take((size_t)P * nnz * sizeof(float));
   const size_t tb = K > 2 ? (size_t)B * N * P * F * esz : 0;
   w.t0 = take(tb);
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
           }
           if (p.act_relu) {
 #pragma unroll
-            for (int c = 0; c < E; ++c) acc[c] = fmaxf(acc[c], 0.f);
+            for (int c = 0; c < E; ++c) acc[c] = magat_relu(acc[c]);
           }
           store_vec<E, ST>(static_cast<ST*>(p.Y) + ((long long)b * N + j) * p.ldy + head * F + col, acc);
         } else {
@@ -708,7 +709,7 @@ __global__ void head_mean_relu_csr_kernel(const ST* __restrict__ ytmp, ST* __res
     }
     const float fp = (float)P;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s[e] = fmaxf(s[e] / fp, 0.f);
+    for (int e = 0; e < 4; ++e) s[e] = magat_relu(s[e] / fp);
     store_vec<4, ST>(y + m * ldy + 4 * c, s);
   }
 }
@@ -761,14 +762,14 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
   if ((size_t)(2 * N + 2) * sizeof(int) > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;   // transpose LDS (N <= 8190)
   const int width = concat ? P * F : F;
   if (ldy < width || (ldy & 3)) return MAGAT_ERR_BAD_SHAPE;
-  const WsLayout w = ws_layout(B, N, nnz, G, F, K, P, mode, concat, sizeof(ST));
+  const bool have_csc = pre_cscptr && pre_cscsrc && pre_cscpos;     // made by magat_gso_csr_build (once per GSO)
+  const WsLayout w = ws_layout(B, N, nnz, G, F, K, P, mode, concat, sizeof(ST), have_csc);
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < w.total)
     return MAGAT_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* ws = static_cast<char*>(workspace);
   const Layout L = layout(G, F, K, P, mode);
   ST* Z = reinterpret_cast<ST*>(ws + w.z);
-  const bool have_csc = pre_cscptr && pre_cscsrc && pre_cscpos;     // made by magat_gso_csr_build (once per GSO)
   int* cscptr = have_csc ? const_cast<int*>(pre_cscptr) : reinterpret_cast<int*>(ws + w.cscptr);
   int* cscsrc = have_csc ? const_cast<int*>(pre_cscsrc) : reinterpret_cast<int*>(ws + w.cscsrc);
   int* cscpos = have_csc ? const_cast<int*>(pre_cscpos) : reinterpret_cast<int*>(ws + w.cscpos);
@@ -906,6 +907,13 @@ extern "C" size_t magat_gat_csr_bf16_workspace_bytes(int B, int N, long long nnz
                                                      int concat) {
   if (B <= 0 || N <= 0 || nnz < 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
   return ws_layout(B, N, nnz, G, F, K, P, mode, concat, sizeof(u16)).total;
+}
+
+// workspace of the *_csc_* entry points (the caller brings the column view: no transpose scratch)
+extern "C" size_t magat_gat_csc_workspace_bytes(int B, int N, long long nnz, int G, int F, int K, int P, int mode,
+                                                int concat, int bf16) {
+  if (B <= 0 || N <= 0 || nnz < 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
+  return ws_layout(B, N, nnz, G, F, K, P, mode, concat, bf16 ? sizeof(u16) : sizeof(float), true).total;
 }
 
 extern "C" int magat_gat_forward_csr_f32(const float* X, const int* rowptr, const int* colidx, long long nnz,

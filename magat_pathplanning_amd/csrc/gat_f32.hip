@@ -640,7 +640,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
         res += biasv;
         if (p.concat) {
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) res[e] = fmaxf(res[e], 0.f);
+          for (int e = 0; e < VEC; ++e) res[e] = magat_relu(res[e]);
         }
         if constexpr (WIDE) ucur[h] = res;      // stored after the tile wait below
         else *reinterpret_cast<fvec*>(yrow + h * ystep) = res;
@@ -663,7 +663,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
           if (hh == hpb - 1 && (ws + h * nwaves) * rpw + grp < N) {
             fvec o;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) o[e] = fmaxf(ysum[h][e] / (float)p.P, 0.f);
+            for (int e = 0; e < VEC; ++e) o[e] = magat_relu(ysum[h][e] / (float)p.P);
             *reinterpret_cast<fvec*>(mrow + h * mstep) = o;
           }
         }
@@ -735,7 +735,7 @@ __global__ void head_mean_relu_kernel(const float* __restrict__ ytmp, float* __r
     f32x4 s = *reinterpret_cast<const f32x4*>(ytmp + m * (long long)P * F + 4 * c);
     for (int q = 1; q < P; ++q) s += *reinterpret_cast<const f32x4*>(ytmp + (m * P + q) * (long long)F + 4 * c);
     const float fp = (float)P;
-    f32x4 r = {fmaxf(s[0] / fp, 0.f), fmaxf(s[1] / fp, 0.f), fmaxf(s[2] / fp, 0.f), fmaxf(s[3] / fp, 0.f)};
+    f32x4 r = {magat_relu(s[0] / fp), magat_relu(s[1] / fp), magat_relu(s[2] / fp), magat_relu(s[3] / fp)};
     *reinterpret_cast<f32x4*>(y + m * ldy + 4 * c) = r;
   }
 }

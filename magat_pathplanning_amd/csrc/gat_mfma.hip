@@ -237,6 +237,11 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
         const int row = idx >> 4, ch = idx & 15;
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + xst + idx * 32);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + xst + idx * 32 + 16);
+        // (the layer's INPUT: a NaN must raise the flag too - fmaxf drops it from the running maximum; everything later is
+        // made of these planes and finite weights)
+        if (!(fabsf(v0[0]) <= 65504.f) | !(fabsf(v0[1]) <= 65504.f) | !(fabsf(v0[2]) <= 65504.f) | !(fabsf(v0[3]) <= 65504.f) |
+            !(fabsf(v1[0]) <= 65504.f) | !(fabsf(v1[1]) <= 65504.f) | !(fabsf(v1[2]) <= 65504.f) | !(fabsf(v1[3]) <= 65504.f))
+          vmax = __builtin_inff();
         uint4 hi, lo;
         split2v(v0[0], v0[1], hi.x, lo.x, vmax);
         split2v(v0[2], v0[3], hi.y, lo.y, vmax);

@@ -139,6 +139,16 @@ __global__ __launch_bounds__(256, 2) void layer1_fused_kernel(const L1Params p) 
       }
     }
     for (int i = t; i < L1_AG; i += 256) win[i * WSTR] = 0u;
+    // range guard of the INPUT: a NaN / Inf / |x| > 65504 state tensor (the reference would hand the NaN on to the logits,
+    // resnet_pytorch.py:40-73 is plain float32) must not become a finite clamp: the negated compare is true for NaN too
+    bool xbad = false;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+#pragma unroll
+      for (int j = 0; j < MAXV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xbad |= !(__builtin_fabsf(v4[i][j][e]) <= 65504.f);
+    if (xbad && p.range_flag) atomicOr(p.range_flag, 1);
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int item = t + 256 * i;

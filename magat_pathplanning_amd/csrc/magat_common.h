@@ -94,6 +94,10 @@ __device__ __forceinline__ unsigned short magat_bf16_rne(float v) {
 }
 __device__ __forceinline__ float magat_bf16_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 
+// ReLU of the float32 kernels: hands a NaN on like torch.relu does (fmaxf(NaN, 0) would turn it into 0) - the range guard
+// sends non-finite inputs to these kernels so that they reach the logits as they do in the reference
+__device__ __forceinline__ float magat_relu(float v) { return v < 0.f ? 0.f : v; }
+
 static inline int magat_check_launch() {
   return hipGetLastError() == hipSuccess ? MAGAT_OK : MAGAT_ERR_LAUNCH;
 }

@@ -29,7 +29,10 @@ def sharded_forward(model, x, S, group=None, gather=True):
     else:
         # fewer instances than ranks: this rank owns nothing, but it still has to enter the all_gather below (a rank that
         # raised on its empty batch would leave the others blocked in the collective)
-        local = torch.zeros(0, 5, dtype=torch.float32, device=x.device)
+        # (on the device and with the width the other ranks' logits have - x may be host-resident)
+        dev = next(model.parameters()).device
+        width = [m for m in model.actionsMLP if isinstance(m, torch.nn.Linear)][-1].out_features
+        local = torch.zeros(0, width, dtype=torch.float32, device=dev)
     if not gather or world == 1:
         return local
     cap = (B + world - 1) // world * N

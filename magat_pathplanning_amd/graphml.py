@@ -91,75 +91,104 @@ def dense_gso_to_csr(S3, self_loops=False):
 
 class CsrStructure:
     """CSR + CSC edge structure of one GSO tensor, made on the device by magat_gso_csr_build (N <= 1024): one streaming
-    pass over S (with addGSO's scrub fused in) + one small kernel, no host synchronisation.  `cap` is the capacity the index
-    arrays were allocated with (B*N*N: cannot overflow) and what the forward kernels receive as `nnz` (they use it only as
-    a stride); the true edge count lives on the device in `nnz_dev`."""
+    pass over S (with addGSO's scrub fused in) + one small kernel, on a side stream under the per-agent CNN.
 
-    _CAP_LIMIT = 1 << 28          # entries; above it the exact (synchronising) path is used
+    Capacity: the index arrays hold `cap` entries - a guess (32 edges per node at first, the dense bound B*N*N at most),
+    not the dense bound: the kernel drops entries beyond it and leaves the true edge count on the device, which travels to
+    pinned host memory behind the build.  `ready()` - called in front of the graph layer, when the encoder's launches are
+    already queued, so the wait costs no GPU time - waits for that copy, and re-builds with a larger capacity in the rare
+    case the guess was too small.  The forward kernels then get the EXACT count (their attention / scratch buffers are
+    sized by it)."""
+
+    _CAP_LIMIT = 1 << 31          # entries (int32 offsets)
 
     def __init__(self):
         self.key = None
-        self.rowptr = self.colidx = self.cscptr = self.csc = self.nnz_dev = self.ws = None
+        self.rowptr = self.colidx = self.cscptr = self.csc = self.nnz_dev = self.nnz_host = self.ws = None
         self.cap = 0
         self.side = self.event = None
+        self.args = None
+        self.nnz = None
 
     @staticmethod
     def supported(B, N):
-        return nat.lib().magat_gso_csr_workspace_bytes(B, N) > 0 and B * N * N <= CsrStructure._CAP_LIMIT
+        return nat.lib().magat_gso_csr_workspace_bytes(B, N) > 0 and B * N * N < CsrStructure._CAP_LIMIT
 
-    def build(self, S3, rule, scrub_nan=0, gso_mode=0):
-        """S3 (B,N,N) contiguous f32|f64 device tensor (scrubbed IN PLACE when asked to)."""
+    def _alloc(self, B, N, cap, dev):
+        lib = nat.lib()
+        if self.rowptr is None or self.rowptr.numel() != B * (N + 1) or self.rowptr.device != dev:
+            self.rowptr = torch.empty(B * (N + 1), dtype=torch.int32, device=dev)
+            self.cscptr = torch.empty(B * (N + 1), dtype=torch.int32, device=dev)
+            self.nnz_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.nnz_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+            self.ws = torch.empty(lib.magat_gso_csr_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
+            self.cap = 0
+        if self.cap < cap or self.colidx is None or self.colidx.device != dev:
+            self.colidx = torch.empty(cap, dtype=torch.int32, device=dev)
+            self.csc = torch.empty(2, cap, dtype=torch.int32, device=dev)
+            self.cap = cap
+
+    def build(self, S3, rule, scrub_nan=0, gso_mode=0, min_cap=0):
+        """S3 (B,N,N) contiguous f32|f64 device tensor (scrubbed IN PLACE when asked to: the caller's stream is then
+        ordered behind the pass, so that S is the scrubbed tensor for every later reader, as after the reference's addGSO)."""
         lib = nat.lib()
         B, N, _ = S3.shape
         dev = S3.device
-        cap = B * N * N
+        dense = B * N * N
         with torch.cuda.device(dev):
-            if self.rowptr is None or self.rowptr.numel() != B * (N + 1) or self.cap != cap or self.rowptr.device != dev:
-                self.rowptr = torch.empty(B * (N + 1), dtype=torch.int32, device=dev)
-                self.cscptr = torch.empty(B * (N + 1), dtype=torch.int32, device=dev)
-                self.colidx = torch.empty(cap, dtype=torch.int32, device=dev)
-                self.csc = torch.empty(2, cap, dtype=torch.int32, device=dev)
-                self.nnz_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-                self.ws = torch.empty(lib.magat_gso_csr_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
-                self.cap = cap
+            if self.rowptr is not None and (self.rowptr.numel() != B * (N + 1) or self.rowptr.device != dev):
+                self.cap = 0
+            cap = max(self.cap, min(dense, max(int(min_cap), 32 * B * N, 1 << 12)))
+            cur = torch.cuda.current_stream(dev)
             # On a side stream by default (MAGAT_CSR_SIDE=0: in the caller's stream): the build needs nothing but S, so it may
             # run under the per-agent CNN wherever the encoder kernels leave compute units free; the layer's CSR kernels wait
-            # for its event (c5: 7.05 -> 7.00 ms per step; most of the 0.39 ms stays exposed because the persistent
-            # encoder kernels fill every register file)
+            # for its event
             side = os.environ.get("MAGAT_CSR_SIDE", "1") == "1"
+            if side and self.side is None:
+                self.side = torch.cuda.Stream(device=dev)
+            run = self.side if side else cur
             if side:
-                if self.side is None:
-                    self.side = torch.cuda.Stream(device=dev)
-                cur = torch.cuda.current_stream(dev)
                 self.side.wait_stream(cur)
-                with torch.cuda.stream(self.side):
-                    nat.check(lib.magat_gso_csr_build(
-                        nat.ptr(S3), 1 if S3.dtype == torch.float64 else 0, int(scrub_nan), int(gso_mode), int(rule),
-                        nat.ptr(self.rowptr), nat.ptr(self.colidx), nat.ptr(self.cscptr), nat.ptr(self.csc[0]),
-                        nat.ptr(self.csc[1]), cap, nat.ptr(self.nnz_dev), nat.ptr(self.ws), self.ws.numel(), B, N,
-                        nat.current_stream(dev)), "magat_gso_csr_build")
-                    self.event = self.side.record_event()
-                S3.record_stream(self.side)
-            else:
-                self.event = None
+            with torch.cuda.stream(run):
+                self._alloc(B, N, cap, dev)          # (allocated under the stream that writes them)
                 nat.check(lib.magat_gso_csr_build(
                     nat.ptr(S3), 1 if S3.dtype == torch.float64 else 0, int(scrub_nan), int(gso_mode), int(rule),
                     nat.ptr(self.rowptr), nat.ptr(self.colidx), nat.ptr(self.cscptr), nat.ptr(self.csc[0]),
-                    nat.ptr(self.csc[1]), cap, nat.ptr(self.nnz_dev), nat.ptr(self.ws), self.ws.numel(), B, N,
+                    nat.ptr(self.csc[1]), self.cap, nat.ptr(self.nnz_dev), nat.ptr(self.ws), self.ws.numel(), B, N,
                     nat.current_stream(dev)), "magat_gso_csr_build")
+                self.nnz_host.copy_(self.nnz_dev, non_blocking=True)
+                self.event = run.record_event()
+            if side:
+                S3.record_stream(self.side)
+                for t in (self.rowptr, self.colidx, self.cscptr, self.csc, self.nnz_dev, self.ws):
+                    t.record_stream(cur)             # (read by the layer's kernels on the caller's stream)
+                if scrub_nan or gso_mode:
+                    cur.wait_event(self.event)       # S is being rewritten: nothing of the caller's may read it earlier
         self.key = (S3.data_ptr(), B, N, S3.dtype, int(rule), str(dev))
+        self.args = (S3, rule, scrub_nan, gso_mode)
+        self.nnz = None
         return self
 
-    def wait(self, dev):
-        """Order the current stream behind a structure built on the side stream."""
-        if getattr(self, "event", None) is not None:
-            torch.cuda.current_stream(dev).wait_event(self.event)
+    def ready(self, dev):
+        """Orders the current stream behind the build and returns the exact edge count (host wait for the count's copy;
+        re-build when the capacity guess was exceeded)."""
+        for _ in range(3):
+            self.event.synchronize()
+            self.nnz = int(self.nnz_host[0])
+            if self.nnz <= self.cap:
+                break
+            S3, rule, scrub, gmode = self.args
+            self.build(S3, rule, scrub, gmode, min_cap=self.nnz + self.nnz // 4)
+        else:
+            raise nat.MagatNativeError("CSR structure build did not converge (nnz %d, cap %d)" % (self.nnz, self.cap))
+        torch.cuda.current_stream(dev).wait_event(self.event)
+        return self.nnz
 
     def matches(self, S3, rule):
         return self.key == (S3.data_ptr(), S3.shape[0], S3.shape[1], S3.dtype, int(rule), str(S3.device))
 
     def exact_nnz(self):
-        return int(self.nnz_dev.item())
+        return self.nnz if self.nnz is not None else self.ready(self.rowptr.device)
 
 
 def gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=None, want_attention=False, csc=None):
@@ -180,7 +209,10 @@ def gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=None, want_attention
     bf16 = X.dtype == torch.bfloat16
     X = X.contiguous() if bf16 else X.contiguous().float()
     sdt = torch.bfloat16 if bf16 else torch.float32
-    ws_fn = lib.magat_gat_csr_bf16_workspace_bytes if bf16 else lib.magat_gat_csr_workspace_bytes
+    if csc is not None:
+        ws_fn = lambda *a: lib.magat_gat_csc_workspace_bytes(*a, 1 if bf16 else 0)
+    else:
+        ws_fn = lib.magat_gat_csr_bf16_workspace_bytes if bf16 else lib.magat_gat_csr_workspace_bytes
     dev = X.device
     sc = layer._scratch
     with torch.cuda.device(dev):
@@ -300,12 +332,10 @@ def gat_forward_rows(X, S, layer, out=None, want_attention=False, plan=None, csr
                 if layer._scratch.csr is None:
                     layer._scratch.csr = CsrStructure()
                 csr = layer._scratch.csr.build(S3, rule)
-            csr.wait(X.device)
-            out, att = gat_forward_rows_csr(X, csr.rowptr, csr.colidx, csr.cap, layer, out=out,
+            nnz = csr.ready(X.device)
+            out, att = gat_forward_rows_csr(X, csr.rowptr, csr.colidx, nnz, layer, out=out,
                                             want_attention=want_attention, csc=(csr.cscptr, csr.csc[0], csr.csc[1]))
-            aij = None
-            if want_attention:       # (only returnAttentionGSO callers: the one place the exact count is needed)
-                aij = _csr_attention_to_dense(att, csr.rowptr, csr.colidx, csr.exact_nnz(), B, N, P)
+            aij = _csr_attention_to_dense(att, csr.rowptr, csr.colidx, nnz, B, N, P) if want_attention else None
             return out, aij
         rowptr, colidx, nnz = dense_gso_to_csr(S3, self_loops=layer.attentionMode == "GAT_origin")
         out, att = gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=out, want_attention=want_attention)

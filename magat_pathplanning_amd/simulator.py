@@ -50,6 +50,9 @@ def batched_gso(pos, comm_radius, symmetric_norm=False, normalize=True, dtype=to
     hands it over, or float32 like the dataloader).  `comm_radius`: one number, or a (B,) float64 device tensor of
     per-instance radii (batched_connect_radius: the radius each instance grew to at step 0)."""
     pos = _dev_i32(pos, "pos")
+    assert pos.dim() == 3 and pos.shape[2] == 2, "pos must be (B,N,2)"
+    if dtype not in (torch.float32, torch.float64):      # (the kernels write 4- or 8-byte entries: nothing else fits S)
+        raise TypeError("batched_gso: dtype must be torch.float32 or torch.float64, got %s" % (dtype,))
     if isinstance(comm_radius, torch.Tensor):
         B, N, _ = pos.shape
         if not comm_radius.is_cuda or comm_radius.dtype != torch.float64 or comm_radius.numel() != B:
@@ -63,8 +66,6 @@ def batched_gso(pos, comm_radius, symmetric_norm=False, normalize=True, dtype=to
                                                     nat.ptr(lam), B, N, nat.current_stream(pos.device)),
                       "magat_sim_gso_radii")
         return (S, lam) if return_lambda else S
-    assert pos.dim() == 3 and pos.shape[2] == 2, "pos must be (B,N,2)"
-    assert dtype in (torch.float32, torch.float64)
     B, N, _ = pos.shape
     S = torch.empty(B, N, N, dtype=dtype, device=pos.device)
     lam = torch.empty(B, dtype=torch.float64, device=pos.device)
@@ -167,7 +168,13 @@ class BatchedEpisode:
     def gso(self, dtype=torch.float64):
         """getGSO(step): at the first call the radius grows until each instance's graph is connected and is kept."""
         if self.radii is None:
-            self.radii = batched_connect_radius(self.pos, self.comm_radius)
+            self.radii, steps = batched_connect_radius(self.pos, self.comm_radius, return_steps=True)
+            # once per episode (the reference grows the radius until the graph IS connected, new_simulator.py:759-768):
+            # an instance still disconnected after the kernel's step limit must not be used silently
+            if bool((steps < 0).any().item()):
+                bad = torch.nonzero(steps < 0).flatten().tolist()
+                raise nat.MagatNativeError("communication graph still disconnected after the radius growth limit in "
+                                           "instances %s" % bad[:8])
         return batched_gso(self.pos, self.radii, symmetric_norm=self.symmetric_norm, dtype=dtype)
 
     def states(self):

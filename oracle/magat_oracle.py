@@ -432,7 +432,10 @@ def init_state_dict(cfg, seed=1337, perturb_bn=True):
             sd["ConvLayers.%d.bias" % idx] = 0.05 * torch.randn(ch[l + 1], generator=g)
             bn("ConvLayers.%d" % (idx + 1), ch[l + 1])
             idx += 3 + (1 if l % 2 == 0 else 0)
-        nfm = 128
+        w = h = cfg.FOV + 2              # decentralplanner_GAT_bottleneck.py:132-140: three MaxPool2d(2), floor mode
+        for _ in range(3):
+            w, h = (w - 2) // 2 + 1, (h - 2) // 2 + 1
+        nfm = 128 * w * h
     bmode = getattr(cfg, "bottleneckMode", "BottomNeck_only")
     G = cfg.bottleneckFeature if bmode in SKIP_MODES else cfg.numInputFeatures
     sd["compressMLP.0.weight"] = xavier(G, nfm)

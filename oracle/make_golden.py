@@ -111,7 +111,11 @@ def model_fixture(classes, name, seed, B, **cfgkw):
             if n_.endswith(".bias") and p_.dim() == 1 and "bn" not in n_ and "downsample" not in n_:
                 p_.normal_(0, 0.05, generator=gen)
     N = cfg.num_agents
-    x = fov_states(gen, B, N)
+    if cfg.FOV == 9:
+        x = fov_states(gen, B, N)
+    else:
+        from magat_pathplanning_amd.synthetic import fov_states as fov_states_any
+        x = fov_states_any(B, N, seed=seed + 1, fov=cfg.FOV)
     f64 = cfgkw.get("_f64", True)
     S = tricky_gso(gen, B, N, 0.25 if N <= 20 else 0.08, True)
     if cfg.bottleneckMode != "BottomNeck_only":
@@ -226,8 +230,27 @@ def main_directed():
         print("wrote", path, os.path.getsize(path) // 1024, "KB")
 
 
+def main_fov():
+    """Round 3: CNN_mode Default at fields of view other than 9 (decentralplanner_GAT_bottleneck*.py:118-147 sizes its
+    feature map from config.FOV): 19 x 19 maps leave 2 x 2 pooled cells (512 features, Flatten is (channel, cell)-ordered),
+    9 x 9 maps one."""
+    _, classes = import_reference()
+    models = [("default_cnn_fov17_skipconcat", dict(num_agents=6, nGraphFilterTaps=3, nAttentionHeads=2, B=2, FOV=17,
+                                                     CNN_mode="Default", bottleneckMode="BottomNeck_skipConcat")),
+              ("default_cnn_fov7", dict(num_agents=7, nGraphFilterTaps=2, nAttentionHeads=2, B=2, FOV=7,
+                                        CNN_mode="Default", attentionMode="GAT_modified", bottleneckFeature=64))]
+    for i, (name, kw) in enumerate(models):
+        B = kw.pop("B")
+        fx = model_fixture(classes, name, 7373 + i, B, **kw)
+        path = os.path.join(OUT, "model_%s.npz" % name)
+        np.savez_compressed(path, **fx)
+        print("wrote", path, os.path.getsize(path) // 1024, "KB")
+
+
 if __name__ == "__main__":
-    if "--directed" in sys.argv:
+    if "--fov" in sys.argv:
+        main_fov()
+    elif "--directed" in sys.argv:
         main_directed()
     elif "--gnn" in sys.argv:
         main_gnn()

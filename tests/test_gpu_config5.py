@@ -73,6 +73,57 @@ def test_gso_csr_build_matches_the_definition(gpu_device, N, dtype, rule):
     assert torch.equal(Sd2.cpu(), w2)
 
 
+def test_gso_csr_capacity_guess_regrows(gpu_device):
+    """The index arrays are sized by a guess (32 edges per node), not by the dense bound B*N*N: a graph denser than the guess
+    makes the kernel drop the overflow, the count that travels back shows it, and ready() re-builds with room - same
+    structure as a construction on the host, and the layer's result equals the dense-kernel result for the same graph."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from magat_pathplanning_amd.graphml import CsrStructure, gat_forward_rows_csr
+    from magat_pathplanning_amd.synthetic import directed_gso
+    B, N = 3, 120
+    S = torch.nan_to_num(directed_gso(B, N, 0.6, seed=5, dtype=torch.float32))
+    Sd = S.to(gpu_device)
+    st = CsrStructure().build(Sd, 0)
+    first_cap = st.cap
+    nnz = st.ready(gpu_device)
+    rowptr, colidx, cscptr, cscsrc, cscpos, want = _legacy_structure(S, 0, gpu_device)
+    assert want > first_cap and nnz == want and st.cap >= nnz and st.cap < B * N * N
+    assert torch.equal(st.rowptr.cpu().long(), rowptr) and torch.equal(st.colidx[:nnz].cpu().long(), colidx)
+    assert torch.equal(st.csc[0][:nnz].cpu().long(), cscsrc) and torch.equal(st.csc[1][:nnz].cpu().long(), cscpos)
+    torch.manual_seed(3)
+    layer = GraphFilterBatchAttentional(32, 32, 3, 2, attentionMode="KeyQuery").to(gpu_device).eval()
+    X = torch.randn(B, N, 32, device=gpu_device)
+    out, _ = gat_forward_rows_csr(X, st.rowptr, st.colidx, nnz, layer, csc=(st.cscptr, st.csc[0], st.csc[1]))
+    layer.addGSO(Sd.unsqueeze(1))
+    with torch.no_grad():
+        dense = layer(X.permute(0, 2, 1).contiguous()).permute(0, 2, 1).reshape(B * N, -1)
+    np.testing.assert_allclose(out.cpu().numpy(), dense.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+def test_addgso_scrub_is_ordered_for_the_callers_stream(gpu_device):
+    """the CSR branch of addGSO scrubs S on a side stream - every reader on the caller's stream after addGSO
+    returns must see the scrubbed tensor (the reference's addGSO has mutated S when it returns), without a device sync."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    from magat_pathplanning_amd.synthetic import comm_gso, make_config
+    B, N = 16, 1000
+    cfg = make_config(num_agents=N, nGraphFilterTaps=2, nAttentionHeads=4, GSO_mode="dist_GSO_one", device=str(gpu_device))
+    cfg.gat_storage = "bf16"
+    net = DecentralPlannerGATNet(cfg).to(gpu_device).eval()
+    S = comm_gso(B, N, 206, seed=3)
+    S[:, 7, 9] = float("nan")
+    want = S.clone()
+    want[torch.isnan(want)] = 0
+    want[want > 0] = 1
+    for _ in range(3):
+        Sd = S.to(gpu_device)
+        big = torch.randn(64, 1024, 1024, device=gpu_device)
+        (big @ big).sum()                                   # the caller's stream is busy: the side stream starts behind it
+        net.addGSO(Sd)
+        seen = Sd.clone()                                   # caller's stream, no synchronisation in between
+        assert torch.equal(seen.cpu(), want)
+
+
 @pytest.mark.parametrize("tiled", [3, 7, 0])
 @pytest.mark.parametrize("storage", ["bf16", "fp32"])
 def test_config5_layer_at_1000_agents(gpu_device, storage, tiled, libopt):

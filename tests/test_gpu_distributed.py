@@ -56,6 +56,12 @@ def _worker(rank, world, port, B, N, ret):
             single = net(x)
         # instance shards never interact: the gathered logits ARE the single-process ones, bit for bit
         assert torch.equal(full, single)
+        if world > 1:
+            # fewer instances than ranks, inputs host-resident: the rank that owns nothing still enters the all_gather,
+            # with a placeholder on ITS device (a CPU placeholder under nccl would fail and leave the others blocked)
+            with torch.no_grad():
+                one = sharded_forward(net, x[:1].cpu(), S[:1].clone(), gather=True)
+            assert torch.equal(one, single[:N])
         if rank == 0:
             ret["ok"] = True
         dist.barrier()

@@ -86,9 +86,11 @@ def test_conv_gemm_vs_conv2d(gpu_device, cin, cout, hin, stride, c2):
     np.testing.assert_allclose(got.numpy(), ref.float().numpy(), rtol=0, atol=3e-5)
 
 
-def test_conv_first(gpu_device):
+@pytest.mark.parametrize("H", [11, 9, 18, 19, 27])
+def test_conv_first(gpu_device, H):
+    """(19 and 27: the 32 padded images of a workgroup exceed the LDS, the kernel walks row bands)"""
     nat, lib = _nat()
-    M, H = 77, 11
+    M = 77
     g = torch.Generator().manual_seed(5)
     x = (torch.rand(M, 3, H, H, generator=g) < 0.3).float()
     w = torch.randn(32, 3, 3, 3, generator=g)

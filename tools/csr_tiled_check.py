@@ -16,7 +16,7 @@ for dt in (torch.float32, torch.bfloat16):
     res = {}
     for tiled in (0, 3):
         nat.set_option("CSR_TILED", tiled)
-        out, att = gat_forward_rows_csr(X, st.rowptr, st.colidx, st.cap, layer, want_attention=True,
+        out, att = gat_forward_rows_csr(X, st.rowptr, st.colidx, st.exact_nnz(), layer, want_attention=True,
                                         csc=(st.cscptr, st.csc[0], st.csc[1]))
         torch.cuda.synchronize()
         nnz = st.exact_nnz()
@@ -31,7 +31,7 @@ y_ref, a_ref = orc.gat_layer_forward(X.permute(0, 2, 1).contiguous(), S.cpu().un
 y_ref = y_ref.permute(0, 2, 1).reshape(B * N, -1)
 for tiled in (0, 1, 2, 3):
     nat.set_option("CSR_TILED", tiled)
-    out, att = gat_forward_rows_csr(X.to(dev), st.rowptr, st.colidx, st.cap, layer, want_attention=False,
+    out, att = gat_forward_rows_csr(X.to(dev), st.rowptr, st.colidx, st.exact_nnz(), layer, want_attention=False,
                                     csc=(st.cscptr, st.csc[0], st.csc[1]))
     torch.cuda.synchronize()
     print("tiled=%d vs oracle: %.3g" % (tiled, float((out.cpu() - y_ref).abs().max())))
