@@ -38,8 +38,15 @@ constexpr int LDS_X2 = MAP32, LDS_Z = 0, LDS_Y = MAP64, LDS_X1N = MAP64 + MAP32,
 constexpr int TAPBIAS = 7 * PIXB;           // tap shifts are (6 dy + dx) pixel slots in [-7, 7]: biased to stay non-negative
 
 // row tiles by tap-validity class: pixel = 6 y + x
-__device__ constexpr int TILE_PIX[9][4] = {{7, 8, 9, 10},    {13, 14, 15, 16}, {19, 20, 21, 22}, {25, 26, 27, 28},
-                                           {1, 2, 3, 4},     {31, 32, 33, 34}, {6, 12, 18, 24},  {11, 17, 23, 29},
+// The order INSIDE a tile (the pixel of slot psl = (lane & 31) >> 3) and the split of the 16 interior pixels over the four
+// interior tiles are chosen for the 2 x 2 pooling behind layer3 (block_full_p_kernel): the four pixels of every corner cell
+// sit at the SAME slot of four different tiles (C, one row edge, one column edge, interior tile 0) - a lane sums them in
+// registers - the edge-middle cells are two in-lane pairs one lane-bit apart (slots {0,1} / {2,3}: DPP row_ror:8; slots
+// {0,2} / {1,3}: lanes 16 apart), and the centre cell is interior tile 3.  Slot pairs {0,1} and {2,3} hold pixels of
+// opposite parity wherever the class allows it (ds_read_b128 is served 16 lanes = two slots at a time: conflict-free);
+// the two column-edge tiles are 2-way, as with any order.
+__device__ constexpr int TILE_PIX[9][4] = {{7, 10, 25, 28},  {26, 27, 8, 9},   {16, 13, 22, 19}, {14, 15, 20, 21},
+                                           {1, 4, 2, 3},     {32, 33, 31, 34}, {6, 12, 24, 18},  {17, 11, 23, 29},
                                            {0, 5, 30, 35}};
 // valid taps t = 3 (dy + 1) + (dx + 1) of every pixel of the tile (corners: union; per-lane validity handled by address)
 __device__ constexpr int TILE_TAPS[9] = {0x1FF, 0x1FF, 0x1FF, 0x1FF, 0x1F8, 0x03F, 0x1B6, 0x0DB, 0x1FF};
@@ -1192,6 +1199,167 @@ __global__ __launch_bounds__(256, 1) void block_full_w4_kernel(const FullParams 
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
+
+// ---- block_full_w4_kernel with the 2 x 2 pooling done in REGISTERS (option BLOCK_FULL = 2).  The pooled epilogue of the kernel
+// above costs 14 k of a group's 162 k cycles with the matrix pipe idle: the 144 accumulators go through an LDS scratch in two
+// passes (scratch writes, barrier, pooling reads, barrier, zero-slot repair).  With the slot order of TILE_PIX a lane holds, for
+// its 16 channels: one whole corner cell (4 registers of 4 tiles), two half cells whose other halves sit one lane-bit away,
+// and a quarter of the centre cell - 11 adds, 4 selects and 4 lane exchanges per channel, no LDS, no barrier; every lane
+// then stores pooled values straight from registers.  The next group's inputs land in the MID region (dead once every wave
+// has left conv2), so the units keep their roles from group to group (no rotation).
+__global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const ChainParams& p = q.c;
+  const L3Params& l3 = q.l;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  for (int i = t; i < 32 * (PIXB / 4); i += 256)
+    *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
+  auto dma_map = [&](const char* base, int group, int lds_off, int first, int step, int last) {
+    const int m0 = group * AG;
+    const long long tile_b = (long long)(m0 >> 7) * NPIX * (128 * 32 * 4) + (m0 & 127) * 16;    // bytes: agent tile, agents
+    for (int item = first; item < last; item += step) {
+      const int blk = item / 5, part = item % 5;             // blk = plane * 4 + chunk
+      const int pix = part * 8 + (lane >> 3);
+      const char* src = base + tile_b + (long long)pix * (128 * 32 * 4) + (blk >> 2) * (256 * 32) + (blk & 3) * 2048 +
+                        (lane & 7) * 16;
+      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(lds_off + blk * BLK + part * 8 * PIXB));
+      if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+    }
+  };
+  const float sA = *p.sA, sB = *p.sB, sC = *p.sC, s1 = *l3.s1, s2 = *l3.s2;
+  bool clamped = false;
+  const int ct = wave & 1, rg = wave >> 1, ct2 = wave;
+  constexpr int BPT1 = 9 * 4 * 2, BPT2A = 9 * 4 * 2, BPT2B = (9 * 4 + 4) * 2;      // 1 KB blocks per channel tile (layer3)
+  f32x4 bq[4];                      // conv2's bias (loaded once: a load behind the input DMA would wait for it)
+  {
+    const int fh = lane >> 5;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const f32x4*>(l3.b2 + 32 * ct2 + 8 * qd + 4 * fh);
+  }
+  const int gstride = (int)gridDim.x;
+  constexpr int U0 = 0, U1 = MAP32, U2 = 2 * MAP32, U3 = 3 * MAP32;
+  if ((int)blockIdx.x < p.groups) {
+    dma_map(p.in1, blockIdx.x, U3, wave, 4, 40);
+    dma_map(p.in2, blockIdx.x, U2, wave, 4, 40);
+  }
+#pragma unroll 1
+  for (int group = blockIdx.x; group < p.groups; group += gstride) {
+    const bool rows_ok = group * AG + ((lane & 31) & 7) < p.M;
+    const bool more = group + gstride < p.groups;
+    FULL_STAMP(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this group's inputs (requested during the previous group's epilogue)
+    __syncthreads();
+    FULL_STAMP(1);
+    // A: layer1.conv2 (32 -> 32) + downsample(stem stride-2 pixels)      X1 @ U3, X2 @ U2 -> Y @ U1
+    switch (wave) {
+      case 0: chain_stage4<W4P0, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
+      case 1: chain_stage4<W4P1, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
+      case 2: chain_stage4<W4P2, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
+      default: chain_stage4<W4P3, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
+    }
+    __syncthreads();
+    FULL_STAMP(2);
+    // B: layer2.conv1 (32 -> 64)                                          Y @ U1 -> Z @ (U2, U3)
+    if (rg == 0) chain_stage4<W4A, 32, 0, 64, false>(p, lds, U1, 0, U2, p.wB, ct, p.bB, sB, group, clamped);
+    else chain_stage4<W4B, 32, 0, 64, false>(p, lds, U1, 0, U2, p.wB, ct, p.bB, sB, group, clamped);
+    __syncthreads();
+    FULL_STAMP(3);
+    // C: layer2.conv2 (64 -> 64) + downsample(Y)                          Z @ (U2, U3), Y @ U1 -> layer3's input @ (U0, U1)
+    if (rg == 0) chain_stage4<W4A, 64, 32, 64, false, true>(p, lds, U2, U1, U0, p.wC, ct, p.bC, sC, group, clamped);
+    else chain_stage4<W4B, 64, 32, 64, false, true>(p, lds, U2, U1, U0, p.wC, ct, p.bC, sC, group, clamped);
+    __syncthreads();
+    FULL_STAMP(4);
+    // layer3: IN = (U0, U1), MID = (U2, U3)
+    constexpr int L_IN = U0, L_MID = U2;
+    const int ct1 = ct, rg1 = rg;
+    f32x16 acc[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      const char* w2 = h == 0 ? l3.w2a + (size_t)ct2 * BPT2A * 1024 : l3.w2b + (size_t)ct2 * BPT2B * 1024;
+      // conv1, output channels 64 h .. 64 h + 63 -> MID (channel tiles 2 h + ct1 of the weight block)
+      const char* w1h = l3.w1 + (size_t)(2 * h) * BPT1 * 1024;
+      if (rg1 == 0) {
+        f32x16 a1[W4A::NT];
+#pragma unroll
+        for (int s = 0; s < W4A::NT; ++s)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
+        walk4<W4A, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1h + (size_t)ct1 * BPT1 * 1024, a1, false);
+        if (h == 0) FULL_STAMP(11);
+        const int tl[W4A::NT] = {W4A::t[0], W4A::t[1], W4A::t[2], W4A::t[3]};
+        epi_to_lds<64, W4A::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
+      } else {
+        f32x16 a1[W4B::NT];
+#pragma unroll
+        for (int s = 0; s < W4B::NT; ++s)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
+        walk4<W4B, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1h + (size_t)ct1 * BPT1 * 1024, a1, false);
+        if (h == 0) FULL_STAMP(11);
+        const int tl[W4B::NT] = {W4B::t[0], W4B::t[1], W4B::t[2], W4B::t[3], W4B::t[4]};
+        epi_to_lds<64, W4B::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
+      }
+      if (h == 0) FULL_STAMP(12);
+      __syncthreads();
+      FULL_STAMP(5 + 2 * h);
+      walk4<W4All, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_MID, L_IN, w2, acc, h == 1);
+      // (after the first half: MID is rewritten by the next conv1; after the second: MID and IN are dead in every wave)
+      L3_LDS_SYNC();
+      FULL_STAMP(6 + 2 * h);
+    }
+    // the next group's inputs -> the MID region, X1 @ U3, X2 @ U2: in flight under the pooling below
+    if (more) {
+      dma_map(p.in1, group + gstride, U3, wave, 4, 40);
+      dma_map(p.in2, group + gstride, U2, wave, 4, 40);
+    }
+    FULL_STAMP(9);
+    // ---- relu(acc * s2 + bias), 2 x 2 sums in registers, stores.  Accumulator s = tile W4All::t[s]:
+    //      0..3 interior tiles Ia Ib Ic Id, 4 C, 5 T (top), 6 B (bottom), 7 L (left), 8 R (right)
+    {
+      const int fr = lane & 31, fh = lane >> 5, agent = fr & 7;
+      const bool lo = (lane >> 3) & 1, hi = (lane >> 4) & 1;       // slot psl = 2 hi + lo
+      const int m = group * AG + agent;
+      // cells of this lane: its corner cell, the row-edge-middle cell it shares with the lane 8 away, the column-edge-middle
+      // cell it shares with the lane 16 away, the centre cell (shared by all four slots)
+      const int cellF = 2 * (int)lo + 6 * (int)hi, cell0 = hi ? 1 : 7, cell1 = lo ? 3 : 5;
+      float* ob = l3.out + (long long)(m >> 7) * 9 * (128 * 128) + (m & 127) * 128 + 32 * ct2 + 4 * fh;
+      const bool mok = m < p.M;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 vF, v0, v1, v2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int r = 4 * qd + c;
+          float v[9];
+#pragma unroll
+          for (int s = 0; s < 9; ++s) v[s] = fmaxf(acc[s][r] * s2 + bq[qd][c], 0.f);
+          const float u = hi ? v[6] : v[5], ux = hi ? v[5] : v[6];
+          const float w_ = lo ? v[8] : v[7], wx = lo ? v[7] : v[8];
+          vF[c] = (v[4] + v[0]) + (u + w_);
+          const float p0 = ux + v[1], p1 = wx + v[2], p2 = v[3];
+          v0[c] = p0 + dpp_mov<0x128>(p0);                       // + the lane 8 away (row_ror:8)
+          v1[c] = p1 + __shfl_xor(p1, 16, 64);                   // + the lane 16 away
+          const float p2b = p2 + dpp_mov<0x128>(p2);
+          v2[c] = p2b + __shfl_xor(p2b, 16, 64);
+        }
+        if (mok) {
+          *reinterpret_cast<f32x4*>(ob + (long long)cellF * (128 * 128) + 8 * qd) = vF;
+          if (!lo) *reinterpret_cast<f32x4*>(ob + (long long)cell0 * (128 * 128) + 8 * qd) = v0;
+          if (!hi) *reinterpret_cast<f32x4*>(ob + (long long)cell1 * (128 * 128) + 8 * qd) = v1;
+          if (!lo && !hi) *reinterpret_cast<f32x4*>(ob + (long long)4 * (128 * 128) + 8 * qd) = v2;
+        }
+      }
+    }
+    FULL_STAMP(10);
+  }
+  if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
+}
+
 }  // namespace
 
 // bytes of one stage's fragment-major weight block (without the trailing scale float)
@@ -1332,7 +1500,10 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
 #ifdef MAGAT_DEBUG_HOOKS
   l.dbg = g_block3_dbg;
 #endif
-  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block_full_w4_kernel), MAGAT_LDS_BLOCK_FULL, LDS_TOTAL) != MAGAT_OK)
+  const bool pooled_regs = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 2;      // 2: pooling in registers (block_full_p_kernel)
+  if (magat_ensure_dyn_lds(pooled_regs ? reinterpret_cast<const void*>(&block_full_p_kernel)
+                                       : reinterpret_cast<const void*>(&block_full_w4_kernel),
+                           pooled_regs ? MAGAT_LDS_BLOCK_FULL_P : MAGAT_LDS_BLOCK_FULL, LDS_TOTAL) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -1341,7 +1512,8 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
   }
   const int grid = p.groups < cus ? p.groups : cus;
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_FULL, st);
-  hipLaunchKernelGGL(block_full_w4_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
+  if (pooled_regs) hipLaunchKernelGGL(block_full_p_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
+  else hipLaunchKernelGGL(block_full_w4_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }

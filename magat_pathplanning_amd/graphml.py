@@ -385,6 +385,24 @@ def pack_torch(weight, weight_bias, mixer, taps, mode_name):
     return Bt, cb
 
 
+def _gemm_nt(a, bt, dev):
+    """a [M][K] @ bt[N][K]^T -> [M][N] float32 on magat_linear_f32 (conv_gemm_f32.hip); K a multiple of 4 after padding."""
+    M, K = a.shape
+    Nn = bt.shape[0]
+    if K % 4:                      # (row strides must be multiples of 4 floats: pad the contraction with zeros)
+        pad = 4 - K % 4
+        a = torch.nn.functional.pad(a, (0, pad))
+        bt = torch.nn.functional.pad(bt, (0, pad))
+        K += pad
+    a, bt = a.contiguous(), bt.contiguous()
+    ldy = (Nn + 3) // 4 * 4
+    y = torch.empty(M, ldy, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().magat_linear_f32(nat.ptr(a), K, nat.ptr(bt), None, nat.ptr(y), ldy, M, Nn, K, 0,
+                                             nat.current_stream(dev)), "magat_linear_f32")
+    return y[:, :Nn]
+
+
 class _GatTrainFunction(torch.autograd.Function):
     """HIP forward + backward of the graph-attention layer for training (pre-activation, per-head output)."""
 
@@ -439,8 +457,10 @@ class _GatTrainFunction(torch.autograd.Function):
                 nat.ptr(datt), B, N, G, F, K, P, mode, stream), "magat_gat_train_backward_f32")
         Bt = packed[:NC * G].view(NC, G)
         X2 = Xc.view(M, G)
-        dX = (dXd + dZ @ Bt).view(B, N, G)                 # plain library GEMMs
-        dBt, dcb = dZ.t() @ X2, dZ.sum(dim=0)
+        # the two dense products of the backward on the library's own float32 MFMA GEMM (deterministic tile order, no split-K
+        # atomics): dX = dXd + dZ Bt, dBt = dZ^T X
+        dX = (dXd + _gemm_nt(dZ, Bt.t().contiguous(), dev)).view(B, N, G)
+        dBt, dcb = _gemm_nt(dZ.t().contiguous(), X2.t().contiguous(), dev), dZ.sum(dim=0)
         grads = [None, None, None, None]
         params = [weight, None if ctx.no_wb else weight_bias, mixer, taps]
         need = [i for i, t in enumerate(params) if t is not None and t.requires_grad]
@@ -689,9 +709,10 @@ class _GnnTrainFunction(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             Bt = weight.detach()[:, 0].permute(1, 0, 2).reshape(K * F, G).float()        # row k*F+f = weight[f,0,k,:]
-            dx = (dZ @ Bt).view(B, N, G).permute(0, 2, 1)
+            dx = _gemm_nt(dZ, Bt.t().contiguous(), dev).reshape(B, N, G).permute(0, 2, 1)
         if ctx.needs_input_grad[1]:
-            dw = (dZ.t() @ X).view(K, F, G).permute(1, 0, 2).reshape(F, 1, K, G).to(weight.dtype)
+            dw = _gemm_nt(dZ.t().contiguous(), X.t().contiguous(), dev).reshape(K, F, G).permute(1, 0, 2) \
+                .reshape(F, 1, K, G).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dY.sum(dim=0).view(F, 1)
         return dx, dw, db, None
