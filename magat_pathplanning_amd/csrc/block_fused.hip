@@ -254,11 +254,12 @@ __device__ __forceinline__ void chain_stage(const ChainParams& p, char* lds, int
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int q = 2 * ks + e;
-        float v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = acc[s][4 * q + c] * scale + bq[q][c];       // (ReLU: the clamp of split2)
-        split2(v[0], v[1], h1[2 * e], h2[2 * e], cl);
-        split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1], cl);
+        // (one packed fma per pair - these epilogues run with the matrix pipe idle, where v_pk_fma_f32 issues like any other
+        //  vector instruction; ReLU is the lower clamp of split2)
+        const f32x2 v01 = __builtin_elementwise_fma(f32x2{acc[s][4 * q], acc[s][4 * q + 1]}, f32x2{scale, scale}, f32x2{bq[q][0], bq[q][1]});
+        const f32x2 v23 = __builtin_elementwise_fma(f32x2{acc[s][4 * q + 2], acc[s][4 * q + 3]}, f32x2{scale, scale}, f32x2{bq[q][2], bq[q][3]});
+        split2(v01[0], v01[1], h1[2 * e], h2[2 * e], cl);
+        split2(v23[0], v23[1], h1[2 * e + 1], h2[2 * e + 1], cl);
       }
       const int chunk = (ct * 2 + ks) * 2 + fh;
       if (LAST) {
@@ -424,11 +425,12 @@ __device__ __forceinline__ void epi_to_lds(char* lds, int out_off, const int (&t
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int q = 2 * ks + e;
-        float v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = acc[s][4 * q + c] * scale + bq[q][c];       // (ReLU: the clamp of split2)
-        split2(v[0], v[1], h1[2 * e], h2[2 * e], cl);
-        split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1], cl);
+        // (one packed fma per pair - these epilogues run with the matrix pipe idle, where v_pk_fma_f32 issues like any other
+        //  vector instruction; ReLU is the lower clamp of split2)
+        const f32x2 v01 = __builtin_elementwise_fma(f32x2{acc[s][4 * q], acc[s][4 * q + 1]}, f32x2{scale, scale}, f32x2{bq[q][0], bq[q][1]});
+        const f32x2 v23 = __builtin_elementwise_fma(f32x2{acc[s][4 * q + 2], acc[s][4 * q + 3]}, f32x2{scale, scale}, f32x2{bq[q][2], bq[q][3]});
+        split2(v01[0], v01[1], h1[2 * e], h2[2 * e], cl);
+        split2(v23[0], v23[1], h1[2 * e + 1], h2[2 * e + 1], cl);
       }
       char* o = lds + out_off + ((ct * 2 + ks) * 2 + fh) * BLK + pix * PIXB + agent * 16;
       *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
@@ -561,6 +563,11 @@ struct W4Item { signed char tp, ks, s, first; };           // tp = 9: the residu
 struct W4All { static constexpr int NT = 9; static constexpr int t[9] = {T_I0, T_I1, T_I2, T_I3, T_C, T_ET, T_EB, T_EL, T_ER}; };
 struct W4A { static constexpr int NT = 4; static constexpr int t[4] = {T_I0, T_I1, T_I2, T_ET}; };           // 33 tile-taps
 struct W4B { static constexpr int NT = 5; static constexpr int t[5] = {T_I3, T_C, T_EB, T_EL, T_ER}; };      // 36 tile-taps
+// the same nine tiles split the other way round - the FOUR interior tiles (36 tile-taps, 4 epilogues) against the FIVE edge and
+// corner tiles (33 tile-taps, 5 epilogues): walk and split-and-store epilogue together are then 0.8 k cycles apart instead of
+// 2.3 k (W4A / W4B give the longer walk ALSO the fifth epilogue), which is what the lighter pair of waves waits at the barrier
+struct W4I { static constexpr int NT = 4; static constexpr int t[4] = {T_I0, T_I1, T_I2, T_I3}; };
+struct W4E { static constexpr int NT = 5; static constexpr int t[5] = {T_C, T_ET, T_EB, T_EL, T_ER}; };
 constexpr int W4_TAPS[9] = {0x1FF, 0x1FF, 0x1FF, 0x1FF, 0x1F8, 0x03F, 0x1B6, 0x0DB, 0x1FF};     // = TILE_TAPS, host-visible
 template <int NMAX> struct W4Seq { W4Item it[NMAX]; int n, nmain; };
 template <typename TL, int KSM, int KS2>
@@ -950,11 +957,12 @@ __device__ __forceinline__ void chain_stage4(const ChainParams& p, char* lds, in
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int q = 2 * ks + e;
-        float v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = acc[s][4 * q + c] * scale + bq[q][c];       // (ReLU: the clamp of split2)
-        split2(v[0], v[1], h1[2 * e], h2[2 * e], cl);
-        split2(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1], cl);
+        // (one packed fma per pair - these epilogues run with the matrix pipe idle, where v_pk_fma_f32 issues like any other
+        //  vector instruction; ReLU is the lower clamp of split2)
+        const f32x2 v01 = __builtin_elementwise_fma(f32x2{acc[s][4 * q], acc[s][4 * q + 1]}, f32x2{scale, scale}, f32x2{bq[q][0], bq[q][1]});
+        const f32x2 v23 = __builtin_elementwise_fma(f32x2{acc[s][4 * q + 2], acc[s][4 * q + 3]}, f32x2{scale, scale}, f32x2{bq[q][2], bq[q][3]});
+        split2(v01[0], v01[1], h1[2 * e], h2[2 * e], cl);
+        split2(v23[0], v23[1], h1[2 * e + 1], h2[2 * e + 1], cl);
       }
       const int chunk = (ct * 2 + ks) * 2 + fh;
       if (LAST) {
@@ -1261,13 +1269,13 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
     __syncthreads();
     FULL_STAMP(2);
     // B: layer2.conv1 (32 -> 64)                                          Y @ U1 -> Z @ (U2, U3)
-    if (rg == 0) chain_stage4<W4A, 32, 0, 64, false>(p, lds, U1, 0, U2, p.wB, ct, p.bB, sB, group, clamped);
-    else chain_stage4<W4B, 32, 0, 64, false>(p, lds, U1, 0, U2, p.wB, ct, p.bB, sB, group, clamped);
+    if (rg == 0) chain_stage4<W4I, 32, 0, 64, false>(p, lds, U1, 0, U2, p.wB, ct, p.bB, sB, group, clamped);
+    else chain_stage4<W4E, 32, 0, 64, false>(p, lds, U1, 0, U2, p.wB, ct, p.bB, sB, group, clamped);
     __syncthreads();
     FULL_STAMP(3);
     // C: layer2.conv2 (64 -> 64) + downsample(Y)                          Z @ (U2, U3), Y @ U1 -> layer3's input @ (U0, U1)
-    if (rg == 0) chain_stage4<W4A, 64, 32, 64, false, true>(p, lds, U2, U1, U0, p.wC, ct, p.bC, sC, group, clamped);
-    else chain_stage4<W4B, 64, 32, 64, false, true>(p, lds, U2, U1, U0, p.wC, ct, p.bC, sC, group, clamped);
+    if (rg == 0) chain_stage4<W4I, 64, 32, 64, false, true>(p, lds, U2, U1, U0, p.wC, ct, p.bC, sC, group, clamped);
+    else chain_stage4<W4E, 64, 32, 64, false, true>(p, lds, U2, U1, U0, p.wC, ct, p.bC, sC, group, clamped);
     __syncthreads();
     FULL_STAMP(4);
     // layer3: IN = (U0, U1), MID = (U2, U3)
@@ -1284,25 +1292,25 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
       // conv1, output channels 64 h .. 64 h + 63 -> MID (channel tiles 2 h + ct1 of the weight block)
       const char* w1h = l3.w1 + (size_t)(2 * h) * BPT1 * 1024;
       if (rg1 == 0) {
-        f32x16 a1[W4A::NT];
+        f32x16 a1[W4I::NT];
 #pragma unroll
-        for (int s = 0; s < W4A::NT; ++s)
+        for (int s = 0; s < W4I::NT; ++s)
 #pragma unroll
           for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
-        walk4<W4A, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1h + (size_t)ct1 * BPT1 * 1024, a1, false);
+        walk4<W4I, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1h + (size_t)ct1 * BPT1 * 1024, a1, false);
         if (h == 0) FULL_STAMP(11);
-        const int tl[W4A::NT] = {W4A::t[0], W4A::t[1], W4A::t[2], W4A::t[3]};
-        epi_to_lds<64, W4A::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
+        const int tl[W4I::NT] = {W4I::t[0], W4I::t[1], W4I::t[2], W4I::t[3]};
+        epi_to_lds<64, W4I::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
       } else {
-        f32x16 a1[W4B::NT];
+        f32x16 a1[W4E::NT];
 #pragma unroll
-        for (int s = 0; s < W4B::NT; ++s)
+        for (int s = 0; s < W4E::NT; ++s)
 #pragma unroll
           for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
-        walk4<W4B, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1h + (size_t)ct1 * BPT1 * 1024, a1, false);
+        walk4<W4E, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1h + (size_t)ct1 * BPT1 * 1024, a1, false);
         if (h == 0) FULL_STAMP(11);
-        const int tl[W4B::NT] = {W4B::t[0], W4B::t[1], W4B::t[2], W4B::t[3], W4B::t[4]};
-        epi_to_lds<64, W4B::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
+        const int tl[W4E::NT] = {W4E::t[0], W4E::t[1], W4E::t[2], W4E::t[3], W4E::t[4]};
+        epi_to_lds<64, W4E::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
       }
       if (h == 0) FULL_STAMP(12);
       __syncthreads();
@@ -1337,7 +1345,7 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
           const int r = 4 * qd + c;
           float v[9];
 #pragma unroll
-          for (int s = 0; s < 9; ++s) v[s] = fmaxf(acc[s][r] * s2 + bq[qd][c], 0.f);
+          for (int s = 0; s < 9; ++s) v[s] = fmaxf(__builtin_fmaf(acc[s][r], s2, bq[qd][c]), 0.f);
           const float u = hi ? v[6] : v[5], ux = hi ? v[5] : v[6];
           const float w_ = lo ? v[8] : v[7], wx = lo ? v[7] : v[8];
           vF[c] = (v[4] + v[0]) + (u + w_);

@@ -43,7 +43,8 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
     {"BLOCK3_FUSED", 2},     // layer3 + ReLU + pool as one launch (two-half intermediate in LDS); needs BLOCK_FUSED.
                              // 2 = four waves x 512 registers, static K walk; 1 = eight waves x 256 registers; 0 = layer by layer
     {"HEAD_F16", 1},         // encoder head on the f16x3 split kernel when its input is the pooled map of the layer3 kernel
-    {"BLOCK_FULL", 1},       // layer1.conv2 -> layer2 -> layer3 -> pool as ONE launch (needs BLOCK_FUSED 2 and BLOCK3_FUSED 2)
+    {"BLOCK_FULL", 2},       // layer1.conv2 -> layer2 -> layer3 -> pool as ONE launch (needs BLOCK_FUSED 2 and BLOCK3_FUSED 2);
+                             // 2: the 2x2 pooling in registers (block_full_p_kernel), 1: through an LDS scratch (block_full_w4_kernel)
     {"GAT_MFMA", 1},         // KeyQuery layer with 128 features, N <= 101, K = 2 | 3 as ONE launch of matrix-core products (gat_mfma.hip)
 };
 
