@@ -384,6 +384,16 @@ typedef struct magat_conv_gemm_desc {
    * true fp32 if the split path clamped" that magat_encoder_forward_f32 / the GAT maps use. */
   int32_t* range_flag;
   const int32_t* run_if;
+  /* Activation scale of the split arithmetic (ABI 3; see "Activation scales" at magat_encoder_calibrate_f32).  in_scale
+   * (device float, may be NULL = 1; a stored 0 also means 1): a POWER OF TWO the f16x3 direct kernel multiplies its float32
+   * activations with on the way into their two half-precision planes (in_fmt 4, in_gl 0), and divides its accumulators by
+   * - exact, and it moves small-magnitude layers into the range where the second plane is a normal number.  acc_scale
+   * (device float, may be NULL): replaces the 1 / weight-scale float stored behind an f16x3 weight block.  absmax (device
+   * float, may be NULL): the float32 kernel (in_fmt 0) atomically maxes the largest |output| of the launch into it
+   * (calibration passes; the word is a non-negative float compared as an integer). */
+  const float* in_scale;
+  const float* acc_scale;
+  float* absmax;
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 
@@ -426,7 +436,24 @@ typedef struct magat_encoder_desc {
   int64_t head16_off; /* float offset of the head weight as f16x2 planes + 2^-e (in_fmt 4), 0 = absent: the head runs as
                          f16x3 split products when its input is the layer3 kernel's pooled map (ABI 2) */
   int64_t comp16_off; /* the same for the compressMLP weight: 0 = absent (float32 MFMA); used together with head16_off (ABI 2) */
+  int64_t scaled_off; /* float offset of the ACTIVATION-SCALE block (encoder.fold_activation_scales; ABI 3), 0 = absent:
+                         [w0' 864 | b0' 32 | b1' 32 | bA' 32 | bB' 64 | bC' 64 | b31' 128 | b32' 128 | sA' sB' sC' s31' s32'
+                          head_in feat_in pad] - the stem weights / biases of the fused chain multiplied by the power-of-two
+                         scale their layer's activations are carried with, the five 1 / weight-scale floats with the scale
+                         ratios folded in, and the in_scale of the head's and compressMLP's float32 loaders */
 } magat_encoder_desc;
+/* Activation scales (ABI 3).  The split arithmetic carries a value as two f16 planes: exact for |v| <= 65504, but the SECOND
+ * plane is a full 11-bit number only for |v| >~ 0.25 - a layer whose activations are all small (a small BatchNorm gamma: an
+ * ordinary thing in a trained checkpoint) would be carried with an absolute floor of 2^-25 per value instead of fp32's
+ * relative 2^-24.  ReLU networks commute with positive scaling, so every plane-forming stage of the fused encoder path carries
+ * its map multiplied by a power of two chosen from the layer's measured magnitude (target: largest value ~2^10; exact, folded
+ * into biases and into the 1 / weight-scale of the epilogues host-side), and the float32 loaders of the head, compressMLP
+ * and the graph layer's maps multiply on load (magat_conv_gemm_desc.in_scale).  magat_encoder_calibrate_f32 measures the
+ * magnitudes: ONE float32 pass (the range guard's re-run path: layer-by-layer float32 MFMA kernels) that also writes feat /
+ * comp, leaving in absmax [16] (device floats, zeroed here) the largest |output| of: [0] stem, [1 + 2 l] layer(l+1).conv1,
+ * [2 + 2 l] layer(l+1).conv2 + downsample (l = 0..2), [7] feat, [8] comp.  Unscaled packs (scaled_off = 0) behave as before. */
+int magat_encoder_calibrate_f32(const magat_encoder_desc* desc_host, const float* x, float* feat, int ldfeat, float* comp,
+                                int ldcomp, void* workspace, size_t workspace_bytes, int M, float* absmax, void* stream);
 /* Range guard (option RANGE_GUARD, default 1).  The convolutions run as f16x3 split products (two half-precision planes per
  * value, fp32 accumulate: as accurate as the fp32 MFMA kernel while every activation stays within +-65504; the fused stem
  * carries its output 16x and needs it below 4094).  Whether a forward stayed inside is checked ON THE DEVICE: every kernel

@@ -47,14 +47,15 @@ class ConvGemmDesc(ctypes.Structure):
                 ("out_tile_stride", ctypes.c_int64),
                 ("in_gl", ctypes.c_int), ("out_gl", ctypes.c_int), ("out_ntile_stride", ctypes.c_int64),
                 ("wt_pix_stride", ctypes.c_int64), ("ldw", ctypes.c_int),
-                ("range_flag", ctypes.c_void_p), ("run_if", ctypes.c_void_p)]
+                ("range_flag", ctypes.c_void_p), ("run_if", ctypes.c_void_p),
+                ("in_scale", ctypes.c_void_p), ("acc_scale", ctypes.c_void_p), ("absmax", ctypes.c_void_p)]
 
 
 class EncoderDesc(ctypes.Structure):
     _fields_ = [("variant", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
                 ("n_feat", ctypes.c_int), ("n_comp", ctypes.c_int), ("pack", ctypes.c_void_p),
                 ("off", ctypes.c_int64 * 32), ("chain_off", ctypes.c_int64), ("chain3_off", ctypes.c_int64),
-                ("head16_off", ctypes.c_int64), ("comp16_off", ctypes.c_int64)]
+                ("head16_off", ctypes.c_int64), ("comp16_off", ctypes.c_int64), ("scaled_off", ctypes.c_int64)]
 
 
 class SimStepDesc(ctypes.Structure):
@@ -123,6 +124,7 @@ _SIGNATURES = {
     "magat_encoder_read_status": (_I, [_P, ctypes.POINTER(ctypes.c_int32), _P]),
     "magat_gat_read_status": (_I, [_P, ctypes.POINTER(ctypes.c_int32), _P]),
     "magat_encoder_forward_f32": (_I, [ctypes.POINTER(EncoderDesc), _P, _P, _I, _P, _I, _P, _Z, _I, _P]),
+    "magat_encoder_calibrate_f32": (_I, [ctypes.POINTER(EncoderDesc), _P, _P, _I, _P, _I, _P, _Z, _I, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

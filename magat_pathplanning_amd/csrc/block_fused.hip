@@ -1477,7 +1477,8 @@ extern "C" int magat_block3_set_debug_buffer(long long* dev_buf) { g_block3_dbg 
 // layer1.conv2 -> layer2 -> layer3 -> pool as ONE launch (block_full_w4_kernel).  Arguments: those of magat_block_chain (without
 // its output) and of magat_block3 (without its input).
 int magat_block_full(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
-                     float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st) {
+                     float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st,
+                     const float* scales) {
   if (!in1 || !in2 || !wchain || !bA || !bB || !bC || !out || !w3 || !b1 || !b2) return MAGAT_ERR_NULL;
   if (M <= 0) return MAGAT_ERR_BAD_SHAPE;
   FullParams q;
@@ -1502,6 +1503,7 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
   l.s1 = reinterpret_cast<const float*>(l.w1 + n1);
   l.s2 = reinterpret_cast<const float*>(l.w2b + n2b);
   l.b1 = b1; l.b2 = b2;
+  if (scales) { p.sA = scales; p.sB = scales + 1; p.sC = scales + 2; l.s1 = scales + 3; l.s2 = scales + 4; }
   l.M = M; l.groups = p.groups;
   l.range_flag = range_flag;
   l.dbg = nullptr;

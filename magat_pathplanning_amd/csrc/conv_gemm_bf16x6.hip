@@ -54,6 +54,7 @@ struct SplitParams {
   int korder;               // direct kernel: 1 = channel slab outer, taps inner (MAGAT_CONV_KORDER)
   int in_gl, out_gl;        // direct kernel: granule-major agent tiles [C/4][128][4] for in/in2 resp. out
   const float* acc_scale;   // NPL == 2: device pointer to 1 / (power-of-two weight scale), applied before the bias
+  const float* in_scale;    // direct kernel, float32 input: power-of-two activation scale (device float; null or 0 = 1)
   int* range_flag;          // range guard (magat_hip.h): OR-ed with 1 when a value had to be clamped into its f16 / fp8 planes
 };
 
@@ -509,6 +510,13 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
       aoff2[i] = (unsigned)((magat_row_off(mrow, p.lda2, p.in2_tile) + 8 * fh) * 4);
     }
   }
+  // activation scale (float32 input only): a power of two applied on the way into the planes, undone with the weight scale
+  float insc = 1.f;
+  if constexpr (!PIN) {
+    if (p.in_scale) insc = *p.in_scale;
+    if (insc == 0.f) insc = 1.f;
+  }
+  const bool scaled_in = !PIN && insc != 1.f;
   const int kmul = PIN ? 256 : (p.in_gl ? 512 : 4);     // bytes per unit of k0 (k0 % 32 == 0)
   // PIN: d1 = k step (+4096), d2 = plane (+256 C bytes: C differs between in and in2);  float32: d1 = second quad,
   // d2 = k step
@@ -620,7 +628,14 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
       } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const f32x4 lo = __builtin_bit_cast(f32x4, fa[i][2 * ks]), hi = __builtin_bit_cast(f32x4, fa[i][2 * ks + 1]);
+          f32x4 lo = __builtin_bit_cast(f32x4, fa[i][2 * ks]), hi = __builtin_bit_cast(f32x4, fa[i][2 * ks + 1]);
+          if (scaled_in) {       // (wave-uniform; single multiplies: v_pk_mul_f32 does not issue under another wave's MFMA)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              asm("v_mul_f32 %0, %1, %2" : "=v"(lo[c]) : "v"(lo[c]), "v"(insc));
+              asm("v_mul_f32 %0, %1, %2" : "=v"(hi[c]) : "v"(hi[c]), "v"(insc));
+            }
+          }
           unsigned h1[4], h2[4];
           split_pair_f16(lo[0], lo[1], h1[0], h2[0], clamped);
           split_pair_f16(lo[2], lo[3], h1[1], h2[1], clamped);
@@ -774,7 +789,7 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
   // epilogue: D[channel][agent]; agent = lane&31, channel = (r&3) + 8*(r>>2) + 4*(lane>>5).  The lane's 4 TN bias quads
   // are fetched as ONE batch of 16-byte loads (per-channel conditional loads cost one L2 round trip per quad).
   const bool vec = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
-  const float acc_scale = *p.acc_scale;
+  const float acc_scale = *p.acc_scale / insc;      // (exact: both are powers of two)
   f32x4 bq[TN][4];
   if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
 #pragma unroll
@@ -974,7 +989,11 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   const int pid = magat_prof_begin(p.tag, st);
   const bool af32 = d->in_fmt == 2;
   // f16x3 (in_fmt 4): wt = [2][Cout][Ktot] f16 bits followed by one float32 = 1 / weight scale (read by the kernel)
-  p.acc_scale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d->wt) + (size_t)2 * p.Cout * p.Ktot * sizeof(u16));
+  p.acc_scale = d->acc_scale ? d->acc_scale
+                             : reinterpret_cast<const float*>(reinterpret_cast<const char*>(d->wt) + (size_t)2 * p.Cout * p.Ktot * sizeof(u16));
+  p.in_scale = d->in_scale;
+  // (the activation scale lives in the direct kernel's float32 loader only)
+  if (d->in_scale && !(d->in_fmt == 4 && d->out_fmt == 0 && d->in_gl == 0 && magat_conv_direct_enabled())) return MAGAT_ERR_UNSUPPORTED;
 #define MAGAT_SPLIT_LAUNCH(BNV, WM, WN)                                                                              \
   do {                                                                                                              \
     if (d->in_fmt == 3)                                                                                             \

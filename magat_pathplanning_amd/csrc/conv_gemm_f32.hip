@@ -46,6 +46,7 @@ struct ConvGemmParams {
   long long out_plane;
   long long out_nt;         // > 0: 128-column tile t of the row-major output lives at out + t * out_nt (row stride ldc = 128)
   const int* run_if;        // range-guard re-run: the kernel does nothing unless *run_if != 0 (null: always runs)
+  float* absmax;            // calibration: largest |output| of the launch (atomic max of the float's bits), or null
   int vgrid;                // number of tiles (virtual workgroups); the launch grid is smaller only for predicated re-runs
 };
 
@@ -264,6 +265,7 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, const in
   const bool vec = FULL && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (p.out_plane & 3) == 0;
   // the lane's bias values first, as one batch of loads (a conditional load per channel inside the store loop costs
   // one L2 round trip per channel quad)
+  float amax = 0.f;
   f32x4 bq[TN][4];
   const bool bvec = p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && n0 + BN <= p.Cout;
 #pragma unroll
@@ -293,6 +295,7 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, const in
         for (int c = 0; c < 4; ++c) {
           v[c] = acc[i][j][4 * q + c] + bq[j][q][c];
           if (p.relu) v[c] = magat_relu(v[c]);
+          if (n + c < p.Cout) amax = fmaxf(amax, fabsf(v[c]));
         }
         const long long o = magat_row_off(m, p.ldc, p.out_tile) + (p.out_nt ? (long long)(n >> 7) * p.out_nt + (n & 127) : n);
         if (p.out_split) {
@@ -327,6 +330,10 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, const in
         }
       }
     }
+  }
+  if (p.absmax) {      // (calibration launches only)
+    amax = wave_max(amax);
+    if (lane == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.absmax), __builtin_bit_cast(unsigned, amax));
   }
 }
 
@@ -404,6 +411,7 @@ extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) 
   p.stride = d->stride; p.pad = d->pad; p.Hout = d->Hout; p.Wout = d->Wout;
   p.C2 = d->C2; p.lda2 = d->lda2; p.W2 = d->W2; p.stride2 = d->stride2;
   p.Cout = d->Cout; p.Ktot = d->kH * d->kW * d->Cin + d->C2; p.ldc = d->ldc; p.relu = d->relu;
+  p.absmax = d->absmax;
   if (d->ldw) {
     if (d->ldw < p.Ktot || (d->ldw & 3)) return MAGAT_ERR_BAD_SHAPE;
     p.Ktot = d->ldw;          // weight row stride

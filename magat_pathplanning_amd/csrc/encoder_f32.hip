@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          int M, int Hr, int Wr, long long out_pix_stride,
                                                          long long out_tile_stride, long long out_plane, int out_gl,
-                                                         int* range_flag, const int* run_if, int BH) {
+                                                         int* range_flag, const int* run_if, int BH, float* absmax) {
   extern __shared__ float img[];
   if (run_if && *run_if == 0) return;        // range-guard re-run: nothing to do unless the split path clamped
   const int H = HC ? HC : Hr, W = WC ? WC : Wr;
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
   for (int q = 0; q < 4; ++q) bch[q] = *reinterpret_cast<const f32x4*>(bias + 8 * q + 4 * (lane >> 5));
   __syncthreads();
   const int abase = (lane & 31) * PS;
+  float amax = 0.f;          // calibration launches: largest stem output of this wave
   for (int lpix = wave; lpix < bh * W; lpix += 4) {
     const int oy = lpix / W, ox = lpix - oy * W;
     const int base = abase + oy * PW + ox;
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
         f32x4 v;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = magat_relu(acc[4 * q + c] + bch[q][c]);
+        if (absmax) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         if (out_gl) {
           *reinterpret_cast<f32x4*>(og + q * 1024) = v;
         } else if (out_plane == 0) {
@@ -177,6 +179,10 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
         }
       }
     }
+  }
+  if (absmax) {
+    amax = wave_max(amax);
+    if (lane == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(absmax), __builtin_bit_cast(unsigned, amax));
   }
 }
 
@@ -220,7 +226,8 @@ __global__ void guard_count_kernel(int* status) {
 
 static int conv_first_launch(const float* x, const float* wt, const float* bias, float* out, int M, int H, int W,
                              long long pix_stride, long long tile_stride, void* stream, long long out_plane = 0,
-                             int out_gl = 0, int* range_flag = nullptr, const int* run_if = nullptr, int tag = MAGAT_TAG_CONV_FIRST);
+                             int out_gl = 0, int* range_flag = nullptr, const int* run_if = nullptr, int tag = MAGAT_TAG_CONV_FIRST,
+                             float* absmax = nullptr);
 
 extern "C" int magat_conv_first_f32(const float* x, const float* wt, const float* bias, float* out, int M, int H,
                                     int W, void* stream) {
@@ -235,7 +242,7 @@ extern "C" int magat_conv_first_tiled_f32(const float* x, const float* wt, const
 
 static int conv_first_launch(const float* x, const float* wt, const float* bias, float* out, int M, int H, int W,
                              long long pix_stride, long long tile_stride, void* stream, long long out_plane, int out_gl,
-                             int* range_flag, const int* run_if, int tag) {
+                             int* range_flag, const int* run_if, int tag, float* absmax) {
   if (!x || !wt || !bias || !out) return MAGAT_ERR_NULL;
   if (M <= 0 || H <= 0 || W <= 0) return MAGAT_ERR_BAD_SHAPE;
   int BH = H;      // rows per band: the whole map when its 32 padded images fit the LDS
@@ -255,10 +262,10 @@ static int conv_first_launch(const float* x, const float* wt, const float* bias,
   const int pid = magat_prof_begin(tag, st);
   if (c11)
     hipLaunchKernelGGL((conv_first_kernel<11, 11>), dim3(blocks), dim3(256), lds, st, x, wt, bias, out, M, H, W,
-                       pix_stride, tile_stride, out_plane, out_gl, range_flag, run_if, H);
+                       pix_stride, tile_stride, out_plane, out_gl, range_flag, run_if, H, absmax);
   else
     hipLaunchKernelGGL((conv_first_kernel<0, 0>), dim3(blocks, bands), dim3(256), lds, st, x, wt, bias, out, M, H, W,
-                       pix_stride, tile_stride, out_plane, out_gl, range_flag, run_if, BH);
+                       pix_stride, tile_stride, out_plane, out_gl, range_flag, run_if, BH, absmax);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
@@ -309,13 +316,14 @@ extern "C" int magat_encoder_read_status(const void* workspace, int32_t status_h
 
 // y = act(x @ w^T + b) on the float32 kernel with the guard's predicate
 static int enc_linear(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int N, int K,
-                      int relu, int tag, const int32_t* run_if, void* stream) {
+                      int relu, int tag, const int32_t* run_if, void* stream, float* absmax = nullptr) {
   magat_conv_gemm_desc d = {};
   d.tag = tag;
   d.in = x; d.wt = w; d.bias = b; d.out = y;
   d.M = M; d.Cin = K; d.lda = ldx; d.Hin = d.Win = 1; d.kH = d.kW = 1; d.stride = 1; d.pad = 0;
   d.Hout = d.Wout = 1; d.Cout = N; d.ldc = ldy; d.relu = relu;
   d.run_if = run_if;
+  d.absmax = absmax;
   return magat_conv_gemm_f32(&d, stream);
 }
 
@@ -323,7 +331,8 @@ static int enc_linear(const float* x, int ldx, const float* w, const float* b, f
 // kernels.  range_flag: where those kernels report a clamp (null: not tracked).  run_if: predicate of the float32
 // re-run (every launch of the pass returns immediately unless *run_if != 0; only valid with split == 0).
 static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* feat, int ldfeat, float* comp, int ldcomp,
-                          float* bufbase, int M, void* stream, int split, int32_t* range_flag, const int32_t* run_if) {
+                          float* bufbase, int M, void* stream, int split, int32_t* range_flag, const int32_t* run_if,
+                          float* absmax = nullptr) {
   const int H = d->H, W = d->W;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int mc = enc_chunk_agents(M);
@@ -364,15 +373,20 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // reaches HBM; buf[0] receives only its 36 stride-2 pixels, the input of the block's residual 1x1 branch.
     // Option L1_FUSED=0 keeps the two launches.
     const bool fused1 = lay == 2 && magat_layer1_fused_lds(W) != 0 && magat_opt(MAGAT_OPT_L1_FUSED) != 0;
+    // the whole chain in two launches (fused stem + the merged chain kernel): the path the activation scales are folded for
+    const bool full_path = fused1 && !mx && d->chain_off > 0 && Ho == 6 && Wo == 6 && nblocks == 3 && d->chain3_off > 0 &&
+                           magat_opt(MAGAT_OPT_BLOCK_FUSED) >= 2 && magat_opt(MAGAT_OPT_BLOCK3_FUSED) >= 2 &&
+                           magat_opt(MAGAT_OPT_BLOCK_FULL);
+    const float* sp = (full_path && d->scaled_off > 0) ? pk + d->scaled_off : nullptr;      // activation-scale block
     int rc;
     if (fused1)
-      rc = magat_layer1_fused(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1],
-                              pk + d->off[24] + permuted(32, 9 * 32), pk + d->off[3], buf[1], buf[0], mm, H, W, st,
-                              range_flag);
+      rc = magat_layer1_fused(x + (size_t)m0 * 3 * H * W, sp ? sp : pk + d->off[0], sp ? sp + 864 : pk + d->off[1],
+                              pk + d->off[24] + permuted(32, 9 * 32), sp ? sp + 896 : pk + d->off[3], buf[1], buf[0], mm, H, W,
+                              st, range_flag);
     else
       rc = conv_first_launch(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W,
                              (long long)MAGAT_TILE_ROWS * 32, (long long)H * W * MAGAT_TILE_ROWS * 32, stream, 0, lay,
-                             range_flag, run_if, tagof(MAGAT_TAG_CONV_FIRST));
+                             range_flag, run_if, tagof(MAGAT_TAG_CONV_FIRST), absmax);
     if (rc != MAGAT_OK) return rc;
     int cur = 0;              // buffer holding the block input
     int hin = H, win = W;
@@ -381,11 +395,11 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // BasicBlock chain kernel (block_fused.hip): layer1.conv2+downsample -> layer2.conv1 -> layer2.conv2+downsample in one
     // launch with the 6x6 maps of an 8-agent group in LDS (3.35 GB of HBM traffic per 51 200 agents become 0.94 GB).
     // Needs the fused stem's plane-granule outputs; option BLOCK_FUSED=0 keeps the layer-by-layer kernels.
-    if (fused1 && !mx && d->chain_off > 0 && Ho == 6 && Wo == 6 && nblocks == 3 && d->chain3_off > 0 &&
-        magat_opt(MAGAT_OPT_BLOCK_FUSED) >= 2 && magat_opt(MAGAT_OPT_BLOCK3_FUSED) >= 2 && magat_opt(MAGAT_OPT_BLOCK_FULL)) {
+    if (full_path) {
       // both chain kernels as ONE launch: layer2's output map stays in LDS as layer3's input
-      rc = magat_block_full(buf[1], buf[0], pk + d->chain_off, pk + d->off[5], pk + d->off[7], pk + d->off[9], buf[2],
-                            pk + d->chain3_off, pk + d->off[11], pk + d->off[13], mm, reinterpret_cast<int*>(range_flag), st);
+      rc = magat_block_full(buf[1], buf[0], pk + d->chain_off, sp ? sp + 928 : pk + d->off[5], sp ? sp + 960 : pk + d->off[7],
+                            sp ? sp + 1024 : pk + d->off[9], buf[2], pk + d->chain3_off, sp ? sp + 1088 : pk + d->off[11],
+                            sp ? sp + 1216 : pk + d->off[13], mm, reinterpret_cast<int*>(range_flag), st, sp ? sp + 1344 : nullptr);
       if (rc != MAGAT_OK) return rc;
       cur = 2; hin = Ho; win = Wo; lstart = 3; pooled_in = true;
     } else if (fused1 && !mx && d->chain_off > 0 && Ho == 6 && Wo == 6 && nblocks >= 2 && magat_opt(MAGAT_OPT_BLOCK_FUSED)) {
@@ -414,6 +428,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
       g.pad = 1; g.Hout = hout; g.Wout = wout; g.Cout = s.cout; g.ldc = s.cout; g.relu = 1;
       g.tag = tagof(MAGAT_TAG_BLOCK_CONV + 2 * l);
       g.range_flag = range_flag; g.run_if = run_if;
+      if (absmax) g.absmax = absmax + 1 + 2 * l;
       if (split >> l & 1) {      // split-MFMA kernel: float32 activations split by its loader, pre-split weights
         if (enc_use_f16(d, l)) { g.in_fmt = 4; g.wt = pk + d->off[24 + 2 * l]; }
         else { g.in_fmt = 2; g.wt = pk + d->off[18 + 2 * l]; }
@@ -437,6 +452,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
       h.Cout = s.cout; h.ldc = s.cout; h.relu = 1;
       h.tag = tagof(MAGAT_TAG_BLOCK_CONV + 2 * l + 1);
       h.range_flag = range_flag; h.run_if = run_if;
+      if (absmax) h.absmax = absmax + 2 + 2 * l;
       if (split >> l & 1) {
         if (enc_use_f16(d, l)) { h.in_fmt = 4; h.wt = pk + d->off[25 + 2 * l]; }
         else { h.in_fmt = 2; h.wt = pk + d->off[19 + 2 * l]; }
@@ -465,13 +481,14 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     if (!pooled_in) { g.pool = 1; g.pool_w = win; }
     g.tag = tagof(MAGAT_TAG_HEAD);
     g.run_if = run_if;
+    if (absmax) g.absmax = absmax + 7;
     // Few agents (the closed-loop batch-1 step): one workgroup per 64 agents would walk all (hin/2)(win/2) clast of K alone
     // (83 us at 100 agents).  Split K by pooled cell instead: every cell is its own 1x1 "output pixel" with its slice of the
     // weight rows (wt_pix_stride / ldw), the partial products land in a free map buffer, a small kernel sums them in
     // a fixed order and adds the bias.  Option HEAD_SPLITK = largest agent count that takes this form (0 = never).
     const int cells = (hin / 2) * (win / 2);
     const int split_max = magat_opt(MAGAT_OPT_HEAD_SPLITK);
-    if (cells > 1 && mm <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
+    if (!absmax && cells > 1 && mm <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
         (size_t)cells * d->n_feat <= enc_buf_floats_per_agent(d)) {     // the partials must fit one map buffer
       float* part = buf[(cur + 1) % 3];                 // [cells][mm][n_feat]
       g.out = part; g.bias = nullptr; g.ldc = d->n_feat;
@@ -494,6 +511,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
       if (pooled_in && split && d->head16_off > 0 && (clast % 32) == 0 && (d->n_feat % 32) == 0 &&
           magat_opt(MAGAT_OPT_HEAD_F16)) {
         g.in_fmt = 4; g.wt = pk + d->head16_off; g.range_flag = range_flag; g.run_if = nullptr;
+        if (d->scaled_off > 0) g.in_scale = pk + d->scaled_off + 1349;
       }
       rc = magat_conv_gemm_f32(&g, stream);
     }
@@ -510,10 +528,11 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
         c.M = mm; c.Cin = d->n_feat; c.lda = ldfeat; c.Hin = c.Win = 1; c.kH = c.kW = 1; c.stride = 1; c.pad = 0;
         c.Hout = c.Wout = 1; c.Cout = d->n_comp; c.ldc = ldcomp; c.relu = 1;
         c.in_fmt = 4; c.range_flag = range_flag;
+        if (d->scaled_off > 0) c.in_scale = pk + d->scaled_off + 1350;
         rc = magat_conv_gemm_f32(&c, stream);
       } else {
         rc = enc_linear(feat + (size_t)m0 * ldfeat, ldfeat, pk + d->off[16], pk + d->off[17], comp + (size_t)m0 * ldcomp,
-                        ldcomp, mm, d->n_comp, d->n_feat, 1, tagof(MAGAT_TAG_COMPRESS), run_if, stream);
+                        ldcomp, mm, d->n_comp, d->n_feat, 1, tagof(MAGAT_TAG_COMPRESS), run_if, stream, absmax ? absmax + 8 : nullptr);
       }
       if (rc != MAGAT_OK) return rc;
     }
@@ -609,4 +628,19 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   }
   magat_prof_end(pid, st);
   return rc;
+}
+
+extern "C" int magat_encoder_calibrate_f32(const magat_encoder_desc* d, const float* x, float* feat, int ldfeat, float* comp,
+                                           int ldcomp, void* workspace, size_t workspace_bytes, int M, float* absmax,
+                                           void* stream) {
+  if (!d || !x || !feat || !d->pack || !absmax) return MAGAT_ERR_NULL;
+  if (M <= 0 || d->H < 3 || d->W < 3 || d->n_feat <= 0) return MAGAT_ERR_BAD_SHAPE;
+  if (d->variant != 0 && d->variant != 1) return MAGAT_ERR_UNSUPPORTED;      // (the Default CNN runs in float32: nothing to scale)
+  if (d->n_comp > 0 && !comp) return MAGAT_ERR_NULL;
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < magat_encoder_workspace_bytes(d, M))
+    return MAGAT_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(absmax, 0, 16 * sizeof(float), st) != hipSuccess) return MAGAT_ERR_LAUNCH;
+  float* bufbase = reinterpret_cast<float*>(static_cast<char*>(workspace) + ENC_STATUS_BYTES);
+  return enc_run_resnet(d, x, feat, ldfeat, comp, ldcomp, bufbase, M, stream, 0, nullptr, nullptr, absmax);
 }

@@ -942,6 +942,9 @@ int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, in
     d.Cout = NC; d.ldc = ldz; d.tag = MAGAT_TAG_GAT_MAPS; d.in_fmt = use_f16 ? 4 : 2;
     if (ntile_stride) { d.ldc = 128; d.out_ntile_stride = ntile_stride; }
     d.range_flag = guard ? status : nullptr;
+    // activation scale of the layer input (magat_hip.h "Activation scales"): float word [4] of the status block, written by
+    // the caller (0 = none); the direct kernel's float32 loader applies it
+    if (status && use_f16 && magat_conv_direct_enabled()) d.in_scale = reinterpret_cast<const float*>(status + 4);
     int rc = magat_conv_gemm_f32(&d, stream);
     if (rc != MAGAT_OK || !guard) return rc;
     const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);
@@ -1188,7 +1191,8 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     const bool guard = magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
     const unsigned* masks = (plan && N <= 128) ? static_cast<const unsigned*>(plan) : nullptr;
     const int rc = magat_gat_mfma_forward(X, G, S, s_is_f64, masks, packed + magat_gat_frag_offset(L.NC, G), bias, Y, ldy, B,
-                                          N, K, P, concat, guard ? status : nullptr, st);
+                                          N, K, P, concat, guard ? status : nullptr, st,
+                                          reinterpret_cast<const float*>(status + 4));
     if (rc != MAGAT_OK || !guard) return rc;
     rerun_only = true;
     p.run_if = status;

@@ -45,6 +45,8 @@ struct GatMfmaParams {
   int B, N, P, ldx, ldy, concat, s_is_f64;
   int hsplit;                 // 1, or P (small batches, concat): a workgroup per (instance, head) instead of per instance
   int* range_flag;
+  const float* x_scale;       // power-of-two activation scale of the X planes (device float; null or 0 = 1): Q, U and the
+                              // accumulators then carry it once, the scores twice (undone in the softmax exponent and in Y)
   long long* dbg;             // MAGAT_DEBUG_HOOKS builds: [grid][4 waves][16] cycle stamps of the last head walked
 };
 
@@ -157,6 +159,12 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
   const float biasv = p.bias ? p.bias[cw_] : 0.f;
   const bool g2_active = 32 * w < KI;              // waves whose i tile holds columns of A
   float vmax = 0.f;                                // running maximum of |values written to f16 planes|
+  float xs = 1.f;
+  if (p.x_scale) xs = *p.x_scale;
+  if (xs == 0.f) xs = 1.f;
+  const float ixs = 1.f / xs;                      // (powers of two: exact)
+  const float kOutScale = kInvScale * ixs;         // Y = acc_0 2^-8 / xs + bias
+  const float kLog2eS = 1.4426950408889634f * ixs * ixs;      // scores carry xs^2
 
   // Weight fragments: ONE ring of four register pairs over the static stream of a head - W_p k steps 0..7, then the eight
   // fragments of tap K - 1, tap K - 2 (, tap 0) - continued into the next head (the stream is the same for every instance:
@@ -237,16 +245,18 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
         const int row = idx >> 4, ch = idx & 15;
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + xst + idx * 32);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + xst + idx * 32 + 16);
-        // (the layer's INPUT: a NaN must raise the flag too - fmaxf drops it from the running maximum; everything later is
-        // made of these planes and finite weights)
-        if (!(fabsf(v0[0]) <= 65504.f) | !(fabsf(v0[1]) <= 65504.f) | !(fabsf(v0[2]) <= 65504.f) | !(fabsf(v0[3]) <= 65504.f) |
-            !(fabsf(v1[0]) <= 65504.f) | !(fabsf(v1[1]) <= 65504.f) | !(fabsf(v1[2]) <= 65504.f) | !(fabsf(v1[3]) <= 65504.f))
-          vmax = __builtin_inff();
+        // the activation scale first (a power of two: exact), then the planes.  A NaN must raise the flag too - fmaxf drops it
+        // from the running maximum; everything later is made of these planes and finite weights
+        float xv[8] = {v0[0] * xs, v0[1] * xs, v0[2] * xs, v0[3] * xs, v1[0] * xs, v1[1] * xs, v1[2] * xs, v1[3] * xs};
+        bool bad = false;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bad |= !(fabsf(xv[e]) <= 65504.f);
+        if (bad) vmax = __builtin_inff();
         uint4 hi, lo;
-        split2v(v0[0], v0[1], hi.x, lo.x, vmax);
-        split2v(v0[2], v0[3], hi.y, lo.y, vmax);
-        split2v(v1[0], v1[1], hi.z, lo.z, vmax);
-        split2v(v1[2], v1[3], hi.w, lo.w, vmax);
+        split2v(xv[0], xv[1], hi.x, lo.x, vmax);
+        split2v(xv[2], xv[3], hi.y, lo.y, vmax);
+        split2v(xv[4], xv[5], hi.z, lo.z, vmax);
+        split2v(xv[6], xv[7], hi.w, lo.w, vmax);
         char* dst = lds + (row * 512 + ((ch ^ (row & 15)) << 4));
         *reinterpret_cast<uint4*>(dst) = hi;
         *reinterpret_cast<uint4*>(dst + 256) = lo;
@@ -465,7 +475,7 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
             GM_PIN();
           }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        constexpr float kLog2e = 1.4426950408889634f;
+        const float kLog2e = kLog2eS;
         const float cexp = mx > -__builtin_inff() ? -mx * kLog2e : 0.f;
         float sum = 0.f;
 #pragma unroll
@@ -612,7 +622,7 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
             for (int e = 0; e < 4; ++e) {
               if (!whole && !(jg + 4 * h + e < N)) continue;
               float* dst = reinterpret_cast<float*>(const_cast<char*>(ybase + (jg + e) * rowb) + lbyte);
-              float v = acc[0][mt][4 * q + e] * kInvScale + biasv;
+              float v = acc[0][mt][4 * q + e] * kOutScale + biasv;
               if constexpr (CONCAT) {
                 v = __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());
               } else {
@@ -686,8 +696,9 @@ int magat_gat_mfma_supported(int N, int G, int F, int K, int mode) {
 
 int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre,
                            const float* packed_frag, const float* bias, float* Y, int ldy, int B, int N, int K, int P,
-                           int concat, int* range_flag, hipStream_t st) {
+                           int concat, int* range_flag, hipStream_t st, const float* x_scale) {
   GatMfmaParams p;
+  p.x_scale = x_scale;
   p.X = X; p.ldx = ldx; p.S = S; p.s_is_f64 = s_is_f64; p.rmask_pre = rmask_pre;
   p.wfrag = reinterpret_cast<const char*>(packed_frag);
   p.bias = bias; p.Y = Y; p.ldy = ldy; p.B = B; p.N = N; p.P = P; p.concat = concat; p.range_flag = range_flag;

@@ -30,7 +30,8 @@ size_t magat_layer1_fused_lds(int W);   // 0: the fused kernel does not take thi
 size_t magat_block_chain_weight_floats();
 size_t magat_block3_weight_floats();
 int magat_block_full(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
-                     float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st);
+                     float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st,
+                     const float* scales = nullptr);      // 5 device floats replacing the 1 / weight-scale of stages A, B, C, layer3.conv1, conv2
 int magat_block3(const void* in, float* out, const float* w, const float* b1, const float* b2, int M, int* range_flag,
                  hipStream_t st);
 int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, long long out_pix_stride, long long out_tile,
@@ -77,7 +78,8 @@ __host__ __device__ inline size_t magat_gat_frag_offset(int NC, int G) {
 int magat_gat_mfma_supported(int N, int G, int F, int K, int mode);
 int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre,
                            const float* packed_frag, const float* bias, float* Y, int ldy, int B, int N, int K, int P,
-                           int concat, int* range_flag, hipStream_t st);
+                           int concat, int* range_flag, hipStream_t st,
+                           const float* x_scale = nullptr);      // device float: power-of-two scale of X's planes (null / 0 = 1)
 
 // hoisted GAT maps Z [M][ldz >= NC] = X [M][G] @ Bt^T + colbias from the packed weights (gat_f32.hip): bf16x6 split when
 // NC % 32 == 0 and G % 32 == 0, else fp32 MFMA

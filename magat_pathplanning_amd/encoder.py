@@ -206,6 +206,62 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
     return pack, offs, meta
 
 
+SCALED_BLOCK_FLOATS = 1352      # magat_hip.h magat_encoder_desc.scaled_off
+
+
+def scale_exponent(m, target_log2=10, lo=-14, hi=24):
+    """Power-of-two exponent e such that m * 2^e lands at ~2^target_log2 (m: largest |activation| of a layer; 0 -> 0)."""
+    if not (m > 0.0) or not math.isfinite(m):
+        return 0
+    return max(lo, min(hi, target_log2 - int(math.floor(math.log2(m))) - 1))
+
+
+def fold_activation_scales(pack, offs, meta, absmax):
+    """The ACTIVATION-SCALE block of the fused encoder path (include/magat_hip.h "Activation scales").  absmax: the 16 floats of
+    magat_encoder_calibrate_f32.  Every BasicBlock keeps ONE scale for its input, its conv1 output and the residual input of
+    its conv2 (they meet in one accumulator); scales change in the epilogue of conv2: s1 (stem .. layer1.conv1), s2
+    (layer1 out .. layer2.conv1), s3 (layer2 out .. layer3.conv1); the pooled layer3 output, feat and comp stay at their
+    true scale in HBM (other kernels read them) and are scaled by their float32 loaders (head_in, feat_in).
+    Returns (block float32 [SCALED_BLOCK_FLOATS], dict of the exponents)."""
+    a = [float(v) for v in absmax]
+    s1 = scale_exponent(max(a[0], a[1]))
+    # the stem's INPUT is not scaled (binary state maps): its scale rides in the stem weights, which the fused stem kernel
+    # splits into f16 planes of 16 w - keep 16 w 2^s1 inside the planes' range whatever the calibration batch looked like
+    w0max = float(max(pack[offs[0]:offs[0] + 864].abs().max(), pack[offs[1]:offs[1] + 32].abs().max()))
+    if w0max > 0.0:
+        s1 = min(s1, 15 - 4 - int(math.ceil(math.log2(w0max))))
+    s2 = scale_exponent(max(a[2], a[3]))
+    s3 = scale_exponent(max(a[4], a[5]))
+    e_head = scale_exponent(4.0 * a[6])          # (the head reads 2x2 SUMS of layer3's output)
+    e_feat = scale_exponent(a[7])
+    f = lambda e: 2.0 ** e
+
+    def seg(slot, n):
+        return pack[offs[slot]:offs[slot] + n].double()
+    blk = torch.zeros(SCALED_BLOCK_FLOATS, dtype=torch.float64)
+    blk[0:864] = seg(0, 864) * f(s1)
+    blk[864:896] = seg(1, 32) * f(s1)
+    blk[896:928] = seg(3, 32) * f(s1)            # layer1.conv1 bias (its 1 / weight-scale is unchanged: in and out share s1)
+    blk[928:960] = seg(5, 32) * f(s2)            # stage A  (layer1.conv2 + downsample): s1 -> s2
+    blk[960:1024] = seg(7, 64) * f(s2)           # stage B  (layer2.conv1)
+    blk[1024:1088] = seg(9, 64) * f(s3)          # stage C  (layer2.conv2 + downsample): s2 -> s3
+    blk[1088:1216] = seg(11, 128) * f(s3)        # layer3.conv1
+    blk[1216:1344] = seg(13, 128)                # layer3.conv2 + downsample: s3 -> true scale
+    ch, c3 = meta["chain"], meta["chain3"]
+    nA, nB, nC = 10240, 18432, 38912             # floats of the three chain weight blocks (block_fused.hip chain_block_bytes)
+    n1, n2a, n2b = 73728, 73728, 81920
+    sA, sB, sC = float(pack[ch + nA]), float(pack[ch + nA + 4 + nB]), float(pack[ch + nA + 4 + nB + 4 + nC])
+    s31, s32 = float(pack[c3 + n1]), float(pack[c3 + n1 + 4 + n2a + 4 + n2b])
+    blk[1344] = sA * f(s2 - s1)
+    blk[1345] = sB
+    blk[1346] = sC * f(s3 - s2)
+    blk[1347] = s31
+    blk[1348] = s32 * f(-s3)
+    blk[1349] = f(e_head)
+    blk[1350] = f(e_feat)
+    return blk.to(torch.float32), dict(s1=s1, s2=s2, s3=s3, head_in=e_head, feat_in=e_feat)
+
+
 def pack_block3_weights(w1, w2):
     """layer3 kernel (csrc/block_fused.hip block3_kernel): conv1 rows [128][9*64] and [conv2 | downsample] rows
     [128][9*128 + 64] -> three fragment-major blocks: conv1; conv2 over intermediate channels 0..63; conv2 over channels

@@ -28,6 +28,8 @@ class _Scratch:
         self.packed = None
         self.packed_key = None
         self.workspace = None
+        self.x_scale = 0.0           # power-of-two activation scale of the layer input (0 = none); float word [4] of the status block
+        self.x_scale_written = None
         self.csr = None              # CsrStructure built in the forward when addGSO did not hand one over
 
 
@@ -37,6 +39,10 @@ def _workspace(sc, need, dev):
     if sc.workspace is None or sc.workspace.numel() < need or sc.workspace.device != dev:
         sc.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
         sc.workspace[:256].zero_()
+        sc.x_scale_written = None
+    if sc.x_scale_written != sc.x_scale:        # activation scale of the layer input (magat_hip.h "Activation scales")
+        sc.workspace[16:20].view(torch.float32).fill_(float(sc.x_scale))
+        sc.x_scale_written = sc.x_scale
     return sc.workspace
 
 

@@ -59,6 +59,10 @@ class _Runtime:
         self.ws = None
         self.plan = GsoPlan()          # GSO-derived masks / walk order, made at addGSO on a side stream
         self.csr = CsrStructure()      # CSR + CSC structure of the GSO (large graphs / bf16 storage), made at addGSO
+        self.calibrated = True         # activation scales of the split arithmetic measured for the current weights
+        self.act_scales = None
+        self.scaled_at = 0
+        self.pack_host = self.pack_offs = self.pack_meta = None
         self.graphs = {}               # (shape key) -> captured hipGraph of one forward (enable_hip_graph)
         self.graph_on = None           # None: follow MAGAT_HIP_GRAPH
 
@@ -201,7 +205,8 @@ class DecentralPlannerGATNet(nn.Module):
         """Range guard of the split arithmetic (include/magat_hip.h): did the LAST inference forward leave the range the
         f16 planes carry exactly, so that the encoder / the graph layer's maps were re-run on the float32 MFMA kernels
         (same stream, automatic), and how often has that happened since the workspaces were allocated.  Synchronises."""
-        out = {"encoder_rerun": False, "encoder_reruns": 0, "gat_rerun": False, "gat_reruns": 0}
+        out = {"encoder_rerun": False, "encoder_reruns": 0, "gat_rerun": False, "gat_reruns": 0,
+               "act_scales": None if self._rt is None else self._rt.act_scales}
         lib = nat.lib()
         st = (ctypes.c_int32 * 2)()
         rt = self._rt
@@ -330,7 +335,12 @@ class DecentralPlannerGATNet(nn.Module):
             lin = (sd["ConvLayers.3.weight"], sd["ConvLayers.3.bias"]) if self.cnn_mode.endswith("_withMLP") else None
             pack, offs, meta = enc.fold_resnet(sd, self.config.FOV + 2, self.config.FOV + 2, "ConvLayers.0", lin,
                                                (sd["compressMLP.0.weight"], sd["compressMLP.0.bias"]))
-            rt.pack = pack.to(dev)
+            # room for the activation-scale block behind the pack (filled by the calibration pass of the first forward)
+            rt.scaled_at = pack.numel()
+            rt.pack_host, rt.pack_offs, rt.pack_meta = pack, offs, meta
+            rt.pack = torch.cat((pack, torch.zeros(enc.SCALED_BLOCK_FLOATS))).to(dev)
+            rt.calibrated, rt.act_scales = False, None
+            self.GFL[0]._scratch.x_scale = 0.0
             d = nat.EncoderDesc()
             d.variant, d.H, d.W = meta["variant"], meta["H"], meta["W"]
             d.n_feat, d.n_comp = meta["n_feat"], meta["n_comp"]
@@ -341,6 +351,7 @@ class DecentralPlannerGATNet(nn.Module):
             d.chain3_off = meta.get("chain3", 0)
             d.head16_off = meta.get("head16", 0)
             d.comp16_off = meta.get("comp16", 0)
+            d.scaled_off = 0
             rt.desc = d
         else:
             side = self.config.FOV + 2
@@ -372,6 +383,30 @@ class DecentralPlannerGATNet(nn.Module):
         rt.cb = sd["compressMLP.0.bias"].to(dev, torch.float32).contiguous()
         rt.key = key
         return rt
+
+    def _calibrate(self, rt, x, feat, comp, nfm, G, M, dev, stream):
+        """include/magat_hip.h "Activation scales": magat_encoder_calibrate_f32 on the batch at hand, then the scale block
+        (encoder.fold_activation_scales) into the pack and the graph layer's input scale into its status block.
+        One host synchronisation per set of weights."""
+        lib = nat.lib()
+        absmax = torch.zeros(16, dtype=torch.float32, device=dev)
+        nat.check(lib.magat_encoder_calibrate_f32(ctypes.byref(rt.desc), nat.ptr(x), nat.ptr(feat), nfm, nat.ptr(comp), G,
+                                                  nat.ptr(rt.ws), rt.ws.numel(), M, nat.ptr(absmax), stream),
+                  "magat_encoder_calibrate_f32")
+        a = absmax.cpu().tolist()
+        blk, info = enc.fold_activation_scales(rt.pack_host, rt.pack_offs, rt.pack_meta, a) if rt.pack_meta.get("chain3", 0) \
+            else (None, {})
+        if blk is not None:
+            rt.pack[rt.scaled_at:rt.scaled_at + enc.SCALED_BLOCK_FLOATS].copy_(blk.to(dev))
+            rt.desc.scaled_off = rt.scaled_at
+        # the graph layer's input (comp): scaled UP only (target 2^6: Q = W x and U = H x keep headroom in their own planes).
+        # A layer input beyond the planes' range is left to the range guard: its scores x_i W x_j are then ~1e10 with float32
+        # steps of ~1e3 - only the float32 form, which rounds in the reference's own order, still follows the reference there
+        e_x = max(0, enc.scale_exponent(a[8], target_log2=6))
+        self.GFL[0]._scratch.x_scale = 2.0 ** e_x
+        info.update(gat_in=e_x, absmax=[float(v) for v in a[:9]])
+        rt.act_scales = info
+        rt.calibrated = True
 
     def _buf(self, name, shape, dev):
         t = self._rt.buffers.get(name)
@@ -407,6 +442,11 @@ class DecentralPlannerGATNet(nn.Module):
             if rt.ws is None or rt.ws.numel() < need or rt.ws.device != dev:
                 rt.ws = torch.empty(need, dtype=torch.uint8, device=dev)
                 rt.ws[:256].zero_()          # range-guard status block (magat_encoder_read_status)
+            if not rt.calibrated and rt.desc.variant in (0, 1) and os.environ.get("MAGAT_ACT_SCALE", "1") == "1":
+                # first forward with these weights: ONE extra float32 pass that measures every layer's magnitude; the
+                # power-of-two activation scales of the split arithmetic are folded from it.  The forward itself then runs
+                # like every later one (same kernels, same scales: identical inputs give identical bits from the first call on)
+                self._calibrate(rt, x, feat, comp, nfm, G, M, dev, stream)
             nat.check(lib.magat_encoder_forward_f32(ctypes.byref(rt.desc), nat.ptr(x), nat.ptr(feat), nfm,
                                                     nat.ptr(comp), G, nat.ptr(rt.ws), rt.ws.numel(), M, stream),
                       "magat_encoder_forward_f32")

@@ -57,7 +57,10 @@ def _run(net, cfg, sd, device, B=4, N=20):
     ("compress", 1.0e4, False, False),    # graph-layer input X ~1.7e4: in range
     ("compress", 1.0e5, False, True),     # X ~1.7e5 > 65504: encoder fine, the layer's maps re-run in fp32
 ])
-def test_scaled_checkpoints_keep_parity(gpu_device, where, scale, expect_enc, expect_gat):
+def test_scaled_checkpoints_keep_parity(gpu_device, monkeypatch, where, scale, expect_enc, expect_gat):
+    """The range guard ALONE (MAGAT_ACT_SCALE=0: every plane carries its layer at the true scale): what leaves the planes' range
+    is re-run in float32.  With the activation scales on (the default, next test) none of these checkpoints re-runs."""
+    monkeypatch.setenv("MAGAT_ACT_SCALE", "0")
     cfg, sd, net = _scaled_model(gpu_device, scale, where=where)
     got, ref = _run(net, cfg, sd, gpu_device)
     st = net.range_status()
@@ -71,9 +74,100 @@ def test_scaled_checkpoints_keep_parity(gpu_device, where, scale, expect_enc, ex
         assert st["gat_rerun"] == expect_gat, st
 
 
-def test_guard_off_shows_what_it_protects_from(gpu_device, libopt):
+@pytest.mark.parametrize("where,scale", [("stem", 1.0), ("stem", 3.0e3), ("stem", 1.0e4), ("layer2", 2.0e3), ("layer2", 1.0e5),
+                                         ("stem", 1.0e-4), ("stem", 1.0e-7), ("layer2", 1.0e-5), ("compress", 1.0e4),
+                                         ("compress", 1.0e5), ("compress", 1.0e-5)])
+def test_activation_scales_keep_every_checkpoint_on_the_fast_path(gpu_device, where, scale):
+    """Default arithmetic: the first forward calibrates (one float32 pass), the power-of-two activation scales are folded, and
+    the SECOND forward - the fast path - keeps the parity without any re-run, whether the checkpoint's activations are 1e5
+    or 1e-7 (include/magat_hip.h "Activation scales")."""
+    cfg, sd, net = _scaled_model(gpu_device, scale, where=where)
+    got0, ref = _run(net, cfg, sd, gpu_device)             # calibration pass (float32 kernels)
+    assert net.range_status()["act_scales"] is not None
+    got, ref = _run(net, cfg, sd, gpu_device)              # fast path with the folded scales
+    st = net.range_status()
+    lim = 1e-4 * max(1.0, float(ref.abs().max()))
+    err, err0 = float((got - ref).abs().max()), float((got0 - ref).abs().max())
+    print("act-scale case %s x%g: max|logit| %.3g, err fast %.3g calibration pass %.3g (limit %.3g), %s" % (
+        where, scale, float(ref.abs().max()), err, err0, lim, st["act_scales"]))
+    assert err <= lim and err0 <= lim, (where, scale, err, err0, lim)
+    assert not st["encoder_rerun"], st
+    # (the graph layer's input is only ever scaled UP: at |X| ~ 1.7e5 the scores are ~1e10, float32 steps of 1e3 - that
+    #  regime stays with the guard's float32 form, which rounds in the reference's order)
+    assert st["gat_rerun"] == (where == "compress" and scale >= 1.0e5), st
+
+
+@pytest.mark.parametrize("where", ["tail", "layer1"])
+@pytest.mark.parametrize("down", [1.0e-3, 1.0e-4, 1.0e-6])
+@pytest.mark.parametrize("act_scale", ["1", "0"])
+def test_small_activations_reamplified_later(gpu_device, monkeypatch, down, where, act_scale):
+    """part of the network carried at a SMALL magnitude and re-amplified behind it, so that the logits are
+    exactly those of the unscaled checkpoint (O(1)) while an absolute error floor on the small maps would be amplified into them.
+      tail:   layer3's output BatchNorms (bn2, downsample) and the head's biases x `down` -> the pooled map, the head's input and
+              feat are all `down` times smaller; compressMLP's weight x 1 / down undoes it.
+      layer1: layer1's output BatchNorms x `down`; layer2's input-side BatchNorms (bn1, downsample) take running_mean x down,
+              running_var x down^2: layer1's output map (the residual input of layer2 as well) is small, everything else is not.
+    Tolerance relative to the output scale: 1e-4 * max(1, |logit|).  With the activation scales (default) the fast path holds
+    it; with MAGAT_ACT_SCALE=0 the planes' 2^-25 floor is what remains (reported; not asserted)."""
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    from magat_pathplanning_amd.synthetic import make_config
+    from oracle import magat_oracle as orc
+    monkeypatch.setenv("MAGAT_ACT_SCALE", act_scale)
+    cfg = make_config(num_agents=20, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcatGNN",
+                      device=str(gpu_device))
+    sd = orc.init_state_dict(cfg, seed=11)
+    pre = "ConvLayers.0."
+    if where == "tail":
+        for bn in ("layer3.0.bn2", "layer3.0.downsample.1"):
+            for k in ("weight", "bias"):
+                sd[pre + bn + "." + k] = sd[pre + bn + "." + k] * down
+        sd[pre + "fc.bias"] = sd[pre + "fc.bias"] * down
+        sd["ConvLayers.3.bias"] = sd["ConvLayers.3.bias"] * down
+        sd["compressMLP.0.weight"] = sd["compressMLP.0.weight"] / down
+    else:
+        for bn in ("layer1.0.bn2", "layer1.0.downsample.1"):
+            for k in ("weight", "bias"):
+                sd[pre + bn + "." + k] = sd[pre + bn + "." + k] * down
+        for bn in ("layer2.0.bn1", "layer2.0.downsample.1"):
+            sd[pre + bn + ".running_mean"] = sd[pre + bn + ".running_mean"] * down
+            sd[pre + bn + ".running_var"] = sd[pre + bn + ".running_var"] * down * down
+    net = DecentralPlannerGATNet(cfg)
+    net.load_state_dict(sd)
+    net = net.to(gpu_device).eval()
+    _run(net, cfg, sd, gpu_device)
+    got, ref = _run(net, cfg, sd, gpu_device)
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    print("re-amplified (%s x %g), ACT_SCALE=%s: max|logit| %.3g err %.3g (%.2g of the scale) %s" % (
+        where, down, act_scale, float(ref.abs().max()), err, err / scale, net.range_status()["act_scales"]))
+    assert 0.05 < float(ref.abs().max()) < 1e3
+    if act_scale == "1":
+        assert err <= 1e-4 * scale, (err, scale)
+        assert not net.range_status()["encoder_rerun"]
+
+
+def test_drift_after_calibration_still_reruns(gpu_device):
+    """The scales come from the calibration batch; inputs that later drive a layer 64x beyond what was measured leave the planes'
+    range again - the guard catches it as before (float32 re-run, status word)."""
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states
+    from oracle import magat_oracle as orc
+    cfg, sd, net = _scaled_model(gpu_device, 1.0, where="stem")
+    _run(net, cfg, sd, gpu_device)
+    x, S = fov_states(4, 20, seed=5) * 3000.0, comm_gso(4, 20, 28, seed=6)
+    ref = orc.planner_forward(x.double(), S.clone().double(), {k: (v.double() if v.is_floating_point() else v)
+                                                                for k, v in sd.items()}, cfg).float()
+    with torch.no_grad():
+        net.addGSO(S.clone().to(gpu_device))
+        got = net(x.to(gpu_device)).cpu()
+    st = net.range_status()
+    assert st["encoder_rerun"], st
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_guard_off_shows_what_it_protects_from(gpu_device, libopt, monkeypatch):
     """With the guard disabled the same out-of-range checkpoint silently loses parity (the clamp is real) - and the status
-    stays clear because nothing is tracked."""
+    stays clear because nothing is tracked.  (MAGAT_ACT_SCALE=0: with the activation scales this checkpoint is in range.)"""
+    monkeypatch.setenv("MAGAT_ACT_SCALE", "0")
     cfg, sd, net = _scaled_model(gpu_device, 1.0e4, where="stem")
     libopt.set("MAGAT_RANGE_GUARD", 0)
     got, ref = _run(net, cfg, sd, gpu_device)
@@ -85,9 +179,10 @@ def test_guard_off_shows_what_it_protects_from(gpu_device, libopt):
     assert net.range_status()["encoder_rerun"]
 
 
-def test_mx_opt_in_is_guarded_too(gpu_device, libopt):
+def test_mx_opt_in_is_guarded_too(gpu_device, libopt, monkeypatch):
     """OPT-IN f16 + block-scaled-fp8 correction form: its e4m3 planes saturate beyond +-448.  Activations in the thousands
     (fine for f16x3) trip the flag there and the float32 re-run restores parity."""
+    monkeypatch.setenv("MAGAT_ACT_SCALE", "0")
     libopt.set("MAGAT_CONV_MX", 1)
     cfg, sd, net = _scaled_model(gpu_device, 1000.0, where="layer2")
     got, ref = _run(net, cfg, sd, gpu_device)
@@ -157,6 +252,9 @@ def test_non_finite_inputs_are_not_clamped_into_finite_numbers(gpu_device, bad):
     cfg, sd, net = _scaled_model(gpu_device, 1.0, where="stem")
     B, N = 4, 20
     x, S = fov_states(B, N, seed=5), comm_gso(B, N, 28, seed=6)
+    with torch.no_grad():      # (a clean first forward: the calibration pass)
+        net.addGSO(S.clone().to(gpu_device))
+        net(x.to(gpu_device))
     x[2, 7, 1, 4, 6] = bad
     ref = orc.planner_forward(x, S.clone(), sd, cfg).view(B, N, 5)
     with torch.no_grad():

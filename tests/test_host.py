@@ -220,3 +220,41 @@ def test_mx_weight_block_decodes_to_the_weights():
     # e4m3: 3 mantissa bits -> relative error <= 2^-4 for normal numbers, absolute <= half a subnormal step below
     assert ((q1 - g1[:, kpi]).abs() <= g1[:, kpi].abs() / 16 + 64.0 * 2.0 ** -10).all()
     assert ((q2 - g2[:, kpi]).abs() <= g2[:, kpi].abs() / 16 + 2.0 ** -10 / 32.0).all()
+
+
+def test_fold_activation_scales_is_exact_and_consistent():
+    """encoder.fold_activation_scales (include/magat_hip.h "Activation scales"): every entry of the block is the pack's value
+    times a power of two; a block's input, conv1 output and residual input share one exponent; the 1 / weight-scale floats
+    carry the exponent DIFFERENCES, so that a chain of layers ends at the true scale."""
+    import math
+    import torch
+    from magat_pathplanning_amd import encoder as enc
+    from magat_pathplanning_amd.synthetic import make_config
+    from oracle import magat_oracle as orc
+    cfg = make_config(num_agents=4)
+    sd = orc.init_state_dict(cfg, seed=3)
+    pack, offs, meta = enc.fold_resnet(sd, 11, 11, "ConvLayers.0", (sd["ConvLayers.3.weight"], sd["ConvLayers.3.bias"]),
+                                       (sd["compressMLP.0.weight"], sd["compressMLP.0.bias"]))
+    absmax = [3e-4, 2e-4, 7.0, 900.0, 0.02, 0.05, 1.5e-6, 4e3, 0.3] + [0.0] * 7
+    blk, info = enc.fold_activation_scales(pack, offs, meta, absmax)
+    assert blk.numel() == enc.SCALED_BLOCK_FLOATS and blk.dtype == torch.float32
+    s1, s2, s3 = info["s1"], info["s2"], info["s3"]
+    assert 2 ** 9 <= max(absmax[0], absmax[1]) * 2.0 ** s1 <= 2 ** 10 or s1 <= 11 - 4 + 9     # (or the stem-weight cap)
+    assert 2 ** 9 <= max(absmax[2], absmax[3]) * 2.0 ** s2 <= 2 ** 10
+    assert 2 ** 9 <= max(absmax[4], absmax[5]) * 2.0 ** s3 <= 2 ** 10
+    w0 = pack[offs[0]:offs[0] + 864]
+    assert torch.equal(blk[0:864], w0 * 2.0 ** s1)                      # exact: a power of two
+    assert float((blk[0:864].abs().max()) * 16) < 65504                 # the stem kernel's f16 planes of 16 w'
+    assert torch.equal(blk[928:960], pack[offs[5]:offs[5] + 32] * 2.0 ** s2)
+    assert torch.equal(blk[1216:1344], pack[offs[13]:offs[13] + 128])   # the chain ends at the true scale
+    ch = meta["chain"]
+    sA, sC = float(pack[ch + 10240]), float(pack[ch + 10240 + 4 + 18432 + 4 + 38912])
+    assert float(blk[1344]) == sA * 2.0 ** (s2 - s1) and float(blk[1346]) == sC * 2.0 ** (s3 - s2)
+    c3 = meta["chain3"]
+    s32 = float(pack[c3 + 73728 + 4 + 73728 + 4 + 81920])
+    assert float(blk[1348]) == s32 * 2.0 ** (-s3)
+    # scale ratios telescope: (s2 - s1) + (s3 - s2) + (0 - s3) = -s1, what the stem put in
+    tot = math.log2(float(blk[1344]) / sA) + math.log2(float(blk[1346]) / sC) + math.log2(float(blk[1348]) / s32)
+    assert tot == -s1
+    for k in ("head_in", "feat_in"):
+        assert float(blk[1349 if k == "head_in" else 1350]) == 2.0 ** info[k]
