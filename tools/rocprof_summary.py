@@ -32,6 +32,7 @@ def short(name):
                    ("block_chain_kernel", "block_chain(layer1.conv2+layer2)"), ("block3_kernel", "block3(layer3+pool)"),
                    ("block_chain_w4_kernel", "block_chain_w4(layer1.conv2+layer2)"), ("block3_w4_kernel", "block3_w4(layer3+pool)"),
                    ("block_full_w4_kernel", "block_full_w4(layer1.conv2+layer2+layer3+pool)"),
+                   ("block_full_p_kernel", "block_full_p(layer1.conv2+layer2+layer3+pool, pooling in registers)"),
                    ("gat_guard_count_kernel", "guard_count(gat)"), ("guard_count_kernel", "guard_count(encoder)"),
                    ("gat_mfma_kernel", "gat_mfma(one-launch KeyQuery layer)"), ("gat_dense_kernel", "gat_dense_kernel"), ("head_mean_relu", "head_mean_relu"),
                    ("pack_kernel", "gat_pack"), ("gso_prepare", "gso_prepare")):
@@ -122,12 +123,16 @@ def main():
            "gat_layer (one launch)", "guard:gat_maps", "guard:gat_graph", "guard:gat_count", "actionsMLP"]
     ours = ("conv_gemm_kernel", "conv_gemm_bf16x6_kernel", "conv_gemm_f16x3_direct_kernel", "conv_first_kernel",
             "layer1_fused_kernel", "gat_dense_kernel", "block_chain_kernel", "block3_kernel", "block_chain_w4_kernel",
-            "block3_w4_kernel", "block_full_w4_kernel", "guard_count_kernel", "gat_mfma_kernel")
+            "block3_w4_kernel", "block_full_w4_kernel", "block_full_p_kernel", "guard_count_kernel", "gat_mfma_kernel")
     layers = defaultdict(dict)
     tr = find(os.path.join(out, "trace"), "*kernel_trace.csv")
     if tr:
         rows = [r for r in csv.DictReader(open(tr)) if any(o in r["Kernel_Name"] for o in ours)]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))          # the CSV is not in dispatch order
+        # the TIMED steps only: the warm-up steps in front of them also hold the one-off calibration pass of the activation
+        # scales (float32 layer-by-layer kernels) and weight packing
+        if len(rows) >= steps * len(SEQ):
+            rows = rows[-steps * len(SEQ):]
         if len(rows) % len(SEQ) == 0:
             dur = defaultdict(list)
             for i, r in enumerate(rows):
@@ -147,6 +152,9 @@ def main():
         key = "Dispatch_Id" if rows and "Dispatch_Id" in rows[0] else None
         if key:
             rows.sort(key=lambda r: int(r[key]))
+        pmc_steps = 2                                    # (tools/profile_round.sh: the PMC passes time 2 steps after 1 warm-up)
+        if len(rows) >= pmc_steps * len(SEQ):
+            rows = rows[-pmc_steps * len(SEQ):]
         if len(rows) % len(SEQ) == 0:
             acc2 = defaultdict(list)
             for i, r in enumerate(rows):
