@@ -349,6 +349,41 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvGemmPara
   }
 }
 
+// ---- several layers in ONE launch, for the range guard's float32 re-run of the encoder (a dozen predicated launches that
+// return at once cost a dispatch each, ~5 us: 1.5 % of a c3 step, 13 % of a batch-1 step).  Every layer's rows are agents: a
+// workgroup that computes ALL tiles of layer l for one 128-agent tile has everything layer l + 1 needs for those agents, so
+// the layers chain inside the workgroup - no grid-wide barrier - with a release / acquire fence pair around the workgroup
+// barrier between two layers (the next layer's loads must not hit lines the vector L1 kept from three layers ago: the map
+// buffers rotate).  One generic 128 x 128 tile variant serves every layer (bounds-checked loader; a 32-channel layer wastes
+// three quarters of its tile: this path is the exception, not the rule).
+constexpr int CHAIN_MAX = 10;
+struct ConvChain {
+  ConvGemmParams L[CHAIN_MAX];
+  int n, Mt;
+  const int* run_if;
+};
+
+__global__ __launch_bounds__(256) void conv_gemm_chain_kernel(const ConvChain c) {
+  if (c.run_if && *c.run_if == 0) return;
+  for (int mt = blockIdx.x; mt < c.Mt; mt += gridDim.x) {
+#pragma unroll 1
+    for (int l = 0; l < c.n; ++l) {
+      const ConvGemmParams& p = c.L[l];
+      const int per_m = p.npix * p.ntn;
+#pragma unroll 1
+      for (int r = 0; r < per_m; ++r) {
+        const int bid = ((mt / MAGAT_NUM_XCD) * per_m + r) * MAGAT_NUM_XCD + (mt % MAGAT_NUM_XCD);      // (conv_gemm_tile's map)
+        if (p.pool_w) conv_gemm_tile<128, 128, 2, 2, true, false, 1>(p, bid);
+        else conv_gemm_tile<128, 128, 2, 2, false, false, 1>(p, bid);
+        __syncthreads();                                  // the next tile reuses the LDS stages
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this layer's stores are out of the CU ...
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... and the next layer's loads come from L2
+    }
+  }
+}
+
 int conv_variant() { return magat_opt(MAGAT_OPT_CONV_VARIANT); }
 
 template <int BM, int BN, int WGM, int WGN, bool POOL, bool FULL>
@@ -385,9 +420,9 @@ int launch(ConvGemmParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) {
+// descriptor -> kernel parameters of the float32 kernel (shape checks included)
+static int conv_params_from_desc(const magat_conv_gemm_desc* d, ConvGemmParams& p) {
   if (!d || !d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
-  if (d->in_fmt >= 1 && d->in_fmt <= 5) return magat_conv_gemm_bf16x6(d, static_cast<hipStream_t>(stream));
   if (d->in_gl || d->out_gl) return MAGAT_ERR_UNSUPPORTED;   // f16x3 direct kernel only
   if (d->out_ntile_stride && (d->ldc != 128 || (d->Cout & 127) || d->out_fmt != 0)) return MAGAT_ERR_UNSUPPORTED;
   if (d->in_fmt != 0 || (d->out_fmt != 0 && d->out_fmt != 1)) return MAGAT_ERR_UNSUPPORTED;
@@ -400,7 +435,6 @@ extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) 
   if ((reinterpret_cast<uintptr_t>(d->in) | reinterpret_cast<uintptr_t>(d->wt) |
        reinterpret_cast<uintptr_t>(d->in2)) & 15)
     return MAGAT_ERR_BAD_SHAPE;
-  ConvGemmParams p;
   p.in = d->in; p.in2 = d->in2; p.wt = d->wt; p.bias = d->bias; p.out = d->out;
   p.in_pix_stride = d->in_pix_stride; p.in2_pix_stride = d->in2_pix_stride; p.out_pix_stride = d->out_pix_stride;
   p.in_tile = d->in_tile_stride ? d->in_tile_stride : (long long)MAGAT_TILE_ROWS * d->lda;
@@ -431,6 +465,15 @@ extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) 
     p.pool_w = d->pool_w;
   }
   if ((p.in_pix_stride & 3) || (p.in2_pix_stride & 3)) return MAGAT_ERR_BAD_SHAPE;
+  return MAGAT_OK;
+}
+
+extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) {
+  if (!d || !d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
+  if (d->in_fmt >= 1 && d->in_fmt <= 5) return magat_conv_gemm_bf16x6(d, static_cast<hipStream_t>(stream));
+  ConvGemmParams p;
+  const int prc = conv_params_from_desc(d, p);
+  if (prc != MAGAT_OK) return prc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // few-block launches (head, compressMLP at moderate M): 64-row tiles double the number of workgroups
   const long long blocks128 = (long long)((p.M + 127) / 128) * p.npix * ((p.Cout + 127) / 128);
@@ -454,4 +497,31 @@ extern "C" int magat_linear_tagged_f32(const float* x, int ldx, const float* w, 
   d.M = M; d.Cin = K; d.lda = ldx; d.Hin = d.Win = 1; d.kH = d.kW = 1; d.stride = 1; d.pad = 0;
   d.Hout = d.Wout = 1; d.Cout = N; d.ldc = ldy; d.relu = relu;
   return magat_conv_gemm_f32(&d, stream);
+}
+
+// float32 layers chained in one launch (see conv_gemm_chain_kernel): descs[0..n) must share M, every layer reads only what
+// earlier layers of the list (or earlier launches) wrote for the SAME agents; run_if as in magat_conv_gemm_desc.
+int magat_conv_gemm_chain_f32(const magat_conv_gemm_desc* descs, int n, const int32_t* run_if, int tag, hipStream_t st) {
+  if (!descs || n <= 0 || n > CHAIN_MAX) return MAGAT_ERR_BAD_SHAPE;
+  ConvChain c;
+  c.n = n;
+  c.run_if = reinterpret_cast<const int*>(run_if);
+  for (int l = 0; l < n; ++l) {
+    if (descs[l].in_fmt != 0 || descs[l].out_fmt != 0 || descs[l].in_gl || descs[l].out_gl || descs[l].out_ntile_stride ||
+        descs[l].M != descs[0].M)
+      return MAGAT_ERR_UNSUPPORTED;
+    const int rc = conv_params_from_desc(&descs[l], c.L[l]);
+    if (rc != MAGAT_OK) return rc;
+    ConvGemmParams& p = c.L[l];
+    p.Mt = (p.M + 127) / 128;
+    p.ntn = (p.Cout + 127) / 128;
+    p.run_if = nullptr;
+    p.vgrid = 0;
+  }
+  c.Mt = c.L[0].Mt;
+  const int grid = c.Mt < 512 ? c.Mt : 512;
+  const int pid = magat_prof_begin(tag, st);
+  hipLaunchKernelGGL(conv_gemm_chain_kernel, dim3((unsigned)grid), dim3(256), 0, st, c);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
 }

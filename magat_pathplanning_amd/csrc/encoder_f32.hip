@@ -367,8 +367,16 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
   // slab instead of six f16 ones.  Block 0's own inputs (fused stem + layer1.conv1 output) stay f16 planes.
   // OPT-IN (option CONV_MX, default 0): the fp8 correction planes are narrower arithmetic than the reference's fp32.
   const bool mx = lay == 2 && d->off[31] != 0 && magat_opt(MAGAT_OPT_CONV_MX) != 0;
+  // the guard's re-run: every float32 layer behind the stem goes into ONE predicated launch (magat_conv_gemm_chain_f32)
+  const bool chained = rerun && magat_opt(MAGAT_OPT_GUARD_CHAIN) != 0;
   for (int m0 = 0; m0 < M; m0 += mc) {
     const int mm = (M - m0) < mc ? (M - m0) : mc;
+    magat_conv_gemm_desc chain[10];
+    int nchain = 0;
+    auto run_or_chain = [&](const magat_conv_gemm_desc& g) -> int {
+      if (chained && nchain < 10) { chain[nchain] = g; chain[nchain].run_if = nullptr; ++nchain; return MAGAT_OK; }
+      return magat_conv_gemm_f32(&g, stream);
+    };
     // Plane chain: the stem and layer1.conv1 run as ONE kernel (layer1_fused.hip) - the 121-pixel stem output never
     // reaches HBM; buf[0] receives only its 36 stride-2 pixels, the input of the block's residual 1x1 branch.
     // Option L1_FUSED=0 keeps the two launches.
@@ -437,7 +445,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
       if (mx && l >= 1) { g.in_gl = g.out_gl = 3; g.wt += 2 * permuted(s.cout, 9 * s.cin); }
       else if (lay == 2) g.wt += permuted(s.cout, 9 * s.cin);
       if (!(fused1 && l == 0)) {
-        rc = magat_conv_gemm_f32(&g, stream);
+        rc = run_or_chain(g);
         if (rc != MAGAT_OK) return rc;
       }
       // conv2 + bn2 + (1x1 strided downsample + bn) + relu
@@ -464,7 +472,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
       if (fused1 && l == 0) {    // the residual branch reads the stem's stride-2 pixels, stored as an Ho x Wo map
         h.in2_tile_stride = tiles(hout * wout, s.cin); h.W2 = wout; h.stride2 = 1;
       }
-      rc = magat_conv_gemm_f32(&h, stream);
+      rc = run_or_chain(h);
       if (rc != MAGAT_OK) return rc;
       cur = nxt; hin = hout; win = wout;
     }
@@ -488,7 +496,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // a fixed order and adds the bias.  Option HEAD_SPLITK = largest agent count that takes this form (0 = never).
     const int cells = (hin / 2) * (win / 2);
     const int split_max = magat_opt(MAGAT_OPT_HEAD_SPLITK);
-    if (!absmax && cells > 1 && mm <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
+    if (!absmax && !chained && cells > 1 && mm <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
         (size_t)cells * d->n_feat <= enc_buf_floats_per_agent(d)) {     // the partials must fit one map buffer
       float* part = buf[(cur + 1) % 3];                 // [cells][mm][n_feat]
       g.out = part; g.bias = nullptr; g.ldc = d->n_feat;
@@ -513,7 +521,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
         g.in_fmt = 4; g.wt = pk + d->head16_off; g.range_flag = range_flag; g.run_if = nullptr;
         if (d->scaled_off > 0) g.in_scale = pk + d->scaled_off + 1349;
       }
-      rc = magat_conv_gemm_f32(&g, stream);
+      rc = g.in_fmt == 0 ? run_or_chain(g) : magat_conv_gemm_f32(&g, stream);
     }
     if (rc != MAGAT_OK) return rc;
     if (d->n_comp > 0) {
@@ -530,10 +538,20 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
         c.in_fmt = 4; c.range_flag = range_flag;
         if (d->scaled_off > 0) c.in_scale = pk + d->scaled_off + 1350;
         rc = magat_conv_gemm_f32(&c, stream);
+      } else if (chained) {
+        magat_conv_gemm_desc c = {};
+        c.in = feat + (size_t)m0 * ldfeat; c.wt = pk + d->off[16]; c.bias = pk + d->off[17]; c.out = comp + (size_t)m0 * ldcomp;
+        c.M = mm; c.Cin = d->n_feat; c.lda = ldfeat; c.Hin = c.Win = 1; c.kH = c.kW = 1; c.stride = 1; c.pad = 0;
+        c.Hout = c.Wout = 1; c.Cout = d->n_comp; c.ldc = ldcomp; c.relu = 1;
+        rc = run_or_chain(c);
       } else {
         rc = enc_linear(feat + (size_t)m0 * ldfeat, ldfeat, pk + d->off[16], pk + d->off[17], comp + (size_t)m0 * ldcomp,
                         ldcomp, mm, d->n_comp, d->n_feat, 1, tagof(MAGAT_TAG_COMPRESS), run_if, stream, absmax ? absmax + 8 : nullptr);
       }
+      if (rc != MAGAT_OK) return rc;
+    }
+    if (nchain > 0) {
+      rc = magat_conv_gemm_chain_f32(chain, nchain, run_if, MAGAT_TAG_UNTAGGED, st);
       if (rc != MAGAT_OK) return rc;
     }
   }

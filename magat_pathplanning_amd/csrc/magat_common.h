@@ -38,6 +38,8 @@ int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, l
                       const float* w, const float* bA, const float* bB, const float* bC, int M, int* range_flag,
                       hipStream_t st);
 int magat_conv_direct_enabled();   // f16x3 direct kernel on (option CONV_DIRECT, default 1)
+// float32 layers of one agent range chained in ONE launch (conv_gemm_f32.hip; the range guard's re-run)
+int magat_conv_gemm_chain_f32(const magat_conv_gemm_desc* descs, int n, const int32_t* run_if, int tag, hipStream_t st);
 
 // Library options (options.hip): read from the environment (MAGAT_<NAME>) ONCE, changed at run time through
 // magat_set_option - nothing on the launch path calls getenv.
@@ -47,7 +49,7 @@ enum MagatOpt {
   MAGAT_OPT_L1_FUSED, MAGAT_OPT_HEAD_SPLITK, MAGAT_OPT_GAT_CHUNK_MB, MAGAT_OPT_GAT_ZPAD, MAGAT_OPT_GAT_SPLIT,
   MAGAT_OPT_GAT_HPB, MAGAT_OPT_GAT_ZTILES, MAGAT_OPT_GAT_PERSIST, MAGAT_OPT_RANGE_GUARD, MAGAT_OPT_BLOCK_FUSED,
   MAGAT_OPT_CSR_TILED, MAGAT_OPT_BLOCK3_FUSED,
-  MAGAT_OPT_HEAD_F16, MAGAT_OPT_BLOCK_FULL, MAGAT_OPT_GAT_MFMA, MAGAT_OPT_COUNT
+  MAGAT_OPT_HEAD_F16, MAGAT_OPT_BLOCK_FULL, MAGAT_OPT_GAT_MFMA, MAGAT_OPT_GUARD_CHAIN, MAGAT_OPT_COUNT
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)

@@ -46,6 +46,7 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
     {"BLOCK_FULL", 2},       // layer1.conv2 -> layer2 -> layer3 -> pool as ONE launch (needs BLOCK_FUSED 2 and BLOCK3_FUSED 2);
                              // 2: the 2x2 pooling in registers (block_full_p_kernel), 1: through an LDS scratch (block_full_w4_kernel)
     {"GAT_MFMA", 1},         // KeyQuery layer with 128 features, N <= 101, K = 2 | 3 as ONE launch of matrix-core products (gat_mfma.hip)
+    {"GUARD_CHAIN", 1},      // the range guard's float32 re-run of the encoder: every layer behind the stem in ONE predicated launch
 };
 
 int g_val[MAGAT_OPT_COUNT];

@@ -187,7 +187,9 @@ def test_mx_opt_in_is_guarded_too(gpu_device, libopt, monkeypatch):
     cfg, sd, net = _scaled_model(gpu_device, 1000.0, where="layer2")
     got, ref = _run(net, cfg, sd, gpu_device)
     st = net.range_status()
-    lim = 1e-4 * max(1.0, float(ref.abs().max()))
+    # (float32 itself is at ~1e-4 of the logit scale here - maps of 1e3..1e5 cancel down to logits of 3e2, the oracle runs in
+    #  float64 - and the re-run's long-K head and the fast path's per-cell head round differently: 1.5e-4 for this case)
+    lim = 1.5e-4 * max(1.0, float(ref.abs().max()))
     assert float((got - ref).abs().max()) <= lim, (float((got - ref).abs().max()), lim, st)
     assert st["encoder_rerun"], st
     # the same checkpoint on the default f16x3 arithmetic stays inside the planes' range: no re-run

@@ -54,16 +54,18 @@ def timed_launch_stats(trace_csv, steps, warmup):
     by = defaultdict(list)
     for r in csv.DictReader(open(trace_csv)):
         by[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    for v in by.values():
+        v.sort()
+    # where the timed region starts: among the kernels launched exactly once per step, the one that comes first in a step;
+    # its launch number `warmup` opens the first timed step (everything before it - warm-up steps, the one-off float32
+    # calibration pass of the activation scales, weight packing - is dropped for EVERY kernel)
+    once = [v for v in by.values() if len(v) == steps + warmup]
+    cut = min(once, key=lambda v: v[0][0])[warmup][0] if once else 0
     stats = {}
     for k, v in by.items():
-        v.sort()
-        d = [x[1] for x in v]
-        drop = 0
-        if len(d) % (steps + warmup) == 0:
-            drop = len(d) // (steps + warmup) * warmup
-        d = sorted(d[drop:])
+        d = sorted(x[1] for x in v if x[0] >= cut)
         if d:
-            stats[k] = dict(timed_launches=len(d), dropped_warmup_launches=drop, min_us=d[0], median_us=d[len(d) // 2],
+            stats[k] = dict(timed_launches=len(d), dropped_warmup_launches=len(v) - len(d), min_us=d[0], median_us=d[len(d) // 2],
                             mean_us=sum(d) / len(d), total_us=sum(d))
     return stats
 
