@@ -1187,7 +1187,8 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
   // One launch of matrix-core products (gat_mfma.hip) when the shape allows; with the range guard on, the two-launch float32
   // form below follows in the same stream, every launch of it predicated on the flag the fused kernel raises.
   bool rerun_only = false;
-  if (!A_opt && gat_one_launch(N, G, F, K, mode, concat)) {
+  // (the one-launch kernel stores Y in 16-byte pieces: a column block at an odd offset of a wider buffer takes the two-launch form)
+  if (!A_opt && gat_one_launch(N, G, F, K, mode, concat) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
     const bool guard = magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
     const unsigned* masks = (plan && N <= 128) ? static_cast<const unsigned*>(plan) : nullptr;
     const int rc = magat_gat_mfma_forward(X, G, S, s_is_f64, masks, packed + magat_gat_frag_offset(L.NC, G), bias, Y, ldy, B,

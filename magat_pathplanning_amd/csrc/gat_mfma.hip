@@ -121,6 +121,26 @@ __device__ __forceinline__ void split2v(float x, float y, unsigned& p1, unsigned
   split_pair(x, y, p1, p2);
 }
 
+// 4 x 4 transpose inside every quad of lanes: afterwards a[r] of quad lane l holds what was a[l] of quad lane r (two butterfly
+// stages of one select + one DPP move + two selects per register pair)
+__device__ __forceinline__ void quad_transpose4(float (&a)[4], int lane) {
+  const bool odd = lane & 1, hi = lane & 2;
+#pragma unroll
+  for (int r0 = 0; r0 < 4; r0 += 2) {
+    const float send = odd ? a[r0] : a[r0 + 1];
+    const float recv = dpp_mov<0xB1>(send);                // quad_perm [1,0,3,2]
+    a[r0] = odd ? recv : a[r0];
+    a[r0 + 1] = odd ? a[r0 + 1] : recv;
+  }
+#pragma unroll
+  for (int r0 = 0; r0 < 2; ++r0) {
+    const float send = hi ? a[r0] : a[r0 + 2];
+    const float recv = dpp_mov<0x4E>(send);                // quad_perm [2,3,0,1]
+    a[r0] = hi ? recv : a[r0];
+    a[r0 + 2] = hi ? a[r0 + 2] : recv;
+  }
+}
+
 // (pointer + compile-time constant: the constant lands in the offset field of the ds instruction)
 __device__ __forceinline__ uint4 lds128(const char* ptr, int coff) { return *reinterpret_cast<const uint4*>(ptr + coff); }
 
@@ -599,11 +619,14 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
       };
       if constexpr (KT == 3) hop(std::integral_constant<int, 1>{});
       hop(std::integral_constant<int, 0>{});
-      // ---- epilogue: Y rows j = 32 mt + 8 q + 4 h + e, column c = cw: a wave-uniform row pointer per register and ONE
-      // per-lane byte offset (scalar base + 32-bit vector offset addressing)
+      // ---- epilogue: a lane holds column c = cw of rows j = 32 mt + 8 q + 4 h + e (e = 0..3).  Stored as they are, that is 64
+      // four-byte stores per lane and head (4.1 k cycles: the address path takes a store instruction at ~64 cycles whatever its
+      // width).  A 4 x 4 transpose inside every quad of lanes turns (4 rows x 1 column) per lane into (1 row x 4 columns):
+      // 16 sixteen-byte stores, each row still a 128-byte run per instruction.
       {
+        const int fq = cw & 3;                                   // this lane's row of the 4 x 4 block after the transpose
         const char* ybase = reinterpret_cast<const char*>(p.Y + (long long)b * N * p.ldy + (CONCAT ? hd * 128 : 0));
-        const unsigned lbyte = (unsigned)(cw + 4 * h * p.ldy) * 4u;
+        const unsigned lbyte = (unsigned)((cw & ~3) + (4 * h + fq) * p.ldy) * 4u;
         const long long rowb = (long long)p.ldy * 4;
         const bool last = hd == p.P - 1;
         const float fp = (float)p.P;
@@ -616,25 +639,29 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int jg = 32 * mt + 8 * q;
-            if (jg >= N) break;
-            const bool whole = jg + 8 <= N;
+            if (jg >= N) break;                                   // (wave-uniform)
+            float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if (!whole && !(jg + 4 * h + e < N)) continue;
-              float* dst = reinterpret_cast<float*>(const_cast<char*>(ybase + (jg + e) * rowb) + lbyte);
-              float v = acc[0][mt][4 * q + e] * kOutScale + biasv;
-              if constexpr (CONCAT) {
-                v = __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());
-              } else {
-                if (hd > 0) v = *dst + v;
-                if (last) v = __builtin_amdgcn_fmed3f(v / fp, 0.f, __builtin_inff());
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(acc[0][mt][4 * q + e], kOutScale, biasv);
+            quad_transpose4(v, lane);
+            const bool rok = jg + 4 * h + fq < N;
+            f32x4* dst = reinterpret_cast<f32x4*>(const_cast<char*>(ybase + jg * rowb) + lbyte);
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            if constexpr (CONCAT) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = __builtin_amdgcn_fmed3f(o[e], 0.f, __builtin_inff());
+            } else {
+              if (hd > 0 && rok) o += *dst;
+              if (last) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __builtin_amdgcn_fmed3f(o[e] / fp, 0.f, __builtin_inff());
               }
-#ifdef GM_WHATIF_NOYST
-              GM_SINK(v);
-#else
-              *dst = v;
-#endif
             }
+#ifdef GM_WHATIF_NOYST
+            GM_SINK(o[0]);
+#else
+            if (rok) *dst = o;
+#endif
           }
       }
       GM_STAMP(10);
