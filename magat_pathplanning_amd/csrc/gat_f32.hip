@@ -833,6 +833,52 @@ __global__ void pack_kernel(const float* __restrict__ weight, const float* __res
   }
 }
 
+// GAT_modified / GAT_origin at G = F = 128: the weight stream of the one-launch kernel (gat_mfma.hip MODE 1) in the SAME shape
+// as KeyQuery's - P blocks of 128 x 128 for G1, then P K tap blocks - as fragment-major f16 planes of 2^8 v.  The G1 block of
+// head p holds the two score vectors a1 W_p (row 0) and a2 W_p (row 1), zeros elsewhere; kconst[p] = a1 . wb + a2 . wb.
+__global__ void pack_frag_rank1_kernel(const float* __restrict__ weight, const float* __restrict__ wbias,
+                                       const float* __restrict__ mixer, const float* __restrict__ taps,
+                                       unsigned short* __restrict__ Fs, float* __restrict__ kconst, int K, int P, int mode) {
+  constexpr int G = 128, F = 128;
+  const long long total = (long long)(P * G + P * K * F) * G;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total + P;
+       idx += (long long)gridDim.x * blockDim.x) {
+    if (idx >= total) {
+      const int hp = (int)(idx - total);
+      float v = 0.f;
+      if (mode == MAGAT_MODE_GAT_MODIFIED && wbias)
+        for (int f = 0; f < F; ++f)
+          v = fmaf(mixer[(long long)hp * 2 * F + f] + mixer[(long long)hp * 2 * F + F + f], wbias[hp * F + f], v);
+      kconst[hp] = v;
+      continue;
+    }
+    const int col = (int)(idx / G), g = (int)(idx % G);
+    float v = 0.f;
+    if (col < P * G) {
+      const int hp = col / G, r = col % G;
+      if (r < 2)
+        for (int f = 0; f < F; ++f)
+          v = fmaf(mixer[(long long)hp * 2 * F + r * F + f], weight[((long long)hp * F + f) * G + g], v);
+    } else {
+      const int r = col - P * G, hp = r / (K * F), k = (r / F) % K, f = r % F;
+      v = mode == MAGAT_MODE_GAT_ORIGIN ? taps[k] * weight[((long long)hp * F + g) * G + f]
+                                        : taps[(((long long)hp * F + f) * K + k) * G + g];
+    }
+    const float vs = v * 256.f;
+    const _Float16 g1 = (_Float16)vs;
+    const _Float16 g2 = (_Float16)(vs - (float)g1);
+    const int rr = col & 127;
+    const long long fo = (long long)(col >> 7) * 32768 + (((rr >> 5) * 8 + (g >> 4)) * 2) * 512 +
+                         ((rr & 31) + 32 * ((g & 15) >> 3)) * 8 + (g & 7);
+    Fs[fo] = __builtin_bit_cast(unsigned short, g1);
+    Fs[fo + 512] = __builtin_bit_cast(unsigned short, g2);
+  }
+}
+
+static bool gat_rank1_frag(int G, int F, int mode) {
+  return G == 128 && F == 128 && (mode == MAGAT_MODE_GAT_MODIFIED || mode == MAGAT_MODE_GAT_ORIGIN);
+}
+
 long long* g_gat_dbg = nullptr;   // see magat_gat_set_debug_buffer
 
 bool supported_width(int w) { return w == 16 || w == 32 || w == 64 || w == 128 || w == 256; }
@@ -893,6 +939,8 @@ extern "C" size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode) 
   if (G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
   const PackLayout L = pack_layout(G, F, K, P, mode);
   if (G == 128 && (L.NC & 127) == 0) return magat_gat_frag_offset(L.NC, G) + (size_t)L.NC * G;
+  if (gat_rank1_frag(G, F, mode))      // + the one-launch kernel's weight stream and the per-head score constants
+    return magat_gat_frag_offset(L.NC, G) + (size_t)(P * G + P * K * F) * G + (((size_t)P + 3) & ~(size_t)3);
   return magat_gat_f16_block_offset(L.NC, G) + (size_t)L.NC * G + 4;
 }
 
@@ -974,6 +1022,11 @@ extern "C" int magat_gat_pack_weights(const float* weight, const float* weight_b
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), weight, weight_bias,
                      mixer, taps, packed, G, F, K, P, mode, L);
+  if (gat_rank1_frag(G, F, mode)) {
+    float* frag = packed + magat_gat_frag_offset(L.NC, G);
+    hipLaunchKernelGGL(pack_frag_rank1_kernel, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), weight, weight_bias,
+                       mixer, taps, reinterpret_cast<unsigned short*>(frag), frag + (size_t)(P * G + P * K * F) * G, K, P, mode);
+  }
   return magat_check_launch();
 }
 
@@ -1191,9 +1244,10 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
   if (!A_opt && gat_one_launch(N, G, F, K, mode, concat) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
     const bool guard = magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
     const unsigned* masks = (plan && N <= 128) ? static_cast<const unsigned*>(plan) : nullptr;
-    const int rc = magat_gat_mfma_forward(X, G, S, s_is_f64, masks, packed + magat_gat_frag_offset(L.NC, G), bias, Y, ldy, B,
-                                          N, K, P, concat, guard ? status : nullptr, st,
-                                          reinterpret_cast<const float*>(status + 4));
+    const float* frag = packed + magat_gat_frag_offset(L.NC, G);
+    const int rc = magat_gat_mfma_forward(X, G, S, s_is_f64, masks, frag, bias, Y, ldy, B, N, K, P, concat,
+                                          guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4), mode,
+                                          mode == MAGAT_MODE_KEYQUERY ? nullptr : frag + (size_t)(P * G + P * K * F) * G);
     if (rc != MAGAT_OK || !guard) return rc;
     rerun_only = true;
     p.run_if = status;

@@ -45,6 +45,8 @@ struct GatMfmaParams {
   int B, N, P, ldx, ldy, concat, s_is_f64;
   int hsplit;                 // 1, or P (small batches, concat): a workgroup per (instance, head) instead of per instance
   int* range_flag;
+  const float* kconst;        // rank-1 score modes: per head a1 . wb + a2 . wb (GAT_modified; zeros for GAT_origin), or null
+  int origin;                 // GAT_origin: the edge rule is |float(S) + I| > 1e-9 (graphML.py:1018)
   const float* x_scale;       // power-of-two activation scale of the X planes (device float; null or 0 = 1): Q, U and the
                               // accumulators then carry it once, the scores twice (undone in the softmax exponent and in Y)
   long long* dbg;             // MAGAT_DEBUG_HOOKS builds: [grid][4 waves][16] cycle stamps of the last head walked
@@ -145,7 +147,11 @@ __device__ __forceinline__ void quad_transpose4(float (&a)[4], int lane) {
 __device__ __forceinline__ uint4 lds128(const char* ptr, int coff) { return *reinterpret_cast<const uint4*>(ptr + coff); }
 
 // MT: 32-row tiles covering the agents (N <= 32 MT); KSI: 16-wide k steps covering them as a contraction index; KT: taps
-template <int MT, int KSI, int KT, bool CONCAT>
+// MODE 0: KeyQuery scores e_ij = x_i . W_p x_j (G1 + G2 products).  MODE 1: the rank-1 scores of GAT_modified / GAT_origin,
+// e_ij = lrelu_0.2(c1_j + c2_i + k_p) with c1 = (a1 W_p) . x, c2 = (a2 W_p) . x (graphML.py:777-796, 1024-1037): the weight
+// block of G1 holds the two vectors a1 W_p, a2 W_p as its rows 0 and 1 (magat_gat_pack_weights), so G1 and the Q planes are
+// the KeyQuery code unchanged and hand c1 / c2 over as columns 0 / 1 of Q; G2's product is replaced by 16 LDS reads per lane.
+template <int MT, int KSI, int KT, bool CONCAT, int MODE>
 __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p) {
   extern __shared__ __align__(16) char lds[];
   constexpr int KI = 16 * KSI, SA = 2 * KI + 16;
@@ -246,8 +252,12 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
               const int i = i0 + 4 * r;
-              const bool f0 = sizeof(ST) == 8 ? fabs((double)v0[r]) > 1e-9 : fabsf((float)v0[r]) > 1e-9f;
-              const bool f1 = sizeof(ST) == 8 ? fabs((double)v1[r]) > 1e-9 : fabsf((float)v1[r]) > 1e-9f;
+              bool f0 = sizeof(ST) == 8 ? fabs((double)v0[r]) > 1e-9 : fabsf((float)v0[r]) > 1e-9f;
+              bool f1 = sizeof(ST) == 8 ? fabs((double)v1[r]) > 1e-9 : fabsf((float)v1[r]) > 1e-9f;
+              if (MODE == 1 && p.origin) {      // self-loops added in float32: |float(S) + I| > 1e-9
+                f0 = fabsf((float)v0[r] + (lane_ == i ? 1.f : 0.f)) > 1e-9f;
+                f1 = fabsf((float)v1[r] + (lane_ + 64 == i ? 1.f : 0.f)) > 1e-9f;
+              }
               const unsigned long long k0 = __ballot(f0 && lane_ < N), k1 = __ballot(f1 && lane_ + 64 < N);
               if (lane_ == 0 && i < N) {
                 unsigned* m = reinterpret_cast<unsigned*>(lds + MO) + 4 * i;
@@ -429,6 +439,20 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
       GM_STAMP(2);
       GM_SYNC();
       GM_STAMP(3);
+      // rank-1 modes: columns 0 / 1 of Q are c1 / c2 (times the input scale): as float32 vectors behind the Q planes (the U^T
+      // region holds 8 KB more than the planes need until the hops), rows past N read the last stored row (masked anyway)
+      const unsigned CF = UO + (unsigned)R8 * 512u;
+      if constexpr (MODE == 1) {
+        for (int j = t; j < 128; j += 256) {
+          const int row = min(j, R8 - 1);
+          const char* qp = lds + UO + row * 512 + ((row & 15) << 4);
+          const _Float16 h0 = *reinterpret_cast<const _Float16*>(qp), h1 = *reinterpret_cast<const _Float16*>(qp + 2);
+          const _Float16 l0 = *reinterpret_cast<const _Float16*>(qp + 256), l1 = *reinterpret_cast<const _Float16*>(qp + 258);
+          *reinterpret_cast<float*>(lds + CF + 4 * j) = (float)h0 + (float)l0;
+          *reinterpret_cast<float*>(lds + CF + 512 + 4 * j) = (float)h1 + (float)l1;
+        }
+        GM_SYNC();
+      }
       // ---- G2: E^T[j][i], softmax over j per column i, A planes [j][i] * 2^8
       if (g2_active) {
         GM_ROWS(rsw, xsw)
@@ -437,6 +461,22 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acce[0][mt][r] = 0.f;
+        if constexpr (MODE == 1) {
+          const float kc = p.kconst ? p.kconst[hd] : 0.f;
+          const float c2i = *reinterpret_cast<const float*>(lds + CF + 512 + 4 * min(cw, 127)) * ixs + kc;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 c1 = *reinterpret_cast<const f32x4*>(lds + CF + 4 * (32 * mt + 8 * q + 4 * h));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float ev = __builtin_fmaf(c1[e], ixs, c2i);
+                acce[0][mt][4 * q + e] = fmaxf(ev, 0.2f * ev);      // LeakyReLU(0.2)
+              }
+            }
+        }
+        if constexpr (MODE == 0) {
         const int rowb = min(32 * w + (cw & 31), N - 1);      // this wave's i tile as B operand
         const unsigned rswb = rowb * 512, xswb = (h ^ (rowb & 15)) << 4;
         const char* qbase = lds + UO;
@@ -469,6 +509,7 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
             }
           GM_PIN();
         }
+        }      // (MODE == 0)
         GM_STAMP(12);
         // masked softmax of row i = cw over its edges j (graphML.py:1771-1776): in-lane over the MT * 16 accumulator
         // registers, one exchange with the partner lane (the other 4-row halves of the same column).  Entries without an
@@ -495,7 +536,7 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
             GM_PIN();
           }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float kLog2e = kLog2eS;
+        const float kLog2e = MODE == 1 ? 1.4426950408889634f : kLog2eS;      // (the rank-1 scores are formed at their true scale)
         const float cexp = mx > -__builtin_inff() ? -mx * kLog2e : 0.f;
         float sum = 0.f;
 #pragma unroll
@@ -683,12 +724,12 @@ int gat_mfma_class(int N) {
   return (N <= 16 * ksi && gat_mfma_lds(N, ksi) <= 160 * 1024) ? c : -1;
 }
 
-template <int MT, int KSI, int KT>
+template <int MT, int KSI, int KT, int MODE>
 int launch(const GatMfmaParams& p, int slot, hipStream_t st) {
   const size_t lds = gat_mfma_lds(p.N, KSI);
-  const void* fn = p.concat ? reinterpret_cast<const void*>(&gat_mfma_kernel<MT, KSI, KT, true>)
-                            : reinterpret_cast<const void*>(&gat_mfma_kernel<MT, KSI, KT, false>);
-  if (magat_ensure_dyn_lds(fn, slot + (p.concat ? 0 : 6), lds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
+  const void* fn = p.concat ? reinterpret_cast<const void*>(&gat_mfma_kernel<MT, KSI, KT, true, MODE>)
+                            : reinterpret_cast<const void*>(&gat_mfma_kernel<MT, KSI, KT, false, MODE>);
+  if (magat_ensure_dyn_lds(fn, slot + (p.concat ? 0 : 6) + 12 * MODE, lds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
   // compute units of the CURRENT device (a cheap attribute query, no cached process-wide value: one process may drive several)
   int cus = 256, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
@@ -704,10 +745,19 @@ int launch(const GatMfmaParams& p, int slot, hipStream_t st) {
   const long long units = q.hsplit > 1 ? (long long)p.B * p.P : p.B;
   const int blocks = (int)(units < (long long)cus * q.hsplit ? units : (long long)cus * q.hsplit);
   const int pid = magat_prof_begin(MAGAT_TAG_GAT_LAYER, st);
-  if (p.concat) hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, true>), dim3(blocks), dim3(256), lds, st, q);
-  else hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, false>), dim3(blocks), dim3(256), lds, st, q);
+  if (p.concat) hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, true, MODE>), dim3(blocks), dim3(256), lds, st, q);
+  else hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, false, MODE>), dim3(blocks), dim3(256), lds, st, q);
   magat_prof_end(pid, st);
   return magat_check_launch();
+}
+
+template <int MODE>
+int launch_class(const GatMfmaParams& p, int K, hipStream_t st) {
+  const int cls = gat_mfma_class(p.N);
+  if (cls == 0) return K == 3 ? launch<1, 2, 3, MODE>(p, MAGAT_LDS_GATM_0, st) : launch<1, 2, 2, MODE>(p, MAGAT_LDS_GATM_0 + 1, st);
+  if (cls == 1) return K == 3 ? launch<2, 4, 3, MODE>(p, MAGAT_LDS_GATM_0 + 2, st) : launch<2, 4, 2, MODE>(p, MAGAT_LDS_GATM_0 + 3, st);
+  if (cls == 2) return K == 3 ? launch<4, 7, 3, MODE>(p, MAGAT_LDS_GATM_0 + 4, st) : launch<4, 7, 2, MODE>(p, MAGAT_LDS_GATM_0 + 5, st);
+  return MAGAT_ERR_UNSUPPORTED;
 }
 
 }  // namespace
@@ -717,15 +767,16 @@ extern "C" int magat_gat_mfma_set_debug_buffer(long long* dev_buf) { g_gat_mfma_
 #endif
 
 int magat_gat_mfma_supported(int N, int G, int F, int K, int mode) {
-  if (mode != MAGAT_MODE_KEYQUERY || G != 128 || F != 128 || (K != 2 && K != 3)) return 0;
+  if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GAT_ORIGIN || G != 128 || F != 128 || (K != 2 && K != 3)) return 0;
   return gat_mfma_class(N) >= 0 ? 1 : 0;
 }
 
 int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre,
                            const float* packed_frag, const float* bias, float* Y, int ldy, int B, int N, int K, int P,
-                           int concat, int* range_flag, hipStream_t st, const float* x_scale) {
+                           int concat, int* range_flag, hipStream_t st, const float* x_scale, int mode, const float* kconst) {
   GatMfmaParams p;
   p.x_scale = x_scale;
+  p.kconst = kconst; p.origin = mode == MAGAT_MODE_GAT_ORIGIN ? 1 : 0;
   p.X = X; p.ldx = ldx; p.S = S; p.s_is_f64 = s_is_f64; p.rmask_pre = rmask_pre;
   p.wfrag = reinterpret_cast<const char*>(packed_frag);
   p.bias = bias; p.Y = Y; p.ldy = ldy; p.B = B; p.N = N; p.P = P; p.concat = concat; p.range_flag = range_flag;
@@ -734,9 +785,5 @@ int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64,
 #ifdef MAGAT_DEBUG_HOOKS
   p.dbg = g_gat_mfma_dbg;
 #endif
-  const int cls = gat_mfma_class(N);
-  if (cls == 0) return K == 3 ? launch<1, 2, 3>(p, MAGAT_LDS_GATM_0, st) : launch<1, 2, 2>(p, MAGAT_LDS_GATM_0 + 1, st);
-  if (cls == 1) return K == 3 ? launch<2, 4, 3>(p, MAGAT_LDS_GATM_0 + 2, st) : launch<2, 4, 2>(p, MAGAT_LDS_GATM_0 + 3, st);
-  if (cls == 2) return K == 3 ? launch<4, 7, 3>(p, MAGAT_LDS_GATM_0 + 4, st) : launch<4, 7, 2>(p, MAGAT_LDS_GATM_0 + 5, st);
-  return MAGAT_ERR_UNSUPPORTED;
+  return mode == MAGAT_MODE_KEYQUERY ? launch_class<0>(p, K, st) : launch_class<1>(p, K, st);
 }

@@ -53,15 +53,15 @@ enum MagatOpt {
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)
-#define MAGAT_LDS_SLOTS 56
+#define MAGAT_LDS_SLOTS 64
 int magat_ensure_dyn_lds(const void* func, int slot, size_t bytes);
 enum MagatLdsSlot {
   MAGAT_LDS_GAT16, MAGAT_LDS_GAT32, MAGAT_LDS_GAT64, MAGAT_LDS_GAT128, MAGAT_LDS_GAT256, MAGAT_LDS_L1FUSED,
   MAGAT_LDS_SIM_GSO_T, MAGAT_LDS_SIM_GSO_F, MAGAT_LDS_SIM_MOVE, MAGAT_LDS_BLOCK_A, MAGAT_LDS_BLOCK_B, MAGAT_LDS_BLOCK_C,
   MAGAT_LDS_SIM_CONN, MAGAT_LDS_CONV_FIRST, MAGAT_LDS_CONV_FIRST11, MAGAT_LDS_GSO_STRUCT, MAGAT_LDS_CSR_TILED_A, MAGAT_LDS_CSR_TILED_B, MAGAT_LDS_CSR_TILED_A16, MAGAT_LDS_CSR_TILED_B16,
   MAGAT_LDS_CSR_TILED_A4, MAGAT_LDS_CSR_TILED_B4, MAGAT_LDS_CSR_TILED_A16_4, MAGAT_LDS_CSR_TILED_B16_4, MAGAT_LDS_BLOCK_B4, MAGAT_LDS_BLOCK_FULL, MAGAT_LDS_BLOCK_FULL_P,
-  MAGAT_LDS_GATM_0,      // gat_mfma.hip: 12 slots (shape class x taps x merge)
-  MAGAT_LDS_GATM_END = MAGAT_LDS_GATM_0 + 12
+  MAGAT_LDS_GATM_0,      // gat_mfma.hip: 24 slots (score mode x shape class x taps x merge)
+  MAGAT_LDS_GATM_END = MAGAT_LDS_GATM_0 + 24
 };
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of
@@ -81,7 +81,9 @@ int magat_gat_mfma_supported(int N, int G, int F, int K, int mode);
 int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre,
                            const float* packed_frag, const float* bias, float* Y, int ldy, int B, int N, int K, int P,
                            int concat, int* range_flag, hipStream_t st,
-                           const float* x_scale = nullptr);      // device float: power-of-two scale of X's planes (null / 0 = 1)
+                           const float* x_scale = nullptr,       // device float: power-of-two scale of X's planes (null / 0 = 1)
+                           int mode = MAGAT_MODE_KEYQUERY,       // GAT_modified / GAT_origin: rank-1 scores (packed_frag: the rank-1 block)
+                           const float* kconst = nullptr);       // per head a1 . wb + a2 . wb (device floats), or null
 
 // hoisted GAT maps Z [M][ldz >= NC] = X [M][G] @ Bt^T + colbias from the packed weights (gat_f32.hip): bf16x6 split when
 // NC % 32 == 0 and G % 32 == 0, else fp32 MFMA

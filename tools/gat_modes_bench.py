@@ -5,7 +5,7 @@ import torch
 from magat_pathplanning_amd import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin, _native as nat
 from magat_pathplanning_amd.graphml import gat_forward_rows
 from magat_pathplanning_amd.synthetic import comm_gso
-B, N = int(sys.argv[1]), int(sys.argv[2])
+B, N = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (512, 100)
 dev = torch.device("cuda:0")
 lib = nat.lib()
 X = torch.randn(B, N, 128, device=dev)
@@ -22,7 +22,7 @@ for mode in ("KeyQuery", "GAT_modified", "GAT_origin"):
                 gat_forward_rows(X, S, layer)
             torch.cuda.synchronize(); lib.magat_profile_enable(0); lib.magat_profile_collect()
         out = []
-        for tag in (10, 11, 13):
+        for tag in (10, 11, 13, 19):
             c, t = ctypes.c_longlong(0), ctypes.c_double(0)
             lib.magat_profile_read(tag, ctypes.byref(c), ctypes.byref(t))
             if c.value:
