@@ -1032,26 +1032,43 @@ __global__ __launch_bounds__(256) void gso_mask_kernel(T* __restrict__ S, unsign
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (row >= rows) return;
-  T* r = S + row * N;
+  // The row is READ through one pointer and (rarely: addGSO's scrub) WRITTEN through another the compiler cannot relate to it:
+  // with the conditional write-back in the same loop as the loads of the same array, every load waited for the store in front
+  // of it (the plain row-degree kernel streams the same bytes at 4.5 TB/s, this loop ran at 2.6).  A lane only ever re-writes
+  // the element it has just read itself, so no ordering between the two is needed.
+  const T* __restrict__ rl = S + row * N;
+  T* rs = S + row * N;
+  asm volatile("" : "+v"(rs));
   const int i = (int)(row % N);
-  // plain 64-column steps at full occupancy (8 waves per SIMD hide the latency; a 16-register batched form compiled to
-  // 236 VGPRs and ran 7x slower)
   int cnt = 0;
-  for (int w = 0; w < W64; ++w) {
-    const int j = w * 64 + lane;
-    bool f = false;
-    if (j < N) {
-      T x = r[j];
-      bool dirty = false;
-      if (scrub_nan && x != x) { x = (T)0; dirty = true; }
-      if (gso_mode == 1 && x > (T)0 && x != (T)1) { x = (T)1; dirty = true; }
-      if (dirty) r[j] = x;
-      f = gso_edge(x, j == i, rule);
+  unsigned long long mine = 0ull;      // word `lane` of the row's bit mask: ONE 128-byte store per row behind the loop
+  // four 64-column steps per batch: the four loads go out before the first value is looked at (one load -> wait -> test per
+  // step left the latency to the occupancy alone)
+  for (int w0 = 0; w0 < W64; w0 += 4) {
+    T xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = (w0 + u) * 64 + lane;
+      xv[u] = (w0 + u < W64 && j < N) ? rl[j] : (T)0;
     }
-    const unsigned long long m = __ballot(f);
-    cnt += __popcll(m);
-    if (lane == 0) masks[row * W64 + w] = m;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int w = w0 + u, j = w * 64 + lane;
+      bool f = false;
+      if (w < W64 && j < N) {
+        T x = xv[u];
+        bool dirty = false;
+        if (scrub_nan && x != x) { x = (T)0; dirty = true; }
+        if (gso_mode == 1 && x > (T)0 && x != (T)1) { x = (T)1; dirty = true; }
+        if (dirty) rs[j] = x;
+        f = gso_edge(x, j == i, rule);
+      }
+      const unsigned long long m = __ballot(f);
+      cnt += __popcll(m);
+      if (lane == w) mine = m;
+    }
   }
+  if (lane < W64) masks[row * W64 + lane] = mine;
   if (lane == 0) inst_tot[row] = cnt;      // per-ROW degree (summed per instance by gso_totals_kernel: 128 k same-line atomics
 }                                          // serialised on one L2 channel took 1 ms)
 
