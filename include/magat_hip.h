@@ -272,6 +272,13 @@ size_t magat_gso_csr_workspace_bytes(int B, int N);
 int magat_gso_csr_build(void* S, int s_is_f64, int scrub_nan, int gso_mode, int edge_rule, int* rowptr, int* colidx,
                         int* cscptr, int* cscsrc, int* cscpos, long long cap, long long* nnz_dev, void* workspace,
                         size_t workspace_bytes, int B, int N, void* stream);
+/* The same build in two halves, for callers that order OTHER streams behind the in-place scrub only: phase 1 = the streaming
+ * pass over S (scrub, bit matrix, edge totals: the only part that writes S), phase 2 = the structure kernel (reads the
+ * workspace phase 1 left, same arguments), phase 0 = both.  An event recorded between the two is all a reader of S has to
+ * wait for. */
+int magat_gso_csr_build_phase(void* S, int s_is_f64, int scrub_nan, int gso_mode, int edge_rule, int* rowptr, int* colidx,
+                              int* cscptr, int* cscsrc, int* cscpos, long long cap, long long* nnz_dev, void* workspace,
+                              size_t workspace_bytes, int B, int N, int phase, void* stream);
 /* magat_gat_forward_csr_{f32,bf16} with the CSC view from magat_gso_csr_build (no per-call transpose; workspace:
  * magat_gat_csc_workspace_bytes - the csr_* figure minus the transpose scratch, 3 * nnz ints) */
 size_t magat_gat_csc_workspace_bytes(int B, int N, long long nnz, int G, int F, int K, int P, int mode, int concat, int bf16);

@@ -17,6 +17,10 @@ SOURCES = ["conv_gemm_f32.hip", "conv_gemm_bf16x6.hip", "block_fused.hip", "gat_
 HEADERS = ["magat_common.h", os.path.join("..", "..", "include", "magat_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value", *os.environ.get("MAGAT_EXTRA_FLAGS", "").split(),
          "-Wno-inline-asm"]
+# block_fused.hip: MFMA results in architectural registers wherever they fit (the chain kernel has all 512 registers of a SIMD to one wave:
+# the epilogues then read the accumulators as plain operands instead of through v_accvgpr_read; chain kernel -0.9 % same-box).  The graph
+# kernel is slower and loses its spill-free allocation under the same flag, so it is per source.
+SOURCE_FLAGS = {"block_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _sources():
@@ -43,7 +47,7 @@ def build(force=False, verbose=False, debug=False):
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
-            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + flags + SOURCE_FLAGS.get(s, []) + ["-c", src, "-o", obj])
     if not jobs and not _newer(lib, objs):
         return lib
 

@@ -1042,17 +1042,20 @@ __global__ __launch_bounds__(256) void gso_mask_kernel(T* __restrict__ S, unsign
   const int i = (int)(row % N);
   int cnt = 0;
   unsigned long long mine = 0ull;      // word `lane` of the row's bit mask: ONE 128-byte store per row behind the loop
-  // four 64-column steps per batch: the four loads go out before the first value is looked at (one load -> wait -> test per
-  // step left the latency to the occupancy alone)
-  for (int w0 = 0; w0 < W64; w0 += 4) {
-    T xv[4];
+  // GSO_MASK_BATCH 64-column steps per batch: the loads of a batch go out before the first value is looked at (one load -> wait
+  // -> test per step left the latency to the occupancy alone)
+#ifndef GSO_MASK_BATCH
+#define GSO_MASK_BATCH 4
+#endif
+  for (int w0 = 0; w0 < W64; w0 += GSO_MASK_BATCH) {
+    T xv[GSO_MASK_BATCH];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GSO_MASK_BATCH; ++u) {
       const int j = (w0 + u) * 64 + lane;
       xv[u] = (w0 + u < W64 && j < N) ? rl[j] : (T)0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GSO_MASK_BATCH; ++u) {
       const int w = w0 + u, j = w * 64 + lane;
       bool f = false;
       if (w < W64 && j < N) {
@@ -1071,6 +1074,70 @@ __global__ __launch_bounds__(256) void gso_mask_kernel(T* __restrict__ S, unsign
   if (lane < W64) masks[row * W64 + lane] = mine;
   if (lane == 0) inst_tot[row] = cnt;      // per-ROW degree (summed per instance by gso_totals_kernel: 128 k same-line atomics
 }                                          // serialised on one L2 channel took 1 ms)
+
+#ifndef MAGAT_GSO_X4
+#define MAGAT_GSO_X4 1
+#endif
+// float rows with N % 4 == 0 (rows 16-byte aligned): every lane loads FOUR columns per request and all requests of the row
+// (N <= 1024: four) go out before the first value is looked at - 16 KB in flight per wave instead of 1 KB per load of the
+// scalar form, which left the pass at the latency x occupancy product (3.9 TB/s at config 5).  A lane's four edge flags are a
+// nibble at bit 4 (lane % 16) of the 64-column word its 16-lane row covers: the word is the OR over the row (DPP).
+__device__ __forceinline__ unsigned gso_dpp_or(unsigned v, const int ctrl_tag) {
+  switch (ctrl_tag) {
+    case 0: return v | (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
+    case 1: return v | (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+    case 2: return v | (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);    // row_ror:4
+    default: return v | (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);   // row_ror:8
+  }
+}
+__global__ __launch_bounds__(256) void gso_mask_x4_kernel(float* __restrict__ S, unsigned long long* __restrict__ masks,
+                                                          int* __restrict__ inst_tot, int N, int W64, long long rows,
+                                                          int scrub_nan, int gso_mode, int rule) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const f32x4* __restrict__ rl = reinterpret_cast<const f32x4*>(S + row * N);
+  float* rs = S + row * N;                       // (write-back pointer the compiler cannot relate to the loads: see below)
+  asm volatile("" : "+v"(rs));
+  const int i = (int)(row % N);
+  f32x4 xv[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int j0 = s * 256 + lane * 4;
+    xv[s] = j0 < N ? rl[s * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  unsigned long long mine = 0ull;                // word `lane` of the row's bit mask (lanes 0..15)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int j0 = s * 256 + lane * 4;
+    unsigned nib = 0;
+    if (j0 < N) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float x = xv[s][c];
+        bool dirty = false;
+        if (scrub_nan && x != x) { x = 0.f; dirty = true; }
+        if (gso_mode == 1 && x > 0.f && x != 1.f) { x = 1.f; dirty = true; }
+        if (dirty) rs[j0 + c] = x;
+        nib |= gso_edge(x, j0 + c == i, rule) ? (1u << c) : 0u;
+      }
+    }
+    const int sh = 4 * (lane & 15);
+    unsigned lo = sh < 32 ? nib << sh : 0u, hi = sh >= 32 ? nib << (sh - 32) : 0u;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { lo = gso_dpp_or(lo, t); hi = gso_dpp_or(hi, t); }
+    // every lane of row q = lane / 16 now holds word 4 s + q; lane w < 16 keeps word w: from row w % 4 when w / 4 == s
+    const int srcl = 16 * (lane & 3);
+    const unsigned glo = (unsigned)__shfl((int)lo, srcl, 64), ghi = (unsigned)__shfl((int)hi, srcl, 64);
+    if ((lane >> 2) == s) mine = ((unsigned long long)ghi << 32) | glo;
+  }
+  int cnt = lane < 16 ? __popcll(mine) : 0;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if (lane < W64) masks[row * W64 + lane] = mine;
+  if (lane == 0) inst_tot[row] = cnt;
+}
 
 // edge total of every instance: one workgroup per instance over its N row degrees
 __global__ __launch_bounds__(256) void gso_totals_kernel(const int* __restrict__ rowdeg, int* __restrict__ inst_tot, int N) {
@@ -1206,10 +1273,12 @@ extern "C" size_t magat_gso_csr_workspace_bytes(int B, int N) {
          magat_align_up((size_t)B * N * sizeof(int), 256);
 }
 
-extern "C" int magat_gso_csr_build(void* S, int s_is_f64, int scrub_nan, int gso_mode, int edge_rule, int* rowptr,
-                                   int* colidx, int* cscptr, int* cscsrc, int* cscpos, long long cap, long long* nnz_dev,
-                                   void* workspace, size_t workspace_bytes, int B, int N, void* stream) {
+extern "C" int magat_gso_csr_build_phase(void* S, int s_is_f64, int scrub_nan, int gso_mode, int edge_rule, int* rowptr,
+                                         int* colidx, int* cscptr, int* cscsrc, int* cscpos, long long cap,
+                                         long long* nnz_dev, void* workspace, size_t workspace_bytes, int B, int N,
+                                         int phase, void* stream) {
   if (!S || !rowptr || !colidx || !cscptr || !cscsrc || !cscpos) return MAGAT_ERR_NULL;
+  if (phase < 0 || phase > 2) return MAGAT_ERR_BAD_SHAPE;
   if (B <= 0 || N <= 0 || cap < 0 || edge_rule < 0 || edge_rule > 2 || gso_mode < 0 || gso_mode > 1)
     return MAGAT_ERR_BAD_SHAPE;
   const size_t need = magat_gso_csr_workspace_bytes(B, N);
@@ -1224,20 +1293,34 @@ extern "C" int magat_gso_csr_build(void* S, int s_is_f64, int scrub_nan, int gso
   int* rowdeg = reinterpret_cast<int*>(reinterpret_cast<char*>(inst_tot) + magat_align_up((size_t)B * sizeof(int), 256));
   const long long rows = (long long)B * N;
   const int pid = magat_prof_begin(MAGAT_TAG_GSO_CSR, st);
-  const unsigned blocks = (unsigned)((rows + 3) / 4);
-  if (s_is_f64)
-    hipLaunchKernelGGL(gso_mask_kernel<double>, dim3(blocks), dim3(256), 0, st, static_cast<double*>(S), masks, rowdeg,
-                       N, W64, rows, scrub_nan, gso_mode, edge_rule);
-  else
-    hipLaunchKernelGGL(gso_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<float*>(S), masks, rowdeg, N,
-                       W64, rows, scrub_nan, gso_mode, edge_rule);
-  hipLaunchKernelGGL(gso_totals_kernel, dim3(B), dim3(256), 0, st, rowdeg, inst_tot, N);
-  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&gso_structure_kernel), MAGAT_LDS_GSO_STRUCT, lds) != MAGAT_OK)
-    return MAGAT_ERR_LAUNCH;
-  hipLaunchKernelGGL(gso_structure_kernel, dim3(B), dim3(1024), lds, st, masks, inst_tot, rowptr, colidx, cscptr, cscsrc,
-                     cscpos, cap, nnz_dev, B, N, W64);
+  if (phase != 2) {
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    if (s_is_f64)
+      hipLaunchKernelGGL(gso_mask_kernel<double>, dim3(blocks), dim3(256), 0, st, static_cast<double*>(S), masks, rowdeg,
+                         N, W64, rows, scrub_nan, gso_mode, edge_rule);
+    else if (MAGAT_GSO_X4 && N % 4 == 0 && !(reinterpret_cast<uintptr_t>(S) & 15))
+      hipLaunchKernelGGL(gso_mask_x4_kernel, dim3(blocks), dim3(256), 0, st, static_cast<float*>(S), masks, rowdeg, N, W64,
+                         rows, scrub_nan, gso_mode, edge_rule);
+    else
+      hipLaunchKernelGGL(gso_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<float*>(S), masks, rowdeg, N,
+                         W64, rows, scrub_nan, gso_mode, edge_rule);
+    hipLaunchKernelGGL(gso_totals_kernel, dim3(B), dim3(256), 0, st, rowdeg, inst_tot, N);
+  }
+  if (phase != 1) {
+    if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&gso_structure_kernel), MAGAT_LDS_GSO_STRUCT, lds) != MAGAT_OK)
+      return MAGAT_ERR_LAUNCH;
+    hipLaunchKernelGGL(gso_structure_kernel, dim3(B), dim3(1024), lds, st, masks, inst_tot, rowptr, colidx, cscptr, cscsrc,
+                       cscpos, cap, nnz_dev, B, N, W64);
+  }
   magat_prof_end(pid, st);
   return magat_check_launch();
+}
+
+extern "C" int magat_gso_csr_build(void* S, int s_is_f64, int scrub_nan, int gso_mode, int edge_rule, int* rowptr,
+                                   int* colidx, int* cscptr, int* cscsrc, int* cscpos, long long cap, long long* nnz_dev,
+                                   void* workspace, size_t workspace_bytes, int B, int N, void* stream) {
+  return magat_gso_csr_build_phase(S, s_is_f64, scrub_nan, gso_mode, edge_rule, rowptr, colidx, cscptr, cscsrc, cscpos, cap,
+                                   nnz_dev, workspace, workspace_bytes, B, N, 0, stream);
 }
 
 // forward with the CSC view made by magat_gso_csr_build (skips the per-call transpose)

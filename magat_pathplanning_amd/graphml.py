@@ -157,19 +157,32 @@ class CsrStructure:
                 self.side.wait_stream(cur)
             with torch.cuda.stream(run):
                 self._alloc(B, N, cap, dev)          # (allocated under the stream that writes them)
-                nat.check(lib.magat_gso_csr_build(
-                    nat.ptr(S3), 1 if S3.dtype == torch.float64 else 0, int(scrub_nan), int(gso_mode), int(rule),
-                    nat.ptr(self.rowptr), nat.ptr(self.colidx), nat.ptr(self.cscptr), nat.ptr(self.csc[0]),
-                    nat.ptr(self.csc[1]), self.cap, nat.ptr(self.nnz_dev), nat.ptr(self.ws), self.ws.numel(), B, N,
-                    nat.current_stream(dev)), "magat_gso_csr_build")
+                rewrites = bool(scrub_nan or gso_mode)
+
+                def phase(ph):
+                    nat.check(lib.magat_gso_csr_build_phase(
+                        nat.ptr(S3), 1 if S3.dtype == torch.float64 else 0, int(scrub_nan), int(gso_mode), int(rule),
+                        nat.ptr(self.rowptr), nat.ptr(self.colidx), nat.ptr(self.cscptr), nat.ptr(self.csc[0]),
+                        nat.ptr(self.csc[1]), self.cap, nat.ptr(self.nnz_dev), nat.ptr(self.ws), self.ws.numel(), B, N,
+                        ph, nat.current_stream(dev)), "magat_gso_csr_build_phase")
+
+                scrubbed = None
+                if side and rewrites:
+                    phase(1)                         # the streaming pass over S: the only part that writes S
+                    scrubbed = run.record_event()
+                    phase(2)
+                else:
+                    phase(0)
                 self.nnz_host.copy_(self.nnz_dev, non_blocking=True)
                 self.event = run.record_event()
             if side:
                 S3.record_stream(self.side)
                 for t in (self.rowptr, self.colidx, self.cscptr, self.csc, self.nnz_dev, self.ws):
                     t.record_stream(cur)             # (read by the layer's kernels on the caller's stream)
-                if scrub_nan or gso_mode:
-                    cur.wait_event(self.event)       # S is being rewritten: nothing of the caller's may read it earlier
+                if scrubbed is not None:
+                    # S is being rewritten: nothing of the caller's may read it earlier.  Only the streaming pass writes S, so the
+                    # caller's stream (next: the per-agent CNN) waits for THAT, and the structure kernel runs beside the CNN
+                    cur.wait_event(scrubbed)
         self.key = (S3.data_ptr(), B, N, S3.dtype, int(rule), str(dev))
         self.args = (S3, rule, scrub_nan, gso_mode)
         self.nnz = None

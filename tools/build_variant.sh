@@ -6,7 +6,7 @@ NAME=$1; SRC=$2; FLAGS=$3
 R=$(cd "$(dirname "$0")/.." && pwd)
 L=$R/magat_pathplanning_amd/lib
 mkdir -p $L/obj_$NAME
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -Wno-inline-asm $FLAGS \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -Wno-inline-asm $( [ "$SRC" == block_fused.hip ] && echo "-mllvm -amdgpu-mfma-vgpr-form" ) $FLAGS \
   -c $R/magat_pathplanning_amd/csrc/$SRC -o $L/obj_$NAME/${SRC%.hip}.o
 OBJS=""
 for o in $L/obj/*.o; do
