@@ -465,12 +465,14 @@ int magat_encoder_calibrate_f32(const magat_encoder_desc* desc_host, const float
  * value, fp32 accumulate: as accurate as the fp32 MFMA kernel while every activation stays within +-65504; the fused stem
  * carries its output 16x and needs it below 4094).  Whether a forward stayed inside is checked ON THE DEVICE: every kernel
  * that forms planes ORs a flag when it had to clamp, and the encoder then re-runs itself on the float32 MFMA kernels in
- * the same stream, predicated on that flag (about ten launches that return immediately when the flag is clear), so feat /
- * comp are fp32-class either way.  The first 256 bytes of `workspace` are the status block, which the caller zeroes ONCE,
+ * the same stream, predicated on that flag (two launches that return immediately when the flag is clear: the stem, and every
+ * layer behind it chained in one kernel whose last workgroup also does the flag's bookkeeping), so feat / comp are fp32-class
+ * either way.  The first 256 bytes of `workspace` are the status block, which the caller zeroes ONCE,
  * when it allocates the workspace (the library keeps its working flag there, clear between forwards).
  * magat_encoder_read_status copies two words to the host: status_host[0] = 1 if the LAST forward clamped and was re-run in
  * float32, status_host[1] = number of re-run forwards since the block was zeroed; it is the one call that synchronises
- * `stream`.  Cost of the guard when nothing clamps: ~12 launches that return at once, 1-1.5 % of a c3 step (measured). */
+ * `stream`.  Cost of the guard when nothing clamps: the two launches above plus two for the graph layer's re-run, ~20 us of a
+ * 2.6 ms c3 step (measured).  The block's words [0..2] and [6] are the library's, [4] is the graph layer's input scale. */
 size_t magat_encoder_workspace_bytes(const magat_encoder_desc* desc_host, int M);
 int magat_encoder_read_status(const void* workspace, int32_t status_host[2], void* stream);
 int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* x /*M,3,H,W*/,

@@ -361,10 +361,14 @@ struct ConvChain {
   ConvGemmParams L[CHAIN_MAX];
   int n, Mt;
   const int* run_if;
+  int* book;            // range-guard bookkeeping by the last workgroup (magat_guard_book), or null
 };
 
 __global__ __launch_bounds__(256) void conv_gemm_chain_kernel(const ConvChain c) {
-  if (c.run_if && *c.run_if == 0) return;
+  if (c.run_if && *c.run_if == 0) {
+    if (c.book) magat_guard_book(c.book);
+    return;
+  }
   for (int mt = blockIdx.x; mt < c.Mt; mt += gridDim.x) {
 #pragma unroll 1
     for (int l = 0; l < c.n; ++l) {
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(256) void conv_gemm_chain_kernel(const ConvChain c)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... and the next layer's loads come from L2
     }
   }
+  if (c.book) magat_guard_book(c.book);
 }
 
 int conv_variant() { return magat_opt(MAGAT_OPT_CONV_VARIANT); }
@@ -501,10 +506,12 @@ extern "C" int magat_linear_tagged_f32(const float* x, int ldx, const float* w, 
 
 // float32 layers chained in one launch (see conv_gemm_chain_kernel): descs[0..n) must share M, every layer reads only what
 // earlier layers of the list (or earlier launches) wrote for the SAME agents; run_if as in magat_conv_gemm_desc.
-int magat_conv_gemm_chain_f32(const magat_conv_gemm_desc* descs, int n, const int32_t* run_if, int tag, hipStream_t st) {
+int magat_conv_gemm_chain_f32(const magat_conv_gemm_desc* descs, int n, const int32_t* run_if, int tag, hipStream_t st,
+                              int32_t* book) {
   if (!descs || n <= 0 || n > CHAIN_MAX) return MAGAT_ERR_BAD_SHAPE;
   ConvChain c;
   c.n = n;
+  c.book = reinterpret_cast<int*>(book);
   c.run_if = reinterpret_cast<const int*>(run_if);
   for (int l = 0; l < n; ++l) {
     if (descs[l].in_fmt != 0 || descs[l].out_fmt != 0 || descs[l].in_gl || descs[l].out_gl || descs[l].out_ntile_stride ||

@@ -332,7 +332,7 @@ static int enc_linear(const float* x, int ldx, const float* w, const float* b, f
 // re-run (every launch of the pass returns immediately unless *run_if != 0; only valid with split == 0).
 static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* feat, int ldfeat, float* comp, int ldcomp,
                           float* bufbase, int M, void* stream, int split, int32_t* range_flag, const int32_t* run_if,
-                          float* absmax = nullptr) {
+                          float* absmax = nullptr, int32_t* book = nullptr, bool* booked = nullptr) {
   const int H = d->H, W = d->W;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int mc = enc_chunk_agents(M);
@@ -551,8 +551,11 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
       if (rc != MAGAT_OK) return rc;
     }
     if (nchain > 0) {
-      rc = magat_conv_gemm_chain_f32(chain, nchain, run_if, MAGAT_TAG_UNTAGGED, st);
+      // (the last chunk's chained launch is the last reader of the guard's flag: its last workgroup does the bookkeeping)
+      const bool last = book && m0 + mc >= M;
+      rc = magat_conv_gemm_chain_f32(chain, nchain, run_if, MAGAT_TAG_UNTAGGED, st, last ? book : nullptr);
       if (rc != MAGAT_OK) return rc;
+      if (last && booked) *booked = true;
     }
   }
   return MAGAT_OK;
@@ -639,8 +642,9 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   int rc = enc_run_resnet(d, x, feat, ldfeat, comp, ldcomp, bufbase, M, stream, split, guard ? status : nullptr, nullptr);
   if (rc != MAGAT_OK || !guard) return rc;
   const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);
-  rc = enc_run_resnet(d, x, feat, ldfeat, comp, ldcomp, bufbase, M, stream, 0, nullptr, status);
-  if (rc == MAGAT_OK) {
+  bool booked = false;
+  rc = enc_run_resnet(d, x, feat, ldfeat, comp, ldcomp, bufbase, M, stream, 0, nullptr, status, nullptr, status, &booked);
+  if (rc == MAGAT_OK && !booked) {
     hipLaunchKernelGGL(guard_count_kernel, dim3(1), dim3(1), 0, st, status);
     if (hipGetLastError() != hipSuccess) rc = MAGAT_ERR_LAUNCH;
   }

@@ -59,6 +59,7 @@ struct GatParams {
   int hpb;                       // heads per workgroup (1, or P: the workgroup walks all heads of its instance and
                                  // loads the next head's Q tile while the current head computes)
   const int* run_if;             // when set: the launch is a no-op unless *run_if != 0 (range-guard re-run of gat_mfma.hip)
+  int* book;                     // when set: this launch is the last reader of the guard's flag (magat_guard_book)
 };
 
 // diag: 1 on the diagonal when the mode adds self-loops (GAT_origin: S.float() + I, graphML.py:1018)
@@ -100,8 +101,10 @@ __global__ void gat_dense_kernel(const GatParams p) {
   const int bl0 = xcd + MAGAT_NUM_XCD * (slot / hgroups);
   const int istride = MAGAT_NUM_XCD * ((int)gridDim.x / MAGAT_NUM_XCD / hgroups);
   const int head0 = (slot % hgroups) * hpb;
-  if (bl0 >= p.B) return;
-  if (p.run_if && *p.run_if == 0) return;
+  if (bl0 >= p.B || (p.run_if && *p.run_if == 0)) {
+    if (p.book) magat_guard_book(p.book);
+    return;
+  }
 
   float* R0 = smem;                      // Q_p, later hop buffer
   float* R1 = R0 + N * RW;               // X_b during the score phase, then U_{K-1} / hop buffer
@@ -720,12 +723,16 @@ __global__ void gat_dense_kernel(const GatParams p) {
     __syncthreads();
     if (t == 0) { dbg[6] = clock64(); dbg[7] = wall_clock64(); }
   }
+  if (p.book) magat_guard_book(p.book);
 }
 
 // mean over heads then ReLU (graphML.py:4663-4667)
 __global__ void head_mean_relu_kernel(const float* __restrict__ ytmp, float* __restrict__ y, long long M, int P,
-                                      int F, int ldy, const int* __restrict__ run_if) {
-  if (run_if && *run_if == 0) return;
+                                      int F, int ldy, const int* __restrict__ run_if, int* book) {
+  if (run_if && *run_if == 0) {
+    if (book) magat_guard_book(book);
+    return;
+  }
   const int FC = F / 4;
   const long long total = M * FC;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -738,6 +745,7 @@ __global__ void head_mean_relu_kernel(const float* __restrict__ ytmp, float* __r
     f32x4 r = {magat_relu(s[0] / fp), magat_relu(s[1] / fp), magat_relu(s[2] / fp), magat_relu(s[3] / fp)};
     *reinterpret_cast<f32x4*>(y + m * ldy + 4 * c) = r;
   }
+  if (book) magat_guard_book(book);
 }
 
 // ---- weight packing: Bt [NC][G] + column bias [NC]
@@ -1226,6 +1234,7 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
   p.order = nullptr;
   p.rmask_pre = nullptr;
   p.run_if = nullptr;
+  p.book = nullptr;
   p.dbg = g_gat_dbg;
   p.skip = 0;
 #ifdef MAGAT_DEBUG_HOOKS
@@ -1299,6 +1308,8 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
         p.order = reinterpret_cast<const int*>(base + magat_align_up((size_t)B * N * 4 * sizeof(unsigned), 256)) + B;
     }
     const int gtag = rerun_only ? MAGAT_TAG_RANGE_GUARD : MAGAT_TAG_GAT_GRAPH;
+    // the re-run's last launch does the guard's bookkeeping: the graph kernel of the last chunk, or the head-mean kernel
+    p.book = (rerun_only && b0 + chunk >= B && (concat || all_fused)) ? reinterpret_cast<int*>(status) : nullptr;
     switch (G) {
       case 16: rc = launch_gat<16, 16>(p, blocks, threads, lds, st, gtag); break;
       case 32: rc = launch_gat<32, 32>(p, blocks, threads, lds, st, gtag); break;
@@ -1314,16 +1325,12 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     long long blocks = (M * (F / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     const int pid = magat_prof_begin(rerun_only ? MAGAT_TAG_RANGE_GUARD : MAGAT_TAG_HEAD_MEAN, st);
-    hipLaunchKernelGGL(head_mean_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Ytmp, Y, M, P, F, ldy, p.run_if);
+    hipLaunchKernelGGL(head_mean_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Ytmp, Y, M, P, F, ldy, p.run_if,
+                       rerun_only ? reinterpret_cast<int*>(status) : nullptr);
     magat_prof_end(pid, st);
     if (magat_check_launch() != MAGAT_OK) return MAGAT_ERR_LAUNCH;
   }
-  if (rerun_only) {      // flag -> status[2], re-run count, flag cleared (after the predicated launches have read it)
-    const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);
-    hipLaunchKernelGGL(gat_guard_count_kernel, dim3(1), dim3(1), 0, st, status);
-    magat_prof_end(pid, st);
-    return magat_check_launch();
-  }
+  // (flag -> status[2], re-run count, flag cleared: done by the last workgroup of the re-run's last launch, magat_guard_book)
   return MAGAT_OK;
 }
 

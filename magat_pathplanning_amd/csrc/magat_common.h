@@ -39,7 +39,8 @@ int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, l
                       hipStream_t st);
 int magat_conv_direct_enabled();   // f16x3 direct kernel on (option CONV_DIRECT, default 1)
 // float32 layers of one agent range chained in ONE launch (conv_gemm_f32.hip; the range guard's re-run)
-int magat_conv_gemm_chain_f32(const magat_conv_gemm_desc* descs, int n, const int32_t* run_if, int tag, hipStream_t st);
+int magat_conv_gemm_chain_f32(const magat_conv_gemm_desc* descs, int n, const int32_t* run_if, int tag, hipStream_t st,
+                              int32_t* book = nullptr);
 
 // Library options (options.hip): read from the environment (MAGAT_<NAME>) ONCE, changed at run time through
 // magat_set_option - nothing on the launch path calls getenv.
@@ -103,6 +104,25 @@ __device__ __forceinline__ float magat_bf16_f32(unsigned short h) { return __bui
 // ReLU of the float32 kernels: hands a NaN on like torch.relu does (fmaxf(NaN, 0) would turn it into 0) - the range guard
 // sends non-finite inputs to these kernels so that they reach the logits as they do in the reference
 __device__ __forceinline__ float magat_relu(float v) { return v < 0.f ? 0.f : v; }
+
+// Range-guard bookkeeping without a launch of its own: the LAST predicated launch that reads a forward's flag calls this from
+// every workgroup after its last read of book[0] (also on its early-exit paths); the workgroup that arrives last moves the
+// flag to book[2], counts the re-run in book[1] and clears book[0] for the next forward (book[6]: arrival counter, zero
+// between launches).  Block-uniform call sites only.
+__device__ __forceinline__ void magat_guard_book(int* book) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned prev = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(book) + 6, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == total - 1) {
+      const int f = book[0];
+      book[2] = f;
+      if (f != 0) book[1] += 1;
+      book[0] = 0;
+      book[6] = 0;
+    }
+  }
+}
 
 static inline int magat_check_launch() {
   return hipGetLastError() == hipSuccess ? MAGAT_OK : MAGAT_ERR_LAUNCH;
