@@ -290,6 +290,13 @@ int magat_gat_forward_csc_bf16(const uint16_t* X, const int* rowptr, const int* 
                                const int* cscsrc, const int* cscpos, long long nnz, const float* packed, const float* bias,
                                uint16_t* Y, int ldy, float* att_opt, void* workspace, size_t workspace_bytes, int B, int N,
                                int G, int F, int K, int P, int mode, int concat, void* stream);
+/* ... and with the RESULT widened to float32 by the kernel that writes it: Y [B*N][ldy] floats holding the bf16-rounded
+ * values the call above stores (bit-identical after a cast), without the caller's bf16 -> float32 pass over Y */
+int magat_gat_forward_csc_bf16_f32out(const uint16_t* X, const int* rowptr, const int* colidx, const int* cscptr,
+                                      const int* cscsrc, const int* cscpos, long long nnz, const float* packed,
+                                      const float* bias, float* Y, int ldy, float* att_opt, void* workspace,
+                                      size_t workspace_bytes, int B, int N, int G, int F, int K, int P, int mode, int concat,
+                                      void* stream);
 
 /* dense GSO -> CSR in two steps (the caller prefix-sums the degrees in between): per-row edge counts, then column fill */
 int magat_gso_row_degrees(const void* S, int s_is_f64, int self_loops /*edge rule: 0 |S|>1e-9, 1 GAT_origin |float(S)+I|>1e-9, 2 float(S)!=0*/, int* deg /*B*N*/, int B,

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "magat_gso_csr_build_phase": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, ctypes.c_longlong, _P, _P, _Z, _I, _I, _I, _P]),
     "magat_gat_forward_csc_f32": (_I, [_P] * 6 + [ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_forward_csc_bf16": (_I, [_P] * 6 + [ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
+    "magat_gat_forward_csc_bf16_f32out": (_I, [_P] * 6 + [ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_cast_rows": (_I, [_P, _P, _I, ctypes.c_longlong, _I, _I, _I, _P]),
     "magat_gso_row_degrees": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "magat_gso_fill_csr": (_I, [_P, _I, _I, _P, _P, _I, _I, _P]),

@@ -68,7 +68,22 @@ struct CsrParams {
   int told_ld, told_head_stride;   // addressing of Told rows: Told + told_off + (b*N+i)*told_ld + head*told_head_stride
   int last;
   int act_relu;           // apply ReLU in the last hop's store (inference); 0 in training (autograd owns it)
+  int y_f32;              // bf16 storage only: Y is a float32 buffer - the last store widens the bf16-ROUNDED result (the values
+                          // a bf16 Y would hold; saves the caller's cast kernel)
 };
+
+// the layer's result rows: ST, or (bf16 storage, y_f32) the same rounded values as float32
+template <int V, typename ST>
+__device__ __forceinline__ void store_y(void* Y, int y_f32, long long off, const float (&o)[V]) {
+  if (sizeof(ST) == 2 && y_f32) {
+    float r[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) r[c] = __builtin_bit_cast(float, (unsigned)magat_bf16_rne(o[c]) << 16);
+    store_vec<V, float>(static_cast<float*>(Y) + off, r);
+  } else {
+    store_vec<V, ST>(static_cast<ST*>(Y) + off, o);
+  }
+}
 
 // ---- 1. CSR -> CSC (per instance), deterministic: counting sort + per-column insertion sort by source
 __global__ __launch_bounds__(256) void csr_transpose_kernel(const int* __restrict__ rowptr,
@@ -282,7 +297,7 @@ __global__ __launch_bounds__(256) void csr_hop_kernel(const CsrParams p) {
 #pragma unroll
       for (int c = 0; c < VEC; ++c) acc[c] = magat_relu(acc[c]);
     }
-    store_vec<VEC, ST>(static_cast<ST*>(p.Y) + ((long long)b * N + j) * p.ldy + head * F + VEC * lane, acc);
+    store_y<VEC, ST>(p.Y, p.y_f32, ((long long)b * N + j) * p.ldy + head * F + VEC * lane, acc);
   } else {
     store_vec<VEC, ST>(static_cast<ST*>(p.Tnew) + (((long long)b * N + j) * p.P + head) * F + VEC * lane, acc);
   }
@@ -305,7 +320,7 @@ __global__ void csr_k1_kernel(const CsrParams p) {
       if (p.bias) v[q] += p.bias[4 * c + q];
       if (p.act_relu) v[q] = magat_relu(v[q]);
     }
-    store_vec<4, ST>(static_cast<ST*>(p.Y) + m * p.ldy + head * F + 4 * c, v);
+    store_y<4, ST>(p.Y, p.y_f32, m * p.ldy + head * F + 4 * c, v);
   }
 }
 
@@ -624,7 +639,7 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
 #pragma unroll
             for (int c = 0; c < E; ++c) acc[c] = magat_relu(acc[c]);
           }
-          store_vec<E, ST>(static_cast<ST*>(p.Y) + ((long long)b * N + j) * p.ldy + head * F + col, acc);
+          store_y<E, ST>(p.Y, p.y_f32, ((long long)b * N + j) * p.ldy + head * F + col, acc);
         } else {
           store_vec<E, ST>(static_cast<ST*>(p.Tnew) + (((long long)b * N + j) * p.P + head) * F + col, acc);
         }
@@ -692,8 +707,8 @@ int run_k1(const CsrParams& p, hipStream_t st) {
 }
 
 template <typename ST>
-__global__ void head_mean_relu_csr_kernel(const ST* __restrict__ ytmp, ST* __restrict__ y, long long M, int P,
-                                          int F, int ldy) {
+__global__ void head_mean_relu_csr_kernel(const ST* __restrict__ ytmp, void* __restrict__ y, long long M, int P,
+                                          int F, int ldy, int y_f32) {
   const int FC = F / 4;
   const long long total = M * FC;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -710,7 +725,7 @@ __global__ void head_mean_relu_csr_kernel(const ST* __restrict__ ytmp, ST* __res
     const float fp = (float)P;
 #pragma unroll
     for (int e = 0; e < 4; ++e) s[e] = magat_relu(s[e] / fp);
-    store_vec<4, ST>(y + m * ldy + 4 * c, s);
+    store_y<4, ST>(y, y_f32, m * ldy + 4 * c, s);
   }
 }
 
@@ -749,10 +764,10 @@ int csr_maps_gemm<u16>(const u16* X, const float* packed, u16* Z, int M, int G, 
 
 template <typename ST>
 int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz, const float* packed,
-                const float* bias, ST* Y, int ldy, float* att_opt, void* workspace, size_t workspace_bytes, int B,
+                const float* bias, void* Y, int ldy, float* att_opt, void* workspace, size_t workspace_bytes, int B,
                 int N, int G, int F, int K, int P, int mode, int concat, void* stream,
                 const float* edge_vals = nullptr, const int* pre_cscptr = nullptr, const int* pre_cscsrc = nullptr,
-                const int* pre_cscpos = nullptr) {
+                const int* pre_cscpos = nullptr, int y_f32 = 0) {
   if (!X || !rowptr || !packed || !Y || (nnz > 0 && !colidx)) return MAGAT_ERR_NULL;
   if (B <= 0 || N <= 0 || nnz < 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
   if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GNN) return MAGAT_ERR_UNSUPPORTED;
@@ -782,7 +797,8 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
 
   CsrParams p = {};
   p.X = X; p.Z = Z; p.rowptr = rowptr; p.colidx = colidx; p.cscptr = cscptr; p.cscsrc = cscsrc; p.cscpos = cscpos;
-  p.att = att; p.bias = bias; p.Y = concat ? Y : Ytmp; p.ldy = concat ? ldy : P * F;
+  p.att = att; p.bias = bias; p.Y = concat ? Y : static_cast<void*>(Ytmp); p.ldy = concat ? ldy : P * F;
+  p.y_f32 = concat ? y_f32 : 0;         // (the per-head rows of the mean form stay in the storage type)
   p.B = B; p.N = N; p.K = K; p.P = P; p.mode = mode; p.concat = concat; p.nnz = nnz;
   p.act_relu = gnn ? 0 : concat;        // GraphFilterBatch has no nonlinearity of its own
   p.NC = L.NC; p.qoff = L.qoff; p.uoff = L.uoff; p.c1off = L.c1off; p.c2off = L.c2off;
@@ -837,7 +853,8 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
     long long blocks = (M * (F / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     const int pid = magat_prof_begin(MAGAT_TAG_HEAD_MEAN, st);
-    hipLaunchKernelGGL((head_mean_relu_csr_kernel<ST>), dim3((unsigned)blocks), dim3(256), 0, st, Ytmp, Y, M, P, F, ldy);
+    hipLaunchKernelGGL((head_mean_relu_csr_kernel<ST>), dim3((unsigned)blocks), dim3(256), 0, st, Ytmp, Y, M, P, F, ldy,
+                       y_f32);
     magat_prof_end(pid, st);
     return magat_check_launch();
   }
@@ -1341,6 +1358,15 @@ extern "C" int magat_gat_forward_csc_bf16(const uint16_t* X, const int* rowptr, 
   if (!cscptr || !cscsrc || !cscpos) return MAGAT_ERR_NULL;
   return csr_forward<u16>(X, rowptr, colidx, nnz, packed, bias, Y, ldy, att_opt, workspace, workspace_bytes, B, N, G, F,
                           K, P, mode, concat, stream, nullptr, cscptr, cscsrc, cscpos);
+}
+extern "C" int magat_gat_forward_csc_bf16_f32out(const uint16_t* X, const int* rowptr, const int* colidx, const int* cscptr,
+                                                 const int* cscsrc, const int* cscpos, long long nnz, const float* packed,
+                                                 const float* bias, float* Y, int ldy, float* att_opt, void* workspace,
+                                                 size_t workspace_bytes, int B, int N, int G, int F, int K, int P, int mode,
+                                                 int concat, void* stream) {
+  if (!cscptr || !cscsrc || !cscpos) return MAGAT_ERR_NULL;
+  return csr_forward<u16>(X, rowptr, colidx, nnz, packed, bias, Y, ldy, att_opt, workspace, workspace_bytes, B, N, G, F,
+                          K, P, mode, concat, stream, nullptr, cscptr, cscsrc, cscpos, 1);
 }
 
 // =====================================================================================================

@@ -213,7 +213,8 @@ class CsrStructure:
 def gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=None, want_attention=False, csc=None):
     """CSR / large-graph form (any N).  X (B,N,G) device rows; rowptr int32 [B*(N+1)] absolute offsets; colidx int32.
     X float32 -> fp32 kernels; X bfloat16 -> the bf16-STORAGE kernels (BASELINE config 5: X, maps, hop states and the
-    result are bf16 in HBM, fp32 arithmetic; `out`, if given, must be bfloat16 too).  nnz: edge count, or any upper bound
+    result are bf16 in HBM, fp32 arithmetic; `out`, if given, is bfloat16 too - or, with the CSC view, float32: the last
+    kernel then stores the bf16-rounded result widened, the values a cast of the bf16 result would give).  nnz: edge count, or any upper bound
     the index arrays were allocated with (the kernels use it as a stride / for sizing only).  csc: optional
     (cscptr, cscsrc, cscpos) made by magat_gso_csr_build - skips the per-call transpose.
     Returns (out (B*N, ld), att (P, nnz) CSR-ordered fp32 attention or None)."""
@@ -241,14 +242,17 @@ def gat_forward_rows_csr(X, rowptr, colidx, nnz, layer, out=None, want_attention
         _workspace(sc, need, dev)
         if out is None:
             out = torch.empty(B * N, width, dtype=sdt, device=dev)
-        elif out.dtype != sdt:
+        elif out.dtype != sdt and not (bf16 and out.dtype == torch.float32 and csc is not None):
             raise TypeError("out must be %s for %s rows" % (sdt, X.dtype))
+        f32out = bf16 and out.dtype == torch.float32      # the last kernel widens the bf16-rounded result itself
         att = torch.empty(P, max(nnz, 1), dtype=torch.float32, device=dev) if want_attention else None
         bias = None if layer.bias is None else layer.bias.detach().to(dev, torch.float32).reshape(-1).contiguous()
         tail = (nnz, nat.ptr(packed), nat.ptr(bias), nat.ptr(out), out.stride(0), nat.ptr(att), nat.ptr(sc.workspace),
                 sc.workspace.numel(), B, N, G, F, K, P, mode, concat, stream)
         if csc is not None:
             fn = lib.magat_gat_forward_csc_bf16 if bf16 else lib.magat_gat_forward_csc_f32
+            if f32out:
+                fn = lib.magat_gat_forward_csc_bf16_f32out
             nat.check(fn(nat.ptr(X), nat.ptr(rowptr), nat.ptr(colidx), nat.ptr(csc[0]), nat.ptr(csc[1]), nat.ptr(csc[2]),
                          *tail), "magat_gat_forward_csc_%s" % ("bf16" if bf16 else "f32"))
         else:

@@ -467,12 +467,16 @@ class DecentralPlannerGATNet(nn.Module):
                 # bf16 storage inside the GAT layer (config.gat_storage='bf16', BASELINE config 5): the layer reads
                 # and writes bf16 rows; the CNN/MLP GEMMs around it stay fp32
                 comp16 = self._buf16("comp16", (M, G), dev)
-                gat16 = self._buf16("gat16", (M, self.gat_width), dev)
                 nat.check(lib.magat_cast_rows(nat.ptr(comp), nat.ptr(comp16), 1, M, G, G, G, stream), "magat_cast_rows")
-                _, aij = gat_forward_rows(comp16.view(B, N, G), self.S, layer, out=gat16, want_attention=want_att,
-                                          csr=rt.csr)
-                nat.check(lib.magat_cast_rows(nat.ptr(gat16), nat.ptr(gat), 0, M, self.gat_width, self.gat_width,
-                                              self.gat_width, stream), "magat_cast_rows")
+                if CsrStructure.supported(B, N):
+                    # (device-built CSR + CSC structure: the layer's last kernel stores the bf16-rounded rows as float32 itself)
+                    _, aij = gat_forward_rows(comp16.view(B, N, G), self.S, layer, out=gat, want_attention=want_att, csr=rt.csr)
+                else:
+                    gat16 = self._buf16("gat16", (M, self.gat_width), dev)
+                    _, aij = gat_forward_rows(comp16.view(B, N, G), self.S, layer, out=gat16, want_attention=want_att,
+                                              csr=rt.csr)
+                    nat.check(lib.magat_cast_rows(nat.ptr(gat16), nat.ptr(gat), 0, M, self.gat_width, self.gat_width,
+                                                  self.gat_width, stream), "magat_cast_rows")
             else:
                 _, aij = gat_forward_rows(comp.view(B, N, G), self.S, layer, out=gat, want_attention=want_att,
                                           plan=rt.plan, csr=rt.csr)

@@ -159,6 +159,31 @@ def test_config5_layer_at_1000_agents(gpu_device, storage, tiled, libopt):
         assert err <= 2e-2 * scale
 
 
+@pytest.mark.parametrize("concat", [True, False])
+def test_bf16_storage_float32_result_is_the_cast_of_the_bf16_result(gpu_device, concat):
+    """magat_gat_forward_csc_bf16_f32out: the layer's last kernel widens its bf16-rounded rows itself - bit for bit the values
+    a bf16 result gives after a cast (the planner's bf16-storage branch uses it instead of a cast kernel)."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from magat_pathplanning_amd.graphml import CsrStructure, gat_forward_rows_csr
+    from magat_pathplanning_amd.synthetic import comm_gso
+    B, N = 3, 200
+    torch.manual_seed(4)
+    layer = GraphFilterBatchAttentional(G5, G5, K5, P5, attentionMode="KeyQuery", concatenate=concat).to(gpu_device).eval()
+    X = (torch.randn(B, N, G5, device=gpu_device) * 0.5).to(torch.bfloat16)
+    S = comm_gso(B, N, 40, seed=2).to(gpu_device)
+    st = CsrStructure().build(S, 0)
+    nnz = st.ready(gpu_device)
+    csc = (st.cscptr, st.csc[0], st.csc[1])
+    width = P5 * G5 if concat else G5
+    y16 = torch.empty(B * N, width, dtype=torch.bfloat16, device=gpu_device)
+    y32 = torch.full((B * N, width + 4), -7.0, dtype=torch.float32, device=gpu_device)      # (a wider buffer: ld > width)
+    gat_forward_rows_csr(X, st.rowptr, st.colidx, nnz, layer, out=y16, csc=csc)
+    gat_forward_rows_csr(X, st.rowptr, st.colidx, nnz, layer, out=y32, csc=csc)
+    assert torch.equal(y32[:, :width].cpu(), y16.float().cpu())
+    assert bool((y32[:, width:] == -7.0).all())
+    assert float(y16.float().abs().max()) > 0
+
+
 def test_config5_model_bf16_at_1000_agents(gpu_device):
     """The whole module at config 5's shape (B=2 instances of 1000 agents, K=2, P=4, gat_storage='bf16') against the fp32
     oracle: error reported and bounded, greedy actions agree; no host synchronisation between addGSO and the logits."""
