@@ -358,6 +358,43 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
         for (int c = 0; c < 4; ++c) bq[j][q][c] = p.bias ? p.bias[n + c] : 0.f;
       }
     }
+  if constexpr (NPL == 1 && TM == 2 && TN == 2) {
+    if (p.out_split == 2 && vec && (p.ldc & 7) == 0) {
+      // One bf16 plane, row-major (the maps of the bf16-storage graph layer: 393 MB per config-5 step): the accumulator layout
+      // gives a lane 8-byte pieces of ONE agent's row, i.e. a store instruction scatters 64 pieces over 32 rows 3 KB apart.
+      // Transposed through the (now idle) stages - 4 KB per wave and 32-agent pass, 16-byte units XOR-swizzled by the agent -
+      // every store instruction writes eight agents' 128-byte runs.
+      __syncthreads();                                   // every wave is done reading the stages
+      char* const wl = reinterpret_cast<char*>(lds) + wave * 4096;
+      const int fr = lane & 31, fh = lane >> 5;
+      u16* const outp = static_cast<u16*>(p.out) + (long long)pix * p.out_pix_stride + n0 + wn * WTN;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[c] = acc[i][j][4 * q + c] + bq[j][q][c];
+              if (p.relu) v[c] = magat_relu(v[c]);
+            }
+            const int u = j * 4 + q;                     // 16-byte unit of channels 32 j + 8 q .. + 7 (this lane: half fh)
+            *reinterpret_cast<uint2*>(wl + fr * 128 + ((u ^ (fr & 7)) << 4) + 8 * fh) =
+                uint2{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+          }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const int r = st * 8 + (lane >> 3), u = lane & 7;
+          const uint4 v = *reinterpret_cast<const uint4*>(wl + r * 128 + ((u ^ (r & 7)) << 4));
+          const int m = m0 + wm * WTM + i * 32 + r;
+          if (m < p.M) *reinterpret_cast<uint4*>(outp + magat_row_off(m, p.ldc, p.out_tile) + 8 * u) = v;
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nb = n0 + wn * WTN + j * 32 + 4 * (lane >> 5);
