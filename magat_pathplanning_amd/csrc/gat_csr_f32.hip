@@ -485,9 +485,14 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
     Row cur, nxt;
     if (RPS * wave < N) fetch(RPS * wave, cur);           // in flight together with the slice
     if (h > 0) __syncthreads();                       // every wave is done with the previous slice
+#ifndef CSR_WHATIF_NODMA      // (timing experiments, tools/csr_layer_bench.py: wrong results)
     tile_dma<ST, LPR>(tile, Zb + h * FPP, p.NC, N, t);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef CSR_WHATIF_NOLOOP
+    if (p.N > 0) continue;
+#endif
     for (int ib = RPS * wave; ib < N; ib += rstep) {
       if (ib + rstep < N) fetch(ib + rstep, nxt);
       const int e0 = cur.e0, deg = cur.deg;
@@ -521,11 +526,23 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
           db = grp_sum<LPR>(db);
           if (es == k && va) mine[r] = da;
           if (es == k + 1 && vb) mine[r] = db;
-          if (last) {
-            if (va) online(da);
-            if (vb) online(db);
-          }
         }
+      }
+      // last pass: the row's softmax over the batched edges from their OWNERS' registers - one maximum and one sum over the
+      // 8-lane group (an owner has R candidates) instead of an online update per edge in every lane (two exponentials and a
+      // dependent chain per edge: the loop is bound by its vector instructions, not by latency - tools/csr_layer_bench.py)
+      if (last) {
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (es + LPR * r < deg) m = fmaxf(m, mine[r]);
+        m = LPR == 8 ? oct_max(m) : fmaxf(fmaxf(m, __shfl_xor(m, 1, 64)), fmaxf(__shfl_xor(m, 2, 64), __shfl_xor(m, 3, 64)));
+        float sl = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (es + LPR * r < deg) sl += __expf(mine[r] - m);
+        sum = grp_sum<LPR>(sl);
+        mx = m;                                           // (rows without edges: -inf and 0, as the online form leaves them)
       }
       // rows with more than 8 R edges: the rest one by one, owner = lane 0 (dependent loads: rare)
       for (int k = LPR * R; k < deg; ++k) {
@@ -597,9 +614,14 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
     Row cur, nxt;
     if (RPS * wave < N) fetch(RPS * wave, cur);
     if (h > 0) __syncthreads();
+#ifndef CSR_WHATIF_NODMA
     tile_dma<ST, LPR>(tile, Tb + h * FPP, p.told_ld, N, t);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef CSR_WHATIF_NOLOOP
+    if (p.N > 0) continue;
+#endif
     for (int jb = RPS * wave; jb < N; jb += rstep) {
       if (jb + rstep < N) fetch(jb + rstep, nxt);
       const int j = jb + eg, deg = cur.deg;

@@ -1,7 +1,8 @@
 """Times the two halves of magat_gso_csr_build at a given shape (default BASELINE config 5: 128 x 1000 x 1000 float32):
 phase 1 = the streaming pass over S (scrub + bit matrix + totals), phase 2 = the structure kernel.  MAGAT_LIB_PATH picks a build."""
 import sys, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from magat_pathplanning_amd import _native as nat
 from magat_pathplanning_amd.graphml import CsrStructure
 from magat_pathplanning_amd.synthetic import comm_gso
