@@ -152,7 +152,8 @@ def kernel_work(nat, cfg, N, S_bytes, deg=None, planned=False, fused_stem=True, 
                               bytes=es * (G + P * G + P * K * F + yw) + 4 * (2 + 3 * deg) + 4 * P * deg * K)
         w["gat_maps_gemm"]["bytes"] = es * (G + NC)
     width = yw + (nfm if cfg.bottleneckMode == "BottomNeck_skipConcat" else 0)
-    w["actionsMLP"] = dict(flops=2 * width * 5, bytes=4 * (width + 5), arith="f32")
+    # the action head (width -> 5) runs as streamed float32 dot products (vector FMAs, option SKINNY): bound by its bytes
+    w["actionsMLP"] = dict(flops=2 * width * 5, bytes=4 * (width + 5), arith=None if lib_opt(nat, "SKINNY") else "f32")
     return w
 
 

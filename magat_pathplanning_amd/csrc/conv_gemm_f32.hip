@@ -425,6 +425,120 @@ int launch(ConvGemmParams& p, hipStream_t st) {
 
 }  // namespace
 
+// ---- skinny layers (the action head: 640 -> 5 at c3): a GEMM whose output is a handful of columns is a stream of dot products -
+// the 32-column MFMA tile spends 27 of its 32 columns on padding and the kernel ran at 0.4-0.6 of the HBM roof.  Here 16 lanes own
+// a row: every lane takes the 16-byte chunks l, l + 16, ... of the row (in, then in2), all of a batch in flight before the first
+// is used, multiplies them with the CO weight rows out of LDS ([chunk][CO] float4s: one row's chunk for every output is one
+// contiguous run) in float32 FMAs, and the 16 partial sums meet in a DPP row reduction.  Summation order is fixed (chunk order
+// inside a lane, then the reduction tree): bit-identical from run to run.
+namespace {
+struct SkinnyParams {
+  const float* in;
+  const float* in2;
+  const float* wt;     // [CO][Ktot]
+  const float* bias;
+  float* out;
+  int M, Cin, C2, lda, lda2, ldc, relu;
+};
+#ifdef SKINNY_BATCH_OVERRIDE
+constexpr int SKINNY_BATCH = SKINNY_BATCH_OVERRIDE;
+#else
+constexpr int SKINNY_BATCH = 8;      // chunks per lane in flight
+#endif
+template <int CO>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyParams p) {
+  extern __shared__ __align__(16) float sk_w[];      // [Ktot / 4][CO][4]
+  const int q1 = p.Cin >> 2, nq = q1 + (p.C2 >> 2), Ktot = 4 * nq;
+  for (int idx = threadIdx.x; idx < nq * CO; idx += 256) {
+    const int q = idx / CO, c = idx - q * CO;
+    *reinterpret_cast<f32x4*>(sk_w + (size_t)idx * 4) = *reinterpret_cast<const f32x4*>(p.wt + (size_t)c * Ktot + 4 * q);
+  }
+  __syncthreads();
+  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;      // 16 rows per workgroup step
+  float bv[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) bv[c] = p.bias ? p.bias[c] : 0.f;
+  for (long long m0 = (long long)blockIdx.x * 16; m0 < p.M; m0 += (long long)gridDim.x * 16) {
+    const long long m = m0 + grp;
+    const bool ok = m < p.M;
+    const long long mr = ok ? m : p.M - 1;
+    const float* r1 = p.in + mr * p.lda;
+    const float* r2 = p.in2 ? p.in2 + mr * p.lda2 - 4 * q1 : r1;      // (chunk q >= q1 lives at r2 + 4 q)
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    for (int qb = l16; qb < nq; qb += 16 * SKINNY_BATCH) {
+      f32x4 x[SKINNY_BATCH];
+#pragma unroll
+      for (int j = 0; j < SKINNY_BATCH; ++j) {
+        const int q = qb + 16 * j;
+        const int qc = q < nq ? q : l16;      // (past the row: chunk l16 again, dropped below)
+        x[j] = *reinterpret_cast<const f32x4*>((qc < q1 ? r1 : r2) + 4 * qc);
+      }
+#pragma unroll
+      for (int j = 0; j < SKINNY_BATCH; ++j) {
+        const int q = qb + 16 * j;
+        if (q < nq) {
+#pragma unroll
+          for (int c = 0; c < CO; ++c) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(sk_w + ((size_t)q * CO + c) * 4);
+            acc[c] = __builtin_fmaf(x[j][3], w[3], __builtin_fmaf(x[j][2], w[2], __builtin_fmaf(x[j][1], w[1],
+                     __builtin_fmaf(x[j][0], w[0], acc[c]))));
+          }
+        }
+      }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      const float s = row16_sum(acc[c]) + bv[c];
+      if (l16 == c) mine = s;
+    }
+    if (ok && l16 < CO) p.out[m * p.ldc + l16] = p.relu ? magat_relu(mine) : mine;
+  }
+}
+
+template <int CO>
+int skinny_launch(const SkinnyParams& p, int tag, hipStream_t st) {
+  const size_t lds = (size_t)(p.Cin + p.C2) * CO * sizeof(float);
+  if (lds > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  long long blocks = ((long long)p.M + 15) / 16;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  const int pid = magat_prof_begin(tag, st);
+  hipLaunchKernelGGL(skinny_gemm_kernel<CO>, dim3((unsigned)blocks), dim3(256), lds, st, p);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
+}
+
+// takes the layer when it is a plain row-major 1x1 product with at most 8 outputs; MAGAT_ERR_UNSUPPORTED = not this form
+int skinny_try(const magat_conv_gemm_desc* d, hipStream_t st) {
+  if (d->in_fmt != 0 || d->out_fmt != 0 || d->in_gl || d->out_gl || d->Cout > 8 || d->Cout < 1 || d->kH != 1 || d->kW != 1 ||
+      d->Hout != 1 || d->Wout != 1 || d->Hin != 1 || d->Win != 1 || d->pool || d->stride != 1 || d->pad != 0 || d->run_if ||
+      d->absmax || d->ldw || d->wt_pix_stride || d->in_tile_stride || d->in2_tile_stride || d->out_tile_stride ||
+      d->out_ntile_stride || d->in_pix_stride || d->in2_pix_stride || d->out_pix_stride || d->M < 4096 ||
+      !magat_opt(MAGAT_OPT_SKINNY))
+    return MAGAT_ERR_UNSUPPORTED;
+  if ((d->Cin & 3) || (d->C2 & 3) || (d->lda & 3) || (d->lda2 & 3) || d->lda < d->Cin || d->ldc < d->Cout || d->C2 < 0 ||
+      (d->C2 > 0 && (!d->in2 || d->lda2 < d->C2 || (d->W2 > 1) || d->stride2 > 1)) ||
+      ((reinterpret_cast<uintptr_t>(d->in) | reinterpret_cast<uintptr_t>(d->wt) | reinterpret_cast<uintptr_t>(d->in2)) & 15))
+    return MAGAT_ERR_UNSUPPORTED;
+  SkinnyParams p;
+  p.in = static_cast<const float*>(d->in); p.in2 = d->C2 > 0 ? static_cast<const float*>(d->in2) : nullptr;
+  p.wt = static_cast<const float*>(d->wt); p.bias = static_cast<const float*>(d->bias); p.out = static_cast<float*>(d->out);
+  p.M = d->M; p.Cin = d->Cin; p.C2 = d->C2; p.lda = d->lda; p.lda2 = d->lda2; p.ldc = d->ldc; p.relu = d->relu;
+  switch (d->Cout) {
+    case 1: return skinny_launch<1>(p, d->tag, st);
+    case 2: return skinny_launch<2>(p, d->tag, st);
+    case 3: return skinny_launch<3>(p, d->tag, st);
+    case 4: return skinny_launch<4>(p, d->tag, st);
+    case 5: return skinny_launch<5>(p, d->tag, st);
+    case 6: return skinny_launch<6>(p, d->tag, st);
+    case 7: return skinny_launch<7>(p, d->tag, st);
+    default: return skinny_launch<8>(p, d->tag, st);
+  }
+}
+}  // namespace
+
 // descriptor -> kernel parameters of the float32 kernel (shape checks included)
 static int conv_params_from_desc(const magat_conv_gemm_desc* d, ConvGemmParams& p) {
   if (!d || !d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
@@ -476,6 +590,10 @@ static int conv_params_from_desc(const magat_conv_gemm_desc* d, ConvGemmParams& 
 extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) {
   if (!d || !d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
   if (d->in_fmt >= 1 && d->in_fmt <= 5) return magat_conv_gemm_bf16x6(d, static_cast<hipStream_t>(stream));
+  {
+    const int src = skinny_try(d, static_cast<hipStream_t>(stream));
+    if (src != MAGAT_ERR_UNSUPPORTED) return src;
+  }
   ConvGemmParams p;
   const int prc = conv_params_from_desc(d, p);
   if (prc != MAGAT_OK) return prc;

@@ -39,6 +39,46 @@ def test_linear_f32(gpu_device, M, N, K, relu):
     np.testing.assert_allclose(y.cpu().numpy(), ref.float().numpy(), rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("M,K1,K2,N,relu", [(51200, 128, 512, 5, 0), (4099, 128, 0, 5, 1), (8192, 64, 36, 8, 0),
+                                            (5000, 132, 128, 1, 0), (100, 128, 512, 5, 0)])
+def test_skinny_layer_is_the_same_product(gpu_device, libopt, M, K1, K2, N, relu):
+    """The action head's form (a 1x1 float32 layer with at most 8 outputs over [in | in2]) as streamed dot products (option
+    SKINNY, from 4096 rows on): against float64, bit-identical from run to run, the padding of wider row buffers untouched,
+    and within float32 rounding of the MFMA-tile kernel it replaces (SKINNY=0)."""
+    nat, lib = _nat()
+    g = torch.Generator().manual_seed(M + K1 + K2 + N)
+    ld1, ld2, ldc = K1 + 4, K2 + 8, N + 3
+    x1 = torch.randn(M, ld1, generator=g).to(gpu_device)
+    x2 = torch.randn(M, max(ld2, 4), generator=g).to(gpu_device)
+    w = (torch.randn(N, K1 + K2, generator=g) / (K1 + K2) ** 0.5).to(gpu_device)
+    b = torch.randn(N, generator=g).to(gpu_device)
+    ref = torch.cat((x1[:, :K1], x2[:, :K2]), 1).double() @ w.double().t() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+
+    def run():
+        y = torch.full((M, ldc), -3.0, device=gpu_device)
+        d = nat.ConvGemmDesc()
+        d.inp, d.Cin, d.lda = x1.data_ptr(), K1, ld1
+        if K2:
+            d.in2, d.C2, d.lda2, d.W2, d.stride2 = x2.data_ptr(), K2, ld2, 1, 1
+        d.wt, d.bias, d.out = w.data_ptr(), b.data_ptr(), y.data_ptr()
+        d.M, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad, d.Hout, d.Wout = M, 1, 1, 1, 1, 1, 0, 1, 1
+        d.Cout, d.ldc, d.relu = N, ldc, relu
+        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "conv_gemm")
+        torch.cuda.synchronize()
+        return y
+
+    libopt.set("SKINNY", 1)
+    y1, y2 = run(), run()
+    libopt.set("SKINNY", 0)
+    y0 = run()
+    assert torch.equal(y1, y2)
+    assert bool((y1[:, N:] == -3.0).all())
+    np.testing.assert_allclose(y1[:, :N].cpu().numpy(), ref.float().cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(y1[:, :N].cpu().numpy(), y0[:, :N].cpu().numpy(), rtol=0, atol=2e-5)
+
+
 def _to_pixel_major(t):           # (M,C,H,W) -> [H*W][M][C]
     M, C, H, W = t.shape
     return t.permute(2, 3, 0, 1).reshape(H * W, M, C).contiguous()
