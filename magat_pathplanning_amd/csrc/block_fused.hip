@@ -299,6 +299,7 @@ struct L3Params {
   int M, groups;
   int* range_flag;
   long long* dbg;
+  int out_gl;             // block_full_p_kernel: 1 = the pooled map granule-major, [agent tile][cell 9][128 / 4][128 agents][4]
 };
 
 // row-tile groups of the conv2 waves: 33 + 36 tile-taps
@@ -1335,7 +1336,12 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
       // cells of this lane: its corner cell, the row-edge-middle cell it shares with the lane 8 away, the column-edge-middle
       // cell it shares with the lane 16 away, the centre cell (shared by all four slots)
       const int cellF = 2 * (int)lo + 6 * (int)hi, cell0 = hi ? 1 : 7, cell1 = lo ? 3 : 5;
-      float* ob = l3.out + (long long)(m >> 7) * 9 * (128 * 128) + (m & 127) * 128 + 32 * ct2 + 4 * fh;
+      // row-major tiles [cell][128 agents][128 channels], or granule-major ones [cell][32 granules][128 agents][4 channels]
+      // (magat_hip.h in_gl = 1: what the encoder head's loader reads as 512 contiguous bytes per half wave; here the eight
+      // agents of a group make one 128-byte run per store instead of eight 16-byte pieces 512 bytes apart)
+      float* ob = l3.out + (long long)(m >> 7) * 9 * (128 * 128) +
+                  (l3.out_gl ? (8 * ct2 + fh) * 512 + (m & 127) * 4 : (m & 127) * 128 + 32 * ct2 + 4 * fh);
+      const int qstep = l3.out_gl ? 1024 : 8;       // channel quads 2 qd (+ fh) of this wave's 32 channels
       const bool mok = m < p.M;
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
@@ -1356,10 +1362,10 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
           v2[c] = p2b + __shfl_xor(p2b, 16, 64);
         }
         if (mok) {
-          *reinterpret_cast<f32x4*>(ob + (long long)cellF * (128 * 128) + 8 * qd) = vF;
-          if (!lo) *reinterpret_cast<f32x4*>(ob + (long long)cell0 * (128 * 128) + 8 * qd) = v0;
-          if (!hi) *reinterpret_cast<f32x4*>(ob + (long long)cell1 * (128 * 128) + 8 * qd) = v1;
-          if (!lo && !hi) *reinterpret_cast<f32x4*>(ob + (long long)4 * (128 * 128) + 8 * qd) = v2;
+          *reinterpret_cast<f32x4*>(ob + (long long)cellF * (128 * 128) + qstep * qd) = vF;
+          if (!lo) *reinterpret_cast<f32x4*>(ob + (long long)cell0 * (128 * 128) + qstep * qd) = v0;
+          if (!hi) *reinterpret_cast<f32x4*>(ob + (long long)cell1 * (128 * 128) + qstep * qd) = v1;
+          if (!lo && !hi) *reinterpret_cast<f32x4*>(ob + (long long)4 * (128 * 128) + qstep * qd) = v2;
         }
       }
     }
@@ -1369,6 +1375,9 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
 }
 
 }  // namespace
+
+// 1 when magat_block_full can write its pooled map granule-major (out_gl = 1) with the current options
+int magat_block_full_out_gl() { return magat_opt(MAGAT_OPT_BLOCK_FULL) >= 2 ? 1 : 0; }
 
 // bytes of one stage's fragment-major weight block (without the trailing scale float)
 static size_t chain_block_bytes(int cin, int c2, int cout) { return (size_t)(cout / 32) * (9 * (cin / 16) + c2 / 16) * 2 * 1024; }
@@ -1478,7 +1487,7 @@ extern "C" int magat_block3_set_debug_buffer(long long* dev_buf) { g_block3_dbg 
 // its output) and of magat_block3 (without its input).
 int magat_block_full(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
                      float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st,
-                     const float* scales) {
+                     const float* scales, int out_gl) {
   if (!in1 || !in2 || !wchain || !bA || !bB || !bC || !out || !w3 || !b1 || !b2) return MAGAT_ERR_NULL;
   if (M <= 0) return MAGAT_ERR_BAD_SHAPE;
   FullParams q;
@@ -1511,6 +1520,8 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
   l.dbg = g_block3_dbg;
 #endif
   const bool pooled_regs = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 2;      // 2: pooling in registers (block_full_p_kernel)
+  if (out_gl != 0 && !(out_gl == 1 && pooled_regs)) return MAGAT_ERR_UNSUPPORTED;      // (magat_block_full_out_gl() tells)
+  l.out_gl = out_gl;
   if (magat_ensure_dyn_lds(pooled_regs ? reinterpret_cast<const void*>(&block_full_p_kernel)
                                        : reinterpret_cast<const void*>(&block_full_w4_kernel),
                            pooled_regs ? MAGAT_LDS_BLOCK_FULL_P : MAGAT_LDS_BLOCK_FULL, LDS_TOTAL) != MAGAT_OK)

@@ -1030,7 +1030,7 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
                              : reinterpret_cast<const float*>(reinterpret_cast<const char*>(d->wt) + (size_t)2 * p.Cout * p.Ktot * sizeof(u16));
   p.in_scale = d->in_scale;
   // (the activation scale lives in the direct kernel's float32 loader only)
-  if (d->in_scale && !(d->in_fmt == 4 && d->out_fmt == 0 && d->in_gl == 0 && magat_conv_direct_enabled())) return MAGAT_ERR_UNSUPPORTED;
+  if (d->in_scale && !(d->in_fmt == 4 && d->out_fmt == 0 && d->in_gl <= 1 && magat_conv_direct_enabled())) return MAGAT_ERR_UNSUPPORTED;
 #define MAGAT_SPLIT_LAUNCH(BNV, WM, WN)                                                                              \
   do {                                                                                                              \
     if (d->in_fmt == 3)                                                                                             \

@@ -403,11 +403,22 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // BasicBlock chain kernel (block_fused.hip): layer1.conv2+downsample -> layer2.conv1 -> layer2.conv2+downsample in one
     // launch with the 6x6 maps of an 8-agent group in LDS (3.35 GB of HBM traffic per 51 200 agents become 0.94 GB).
     // Needs the fused stem's plane-granule outputs; option BLOCK_FUSED=0 keeps the layer-by-layer kernels.
+    // The pooled map goes to the head granule-major ([cell][128 / 4][128 agents][4 floats]) when the head is the f16x3 direct
+    // GEMM: its loader then reads 512 contiguous bytes per half wave instead of 32 bytes out of every agent's 512-byte row, and
+    // the chain kernel stores 128-byte runs instead of 16-byte pieces.  (Not for the few-agent form of the head, which splits K
+    // by pooled cell on the float32 kernel; option HEAD_GL=0: row-major tiles.)
+    const int clast_ = shapes[nblocks - 1].cout;
+    const bool head_splitk = !absmax && !chained && mm <= magat_opt(MAGAT_OPT_HEAD_SPLITK) && (clast_ & 3) == 0 &&
+                             (d->n_feat & 3) == 0 && (size_t)9 * d->n_feat <= enc_buf_floats_per_agent(d);
+    const bool head_gl = full_path && !rerun && split && d->head16_off > 0 && (clast_ % 32) == 0 && (d->n_feat % 32) == 0 &&
+                         magat_opt(MAGAT_OPT_HEAD_F16) && magat_conv_direct_enabled() && !head_splitk &&
+                         magat_block_full_out_gl() && magat_opt(MAGAT_OPT_HEAD_GL);
     if (full_path) {
       // both chain kernels as ONE launch: layer2's output map stays in LDS as layer3's input
       rc = magat_block_full(buf[1], buf[0], pk + d->chain_off, sp ? sp + 928 : pk + d->off[5], sp ? sp + 960 : pk + d->off[7],
                             sp ? sp + 1024 : pk + d->off[9], buf[2], pk + d->chain3_off, sp ? sp + 1088 : pk + d->off[11],
-                            sp ? sp + 1216 : pk + d->off[13], mm, reinterpret_cast<int*>(range_flag), st, sp ? sp + 1344 : nullptr);
+                            sp ? sp + 1216 : pk + d->off[13], mm, reinterpret_cast<int*>(range_flag), st, sp ? sp + 1344 : nullptr,
+                            head_gl ? 1 : 0);
       if (rc != MAGAT_OK) return rc;
       cur = 2; hin = Ho; win = Wo; lstart = 3; pooled_in = true;
     } else if (fused1 && !mx && d->chain_off > 0 && Ho == 6 && Wo == 6 && nblocks >= 2 && magat_opt(MAGAT_OPT_BLOCK_FUSED)) {
@@ -520,6 +531,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
           magat_opt(MAGAT_OPT_HEAD_F16)) {
         g.in_fmt = 4; g.wt = pk + d->head16_off; g.range_flag = range_flag; g.run_if = nullptr;
         if (d->scaled_off > 0) g.in_scale = pk + d->scaled_off + 1349;
+        if (head_gl) g.in_gl = 1;
       }
       rc = g.in_fmt == 0 ? run_or_chain(g) : magat_conv_gemm_f32(&g, stream);
     }

@@ -31,7 +31,9 @@ size_t magat_block_chain_weight_floats();
 size_t magat_block3_weight_floats();
 int magat_block_full(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
                      float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st,
-                     const float* scales = nullptr);      // 5 device floats replacing the 1 / weight-scale of stages A, B, C, layer3.conv1, conv2
+                     const float* scales = nullptr,       // 5 device floats replacing the 1 / weight-scale of stages A, B, C, layer3.conv1, conv2
+                     int out_gl = 0);                     // 1: pooled map granule-major (when magat_block_full_out_gl())
+int magat_block_full_out_gl();
 int magat_block3(const void* in, float* out, const float* w, const float* b1, const float* b2, int M, int* range_flag,
                  hipStream_t st);
 int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, long long out_pix_stride, long long out_tile,
@@ -50,7 +52,7 @@ enum MagatOpt {
   MAGAT_OPT_L1_FUSED, MAGAT_OPT_HEAD_SPLITK, MAGAT_OPT_GAT_CHUNK_MB, MAGAT_OPT_GAT_ZPAD, MAGAT_OPT_GAT_SPLIT,
   MAGAT_OPT_GAT_HPB, MAGAT_OPT_GAT_ZTILES, MAGAT_OPT_GAT_PERSIST, MAGAT_OPT_RANGE_GUARD, MAGAT_OPT_BLOCK_FUSED,
   MAGAT_OPT_CSR_TILED, MAGAT_OPT_BLOCK3_FUSED,
-  MAGAT_OPT_HEAD_F16, MAGAT_OPT_BLOCK_FULL, MAGAT_OPT_GAT_MFMA, MAGAT_OPT_GUARD_CHAIN, MAGAT_OPT_SKINNY, MAGAT_OPT_COUNT
+  MAGAT_OPT_HEAD_F16, MAGAT_OPT_BLOCK_FULL, MAGAT_OPT_GAT_MFMA, MAGAT_OPT_GUARD_CHAIN, MAGAT_OPT_HEAD_GL, MAGAT_OPT_SKINNY, MAGAT_OPT_COUNT
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)

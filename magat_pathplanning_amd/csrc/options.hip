@@ -47,6 +47,7 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
                              // 2: the 2x2 pooling in registers (block_full_p_kernel), 1: through an LDS scratch (block_full_w4_kernel)
     {"GAT_MFMA", 1},         // KeyQuery layer with 128 features, N <= 101, K = 2 | 3 as ONE launch of matrix-core products (gat_mfma.hip)
     {"GUARD_CHAIN", 1},      // the range guard's float32 re-run of the encoder: every layer behind the stem in ONE predicated launch
+    {"HEAD_GL", 1},          // pooled map of the chain kernel granule-major for the f16x3 head (0: row-major agent tiles)
     {"SKINNY", 1},           // float32 1x1 layers with at most 8 outputs (the action head) as streamed dot products, not MFMA tiles
 };
 
