@@ -323,8 +323,25 @@ class DecentralPlannerGATNet(nn.Module):
     # ------------------------------------------------------------------ inference path (HIP)
     def _refresh(self, dev):
         rt = self._rt
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
-            tuple((b.data_ptr(), b._version) for b in self.buffers()) + (str(dev),)
+        # (address, version) of every parameter and buffer: an iterative walk over the module dicts - the closed-loop step of
+        # one planning instance is host-bound, and nn.Module.parameters() / buffers() (recursive generators with a memo
+        # set) were two thirds of this method's caller
+        key = [dev]
+        stack = [self]
+        while stack:
+            m = stack.pop()
+            for t in m._parameters.values():
+                if t is not None:
+                    key.append(t.data_ptr())
+                    key.append(t._version)
+            for t in m._buffers.values():
+                if t is not None:
+                    key.append(t.data_ptr())
+                    key.append(t._version)
+            for c in m._modules.values():
+                if c is not None:
+                    stack.append(c)
+        key = tuple(key)
         if rt.key == key:
             return rt
         sd = {k: v.detach() for k, v in self.state_dict().items()}
