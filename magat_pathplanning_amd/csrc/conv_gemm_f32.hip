@@ -515,7 +515,7 @@ int skinny_try(const magat_conv_gemm_desc* d, hipStream_t st) {
   if (d->in_fmt != 0 || d->out_fmt != 0 || d->in_gl || d->out_gl || d->Cout > 8 || d->Cout < 1 || d->kH != 1 || d->kW != 1 ||
       d->Hout != 1 || d->Wout != 1 || d->Hin != 1 || d->Win != 1 || d->pool || d->stride != 1 || d->pad != 0 || d->run_if ||
       d->absmax || d->ldw || d->wt_pix_stride || d->in_tile_stride || d->in2_tile_stride || d->out_tile_stride ||
-      d->out_ntile_stride || d->in_pix_stride || d->in2_pix_stride || d->out_pix_stride || d->M < 4096 ||
+      d->out_ntile_stride || d->in_pix_stride || d->in2_pix_stride || d->out_pix_stride || d->M < 1 ||
       !magat_opt(MAGAT_OPT_SKINNY))
     return MAGAT_ERR_UNSUPPORTED;
   if ((d->Cin & 3) || (d->C2 & 3) || (d->lda & 3) || (d->lda2 & 3) || d->lda < d->Cin || d->ldc < d->Cout || d->C2 < 0 ||

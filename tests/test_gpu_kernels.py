@@ -43,7 +43,7 @@ def test_linear_f32(gpu_device, M, N, K, relu):
                                             (5000, 132, 128, 1, 0), (100, 128, 512, 5, 0)])
 def test_skinny_layer_is_the_same_product(gpu_device, libopt, M, K1, K2, N, relu):
     """The action head's form (a 1x1 float32 layer with at most 8 outputs over [in | in2]) as streamed dot products (option
-    SKINNY, from 4096 rows on): against float64, bit-identical from run to run, the padding of wider row buffers untouched,
+    SKINNY): against float64, bit-identical from run to run, the padding of wider row buffers untouched,
     and within float32 rounding of the MFMA-tile kernel it replaces (SKINNY=0)."""
     nat, lib = _nat()
     g = torch.Generator().manual_seed(M + K1 + K2 + N)
