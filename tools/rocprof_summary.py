@@ -115,54 +115,47 @@ def main():
         for k, (n, tot) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
             lines.append("%-28s launches=%5d avg_KiB=%14.1f" % (k, n, tot / n))
             res["kernels"].setdefault(k, {})[ctr + "_KiB_per_launch"] = tot / n
-    # per-layer split: the library launches a fixed kernel sequence per addGSO+forward step (c3 workload, default options:
-    # fused stem, the chain kernels as one launch, the GAT layer as one launch, range guard on).  "guard:*" entries are the
-    # predicated float32 re-run launches of the range guard (no-ops while nothing clamps).
-    SEQ = ["conv_first+layer1.conv1 (fused)", "layer1.conv2+layer2+layer3 (fused, pooled)",
-           "head(avgpool+fc+linear)", "compressMLP",
-           "guard:conv_first", "guard:layer1.conv1", "guard:layer1.conv2", "guard:layer2.conv1", "guard:layer2.conv2",
-           "guard:layer3.conv1", "guard:layer3.conv2", "guard:head", "guard:compress", "guard:count",
-           "gat_layer (one launch)", "guard:gat_maps", "guard:gat_graph", "guard:gat_count", "actionsMLP"]
-    ours = ("conv_gemm_kernel", "conv_gemm_bf16x6_kernel", "conv_gemm_f16x3_direct_kernel", "conv_first_kernel",
-            "layer1_fused_kernel", "gat_dense_kernel", "block_chain_kernel", "block3_kernel", "block_chain_w4_kernel",
-            "block3_w4_kernel", "block_full_w4_kernel", "block_full_p_kernel", "guard_count_kernel", "gat_mfma_kernel")
+    # per-layer view, keyed like the bench line's kernel table: every kernel NAME that belongs to a tag, its launches taken
+    # in dispatch order and the LAST steps * (launches per step) of them kept - the warm-up steps in front also hold the
+    # one-off float32 calibration pass and the weight packing.  (A positional "launch i of the step" mapping, as rounds 1-2
+    # had it, silently mis-assigns everything behind the first launch the step gains or loses.)
+    TAGS = [("conv_first+layer1.conv1 (fused)", "layer1_fused_kernel", 1, 0),
+            ("layer1.conv2+layer2+layer3 (fused, pooled)", "block_full_", 1, 0),
+            ("head(avgpool+fc+linear)", "conv_gemm_f16x3_direct_kernel<128, 1, 0>", 2, 0),      # two launches per step:
+            ("compressMLP", "conv_gemm_f16x3_direct_kernel<128, 1, 0>", 2, 1),                 # head, then compressMLP
+            ("gat_layer (one launch)", "gat_mfma_kernel", 1, 0),
+            ("actionsMLP", "skinny_gemm_kernel", 1, 0)]
+    SEQ = [t[0] for t in TAGS]
     layers = defaultdict(dict)
+
+    def per_tag(rows, order_key, value, nsteps):
+        """rows of one csv -> {tag: [values of the last nsteps steps]}"""
+        got = {}
+        for tag, needle, per_step, which in TAGS:
+            mine = [r for r in rows if needle in r["Kernel_Name"]]
+            mine.sort(key=order_key)
+            mine = mine[-nsteps * per_step:]
+            if len(mine) == nsteps * per_step:
+                got[tag] = [value(r) for i, r in enumerate(mine) if i % per_step == which]
+        return got
+
     tr = find(os.path.join(out, "trace"), "*kernel_trace.csv")
     if tr:
-        rows = [r for r in csv.DictReader(open(tr)) if any(o in r["Kernel_Name"] for o in ours)]
-        rows.sort(key=lambda r: int(r["Start_Timestamp"]))          # the CSV is not in dispatch order
-        # the TIMED steps only: the warm-up steps in front of them also hold the one-off calibration pass of the activation
-        # scales (float32 layer-by-layer kernels) and weight packing
-        if len(rows) >= steps * len(SEQ):
-            rows = rows[-steps * len(SEQ):]
-        if len(rows) % len(SEQ) == 0:
-            dur = defaultdict(list)
-            for i, r in enumerate(rows):
-                dur[SEQ[i % len(SEQ)]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-            for k, v in dur.items():
-                layers[k]["avg_us"] = sum(v) / len(v)
-                layers[k]["launches"] = len(v)
-        else:
-            lines.append("(per-layer view skipped: %d library launches are not a multiple of the %d-launch step sequence)"
-                         % (len(rows), len(SEQ)))
+        rows = list(csv.DictReader(open(tr)))
+        for k, v in per_tag(rows, lambda r: int(r["Start_Timestamp"]),
+                            lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, steps).items():
+            layers[k]["avg_us"] = sum(v) / len(v)
+            layers[k]["launches"] = len(v)
     for ctr, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         cc = find(os.path.join(out, sub), "*counter_collection.csv")
         if not cc:
             continue
-        rows = [r for r in csv.DictReader(open(cc)) if r.get("Counter_Name") == ctr and
-                any(o in r["Kernel_Name"] for o in ours)]
+        rows = [r for r in csv.DictReader(open(cc)) if r.get("Counter_Name") == ctr]
         key = "Dispatch_Id" if rows and "Dispatch_Id" in rows[0] else None
-        if key:
-            rows.sort(key=lambda r: int(r[key]))
         pmc_steps = 2                                    # (tools/profile_round.sh: the PMC passes time 2 steps after 1 warm-up)
-        if len(rows) >= pmc_steps * len(SEQ):
-            rows = rows[-pmc_steps * len(SEQ):]
-        if len(rows) % len(SEQ) == 0:
-            acc2 = defaultdict(list)
-            for i, r in enumerate(rows):
-                acc2[SEQ[i % len(SEQ)]].append(float(r["Counter_Value"]))
-            for k, v in acc2.items():
-                layers[k][ctr + "_KiB_per_launch"] = sum(v) / len(v)
+        for k, v in per_tag(rows, (lambda r: int(r[key])) if key else (lambda r: 0), lambda r: float(r["Counter_Value"]),
+                            pmc_steps).items():
+            layers[k][ctr + "_KiB_per_launch"] = sum(v) / len(v)
     lines.append("== per-layer view (dispatch order within a step): avg_us | HBM read MB (2*FETCH) | write MB")
     for k in SEQ:
         v = layers.get(k)
