@@ -321,11 +321,12 @@ class DecentralPlannerGATNet(nn.Module):
         return self.actionsMLP(shared)
 
     # ------------------------------------------------------------------ inference path (HIP)
-    def _refresh(self, dev):
-        rt = self._rt
-        # (address, version) of every parameter and buffer: an iterative walk over the module dicts - the closed-loop step of
-        # one planning instance is host-bound, and nn.Module.parameters() / buffers() (recursive generators with a memo
-        # set) were two thirds of this method's caller
+    def _weights_key(self, dev):
+        """(address, version) of every parameter and buffer of the module tree: what the folded / packed weights of the HIP
+        path were made from.  An iterative walk over the module dicts - the closed-loop step of one planning instance is
+        host-bound, and nn.Module.parameters() / buffers() (recursive generators with a memo set) were two thirds of a
+        forward's host time.  Changes under any of: load_state_dict / in-place updates (version), .to() / a replaced
+        Parameter (address), a replaced or added submodule (walked afresh every call)."""
         key = [dev]
         stack = [self]
         while stack:
@@ -341,7 +342,11 @@ class DecentralPlannerGATNet(nn.Module):
             for c in m._modules.values():
                 if c is not None:
                     stack.append(c)
-        key = tuple(key)
+        return tuple(key)
+
+    def _refresh(self, dev):
+        rt = self._rt
+        key = self._weights_key(dev)
         if rt.key == key:
             return rt
         sd = {k: v.detach() for k, v in self.state_dict().items()}

@@ -258,3 +258,39 @@ def test_fold_activation_scales_is_exact_and_consistent():
     assert tot == -s1
     for k in ("head_in", "feat_in"):
         assert float(blk[1349 if k == "head_in" else 1350]) == 2.0 ** info[k]
+
+
+def test_weights_key_sees_every_way_the_weights_can_change():
+    """planner._weights_key (the per-forward check that decides whether the packed weights of the HIP path are still valid):
+    equal for an untouched module; different after an in-place update, load_state_dict, a replaced Parameter, a replaced
+    submodule, a BatchNorm buffer update, and for another device."""
+    import copy
+    import torch
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    from magat_pathplanning_amd.synthetic import make_config
+    cfg = make_config(num_agents=10, nGraphFilterTaps=2, nAttentionHeads=2, device="cpu")
+    net = DecentralPlannerGATNet(cfg).eval()
+    dev = torch.device("cpu")
+    k0 = net._weights_key(dev)
+    assert net._weights_key(dev) == k0
+    n_tensors = sum(1 for _ in net.parameters()) + sum(1 for _ in net.buffers())
+    assert len(k0) == 1 + 2 * n_tensors                      # every tensor is in it
+    with torch.no_grad():
+        next(net.parameters()).add_(1.0)
+    k1 = net._weights_key(dev)
+    assert k1 != k0
+    net.load_state_dict(copy.deepcopy(net.state_dict()))
+    k2 = net._weights_key(dev)
+    assert k2 != k1
+    lin = net.compressMLP[0]
+    lin.weight = torch.nn.Parameter(lin.weight.detach().clone())
+    k3 = net._weights_key(dev)
+    assert k3 != k2
+    net.compressMLP[0] = torch.nn.Linear(lin.in_features, lin.out_features)
+    k4 = net._weights_key(dev)
+    assert k4 != k3
+    bn = next(m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    with torch.no_grad():
+        bn.running_mean.mul_(0.5)
+    assert net._weights_key(dev) != k4
+    assert net._weights_key(torch.device("cuda:0"))[0] != k4[0]
