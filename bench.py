@@ -11,8 +11,10 @@ inside a step; the only collectives are the barrier, the MAX of the elapsed time
 
 Rank 0 prints ONE JSON line.  `value` is measured with the library's DEFAULT arithmetic, which is fp32-class
 (f16x3 split products, see `dtype`); extra objects:
-  roofline       dominant kernel of the timed region: ALGORITHMIC flops (or bytes) / hipEvent time / the dense peak of the
-                 data type its MFMAs are issued in; `issued_*` = the matrix-core flops actually issued (3x for f16x3)
+  roofline       dominant kernel of the step: ALGORITHMIC flops (or bytes) / hipEvent time / the dense peak of the
+                 data type its MFMAs are issued in; `issued_*` = the matrix-core flops actually issued (3x for f16x3).
+                 The hipEvent times come from a second, instrumented pass of the same K steps right behind the timed
+                 region (`instrumented_ms_per_step`): the event pairs cost 2-3 % of a step and are kept out of `value`
   roofline_gat   the hand-written graph kernel the north star names, against HBM
   kernels        every kernel tag (hipEvents on the launch stream through the library's profiling hooks)
   north_star_b1024  the same model at the north-star shape N=100, batch 1024 (a-s/s, graph-kernel GB/s and fraction)
@@ -371,10 +373,6 @@ def main():
         with torch.no_grad():
             for _ in range(warmup):
                 out = step()
-            if timing:
-                lib.magat_profile_reserve(40 * (steps + 1))      # event pairs created outside the timed region
-                lib.magat_profile_reset()
-                lib.magat_profile_enable(1)
             # a full collection of the interpreter's heap (torch + numpy: ~1e6 objects) inside the step loop showed up as one-off
             # 50-90 ms host stalls: collect now, move the survivors out of the collector's reach; every step still runs in full
             gc.collect()
@@ -385,6 +383,20 @@ def main():
                 out = step()
             barrier()
             elapsed = time.perf_counter() - t0
+            # The per-kernel times come from a SECOND pass of the same `steps` steps, right behind the timed region, with the
+            # library's hipEvent pairs around every launch: ~14 pairs per step cost 2-3 % of a c3 step (same box: 2.47 ms
+            # against 2.53), and the timed region is the workload, not the instrumentation.  Its own elapsed time is reported
+            # next to the table (`instrumented_ms_per_step`).
+            if timing:
+                lib.magat_profile_reserve(40 * (steps + 1))      # event pairs created outside the instrumented pass
+                lib.magat_profile_reset()
+                lib.magat_profile_enable(1)
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    out = step()
+                barrier()
+                run_leg.instrumented_ms = (time.perf_counter() - t1) / steps * 1e3
             gc.unfreeze()
         kern = {}
         if timing:
@@ -466,6 +478,7 @@ def main():
     # measure the instrumentation); rank 0's table is the one reported
     timing = not args.no_kernel_timing
     elapsed, kern, per_rank_ms = run_leg(x, S, args.steps, args.warmup, timing)
+    instr_ms = getattr(run_leg, "instrumented_ms", 0.0)
     # what each rank ran on: the 0.9-scaling target is decided by the slowest die, so the line names them
     props = torch.cuda.get_device_properties(dev)
     mine = {"rank": rank, "device": props.name, "cus": props.multi_processor_count,
@@ -510,6 +523,10 @@ def main():
                 if gk in table:
                     res["roofline_gat"] = roof(table, gk, B, N, pmc)
             res["kernel_time_ms_per_step"] = round(sum(v["ms_per_step"] for k, v in table.items() if k != "gat_prepare"), 4)
+            res["instrumented_ms_per_step"] = round(instr_ms, 4)
+            res["kernel_timing"] = ("hipEvent pairs around every library launch, on the launch stream, in a second pass of the "
+                                    "same %d steps right behind the timed region (the pairs cost 2-3 %% of a step: the timed "
+                                    "region runs without them)" % args.steps)
         if cpu is not None:
             res["cpu_baseline"] = cpu
 
