@@ -40,7 +40,11 @@ def _legacy_structure(S, rule, device):
 
 
 @pytest.mark.parametrize("N,dtype,rule", [(1000, torch.float32, 0), (1000, torch.float64, 0), (333, torch.float32, 1),
-                                          (64, torch.float64, 2), (1024, torch.float32, 0)])
+                                          (64, torch.float64, 2), (1024, torch.float32, 0),
+                                          # float32 rows of N % 4 == 0 take the four-columns-per-lane pass: every edge rule,
+                                          # a row shorter than one request, a row that ends inside the second 256-column step
+                                          (200, torch.float32, 1), (132, torch.float32, 2), (8, torch.float32, 0),
+                                          (260, torch.float32, 0)])
 def test_gso_csr_build_matches_the_definition(gpu_device, N, dtype, rule):
     """magat_gso_csr_build: rowptr / colidx / cscptr / cscsrc / cscpos bit-exact against a host construction, the device
     edge total, and the fused in-place scrub (NaN -> 0, dist_GSO_one) against torch on the same tensor."""
