@@ -1,6 +1,7 @@
 """Closed-loop-style latency: one planning instance per step (the reference's test_batch_size=1 usage), eager and with the
 product's own graph mode.  Per-step wall times (addGSO + forward + copy of the logits to the host); the MEDIAN is the figure -
-the mean of a loop also carries whatever one-off stall the process met (a single 80 ms hiccup in 200 steps reads as +400 us)."""
+the mean of a loop also carries whatever one-off stall the process met: the first `.cpu()` of a new result size costs ~90 ms in the
+runtime (tools/stall_probe.py: step 0 of a new shape, no garbage collection involved), which reads as +450 us over 200 steps."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
