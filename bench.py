@@ -154,8 +154,11 @@ def kernel_work(nat, cfg, N, S_bytes, deg=None, planned=False, fused_stem=True, 
                               bytes=es * (G + P * G + P * K * F + yw) + 4 * (2 + 3 * deg) + 4 * P * deg * K)
         w["gat_maps_gemm"]["bytes"] = es * (G + NC)
     width = yw + (nfm if cfg.bottleneckMode == "BottomNeck_skipConcat" else 0)
-    # the action head (width -> 5) runs as streamed float32 dot products (vector FMAs, option SKINNY): bound by its bytes
-    w["actionsMLP"] = dict(flops=2 * width * 5, bytes=4 * (width + 5), arith=None if lib_opt(nat, "SKINNY") else "f32")
+    # the action head (width -> 5) runs as streamed float32 dot products (vector FMAs, option SKINNY): bound by its bytes; with
+    # bf16 storage in the graph layer it reads that layer's rows as bf16
+    skinny = bool(lib_opt(nat, "SKINNY"))
+    gbytes = 2 if (skinny and getattr(cfg, "gat_storage", "fp32") == "bf16" and yw % 8 == 0) else 4
+    w["actionsMLP"] = dict(flops=2 * width * 5, bytes=gbytes * yw + 4 * (width - yw + 5), arith=None if skinny else "f32")
     return w
 
 

@@ -408,6 +408,11 @@ typedef struct magat_conv_gemm_desc {
   const float* in_scale;
   const float* acc_scale;
   float* absmax;
+  /* bit 0: `in` holds bf16 rows, bit 1: `in2` does (lda / lda2 in bf16 elements; width and stride multiples of 8): the graph layer's
+   * bf16-storage result as the action head's input, read as it is instead of through a cast pass.  Taken by the
+   * streamed-dot-product form of a layer with at most 8 outputs only (float32 1x1, option SKINNY); every other kernel returns
+   * MAGAT_ERR_UNSUPPORTED. */
+  int bf16_rows;
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 

@@ -48,7 +48,8 @@ class ConvGemmDesc(ctypes.Structure):
                 ("in_gl", ctypes.c_int), ("out_gl", ctypes.c_int), ("out_ntile_stride", ctypes.c_int64),
                 ("wt_pix_stride", ctypes.c_int64), ("ldw", ctypes.c_int),
                 ("range_flag", ctypes.c_void_p), ("run_if", ctypes.c_void_p),
-                ("in_scale", ctypes.c_void_p), ("acc_scale", ctypes.c_void_p), ("absmax", ctypes.c_void_p)]
+                ("in_scale", ctypes.c_void_p), ("acc_scale", ctypes.c_void_p), ("absmax", ctypes.c_void_p),
+                ("bf16_rows", ctypes.c_int)]
 
 
 class EncoderDesc(ctypes.Structure):

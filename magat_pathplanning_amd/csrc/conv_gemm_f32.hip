@@ -439,6 +439,7 @@ struct SkinnyParams {
   const float* bias;
   float* out;
   int M, Cin, C2, lda, lda2, ldc, relu;
+  int bf16_rows;       // bit 0: in rows are bf16 (8-byte chunks of 4 values), bit 1: in2 rows
 };
 #ifdef SKINNY_BATCH_OVERRIDE
 constexpr int SKINNY_BATCH = SKINNY_BATCH_OVERRIDE;
@@ -458,32 +459,47 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyParams p) 
   float bv[CO];
 #pragma unroll
   for (int c = 0; c < CO; ++c) bv[c] = p.bias ? p.bias[c] : 0.f;
+  // a lane's unit of work is a 16-byte PIECE of the row: one chunk of 4 float32 values, or two chunks of a bf16 row
+  const bool b1 = p.bf16_rows & 1, b2 = (p.bf16_rows >> 1) & 1;
+  const int np1 = b1 ? p.Cin >> 3 : q1, np2 = b2 ? p.C2 >> 3 : p.C2 >> 2, np = np1 + np2;
   for (long long m0 = (long long)blockIdx.x * 16; m0 < p.M; m0 += (long long)gridDim.x * 16) {
     const long long m = m0 + grp;
     const bool ok = m < p.M;
     const long long mr = ok ? m : p.M - 1;
-    const float* r1 = p.in + mr * p.lda;
-    const float* r2 = p.in2 ? p.in2 + mr * p.lda2 - 4 * q1 : r1;      // (chunk q >= q1 lives at r2 + 4 q)
+    const char* r1 = reinterpret_cast<const char*>(p.in) + mr * p.lda * (b1 ? 2 : 4);
+    const char* r2 = reinterpret_cast<const char*>(p.in2) + mr * p.lda2 * (b2 ? 2 : 4) - 16LL * np1;   // (piece pc >= np1 at r2 + 16 pc)
     float acc[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[c] = 0.f;
-    for (int qb = l16; qb < nq; qb += 16 * SKINNY_BATCH) {
-      f32x4 x[SKINNY_BATCH];
+    auto fma4 = [&](const f32x4& xv, int q) {
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sk_w + ((size_t)q * CO + c) * 4);
+        acc[c] = __builtin_fmaf(xv[3], w[3], __builtin_fmaf(xv[2], w[2], __builtin_fmaf(xv[1], w[1],
+                 __builtin_fmaf(xv[0], w[0], acc[c]))));
+      }
+    };
+    for (int pb = l16; pb < np; pb += 16 * SKINNY_BATCH) {
+      uint4 x[SKINNY_BATCH];
 #pragma unroll
       for (int j = 0; j < SKINNY_BATCH; ++j) {
-        const int q = qb + 16 * j;
-        const int qc = q < nq ? q : l16;      // (past the row: chunk l16 again, dropped below)
-        x[j] = *reinterpret_cast<const f32x4*>((qc < q1 ? r1 : r2) + 4 * qc);
+        const int pq = pb + 16 * j;
+        const int pc = pq < np ? pq : l16;      // (past the row: piece l16 again, dropped below)
+        x[j] = *reinterpret_cast<const uint4*>((pc < np1 ? r1 : r2) + 16LL * pc);
       }
 #pragma unroll
       for (int j = 0; j < SKINNY_BATCH; ++j) {
-        const int q = qb + 16 * j;
-        if (q < nq) {
-#pragma unroll
-          for (int c = 0; c < CO; ++c) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(sk_w + ((size_t)q * CO + c) * 4);
-            acc[c] = __builtin_fmaf(x[j][3], w[3], __builtin_fmaf(x[j][2], w[2], __builtin_fmaf(x[j][1], w[1],
-                     __builtin_fmaf(x[j][0], w[0], acc[c]))));
+        const int pq = pb + 16 * j;
+        if (pq < np) {
+          const bool first = pq < np1;
+          if (first ? b1 : b2) {      // eight bf16 values: chunks q, q + 1
+            const int q = first ? 2 * pq : q1 + 2 * (pq - np1);
+            fma4(f32x4{__builtin_bit_cast(float, x[j].x << 16), __builtin_bit_cast(float, x[j].x & 0xffff0000u),
+                       __builtin_bit_cast(float, x[j].y << 16), __builtin_bit_cast(float, x[j].y & 0xffff0000u)}, q);
+            fma4(f32x4{__builtin_bit_cast(float, x[j].z << 16), __builtin_bit_cast(float, x[j].z & 0xffff0000u),
+                       __builtin_bit_cast(float, x[j].w << 16), __builtin_bit_cast(float, x[j].w & 0xffff0000u)}, q + 1);
+          } else {
+            fma4(__builtin_bit_cast(f32x4, x[j]), first ? pq : q1 + (pq - np1));
           }
         }
       }
@@ -520,12 +536,15 @@ int skinny_try(const magat_conv_gemm_desc* d, hipStream_t st) {
     return MAGAT_ERR_UNSUPPORTED;
   if ((d->Cin & 3) || (d->C2 & 3) || (d->lda & 3) || (d->lda2 & 3) || d->lda < d->Cin || d->ldc < d->Cout || d->C2 < 0 ||
       (d->C2 > 0 && (!d->in2 || d->lda2 < d->C2 || (d->W2 > 1) || d->stride2 > 1)) ||
-      ((reinterpret_cast<uintptr_t>(d->in) | reinterpret_cast<uintptr_t>(d->wt) | reinterpret_cast<uintptr_t>(d->in2)) & 15))
+      ((reinterpret_cast<uintptr_t>(d->wt) | reinterpret_cast<uintptr_t>(d->in) | reinterpret_cast<uintptr_t>(d->in2)) & 15) ||
+      (d->bf16_rows & ~3) || ((d->bf16_rows & 2) && d->C2 <= 0) ||
+      ((d->bf16_rows & 1) && ((d->Cin & 7) || (d->lda & 7))) || ((d->bf16_rows & 2) && ((d->C2 & 7) || (d->lda2 & 7))))
     return MAGAT_ERR_UNSUPPORTED;
   SkinnyParams p;
   p.in = static_cast<const float*>(d->in); p.in2 = d->C2 > 0 ? static_cast<const float*>(d->in2) : nullptr;
   p.wt = static_cast<const float*>(d->wt); p.bias = static_cast<const float*>(d->bias); p.out = static_cast<float*>(d->out);
   p.M = d->M; p.Cin = d->Cin; p.C2 = d->C2; p.lda = d->lda; p.lda2 = d->lda2; p.ldc = d->ldc; p.relu = d->relu;
+  p.bf16_rows = d->bf16_rows;
   switch (d->Cout) {
     case 1: return skinny_launch<1>(p, d->tag, st);
     case 2: return skinny_launch<2>(p, d->tag, st);
@@ -589,11 +608,13 @@ static int conv_params_from_desc(const magat_conv_gemm_desc* d, ConvGemmParams& 
 
 extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) {
   if (!d || !d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
+  if (d->bf16_rows && d->in_fmt != 0) return MAGAT_ERR_UNSUPPORTED;
   if (d->in_fmt >= 1 && d->in_fmt <= 5) return magat_conv_gemm_bf16x6(d, static_cast<hipStream_t>(stream));
   {
     const int src = skinny_try(d, static_cast<hipStream_t>(stream));
     if (src != MAGAT_ERR_UNSUPPORTED) return src;
   }
+  if (d->bf16_rows) return MAGAT_ERR_UNSUPPORTED;      // (the streamed form only)
   ConvGemmParams p;
   const int prc = conv_params_from_desc(d, p);
   if (prc != MAGAT_OK) return prc;

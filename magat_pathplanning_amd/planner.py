@@ -475,6 +475,7 @@ class DecentralPlannerGATNet(nn.Module):
             layer = self.GFL[0]
             layer.addGSO(self.S)
             gat = self._buf("gat", (M, self.gat_width), dev)
+            gat_rows = gat          # what the action head reads: `gat`, or the layer's bf16 rows (bf16 storage, see below)
             want_att = layer.return_attention or bool(getattr(self.config, "return_attentionGSO", False))
             Ns = self.S.shape[-1]
             if Ns > N:
@@ -490,8 +491,14 @@ class DecentralPlannerGATNet(nn.Module):
                 # and writes bf16 rows; the CNN/MLP GEMMs around it stay fp32
                 comp16 = self._buf16("comp16", (M, G), dev)
                 nat.check(lib.magat_cast_rows(nat.ptr(comp), nat.ptr(comp16), 1, M, G, G, G, stream), "magat_cast_rows")
-                if CsrStructure.supported(B, N):
-                    # (device-built CSR + CSC structure: the layer's last kernel stores the bf16-rounded rows as float32 itself)
+                # the layer's bf16 rows go to the action head as they are when it runs as streamed dot products (at most 8
+                # outputs, option SKINNY: its loader widens them); otherwise the layer's last kernel stores them widened
+                # (device-built CSR + CSC structure), or a cast pass follows
+                if rt.act[0].shape[0] <= 8 and nat.get_option("SKINNY") and self.gat_width % 8 == 0:
+                    gat_rows = self._buf16("gat16", (M, self.gat_width), dev)
+                    _, aij = gat_forward_rows(comp16.view(B, N, G), self.S, layer, out=gat_rows, want_attention=want_att,
+                                              csr=rt.csr)
+                elif CsrStructure.supported(B, N):
                     _, aij = gat_forward_rows(comp16.view(B, N, G), self.S, layer, out=gat, want_attention=want_att, csr=rt.csr)
                 else:
                     gat16 = self._buf16("gat16", (M, self.gat_width), dev)
@@ -507,13 +514,16 @@ class DecentralPlannerGATNet(nn.Module):
             nout = rt.act[0].shape[0]
             out = torch.empty(M, nout, dtype=torch.float32, device=dev)
             d = nat.ConvGemmDesc()
+            rows16 = gat_rows.dtype == torch.bfloat16
             if self.skip in ("skipConcat", "skipConcatGNN", "skipAddGNN"):
                 src = feat if self.skip == "skipConcat" else comp
                 d.inp, d.Cin, d.lda = src.data_ptr(), src.shape[1], src.stride(0)
-                d.in2, d.C2, d.lda2 = gat.data_ptr(), gat.shape[1], gat.stride(0)
+                d.in2, d.C2, d.lda2 = gat_rows.data_ptr(), gat_rows.shape[1], gat_rows.stride(0)
                 d.W2, d.stride2 = 1, 1
+                d.bf16_rows = 2 if rows16 else 0
             else:
-                d.inp, d.Cin, d.lda = gat.data_ptr(), gat.shape[1], gat.stride(0)
+                d.inp, d.Cin, d.lda = gat_rows.data_ptr(), gat_rows.shape[1], gat_rows.stride(0)
+                d.bf16_rows = 1 if rows16 else 0
             d.wt, d.bias, d.out = rt.act[0].data_ptr(), rt.act[1].data_ptr(), out.data_ptr()
             d.M, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad, d.Hout, d.Wout = M, 1, 1, 1, 1, 1, 0, 1, 1
             d.Cout, d.ldc, d.relu = nout, nout, 1 if self.config.use_dropout else 0

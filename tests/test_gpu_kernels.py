@@ -79,6 +79,51 @@ def test_skinny_layer_is_the_same_product(gpu_device, libopt, M, K1, K2, N, relu
     np.testing.assert_allclose(y1[:, :N].cpu().numpy(), y0[:, :N].cpu().numpy(), rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("M,K1,K2,N,rows16", [(20000, 128, 512, 5, 2), (4099, 512, 0, 5, 1), (777, 64, 40, 3, 3),
+                                              (100, 128, 512, 5, 2)])
+def test_skinny_layer_reads_bf16_rows(gpu_device, M, K1, K2, N, rows16):
+    """magat_conv_gemm_desc.bf16_rows: the action head's inputs as bf16 rows (the bf16-storage graph layer's result, read as
+    it is) - against float64 over the same bf16 values, next to a float32 `in` where only `in2` is bf16; row strides wider
+    than the rows; bit-identical from run to run.  Any other kernel refuses the flag."""
+    nat, lib = _nat()
+    g = torch.Generator().manual_seed(M + K1 + K2 + N)
+    ld1, ld2, ldc = K1 + 8, K2 + 16, N + 1
+    x1 = torch.randn(M, ld1, generator=g)
+    x2 = torch.randn(M, max(ld2, 8), generator=g)
+    if rows16 & 1:
+        x1 = x1.to(torch.bfloat16)
+    if rows16 & 2:
+        x2 = x2.to(torch.bfloat16)
+    x1, x2 = x1.to(gpu_device), x2.to(gpu_device)
+    w = (torch.randn(N, K1 + K2, generator=g) / (K1 + K2) ** 0.5).to(gpu_device)
+    b = torch.randn(N, generator=g).to(gpu_device)
+    ref = torch.cat((x1[:, :K1].double(), x2[:, :K2].double()), 1) @ w.double().t() + b.double()
+
+    def desc(y, cout=N):
+        d = nat.ConvGemmDesc()
+        d.inp, d.Cin, d.lda = x1.data_ptr(), K1, ld1
+        if K2:
+            d.in2, d.C2, d.lda2, d.W2, d.stride2 = x2.data_ptr(), K2, ld2, 1, 1
+        d.wt, d.bias, d.out = w.data_ptr(), b.data_ptr(), y.data_ptr()
+        d.M, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad, d.Hout, d.Wout = M, 1, 1, 1, 1, 1, 0, 1, 1
+        d.Cout, d.ldc, d.relu, d.bf16_rows = cout, ldc, 0, rows16
+        return d
+
+    outs = []
+    for _ in range(2):
+        y = torch.full((M, ldc), -3.0, device=gpu_device)
+        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(desc(y)), nat.current_stream(gpu_device)), "conv_gemm")
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1]) and bool((outs[0][:, N:] == -3.0).all())
+    np.testing.assert_allclose(outs[0][:, :N].cpu().numpy(), ref.float().cpu().numpy(), rtol=0, atol=2e-5)
+    # a layer the streamed form does not take (32 outputs): the MFMA-tile kernels have no bf16 loader and say so
+    wide = torch.empty(M, 32, device=gpu_device)
+    d = desc(wide, 32)
+    d.ldc = 32
+    assert lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)) == -2      # MAGAT_ERR_UNSUPPORTED
+
+
 def _to_pixel_major(t):           # (M,C,H,W) -> [H*W][M][C]
     M, C, H, W = t.shape
     return t.permute(2, 3, 0, 1).reshape(H * W, M, C).contiguous()
