@@ -77,6 +77,40 @@ def test_gso_csr_build_matches_the_definition(gpu_device, N, dtype, rule):
     assert torch.equal(Sd2.cpu(), w2)
 
 
+def test_gso_csr_build_at_config5_size(gpu_device):
+    """BASELINE config 5's full shape (128 instances x 1000 agents, 512 MB of GSO) through size-independent properties: the
+    device edge total equals torch's count over the scrubbed tensor, every row's degree equals its row count, column indices
+    ascend inside a row and hit edges only, the CSC view holds every edge exactly once, and a second build is bit-identical."""
+    from magat_pathplanning_amd.graphml import CsrStructure
+    from magat_pathplanning_amd.synthetic import comm_gso
+    B, N = 128, 1000
+    S = comm_gso(B, N, 160, seed=9).to(gpu_device)
+    S[5, 17, 400] = float("nan")
+    st = CsrStructure().build(S, 0, scrub_nan=1)
+    nnz = st.ready(gpu_device)
+    assert not bool(torch.isnan(S).any())
+    edges = S.abs() > 1e-9
+    assert nnz == int(edges.sum())
+    rp = st.rowptr.view(B, N + 1).long()
+    deg = rp[:, 1:] - rp[:, :-1]
+    assert torch.equal(deg, edges.sum(-1))
+    assert int(rp[0, 0]) == 0 and int(rp[-1, -1]) == nnz and bool((rp[1:, 0] == rp[:-1, -1]).all())
+    rows = torch.repeat_interleave(torch.arange(B * N, device=gpu_device), deg.reshape(-1))
+    cols = st.colidx[:nnz].long()
+    assert bool(edges.view(B * N, N)[rows, cols].all())                       # every stored index is an edge
+    same_row = rows[1:] == rows[:-1]
+    assert bool((cols[1:][same_row] > cols[:-1][same_row]).all())             # ascending inside a row
+    pos = st.csc[1][:nnz].long()
+    assert torch.equal(torch.sort(pos).values, torch.arange(nnz, device=gpu_device))      # CSC = a permutation of the edges
+    src = st.csc[0][:nnz].long()
+    assert torch.equal(src, (rows % N)[pos])                                  # ... whose sources are those edges' rows
+    first = [t.clone() for t in (st.rowptr, st.colidx[:nnz], st.cscptr, st.csc[0][:nnz], st.csc[1][:nnz])]
+    st2 = CsrStructure().build(S, 0, scrub_nan=1)
+    assert st2.ready(gpu_device) == nnz
+    for a, b in zip(first, (st2.rowptr, st2.colidx[:nnz], st2.cscptr, st2.csc[0][:nnz], st2.csc[1][:nnz])):
+        assert torch.equal(a, b)
+
+
 def test_gso_csr_capacity_guess_regrows(gpu_device):
     """The index arrays are sized by a guess (32 edges per node), not by the dense bound B*N*N: a graph denser than the guess
     makes the kernel drop the overflow, the count that travels back shows it, and ready() re-builds with room - same
