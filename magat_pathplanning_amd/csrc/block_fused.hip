@@ -1351,7 +1351,7 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
           const int r = 4 * qd + c;
           float v[9];
 #pragma unroll
-          for (int s = 0; s < 9; ++s) v[s] = fmaxf(__builtin_fmaf(acc[s][r], s2, bq[qd][c]), 0.f);
+          for (int s = 0; s < 9; ++s) v[s] = magat_relu(__builtin_fmaf(acc[s][r], s2, bq[qd][c]));      // (keeps NaN, like torch.relu)
           const float u = hi ? v[6] : v[5], ux = hi ? v[5] : v[6];
           const float w_ = lo ? v[8] : v[7], wx = lo ? v[7] : v[8];
           vF[c] = (v[4] + v[0]) + (u + w_);

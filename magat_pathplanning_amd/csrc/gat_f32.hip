@@ -784,7 +784,8 @@ __global__ void pack_kernel(const float* __restrict__ weight, const float* __res
   unsigned short* Hs = reinterpret_cast<unsigned short*>(packed + magat_gat_f16_block_offset(L.NC, G));
   // the same two planes once more in MFMA-fragment order for gat_mfma.hip (G = 128): 128-row blocks of Bt, per block
   // [32-row tile 4][k step 8][plane 2][lane 64][8 halfs], lane = row % 32 + 32 * (k % 16 / 8)
-  unsigned short* Fs = (G == 128 && (L.NC & 127) == 0)
+  // (KeyQuery only: the rank-1 modes' stream at the same offset is written by pack_frag_rank1_kernel, with its own size)
+  unsigned short* Fs = (G == 128 && (L.NC & 127) == 0 && mode == MAGAT_MODE_KEYQUERY)
                            ? reinterpret_cast<unsigned short*>(packed + magat_gat_frag_offset(L.NC, G)) : nullptr;
   const long long total = (long long)L.NC * G;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total + L.NC;
@@ -946,9 +947,9 @@ extern "C" int magat_gat_set_debug_skip(int mask) { g_gat_skip = mask; return MA
 extern "C" size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode) {
   if (G <= 0 || F <= 0 || K <= 0 || P <= 0) return 0;
   const PackLayout L = pack_layout(G, F, K, P, mode);
-  if (G == 128 && (L.NC & 127) == 0) return magat_gat_frag_offset(L.NC, G) + (size_t)L.NC * G;
   if (gat_rank1_frag(G, F, mode))      // + the one-launch kernel's weight stream and the per-head score constants
     return magat_gat_frag_offset(L.NC, G) + (size_t)(P * G + P * K * F) * G + (((size_t)P + 3) & ~(size_t)3);
+  if (G == 128 && (L.NC & 127) == 0 && mode == MAGAT_MODE_KEYQUERY) return magat_gat_frag_offset(L.NC, G) + (size_t)L.NC * G;
   return magat_gat_f16_block_offset(L.NC, G) + (size_t)L.NC * G + 4;
 }
 

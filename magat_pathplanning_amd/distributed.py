@@ -36,9 +36,12 @@ def sharded_forward(model, x, S, group=None, gather=True):
     if not gather or world == 1:
         return local
     cap = (B + world - 1) // world * N
-    pad = torch.zeros(cap, local.shape[1], dtype=local.dtype, device=local.device)
+    # (gloo has no all_gather over device tensors: staged through the host there - the CPU tests, and the two-processes-on-
+    #  one-GPU test; under nccl = RCCL the logits never leave the devices)
+    via_host = local.is_cuda and dist.get_backend(group) == "gloo"
+    pad = torch.zeros(cap, local.shape[1], dtype=local.dtype, device="cpu" if via_host else local.device)
     pad[: local.shape[0]] = local.detach()
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     rows = [shard_range(B, r, world) for r in range(world)]
-    return torch.cat([parts[r][: (e - s) * N] for r, (s, e) in enumerate(rows)], dim=0)
+    return torch.cat([parts[r][: (e - s) * N] for r, (s, e) in enumerate(rows)], dim=0).to(local.device)

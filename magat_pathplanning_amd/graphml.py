@@ -183,8 +183,10 @@ class CsrStructure:
                     # S is being rewritten: nothing of the caller's may read it earlier.  Only the streaming pass writes S, so the
                     # caller's stream (next: the per-agent CNN) waits for THAT, and the structure kernel runs beside the CNN
                     cur.wait_event(scrubbed)
-        self.key = (S3.data_ptr(), B, N, S3.dtype, int(rule), str(dev))
-        self.args = (S3, rule, scrub_nan, gso_mode)
+        # (S._version: a torch-side in-place change of S behind addGSO makes the structure stale; the kernels' own scrub does
+        #  not count - it writes through the raw pointer)
+        self.key = (S3.data_ptr(), S3._version, B, N, S3.dtype, int(rule), str(dev))
+        self.args = (S3, rule, scrub_nan, gso_mode)      # kept until ready(): a re-build needs S once more
         self.nnz = None
         return self
 
@@ -201,10 +203,11 @@ class CsrStructure:
         else:
             raise nat.MagatNativeError("CSR structure build did not converge (nnz %d, cap %d)" % (self.nnz, self.cap))
         torch.cuda.current_stream(dev).wait_event(self.event)
+        self.args = None        # the count fits: nothing needs S again (no strong reference to ~1 GB of GSO at config 5)
         return self.nnz
 
     def matches(self, S3, rule):
-        return self.key == (S3.data_ptr(), S3.shape[0], S3.shape[1], S3.dtype, int(rule), str(S3.device))
+        return self.key == (S3.data_ptr(), S3._version, S3.shape[0], S3.shape[1], S3.dtype, int(rule), str(S3.device))
 
     def exact_nnz(self):
         return self.nnz if self.nnz is not None else self.ready(self.rowptr.device)

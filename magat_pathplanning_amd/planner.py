@@ -15,6 +15,7 @@ Training (autograd on): the graph layer's forward AND backward run on HIP kernel
 _GnnTrainFunction); the CNN / MLP parameter containers train through torch autograd.
 """
 import ctypes
+import hashlib
 import os
 
 import torch
@@ -47,6 +48,9 @@ def weights_init(m):
         m.bias.data.fill_(0.0)
 
 
+CAL_AGENTS = 2048      # agents of the canonical calibration batch (synthetic.calibration_states)
+
+
 class _Runtime:
     """Device-side caches of one module instance (never pickled)."""
 
@@ -59,8 +63,9 @@ class _Runtime:
         self.ws = None
         self.plan = GsoPlan()          # GSO-derived masks / walk order, made at addGSO on a side stream
         self.csr = CsrStructure()      # CSR + CSC structure of the GSO (large graphs / bf16 storage), made at addGSO
-        self.calibrated = True         # activation scales of the split arithmetic measured for the current weights
+        self.calibrated = True         # activation scales of the split arithmetic folded for the current weights
         self.act_scales = None
+        self.digest = None             # fingerprint of the folded encoder pack (what a calibration belongs to)
         self.scaled_at = 0
         self.pack_host = self.pack_offs = self.pack_meta = None
         self.graphs = {}               # (shape key) -> captured hipGraph of one forward (enable_hip_graph)
@@ -147,6 +152,9 @@ class DecentralPlannerGATNet(nn.Module):
             self.actionsMLP = nn.Sequential(nn.Linear(width, numAction))
         self.apply(weights_init)
         self._rt = _Runtime()
+        # layer magnitudes the activation scales are folded from: {"digest", "absmax", "source"}.  Unlike _rt it IS pickled: a
+        # spawned worker that unpickles the same weights folds the same exponents without measuring anything
+        self._cal = None
 
     # ------------------------------------------------------------------ pickling (spawned workers)
     def __getstate__(self):
@@ -158,6 +166,7 @@ class DecentralPlannerGATNet(nn.Module):
     def __setstate__(self, st):
         super().__setstate__(st)
         self._rt = _Runtime()
+        self.__dict__.setdefault("_cal", None)       # (modules pickled before the calibration record existed)
 
     # ------------------------------------------------------------------ boundary
     def addGSO(self, S):
@@ -362,6 +371,7 @@ class DecentralPlannerGATNet(nn.Module):
             rt.pack_host, rt.pack_offs, rt.pack_meta = pack, offs, meta
             rt.pack = torch.cat((pack, torch.zeros(enc.SCALED_BLOCK_FLOATS))).to(dev)
             rt.calibrated, rt.act_scales = False, None
+            rt.digest = hashlib.blake2b(pack.numpy().tobytes(), digest_size=16).hexdigest()
             self.GFL[0]._scratch.x_scale = 0.0
             d = nat.EncoderDesc()
             d.variant, d.H, d.W = meta["variant"], meta["H"], meta["W"]
@@ -406,16 +416,28 @@ class DecentralPlannerGATNet(nn.Module):
         rt.key = key
         return rt
 
-    def _calibrate(self, rt, x, feat, comp, nfm, G, M, dev, stream):
-        """include/magat_hip.h "Activation scales": magat_encoder_calibrate_f32 on the batch at hand, then the scale block
-        (encoder.fold_activation_scales) into the pack and the graph layer's input scale into its status block.
-        One host synchronisation per set of weights."""
+    def _measure(self, rt, x, dev):
+        """magat_encoder_calibrate_f32 over the agent rows x (M, 3, W, H): ONE float32 pass (the guard's layer-by-layer
+        kernels) that leaves the largest |output| of every layer in absmax[16].  Own scratch: nothing of the forward's
+        buffers is touched.  Returns the DEVICE tensor (no synchronisation here)."""
         lib = nat.lib()
-        absmax = torch.zeros(16, dtype=torch.float32, device=dev)
-        nat.check(lib.magat_encoder_calibrate_f32(ctypes.byref(rt.desc), nat.ptr(x), nat.ptr(feat), nfm, nat.ptr(comp), G,
-                                                  nat.ptr(rt.ws), rt.ws.numel(), M, nat.ptr(absmax), stream),
-                  "magat_encoder_calibrate_f32")
-        a = absmax.cpu().tolist()
+        M = x.shape[0]
+        with torch.cuda.device(dev):
+            stream = nat.current_stream(dev)
+            ws = torch.empty(lib.magat_encoder_workspace_bytes(ctypes.byref(rt.desc), M), dtype=torch.uint8, device=dev)
+            ws[:256].zero_()
+            feat = torch.empty(M, self.numFeatureMap, dtype=torch.float32, device=dev)
+            comp = torch.empty(M, self.numFeatures2Share, dtype=torch.float32, device=dev)
+            absmax = torch.zeros(16, dtype=torch.float32, device=dev)
+            nat.check(lib.magat_encoder_calibrate_f32(ctypes.byref(rt.desc), nat.ptr(x), nat.ptr(feat), self.numFeatureMap,
+                                                      nat.ptr(comp), self.numFeatures2Share, nat.ptr(ws), ws.numel(), M,
+                                                      nat.ptr(absmax), stream), "magat_encoder_calibrate_f32")
+        return absmax
+
+    def _fold_scales(self, rt, dev):
+        """self._cal["absmax"] -> the scale block (encoder.fold_activation_scales) behind the pack and the graph layer's
+        input scale: host arithmetic on 16 floats, the same in every process that holds the same weights and magnitudes."""
+        a = list(self._cal["absmax"])
         blk, info = enc.fold_activation_scales(rt.pack_host, rt.pack_offs, rt.pack_meta, a) if rt.pack_meta.get("chain3", 0) \
             else (None, {})
         if blk is not None:
@@ -426,9 +448,52 @@ class DecentralPlannerGATNet(nn.Module):
         # steps of ~1e3 - only the float32 form, which rounds in the reference's own order, still follows the reference there
         e_x = max(0, enc.scale_exponent(a[8], target_log2=6))
         self.GFL[0]._scratch.x_scale = 2.0 ** e_x
-        info.update(gat_in=e_x, absmax=[float(v) for v in a[:9]])
+        info.update(gat_in=e_x, absmax=[float(v) for v in a[:9]], source=self._cal["source"])
         rt.act_scales = info
         rt.calibrated = True
+        rt.graphs.clear()
+
+    def _ensure_calibrated(self, rt, dev):
+        """Activation scales for the current weights (include/magat_hip.h "Activation scales").  The magnitudes come from
+        (1) self._cal when it belongs to these weights (an explicit calibrate(), or inherited through pickling), else
+        (2) ONE float32 pass over the canonical batch synthetic.calibration_states(FOV, CAL_AGENTS, seed 0): a function of the
+        config alone, so every rank / spawned worker / fresh module with the same state_dict folds the SAME exponents -
+        the logits of a planning instance do not depend on which batch or shard a process happened to see first (SURVEY.md
+        section 8(e): shards concatenate bit-exactly to the single-process result).  One host synchronisation per set of
+        weights.  Inputs that drive a layer 64x beyond the measured magnitude leave the planes and are re-run in float32 by
+        the range guard (range_status() counts it); calibrate(x) measures on the caller's own data instead."""
+        if self._cal is None or self._cal.get("digest") != rt.digest:
+            from .synthetic import calibration_states
+            xc = calibration_states(self.config.FOV, CAL_AGENTS, seed=0).to(dev)
+            self._cal = {"digest": rt.digest, "absmax": self._measure(rt, xc, dev).cpu().tolist(), "source": "canonical"}
+        self._fold_scales(rt, dev)
+
+    @torch.no_grad()
+    def calibrate(self, x=None, group=None):
+        """Explicit calibration of the activation scales (optional; the default is the canonical batch, see
+        _ensure_calibrated).  x: state tensors (B, N, 3, W, H) or (M, 3, W, H) on the model's device, None = the canonical
+        batch.  With torch.distributed initialised the measured magnitudes are all-reduced (MAX) over `group`, so that ranks
+        that calibrate on their own shards still agree on every exponent.  The result stays with the module (it is pickled
+        with it) until the weights change; returns range_status()["act_scales"]."""
+        import torch.distributed as dist
+        dev = torch.device(self.config.device)
+        rt = self._refresh(dev)
+        if rt.desc.variant not in (0, 1) or os.environ.get("MAGAT_ACT_SCALE", "1") != "1":
+            return None
+        if x is None:
+            from .synthetic import calibration_states
+            xr, source = calibration_states(self.config.FOV, CAL_AGENTS, seed=0).to(dev), "canonical"
+        else:
+            side = self.config.FOV + 2
+            xr, source = x.reshape(-1, 3, side, side).to(dev).contiguous().float(), "user"
+        absmax = self._measure(rt, xr, dev)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            red = absmax if dist.get_backend(group) != "gloo" else absmax.cpu()
+            dist.all_reduce(red, op=dist.ReduceOp.MAX, group=group)
+            absmax = red
+        self._cal = {"digest": rt.digest, "absmax": absmax.cpu().tolist(), "source": source}
+        self._fold_scales(rt, dev)
+        return rt.act_scales
 
     def _buf(self, name, shape, dev):
         t = self._rt.buffers.get(name)
@@ -465,10 +530,10 @@ class DecentralPlannerGATNet(nn.Module):
                 rt.ws = torch.empty(need, dtype=torch.uint8, device=dev)
                 rt.ws[:256].zero_()          # range-guard status block (magat_encoder_read_status)
             if not rt.calibrated and rt.desc.variant in (0, 1) and os.environ.get("MAGAT_ACT_SCALE", "1") == "1":
-                # first forward with these weights: ONE extra float32 pass that measures every layer's magnitude; the
-                # power-of-two activation scales of the split arithmetic are folded from it.  The forward itself then runs
-                # like every later one (same kernels, same scales: identical inputs give identical bits from the first call on)
-                self._calibrate(rt, x, feat, comp, nfm, G, M, dev, stream)
+                # first forward with these weights: the power-of-two activation scales of the split arithmetic are folded
+                # from the canonical calibration batch (or from an explicit / inherited calibration) - never from the batch
+                # at hand, so the forward runs like every later one and like every other process with these weights
+                self._ensure_calibrated(rt, dev)
             nat.check(lib.magat_encoder_forward_f32(ctypes.byref(rt.desc), nat.ptr(x), nat.ptr(feat), nfm,
                                                     nat.ptr(comp), G, nat.ptr(rt.ws), rt.ws.numel(), M, stream),
                       "magat_encoder_forward_f32")
@@ -528,7 +593,20 @@ class DecentralPlannerGATNet(nn.Module):
             d.M, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad, d.Hout, d.Wout = M, 1, 1, 1, 1, 1, 0, 1, 1
             d.Cout, d.ldc, d.relu = nout, nout, 1 if self.config.use_dropout else 0
             d.tag = nat.TAG_ACTIONS
-            nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), stream), "magat_conv_gemm_f32(actionsMLP.0)")
+            rc = lib.magat_conv_gemm_f32(ctypes.byref(d), stream)
+            if rc == -2 and rows16:
+                # MAGAT_ERR_UNSUPPORTED: only the streamed-dot-product kernel reads bf16 rows, and it declined (its weight
+                # block exceeds 64 KB of LDS: e.g. CNN_mode Default with skipConcat at a large FOV): widen the rows and take
+                # the float32 kernel instead of failing the forward
+                nat.check(lib.magat_cast_rows(nat.ptr(gat_rows), nat.ptr(gat), 0, M, self.gat_width, self.gat_width,
+                                              self.gat_width, stream), "magat_cast_rows")
+                if d.C2:
+                    d.in2, d.lda2 = gat.data_ptr(), gat.stride(0)
+                else:
+                    d.inp, d.lda = gat.data_ptr(), gat.stride(0)
+                d.bf16_rows = 0
+                rc = lib.magat_conv_gemm_f32(ctypes.byref(d), stream)
+            nat.check(rc, "magat_conv_gemm_f32(actionsMLP.0)")
             if self.config.use_dropout:
                 out2 = torch.empty(M, rt.act[2].shape[0], dtype=torch.float32, device=dev)
                 nat.check(lib.magat_linear_f32(nat.ptr(out), nout, nat.ptr(rt.act[2]), nat.ptr(rt.act[3]),

@@ -30,6 +30,28 @@ def fov_states(B, N, seed=1337, fov=9):
     return x
 
 
+def calibration_states(fov=9, agents=2048, seed=0):
+    """The CANONICAL calibration batch of the split arithmetic's activation scales (planner._calibrate): `agents` state
+    tensors (agents, 3, fov+2, fov+2) that depend on nothing but (fov, agents, seed) - every process that holds the same
+    weights measures the same layer magnitudes from it, whatever batch or shard it is given first.  Same three binary
+    channels as fov_states (obstacles / goal / neighbouring agents, AgentState.toInputTensor 'Project_G':
+    dataloader/statetransformer_Guidance.py:185-239), with the obstacle and agent densities swept per agent over the range
+    the maps of SURVEY.md section 8 span (0 .. 0.3 obstacles, 0 .. 0.5 agents) and the goal either inside the field of
+    view or projected onto its border ring."""
+    g = torch.Generator().manual_seed(seed)
+    w = fov + 2
+    x = torch.zeros(agents, 3, w, w)
+    d_obs = torch.linspace(0.0, 0.3, agents)[torch.randperm(agents, generator=g)].view(-1, 1, 1)
+    d_agt = torch.linspace(0.0, 0.5, agents)[torch.randperm(agents, generator=g)].view(-1, 1, 1)
+    x[:, 0, 1:-1, 1:-1] = (torch.rand(agents, fov, fov, generator=g) < d_obs).float()
+    x[:, 2, 1:-1, 1:-1] = (torch.rand(agents, fov, fov, generator=g) < d_agt).float()
+    x[:, 2, w // 2, w // 2] = 1.0
+    gy = torch.randint(0, w, (agents,), generator=g)
+    gx = torch.randint(0, w, (agents,), generator=g)
+    x[torch.arange(agents), 1, gy, gx] = 1.0
+    return x
+
+
 def comm_gso(B, N, map_w, comm_radius=7.0, seed=1337, dtype=torch.float32, normalize=True):
     """Uniform integer positions on a map_w x map_w grid, W = (dist < R) with zero diagonal,
     S = W / lambda_max(W) (symmetric, so eigvalsh)."""

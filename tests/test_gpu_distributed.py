@@ -22,14 +22,18 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, B, N, ret):
+def _worker(rank, world, port, B, N, ret, backend="nccl", one_device=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    idx = 0 if one_device else rank
+    torch.cuda.set_device(idx)
+    dev = torch.device("cuda", idx)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         sys.path.insert(0, ROOT)
         from magat_pathplanning_amd import DecentralPlannerGATNet, _native
@@ -42,12 +46,21 @@ def _worker(rank, world, port, B, N, ret):
         net = DecentralPlannerGATNet(cfg)
         net.load_state_dict(orc.init_state_dict(cfg, seed=5))
         net = net.to(dev).eval()
-        x, S = fov_states(B, N, seed=3).to(dev), comm_gso(B, N, 28, seed=4).to(dev)
+        x, S = fov_states(B, N, seed=3), comm_gso(B, N, 28, seed=4).to(dev)
+        # the shards differ in magnitude (sparse maps in the first half of the batch, saturated ones in the second): every
+        # rank's FIRST batch is its own shard, and the exponents of the split arithmetic must not follow it
+        x[: B // 2, :, 0] *= 0.0
+        x[B // 2:, :, 0, 1:-1, 1:-1] = 1.0
+        x[B // 2:, :, 2, 1:-1, 1:-1] = 1.0
+        x = x.to(dev)
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
         assert int(ones.item()) == world
         with torch.no_grad():
             full = sharded_forward(net, x, S.clone(), gather=True)
+            scales = [None] * world
+            dist.all_gather_object(scales, net.range_status()["act_scales"])
+            assert all(s == scales[0] for s in scales) and scales[0]["source"] == "canonical", scales
             local = sharded_forward(net, x, S.clone(), gather=False)
             b0, b1 = shard_range(B, rank, world)
             assert local.shape[0] == (b1 - b0) * N
@@ -77,6 +90,18 @@ def test_sharded_forward_hip_over_rccl(gpu_device, world):
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_worker, args=(world, _free_port(), 6, 20, ret), nprocs=world, join=True)
+        assert ret.get("ok")
+
+
+def test_two_processes_share_one_gpu(gpu_device):
+    """World size 2 WITHOUT a second GPU: two spawned processes drive the same device (the HIP forward of each rank's shard
+    runs on it; gloo carries the barrier and the gather).  Each process builds its own module, folds its own activation
+    scales and sees only its own - deliberately unlike - shard first: the gathered logits equal the single-process result
+    bit for bit."""
+    import torch.multiprocessing as mp
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(2, _free_port(), 6, 20, ret, "gloo", True), nprocs=2, join=True)
         assert ret.get("ok")
 
 

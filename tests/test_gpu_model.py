@@ -102,6 +102,95 @@ def test_shard_equivalence_and_pickle(gpu_device):
         assert torch.equal(clone(x), full)
 
 
+def _two_unlike_shards(device, B=6, N=20):
+    """A batch whose halves drive the layers to clearly different magnitudes (sparse maps first, saturated maps second): under
+    a first-batch calibration the two halves would fold different activation-scale exponents."""
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states
+    x = fov_states(B, N, seed=21)
+    h = B // 2
+    x[:h, :, 0] *= 0.0                                   # no obstacles, few agents
+    x[:h, :, 2, 1:-1, 1:-1] *= 0.0
+    x[h:, :, 0, 1:-1, 1:-1] = 1.0                        # every cell an obstacle / an agent
+    x[h:, :, 2, 1:-1, 1:-1] = 1.0
+    S = comm_gso(B, N, 28, seed=22)
+    return x.to(device), S.to(device), h
+
+
+def test_shard_order_and_process_history_do_not_change_the_bits(gpu_device):
+    """VERDICT r03 item 1 / SURVEY.md section 8(e): the logits of a planning instance must not depend on which shard a
+    process saw FIRST.  Two fresh modules with one state_dict, one fed shard A first, the other shard B first, and a third
+    that sees the whole batch: concat(a, b) == full bit for bit, and all three fold the same activation-scale exponents
+    (they come from the canonical calibration batch, a function of the config alone).  The same with pickled clones whose
+    first batch differs from the parent's - how torch.multiprocessing.spawn workers receive the model."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd.synthetic import make_config
+    cfg = make_config(num_agents=20, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat")
+    sd = orc.init_state_dict(cfg, seed=31)
+    x, S, h = _two_unlike_shards(gpu_device)
+    nets = [_build(cfg, sd, gpu_device) for _ in range(3)]
+    with torch.no_grad():
+        nets[0].addGSO(S[:h].contiguous())
+        a = nets[0](x[:h]).clone()                       # rank 0: shard A is its first batch
+        nets[1].addGSO(S[h:].contiguous())
+        b = nets[1](x[h:]).clone()                       # rank 1: shard B is its first batch
+        nets[2].addGSO(S.clone())
+        full = nets[2](x).clone()                        # single process: the whole batch
+        # ... and each of them on the OTHER shard afterwards
+        nets[0].addGSO(S[h:].contiguous())
+        b0 = nets[0](x[h:]).clone()
+        nets[1].addGSO(S[:h].contiguous())
+        a1 = nets[1](x[:h]).clone()
+    assert torch.equal(torch.cat((a, b)), full)
+    assert torch.equal(torch.cat((a1, b0)), full)
+    sc = [n.range_status()["act_scales"] for n in nets]
+    assert sc[0] is not None and sc[0]["source"] == "canonical"
+    assert sc[0] == sc[1] == sc[2], sc
+    # a clone pickled BEFORE its parent has seen anything, first batch = shard B; one pickled after, first batch = shard A
+    parent = _build(cfg, sd, gpu_device)
+    early = pickle.loads(pickle.dumps(parent))
+    with torch.no_grad():
+        parent.addGSO(S[:h].contiguous())
+        pa = parent(x[:h]).clone()
+        early.addGSO(S[h:].contiguous())
+        eb = early(x[h:]).clone()
+        late = pickle.loads(pickle.dumps(parent))
+        late.addGSO(S[h:].contiguous())
+        lb = late(x[h:]).clone()
+    assert torch.equal(torch.cat((pa, eb)), full) and torch.equal(lb, eb)
+    assert late.range_status()["act_scales"] == sc[0]
+
+
+def test_explicit_calibration_travels_with_the_module(gpu_device):
+    """model.calibrate(x): magnitudes measured on the caller's own data (source 'user').  They are pickled with the module,
+    so a clone reproduces the parent's bits on ANY batch without having seen the calibration data; a weight change drops
+    them (back to the canonical batch)."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd.synthetic import make_config
+    cfg = make_config(num_agents=20, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat")
+    sd = orc.init_state_dict(cfg, seed=32)
+    x, S, h = _two_unlike_shards(gpu_device)
+    net = _build(cfg, sd, gpu_device)
+    info = net.calibrate(x[h:])
+    assert info["source"] == "user"
+    clone = pickle.loads(pickle.dumps(net))
+    with torch.no_grad():
+        net.addGSO(S.clone())
+        full = net(x).clone()
+        clone.addGSO(S[:h].contiguous())
+        a = clone(x[:h]).clone()
+        clone.addGSO(S[h:].contiguous())
+        b = clone(x[h:]).clone()
+    assert clone.range_status()["act_scales"] == net.range_status()["act_scales"]
+    assert torch.equal(torch.cat((a, b)), full)
+    ref = orc.planner_forward(x.cpu(), S.cpu().clone(), sd, cfg)
+    assert float((full.cpu() - ref).abs().max()) <= 1e-4
+    with torch.no_grad():
+        net.compressMLP[0].bias.add_(0.0)                # any in-place touch = "the weights changed"
+        net.addGSO(S.clone())
+        net(x)
+    assert net.range_status()["act_scales"]["source"] == "canonical"
+
+
 def test_shard_equivalence_across_the_head_split(gpu_device, monkeypatch, libopt):
     """The one size-dependent piece of arithmetic is the encoder head: below MAGAT_HEAD_SPLITK agents (12288) it sums nine
     per-cell partial products, above it runs one long-K GEMM.  A batch above the threshold cut into shards below it
