@@ -21,6 +21,10 @@ Rank 0 prints ONE JSON line.  `value` is measured with the library's DEFAULT ari
   c2, c5         BASELINE configs[1] and [4] (N=20 batch 1024; N=1000 CSR bf16 batch 128) as extra legs: a-s/s, ms/step and the
                  graph layer's kernels against their roofs
   per_rank_ms, ranks   every rank's own elapsed time per step and the device it ran on (`ms_per_step` is their MAX)
+  published_f32p4  the published model setting (N=10, K=2, P=4, G=32, head-mean, batch 1024) as its own leg
+  f32_strict     the headline workload with every product on the float32 matrix cores (no split planes): a-s/s and the dominant
+                 kernel against the 157.3 TF float32 MFMA roof
+  ms_per_step_device  hipEvent pair around the K timed steps on the launch stream (ms_per_step is host wall-clock over barriers)
   mx_opt_in      the same workload with the OPT-IN block-scaled-fp8 correction products (NOT fp32-class; labelled, never `value`)
   cpu_baseline   the pinned CPU oracle (kind "port") on this box's host cores: processes x threads sweep over the physical
                  cores, median of three runs of the best split, bounded sample; runs BEFORE the GPU legs
@@ -51,6 +55,9 @@ WORKLOADS = {
     # config 5: large sparse graph -> CSR kernels, bf16 storage inside the GAT layer; c5f32 = same shape, fp32 storage
     "c5": (128, 1000, 160, 2, 4, 128, "BottomNeck_only", "ResNetLarge_withMLP", True),
     "c5f32": (128, 1000, 160, 2, 4, 128, "BottomNeck_only", "ResNetLarge_withMLP", True),
+    # the PUBLISHED MAGAT setting (scripts/train_DMap.sh:42, "MAGAT F-32-P4"; the released checkpoints, README.md:385-390): 10 agents,
+    # 20x20 map, K=2, 4 heads of 32 features, head MEAN (no --AttentionConcat), BottomNeck_only; batch 1024 planning instances
+    "published_f32p4": (1024, 10, 20, 2, 4, 32, "BottomNeck_only", "ResNetLarge_withMLP", False),
 }
 GAT_STORAGE = {"c5": "bf16"}
 
@@ -179,7 +186,8 @@ def load_pmc_traffic():
     out = {}
     for k, v in d.get("layers", {}).items():
         if "hbm_bytes_per_launch" in v:
-            out[k] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.relpath(paths[-1], ROOT)}
+            out[k] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.relpath(paths[-1], ROOT),
+                      "collected": d.get("collected", "a gpurun MI355X box of the round named by the directory (builder's run)")}
     return out
 
 
@@ -253,7 +261,7 @@ def cpu_baseline(cfg, sd, N, map_w, budget_s=30.0):
     splits = []
     for th in (1, 2, 4, 8, 16, 32):
         pr = max(1, phys // th)
-        if pr * th <= logical and pr <= 64:
+        if pr * th <= logical and pr <= 256:        # (one process per physical core is part of the sweep)
             splits.append((pr, th))
     splits.append((1, min(phys, logical)))
     splits = sorted(set(splits))
@@ -381,11 +389,15 @@ def main():
             gc.collect()
             gc.freeze()
             barrier()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
+            ev0.record()                     # (torch's current stream IS the stream the library launches on)
             for _ in range(steps):
                 out = step()
+            ev1.record()
             barrier()
             elapsed = time.perf_counter() - t0
+            run_leg.device_ms = ev0.elapsed_time(ev1) / steps
             # The per-kernel times come from a SECOND pass of the same `steps` steps, right behind the timed region, with the
             # library's hipEvent pairs around every launch: ~14 pairs per step cost 2-3 % of a c3 step (same box: 2.47 ms
             # against 2.53), and the timed region is the workload, not the instrumentation.  Its own elapsed time is reported
@@ -467,6 +479,11 @@ def main():
         r = {"kernel": name, "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"], "unit": e["unit"],
              "frac": e["frac"], "traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
              "traffic_source": None if tr is None else tr["source"],
+             "traffic_collected": None if tr is None else tr["collected"],
+             # PMC counters cannot be read from inside this process: `traffic` is the committed rocprofv3 --pmc pass of the same
+             # command on ANOTHER box, bytes per launch (a property of the kernel and the workload, not of the clock) - it is
+             # NOT a measurement of this run, and hbm_traffic_gbs divides it by THIS run's time
+             "traffic_measured_in_this_run": False,
              "algorithmic_per_launch": round((e["bytes_per_agent_step"] if e["bound"] == "hbm" else
                                               e["flops_per_agent_step"]) * Bk * Nk),
              "avg_us": e["avg_us"], "launches": e["launches"]}
@@ -482,6 +499,7 @@ def main():
     timing = not args.no_kernel_timing
     elapsed, kern, per_rank_ms = run_leg(x, S, args.steps, args.warmup, timing)
     instr_ms = getattr(run_leg, "instrumented_ms", 0.0)
+    dev_ms = getattr(run_leg, "device_ms", 0.0)      # hipEvent pair around the K timed steps on the launch stream (this rank)
     # what each rank ran on: the 0.9-scaling target is decided by the slowest die, so the line names them
     props = torch.cuda.get_device_properties(dev)
     mine = {"rank": rank, "device": props.name, "cus": props.multi_processor_count,
@@ -498,7 +516,8 @@ def main():
         ariths = sorted({conv_arith(nat, cfg, l) for l in range(3)})
         res = {"metric": "agent-steps/s (batched GAT forward)", "value": round(value, 1), "unit": "agent-steps/s",
                "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": round(ms, 4), "ms_per_step_device": round(dev_ms, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "per_rank_ms": [round(v / args.steps, 4) for v in per_rank_ms], "ranks": rank_info,
                "dtype": "f32 in/out, fp32-class arithmetic: convolutions + GAT maps as %s split products on the 16-bit matrix "
                         "cores with f32 accumulation (the encoder head too, on the layer3 kernel's pooled map; with GAT_MFMA the attention "
@@ -579,7 +598,50 @@ def main():
             res[wl] = leg
             del netw, xw, Sw
             torch.cuda.empty_cache()
-        # (c) OPT-IN MX arithmetic on the headline workload, clearly labelled
+        # (c) the published model setting (N=10, K=2, 4 heads x 32 features, head-mean) as its own leg
+        Bw, Nw, mw, Kw, Pw, Gw, bmw, cnw, ccw = WORKLOADS["published_f32p4"]
+        cfgw = make_config(num_agents=Nw, nGraphFilterTaps=Kw, nAttentionHeads=Pw, bottleneckFeature=Gw, bottleneckMode=bmw,
+                           CNN_mode=cnw, AttentionConcat=ccw, device=str(dev))
+        netw = build_model(cfgw, dev)
+        xw, Sw = fov_states(Bw, Nw, seed=13).to(dev), comm_gso(Bw, Nw, mw, seed=14).to(dev)
+        el, kw, _ = run_leg(xw, Sw, esteps, 3, timing, net=netw)
+        leg = {"workload": "published MAGAT F-32-P4 (scripts/train_DMap.sh:42): N=%d, %dx%d map, K=%d, P=%d, G=F=%d, head-mean, "
+                           "BottomNeck_only, batch %d" % (Nw, mw, mw, Kw, Pw, Gw, Bw),
+               "steps": esteps, "value": round(Bw * Nw * esteps / el, 1), "unit": "agent-steps/s",
+               "ms_per_step": round(el / esteps * 1e3, 4), "ms_per_step_device": round(getattr(run_leg, "device_ms", 0.0), 4),
+               "graph_layer_one_launch": bool(lib.magat_gat_one_launch_supported(Nw, Gw, Gw, Kw, 0, 0))}
+        if timing:
+            tw = kernel_table(kw, esteps, Bw, Nw, Sw, {}, cfg=cfgw)
+            keep = ("avg_us", "ms_per_step", "launches", "bound", "achieved", "peak", "unit", "frac", "bytes_per_agent_step")
+            leg["kernels"] = {k: {q: v[q] for q in keep if q in v} for k, v in tw.items()}
+        res["published_f32p4"] = leg
+        del netw, xw, Sw
+        torch.cuda.empty_cache()
+        # (d) STRICT float32: every product on the float32 matrix cores (v_mfma_f32_32x32x2_f32, 157.3 TF peak) - no split
+        # planes anywhere (CONV_SPLIT=0, HEAD_F16=0, GAT_SPLIT=0, GAT_MFMA=0).  The headline's f16x3 arithmetic is fp32-CLASS
+        # (22-bit products, fp32 accumulation, measured error = this form's); this leg is the number a reader who wants
+        # IEEE float32 products gets from the same library
+        strict = {"CONV_SPLIT": 0, "HEAD_F16": 0, "GAT_SPLIT": 0, "GAT_MFMA": 0}
+        for k_, v_ in strict.items():
+            nat.set_option(k_, v_)
+        nets = build_model(cfg, dev)
+        el, ks_, _ = run_leg(x, S, esteps, ewarm, timing, net=nets)
+        f32 = {"options": strict, "steps": esteps, "value": round(B * N * esteps / el, 1), "unit": "agent-steps/s",
+               "ms_per_step": round(el / esteps * 1e3, 4), "ms_per_step_device": round(getattr(run_leg, "device_ms", 0.0), 4),
+               "arithmetic": ARITH["f32"][1]}
+        if timing:
+            ts = kernel_table(ks_, esteps, B, N, S, {})
+            bounded = [k for k, v in ts.items() if "bound" in v and k != "gat_prepare"]
+            if bounded:
+                dom = max(bounded, key=lambda k: ts[k]["ms_per_step"])
+                f32["roofline"] = roof(ts, dom, B, N, {})
+            f32["kernels_ms_per_step"] = {k: v["ms_per_step"] for k, v in ts.items()}
+        res["f32_strict"] = f32
+        for k_ in strict:
+            nat.reset_option(k_)
+        del nets
+        torch.cuda.empty_cache()
+        # (e) OPT-IN MX arithmetic on the headline workload, clearly labelled
         nat.set_option("CONV_MX", 1)
         if conv_arith(nat, cfg, 1) == "f16+mxfp8":
             el, _, _ = run_leg(x, S, esteps, ewarm, False)

@@ -41,6 +41,11 @@ extern "C" {
                                      magat_gnn_forward_csr_f32; P = 1, taps = weight (F,1,K,G), no ReLU inside the layer) */
 
 int magat_abi_version(void);
+/* 0 = release build.  1 = EXPERIMENT build: at least one source was compiled with timing-experiment switches (*_WHATIF_*:
+ * phases of a kernel replaced by register sinks - the results are WRONG by design; tools/whatif_*.sh).  Such a source only
+ * compiles under -DMAGAT_EXPERIMENT_BUILD, which also marks the library here; the Python binding refuses to load a library
+ * whose flavor is not 0 unless MAGAT_ALLOW_EXPERIMENT_BUILD=1 (the probe scripts set it). (ABI 4) */
+int magat_build_flavor(void);
 const char* magat_error_string(int code);
 
 /* Options.  Every tunable of the library lives in one table that is seeded from the environment (MAGAT_<NAME>) ONCE, at

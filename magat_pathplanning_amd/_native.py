@@ -73,6 +73,7 @@ class SimStepDesc(ctypes.Structure):
 _I, _P, _Z = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 _SIGNATURES = {
     "magat_abi_version": (ctypes.c_int, []),
+    "magat_build_flavor": (ctypes.c_int, []),
     "magat_error_string": (ctypes.c_char_p, [_I]),
     "magat_set_option": (_I, [ctypes.c_char_p, _I]),
     "magat_get_option": (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
@@ -150,6 +151,11 @@ def lib():
                 for name, (res, args) in _SIGNATURES.items():
                     fn = getattr(handle, name)
                     fn.restype, fn.argtypes = res, args
+                if handle.magat_build_flavor() != 0 and os.environ.get("MAGAT_ALLOW_EXPERIMENT_BUILD", "0") != "1":
+                    raise MagatNativeError(
+                        "%s is an EXPERIMENT build (compiled with *_WHATIF_* timing switches: its results are wrong by "
+                        "design).  Rebuild with `python -m magat_pathplanning_amd.build_native --force`; the timing probes "
+                        "under tools/ set MAGAT_ALLOW_EXPERIMENT_BUILD=1." % LIB_PATH)
                 _lib = handle
     return _lib
 

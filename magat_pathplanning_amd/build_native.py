@@ -15,8 +15,7 @@ LIB_DEBUG = os.path.join(PKG, "lib", "libmagat_hip_debug.so")
 SOURCES = ["conv_gemm_f32.hip", "conv_gemm_bf16x6.hip", "block_fused.hip", "gat_f32.hip", "gat_mfma.hip", "gat_csr_f32.hip",
            "encoder_f32.hip", "layer1_fused.hip", "sim_frontend.hip", "profile.hip", "options.hip"]
 HEADERS = ["magat_common.h", os.path.join("..", "..", "include", "magat_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value", *os.environ.get("MAGAT_EXTRA_FLAGS", "").split(),
-         "-Wno-inline-asm"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value", "-Wno-inline-asm"]
 # block_fused.hip: MFMA results in architectural registers wherever they fit (the chain kernel has all 512 registers of a SIMD to one wave:
 # the epilogues then read the accumulators as plain operands instead of through v_accvgpr_read; chain kernel -0.9 % same-box).  The graph
 # kernel is slower and loses its spill-free allocation under the same flag, so it is per source.
@@ -40,7 +39,9 @@ def build(force=False, verbose=False, debug=False):
     objdir = os.path.join(PKG, "lib", "obj_debug" if debug else "obj")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    flags = FLAGS + (["-DMAGAT_DEBUG_HOOKS"] if debug else [])
+    # MAGAT_EXTRA_FLAGS (kernel experiments, tools/whatif_*.sh, tools/ab_flags.sh) reaches the DEBUG library only: the release
+    # library libmagat_hip.so is always built from the sources as they are
+    flags = FLAGS + (["-DMAGAT_DEBUG_HOOKS"] + os.environ.get("MAGAT_EXTRA_FLAGS", "").split() if debug else [])
     jobs, objs = [], []
     for s in _sources():
         src = os.path.join(CSRC, s)

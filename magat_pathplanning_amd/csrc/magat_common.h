@@ -9,6 +9,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Timing-experiment switches (*_WHATIF_*: a phase of a kernel replaced by a register sink or a constant - wrong results by
+// design; tools/whatif_*.sh, tools/csr_layer_bench.py) compile only into an EXPERIMENT build: the source must be compiled
+// with -DMAGAT_EXPERIMENT_BUILD, which marks the library (magat_build_flavor() = 1; the Python binding refuses to load it
+// unless MAGAT_ALLOW_EXPERIMENT_BUILD=1).  A release build - build_native.build() without --debug - never passes extra
+// flags, so a stray environment variable cannot produce a silently wrong libmagat_hip.so.
+#if (defined(MAGAT_WHATIF_NO_W) || defined(MAGAT_WHATIF_NO_LDS) || defined(CSR_WHATIF_NODMA) || defined(CSR_WHATIF_NOLOOP) || \
+     defined(GM_WHATIF_NOQW) || defined(GM_WHATIF_NOAW) || defined(GM_WHATIF_NOYST)) && !defined(MAGAT_EXPERIMENT_BUILD)
+#error "*_WHATIF_* timing switches produce wrong results: they compile only with -DMAGAT_EXPERIMENT_BUILD (see magat_common.h)"
+#endif
+extern "C" int magat_experiment_mark(void);      // options.hip
+#ifdef MAGAT_EXPERIMENT_BUILD
+namespace { struct MagatExperimentMark { MagatExperimentMark() { magat_experiment_mark(); } } g_magat_experiment_mark; }
+#endif
+
 #define MAGAT_WAVE 64
 #define MAGAT_TILE_ROWS 128   // agent-tile height of the tile-major activation layout
 // element offset of row m: (m / 128) * tile_stride + (m % 128) * ld

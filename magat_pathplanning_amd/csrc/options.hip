@@ -71,6 +71,10 @@ int magat_opt(int id) {
   return (id >= 0 && id < MAGAT_OPT_COUNT) ? g_val[id] : 0;
 }
 
+static int g_experiment_build = 0;
+extern "C" int magat_experiment_mark(void) { g_experiment_build = 1; return 0; }
+extern "C" int magat_build_flavor(void) { return g_experiment_build; }
+
 extern "C" int magat_set_option(const char* name, int value) {
   if (!name) return MAGAT_ERR_NULL;
   std::call_once(g_once, init_opts);

@@ -247,8 +247,53 @@ def main_fov():
         print("wrote", path, os.path.getsize(path) // 1024, "KB")
 
 
+def main_grad():
+    """Round 4: GRADIENT fixtures made by the real reference's autograd (the training step's loss.backward(),
+    agents/decentralplannerlocal_OnlineExpert_GAT.py:560-567, at the layer level): for the seven shapes of
+    tests/test_gpu_kernels.py::test_gat_training_backward_* - all three attention modes, concat and mean, K = 1..4 - over
+    DIRECTED GSOs (synthetic.directed_gso: asymmetric masks, a one-way edge into an isolated node, threshold entries, a NaN),
+    loss = sum(y * wgt) with a seeded weighting: y, dL/dx and dL/d(parameter) of GraphFilterBatchAttentional(_Origin) run
+    in float64 (the reference's own code on double tensors: a reference tighter than float32 rounding, so the HIP backward
+    is compared with the REFERENCE's gradients, not with this package's composite)."""
+    from magat_pathplanning_amd.synthetic import directed_gso
+    gml, _ = import_reference()
+    cases = [("KeyQuery", True, 12, 64, 3, 2), ("KeyQuery", False, 20, 128, 2, 4), ("GAT_modified", True, 9, 32, 4, 3),
+             ("KeyQuery", True, 30, 16, 1, 2), ("GAT_modified", False, 40, 128, 3, 2), ("GAT_origin", True, 14, 32, 3, 4),
+             ("GAT_origin", False, 25, 64, 2, 2)]
+    for si, (mode, concat, N, G, K, P) in enumerate(cases):
+        seed = 8337 + 23 * si
+        gen = torch.Generator().manual_seed(seed)
+        torch.manual_seed(seed)
+        cls = gml.GraphFilterBatchAttentional_Origin if mode == "GAT_origin" else gml.GraphFilterBatchAttentional
+        layer = cls(G, G, K, P, 1, True, concatenate=concat, attentionMode=mode)
+        with torch.no_grad():
+            if mode != "GAT_origin":
+                layer.weight_bias.uniform_(-0.3, 0.3, generator=gen)
+        layer = layer.double()          # (parameters, x and wgt are float32 values: the fixture stores them losslessly as float32)
+        B = 3
+        x = (torch.randn(B, G, N, generator=gen) * 0.6).double().requires_grad_(True)
+        S = directed_gso(B, N, 0.3 if N <= 20 else 0.12, seed=seed + 1, dtype=torch.float64).unsqueeze(1)
+        wgt = torch.randn(B, P * G if concat else G, N, generator=gen).double()
+        layer.addGSO(S)
+        y = layer(x)
+        (y * wgt).sum().backward()
+        f32 = lambda t: t.detach().numpy().astype(np.float32)
+        assert all(np.array_equal(f32(t).astype(np.float64), t.detach().numpy()) for t in [x, wgt] + list(layer.parameters()))
+        out = dict(x=f32(x), S=S.numpy(), wgt=f32(wgt), y=f32(y), dx=f32(x.grad),
+                   mode=np.array(mode), concat=np.int64(concat), N=N, G=G, K=K, P=P)
+        for k, v in layer.named_parameters():
+            out["p_" + k] = f32(v)
+            out["g_" + k] = f32(v.grad if v.grad is not None else torch.zeros_like(v))
+        path = os.path.join(OUT, "grad_%s_%s_N%d_G%d_K%d_P%d.npz" % (mode, "concat" if concat else "mean", N, G, K, P))
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path) // 1024, "KB", {k: float(np.abs(v).max()) for k, v in out.items()
+                                                                    if k.startswith("g_") or k == "dx"})
+
+
 if __name__ == "__main__":
-    if "--fov" in sys.argv:
+    if "--grad" in sys.argv:
+        main_grad()
+    elif "--fov" in sys.argv:
         main_fov()
     elif "--directed" in sys.argv:
         main_directed()

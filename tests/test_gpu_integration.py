@@ -55,9 +55,14 @@ def _reference_layer(z, p, device, concat, s64):
 @pytest.mark.parametrize("concat", [True, False], ids=["concat", "mean"])
 @pytest.mark.parametrize("path", LAYER, ids=[os.path.basename(p)[4:-4] for p in LAYER])
 def test_documented_dense_binding_vs_reference_vectors(gpu_device, stub, path, concat, s64):
+    from magat_pathplanning_amd import _native as nat
     z, p = load_layer_fixture(path)
     if z["S"].dtype == np.float64 and not s64:
         pytest.skip("fixture's GSO holds float64-only entries")
+    if not nat.lib().magat_gat_dense_supported(int(z["N"]), int(z["G"]), int(z["G"])):
+        # (N x G beyond the LDS-resident kernel, e.g. N = 128 at 128 features: the *_csr_* entry points take it - the stub
+        #  would raise the RuntimeError it documents, see test_documented_binding_reports_errors_as_codes)
+        pytest.skip("shape outside magat_gat_dense_supported")
     me = _reference_layer(z, p, gpu_device, concat, s64)
     x = torch.from_numpy(z["x"]).to(gpu_device)
     want = z["y_concat" if concat else "y_mean"]

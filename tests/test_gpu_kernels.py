@@ -476,6 +476,50 @@ def test_gat_training_backward_matches_autograd(gpu_device, mode, concat, N, G, 
         close(getattr(layer, n_).grad, getattr(ref, n_).grad, n_)
 
 
+GRAD = golden_paths("grad_")
+
+
+def _grad_fixture_layer(z, device, dtype):
+    from magat_pathplanning_amd import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin
+    mode, concat = str(z["mode"]), bool(int(z["concat"]))
+    G, K, P = int(z["G"]), int(z["K"]), int(z["P"])
+    cls = GraphFilterBatchAttentional_Origin if mode == "GAT_origin" else GraphFilterBatchAttentional
+    layer = cls(G, G, K, P, concatenate=concat, attentionMode=mode)
+    layer.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p_")})
+    return layer.to(device=device, dtype=dtype)
+
+
+@pytest.mark.parametrize("path", GRAD, ids=[os.path.basename(p)[5:-4] for p in GRAD])
+def test_gat_training_backward_vs_reference_made_gradients(gpu_device, path):
+    """the HIP training forward / backward of the layer against gradients produced by the REAL
+    reference's autograd (oracle/make_golden.py --grad: GraphFilterBatchAttentional(_Origin) of utils/graphUtils/graphML.py
+    in float64, loss.backward() as in agents/decentralplannerlocal_OnlineExpert_GAT.py:560-567) over directed GSOs: y,
+    dL/dx and every parameter gradient within 2e-4 of the gradient's scale.  (The float64-composite check above stays as
+    the second gate; tests/test_host.py pins that composite to these same vectors on the CPU.)"""
+    z = np.load(path, allow_pickle=False)
+    layer = _grad_fixture_layer(z, gpu_device, torch.float32).train()
+    xg = torch.from_numpy(z["x"]).to(gpu_device).requires_grad_(True)
+    layer.addGSO(torch.from_numpy(z["S"]).to(gpu_device))
+    y = layer(xg)
+    (y * torch.from_numpy(z["wgt"]).to(gpu_device)).sum().backward()
+    torch.cuda.synchronize()
+
+    def close(a, b, what):
+        a, b = a.detach().cpu().double(), torch.from_numpy(b).double()
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 2e-4 * scale, (what, float((a - b).abs().max()), scale)
+
+    close(y, z["y"], "y")
+    close(xg.grad, z["dx"], "dx")
+    for k in z.files:
+        if k.startswith("g_"):
+            got = getattr(layer, k[2:]).grad
+            if got is None:                      # a parameter the mode does not use: the reference's gradient is zero too
+                assert not np.any(z[k]), k
+            else:
+                close(got, z[k], k)
+
+
 def test_gat_training_backward_stress_poisoned_buffers(gpu_device):
     """`test_gat_training_backward_matches_autograd[GAT_modified-False-40-128-3-2]` once failed (dx off by
     2e-2 on a few rows) in about forty suite runs.  500 forward + backward passes of that parametrisation, every one checked

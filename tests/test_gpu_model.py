@@ -185,7 +185,11 @@ def test_explicit_calibration_travels_with_the_module(gpu_device):
     ref = orc.planner_forward(x.cpu(), S.cpu().clone(), sd, cfg)
     assert float((full.cpu() - ref).abs().max()) <= 1e-4
     with torch.no_grad():
-        net.compressMLP[0].bias.add_(0.0)                # any in-place touch = "the weights changed"
+        net.compressMLP[0].bias.add_(0.0)                # touched, same values: the record is keyed on the CONTENT of the pack
+        net.addGSO(S.clone())
+        assert torch.equal(net(x), full)
+        assert net.range_status()["act_scales"]["source"] == "user"
+        net.compressMLP[0].bias.add_(0.25)               # the weights changed: the record no longer belongs to them
         net.addGSO(S.clone())
         net(x)
     assert net.range_status()["act_scales"]["source"] == "canonical"

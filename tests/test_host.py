@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = nat.lib()                       # loads without a GPU
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.magat_abi_version() == 3
+    assert lib.magat_abi_version() == 4
     assert lib.magat_error_string(-2).decode().startswith("unsupported")
     # pure host queries work without a device
     nc = 4 * 128 + 4 * 3 * 128            # fp32 [NC][G] + column bias [NC] + bf16x3 planes [3][NC][G] + f16x2 planes + scale
@@ -106,6 +106,40 @@ def test_layer_training_composite_matches_reference(path):
     y = layer(torch.from_numpy(z["x"]))
     np.testing.assert_allclose(y.detach().numpy(), z["y_concat"], rtol=0, atol=5e-6)
     assert "attentionMode=%s" % str(z["mode"]) in repr(layer)
+
+
+GRAD = golden_paths("grad_")
+
+
+@pytest.mark.parametrize("path", GRAD, ids=[os.path.basename(p)[5:-4] for p in GRAD])
+def test_training_composite_gradients_match_reference_made_gradients(path):
+    """The float64 composite the GPU gradient tests use as their tight second gate, pinned on the CPU to gradients made by
+    the REAL reference's autograd (oracle/make_golden.py --grad; directed GSOs, all three attention modes, K = 1..4):
+    y, dL/dx and every parameter gradient to 1e-6 of the gradient's scale (the fixture stores float32)."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin
+    z = np.load(path, allow_pickle=False)
+    mode, concat = str(z["mode"]), bool(int(z["concat"]))
+    G, K, P = int(z["G"]), int(z["K"]), int(z["P"])
+    cls = GraphFilterBatchAttentional_Origin if mode == "GAT_origin" else GraphFilterBatchAttentional
+    layer = cls(G, G, K, P, concatenate=concat, attentionMode=mode)
+    layer.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p_")})
+    layer = layer.double()
+    x = torch.from_numpy(z["x"]).double().requires_grad_(True)
+    layer.addGSO(torch.from_numpy(z["S"]))
+    y = layer(x)
+    (y * torch.from_numpy(z["wgt"]).double()).sum().backward()
+
+    def close(a, b, what):
+        b = torch.from_numpy(b).double()
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a.detach() - b).abs().max()) <= 1e-6 * scale, (what, float((a.detach() - b).abs().max()), scale)
+
+    close(y, z["y"], "y")
+    close(x.grad, z["dx"], "dx")
+    for k in z.files:
+        if k.startswith("g_"):
+            g = getattr(layer, k[2:]).grad
+            close(torch.zeros_like(getattr(layer, k[2:])) if g is None else g, z[k], k)
 
 
 def test_module_pickles_without_device_state():

@@ -6,13 +6,11 @@ cd $(dirname $0)/..
 SRC=${SRC:-block_fused.hip}
 IFS="|" read -ra VARS <<< "|${FLAG_LIST}|x"; unset "VARS[${#VARS[@]}-1]"; VARS+=("")
 for F in "${VARS[@]}"; do
-  touch magat_pathplanning_amd/csrc/$SRC
-  MAGAT_EXTRA_FLAGS="$F" python -m magat_pathplanning_amd.build_native > /dev/null 2>&1 || { echo "build failed: $F"; continue; }
-  python bench.py --no-cpu-baseline --no-extra-legs --steps 30 --warmup 5 2>/dev/null | python -c "
+  bash tools/build_variant.sh ab $SRC "$F" > /dev/null 2>&1 || { echo "build failed: $F"; continue; }
+  MAGAT_LIB_PATH=magat_pathplanning_amd/lib/libmagat_hip_ab.so python bench.py --no-cpu-baseline --no-extra-legs --steps 30 --warmup 5 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
 ks = [k for k in d['kernels'] if any(s in k for s in '''${KERNELS:-layer}'''.split('|'))]
 print('flags [%s]: %.4f ms/step  ' % ('''$F''', d['ms_per_step']) + '  '.join('%s %.1f us' % (k, d['kernels'][k]['avg_us']) for k in ks))"
 done
-touch magat_pathplanning_amd/csrc/$SRC
-python -m magat_pathplanning_amd.build_native > /dev/null 2>&1
+rm -f magat_pathplanning_amd/lib/libmagat_hip_ab.so

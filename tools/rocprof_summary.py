@@ -179,6 +179,11 @@ def main():
                                                               v["hbm_write_bytes_per_launch"] / 1e6))
     with open(os.path.join(out, "summary_%s.txt" % tag), "w") as f:
         f.write("\n".join(lines) + "\n")
+    import datetime
+    import socket
+    # provenance of the PMC bytes bench.py quotes as `roofline.traffic` (they are read from THIS file on other boxes)
+    res["collected"] = "rocprofv3 --pmc passes of tools/profile_round.sh on gpurun box %s, %s UTC" % (
+        socket.gethostname(), datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M"))
     with open(os.path.join(out, "summary_%s.json" % tag), "w") as f:
         json.dump(res, f, indent=1)
     print("\n".join(lines))

@@ -6,10 +6,10 @@
 cd $(dirname $0)/..
 for V in ${WHATIF_LIST:-NONE NO_LDS NO_W}; do
   touch magat_pathplanning_amd/csrc/block_fused.hip
-  F=""; for X in ${V//+/ }; do [ $X = NONE ] || F="$F -DMAGAT_WHATIF_$X"; done
+  F="-DMAGAT_EXPERIMENT_BUILD"; for X in ${V//+/ }; do [ $X = NONE ] || F="$F -DMAGAT_WHATIF_$X"; done
   MAGAT_EXTRA_FLAGS="$F" python -m magat_pathplanning_amd.build_native --debug > /dev/null 2>&1 || { echo "build failed $V"; continue; }
   echo "== $V"
-  MAGAT_LIB_PATH=magat_pathplanning_amd/lib/libmagat_hip_debug.so python tools/chain_phase_probe.py 2>&1 | tail -20
+  MAGAT_ALLOW_EXPERIMENT_BUILD=1 MAGAT_LIB_PATH=magat_pathplanning_amd/lib/libmagat_hip_debug.so python tools/chain_phase_probe.py 2>&1 | tail -20
 done
 touch magat_pathplanning_amd/csrc/block_fused.hip
 python -m magat_pathplanning_amd.build_native --debug > /dev/null 2>&1

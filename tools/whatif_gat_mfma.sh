@@ -5,10 +5,10 @@
 cd $(dirname $0)/..
 for V in ${WHATIF_LIST:-NONE NOQW NOAW NOYST}; do
   touch magat_pathplanning_amd/csrc/gat_mfma.hip
-  F=""; for X in ${V//+/ }; do [ $X = NONE ] || F="$F -DGM_WHATIF_$X"; done
+  F="-DMAGAT_EXPERIMENT_BUILD"; for X in ${V//+/ }; do [ $X = NONE ] || F="$F -DGM_WHATIF_$X"; done
   MAGAT_EXTRA_FLAGS="$F" python -m magat_pathplanning_amd.build_native --debug > /dev/null 2>&1 || { echo "build failed $V"; continue; }
   echo "== $V"
-  MAGAT_LIB_PATH=magat_pathplanning_amd/lib/libmagat_hip_debug.so python tools/gat_mfma_probe.py $PROBE_ARGS 2>&1 | grep -A12 "layer:\|wave 0"
+  MAGAT_ALLOW_EXPERIMENT_BUILD=1 MAGAT_LIB_PATH=magat_pathplanning_amd/lib/libmagat_hip_debug.so python tools/gat_mfma_probe.py $PROBE_ARGS 2>&1 | grep -A12 "layer:\|wave 0"
 done
 touch magat_pathplanning_amd/csrc/gat_mfma.hip
 python -m magat_pathplanning_amd.build_native --debug > /dev/null 2>&1
