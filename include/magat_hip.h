@@ -465,6 +465,10 @@ typedef struct magat_encoder_desc {
                           head_in feat_in pad] - the stem weights / biases of the fused chain multiplied by the power-of-two
                          scale their layer's activations are carried with, the five 1 / weight-scale floats with the scale
                          ratios folded in, and the in_scale of the head's and compressMLP's float32 loaders */
+  int64_t l1frag_off; /* float offset of layer1.conv1 as fragment-major f16 planes (encoder.pack_chain_weights(rows, 32, 0):
+                         [tap 9][k step 2][plane 2] 1 KB blocks + [2^-e, 0, 0, 0]; ABI 4), 0 = absent.  With it (11 x 11 maps,
+                         option L1_FUSED = 2) the stem and layer1.conv1 run as the eight-agent-group kernel of block_fused.hip
+                         (every stem pixel computed once, operands read straight out of LDS) instead of layer1_fused.hip */
 } magat_encoder_desc;
 /* Activation scales (ABI 3).  The split arithmetic carries a value as two f16 planes: exact for |v| <= 65504, but the SECOND
  * plane is a full 11-bit number only for |v| >~ 0.25 - a layer whose activations are all small (a small BatchNorm gamma: an
@@ -478,6 +482,16 @@ typedef struct magat_encoder_desc {
  * [2 + 2 l] layer(l+1).conv2 + downsample (l = 0..2), [7] feat, [8] comp.  Unscaled packs (scaled_off = 0) behave as before. */
 int magat_encoder_calibrate_f32(const magat_encoder_desc* desc_host, const float* x, float* feat, int ldfeat, float* comp,
                                 int ldcomp, void* workspace, size_t workspace_bytes, int M, float* absmax, void* stream);
+/* The first stage of the fused encoder path on its own (ABI 4; what magat_encoder_forward_f32 launches first, exported so
+ * that the stage can be tested and profiled in isolation): stem conv3x3(3 -> 32)+BN+ReLU fused with layer1.conv1
+ * (32 -> 32, stride 2)+BN+ReLU.  x (M,3,H,W) -> out: layer1.conv1's output, ctr: the stem output at the stride-2 pixels (the
+ * input of the block's residual 1x1 branch), both as [ceil(M/128)][Ho*Wo] f16 plane-granule tiles of 32 channels
+ * (in_gl = 2 above; 128*32*4 bytes per tile, the caller provides whole tiles).  form 2: groups of eight agents, every stem pixel
+ * computed once (block_fused.hip stem8_kernel; 11 x 11 maps, needs desc->l1frag_off); form 1: 64-agent row bands
+ * (layer1_fused.hip); form 0: what the encoder would pick (option L1_FUSED).  Uses the activation-scale block when
+ * desc->scaled_off is set.  range_flag (device int32, may be NULL) is OR-ed with 1 when a value left the planes' range. */
+int magat_encoder_stem_block_f32(const magat_encoder_desc* desc_host, const float* x, void* out, void* ctr, int M, int form,
+                                 int32_t* range_flag, void* stream);
 /* Range guard (option RANGE_GUARD, default 1).  The convolutions run as f16x3 split products (two half-precision planes per
  * value, fp32 accumulate: as accurate as the fp32 MFMA kernel while every activation stays within +-65504; the fused stem
  * carries its output 16x and needs it below 4094).  Whether a forward stayed inside is checked ON THE DEVICE: every kernel

@@ -56,7 +56,8 @@ class EncoderDesc(ctypes.Structure):
     _fields_ = [("variant", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
                 ("n_feat", ctypes.c_int), ("n_comp", ctypes.c_int), ("pack", ctypes.c_void_p),
                 ("off", ctypes.c_int64 * 32), ("chain_off", ctypes.c_int64), ("chain3_off", ctypes.c_int64),
-                ("head16_off", ctypes.c_int64), ("comp16_off", ctypes.c_int64), ("scaled_off", ctypes.c_int64)]
+                ("head16_off", ctypes.c_int64), ("comp16_off", ctypes.c_int64), ("scaled_off", ctypes.c_int64),
+                ("l1frag_off", ctypes.c_int64)]
 
 
 class SimStepDesc(ctypes.Structure):
@@ -128,6 +129,7 @@ _SIGNATURES = {
     "magat_encoder_read_status": (_I, [_P, ctypes.POINTER(ctypes.c_int32), _P]),
     "magat_gat_read_status": (_I, [_P, ctypes.POINTER(ctypes.c_int32), _P]),
     "magat_encoder_forward_f32": (_I, [ctypes.POINTER(EncoderDesc), _P, _P, _I, _P, _I, _P, _Z, _I, _P]),
+    "magat_encoder_stem_block_f32": (_I, [ctypes.POINTER(EncoderDesc), _P, _P, _P, _I, _I, _P, _P]),
     "magat_encoder_calibrate_f32": (_I, [ctypes.POINTER(EncoderDesc), _P, _P, _I, _P, _I, _P, _Z, _I, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

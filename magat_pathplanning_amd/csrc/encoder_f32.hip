@@ -229,6 +229,30 @@ static int conv_first_launch(const float* x, const float* wt, const float* bias,
                              int out_gl = 0, int* range_flag = nullptr, const int* run_if = nullptr, int tag = MAGAT_TAG_CONV_FIRST,
                              float* absmax = nullptr);
 
+extern "C" int magat_encoder_stem_block_f32(const magat_encoder_desc* d, const float* x, void* out, void* ctr, int M, int form,
+                                            int32_t* range_flag, void* stream) {
+  if (!d || !d->pack || !x || !out || !ctr) return MAGAT_ERR_NULL;
+  if (M <= 0 || form < 0 || form > 2) return MAGAT_ERR_BAD_SHAPE;
+  if (d->variant != 0 && d->variant != 1) return MAGAT_ERR_UNSUPPORTED;
+  if (d->off[30] == 0) return MAGAT_ERR_UNSUPPORTED;        // (the pack holds no plane-granule weight copies)
+  const float* pk = d->pack;
+  const int H = d->H, W = d->W;
+  const float* sp = d->scaled_off > 0 ? pk + d->scaled_off : nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool can8 = H == 11 && W == 11 && d->l1frag_off > 0;
+  if (form == 0) form = (can8 && magat_opt(MAGAT_OPT_L1_FUSED) >= 2) ? 2 : 1;
+  if (form == 2) {
+    if (!can8) return MAGAT_ERR_UNSUPPORTED;
+    return magat_stem8(x, sp ? sp : pk + d->off[0], sp ? sp + 864 : pk + d->off[1], pk + d->l1frag_off,
+                       sp ? sp + 896 : pk + d->off[3], out, ctr, M, H, W, st, reinterpret_cast<int*>(range_flag));
+  }
+  if (magat_layer1_fused_lds(W) == 0) return MAGAT_ERR_UNSUPPORTED;
+  // (the K-permuted f16 copy of layer1.conv1 sits behind the plain one: two planes + one scale float, padded to 4 floats)
+  const int64_t permuted = ((int64_t)32 * 9 * 32 + 1 + 3) & ~3LL;
+  return magat_layer1_fused(x, sp ? sp : pk + d->off[0], sp ? sp + 864 : pk + d->off[1], pk + d->off[24] + permuted,
+                            sp ? sp + 896 : pk + d->off[3], out, ctr, M, H, W, st, reinterpret_cast<int*>(range_flag));
+}
+
 extern "C" int magat_conv_first_f32(const float* x, const float* wt, const float* bias, float* out, int M, int H,
                                     int W, void* stream) {
   return conv_first_launch(x, wt, bias, out, M, H, W, (long long)M * 32, (long long)MAGAT_TILE_ROWS * 32, stream);
@@ -387,7 +411,13 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
                            magat_opt(MAGAT_OPT_BLOCK_FULL);
     const float* sp = (full_path && d->scaled_off > 0) ? pk + d->scaled_off : nullptr;      // activation-scale block
     int rc;
-    if (fused1)
+    // ... as the eight-agent-group kernel (block_fused.hip stem8_kernel: every stem pixel once, no im2col instructions) when
+    // the map is 11 x 11 and the pack holds layer1.conv1 fragment-major (option L1_FUSED = 2, the default)
+    const bool stem8 = fused1 && H == 11 && W == 11 && d->l1frag_off > 0 && magat_opt(MAGAT_OPT_L1_FUSED) >= 2;
+    if (stem8)
+      rc = magat_stem8(x + (size_t)m0 * 3 * H * W, sp ? sp : pk + d->off[0], sp ? sp + 864 : pk + d->off[1],
+                       pk + d->l1frag_off, sp ? sp + 896 : pk + d->off[3], buf[1], buf[0], mm, H, W, st, range_flag);
+    else if (fused1)
       rc = magat_layer1_fused(x + (size_t)m0 * 3 * H * W, sp ? sp : pk + d->off[0], sp ? sp + 864 : pk + d->off[1],
                               pk + d->off[24] + permuted(32, 9 * 32), sp ? sp + 896 : pk + d->off[3], buf[1], buf[0], mm, H, W,
                               st, range_flag);

@@ -39,7 +39,9 @@ void magat_prof_end(int id, hipStream_t st);
 int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st);
 int magat_layer1_fused(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, void* out,
                        void* ctr, int M, int H, int W, hipStream_t st, int* range_flag = nullptr);   // layer1_fused.hip
-size_t magat_layer1_fused_lds(int W);   // 0: the fused kernel does not take this map width
+size_t magat_layer1_fused_lds(int W);
+int magat_stem8(const float* x, const float* w0, const float* b0, const float* w1f, const float* b1, void* out, void* ctr,
+                int M, int H, int W, hipStream_t st, int* range_flag = nullptr);      // block_fused.hip: the 8-agent-group form   // 0: the fused kernel does not take this map width
 // BasicBlock chain kernel (block_fused.hip): layer1.conv2+ds -> layer2.conv1 -> layer2.conv2+ds on 6x6 maps, maps in LDS
 size_t magat_block_chain_weight_floats();
 size_t magat_block3_weight_floats();
@@ -78,7 +80,8 @@ enum MagatLdsSlot {
   MAGAT_LDS_SIM_CONN, MAGAT_LDS_CONV_FIRST, MAGAT_LDS_CONV_FIRST11, MAGAT_LDS_GSO_STRUCT, MAGAT_LDS_CSR_TILED_A, MAGAT_LDS_CSR_TILED_B, MAGAT_LDS_CSR_TILED_A16, MAGAT_LDS_CSR_TILED_B16,
   MAGAT_LDS_CSR_TILED_A4, MAGAT_LDS_CSR_TILED_B4, MAGAT_LDS_CSR_TILED_A16_4, MAGAT_LDS_CSR_TILED_B16_4, MAGAT_LDS_BLOCK_B4, MAGAT_LDS_BLOCK_FULL, MAGAT_LDS_BLOCK_FULL_P,
   MAGAT_LDS_GATM_0,      // gat_mfma.hip: 24 slots (score mode x shape class x taps x merge)
-  MAGAT_LDS_GATM_END = MAGAT_LDS_GATM_0 + 24
+  MAGAT_LDS_GATM_END = MAGAT_LDS_GATM_0 + 24,
+  MAGAT_LDS_STEM8
 };
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of

@@ -201,8 +201,15 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
             comp16 = torch.cat((comp16, torch.zeros(pad)))
         comp16_off = pack.numel()
         pack = torch.cat([pack, comp16]).contiguous()
+    # layer1.conv1 fragment-major for the eight-agent-group stem kernel (csrc/block_fused.hip stem8_kernel; 11x11 maps)
+    l1frag_off = 0
+    if H == 11 and W == 11:
+        nxt = sorted(o for o in offs[:18] if o > offs[2])
+        w1rows = pack[offs[2]:(nxt[0] if nxt else n_f32)][:32 * 288].reshape(32, 288)
+        l1frag_off = pack.numel()
+        pack = torch.cat([pack, pack_chain_weights(w1rows, 32, 0)]).contiguous()
     meta = dict(variant=0 if large else 1, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast, chain=chain_off,
-                chain3=chain3_off, head16=head16_off, comp16=comp16_off)
+                chain3=chain3_off, head16=head16_off, comp16=comp16_off, l1frag=l1frag_off)
     return pack, offs, meta
 
 

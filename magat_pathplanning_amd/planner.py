@@ -383,6 +383,7 @@ class DecentralPlannerGATNet(nn.Module):
             d.chain3_off = meta.get("chain3", 0)
             d.head16_off = meta.get("head16", 0)
             d.comp16_off = meta.get("comp16", 0)
+            d.l1frag_off = meta.get("l1frag", 0)
             d.scaled_off = 0
             rt.desc = d
         else:
