@@ -149,12 +149,10 @@ __device__ __forceinline__ void w4_fill(const char* wbase, unsigned lane16, u32x
 }
 // (Filling the ring one stage ahead - before the previous stage's epilogue and an LDS-only barrier - was measured and is
 //  slower: chain 608-624 -> 659 us, layer3 1.50-1.52 -> 1.53 ms same-box; the rings of two stages then overlap in registers.)
-// walk4_ring: the walk over a weight ring the CALLER has filled (w4_fill of the first D - 1 k steps) - a stage whose weights
-// do not depend on anything the barrier in front of it orders may request them before that barrier (stem8.hip).
 template <typename TL, int KSM, int KS2, int PS_IN, int PS_IN2, int D, typename GEO = GeoChain>
-__device__ __forceinline__ void walk4_ring(char* lds, int in_off, int in2_off, const char* wbase, f32x16 (&acc)[TL::NT], bool with_res,
-                                           u32x4 (&w)[D][2]) {
+__device__ __forceinline__ void walk4(char* lds, int in_off, int in2_off, const char* wbase, f32x16 (&acc)[TL::NT], bool with_res) {
   constexpr int RP = GEO::RP, GBLK = GEO::BLKB;
+  u32x4 w[D][2];
   constexpr int NT = TL::NT;
   constexpr auto SQ = w4_seq<TL, KSM, KS2>();
   constexpr int NMAIN = 9 * KSM, NSTEP = NMAIN + KS2;
@@ -201,6 +199,7 @@ __device__ __forceinline__ void walk4_ring(char* lds, int in_off, int in2_off, c
       dst = *reinterpret_cast<const u32x4*>(lds + b0[it.s] + (sh * PIXB + pl * PS_IN + it.ks * 2 * GBLK));
     }
   };
+  w4_fill<NSTEP, D>(wbase, lane16, w);
 #pragma unroll
   for (int j = 0; j < AV - 1; ++j) {
     rd(SQ.it[j], 0, av[j][0]);
@@ -231,15 +230,6 @@ __device__ __forceinline__ void walk4_ring(char* lds, int in_off, int in2_off, c
   }
 }
 
-
-template <typename TL, int KSM, int KS2, int PS_IN, int PS_IN2, int D, typename GEO = GeoChain>
-__device__ __forceinline__ void walk4(char* lds, int in_off, int in2_off, const char* wbase, f32x16 (&acc)[TL::NT], bool with_res) {
-  u32x4 w[D][2];
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));        // (laundered: see w4_fill)
-  w4_fill<9 * KSM + KS2, D>(wbase, (unsigned)(tid & 63) * 16u, w);
-  walk4_ring<TL, KSM, KS2, PS_IN, PS_IN2, D, GEO>(lds, in_off, in2_off, wbase, acc, with_res, w);
-}
 
 // row-tile split of a one-channel-tile stage over the four waves (chain stage A, layer1.conv1): 18 / 18 / 15 / 18 tile-taps
 struct W4P0 { static constexpr int NT = 2; static constexpr int t[2] = {T_I0, T_I1}; };

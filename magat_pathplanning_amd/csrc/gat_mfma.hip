@@ -62,9 +62,9 @@ long long* g_gat_mfma_dbg = nullptr;
 // timing experiments (tools/whatif_gat_mfma.sh; wrong results): a store replaced by a register sink
 #define GM_SINK(x) asm volatile("" ::"v"(x))
 #ifdef GM_WHATIF_NOQW
-#define GM_QW(ptr, val) GM_SINK(val)
+#define GM_QW(ptr, val) do { const uint2 v_ = (val); GM_SINK(v_.x); GM_SINK(v_.y); } while (0)
 #else
-#define GM_QW(ptr, val) *reinterpret_cast<unsigned short*>(ptr) = (val)
+#define GM_QW(ptr, val) *reinterpret_cast<uint2*>(ptr) = (val)
 #endif
 #ifdef GM_WHATIF_NOAW
 #define GM_AW(ptr, val) GM_SINK(val)
@@ -372,7 +372,9 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
           for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-              accq[0][mt] = mfma16(a[mt][q == 2 ? 1 : 0], wr[ks & 3][q == 1 ? 1 : 0], accq[0][mt]);
+              // (operands SWAPPED: the tile is Q^T - a lane holds agent row j = 32 mt + lane % 32 and FOUR CONSECUTIVE columns
+              //  g per register quad, i.e. 8 contiguous bytes of a Q plane row: the planes are stored as they are, no transpose)
+              accq[0][mt] = mfma16(wr[ks & 3][q == 1 ? 1 : 0], a[mt][q == 2 ? 1 : 0], accq[0][mt]);
               if (ks + 1 < 8 && q >= 1)
                 a[mt][q - 1] = lds128(lds + (rsw[mt] + (xsw[mt] ^ (unsigned)((ks + 1) << 5))), 256 * (q - 1));
             }
@@ -380,25 +382,29 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
           GM_PIN();
         }
         GM_STAMP(11);
-        // Q planes [j][g] (chunks swizzled by row): a lane holds column g = cw, rows j = 32 mt + 8 q + 4 h + e.  The swizzle
-        // term (j & 15) = (8 (q & 1) + e) | 4 h takes 8 values per lane: 8 base addresses, everything else is an immediate.
+        // Q planes [j][g] (16-byte chunks swizzled by row).  The G1 tile is Q^T: a lane holds row j = 32 mt + lane % 32 and, in
+        // register quad q, columns g = 32 w + 8 q + 4 h + (0..3) - half of chunk 4 w + q of its row: ONE 8-byte store per plane
+        // and quad (round 4; the untransposed tile needed eight 2-byte stores, 16 cycles each with four waves writing).  Rows
+        // past the stored groups of 8 go to a dump row behind the planes (dead space of the U^T region until the hops).
         {
-          const unsigned gx = ((cw >> 3) ^ (4 * h)) << 4;
-          const unsigned qb = UO + 4 * h * 512 + (cw & 7) * 2;
-          char* qa[8];
+          const int fr_ = cw & 31;
+          unsigned jb[MT];
 #pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            unsigned qo = qb + (gx ^ (unsigned)(((c & 4) * 2 + (c & 3)) << 4));
-            asm volatile("" : "+v"(qo));      // (kept as 8 registers: not re-formed from its parts at every write)
-            qa[c] = lds + qo;
+          for (int mt = 0; mt < MT; ++mt) {
+            const int j = 32 * mt + fr_;
+            jb[mt] = UO + (unsigned)(j < R8 ? j : R8) * 512u + 8u * h;
+          }
+          unsigned qx[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            qx[q] = (unsigned)(((4 * w + q) ^ (fr_ & 15)) << 4);
+            asm volatile("" : "+v"(qx[q]));      // (kept as 4 registers: not re-formed from its parts at every write)
           }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              // this row group's arithmetic (rows past N: harmless values; the planes hold whole groups of 8 rows, the rows
-              // past N are never read) alternating with the six MFMAs of tap K - 1 that fall to it; the stores follow under
-              // a wave-uniform branch
+              // this quad's arithmetic alternating with the six MFMAs of tap K - 1 that fall to it
               constexpr int TPG = TAP_ALL / (MT * 4);      // = 6
               const int t0 = (mt * 4 + q) * TPG;
               unsigned hq[2], lq[2];
@@ -417,22 +423,12 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
               split2v(v23[0], v23[1], hq[1], lq[1], vmax);
               GM_PIN();
               tap_one(KT - 1, t0 + 4);
-              const int jg = 32 * mt + 8 * q;
-              const unsigned short hv[4] = {(unsigned short)hq[0], (unsigned short)(hq[0] >> 16), (unsigned short)hq[1],
-                                            (unsigned short)(hq[1] >> 16)};
-              const unsigned short lv[4] = {(unsigned short)lq[0], (unsigned short)(lq[0] >> 16), (unsigned short)lq[1],
-                                            (unsigned short)(lq[1] >> 16)};
+              char* o = lds + (jb[mt] + qx[q]);
               GM_PIN();
               tap_one(KT - 1, t0 + 5);
               GM_PIN();
-              if (jg < N) {                                         // (wave-uniform)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  char* o = qa[(q & 1) * 4 + e] + (jg + e) * 512;
-                  GM_QW(o, hv[e]);
-                  GM_QW(o + 256, lv[e]);
-                }
-              }
+              GM_QW(o, (uint2{hq[0], hq[1]}));
+              GM_QW(o + 256, (uint2{lq[0], lq[1]}));
             }
         }
       }
