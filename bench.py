@@ -601,7 +601,7 @@ def main():
         # (c) the published model setting (N=10, K=2, 4 heads x 32 features, head-mean) as its own leg
         Bw, Nw, mw, Kw, Pw, Gw, bmw, cnw, ccw = WORKLOADS["published_f32p4"]
         cfgw = make_config(num_agents=Nw, nGraphFilterTaps=Kw, nAttentionHeads=Pw, bottleneckFeature=Gw, bottleneckMode=bmw,
-                           CNN_mode=cnw, AttentionConcat=ccw, device=str(dev))
+                           CNN_mode=cnw, AttentionConcat=ccw, device=str(dev), gat_storage="fp32")
         netw = build_model(cfgw, dev)
         xw, Sw = fov_states(Bw, Nw, seed=13).to(dev), comm_gso(Bw, Nw, mw, seed=14).to(dev)
         el, kw, _ = run_leg(xw, Sw, esteps, 3, timing, net=netw)

@@ -29,6 +29,7 @@ def short(name):
                    ("conv_gemm_kernel<128, 128", "conv_gemm_f32<128,128>"), ("conv_gemm_kernel<128, 64", "conv_gemm_f32<128,64>"),
                    ("conv_gemm_kernel<128, 32", "conv_gemm_f32<128,32>"), ("conv_first_kernel", "conv_first"),
                    ("layer1_fused_kernel", "layer1_fused(stem+layer1.conv1)"),
+                   ("stem8_kernel", "stem8(stem+layer1.conv1, eight-agent groups)"),
                    ("block_chain_kernel", "block_chain(layer1.conv2+layer2)"), ("block3_kernel", "block3(layer3+pool)"),
                    ("block_chain_w4_kernel", "block_chain_w4(layer1.conv2+layer2)"), ("block3_w4_kernel", "block3_w4(layer3+pool)"),
                    ("block_full_w4_kernel", "block_full_w4(layer1.conv2+layer2+layer3+pool)"),
@@ -119,7 +120,13 @@ def main():
     # in dispatch order and the LAST steps * (launches per step) of them kept - the warm-up steps in front also hold the
     # one-off float32 calibration pass and the weight packing.  (A positional "launch i of the step" mapping, as rounds 1-2
     # had it, silently mis-assigns everything behind the first launch the step gains or loses.)
-    TAGS = [("conv_first+layer1.conv1 (fused)", "layer1_fused_kernel", 1, 0),
+    stem_kernel = "stem8_kernel"      # (option L1_FUSED = 2, the default since round 4; the row-band form: layer1_fused_kernel)
+    try:
+        if not any("stem8_kernel" in r["Kernel_Name"] for r in csv.DictReader(open(find(os.path.join(out, "trace"), "*kernel_trace.csv")))):
+            stem_kernel = "layer1_fused_kernel"
+    except Exception:
+        pass
+    TAGS = [("conv_first+layer1.conv1 (fused)", stem_kernel, 1, 0),
             ("layer1.conv2+layer2+layer3 (fused, pooled)", "block_full_", 1, 0),
             ("head(avgpool+fc+linear)", "conv_gemm_f16x3_direct_kernel<128, 1, 0>", 2, 0),      # two launches per step:
             ("compressMLP", "conv_gemm_f16x3_direct_kernel<128, 1, 0>", 2, 1),                 # head, then compressMLP
