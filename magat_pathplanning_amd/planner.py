@@ -496,6 +496,68 @@ class DecentralPlannerGATNet(nn.Module):
         self._fold_scales(rt, dev)
         return rt.act_scales
 
+    def _run_encoder(self, rt, x, M, dev, stream):
+        """ConvLayers + compressMLP of M agents on the HIP encoder: (feat (M, numFeatureMap), comp (M, G))."""
+        lib = nat.lib()
+        G, nfm = self.numFeatures2Share, self.numFeatureMap
+        feat = self._buf("feat", (M, nfm), dev)
+        comp = self._buf("comp", (M, G), dev)
+        need = lib.magat_encoder_workspace_bytes(ctypes.byref(rt.desc), M)
+        if rt.ws is None or rt.ws.numel() < need or rt.ws.device != dev:
+            rt.ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            rt.ws[:256].zero_()          # range-guard status block (magat_encoder_read_status)
+        if not rt.calibrated and rt.desc.variant in (0, 1) and os.environ.get("MAGAT_ACT_SCALE", "1") == "1":
+            # first forward with these weights: the power-of-two activation scales of the split arithmetic are folded
+            # from the canonical calibration batch (or from an explicit / inherited calibration) - never from the batch
+            # at hand, so the forward runs like every later one and like every other process with these weights
+            self._ensure_calibrated(rt, dev)
+        nat.check(lib.magat_encoder_forward_f32(ctypes.byref(rt.desc), nat.ptr(x), nat.ptr(feat), nfm,
+                                                nat.ptr(comp), G, nat.ptr(rt.ws), rt.ws.numel(), M, stream),
+                  "magat_encoder_forward_f32")
+        return feat, comp
+
+    def _run_actions(self, rt, feat, comp, gat, gat_rows, M, dev, stream):
+        """actionsMLP (+ the skip source as a second K segment) on the graph layer's rows."""
+        lib = nat.lib()
+        nout = rt.act[0].shape[0]
+        out = torch.empty(M, nout, dtype=torch.float32, device=dev)
+        d = nat.ConvGemmDesc()
+        rows16 = gat_rows.dtype == torch.bfloat16
+        if self.skip in ("skipConcat", "skipConcatGNN", "skipAddGNN"):
+            src = feat if self.skip == "skipConcat" else comp
+            d.inp, d.Cin, d.lda = src.data_ptr(), src.shape[1], src.stride(0)
+            d.in2, d.C2, d.lda2 = gat_rows.data_ptr(), gat_rows.shape[1], gat_rows.stride(0)
+            d.W2, d.stride2 = 1, 1
+            d.bf16_rows = 2 if rows16 else 0
+        else:
+            d.inp, d.Cin, d.lda = gat_rows.data_ptr(), gat_rows.shape[1], gat_rows.stride(0)
+            d.bf16_rows = 1 if rows16 else 0
+        d.wt, d.bias, d.out = rt.act[0].data_ptr(), rt.act[1].data_ptr(), out.data_ptr()
+        d.M, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad, d.Hout, d.Wout = M, 1, 1, 1, 1, 1, 0, 1, 1
+        d.Cout, d.ldc, d.relu = nout, nout, 1 if self.config.use_dropout else 0
+        d.tag = nat.TAG_ACTIONS
+        rc = lib.magat_conv_gemm_f32(ctypes.byref(d), stream)
+        if rc == -2 and rows16:
+            # MAGAT_ERR_UNSUPPORTED: only the streamed-dot-product kernel reads bf16 rows, and it declined (its weight
+            # block exceeds 64 KB of LDS: e.g. CNN_mode Default with skipConcat at a large FOV): widen the rows and take
+            # the float32 kernel instead of failing the forward
+            nat.check(lib.magat_cast_rows(nat.ptr(gat_rows), nat.ptr(gat), 0, M, self.gat_width, self.gat_width,
+                                          self.gat_width, stream), "magat_cast_rows")
+            if d.C2:
+                d.in2, d.lda2 = gat.data_ptr(), gat.stride(0)
+            else:
+                d.inp, d.lda = gat.data_ptr(), gat.stride(0)
+            d.bf16_rows = 0
+            rc = lib.magat_conv_gemm_f32(ctypes.byref(d), stream)
+        nat.check(rc, "magat_conv_gemm_f32(actionsMLP.0)")
+        if self.config.use_dropout:
+            out2 = torch.empty(M, rt.act[2].shape[0], dtype=torch.float32, device=dev)
+            nat.check(lib.magat_linear_f32(nat.ptr(out), nout, nat.ptr(rt.act[2]), nat.ptr(rt.act[3]),
+                                           nat.ptr(out2), out2.shape[1], M, out2.shape[1], nout, 0, stream),
+                      "magat_linear_f32(actionsMLP.3)")
+            out = out2
+        return out
+
     def _buf(self, name, shape, dev):
         t = self._rt.buffers.get(name)
         if t is None or tuple(t.shape) != tuple(shape) or t.device != dev:
@@ -524,20 +586,7 @@ class DecentralPlannerGATNet(nn.Module):
         nfm = self.numFeatureMap
         with torch.cuda.device(dev):
             stream = nat.current_stream(dev)
-            feat = self._buf("feat", (M, nfm), dev)
-            comp = self._buf("comp", (M, G), dev)
-            need = lib.magat_encoder_workspace_bytes(ctypes.byref(rt.desc), M)
-            if rt.ws is None or rt.ws.numel() < need or rt.ws.device != dev:
-                rt.ws = torch.empty(need, dtype=torch.uint8, device=dev)
-                rt.ws[:256].zero_()          # range-guard status block (magat_encoder_read_status)
-            if not rt.calibrated and rt.desc.variant in (0, 1) and os.environ.get("MAGAT_ACT_SCALE", "1") == "1":
-                # first forward with these weights: the power-of-two activation scales of the split arithmetic are folded
-                # from the canonical calibration batch (or from an explicit / inherited calibration) - never from the batch
-                # at hand, so the forward runs like every later one and like every other process with these weights
-                self._ensure_calibrated(rt, dev)
-            nat.check(lib.magat_encoder_forward_f32(ctypes.byref(rt.desc), nat.ptr(x), nat.ptr(feat), nfm,
-                                                    nat.ptr(comp), G, nat.ptr(rt.ws), rt.ws.numel(), M, stream),
-                      "magat_encoder_forward_f32")
+            feat, comp = self._run_encoder(rt, x, M, dev, stream)
             layer = self.GFL[0]
             layer.addGSO(self.S)
             gat = self._buf("gat", (M, self.gat_width), dev)
@@ -576,42 +625,159 @@ class DecentralPlannerGATNet(nn.Module):
                 _, aij = gat_forward_rows(comp.view(B, N, G), self.S, layer, out=gat, want_attention=want_att,
                                           plan=rt.plan, csr=rt.csr)
             layer.aij = aij
-            # actionsMLP
-            nout = rt.act[0].shape[0]
-            out = torch.empty(M, nout, dtype=torch.float32, device=dev)
-            d = nat.ConvGemmDesc()
-            rows16 = gat_rows.dtype == torch.bfloat16
-            if self.skip in ("skipConcat", "skipConcatGNN", "skipAddGNN"):
-                src = feat if self.skip == "skipConcat" else comp
-                d.inp, d.Cin, d.lda = src.data_ptr(), src.shape[1], src.stride(0)
-                d.in2, d.C2, d.lda2 = gat_rows.data_ptr(), gat_rows.shape[1], gat_rows.stride(0)
-                d.W2, d.stride2 = 1, 1
-                d.bf16_rows = 2 if rows16 else 0
-            else:
-                d.inp, d.Cin, d.lda = gat_rows.data_ptr(), gat_rows.shape[1], gat_rows.stride(0)
-                d.bf16_rows = 1 if rows16 else 0
-            d.wt, d.bias, d.out = rt.act[0].data_ptr(), rt.act[1].data_ptr(), out.data_ptr()
-            d.M, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad, d.Hout, d.Wout = M, 1, 1, 1, 1, 1, 0, 1, 1
-            d.Cout, d.ldc, d.relu = nout, nout, 1 if self.config.use_dropout else 0
-            d.tag = nat.TAG_ACTIONS
-            rc = lib.magat_conv_gemm_f32(ctypes.byref(d), stream)
-            if rc == -2 and rows16:
-                # MAGAT_ERR_UNSUPPORTED: only the streamed-dot-product kernel reads bf16 rows, and it declined (its weight
-                # block exceeds 64 KB of LDS: e.g. CNN_mode Default with skipConcat at a large FOV): widen the rows and take
-                # the float32 kernel instead of failing the forward
-                nat.check(lib.magat_cast_rows(nat.ptr(gat_rows), nat.ptr(gat), 0, M, self.gat_width, self.gat_width,
-                                              self.gat_width, stream), "magat_cast_rows")
-                if d.C2:
-                    d.in2, d.lda2 = gat.data_ptr(), gat.stride(0)
-                else:
-                    d.inp, d.lda = gat.data_ptr(), gat.stride(0)
-                d.bf16_rows = 0
-                rc = lib.magat_conv_gemm_f32(ctypes.byref(d), stream)
-            nat.check(rc, "magat_conv_gemm_f32(actionsMLP.0)")
-            if self.config.use_dropout:
-                out2 = torch.empty(M, rt.act[2].shape[0], dtype=torch.float32, device=dev)
-                nat.check(lib.magat_linear_f32(nat.ptr(out), nout, nat.ptr(rt.act[2]), nat.ptr(rt.act[3]),
-                                               nat.ptr(out2), out2.shape[1], M, out2.shape[1], nout, 0, stream),
-                          "magat_linear_f32(actionsMLP.3)")
-                out = out2
+            out = self._run_actions(rt, feat, comp, gat, gat_rows, M, dev, stream)
         return out
+
+
+class DecentralPlannerNet(DecentralPlannerGATNet):
+    """Drop-in for the reference's GNN-baseline model class `DecentralPlannerNet` (graphs/models/decentralplanner.py:14-398; the
+    first command of scripts/train_DMap.sh:30, agents/decentralplannerlocal*.py): the same per-agent CNN encoder and
+    compressMLP, ONE GraphFilterBatch layer (graphML.py:5581-5700; y = bias + sum_k (x S^k) h_k with the GSO values as edge
+    weights) followed by a ReLU unless config.no_ReLU, and the action MLP.  Same constructor (config object), addGSO(S)
+    (:336-353: NaN scrub in place, dist_GSO_one, full_GSO), forward(x) -> (B*N, 5) logits and state_dict layout (ConvLayers.*,
+    compressMLP.0.*, GFL.0.{weight (F,1,K,G), bias (F,1)}, actionsMLP.*).  Inference runs on the same gfx950 kernels as
+    DecentralPlannerGATNet: magat_encoder_forward_f32, the CSR graph-filter kernels (magat_gnn_forward_csr_f32) and the
+    action-head GEMM; with autograd on, the graph layer's HIP forward / backward (_GnnTrainFunction) under torch autograd.
+    The reference's dilated-convolution variants (config.use_dilated) are outside the built path."""
+
+    def __init__(self, config):
+        nn.Module.__init__(self)
+        from .graphml import GraphFilterBatch
+        self.config = config
+        self.S = None
+        self.numAgents = config.num_agents
+        if getattr(config, "use_dilated", False):
+            raise NotImplementedError("config.use_dilated: the dilated-CNN variants of DecentralPlannerNet "
+                                      "(decentralplanner.py:57-86) are outside the built hot path")
+        self.skip = "only"
+        inW = inH = config.FOV + 2
+        numAction = 5
+        mode = config.CNN_mode
+        self.cnn_mode = mode
+        if mode in ("ResNetSlim_withMLP", "ResNetLarge_withMLP"):
+            body = ResNetSlim() if "Slim" in mode else ResNet()
+            self.ConvLayers = nn.Sequential(body, nn.Dropout(0.2), nn.Flatten(),
+                                            nn.Linear(1152, config.numInputFeatures, bias=True))
+            numFeatureMap = config.numInputFeatures
+        elif mode in ("ResNetSlim", "ResNetLarge"):
+            body = ResNetSlim() if "Slim" in mode else ResNet()
+            self.ConvLayers = nn.Sequential(body, nn.Dropout(0.2))
+            numFeatureMap = 1152
+        else:
+            chans = [3, 32, 32, 64, 64, 128]
+            layers, w, h = [], inW, inH
+            for l in range(5):
+                layers += [nn.Conv2d(chans[l], chans[l + 1], 3, 1, 1, bias=True), nn.BatchNorm2d(chans[l + 1]),
+                           nn.ReLU(inplace=True)]
+                if l % 2 == 0:
+                    layers.append(nn.MaxPool2d(kernel_size=2))
+                    w, h = (w - 2) // 2 + 1, (h - 2) // 2 + 1
+            self.ConvLayers = nn.Sequential(*layers)
+            numFeatureMap = chans[-1] * w * h
+            self.cnn_mode = "Default"
+        self.numFeatureMap = numFeatureMap
+        nif = config.numInputFeatures
+        self.compressMLP = nn.Sequential(nn.Linear(numFeatureMap, nif, bias=True), nn.ReLU(inplace=True))
+        self.numFeatures2Share = nif
+        self.L = 1
+        self.F = [nif, nif]
+        self.K = [config.nGraphFilterTaps]
+        self.E = 1
+        self.bias = True
+        gfl = [GraphFilterBatch(self.F[0], self.F[1], self.K[0], self.E, self.bias)]
+        self.no_relu = bool(getattr(config, "no_ReLU", False))
+        if not self.no_relu:
+            gfl.append(nn.ReLU(inplace=True))
+        self.GFL = nn.Sequential(*gfl)
+        self.gat_width = nif
+        if config.use_dropout:
+            self.actionsMLP = nn.Sequential(nn.Linear(nif, nif), nn.ReLU(inplace=True), nn.Dropout(p=0.2),
+                                            nn.Linear(nif, numAction), nn.Dropout(p=0.2))
+        else:
+            self.actionsMLP = nn.Sequential(nn.Linear(nif, numAction))
+        self.apply(weights_init)
+        self._rt = _Runtime()
+        self._cal = None
+
+    def addGSO(self, S):
+        """decentralplanner.py:336-353: aliases the caller's tensor, scrubs NaN in place, dist_GSO_one / full_GSO."""
+        assert len(S.shape) == 3
+        gso_mode = {"dist_GSO_one": 1, "full_GSO": 2}.get(self.config.GSO_mode, 0)
+        if S.is_cuda and S.is_contiguous() and S.dtype in (torch.float32, torch.float64) and gso_mode != 2 and S.numel() > 0:
+            with torch.cuda.device(S.device):
+                nat.check(nat.lib().magat_gso_prepare(nat.ptr(S), 1 if S.dtype == torch.float64 else 0, S.numel(), 1, gso_mode,
+                                                      nat.current_stream(S.device)), "magat_gso_prepare")
+            self.S = S.unsqueeze(1)
+            return
+        self.S = S.unsqueeze(1)
+        self.S[torch.isnan(self.S)] = 0
+        if gso_mode == 1:
+            self.S[self.S > 0] = 1
+        elif gso_mode == 2:
+            self.S = torch.ones_like(self.S).to(self.config.device)
+
+    def returnAttentionGSO(self):
+        raise AttributeError("DecentralPlannerNet has no attention (GraphFilterBatch)")
+
+    def range_status(self):
+        out = {"encoder_rerun": False, "encoder_reruns": 0, "gat_rerun": False, "gat_reruns": 0,
+               "act_scales": None if self._rt is None else self._rt.act_scales}
+        st = (ctypes.c_int32 * 2)()
+        rt = self._rt
+        if rt is not None and rt.ws is not None:
+            with torch.cuda.device(rt.ws.device):
+                nat.check(nat.lib().magat_encoder_read_status(nat.ptr(rt.ws), st, nat.current_stream(rt.ws.device)),
+                          "magat_encoder_read_status")
+            out["encoder_rerun"], out["encoder_reruns"] = bool(st[0]), int(st[1])
+        return out
+
+    def enable_hip_graph(self, on=True):
+        if on:
+            raise NotImplementedError("hipGraph capture is built for DecentralPlannerGATNet's dense graph layer only")
+
+    def forward(self, inputTensor):
+        (B, N, C, W, H) = inputTensor.shape
+        dev = torch.device(self.config.device)
+        x = inputTensor.reshape(B * N, C, W, H).to(dev)
+        if self.S is None:
+            raise TypeError("addGSO must be called before forward")
+        side = self.config.FOV + 2
+        if (C, W, H) != (3, side, side):
+            raise RuntimeError("DecentralPlannerNet built for (3, %d, %d) state maps (config.FOV + 2), got (%d, %d, %d)"
+                               % (side, side, C, W, H))
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad or self.training:
+            nat.require_device_or_composite(x, "DecentralPlannerNet in training / autograd mode")
+            return self._forward_autograd(x, B, N)
+        return self._forward_hip(x, B, N)
+
+    def _forward_autograd(self, x, B, N):
+        feat = self.ConvLayers(x)
+        feat = feat.view(feat.size(0), -1)
+        comp = self.compressMLP(feat)
+        xg = comp.reshape(B, N, self.numFeatures2Share).permute(0, 2, 1)
+        self.GFL[0].addGSO(self.S)
+        shared = self.GFL(xg)
+        shared = shared.permute(0, 2, 1).reshape(B * N, shared.shape[1])
+        return self.actionsMLP(shared)
+
+    @torch.no_grad()
+    def _forward_hip(self, x, B, N):
+        if not x.is_cuda:
+            raise nat.MagatNativeError("inference runs on the HIP path only; config.device=%r is not a GPU "
+                                       "(no CPU fallback)" % (self.config.device,))
+        dev = x.device
+        M = B * N
+        rt = self._refresh(dev)
+        x = x.contiguous().float()
+        with torch.cuda.device(dev):
+            stream = nat.current_stream(dev)
+            feat, comp = self._run_encoder(rt, x, M, dev, stream)
+            layer = self.GFL[0]
+            layer.addGSO(self.S)
+            # GraphFilterBatch on the CSR kernels: rows in, rows out ((B, F, N) is a view of the (M, F) result)
+            y = layer._forward_hip(comp.view(B, N, self.numFeatures2Share).permute(0, 2, 1))[0]
+            rows = y.permute(0, 2, 1).reshape(M, self.gat_width)
+            if not self.no_relu:
+                rows = torch.relu_(rows)
+            return self._run_actions(rt, feat, comp, rows, rows, M, dev, stream)

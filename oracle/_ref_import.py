@@ -51,6 +51,13 @@ def import_reference():
     return gml, classes
 
 
+def import_reference_gnn_model():
+    """The GNN-baseline model class DecentralPlannerNet (graphs/models/decentralplanner.py)."""
+    import_reference()
+    import importlib
+    return importlib.import_module("graphs.models.decentralplanner").DecentralPlannerNet
+
+
 def make_config(**kw):
     """config object with the fields DecentralPlannerGATNet reads."""
     base = dict(num_agents=10, FOV=9, bottleneckFeature=128, numInputFeatures=128,

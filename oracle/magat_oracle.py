@@ -374,6 +374,25 @@ def planner_forward(x, S, sd, cfg, return_parts=False):
     return h
 
 
+def planner_gnn_forward(x, S, sd, cfg):
+    """DecentralPlannerNet addGSO + forward in eval mode (graphs/models/decentralplanner.py:336-398): encoder, compressMLP,
+    ONE GraphFilterBatch (graphML.py:5670-5689 -> BatchLSIGF :5485-5579), ReLU unless cfg.no_ReLU, action MLP.  addGSO of this
+    class always scrubs NaN (:346), like the BottomNeck_only GAT file.  S is mutated in place like the reference."""
+    B, N = x.shape[0], x.shape[1]
+    S4 = add_gso(S, cfg.GSO_mode, "BottomNeck_only")
+    feat = conv_layers_forward(x.reshape(B * N, *x.shape[2:]), sd, cfg.CNN_mode)
+    comp = torch.relu(tnf.linear(feat, sd["compressMLP.0.weight"], sd["compressMLP.0.bias"]))
+    xg = comp.reshape(B, N, comp.shape[1]).permute(0, 2, 1)
+    yg = graph_filter_batch_forward(xg, S4, sd["GFL.0.weight"], sd["GFL.0.bias"])
+    if not getattr(cfg, "no_ReLU", False):
+        yg = torch.relu(yg)
+    shared = yg.permute(0, 2, 1).reshape(B * N, yg.shape[1])
+    h = tnf.linear(shared, sd["actionsMLP.0.weight"], sd["actionsMLP.0.bias"])
+    if getattr(cfg, "use_dropout", False):
+        h = tnf.linear(torch.relu(h), sd["actionsMLP.3.weight"], sd["actionsMLP.3.bias"])
+    return h
+
+
 # ------------------------------------------------------------- reference init
 def init_state_dict(cfg, seed=1337, perturb_bn=True):
     """Random weights with the reference's shapes and init laws (weights_init

@@ -247,6 +247,45 @@ def main_fov():
         print("wrote", path, os.path.getsize(path) // 1024, "KB")
 
 
+def main_gnn_model():
+    """Round 4: DecentralPlannerNet (graphs/models/decentralplanner.py:14-398: encoder + ONE GraphFilterBatch + ReLU + action
+    MLP, the paper's GNN baseline and the first command of scripts/train_DMap.sh:30) - model-level fixtures: the published
+    setting (10 agents, K = 2, 128 features, ResNetLarge_withMLP, dist_GSO), one with use_dropout / ResNetSlim / dist_GSO_one
+    / K = 3, one with the Default CNN and no_ReLU."""
+    from oracle._ref_import import import_reference_gnn_model
+    cls = import_reference_gnn_model()
+    cases = [("gnn_published", dict(num_agents=10, nGraphFilterTaps=2), 3),
+             ("gnn_dropout_slim_one", dict(num_agents=12, nGraphFilterTaps=3, use_dropout=True, CNN_mode="ResNetSlim",
+                                           GSO_mode="dist_GSO_one", numInputFeatures=64), 2),
+             ("gnn_default_cnn_norelu", dict(num_agents=9, nGraphFilterTaps=4, CNN_mode="Default", no_ReLU=True), 2)]
+    for i, (name, kw, B) in enumerate(cases):
+        cfg = make_config(use_dilated=False, no_ReLU=kw.pop("no_ReLU", False), **kw)
+        seed = 9191 + i
+        gen = torch.Generator().manual_seed(seed)
+        torch.manual_seed(seed)
+        model = cls(cfg).eval()
+        with torch.no_grad():
+            for mod in model.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.running_mean.normal_(0, 0.2, generator=gen)
+                    mod.running_var.uniform_(0.5, 1.5, generator=gen)
+                    mod.bias.normal_(0, 0.1, generator=gen)
+        N = cfg.num_agents
+        x = fov_states(gen, B, N)
+        S = tricky_gso(gen, B, N, 0.3, True)
+        S_in = S.clone()
+        model.addGSO(S)
+        with torch.no_grad():
+            logits = model(x)
+        out = dict(x=x.numpy().astype(np.uint8), S=S_in.numpy(), S_after=model.S[:, 0].numpy(), logits=logits.numpy(),
+                   cfg=np.array(repr(vars(cfg))))
+        for k, v in model.state_dict().items():
+            out["sd/" + k] = v.numpy()
+        path = os.path.join(OUT, "gnnmodel_%s.npz" % name[4:])
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path) // 1024, "KB", "max|logit| %.3g" % float(np.abs(out["logits"]).max()))
+
+
 def main_grad():
     """Round 4: GRADIENT fixtures made by the real reference's autograd (the training step's loss.backward(),
     agents/decentralplannerlocal_OnlineExpert_GAT.py:560-567, at the layer level): for the seven shapes of
@@ -293,6 +332,8 @@ def main_grad():
 if __name__ == "__main__":
     if "--grad" in sys.argv:
         main_grad()
+    elif "--gnn-model" in sys.argv:
+        main_gnn_model()
     elif "--fov" in sys.argv:
         main_fov()
     elif "--directed" in sys.argv:

@@ -565,3 +565,29 @@ def test_forward_is_deterministic_and_independent_of_batch_composition(gpu_devic
             alone = net(x[b:b + 1].contiguous())
             # (the encoder head changes its summation form with the agent count: float32 rounding, not bit equality)
             assert float((alone - ref[b * N:(b + 1) * N]).abs().max()) <= 2e-5
+
+
+GNNMODEL = golden_paths("gnnmodel_")
+
+
+@pytest.mark.parametrize("path", GNNMODEL, ids=[os.path.basename(p)[:-4] for p in GNNMODEL])
+def test_gnn_model_vs_reference_golden(gpu_device, path):
+    """DecentralPlannerNet (the GNN-baseline class, graphs/models/decentralplanner.py) on the HIP kernels - encoder, CSR
+    graph-filter layer, action head - against logits made by the real reference; addGSO mutates the caller's tensor alike."""
+    from magat_pathplanning_amd import DecentralPlannerNet
+    z, sd, cfg = load_model_fixture(path)
+    cfg.device = str(gpu_device)
+    net = DecentralPlannerNet(cfg)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(gpu_device).eval()
+    x = torch.from_numpy(z["x"].astype(np.float32)).to(gpu_device)
+    S = torch.from_numpy(z["S"].copy()).to(gpu_device)
+    with torch.no_grad():
+        net.addGSO(S)
+        logits = net(x)
+        again = net(x)
+    torch.cuda.synchronize()
+    assert logits.shape == z["logits"].shape and torch.equal(logits, again)
+    assert float(np.abs(logits.cpu().numpy() - z["logits"]).max()) <= TOL
+    np.testing.assert_array_equal(S.cpu().numpy(), z["S_after"])
+    assert not net.range_status()["encoder_rerun"]

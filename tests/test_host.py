@@ -328,3 +328,24 @@ def test_weights_key_sees_every_way_the_weights_can_change():
         bn.running_mean.mul_(0.5)
     assert net._weights_key(dev) != k4
     assert net._weights_key(torch.device("cuda:0"))[0] != k4[0]
+
+
+def test_gnn_model_class_surface_matches_the_reference_fixture():
+    """DecentralPlannerNet: reference-made state_dicts load strict=True (same keys and shapes), the module pickles, and the
+    autograd path (torch composite on CPU tensors, host tests only) reproduces the reference's logits."""
+    from magat_pathplanning_amd import DecentralPlannerNet
+    for path in golden_paths("gnnmodel_"):
+        z, sd, cfg = load_model_fixture(path)
+        cfg.device = "cpu"
+        net = DecentralPlannerNet(cfg)
+        net.load_state_dict(sd, strict=True)
+        net.train(False)
+        pickle.loads(pickle.dumps(net))
+        x = torch.from_numpy(z["x"].astype(np.float32))
+        S = torch.from_numpy(z["S"].copy())
+        net.addGSO(S)
+        np.testing.assert_array_equal(S.numpy(), z["S_after"])
+        for p_ in net.parameters():
+            p_.requires_grad_(True)
+        y = net(x)          # grad enabled -> the differentiable composite
+        np.testing.assert_allclose(y.detach().numpy(), z["logits"], rtol=0, atol=5e-6 * max(1.0, float(np.abs(z["logits"]).max())))

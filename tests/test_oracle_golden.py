@@ -83,3 +83,19 @@ def test_graph_filter_batch_oracle_matches_reference(path):
     y = orc.graph_filter_batch_forward(torch.from_numpy(z["x"]), torch.from_numpy(z["S"]), torch.from_numpy(z["p_weight"]),
                                        torch.from_numpy(z["p_bias"]))
     np.testing.assert_allclose(y.numpy(), z["y"], rtol=0, atol=2e-6)
+
+
+GNNMODEL = golden_paths("gnnmodel_")
+
+
+@pytest.mark.parametrize("path", GNNMODEL, ids=[os.path.basename(p)[:-4] for p in GNNMODEL])
+def test_gnn_model_oracle_matches_reference(path):
+    """DecentralPlannerNet (graphs/models/decentralplanner.py; oracle/make_golden.py --gnn-model): the oracle's restatement
+    against logits and the mutated GSO made by the real reference."""
+    z, sd, cfg = load_model_fixture(path)
+    assert len(GNNMODEL) == 3
+    x = torch.from_numpy(z["x"].astype(np.float32))
+    S = torch.from_numpy(z["S"].copy())
+    got = orc.planner_gnn_forward(x, S, sd, cfg)
+    np.testing.assert_allclose(got.numpy(), z["logits"], rtol=0, atol=2e-6 * max(1.0, float(np.abs(z["logits"]).max())))
+    np.testing.assert_array_equal(S.numpy(), z["S_after"])
