@@ -42,7 +42,8 @@ struct GatMfmaParams {
   const char* wfrag;          // fragment-major weight planes: 64 KB blocks, [P] W_p then [P*K] H_pk
   const float* bias;          // [128] or null
   float* Y;                   // [B*N][ldy]; concat: head p at column 128 p
-  int B, N, P, ldx, ldy, concat, s_is_f64;
+  int B, N, P, ldx, ldy, concat, s_is_f64;       // (PACK: B = number of PACKS of four instances, Binst = instances)
+  int Binst;
   int hsplit;                 // 1, or P (small batches, concat): a workgroup per (instance, head) instead of per instance
   int* range_flag;
   const float* kconst;        // rank-1 score modes: per head a1 . wb + a2 . wb (GAT_modified; zeros for GAT_origin), or null
@@ -151,10 +152,20 @@ __device__ __forceinline__ uint4 lds128(const char* ptr, int coff) { return *rei
 // e_ij = lrelu_0.2(c1_j + c2_i + k_p) with c1 = (a1 W_p) . x, c2 = (a2 W_p) . x (graphML.py:777-796, 1024-1037): the weight
 // block of G1 holds the two vectors a1 W_p, a2 W_p as its rows 0 and 1 (magat_gat_pack_weights), so G1 and the Q planes are
 // the KeyQuery code unchanged and hand c1 / c2 over as columns 0 / 1 of Q; G2's product is replaced by 16 LDS reads per lane.
-template <int MT, int KSI, int KT, bool CONCAT, int MODE>
+// PACK (round 4; N <= 32): FOUR planning instances per pass, instance s in the 32-row slot s of the 128 rows (MT = 4, KSI = 2).
+// The per-agent products (G1, G3: rows are agents, the contraction runs over features) take the four slots as their four row
+// tiles - every weight fragment is streamed once per pack instead of once per instance, which is what bounded small graphs -
+// and the graph products keep to the diagonal blocks: wave w scores instance w only (G2: one tile instead of MT x 4), the A
+// planes hold [128 rows j][32 local columns i], and a hop of slot s contracts over that instance's two k steps.  An instance's
+// arithmetic does not depend on its slot (same products, same k order, same intra-step positions as the unpacked N <= 32
+// kernel): packed, unpacked and differently sharded batches agree bit for bit.
+template <int MT, int KSI, int KT, bool CONCAT, int MODE, bool PACK = false>
 __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p) {
   extern __shared__ __align__(16) char lds[];
+  static_assert(!PACK || (MT == 4 && KSI == 2), "PACK: four 32-row slots");
   constexpr int KI = 16 * KSI, SA = 2 * KI + 16;
+  constexpr int KIU = PACK ? 128 : KI, SAU = 2 * KIU + 16;      // U^T planes [128 c][KIU columns i]; A planes [rows j][KI]
+  constexpr int MTS = PACK ? 1 : MT;                            // row tiles of a wave's score tile column (PACK: its own slot)
   constexpr float kInvScale = 1.f / 256.f;
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -162,10 +173,11 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
   const int N = p.N;
   // LDS map.  X / Q planes: row r at 512 r, hi plane then lo plane (256 B each), 16-byte chunk c of a plane at
   // (c ^ (r & 15)) << 4.  A / U^T planes: rows SA bytes apart, lo plane behind the hi plane.
-  const int R8 = (N + 7) & ~7;                              // rows of the Q / A planes: whole groups of 8 are stored
-  const unsigned AO = 512u * N, AP = (unsigned)R8 * SA;     // A planes [R8][SA]
-  const unsigned UO = AO + 2 * AP;                          // U^T planes [128][SA]; the Q planes [R8][512] share the region
-  constexpr unsigned UP = 128 * SA;
+  const int NR = PACK ? 128 : N;                            // rows of the X planes
+  const int R8 = PACK ? 128 : (N + 7) & ~7;                 // rows of the Q / A planes: whole groups of 8 are stored
+  const unsigned AO = 512u * NR, AP = (unsigned)R8 * SA;    // A planes [R8][SA]
+  const unsigned UO = AO + 2 * AP;                          // U^T planes [128][SAU]; the Q planes [R8][512] share the region
+  constexpr unsigned UP = 128 * SAU;
   const unsigned MO = AO;      // edge masks [N][4], staged when there is no plan: read into registers behind the prologue
                                // barrier, dead before the first A plane is written (two barriers later)
 
@@ -176,14 +188,14 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
   //   GM_ROWS(rsw, xsw): byte offset of row min(32 mt + lane % 32, N - 1) in the X / Q planes and its swizzle term
   //   GM_AROWS(rpa):     the same row in the A planes (+ 16 bytes for the upper lane half)
 #define GM_ROWS(rsw, xsw) unsigned rsw[MT], xsw[MT]; { int l_ = lane; asm volatile("" : "+v"(l_)); _Pragma("unroll") \
-    for (int mt_ = 0; mt_ < MT; ++mt_) { const int row_ = min(32 * mt_ + (l_ & 31), N - 1); rsw[mt_] = row_ * 512; \
+    for (int mt_ = 0; mt_ < MT; ++mt_) { const int row_ = PACK ? 32 * mt_ + (l_ & 31) : min(32 * mt_ + (l_ & 31), N - 1); rsw[mt_] = row_ * 512; \
       xsw[mt_] = ((l_ >> 5) ^ (row_ & 15)) << 4; } }
 #define GM_AROWS(rpa) unsigned rpa[MT]; { int l_ = lane; asm volatile("" : "+v"(l_)); _Pragma("unroll") \
-    for (int mt_ = 0; mt_ < MT; ++mt_) rpa[mt_] = AO + min(32 * mt_ + (l_ & 31), N - 1) * SA + (l_ >> 5) * 16; }
+    for (int mt_ = 0; mt_ < MT; ++mt_) rpa[mt_] = AO + (PACK ? 32 * mt_ + (l_ & 31) : min(32 * mt_ + (l_ & 31), N - 1)) * SA + (l_ >> 5) * 16; }
   const int cw_ = 32 * w + fr;                     // this lane's output column (g in G1, i in G2, c in G3 / hops)
   const char* wl = p.wfrag + (size_t)w * 16384 + lane * 16;   // this wave's 32-row tile of a weight block
   const float biasv = p.bias ? p.bias[cw_] : 0.f;
-  const bool g2_active = 32 * w < KI;              // waves whose i tile holds columns of A
+  const bool g2_active = PACK || 32 * w < KI;      // waves whose i tile holds columns of A (PACK: every wave scores its slot)
   float vmax = 0.f;                                // running maximum of |values written to f16 planes|
   float xs = 1.f;
   if (p.x_scale) xs = *p.x_scale;
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
   const int hpw = p.P / p.hsplit, hlo = ((int)blockIdx.x % p.hsplit) * hpw, hhi = hlo + hpw;
   const int b0 = (int)blockIdx.x / p.hsplit, bstride = (int)gridDim.x / p.hsplit;
   uint4 wr[4][2];
-  auto wr_load = [&](int hd_, int f) {      // f: static position in the stream of head hd_ (f >= FPH: the next head's)
+  auto wr_load = [&](int hd_, int f) __attribute__((always_inline)) {      // f: static position in the stream of head hd_ (f >= FPH: the next head's)
     int hh = hd_;
     if (f >= FPH) { hh = hd_ + 1 == hhi ? hlo : hd_ + 1; f -= FPH; }
     const int ks = f & 7;
@@ -226,17 +238,45 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
       int t = threadIdx.x;
       asm volatile("" : "+v"(t));      // (per instance: the address arithmetic below is not hoisted into long-lived registers)
       const int lane_ = t & 63;
-      const float* Xb = p.X + (long long)b * N * p.ldx;
+      // (PACK: b counts packs; instance 4 b + s fills rows 32 s .. 32 s + N - 1, rows that do not exist become zero planes)
+      const float* Xb = p.X + (long long)b * (PACK ? 4 : 1) * N * p.ldx;
       const unsigned xst = AO + 2048;
-      for (int c = w; c * 64 < N * 32; c += 4) {           // 64 chunks of 16 bytes per wave instruction; 32 chunks per row
+      for (int c = w; c * 64 < NR * 32; c += 4) {          // 64 chunks of 16 bytes per wave instruction; 32 chunks per row
         const int ch = c * 64 + lane_;
-        const float* src = Xb + (long long)(ch >> 5) * p.ldx + (ch & 31) * 4;
+        const int row = ch >> 5;
+        const long long arow = PACK ? (long long)(row >> 5) * N + (row & 31) : row;      // agent row behind Xb
+        const bool rok = PACK ? ((row & 31) < N && 4 * b + (row >> 5) < p.Binst) : ch < N * 32;
+        const float* src = Xb + arow * p.ldx + (ch & 31) * 4;
         const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + xst + (unsigned)c * 1024u);
-        if (ch < N * 32) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+        if (rok) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
       }
       // (the masks are formed while the X rows are in flight: their first batch of GSO rows shares that round trip)
       if (!p.rmask_pre) {        // GSO rows -> 128-bit edge masks (one wave per row, ballot; |S| > 1e-9 as in gat_f32.hip)
         // rows w, w + 4, ...: eight rows' loads are issued before the first ballot (one memory latency per batch, not per row)
+        auto stage_pack = [&](auto tag) __attribute__((always_inline)) {      // PACK: row R = 32 s + i of the pack; 32-bit masks over the instance's own columns
+          typedef decltype(tag) ST;
+          const int j0 = (lane_ & 31) < N ? (lane_ & 31) : N - 1;
+          for (int R0 = w; R0 < 128; R0 += 32) {
+            ST v0[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const int R = R0 + 4 * r, sl = R >> 5, i = min(R & 31, N - 1);
+              const int inst = min(4 * b + sl, p.Binst - 1);
+              v0[r] = (static_cast<const ST*>(p.S) + (long long)inst * N * N)[(long long)i * N + j0];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const int R = R0 + 4 * r, sl = R >> 5, i = R & 31;
+              bool f0 = sizeof(ST) == 8 ? fabs((double)v0[r]) > 1e-9 : fabsf((float)v0[r]) > 1e-9f;
+              if (MODE == 1 && p.origin) f0 = fabsf((float)v0[r] + ((lane_ & 31) == i ? 1.f : 0.f)) > 1e-9f;
+              const unsigned long long k0 = __ballot(f0 && lane_ < N);
+              if (lane_ == 0) {
+                unsigned* m = reinterpret_cast<unsigned*>(lds + MO) + 4 * R;
+                m[0] = (i < N && 4 * b + sl < p.Binst) ? (unsigned)k0 : 0u; m[1] = 0u; m[2] = 0u; m[3] = 0u;
+              }
+            }
+          }
+        };
         auto stage = [&](auto tag) {
           typedef decltype(tag) ST;
           const ST* Sp = static_cast<const ST*>(p.S) + (long long)b * N * N;
@@ -266,15 +306,21 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
             }
           }
         };
-        if (p.s_is_f64) stage(double{});
-        else stage(float{});
+        if constexpr (PACK) {
+          if (p.s_is_f64) stage_pack(double{});
+          else stage_pack(float{});
+        } else {
+          if (p.s_is_f64) stage(double{});
+          else stage(float{});
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       GM_SYNC();
-      for (int idx = t; idx < N * 16; idx += 256) {
+      for (int idx = t; idx < NR * 16; idx += 256) {
         const int row = idx >> 4, ch = idx & 15;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + xst + idx * 32);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + xst + idx * 32 + 16);
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + xst + idx * 32);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + xst + idx * 32 + 16);
+        if (PACK && !((row & 31) < N && 4 * b + (row >> 5) < p.Binst)) v0 = v1 = f32x4{0.f, 0.f, 0.f, 0.f};      // (nothing was fetched)
         // the activation scale first (a power of two: exact), then the planes.  A NaN must raise the flag too - fmaxf drops it
         // from the running maximum; everything later is made of these planes and finite weights
         float xv[8] = {v0[0] * xs, v0[1] * xs, v0[2] * xs, v0[3] * xs, v1[0] * xs, v1[1] * xs, v1[2] * xs, v1[3] * xs};
@@ -296,7 +342,13 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
     GM_STAMP(15);
     // edge mask of this lane's row i = cw (bits j), shifted so that bit (8 (r / 4) + r % 4) is row 32 mt + ... of the tile
     unsigned mk[4] = {0u, 0u, 0u, 0u};
-    if (cw_ < N) {
+    if constexpr (PACK) {      // row i = lane % 32 of instance 4 b + w; its mask covers the instance's own (<= 32) columns
+      if (fr < N && 4 * b + w < p.Binst) {
+        const unsigned m = p.rmask_pre ? p.rmask_pre[((long long)(4 * b + w) * N + fr) * 4]
+                                       : *reinterpret_cast<const unsigned*>(lds + MO + 16 * cw_);
+        mk[0] = m >> (4 * h_);
+      }
+    } else if (cw_ < N) {
       const uint4 m = p.rmask_pre ? *reinterpret_cast<const uint4*>(p.rmask_pre + ((long long)b * N + cw_) * 4)
                                   : *reinterpret_cast<const uint4*>(lds + MO + 16 * cw_);
       mk[0] = m.x >> (4 * h_); mk[1] = m.y >> (4 * h_); mk[2] = m.z >> (4 * h_); mk[3] = m.w >> (4 * h_);
@@ -320,12 +372,12 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
       // X fragments of a tap: ONE register set.  Within a k step the products run hi*hi, hi*lo, lo*hi over the row tiles, so
       // tile mt's hi plane is free after the second product and its lo plane after the third: each is re-loaded for the
       // next k step right behind its last MFMA (a whole product, >= 128 cycles, ahead of its next use).
-      auto tap_load_a1 = [&](int ks, int mt, int pl) {
+      auto tap_load_a1 = [&](int ks, int mt, int pl) __attribute__((always_inline)) {
         const char* ap = lds + (rsw3[mt] + (xsw3[mt] ^ (unsigned)(ks << 5)));
         a3[mt][pl] = lds128(ap, 256 * pl);
       };
       // item i of tap k's static MFMA sequence (k step, product, row tile); i is a constant wherever this is called
-      auto tap_one = [&](int k, int i) {
+      auto tap_one = [&](int k, int i) __attribute__((always_inline)) {
         const int ks = i / TAP_PER, r = i % TAP_PER;
         const int f = 8 + 8 * (KT - 1 - k) + ks;      // this k step's fragment in the weight stream
         if (i == 0) {
@@ -343,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
         if (ks + 1 < 8 && q >= 1) tap_load_a1(ks + 1, mt, q - 1);
         if (r == TAP_PER - 1) wr_load(hd, f + 4);      // (the k step's last MFMA: its slot takes the fragment four ahead)
       };
-      auto tap_upto4 = [&](int k, int lo, int hi) {      // items lo .. hi - 1, hi - lo <= 4
+      auto tap_upto4 = [&](int k, int lo, int hi) __attribute__((always_inline)) {      // items lo .. hi - 1, hi - lo <= 4
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (lo + j < hi) tap_one(k, lo + j);
@@ -451,20 +503,36 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
       }
       // ---- G2: E^T[j][i], softmax over j per column i, A planes [j][i] * 2^8
       if (g2_active) {
-        GM_ROWS(rsw, xsw)
-        f32x16 acce[1][MT];
+        // (rows j of the score tiles: every row tile of the instance - or, PACK, the one slot this wave scores: tile w)
+        unsigned rsw[MTS], xsw[MTS];
+        {
+          int l_ = lane;
+          asm volatile("" : "+v"(l_));
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+          for (int mt_ = 0; mt_ < MTS; ++mt_) {
+            const int row_ = PACK ? 32 * w + (l_ & 31) : min(32 * mt_ + (l_ & 31), N - 1);
+            rsw[mt_] = row_ * 512;
+            xsw[mt_] = ((l_ >> 5) ^ (row_ & 15)) << 4;
+          }
+        }
+        constexpr int TR = MT / MTS;      // MFMAs of tap K - 2 per interleave point (PACK: four times fewer points)
+        auto tap_run = [&](int lo) __attribute__((always_inline)) {
+#pragma unroll
+          for (int i = 0; i < TR; ++i) tap_one(KT - 2, lo + i);
+        };
+        f32x16 acce[1][MTS];
+#pragma unroll
+        for (int mt = 0; mt < MTS; ++mt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acce[0][mt][r] = 0.f;
         if constexpr (MODE == 1) {
           const float kc = p.kconst ? p.kconst[hd] : 0.f;
           const float c2i = *reinterpret_cast<const float*>(lds + CF + 512 + 4 * min(cw, 127)) * ixs + kc;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
+          for (int mt = 0; mt < MTS; ++mt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const f32x4 c1 = *reinterpret_cast<const f32x4*>(lds + CF + 4 * (32 * mt + 8 * q + 4 * h));
+              const f32x4 c1 = *reinterpret_cast<const f32x4*>(lds + CF + 4 * (32 * (PACK ? w : mt) + 8 * q + 4 * h));
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const float ev = __builtin_fmaf(c1[e], ixs, c2i);
@@ -473,12 +541,12 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
             }
         }
         if constexpr (MODE == 0) {
-        const int rowb = min(32 * w + (cw & 31), N - 1);      // this wave's i tile as B operand
+        const int rowb = PACK ? cw : min(32 * w + (cw & 31), N - 1);      // this wave's i tile as B operand
         const unsigned rswb = rowb * 512, xswb = (h ^ (rowb & 15)) << 4;
         const char* qbase = lds + UO;
-        uint4 a[MT][2], bq[2][2];
+        uint4 a[MTS][2], bq[2][2];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = 0; mt < MTS; ++mt) {
           const char* ap = qbase + (rsw[mt] + xsw[mt]);
           a[mt][0] = lds128(ap, 0);
           a[mt][1] = lds128(ap, 256);
@@ -498,7 +566,7 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
 #pragma unroll
           for (int q = 0; q < 3; ++q)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < MTS; ++mt) {
               acce[0][mt] = mfma16(a[mt][q == 2 ? 1 : 0], bq[ks & 1][q == 1 ? 1 : 0], acce[0][mt]);
               if (ks + 1 < 8 && q >= 1)
                 a[mt][q - 1] = lds128(qbase + (rsw[mt] + (xsw[mt] ^ (unsigned)((ks + 1) << 5))), 256 * (q - 1));
@@ -515,10 +583,10 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
         unsigned mkl[4] = {mk[0], mk[1], mk[2], mk[3]};      // (laundered: the per-entry masks are formed here, per head)
         asm volatile("" : "+v"(mkl[0]), "+v"(mkl[1]), "+v"(mkl[2]), "+v"(mkl[3]));
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MTS; ++mt)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {      // (one MFMA of tap K - 2 per four entries)
-            tap_one(KT - 2, (mt * 4 + q) * TAP_ALL / (24 * MT));
+            tap_run(TR * (mt * 4 + q));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int r = 4 * q + e;
@@ -536,10 +604,10 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
         const float cexp = mx > -__builtin_inff() ? -mx * kLog2e : 0.f;
         float sum = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MTS; ++mt)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            tap_one(KT - 2, (4 * MT + mt * 4 + q) * TAP_ALL / (24 * MT));
+            tap_run(4 * MT + TR * (mt * 4 + q));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int r = 4 * q + e;
@@ -553,33 +621,34 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
         GM_STAMP(13);
         {
           // (lanes past the KI columns of A store into the 8 pad columns of the row: nothing reads them)
-          char* abp = lds + (AO + 4 * h * SA + min(cw, KI + 7) * 2);
+          // (PACK: rows 32 w + ... of the pack, local column i = lane % 32)
+          char* abp = lds + (PACK ? AO + (32 * w + 4 * h) * SA + (cw & 31) * 2 : AO + 4 * h * SA + min(cw, KI + 7) * 2);
           char* alp = abp + AP;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
+          for (int mt = 0; mt < MTS; ++mt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const int t0 = (8 * MT + (mt * 4 + q) * 4) * TAP_ALL / (24 * MT);      // four MFMAs of tap K - 2 per row group
+              const int t0 = 8 * MT + TR * (mt * 4 + q) * 4;      // four (PACK: sixteen) MFMAs of tap K - 2 per row group
               unsigned ha[2], la[2];
-              tap_one(KT - 2, t0);
+              tap_run(t0);
               // (single multiplies on purpose: v_pk_mul_f32 does not run under an MFMA of the same wave - tools/exp/mfma_valu.hip)
               const float v01[2] = {mul1(acce[0][mt][4 * q], inv), mul1(acce[0][mt][4 * q + 1], inv)};
               const float v23[2] = {mul1(acce[0][mt][4 * q + 2], inv), mul1(acce[0][mt][4 * q + 3], inv)};
               GM_PIN();
-              tap_one(KT - 2, t0 + 1);
+              tap_run(t0 + TR);
               split_pair(v01[0], v01[1], ha[0], la[0]);
               GM_PIN();
-              tap_one(KT - 2, t0 + 2);
+              tap_run(t0 + 2 * TR);
               split_pair(v23[0], v23[1], ha[1], la[1]);
               GM_PIN();
-              tap_one(KT - 2, t0 + 3);
+              tap_run(t0 + 3 * TR);
               const int jg = 32 * mt + 8 * q;
               const unsigned short hv[4] = {(unsigned short)ha[0], (unsigned short)(ha[0] >> 16), (unsigned short)ha[1],
                                             (unsigned short)(ha[1] >> 16)};
               const unsigned short lv[4] = {(unsigned short)la[0], (unsigned short)(la[0] >> 16), (unsigned short)la[1],
                                             (unsigned short)(la[1] >> 16)};
               GM_PIN();
-              if (jg < N) {                                         // (wave-uniform)
+              if (PACK || jg < N) {                                 // (wave-uniform; PACK: every row of the slot - rows past N are zeros)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   GM_AW(abp + (jg + e) * SA, hv[e]);
@@ -600,16 +669,16 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
       auto hop = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
         // U^T planes [c][i] <- acc_{k+1} 2^-8: a lane holds column c = cw, 4 consecutive i per register quad
-        char* ub = lds + (UO + cw * SA + h * 8);       // (+ 4 h rows of the quad: 8 bytes)
+        char* ub = lds + (UO + cw * SAU + h * 8);      // (+ 4 h rows of the quad: 8 bytes)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int i0 = 32 * mt + 8 * q;      // + 4 h
-            if (i0 < KI) {                        // (KI is a multiple of 16: both 4-row halves are inside or outside)
+            if (i0 < KIU) {                       // (KIU is a multiple of 16: both 4-row halves are inside or outside)
               // (K = 3: tap 0, half under each hop's plane conversion; the last hop's product needs it complete)
-              constexpr int NG2 = KI / 4;      // row groups of both hops
-              const int gi = (k == 1 ? 0 : KI / 8) + mt * 4 + q;
+              constexpr int NG2 = KIU / 4;     // row groups of both hops
+              const int gi = (k == 1 ? 0 : KIU / 8) + mt * 4 + q;
               const int u0 = TAP_ALL * gi / NG2, u1 = TAP_ALL * (gi + 1) / NG2, um = (u0 + u1) / 2;
               uint2 hi, lo;
               if constexpr (KT == 3) tap_upto4(0, u0, um);
@@ -626,10 +695,31 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's own rows: no barrier
         GM_AROWS(rpa)
-        const char* up = lds + (UO + cw * SA + h * 16);
+        const char* up = lds + (UO + cw * SAU + h * 16);
         const char* apl[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) apl[mt] = lds + rpa[mt];
+        if constexpr (PACK) {
+          // block-diagonal hop: slot mt contracts over its own instance - A rows 32 mt + .. (32 local columns) against columns
+          // 32 mt .. 32 mt + 31 of the U^T rows: two k steps per slot, the products in the order of the unpacked kernel
+          uint4 a[MT][2], bu[MT][2];
+#pragma unroll
+          for (int ks = 0; ks < KSI; ++ks) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              a[mt][0] = lds128(apl[mt], ks * 32);
+              a[mt][1] = lds128(apl[mt] + AP, ks * 32);
+              bu[mt][0] = lds128(up, 64 * mt + 32 * ks);
+              bu[mt][1] = lds128(up, 64 * mt + 32 * ks + UP);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+                acc[k][mt] = mfma16(a[mt][q == 2 ? 1 : 0], bu[mt][q == 1 ? 1 : 0], acc[k][mt]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
         uint4 a[2][MT][2], bu[2][2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -652,6 +742,7 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
           mma_step_row<MT>(acc[k], a[ks & 1], bu[ks & 1]);
           __builtin_amdgcn_sched_barrier(0);
         }
+        }      // (!PACK)
         GM_STAMP(7 + (KT - 2 - k));
       };
       if constexpr (KT == 3) hop(std::integral_constant<int, 1>{});
@@ -662,7 +753,8 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
       // 16 sixteen-byte stores, each row still a 128-byte run per instruction.
       {
         const int fq = cw & 3;                                   // this lane's row of the 4 x 4 block after the transpose
-        const char* ybase = reinterpret_cast<const char*>(p.Y + (long long)b * N * p.ldy + (CONCAT ? hd * 128 : 0));
+        // (PACK: slot mt is instance 4 b + mt, its rows the N agents of that instance)
+        const char* ybase = reinterpret_cast<const char*>(p.Y + (long long)b * (PACK ? 4 : 1) * N * p.ldy + (CONCAT ? hd * 128 : 0));
         const unsigned lbyte = (unsigned)((cw & ~3) + (4 * h + fq) * p.ldy) * 4u;
         const long long rowb = (long long)p.ldy * 4;
         const bool last = hd == p.P - 1;
@@ -675,14 +767,14 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int jg = 32 * mt + 8 * q;
+            const int jg = PACK ? 8 * q : 32 * mt + 8 * q;        // first row of the quad group inside its instance
             if (jg >= N) break;                                   // (wave-uniform)
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(acc[0][mt][4 * q + e], kOutScale, biasv);
             quad_transpose4(v, lane);
-            const bool rok = jg + 4 * h + fq < N;
-            f32x4* dst = reinterpret_cast<f32x4*>(const_cast<char*>(ybase + jg * rowb) + lbyte);
+            const bool rok = jg + 4 * h + fq < N && (!PACK || 4 * b + mt < p.Binst);
+            f32x4* dst = reinterpret_cast<f32x4*>(const_cast<char*>(ybase + ((PACK ? mt * N : 0) + jg) * rowb) + lbyte);
             f32x4 o = {v[0], v[1], v[2], v[3]};
             if constexpr (CONCAT) {
 #pragma unroll
@@ -711,6 +803,8 @@ size_t gat_mfma_lds(int N, int ksi) {
   const size_t sa = 2 * 16 * (size_t)ksi + 16, r8 = ((size_t)N + 7) & ~(size_t)7;
   return 2 * (size_t)N * 256 + 2 * r8 * sa + 2 * 128 * sa;
 }
+// PACK form: X planes [128], A planes [128][80], U^T planes [128][272]
+constexpr size_t kGatPackLds = 2 * 128 * 256 + 2 * 128 * 80 + 2 * 128 * 272;
 
 // shape classes: (MT, KSI) = (1, 2) N <= 32, (2, 4) N <= 64, (4, 7) N <= 102 (the LDS bound)
 int gat_mfma_class(int N) {
@@ -718,6 +812,28 @@ int gat_mfma_class(int N) {
   const int c = N <= 32 ? 0 : (N <= 64 ? 1 : 2);
   const int ksi = c == 0 ? 2 : (c == 1 ? 4 : 7);
   return (N <= 16 * ksi && gat_mfma_lds(N, ksi) <= 160 * 1024) ? c : -1;
+}
+
+// four instances per pass (N <= 32; see the kernel): one workgroup per pack, every head in it
+template <int KT, int MODE>
+int launch_pack(const GatMfmaParams& p, int slot, hipStream_t st) {
+  const void* fn = p.concat ? reinterpret_cast<const void*>(&gat_mfma_kernel<4, 2, KT, true, MODE, true>)
+                            : reinterpret_cast<const void*>(&gat_mfma_kernel<4, 2, KT, false, MODE, true>);
+  if (magat_ensure_dyn_lds(fn, slot, kGatPackLds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
+  GatMfmaParams q = p;
+  q.Binst = p.B;
+  q.B = (p.B + 3) / 4;
+  q.hsplit = 1;
+  const int blocks = q.B < cus ? q.B : cus;
+  const int pid = magat_prof_begin(MAGAT_TAG_GAT_LAYER, st);
+  if (p.concat) hipLaunchKernelGGL((gat_mfma_kernel<4, 2, KT, true, MODE, true>), dim3(blocks), dim3(256), kGatPackLds, st, q);
+  else hipLaunchKernelGGL((gat_mfma_kernel<4, 2, KT, false, MODE, true>), dim3(blocks), dim3(256), kGatPackLds, st, q);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
 }
 
 template <int MT, int KSI, int KT, int MODE>
@@ -750,6 +866,18 @@ int launch(const GatMfmaParams& p, int slot, hipStream_t st) {
 template <int MODE>
 int launch_class(const GatMfmaParams& p, int K, hipStream_t st) {
   const int cls = gat_mfma_class(p.N);
+  // N <= 32: four instances per pass once the batch fills the chip that way (option GAT_PACK, default 1; below that a workgroup
+  // per instance - or per (instance, head) - has the shorter critical path: the closed-loop step of a single instance).  Packed
+  // and unpacked forms produce the same bits for every instance.
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
+  const int pack = magat_opt(MAGAT_OPT_GAT_PACK);
+  if (cls == 0 && pack && (pack >= 2 || (long long)p.B >= 2LL * cus)) {
+    const int slot = MAGAT_LDS_GATP_0 + 4 * MODE + (K == 3 ? 0 : 2) + (p.concat ? 0 : 1);
+    return K == 3 ? launch_pack<3, MODE>(p, slot, st) : launch_pack<2, MODE>(p, slot, st);
+  }
   if (cls == 0) return K == 3 ? launch<1, 2, 3, MODE>(p, MAGAT_LDS_GATM_0, st) : launch<1, 2, 2, MODE>(p, MAGAT_LDS_GATM_0 + 1, st);
   if (cls == 1) return K == 3 ? launch<2, 4, 3, MODE>(p, MAGAT_LDS_GATM_0 + 2, st) : launch<2, 4, 2, MODE>(p, MAGAT_LDS_GATM_0 + 3, st);
   if (cls == 2) return K == 3 ? launch<4, 7, 3, MODE>(p, MAGAT_LDS_GATM_0 + 4, st) : launch<4, 7, 2, MODE>(p, MAGAT_LDS_GATM_0 + 5, st);
@@ -778,6 +906,7 @@ int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64,
   p.bias = bias; p.Y = Y; p.ldy = ldy; p.B = B; p.N = N; p.P = P; p.concat = concat; p.range_flag = range_flag;
   p.dbg = nullptr;
   p.hsplit = 1;
+  p.Binst = B;
 #ifdef MAGAT_DEBUG_HOOKS
   p.dbg = g_gat_mfma_dbg;
 #endif

@@ -68,7 +68,7 @@ enum MagatOpt {
   MAGAT_OPT_L1_FUSED, MAGAT_OPT_HEAD_SPLITK, MAGAT_OPT_GAT_CHUNK_MB, MAGAT_OPT_GAT_ZPAD, MAGAT_OPT_GAT_SPLIT,
   MAGAT_OPT_GAT_HPB, MAGAT_OPT_GAT_ZTILES, MAGAT_OPT_GAT_PERSIST, MAGAT_OPT_RANGE_GUARD, MAGAT_OPT_BLOCK_FUSED,
   MAGAT_OPT_CSR_TILED, MAGAT_OPT_BLOCK3_FUSED,
-  MAGAT_OPT_HEAD_F16, MAGAT_OPT_BLOCK_FULL, MAGAT_OPT_GAT_MFMA, MAGAT_OPT_GUARD_CHAIN, MAGAT_OPT_HEAD_GL, MAGAT_OPT_SKINNY, MAGAT_OPT_COUNT
+  MAGAT_OPT_HEAD_F16, MAGAT_OPT_BLOCK_FULL, MAGAT_OPT_GAT_MFMA, MAGAT_OPT_GUARD_CHAIN, MAGAT_OPT_HEAD_GL, MAGAT_OPT_SKINNY, MAGAT_OPT_GAT_PACK, MAGAT_OPT_COUNT
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)
@@ -81,7 +81,9 @@ enum MagatLdsSlot {
   MAGAT_LDS_CSR_TILED_A4, MAGAT_LDS_CSR_TILED_B4, MAGAT_LDS_CSR_TILED_A16_4, MAGAT_LDS_CSR_TILED_B16_4, MAGAT_LDS_BLOCK_B4, MAGAT_LDS_BLOCK_FULL, MAGAT_LDS_BLOCK_FULL_P,
   MAGAT_LDS_GATM_0,      // gat_mfma.hip: 24 slots (score mode x shape class x taps x merge)
   MAGAT_LDS_GATM_END = MAGAT_LDS_GATM_0 + 24,
-  MAGAT_LDS_STEM8
+  MAGAT_LDS_STEM8,
+  MAGAT_LDS_GATP_0,      // gat_mfma.hip PACK form: 8 slots (score mode x taps x merge)
+  MAGAT_LDS_GATP_END = MAGAT_LDS_GATP_0 + 8
 };
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of

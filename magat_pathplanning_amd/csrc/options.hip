@@ -49,6 +49,8 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
     {"GUARD_CHAIN", 1},      // the range guard's float32 re-run of the encoder: every layer behind the stem in ONE predicated launch
     {"HEAD_GL", 1},          // pooled map of the chain kernel granule-major for the f16x3 head (0: row-major agent tiles)
     {"SKINNY", 1},           // float32 1x1 layers with at most 8 outputs (the action head) as streamed dot products, not MFMA tiles
+    {"GAT_PACK", 1},         // one-launch graph layer, N <= 32: four planning instances per pass (1: when the batch fills the chip
+                             // that way; 2: always; 0: never)
 };
 
 int g_val[MAGAT_OPT_COUNT];

@@ -166,3 +166,60 @@ def test_gat_mfma_orientation_is_observable(gpu_device, tag_counts):
     changed = (y - y_empty).abs().amax(dim=1) > 1e-4            # (B, N): nodes whose output the edge changed
     assert changed[0].nonzero().flatten().tolist() == [31]
     assert changed[1].nonzero().flatten().tolist() == [7]
+
+
+@pytest.mark.parametrize("mode", ["KeyQuery", "GAT_modified", "GAT_origin"])
+@pytest.mark.parametrize("N,K,P,concat,dt,B", [(20, 3, 4, True, torch.float64, 7), (10, 2, 1, True, torch.float32, 9),
+                                               (32, 3, 4, False, torch.float32, 5), (1, 3, 2, True, torch.float32, 4),
+                                               (17, 2, 4, False, torch.float64, 6), (12, 3, 4, True, torch.float32, 13)])
+def test_gat_mfma_packed_instances_same_bits_as_unpacked(gpu_device, libopt, tag_counts, mode, N, K, P, concat, dt, B):
+    """Round 4, small graphs (N <= 32): four planning instances per pass of the one-launch kernel, each in its own 32-row slot
+    (option GAT_PACK: 2 = always, 0 = never, 1 = when the batch fills the chip).  An instance's arithmetic does not depend on
+    its slot or on its pack mates: packed and unpacked forms agree BIT FOR BIT - batches that do not fill their last pack,
+    directed GSOs with threshold entries and a NaN, all three attention modes, both merges - and both match the oracle."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin
+    from magat_pathplanning_amd.synthetic import directed_gso
+    from oracle import magat_oracle as orc
+    torch.manual_seed(77 + N)
+    g = torch.Generator().manual_seed(N + B)
+    cls = GraphFilterBatchAttentional_Origin if mode == "GAT_origin" else GraphFilterBatchAttentional
+    layer = cls(128, 128, K, P, concatenate=concat, attentionMode=mode)
+    if mode == "GAT_modified":
+        with torch.no_grad():
+            layer.weight_bias.uniform_(-0.3, 0.3, generator=g)
+    S = directed_gso(B, N, 0.3, seed=N + 3, dtype=dt)
+    x = torch.randn(B, 128, N, generator=g) * 0.7
+    y_ref, _ = orc.gat_layer_forward(x, S.unsqueeze(1), {k: v.detach() for k, v in layer.state_dict().items()}, mode, concat)
+    layer = layer.to(gpu_device).eval()
+    out = {}
+    for pack in (2, 0):
+        libopt.set("GAT_PACK", pack)
+        layer.addGSO(S.unsqueeze(1).to(gpu_device))
+        with tag_counts() as tc, torch.no_grad():
+            out[pack] = layer(x.to(gpu_device)).cpu()
+        assert tc["gat_layer (one launch)"] > 0, tc.counts
+    assert torch.isfinite(out[2]).all()
+    assert torch.equal(out[2], out[0])
+    np.testing.assert_allclose(out[2].numpy(), y_ref.numpy(), rtol=0, atol=3e-5)
+    # ... and the position inside the batch (= the slot) does not matter either
+    libopt.set("GAT_PACK", 2)
+    perm = torch.randperm(B, generator=g)
+    layer.addGSO(S[perm].unsqueeze(1).to(gpu_device))
+    with torch.no_grad():
+        yp = layer(x[perm].to(gpu_device)).cpu()
+    assert torch.equal(yp, out[2][perm])
+
+
+def test_gat_mfma_packed_at_benchmark_size(gpu_device, libopt):
+    """BASELINE config 2's graph layer (1024 instances of 20 agents, K = 3, P = 4): the packed form is what runs by default at
+    this size (GAT_PACK = 1) and equals the unpacked form bit for bit."""
+    B, N, K, P = 1024, 20, 3, 4
+    layer, S, x = _layer_and_inputs(B, N, K, P, True, seed=11)
+    layer = layer.to(gpu_device).eval()
+    out = {}
+    for pack in (1, 0):
+        libopt.set("GAT_PACK", pack)
+        layer.addGSO(S.unsqueeze(1).to(gpu_device))
+        with torch.no_grad():
+            out[pack] = layer(x.to(gpu_device)).cpu()
+    assert torch.equal(out[1], out[0])
