@@ -1299,6 +1299,10 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     // several instances, prefetching across the instance boundary as well
     int inst_slots = (cb + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD;
     if (magat_opt(MAGAT_OPT_GAT_PERSIST) && hpb == P && hpb > 1 && inst_slots > GAT_PLAN_WALKERS) inst_slots = GAT_PLAN_WALKERS;
+    // the range guard's predicated re-run: a launch that returns at once still pays for every workgroup it dispatches - with one
+    // workgroup per (instance, head) that was 4096 dispatches, 76 us per forward at BASELINE config 2 (1024 instances of 20
+    // agents; 88 us of a 1.10 ms step went to the guard).  The workgroups walk the instances instead (istride below)
+    if (rerun_only && inst_slots > 128) inst_slots = 128;
     const int blocks = inst_slots * (P / hpb);
     p.order = nullptr;
     p.rmask_pre = nullptr;

@@ -279,3 +279,34 @@ def test_non_finite_inputs_are_not_clamped_into_finite_numbers(gpu_device, bad):
     with torch.no_grad():
         got = net(x.to(gpu_device)).cpu().view(B, N, 5)
     assert not net.range_status()["encoder_rerun"] and torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("B,N", [(300, 20), (1100, 10), (40, 100)])
+def test_graph_layer_rerun_with_many_instances(gpu_device, B, N):
+    """The guard's float32 re-run of the graph layer walks the instances with a capped grid (a predicated launch pays for
+    every workgroup it dispatches: 4096 of them cost 76 us per forward at BASELINE config 2).  A layer input beyond the planes'
+    range at instance counts far above the cap: the re-run must rewrite EVERY instance's rows (checked against the oracle)."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional, _native as nat
+    from magat_pathplanning_amd.synthetic import comm_gso
+    from oracle import magat_oracle as orc
+    import ctypes
+    torch.manual_seed(5)
+    g = torch.Generator().manual_seed(B + N)
+    layer = GraphFilterBatchAttentional(128, 128, 3, 4, concatenate=True, attentionMode="KeyQuery")
+    with torch.no_grad():                 # small weights: the scores stay where float32 follows the reference
+        layer.weight.mul_(1e-4)
+    S = comm_gso(B, N, {100: 50, 20: 28, 10: 20}[N], seed=3)
+    x = torch.randn(B, 128, N, generator=g) * 0.5
+    x[::7] *= 4.0e5                       # every seventh instance leaves the f16 range
+    y_ref, _ = orc.gat_layer_forward(x.double(), S.unsqueeze(1).double(),
+                                     {k: v.detach().double() for k, v in layer.state_dict().items()}, "KeyQuery", True)
+    layer = layer.to(gpu_device).eval()
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    with torch.no_grad():
+        y = layer(x.to(gpu_device)).cpu()
+    st = (ctypes.c_int32 * 2)()
+    ws = layer._scratch.workspace
+    nat.check(nat.lib().magat_gat_read_status(nat.ptr(ws), st, nat.current_stream(ws.device)), "magat_gat_read_status")
+    assert st[0] == 1, list(st)
+    scale = y_ref.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1.0)
+    assert float(((y.double() - y_ref).abs() / scale).max()) <= 1e-4
