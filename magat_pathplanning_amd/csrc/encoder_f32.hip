@@ -35,7 +35,13 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
   const int PS = (3 * PHW) | 1;            // odd per-agent stride
   const int HW = H * W;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int m0 = blockIdx.x * 32;
+  float amax = 0.f;          // calibration launches: largest stem output of this wave
+  // (grid-stride over the 32-agent blocks: one block per workgroup in ordinary launches; the range guard's predicated re-run
+  //  is launched with a capped grid - a launch that returns at once still pays for every workgroup it dispatches, and these
+  //  carry 65 KB of LDS each: 1600 .. 4000 of them were 10 .. 26 us per forward)
+  for (int blk = blockIdx.x; blk * 32 < M; blk += gridDim.x) {
+  if (blk != (int)blockIdx.x) __syncthreads();
+  const int m0 = blk * 32;
   for (int i = t; i < 32 * PS; i += 256) img[i] = 0.f;
   __syncthreads();
   const int per = 3 * HW;
@@ -101,7 +107,6 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
   for (int q = 0; q < 4; ++q) bch[q] = *reinterpret_cast<const f32x4*>(bias + 8 * q + 4 * (lane >> 5));
   __syncthreads();
   const int abase = (lane & 31) * PS;
-  float amax = 0.f;          // calibration launches: largest stem output of this wave
   for (int lpix = wave; lpix < bh * W; lpix += 4) {
     const int oy = lpix / W, ox = lpix - oy * W;
     const int base = abase + oy * PW + ox;
@@ -180,6 +185,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
       }
     }
   }
+  }      // (32-agent blocks)
   if (absmax) {
     amax = wave_max(amax);
     if (lane == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(absmax), __builtin_bit_cast(unsigned, amax));
@@ -281,7 +287,8 @@ static int conv_first_launch(const float* x, const float* wt, const float* bias,
                                : reinterpret_cast<const void*>(&conv_first_kernel<0, 0>),
                            c11 ? MAGAT_LDS_CONV_FIRST11 : MAGAT_LDS_CONV_FIRST, lds) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
-  const int blocks = (M + 31) / 32;
+  int blocks = (M + 31) / 32;
+  if (run_if && blocks > 256) blocks = 256;      // predicated re-run: a capped grid that walks the blocks (see the kernel)
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int pid = magat_prof_begin(tag, st);
   if (c11)

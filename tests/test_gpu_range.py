@@ -310,3 +310,24 @@ def test_graph_layer_rerun_with_many_instances(gpu_device, B, N):
     assert st[0] == 1, list(st)
     scale = y_ref.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1.0)
     assert float(((y.double() - y_ref).abs() / scale).max()) <= 1e-4
+
+
+def test_encoder_rerun_with_more_agent_blocks_than_the_capped_grid(gpu_device, monkeypatch):
+    """The predicated float32 stem of the guard's re-run is launched with at most 256 workgroups that walk the 32-agent blocks
+    (a no-op launch still pays for every workgroup it dispatches).  9 000 agents = 282 blocks with an out-of-range stem: the
+    re-run must rewrite every agent (oracle on a sample of instances)."""
+    monkeypatch.setenv("MAGAT_ACT_SCALE", "0")
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states
+    from oracle import magat_oracle as orc
+    cfg, sd, net = _scaled_model(gpu_device, 1.0e4, where="stem", N=100)
+    B, N = 90, 100
+    x, S = fov_states(B, N, seed=8), comm_gso(B, N, 50, seed=9)
+    with torch.no_grad():
+        net.addGSO(S.clone().to(gpu_device))
+        got = net(x.to(gpu_device)).cpu()
+    assert net.range_status()["encoder_rerun"]
+    for b in (0, 41, 89):
+        ref = orc.planner_forward(x[b:b + 1].double(), S[b:b + 1].clone().double(),
+                                  {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, cfg).float()
+        lim = 1e-4 * max(1.0, float(ref.abs().max()))
+        assert float((got[b * N:(b + 1) * N] - ref).abs().max()) <= lim, b
