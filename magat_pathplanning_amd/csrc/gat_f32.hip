@@ -1198,7 +1198,7 @@ extern "C" size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, i
 static bool gat_one_launch(int N, int G, int F, int K, int mode, int concat) {
   (void)concat;
   return magat_opt(MAGAT_OPT_GAT_MFMA) && magat_opt(MAGAT_OPT_GAT_SPLIT) && magat_opt(MAGAT_OPT_CONV_F16) &&
-         magat_gat_mfma_supported(N, G, F, K, mode);
+         (magat_gat_mfma_supported(N, G, F, K, mode) || magat_gat_small_supported(N, G, F, K, mode));
 }
 
 extern "C" int magat_gat_one_launch_supported(int N, int G, int F, int K, int mode, int concat) {
@@ -1255,9 +1255,13 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     const bool guard = magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
     const unsigned* masks = (plan && N <= 128) ? static_cast<const unsigned*>(plan) : nullptr;
     const float* frag = packed + magat_gat_frag_offset(L.NC, G);
-    const int rc = magat_gat_mfma_forward(X, G, S, s_is_f64, masks, frag, bias, Y, ldy, B, N, K, P, concat,
-                                          guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4), mode,
-                                          mode == MAGAT_MODE_KEYQUERY ? nullptr : frag + (size_t)(P * G + P * K * F) * G);
+    // (128 features: gat_mfma.hip; 32 / 64 features on graphs of at most 32 agents: gat_small.hip, a wave per instance)
+    const int rc = G == 128
+        ? magat_gat_mfma_forward(X, G, S, s_is_f64, masks, frag, bias, Y, ldy, B, N, K, P, concat,
+                                 guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4), mode,
+                                 mode == MAGAT_MODE_KEYQUERY ? nullptr : frag + (size_t)(P * G + P * K * F) * G)
+        : magat_gat_small_forward(X, G, S, s_is_f64, masks, packed + magat_gat_f16_block_offset(L.NC, G), L.NC, bias, Y, ldy, B,
+                                  N, G, K, P, concat, guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4));
     if (rc != MAGAT_OK || !guard) return rc;
     rerun_only = true;
     p.run_if = status;

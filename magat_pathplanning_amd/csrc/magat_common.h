@@ -72,7 +72,7 @@ enum MagatOpt {
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)
-#define MAGAT_LDS_SLOTS 64
+#define MAGAT_LDS_SLOTS 96
 int magat_ensure_dyn_lds(const void* func, int slot, size_t bytes);
 enum MagatLdsSlot {
   MAGAT_LDS_GAT16, MAGAT_LDS_GAT32, MAGAT_LDS_GAT64, MAGAT_LDS_GAT128, MAGAT_LDS_GAT256, MAGAT_LDS_L1FUSED,
@@ -83,7 +83,9 @@ enum MagatLdsSlot {
   MAGAT_LDS_GATM_END = MAGAT_LDS_GATM_0 + 24,
   MAGAT_LDS_STEM8,
   MAGAT_LDS_GATP_0,      // gat_mfma.hip PACK form: 8 slots (score mode x taps x merge)
-  MAGAT_LDS_GATP_END = MAGAT_LDS_GATP_0 + 8
+  MAGAT_LDS_GATP_END = MAGAT_LDS_GATP_0 + 8,
+  MAGAT_LDS_GATS_0,      // gat_small.hip: 8 slots (width x taps x merge)
+  MAGAT_LDS_GATS_END = MAGAT_LDS_GATS_0 + 8
 };
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of
@@ -98,6 +100,11 @@ __host__ __device__ inline size_t magat_gat_f16_block_offset(int NC, int G) {
 __host__ __device__ inline size_t magat_gat_frag_offset(int NC, int G) {
   return (magat_gat_f16_block_offset(NC, G) + (size_t)NC * G + 4 + 3) & ~(size_t)3;
 }
+// one-launch KeyQuery layer for small graphs and narrow features (gat_small.hip: N <= 32, G = F in {32, 64}, K = 2 | 3)
+int magat_gat_small_supported(int N, int G, int F, int K, int mode);
+int magat_gat_small_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre, const float* Hs,
+                            int NC, const float* bias, float* Y, int ldy, int B, int N, int G, int K, int P, int concat,
+                            int* range_flag, hipStream_t st, const float* x_scale);
 // one-launch KeyQuery layer on the matrix cores (gat_mfma.hip)
 int magat_gat_mfma_supported(int N, int G, int F, int K, int mode);
 int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre,

@@ -286,6 +286,23 @@ def main_gnn_model():
         print("wrote", path, os.path.getsize(path) // 1024, "KB", "max|logit| %.3g" % float(np.abs(out["logits"]).max()))
 
 
+def main_small():
+    """Round 4: layer fixtures at the PUBLISHED widths on small graphs (scripts/train_DMap.sh:42-46: 10 agents, bottleneckFeature
+    32, four heads, K = 2) - the shapes the wave-per-instance one-launch kernel (csrc/gat_small.hip) takes: N <= 32,
+    G = F in {32, 64}, KeyQuery; directed GSOs with threshold entries and a NaN."""
+    from magat_pathplanning_amd.synthetic import directed_gso
+    gml, _ = import_reference()
+    cases = [(10, 32, 2, 4, 0.3, True), (20, 64, 3, 4, 0.25, False), (32, 32, 3, 2, 0.15, True), (7, 64, 2, 1, 0.5, False)]
+    for si, (N, G, K, P, dens, f64) in enumerate(cases):
+        seed = 7337 + 29 * si
+        fx = layer_fixture(gml, "KeyQuery", N, G, K, P, seed=seed, density=dens, f64=f64,
+                           gso=lambda B, N_: directed_gso(B, N_, dens, seed=seed + 1,
+                                                          dtype=torch.float64 if f64 else torch.float32))
+        path = os.path.join(OUT, "gat_KeyQuery_small_N%d_G%d_K%d_P%d.npz" % (N, G, K, P))
+        np.savez_compressed(path, **fx)
+        print("wrote", path, os.path.getsize(path) // 1024, "KB")
+
+
 def main_grad():
     """Round 4: GRADIENT fixtures made by the real reference's autograd (the training step's loss.backward(),
     agents/decentralplannerlocal_OnlineExpert_GAT.py:560-567, at the layer level): for the seven shapes of
@@ -332,6 +349,8 @@ def main_grad():
 if __name__ == "__main__":
     if "--grad" in sys.argv:
         main_grad()
+    elif "--small" in sys.argv:
+        main_small()
     elif "--gnn-model" in sys.argv:
         main_gnn_model()
     elif "--fov" in sys.argv:

@@ -242,3 +242,41 @@ def test_packed_graph_layer_with_the_gso_plan(gpu_device, monkeypatch):
             net.addGSO(S.clone())
             out[plan] = net(x).clone()
     assert torch.isfinite(out["1"]).all() and torch.equal(out["0"], out["1"])
+
+
+@pytest.mark.parametrize("N,G,K,P,concat,dt,B", [(10, 32, 2, 4, False, torch.float32, 70), (10, 32, 2, 4, True, torch.float64, 5),
+                                                 (20, 64, 3, 4, True, torch.float32, 33), (32, 32, 3, 2, False, torch.float64, 9),
+                                                 (1, 32, 2, 1, True, torch.float32, 3), (27, 64, 2, 3, False, torch.float32, 1030)])
+def test_small_graph_kernel_vs_oracle_and_two_launch_form(gpu_device, libopt, tag_counts, N, G, K, P, concat, dt, B):
+    """csrc/gat_small.hip (round 4): the published widths (G = F = 32 | 64) on graphs of at most 32 agents as ONE launch, a wave
+    per planning instance.  Against the oracle on directed GSOs (threshold entries, a NaN), against the two-launch form, and the
+    instance-independence property: a permuted batch gives the permuted rows bit for bit (an instance's result depends on
+    neither its wave nor its workgroup)."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from magat_pathplanning_amd.synthetic import directed_gso
+    from oracle import magat_oracle as orc
+    torch.manual_seed(31 + N + G)
+    g = torch.Generator().manual_seed(N * G + B)
+    layer = GraphFilterBatchAttentional(G, G, K, P, concatenate=concat, attentionMode="KeyQuery")
+    Bo = min(B, 40)                       # (the oracle on the first instances only: it is a CPU restatement)
+    S = directed_gso(B, N, 0.3, seed=N + G, dtype=dt)
+    x = torch.randn(B, G, N, generator=g) * 0.7
+    y_ref, _ = orc.gat_layer_forward(x[:Bo], S[:Bo].unsqueeze(1), {k: v.detach() for k, v in layer.state_dict().items()},
+                                     "KeyQuery", concat)
+    layer = layer.to(gpu_device).eval()
+    out = {}
+    for fused in (1, 0):
+        libopt.set("GAT_MFMA", fused)
+        layer.addGSO(S.unsqueeze(1).to(gpu_device))
+        with tag_counts() as tc, torch.no_grad():
+            out[fused] = layer(x.to(gpu_device)).cpu()
+        assert (tc["gat_layer (one launch)"] > 0) == bool(fused), tc.counts
+    assert torch.isfinite(out[1]).all()
+    np.testing.assert_allclose(out[1][:Bo].numpy(), y_ref.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out[1].numpy(), out[0].numpy(), rtol=0, atol=2e-5)
+    libopt.set("GAT_MFMA", 1)
+    perm = torch.randperm(B, generator=g)
+    layer.addGSO(S[perm].unsqueeze(1).to(gpu_device))
+    with torch.no_grad():
+        yp = layer(x[perm].to(gpu_device)).cpu()
+    assert torch.equal(yp, out[1][perm])

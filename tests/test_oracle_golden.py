@@ -13,7 +13,7 @@ MODEL = golden_paths("model_")
 
 
 def test_fixtures_present():
-    assert len(LAYER) == 23 and len(MODEL) == 9      # 14 + the 9 directed-GSO layer fixtures of round 3
+    assert len(LAYER) == 27 and len(MODEL) == 9      # 14 + the 9 directed-GSO fixtures of round 3 + 4 small-graph ones (round 4)
 
 
 @pytest.mark.parametrize("path", LAYER, ids=[os.path.basename(p)[:-4] for p in LAYER])
