@@ -1251,7 +1251,9 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
   // form below follows in the same stream, every launch of it predicated on the flag the fused kernel raises.
   bool rerun_only = false;
   // (the one-launch kernel stores Y in 16-byte pieces: a column block at an odd offset of a wider buffer takes the two-launch form)
-  if (!A_opt && gat_one_launch(N, G, F, K, mode, concat) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
+  // ... and the small-graph kernel loads X rows as 16-byte pieces)
+  if (!A_opt && gat_one_launch(N, G, F, K, mode, concat) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
+      (G == 128 || (reinterpret_cast<uintptr_t>(X) & 15) == 0)) {
     const bool guard = magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
     const unsigned* masks = (plan && N <= 128) ? static_cast<const unsigned*>(plan) : nullptr;
     const float* frag = packed + magat_gat_frag_offset(L.NC, G);
