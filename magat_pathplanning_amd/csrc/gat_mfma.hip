@@ -6,6 +6,7 @@
 // Per planning instance b and head p, with X the [N][128] feature rows (all products are f16x3 split products - two f16
 // planes per operand, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation; weights carry a fixed 2^8):
 //   G1  Q[j][g]   = sum_f X[j][f] W_p[g][f]                      -> planes Q [j][g]        (graphML.py:1767-1769)
+//       (issued with swapped operands since round 4: the tile is Q^T and the planes are stored without a transpose)
 //   G2  E^T[j][i] = sum_g Q[j][g] X[i][g]   (e[i][j] = x_i . q_j), masked row softmax over j IN the accumulator layout
 //                   (a lane owns column i: its row of the softmax is 16 MT registers + the partner lane)
 //                                                               -> planes A [j][i] * 2^8   (graphML.py:1771-1776)

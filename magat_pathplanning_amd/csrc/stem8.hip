@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512, 1) void stem8_kernel(const Stem8Params p) {
   // EIGHT waves, two per SIMD: a lone wave issues in order - one instruction per ~5 cycles, and nothing beside its own MFMAs
   // (measured: the four-wave form of this kernel ran the stem's 9 MFMAs + ~105 vector / LDS instructions per tile as their
   // plain sum) - so the overlap of matrix and vector work has to come from a second wave on the SIMD:
-  //   phase 1 (all eight waves): the stem, four row tiles per wave;
+  //   phase 1 (all eight waves): the stem - five row tiles for waves 0-3, three for waves 4-7;
   //   phase 2: waves 0-3 = layer1.conv1 (the nine row tiles dealt as in the chain kernel's stage A: fragment weights are
   //            streamed once per tile list), waves 4-7 = everything that is vector / LDS work only - the NEXT group's raw
   //            maps -> f16 planes, the request for the maps of the group after it, and this group's stride-2 copy.
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512, 1) void stem8_kernel(const Stem8Params p) {
     S8_STAMP(0);
     L3_LDS_SYNC();        // this group's planes are written; every wave is done with the previous group's stem map
     S8_STAMP(1);
-    // ---- phase 1, stem: tiles of 4 pixels x 8 agents, wave w takes tiles w, w + 8, w + 16, w + 24 (tile 31 does not exist: its
+    // ---- phase 1, stem: tiles of 4 pixels x 8 agents (tile 31 does not exist: its
     // lanes repeat pixel 120, as the unused slots of tile 30 do - identical values written twice).  Software-pipelined: the
     // nine MFMAs of tile i alternate with the eight split-and-store pieces of tile i - 1's epilogue, the operand reads of
     // tile i + 1 are issued in front of them (what this wave cannot overlap, the other wave of its SIMD does).

@@ -26,6 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.magat_abi_version() == 4
+    assert lib.magat_build_flavor() == 0          # a release build: no timing-experiment switches compiled in
     assert lib.magat_error_string(-2).decode().startswith("unsupported")
     # pure host queries work without a device
     nc = 4 * 128 + 4 * 3 * 128            # fp32 [NC][G] + column bias [NC] + bf16x3 planes [3][NC][G] + f16x2 planes + scale
