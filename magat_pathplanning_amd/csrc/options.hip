@@ -28,7 +28,8 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
     {"CONV_PCHAIN", 1},      // f16 plane-granule activation chain between the BasicBlock convolutions
     {"CONV_MX", 0},          // OPT-IN: layer2/layer3 correction products in block-scaled fp8 (narrower than fp32-class)
     {"L1_FUSED", 2},         // stem + layer1.conv1 as one kernel: 2 = eight-agent groups (stem8_kernel), 1 = 64-agent row bands
-    {"HEAD_SPLITK", 12288},  // largest agent count for which the encoder head splits K by pooled cell
+    {"HEAD_SPLITK", 5120},   // largest agent count for which the encoder head splits K by pooled cell (round 4: measured crossover
+                             // against the f16x3 direct kernel at 4000-6000 agents; was 12288)
     {"GAT_CHUNK_MB", 2048},  // cap of the hoisted-map intermediate Z
     {"GAT_ZPAD", 32},        // row skew of Z (floats)
     {"GAT_SPLIT", 1},        // GAT maps on the split-MFMA GEMM
