@@ -56,6 +56,8 @@ const char* magat_error_string(int code);
  *   CONV_MX     (0)  OPT-IN block-scaled fp8 correction planes in layer2 / layer3 (narrower than fp32-class arithmetic)
  *   CONV_SPLIT  (7)  bit l: BasicBlock l+1 on the f16x3 split kernels; 0 = every convolution on the fp32 MFMA kernel
  *   HEAD_SPLITK      largest agent count whose encoder head sums per-cell partials (0: one long-K GEMM, bit-exact resharding)
+ *   CONV_BNFILL (256) f16x3 GEMMs with few agent tiles (the head at a few thousand agents) narrow their 128-column tile to 64 / 32
+ *                    until the launch has this many workgroups; results are bit-identical for every value
  *   BLOCK_FUSED (1), BLOCK3_FUSED (2)  BasicBlock chain kernels (maps of an 8-agent group in LDS); BLOCK3_FUSED 2 = the four-wave,
  *                    512-register form of the layer3 kernel, 1 = the eight-wave form, 0 = one launch per convolution
  *   BLOCK_FULL  (1)  both chain kernels as ONE launch (layer2's output never leaves the CU); needs BLOCK_FUSED 2, BLOCK3_FUSED 2

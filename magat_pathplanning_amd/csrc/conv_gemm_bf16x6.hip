@@ -968,6 +968,7 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
   }
 }
 
+
 }  // namespace
 
 // MAGAT_CONV_DIRECT=0 keeps f16x3 (in_fmt 4, out_fmt 0) on the 2x2 LDS-staged kernel
@@ -982,7 +983,19 @@ int magat_conv_direct_enabled() { return magat_opt(MAGAT_OPT_CONV_DIRECT); }
 int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   if (!d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
   if (d->M <= 0 || d->Cin <= 0 || d->Cout <= 0) return MAGAT_ERR_BAD_SHAPE;
-  const int BN = d->Cout % 128 == 0 ? 128 : (d->Cout % 64 == 0 ? 64 : 32);
+  int BN = d->Cout % 128 == 0 ? 128 : (d->Cout % 64 == 0 ? 64 : 32);
+  // few agents and one output pixel (the encoder head at the published batch sizes: 80 workgroups of 128 x 128 walking K = 1152
+  // alone on a 256-CU chip): narrower column tiles until the launch fills the chip (option CONV_BNFILL = the workgroup count
+  // to reach).  Head at 10 240 / 20 480 agents 46 -> 37 / 58 -> 48 us; narrower than the fill needs is SLOWER (51 200 agents at
+  // 64 / 32 columns: 72 -> 87 / 104 us), because every column tile splits the same activations into planes again.  What is
+  // left is the K walk itself: 36 slabs x ~1 000 cycles of barrier -> LDS read -> dependent MFMAs -> LDS write whatever the
+  // memory does (counters of a 4-slab-prefetch experiment: 321 cycles of average L2 latency, no TLB misses, waves half
+  // issuing, a third in barriers - profiles/r04d/head_stream_counters.txt; that kernel, a variant that splits the
+  // activations once per workgroup through LDS, and padded tile strides all landed on the same 32-34 us).
+  if (d->in_fmt == 4 && d->out_fmt == 0 && !d->out_ntile_stride && !d->out_gl && magat_conv_direct_enabled()) {
+    const long long want = magat_opt(MAGAT_OPT_CONV_BNFILL);
+    while (BN > 32 && (long long)((d->M + BM - 1) / BM) * d->Hout * d->Wout * (d->Cout / BN) < want) BN >>= 1;
+  }
   if ((d->Cout % BN) || (d->Cin % BK) || (d->C2 % BK) || (d->lda % 8) || (d->C2 > 0 && (d->lda2 % 8)) || d->pool)
     return MAGAT_ERR_UNSUPPORTED;
   if (d->in_fmt < 1 || d->in_fmt > 5 || d->out_fmt < 0 || d->out_fmt > 3) return MAGAT_ERR_UNSUPPORTED;

@@ -52,6 +52,9 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
     {"SKINNY", 1},           // float32 1x1 layers with at most 8 outputs (the action head) as streamed dot products, not MFMA tiles
     {"GAT_PACK", 1},         // one-launch graph layer, N <= 32: four planning instances per pass (1: when the batch fills the chip
                              // that way; 2: always; 0: never)
+    {"CONV_BNFILL", 256},    // f16x3 direct kernel: narrow the output-channel tile (128 -> 64 -> 32) until the launch has at
+                             // least this many workgroups (0: never).  Column tiling does not touch any element's summation order:
+                             // bit-identical
 };
 
 int g_val[MAGAT_OPT_COUNT];

@@ -224,6 +224,11 @@ def test_shard_equivalence_across_the_head_split(gpu_device, monkeypatch, libopt
     full0, parts0 = run()
     assert torch.equal(full0, parts0)
     assert torch.equal(full0, full)                   # above the threshold the default already is the one-GEMM form
+    # the column tile of the head GEMM narrows until the launch fills the chip (CONV_BNFILL; 7000 agents: 55 agent tiles ->
+    # 32-column tiles): no element's summation order depends on it
+    libopt.set("MAGAT_CONV_BNFILL", "0")
+    full1, parts1 = run()
+    assert torch.equal(full1, full0) and torch.equal(parts1, parts0)
 
 
 def test_cpu_tensor_inference_fails_loudly(gpu_device):
