@@ -706,12 +706,27 @@ __device__ __forceinline__ void chain_stage4(const ChainParams& p, char* lds, in
   const int lane = threadIdx.x & 63;
   const int fr = lane & 31, fh = lane >> 5, agent = fr & 7, psl = fr >> 3;
   f32x16 acc[NT];
+#if defined(MAGAT_WHATIF_TWICE) && defined(MAGAT_DEBUG_HOOKS)
+  // timing experiment (results unchanged): the walk runs twice, so that stage time (twice) - stage time (once) = the time of a
+  // walk whose code is already in the instruction cache (tools/chain_phase_probe.py; DESIGN.md 4.1 "cold code")
+#pragma unroll 1
+  for (int rep = 0; rep < 2; ++rep) {
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+    asm volatile("" ::: "memory");
+    walk4<TL, KSM, KS2, (CIN / 8) * BLK, (C2 > 0 ? C2 / 8 : 1) * BLK, w4_depth(NT, KSM)>(
+        lds, in_off, in2_off, wts + (size_t)ct * BPT * 1024, acc, true);
+  }
+#else
 #pragma unroll
   for (int s = 0; s < NT; ++s)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
   walk4<TL, KSM, KS2, (CIN / 8) * BLK, (C2 > 0 ? C2 / 8 : 1) * BLK, w4_depth(NT, KSM)>(
       lds, in_off, in2_off, wts + (size_t)ct * BPT * 1024, acc, true);
+#endif
   if (SYNC_BEFORE_EPI) __syncthreads();       // the output overwrites a map that other waves read until their walks end
   // epilogue: as chain_stage
   f32x4 bq[4];
@@ -1072,8 +1087,7 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
     for (int s = 0; s < 9; ++s)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
+    auto l3_half = [&](const int h) __attribute__((always_inline)) {
       const char* w2 = h == 0 ? l3.w2a + (size_t)ct2 * BPT2A * 1024 : l3.w2b + (size_t)ct2 * BPT2B * 1024;
       // conv1, output channels 64 h .. 64 h + 63 -> MID (channel tiles 2 h + ct1 of the weight block)
       const char* w1h = l3.w1 + (size_t)(2 * h) * BPT1 * 1024;
@@ -1084,7 +1098,7 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
 #pragma unroll
           for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
         walk4<W4I, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1h + (size_t)ct1 * BPT1 * 1024, a1, false);
-        if (h == 0) FULL_STAMP(11);
+        if (h == 0) FULL_STAMP(11); else FULL_STAMP(13);
         const int tl[W4I::NT] = {W4I::t[0], W4I::t[1], W4I::t[2], W4I::t[3]};
         epi_to_lds<64, W4I::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
       } else {
@@ -1094,18 +1108,27 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
 #pragma unroll
           for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
         walk4<W4E, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1h + (size_t)ct1 * BPT1 * 1024, a1, false);
-        if (h == 0) FULL_STAMP(11);
+        if (h == 0) FULL_STAMP(11); else FULL_STAMP(13);
         const int tl[W4E::NT] = {W4E::t[0], W4E::t[1], W4E::t[2], W4E::t[3], W4E::t[4]};
         epi_to_lds<64, W4E::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
       }
-      if (h == 0) FULL_STAMP(12);
+      if (h == 0) FULL_STAMP(12); else FULL_STAMP(14);
       __syncthreads();
       FULL_STAMP(5 + 2 * h);
       walk4<W4All, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_MID, L_IN, w2, acc, h == 1);
       // (after the first half: MID is rewritten by the next conv1; after the second: MID and IN are dead in every wave)
       L3_LDS_SYNC();
       FULL_STAMP(6 + 2 * h);
-    }
+    };
+#if defined(MAGAT_L3_UNROLL_H) && defined(MAGAT_DEBUG_HOOKS)
+    // timing experiment (results unchanged): a separate code body per half - the second half then runs code that is NOT in the
+    // instruction cache yet, like every other stage of the group loop (DESIGN.md 4.1 "cold code")
+    l3_half(0);
+    l3_half(1);
+#else
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) l3_half(h);
+#endif
     // the next group's inputs -> the MID region, X1 @ U3, X2 @ U2: in flight under the pooling below
     if (more) {
       dma_map(p.in1, group + gstride, U3, wave, 4, 40);

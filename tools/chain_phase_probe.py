@@ -72,7 +72,11 @@ if full:
         print("  layer3.conv1 half 0 by wave: walk " + " ".join("%.0f" % (t[:, w, 11] - t[:, w, 4]).mean() for w in range(4)) +
               " | epilogue " + " ".join("%.0f" % (t[:, w, 12] - t[:, w, 11]).mean() for w in range(4)) +
               " | barrier wait " + " ".join("%.0f" % (t[:, w, 5] - t[:, w, 12]).mean() for w in range(4)))
-    if t[:, 0, 13].any():
+    if t[:, 0, 13].any() and t[:, 0, 14].any() and not t[:, 0, 15].any():      # block_full_p_kernel: stamps 13 / 14 = half 1's walk / epilogue
+        print("  layer3.conv1 half 1 by wave: walk " + " ".join("%.0f" % (t[:, w, 13] - t[:, w, 6]).mean() for w in range(4)) +
+              " | epilogue " + " ".join("%.0f" % (t[:, w, 14] - t[:, w, 13]).mean() for w in range(4)) +
+              " | barrier wait " + " ".join("%.0f" % (t[:, w, 7] - t[:, w, 14]).mean() for w in range(4)))
+    elif t[:, 0, 13].any():
         f = lambda a, b: " ".join("%.0f" % (t[:, w, a] - t[:, w, b]).mean() for w in range(4))
         print("  pooled epilogue pass 0 by wave: S write (waves 0-1) / DMA requests (2-3) " + f(13, 8) + " | barrier " + f(14, 13) +
               " | pool + store " + f(15, 14) + " | barrier " + f(9, 15))
