@@ -177,7 +177,7 @@ __device__ __forceinline__ void chain_stage(const ChainParams& p, char* lds, int
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     if (tl[s] < 0) continue;
-    const int pix = TILE_PIX[tl[s]][psl];
+    const int pix = tile_pix(tl[s], psl);
     if (LAST && p.out_gl == 0) {         // float32 row-major agent tiles [tile][pixel][128][COUT]
       if (mok) {
         float* orow = reinterpret_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +
@@ -363,7 +363,7 @@ __device__ __forceinline__ void epi_to_lds(char* lds, int out_off, const int (&t
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     if (tl[s] < 0) continue;
-    const int pix = TILE_PIX[tl[s]][psl];
+    const int pix = tile_pix(tl[s], psl);
     float cl = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256, 1) void block3_w4_kernel(const L3Params p) {
         const int fr = lane & 31, fh = lane >> 5, agent = fr & 7, psl = fr >> 3;
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-          const int pix = TILE_PIX[W4All::t[s]][psl];
+          const int pix = tile_pix(W4All::t[s], psl);
           const int row = pix * AG + agent;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -736,7 +736,7 @@ __device__ __forceinline__ void chain_stage4(const ChainParams& p, char* lds, in
   const bool mok = m < p.M;
 #pragma unroll
   for (int s = 0; s < NT; ++s) {
-    const int pix = TILE_PIX[TL::t[s]][psl];
+    const int pix = tile_pix(TL::t[s], psl);
     if (LAST && p.out_gl == 0) {         // float32 row-major agent tiles [tile][pixel][128][COUT]
       if (mok) {
         float* orow = reinterpret_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(256, 1) void block_full_w4_kernel(const FullParams 
         const int fr = lane & 31, fh = lane >> 5, agent = fr & 7, psl = fr >> 3;
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-          const int pix = TILE_PIX[W4All::t[s]][psl];
+          const int pix = tile_pix(W4All::t[s], psl);
           const int row = pix * AG + agent;
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) {

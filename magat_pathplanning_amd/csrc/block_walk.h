@@ -29,6 +29,14 @@ constexpr int TAPBIAS = 7 * PIXB;           // tap shifts are (6 dy + dx) pixel 
 __device__ constexpr int TILE_PIX[9][4] = {{7, 10, 25, 28},  {26, 27, 8, 9},   {16, 13, 22, 19}, {14, 15, 20, 21},
                                            {1, 4, 2, 3},     {32, 33, 31, 34}, {6, 12, 24, 18},  {17, 11, 23, 29},
                                            {0, 5, 30, 35}};
+// TILE_PIX[tile][psl] for a tile known at compile time and the lane's slot: a shift of the four bytes as a literal.  (The table
+// lookup is a global load - an L2 round trip in front of every walk's first operand read and every epilogue's first store,
+// because the thread index they start from is laundered against hoisting; round 4.)
+__device__ __forceinline__ int tile_pix(int tile, int psl) {
+  const unsigned packed = (unsigned)TILE_PIX[tile][0] | (unsigned)TILE_PIX[tile][1] << 8 | (unsigned)TILE_PIX[tile][2] << 16 |
+                          (unsigned)TILE_PIX[tile][3] << 24;
+  return (int)((packed >> (8 * psl)) & 0xFFu);
+}
 // valid taps t = 3 (dy + 1) + (dx + 1) of every pixel of the tile (corners: union; per-lane validity handled by address)
 __device__ constexpr int TILE_TAPS[9] = {0x1FF, 0x1FF, 0x1FF, 0x1FF, 0x1F8, 0x03F, 0x1B6, 0x0DB, 0x1FF};
 constexpr int T_I0 = 0, T_I1 = 1, T_I2 = 2, T_I3 = 3, T_ET = 4, T_EB = 5, T_EL = 6, T_ER = 7, T_C = 8;
@@ -168,7 +176,7 @@ __device__ __forceinline__ void walk4(char* lds, int in_off, int in2_off, const 
   unsigned cab = 0;
 #pragma unroll
   for (int s = 0; s < NT; ++s) {
-    const int pix = TILE_PIX[TL::t[s]][psl];
+    const int pix = tile_pix(TL::t[s], psl);
     ab[s] = (unsigned)(GEO::base(pix) * PIXB + agent * 16 + fh * GBLK);
     b0[s] = ab[s] + (unsigned)(in_off + w4_minshift(TL::t[s], RP) * PIXB);
     if (TL::t[s] == T_C) {

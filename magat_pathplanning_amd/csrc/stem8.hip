@@ -90,7 +90,7 @@ __device__ __forceinline__ void stem8_conv1(const Stem8Params& p, char* lds, int
   const bool mok = m < p.M;
 #pragma unroll
   for (int s = 0; s < NT; ++s) {
-    const int pix = TILE_PIX[TL::t[s]][psl];
+    const int pix = tile_pix(TL::t[s], psl);
     float cl = 0.f;
     char* o = p.out + ((long long)(m >> 7) * NPIX + pix) * (128 * 32 * 4) + (m & 127) * 16 + fh * 2048;
 #pragma unroll
