@@ -22,6 +22,21 @@
 #include "magat_common.h"
 
 namespace {
+// MAGAT_CHAIN_NT: the one-launch kernel's activation traffic (input maps in, pooled map out) marked non-temporal, so that the
+// 1.8 MB of weight fragments every CU of an XCD re-reads per agent group are what its L2 keeps
+#ifndef MAGAT_CHAIN_NT
+#define MAGAT_CHAIN_NT 3      /* bit 0: the input maps, bit 1: the pooled map */
+#endif
+#if MAGAT_CHAIN_NT & 1
+#define MAGAT_CHAIN_NT_STR " nt"
+#else
+#define MAGAT_CHAIN_NT_STR ""
+#endif
+#if MAGAT_CHAIN_NT & 2
+#define CHAIN_OUT_STORE(ptr, val) __builtin_nontemporal_store((val), reinterpret_cast<f32x4*>(ptr))
+#else
+#define CHAIN_OUT_STORE(ptr, val) (*reinterpret_cast<f32x4*>(ptr) = (val))
+#endif
 #include "block_walk.h"
 struct ChainParams {
   const char* in1;        // layer1.conv1 output, f16 plane granules, 32 channels: [agent tile][pixel][128 agents x 128 B]
@@ -709,6 +724,22 @@ __device__ __forceinline__ void chain_stage4(const ChainParams& p, char* lds, in
 #if defined(MAGAT_WHATIF_TWICE) && defined(MAGAT_DEBUG_HOOKS)
   // timing experiment (results unchanged): the walk runs twice, so that stage time (twice) - stage time (once) = the time of a
   // walk whose code is already in the instruction cache (tools/chain_phase_probe.py; DESIGN.md 4.1 "cold code")
+#if MAGAT_WHATIF_TWICE == 2       // ... as two COPIES of the walk's code: the second pass finds its data warm and its code cold
+  for (int rep = 0; rep < 2; ++rep) {
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+    asm volatile("" ::: "memory");
+    if (rep == 0)
+      walk4<TL, KSM, KS2, (CIN / 8) * BLK, (C2 > 0 ? C2 / 8 : 1) * BLK, w4_depth(NT, KSM)>(
+          lds, in_off, in2_off, wts + (size_t)ct * BPT * 1024, acc, true);
+    else
+      walk4<TL, KSM, KS2, (CIN / 8) * BLK, (C2 > 0 ? C2 / 8 : 1) * BLK, w4_depth(NT, KSM)>(
+          lds, in_off, in2_off, wts + (size_t)ct * BPT * 1024, acc, true);
+    asm volatile("" ::: "memory");
+  }
+#else
 #pragma unroll 1
   for (int rep = 0; rep < 2; ++rep) {
 #pragma unroll
@@ -719,6 +750,7 @@ __device__ __forceinline__ void chain_stage4(const ChainParams& p, char* lds, in
     walk4<TL, KSM, KS2, (CIN / 8) * BLK, (C2 > 0 ? C2 / 8 : 1) * BLK, w4_depth(NT, KSM)>(
         lds, in_off, in2_off, wts + (size_t)ct * BPT * 1024, acc, true);
   }
+#endif
 #else
 #pragma unroll
   for (int s = 0; s < NT; ++s)
@@ -1033,7 +1065,7 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
       const char* src = base + tile_b + (long long)pix * (128 * 32 * 4) + (blk >> 2) * (256 * 32) + (blk & 3) * 2048 +
                         (lane & 7) * 16;
       const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(lds_off + blk * BLK + part * 8 * PIXB));
-      if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+      if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" MAGAT_CHAIN_NT_STR ::"v"(src), "s"(m0v) : "memory", "m0");
     }
   };
   const float sA = *p.sA, sB = *p.sB, sC = *p.sC, s1 = *l3.s1, s2 = *l3.s2;
@@ -1170,10 +1202,10 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
           v2[c] = p2b + __shfl_xor(p2b, 16, 64);
         }
         if (mok) {
-          *reinterpret_cast<f32x4*>(ob + (long long)cellF * (128 * 128) + qstep * qd) = vF;
-          if (!lo) *reinterpret_cast<f32x4*>(ob + (long long)cell0 * (128 * 128) + qstep * qd) = v0;
-          if (!hi) *reinterpret_cast<f32x4*>(ob + (long long)cell1 * (128 * 128) + qstep * qd) = v1;
-          if (!lo && !hi) *reinterpret_cast<f32x4*>(ob + (long long)4 * (128 * 128) + qstep * qd) = v2;
+          CHAIN_OUT_STORE(ob + (long long)cellF * (128 * 128) + qstep * qd, vF);
+          if (!lo) CHAIN_OUT_STORE(ob + (long long)cell0 * (128 * 128) + qstep * qd, v0);
+          if (!hi) CHAIN_OUT_STORE(ob + (long long)cell1 * (128 * 128) + qstep * qd, v1);
+          if (!lo && !hi) CHAIN_OUT_STORE(ob + (long long)4 * (128 * 128) + qstep * qd, v2);
         }
       }
     }

@@ -5,6 +5,21 @@
 #include "magat_common.h"
 
 namespace {
+// MAGAT_STEM8_NT: the kernel's streams (state maps in, the two plane maps out - 472 MB nobody reads before the launch ends)
+// marked non-temporal (bit 0 loads, bit 1 stores)
+#ifndef MAGAT_STEM8_NT
+#define MAGAT_STEM8_NT 0      /* measured: neutral to +2 us (profiles/r04e/ab_nt2.txt); the hooks stay for the next look */
+#endif
+#if MAGAT_STEM8_NT & 1
+#define S8_NT_STR " nt"
+#else
+#define S8_NT_STR ""
+#endif
+#if MAGAT_STEM8_NT & 2
+#define S8_OUT_STORE(ptr, val) __builtin_nontemporal_store((val), reinterpret_cast<u32x4*>(ptr))
+#else
+#define S8_OUT_STORE(ptr, val) (*reinterpret_cast<u32x4*>(ptr) = (val))
+#endif
 #include "block_walk.h"
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -105,8 +120,8 @@ __device__ __forceinline__ void stem8_conv1(const Stem8Params& p, char* lds, int
         split2(v23[0], v23[1], h1[2 * e + 1], h2[2 * e + 1], cl);
       }
       if (mok) {
-        *reinterpret_cast<u32x4*>(o + ks * 4096) = u32x4{h1[0], h1[1], h1[2], h1[3]};
-        *reinterpret_cast<u32x4*>(o + ks * 4096 + 256 * 32) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+        S8_OUT_STORE(o + ks * 4096, (u32x4{h1[0], h1[1], h1[2], h1[3]}));
+        S8_OUT_STORE(o + ks * 4096 + 256 * 32, (u32x4{h2[0], h2[1], h2[2], h2[3]}));
       }
     }
     clamped |= cl > 65504.f && mok;
@@ -171,7 +186,7 @@ __global__ __launch_bounds__(512, 1) void stem8_kernel(const Stem8Params p) {
         const int off = rb0 + c * 1024 + lane * 16;
         const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(rawq + c * 1024));
         if (off < rb1)
-          asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + off), "s"(m0v) : "memory", "m0");
+          asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" S8_NT_STR ::"v"(src + off), "s"(m0v) : "memory", "m0");
       }
     } else {
       for (int i = lane; i < 2 * 363; i += 64) {
@@ -340,8 +355,8 @@ __global__ __launch_bounds__(512, 1) void stem8_kernel(const Stem8Params p) {
         }
         if (m < p.M) {
           char* o = p.ctr + ((long long)(m >> 7) * NPIX + opix) * (128 * 32 * 4) + (m & 127) * 16 + chunk * 2048;
-          *reinterpret_cast<u32x4*>(o) = hi;
-          *reinterpret_cast<u32x4*>(o + 256 * 32) = lo;
+          S8_OUT_STORE(o, hi);
+          S8_OUT_STORE(o + 256 * 32, lo);
         }
       }
       S8_STAMP(5);
