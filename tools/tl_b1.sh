@@ -21,7 +21,7 @@ import csv
 rows=list(csv.DictReader(open('gpurun_out/tl_b1/b1_kernel_trace.csv')))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # last step: find the last layer1_fused kernel
-idx=[i for i,r in enumerate(rows) if 'layer1_fused' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if 'stem8' in r['Kernel_Name'] or 'layer1_fused' in r['Kernel_Name']]
 a=idx[-1]-3; t0=int(rows[a]['Start_Timestamp'])
 for r in rows[a:]:
     s,e=int(r['Start_Timestamp']),int(r['End_Timestamp'])
