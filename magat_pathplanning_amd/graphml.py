@@ -463,10 +463,11 @@ class _GatTrainFunction(torch.autograd.Function):
         ctx.save_for_backward(Xc, Z, att, T if T is not None else torch.empty(0, device=dev), rowptr, colidx, cscptr,
                               csc, packed, weight, weight_bias if weight_bias is not None else torch.empty(0, device=dev),
                               mixer, taps)
-        return Ypre
+        ctx.mark_non_differentiable(att)
+        return Ypre, att           # att (P, nnz): the attention of every stored edge, row-major CSR order
 
     @staticmethod
-    def backward(ctx, dYpre):
+    def backward(ctx, dYpre, _datt=None):
         lib = nat.lib()
         Xc, Z, att, T, rowptr, colidx, cscptr, csc, packed, weight, weight_bias, mixer, taps = ctx.saved_tensors
         B, N, G, F, K, P, mode, NC = ctx.dims
@@ -543,16 +544,35 @@ def _composite(layer, x, S):
     return out.transpose(1, 2), A.unsqueeze(2)
 
 
+def _is_relu(fn):
+    return fn is nn.functional.relu or fn is torch.relu or isinstance(fn, nn.ReLU)
+
+
+class _EdgeView:
+    """Edge feature e of a layer as an E = 1 layer: the parameter slices (views: gradients reach the parameters) and its own
+    packed-weights cache."""
+
+    def __init__(self, layer, e):
+        self.layer, self.e = layer, e
+        self.F, self.K, self.P, self.G, self.attentionMode = layer.F, layer.K, layer.P, layer.G, layer.attentionMode
+        self._scratch = _Scratch()
+
+    def _pack_tensors(self):
+        w, wb, mx, tp = self.layer._pack_tensors()
+        e = self.e
+        tp_e = tp[e:e + 1] if self.attentionMode == "GAT_origin" else tp[:, :, e:e + 1]       # filterWeight (E,K) | (P,F,E,K,G)
+        return w[:, e:e + 1], None if wb is None else wb[:, e:e + 1], mx[:, e:e + 1], tp_e
+
+
 class GraphFilterBatchAttentional(nn.Module):
     """Drop-in for the reference class of the same name (graphML.py:4506-4685)."""
+
+    _edge_views = None
 
     def __init__(self, G, F, K, P, E=1, bias=True, nonlinearity=nn.functional.relu, concatenate=True,
                  attentionMode="GAT_modified"):
         super().__init__()
-        if E != 1:
-            raise NotImplementedError("edge_features E=1 only (the planner models use E=1, …bottleneck.py:181)")
-        if nonlinearity is not nn.functional.relu and nonlinearity is not torch.relu:
-            raise NotImplementedError("the fused kernel applies ReLU (the only nonlinearity the models use)")
+        # E > 1 and nonlinearities other than ReLU take the general path of forward() (round 4): the models use E = 1 and ReLU
         if attentionMode not in _MODES:
             raise NotImplementedError("attentionMode %r: KeyQuery and GAT_modified are built" % (attentionMode,))
         self.G, self.F, self.K, self.P, self.E = G, F, K, P, E
@@ -598,6 +618,7 @@ class GraphFilterBatchAttentional(nn.Module):
         st = self.__dict__.copy()
         st["_scratch"] = None
         st["aij"] = None
+        st["_edge_views"] = None
         return st
 
     def __setstate__(self, st):
@@ -624,7 +645,9 @@ class GraphFilterBatchAttentional(nn.Module):
         if Nin < self.N:
             x = torch.cat((x, torch.zeros(B, Gin, self.N - Nin, dtype=x.dtype, device=x.device)), dim=2)
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if needs_grad and x.is_cuda and not self.return_attention:
+        if self.E != 1 or not _is_relu(self.nonlinearity):
+            y = self._forward_general(x)
+        elif needs_grad and x.is_cuda and not self.return_attention:
             # training on the GPU: HIP forward + backward of the graph layer (CSR kernels), ReLU / head merge in torch
             N = self.N
             S3 = self.S.reshape(B, N, N).to(x.device)
@@ -632,8 +655,8 @@ class GraphFilterBatchAttentional(nn.Module):
                 S3 = S3.float()
             rowptr, colidx, nnz = dense_gso_to_csr(S3.contiguous(), self_loops=self.attentionMode == "GAT_origin")
             w_, wb_, mx_, tp_ = self._pack_tensors()
-            Ypre = _GatTrainFunction.apply(x.permute(0, 2, 1).contiguous(), w_, wb_, mx_, tp_, self.bias, rowptr,
-                                           colidx, nnz, self)
+            Ypre, _ = _GatTrainFunction.apply(x.permute(0, 2, 1).contiguous(), w_, wb_, mx_, tp_, self.bias, rowptr,
+                                              colidx, nnz, self)
             Yh = Ypre.view(B, N, self.P, self.F)
             if self.concatenate:
                 y = torch.relu(Yh).reshape(B, N, self.P * self.F).permute(0, 2, 1)
@@ -655,6 +678,54 @@ class GraphFilterBatchAttentional(nn.Module):
             y = y[:, :, :Nin]
         return y
 
+    def _forward_general(self, x):
+        """E > 1 edge features and / or a nonlinearity other than ReLU (graphML.py:1262-1286, 1744-1775, 4654-4667) on the HIP
+        kernels of the training path, which hand out the PRE-activation per-head rows: the edge mask is the union of the E
+        GSOs (sum_e |S_e| > 1e-9 - for GAT_origin of |float(S_e) + I|), every edge feature is an E = 1 layer over that mask
+        with its own slice of the parameters (magat_gat_train_forward_f32), their rows are summed, the bias is added once and
+        the constructor's nonlinearity - any torch callable - is applied in the reference's own layout.  Differentiable: the
+        slices are views of the parameters and each E = 1 pass carries the HIP backward."""
+        if not x.is_cuda:
+            raise nat.MagatNativeError("GraphFilterBatchAttentional (E > 1 or a nonlinearity other than ReLU) runs on the HIP "
+                                       "kernels: move the module and its input to the GPU")
+        B, _, N = x.shape
+        P, F, E = self.P, self.F, self.E
+        S = self.S.to(x.device)
+        if S.dtype not in (torch.float32, torch.float64):
+            S = S.float()
+        origin = self.attentionMode == "GAT_origin"
+        if E == 1:
+            Su, loops = S.reshape(B, N, N), origin
+        elif origin:
+            Su, loops = (S.float() + torch.eye(N, dtype=torch.float32, device=S.device).view(1, 1, N, N)).abs().sum(dim=1), False
+        else:
+            Su, loops = S.abs().sum(dim=1), False
+        rowptr, colidx, nnz = dense_gso_to_csr(Su.contiguous(), self_loops=loops)
+        rows = x.permute(0, 2, 1).contiguous()
+        if self._edge_views is None or len(self._edge_views) != E:
+            self._edge_views = [_EdgeView(self, e) for e in range(E)]
+        Ypre, atts = None, []
+        for e, view in enumerate(self._edge_views):
+            w_, wb_, mx_, tp_ = view._pack_tensors()
+            Ye, att = _GatTrainFunction.apply(rows, w_, wb_, mx_, tp_, self.bias if e == 0 else None, rowptr, colidx, nnz, view)
+            Ypre = Ye if Ypre is None else Ypre + Ye
+            atts.append(att)
+        if self.return_attention:
+            rp = rowptr.view(B, N + 1)
+            deg = (rp[:, 1:] - rp[:, :-1]).reshape(-1).long()
+            r = torch.repeat_interleave(torch.arange(B * N, device=x.device), deg)
+            A = torch.zeros(P, E, B * N, N, dtype=torch.float32, device=x.device)
+            for e, att in enumerate(atts):
+                A[:, e, r, colidx[:nnz].long()] = att[:, :nnz]
+            self.aij = A.view(P, E, B, N, N).permute(2, 0, 1, 3, 4).contiguous()
+        else:
+            self.aij = None
+        y = Ypre.view(B, N, P, F).permute(0, 2, 3, 1)                  # B x P x F x N, as graphML.py:4650 hands it over
+        if self.concatenate:
+            y = self.nonlinearity(y)
+            return y.permute(0, 3, 1, 2).reshape(B, N, P * F).permute(0, 2, 1)
+        return self.nonlinearity(torch.mean(y, dim=1))
+
     def extra_repr(self):
         s = "in_features=%d, out_features=%d, filter_taps=%d, attention_heads=%d, edge_features=%d, bias=%s, " % (
             self.G, self.F, self.K, self.P, self.E, self.bias is not None)
@@ -672,8 +743,6 @@ class GraphFilterBatchAttentional_Origin(GraphFilterBatchAttentional):
     def __init__(self, G, F, K, P, E=1, bias=True, nonlinearity=nn.functional.relu, concatenate=True,
                  attentionMode="GAT_origin"):
         nn.Module.__init__(self)
-        if E != 1:
-            raise NotImplementedError("edge_features E=1 only")
         if G != F:
             raise NotImplementedError("GAT_origin needs F == G (the reference reshapes W (P,G,E,F) into (P,F,E,1,G))")
         self.G, self.F, self.K, self.P, self.E = G, F, K, P, E

@@ -121,10 +121,12 @@ def lsigf_attention(h, x, aij, b):
     return y
 
 
-def gat_layer_forward(x, S4, p, mode="KeyQuery", concat=True, n_graph=None):
+def gat_layer_forward(x, S4, p, mode="KeyQuery", concat=True, n_graph=None, nonlinearity=torch.relu):
     """GraphFilterBatchAttentional.forward (graphML.py:4636-4671).
-    x (B,G,Nin) f32; S4 (B,1,N,N); p: dict with mixer, weight_bias, filterWeight, bias,
-    weight (torch tensors).  Returns (y (B,P*F|F,Nin), aij (B,P,1,N,N))."""
+    x (B,G,Nin) f32; S4 (B,E,N,N); p: dict with mixer, weight_bias, filterWeight, bias,
+    weight (torch tensors).  Returns (y (B,P*F|F,Nin), aij (B,P,E,N,N)).  E > 1: the edge mask is the union of the E GSOs
+    (edge_mask), scores and taps are per (head, edge feature), the taps of all edge features are summed (lsigf_attention);
+    nonlinearity: the layer's constructor argument, applied to (B,P,F,N) before the concat or to the head mean (B,F,N)."""
     B, G, Nin = x.shape
     N = S4.shape[2] if n_graph is None else n_graph
     if Nin < N:
@@ -148,10 +150,10 @@ def gat_layer_forward(x, S4, p, mode="KeyQuery", concat=True, n_graph=None):
     y = lsigf_attention(taps, x, aij, p.get("bias"))
     P, F = taps.shape[0], taps.shape[1]
     if concat:
-        y = torch.relu(y)
+        y = nonlinearity(y)
         y = y.permute(0, 3, 1, 2).reshape(B, N, P * F).permute(0, 2, 1)
     else:
-        y = torch.relu(y.mean(dim=1))
+        y = nonlinearity(y.mean(dim=1))
     if Nin < N:
         y = y[:, :, :Nin]
     return y, aij

@@ -346,8 +346,59 @@ def main_grad():
                                                                     if k.startswith("g_") or k == "dx"})
 
 
+ACTIVATIONS = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid,
+               "leaky_relu": lambda t: torch.nn.functional.leaky_relu(t, 0.1), "identity": lambda t: t}
+
+
+def main_edge():
+    """Round 4: the layer's two remaining constructor arguments - E > 1 edge features (the union of the E GSOs is the edge mask,
+    every (head, edge feature) has its own score and tap weights, the taps of all edge features are summed:
+    graphML.py:1262-1286, 1744-1775) and a nonlinearity other than ReLU (graphML.py:4654-4667) - through the reference's own
+    GraphFilterBatchAttentional(_Origin).forward; directed GSOs per edge feature, concat and mean, Nin < N."""
+    from magat_pathplanning_amd.synthetic import directed_gso
+    gml, _ = import_reference()
+    cases = [("KeyQuery", 2, "relu", 12, 16, 3, 2), ("KeyQuery", 1, "tanh", 10, 32, 2, 4), ("KeyQuery", 3, "sigmoid", 20, 128, 3, 2),
+             ("GAT_modified", 2, "tanh", 14, 32, 3, 3), ("GAT_modified", 1, "leaky_relu", 9, 64, 2, 2),
+             ("GAT_origin", 2, "relu", 11, 16, 3, 2), ("GAT_origin", 1, "identity", 16, 32, 2, 4)]
+    for si, (mode, E, act, N, G, K, P) in enumerate(cases):
+        seed = 9337 + 31 * si
+        gen = torch.Generator().manual_seed(seed)
+        B, F = 2, G
+        cls = gml.GraphFilterBatchAttentional_Origin if mode == "GAT_origin" else gml.GraphFilterBatchAttentional
+        layers = {}
+        for concat in (True, False):
+            torch.manual_seed(seed)
+            layers[concat] = cls(G, F, K, P, E, True, nonlinearity=ACTIVATIONS[act], concatenate=concat, attentionMode=mode)
+        ref = layers[True]
+        with torch.no_grad():
+            if mode != "GAT_origin":
+                ref.weight_bias.uniform_(-0.3, 0.3, generator=gen)
+            layers[False].load_state_dict(ref.state_dict())
+        x = torch.randn(B, G, N, generator=gen) * 0.7
+        f64 = si % 2 == 1
+        S = torch.stack([directed_gso(B, N, 0.25, seed=seed + 1 + e, dtype=torch.float64 if f64 else torch.float32)
+                         for e in range(E)], dim=1)
+        out = {}
+        with torch.no_grad():
+            for concat, lay in layers.items():
+                lay.addGSO(S)
+                out["y_concat" if concat else "y_mean"] = lay(x).numpy()
+            out["aij"] = ref.aij.astype(np.float32)
+            nin = max(1, N - 3)
+            out["y_concat_nin"] = ref(x[:, :, :nin].contiguous()).numpy()
+            out["nin"] = np.int64(nin)
+        out.update(x=x.numpy(), S=S.numpy(), mode=np.array(mode), act=np.array(act), N=N, G=G, K=K, P=P, E=E)
+        for k, v in ref.state_dict().items():
+            out["p_" + k] = v.numpy()
+        path = os.path.join(OUT, "edge_%s_E%d_%s_N%d_G%d_K%d_P%d.npz" % (mode, E, act, N, G, K, P))
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path) // 1024, "KB", float(np.abs(out["y_concat"]).max()))
+
+
 if __name__ == "__main__":
-    if "--grad" in sys.argv:
+    if "--edge" in sys.argv:
+        main_edge()
+    elif "--grad" in sys.argv:
         main_grad()
     elif "--small" in sys.argv:
         main_small()

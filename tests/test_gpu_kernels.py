@@ -235,6 +235,77 @@ def test_gat_layer_vs_reference_golden(gpu_device, tag_counts, path, want_att):
                 assert (tc[ONE_LAUNCH] > 0) == one_launch, tc.counts
 
 
+EDGE = golden_paths("edge_")
+EDGE_ACT = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid,
+            "leaky_relu": lambda t: torch.nn.functional.leaky_relu(t, 0.1), "identity": lambda t: t}
+
+
+@pytest.mark.parametrize("want_att", [False, True], ids=["no_attention", "with_attention"])
+@pytest.mark.parametrize("path", EDGE, ids=[os.path.basename(p)[:-4] for p in EDGE])
+def test_gat_edge_features_and_nonlinearity_vs_reference_golden(gpu_device, path, want_att):
+    """E > 1 edge features and nonlinearities other than ReLU (the layer's general path: one E = 1 pass of the HIP training-path
+    kernels per edge feature over the union mask) vs the outputs of the real reference; all three attention modes, concat and
+    mean, Nin < N, float32 and float64 directed GSOs per edge feature."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin
+    z, p = load_layer_fixture(path)
+    mode, N, G, K, P, E = str(z["mode"]), int(z["N"]), int(z["G"]), int(z["K"]), int(z["P"]), int(z["E"])
+    act = EDGE_ACT[str(z["act"])]
+    x = torch.from_numpy(z["x"]).to(gpu_device)
+    S = torch.from_numpy(z["S"]).to(gpu_device)
+    cls = GraphFilterBatchAttentional_Origin if mode == "GAT_origin" else GraphFilterBatchAttentional
+    for concat, key in ((True, "y_concat"), (False, "y_mean")):
+        layer = cls(G, G, K, P, E, True, nonlinearity=act, concatenate=concat, attentionMode=mode)
+        layer.load_state_dict(p)
+        layer = layer.to(gpu_device).eval()
+        layer.return_attention = want_att
+        layer.addGSO(S)
+        with torch.no_grad():
+            y = layer(x)
+        assert tuple(y.shape) == tuple(z[key].shape)
+        np.testing.assert_allclose(y.cpu().numpy(), z[key], rtol=0, atol=1e-5)
+        if want_att:
+            np.testing.assert_allclose(layer.aij.cpu().numpy(), z["aij"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(layer.returnAttentionGSO(), z["aij"].mean(axis=1), rtol=0, atol=2e-6)
+        if concat:
+            nin = int(z["nin"])
+            with torch.no_grad():
+                yn = layer(x[:, :, :nin].contiguous())
+            np.testing.assert_allclose(yn.cpu().numpy(), z["y_concat_nin"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("path", [p for p in EDGE if "_E2_" in p or "_E3_" in p], ids=lambda p: os.path.basename(p)[:-4])
+def test_gat_edge_features_backward_matches_oracle_autograd(gpu_device, path):
+    """Gradients through the general path (parameter slices per edge feature + the HIP backward of every pass) against
+    float64 autograd through the oracle restatement (pinned to these fixtures' forwards on the CPU)."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin
+    from oracle import magat_oracle as orc
+    z, p = load_layer_fixture(path)
+    mode, G, K, P, E = str(z["mode"]), int(z["G"]), int(z["K"]), int(z["P"]), int(z["E"])
+    act = EDGE_ACT[str(z["act"])]
+    cls = GraphFilterBatchAttentional_Origin if mode == "GAT_origin" else GraphFilterBatchAttentional
+    layer = cls(G, G, K, P, E, True, nonlinearity=act, concatenate=True, attentionMode=mode)
+    layer.load_state_dict(p)
+    layer = layer.to(gpu_device).train()
+    S = torch.from_numpy(z["S"])
+    x = torch.from_numpy(z["x"])
+    g = torch.Generator().manual_seed(3)
+    wgt = torch.randn(x.shape[0], P * G, x.shape[2], generator=g)
+    xd = x.to(gpu_device).requires_grad_(True)
+    layer.addGSO(S.to(gpu_device))
+    (layer(xd) * wgt.to(gpu_device)).sum().backward()
+    p64 = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    x64 = x.double().requires_grad_(True)
+    y64, _ = orc.gat_layer_forward(x64, S.double(), p64, mode, True, nonlinearity=act)
+    (y64 * wgt.double()).sum().backward()
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), x64.grad.float().numpy(), rtol=0, atol=2e-4)
+    for k, v in layer.named_parameters():
+        want = p64[k].grad
+        want = torch.zeros_like(p64[k]) if want is None else want
+        scale = max(1.0, float(want.abs().max()))
+        got = torch.zeros_like(v) if v.grad is None else v.grad          # (KeyQuery does not touch mixer / weight_bias)
+        np.testing.assert_allclose(got.cpu().numpy(), want.float().numpy(), rtol=0, atol=2e-4 * scale, err_msg=k)
+
+
 def test_gat_isolated_rows_are_exact_zero_not_nan(gpu_device):
     from magat_pathplanning_amd import GraphFilterBatchAttentional
     layer = GraphFilterBatchAttentional(32, 32, 3, 2, attentionMode="KeyQuery").to(gpu_device).eval()

@@ -99,3 +99,25 @@ def test_gnn_model_oracle_matches_reference(path):
     got = orc.planner_gnn_forward(x, S, sd, cfg)
     np.testing.assert_allclose(got.numpy(), z["logits"], rtol=0, atol=2e-6 * max(1.0, float(np.abs(z["logits"]).max())))
     np.testing.assert_array_equal(S.numpy(), z["S_after"])
+
+
+EDGE = golden_paths("edge_")
+ACTIVATIONS = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid,
+               "leaky_relu": lambda t: torch.nn.functional.leaky_relu(t, 0.1), "identity": lambda t: t}
+
+
+@pytest.mark.parametrize("path", EDGE, ids=[os.path.basename(p)[:-4] for p in EDGE])
+def test_edge_feature_and_nonlinearity_oracle_matches_reference(path):
+    """E > 1 edge features / a nonlinearity other than ReLU (oracle/make_golden.py --edge: the reference's own forward)."""
+    assert len(EDGE) == 7
+    z, p = load_layer_fixture(path)
+    x, S = torch.from_numpy(z["x"]), torch.from_numpy(z["S"])
+    mode, act = str(z["mode"]), ACTIVATIONS[str(z["act"])]
+    assert S.shape[1] == int(z["E"])
+    for concat, key in ((True, "y_concat"), (False, "y_mean")):
+        y, aij = orc.gat_layer_forward(x, S, p, mode, concat, nonlinearity=act)
+        np.testing.assert_allclose(y.numpy(), z[key], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(aij.numpy(), z["aij"], rtol=0, atol=1e-6)
+    nin = int(z["nin"])
+    y, _ = orc.gat_layer_forward(x[:, :, :nin].contiguous(), S, p, mode, True, nonlinearity=act)
+    np.testing.assert_allclose(y.numpy(), z["y_concat_nin"], rtol=0, atol=2e-6)
