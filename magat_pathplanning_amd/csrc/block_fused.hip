@@ -401,6 +401,40 @@ __device__ __forceinline__ void epi_to_lds(char* lds, int out_off, const int (&t
   }
 }
 
+// epi_to_lds with the tiles' pixels as run-time values (pix[s] < 0: no such tile in this wave's role)
+template <int COUT, int NS>
+__device__ __forceinline__ void epi_rt(char* lds, int out_off, const int (&pix)[NS], const f32x16 (&acc)[NS], int ct,
+                                       const float* bias, float scale, bool rows_ok, bool& clamped) {
+  constexpr int PS_OUT = (COUT / 8) * BLK;
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));
+  const int fr = lane & 31, fh = lane >> 5, agent = fr & 7;
+  f32x4 bq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bias + 32 * ct + 8 * q + 4 * fh);
+  float cl = 0.f;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    if (pix[s] < 0) continue;             // (wave-uniform)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      unsigned h1[4], h2[4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int q = 2 * ks + e;
+        const f32x2 v01 = __builtin_elementwise_fma(f32x2{acc[s][4 * q], acc[s][4 * q + 1]}, f32x2{scale, scale}, f32x2{bq[q][0], bq[q][1]});
+        const f32x2 v23 = __builtin_elementwise_fma(f32x2{acc[s][4 * q + 2], acc[s][4 * q + 3]}, f32x2{scale, scale}, f32x2{bq[q][2], bq[q][3]});
+        split2(v01[0], v01[1], h1[2 * e], h2[2 * e], cl);
+        split2(v23[0], v23[1], h1[2 * e + 1], h2[2 * e + 1], cl);
+      }
+      char* o = lds + out_off + ((ct * 2 + ks) * 2 + fh) * BLK + pix[s] * PIXB + agent * 16;
+      *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+      *reinterpret_cast<u32x4*>(o + PS_OUT) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+    }
+  }
+  clamped |= cl > 65504.f && rows_ok;
+}
+
 // row-tile groups of the 64-output-channel conv1 halves (as the chain kernel's stage B): 18 / 18 / 15 / 18 tile-taps
 __device__ constexpr int L3_G1[4][3] = {{T_I0, T_I1, -1}, {T_I2, T_I3, -1}, {T_C, T_ET, -1}, {T_EB, T_EL, T_ER}};
 
@@ -1214,6 +1248,193 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
+// ---- The compact form of block_full_p_kernel (option BLOCK_FULL = 3): the same products in the same order from a loop body
+// that is meant to fit the 64 KB instruction cache two CUs share (in the 107 KB loop of block_full_p_kernel every
+// walk runs at 84-87 % of its MFMA issue rate where the same walk in a kernel that fits runs at 93-95 %).  One body per
+// structure: waves 0 / 1 of stage A share theirs (run-time pixels), stage C and the two conv1 halves are three passes of one
+// loop, every stage has ONE split-and-store epilogue for both row-group roles (run-time pixels, the fifth tile skipped by the
+// interior role).
+__global__ __launch_bounds__(256, 1) void block_full_c_kernel(const FullParams q) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const ChainParams& p = q.c;
+  const L3Params& l3 = q.l;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  for (int i = t; i < 32 * (PIXB / 4); i += 256)
+    *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
+  auto dma_map = [&](const char* base, int group, int lds_off, int first, int step, int last) {
+    const int m0 = group * AG;
+    const long long tile_b = (long long)(m0 >> 7) * NPIX * (128 * 32 * 4) + (m0 & 127) * 16;    // bytes: agent tile, agents
+    for (int item = first; item < last; item += step) {
+      const int blk = item / 5, part = item % 5;             // blk = plane * 4 + chunk
+      const int pix = part * 8 + (lane >> 3);
+      const char* src = base + tile_b + (long long)pix * (128 * 32 * 4) + (blk >> 2) * (256 * 32) + (blk & 3) * 2048 +
+                        (lane & 7) * 16;
+      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(lds_off + blk * BLK + part * 8 * PIXB));
+      if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" MAGAT_CHAIN_NT_STR ::"v"(src), "s"(m0v) : "memory", "m0");
+    }
+  };
+  const float sA = *p.sA, sB = *p.sB, sC = *p.sC, s1 = *l3.s1, s2 = *l3.s2;
+  bool clamped = false;
+  const int ct = wave & 1, rg = wave >> 1, ct2 = wave;
+  constexpr int BPT1 = 9 * 4 * 2, BPT2A = 9 * 4 * 2, BPT2B = (9 * 4 + 4) * 2;      // 1 KB blocks per channel tile (layer3)
+  f32x4 bq[4];                      // conv2's bias (loaded once: a load behind the input DMA would wait for it)
+  {
+    const int fh = lane >> 5;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const f32x4*>(l3.b2 + 32 * ct2 + 8 * qd + 4 * fh);
+  }
+  const int gstride = (int)gridDim.x;
+  constexpr int U0 = 0, U1 = MAP32, U2 = 2 * MAP32, U3 = 3 * MAP32;
+  if ((int)blockIdx.x < p.groups) {
+    dma_map(p.in1, blockIdx.x, U3, wave, 4, 40);
+    dma_map(p.in2, blockIdx.x, U2, wave, 4, 40);
+  }
+#pragma unroll 1
+  for (int group = blockIdx.x; group < p.groups; group += gstride) {
+    const bool rows_ok = group * AG + ((lane & 31) & 7) < p.M;
+    const bool more = group + gstride < p.groups;
+    FULL_STAMP(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this group's inputs (requested during the previous group's epilogue)
+    __syncthreads();
+    FULL_STAMP(1);
+    const int fr_ = lane & 31, psl_ = fr_ >> 3;
+    // A: layer1.conv2 (32 -> 32) + downsample(stem stride-2 pixels)      X1 @ U3, X2 @ U2 -> Y @ U1
+    // (waves 0 and 1 - two interior tiles each, every tap valid - run ONE body with their pixels as run-time values)
+    {
+      f32x16 a[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[s][r] = 0.f;
+      int pix[3];
+      if (wave < 2) {
+        pix[0] = wave ? tile_pix(T_I2, psl_) : tile_pix(T_I0, psl_);
+        pix[1] = wave ? tile_pix(T_I3, psl_) : tile_pix(T_I1, psl_);
+        pix[2] = -1;
+        walk4<W4P0, 2, 2, 4 * BLK, 4 * BLK, w4_depth(2, 2), GeoChain, 3, true>(lds, U3, U2, p.wA, a, true, pix);
+      } else if (wave == 2) {
+        pix[0] = tile_pix(W4P2::t[0], psl_); pix[1] = tile_pix(W4P2::t[1], psl_); pix[2] = -1;
+        walk4<W4P2, 2, 2, 4 * BLK, 4 * BLK, w4_depth(2, 2), GeoChain, 3>(lds, U3, U2, p.wA, a, true);
+      } else {
+        pix[0] = tile_pix(W4P3::t[0], psl_); pix[1] = tile_pix(W4P3::t[1], psl_); pix[2] = tile_pix(W4P3::t[2], psl_);
+        walk4<W4P3, 2, 2, 4 * BLK, 4 * BLK, w4_depth(3, 2), GeoChain, 3>(lds, U3, U2, p.wA, a, true);
+      }
+      epi_rt<32, 3>(lds, U1, pix, a, 0, p.bA, sA, rows_ok, clamped);
+    }
+    __syncthreads();
+    FULL_STAMP(2);
+    // row-group roles of the 64-channel stages: their pixels, and one accumulator array / one epilogue for both
+    int pix5[5];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) pix5[s] = rg ? tile_pix(W4E::t[s], psl_) : tile_pix(W4I::t[s], psl_);
+    pix5[4] = rg ? tile_pix(W4E::t[4], psl_) : -1;
+    // B: layer2.conv1 (32 -> 64)                                          Y @ U1 -> Z @ (U2, U3)
+    {
+      f32x16 a[5];
+#pragma unroll
+      for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[s][r] = 0.f;
+      if (rg == 0) walk4<W4I, 2, 0, 4 * BLK, BLK, w4_depth(W4I::NT, 2), GeoChain, 5>(lds, U1, 0, p.wB + (size_t)ct * (36 * 1024), a, true);
+      else walk4<W4E, 2, 0, 4 * BLK, BLK, w4_depth(W4E::NT, 2), GeoChain, 5>(lds, U1, 0, p.wB + (size_t)ct * (36 * 1024), a, true);
+      epi_rt<64, 5>(lds, U2, pix5, a, ct, p.bB, sB, rows_ok, clamped);
+    }
+    __syncthreads();
+    FULL_STAMP(3);
+    // Stage C and the two halves of layer3.conv1 are the same walk (64 -> 64 channels, 3 x 3, the same two tile lists; C has a
+    // residual segment of two k steps on top) and the same split-and-store epilogue: three passes through ONE body per role.
+    // Pass 0 = stage C (Z @ U2, Y @ U1 -> IN @ U0), passes 1 / 2 = conv1 halves (IN -> MID @ U2), each followed by its half
+    // of conv2.
+    constexpr int L_IN = U0, L_MID = U2;
+    const int ct1 = ct;
+    f32x16 acc[9];
+#pragma unroll 1
+    for (int it = 0; it < 3; ++it) {
+      const int in_off = it == 0 ? U2 : L_IN, out_off = it == 0 ? U0 : L_MID;
+      const char* wts = it == 0 ? p.wC + (size_t)ct * (76 * 1024) : l3.w1 + (size_t)(2 * (it - 1) + ct1) * BPT1 * 1024;
+      const float* bias = it == 0 ? p.bC : l3.b1 + 64 * (it - 1);
+      const float scale = it == 0 ? sC : s1;
+      f32x16 a[5];
+#pragma unroll
+      for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[s][r] = 0.f;
+      if (rg == 0) walk4<W4I, 4, 2, 8 * BLK, 4 * BLK, MAGAT_W4_D, GeoChain, 5>(lds, in_off, U1, wts, a, it == 0);
+      else walk4<W4E, 4, 2, 8 * BLK, 4 * BLK, MAGAT_W4_D, GeoChain, 5>(lds, in_off, U1, wts, a, it == 0);
+      if (it == 1) FULL_STAMP(11); else if (it == 2) FULL_STAMP(13);
+      if (it == 0) __syncthreads();       // (stage C's output overwrites Y @ U1, which other waves read until their walks end)
+      epi_rt<64, 5>(lds, out_off, pix5, a, ct, bias, scale, rows_ok, clamped);
+      if (it == 1) FULL_STAMP(12); else if (it == 2) FULL_STAMP(14);
+      __syncthreads();
+      if (it == 0) {
+        FULL_STAMP(4);
+#pragma unroll
+        for (int s = 0; s < 9; ++s)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+      } else {
+        const int h = it - 1;
+        const char* w2 = h == 0 ? l3.w2a + (size_t)ct2 * BPT2A * 1024 : l3.w2b + (size_t)ct2 * BPT2B * 1024;
+        FULL_STAMP(5 + 2 * h);
+        walk4<W4All, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_MID, L_IN, w2, acc, h == 1);
+        L3_LDS_SYNC();
+        FULL_STAMP(6 + 2 * h);
+      }
+    }
+    // the next group's inputs -> the MID region, X1 @ U3, X2 @ U2: in flight under the pooling below
+    if (more) {
+      dma_map(p.in1, group + gstride, U3, wave, 4, 40);
+      dma_map(p.in2, group + gstride, U2, wave, 4, 40);
+    }
+    FULL_STAMP(9);
+    // ---- relu(acc * s2 + bias), 2 x 2 sums in registers, stores.  Accumulator s = tile W4All::t[s]:
+    //      0..3 interior tiles Ia Ib Ic Id, 4 C, 5 T (top), 6 B (bottom), 7 L (left), 8 R (right)
+    {
+      const int fr = lane & 31, fh = lane >> 5, agent = fr & 7;
+      const bool lo = (lane >> 3) & 1, hi = (lane >> 4) & 1;       // slot psl = 2 hi + lo
+      const int m = group * AG + agent;
+      // cells of this lane: its corner cell, the row-edge-middle cell it shares with the lane 8 away, the column-edge-middle
+      // cell it shares with the lane 16 away, the centre cell (shared by all four slots)
+      const int cellF = 2 * (int)lo + 6 * (int)hi, cell0 = hi ? 1 : 7, cell1 = lo ? 3 : 5;
+      // row-major tiles [cell][128 agents][128 channels], or granule-major ones [cell][32 granules][128 agents][4 channels]
+      // (magat_hip.h in_gl = 1: what the encoder head's loader reads as 512 contiguous bytes per half wave; here the eight
+      // agents of a group make one 128-byte run per store instead of eight 16-byte pieces 512 bytes apart)
+      float* ob = l3.out + (long long)(m >> 7) * 9 * (128 * 128) +
+                  (l3.out_gl ? (8 * ct2 + fh) * 512 + (m & 127) * 4 : (m & 127) * 128 + 32 * ct2 + 4 * fh);
+      const int qstep = l3.out_gl ? 1024 : 8;       // channel quads 2 qd (+ fh) of this wave's 32 channels
+      const bool mok = m < p.M;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 vF, v0, v1, v2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int r = 4 * qd + c;
+          float v[9];
+#pragma unroll
+          for (int s = 0; s < 9; ++s) v[s] = magat_relu(__builtin_fmaf(acc[s][r], s2, bq[qd][c]));      // (keeps NaN, like torch.relu)
+          const float u = hi ? v[6] : v[5], ux = hi ? v[5] : v[6];
+          const float w_ = lo ? v[8] : v[7], wx = lo ? v[7] : v[8];
+          vF[c] = (v[4] + v[0]) + (u + w_);
+          const float p0 = ux + v[1], p1 = wx + v[2], p2 = v[3];
+          v0[c] = p0 + dpp_mov<0x128>(p0);                       // + the lane 8 away (row_ror:8)
+          v1[c] = p1 + __shfl_xor(p1, 16, 64);                   // + the lane 16 away
+          const float p2b = p2 + dpp_mov<0x128>(p2);
+          v2[c] = p2b + __shfl_xor(p2b, 16, 64);
+        }
+        if (mok) {
+          CHAIN_OUT_STORE(ob + (long long)cellF * (128 * 128) + qstep * qd, vF);
+          if (!lo) CHAIN_OUT_STORE(ob + (long long)cell0 * (128 * 128) + qstep * qd, v0);
+          if (!hi) CHAIN_OUT_STORE(ob + (long long)cell1 * (128 * 128) + qstep * qd, v1);
+          if (!lo && !hi) CHAIN_OUT_STORE(ob + (long long)4 * (128 * 128) + qstep * qd, v2);
+        }
+      }
+    }
+    FULL_STAMP(10);
+  }
+  if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
+}
+
 }  // namespace
 
 // 1 when magat_block_full can write its pooled map granule-major (out_gl = 1) with the current options
@@ -1361,11 +1582,14 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
   l.dbg = g_block3_dbg;
 #endif
   const bool pooled_regs = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 2;      // 2: pooling in registers (block_full_p_kernel)
+  const bool compact = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 3;          // 3: + the compact loop body (block_full_c_kernel)
   if (out_gl != 0 && !(out_gl == 1 && pooled_regs)) return MAGAT_ERR_UNSUPPORTED;      // (magat_block_full_out_gl() tells)
   l.out_gl = out_gl;
-  if (magat_ensure_dyn_lds(pooled_regs ? reinterpret_cast<const void*>(&block_full_p_kernel)
-                                       : reinterpret_cast<const void*>(&block_full_w4_kernel),
-                           pooled_regs ? MAGAT_LDS_BLOCK_FULL_P : MAGAT_LDS_BLOCK_FULL, LDS_TOTAL) != MAGAT_OK)
+  if (magat_ensure_dyn_lds(compact ? reinterpret_cast<const void*>(&block_full_c_kernel)
+                           : pooled_regs ? reinterpret_cast<const void*>(&block_full_p_kernel)
+                                         : reinterpret_cast<const void*>(&block_full_w4_kernel),
+                           compact ? MAGAT_LDS_BLOCK_FULL_C : pooled_regs ? MAGAT_LDS_BLOCK_FULL_P : MAGAT_LDS_BLOCK_FULL,
+                           LDS_TOTAL) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -1374,7 +1598,8 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
   }
   const int grid = p.groups < cus ? p.groups : cus;
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_FULL, st);
-  if (pooled_regs) hipLaunchKernelGGL(block_full_p_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
+  if (compact) hipLaunchKernelGGL(block_full_c_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
+  else if (pooled_regs) hipLaunchKernelGGL(block_full_p_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
   else hipLaunchKernelGGL(block_full_w4_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
   magat_prof_end(pid, st);
   return magat_check_launch();

@@ -159,8 +159,13 @@ __device__ __forceinline__ void w4_fill(const char* wbase, unsigned lane16, u32x
 }
 // (Filling the ring one stage ahead - before the previous stage's epilogue and an LDS-only barrier - was measured and is
 //  slower: chain 608-624 -> 659 us, layer3 1.50-1.52 -> 1.53 ms same-box; the rings of two stages then overlap in registers.)
-template <typename TL, int KSM, int KS2, int PS_IN, int PS_IN2, int D, typename GEO = GeoChain>
-__device__ __forceinline__ void walk4(char* lds, int in_off, int in2_off, const char* wbase, f32x16 (&acc)[TL::NT], bool with_res) {
+// NA: length of the caller's accumulator array (>= TL::NT: roles with unlike tile counts share one array and one epilogue);
+// rpix (RTPIX): the tiles' pixels of this lane as run-time values - two roles whose tile lists have the same STRUCTURE (tap
+// masks, corner flag) then share one body (the compact form of the one-launch kernel, block_fused.hip).
+template <typename TL, int KSM, int KS2, int PS_IN, int PS_IN2, int D, typename GEO = GeoChain, int NA = TL::NT, bool RTPIX = false>
+__device__ __forceinline__ void walk4(char* lds, int in_off, int in2_off, const char* wbase, f32x16 (&acc)[NA], bool with_res,
+                                      const int* rpix = nullptr) {
+  static_assert(NA >= TL::NT, "accumulator array shorter than the tile list");
   constexpr int RP = GEO::RP, GBLK = GEO::BLKB;
   u32x4 w[D][2];
   constexpr int NT = TL::NT;
@@ -176,7 +181,7 @@ __device__ __forceinline__ void walk4(char* lds, int in_off, int in2_off, const 
   unsigned cab = 0;
 #pragma unroll
   for (int s = 0; s < NT; ++s) {
-    const int pix = tile_pix(TL::t[s], psl);
+    const int pix = RTPIX ? rpix[s] : tile_pix(TL::t[s], psl);
     ab[s] = (unsigned)(GEO::base(pix) * PIXB + agent * 16 + fh * GBLK);
     b0[s] = ab[s] + (unsigned)(in_off + w4_minshift(TL::t[s], RP) * PIXB);
     if (TL::t[s] == T_C) {

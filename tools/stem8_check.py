@@ -70,12 +70,13 @@ def main():
                     print("  ", name, "bad entries", len(bad), "agents", sorted(set(bad[:, 0].tolist()))[:12], "pixels",
                           sorted(set(bad[:, 1].tolist()))[:40], "channels", sorted(set(bad[:, 2].tolist()))[:34])
     if "--time" in sys.argv:
-        M = 51200
-        xd = fov_states(512, 100, seed=1).view(M, 3, 11, 11).to(dev).contiguous()
+      ms = [int(a) for a in sys.argv[sys.argv.index("--time") + 1:] if a.isdigit()] or [51200]
+      for M in ms:                                   # (--time 51200 65536 ...: the stage's time by agent count, multiples of 128)
+        xd = fov_states(M // 100 + 1, 100, seed=1).view(-1, 3, 11, 11)[:M].to(dev).contiguous()
         T = M // 128
         out = torch.zeros(T * 36 * 16384, dtype=torch.uint8, device=dev)
         ctr = torch.zeros_like(out)
-        for form in (1, 2, 1, 2):
+        for form in ((1, 2, 1, 2) if len(ms) == 1 else (2, 2)):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             for it in range(3):
                 lib.magat_encoder_stem_block_f32(ctypes.byref(rt.desc), nat.ptr(xd), nat.ptr(out), nat.ptr(ctr), M, form, None,
