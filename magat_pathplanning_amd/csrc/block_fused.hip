@@ -1254,6 +1254,7 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
 // structure: waves 0 / 1 of stage A share theirs (run-time pixels), stage C and the two conv1 halves are three passes of one
 // loop, every stage has ONE split-and-store epilogue for both row-group roles (run-time pixels, the fifth tile skipped by the
 // interior role).
+template <bool ROWS>        // ROWS: the interior-tile role of the 64 -> 64 walks as a rolled loop over the tap rows (walk_rows4)
 __global__ __launch_bounds__(256, 1) void block_full_c_kernel(const FullParams q) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const ChainParams& p = q.c;
@@ -1360,8 +1361,16 @@ __global__ __launch_bounds__(256, 1) void block_full_c_kernel(const FullParams q
       for (int s = 0; s < 5; ++s)
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[s][r] = 0.f;
-      if (rg == 0) walk4<W4I, 4, 2, 8 * BLK, 4 * BLK, MAGAT_W4_D, GeoChain, 5>(lds, in_off, U1, wts, a, it == 0);
-      else walk4<W4E, 4, 2, 8 * BLK, 4 * BLK, MAGAT_W4_D, GeoChain, 5>(lds, in_off, U1, wts, a, it == 0);
+      if (rg == 0) {
+        if constexpr (ROWS) {
+          const int pixI[4] = {pix5[0], pix5[1], pix5[2], pix5[3]};
+          walk_rows4<4, 2, 8 * BLK, 4 * BLK, 5>(lds, in_off, U1, wts, a, it == 0, pixI);
+        } else {
+          walk4<W4I, 4, 2, 8 * BLK, 4 * BLK, MAGAT_W4_D, GeoChain, 5>(lds, in_off, U1, wts, a, it == 0);
+        }
+      } else {
+        walk4<W4E, 4, 2, 8 * BLK, 4 * BLK, MAGAT_W4_D, GeoChain, 5>(lds, in_off, U1, wts, a, it == 0);
+      }
       if (it == 1) FULL_STAMP(11); else if (it == 2) FULL_STAMP(13);
       if (it == 0) __syncthreads();       // (stage C's output overwrites Y @ U1, which other waves read until their walks end)
       epi_rt<64, 5>(lds, out_off, pix5, a, ct, bias, scale, rows_ok, clamped);
@@ -1583,12 +1592,15 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
 #endif
   const bool pooled_regs = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 2;      // 2: pooling in registers (block_full_p_kernel)
   const bool compact = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 3;          // 3: + the compact loop body (block_full_c_kernel)
+  const bool rows = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 4;             // 4: + its interior walks rolled over the tap rows
   if (out_gl != 0 && !(out_gl == 1 && pooled_regs)) return MAGAT_ERR_UNSUPPORTED;      // (magat_block_full_out_gl() tells)
   l.out_gl = out_gl;
-  if (magat_ensure_dyn_lds(compact ? reinterpret_cast<const void*>(&block_full_c_kernel)
+  if (magat_ensure_dyn_lds(rows ? reinterpret_cast<const void*>(&block_full_c_kernel<true>)
+                           : compact ? reinterpret_cast<const void*>(&block_full_c_kernel<false>)
                            : pooled_regs ? reinterpret_cast<const void*>(&block_full_p_kernel)
                                          : reinterpret_cast<const void*>(&block_full_w4_kernel),
-                           compact ? MAGAT_LDS_BLOCK_FULL_C : pooled_regs ? MAGAT_LDS_BLOCK_FULL_P : MAGAT_LDS_BLOCK_FULL,
+                           rows ? MAGAT_LDS_BLOCK_FULL_C4 : compact ? MAGAT_LDS_BLOCK_FULL_C : pooled_regs ? MAGAT_LDS_BLOCK_FULL_P
+                                                                                    : MAGAT_LDS_BLOCK_FULL,
                            LDS_TOTAL) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
   int dev = 0, cus = 256;
@@ -1598,7 +1610,8 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
   }
   const int grid = p.groups < cus ? p.groups : cus;
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_FULL, st);
-  if (compact) hipLaunchKernelGGL(block_full_c_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
+  if (rows) hipLaunchKernelGGL(block_full_c_kernel<true>, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
+  else if (compact) hipLaunchKernelGGL(block_full_c_kernel<false>, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
   else if (pooled_regs) hipLaunchKernelGGL(block_full_p_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
   else hipLaunchKernelGGL(block_full_w4_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
   magat_prof_end(pid, st);
