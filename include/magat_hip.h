@@ -423,6 +423,22 @@ typedef struct magat_conv_gemm_desc {
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training of the per-agent CNN (ABI 5; agents/decentralplannerlocal_OnlineExpert_GAT.py:556-567 trains the whole module, the
+ * convolutions of resnet_pytorch.py:40-73, 427-524 are 96 % of a step's FLOPs).  The training-mode forward of a convolution and
+ * its INPUT gradient are magat_conv_gemm_f32 calls (bias = NULL, relu = 0: the input gradient of a stride-1 convolution is the
+ * convolution of dY with mirrored taps and swapped channel roles, wt' [Cin][(kH*kW) * Cout]; of a strided one the same over the
+ * zero-stuffed dY).  The WEIGHT gradient is this entry:
+ *     dW[co][ty*kW+tx][ci] = sum over output pixels (oy,ox) and agents m of dY[oy*Wout+ox][m][co] * X[iy*Win+ix][m][ci],
+ *     iy = oy*stride - pad + ty (taps that fall into the padding are skipped).
+ * x / dy pixel-major float32 as for magat_conv_gemm_f32 (row strides lda / ldc, pixel strides in floats); Cout % 32 == 0.
+ * part: magat_conv_wgrad_workspace_floats() floats = [chunks][Cout][kH*kW][Cin] partial sums over agent chunks; *chunks_out
+ * (host int) = how many the caller has to add up (fixed order: deterministic gradients, no atomics). */
+size_t magat_conv_wgrad_workspace_floats(int M, int Cin, int Cout, int kH, int kW);
+int magat_conv_wgrad_f32(const float* x, long long x_pix_stride, int lda, const float* dy, long long dy_pix_stride, int ldc,
+                         float* part, int* chunks_out, int M, int Cin, int Cout, int Hin, int Win, int Hout, int Wout, int kH,
+                         int kW, int stride, int pad, void* stream);
+
 /* y[M,N] = act(x[M,K] @ w[N,K]^T + b)   (torch.nn.Linear; …bottleneck.py:105,160,229) */
 int magat_linear_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M,
                      int N, int K, int relu, void* stream);
@@ -536,7 +552,8 @@ int magat_encoder_forward_f32(const magat_encoder_desc* desc_host, const float* 
 #define MAGAT_TAG_GAT_CAST 21     /* float32 <-> bf16 row casts around the bf16-storage graph layer */
 #define MAGAT_TAG_BLOCK3 22       /* layer3 + ReLU + 2x2 pool in one launch (block_fused.hip) */
 #define MAGAT_TAG_BLOCK_FULL 23   /* layer1.conv2 -> layer2 -> layer3 -> pool in one launch (block_fused.hip) */
-#define MAGAT_PROF_TAGS 24
+#define MAGAT_TAG_CONV_WGRAD 24   /* weight gradient of a convolution (conv_train.hip; training) */
+#define MAGAT_PROF_TAGS 25
 int magat_gat_set_debug_buffer(long long* dev_buf); /* [grid][8] int64 phase timestamps of gat_dense_kernel; NULL = off */
 int magat_profile_reserve(int spans);   /* pre-create event pairs (keeps hipEventCreate out of a timed region) */
 int magat_profile_enable(int on);

@@ -1,0 +1,151 @@
+// Training of the per-agent CNN on the HIP path: the weight gradient of a convolution over pixel-major activations.
+//
+// The reference trains the whole module through autograd (agents/decentralplannerlocal_OnlineExpert_GAT.py:556-567); the
+// convolutions of resnet_pytorch.py:40-73, 427-524 are 96 % of a training step's FLOPs.  Forward (training mode) and the
+// input gradient are the float32 implicit-GEMM kernel of conv_gemm_f32.hip (magat_conv_gemm_f32: the input gradient of a
+// stride-1 convolution IS a convolution of dY with the taps mirrored and the channel roles swapped; a strided one is the same
+// over the zero-stuffed dY) - this file adds the one product that kernel cannot express, the WEIGHT gradient
+//     dW[co][tap][ci] = sum over output pixels o and agents m of  dY[o][m][co] * X[in(o, tap)][m][ci],
+// a GEMM whose contraction runs over (pixel, agent) pairs - tens of thousands of rows - and whose result is at most
+// 128 x 1152.  One wave per (output-channel tile, input-channel tile, tap, agent chunk): v_mfma_f32_32x32x2_f32 with the
+// two contraction rows of an instruction = two agents of one pixel (lanes 0-31 / 32-63 read 128 contiguous bytes of one
+// agent's channels each: no transposes, no LDS), 2 x 2 register tiles of 32 x 32 where the channel counts allow it.  The agent
+// chunks write partial sums; the caller adds them up in a fixed order (deterministic gradients, no atomics).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/magat_hip.h"
+#include "magat_common.h"
+
+namespace {
+
+struct WgradParams {
+  const float* x;
+  const float* dy;
+  float* part;
+  long long x_pix_stride, dy_pix_stride;
+  int M, Cin, lda, Cout, ldc;
+  int Hin, Win, Hout, Wout, kH, kW, stride, pad;
+  int chunks, mc;              // agents per chunk (even)
+  int tiles_ci;                // input-channel tiles of 32 * NCI
+};
+
+template <int NCO, int NCI>
+__global__ __launch_bounds__(64) void wgrad_kernel(const WgradParams p) {
+  const int lane = threadIdx.x;
+  const int col = lane & 31, half = lane >> 5;
+  int b = blockIdx.x;
+  const int tci = b % p.tiles_ci; b /= p.tiles_ci;
+  const int taps = p.kH * p.kW;
+  const int tap = b % taps; b /= taps;
+  const int chunk = b % p.chunks;
+  const int tco = b / p.chunks;
+  const int co0 = tco * 32 * NCO, ci0 = tci * 32 * NCI;
+  const int ty = tap / p.kW, tx = tap - ty * p.kW;
+  const int m0 = chunk * p.mc;
+  const int m1 = m0 + p.mc < p.M ? m0 + p.mc : p.M;
+  f32x16 acc[NCO][NCI];
+#pragma unroll
+  for (int i = 0; i < NCO; ++i)
+#pragma unroll
+    for (int j = 0; j < NCI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  bool cok[NCI];
+#pragma unroll
+  for (int j = 0; j < NCI; ++j) cok[j] = ci0 + 32 * j + col < p.Cin;        // (the stem's 3 -> 4 channels: a partial tile)
+  for (int oy = 0; oy < p.Hout; ++oy) {
+    const int iy = oy * p.stride - p.pad + ty;
+    if (iy < 0 || iy >= p.Hin) continue;
+    for (int ox = 0; ox < p.Wout; ++ox) {
+      const int ix = ox * p.stride - p.pad + tx;
+      if (ix < 0 || ix >= p.Win) continue;
+      const float* dyp = p.dy + (long long)(oy * p.Wout + ox) * p.dy_pix_stride + co0 + col;
+      const float* xp = p.x + (long long)(iy * p.Win + ix) * p.x_pix_stride + ci0 + col;
+      // four row pairs per step: their 4 * (NCO + NCI) loads are in flight together (a contraction row pair = two agents)
+      constexpr int U = 4;
+      for (int mm = m0; mm < m1; mm += 2 * U) {
+        float a[U][NCO], bb[U][NCI];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int m = mm + 2 * u + half;
+          const bool ok = m < m1;
+#pragma unroll
+          for (int i = 0; i < NCO; ++i) a[u][i] = ok ? dyp[(long long)m * p.ldc + 32 * i] : 0.f;
+#pragma unroll
+          for (int j = 0; j < NCI; ++j) bb[u][j] = ok && cok[j] ? xp[(long long)m * p.lda + 32 * j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int i = 0; i < NCO; ++i)
+#pragma unroll
+            for (int j = 0; j < NCI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], bb[u][j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // part[chunk][co][tap][ci]
+  float* out = p.part + (long long)chunk * p.Cout * taps * p.Cin;
+#pragma unroll
+  for (int i = 0; i < NCO; ++i)
+#pragma unroll
+    for (int j = 0; j < NCI; ++j) {
+      if (!cok[j]) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
+        out[((long long)co * taps + tap) * p.Cin + ci0 + 32 * j + col] = acc[i][j][r];
+      }
+    }
+}
+
+}  // namespace
+
+size_t magat_conv_wgrad_workspace_floats(int M, int Cin, int Cout, int kH, int kW) {
+  if (M <= 0 || Cin <= 0 || Cout <= 0 || kH <= 0 || kW <= 0) return 0;
+  const int nco = Cout % 64 == 0 ? 2 : 1, nci = Cin % 64 == 0 ? 2 : 1;
+  const long long waves = (long long)(Cout / (32 * nco)) * ((Cin + 32 * nci - 1) / (32 * nci)) * kH * kW;
+  long long chunks = (4096 + waves - 1) / waves;            // ~four waves per SIMD of the chip
+  const long long maxc = (M + 63) / 64;                     // at least 64 agents per chunk
+  if (chunks > maxc) chunks = maxc;
+  if (chunks < 1) chunks = 1;
+  return (size_t)chunks * Cout * kH * kW * Cin;
+}
+
+// x: [Hin*Win][M][lda >= Cin] float32 pixel-major (pixel stride x_pix_stride floats); dy: [Hout*Wout][M][ldc >= Cout];
+// part: magat_conv_wgrad_workspace_floats(...) floats = [chunks][Cout][kH*kW][Cin] partial sums (the caller sums over the
+// first axis; *chunks_out tells how many).  Cout a multiple of 32.
+int magat_conv_wgrad_f32(const float* x, long long x_pix_stride, int lda, const float* dy, long long dy_pix_stride, int ldc,
+                         float* part, int* chunks_out, int M, int Cin, int Cout, int Hin, int Win, int Hout, int Wout, int kH,
+                         int kW, int stride, int pad, void* stream) {
+  if (!x || !dy || !part || !chunks_out) return MAGAT_ERR_NULL;
+  if (M <= 0 || Cin <= 0 || Cout <= 0 || Cout % 32 || lda < Cin || ldc < Cout || kH <= 0 || kW <= 0 || stride <= 0 || pad < 0 ||
+      Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0)
+    return MAGAT_ERR_BAD_SHAPE;
+  const int nco = Cout % 64 == 0 ? 2 : 1, nci = Cin % 64 == 0 ? 2 : 1;
+  WgradParams p;
+  p.x = x; p.dy = dy; p.part = part;
+  p.x_pix_stride = x_pix_stride; p.dy_pix_stride = dy_pix_stride;
+  p.M = M; p.Cin = Cin; p.lda = lda; p.Cout = Cout; p.ldc = ldc;
+  p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.kH = kH; p.kW = kW; p.stride = stride; p.pad = pad;
+  p.tiles_ci = (Cin + 32 * nci - 1) / (32 * nci);
+  const int tiles_co = Cout / (32 * nco);
+  const size_t total = magat_conv_wgrad_workspace_floats(M, Cin, Cout, kH, kW);
+  p.chunks = (int)(total / ((size_t)Cout * kH * kW * Cin));
+  p.mc = ((M + p.chunks - 1) / p.chunks + 1) & ~1;
+  if ((long long)p.mc * (p.chunks - 1) >= M) {              // (rounding the chunk length up to even emptied the last chunks)
+    p.chunks = (M + p.mc - 1) / p.mc;
+  }
+  *chunks_out = p.chunks;
+  const unsigned grid = (unsigned)((long long)tiles_co * p.chunks * kH * kW * p.tiles_ci);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int pid = magat_prof_begin(MAGAT_TAG_CONV_WGRAD, st);
+  if (nco == 2 && nci == 2) hipLaunchKernelGGL((wgrad_kernel<2, 2>), dim3(grid), dim3(64), 0, st, p);
+  else if (nco == 2) hipLaunchKernelGGL((wgrad_kernel<2, 1>), dim3(grid), dim3(64), 0, st, p);
+  else if (nci == 2) hipLaunchKernelGGL((wgrad_kernel<1, 2>), dim3(grid), dim3(64), 0, st, p);
+  else hipLaunchKernelGGL((wgrad_kernel<1, 1>), dim3(grid), dim3(64), 0, st, p);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
+}

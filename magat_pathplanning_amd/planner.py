@@ -12,7 +12,8 @@ Inference (eval / no_grad) runs entirely on the gfx950 kernels behind include/ma
                                kernels for N > 128 or bf16 storage)
   actionsMLP (+skip inputs) -> magat_conv_gemm_f32          (skip source as second K segment)
 Training (autograd on): the graph layer's forward AND backward run on HIP kernels (graphml._GatTrainFunction,
-_GnnTrainFunction); the CNN / MLP parameter containers train through torch autograd.
+_GnnTrainFunction), and so do the convolutions of the ResNet trunks (train_cnn.py: forward, input and weight gradients on the
+float32 matrix-core kernels); BatchNorm / ReLU / pooling and the MLPs train through torch ops on the GPU.
 """
 import ctypes
 import hashlib
@@ -50,6 +51,8 @@ def weights_init(m):
 
 CAL_AGENTS = 2048      # agents of the canonical calibration batch (synthetic.calibration_states)
 
+
+from .train_cnn import convlayers_forward  # noqa: E402
 
 class _Runtime:
     """Device-side caches of one module instance (never pickled)."""
@@ -314,7 +317,7 @@ class DecentralPlannerGATNet(nn.Module):
 
     # ------------------------------------------------------------------ training path (torch ops)
     def _forward_autograd(self, x, B, N):
-        feat = self.ConvLayers(x)
+        feat = convlayers_forward(self.ConvLayers, x)       # (ResNet trunks: HIP convolution kernels, train_cnn.py)
         feat = feat.view(feat.size(0), -1)
         comp = self.compressMLP(feat)
         xg = comp.reshape(B, N, self.numFeatures2Share).permute(0, 2, 1)
@@ -752,7 +755,7 @@ class DecentralPlannerNet(DecentralPlannerGATNet):
         return self._forward_hip(x, B, N)
 
     def _forward_autograd(self, x, B, N):
-        feat = self.ConvLayers(x)
+        feat = convlayers_forward(self.ConvLayers, x)       # (ResNet trunks: HIP convolution kernels, train_cnn.py)
         feat = feat.view(feat.size(0), -1)
         comp = self.compressMLP(feat)
         xg = comp.reshape(B, N, self.numFeatures2Share).permute(0, 2, 1)

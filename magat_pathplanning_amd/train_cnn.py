@@ -1,0 +1,173 @@
+"""Training of the per-agent ResNet encoders on the HIP kernels (round 4).
+
+The reference trains the whole module through autograd (agents/decentralplannerlocal_OnlineExpert_GAT.py:556-567); the
+convolutions of graphs/models/resnet_pytorch.py:40-73, 427-524 are 96 % of a training step's FLOPs.  Here every convolution of
+the trunk - training-mode forward, input gradient and weight gradient - runs on this library's float32 matrix-core kernels over
+PIXEL-MAJOR activations [pixel][agent][channel] (the layout magat_conv_gemm_f32 is built around):
+
+  forward          magat_conv_gemm_f32 (bias = NULL, relu = 0)
+  input gradient   magat_conv_gemm_f32 again: dX = conv(dY, mirrored taps, channel roles swapped); a strided convolution
+                   takes the zero-stuffed dY (the stride-2 3x3 of layer1 and its 1x1 downsample)
+  weight gradient  magat_conv_wgrad_f32 (csrc/conv_train.hip: the contraction over (pixel, agent) rows on
+                   v_mfma_f32_32x32x2_f32, partial sums per agent chunk added in a fixed order - deterministic)
+
+BatchNorm (batch statistics, running-stat updates exactly as torch.nn.BatchNorm2d does them), ReLU, the residual adds and the
+2 x 2 average pool are elementwise / reduction work: torch ops on the GPU over the same pixel-major tensors.  CNN_mode
+'Default' (conv + BN + ReLU + MaxPool stacks) keeps the torch convolutions.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as tnf
+
+from . import _native as nat
+
+
+def _conv_gemm(x, wt, hin, win, kh, kw, stride, pad, hout, wout):
+    """x [hin*win][M][Cin] float32 contiguous, wt [Cout][kh*kw*Cin] -> [hout*wout][M][Cout] (no bias, no activation)."""
+    lib = nat.lib()
+    _, M, cin = x.shape
+    cout = wt.shape[0]
+    dev = x.device
+    out = torch.empty(hout * wout, M, cout, dtype=torch.float32, device=dev)
+    d = nat.ConvGemmDesc()
+    d.inp, d.wt, d.bias, d.out = x.data_ptr(), wt.data_ptr(), None, out.data_ptr()
+    d.in_pix_stride, d.out_pix_stride = M * cin, M * cout
+    d.M, d.Cin, d.lda = M, cin, cin
+    d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad, d.Hout, d.Wout = hin, win, kh, kw, stride, pad, hout, wout
+    d.Cout, d.ldc, d.relu = cout, cout, 0
+    with torch.cuda.device(dev):
+        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(dev)), "magat_conv_gemm_f32 (training)")
+    return out
+
+
+def _pad4(t):
+    """channel count (last axis) up to a multiple of 4 with zeros (the kernels' row strides)"""
+    c = t.shape[-1]
+    return t if c % 4 == 0 else tnf.pad(t, (0, 4 - c % 4))
+
+
+class _ConvPixelMajor(torch.autograd.Function):
+    """y = conv2d(x, weight, stride, pad) over pixel-major tensors: x [hin*win][M][Cin4], y [hout*wout][M][Cout]; weight in
+    torch's (Cout, Cin, kh, kw) layout (Cin4 = Cin rounded up to 4: the padded channels are zeros)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, hin, win, stride, pad):
+        cout, cin, kh, kw = weight.shape
+        hout, wout = (hin + 2 * pad - kh) // stride + 1, (win + 2 * pad - kw) // stride + 1
+        x = x.contiguous()
+        w = _pad4(weight.detach().float().permute(0, 2, 3, 1))                    # (Cout, kh, kw, Cin4)
+        assert w.shape[3] == x.shape[2], (w.shape, x.shape)
+        y = _conv_gemm(x, w.reshape(cout, -1).contiguous(), hin, win, kh, kw, stride, pad, hout, wout)
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (hin, win, stride, pad, hout, wout)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        hin, win, stride, pad, hout, wout = ctx.geom
+        cout, cin, kh, kw = weight.shape
+        _, M, cin4 = x.shape
+        dev = x.device
+        dy = dy.contiguous().float()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # dX[i] = sum_taps W[tap]^T dY[(i + pad - tap) / stride]: the stride-1 convolution of the zero-stuffed dY with
+            # the mirrored taps, pad' = k - 1 - pad; rows of X the forward never reached get no tap and stay zero
+            if stride == 1:
+                dyz, hz, wz = dy, hout, wout
+            else:
+                hz, wz = (hout - 1) * stride + 1, (wout - 1) * stride + 1
+                dyz = torch.zeros(hz, wz, M, cout, dtype=torch.float32, device=dev)
+                dyz[::stride, ::stride] = dy.view(hout, wout, M, cout)
+                dyz = dyz.view(hz * wz, M, cout)
+            wr = weight.detach().float().flip(2, 3)                                      # mirrored taps
+            if cin4 != cin:
+                wr = tnf.pad(wr, (0, 0, 0, 0, 0, cin4 - cin))                            # (zero rows for the padded channels)
+            wr = wr.permute(1, 2, 3, 0).reshape(cin4, kh * kw * cout).contiguous()      # [Cin4][(u, v, co)]
+            dx = _conv_gemm(dyz, wr, hz, wz, kh, kw, 1, kh - 1 - pad, hin, win)
+        if ctx.needs_input_grad[1]:
+            lib = nat.lib()
+            nfl = lib.magat_conv_wgrad_workspace_floats(M, cin4, cout, kh, kw)
+            part = torch.empty(nfl, dtype=torch.float32, device=dev)
+            chunks = ctypes.c_int(0)
+            with torch.cuda.device(dev):
+                nat.check(lib.magat_conv_wgrad_f32(nat.ptr(x), M * cin4, cin4, nat.ptr(dy), M * cout, cout, nat.ptr(part),
+                                                   ctypes.byref(chunks), M, cin4, cout, hin, win, hout, wout, kh, kw, stride,
+                                                   pad, nat.current_stream(dev)), "magat_conv_wgrad_f32")
+            n = chunks.value
+            dwp = part[:n * cout * kh * kw * cin4].view(n, cout, kh, kw, cin4).sum(dim=0)
+            dw = dwp[..., :cin].permute(0, 3, 1, 2).contiguous().to(weight.dtype)
+        return dx, dw, None, None, None, None
+
+
+def _batch_norm(m, t):
+    """torch.nn.BatchNorm2d.forward over a pixel-major tensor [P][M][C]: the statistics run over every (pixel, agent) row,
+    i.e. over (N, H, W) of the NCHW tensor; running statistics / num_batches_tracked are updated as nn.BatchNorm does."""
+    P, M, C = t.shape
+    factor = 0.0 if m.momentum is None else m.momentum
+    if m.training and m.track_running_stats and m.num_batches_tracked is not None:
+        m.num_batches_tracked.add_(1)
+        factor = 1.0 / float(m.num_batches_tracked) if m.momentum is None else m.momentum
+    use_batch = m.training or (m.running_mean is None and m.running_var is None)
+    y = tnf.batch_norm(t.reshape(P * M, C), m.running_mean if (not m.training or m.track_running_stats) else None,
+                       m.running_var if (not m.training or m.track_running_stats) else None, m.weight, m.bias, use_batch,
+                       factor, m.eps)
+    return y.view(P, M, C)
+
+
+def _conv(m, t, h, w):
+    """nn.Conv2d `m` over the pixel-major map t [h*w][M][Cin4] -> (map, h', w')"""
+    kh, kw = m.kernel_size
+    s, p = m.stride[0], m.padding[0]
+    y = _ConvPixelMajor.apply(t, m.weight, h, w, s, p)
+    ho, wo = (h + 2 * p - kh) // s + 1, (w + 2 * p - kw) // s + 1
+    if m.bias is not None:
+        y = y + m.bias.view(1, 1, -1)
+    return y, ho, wo
+
+
+def _basic_block(blk, t, h, w):
+    out, ho, wo = _conv(blk.conv1, t, h, w)
+    out = torch.relu(_batch_norm(blk.bn1, out))
+    out, _, _ = _conv(blk.conv2, out, ho, wo)
+    out = _batch_norm(blk.bn2, out)
+    if blk.downsample is None:
+        res = t
+    else:
+        res, _, _ = _conv(blk.downsample[0], t, h, w)
+        res = _batch_norm(blk.downsample[1], res)
+    return torch.relu(out + res), ho, wo
+
+
+def resnet_forward(body, x):
+    """resnet.ResNet / ResNetSlim forward (resnet_pytorch.py:495-524) on the HIP convolution kernels, differentiable.
+    x (M, 3, H, W) CUDA float32 -> (M, num_classes, H', W') like body(x)."""
+    M, c, h, w = x.shape
+    t = _pad4(x.float().permute(2, 3, 0, 1).reshape(h * w, M, c)).contiguous()         # [pixel][agent][4]
+    t, h, w = _conv(body.conv1, t, h, w)
+    t = torch.relu(_batch_norm(body.bn1, t))
+    for i in range(body.n_layers):
+        t, h, w = _basic_block(getattr(body, "layer%d" % (i + 1))[0], t, h, w)
+    k = body.avgpool.kernel_size
+    k = k if isinstance(k, int) else k[0]
+    h2, w2 = h // k, w // k
+    C = t.shape[2]
+    t = t.view(h, w, M, C)[:h2 * k, :w2 * k].reshape(h2, k, w2, k, M, C).mean(dim=(1, 3)).reshape(h2 * w2, M, C)
+    t, _, _ = _conv(body.fc, t.contiguous(), h2, w2)
+    return t.permute(1, 2, 0).reshape(M, t.shape[2], h2, w2)
+
+
+def convlayers_forward(conv_layers, x):
+    """planner.ConvLayers(x) under autograd: the ResNet trunk on the HIP kernels when the input is on the GPU (environment
+    MAGAT_TRAIN_CNN=torch keeps torch's own convolutions), the layers behind it (Dropout, Flatten, Linear) as they are."""
+    import os
+    from .resnet import _ResNetBase
+    body = conv_layers[0] if len(conv_layers) > 0 else None
+    if x.is_cuda and isinstance(body, _ResNetBase) and os.environ.get("MAGAT_TRAIN_CNN", "hip") != "torch":
+        y = resnet_forward(body, x)
+        for m in list(conv_layers)[1:]:
+            y = m(y)
+        return y
+    return conv_layers(x)

@@ -1,0 +1,131 @@
+"""Training of the per-agent CNN on the HIP convolution kernels (train_cnn.py, csrc/conv_train.hip) against torch's own
+float64 autograd of the same layers on the CPU: convolution forward / input gradient / weight gradient at every geometry the
+ResNet trunks use, the whole trunk in training mode (batch-statistics BatchNorm, running-stat updates), and a training step of
+the planner with either convolution backend."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as tnf
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / max(1e-12, float(b.abs().max())))
+
+
+# (Cin, Cout, k, stride, pad, H)   stem; layer1.conv1 (stride 2); its 1x1 downsample; the 3x3s of the chain; the head's 1x1
+GEOMS = [(3, 32, 3, 1, 1, 11), (32, 32, 3, 2, 1, 11), (32, 32, 1, 2, 0, 11), (32, 64, 3, 1, 1, 6), (64, 64, 3, 1, 1, 6),
+         (64, 128, 1, 1, 0, 6), (128, 128, 3, 1, 1, 6), (128, 128, 1, 1, 0, 3), (32, 32, 3, 2, 1, 12)]
+
+
+@pytest.mark.parametrize("M", [77, 150])
+@pytest.mark.parametrize("geom", GEOMS, ids=lambda g: "c%d_%d_k%d_s%d_p%d_h%d" % g)
+def test_conv_forward_dgrad_wgrad_match_torch(gpu_device, geom, M):
+    from magat_pathplanning_amd.train_cnn import _ConvPixelMajor, _pad4
+    cin, cout, k, s, p, H = geom
+    g = torch.Generator().manual_seed(11 + cin + cout + k + s + M)
+    x = torch.randn(M, cin, H, H, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.2
+    ho = (H + 2 * p - k) // s + 1
+    wgt = torch.randn(M, cout, ho, ho, generator=g)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = tnf.conv2d(x64, w64, None, s, p)
+    (y64 * wgt.double()).sum().backward()
+    xd = _pad4(x.permute(2, 3, 0, 1).reshape(H * H, M, cin)).contiguous().to(gpu_device).requires_grad_(True)
+    wd = w.to(gpu_device).requires_grad_(True)
+    y = _ConvPixelMajor.apply(xd, wd, H, H, s, p)
+    assert tuple(y.shape) == (ho * ho, M, cout)
+    (y * wgt.permute(2, 3, 0, 1).reshape(ho * ho, M, cout).to(gpu_device)).sum().backward()
+    ynchw = y.detach().cpu().view(ho, ho, M, cout).permute(2, 3, 0, 1)
+    assert _rel(ynchw.double(), y64.detach()) < 2e-6
+    dx = xd.grad.cpu()[..., :cin].view(H, H, M, cin).permute(2, 3, 0, 1)
+    assert _rel(dx.double(), x64.grad) < 2e-6
+    assert float(xd.grad[..., cin:].abs().max()) == 0.0 if cin % 4 else True
+    assert _rel(wd.grad.cpu().double(), w64.grad) < 5e-6
+
+
+@pytest.mark.parametrize("slim", [False, True], ids=["ResNetLarge", "ResNetSlim"])
+def test_resnet_training_step_matches_torch(gpu_device, slim):
+    """Trunk in TRAINING mode: output, the gradient of every parameter and of the input, and the BatchNorm running statistics
+    after the step against the module's own torch forward in float64 on the CPU."""
+    from magat_pathplanning_amd.resnet import ResNet, ResNetSlim
+    from magat_pathplanning_amd.train_cnn import resnet_forward
+    torch.manual_seed(3)
+    body = (ResNetSlim if slim else ResNet)()
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for m in body.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5, generator=g)
+                m.bias.normal_(0, 0.2, generator=g)
+    M = 45
+    x = (torch.rand(M, 3, 11, 11, generator=g) < 0.3).float() + 0.1 * torch.randn(M, 3, 11, 11, generator=g)
+    ref = copy.deepcopy(body).double().train()
+    dev = copy.deepcopy(body).to(gpu_device).train()
+    x64 = x.double().requires_grad_(True)
+    y64 = ref(x64)
+    wgt = torch.randn(y64.shape, generator=g)
+    (y64 * wgt.double()).sum().backward()
+    xd = x.to(gpu_device).requires_grad_(True)
+    y = resnet_forward(dev, xd)
+    assert tuple(y.shape) == tuple(y64.shape)
+    (y * wgt.to(gpu_device)).sum().backward()
+    assert _rel(y.detach().cpu().double(), y64.detach()) < 1e-5
+    assert _rel(xd.grad.cpu().double(), x64.grad) < 1e-4
+    pr = dict(ref.named_parameters())
+    for k, v in dev.named_parameters():
+        assert v.grad is not None, k
+        assert _rel(v.grad.cpu().double(), pr[k].grad) < 2e-4, k
+    br = dict(ref.named_buffers())
+    for k, v in dev.named_buffers():
+        if v.dtype.is_floating_point:
+            assert _rel(v.cpu().double(), br[k]) < 1e-5, k
+        else:
+            assert int(v) == int(br[k]), k
+    # evaluation mode under autograd: running statistics, no updates
+    dev.eval(); ref.eval()
+    y = resnet_forward(dev, x.to(gpu_device))
+    assert _rel(y.detach().cpu().double(), ref(x.double()).detach()) < 1e-5
+
+
+def test_planner_training_step_hip_convolutions_vs_torch_convolutions(gpu_device, monkeypatch):
+    """loss.backward() through DecentralPlannerGATNet in training mode (agents/..._GAT.py:556-567): the HIP convolution
+    backend (default) against torch's (MAGAT_TRAIN_CNN=torch) from identical weights - logits, every gradient, the BatchNorm
+    buffers - and one optimiser step of each ends in the same parameters."""
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N = 6, 10
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat", device="cuda:0")
+    torch.manual_seed(21)
+    base = DecentralPlannerGATNet(cfg)
+    for m in base.modules():              # (Dropout draws from the device generator: the two runs must see the same stream)
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    x = fov_states(B, N, seed=5).to(gpu_device)
+    S = comm_gso(B, N, 20, seed=6).to(gpu_device)
+    tgt = torch.randint(0, 5, (B * N,), generator=torch.Generator().manual_seed(7)).to(gpu_device)
+    res = {}
+    for backend in ("hip", "torch"):
+        monkeypatch.setenv("MAGAT_TRAIN_CNN", backend)
+        net = copy.deepcopy(base).to(gpu_device).train()
+        opt = torch.optim.SGD(net.parameters(), lr=0.05)
+        net.addGSO(S.clone())
+        logits = net(x)
+        loss = tnf.cross_entropy(logits, tgt)
+        opt.zero_grad()
+        loss.backward()
+        grads = {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None}
+        opt.step()
+        res[backend] = (logits.detach(), grads, {k: v.detach().clone() for k, v in net.state_dict().items()})
+    lh, gh, sh = res["hip"]
+    lt, gt, st = res["torch"]
+    assert _rel(lh, lt) < 1e-4
+    assert gh.keys() == gt.keys() and any(k.startswith("ConvLayers.0.layer3") for k in gh)
+    for k in gh:
+        assert _rel(gh[k], gt[k]) < 2e-3, k
+    for k in sh:
+        if sh[k].dtype.is_floating_point:
+            assert _rel(sh[k], st[k]) < 1e-4, k
