@@ -206,6 +206,50 @@ def build_model(cfg, device, seed=1337):
     return net.to(device).eval()
 
 
+def train_step_leg(dev, steps=10):
+    import torch
+    import torch.nn.functional as tnf
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    out = {"what": "forward + cross-entropy + backward + SGD step, train mode (batch-statistics BatchNorm), K=3, P=4, "
+                   "BottomNeck_skipConcat; ms per step", "steps": steps}
+    prev = os.environ.get("MAGAT_TRAIN_CNN")
+    try:
+        for Bt, Nt in ((64, 100), (64, 10)):
+            cfgt = make_config(num_agents=Nt, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat",
+                               device=str(dev))
+            xt = fov_states(Bt, Nt, seed=21).to(dev)
+            St = comm_gso(Bt, Nt, 20 if Nt <= 20 else 50, seed=22).to(dev)
+            tgt = torch.randint(0, 5, (Bt * Nt,), generator=torch.Generator().manual_seed(23)).to(dev)
+            row = {}
+            for backend in ("hip", "torch"):
+                os.environ["MAGAT_TRAIN_CNN"] = backend
+                torch.manual_seed(24)
+                net = DecentralPlannerGATNet(cfgt).to(dev).train()
+                opt = torch.optim.SGD(net.parameters(), lr=0.01)
+                for it in range(3 + steps):
+                    if it == 3:
+                        torch.cuda.synchronize(dev)
+                        t0 = time.perf_counter()
+                    net.addGSO(St)
+                    loss = tnf.cross_entropy(net(xt), tgt)
+                    opt.zero_grad()
+                    loss.backward()
+                    opt.step()
+                torch.cuda.synchronize(dev)
+                row["convolutions_%s_ms" % ("hip" if backend == "hip" else "torch_miopen")] = round(
+                    (time.perf_counter() - t0) / steps * 1e3, 3)
+                del net, opt
+            out["%dx%d_agents" % (Bt, Nt)] = row
+    finally:
+        if prev is None:
+            os.environ.pop("MAGAT_TRAIN_CNN", None)
+        else:
+            os.environ["MAGAT_TRAIN_CNN"] = prev
+        torch.cuda.empty_cache()
+    return out
+
+
 def physical_cores():
     try:
         import psutil
@@ -651,6 +695,13 @@ def main():
                                 "note": "option CONV_MX=1: NOT fp32-class (logits move 5e-6..1e-5 from the oracle instead of "
                                         "~1e-6); reported for comparison only"}
         nat.reset_option("CONV_MX")
+        # (f) a TRAINING step (forward + cross-entropy + backward + SGD, train mode; agents/..._GAT.py:556-567) with the
+        # convolutions on this library's kernels (train_cnn.py) and on torch's (MIOpen); the graph layer on its HIP
+        # forward / backward either way.  Not part of `value`.
+        try:
+            res["train_step"] = train_step_leg(dev)
+        except Exception as e:          # (a reported extra: never takes the bench line down)
+            res["train_step"] = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -432,12 +432,13 @@ int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
  *     dW[co][ty*kW+tx][ci] = sum over output pixels (oy,ox) and agents m of dY[oy*Wout+ox][m][co] * X[iy*Win+ix][m][ci],
  *     iy = oy*stride - pad + ty (taps that fall into the padding are skipped).
  * x / dy pixel-major float32 as for magat_conv_gemm_f32 (row strides lda / ldc, pixel strides in floats); Cout % 32 == 0.
- * part: magat_conv_wgrad_workspace_floats() floats = [chunks][Cout][kH*kW][Cin] partial sums over agent chunks; *chunks_out
- * (host int) = how many the caller has to add up (fixed order: deterministic gradients, no atomics). */
-size_t magat_conv_wgrad_workspace_floats(int M, int Cin, int Cout, int kH, int kW);
+ * part: magat_conv_wgrad_workspace_floats() floats = [chunks][Cout][cin_w][kH][kW] partial sums over chunks of the contraction (agent ranges x groups of output pixels), each in
+ * torch's own weight layout (cin_w <= Cin: the channels the weight tensor has - the stem's rows carry a fourth, padded
+ * channel); *chunks_out (host int) = how many the caller has to add up (fixed order: deterministic gradients, no atomics). */
+size_t magat_conv_wgrad_workspace_floats(int M, int Cin, int cin_w, int Cout, int kH, int kW, int npix /* Hout*Wout */);
 int magat_conv_wgrad_f32(const float* x, long long x_pix_stride, int lda, const float* dy, long long dy_pix_stride, int ldc,
-                         float* part, int* chunks_out, int M, int Cin, int Cout, int Hin, int Win, int Hout, int Wout, int kH,
-                         int kW, int stride, int pad, void* stream);
+                         float* part, int* chunks_out, int M, int Cin, int cin_w, int Cout, int Hin, int Win, int Hout, int Wout,
+                         int kH, int kW, int stride, int pad, void* stream);
 
 /* y[M,N] = act(x[M,K] @ w[N,K]^T + b)   (torch.nn.Linear; …bottleneck.py:105,160,229) */
 int magat_linear_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M,

@@ -27,7 +27,9 @@ struct WgradParams {
   long long x_pix_stride, dy_pix_stride;
   int M, Cin, lda, Cout, ldc;
   int Hin, Win, Hout, Wout, kH, kW, stride, pad;
-  int chunks, mc;              // agents per chunk (even)
+  int cin_out;                 // channels of the weight tensor itself (<= Cin: the stem's fourth channel is padding)
+  int chunks, mc;              // chunks = pixel groups x agent ranges; agents per range (even)
+  int cm, pc;                  // agent ranges; output pixels per pixel group
   int tiles_ci;                // input-channel tiles of 32 * NCI
 };
 
@@ -43,8 +45,11 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const WgradParams p) {
   const int tco = b / p.chunks;
   const int co0 = tco * 32 * NCO, ci0 = tci * 32 * NCI;
   const int ty = tap / p.kW, tx = tap - ty * p.kW;
-  const int m0 = chunk * p.mc;
+  const int m0 = (chunk % p.cm) * p.mc;
   const int m1 = m0 + p.mc < p.M ? m0 + p.mc : p.M;
+  const int o0 = (chunk / p.cm) * p.pc;
+  const int npix = p.Hout * p.Wout;
+  const int o1 = o0 + p.pc < npix ? o0 + p.pc : npix;
   f32x16 acc[NCO][NCI];
 #pragma unroll
   for (int i = 0; i < NCO; ++i)
@@ -55,10 +60,11 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const WgradParams p) {
   bool cok[NCI];
 #pragma unroll
   for (int j = 0; j < NCI; ++j) cok[j] = ci0 + 32 * j + col < p.Cin;        // (the stem's 3 -> 4 channels: a partial tile)
-  for (int oy = 0; oy < p.Hout; ++oy) {
+  for (int o = o0; o < o1; ++o) {
+    const int oy = o / p.Wout, ox = o - oy * p.Wout;
     const int iy = oy * p.stride - p.pad + ty;
     if (iy < 0 || iy >= p.Hin) continue;
-    for (int ox = 0; ox < p.Wout; ++ox) {
+    {
       const int ix = ox * p.stride - p.pad + tx;
       if (ix < 0 || ix >= p.Win) continue;
       const float* dyp = p.dy + (long long)(oy * p.Wout + ox) * p.dy_pix_stride + co0 + col;
@@ -86,58 +92,72 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const WgradParams p) {
       }
     }
   }
-  // part[chunk][co][tap][ci]
-  float* out = p.part + (long long)chunk * p.Cout * taps * p.Cin;
+  // part[chunk][co][ci][tap]: torch's (Cout, Cin, kH, kW) layout per chunk - the caller's sum over the chunks IS the gradient
+  // tensor (the stores are 4 * taps bytes apart: a few KB per wave, once)
+  float* out = p.part + (long long)chunk * p.Cout * taps * p.cin_out;
 #pragma unroll
   for (int i = 0; i < NCO; ++i)
 #pragma unroll
     for (int j = 0; j < NCI; ++j) {
-      if (!cok[j]) continue;
+      const int ci = ci0 + 32 * j + col;
+      if (ci >= p.cin_out) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
-        out[((long long)co * taps + tap) * p.Cin + ci0 + 32 * j + col] = acc[i][j][r];
+        out[((long long)co * p.cin_out + ci) * taps + tap] = acc[i][j][r];
       }
     }
 }
 
 }  // namespace
 
-size_t magat_conv_wgrad_workspace_floats(int M, int Cin, int Cout, int kH, int kW) {
-  if (M <= 0 || Cin <= 0 || Cout <= 0 || kH <= 0 || kW <= 0) return 0;
+// chunks of the contraction: agent ranges of >= 64 agents x groups of output pixels, about four waves per SIMD of the chip
+static void wgrad_chunks(int M, int Cin, int Cout, int kH, int kW, int npix, int* cm, int* mc, int* cpix, int* pc) {
   const int nco = Cout % 64 == 0 ? 2 : 1, nci = Cin % 64 == 0 ? 2 : 1;
   const long long waves = (long long)(Cout / (32 * nco)) * ((Cin + 32 * nci - 1) / (32 * nci)) * kH * kW;
-  long long chunks = (4096 + waves - 1) / waves;            // ~four waves per SIMD of the chip
-  const long long maxc = (M + 63) / 64;                     // at least 64 agents per chunk
-  if (chunks > maxc) chunks = maxc;
-  if (chunks < 1) chunks = 1;
-  return (size_t)chunks * Cout * kH * kW * Cin;
+  long long want = (4096 + waves - 1) / waves;
+  if (want < 1) want = 1;
+  long long a = (M + 63) / 64;                               // agent ranges
+  if (a > want) a = want;
+  int len = (int)(((M + a - 1) / a + 1) & ~1LL);             // agents per range, even
+  a = (M + len - 1) / len;
+  long long g = (want + a - 1) / a;                          // pixel groups
+  if (g > npix) g = npix;
+  if (g < 1) g = 1;
+  int per = (int)((npix + g - 1) / g);
+  g = (npix + per - 1) / per;
+  *cm = (int)a; *mc = len; *cpix = (int)g; *pc = per;
+}
+
+size_t magat_conv_wgrad_workspace_floats(int M, int Cin, int cin_w, int Cout, int kH, int kW, int npix) {
+  if (M <= 0 || Cin <= 0 || Cout <= 0 || kH <= 0 || kW <= 0 || npix <= 0 || cin_w <= 0) return 0;
+  int cm, mc, cpix, pc;
+  wgrad_chunks(M, Cin, Cout, kH, kW, npix, &cm, &mc, &cpix, &pc);
+  return (size_t)cm * cpix * Cout * kH * kW * cin_w;
 }
 
 // x: [Hin*Win][M][lda >= Cin] float32 pixel-major (pixel stride x_pix_stride floats); dy: [Hout*Wout][M][ldc >= Cout];
-// part: magat_conv_wgrad_workspace_floats(...) floats = [chunks][Cout][kH*kW][Cin] partial sums (the caller sums over the
-// first axis; *chunks_out tells how many).  Cout a multiple of 32.
+// part: magat_conv_wgrad_workspace_floats(...) floats = [chunks][Cout][cin_w][kH][kW] partial sums in torch's weight layout
+// (cin_w <= Cin: the channels the weight tensor has; the caller sums over the first axis, *chunks_out tells how many).
+// Cout a multiple of 32.
 int magat_conv_wgrad_f32(const float* x, long long x_pix_stride, int lda, const float* dy, long long dy_pix_stride, int ldc,
-                         float* part, int* chunks_out, int M, int Cin, int Cout, int Hin, int Win, int Hout, int Wout, int kH,
-                         int kW, int stride, int pad, void* stream) {
+                         float* part, int* chunks_out, int M, int Cin, int cin_w, int Cout, int Hin, int Win, int Hout, int Wout,
+                         int kH, int kW, int stride, int pad, void* stream) {
   if (!x || !dy || !part || !chunks_out) return MAGAT_ERR_NULL;
   if (M <= 0 || Cin <= 0 || Cout <= 0 || Cout % 32 || lda < Cin || ldc < Cout || kH <= 0 || kW <= 0 || stride <= 0 || pad < 0 ||
-      Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0)
+      Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || cin_w <= 0 || cin_w > Cin)
     return MAGAT_ERR_BAD_SHAPE;
   const int nco = Cout % 64 == 0 ? 2 : 1, nci = Cin % 64 == 0 ? 2 : 1;
   WgradParams p;
   p.x = x; p.dy = dy; p.part = part;
   p.x_pix_stride = x_pix_stride; p.dy_pix_stride = dy_pix_stride;
-  p.M = M; p.Cin = Cin; p.lda = lda; p.Cout = Cout; p.ldc = ldc;
+  p.M = M; p.Cin = Cin; p.lda = lda; p.Cout = Cout; p.ldc = ldc; p.cin_out = cin_w;
   p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.kH = kH; p.kW = kW; p.stride = stride; p.pad = pad;
   p.tiles_ci = (Cin + 32 * nci - 1) / (32 * nci);
   const int tiles_co = Cout / (32 * nco);
-  const size_t total = magat_conv_wgrad_workspace_floats(M, Cin, Cout, kH, kW);
-  p.chunks = (int)(total / ((size_t)Cout * kH * kW * Cin));
-  p.mc = ((M + p.chunks - 1) / p.chunks + 1) & ~1;
-  if ((long long)p.mc * (p.chunks - 1) >= M) {              // (rounding the chunk length up to even emptied the last chunks)
-    p.chunks = (M + p.mc - 1) / p.mc;
-  }
+  int cpix;
+  wgrad_chunks(M, Cin, Cout, kH, kW, Hout * Wout, &p.cm, &p.mc, &cpix, &p.pc);
+  p.chunks = p.cm * cpix;
   *chunks_out = p.chunks;
   const unsigned grid = (unsigned)((long long)tiles_co * p.chunks * kH * kW * p.tiles_ci);
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -82,23 +82,22 @@ class _ConvPixelMajor(torch.autograd.Function):
                 dyz = torch.zeros(hz, wz, M, cout, dtype=torch.float32, device=dev)
                 dyz[::stride, ::stride] = dy.view(hout, wout, M, cout)
                 dyz = dyz.view(hz * wz, M, cout)
-            wr = weight.detach().float().flip(2, 3)                                      # mirrored taps
+            wr = weight.detach().float().permute(1, 2, 3, 0).flip(1, 2)                 # [Cin][u][v][co], taps mirrored: one copy
             if cin4 != cin:
-                wr = tnf.pad(wr, (0, 0, 0, 0, 0, cin4 - cin))                            # (zero rows for the padded channels)
-            wr = wr.permute(1, 2, 3, 0).reshape(cin4, kh * kw * cout).contiguous()      # [Cin4][(u, v, co)]
+                wr = tnf.pad(wr, (0, 0, 0, 0, 0, 0, 0, cin4 - cin))                      # (zero rows for the padded channels)
+            wr = wr.reshape(cin4, kh * kw * cout).contiguous()        # (flip keeps the permuted strides: this is the copy that counts)
             dx = _conv_gemm(dyz, wr, hz, wz, kh, kw, 1, kh - 1 - pad, hin, win)
         if ctx.needs_input_grad[1]:
             lib = nat.lib()
-            nfl = lib.magat_conv_wgrad_workspace_floats(M, cin4, cout, kh, kw)
+            nfl = lib.magat_conv_wgrad_workspace_floats(M, cin4, cin, cout, kh, kw, hout * wout)
             part = torch.empty(nfl, dtype=torch.float32, device=dev)
             chunks = ctypes.c_int(0)
             with torch.cuda.device(dev):
                 nat.check(lib.magat_conv_wgrad_f32(nat.ptr(x), M * cin4, cin4, nat.ptr(dy), M * cout, cout, nat.ptr(part),
-                                                   ctypes.byref(chunks), M, cin4, cout, hin, win, hout, wout, kh, kw, stride,
-                                                   pad, nat.current_stream(dev)), "magat_conv_wgrad_f32")
-            n = chunks.value
-            dwp = part[:n * cout * kh * kw * cin4].view(n, cout, kh, kw, cin4).sum(dim=0)
-            dw = dwp[..., :cin].permute(0, 3, 1, 2).contiguous().to(weight.dtype)
+                                                   ctypes.byref(chunks), M, cin4, cin, cout, hin, win, hout, wout, kh, kw,
+                                                   stride, pad, nat.current_stream(dev)), "magat_conv_wgrad_f32")
+            n = chunks.value                          # partial sums per agent chunk, each in the weight's own layout
+            dw = part[:n * weight.numel()].view(n, cout, cin, kh, kw).sum(dim=0).to(weight.dtype)
         return dx, dw, None, None, None, None
 
 
