@@ -12,8 +12,8 @@ PIXEL-MAJOR activations [pixel][agent][channel] (the layout magat_conv_gemm_f32 
                    v_mfma_f32_32x32x2_f32, partial sums per agent chunk added in a fixed order - deterministic)
 
 BatchNorm (batch statistics, running-stat updates exactly as torch.nn.BatchNorm2d does them), ReLU, the residual adds and the
-2 x 2 average pool are elementwise / reduction work: torch ops on the GPU over the same pixel-major tensors.  CNN_mode
-'Default' (conv + BN + ReLU + MaxPool stacks) keeps the torch convolutions.
+2 x 2 average / max pools are elementwise / reduction work: torch ops on the GPU over the same pixel-major tensors.  CNN_mode
+'Default' (conv + BN + ReLU + MaxPool stacks) runs on the same kernels (conv_stack_forward).
 """
 import ctypes
 
@@ -158,6 +158,45 @@ def resnet_forward(body, x):
     return t.permute(1, 2, 0).reshape(M, t.shape[2], h2, w2)
 
 
+def conv_stack_forward(seq, x):
+    """CNN_mode 'Default' (decentralplanner_GAT_bottleneck.py:118-140: five conv3x3(+bias) + BatchNorm + ReLU layers with a
+    MaxPool2d(2) behind the first, third and fifth) on the same kernels: any nn.Sequential of Conv2d / BatchNorm2d / ReLU /
+    MaxPool2d / AvgPool2d / Dropout over pixel-major maps.  x (M, C, H, W) -> (M, C', H', W')."""
+    import torch.nn as nn
+    M, c, h, w = x.shape
+    t = _pad4(x.float().permute(2, 3, 0, 1).reshape(h * w, M, c)).contiguous()
+    for m in seq:
+        if isinstance(m, nn.Conv2d):
+            t, h, w = _conv(m, t, h, w)
+        elif isinstance(m, nn.BatchNorm2d):
+            t = _batch_norm(m, t)
+        elif isinstance(m, nn.ReLU):
+            t = torch.relu(t)
+        elif isinstance(m, (nn.MaxPool2d, nn.AvgPool2d)):
+            k = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
+            st = m.stride if isinstance(m.stride, int) else m.stride[0]
+            if st != k or (m.padding if isinstance(m.padding, int) else m.padding[0]) != 0:
+                raise NotImplementedError("pooling with stride != kernel or padding")
+            h2, w2, C = h // k, w // k, t.shape[2]
+            v = t.view(h, w, M, C)[:h2 * k, :w2 * k].reshape(h2, k, w2, k, M, C)
+            t = (v.amax(dim=(1, 3)) if isinstance(m, nn.MaxPool2d) else v.mean(dim=(1, 3))).reshape(h2 * w2, M, C).contiguous()
+            h, w = h2, w2
+        elif isinstance(m, nn.Dropout):
+            t = m(t)
+        else:
+            raise NotImplementedError("layer %r in a convolution stack" % (type(m).__name__,))
+    return t.permute(1, 2, 0).reshape(M, t.shape[2], h, w)
+
+
+def _is_conv_stack(seq):
+    import torch.nn as nn
+    mods = list(seq)
+    return len(mods) > 0 and isinstance(mods[0], nn.Conv2d) and all(
+        isinstance(m, (nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.MaxPool2d, nn.AvgPool2d, nn.Dropout)) for m in mods) and all(
+        m.out_channels % 32 == 0 and m.groups == 1 and m.dilation == (1, 1) and m.stride[0] == m.stride[1] and
+        m.padding[0] == m.padding[1] for m in mods if isinstance(m, nn.Conv2d))
+
+
 def convlayers_forward(conv_layers, x):
     """planner.ConvLayers(x) under autograd: the ResNet trunk on the HIP kernels when the input is on the GPU (environment
     MAGAT_TRAIN_CNN=torch keeps torch's own convolutions), the layers behind it (Dropout, Flatten, Linear) as they are."""
@@ -169,4 +208,6 @@ def convlayers_forward(conv_layers, x):
         for m in list(conv_layers)[1:]:
             y = m(y)
         return y
+    if x.is_cuda and os.environ.get("MAGAT_TRAIN_CNN", "hip") != "torch" and _is_conv_stack(conv_layers):
+        return conv_stack_forward(conv_layers, x)
     return conv_layers(x)

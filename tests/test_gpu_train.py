@@ -129,3 +129,45 @@ def test_planner_training_step_hip_convolutions_vs_torch_convolutions(gpu_device
     for k in sh:
         if sh[k].dtype.is_floating_point:
             assert _rel(sh[k], st[k]) < 1e-4, k
+
+
+def test_default_cnn_training_step_matches_torch(gpu_device):
+    """CNN_mode 'Default' (conv3x3 + bias, BatchNorm, ReLU, MaxPool2d stacks) in training mode on the HIP convolution kernels
+    against the same nn.Sequential in float64 on the CPU: output, every gradient, the BatchNorm buffers."""
+    import torch.nn as nn
+    from magat_pathplanning_amd.train_cnn import conv_stack_forward, _is_conv_stack
+    torch.manual_seed(8)
+    chans = [3, 32, 32, 64, 64, 128]
+    layers = []
+    for l in range(5):
+        layers += [nn.Conv2d(chans[l], chans[l + 1], 3, 1, 1, bias=True), nn.BatchNorm2d(chans[l + 1]), nn.ReLU(inplace=True)]
+        if l % 2 == 0:
+            layers.append(nn.MaxPool2d(kernel_size=2))
+    seq = nn.Sequential(*layers)
+    assert _is_conv_stack(seq)
+    g = torch.Generator().manual_seed(9)
+    M = 37
+    x = (torch.rand(M, 3, 11, 11, generator=g) < 0.3).float() + 0.1 * torch.randn(M, 3, 11, 11, generator=g)
+    ref = copy.deepcopy(seq).double().train()
+    dev = copy.deepcopy(seq).to(gpu_device).train()
+    x64 = x.double().requires_grad_(True)
+    y64 = ref(x64)
+    wgt = torch.randn(y64.shape, generator=g)
+    (y64 * wgt.double()).sum().backward()
+    xd = x.to(gpu_device).requires_grad_(True)
+    y = conv_stack_forward(dev, xd)
+    assert tuple(y.shape) == tuple(y64.shape)
+    (y * wgt.to(gpu_device)).sum().backward()
+    assert _rel(y.detach().cpu().double(), y64.detach()) < 1e-5
+    assert _rel(xd.grad.cpu().double(), x64.grad) < 2e-4
+    pr = dict(ref.named_parameters())
+    gmax = max(float(p_.grad.abs().max()) for p_ in pr.values())
+    for k, v in dev.named_parameters():
+        # (a convolution's bias in front of a training-mode BatchNorm has a gradient of exactly zero in exact arithmetic:
+        #  an absolute floor relative to the largest gradient of the stack)
+        err = float((v.grad.cpu().double() - pr[k].grad).abs().max())
+        assert err < 5e-4 * float(pr[k].grad.abs().max()) + 1e-6 * gmax, (k, err)
+    br = dict(ref.named_buffers())
+    for k, v in dev.named_buffers():
+        if v.dtype.is_floating_point:
+            assert _rel(v.cpu().double(), br[k]) < 1e-5, k
