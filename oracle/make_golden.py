@@ -395,8 +395,62 @@ def main_edge():
         print("wrote", path, os.path.getsize(path) // 1024, "KB", float(np.abs(out["y_concat"]).max()))
 
 
+def main_train():
+    """Round 4: a TRAINING step of the whole model by the real reference (agents/decentralplannerlocal_OnlineExpert_GAT.py:
+    556-567: train mode, cross-entropy, loss.backward()): logits, loss, the gradient of every parameter and the BatchNorm
+    buffers behind the forward (batch statistics), run in float64 (the reference's own modules on double tensors; inputs and
+    parameters are float32 values).  Dropout probabilities are set to 0 (its masks would depend on the generator of the
+    device that draws them)."""
+    _, classes = import_reference()
+    cases = [("train_skipconcat_keyquery", 9437, 3, dict(num_agents=8, nGraphFilterTaps=3, nAttentionHeads=2, bottleneckFeature=64,
+                                                          attentionMode="KeyQuery", bottleneckMode="BottomNeck_skipConcat")),
+             ("train_only_slim_modified", 9471, 2, dict(num_agents=10, nGraphFilterTaps=2, nAttentionHeads=4, bottleneckFeature=32,
+                                                        attentionMode="GAT_modified", bottleneckMode="BottomNeck_only",
+                                                        CNN_mode="ResNetSlim_withMLP", AttentionConcat=False))]
+    for name, seed, B, kw in cases:
+        cfg = make_config(**kw)
+        gen = torch.Generator().manual_seed(seed)
+        torch.manual_seed(seed)
+        model = classes[cfg.bottleneckMode](cfg).train()
+        with torch.no_grad():
+            for mod in model.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.weight.uniform_(0.5, 1.5, generator=gen)
+                    mod.bias.normal_(0, 0.1, generator=gen)
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+            if hasattr(model.GFL[0], "weight_bias"):
+                model.GFL[0].weight_bias.uniform_(-0.3, 0.3, generator=gen)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        model = model.double()
+        N = cfg.num_agents
+        x = fov_states(gen, B, N)
+        from magat_pathplanning_amd.synthetic import comm_gso
+        S = comm_gso(B, N, 20, seed=seed + 1, dtype=torch.float64)
+        target = torch.randint(0, 5, (B * N,), generator=gen)
+        model.addGSO(S.clone())
+        logits = model(x.double())
+        loss = torch.nn.functional.cross_entropy(logits, target)
+        loss.backward()
+        f32 = lambda t: t.detach().numpy().astype(np.float32)
+        out = dict(x=x.numpy().astype(np.uint8), S=S.numpy(), target=target.numpy(), logits=f32(logits), loss=np.float64(loss.item()),
+                   cfg=np.array(repr(vars(cfg))))
+        for k, v in sd0.items():
+            out["sd/" + k] = v.numpy()
+        for k, v in model.named_parameters():
+            out["g/" + k] = f32(v.grad if v.grad is not None else torch.zeros_like(v))
+        for k, v in model.named_buffers():
+            out["b/" + k] = v.detach().numpy().astype(np.float32 if v.dtype.is_floating_point else np.int64)
+        path = os.path.join(OUT, "%s.npz" % name)
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path) // 1024, "KB", "loss", float(loss),
+              "max|g|", max(float(np.abs(v).max()) for k, v in out.items() if k.startswith("g/")))
+
+
 if __name__ == "__main__":
-    if "--edge" in sys.argv:
+    if "--train" in sys.argv:
+        main_train()
+    elif "--edge" in sys.argv:
         main_edge()
     elif "--grad" in sys.argv:
         main_grad()
