@@ -250,16 +250,19 @@ __device__ __forceinline__ void walk4(char* lds, int in_off, int in2_off, const 
 // over the three tap ROWS (the compact form of the one-launch kernel: 48 items of code instead of 144).  Same items in the
 // same order as walk4<W4I, 4, KS2, ...> - per accumulator: taps 0..8, k steps 0..3, then the residual segment - so the sums
 // are bit-identical.  What makes a rolled loop possible: a tap row is 12 k steps (a multiple of the weight ring D = 4: the
-// slot of a k step does not depend on the row) and 12 NT items (a multiple of the operand ring AV = 4); inside a row the
+// slot of a k step does not depend on the row) and 12 NT items (a multiple of the operand ring AV = 3); inside a row the
 // taps' pixel shifts are immediates (dx = -1, 0, 1, and 6 + dx for the look-ahead reads that belong to the next row), the row
 // itself is ONE add per tile base and iteration.  The weight k steps are contiguous in memory: a scalar pointer runs D - 1
 // k steps ahead of the products and stops at the stream's last k step (re-reads it: nothing beyond the stream is touched).
 // The residual segment (KS2 k steps over the block input, plane stride of its own) follows as straight-line items.
+#ifndef MAGAT_ROWS_AV
+#define MAGAT_ROWS_AV 3      /* operand ring of the rolled walk: 3 (as walk4) measured 1 % better than 4 on the kernel */
+#endif
 template <int NT, int KS2, int PS_IN, int PS_IN2, int NA = NT>
 __device__ __forceinline__ void walk_rows4(char* lds, int in_off, int in2_off, const char* wbase, f32x16 (&acc)[NA], bool with_res,
                                            const int (&pix)[NT]) {
   static_assert(NA >= NT, "accumulator array shorter than the tile list");
-  constexpr int KSM = 4, D = 4, AV = 4, LA = AV - 1, NI = 3 * KSM * NT;      // items per tap row
+  constexpr int KSM = 4, D = 4, AV = MAGAT_ROWS_AV, LA = AV - 1, NI = 3 * KSM * NT;      // items per tap row
   static_assert(NI % AV == 0 && (3 * KSM) % D == 0, "ring sizes must divide a tap row");
   u32x4 w[D][2], av[AV][2];
   int tid = threadIdx.x;
@@ -280,7 +283,7 @@ __device__ __forceinline__ void walk_rows4(char* lds, int in_off, int in2_off, c
     b[0] = *reinterpret_cast<const u32x4*>(wn + lane16);
     b[1] = *reinterpret_cast<const u32x4*>(wn + (lane16 + 1024u));
     ++nfetched;
-    wn += nfetched < total ? 2048 : 0;
+    wn += nfetched < total ? 2048 : 0;       // (measured: the clamp costs nothing - profiles/r04g)
   };
   // item j of a row: tap dx = j / (KSM * NT), k step (j / NT) % KSM, tile j % NT; j >= NI: the same item of the next row
   auto rd = [&](int j, int pl, u32x4& dst) {
