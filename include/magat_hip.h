@@ -440,6 +440,21 @@ int magat_conv_wgrad_f32(const float* x, long long x_pix_stride, int lda, const 
                          float* part, int* chunks_out, int M, int Cin, int cin_w, int Cout, int Hin, int Win, int Hout, int Wout,
                          int kH, int kW, int stride, int pad, void* stream);
 
+/* nn.BatchNorm2d in TRAINING mode (batch statistics; resnet_pytorch.py:42-58) over pixel-major rows x[rows = pixels * agents][C]
+ * (contiguous, C a power of two times 4, <= 256), ReLU fused on request:
+ *   forward   y = [relu]((x - mean) * invstd * gamma + beta); save_mean / save_invstd [C] for the backward; running_mean /
+ *             running_var (nullable) updated in place as nn.BatchNorm does (momentum = the exponential-average factor,
+ *             unbiased variance)
+ *   backward  dx, dgamma [C], dbeta [C] from dy (relu: masked by y > 0, y = the forward's output)
+ * workspace: magat_bn_train_workspace_floats(rows, C) floats (0 = unsupported shape).  Deterministic (fixed summation order). */
+size_t magat_bn_train_workspace_floats(long long rows, int C);
+int magat_bn_train_forward_f32(const float* x, float* y, long long rows, int C, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, int relu, float* save_mean,
+                               float* save_invstd, float* workspace, void* stream);
+int magat_bn_train_backward_f32(const float* x, const float* y, const float* dy, float* dx, long long rows, int C,
+                                const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* dgamma,
+                                float* dbeta, float* workspace, void* stream);
+
 /* y[M,N] = act(x[M,K] @ w[N,K]^T + b)   (torch.nn.Linear; …bottleneck.py:105,160,229) */
 int magat_linear_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M,
                      int N, int K, int relu, void* stream);

@@ -117,6 +117,9 @@ _SIGNATURES = {
     "magat_conv_gemm_f32": (_I, [ctypes.POINTER(ConvGemmDesc), _P]),
     "magat_conv_wgrad_workspace_floats": (_Z, [_I] * 7),
     "magat_conv_wgrad_f32": (_I, [_P, ctypes.c_longlong, _I, _P, ctypes.c_longlong, _I, _P, ctypes.POINTER(ctypes.c_int)] + [_I] * 12 + [_P]),
+    "magat_bn_train_workspace_floats": (_Z, [ctypes.c_longlong, _I]),
+    "magat_bn_train_forward_f32": (_I, [_P, _P, ctypes.c_longlong, _I, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I, _P, _P, _P, _P]),
+    "magat_bn_train_backward_f32": (_I, [_P, _P, _P, _P, ctypes.c_longlong, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     "magat_linear_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "magat_linear_tagged_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "magat_gat_set_debug_buffer": (_I, [_P]),

@@ -11,8 +11,10 @@ PIXEL-MAJOR activations [pixel][agent][channel] (the layout magat_conv_gemm_f32 
   weight gradient  magat_conv_wgrad_f32 (csrc/conv_train.hip: the contraction over (pixel, agent) rows on
                    v_mfma_f32_32x32x2_f32, partial sums per agent chunk added in a fixed order - deterministic)
 
-BatchNorm (batch statistics, running-stat updates exactly as torch.nn.BatchNorm2d does them), ReLU, the residual adds and the
-2 x 2 average / max pools are elementwise / reduction work: torch ops on the GPU over the same pixel-major tensors.  CNN_mode
+  BatchNorm (+ReLU) magat_bn_train_{forward,backward}_f32: batch statistics in one streaming pass, running-stat updates exactly as
+                   torch.nn.BatchNorm2d makes them, ReLU and its mask fused
+
+The residual adds and the 2 x 2 average / max pools are torch ops on the GPU over the same pixel-major tensors.  CNN_mode
 'Default' (conv + BN + ReLU + MaxPool stacks) runs on the same kernels (conv_stack_forward).
 """
 import ctypes
@@ -101,15 +103,68 @@ class _ConvPixelMajor(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
-def _batch_norm(m, t):
-    """torch.nn.BatchNorm2d.forward over a pixel-major tensor [P][M][C]: the statistics run over every (pixel, agent) row,
-    i.e. over (N, H, W) of the NCHW tensor; running statistics / num_batches_tracked are updated as nn.BatchNorm does."""
+class _BatchNormTrain(torch.autograd.Function):
+    """Training-mode BatchNorm (+ ReLU) over rows [R][C] on magat_bn_train_{forward,backward}_f32 (csrc/conv_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, factor, eps, relu):
+        lib = nat.lib()
+        R, C = x.shape
+        dev = x.device
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.magat_bn_train_workspace_floats(R, C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(lib.magat_bn_train_forward_f32(nat.ptr(x), nat.ptr(y), R, C, nat.ptr(gamma.detach()), nat.ptr(beta.detach()),
+                                                     nat.ptr(running_mean), nat.ptr(running_var), float(factor), float(eps),
+                                                     int(relu), nat.ptr(mean), nat.ptr(invstd), nat.ptr(ws),
+                                                     nat.current_stream(dev)), "magat_bn_train_forward_f32")
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = nat.lib()
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        R, C = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.magat_bn_train_workspace_floats(R, C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(lib.magat_bn_train_backward_f32(nat.ptr(x), nat.ptr(y), nat.ptr(dy), nat.ptr(dx), R, C, nat.ptr(gamma.detach()),
+                                                      nat.ptr(mean), nat.ptr(invstd), int(ctx.relu), nat.ptr(dgamma), nat.ptr(dbeta),
+                                                      nat.ptr(ws), nat.current_stream(dev)), "magat_bn_train_backward_f32")
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def _batch_norm(m, t, relu=False):
+    """torch.nn.BatchNorm2d.forward (+ ReLU) over a pixel-major tensor [P][M][C]: the statistics run over every (pixel, agent)
+    row, i.e. over (N, H, W) of the NCHW tensor; running statistics / num_batches_tracked are updated as nn.BatchNorm does.
+    Training mode with affine parameters: the HIP kernels (one streaming pass per reduction); otherwise torch's batch_norm."""
     P, M, C = t.shape
     factor = 0.0 if m.momentum is None else m.momentum
     if m.training and m.track_running_stats and m.num_batches_tracked is not None:
         m.num_batches_tracked.add_(1)
         factor = 1.0 / float(m.num_batches_tracked) if m.momentum is None else m.momentum
     use_batch = m.training or (m.running_mean is None and m.running_var is None)
+    if (use_batch and t.is_cuda and m.affine and t.dtype == torch.float32 and m.weight.dtype == torch.float32 and
+            nat.lib().magat_bn_train_workspace_floats(P * M, C) > 0):
+        track = m.training and m.track_running_stats
+        y = _BatchNormTrain.apply(t.reshape(P * M, C), m.weight, m.bias, m.running_mean if track else None,
+                                  m.running_var if track else None, factor, m.eps, relu)
+        return y.view(P, M, C)
+    y = _batch_norm_torch(m, t, factor, use_batch)
+    return torch.relu(y) if relu else y
+
+
+def _batch_norm_torch(m, t, factor, use_batch):
+    P, M, C = t.shape
     y = tnf.batch_norm(t.reshape(P * M, C), m.running_mean if (not m.training or m.track_running_stats) else None,
                        m.running_var if (not m.training or m.track_running_stats) else None, m.weight, m.bias, use_batch,
                        factor, m.eps)
@@ -129,7 +184,7 @@ def _conv(m, t, h, w):
 
 def _basic_block(blk, t, h, w):
     out, ho, wo = _conv(blk.conv1, t, h, w)
-    out = torch.relu(_batch_norm(blk.bn1, out))
+    out = _batch_norm(blk.bn1, out, relu=True)
     out, _, _ = _conv(blk.conv2, out, ho, wo)
     out = _batch_norm(blk.bn2, out)
     if blk.downsample is None:
@@ -146,7 +201,7 @@ def resnet_forward(body, x):
     M, c, h, w = x.shape
     t = _pad4(x.float().permute(2, 3, 0, 1).reshape(h * w, M, c)).contiguous()         # [pixel][agent][4]
     t, h, w = _conv(body.conv1, t, h, w)
-    t = torch.relu(_batch_norm(body.bn1, t))
+    t = _batch_norm(body.bn1, t, relu=True)
     for i in range(body.n_layers):
         t, h, w = _basic_block(getattr(body, "layer%d" % (i + 1))[0], t, h, w)
     k = body.avgpool.kernel_size
