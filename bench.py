@@ -237,7 +237,7 @@ def train_step_leg(dev, steps=10):
                     loss.backward()
                     opt.step()
                 torch.cuda.synchronize(dev)
-                row["convolutions_%s_ms" % ("hip" if backend == "hip" else "torch_miopen")] = round(
+                row["cnn_on_%s_ms" % ("hip_kernels" if backend == "hip" else "torch_miopen")] = round(
                     (time.perf_counter() - t0) / steps * 1e3, 3)
                 del net, opt
             out["%dx%d_agents" % (Bt, Nt)] = row
@@ -696,8 +696,8 @@ def main():
                                         "~1e-6); reported for comparison only"}
         nat.reset_option("CONV_MX")
         # (f) a TRAINING step (forward + cross-entropy + backward + SGD, train mode; agents/..._GAT.py:556-567) with the
-        # convolutions on this library's kernels (train_cnn.py) and on torch's (MIOpen); the graph layer on its HIP
-        # forward / backward either way.  Not part of `value`.
+        # CNN's convolutions and BatchNorm on this library's kernels (train_cnn.py) and on torch's (MIOpen / ATen); the graph
+        # layer on its HIP forward / backward either way.  Not part of `value`.
         try:
             res["train_step"] = train_step_leg(dev)
         except Exception as e:          # (a reported extra: never takes the bench line down)

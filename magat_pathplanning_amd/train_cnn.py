@@ -220,13 +220,19 @@ def conv_stack_forward(seq, x):
     import torch.nn as nn
     M, c, h, w = x.shape
     t = _pad4(x.float().permute(2, 3, 0, 1).reshape(h * w, M, c)).contiguous()
-    for m in seq:
+    mods = list(seq)
+    fused = set()
+    for i, m in enumerate(mods):
         if isinstance(m, nn.Conv2d):
             t, h, w = _conv(m, t, h, w)
         elif isinstance(m, nn.BatchNorm2d):
-            t = _batch_norm(m, t)
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)          # (BatchNorm + ReLU: one kernel pair)
+            if relu:
+                fused.add(i + 1)
+            t = _batch_norm(m, t, relu=relu)
         elif isinstance(m, nn.ReLU):
-            t = torch.relu(t)
+            if i not in fused:
+                t = torch.relu(t)
         elif isinstance(m, (nn.MaxPool2d, nn.AvgPool2d)):
             k = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
             st = m.stride if isinstance(m.stride, int) else m.stride[0]

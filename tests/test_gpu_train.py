@@ -171,3 +171,30 @@ def test_default_cnn_training_step_matches_torch(gpu_device):
     for k, v in dev.named_buffers():
         if v.dtype.is_floating_point:
             assert _rel(v.cpu().double(), br[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("rows,C", [(77 * 36, 32), (1001, 64), (23040, 128), (5, 128)])
+def test_batchnorm_training_kernels_match_torch(gpu_device, rows, C, relu):
+    """magat_bn_train_{forward,backward}_f32 through train_cnn._BatchNormTrain against torch.nn.functional.batch_norm (+ relu) in
+    float64: output, dx / dgamma / dbeta, and the running statistics (momentum 0.1, unbiased variance)."""
+    from magat_pathplanning_amd.train_cnn import _BatchNormTrain
+    g = torch.Generator().manual_seed(rows + C + int(relu))
+    x = torch.randn(rows, C, generator=g) * 1.7 + 0.4
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    wgt = torch.randn(rows, C, generator=g)
+    x64, g64, b64 = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm64, rv64 = rm.double().clone(), rv.double().clone()
+    y64 = tnf.batch_norm(x64, rm64, rv64, g64, b64, True, 0.1, 1e-5)
+    y64 = torch.relu(y64) if relu else y64
+    (y64 * wgt.double()).sum().backward()
+    xd, gd, bd = (t.to(gpu_device).requires_grad_(True) for t in (x, gamma, beta))
+    rmd, rvd = rm.to(gpu_device), rv.to(gpu_device)
+    y = _BatchNormTrain.apply(xd, gd, bd, rmd, rvd, 0.1, 1e-5, relu)
+    (y * wgt.to(gpu_device)).sum().backward()
+    assert _rel(y.detach().cpu().double(), y64.detach()) < 2e-6
+    assert _rel(xd.grad.cpu().double(), x64.grad) < 2e-5
+    assert _rel(gd.grad.cpu().double(), g64.grad) < 2e-5
+    assert _rel(bd.grad.cpu().double(), b64.grad) < 2e-5
+    assert _rel(rmd.cpu().double(), rm64) < 1e-6 and _rel(rvd.cpu().double(), rv64) < 1e-6
