@@ -576,6 +576,11 @@ int magat_profile_enable(int on);
 int magat_profile_collect(void);
 int magat_profile_read(int tag, long long* count, double* total_ms);
 int magat_profile_reset(void);
+/* What the device SUSTAINS on v_mfma_f32_32x32x16_f16 from registers alone (operand bits toggling), one wave per SIMD on every
+ * CU, in one launch of about ms_target milliseconds: *tflops (dense f16).  The clock the chip holds under matrix load is part
+ * of the figure (MI355X: 1.5-1.6 PFLOP/s against the 2.5 PFLOP/s of the 2.4 GHz peak clock).  scratch: 256 * CUs floats.
+ * Synchronises the stream.  (ABI 5; bench.py's `roofline.sustained_*` keys) */
+int magat_mfma_sustained_f16(double* tflops, float* scratch, int ms_target, void* stream);
 
 #ifdef __cplusplus
 }

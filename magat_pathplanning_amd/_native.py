@@ -128,6 +128,7 @@ _SIGNATURES = {
     "magat_profile_collect": (_I, []),
     "magat_profile_read": (_I, [_I, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),
     "magat_profile_reset": (_I, []),
+    "magat_mfma_sustained_f16": (_I, [ctypes.POINTER(ctypes.c_double), _P, _I, _P]),
     "magat_conv_first_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "magat_conv_first_tiled_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "magat_encoder_workspace_bytes": (_Z, [ctypes.POINTER(EncoderDesc), _I]),

@@ -64,6 +64,14 @@ long long* g_block3_dbg = nullptr;
 #else
 #define FULL_STAMP(i) do { } while (0)
 #endif
+// the workgroup's core-clock count next to the constant 100 MHz counter, at its start (k = 0) and end (k = 1): row "wave 4" of
+// the debug buffer - the clock the chip actually holds under this kernel (tools/chain_phase_probe.py prints it)
+#ifdef MAGAT_DEBUG_HOOKS
+#define FULL_CLOCKS(k) do { if (l3.dbg && threadIdx.x == 0) { long long* d_ = l3.dbg + ((long long)blockIdx.x * 8 + 4) * 16 + 2 * (k); \
+    d_[0] = (long long)__builtin_readcyclecounter(); d_[1] = (long long)__builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define FULL_CLOCKS(k) do { } while (0)
+#endif
 // per-wave phase stamps of the layer3 kernel (debug build): [workgroup][wave 8][16], before and after every barrier
 #ifdef MAGAT_DEBUG_HOOKS
 #define L3_STAMP(i) do { if (p.dbg && (threadIdx.x & 63) == 0) p.dbg[((long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -1112,6 +1120,7 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const f32x4*>(l3.b2 + 32 * ct2 + 8 * qd + 4 * fh);
   }
+  FULL_CLOCKS(0);
   const int gstride = (int)gridDim.x;
   constexpr int U0 = 0, U1 = MAP32, U2 = 2 * MAP32, U3 = 3 * MAP32;
   if ((int)blockIdx.x < p.groups) {
@@ -1245,6 +1254,7 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
     }
     FULL_STAMP(10);
   }
+  FULL_CLOCKS(1);
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
@@ -1254,7 +1264,10 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
 // structure: waves 0 / 1 of stage A share theirs (run-time pixels), stage C and the two conv1 halves are three passes of one
 // loop, every stage has ONE split-and-store epilogue for both row-group roles (run-time pixels, the fifth tile skipped by the
 // interior role).
-template <bool ROWS>        // ROWS: the interior-tile role of the 64 -> 64 walks as a rolled loop over the tap rows (walk_rows4)
+// FORM 0: straight-line walks.  1: the interior-tile role of the 64 -> 64 walks (stage C, conv1) as a rolled loop over the tap rows
+// (walk_rows4).  2: + layer3.conv2 as two passes per half - its four interior tiles through walk_rows4, its five edge / corner
+// tiles through the edge role's straight-line walk (the weight stream of a channel tile is read twice).
+template <int FORM>
 __global__ __launch_bounds__(256, 1) void block_full_c_kernel(const FullParams q) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const ChainParams& p = q.c;
@@ -1285,6 +1298,7 @@ __global__ __launch_bounds__(256, 1) void block_full_c_kernel(const FullParams q
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const f32x4*>(l3.b2 + 32 * ct2 + 8 * qd + 4 * fh);
   }
+  FULL_CLOCKS(0);
   const int gstride = (int)gridDim.x;
   constexpr int U0 = 0, U1 = MAP32, U2 = 2 * MAP32, U3 = 3 * MAP32;
   if ((int)blockIdx.x < p.groups) {
@@ -1362,7 +1376,7 @@ __global__ __launch_bounds__(256, 1) void block_full_c_kernel(const FullParams q
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[s][r] = 0.f;
       if (rg == 0) {
-        if constexpr (ROWS) {
+        if constexpr (FORM >= 1) {
           const int pixI[4] = {pix5[0], pix5[1], pix5[2], pix5[3]};
           walk_rows4<4, 2, 8 * BLK, 4 * BLK, 5>(lds, in_off, U1, wts, a, it == 0, pixI);
         } else {
@@ -1386,7 +1400,13 @@ __global__ __launch_bounds__(256, 1) void block_full_c_kernel(const FullParams q
         const int h = it - 1;
         const char* w2 = h == 0 ? l3.w2a + (size_t)ct2 * BPT2A * 1024 : l3.w2b + (size_t)ct2 * BPT2B * 1024;
         FULL_STAMP(5 + 2 * h);
-        walk4<W4All, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_MID, L_IN, w2, acc, h == 1);
+        if constexpr (FORM >= 2) {
+          const int pixI[4] = {tile_pix(W4I::t[0], psl_), tile_pix(W4I::t[1], psl_), tile_pix(W4I::t[2], psl_), tile_pix(W4I::t[3], psl_)};
+          walk_rows4<4, 4, 8 * BLK, 8 * BLK, 9>(lds, L_MID, L_IN, w2, acc, h == 1, pixI);                  // acc[0..3]: interior tiles
+          walk4<W4E, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D, GeoChain, 5>(lds, L_MID, L_IN, w2, reinterpret_cast<f32x16(&)[5]>(acc[4]), h == 1);
+        } else {
+          walk4<W4All, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_MID, L_IN, w2, acc, h == 1);
+        }
         L3_LDS_SYNC();
         FULL_STAMP(6 + 2 * h);
       }
@@ -1441,6 +1461,7 @@ __global__ __launch_bounds__(256, 1) void block_full_c_kernel(const FullParams q
     }
     FULL_STAMP(10);
   }
+  FULL_CLOCKS(1);
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
@@ -1593,13 +1614,15 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
   const bool pooled_regs = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 2;      // 2: pooling in registers (block_full_p_kernel)
   const bool compact = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 3;          // 3: + the compact loop body (block_full_c_kernel)
   const bool rows = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 4;             // 4: + its interior walks rolled over the tap rows
+  const bool twopass = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 5;          // 5: + conv2 as an interior pass and an edge pass
   if (out_gl != 0 && !(out_gl == 1 && pooled_regs)) return MAGAT_ERR_UNSUPPORTED;      // (magat_block_full_out_gl() tells)
   l.out_gl = out_gl;
-  if (magat_ensure_dyn_lds(rows ? reinterpret_cast<const void*>(&block_full_c_kernel<true>)
-                           : compact ? reinterpret_cast<const void*>(&block_full_c_kernel<false>)
+  if (magat_ensure_dyn_lds(twopass ? reinterpret_cast<const void*>(&block_full_c_kernel<2>)
+                           : rows ? reinterpret_cast<const void*>(&block_full_c_kernel<1>)
+                           : compact ? reinterpret_cast<const void*>(&block_full_c_kernel<0>)
                            : pooled_regs ? reinterpret_cast<const void*>(&block_full_p_kernel)
                                          : reinterpret_cast<const void*>(&block_full_w4_kernel),
-                           rows ? MAGAT_LDS_BLOCK_FULL_C4 : compact ? MAGAT_LDS_BLOCK_FULL_C : pooled_regs ? MAGAT_LDS_BLOCK_FULL_P
+                           twopass ? MAGAT_LDS_BLOCK_FULL_C5 : rows ? MAGAT_LDS_BLOCK_FULL_C4 : compact ? MAGAT_LDS_BLOCK_FULL_C : pooled_regs ? MAGAT_LDS_BLOCK_FULL_P
                                                                                     : MAGAT_LDS_BLOCK_FULL,
                            LDS_TOTAL) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
@@ -1610,8 +1633,9 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
   }
   const int grid = p.groups < cus ? p.groups : cus;
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_FULL, st);
-  if (rows) hipLaunchKernelGGL(block_full_c_kernel<true>, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
-  else if (compact) hipLaunchKernelGGL(block_full_c_kernel<false>, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
+  if (twopass) hipLaunchKernelGGL(block_full_c_kernel<2>, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
+  else if (rows) hipLaunchKernelGGL(block_full_c_kernel<1>, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
+  else if (compact) hipLaunchKernelGGL(block_full_c_kernel<0>, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
   else if (pooled_regs) hipLaunchKernelGGL(block_full_p_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
   else hipLaunchKernelGGL(block_full_w4_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
   magat_prof_end(pid, st);

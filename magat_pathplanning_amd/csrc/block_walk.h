@@ -277,13 +277,16 @@ __device__ __forceinline__ void walk_rows4(char* lds, int in_off, int in2_off, c
     rb[s] = ab[s] + (unsigned)(in_off - 7 * PIXB);                    // tap (dy -1, dx -1): shift 6 * (-1) + (-1)
   }
   const int total = 9 * KSM + (with_res ? KS2 : 0);                  // k steps of this walk's weight stream
-  const char* wn = wbase;                                             // the next k step to fetch (wave-uniform)
+  // the next k step to fetch: a 32-bit per-lane offset from the (scalar) stream base - the loads keep the scalar-base form of
+  // walk4 and the offset of the NEXT k step is ready a k step ahead (a 64-bit per-lane pointer formed in front of every load
+  // cost 0.3 k cycles per walk); it stops at the stream's last k step
+  unsigned voff = lane16;
   int nfetched = 0;
   auto load_next = [&](u32x4 (&b)[2]) {
-    b[0] = *reinterpret_cast<const u32x4*>(wn + lane16);
-    b[1] = *reinterpret_cast<const u32x4*>(wn + (lane16 + 1024u));
+    b[0] = *reinterpret_cast<const u32x4*>(wbase + voff);
+    b[1] = *reinterpret_cast<const u32x4*>(wbase + (voff + 1024u));
     ++nfetched;
-    wn += nfetched < total ? 2048 : 0;       // (measured: the clamp costs nothing - profiles/r04g)
+    voff += nfetched < total ? 2048u : 0u;
   };
   // item j of a row: tap dx = j / (KSM * NT), k step (j / NT) % KSM, tile j % NT; j >= NI: the same item of the next row
   auto rd = [&](int j, int pl, u32x4& dst) {
@@ -298,7 +301,11 @@ __device__ __forceinline__ void walk_rows4(char* lds, int in_off, int in2_off, c
     rd(j, 0, av[j][0]);
     rd(j, 1, av[j][1]);
   }
+#ifdef MAGAT_ROWS_UNROLL       // timing experiment: the same formulation as straight-line code
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
   for (int row = 0; row < 3; ++row) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {

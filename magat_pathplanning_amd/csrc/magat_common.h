@@ -79,7 +79,7 @@ enum MagatLdsSlot {
   MAGAT_LDS_GAT16, MAGAT_LDS_GAT32, MAGAT_LDS_GAT64, MAGAT_LDS_GAT128, MAGAT_LDS_GAT256, MAGAT_LDS_L1FUSED,
   MAGAT_LDS_SIM_GSO_T, MAGAT_LDS_SIM_GSO_F, MAGAT_LDS_SIM_MOVE, MAGAT_LDS_BLOCK_A, MAGAT_LDS_BLOCK_B, MAGAT_LDS_BLOCK_C,
   MAGAT_LDS_SIM_CONN, MAGAT_LDS_CONV_FIRST, MAGAT_LDS_CONV_FIRST11, MAGAT_LDS_GSO_STRUCT, MAGAT_LDS_CSR_TILED_A, MAGAT_LDS_CSR_TILED_B, MAGAT_LDS_CSR_TILED_A16, MAGAT_LDS_CSR_TILED_B16,
-  MAGAT_LDS_CSR_TILED_A4, MAGAT_LDS_CSR_TILED_B4, MAGAT_LDS_CSR_TILED_A16_4, MAGAT_LDS_CSR_TILED_B16_4, MAGAT_LDS_BLOCK_B4, MAGAT_LDS_BLOCK_FULL, MAGAT_LDS_BLOCK_FULL_P, MAGAT_LDS_BLOCK_FULL_C, MAGAT_LDS_BLOCK_FULL_C4,
+  MAGAT_LDS_CSR_TILED_A4, MAGAT_LDS_CSR_TILED_B4, MAGAT_LDS_CSR_TILED_A16_4, MAGAT_LDS_CSR_TILED_B16_4, MAGAT_LDS_BLOCK_B4, MAGAT_LDS_BLOCK_FULL, MAGAT_LDS_BLOCK_FULL_P, MAGAT_LDS_BLOCK_FULL_C, MAGAT_LDS_BLOCK_FULL_C4, MAGAT_LDS_BLOCK_FULL_C5,
   MAGAT_LDS_GATM_0,      // gat_mfma.hip: 24 slots (score mode x shape class x taps x merge)
   MAGAT_LDS_GATM_END = MAGAT_LDS_GATM_0 + 24,
   MAGAT_LDS_STEM8,

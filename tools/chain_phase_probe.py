@@ -68,6 +68,9 @@ if full:
     print("merged kernel, cycles per agent group incl. the barrier behind each phase; total %.0f" % (t[:, :4, 10] - t[:, :4, 0]).mean())
     for i, n in enumerate(names):
         print("  %-34s" % n + "".join("%8.0f" % d[:, w, i].mean() for w in range(4)))
+    if t[:, 4, 0].any() and t[:, 4, 3].any():         # FULL_CLOCKS: core-clock cycles and 100 MHz ticks of every workgroup, start to end
+        cyc, ticks = t[:, 4, 2] - t[:, 4, 0], t[:, 4, 3] - t[:, 4, 1]
+        print("  workgroups: %.0f core cycles in %.1f us each: the kernel ran at %.0f MHz" % (cyc.mean(), ticks.mean() / 100.0, (cyc / ticks).mean() * 100.0))
     if t[:, 0, 11].any():
         print("  layer3.conv1 half 0 by wave: walk " + " ".join("%.0f" % (t[:, w, 11] - t[:, w, 4]).mean() for w in range(4)) +
               " | epilogue " + " ".join("%.0f" % (t[:, w, 12] - t[:, w, 11]).mean() for w in range(4)) +
