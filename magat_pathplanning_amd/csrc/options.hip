@@ -47,7 +47,8 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
     {"BLOCK_FULL", 2},       // layer1.conv2 -> layer2 -> layer3 -> pool as ONE launch (needs BLOCK_FUSED 2 and BLOCK3_FUSED 2);
                              // 2: the 2x2 pooling in registers (block_full_p_kernel), 1: through an LDS scratch (block_full_w4_kernel);
                              // 3 / 4 (opt-in, bit-identical to 2, not faster yet): the compact loop body (block_full_c_kernel:
-                             // shared walk / epilogue bodies, 80 KB instead of 114; 4: interior walks rolled over the tap rows, 76 KB)
+                             // shared walk / epilogue bodies, 80 KB instead of 114; 4: interior walks rolled over the tap rows, 74 KB;
+                             // 5: conv2 as a rolled interior pass + an edge pass, 67 KB)
     {"GAT_MFMA", 1},         // KeyQuery layer with 128 features, N <= 101, K = 2 | 3 as ONE launch of matrix-core products (gat_mfma.hip)
     {"GUARD_CHAIN", 1},      // the range guard's float32 re-run of the encoder: every layer behind the stem in ONE predicated launch
     {"HEAD_GL", 1},          // pooled map of the chain kernel granule-major for the f16x3 head (0: row-major agent tiles)
