@@ -253,30 +253,30 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(const BnParams p)
   }
 }
 
-// sums of the partials of 32 channels per workgroup: 8 lanes per channel walk the blocks, folded through LDS in double
+// sums of one channel's block partials: a wave per channel, every lane walks blocks / 64 of them, folded in double in a fixed
+// order (8 lanes per channel in 4 workgroups took 19 us at 512 blocks: a chain of dependent loads)
 __device__ __forceinline__ bool bn_fold(const BnParams& p, int& ch, double& s, double& s2) {
-  __shared__ double red[2][256];
-  const int c = threadIdx.x & 31, l = threadIdx.x >> 5;
-  ch = blockIdx.x * 32 + c;
+  __shared__ double red[2][64];
+  ch = blockIdx.x;
+  const int l = threadIdx.x;
   double a = 0.0, b = 0.0;
-  if (ch < p.C)
-    for (int blk = l; blk < p.blocks; blk += 8) {
-      a += (double)p.part[((long long)blk * 2 + 0) * p.C + ch];
-      b += (double)p.part[((long long)blk * 2 + 1) * p.C + ch];
-    }
-  red[0][threadIdx.x] = a;
-  red[1][threadIdx.x] = b;
+  for (int blk = l; blk < p.blocks; blk += 64) {
+    a += (double)p.part[((long long)blk * 2 + 0) * p.C + ch];
+    b += (double)p.part[((long long)blk * 2 + 1) * p.C + ch];
+  }
+  red[0][l] = a;
+  red[1][l] = b;
   __syncthreads();
-  if (l != 0 || ch >= p.C) return false;
+  if (l != 0) return false;
   s = 0.0; s2 = 0.0;
-  for (int k = 0; k < 8; ++k) {
-    s += red[0][k * 32 + c];
-    s2 += red[1][k * 32 + c];
+  for (int k = 0; k < 64; ++k) {
+    s += red[0][k];
+    s2 += red[1][k];
   }
   return true;
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const BnParams p) {
+__global__ __launch_bounds__(64) void bn_finalize_fwd_kernel(const BnParams p) {
   int ch;
   double s, s2;
   if (!bn_fold(p, ch, s, s2)) return;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const BnParams p) 
   }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const BnParams p) {
+__global__ __launch_bounds__(64) void bn_finalize_bwd_kernel(const BnParams p) {
   int ch;
   double s, s2;
   if (!bn_fold(p, ch, s, s2)) return;
@@ -370,7 +370,7 @@ int magat_bn_train_forward_f32(const float* x, float* y, long long rows, int C, 
   p.blocks = bn_blocks(rows, C, &p.rows_per_block);
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(p.blocks), dim3(BN_THREADS), 0, st, p);
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 31) / 32), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(64), 0, st, p);
   const long long total = rows * (C >> 2);
   long long grid = (total + BN_THREADS - 1) / BN_THREADS;
   if (grid > 4096) grid = 4096;
@@ -392,7 +392,7 @@ int magat_bn_train_backward_f32(const float* x, const float* y, const float* dy,
   p.blocks = bn_blocks(rows, C, &p.rows_per_block);
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(p.blocks), dim3(BN_THREADS), 0, st, p);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 31) / 32), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, st, p);
   const long long total = rows * (C >> 2);
   long long grid = (total + BN_THREADS - 1) / BN_THREADS;
   if (grid > 4096) grid = 4096;
