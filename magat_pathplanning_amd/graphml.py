@@ -786,7 +786,9 @@ class _GnnTrainFunction(torch.autograd.Function):
         ctx.layer, ctx.nnz, ctx.shape = layer, nnz, tuple(x.shape)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(X, rowptr, colidx, vals, weight)
-        return y
+        # (a tensor of its own: _forward_hip hands out a permuted VIEW of the kernel's rows, and an in-place op behind the layer -
+        #  the model's ReLU(inplace=True) - on a view made inside a custom Function is refused by autograd)
+        return y.clone()
 
     @staticmethod
     def backward(ctx, dy):

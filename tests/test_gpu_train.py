@@ -198,3 +198,32 @@ def test_batchnorm_training_kernels_match_torch(gpu_device, rows, C, relu):
     assert _rel(gd.grad.cpu().double(), g64.grad) < 2e-5
     assert _rel(bd.grad.cpu().double(), b64.grad) < 2e-5
     assert _rel(rmd.cpu().double(), rm64) < 1e-6 and _rel(rvd.cpu().double(), rv64) < 1e-6
+
+
+def test_gnn_baseline_training_step_hip_vs_torch_convolutions(gpu_device, monkeypatch):
+    """DecentralPlannerNet (the GNN-baseline model class, graphs/models/decentralplanner.py) in training mode: its CNN trains on
+    the HIP kernels too - logits and gradients against torch's convolutions from identical weights."""
+    from magat_pathplanning_amd import DecentralPlannerNet
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N = 4, 10
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, device="cuda:0")
+    torch.manual_seed(31)
+    base = DecentralPlannerNet(cfg)
+    for m in base.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    x = fov_states(B, N, seed=5).to(gpu_device)
+    S = comm_gso(B, N, 20, seed=6).to(gpu_device)
+    tgt = torch.randint(0, 5, (B * N,), generator=torch.Generator().manual_seed(7)).to(gpu_device)
+    res = {}
+    for backend in ("hip", "torch"):
+        monkeypatch.setenv("MAGAT_TRAIN_CNN", backend)
+        net = copy.deepcopy(base).to(gpu_device).train()
+        net.addGSO(S.clone())
+        logits = net(x)
+        tnf.cross_entropy(logits, tgt).backward()
+        res[backend] = (logits.detach(), {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None})
+    assert _rel(res["hip"][0], res["torch"][0]) < 1e-4
+    assert res["hip"][1].keys() == res["torch"][1].keys()
+    for k in res["hip"][1]:
+        assert _rel(res["hip"][1][k], res["torch"][1][k]) < 2e-3, k
