@@ -210,7 +210,7 @@ def resnet_forward(body, x):
     C = t.shape[2]
     t = t.view(h, w, M, C)[:h2 * k, :w2 * k].reshape(h2, k, w2, k, M, C).mean(dim=(1, 3)).reshape(h2 * w2, M, C)
     t, _, _ = _conv(body.fc, t.contiguous(), h2, w2)
-    return t.permute(1, 2, 0).reshape(M, t.shape[2], h2, w2)
+    return t.permute(1, 2, 0).reshape(M, t.shape[2], h2, w2).contiguous()      # (NCHW like body(x): callers .view() it)
 
 
 def conv_stack_forward(seq, x):
@@ -246,7 +246,7 @@ def conv_stack_forward(seq, x):
             t = m(t)
         else:
             raise NotImplementedError("layer %r in a convolution stack" % (type(m).__name__,))
-    return t.permute(1, 2, 0).reshape(M, t.shape[2], h, w)
+    return t.permute(1, 2, 0).reshape(M, t.shape[2], h, w).contiguous()
 
 
 def _is_conv_stack(seq):

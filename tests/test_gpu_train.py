@@ -227,3 +227,38 @@ def test_gnn_baseline_training_step_hip_vs_torch_convolutions(gpu_device, monkey
     assert res["hip"][1].keys() == res["torch"][1].keys()
     for k in res["hip"][1]:
         assert _rel(res["hip"][1][k], res["torch"][1][k]) < 2e-3, k
+
+
+def test_every_model_variant_trains_and_infers(gpu_device):
+    """One training step (cross-entropy, backward) and one inference forward of every (skip variant, CNN_mode, attention mode)
+    combination of DecentralPlannerGATNet and every CNN_mode of DecentralPlannerNet: finite logits and gradients, nothing raises
+    (this sweep found the ResNetLarge / ResNetSlim trunks handing out a non-contiguous map and the GNN-baseline class refusing
+    to train on the GPU)."""
+    import itertools
+    from magat_pathplanning_amd import DecentralPlannerGATNet, DecentralPlannerNet
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N = 3, 7
+    x = fov_states(B, N, seed=5).to(gpu_device)
+    S = comm_gso(B, N, 20, seed=6).to(gpu_device)
+    tgt = torch.randint(0, 5, (B * N,), generator=torch.Generator().manual_seed(2)).to(gpu_device)
+    cnns = ["ResNetLarge_withMLP", "ResNetSlim_withMLP", "ResNetLarge", "ResNetSlim", "Default"]
+    for skip, cnn, att in itertools.product(["BottomNeck_only", "BottomNeck_skipConcat", "BottomNeck_skipConcatGNN",
+                                             "BottomNeck_skipAddGNN", ""], cnns, ["KeyQuery", "GAT_origin"]):
+        concat = skip != "BottomNeck_skipAddGNN"            # (that variant ADDS the bottleneck feature: head mean, as the reference needs)
+        cfg = make_config(num_agents=N, nGraphFilterTaps=2, nAttentionHeads=2, bottleneckMode=skip, CNN_mode=cnn, attentionMode=att,
+                          AttentionConcat=concat, device="cuda:0")
+        torch.manual_seed(1)
+        net = DecentralPlannerGATNet(cfg).to(gpu_device).train()
+        net.addGSO(S.clone())
+        tnf.cross_entropy(net(x), tgt).backward()
+        assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None), (skip, cnn, att)
+        net.eval()
+        with torch.no_grad():
+            net.addGSO(S.clone())
+            assert torch.isfinite(net(x)).all(), (skip, cnn, att)
+    for cnn in cnns:
+        cfg = make_config(num_agents=N, nGraphFilterTaps=3, CNN_mode=cnn, device="cuda:0")
+        net = DecentralPlannerNet(cfg).to(gpu_device).train()
+        net.addGSO(S.clone())
+        tnf.cross_entropy(net(x), tgt).backward()
+        assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None), cnn
