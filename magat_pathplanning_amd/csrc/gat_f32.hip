@@ -318,7 +318,11 @@ __global__ void gat_dense_kernel(const GatParams p) {
   // of the group: harmless, never stored)
   const int ws_head = __builtin_amdgcn_readfirstlane(wl);
   auto load_urows = [&](fvec (&dst)[HMAX], int kk) {
-    const float* base = Zb + (long long)(ws_head * rpw + grp) * zrow + zcol(p.uoff + (head * K + kk) * F) + VEC * sub;
+    // (the lane's first row itself is clamped: with RPW rows per wave step - G, F < 64 - the row groups of the upper waves lie
+    //  past N altogether, and for the last instance of the batch past the end of Z: found by tools/exp/fuzz_forward.py as a
+    //  memory fault at N = 103, G = 16)
+    const int r0 = ws_head * rpw + grp;
+    const float* base = Zb + (long long)(r0 < N ? r0 : 0) * zrow + zcol(p.uoff + (head * K + kk) * F) + VEC * sub;
     const long long step = (long long)nwaves * rpw * zrow;
 #pragma unroll
     for (int h = 0; h < HMAX; ++h) {

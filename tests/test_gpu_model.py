@@ -598,3 +598,23 @@ def test_gnn_model_vs_reference_golden(gpu_device, path):
     assert float(np.abs(logits.cpu().numpy() - z["logits"]).max()) <= TOL
     np.testing.assert_array_equal(S.cpu().numpy(), z["S_after"])
     assert not net.range_status()["encoder_rerun"]
+
+
+def test_narrow_graph_layer_with_upper_waves_past_n(gpu_device):
+    """Regression (found by tools/exp/fuzz_forward.py as a GPU memory fault): G = F = 16 at N = 103 - the two-launch graph kernel's
+    narrow form has 16 rows per wave step, the row groups of its upper waves lie past N, and their U-row base pointer was not
+    clamped (for the last instance of a batch it pointed past the end of Z).  The configuration that faulted, against the oracle."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N = 2, 103
+    cfg = make_config(num_agents=N, nGraphFilterTaps=2, nAttentionHeads=2, bottleneckFeature=16, bottleneckMode="BottomNeck_skipConcat",
+                      CNN_mode="ResNetLarge", attentionMode="KeyQuery", AttentionConcat=True, device="cuda:0")
+    sd = orc.init_state_dict(cfg, seed=100)
+    x = fov_states(B, N, seed=3)
+    S = comm_gso(B, N, 50, seed=4, dtype=torch.float64)
+    ref = orc.planner_forward(x, S.clone(), sd, cfg).numpy()
+    net = _build(cfg, sd, gpu_device)
+    with torch.no_grad():
+        net.addGSO(S.clone().to(gpu_device))
+        got = net(x.to(gpu_device)).cpu().numpy()
+    assert np.abs(got - ref).max() <= TOL

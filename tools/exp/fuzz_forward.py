@@ -1,0 +1,49 @@
+"""Random model configurations through the HIP inference path against the CPU oracle (test infrastructure: a sweep, not a product
+path).   python tools/exp/fuzz_forward.py [count] [seed]"""
+import os, sys, random
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+import numpy as np, torch
+from magat_pathplanning_amd import DecentralPlannerGATNet
+from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+from oracle import magat_oracle as orc
+dev = torch.device("cuda:0")
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for it in range(count):
+    N = rng.choice([1, 2, 3, 5, 8, 10, 17, 31, 32, 33, 50, 64, 100, 102, 103, 128, 129, 150])
+    B = rng.choice([1, 2, 3, 5]) if N < 100 else rng.choice([1, 2])
+    G = rng.choice([16, 32, 64, 128])
+    K = rng.choice([1, 2, 3, 4])
+    P = rng.choice([1, 2, 4])
+    att = rng.choice(["KeyQuery", "GAT_modified", "GAT_origin"])
+    skip = rng.choice(["BottomNeck_only", "BottomNeck_skipConcat", "BottomNeck_skipConcatGNN", "BottomNeck_skipAddGNN", ""])
+    cnn = rng.choice(["ResNetLarge_withMLP", "ResNetSlim_withMLP", "ResNetLarge", "ResNetSlim", "Default"])
+    if skip == "BottomNeck_skipAddGNN" and cnn.endswith("_withMLP"):
+        cnn = "Default"            # (that reference file has no *_withMLP branch: the product maps it to Default, the oracle's init does not)
+    concat = rng.choice([True, False]) if skip != "BottomNeck_skipAddGNN" else False
+    f64 = rng.choice([True, False])
+    kw = dict(num_agents=N, nGraphFilterTaps=K, nAttentionHeads=P, bottleneckFeature=G, bottleneckMode=skip, CNN_mode=cnn,
+              attentionMode=att, AttentionConcat=concat)
+    print("try  B=%d N=%d G=%d K=%d P=%d %s %s %s concat=%s f64=%s" % (B, N, G, K, P, att, skip or "legacy", cnn, concat, f64), flush=True)
+    try:
+        cfg = make_config(device="cuda:0", **kw)
+        sd = orc.init_state_dict(cfg, seed=100 + it)
+        x = fov_states(B, N, seed=it)
+        S = comm_gso(B, N, 20 if N <= 20 else 50, seed=it + 1, dtype=torch.float64 if f64 else torch.float32)
+        ref = orc.planner_forward(x, S.clone(), sd, cfg).numpy()
+        net = DecentralPlannerGATNet(cfg)
+        net.load_state_dict(sd)
+        net = net.to(dev).eval()
+        with torch.no_grad():
+            net.addGSO(S.clone().to(dev))
+            got = net(x.to(dev)).cpu().numpy()
+        err = float(np.abs(got - ref).max())
+        ok = err <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+        if not ok:
+            bad += 1
+        print("%s err %.2e  B=%d N=%d G=%d K=%d P=%d %s %s %s concat=%s f64=%s" % ("ok  " if ok else "BAD ", err, B, N, G, K, P, att, skip or "legacy", cnn, concat, f64), flush=True)
+    except Exception as e:
+        bad += 1
+        print("RAISE B=%d N=%d G=%d K=%d P=%d %s %s %s concat=%s -> %s" % (B, N, G, K, P, att, skip or "legacy", cnn, concat, repr(e)[:160]))
+print("failures:", bad, "of", count)
