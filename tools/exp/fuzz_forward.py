@@ -23,13 +23,14 @@ for it in range(count):
         cnn = "Default"            # (that reference file has no *_withMLP branch: the product maps it to Default, the oracle's init does not)
     concat = rng.choice([True, False]) if skip != "BottomNeck_skipAddGNN" else False
     f64 = rng.choice([True, False])
-    kw = dict(num_agents=N, nGraphFilterTaps=K, nAttentionHeads=P, bottleneckFeature=G, bottleneckMode=skip, CNN_mode=cnn,
+    fov = rng.choice([9, 9, 9, 5, 7, 11, 13, 15]) if len(sys.argv) > 3 and sys.argv[3] == "fov" else 9
+    kw = dict(FOV=fov, num_agents=N, nGraphFilterTaps=K, nAttentionHeads=P, bottleneckFeature=G, bottleneckMode=skip, CNN_mode=cnn,
               attentionMode=att, AttentionConcat=concat)
-    print("try  B=%d N=%d G=%d K=%d P=%d %s %s %s concat=%s f64=%s" % (B, N, G, K, P, att, skip or "legacy", cnn, concat, f64), flush=True)
+    print("try  B=%d N=%d G=%d K=%d P=%d %s %s %s concat=%s f64=%s" % (B, N, G, K, P, att, skip or "legacy", cnn, concat, f64) + " fov=%d" % fov, flush=True)
     try:
         cfg = make_config(device="cuda:0", **kw)
         sd = orc.init_state_dict(cfg, seed=100 + it)
-        x = fov_states(B, N, seed=it)
+        x = fov_states(B, N, seed=it, fov=fov)
         S = comm_gso(B, N, 20 if N <= 20 else 50, seed=it + 1, dtype=torch.float64 if f64 else torch.float32)
         ref = orc.planner_forward(x, S.clone(), sd, cfg).numpy()
         net = DecentralPlannerGATNet(cfg)
