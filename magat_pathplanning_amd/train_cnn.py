@@ -121,6 +121,11 @@ class _BatchNormTrain(torch.autograd.Function):
                                                      nat.ptr(running_mean), nat.ptr(running_var), float(factor), float(eps),
                                                      int(relu), nat.ptr(mean), nat.ptr(invstd), nat.ptr(ws),
                                                      nat.current_stream(dev)), "magat_bn_train_forward_f32")
+        # the kernel updated the running statistics in place: tell torch (version counters are what the inference path's
+        # weights key - planner._weights_key - and autograd's in-place checks look at)
+        for buf in (running_mean, running_var):
+            if buf is not None:
+                torch.autograd.graph.increment_version(buf)
         ctx.save_for_backward(x, y, gamma, mean, invstd)
         ctx.relu = bool(relu)
         return y

@@ -262,3 +262,38 @@ def test_every_model_variant_trains_and_infers(gpu_device):
         net.addGSO(S.clone())
         tnf.cross_entropy(net(x), tgt).backward()
         assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None), cnn
+
+
+def test_inference_sees_what_training_changed(gpu_device):
+    """Between training steps the inference path must run on the module's CURRENT parameters and BatchNorm statistics - also when
+    only the buffers moved (a training-mode forward without an optimiser step: the HIP BatchNorm kernels update the running
+    statistics in place and bump their version counters, which planner._weights_key watches): inference logits against the
+    oracle evaluated on the state_dict of the moment."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N = 4, 10
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=2, bottleneckMode="BottomNeck_skipConcat", device="cuda:0")
+    torch.manual_seed(5)
+    net = DecentralPlannerGATNet(cfg).to(gpu_device)
+    x, S = fov_states(B, N, seed=1), comm_gso(B, N, 20, seed=2)
+    tgt = torch.randint(0, 5, (B * N,), generator=torch.Generator().manual_seed(3)).to(gpu_device)
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    for step in range(4):
+        net.eval()
+        with torch.no_grad():
+            net.addGSO(S.clone().to(gpu_device))
+            got = net(x.to(gpu_device)).cpu().numpy()
+        sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        ref = orc.planner_forward(x, S.clone(), sd, cfg).numpy()
+        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max())), step
+        net.train()
+        net.addGSO(S.clone().to(gpu_device))
+        if step == 1:           # buffers only
+            with torch.no_grad():
+                net(x.to(gpu_device))
+        else:
+            loss = tnf.cross_entropy(net(x.to(gpu_device)), tgt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
