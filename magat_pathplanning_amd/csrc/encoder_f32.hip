@@ -445,7 +445,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // the chain kernel stores 128-byte runs instead of 16-byte pieces.  (Not for the few-agent form of the head, which splits K
     // by pooled cell on the float32 kernel; option HEAD_GL=0: row-major tiles.)
     const int clast_ = shapes[nblocks - 1].cout;
-    const bool head_splitk = !absmax && !chained && mm <= magat_opt(MAGAT_OPT_HEAD_SPLITK) && (clast_ & 3) == 0 &&
+    const bool head_splitk = !absmax && !chained && M <= magat_opt(MAGAT_OPT_HEAD_SPLITK) && (clast_ & 3) == 0 &&
                              (d->n_feat & 3) == 0 && (size_t)9 * d->n_feat <= enc_buf_floats_per_agent(d);
     const bool head_gl = full_path && !rerun && split && d->head16_off > 0 && (clast_ % 32) == 0 && (d->n_feat % 32) == 0 &&
                          magat_opt(MAGAT_OPT_HEAD_F16) && magat_conv_direct_enabled() && !head_splitk &&
@@ -541,10 +541,12 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // Few agents (the closed-loop batch-1 step): one workgroup per 64 agents would walk all (hin/2)(win/2) clast of K alone
     // (83 us at 100 agents).  Split K by pooled cell instead: every cell is its own 1x1 "output pixel" with its slice of the
     // weight rows (wt_pix_stride / ldw), the partial products land in a free map buffer, a small kernel sums them in
-    // a fixed order and adds the bias.  Option HEAD_SPLITK = largest agent count that takes this form (0 = never).
+    // a fixed order and adds the bias.  Option HEAD_SPLITK = largest agent count that takes this form (0 = never) - the
+    // count of the whole call (M), not of the chunk: the short last chunk of a 70 100-agent batch must sum in the same
+    // order as its other chunks, or the batch would differ in the last bit from the same agents presented as shards.
     const int cells = (hin / 2) * (win / 2);
     const int split_max = magat_opt(MAGAT_OPT_HEAD_SPLITK);
-    if (!absmax && !chained && cells > 1 && mm <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
+    if (!absmax && !chained && cells > 1 && M <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
         (size_t)cells * d->n_feat <= enc_buf_floats_per_agent(d)) {     // the partials must fit one map buffer
       float* part = buf[(cur + 1) % 3];                 // [cells][mm][n_feat]
       g.out = part; g.bias = nullptr; g.ldc = d->n_feat;

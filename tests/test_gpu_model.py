@@ -231,6 +231,37 @@ def test_shard_equivalence_across_the_head_split(gpu_device, monkeypatch, libopt
     assert torch.equal(full1, full0) and torch.equal(parts1, parts0)
 
 
+def test_shard_equivalence_across_the_encoder_chunk(gpu_device, libopt):
+    """The encoder walks a batch in chunks of MAGAT_ENC_CHUNK agents (65 536).  The form of the head is chosen on the
+    agent count of the whole call, so the short last chunk sums like the others and a batch that spills into a second
+    chunk still equals its own shards bit for bit (found by tools/exp/big_ragged.py at 70 100 agents; here the chunk is
+    set to 8192 so that 9000 agents reproduce it in a second)."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N = 90, 100                                    # 9000 agents: chunks of 8192 + 808 (the latter below HEAD_SPLITK)
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat")
+    net = _build(cfg, orc.init_state_dict(cfg, seed=13), gpu_device)
+    x = fov_states(B, N, seed=5).to(gpu_device)
+    S = comm_gso(B, N, 50, seed=6).to(gpu_device)
+    cut = 60                                          # shards of 6000 and 3000 agents; the second is below HEAD_SPLITK, so
+    # the shards are compared with the head pinned to one form, and the chunk loop on its own (whole batch chunked against
+    # the whole batch in one pass) with the default options
+    with torch.no_grad():
+        net.addGSO(S)
+        whole = net(x).clone()
+        libopt.set("MAGAT_ENC_CHUNK", "8192")
+        chunked = net(x).clone()
+        assert torch.equal(chunked, whole)
+        libopt.set("MAGAT_HEAD_SPLITK", "0")
+        chunked0 = net(x).clone()
+        net.addGSO(S[:cut].contiguous())
+        a = net(x[:cut]).clone()
+        net.addGSO(S[cut:].contiguous())
+        b = net(x[cut:]).clone()
+    assert torch.equal(chunked0, whole)
+    assert torch.equal(torch.cat((a, b)), whole)
+
+
 def test_cpu_tensor_inference_fails_loudly(gpu_device):
     from magat_pathplanning_amd import DecentralPlannerGATNet, _native
     from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
