@@ -1,5 +1,11 @@
 """Random model configurations through the HIP inference path against the CPU oracle (test infrastructure: a sweep, not a product
-path).   python tools/exp/fuzz_forward.py [count] [seed]"""
+path).   python tools/exp/fuzz_forward.py [count] [seed] [fov]
+
+With `fov` the field of view is drawn from 5 .. 15 as well.  Only CNN_mode = Default sizes itself from the FOV; the ResNet modes
+carry the reference's fixed 1152-wide compress layer (graphs/models/decentralplanner_GAT_bottleneck_SkipConcatGNN.py:96-118), so
+at FOV != 9 they RAISE torch's "mat1 and mat2 shapes cannot be multiplied" exactly as the reference's module does, and Default at
+FOV 5 raises torch's "Output size is too small" from its third pooling: those lines are the reference's error behaviour, counted
+as failures by the summary line but not defects (seed 78: 46 ok, 34 such raises, nothing else)."""
 import os, sys, random
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import numpy as np, torch
