@@ -4,6 +4,7 @@ import ctypes
 import os
 import pickle
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -350,3 +351,12 @@ def test_gnn_model_class_surface_matches_the_reference_fixture():
             p_.requires_grad_(True)
         y = net(x)          # grad enabled -> the differentiable composite
         np.testing.assert_allclose(y.detach().numpy(), z["logits"], rtol=0, atol=5e-6 * max(1.0, float(np.abs(z["logits"]).max())))
+
+
+def test_graft_entry_build_passes():
+    """The driver's "does it build" check is __graft_entry__.build(): run it here too (incremental: the library the other host
+    tests load is already built), so that an ABI bump or a new source file cannot leave it behind the suite."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
