@@ -503,6 +503,10 @@ typedef struct magat_encoder_desc {
                          [tap 9][k step 2][plane 2] 1 KB blocks + [2^-e, 0, 0, 0]; ABI 4), 0 = absent.  With it (11 x 11 maps,
                          option L1_FUSED = 2) the stem and layer1.conv1 run as the eight-agent-group kernel of block_fused.hip
                          (every stem pixel computed once, operands read straight out of LDS) instead of layer1_fused.hip */
+  int form_agents;    /* ABI 6: the agent count the batch-size-dependent kernel FORMS are chosen on (the encoder head's split-K
+                         form below option HEAD_SPLITK), 0 = this call's M.  A shard of a larger batch passes the GLOBAL agent
+                         count here (distributed.sharded_forward does), so that every shard sums in the order the whole batch
+                         would: shards then concatenate to the single-process result bit for bit whatever their size */
 } magat_encoder_desc;
 /* Activation scales (ABI 3).  The split arithmetic carries a value as two f16 planes: exact for |v| <= 65504, but the SECOND
  * plane is a full 11-bit number only for |v| >~ 0.25 - a layer whose activations are all small (a small BatchNorm gamma: an

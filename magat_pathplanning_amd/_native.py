@@ -57,7 +57,7 @@ class EncoderDesc(ctypes.Structure):
                 ("n_feat", ctypes.c_int), ("n_comp", ctypes.c_int), ("pack", ctypes.c_void_p),
                 ("off", ctypes.c_int64 * 32), ("chain_off", ctypes.c_int64), ("chain3_off", ctypes.c_int64),
                 ("head16_off", ctypes.c_int64), ("comp16_off", ctypes.c_int64), ("scaled_off", ctypes.c_int64),
-                ("l1frag_off", ctypes.c_int64)]
+                ("l1frag_off", ctypes.c_int64), ("form_agents", ctypes.c_int)]
 
 
 class SimStepDesc(ctypes.Structure):

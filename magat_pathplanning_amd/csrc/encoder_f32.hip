@@ -445,7 +445,9 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // the chain kernel stores 128-byte runs instead of 16-byte pieces.  (Not for the few-agent form of the head, which splits K
     // by pooled cell on the float32 kernel; option HEAD_GL=0: row-major tiles.)
     const int clast_ = shapes[nblocks - 1].cout;
-    const bool head_splitk = !absmax && !chained && M <= magat_opt(MAGAT_OPT_HEAD_SPLITK) && (clast_ & 3) == 0 &&
+    // (the agent count the head's form is chosen on: the whole call's, or - a shard of a larger batch - the global one)
+    const int Mform = d->form_agents > 0 ? d->form_agents : M;
+    const bool head_splitk = !absmax && !chained && Mform <= magat_opt(MAGAT_OPT_HEAD_SPLITK) && (clast_ & 3) == 0 &&
                              (d->n_feat & 3) == 0 && (size_t)9 * d->n_feat <= enc_buf_floats_per_agent(d);
     const bool head_gl = full_path && !rerun && split && d->head16_off > 0 && (clast_ % 32) == 0 && (d->n_feat % 32) == 0 &&
                          magat_opt(MAGAT_OPT_HEAD_F16) && magat_conv_direct_enabled() && !head_splitk &&
@@ -546,7 +548,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // order as its other chunks, or the batch would differ in the last bit from the same agents presented as shards.
     const int cells = (hin / 2) * (win / 2);
     const int split_max = magat_opt(MAGAT_OPT_HEAD_SPLITK);
-    if (!absmax && !chained && cells > 1 && M <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
+    if (!absmax && !chained && cells > 1 && Mform <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
         (size_t)cells * d->n_feat <= enc_buf_floats_per_agent(d)) {     // the partials must fit one map buffer
       float* part = buf[(cur + 1) % 3];                 // [cells][mm][n_feat]
       g.out = part; g.bias = nullptr; g.ldc = d->n_feat;

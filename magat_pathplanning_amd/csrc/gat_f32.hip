@@ -1402,7 +1402,7 @@ extern "C" int magat_gso_prepare(void* S, int s_is_f64, size_t count, int scrub_
   return magat_check_launch();
 }
 
-extern "C" int magat_abi_version(void) { return 5; }
+extern "C" int magat_abi_version(void) { return 6; }
 
 extern "C" const char* magat_error_string(int code) {
   switch (code) {

@@ -25,7 +25,15 @@ def sharded_forward(model, x, S, group=None, gather=True):
     if b1 > b0:
         Sl = S[b0:b1].contiguous()
         model.addGSO(Sl)
-        local = model(x[b0:b1])
+        # the kernel forms that depend on the batch size (the encoder head's split-K form for few agents) are chosen on the
+        # GLOBAL agent count, not on the shard's: 64 instances of 100 agents over 8 ranks (800 agents each) sum in the order
+        # the 6400-agent batch does - the shards concatenate to the single-process result BIT FOR BIT with default options
+        prev = getattr(model, "form_agents", 0)
+        model.form_agents = B * N
+        try:
+            local = model(x[b0:b1])
+        finally:
+            model.form_agents = prev
     else:
         # fewer instances than ranks: this rank owns nothing, but it still has to enter the all_gather below (a rank that
         # raised on its empty batch would leave the others blocked in the collective)

@@ -155,6 +155,9 @@ class DecentralPlannerGATNet(nn.Module):
             self.actionsMLP = nn.Sequential(nn.Linear(width, numAction))
         self.apply(weights_init)
         self._rt = _Runtime()
+        # agent count the batch-size-dependent kernel forms are chosen on (0: each call's own); set around a shard's forward by
+        # distributed.sharded_forward (magat_encoder_desc.form_agents)
+        self.form_agents = 0
         # layer magnitudes the activation scales are folded from: {"digest", "absmax", "source"}.  Unlike _rt it IS pickled: a
         # spawned worker that unpickles the same weights folds the same exponents without measuring anything
         self._cal = None
@@ -514,6 +517,9 @@ class DecentralPlannerGATNet(nn.Module):
             # from the canonical calibration batch (or from an explicit / inherited calibration) - never from the batch
             # at hand, so the forward runs like every later one and like every other process with these weights
             self._ensure_calibrated(rt, dev)
+        # a shard of a larger batch chooses its batch-size-dependent kernel forms on the GLOBAL agent count (set by
+        # distributed.sharded_forward): the shards then concatenate to the single-process result bit for bit
+        rt.desc.form_agents = max(0, int(getattr(self, "form_agents", 0) or 0))
         nat.check(lib.magat_encoder_forward_f32(ctypes.byref(rt.desc), nat.ptr(x), nat.ptr(feat), nfm,
                                                 nat.ptr(comp), G, nat.ptr(rt.ws), rt.ws.numel(), M, stream),
                   "magat_encoder_forward_f32")
@@ -700,6 +706,7 @@ class DecentralPlannerNet(DecentralPlannerGATNet):
             self.actionsMLP = nn.Sequential(nn.Linear(nif, numAction))
         self.apply(weights_init)
         self._rt = _Runtime()
+        self.form_agents = 0
         self._cal = None
 
     def addGSO(self, S):

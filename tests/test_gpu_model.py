@@ -231,6 +231,47 @@ def test_shard_equivalence_across_the_head_split(gpu_device, monkeypatch, libopt
     assert torch.equal(full1, full0) and torch.equal(parts1, parts0)
 
 
+def test_shards_choose_their_forms_on_the_global_agent_count(gpu_device, tag_counts):
+    """64 instances of 100 agents cut into 8 shards of 800 agents - every shard far below
+    HEAD_SPLITK (5120), the whole batch (6400) above it.  distributed.sharded_forward hands the GLOBAL agent count to the
+    encoder (magat_encoder_desc.form_agents, ABI 6), so each shard's head runs the form the whole batch runs and the
+    shards concatenate to the single-process logits BIT FOR BIT with default options; without the hint the same shards
+    differ in the last bits (which is what makes the assertion meaningful).  Here the eight ranks are walked by one
+    process through sharded_forward's own code path (its rank / world come from a stand-in process group)."""
+    from unittest import mock
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd import distributed as D
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N, world = 64, 100, 8
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat")
+    sd = orc.init_state_dict(cfg, seed=21)
+    net = _build(cfg, sd, gpu_device)
+    x = fov_states(B, N, seed=7).to(gpu_device)
+    S = comm_gso(B, N, 50, seed=8).to(gpu_device)
+    with torch.no_grad():
+        net.addGSO(S.clone())
+        whole = net(x).clone()
+        parts, plain = [], []
+        for rank in range(world):
+            with mock.patch.object(D.dist, "is_initialized", return_value=True), \
+                    mock.patch.object(D.dist, "get_world_size", return_value=world), \
+                    mock.patch.object(D.dist, "get_rank", return_value=rank):
+                parts.append(D.sharded_forward(net, x, S.clone(), gather=False).clone())
+            b0, b1 = D.shard_range(B, rank, world)
+            net.addGSO(S[b0:b1].contiguous())
+            plain.append(net(x[b0:b1]).clone())        # the same shard WITHOUT the hint: the few-agent form of the head
+        assert net.form_agents == 0                    # (restored behind every shard)
+    got = torch.cat(parts)
+    assert got.shape == whole.shape and torch.equal(got, whole)
+    unhinted = torch.cat(plain)
+    assert not torch.equal(unhinted, whole) and (unhinted - whole).abs().max().item() <= 1e-5
+    # and against the oracle on a sample of instances (the logits themselves, not only their agreement)
+    pick = [0, 9, 33, 63]
+    ref = orc.planner_forward(x[pick].cpu(), S[pick].cpu().clone(), sd, cfg)
+    rows = torch.cat([whole[b * N:(b + 1) * N] for b in pick]).cpu()
+    assert float((rows - ref).abs().max()) <= 1e-4
+
+
 def test_shard_equivalence_across_the_encoder_chunk(gpu_device, libopt):
     """The encoder walks a batch in chunks of MAGAT_ENC_CHUNK agents (65 536).  The form of the head is chosen on the
     agent count of the whole call, so the short last chunk sums like the others and a batch that spills into a second
