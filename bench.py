@@ -210,13 +210,15 @@ def sustained_mfma_tflops(lib, dev):
     import torch
     from magat_pathplanning_amd import _native as nat
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    scratch = torch.empty(256 * cus, dtype=torch.float32, device=dev)
-    best = 0.0
+    scratch = torch.empty(256 * cus + 4 * cus, dtype=torch.float32, device=dev)      # results + the kernel's own clock stamps
+    best = (0.0, 0.0, 0.0)
     for _ in range(3):
-        v = ctypes.c_double(0.0)
-        nat.check(lib.magat_mfma_sustained_f16(ctypes.byref(v), nat.ptr(scratch), 5, nat.current_stream(dev)), "magat_mfma_sustained_f16")
-        best = max(best, v.value)
-    return best
+        v, mhz, per = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        nat.check(lib.magat_mfma_sustained_f16_ex(ctypes.byref(v), ctypes.byref(mhz), ctypes.byref(per), nat.ptr(scratch), 5,
+                                                  nat.current_stream(dev)), "magat_mfma_sustained_f16_ex")
+        best = max(best, (v.value, mhz.value, per.value))
+    sustained_mfma_tflops.clock_mhz, sustained_mfma_tflops.per_clk = best[1], best[2]
+    return best[0]
 
 
 def train_step_leg(dev, steps=10):
@@ -228,14 +230,14 @@ def train_step_leg(dev, steps=10):
                    "BottomNeck_skipConcat; ms per step", "steps": steps}
     prev = os.environ.get("MAGAT_TRAIN_CNN")
     try:
-        for Bt, Nt in ((64, 100), (64, 10)):
+        for Bt, Nt in ((64, 100), (64, 32), (64, 10)):
             cfgt = make_config(num_agents=Nt, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat",
                                device=str(dev))
             xt = fov_states(Bt, Nt, seed=21).to(dev)
             St = comm_gso(Bt, Nt, 20 if Nt <= 20 else 50, seed=22).to(dev)
             tgt = torch.randint(0, 5, (Bt * Nt,), generator=torch.Generator().manual_seed(23)).to(dev)
             row = {}
-            for backend in ("hip", "torch"):
+            for backend in ("hip", "torch", "auto"):
                 os.environ["MAGAT_TRAIN_CNN"] = backend
                 torch.manual_seed(24)
                 net = DecentralPlannerGATNet(cfgt).to(dev).train()
@@ -250,7 +252,8 @@ def train_step_leg(dev, steps=10):
                     loss.backward()
                     opt.step()
                 torch.cuda.synchronize(dev)
-                row["cnn_on_%s_ms" % ("hip_kernels" if backend == "hip" else "torch_miopen")] = round(
+                # (`auto` is the module's default: torch's convolutions below train_cnn.TRAIN_HIP_MIN_AGENTS agents, the HIP ones above)
+                row[{"hip": "cnn_on_hip_kernels_ms", "torch": "cnn_on_torch_miopen_ms", "auto": "default_auto_ms"}[backend]] = round(
                     (time.perf_counter() - t0) / steps * 1e3, 3)
                 del net, opt
             out["%dx%d_agents" % (Bt, Nt)] = row
@@ -384,6 +387,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip north_star_b1024 and mx_opt_in")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="REHEARSAL of the N > 1 launch on a box with fewer GPUs than ranks: every rank drives cuda:0, the "
+                         "collectives (sum of ones, barrier, gather of the elapsed times) go over gloo.  Exercises bench.py's own "
+                         "rank logic (ranks_seen, per_rank_ms, MAX over ranks); its value is NOT a scaling measurement and the "
+                         "line says so (config.rehearsal)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -396,6 +404,8 @@ def main():
 
     import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -405,8 +415,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)          # "nccl" IS RCCL on ROCm
-        ones = torch.ones(1, device=dev)
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)          # "nccl" IS RCCL on ROCm
+        ones = torch.ones(1, device="cpu" if args.share_gpu else dev)
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
 
@@ -482,7 +495,7 @@ def main():
         assert out.shape == (x.shape[0] * x.shape[1], 5) and bool(torch.isfinite(out).all())
         per_rank = [elapsed * 1e3]
         if dist is not None:
-            mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            mine = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else dev)
             every = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(every, mine)
             per_rank = [float(t.item()) * 1e3 for t in every]
@@ -590,6 +603,9 @@ def main():
                           "options": {k: lib_opt(nat, k) for k in ("CONV_MX", "CONV_SPLIT", "CONV_F16", "RANGE_GUARD",
                                                                     "BLOCK_FUSED", "BLOCK3_FUSED", "BLOCK_FULL", "HEAD_F16", "GAT_MFMA")},
                           "global_batch": B * world, "agents": N, "parallelism": "instance-sharded x%d" % world}}
+        if args.share_gpu:
+            res["config"]["rehearsal"] = ("--share-gpu: %d ranks drive ONE device over gloo - the launch / rank logic of the "
+                                          "N > 1 run, not a scaling measurement" % world)
         if timing:
             pmc = load_pmc_traffic() if args.workload == "c3" and not args.batch else {}
             table = kernel_table(kern, args.steps, B, N, S, pmc)
@@ -610,6 +626,11 @@ def main():
                     r_ = res.get(rk)
                     if r_ and r_.get("bound") == "mfma" and "issued_tflops" in r_:
                         r_["sustained_f16_mfma_tflops_measured"] = round(sus, 1)
+                        # the measurement's own evidence: the core clock the chip held inside that launch (read by the kernel)
+                        # and the flop per clock and SIMD it amounts to - 1024 = a matrix pipe that never idles
+                        r_["sustained_clock_mhz"] = round(sustained_mfma_tflops.clock_mhz, 1)
+                        r_["sustained_flop_per_clk_per_simd"] = round(sustained_mfma_tflops.per_clk, 1)
+                        r_["sustained_frac_of_issue_limit"] = round(sustained_mfma_tflops.per_clk / 1024.0, 4)
                         r_["issued_frac_of_sustained"] = round(r_["issued_tflops"] / sus, 4)
                         r_["frac_of_sustained"] = round(r_["achieved"] / sus, 4)
                         r_["sustained_note"] = ("magat_mfma_sustained_f16: v_mfma_f32_32x32x16_f16 from registers only, one wave "

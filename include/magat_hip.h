@@ -67,7 +67,8 @@ const char* magat_error_string(int code);
  * Returns MAGAT_ERR_UNSUPPORTED for an unknown name. */
 int magat_set_option(const char* name, int value);
 int magat_get_option(const char* name, int* value);
-int magat_reset_option(const char* name);   /* back to the built-in default (not the environment's value) */
+int magat_reset_option(const char* name);   /* back to the value the process started with: MAGAT_<NAME> from the environment if it
+                                                was set, else the built-in default (ABI 6; was: always the built-in default) */
 
 /* ------------------------------------------------------------------------------------------
  * GAT layer: GraphFilterBatchAttentional.forward  (utils/graphUtils/graphML.py:4636-4671)
@@ -585,6 +586,24 @@ int magat_profile_reset(void);
  * of the figure (MI355X: 1.5-1.6 PFLOP/s against the 2.5 PFLOP/s of the 2.4 GHz peak clock).  scratch: 256 * CUs floats.
  * Synchronises the stream.  (ABI 5; bench.py's `roofline.sustained_*` keys) */
 int magat_mfma_sustained_f16(double* tflops, float* scratch, int ms_target, void* stream);
+/* (ABI 6) the same launch with its own clock evidence: *clock_mhz = the core clock the chip held inside it (median over the CUs
+ * of core-clock cycles / 100 MHz ticks, read by the kernel itself), *per_clk = flop per clock and SIMD the rate amounts to at
+ * that clock (1024 = one v_mfma_f32_32x32x16_f16 issued every 32 cycles: a matrix pipe that never idles), so that
+ * sustained = clock x per_clk x SIMDs.  Either may be NULL.  scratch: 256 * CUs floats + 2 * CUs int64 behind them. */
+int magat_mfma_sustained_f16_ex(double* tflops, double* clock_mhz, double* per_clk, float* scratch, int ms_target, void* stream);
+/* Which FORM of a kernel the launches took since magat_form_reset (host-side counters, bumped where a launcher decides): the
+ * forms that exist only at benchmark sizes are asserted by the full-size parity tests (tests/test_gpu_fullsize.py). */
+#define MAGAT_FORM_HEAD_LONGK 0   /* encoder head as ONE long-K f16x3 GEMM (agents above option HEAD_SPLITK) */
+#define MAGAT_FORM_HEAD_SPLITK 1  /* encoder head as per-cell partial products + sum (few agents) */
+#define MAGAT_FORM_GAT_PACK 2     /* one-launch graph kernel, four instances per pass (N <= 32, batch fills the chip) */
+#define MAGAT_FORM_GAT_PERSIST 3  /* one-launch graph kernel, more planning instances than workgroups (persistent walk) */
+#define MAGAT_FORM_GAT_HSPLIT 4   /* one-launch graph kernel, a workgroup per (instance, head) (small batches) */
+#define MAGAT_FORM_CHAIN_PERSIST 5 /* chain kernel: more 8-agent groups than workgroups (persistent group loop) */
+#define MAGAT_FORM_HEAD_COMPRESS 6 /* compressMLP computed in the head GEMM's epilogue (one launch for both) */
+#define MAGAT_FORM_GUARD_ONE 7    /* range guard of the encoder as one predicated launch */
+#define MAGAT_FORMS 8
+long long magat_form_count(int id);
+int magat_form_reset(void);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,9 @@ TAGS = {0: "untagged", 1: "conv_first", 2: "layer1.conv1", 3: "layer1.conv2+ds",
         9: "compressMLP", 10: "gat_maps_gemm", 11: "gat_graph", 12: "actionsMLP", 13: "head_mean",
         14: "gat_pack", 15: "gso_prepare", 16: "gat_prepare", 17: "range_guard", 18: "layer1.conv2+layer2 (fused)", 19: "gat_layer (one launch)", 20: "gso_to_csr", 21: "gat_cast", 22: "layer3 (fused, pooled)", 23: "layer1.conv2+layer2+layer3 (fused, pooled)"}
 TAG_ACTIONS = 12
+# magat_form_count ids (include/magat_hip.h MAGAT_FORM_*)
+FORMS = {"head_longk": 0, "head_splitk": 1, "gat_pack": 2, "gat_persist": 3, "gat_hsplit": 4, "chain_persist": 5,
+         "head_compress": 6, "guard_one": 7}
 
 _lock = threading.Lock()
 _lib = None
@@ -129,6 +132,9 @@ _SIGNATURES = {
     "magat_profile_read": (_I, [_I, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),
     "magat_profile_reset": (_I, []),
     "magat_mfma_sustained_f16": (_I, [ctypes.POINTER(ctypes.c_double), _P, _I, _P]),
+    "magat_mfma_sustained_f16_ex": (_I, [ctypes.POINTER(ctypes.c_double)] * 3 + [_P, _I, _P]),
+    "magat_form_count": (ctypes.c_longlong, [_I]),
+    "magat_form_reset": (_I, []),
     "magat_conv_first_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "magat_conv_first_tiled_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "magat_encoder_workspace_bytes": (_Z, [ctypes.POINTER(EncoderDesc), _I]),

@@ -1632,6 +1632,7 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
   const int grid = p.groups < cus ? p.groups : cus;
+  if (p.groups > cus) magat_form_note(MAGAT_FORM_CHAIN_PERSIST);
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_FULL, st);
   if (twopass) hipLaunchKernelGGL(block_full_c_kernel<2>, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
   else if (rows) hipLaunchKernelGGL(block_full_c_kernel<1>, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);

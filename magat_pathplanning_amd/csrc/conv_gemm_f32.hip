@@ -80,8 +80,10 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, const in
   const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
   const int ty0 = iy0 < 0 ? -iy0 : 0, tx0 = ix0 < 0 ? -ix0 : 0;
   const int ty1 = min(p.kH, p.Hin - iy0), tx1 = min(p.kW, p.Win - ix0);
-  const int ntx = tx1 - tx0;
-  const int ntaps = (ty1 - ty0) * ntx;
+  // (window lengths clamped at 0: with stride >= 3 both can be negative for a pixel whose window lies past the map - the input
+  //  gradient over a zero-stuffed map - and their product would be a positive tap count that reads past the map)
+  const int ntx = max(tx1 - tx0, 0);
+  const int ntaps = max(ty1 - ty0, 0) * ntx;
   const int spt = (p.Cin + BK - 1) / BK;
   const int spt2 = (p.C2 + BK - 1) / BK;
   const int nslab = ntaps * spt + spt2;

@@ -217,12 +217,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(const BnParams p)
     mu = *reinterpret_cast<const f32x4*>(p.mean + 4 * q);
     is = *reinterpret_cast<const f32x4*>(p.invstd + 4 * q);
   }
+  // MODE 0: shifted sums.  var = E[x^2] - mean^2 in float32 partials loses ~1e-7 mean^2 / var of relative accuracy when
+  // |mean| >> std (a conv bias in front of the BatchNorm, drifting activations); with a per-channel pivot taken from the data
+  // itself (row 0: within a few std of the mean) the sums are of (x - pivot) and nothing cancels.  torch uses Welford.
+  if (MODE == 0 && rl < lanes) mu = *reinterpret_cast<const f32x4*>(p.x + 4 * q);
   if (rl < lanes)
     for (long long r = r0 + rl; r < r1; r += lanes) {
       const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + r * p.C + 4 * q);
       if (MODE == 0) {
-        sa += xv;
-        sb += xv * xv;
+        const f32x4 d0 = xv - mu;
+        sa += d0;
+        sb += d0 * d0;
       } else {
         f32x4 d = *reinterpret_cast<const f32x4*>(p.dy + r * p.C + 4 * q);
         if (p.relu) {
@@ -281,8 +286,9 @@ __global__ __launch_bounds__(64) void bn_finalize_fwd_kernel(const BnParams p) {
   double s, s2;
   if (!bn_fold(p, ch, s, s2)) return;
   const double n = (double)p.rows;
-  const double m = s / n;
-  double var = s2 / n - m * m;
+  const double ms = s / n;                    // mean of (x - pivot), pivot = row 0 of the channel (bn_reduce_kernel)
+  const double m = (double)p.x[ch] + ms;
+  double var = s2 / n - ms * ms;
   if (var < 0.0) var = 0.0;
   p.mean[ch] = (float)m;
   p.invstd[ch] = (float)(1.0 / sqrt(var + (double)p.eps));

@@ -551,6 +551,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     if (!absmax && !chained && cells > 1 && Mform <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
         (size_t)cells * d->n_feat <= enc_buf_floats_per_agent(d)) {     // the partials must fit one map buffer
       float* part = buf[(cur + 1) % 3];                 // [cells][mm][n_feat]
+      if (!rerun) magat_form_note(MAGAT_FORM_HEAD_SPLITK);
       g.out = part; g.bias = nullptr; g.ldc = d->n_feat;
       g.out_pix_stride = (long long)mm * d->n_feat;
       g.kH = g.kW = 1; g.Hout = hin / 2; g.Wout = win / 2;
@@ -573,6 +574,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
         g.in_fmt = 4; g.wt = pk + d->head16_off; g.range_flag = range_flag; g.run_if = nullptr;
         if (d->scaled_off > 0) g.in_scale = pk + d->scaled_off + 1349;
         if (head_gl) g.in_gl = 1;
+        magat_form_note(MAGAT_FORM_HEAD_LONGK);
       }
       rc = g.in_fmt == 0 ? run_or_chain(g) : magat_conv_gemm_f32(&g, stream);
     }

@@ -830,6 +830,7 @@ int launch_pack(const GatMfmaParams& p, int slot, hipStream_t st) {
   q.B = (p.B + 3) / 4;
   q.hsplit = 1;
   const int blocks = q.B < cus ? q.B : cus;
+  magat_form_note(MAGAT_FORM_GAT_PACK);
   const int pid = magat_prof_begin(MAGAT_TAG_GAT_LAYER, st);
   if (p.concat) hipLaunchKernelGGL((gat_mfma_kernel<4, 2, KT, true, MODE, true>), dim3(blocks), dim3(256), kGatPackLds, st, q);
   else hipLaunchKernelGGL((gat_mfma_kernel<4, 2, KT, false, MODE, true>), dim3(blocks), dim3(256), kGatPackLds, st, q);
@@ -857,6 +858,8 @@ int launch(const GatMfmaParams& p, int slot, hipStream_t st) {
   q.hsplit = (p.concat && p.P > 1 && split < unsplit) ? p.P : 1;
   const long long units = q.hsplit > 1 ? (long long)p.B * p.P : p.B;
   const int blocks = (int)(units < (long long)cus * q.hsplit ? units : (long long)cus * q.hsplit);
+  if (q.hsplit > 1) magat_form_note(MAGAT_FORM_GAT_HSPLIT);
+  if (units > blocks) magat_form_note(MAGAT_FORM_GAT_PERSIST);
   const int pid = magat_prof_begin(MAGAT_TAG_GAT_LAYER, st);
   if (p.concat) hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, true, MODE>), dim3(blocks), dim3(256), lds, st, q);
   else hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, false, MODE>), dim3(blocks), dim3(256), lds, st, q);

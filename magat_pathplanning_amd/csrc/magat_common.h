@@ -34,6 +34,7 @@ __host__ __device__ __forceinline__ long long magat_row_off(long long m, long lo
 // per-kernel timing hooks (profile.hip); tags are listed in include/magat_hip.h
 int magat_prof_begin(int tag, hipStream_t st);
 void magat_prof_end(int id, hipStream_t st);
+void magat_form_note(int id);      // which form a launch took (MAGAT_FORM_*; profile.hip)
 
 // bf16x6 split-MFMA GEMM (conv_gemm_bf16x6.hip), reached through magat_conv_gemm_f32 when desc->in_fmt == 1
 int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st);

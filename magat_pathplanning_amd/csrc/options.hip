@@ -61,6 +61,7 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
 };
 
 int g_val[MAGAT_OPT_COUNT];
+int g_start[MAGAT_OPT_COUNT];      // the value the process STARTED with: the compile-time default, or the environment's
 std::once_flag g_once;
 
 void init_opts() {
@@ -70,6 +71,7 @@ void init_opts() {
     strncat(key, kOpts[i].name, sizeof(key) - 7);
     const char* e = getenv(key);
     if (e && *e) g_val[i] = atoi(e);
+    g_start[i] = g_val[i];
   }
 }
 
@@ -114,7 +116,8 @@ extern "C" int magat_reset_option(const char* name) {
   if (!strncmp(name, "MAGAT_", 6)) name += 6;
   for (int i = 0; i < MAGAT_OPT_COUNT; ++i)
     if (!strcmp(name, kOpts[i].name)) {
-      g_val[i] = kOpts[i].def;
+      g_val[i] = g_start[i];      // (the environment's value when MAGAT_<NAME> was set at start-up, not the compile-time default:
+                                  //  a deployment's setting survives a test or tool that flips the option and resets it)
       return MAGAT_OK;
     }
   return MAGAT_ERR_UNSUPPORTED;

@@ -1,6 +1,7 @@
 // Optional per-kernel timing hooks (bench.py's roofline leg): when enabled, every kernel launch made by
 // the library is bracketed by hipEvents recorded on the launch stream; magat_profile_collect() (after the
 // caller has synchronised) folds them into per-tag totals.  Disabled by default: zero cost on the hot path.
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -103,7 +104,9 @@ extern "C" int magat_profile_reset(void) {
 namespace {
 typedef _Float16 mp_f16x8 __attribute__((ext_vector_type(8)));
 typedef float mp_f32x16 __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(256) void mfma_sustained_kernel(float* out, int iters) {
+__global__ __launch_bounds__(256) void mfma_sustained_kernel(float* out, int iters, long long* stamps) {
+  // core-clock counter next to the constant 100 MHz counter, first and last instruction of the wave: the clock the chip HELD
+  const long long c0 = (long long)__builtin_readcyclecounter(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
   mp_f32x16 acc[4];
   for (int j = 0; j < 4; ++j)
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
@@ -128,12 +131,27 @@ __global__ __launch_bounds__(256) void mfma_sustained_kernel(float* out, int ite
   for (int j = 0; j < 4; ++j)
     for (int r = 0; r < 16; ++r) s += acc[j][r];
   out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (stamps && threadIdx.x == 0) {
+    stamps[2 * blockIdx.x] = (long long)__builtin_readcyclecounter() - c0;
+    stamps[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime() - r0;
+  }
 }
 }  // namespace
 
 // *tflops = the f16 dense matrix-core rate of one ~ms_target ms launch of the loop above on the current device (one wave per
 // SIMD on every CU; synchronises the stream).  scratch: 256 * CUs floats.
+// (ABI 6) the same measurement with its own evidence: *clock_mhz = the core clock the chip held inside that launch (median over
+// the CUs of core-clock cycles / 100 MHz ticks, both read by the kernel itself), *per_clk = flop per clock and SIMD the rate
+// amounts to at that clock - 1024 is one v_mfma_f32_32x32x16_f16 (32768 flop) issued every 32 cycles, i.e. a matrix pipe that
+// never idles: sustained = clock x per_clk x SIMDs, so "x of the sustained rate" is a statement about ISSUE, the gap to the
+// nominal 2.5 PFLOP/s a statement about the clock.  scratch: 256 * CUs floats + 2 * CUs int64 behind them.
+extern "C" int magat_mfma_sustained_f16_ex(double* tflops, double* clock_mhz, double* per_clk, float* scratch, int ms_target,
+                                           void* stream);
 extern "C" int magat_mfma_sustained_f16(double* tflops, float* scratch, int ms_target, void* stream) {
+  return magat_mfma_sustained_f16_ex(tflops, nullptr, nullptr, scratch, ms_target, stream);
+}
+extern "C" int magat_mfma_sustained_f16_ex(double* tflops, double* clock_mhz, double* per_clk, float* scratch, int ms_target,
+                                           void* stream) {
   if (!tflops || !scratch) return MAGAT_ERR_NULL;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -146,7 +164,9 @@ extern "C" int magat_mfma_sustained_f16(double* tflops, float* scratch, int ms_t
   // 32 MFMAs of 32 cycles per iteration and SIMD: ~1700 iterations per ms at 1.75 GHz
   const int iters = (ms_target > 0 ? ms_target : 5) * 1700;
   hipEventRecord(e0, st);
-  hipLaunchKernelGGL(mfma_sustained_kernel, dim3((unsigned)cus), dim3(256), 0, st, scratch, iters);
+  // (the plain entry point's scratch holds the float results only: no stamps there)
+  long long* stamps = (clock_mhz || per_clk) ? reinterpret_cast<long long*>(scratch + (size_t)256 * cus) : nullptr;
+  hipLaunchKernelGGL(mfma_sustained_kernel, dim3((unsigned)cus), dim3(256), 0, st, scratch, iters, stamps);
   hipEventRecord(e1, st);
   int rc = magat_check_launch();
   float ms = 0.f;
@@ -156,5 +176,38 @@ extern "C" int magat_mfma_sustained_f16(double* tflops, float* scratch, int ms_t
   hipEventDestroy(e1);
   if (rc != MAGAT_OK) return rc;
   *tflops = (double)cus * 4 * iters * 32 * 32768.0 / ((double)ms * 1e9);
+  if (stamps) {
+    std::vector<long long> h(2 * (size_t)cus);
+    if (hipMemcpy(h.data(), stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return MAGAT_ERR_LAUNCH;
+    std::vector<double> mhz;
+    for (int i = 0; i < cus; ++i)
+      if (h[2 * i + 1] > 0) mhz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 100.0);
+    if (mhz.empty()) return MAGAT_ERR_LAUNCH;
+    std::sort(mhz.begin(), mhz.end());
+    const double med = mhz[mhz.size() / 2];
+    if (clock_mhz) *clock_mhz = med;
+    if (per_clk) *per_clk = *tflops * 1e12 / (med * 1e6 * (double)cus * 4);
+  }
+  return MAGAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Which FORM of a kernel a launch took (host-side counters, bumped where the launcher decides; tests assert on them next to the
+// per-tag launch counts: the forms below exist only at benchmark sizes and must not be swapped silently).
+namespace { long long g_forms[MAGAT_FORMS]; }
+void magat_form_note(int id) {
+  if (id >= 0 && id < MAGAT_FORMS) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_forms[id] += 1;
+  }
+}
+extern "C" long long magat_form_count(int id) {
+  if (id < 0 || id >= MAGAT_FORMS) return -1;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_forms[id];
+}
+extern "C" int magat_form_reset(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < MAGAT_FORMS; ++i) g_forms[i] = 0;
   return MAGAT_OK;
 }

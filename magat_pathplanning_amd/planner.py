@@ -236,6 +236,17 @@ class DecentralPlannerGATNet(nn.Module):
                 nat.check(lib.magat_gat_read_status(nat.ptr(ws), st, nat.current_stream(ws.device)),
                           "magat_gat_read_status")
             out["gat_rerun"], out["gat_reruns"] = bool(st[0]), int(st[1])
+        sc = out["act_scales"]
+        if out["encoder_reruns"] >= 3 and sc and sc.get("source") == "canonical":
+            # the canonical calibration batch does not fit this deployment's inputs (non-binary channels, another FOV encoding):
+            # every forward then pays the float32 re-run - correct, but slow.  Say so once; calibrate(x) on real inputs fixes it
+            out["hint"] = ("the float32 re-run fired %d times with activation scales from the canonical calibration batch: "
+                           "call model.calibrate(x) on representative inputs (and again after load_state_dict / training)"
+                           % out["encoder_reruns"])
+            if not getattr(self, "_warned_reruns", False):
+                import warnings
+                warnings.warn("magat_pathplanning_amd: " + out["hint"])
+                self._warned_reruns = True
         return out
 
     def forward(self, inputTensor):
@@ -785,8 +796,17 @@ class DecentralPlannerNet(DecentralPlannerGATNet):
             feat, comp = self._run_encoder(rt, x, M, dev, stream)
             layer = self.GFL[0]
             layer.addGSO(self.S)
-            # GraphFilterBatch on the CSR kernels: rows in, rows out ((B, F, N) is a view of the (M, F) result)
-            y = layer._forward_hip(comp.view(B, N, self.numFeatures2Share).permute(0, 2, 1))[0]
+            if self.S.shape[0] != B or self.S.shape[-1] < N:
+                raise RuntimeError("DecentralPlannerNet: GSO of shape %s does not match a batch of %d instances x %d agents"
+                                   % (tuple(self.S.shape), B, N))
+            xg = comp.view(B, N, self.numFeatures2Share).permute(0, 2, 1)
+            if self.S.shape[-1] == N:
+                # GraphFilterBatch on the CSR kernels: rows in, rows out ((B, F, N) is a view of the (M, F) result)
+                y = layer._forward_hip(xg)[0]
+            else:
+                # more GSO nodes than agents: the layer's own forward zero-pads the signal to the GSO's size and trims its
+                # output (graphML.py:5670-5689) - the CSR structure is built for the GSO's N, so the rows must match it
+                y = layer(xg)
             rows = y.permute(0, 2, 1).reshape(M, self.gat_width)
             if not self.no_relu:
                 rows = torch.relu_(rows)

@@ -260,20 +260,41 @@ def _is_conv_stack(seq):
     return len(mods) > 0 and isinstance(mods[0], nn.Conv2d) and all(
         isinstance(m, (nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.MaxPool2d, nn.AvgPool2d, nn.Dropout)) for m in mods) and all(
         m.out_channels % 32 == 0 and m.groups == 1 and m.dilation == (1, 1) and m.stride[0] == m.stride[1] and
-        m.padding[0] == m.padding[1] for m in mods if isinstance(m, nn.Conv2d))
+        m.stride[0] <= 2 and m.padding_mode == "zeros" and not isinstance(m.padding, str) and
+        m.padding[0] == m.padding[1] for m in mods if isinstance(m, nn.Conv2d)) and all(
+        not m.ceil_mode for m in mods if isinstance(m, (nn.MaxPool2d, nn.AvgPool2d)))
+
+
+# Agents (rows of the convolution GEMMs) from which the HIP convolution / BatchNorm kernels beat torch's (MIOpen) in a training
+# step.  Measured (bench.py `train_step`, profiles/r04j): 640 agents (the reference's own training batch, scripts/
+# train_DMap.sh:30-46: 64 x 10) 3.83 ms on the HIP kernels against 3.14 ms on torch's - a step there is ~300 launches of a few
+# microseconds each and torch's fused BatchNorm wins; 6400 agents 9.1 against 13.5 ms.  MAGAT_TRAIN_CNN = hip | torch forces
+# one side; the default `auto` takes torch's convolutions below the crossover, so that dropping the module into the reference's
+# training loop never makes a step slower.
+TRAIN_HIP_MIN_AGENTS = 2048
+
+
+def _use_hip_convs(x):
+    import os
+    mode = os.environ.get("MAGAT_TRAIN_CNN", "auto")
+    if not x.is_cuda or mode == "torch":
+        return False
+    return mode == "hip" or x.shape[0] >= TRAIN_HIP_MIN_AGENTS
 
 
 def convlayers_forward(conv_layers, x):
-    """planner.ConvLayers(x) under autograd: the ResNet trunk on the HIP kernels when the input is on the GPU (environment
-    MAGAT_TRAIN_CNN=torch keeps torch's own convolutions), the layers behind it (Dropout, Flatten, Linear) as they are."""
-    import os
+    """planner.ConvLayers(x) under autograd: the ResNet trunk on the HIP kernels when the input is on the GPU and the batch is
+    large enough for them to win (see TRAIN_HIP_MIN_AGENTS; environment MAGAT_TRAIN_CNN = hip | torch | auto), the layers
+    behind it (Dropout, Flatten, Linear) as they are."""
     from .resnet import _ResNetBase
     body = conv_layers[0] if len(conv_layers) > 0 else None
-    if x.is_cuda and isinstance(body, _ResNetBase) and os.environ.get("MAGAT_TRAIN_CNN", "hip") != "torch":
+    if not _use_hip_convs(x):
+        return conv_layers(x)
+    if isinstance(body, _ResNetBase):
         y = resnet_forward(body, x)
         for m in list(conv_layers)[1:]:
             y = m(y)
         return y
-    if x.is_cuda and os.environ.get("MAGAT_TRAIN_CNN", "hip") != "torch" and _is_conv_stack(conv_layers):
+    if _is_conv_stack(conv_layers):
         return conv_stack_forward(conv_layers, x)
     return conv_layers(x)

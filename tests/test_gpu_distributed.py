@@ -129,3 +129,30 @@ def test_bench_runs_as_the_driver_launches_it(gpu_device):
     assert r.returncode == 0, r.stderr[-2000:]
     d = _one_json_line(r.stdout)
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["value"] > 0
+
+
+def test_bench_eight_ranks_rehearsed_on_one_gpu(gpu_device):
+    """the driver's N = 8 command line - torch.distributed.run with eight ranks of bench.py - run for
+    real on a one-GPU box (`--share-gpu`: every rank drives cuda:0, gloo carries the collectives).  What is exercised is
+    bench.py's OWN rank logic: RANK / LOCAL_RANK / WORLD_SIZE from the environment, the sum of ones (ranks_seen == 8), the
+    barriers either side of the timed region, the gather of every rank's elapsed time (per_rank_ms has eight entries and the
+    reported ms_per_step is their MAX), whole-job `value` = 8 x batch x N x steps / that time, one JSON line from rank 0
+    only.  The first real 8-GPU run is then not the first run of this code; its numbers are not a scaling measurement."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    steps, batch = 3, 16
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", str(steps), "--warmup", "1",
+                        "--batch", str(batch), "--no-cpu-baseline", "--no-kernel-timing", "--share-gpu"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["scaling"] == "weak"
+    assert len(d["per_rank_ms"]) == 8 and len(d["ranks"]) == 8
+    assert sorted(x["rank"] for x in d["ranks"]) == list(range(8))
+    assert abs(d["ms_per_step"] - max(d["per_rank_ms"])) <= 1e-3
+    assert d["config"]["global_batch"] == 8 * batch and "rehearsal" in d["config"]
+    want = 8 * batch * 100 / (d["ms_per_step"] * 1e-3)
+    assert abs(d["value"] - want) <= 1e-3 * want

@@ -173,6 +173,27 @@ def test_default_cnn_training_step_matches_torch(gpu_device):
             assert _rel(v.cpu().double(), br[k]) < 1e-5, k
 
 
+def test_batchnorm_training_statistics_with_a_large_mean(gpu_device):
+    """channels with |mean| >> std (a conv bias in front of the BatchNorm: CNN_mode Default, or drifting activations).
+    The sums are taken of (x - pivot) with a per-channel pivot from the data, so the variance does not cancel: mean / std = 1e3
+    here, where E[x^2] - mean^2 in float32 partials is off by ~10 % in the variance.  Against float64 on the same float32 values;
+    the bounds left are the float32 rounding of the saved mean (6e-5 of a standard deviation)."""
+    from magat_pathplanning_amd.train_cnn import _BatchNormTrain
+    rows, C = 23040, 64
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(rows, C, generator=g) * (torch.rand(C, generator=g) + 0.5) + 1000.0
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    rm, rv = torch.zeros(C), torch.ones(C)
+    x64 = x.double()
+    rm64, rv64 = rm.double().clone(), rv.double().clone()
+    y64 = tnf.batch_norm(x64, rm64, rv64, gamma.double(), beta.double(), True, 0.1, 1e-5)
+    rmd, rvd = rm.to(gpu_device), rv.to(gpu_device)
+    y = _BatchNormTrain.apply(x.to(gpu_device), gamma.to(gpu_device), beta.to(gpu_device), rmd, rvd, 0.1, 1e-5, False)
+    assert _rel(rvd.cpu().double(), rv64) < 1e-5          # (was ~1e-1 relative in the variance with unshifted float32 sums)
+    assert _rel(rmd.cpu().double(), rm64) < 1e-6
+    assert float((y.cpu().double() - y64).abs().max()) < 5e-4
+
+
 @pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("rows,C", [(77 * 36, 32), (1001, 64), (23040, 128), (5, 128)])
 def test_batchnorm_training_kernels_match_torch(gpu_device, rows, C, relu):
@@ -229,7 +250,22 @@ def test_gnn_baseline_training_step_hip_vs_torch_convolutions(gpu_device, monkey
         assert _rel(res["hip"][1][k], res["torch"][1][k]) < 2e-3, k
 
 
-def test_every_model_variant_trains_and_infers(gpu_device):
+def test_training_backend_is_chosen_by_batch_size(gpu_device, monkeypatch):
+    """MAGAT_TRAIN_CNN=auto (the default): torch's convolutions below train_cnn.TRAIN_HIP_MIN_AGENTS agents - the reference's own
+    training batch (64 x 10 agents, scripts/train_DMap.sh:30-46) is launch-bound and must not get slower by dropping this
+    module in - the HIP convolution kernels from there on; hip / torch force one side."""
+    from magat_pathplanning_amd import train_cnn as tc
+    small = torch.zeros(640, 3, 11, 11, device=gpu_device)
+    large = torch.zeros(tc.TRAIN_HIP_MIN_AGENTS, 3, 11, 11, device=gpu_device)
+    monkeypatch.delenv("MAGAT_TRAIN_CNN", raising=False)
+    assert not tc._use_hip_convs(small) and tc._use_hip_convs(large) and not tc._use_hip_convs(large.cpu())
+    monkeypatch.setenv("MAGAT_TRAIN_CNN", "hip")
+    assert tc._use_hip_convs(small)
+    monkeypatch.setenv("MAGAT_TRAIN_CNN", "torch")
+    assert not tc._use_hip_convs(large)
+
+
+def test_every_model_variant_trains_and_infers(gpu_device, monkeypatch):
     """One training step (cross-entropy, backward) and one inference forward of every (skip variant, CNN_mode, attention mode)
     combination of DecentralPlannerGATNet and every CNN_mode of DecentralPlannerNet: finite logits and gradients, nothing raises
     (this sweep found the ResNetLarge / ResNetSlim trunks handing out a non-contiguous map and the GNN-baseline class refusing
@@ -237,6 +273,7 @@ def test_every_model_variant_trains_and_infers(gpu_device):
     import itertools
     from magat_pathplanning_amd import DecentralPlannerGATNet, DecentralPlannerNet
     from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    monkeypatch.setenv("MAGAT_TRAIN_CNN", "hip")      # (21 agents: `auto` would take torch's convolutions)
     B, N = 3, 7
     x = fov_states(B, N, seed=5).to(gpu_device)
     S = comm_gso(B, N, 20, seed=6).to(gpu_device)
@@ -264,7 +301,8 @@ def test_every_model_variant_trains_and_infers(gpu_device):
         assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None), cnn
 
 
-def test_inference_sees_what_training_changed(gpu_device):
+@pytest.mark.parametrize("backend", ["hip", "auto"])
+def test_inference_sees_what_training_changed(gpu_device, monkeypatch, backend):
     """Between training steps the inference path must run on the module's CURRENT parameters and BatchNorm statistics - also when
     only the buffers moved (a training-mode forward without an optimiser step: the HIP BatchNorm kernels update the running
     statistics in place and bump their version counters, which planner._weights_key watches): inference logits against the
@@ -272,6 +310,7 @@ def test_inference_sees_what_training_changed(gpu_device):
     from oracle import magat_oracle as orc
     from magat_pathplanning_amd import DecentralPlannerGATNet
     from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    monkeypatch.setenv("MAGAT_TRAIN_CNN", backend)     # (40 agents: `auto` = torch's convolutions, `hip` = the HIP kernels)
     B, N = 4, 10
     cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=2, bottleneckMode="BottomNeck_skipConcat", device="cuda:0")
     torch.manual_seed(5)

@@ -360,3 +360,21 @@ def test_graft_entry_build_passes():
     sys.path.insert(0, ROOT)
     ge = importlib.import_module("__graft_entry__")
     ge.build()
+
+
+def test_reset_option_restores_the_environments_value():
+    """magat_reset_option goes back to what the PROCESS started with - MAGAT_<NAME> from the environment when it was set, else the
+    built-in default (a deployment's setting must survive a tool that flips an option and resets it).  The
+    library reads the environment once, so this needs a fresh process."""
+    import subprocess
+    import sys
+    code = ("from magat_pathplanning_amd import _native as n\n"
+            "assert n.get_option('HEAD_SPLITK') == 777 and n.get_option('GAT_PACK') == 1\n"
+            "n.set_option('HEAD_SPLITK', 5); n.set_option('GAT_PACK', 0)\n"
+            "n.reset_option('HEAD_SPLITK'); n.reset_option('GAT_PACK')\n"
+            "assert n.get_option('HEAD_SPLITK') == 777 and n.get_option('GAT_PACK') == 1\n"
+            "print('ok')\n")
+    env = dict(os.environ, MAGAT_HEAD_SPLITK="777")
+    env.pop("MAGAT_GAT_PACK", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
