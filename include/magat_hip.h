@@ -421,6 +421,19 @@ typedef struct magat_conv_gemm_desc {
    * streamed-dot-product form of a layer with at most 8 outputs only (float32 1x1, option SKINNY); every other kernel returns
    * MAGAT_ERR_UNSUPPORTED. */
   int bf16_rows;
+  /* A SECOND 1x1 layer computed in the epilogue of the first (ABI 6; f16x3 direct kernel only: in_fmt 4, out_fmt 0, out_gl 0,
+   * float32 input, ONE output pixel, Cout == Cout2 == 128, so that a workgroup tile holds whole rows): out2 [M][ldc2] =
+   * act2(out . wt2^T + bias2), with `out` still written.  wt2 = [2][Cout2][Cout] f16 planes of (weight * 2^e) followed by one
+   * float32 2^-e (the in_fmt 4 weight block of that layer's own launch), in_scale2 as in_scale for that layer (NULL = 1).
+   * compressMLP behind the encoder head: one launch instead of two, the 128-wide feature rows never re-read; bit for bit the
+   * result of the two launches.  wt2 = NULL: no second layer.  Shapes the fused form does not take (narrowed column tiles of
+   * a small batch, option CONV_TEPI off, ...) return MAGAT_ERR_UNSUPPORTED before anything is launched - the caller then
+   * issues the two layers on their own. */
+  const void* wt2;
+  const float* bias2;
+  float* out2;
+  const float* in_scale2;
+  int Cout2, ldc2, relu2;
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 

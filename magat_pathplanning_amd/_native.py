@@ -52,7 +52,9 @@ class ConvGemmDesc(ctypes.Structure):
                 ("wt_pix_stride", ctypes.c_int64), ("ldw", ctypes.c_int),
                 ("range_flag", ctypes.c_void_p), ("run_if", ctypes.c_void_p),
                 ("in_scale", ctypes.c_void_p), ("acc_scale", ctypes.c_void_p), ("absmax", ctypes.c_void_p),
-                ("bf16_rows", ctypes.c_int)]
+                ("bf16_rows", ctypes.c_int),
+                ("wt2", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("out2", ctypes.c_void_p), ("in_scale2", ctypes.c_void_p),
+                ("Cout2", ctypes.c_int), ("ldc2", ctypes.c_int), ("relu2", ctypes.c_int)]
 
 
 class EncoderDesc(ctypes.Structure):

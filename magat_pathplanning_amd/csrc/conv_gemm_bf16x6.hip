@@ -56,6 +56,12 @@ struct SplitParams {
   const float* acc_scale;   // NPL == 2: device pointer to 1 / (power-of-two weight scale), applied before the bias
   const float* in_scale;    // direct kernel, float32 input: power-of-two activation scale (device float; null or 0 = 1)
   int* range_flag;          // range guard (magat_hip.h): OR-ed with 1 when a value had to be clamped into its f16 / fp8 planes
+  // second 1x1 layer computed in the epilogue (direct kernel, FUSE2; magat_conv_gemm_desc.wt2 ...): out2 = act(out . wt2^T + bias2)
+  const u16* wt2;           // [2][Cout2][Cout] f16 planes of (weight * 2^e) followed by one float32 2^-e
+  const float* bias2;
+  float* out2;
+  const float* in_scale2;   // power-of-two scale of `out` on its way into the planes (device float; null or 0 = 1)
+  int ldc2, relu2;
 };
 
 // the guard's device-side flag: lanes that clamped (normally none: one skipped branch) OR it
@@ -491,9 +497,17 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 // per row and slab.  Per slab: two f16 MFMAs (h1 g1) and ONE v_mfma_scale_f32_32x32x64_f8f6f4 whose K = 64 is
 // [q(h1) | q(h2)] . [q(g2) ; q(g1)] - lanes 0-31 hold K block 0, lanes 32-63 block 1, one power-of-two scale per block.
 // Same bytes moved as the f16x3 form, half the matrix passes; logits move by 4e-6 (tests/arith_probe.py).
-template <int BN, int TM, int INF>
+// FUSE2 (BN = 128 = Cout, TM = 1, float32 input, one output pixel, row-major float32 output; round 5): a SECOND 1x1 layer of
+// 128 outputs on the workgroup's finished rows - compressMLP behind the encoder head - computed in the epilogue: a wave holds
+// its 32 agents' complete 128-wide rows in its accumulators, so the rows become the second layer's activation planes in
+// registers (the same scale, split and k order as the layer's own launch: one v_permlane32_swap per register pair turns the
+// accumulator layout - a lane half holds channels 8 q + 4 h + c - into the natural k order of an operand), its four weight slabs
+// travel through the idle weight stages, 96 more MFMAs per wave.  Bit for bit the result of the two launches it replaces (the
+// same products in the same order on the same planes); saves a launch and the re-read of the rows (19 us -> ~8 at c3).
+template <int BN, int TM, int INF, bool FUSE2 = false>
 __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_kernel(const SplitParams p) {
   constexpr bool PIN = INF >= 1, MX = INF == 2;
+  static_assert(!FUSE2 || (BN == 128 && TM == 1 && INF == 0), "FUSE2: whole 128-wide rows per wave, float32 input");
   constexpr int TN = BN / 32;
   constexpr int STAGE = 2 * BN * 64;                    // bytes per weight stage: two planes of BN rows x 64 B
   __shared__ __attribute__((aligned(1024))) char Bs[2 * STAGE];
@@ -841,11 +855,15 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
 #pragma unroll
         for (int c = 0; c < 4; ++c) bq[j][q][c] = p.bias ? p.bias[n0 + j * 32 + 4 * fh + 8 * q + c] : 0.f;
   }
-  if (TN >= 2 && p.out_gl == 0 && vec && p.tepi) {
-    // Row-major float32 output (the GAT maps' Z, the last conv's map for the pooled head): the accumulator layout gives a
-    // lane four 16-byte pieces of ONE agent's row per channel tile, i.e. a store instruction scatters 64 pieces over 32
-    // rows.  Transposed through the (now idle) weight stages - one 64 BN-byte region per wave, 16-byte units XOR-swizzled
-    // by the agent - every store instruction writes four agents' BN/2-channel runs (256 B each at BN = 128).
+  // Row-major float32 output (the GAT maps' Z, the last conv's map for the pooled head): the accumulator layout gives a
+  // lane four 16-byte pieces of ONE agent's row per channel tile, i.e. a store instruction scatters 64 pieces over 32
+  // rows.  Transposed through the (now idle) weight stages - one 64 BN-byte region per wave, 16-byte units XOR-swizzled
+  // by the agent - every store instruction writes four agents' BN/2-channel runs (256 B each at BN = 128).
+  // (a lambda since round 5: the fused second layer stores its rows the same way)
+  // on_tile(j, vv): called with the 16 finished values of row group 0's channel tile j (the fused second layer forms its
+  // activation planes from them: accumulators and biases are then consumed ONCE, tile by tile)
+  auto store_rows_t = [&](f32x16 (&ac)[TM][TN], const float scl, const f32x4 (&bb)[TN][4], const int relu, float* const obase,
+                          const int ldo, const long long otile, auto on_tile) __attribute__((always_inline)) {
     constexpr int CP = BN / 2, UP = CP / 4;             // channels / 16-byte units per pass and agent
     constexpr int JP = CP / 32;                          // channel tiles per pass
     __syncthreads();                                     // every wave is done reading the weight stages
@@ -858,30 +876,142 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
 #pragma unroll
         for (int jj = 0; jj < JP; ++jj) {
           const int j = ps * JP + jj;
+          float vv[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             f32x4 v;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              v[c] = acc[i][j][4 * q + c] * acc_scale + bq[j][q][c];
-              if (p.relu) v[c] = magat_relu(v[c]);
+              v[c] = ac[i][j][4 * q + c] * scl + bb[j][q][c];
+              if (relu) v[c] = magat_relu(v[c]);
+              vv[4 * q + c] = v[c];
             }
             const int u = jj * 8 + 2 * q + fh;          // 16-byte unit of channels 32 jj + 8 q + 4 fh .. + 3
             *reinterpret_cast<f32x4*>(wl + fr * (CP * 4) + ((u ^ (fr & (UP - 1))) * 16)) = v;
           }
+          if (i == 0) on_tile(j, vv);
         }
 #pragma unroll
         for (int st = 0; st < 32 * UP / 64; ++st) {
           const int r = st * (64 / UP) + lane / UP, u = lane % UP;
           const f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * (CP * 4) + ((u ^ (r & (UP - 1))) * 16));
           const int m = mb + r;
-          if (m < p.M)
-            *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +
-                                      magat_row_off(m, p.ldc, p.out_tile) + (p.out_nt ? ntile * p.out_nt : n0) + ps * CP +
-                                      4 * u) = v;
+          if (m < p.M) *reinterpret_cast<f32x4*>(obase + magat_row_off(m, ldo, otile) + ps * CP + 4 * u) = v;
         }
       }
     }
+  };
+  if constexpr (FUSE2) {
+    // ---- the second layer on the finished rows (see the template comment).  First its activation planes - from the very
+    // values the store below writes: v = acc * acc_scale + bias (ReLU if the first layer has one), times the second layer's
+    // input scale, split exactly as that layer's own float32 loader splits them.
+    float insc2 = 1.f;
+    if (p.in_scale2) insc2 = *p.in_scale2;
+    if (insc2 == 0.f) insc2 = 1.f;
+    u32x4 qb[8][2];                                       // [k step of the second layer's K = 128][plane]
+    auto planes_of = [&](int j, const float (&vv)[16]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        unsigned h1[4], h2[4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int q = 2 * ks + e;
+          float v[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            v[c] = vv[4 * q + c];
+            if (insc2 != 1.f) asm("v_mul_f32 %0, %1, %2" : "=v"(v[c]) : "v"(v[c]), "v"(insc2));
+          }
+          split_pair_f16(v[0], v[1], h1[2 * e], h2[2 * e], clamped);
+          split_pair_f16(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1], clamped);
+        }
+        // accumulator layout -> operand k order: lane half h holds channels 16 ks + 8 e + 4 h + c in (e, c); an operand's lane
+        // half h holds 16 ks + 8 h + i.  Half 0 keeps its e = 0 quad and takes half 1's e = 0 quad as i = 4..7; half 1 takes
+        // half 0's e = 1 quad as i = 0..3 and keeps its own: the upper half of the e = 0 registers swaps with the lower half of
+        // the e = 1 registers (v_permlane32_swap), dword by dword
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const auto r1 = __builtin_amdgcn_permlane32_swap(h1[d], h1[2 + d], false, false);
+          h1[d] = r1[0]; h1[2 + d] = r1[1];
+          const auto r2 = __builtin_amdgcn_permlane32_swap(h2[d], h2[2 + d], false, false);
+          h2[d] = r2[0]; h2[2 + d] = r2[1];
+        }
+        qb[2 * j + ks][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
+        qb[2 * j + ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
+      }
+    };
+    // the first layer's rows (through the weight stages: a barrier in front, stores behind), the planes formed on the way
+    store_rows_t(acc, acc_scale, bq, p.relu, static_cast<float*>(p.out) + (long long)pix * p.out_pix_stride + n0, p.ldc, p.out_tile,
+                 planes_of);
+    report_clamped(p.range_flag, clamped);
+    clamped = false;
+    // the second layer's K = 128: four 32-wide slabs through the two weight stages, as in the main loop
+    const char* const w2b = reinterpret_cast<const char*>(p.wt2);
+    unsigned boff2[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int id = wave + 4 * i;
+      const int plane = id / (BN / 16), row = (id % (BN / 16)) * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ ((row >> 2) & 3);
+      boff2[i] = (unsigned)((plane * (BN * BN) + row * BN + c * 8) * 2);
+    }
+    auto dma2 = [&](int slab, int stage) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const char* src = w2b + slab * 64 + boff2[i];
+        const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Bs + (unsigned)(wave + 4 * i) * 1024u +
+                                                            (unsigned)stage * (unsigned)STAGE);
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    __syncthreads();                                     // the row stores' staging reads are done: the stages are free again
+    dma2(0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < BN / BK; ++s2) {
+      landed();
+      if (s2 + 1 < BN / BK) dma2(s2 + 1, (s2 + 1) & 1);
+      const char* bst = Bs + (s2 & 1) * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = 2 * ks + fh;
+        constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          // (one weight plane in registers at a time - the third product re-reads plane 0: 64 accumulator + 64 activation-plane
+          //  registers leave no room for both planes of four channel tiles under the 168 registers of three waves per SIMD)
+          asm volatile("" ::: "memory");
+          u32x4 fb[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int row = j * 32 + fr;
+            fb[j] = *reinterpret_cast<const u32x4*>(bst + PB[q] * (BN * 64) + (row * 4 + (c ^ ((row >> 2) & 3))) * 16);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]),
+                                                               __builtin_bit_cast(f16x8, qb[2 * s2 + ks][PA[q]]), acc[0][j], 0, 0, 0);
+        }
+      }
+    }
+    const float acc_scale2 = *reinterpret_cast<const float*>(w2b + (size_t)2 * BN * BN * 2) / insc2;
+    f32x4 bq2[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bq2[j][q][c] = p.bias2 ? p.bias2[j * 32 + 4 * fh + 8 * q + c] : 0.f;
+    store_rows_t(acc, acc_scale2, bq2, p.relu2, p.out2, p.ldc2, (long long)MAGAT_TILE_ROWS * p.ldc2, [](int, const float (&)[16]) {});
+    return;
+  }
+  if (TN >= 2 && p.out_gl == 0 && vec && p.tepi) {
+    store_rows_t(acc, acc_scale, bq, p.relu,
+                 static_cast<float*>(p.out) + (long long)pix * p.out_pix_stride + (p.out_nt ? ntile * p.out_nt : n0), p.ldc,
+                 p.out_tile, [](int, const float (&)[16]) {});
     return;
   }
 #pragma unroll
@@ -998,6 +1128,13 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   }
   if ((d->Cout % BN) || (d->Cin % BK) || (d->C2 % BK) || (d->lda % 8) || (d->C2 > 0 && (d->lda2 % 8)) || d->pool)
     return MAGAT_ERR_UNSUPPORTED;
+  // second layer in the epilogue (magat_hip.h wt2): whole 128-wide rows per workgroup tile, the transposed row store
+  const bool fuse2 = d->wt2 != nullptr;
+  if (fuse2 && !(d->in_fmt == 4 && d->out_fmt == 0 && d->in_gl <= 1 && d->out_gl == 0 && !d->out_ntile_stride && BN == 128 &&
+                 d->Cout == 128 && d->Cout2 == 128 && d->Hout * d->Wout == 1 && d->out2 && (d->ldc & 3) == 0 && (d->ldc2 & 3) == 0 &&
+                 (reinterpret_cast<uintptr_t>(d->out) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->out2) & 15) == 0 &&
+                 magat_conv_direct_enabled() && magat_opt(MAGAT_OPT_CONV_TEPI)))
+    return MAGAT_ERR_UNSUPPORTED;
   if (d->in_fmt < 1 || d->in_fmt > 5 || d->out_fmt < 0 || d->out_fmt > 3) return MAGAT_ERR_UNSUPPORTED;
   if (d->wt_pix_stride || d->ldw) return MAGAT_ERR_UNSUPPORTED;     // float32 kernel only
   if (d->in_fmt >= 4 && d->out_fmt != 0 && d->out_fmt != 3) return MAGAT_ERR_UNSUPPORTED;
@@ -1023,6 +1160,8 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.in_gl = d->in_gl; p.out_gl = d->out_gl;
   p.out_nt = d->out_ntile_stride;
   p.range_flag = reinterpret_cast<int*>(d->range_flag);
+  p.wt2 = static_cast<const u16*>(d->wt2); p.bias2 = d->bias2; p.out2 = d->out2; p.in_scale2 = d->in_scale2;
+  p.ldc2 = d->ldc2; p.relu2 = d->relu2;
   if (p.out_nt && !(d->in_fmt == 4 && d->out_fmt == 0 && d->out_gl == 0 && BN == 128 && magat_conv_direct_enabled()))
     return MAGAT_ERR_UNSUPPORTED;
   p.korder = magat_opt(MAGAT_OPT_CONV_KORDER);
@@ -1065,7 +1204,7 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   if (d->in_gl < 0 || d->in_gl > 3 || d->out_gl < 0 || d->out_gl > 3) return MAGAT_ERR_UNSUPPORTED;
   if (d->in_fmt == 4 && d->out_fmt == 0 && direct) {
     const int tm2 = magat_opt(MAGAT_OPT_CONV_TM);     // 1: one 32-agent row group per wave everywhere
-    const bool two = tm2 >= 2 && (long long)(p.Mt / 2) * p.npix * p.ntn >= 2048;   // enough 256-agent tiles to fill the chip
+    const bool two = !fuse2 && tm2 >= 2 && (long long)(p.Mt / 2) * p.npix * p.ntn >= 2048;   // enough 256-agent tiles to fill the chip
     const long long mt = two ? (p.Mt + 1) / 2 : p.Mt;
     const long long g2 = (mt + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD * p.npix * p.ntn;
     p.Mt = (int)mt;
@@ -1085,7 +1224,10 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
       hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1, 0>), dim3((unsigned)g2), dim3(256), 0, st, p);      \
   } while (0)
     const bool pin = d->in_gl == 2, mxin = d->in_gl == 3;
-    if (BN == 128) MAGAT_DIRECT_LAUNCH(128);
+    if (fuse2) {
+      magat_form_note(MAGAT_FORM_HEAD_COMPRESS);
+      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<128, 1, 0, true>), dim3((unsigned)g2), dim3(256), 0, st, p);
+    } else if (BN == 128) MAGAT_DIRECT_LAUNCH(128);
     else if (BN == 64) MAGAT_DIRECT_LAUNCH(64);
     else MAGAT_DIRECT_LAUNCH(32);
 #undef MAGAT_DIRECT_LAUNCH

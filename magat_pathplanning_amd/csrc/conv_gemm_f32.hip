@@ -611,6 +611,7 @@ static int conv_params_from_desc(const magat_conv_gemm_desc* d, ConvGemmParams& 
 extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) {
   if (!d || !d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
   if (d->bf16_rows && d->in_fmt != 0) return MAGAT_ERR_UNSUPPORTED;
+  if (d->wt2 && d->in_fmt != 4) return MAGAT_ERR_UNSUPPORTED;      // (a second layer in the epilogue: f16x3 direct kernel only)
   if (d->in_fmt >= 1 && d->in_fmt <= 5) return magat_conv_gemm_bf16x6(d, static_cast<hipStream_t>(stream));
   {
     const int src = skinny_try(d, static_cast<hipStream_t>(stream));

@@ -548,6 +548,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // order as its other chunks, or the batch would differ in the last bit from the same agents presented as shards.
     const int cells = (hin / 2) * (win / 2);
     const int split_max = magat_opt(MAGAT_OPT_HEAD_SPLITK);
+    bool compress_done = false;      // compressMLP rode in the head's epilogue
     if (!absmax && !chained && cells > 1 && Mform <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
         (size_t)cells * d->n_feat <= enc_buf_floats_per_agent(d)) {     // the partials must fit one map buffer
       float* part = buf[(cur + 1) % 3];                 // [cells][mm][n_feat]
@@ -575,11 +576,24 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
         if (d->scaled_off > 0) g.in_scale = pk + d->scaled_off + 1349;
         if (head_gl) g.in_gl = 1;
         magat_form_note(MAGAT_FORM_HEAD_LONGK);
+        // compressMLP in the head's epilogue (round 5; option HEAD_COMPRESS): the 128-wide feature rows are complete in the
+        // workgroup's registers, so the second layer runs on them there - one launch instead of two, bit for bit the same
+        // comp.  Declined (MAGAT_ERR_UNSUPPORTED, nothing launched) when the head's column tile was narrowed for a small
+        // batch: the two launches follow as before.
+        if (!rerun && comp && d->n_comp == 128 && d->n_feat == 128 && d->comp16_off > 0 && magat_opt(MAGAT_OPT_HEAD_COMPRESS)) {
+          magat_conv_gemm_desc f = g;
+          f.wt2 = pk + d->comp16_off; f.bias2 = pk + d->off[17]; f.out2 = comp + (size_t)m0 * ldcomp;
+          f.Cout2 = d->n_comp; f.ldc2 = ldcomp; f.relu2 = 1;
+          f.in_scale2 = d->scaled_off > 0 ? pk + d->scaled_off + 1350 : nullptr;
+          rc = magat_conv_gemm_f32(&f, stream);
+          if (rc == MAGAT_OK) compress_done = true;
+          else if (rc != MAGAT_ERR_UNSUPPORTED) return rc;
+        }
       }
-      rc = g.in_fmt == 0 ? run_or_chain(g) : magat_conv_gemm_f32(&g, stream);
+      if (!compress_done) rc = g.in_fmt == 0 ? run_or_chain(g) : magat_conv_gemm_f32(&g, stream);
     }
     if (rc != MAGAT_OK) return rc;
-    if (d->n_comp > 0) {
+    if (d->n_comp > 0 && !compress_done) {
       // compressMLP: f16x3 split products on the direct kernel when the head ran that way (large pooled batches), else
       // float32 MFMA (and always in the guard's re-run)
       if (!rerun && pooled_in && split && d->comp16_off > 0 && (d->n_feat % 32) == 0 && (d->n_comp % 32) == 0 &&

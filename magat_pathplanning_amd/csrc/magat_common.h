@@ -70,7 +70,7 @@ enum MagatOpt {
   MAGAT_OPT_GAT_HPB, MAGAT_OPT_GAT_ZTILES, MAGAT_OPT_GAT_PERSIST, MAGAT_OPT_RANGE_GUARD, MAGAT_OPT_BLOCK_FUSED,
   MAGAT_OPT_CSR_TILED, MAGAT_OPT_BLOCK3_FUSED,
   MAGAT_OPT_HEAD_F16, MAGAT_OPT_BLOCK_FULL, MAGAT_OPT_GAT_MFMA, MAGAT_OPT_GUARD_CHAIN, MAGAT_OPT_HEAD_GL, MAGAT_OPT_SKINNY, MAGAT_OPT_GAT_PACK,
-  MAGAT_OPT_CONV_BNFILL, MAGAT_OPT_COUNT
+  MAGAT_OPT_CONV_BNFILL, MAGAT_OPT_HEAD_COMPRESS, MAGAT_OPT_COUNT
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)

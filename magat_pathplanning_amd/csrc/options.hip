@@ -58,6 +58,8 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
     {"CONV_BNFILL", 256},    // f16x3 direct kernel: narrow the output-channel tile (128 -> 64 -> 32) until the launch has at
                              // least this many workgroups (0: never).  Column tiling does not touch any element's summation order:
                              // bit-identical
+    {"HEAD_COMPRESS", 1},    // compressMLP computed in the encoder head's epilogue (one launch; needs the 128-column head tile:
+                             // batches whose head tile was narrowed by CONV_BNFILL keep the two launches; bit-identical)
 };
 
 int g_val[MAGAT_OPT_COUNT];

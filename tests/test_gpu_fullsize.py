@@ -68,6 +68,7 @@ def test_full_batch_against_oracle_on_sampled_instances(gpu_device, tag_counts, 
     assert not st["encoder_rerun"] and not st["gat_rerun"], st
     assert forms["head_longk"] == 1 and forms["head_splitk"] == 0, forms          # B N agents > HEAD_SPLITK
     assert forms["chain_persist"] == 1, forms                                   # B N / 8 groups > CUs
+    assert forms["head_compress"] == (1 if B * N >= 32768 else 0), forms        # compressMLP in the head's epilogue (128-column tile)
     if N <= 32:
         assert forms["gat_pack"] == 1 and forms["gat_hsplit"] == 0, forms         # four instances per pass
     else:
@@ -97,4 +98,5 @@ def test_config5_full_batch_bf16_against_oracle_on_sampled_instances(gpu_device,
     assert err <= 2e-2 * max(1.0, float(ref.abs().max())), err
     assert agree >= 0.97, agree
     assert tc["gat_graph"] >= 1 and tc["gat_layer (one launch)"] == 0, tc.counts          # the CSR kernels, not the dense layer
-    assert forms["head_longk"] == 1 and forms["chain_persist"] == 1, forms
+    # (128 000 agents = two encoder passes of ENC_CHUNK = 65 536 agents: each with the long-K head and the persistent chain walk)
+    assert forms["head_longk"] == 2 and forms["head_splitk"] == 0 and forms["chain_persist"] == 2, forms

@@ -272,6 +272,53 @@ def test_shards_choose_their_forms_on_the_global_agent_count(gpu_device, tag_cou
     assert float((rows - ref).abs().max()) <= 1e-4
 
 
+def test_compress_in_the_head_epilogue_is_bit_identical(gpu_device, libopt):
+    """Round 5: compressMLP computed in the encoder head's epilogue (option HEAD_COMPRESS, default on; one launch for both
+    layers once the head keeps its 128-column tile, i.e. from 32 768 agents on) against the two launches it replaces: the same
+    products in the same order on the same planes - logits equal BIT FOR BIT, so a batch that takes the fused form and its
+    shards that do not (narrowed head tiles) still concatenate exactly.  The form counters say which one ran."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd import _native as nat
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N = 331, 100                                   # 33 100 agents: 259 agent tiles, a ragged last one
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat")
+    sd = orc.init_state_dict(cfg, seed=23)
+    net = _build(cfg, sd, gpu_device)
+    x = fov_states(B, N, seed=9).to(gpu_device)
+    S = comm_gso(B, N, 50, seed=10).to(gpu_device)
+    lib = nat.lib()
+    with torch.no_grad():
+        net.addGSO(S.clone())
+        net(x)
+        lib.magat_form_reset()
+        net.addGSO(S.clone())
+        fused = net(x).clone()
+        assert lib.magat_form_count(nat.FORMS["head_compress"]) == 1
+        libopt.set("MAGAT_HEAD_COMPRESS", 0)
+        lib.magat_form_reset()
+        net.addGSO(S.clone())
+        two = net(x).clone()
+        assert lib.magat_form_count(nat.FORMS["head_compress"]) == 0
+        assert torch.equal(fused, two)
+        libopt.reset("MAGAT_HEAD_COMPRESS")
+        # halves of the batch (16 500 / 16 600 agents: narrowed head tiles, two launches) with the global form hint
+        h = 165
+        net.form_agents = B * N
+        lib.magat_form_reset()
+        net.addGSO(S[:h].contiguous())
+        a = net(x[:h]).clone()
+        net.addGSO(S[h:].contiguous())
+        b = net(x[h:]).clone()
+        net.form_agents = 0
+        assert lib.magat_form_count(nat.FORMS["head_compress"]) == 0
+        assert torch.equal(torch.cat((a, b)), fused)
+    pick = [0, 164, 165, 330]
+    ref = orc.planner_forward(x[pick].cpu(), S[pick].cpu().clone(), sd, cfg)
+    rows = torch.cat([fused[b_ * N:(b_ + 1) * N] for b_ in pick]).cpu()
+    assert float((rows - ref).abs().max()) <= 1e-4
+    assert not net.range_status()["encoder_rerun"]
+
+
 def test_shard_equivalence_across_the_encoder_chunk(gpu_device, libopt):
     """The encoder walks a batch in chunks of MAGAT_ENC_CHUNK agents (65 536).  The form of the head is chosen on the
     agent count of the whole call, so the short last chunk sums like the others and a batch that spills into a second
