@@ -505,12 +505,16 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 // travel through the idle weight stages, 96 more MFMAs per wave.  Bit for bit the result of the two launches it replaces (the
 // same products in the same order on the same planes); saves a launch and the re-read of the rows (19 us -> ~8 at c3).
 template <int BN, int TM, int INF, bool FUSE2 = false>
-__global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_kernel(const SplitParams p) {
+__global__ __launch_bounds__(256, (TM == 1 && !FUSE2) ? 3 : 2) void conv_gemm_f16x3_direct_kernel(const SplitParams p) {
   constexpr bool PIN = INF >= 1, MX = INF == 2;
   static_assert(!FUSE2 || (BN == 128 && TM == 1 && INF == 0), "FUSE2: whole 128-wide rows per wave, float32 input");
   constexpr int TN = BN / 32;
   constexpr int STAGE = 2 * BN * 64;                    // bytes per weight stage: two planes of BN rows x 64 B
-  __shared__ __attribute__((aligned(1024))) char Bs[2 * STAGE];
+  // (FUSE2: two more stages - the second layer's first two weight slabs are requested before the first layer's rows are stored
+  //  and land under that store; two workgroups per CU either way: 64 KB of LDS, 256 registers - its epilogue holds 64
+  //  accumulator and 64 activation-plane registers next to the operands and spilled 56 registers at three waves per SIMD,
+  //  which cost more than the launch it saves: 93.6 us against 71.6 + 18.6)
+  __shared__ __attribute__((aligned(1024))) char Bs[(FUSE2 ? 4 : 2) * STAGE];
 
   const int bid = blockIdx.x;
   const int xcd = bid % MAGAT_NUM_XCD, slot = bid / MAGAT_NUM_XCD;
@@ -866,7 +870,10 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
                           const int ldo, const long long otile, auto on_tile) __attribute__((always_inline)) {
     constexpr int CP = BN / 2, UP = CP / 4;             // channels / 16-byte units per pass and agent
     constexpr int JP = CP / 32;                          // channel tiles per pass
-    __syncthreads();                                     // every wave is done reading the weight stages
+    // every wave is done reading the weight stages (FUSE2: an LDS-only barrier - __syncthreads() carries vmcnt(0) and would
+    // sit out the second layer's weight slabs that are in flight into stages 2 / 3)
+    if constexpr (FUSE2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
     char* const wl = Bs + wave * (64 * BN);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -940,12 +947,7 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
         qb[2 * j + ks][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
       }
     };
-    // the first layer's rows (through the weight stages: a barrier in front, stores behind), the planes formed on the way
-    store_rows_t(acc, acc_scale, bq, p.relu, static_cast<float*>(p.out) + (long long)pix * p.out_pix_stride + n0, p.ldc, p.out_tile,
-                 planes_of);
-    report_clamped(p.range_flag, clamped);
-    clamped = false;
-    // the second layer's K = 128: four 32-wide slabs through the two weight stages, as in the main loop
+    // the second layer's weight slabs 0 / 1 -> stages 2 / 3 (nobody else's: no barrier needed), in flight under the row store
     const char* const w2b = reinterpret_cast<const char*>(p.wt2);
     unsigned boff2[TN];
 #pragma unroll
@@ -964,37 +966,44 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv_gemm_f16x3_direct_k
         asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
       }
     };
+    dma2(0, 2);
+    dma2(1, 3);
+    // the first layer's rows (through the weight stages: a barrier in front, stores behind), the planes formed on the way
+    store_rows_t(acc, acc_scale, bq, p.relu, static_cast<float*>(p.out) + (long long)pix * p.out_pix_stride + n0, p.ldc, p.out_tile,
+                 planes_of);
+    report_clamped(p.range_flag, clamped);
+    clamped = false;
+    // the second layer's K = 128: four 32-wide slabs - 0 / 1 are in stages 2 / 3 by now, 2 / 3 follow into stages 0 / 1 once
+    // every wave is done with the row store's staging reads; ONE more barrier in front of the second pair
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-    __syncthreads();                                     // the row stores' staging reads are done: the stages are free again
-    dma2(0, 0);
+    landed();                                             // slabs 0 / 1 landed for everyone; the staging reads are done
+    dma2(2, 0);
+    dma2(3, 1);
 #pragma unroll
     for (int s2 = 0; s2 < BN / BK; ++s2) {
-      landed();
-      if (s2 + 1 < BN / BK) dma2(s2 + 1, (s2 + 1) & 1);
-      const char* bst = Bs + (s2 & 1) * STAGE;
+      if (s2 == 2) landed();
+      const char* bst = Bs + ((s2 + 2) & 3) * STAGE;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int c = 2 * ks + fh;
         constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
+        u32x4 fb[TN][2];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          // (one weight plane in registers at a time - the third product re-reads plane 0: 64 accumulator + 64 activation-plane
-          //  registers leave no room for both planes of four channel tiles under the 168 registers of three waves per SIMD)
-          asm volatile("" ::: "memory");
-          u32x4 fb[TN];
+        for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const int row = j * 32 + fr;
-            fb[j] = *reinterpret_cast<const u32x4*>(bst + PB[q] * (BN * 64) + (row * 4 + (c ^ ((row >> 2) & 3))) * 16);
+            fb[j][pl] = *reinterpret_cast<const u32x4*>(bst + pl * (BN * 64) + (row * 4 + (c ^ ((row >> 2) & 3))) * 16);
           }
 #pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]),
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j][PB[q]]),
                                                                __builtin_bit_cast(f16x8, qb[2 * s2 + ks][PA[q]]), acc[0][j], 0, 0, 0);
-        }
       }
     }
     const float acc_scale2 = *reinterpret_cast<const float*>(w2b + (size_t)2 * BN * BN * 2) / insc2;

@@ -368,7 +368,7 @@ struct ConvChain {
 
 __global__ __launch_bounds__(256) void conv_gemm_chain_kernel(const ConvChain c) {
   if (c.run_if && *c.run_if == 0) {
-    if (c.book) magat_guard_book(c.book);
+    if (c.book) magat_guard_book_idle(c.book);
     return;
   }
   for (int mt = blockIdx.x; mt < c.Mt; mt += gridDim.x) {

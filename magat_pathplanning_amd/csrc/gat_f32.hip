@@ -101,7 +101,11 @@ __global__ void gat_dense_kernel(const GatParams p) {
   const int bl0 = xcd + MAGAT_NUM_XCD * (slot / hgroups);
   const int istride = MAGAT_NUM_XCD * ((int)gridDim.x / MAGAT_NUM_XCD / hgroups);
   const int head0 = (slot % hgroups) * hpb;
-  if (bl0 >= p.B || (p.run_if && *p.run_if == 0)) {
+  if (p.run_if && *p.run_if == 0) {
+    if (p.book) magat_guard_book_idle(p.book);
+    return;
+  }
+  if (bl0 >= p.B) {
     if (p.book) magat_guard_book(p.book);
     return;
   }
@@ -734,7 +738,7 @@ __global__ void gat_dense_kernel(const GatParams p) {
 __global__ void head_mean_relu_kernel(const float* __restrict__ ytmp, float* __restrict__ y, long long M, int P,
                                       int F, int ldy, const int* __restrict__ run_if, int* book) {
   if (run_if && *run_if == 0) {
-    if (book) magat_guard_book(book);
+    if (book) magat_guard_book_idle(book);
     return;
   }
   const int FC = F / 4;

@@ -71,8 +71,6 @@ class _Runtime:
         self.digest = None             # fingerprint of the folded encoder pack (what a calibration belongs to)
         self.scaled_at = 0
         self.pack_host = self.pack_offs = self.pack_meta = None
-        self.graphs = {}               # (shape key) -> captured hipGraph of one forward (enable_hip_graph)
-        self.graph_on = None           # None: follow MAGAT_HIP_GRAPH
 
 
 class DecentralPlannerGATNet(nn.Module):
@@ -265,69 +263,7 @@ class DecentralPlannerGATNet(nn.Module):
         if needs_grad or self.training:
             nat.require_device_or_composite(x, "DecentralPlannerGATNet in training / autograd mode")
             return self._forward_autograd(x, B, N)
-        on = self._rt.graph_on
-        if on is None:
-            on = os.environ.get("MAGAT_HIP_GRAPH", "0") == "1"
-        if on and x.is_cuda:
-            return self._forward_graphed(x, B, N)
         return self._forward_hip(x, B, N)
-
-    # ------------------------------------------------------------------ inference path, replayed as one hipGraph
-    def enable_hip_graph(self, on=True):
-        """Closed-loop use (one planning instance per simulator step, the reference's test_batch_size=1 loop,
-        agents/decentralplanner_GAT.py:880-900) is launch-bound: ~16 kernels of a few microseconds each.  With the
-        graph on, the first forward of a (B, N, dtype) shape is captured into a hipGraph over static copies of x and S,
-        later ones cost two copies + one replay (+ the copy of the logits into a fresh tensor).  Same kernels, same
-        results.  Shapes the capture cannot hold (CSR GSO with its host-visible nnz, bf16 storage, returned attention)
-        run eagerly on the same HIP path.  Graphs are dropped when a parameter changes.  None = follow MAGAT_HIP_GRAPH."""
-        self._rt.graph_on = None if on is None else bool(on)
-        self._rt.graphs.clear()
-
-    @torch.no_grad()
-    def _forward_graphed(self, x, B, N):
-        lib = nat.lib()
-        dev = x.device
-        rt = self._refresh(dev)
-        layer = self.GFL[0]
-        if self.S.shape[-1] != N or self.S.shape[0] != B:
-            return self._forward_hip(x, B, N)            # padded / mismatched GSO: the eager path decides
-        S3 = self.S.reshape(B, N, N)
-        want_att = layer.return_attention or bool(getattr(self.config, "return_attentionGSO", False))
-        if (want_att or layer.storage_dtype == torch.bfloat16 or S3.device != dev or
-                S3.dtype not in (torch.float32, torch.float64) or
-                not lib.magat_gat_dense_supported(N, self.numFeatures2Share, layer.F)):
-            return self._forward_hip(x, B, N)
-        key = (B, N, tuple(x.shape[1:]), S3.dtype, str(dev))
-        ent = rt.graphs.get(key)
-        if ent is None:
-            with torch.cuda.device(dev):
-                sx = x.contiguous().float().clone()
-                sS = S3.contiguous().clone()
-                saved = self.S
-                self.S = sS.view(B, 1, N, N)
-                try:
-                    cur = torch.cuda.current_stream(dev)
-                    side = torch.cuda.Stream(device=dev)
-                    side.wait_stream(cur)
-                    with torch.cuda.stream(side):          # warm: allocations, weight packs, kernel attributes
-                        self._forward_hip(sx, B, N)
-                    cur.wait_stream(side)
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        sy = self._forward_hip(sx, B, N)
-                finally:
-                    self.S = saved
-                # the graph holds raw pointers: keep every buffer it was captured over alive with it
-                keep = [rt.pack, rt.ws, rt.act, rt.cw, rt.cb, list(rt.buffers.values()),
-                        layer._scratch.workspace, layer._scratch.packed]
-                ent = (g, sx, sS, sy, keep)
-                rt.graphs[key] = ent
-        g, sx, sS, sy, _ = ent
-        sx.copy_(x)
-        sS.copy_(S3)
-        g.replay()
-        layer.aij = None
-        return sy.clone()
 
     # ------------------------------------------------------------------ training path (torch ops)
     def _forward_autograd(self, x, B, N):
@@ -378,7 +314,6 @@ class DecentralPlannerGATNet(nn.Module):
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         rt.pack = rt.desc = None
         cells = None                   # CNN_mode Default: pooled cells of the last map (feature order, see below)
-        rt.graphs.clear()              # captured graphs point into the old packs
         if self.cnn_mode.startswith("ResNet"):
             lin = (sd["ConvLayers.3.weight"], sd["ConvLayers.3.bias"]) if self.cnn_mode.endswith("_withMLP") else None
             pack, offs, meta = enc.fold_resnet(sd, self.config.FOV + 2, self.config.FOV + 2, "ConvLayers.0", lin,
@@ -469,7 +404,6 @@ class DecentralPlannerGATNet(nn.Module):
         info.update(gat_in=e_x, absmax=[float(v) for v in a[:9]], source=self._cal["source"])
         rt.act_scales = info
         rt.calibrated = True
-        rt.graphs.clear()
 
     def _ensure_calibrated(self, rt, dev):
         """Activation scales for the current weights (include/magat_hip.h "Activation scales").  The magnitudes come from
@@ -751,10 +685,6 @@ class DecentralPlannerNet(DecentralPlannerGATNet):
                           "magat_encoder_read_status")
             out["encoder_rerun"], out["encoder_reruns"] = bool(st[0]), int(st[1])
         return out
-
-    def enable_hip_graph(self, on=True):
-        if on:
-            raise NotImplementedError("hipGraph capture is built for DecentralPlannerGATNet's dense graph layer only")
 
     def forward(self, inputTensor):
         (B, N, C, W, H) = inputTensor.shape
