@@ -25,7 +25,6 @@ Rank 0 prints ONE JSON line.  `value` is measured with the library's DEFAULT ari
   f32_strict     the headline workload with every product on the float32 matrix cores (no split planes): a-s/s and the dominant
                  kernel against the 157.3 TF float32 MFMA roof
   ms_per_step_device  hipEvent pair around the K timed steps on the launch stream (ms_per_step is host wall-clock over barriers)
-  mx_opt_in      the same workload with the OPT-IN block-scaled-fp8 correction products (NOT fp32-class; labelled, never `value`)
   cpu_baseline   the pinned CPU oracle (kind "port") on this box's host cores: processes x threads sweep over the physical
                  cores, median of three runs of the best split, bounded sample; runs BEFORE the GPU legs
 """
@@ -43,7 +42,6 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_F32_TFLOPS = 157.3    # fp32 MFMA (v_mfma_f32_32x32x2_f32) = fp32 vector peak
-PEAK_FP8_TFLOPS = 5000.0   # dense MXFP8 (v_mfma_scale_f32_32x32x64_f8f6f4)
 PEAK_16_TFLOPS = 2500.0    # dense 16-bit MFMA (v_mfma_f32_32x32x16_{f16,bf16})
 
 WORKLOADS = {
@@ -66,11 +64,7 @@ ARITH = {
     "f32": (1.0, "f32 MFMA (v_mfma_f32_32x32x2_f32)", PEAK_F32_TFLOPS),
     "f16x3": (3.0, "f16x3 split: 2 f16 planes per value (22 significand bits), 3 f16 MFMAs per fp32 multiply-add, "
                    "f32 accumulate (fp32-class: measured error = the fp32 MFMA kernel's)", PEAK_16_TFLOPS),
-    "bf16x6": (6.0, "bf16x6 split: 3 bf16 planes per value, 6 bf16 MFMAs per fp32 multiply-add, f32 accumulate", PEAK_16_TFLOPS),
     "bf16": (1.0, "bf16 MFMA, f32 accumulate (bf16 storage variant)", PEAK_16_TFLOPS),
-    # OPT-IN, not fp32-class: main product on f16 MFMAs, both 2^-11-sized correction products in one block-scaled fp8 MFMA
-    "f16+mxfp8": (3.0, "OPT-IN f16 main product + 2 correction products in block-scaled fp8 (e4m3): narrower than fp32",
-                  round(3.0 / (1.0 / PEAK_16_TFLOPS + 2.0 / PEAK_FP8_TFLOPS), 1)),
 }
 
 
@@ -88,11 +82,6 @@ def conv_arith(nat, cfg, layer):
     """Arithmetic form of BasicBlock `layer` (0..2) with the library's current options (csrc/encoder_f32.hip)."""
     if not cfg.CNN_mode.startswith("ResNet") or not (lib_opt(nat, "CONV_SPLIT") >> layer & 1):
         return "f32"
-    if not lib_opt(nat, "CONV_F16"):
-        return "bf16x6"
-    chain = lib_opt(nat, "CONV_PCHAIN") and lib_opt(nat, "CONV_DIRECT") and lib_opt(nat, "CONV_SPLIT") == 7
-    if chain and lib_opt(nat, "CONV_MX") and layer >= 1:
-        return "f16+mxfp8"
     return "f16x3"
 
 
@@ -139,7 +128,7 @@ def kernel_work(nat, cfg, N, S_bytes, deg=None, planned=False, fused_stem=True, 
     w["compressMLP"] = dict(flops=2 * nfm * G, bytes=4 * (nfm + G), arith=head_a)     # (follows the head's arithmetic)
     gat_a = "f32"
     if lib_opt(nat, "GAT_SPLIT") and NC % 32 == 0 and G % 32 == 0:
-        gat_a = "f16x3" if lib_opt(nat, "CONV_F16") else "bf16x6"
+        gat_a = "f16x3"
     if getattr(cfg, "gat_storage", "fp32") == "bf16":
         gat_a = "bf16"
     w["gat_maps_gemm"] = dict(flops=2 * G * NC, bytes=4 * (G + NC), arith=gat_a)
@@ -386,7 +375,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip north_star_b1024 and mx_opt_in")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the north_star_b1024 / c2 / c5 / published / f32_strict / train_step legs")
     ap.add_argument("--share-gpu", action="store_true",
                     help="REHEARSAL of the N > 1 launch on a box with fewer GPUs than ranks: every rank drives cuda:0, the "
                          "collectives (sum of ones, barrier, gather of the elapsed times) go over gloo.  Exercises bench.py's own "
@@ -600,8 +589,8 @@ def main():
                                          "head-concat" if concat else "head-mean", B, B * world),
                           "arithmetic": {a: ARITH[a][1] for a in ariths},
                           "parity": "logits within 1e-4 of the reference (gate; observed ~1e-6 with this arithmetic)",
-                          "options": {k: lib_opt(nat, k) for k in ("CONV_MX", "CONV_SPLIT", "CONV_F16", "RANGE_GUARD",
-                                                                    "BLOCK_FUSED", "BLOCK3_FUSED", "BLOCK_FULL", "HEAD_F16", "GAT_MFMA")},
+                          "options": {k: lib_opt(nat, k) for k in ("CONV_SPLIT", "RANGE_GUARD", "BLOCK_FUSED", "HEAD_F16",
+                                                                    "HEAD_COMPRESS", "GAT_MFMA", "GAT_PACK")},
                           "global_batch": B * world, "agents": N, "parallelism": "instance-sharded x%d" % world}}
         if args.share_gpu:
             res["config"]["rehearsal"] = ("--share-gpu: %d ranks drive ONE device over gloo - the launch / rank logic of the "
@@ -735,16 +724,6 @@ def main():
             nat.reset_option(k_)
         del nets
         torch.cuda.empty_cache()
-        # (e) OPT-IN MX arithmetic on the headline workload, clearly labelled
-        nat.set_option("CONV_MX", 1)
-        if conv_arith(nat, cfg, 1) == "f16+mxfp8":
-            el, _, _ = run_leg(x, S, esteps, ewarm, False)
-            res["mx_opt_in"] = {"value": round(B * N * esteps / el, 1), "unit": "agent-steps/s",
-                                "ms_per_step": round(el / esteps * 1e3, 4), "steps": esteps,
-                                "arithmetic": ARITH["f16+mxfp8"][1],
-                                "note": "option CONV_MX=1: NOT fp32-class (logits move 5e-6..1e-5 from the oracle instead of "
-                                        "~1e-6); reported for comparison only"}
-        nat.reset_option("CONV_MX")
         # (f) a TRAINING step (forward + cross-entropy + backward + SGD, train mode; agents/..._GAT.py:556-567) with the
         # CNN's convolutions and BatchNorm on this library's kernels (train_cnn.py) and on torch's (MIOpen / ATen); the graph
         # layer on its HIP forward / backward either way.  Not part of `value`.

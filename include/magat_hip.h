@@ -50,20 +50,28 @@ const char* magat_error_string(int code);
 
 /* Options.  Every tunable of the library lives in one table that is seeded from the environment (MAGAT_<NAME>) ONCE, at
  * first use, and is read / changed through these calls afterwards; nothing on the launch path calls getenv.  `name` with
- * or without the MAGAT_ prefix.  The ones a deployment may care about (the rest are A/B switches of the kernels, listed in
- * csrc/options.hip):
- *   RANGE_GUARD (1)  split-arithmetic range guard of the encoder: see magat_encoder_status
- *   CONV_MX     (0)  OPT-IN block-scaled fp8 correction planes in layer2 / layer3 (narrower than fp32-class arithmetic)
- *   CONV_SPLIT  (7)  bit l: BasicBlock l+1 on the f16x3 split kernels; 0 = every convolution on the fp32 MFMA kernel
- *   HEAD_SPLITK      largest agent count whose encoder head sums per-cell partials (0: one long-K GEMM, bit-exact resharding)
+ * or without the MAGAT_ prefix.  All seventeen (round 5: the A/B switches of kernel forms that lost their measurements are gone
+ * with those forms; csrc/options.hip holds the table):
+ *   RANGE_GUARD (1)  split-arithmetic range guard (encoder and graph layer): see magat_encoder_read_status
+ *   CONV_SPLIT  (7)  bit l: BasicBlock l+1 on the f16x3 split kernels; 0 = every convolution on the fp32 MFMA kernel (strict float32)
+ *   CONV_PCHAIN (1), CONV_TM (2)  activation layout / tile height of the f16x3 split GEMMs (f16 plane granules against
+ *                    float32 tiles, 256- against 128-agent tiles)
+ *   L1_FUSED    (2)  stem + layer1.conv1 as one kernel: 2 = eight-agent groups (11 x 11 maps), 1 = row bands, 0 = two launches
+ *   BLOCK_FUSED (2)  BasicBlock chain with the 6 x 6 maps of eight agents in LDS: 2 = layer1.conv2 -> layer2 -> layer3 -> pool as
+ *                    ONE launch, 1 = two launches, 0 = one launch per convolution
+ *   HEAD_F16    (1)  encoder head (and compressMLP) as f16x3 split products when its input is the chain kernel's pooled map
+ *   HEAD_COMPRESS (1) compressMLP in the head GEMM's epilogue (one launch, bit-identical; from 32 768 agents on)
+ *   HEAD_SPLITK (5120) largest agent count whose encoder head sums per-cell partials; decided on magat_encoder_desc.form_agents
+ *                    when a shard sets it (bit-exact resharding with default options)
  *   CONV_BNFILL (256) f16x3 GEMMs with few agent tiles (the head at a few thousand agents) narrow their 128-column tile to 64 / 32
  *                    until the launch has this many workgroups; results are bit-identical for every value
- *   BLOCK_FUSED (1), BLOCK3_FUSED (2)  BasicBlock chain kernels (maps of an 8-agent group in LDS); BLOCK3_FUSED 2 = the four-wave,
- *                    512-register form of the layer3 kernel, 1 = the eight-wave form, 0 = one launch per convolution
- *   BLOCK_FULL  (1)  both chain kernels as ONE launch (layer2's output never leaves the CU); needs BLOCK_FUSED 2, BLOCK3_FUSED 2
- *   HEAD_F16    (1)  encoder head (and compressMLP behind it) as f16x3 split products when its input is the layer3 kernel's pooled map
- *   GAT_MFMA    (1)  magat_gat_forward_*: KeyQuery, G = F = 128, N <= 101, K = 2 | 3, A_opt == NULL run as ONE launch of matrix-core
- *                    products (maps, scores, softmax, hops; csrc/gat_mfma.hip); 0 = maps GEMM + graph kernel
+ *   ENC_CHUNK (65536), GAT_CHUNK_MB (2048)  workspace bounds: agents per encoder pass, size of the two-launch graph layer's maps
+ *   GAT_MFMA    (1)  graph layer with G = F = 128, N <= 102, K = 2 | 3, A_opt == NULL as ONE launch of matrix-core products
+ *                    (maps, scores, softmax, hops; csrc/gat_mfma.hip; G = F in {32, 64}, N <= 32: csrc/gat_small.hip); 0 = maps
+ *                    GEMM + graph kernel;  GAT_SPLIT (1) that GEMM on the split kernels;  GAT_PACK (1) four instances per pass
+ *                    at N <= 32 once the batch fills the chip (bit-identical)
+ *   CSR_TILED   (3)  CSR path (N > 128 / bf16 storage): LDS-tiled score / hop kernels;  SKINNY (1) the action head as streamed
+ *                    dot products
  * Returns MAGAT_ERR_UNSUPPORTED for an unknown name. */
 int magat_set_option(const char* name, int value);
 int magat_get_option(const char* name, int* value);
@@ -427,7 +435,7 @@ typedef struct magat_conv_gemm_desc {
    * float32 2^-e (the in_fmt 4 weight block of that layer's own launch), in_scale2 as in_scale for that layer (NULL = 1).
    * compressMLP behind the encoder head: one launch instead of two, the 128-wide feature rows never re-read; bit for bit the
    * result of the two launches.  wt2 = NULL: no second layer.  Shapes the fused form does not take (narrowed column tiles of
-   * a small batch, option CONV_TEPI off, ...) return MAGAT_ERR_UNSUPPORTED before anything is launched - the caller then
+   * a small batch, misaligned rows, ...) return MAGAT_ERR_UNSUPPORTED before anything is launched - the caller then
    * issues the two layers on their own. */
   const void* wt2;
   const float* bias2;

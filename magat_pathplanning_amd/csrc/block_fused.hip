@@ -446,112 +446,6 @@ __device__ __forceinline__ void epi_rt(char* lds, int out_off, const int (&pix)[
 // row-tile groups of the 64-output-channel conv1 halves (as the chain kernel's stage B): 18 / 18 / 15 / 18 tile-taps
 __device__ constexpr int L3_G1[4][3] = {{T_I0, T_I1, -1}, {T_I2, T_I3, -1}, {T_C, T_ET, -1}, {T_EB, T_EL, T_ER}};
 
-__global__ __launch_bounds__(512, 2) void block3_kernel(const L3Params p) {
-  extern __shared__ __attribute__((aligned(1024))) char lds[];
-  constexpr int L_IN = 0, L_MID = MAP64;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int group = blockIdx.x;
-  if (group >= p.groups) return;
-  L3_STAMP(0);
-  for (int i = t; i < 32 * (PIXB / 4); i += 512)
-    *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
-  {   // input map: 16 (plane, chunk) blocks x 36 pixels x 128 B of this agent group
-    const int m0 = group * AG;
-    const long long tile_b = (long long)(m0 >> 7) * NPIX * (128 * 64 * 4) + (m0 & 127) * 16;
-    for (int item = wave; item < 16 * 5; item += 8) {
-      const int blk = item / 5, part = item % 5;             // blk = plane * 8 + chunk
-      const int pix = part * 8 + (lane >> 3);
-      const char* src = p.in + tile_b + (long long)pix * (128 * 64 * 4) + (blk >> 3) * (256 * 64) + (blk & 7) * 2048 +
-                        (lane & 7) * 16;
-      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(L_IN + blk * BLK + part * 8 * PIXB));
-      if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
-    }
-  }
-  const float s1 = *p.s1, s2 = *p.s2;
-  bool clamped = false;
-  const bool rows_ok = group * AG + ((lane & 31) & 7) < p.M;
-  // conv1 role of this wave (per half): channel tile ct1 of the half, row-tile group; conv2 role: output channel tile ct2,
-  // one of two row-tile groups
-  const int ct1 = wave & 1;
-  int tl1[3];
-#pragma unroll
-  for (int s = 0; s < 3; ++s) tl1[s] = L3_G1[wave >> 1][s];
-  const int ct2 = wave & 3, rg = wave >> 2;
-  int tl2[5];
-#pragma unroll
-  for (int s = 0; s < 5; ++s) tl2[s] = L3_RG[rg][s];
-  f32x16 acc[5];
-#pragma unroll
-  for (int s = 0; s < 5; ++s)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-  constexpr int BPT1 = 9 * 4 * 2, BPT2A = 9 * 4 * 2, BPT2B = (9 * 4 + 4) * 2;      // 1 KB blocks per channel tile
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  L3_STAMP(1);
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    {   // conv1, output channels 64 h .. 64 h + 63 -> MID (channel tiles 2 h, 2 h + 1 of the weight block)
-      f32x16 a1[3];
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
-      conv_walk<4, 0, 3>(lds, L_IN, 0, p.w1 + (size_t)(2 * h + ct1) * BPT1 * 1024 + lane * 16, tl1, a1);
-      epi_to_lds<64, 3>(lds, L_MID, tl1, a1, ct1, p.b1 + 64 * h, s1, rows_ok, clamped);
-    }
-    L3_STAMP(2 + 4 * h);
-    __syncthreads();
-    L3_STAMP(3 + 4 * h);
-    // conv2: K over these 64 intermediate channels (second half: + the residual 1x1 over the 64 input channels)
-    if (h == 0) conv_walk<4, 0, 5>(lds, L_MID, 0, p.w2a + (size_t)ct2 * BPT2A * 1024 + lane * 16, tl2, acc);
-    else conv_walk<4, 4, 5>(lds, L_MID, L_IN, p.w2b + (size_t)ct2 * BPT2B * 1024 + lane * 16, tl2, acc);
-    L3_STAMP(4 + 4 * h);
-    __syncthreads();          // MID is rewritten by the next half / becomes scratch
-    L3_STAMP(5 + 4 * h);
-  }
-  // ReLU'd output -> LDS scratch [pixel][agent][128 floats] (16-byte quads XOR-swizzled by the row: the 32 lanes that hold the
-  // same quad index then hit 32 different bank groups), then the 2x2 sums
-  float* S = reinterpret_cast<float*>(lds);
-  {
-    const int fr = lane & 31, fh = lane >> 5, agent = fr & 7, psl = fr >> 3;
-    f32x4 bq[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(p.b2 + 32 * ct2 + 8 * q + 4 * fh);
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-      if (tl2[s] < 0) continue;
-      const int pix = TILE_PIX[tl2[s]][psl];
-      const int row = pix * AG + agent;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 v;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * s2 + bq[q][c], 0.f);
-        const int Q = 8 * ct2 + 2 * q + fh;
-        *reinterpret_cast<f32x4*>(S + row * 128 + ((Q ^ (row & 31)) << 2)) = v;
-      }
-    }
-  }
-  __syncthreads();
-  for (int o = t; o < 9 * AG * 32; o += 512) {
-    const int Q = o & 31, agent = (o >> 5) & 7, cell = o >> 8;
-    const int cy = cell / 3, cx = cell - 3 * cy;
-    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int pix = (2 * cy + (e >> 1)) * 6 + 2 * cx + (e & 1);
-      const int row = pix * AG + agent;
-      sum += *reinterpret_cast<const f32x4*>(S + row * 128 + ((Q ^ (row & 31)) << 2));
-    }
-    const int m = group * AG + agent;
-    if (m < p.M)
-      *reinterpret_cast<f32x4*>(p.out + ((long long)(m >> 7) * 9 + cell) * (128 * 128) + (m & 127) * 128 + 4 * Q) = sum;
-  }
-  L3_STAMP(10);
-  if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
-}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // layer3, "w4" form: FOUR waves per workgroup, one per SIMD, each with the whole 512-entry register budget (256 arch + 256
@@ -699,58 +593,6 @@ __global__ __launch_bounds__(256, 1) void block3_w4_kernel(const L3Params p) {
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
-// PERSISTENT workgroups (one per CU), each walking agent groups g, g + grid, ...  The main input map of the NEXT group
-// (layer1.conv1's output, 37 KB) streams into a fourth LDS region with LDS-direct loads while stages B and C of the current
-// group run; only the 32-channel residual input is fetched at the top of an iteration (half of the 8.4 k-cycle prologue a
-// one-group-per-workgroup launch pays with nothing to overlap it; the other half does not fit: 5 x 37 KB > 160 KB).
-__global__ __launch_bounds__(512, 2) void block_chain_kernel(const ChainParams p) {
-  extern __shared__ __attribute__((aligned(1024))) char lds[];
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  // zero pixel of every (plane, chunk) block (32 blocks): written once, never overwritten
-  for (int i = t; i < 32 * (PIXB / 4); i += 512)
-    *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
-  // one 32-channel input map of an agent group: for (plane, chunk) the 36 pixels x 128 B, 8 pixels per LDS-direct instruction
-  auto dma_map = [&](const char* base, int group, int lds_off) {
-    const int m0 = group * AG;
-    const long long tile_b = (long long)(m0 >> 7) * NPIX * (128 * 32 * 4) + (m0 & 127) * 16;    // bytes: agent tile, agents
-    for (int item = wave; item < 8 * 5; item += 8) {
-      const int blk = item / 5, part = item % 5;             // blk = plane * 4 + chunk
-      const int pix = part * 8 + (lane >> 3);
-      const char* src = base + tile_b + (long long)pix * (128 * 32 * 4) + (blk >> 2) * (256 * 32) + (blk & 3) * 2048 +
-                        (lane & 7) * 16;
-      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(lds_off + blk * BLK + part * 8 * PIXB));
-      if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
-    }
-  };
-  const float sA = *p.sA, sB = *p.sB, sC = *p.sC;
-  bool clamped = false;
-  int group = blockIdx.x;
-  if (group < p.groups) dma_map(p.in1, group, LDS_X1N);
-  for (; group < p.groups; group += (int)gridDim.x) {
-    CHAIN_STAMP(0);
-    __syncthreads();            // every wave is done reading the previous group's maps (and the zero pixels are written)
-    dma_map(p.in2, group, LDS_X2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this group's main input (issued an iteration ago) + the residual input
-    __syncthreads();
-    CHAIN_STAMP(1);
-    // A: layer1.conv2 (32 -> 32) + downsample(stem stride-2 pixels)      X1 (prefetch region), X2 -> Y
-    chain_stage<32, 32, 32, false>(p, lds, LDS_X1N, LDS_X2, LDS_Y, p.wA, p.bA, sA, group, clamped);
-    CHAIN_STAMP(2);
-    __syncthreads();
-    CHAIN_STAMP(3);
-    if (group + (int)gridDim.x < p.groups) dma_map(p.in1, group + (int)gridDim.x, LDS_X1N);      // lands under stages B and C
-    // B: layer2.conv1 (32 -> 64)                                          Y -> Z
-    chain_stage<32, 0, 64, false>(p, lds, LDS_Y, 0, LDS_Z, p.wB, p.bB, sB, group, clamped);
-    CHAIN_STAMP(4);
-    __syncthreads();
-    CHAIN_STAMP(5);
-    // C: layer2.conv2 (64 -> 64) + downsample(Y)                          Z, Y -> global
-    chain_stage<64, 32, 64, true>(p, lds, LDS_Z, LDS_Y, 0, p.wC, p.bC, sC, group, clamped);
-    CHAIN_STAMP(6);
-  }
-  if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
-}
 
 // ---- the chain kernel in the four-wave form (see walk4): stage A = one channel tile, the nine row tiles dealt to the four
 // waves; stages B and C = (channel tile, one of two row-tile groups) per wave
@@ -921,169 +763,9 @@ __global__ __launch_bounds__(256, 1) void block_chain_w4_kernel(const ChainParam
 //   layer3: IN (U0', U1'), MID (U2', U3'); pooled epilogue scratch in MID; meanwhile the next X1 -> U1', X2 -> U0' (= its U3'', U2'').
 struct FullParams { ChainParams c; L3Params l; };
 
-__global__ __launch_bounds__(256, 1) void block_full_w4_kernel(const FullParams q) {
-  extern __shared__ __attribute__((aligned(1024))) char lds[];
-  const ChainParams& p = q.c;
-  const L3Params& l3 = q.l;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  for (int i = t; i < 32 * (PIXB / 4); i += 256)
-    *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
-  // items first, first + step, ... < last of the 40 LDS-direct instructions of one 32-channel input map
-  auto dma_map = [&](const char* base, int group, int lds_off, int first, int step, int last) {
-    const int m0 = group * AG;
-    const long long tile_b = (long long)(m0 >> 7) * NPIX * (128 * 32 * 4) + (m0 & 127) * 16;    // bytes: agent tile, agents
-    for (int item = first; item < last; item += step) {
-      const int blk = item / 5, part = item % 5;             // blk = plane * 4 + chunk
-      const int pix = part * 8 + (lane >> 3);
-      const char* src = base + tile_b + (long long)pix * (128 * 32 * 4) + (blk >> 2) * (256 * 32) + (blk & 3) * 2048 +
-                        (lane & 7) * 16;
-      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(lds_off + blk * BLK + part * 8 * PIXB));
-      if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
-    }
-  };
-  const float sA = *p.sA, sB = *p.sB, sC = *p.sC, s1 = *l3.s1, s2 = *l3.s2;
-  bool clamped = false;
-  const int ct = wave & 1, rg = wave >> 1, ct2 = wave;
-  constexpr int BPT1 = 9 * 4 * 2, BPT2A = 9 * 4 * 2, BPT2B = (9 * 4 + 4) * 2;      // 1 KB blocks per channel tile (layer3)
-  f32x4 bq[4];                      // conv2's bias (loaded once: a load behind the input DMA would wait for it)
-  {
-    const int fh = lane >> 5;
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const f32x4*>(l3.b2 + 32 * ct2 + 8 * qd + 4 * fh);
-  }
-  const int gstride = (int)gridDim.x;
-  int parity = 0;
-  if ((int)blockIdx.x < p.groups) {
-    dma_map(p.in1, blockIdx.x, 3 * MAP32, wave, 4, 40);
-    dma_map(p.in2, blockIdx.x, 2 * MAP32, wave, 4, 40);
-  }
-#pragma unroll 1
-  for (int group = blockIdx.x; group < p.groups; group += gstride, parity ^= 1) {
-    const int U0 = parity ? 2 * MAP32 : 0, U1 = U0 + MAP32, U2 = parity ? 0 : 2 * MAP32, U3 = U2 + MAP32;
-    const bool rows_ok = group * AG + ((lane & 31) & 7) < p.M;
-    const bool more = group + gstride < p.groups;
-    FULL_STAMP(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this group's inputs (requested during the previous group's epilogue)
-    __syncthreads();
-    FULL_STAMP(1);
-    // A: layer1.conv2 (32 -> 32) + downsample(stem stride-2 pixels)      X1 @ U3, X2 @ U2 -> Y @ U1
-    switch (wave) {
-      case 0: chain_stage4<W4P0, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
-      case 1: chain_stage4<W4P1, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
-      case 2: chain_stage4<W4P2, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
-      default: chain_stage4<W4P3, 32, 32, 32, false>(p, lds, U3, U2, U1, p.wA, 0, p.bA, sA, group, clamped); break;
-    }
-    __syncthreads();
-    FULL_STAMP(2);
-    // B: layer2.conv1 (32 -> 64)                                          Y @ U1 -> Z @ (U2, U3)
-    if (rg == 0) chain_stage4<W4A, 32, 0, 64, false>(p, lds, U1, 0, U2, p.wB, ct, p.bB, sB, group, clamped);
-    else chain_stage4<W4B, 32, 0, 64, false>(p, lds, U1, 0, U2, p.wB, ct, p.bB, sB, group, clamped);
-    __syncthreads();
-    FULL_STAMP(3);
-    // C: layer2.conv2 (64 -> 64) + downsample(Y)                          Z @ (U2, U3), Y @ U1 -> layer3's input @ (U0, U1)
-    if (rg == 0) chain_stage4<W4A, 64, 32, 64, false, true>(p, lds, U2, U1, U0, p.wC, ct, p.bC, sC, group, clamped);
-    else chain_stage4<W4B, 64, 32, 64, false, true>(p, lds, U2, U1, U0, p.wC, ct, p.bC, sC, group, clamped);
-    __syncthreads();
-    FULL_STAMP(4);
-    // layer3: IN = (U0, U1), MID = (U2, U3)
-    const int L_IN = U0, L_MID = U2;
-    const int ct1 = ct, rg1 = rg;
-    f32x16 acc[9];
-#pragma unroll
-    for (int s = 0; s < 9; ++s)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-      const char* w1 = l3.w1 + (size_t)(2 * h + ct1) * BPT1 * 1024;
-      const char* w2 = h == 0 ? l3.w2a + (size_t)ct2 * BPT2A * 1024 : l3.w2b + (size_t)ct2 * BPT2B * 1024;
-      if (rg1 == 0) {
-        f32x16 a1[W4A::NT];
-#pragma unroll
-        for (int s = 0; s < W4A::NT; ++s)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
-        walk4<W4A, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1, a1, false);
-        if (h == 0) FULL_STAMP(11);
-        const int tl[W4A::NT] = {W4A::t[0], W4A::t[1], W4A::t[2], W4A::t[3]};
-        epi_to_lds<64, W4A::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
-      } else {
-        f32x16 a1[W4B::NT];
-#pragma unroll
-        for (int s = 0; s < W4B::NT; ++s)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) a1[s][r] = 0.f;
-        walk4<W4B, 4, 0, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_IN, 0, w1, a1, false);
-        if (h == 0) FULL_STAMP(11);
-        const int tl[W4B::NT] = {W4B::t[0], W4B::t[1], W4B::t[2], W4B::t[3], W4B::t[4]};
-        epi_to_lds<64, W4B::NT>(lds, L_MID, tl, a1, ct1, l3.b1 + 64 * h, s1, rows_ok, clamped);
-      }
-      if (h == 0) FULL_STAMP(12);
-      __syncthreads();
-      FULL_STAMP(5 + 2 * h);
-      walk4<W4All, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_MID, L_IN, w2, acc, h == 1);
-      __syncthreads();          // MID is rewritten by the next half / becomes scratch; after the second half IN is dead too
-      FULL_STAMP(6 + 2 * h);
-    }
-    // pooled epilogue, 64 channels per pass in the MID region; the two waves with nothing to write in a pass request the NEXT
-    // group's inputs into the dead IN region: X1 -> U1 (its U3 after the rotation), X2 -> U0 (its U2)
-    float* S = reinterpret_cast<float*>(lds + L_MID);
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      if ((ct2 >> 1) != half) {
-        if (more) {
-          if (half == 0) dma_map(p.in1, group + gstride, U1, wave & 1, 2, 40);
-          else dma_map(p.in2, group + gstride, U0, wave & 1, 2, 40);
-        }
-      } else {
-        const int fr = lane & 31, fh = lane >> 5, agent = fr & 7, psl = fr >> 3;
-#pragma unroll
-        for (int s = 0; s < 9; ++s) {
-          const int pix = tile_pix(W4All::t[s], psl);
-          const int row = pix * AG + agent;
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            f32x4 v;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * qd + c] * s2 + bq[qd][c], 0.f);
-            const int Q = 8 * (ct2 & 1) + 2 * qd + fh;
-            *reinterpret_cast<f32x4*>(S + row * 64 + ((Q ^ (row & 15)) << 2)) = v;
-          }
-        }
-      }
-      if (half == 0) FULL_STAMP(13);
-      L3_LDS_SYNC();
-      if (half == 0) FULL_STAMP(14);
-      for (int o = t; o < 9 * AG * 16; o += 256) {
-        const int Q = o & 15, agent = (o >> 4) & 7, cell = o >> 7;
-        const int cy = cell / 3, cx = cell - 3 * cy;
-        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int pix = (2 * cy + (e >> 1)) * 6 + 2 * cx + (e & 1);
-          const int row = pix * AG + agent;
-          sum += *reinterpret_cast<const f32x4*>(S + row * 64 + ((Q ^ (row & 15)) << 2));
-        }
-        const int m = group * AG + agent;
-        if (m < p.M)
-          *reinterpret_cast<f32x4*>(l3.out + ((long long)(m >> 7) * 9 + cell) * (128 * 128) + (m & 127) * 128 + 64 * half +
-                                    4 * Q) = sum;
-      }
-      if (half == 0) FULL_STAMP(15);
-      L3_LDS_SYNC();
-      if (half == 0) FULL_STAMP(9);
-    }
-    // the scratch ran over the zero pixel slots of the MID blocks
-    for (int i = t; i < 16 * (PIXB / 4); i += 256)
-      *reinterpret_cast<unsigned*>(lds + L_MID + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
-    FULL_STAMP(10);
-  }
-  if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
-}
 
 
-// ---- block_full_w4_kernel with the 2 x 2 pooling done in REGISTERS (option BLOCK_FULL = 2).  The pooled epilogue of the kernel
+// ---- The one-launch kernel (option BLOCK_FUSED = 2, the default) with the 2 x 2 pooling done in REGISTERS.  The pooled epilogue of the kernel
 // above costs 14 k of a group's 162 k cycles with the matrix pipe idle: the 144 accumulators go through an LDS scratch in two
 // passes (scratch writes, barrier, pooling reads, barrier, zero-slot repair).  With the slot order of TILE_PIX a lane holds, for
 // its 16 channels: one whole corner cell (4 registers of 4 tiles), two half cells whose other halves sit one lane-bit away,
@@ -1258,217 +940,11 @@ __global__ __launch_bounds__(256, 1) void block_full_p_kernel(const FullParams q
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
-// ---- The compact form of block_full_p_kernel (option BLOCK_FULL = 3): the same products in the same order from a loop body
-// that is meant to fit the 64 KB instruction cache two CUs share (in the 107 KB loop of block_full_p_kernel every
-// walk runs at 84-87 % of its MFMA issue rate where the same walk in a kernel that fits runs at 93-95 %).  One body per
-// structure: waves 0 / 1 of stage A share theirs (run-time pixels), stage C and the two conv1 halves are three passes of one
-// loop, every stage has ONE split-and-store epilogue for both row-group roles (run-time pixels, the fifth tile skipped by the
-// interior role).
-// FORM 0: straight-line walks.  1: the interior-tile role of the 64 -> 64 walks (stage C, conv1) as a rolled loop over the tap rows
-// (walk_rows4).  2: + layer3.conv2 as two passes per half - its four interior tiles through walk_rows4, its five edge / corner
-// tiles through the edge role's straight-line walk (the weight stream of a channel tile is read twice).
-template <int FORM>
-__global__ __launch_bounds__(256, 1) void block_full_c_kernel(const FullParams q) {
-  extern __shared__ __attribute__((aligned(1024))) char lds[];
-  const ChainParams& p = q.c;
-  const L3Params& l3 = q.l;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  for (int i = t; i < 32 * (PIXB / 4); i += 256)
-    *reinterpret_cast<unsigned*>(lds + (i / (PIXB / 4)) * BLK + ZPIX * PIXB + (i % (PIXB / 4)) * 4) = 0u;
-  auto dma_map = [&](const char* base, int group, int lds_off, int first, int step, int last) {
-    const int m0 = group * AG;
-    const long long tile_b = (long long)(m0 >> 7) * NPIX * (128 * 32 * 4) + (m0 & 127) * 16;    // bytes: agent tile, agents
-    for (int item = first; item < last; item += step) {
-      const int blk = item / 5, part = item % 5;             // blk = plane * 4 + chunk
-      const int pix = part * 8 + (lane >> 3);
-      const char* src = base + tile_b + (long long)pix * (128 * 32 * 4) + (blk >> 2) * (256 * 32) + (blk & 3) * 2048 +
-                        (lane & 7) * 16;
-      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)(lds_off + blk * BLK + part * 8 * PIXB));
-      if (pix < NPIX) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" MAGAT_CHAIN_NT_STR ::"v"(src), "s"(m0v) : "memory", "m0");
-    }
-  };
-  const float sA = *p.sA, sB = *p.sB, sC = *p.sC, s1 = *l3.s1, s2 = *l3.s2;
-  bool clamped = false;
-  const int ct = wave & 1, rg = wave >> 1, ct2 = wave;
-  constexpr int BPT1 = 9 * 4 * 2, BPT2A = 9 * 4 * 2, BPT2B = (9 * 4 + 4) * 2;      // 1 KB blocks per channel tile (layer3)
-  f32x4 bq[4];                      // conv2's bias (loaded once: a load behind the input DMA would wait for it)
-  {
-    const int fh = lane >> 5;
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const f32x4*>(l3.b2 + 32 * ct2 + 8 * qd + 4 * fh);
-  }
-  FULL_CLOCKS(0);
-  const int gstride = (int)gridDim.x;
-  constexpr int U0 = 0, U1 = MAP32, U2 = 2 * MAP32, U3 = 3 * MAP32;
-  if ((int)blockIdx.x < p.groups) {
-    dma_map(p.in1, blockIdx.x, U3, wave, 4, 40);
-    dma_map(p.in2, blockIdx.x, U2, wave, 4, 40);
-  }
-#pragma unroll 1
-  for (int group = blockIdx.x; group < p.groups; group += gstride) {
-    const bool rows_ok = group * AG + ((lane & 31) & 7) < p.M;
-    const bool more = group + gstride < p.groups;
-    FULL_STAMP(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this group's inputs (requested during the previous group's epilogue)
-    __syncthreads();
-    FULL_STAMP(1);
-    const int fr_ = lane & 31, psl_ = fr_ >> 3;
-    // A: layer1.conv2 (32 -> 32) + downsample(stem stride-2 pixels)      X1 @ U3, X2 @ U2 -> Y @ U1
-    // (waves 0 and 1 - two interior tiles each, every tap valid - run ONE body with their pixels as run-time values)
-    {
-      f32x16 a[3];
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[s][r] = 0.f;
-      int pix[3];
-      if (wave < 2) {
-        pix[0] = wave ? tile_pix(T_I2, psl_) : tile_pix(T_I0, psl_);
-        pix[1] = wave ? tile_pix(T_I3, psl_) : tile_pix(T_I1, psl_);
-        pix[2] = -1;
-        walk4<W4P0, 2, 2, 4 * BLK, 4 * BLK, w4_depth(2, 2), GeoChain, 3, true>(lds, U3, U2, p.wA, a, true, pix);
-      } else if (wave == 2) {
-        pix[0] = tile_pix(W4P2::t[0], psl_); pix[1] = tile_pix(W4P2::t[1], psl_); pix[2] = -1;
-        walk4<W4P2, 2, 2, 4 * BLK, 4 * BLK, w4_depth(2, 2), GeoChain, 3>(lds, U3, U2, p.wA, a, true);
-      } else {
-        pix[0] = tile_pix(W4P3::t[0], psl_); pix[1] = tile_pix(W4P3::t[1], psl_); pix[2] = tile_pix(W4P3::t[2], psl_);
-        walk4<W4P3, 2, 2, 4 * BLK, 4 * BLK, w4_depth(3, 2), GeoChain, 3>(lds, U3, U2, p.wA, a, true);
-      }
-      epi_rt<32, 3>(lds, U1, pix, a, 0, p.bA, sA, rows_ok, clamped);
-    }
-    __syncthreads();
-    FULL_STAMP(2);
-    // row-group roles of the 64-channel stages: their pixels, and one accumulator array / one epilogue for both
-    int pix5[5];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) pix5[s] = rg ? tile_pix(W4E::t[s], psl_) : tile_pix(W4I::t[s], psl_);
-    pix5[4] = rg ? tile_pix(W4E::t[4], psl_) : -1;
-    // B: layer2.conv1 (32 -> 64)                                          Y @ U1 -> Z @ (U2, U3)
-    {
-      f32x16 a[5];
-#pragma unroll
-      for (int s = 0; s < 5; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[s][r] = 0.f;
-      if (rg == 0) walk4<W4I, 2, 0, 4 * BLK, BLK, w4_depth(W4I::NT, 2), GeoChain, 5>(lds, U1, 0, p.wB + (size_t)ct * (36 * 1024), a, true);
-      else walk4<W4E, 2, 0, 4 * BLK, BLK, w4_depth(W4E::NT, 2), GeoChain, 5>(lds, U1, 0, p.wB + (size_t)ct * (36 * 1024), a, true);
-      epi_rt<64, 5>(lds, U2, pix5, a, ct, p.bB, sB, rows_ok, clamped);
-    }
-    __syncthreads();
-    FULL_STAMP(3);
-    // Stage C and the two halves of layer3.conv1 are the same walk (64 -> 64 channels, 3 x 3, the same two tile lists; C has a
-    // residual segment of two k steps on top) and the same split-and-store epilogue: three passes through ONE body per role.
-    // Pass 0 = stage C (Z @ U2, Y @ U1 -> IN @ U0), passes 1 / 2 = conv1 halves (IN -> MID @ U2), each followed by its half
-    // of conv2.
-    constexpr int L_IN = U0, L_MID = U2;
-    const int ct1 = ct;
-    f32x16 acc[9];
-#pragma unroll 1
-    for (int it = 0; it < 3; ++it) {
-      const int in_off = it == 0 ? U2 : L_IN, out_off = it == 0 ? U0 : L_MID;
-      const char* wts = it == 0 ? p.wC + (size_t)ct * (76 * 1024) : l3.w1 + (size_t)(2 * (it - 1) + ct1) * BPT1 * 1024;
-      const float* bias = it == 0 ? p.bC : l3.b1 + 64 * (it - 1);
-      const float scale = it == 0 ? sC : s1;
-      f32x16 a[5];
-#pragma unroll
-      for (int s = 0; s < 5; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[s][r] = 0.f;
-      if (rg == 0) {
-        if constexpr (FORM >= 1) {
-          const int pixI[4] = {pix5[0], pix5[1], pix5[2], pix5[3]};
-          walk_rows4<4, 2, 8 * BLK, 4 * BLK, 5>(lds, in_off, U1, wts, a, it == 0, pixI);
-        } else {
-          walk4<W4I, 4, 2, 8 * BLK, 4 * BLK, MAGAT_W4_D, GeoChain, 5>(lds, in_off, U1, wts, a, it == 0);
-        }
-      } else {
-        walk4<W4E, 4, 2, 8 * BLK, 4 * BLK, MAGAT_W4_D, GeoChain, 5>(lds, in_off, U1, wts, a, it == 0);
-      }
-      if (it == 1) FULL_STAMP(11); else if (it == 2) FULL_STAMP(13);
-      if (it == 0) __syncthreads();       // (stage C's output overwrites Y @ U1, which other waves read until their walks end)
-      epi_rt<64, 5>(lds, out_off, pix5, a, ct, bias, scale, rows_ok, clamped);
-      if (it == 1) FULL_STAMP(12); else if (it == 2) FULL_STAMP(14);
-      __syncthreads();
-      if (it == 0) {
-        FULL_STAMP(4);
-#pragma unroll
-        for (int s = 0; s < 9; ++s)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-      } else {
-        const int h = it - 1;
-        const char* w2 = h == 0 ? l3.w2a + (size_t)ct2 * BPT2A * 1024 : l3.w2b + (size_t)ct2 * BPT2B * 1024;
-        FULL_STAMP(5 + 2 * h);
-        if constexpr (FORM >= 2) {
-          const int pixI[4] = {tile_pix(W4I::t[0], psl_), tile_pix(W4I::t[1], psl_), tile_pix(W4I::t[2], psl_), tile_pix(W4I::t[3], psl_)};
-          walk_rows4<4, 4, 8 * BLK, 8 * BLK, 9>(lds, L_MID, L_IN, w2, acc, h == 1, pixI);                  // acc[0..3]: interior tiles
-          walk4<W4E, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D, GeoChain, 5>(lds, L_MID, L_IN, w2, reinterpret_cast<f32x16(&)[5]>(acc[4]), h == 1);
-        } else {
-          walk4<W4All, 4, 4, 8 * BLK, 8 * BLK, MAGAT_W4_D>(lds, L_MID, L_IN, w2, acc, h == 1);
-        }
-        L3_LDS_SYNC();
-        FULL_STAMP(6 + 2 * h);
-      }
-    }
-    // the next group's inputs -> the MID region, X1 @ U3, X2 @ U2: in flight under the pooling below
-    if (more) {
-      dma_map(p.in1, group + gstride, U3, wave, 4, 40);
-      dma_map(p.in2, group + gstride, U2, wave, 4, 40);
-    }
-    FULL_STAMP(9);
-    // ---- relu(acc * s2 + bias), 2 x 2 sums in registers, stores.  Accumulator s = tile W4All::t[s]:
-    //      0..3 interior tiles Ia Ib Ic Id, 4 C, 5 T (top), 6 B (bottom), 7 L (left), 8 R (right)
-    {
-      const int fr = lane & 31, fh = lane >> 5, agent = fr & 7;
-      const bool lo = (lane >> 3) & 1, hi = (lane >> 4) & 1;       // slot psl = 2 hi + lo
-      const int m = group * AG + agent;
-      // cells of this lane: its corner cell, the row-edge-middle cell it shares with the lane 8 away, the column-edge-middle
-      // cell it shares with the lane 16 away, the centre cell (shared by all four slots)
-      const int cellF = 2 * (int)lo + 6 * (int)hi, cell0 = hi ? 1 : 7, cell1 = lo ? 3 : 5;
-      // row-major tiles [cell][128 agents][128 channels], or granule-major ones [cell][32 granules][128 agents][4 channels]
-      // (magat_hip.h in_gl = 1: what the encoder head's loader reads as 512 contiguous bytes per half wave; here the eight
-      // agents of a group make one 128-byte run per store instead of eight 16-byte pieces 512 bytes apart)
-      float* ob = l3.out + (long long)(m >> 7) * 9 * (128 * 128) +
-                  (l3.out_gl ? (8 * ct2 + fh) * 512 + (m & 127) * 4 : (m & 127) * 128 + 32 * ct2 + 4 * fh);
-      const int qstep = l3.out_gl ? 1024 : 8;       // channel quads 2 qd (+ fh) of this wave's 32 channels
-      const bool mok = m < p.M;
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        f32x4 vF, v0, v1, v2;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int r = 4 * qd + c;
-          float v[9];
-#pragma unroll
-          for (int s = 0; s < 9; ++s) v[s] = magat_relu(__builtin_fmaf(acc[s][r], s2, bq[qd][c]));      // (keeps NaN, like torch.relu)
-          const float u = hi ? v[6] : v[5], ux = hi ? v[5] : v[6];
-          const float w_ = lo ? v[8] : v[7], wx = lo ? v[7] : v[8];
-          vF[c] = (v[4] + v[0]) + (u + w_);
-          const float p0 = ux + v[1], p1 = wx + v[2], p2 = v[3];
-          v0[c] = p0 + dpp_mov<0x128>(p0);                       // + the lane 8 away (row_ror:8)
-          v1[c] = p1 + __shfl_xor(p1, 16, 64);                   // + the lane 16 away
-          const float p2b = p2 + dpp_mov<0x128>(p2);
-          v2[c] = p2b + __shfl_xor(p2b, 16, 64);
-        }
-        if (mok) {
-          CHAIN_OUT_STORE(ob + (long long)cellF * (128 * 128) + qstep * qd, vF);
-          if (!lo) CHAIN_OUT_STORE(ob + (long long)cell0 * (128 * 128) + qstep * qd, v0);
-          if (!hi) CHAIN_OUT_STORE(ob + (long long)cell1 * (128 * 128) + qstep * qd, v1);
-          if (!lo && !hi) CHAIN_OUT_STORE(ob + (long long)4 * (128 * 128) + qstep * qd, v2);
-        }
-      }
-    }
-    FULL_STAMP(10);
-  }
-  FULL_CLOCKS(1);
-  if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
-}
 
 }  // namespace
 
 // 1 when magat_block_full can write its pooled map granule-major (out_gl = 1) with the current options
-int magat_block_full_out_gl() { return magat_opt(MAGAT_OPT_BLOCK_FULL) >= 2 ? 1 : 0; }
+int magat_block_full_out_gl() { return 1; }
 
 // bytes of one stage's fragment-major weight block (without the trailing scale float)
 static size_t chain_block_bytes(int cin, int c2, int cout) { return (size_t)(cout / 32) * (9 * (cin / 16) + c2 / 16) * 2 * 1024; }
@@ -1503,10 +979,7 @@ int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, l
 #ifdef MAGAT_DEBUG_HOOKS
   p.dbg = g_chain_dbg;
 #endif
-  const bool w4 = magat_opt(MAGAT_OPT_BLOCK_FUSED) >= 2;       // 2: four waves x 512 registers; 1: eight waves x 256
-  if (magat_ensure_dyn_lds(w4 ? reinterpret_cast<const void*>(&block_chain_w4_kernel)
-                              : reinterpret_cast<const void*>(&block_chain_kernel),
-                           w4 ? MAGAT_LDS_BLOCK_B4 : MAGAT_LDS_BLOCK_A, LDS_TOTAL) != MAGAT_OK)
+  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block_chain_w4_kernel), MAGAT_LDS_BLOCK_B4, LDS_TOTAL) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -1515,8 +988,7 @@ int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, l
   }
   const int grid = p.groups < cus ? p.groups : cus;
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_CHAIN, st);
-  if (w4) hipLaunchKernelGGL(block_chain_w4_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, p);
-  else hipLaunchKernelGGL(block_chain_kernel, dim3((unsigned)grid), dim3(512), LDS_TOTAL, st, p);
+  hipLaunchKernelGGL(block_chain_w4_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
@@ -1545,26 +1017,16 @@ int magat_block3(const void* in, float* out, const float* w, const float* b1, co
   p.dbg = g_block3_dbg;
 #endif
   constexpr size_t lds = 2 * MAP64;
-  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block3_kernel), MAGAT_LDS_BLOCK_B, lds) != MAGAT_OK)
-    return MAGAT_ERR_LAUNCH;
-  const bool w4 = magat_opt(MAGAT_OPT_BLOCK3_FUSED) >= 2;      // 2: four waves x 512 registers; 1: eight waves x 256
-  if (w4 && magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block3_w4_kernel), MAGAT_LDS_BLOCK_C, lds) != MAGAT_OK)
+  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block3_w4_kernel), MAGAT_LDS_BLOCK_C, lds) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK3, st);
-  if (w4) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      int v = 0;
-      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
-#ifdef MAGAT_B3W4_ONESHOT
-    const int grid = p.groups;
-#else
-    const int grid = p.groups < cus ? p.groups : cus;
-#endif
-    hipLaunchKernelGGL(block3_w4_kernel, dim3((unsigned)grid), dim3(256), lds, st, p);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  else hipLaunchKernelGGL(block3_kernel, dim3((unsigned)p.groups), dim3(512), lds, st, p);
+  const int grid = p.groups < cus ? p.groups : cus;
+  hipLaunchKernelGGL(block3_w4_kernel, dim3((unsigned)grid), dim3(256), lds, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
@@ -1575,7 +1037,7 @@ extern "C" int magat_block3_set_debug_buffer(long long* dev_buf) { g_block3_dbg 
 #endif
 
 
-// layer1.conv2 -> layer2 -> layer3 -> pool as ONE launch (block_full_w4_kernel).  Arguments: those of magat_block_chain (without
+// layer1.conv2 -> layer2 -> layer3 -> pool as ONE launch (block_full_p_kernel).  Arguments: those of magat_block_chain (without
 // its output) and of magat_block3 (without its input).
 int magat_block_full(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
                      float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st,
@@ -1611,20 +1073,9 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
 #ifdef MAGAT_DEBUG_HOOKS
   l.dbg = g_block3_dbg;
 #endif
-  const bool pooled_regs = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 2;      // 2: pooling in registers (block_full_p_kernel)
-  const bool compact = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 3;          // 3: + the compact loop body (block_full_c_kernel)
-  const bool rows = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 4;             // 4: + its interior walks rolled over the tap rows
-  const bool twopass = magat_opt(MAGAT_OPT_BLOCK_FULL) >= 5;          // 5: + conv2 as an interior pass and an edge pass
-  if (out_gl != 0 && !(out_gl == 1 && pooled_regs)) return MAGAT_ERR_UNSUPPORTED;      // (magat_block_full_out_gl() tells)
+  if (out_gl != 0 && out_gl != 1) return MAGAT_ERR_UNSUPPORTED;
   l.out_gl = out_gl;
-  if (magat_ensure_dyn_lds(twopass ? reinterpret_cast<const void*>(&block_full_c_kernel<2>)
-                           : rows ? reinterpret_cast<const void*>(&block_full_c_kernel<1>)
-                           : compact ? reinterpret_cast<const void*>(&block_full_c_kernel<0>)
-                           : pooled_regs ? reinterpret_cast<const void*>(&block_full_p_kernel)
-                                         : reinterpret_cast<const void*>(&block_full_w4_kernel),
-                           twopass ? MAGAT_LDS_BLOCK_FULL_C5 : rows ? MAGAT_LDS_BLOCK_FULL_C4 : compact ? MAGAT_LDS_BLOCK_FULL_C : pooled_regs ? MAGAT_LDS_BLOCK_FULL_P
-                                                                                    : MAGAT_LDS_BLOCK_FULL,
-                           LDS_TOTAL) != MAGAT_OK)
+  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block_full_p_kernel), MAGAT_LDS_BLOCK_FULL_P, LDS_TOTAL) != MAGAT_OK)
     return MAGAT_ERR_LAUNCH;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -1634,11 +1085,7 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
   const int grid = p.groups < cus ? p.groups : cus;
   if (p.groups > cus) magat_form_note(MAGAT_FORM_CHAIN_PERSIST);
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_FULL, st);
-  if (twopass) hipLaunchKernelGGL(block_full_c_kernel<2>, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
-  else if (rows) hipLaunchKernelGGL(block_full_c_kernel<1>, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
-  else if (compact) hipLaunchKernelGGL(block_full_c_kernel<0>, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
-  else if (pooled_regs) hipLaunchKernelGGL(block_full_p_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
-  else hipLaunchKernelGGL(block_full_w4_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
+  hipLaunchKernelGGL(block_full_p_kernel, dim3((unsigned)grid), dim3(256), LDS_TOTAL, st, q);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }

@@ -50,8 +50,8 @@ struct SplitParams {
   int Cout, Ktot, ldc, relu;
   int ntn, npix, tag, out_split;
   long long out_nt;         // direct kernel, row-major output: column tile t at out + t * out_nt (0: column 128 t of the row)
-  int tepi;                 // direct kernel: row-major float32 output transposed through LDS (MAGAT_CONV_TEPI)
-  int korder;               // direct kernel: 1 = channel slab outer, taps inner (MAGAT_CONV_KORDER)
+  int tepi;                 // direct kernel: row-major float32 output transposed through LDS (always 1 since round 5)
+  int korder;               // direct kernel: 1 = channel slab outer, taps inner (always 1 since round 5)
   int in_gl, out_gl;        // direct kernel: granule-major agent tiles [C/4][128][4] for in/in2 resp. out
   const float* acc_scale;   // NPL == 2: device pointer to 1 / (power-of-two weight scale), applied before the bias
   const float* in_scale;    // direct kernel, float32 input: power-of-two activation scale (device float; null or 0 = 1)
@@ -492,11 +492,6 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 // PIN: in / in2 arrive as f16 PLANE PAIRS in the plane-granule layout (in_gl = 2, magat_hip.h): the producer's epilogue
 // split every value once, the loader here fetches finished 16-byte MFMA operands and does no VALU work at all (with
 // float32 input every value is split once per tap it is used by - 7 times on a 6x6 map).
-// INF 2 (in_gl = 3, "f16 + MX correction"): plane 0 as above, plane 1 carries, per agent and 32-channel tile, 32 bytes
-// e4m3(h1) and 32 bytes e4m3(h2 * 2^11) instead of the f16 h2; the weights' plane 1 carries [e4m3(g2 * 2^5) | e4m3(g1 * 2^-6)]
-// per row and slab.  Per slab: two f16 MFMAs (h1 g1) and ONE v_mfma_scale_f32_32x32x64_f8f6f4 whose K = 64 is
-// [q(h1) | q(h2)] . [q(g2) ; q(g1)] - lanes 0-31 hold K block 0, lanes 32-63 block 1, one power-of-two scale per block.
-// Same bytes moved as the f16x3 form, half the matrix passes; logits move by 4e-6 (tests/arith_probe.py).
 // FUSE2 (BN = 128 = Cout, TM = 1, float32 input, one output pixel, row-major float32 output; round 5): a SECOND 1x1 layer of
 // 128 outputs on the workgroup's finished rows - compressMLP behind the encoder head - computed in the epilogue: a wave holds
 // its 32 agents' complete 128-wide rows in its accumulators, so the rows become the second layer's activation planes in
@@ -506,7 +501,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const SplitPar
 // same products in the same order on the same planes); saves a launch and the re-read of the rows (19 us -> ~8 at c3).
 template <int BN, int TM, int INF, bool FUSE2 = false>
 __global__ __launch_bounds__(256, (TM == 1 && !FUSE2) ? 3 : 2) void conv_gemm_f16x3_direct_kernel(const SplitParams p) {
-  constexpr bool PIN = INF >= 1, MX = INF == 2;
+  constexpr bool PIN = INF >= 1;
   static_assert(!FUSE2 || (BN == 128 && TM == 1 && INF == 0), "FUSE2: whole 128-wide rows per wave, float32 input");
   constexpr int TN = BN / 32;
   constexpr int STAGE = 2 * BN * 64;                    // bytes per weight stage: two planes of BN rows x 64 B
@@ -657,13 +652,8 @@ __global__ __launch_bounds__(256, (TM == 1 && !FUSE2) ? 3 : 2) void conv_gemm_f1
     const char* a = na[i];
     fa[i][0] = *reinterpret_cast<const u32x4*>(a);
     fa[i][1] = *reinterpret_cast<const u32x4*>(a + d1);
-    if constexpr (MX) {     // plane 1: this lane's K block = granules 2 fh, 2 fh + 1 of the tile (aoff already has + 2048 fh)
-      fa[i][2] = *reinterpret_cast<const u32x4*>(a + nd2 + fh * 2048);
-      fa[i][3] = *reinterpret_cast<const u32x4*>(a + nd2 + fh * 2048 + 2048);
-    } else {
-      fa[i][2] = *reinterpret_cast<const u32x4*>(a + nd2);
-      fa[i][3] = *reinterpret_cast<const u32x4*>(a + nd2 + d1);
-    }
+    fa[i][2] = *reinterpret_cast<const u32x4*>(a + nd2);
+    fa[i][3] = *reinterpret_cast<const u32x4*>(a + nd2 + d1);
   };
   // (the LDS-direct loads always go out AFTER the register loads of the slab: vmcnt retires in order, so the compiler's
   // waits for the activation registers - it cannot see the asm loads - never include the weight fill)
@@ -767,71 +757,7 @@ __global__ __launch_bounds__(256, (TM == 1 && !FUSE2) ? 3 : 2) void conv_gemm_f1
     // of the loads to the gaps (all activation loads first, weight pieces first, two pieces per gap) are within +-3 %.)
     if constexpr (IL) take_regs();
   };
-  // e8m0 block scales of the MX instruction (value = stored * 2^(scale - 127)): weights block 0 = g2 * 2^5, block 1 = g1 * 2^-6;
-  // activations block 0 = h1, block 1 = h2 * 2^11
-  const int mx_sa = fh ? 133 : 122, mx_sb = fh ? 116 : 127;
-  auto compute_mx = [&](int s, auto il_tag) {
-    constexpr bool IL = decltype(il_tag)::value;
-    const char* bst = Bs + (s & 1) * STAGE;
-    const int nstage = (s + 1) & 1;
-    if constexpr (IL) advance();
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {           // MFMA groups: h1 g1 (k step 0), h1 g1 (k step 1), the MX correction
-      if (g < 2) {
-        u32x4 fb[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int row = j * 32 + fr;
-          fb[j] = *reinterpret_cast<const u32x4*>(bst + (row * 4 + ((2 * g + fh) ^ ((row >> 2) & 3))) * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]),
-                                                               __builtin_bit_cast(f16x8, qa[i][g][0]), acc[i][j], 0, 0, 0);
-      } else {
-        i32x8 fq[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int row = j * 32 + fr;
-          const u32x4 lo = *reinterpret_cast<const u32x4*>(bst + BN * 64 + (row * 4 + ((2 * fh) ^ ((row >> 2) & 3))) * 16);
-          const u32x4 hi = *reinterpret_cast<const u32x4*>(bst + BN * 64 + (row * 4 + ((2 * fh + 1) ^ ((row >> 2) & 3))) * 16);
-          fq[j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const u32x4 lo = qa[i][0][1], hi = qa[i][1][1];
-          const i32x8 aq = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fq[j], aq, acc[i][j], 0, 0, 0, mx_sa, 0, mx_sb);
-        }
-      }
-      if constexpr (IL) {                   // the next slab's loads go into the gaps behind the groups
-        __builtin_amdgcn_sched_barrier(0);
-        if (g == 0) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) load_a(i);
-        } else {
-#pragma unroll
-          for (int e = 0; e < (TN + 1) / 2; ++e) {
-            const int piece = (g - 1) * ((TN + 1) / 2) + e;
-            if (piece < TN) dma(piece, nstage);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if constexpr (IL) take_regs();
-  };
-  if constexpr (MX) {
-    for (int s = 0; s + 1 < nslab; ++s) {
-      compute_mx(s, std::true_type{});
-      landed();
-    }
-    if (nslab > 0) compute_mx(nslab - 1, std::false_type{});
-  } else {
+  {
     for (int s = 0; s + 1 < nslab; ++s) {
       compute(s, std::true_type{});
       landed();
@@ -1037,7 +963,7 @@ __global__ __launch_bounds__(256, (TM == 1 && !FUSE2) ? 3 : 2) void conv_gemm_f1
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          unsigned h1[4], h2[4], q1w[2], q2w[2];
+          unsigned h1[4], h2[4];
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const int q = 2 * ks + e;
@@ -1049,32 +975,10 @@ __global__ __launch_bounds__(256, (TM == 1 && !FUSE2) ? 3 : 2) void conv_gemm_f1
             }
             split_pair_f16(v[0], v[1], h1[2 * e], h2[2 * e], clamped);
             split_pair_f16(v[2], v[3], h1[2 * e + 1], h2[2 * e + 1], clamped);
-            if (p.out_gl == 3) {      // MX consumer: e4m3(h1) and e4m3((v - h1) * 2^11), four bytes each
-              float a[4], r[4];
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                const float vc = __builtin_amdgcn_fmed3f(v[c], -65504.f, 65504.f);
-                const float hf = (float)(_Float16)vc;
-                clamped |= __builtin_fabsf(hf) > 448.f;          // the e4m3 plane of h1 saturates: outside the MX form's range
-                a[c] = __builtin_amdgcn_fmed3f(hf, -448.f, 448.f);
-                r[c] = __builtin_amdgcn_fmed3f((vc - hf) * 2048.f, -448.f, 448.f);
-              }
-              int w = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], 0, false);
-              q1w[e] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], w, true);
-              w = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], 0, false);
-              q2w[e] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], w, true);
-            }
           }
           char* const o = ob + (long long)(((n0 >> 5) + j) * 2 + ks) * 4096;
           *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
-          if (p.out_gl == 3) {
-            // plane 1 of the tile: granule fh = this lane's 16 e4m3(h1) bytes (byte 4 q + c), granule 2 + fh the e4m3(h2) ones
-            char* const ot = ob + (long long)(((n0 >> 5) + j) * 2) * 4096 + oplane + 8 * ks;
-            *reinterpret_cast<u32x2*>(ot) = u32x2{q1w[0], q1w[1]};
-            *reinterpret_cast<u32x2*>(ot + 4096) = u32x2{q2w[0], q2w[1]};
-          } else {
-            *reinterpret_cast<u32x4*>(o + oplane) = u32x4{h2[0], h2[1], h2[2], h2[3]};
-          }
+          *reinterpret_cast<u32x4*>(o + oplane) = u32x4{h2[0], h2[1], h2[2], h2[3]};
         }
       report_clamped(p.range_flag, clamped);
       clamped = false;
@@ -1110,8 +1014,8 @@ __global__ __launch_bounds__(256, (TM == 1 && !FUSE2) ? 3 : 2) void conv_gemm_f1
 
 }  // namespace
 
-// MAGAT_CONV_DIRECT=0 keeps f16x3 (in_fmt 4, out_fmt 0) on the 2x2 LDS-staged kernel
-int magat_conv_direct_enabled() { return magat_opt(MAGAT_OPT_CONV_DIRECT); }
+// (f16x3 = the register-direct kernel; its 2x2 LDS-staged form - option CONV_DIRECT = 0 of rounds 1-4 - was removed in round 5)
+int magat_conv_direct_enabled() { return 1; }
 
 // in_fmt 5: like 4, but in/in2 arrive as the two f16 planes already (written by a producer with out_fmt 3): no split work.
 // in_fmt 4: in/in2 float32 split on load into two f16 planes, wt = [2][Cout][Ktot] f16 planes of (weight * 2^e) followed
@@ -1142,9 +1046,11 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   if (fuse2 && !(d->in_fmt == 4 && d->out_fmt == 0 && d->in_gl <= 1 && d->out_gl == 0 && !d->out_ntile_stride && BN == 128 &&
                  d->Cout == 128 && d->Cout2 == 128 && d->Hout * d->Wout == 1 && d->out2 && (d->ldc & 3) == 0 && (d->ldc2 & 3) == 0 &&
                  (reinterpret_cast<uintptr_t>(d->out) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->out2) & 15) == 0 &&
-                 magat_conv_direct_enabled() && magat_opt(MAGAT_OPT_CONV_TEPI)))
+                 magat_conv_direct_enabled()))
     return MAGAT_ERR_UNSUPPORTED;
-  if (d->in_fmt < 1 || d->in_fmt > 5 || d->out_fmt < 0 || d->out_fmt > 3) return MAGAT_ERR_UNSUPPORTED;
+  if ((d->in_fmt != 3 && d->in_fmt != 4) || d->out_fmt < 0 || d->out_fmt > 3) return MAGAT_ERR_UNSUPPORTED;
+  if (d->in_fmt == 4 && d->out_fmt != 0) return MAGAT_ERR_UNSUPPORTED;                       // f16x3: float32 rows / granules out
+  if (d->in_fmt == 3 && d->out_fmt != 0 && d->out_fmt != 2) return MAGAT_ERR_UNSUPPORTED;   // plain bf16: float32 or bf16 out
   if (d->wt_pix_stride || d->ldw) return MAGAT_ERR_UNSUPPORTED;     // float32 kernel only
   if (d->in_fmt >= 4 && d->out_fmt != 0 && d->out_fmt != 3) return MAGAT_ERR_UNSUPPORTED;
   if (d->out_fmt == 3 && d->in_fmt < 4) return MAGAT_ERR_UNSUPPORTED;
@@ -1173,8 +1079,8 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.ldc2 = d->ldc2; p.relu2 = d->relu2;
   if (p.out_nt && !(d->in_fmt == 4 && d->out_fmt == 0 && d->out_gl == 0 && BN == 128 && magat_conv_direct_enabled()))
     return MAGAT_ERR_UNSUPPORTED;
-  p.korder = magat_opt(MAGAT_OPT_CONV_KORDER);
-  p.tepi = magat_opt(MAGAT_OPT_CONV_TEPI);
+  p.korder = 1;      // (direct kernel K walk: channel slab outer, taps inner; the tap-major order of round 1 re-fetched every chunk 3.6x)
+  p.tepi = 1;        // (row-major float32 output transposed through LDS)
   p.Mt = (p.M + BM - 1) / BM;
   p.ntn = p.Cout / BN;
   if (magat_row_off(p.M, p.lda, p.in_tile) * 4 >= 0xffffffffLL ||
@@ -1185,32 +1091,20 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   const long long grid = groups * MAGAT_NUM_XCD * p.npix * p.ntn;
   if (grid <= 0 || grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
   const int pid = magat_prof_begin(p.tag, st);
-  const bool af32 = d->in_fmt == 2;
   // f16x3 (in_fmt 4): wt = [2][Cout][Ktot] f16 bits followed by one float32 = 1 / weight scale (read by the kernel)
   p.acc_scale = d->acc_scale ? d->acc_scale
                              : reinterpret_cast<const float*>(reinterpret_cast<const char*>(d->wt) + (size_t)2 * p.Cout * p.Ktot * sizeof(u16));
   p.in_scale = d->in_scale;
   // (the activation scale lives in the direct kernel's float32 loader only)
   if (d->in_scale && !(d->in_fmt == 4 && d->out_fmt == 0 && d->in_gl <= 1 && magat_conv_direct_enabled())) return MAGAT_ERR_UNSUPPORTED;
+  // (round 5: the bf16x6 flavour - in_fmt 1 / 2, three bf16 planes, six products -, the pre-split f16 input of in_fmt 5 and
+  //  the LDS-staged f16x3 form are gone with their users: what is left of the LDS-staged kernel is the plain-bf16 GEMM of the
+  //  bf16-storage graph layer, in_fmt 3)
 #define MAGAT_SPLIT_LAUNCH(BNV, WM, WN)                                                                              \
-  do {                                                                                                              \
-    if (d->in_fmt == 3)                                                                                             \
-      hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<false, BNV, WM, WN, 1>), dim3((unsigned)grid), dim3(256), 0, st,  \
-                         p);                                                                                        \
-    else if (d->in_fmt == 4)                                                                                        \
-      hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<true, BNV, WM, WN, 2>), dim3((unsigned)grid), dim3(256), 0, st,   \
-                         p);                                                                                        \
-    else if (d->in_fmt == 5)                                                                                        \
-      hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<false, BNV, WM, WN, 2>), dim3((unsigned)grid), dim3(256), 0, st,  \
-                         p);                                                                                        \
-    else if (af32)                                                                                                  \
-      hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<true, BNV, WM, WN>), dim3((unsigned)grid), dim3(256), 0, st, p);  \
-    else                                                                                                            \
-      hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<false, BNV, WM, WN>), dim3((unsigned)grid), dim3(256), 0, st, p); \
-  } while (0)
+  hipLaunchKernelGGL((conv_gemm_bf16x6_kernel<false, BNV, WM, WN, 1>), dim3((unsigned)grid), dim3(256), 0, st, p)
   const int direct = magat_conv_direct_enabled();
   if ((d->in_gl || d->out_gl) && !(d->in_fmt == 4 && d->out_fmt == 0 && direct)) return MAGAT_ERR_UNSUPPORTED;
-  if (d->in_gl < 0 || d->in_gl > 3 || d->out_gl < 0 || d->out_gl > 3) return MAGAT_ERR_UNSUPPORTED;
+  if (d->in_gl < 0 || d->in_gl > 2 || d->out_gl < 0 || d->out_gl > 2) return MAGAT_ERR_UNSUPPORTED;
   if (d->in_fmt == 4 && d->out_fmt == 0 && direct) {
     const int tm2 = magat_opt(MAGAT_OPT_CONV_TM);     // 1: one 32-agent row group per wave everywhere
     const bool two = !fuse2 && tm2 >= 2 && (long long)(p.Mt / 2) * p.npix * p.ntn >= 2048;   // enough 256-agent tiles to fill the chip
@@ -1219,11 +1113,7 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
     p.Mt = (int)mt;
 #define MAGAT_DIRECT_LAUNCH(BNV)                                                                                     \
   do {                                                                                                              \
-    if (two && mxin)                                                                                                \
-      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2, 2>), dim3((unsigned)g2), dim3(256), 0, st, p);      \
-    else if (mxin)                                                                                                  \
-      hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1, 2>), dim3((unsigned)g2), dim3(256), 0, st, p);      \
-    else if (two && pin)                                                                                            \
+    if (two && pin)                                                                                                 \
       hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2, 1>), dim3((unsigned)g2), dim3(256), 0, st, p);      \
     else if (two)                                                                                                   \
       hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 2, 0>), dim3((unsigned)g2), dim3(256), 0, st, p);      \
@@ -1232,7 +1122,7 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
     else                                                                                                            \
       hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<BNV, 1, 0>), dim3((unsigned)g2), dim3(256), 0, st, p);      \
   } while (0)
-    const bool pin = d->in_gl == 2, mxin = d->in_gl == 3;
+    const bool pin = d->in_gl == 2;
     if (fuse2) {
       magat_form_note(MAGAT_FORM_HEAD_COMPRESS);
       hipLaunchKernelGGL((conv_gemm_f16x3_direct_kernel<128, 1, 0, true>), dim3((unsigned)g2), dim3(256), 0, st, p);

@@ -42,7 +42,6 @@ struct ConvGemmParams {
   int pool_w;   // POOL: physical input width (input pixel (iy,ix) = sum or max of the 2x2 physical pixels)
   int pool_max; // POOL: 0 = sum (AvgPool2d with 1/4 in the weights), 1 = max (MaxPool2d)
   long long wt_pix;         // per-output-pixel weight offset (floats); 0 = shared weights
-  int out_split;            // epilogue writes three bf16 planes (out_plane elements apart) instead of float32
   long long out_plane;
   long long out_nt;         // > 0: 128-column tile t of the row-major output lives at out + t * out_nt (row stride ldc = 128)
   const int* run_if;        // range-guard re-run: the kernel does nothing unless *run_if != 0 (null: always runs)
@@ -300,30 +299,7 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, const in
           if (n + c < p.Cout) amax = fmaxf(amax, fabsf(v[c]));
         }
         const long long o = magat_row_off(m, p.ldc, p.out_tile) + (p.out_nt ? (long long)(n >> 7) * p.out_nt + (n & 127) : n);
-        if (p.out_split) {
-          unsigned short h[3][4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            h[0][c] = magat_bf16_rne(v[c]);
-            const float r1 = v[c] - magat_bf16_f32(h[0][c]);
-            h[1][c] = magat_bf16_rne(r1);
-            h[2][c] = magat_bf16_rne(r1 - magat_bf16_f32(h[1][c]));
-          }
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            unsigned short* dst = sbase + pl * p.out_plane + o;
-            if (vec) {
-              uint2 pk;
-              pk.x = (unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16);
-              pk.y = (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16);
-              *reinterpret_cast<uint2*>(dst) = pk;
-            } else {
-#pragma unroll
-              for (int c = 0; c < 4; ++c)
-                if (n + c < p.Cout) dst[c] = h[pl][c];
-            }
-          }
-        } else if (vec) {
+        if (vec) {
           *reinterpret_cast<f32x4*>(obase + o) = f32x4{v[0], v[1], v[2], v[3]};
         } else {
 #pragma unroll
@@ -391,22 +367,16 @@ __global__ __launch_bounds__(256) void conv_gemm_chain_kernel(const ConvChain c)
   if (c.book) magat_guard_book(c.book);
 }
 
-int conv_variant() { return magat_opt(MAGAT_OPT_CONV_VARIANT); }
-
 template <int BM, int BN, int WGM, int WGN, bool POOL, bool FULL>
 int launch2(ConvGemmParams& p, hipStream_t st, long long grid) {
   const int pid = magat_prof_begin(p.tag, st);
   // Measured on MI355X (tools/conv_bench.py, 51200 agents): the single-buffer form wins everywhere because it
   // fits one more workgroup per CU (l3.conv2: 122 -> 129 TF); capping the 128x128 tile at 128 registers
-  // (4 waves/SIMD, 11 spilled VGPRs) adds another 2-3 % (131.6 TF).  MAGAT_CONV_VARIANT=9 keeps the
-  // double-buffered kernel selectable for A/B runs.
+  // (4 waves/SIMD, 11 spilled VGPRs) adds another 2-3 % (131.6 TF).
   constexpr int MINW = (BM == 128 && BN == 128) ? 4 : 1;
   p.vgrid = (int)grid;
   const unsigned launch_grid = (unsigned)((p.run_if && grid > 512) ? 512 : grid);
-  if (conv_variant() != 9)
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, POOL, FULL, 1, MINW>), dim3(launch_grid), dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, POOL, FULL, 2>), dim3(launch_grid), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, POOL, FULL, 1, MINW>), dim3(launch_grid), dim3(256), 0, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
@@ -565,7 +535,7 @@ static int conv_params_from_desc(const magat_conv_gemm_desc* d, ConvGemmParams& 
   if (!d || !d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
   if (d->in_gl || d->out_gl) return MAGAT_ERR_UNSUPPORTED;   // f16x3 direct kernel only
   if (d->out_ntile_stride && (d->ldc != 128 || (d->Cout & 127) || d->out_fmt != 0)) return MAGAT_ERR_UNSUPPORTED;
-  if (d->in_fmt != 0 || (d->out_fmt != 0 && d->out_fmt != 1)) return MAGAT_ERR_UNSUPPORTED;
+  if (d->in_fmt != 0 || d->out_fmt != 0) return MAGAT_ERR_UNSUPPORTED;
   if (d->M <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->kH <= 0 || d->kW <= 0 ||
       d->stride <= 0 || d->pad < 0 || d->C2 < 0)
     return MAGAT_ERR_BAD_SHAPE;
@@ -594,7 +564,6 @@ static int conv_params_from_desc(const magat_conv_gemm_desc* d, ConvGemmParams& 
   p.wt_pix = d->wt_pix_stride;
   p.npix = d->Hout * d->Wout;
   p.tag = d->tag;
-  p.out_split = d->out_fmt == 1;
   p.out_plane = d->out_plane_stride;
   p.out_nt = d->out_ntile_stride;
   p.run_if = reinterpret_cast<const int*>(d->run_if);

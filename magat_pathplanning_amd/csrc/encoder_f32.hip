@@ -306,15 +306,13 @@ static int conv_first_launch(const float* x, const float* wt, const float* bias,
 static int enc_split_mask(const magat_encoder_desc* d, int v) {
   int m = 0;
   for (int l = 0; l < 3; ++l)
-    if ((v >> l & 1) && d->off[18 + 2 * l] > 0 && d->off[19 + 2 * l] > 0) m |= 1 << l;
+    if ((v >> l & 1) && d->off[24 + 2 * l] > 0 && d->off[25 + 2 * l] > 0) m |= 1 << l;
   return m;
 }
 
-// Split flavour of those layers: f16x3 (two f16 planes, three v_mfma_f32_32x32x16_f16 per product, in_fmt 4) when the
-// pack carries the f16 weight planes, else bf16x6 (in_fmt 2).  Option CONV_F16=0 forces bf16x6.
-static bool enc_use_f16(const magat_encoder_desc* d, int l) {
-  return magat_opt(MAGAT_OPT_CONV_F16) && d->off[24 + 2 * l] > 0 && d->off[25 + 2 * l] > 0;
-}
+// Split flavour of those layers: f16x3 (two f16 planes, three v_mfma_f32_32x32x16_f16 per product, in_fmt 4): the pack carries
+// the f16 weight planes for every layer of the mask (enc_split_mask).  (The bf16x6 flavour of round 1 was removed in round 5.)
+static bool enc_use_f16(const magat_encoder_desc* d, int l) { return d->off[24 + 2 * l] > 0 && d->off[25 + 2 * l] > 0; }
 
 // floats per agent of one rotating activation buffer
 static size_t enc_buf_floats_per_agent(const magat_encoder_desc* d) {
@@ -397,9 +395,9 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
   // activation plane carries e4m3(h1) | e4m3(h2 * 2^11) and the consumers issue two f16 MFMAs + one block-scaled fp8 MFMA per
   // slab instead of six f16 ones.  Block 0's own inputs (fused stem + layer1.conv1 output) stay f16 planes.
   // OPT-IN (option CONV_MX, default 0): the fp8 correction planes are narrower arithmetic than the reference's fp32.
-  const bool mx = lay == 2 && d->off[31] != 0 && magat_opt(MAGAT_OPT_CONV_MX) != 0;
+  const bool mx = false;      // (the f16 + MX-correction form of rounds 1-4 was removed in round 5: narrower than fp32 and slower than the default)
   // the guard's re-run: every float32 layer behind the stem goes into ONE predicated launch (magat_conv_gemm_chain_f32)
-  const bool chained = rerun && magat_opt(MAGAT_OPT_GUARD_CHAIN) != 0;
+  const bool chained = rerun;
   for (int m0 = 0; m0 < M; m0 += mc) {
     const int mm = (M - m0) < mc ? (M - m0) : mc;
     magat_conv_gemm_desc chain[10];
@@ -414,8 +412,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     const bool fused1 = lay == 2 && magat_layer1_fused_lds(W) != 0 && magat_opt(MAGAT_OPT_L1_FUSED) != 0;
     // the whole chain in two launches (fused stem + the merged chain kernel): the path the activation scales are folded for
     const bool full_path = fused1 && !mx && d->chain_off > 0 && Ho == 6 && Wo == 6 && nblocks == 3 && d->chain3_off > 0 &&
-                           magat_opt(MAGAT_OPT_BLOCK_FUSED) >= 2 && magat_opt(MAGAT_OPT_BLOCK3_FUSED) >= 2 &&
-                           magat_opt(MAGAT_OPT_BLOCK_FULL);
+                           magat_opt(MAGAT_OPT_BLOCK_FUSED) >= 2;
     const float* sp = (full_path && d->scaled_off > 0) ? pk + d->scaled_off : nullptr;      // activation-scale block
     int rc;
     // ... as the eight-agent-group kernel (block_fused.hip stem8_kernel: every stem pixel once, no im2col instructions) when
@@ -443,7 +440,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // The pooled map goes to the head granule-major ([cell][128 / 4][128 agents][4 floats]) when the head is the f16x3 direct
     // GEMM: its loader then reads 512 contiguous bytes per half wave instead of 32 bytes out of every agent's 512-byte row, and
     // the chain kernel stores 128-byte runs instead of 16-byte pieces.  (Not for the few-agent form of the head, which splits K
-    // by pooled cell on the float32 kernel; option HEAD_GL=0: row-major tiles.)
+    // by pooled cell on the float32 kernel.)
     const int clast_ = shapes[nblocks - 1].cout;
     // (the agent count the head's form is chosen on: the whole call's, or - a shard of a larger batch - the global one)
     const int Mform = d->form_agents > 0 ? d->form_agents : M;
@@ -451,7 +448,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
                              (d->n_feat & 3) == 0 && (size_t)9 * d->n_feat <= enc_buf_floats_per_agent(d);
     const bool head_gl = full_path && !rerun && split && d->head16_off > 0 && (clast_ % 32) == 0 && (d->n_feat % 32) == 0 &&
                          magat_opt(MAGAT_OPT_HEAD_F16) && magat_conv_direct_enabled() && !head_splitk &&
-                         magat_block_full_out_gl() && magat_opt(MAGAT_OPT_HEAD_GL);
+                         magat_block_full_out_gl();
     if (full_path) {
       // both chain kernels as ONE launch: layer2's output map stays in LDS as layer3's input
       rc = magat_block_full(buf[1], buf[0], pk + d->chain_off, sp ? sp + 928 : pk + d->off[5], sp ? sp + 960 : pk + d->off[7],
@@ -466,7 +463,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
       if (rc != MAGAT_OK) return rc;
       cur = 2; hin = Ho; win = Wo; lstart = 2;
       // ... and layer3 + ReLU + AvgPool2d(2) as one more launch: the head then reads 9 pooled cells instead of 36 pixels
-      if (nblocks == 3 && d->chain3_off > 0 && magat_opt(MAGAT_OPT_BLOCK3_FUSED)) {
+      if (nblocks == 3 && d->chain3_off > 0) {
         rc = magat_block3(buf[2], buf[0], pk + d->chain3_off, pk + d->off[11], pk + d->off[13], mm,
                           reinterpret_cast<int*>(range_flag), st);
         if (rc != MAGAT_OK) return rc;
@@ -488,8 +485,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
       g.range_flag = range_flag; g.run_if = run_if;
       if (absmax) g.absmax = absmax + 1 + 2 * l;
       if (split >> l & 1) {      // split-MFMA kernel: float32 activations split by its loader, pre-split weights
-        if (enc_use_f16(d, l)) { g.in_fmt = 4; g.wt = pk + d->off[24 + 2 * l]; }
-        else { g.in_fmt = 2; g.wt = pk + d->off[18 + 2 * l]; }
+        g.in_fmt = 4; g.wt = pk + d->off[24 + 2 * l];
       }
       g.in_gl = g.out_gl = lay;
       if (mx && l >= 1) { g.in_gl = g.out_gl = 3; g.wt += 2 * permuted(s.cout, 9 * s.cin); }
@@ -512,8 +508,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
       h.range_flag = range_flag; h.run_if = run_if;
       if (absmax) h.absmax = absmax + 2 + 2 * l;
       if (split >> l & 1) {
-        if (enc_use_f16(d, l)) { h.in_fmt = 4; h.wt = pk + d->off[25 + 2 * l]; }
-        else { h.in_fmt = 2; h.wt = pk + d->off[19 + 2 * l]; }
+        h.in_fmt = 4; h.wt = pk + d->off[25 + 2 * l];
       }
       h.in_gl = lay; h.out_gl = l + 1 < nblocks ? lay : 0;
       if (mx && l + 1 < nblocks) h.out_gl = 3;

@@ -696,9 +696,9 @@ int launch_tiled(const CsrParams& p, int width, bool scores, hipStream_t st) {
 }
 template <typename ST>
 int run_tiled(const CsrParams& p, int width, bool scores, hipStream_t st) {
-  // option CSR_TILED bit 2: 64-byte slices in 512-thread workgroups (two per CU) when a 128-byte slice leaves room for one
-  const bool half = (magat_opt(MAGAT_OPT_CSR_TILED) & 4) && (size_t)((p.N + 7) / 8) * 1024 > 80 * 1024;
-  return half ? launch_tiled<ST, 4>(p, width, scores, st) : launch_tiled<ST, 8>(p, width, scores, st);
+  // (the 64-byte-slice form - 512-thread workgroups, two per CU, option CSR_TILED bit 2 of rounds 2-4 - doubled the passes and
+  //  their per-row bookkeeping and measured 27 % slower: removed in round 5)
+  return launch_tiled<ST, 8>(p, width, scores, st);
 }
 
 template <int G, typename ST = float>

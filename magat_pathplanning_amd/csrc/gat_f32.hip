@@ -965,10 +965,7 @@ extern "C" size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode) 
 // row stride of the hoisted-map intermediate Z in the dense path: NC + pad.  NC is a multiple of 128 floats at the
 // benchmark shapes (2048 -> 8 KB rows): the tiles a workgroup reads are 512-byte row pieces exactly 8 KB apart, which
 // all land in the same HBM channels; a 128-byte skew per row spreads them.
-static int gat_zpad() {
-  const int v = magat_opt(MAGAT_OPT_GAT_ZPAD);
-  return (v < 0 || (v & 3)) ? 0 : v;
-}
+static int gat_zpad() { return 32; }      // row skew of Z (floats)
 // float32-MFMA form of the maps (exact fp32 products): the guard's re-run, and the training path
 static int gat_maps_gemm_f32(const float* X, const float* packed, float* Z, int M, int G, int NC, int ldz, void* stream,
                              long long ntile_stride, const int32_t* run_if, int tag) {
@@ -996,7 +993,7 @@ int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, in
                         long long ntile_stride, int32_t* status, int force_f32) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!force_f32 && magat_opt(MAGAT_OPT_GAT_SPLIT) && NC % 32 == 0 && G % 32 == 0) {
-    const int use_f16 = magat_opt(MAGAT_OPT_CONV_F16);
+    const int use_f16 = 1;      // (f16x3; the bf16x6 flavour was removed in round 5 - its weight planes still sit in the pack)
     const bool guard = status && use_f16 && magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
     magat_conv_gemm_desc d = {};
     d.in = X;
@@ -1205,7 +1202,7 @@ extern "C" size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, i
 
 static bool gat_one_launch(int N, int G, int F, int K, int mode, int concat) {
   (void)concat;
-  return magat_opt(MAGAT_OPT_GAT_MFMA) && magat_opt(MAGAT_OPT_GAT_SPLIT) && magat_opt(MAGAT_OPT_CONV_F16) &&
+  return magat_opt(MAGAT_OPT_GAT_MFMA) && magat_opt(MAGAT_OPT_GAT_SPLIT) &&
          (magat_gat_mfma_supported(N, G, F, K, mode) || magat_gat_small_supported(N, G, F, K, mode));
 }
 
@@ -1276,7 +1273,7 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     rerun_only = true;
     p.run_if = status;
   }
-  const int hpb_env = magat_opt(MAGAT_OPT_GAT_HPB);
+  const int hpb_env = 0;      // (heads per workgroup: automatic)
   auto hpb_for = [&](int cb) {
     int h = 1;
     if (G >= 64 && P > 1 && lds > 80 * 1024 && cb >= 256) h = P;
@@ -1289,9 +1286,9 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     const int cb = (B - b0) < chunk ? (B - b0) : chunk;
     // Z in 128-column tiles ([tile][cb * N][128]: an instance's Q_p / U_pk tile is ONE contiguous N x 128 run for the
     // LDS-direct loads, and every workgroup of the maps GEMM writes one contiguous region) when the dense kernel with
-    // 128-wide features consumes it and the f16x3 direct GEMM produces it; MAGAT_GAT_ZTILES=0 keeps NC-wide rows.
+    // 128-wide features consumes it and the f16x3 direct GEMM produces it.
     const bool ztiles = G == 128 && F == 128 && L.NC % 128 == 0 && magat_conv_direct_enabled() &&
-                        magat_opt(MAGAT_OPT_GAT_ZTILES) && magat_opt(MAGAT_OPT_GAT_SPLIT) && magat_opt(MAGAT_OPT_CONV_F16);
+                        magat_opt(MAGAT_OPT_GAT_SPLIT);
     p.zts = ztiles ? (long long)cb * N * 128 : 0;
     // (one chunk is the rule; with several, a clamp in an earlier chunk leaves the flag set only until the next chunk's
     // own GEMM clears it - status[1] still counts every re-run)
@@ -1312,7 +1309,7 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     // with one workgroup per CU (hpb == P case) the grid is capped at one workgroup per CU and every workgroup walks
     // several instances, prefetching across the instance boundary as well
     int inst_slots = (cb + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD * MAGAT_NUM_XCD;
-    if (magat_opt(MAGAT_OPT_GAT_PERSIST) && hpb == P && hpb > 1 && inst_slots > GAT_PLAN_WALKERS) inst_slots = GAT_PLAN_WALKERS;
+    if (hpb == P && hpb > 1 && inst_slots > GAT_PLAN_WALKERS) inst_slots = GAT_PLAN_WALKERS;
     // the range guard's predicated re-run: a launch that returns at once still pays for every workgroup it dispatches - with one
     // workgroup per (instance, head) that was 4096 dispatches, 76 us per forward at BASELINE config 2 (1024 instances of 20
     // agents; 88 us of a 1.10 ms step went to the guard).  The workgroups walk the instances instead (istride below)

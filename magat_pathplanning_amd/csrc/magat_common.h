@@ -56,7 +56,7 @@ int magat_block3(const void* in, float* out, const float* w, const float* b1, co
 int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, long long out_pix_stride, long long out_tile,
                       const float* w, const float* bA, const float* bB, const float* bC, int M, int* range_flag,
                       hipStream_t st);
-int magat_conv_direct_enabled();   // f16x3 direct kernel on (option CONV_DIRECT, default 1)
+int magat_conv_direct_enabled();   // 1 (the f16x3 GEMM is the register-direct kernel)
 // float32 layers of one agent range chained in ONE launch (conv_gemm_f32.hip; the range guard's re-run)
 int magat_conv_gemm_chain_f32(const magat_conv_gemm_desc* descs, int n, const int32_t* run_if, int tag, hipStream_t st,
                               int32_t* book = nullptr);
@@ -64,13 +64,10 @@ int magat_conv_gemm_chain_f32(const magat_conv_gemm_desc* descs, int n, const in
 // Library options (options.hip): read from the environment (MAGAT_<NAME>) ONCE, changed at run time through
 // magat_set_option - nothing on the launch path calls getenv.
 enum MagatOpt {
-  MAGAT_OPT_CONV_DIRECT, MAGAT_OPT_CONV_KORDER, MAGAT_OPT_CONV_TEPI, MAGAT_OPT_CONV_TM, MAGAT_OPT_CONV_VARIANT,
-  MAGAT_OPT_ENC_CHUNK, MAGAT_OPT_CONV_SPLIT, MAGAT_OPT_CONV_F16, MAGAT_OPT_CONV_PCHAIN, MAGAT_OPT_CONV_MX,
-  MAGAT_OPT_L1_FUSED, MAGAT_OPT_HEAD_SPLITK, MAGAT_OPT_GAT_CHUNK_MB, MAGAT_OPT_GAT_ZPAD, MAGAT_OPT_GAT_SPLIT,
-  MAGAT_OPT_GAT_HPB, MAGAT_OPT_GAT_ZTILES, MAGAT_OPT_GAT_PERSIST, MAGAT_OPT_RANGE_GUARD, MAGAT_OPT_BLOCK_FUSED,
-  MAGAT_OPT_CSR_TILED, MAGAT_OPT_BLOCK3_FUSED,
-  MAGAT_OPT_HEAD_F16, MAGAT_OPT_BLOCK_FULL, MAGAT_OPT_GAT_MFMA, MAGAT_OPT_GUARD_CHAIN, MAGAT_OPT_HEAD_GL, MAGAT_OPT_SKINNY, MAGAT_OPT_GAT_PACK,
-  MAGAT_OPT_CONV_BNFILL, MAGAT_OPT_HEAD_COMPRESS, MAGAT_OPT_COUNT
+  MAGAT_OPT_ENC_CHUNK, MAGAT_OPT_CONV_SPLIT, MAGAT_OPT_CONV_PCHAIN,
+  MAGAT_OPT_L1_FUSED, MAGAT_OPT_HEAD_SPLITK, MAGAT_OPT_GAT_CHUNK_MB, MAGAT_OPT_GAT_SPLIT, MAGAT_OPT_RANGE_GUARD,
+  MAGAT_OPT_BLOCK_FUSED, MAGAT_OPT_CSR_TILED, MAGAT_OPT_HEAD_F16, MAGAT_OPT_GAT_MFMA, MAGAT_OPT_SKINNY, MAGAT_OPT_GAT_PACK,
+  MAGAT_OPT_CONV_BNFILL, MAGAT_OPT_HEAD_COMPRESS, MAGAT_OPT_CONV_TM, MAGAT_OPT_COUNT
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)

@@ -17,41 +17,22 @@ struct OptEntry {
 
 // order = enum MagatOpt (magat_common.h)
 const OptEntry kOpts[MAGAT_OPT_COUNT] = {
-    {"CONV_DIRECT", 1},      // f16x3 convolutions on the register-direct kernel (0: 2x2 LDS-staged kernel)
-    {"CONV_KORDER", 1},      // direct kernel K walk: 1 = channel slab outer, taps inner
-    {"CONV_TEPI", 1},        // direct kernel: row-major float32 output transposed through LDS
-    {"CONV_TM", 2},          // direct kernel: 32-agent row groups per wave (2 = 256-agent tiles when the chip fills)
-    {"CONV_VARIANT", 0},     // fp32 MFMA kernel variant (9 = double-buffered form)
     {"ENC_CHUNK", 65536},    // agents per encoder pass (workspace bound)
-    {"CONV_SPLIT", 7},       // bit l: BasicBlock l+1 on the split-MFMA kernels (0 = fp32 MFMA everywhere)
-    {"CONV_F16", 1},         // split flavour: 1 = f16x3, 0 = bf16x6
+    {"CONV_SPLIT", 7},       // bit l: BasicBlock l+1 on the split-MFMA kernels (0 = fp32 MFMA everywhere: the strict-float32 form)
     {"CONV_PCHAIN", 1},      // f16 plane-granule activation chain between the BasicBlock convolutions
-    {"CONV_MX", 0},          // OPT-IN: layer2/layer3 correction products in block-scaled fp8 (narrower than fp32-class)
-    {"L1_FUSED", 2},         // stem + layer1.conv1 as one kernel: 2 = eight-agent groups (stem8_kernel), 1 = 64-agent row bands
-    {"HEAD_SPLITK", 5120},   // largest agent count for which the encoder head splits K by pooled cell (round 4: measured crossover
-                             // against the f16x3 direct kernel at 4000-6000 agents; was 12288)
-    {"GAT_CHUNK_MB", 2048},  // cap of the hoisted-map intermediate Z
-    {"GAT_ZPAD", 32},        // row skew of Z (floats)
-    {"GAT_SPLIT", 1},        // GAT maps on the split-MFMA GEMM
-    {"GAT_HPB", 0},          // heads per workgroup override (0 = automatic)
-    {"GAT_ZTILES", 1},       // Z in 128-column tiles
-    {"GAT_PERSIST", 1},      // persistent graph-kernel workgroups
-    {"RANGE_GUARD", 1},      // split-arithmetic range guard: overflow flag + stream-ordered fp32 re-run of the encoder
-    {"BLOCK_FUSED", 2},      // BasicBlock chain kernel (conv1 -> conv2 (+downsample) with the 6x6 maps in LDS): 2 = four waves x 512
-                             // registers (static K walk), 1 = eight waves x 256, 0 = one launch per convolution
-    {"CSR_TILED", 3},        // CSR path, N <= 1024: LDS-tiled kernels (bit 0 scores, bit 1 hops) instead of L2 gathers; bit 2 (opt-in,
-                             // measured slower): 64-byte slices in 512-thread workgroups, two per CU
-    {"BLOCK3_FUSED", 2},     // layer3 + ReLU + pool as one launch (two-half intermediate in LDS); needs BLOCK_FUSED.
-                             // 2 = four waves x 512 registers, static K walk; 1 = eight waves x 256 registers; 0 = layer by layer
+    {"L1_FUSED", 2},         // stem + layer1.conv1 as one kernel: 2 = eight-agent groups (stem8_kernel; 11 x 11 maps), 1 = 64-agent row
+                             // bands (the form of every other map size), 0 = two launches
+    {"HEAD_SPLITK", 5120},   // largest agent count for which the encoder head splits K by pooled cell (measured crossover against the
+                             // f16x3 direct kernel at 4000-6000 agents); chosen on magat_encoder_desc.form_agents when that is set
+    {"GAT_CHUNK_MB", 2048},  // cap of the two-launch graph layer's hoisted-map intermediate Z
+    {"GAT_SPLIT", 1},        // GAT maps on the split-MFMA GEMM (0 = fp32 MFMA)
+    {"RANGE_GUARD", 1},      // split-arithmetic range guard: overflow flag + stream-ordered fp32 re-run
+    {"BLOCK_FUSED", 2},      // BasicBlock chain with the 6x6 maps of eight agents in LDS (four waves x 512 registers, static K walk):
+                             // 2 = layer1.conv2 -> layer2 -> layer3 -> pool as ONE launch (block_full_p_kernel), 1 = two launches
+                             // (layer1.conv2 + layer2; layer3 + pool), 0 = one launch per convolution
+    {"CSR_TILED", 3},        // CSR path, N <= 1024: LDS-tiled kernels (bit 0 scores, bit 1 hops) instead of L2 gathers
     {"HEAD_F16", 1},         // encoder head on the f16x3 split kernel when its input is the pooled map of the layer3 kernel
-    {"BLOCK_FULL", 2},       // layer1.conv2 -> layer2 -> layer3 -> pool as ONE launch (needs BLOCK_FUSED 2 and BLOCK3_FUSED 2);
-                             // 2: the 2x2 pooling in registers (block_full_p_kernel), 1: through an LDS scratch (block_full_w4_kernel);
-                             // 3 / 4 (opt-in, bit-identical to 2, not faster yet): the compact loop body (block_full_c_kernel:
-                             // shared walk / epilogue bodies, 80 KB instead of 114; 4: interior walks rolled over the tap rows, 74 KB;
-                             // 5: conv2 as a rolled interior pass + an edge pass, 67 KB)
-    {"GAT_MFMA", 1},         // KeyQuery layer with 128 features, N <= 101, K = 2 | 3 as ONE launch of matrix-core products (gat_mfma.hip)
-    {"GUARD_CHAIN", 1},      // the range guard's float32 re-run of the encoder: every layer behind the stem in ONE predicated launch
-    {"HEAD_GL", 1},          // pooled map of the chain kernel granule-major for the f16x3 head (0: row-major agent tiles)
+    {"GAT_MFMA", 1},         // graph layer with 128 features, N <= 102, K = 2 | 3 as ONE launch of matrix-core products (gat_mfma.hip)
     {"SKINNY", 1},           // float32 1x1 layers with at most 8 outputs (the action head) as streamed dot products, not MFMA tiles
     {"GAT_PACK", 1},         // one-launch graph layer, N <= 32: four planning instances per pass (1: when the batch fills the chip
                              // that way; 2: always; 0: never)
@@ -60,6 +41,8 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
                              // bit-identical
     {"HEAD_COMPRESS", 1},    // compressMLP computed in the encoder head's epilogue (one launch; needs the 128-column head tile:
                              // batches whose head tile was narrowed by CONV_BNFILL keep the two launches; bit-identical)
+    {"CONV_TM", 2},          // direct kernel: 32-agent row groups per wave (2 = 256-agent tiles once they fill the chip; 1 = never:
+                             // the reference form the 256-agent tiles are tested against, bit-identical)
 };
 
 int g_val[MAGAT_OPT_COUNT];

@@ -12,8 +12,7 @@ the "encoder pack" consumed by magat_encoder_forward_f32 (include/magat_hip.h):
           the GEMM sum-pools the 2x2 windows while loading its A operand)
   off[15] head bias [n_feat]
   off[16] compressMLP weight [G][n_feat]                   off[17] compressMLP bias [G]
-  off[18+2l] layer(l+1).conv1 weight as bf16x3 planes [3][Cout][9*Cin]            (raw bf16 bits)
-  off[19+2l] layer(l+1).[conv2|downsample] weight as bf16x3 planes [3][Cout][9*Cout+Cin]
+  off[18..23] empty since round 5 (the bf16x3 weight planes of round 1's bf16x6 flavour)
   off[24+2l], off[25+2l] the same two weights as f16x2 planes of (w * 2^e) + one float32 2^-e  ("f16x3" GEMM, in_fmt 4)
 
 Every offset is a multiple of 4 floats.  Folding is done in float64 and stored as float32.
@@ -102,27 +101,15 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
         n_comp = compress[0].shape[0]
     pack = torch.cat(parts).to(torch.float32).contiguous()
     if True:
-        # block-conv weights once more as bf16x3 planes (raw bf16 bits stored inside the float32 pack) for the
-        # split-MFMA kernel (csrc/conv_gemm_bf16x6.hip): off[18+2l] = layer(l+1).conv1, off[19+2l] = [conv2|downsample]
+        # block-conv weights once more for the split-MFMA kernels (csrc/conv_gemm_bf16x6.hip).  Slots 18..23 (the bf16x3
+        # planes of round 1's bf16x6 flavour) stay empty since round 5.
         raws = []
         cursor_f = pack.numel()
         n_f32 = pack.numel()
         pairs = []
         for l in range(nblocks):
             pairs += [(18 + 2 * l, 2 + 4 * l), (19 + 2 * l, 4 + 4 * l)]
-        for slot, src in pairs:
-            nxt = sorted(o for o in offs[:18] if o > offs[src])
-            end = nxt[0] if nxt else n_f32
-            w32 = pack[offs[src]:end]
-            # drop the <=3 floats of alignment padding: weight sizes here are multiples of 4 already
-            planes = split_bf16x3(w32).view(torch.float32).reshape(-1)
-            pad = (-planes.numel()) % 4
-            if pad:
-                planes = torch.cat((planes, torch.zeros(pad)))
-            offs[slot] = cursor_f
-            cursor_f += planes.numel()
-            raws.append(planes)
-        # ... and as f16x2 planes of the power-of-two-scaled weights followed by the inverse scale ("f16x3" GEMM, in_fmt 4):
+        # As f16x2 planes of the power-of-two-scaled weights followed by the inverse scale ("f16x3" GEMM, in_fmt 4):
         # off[24+2l] = layer(l+1).conv1, off[25+2l] = [conv2|downsample]
         # Each f16 block is followed by a second copy with the K columns of every 32-wide slab permuted for activations
         # stored as f16 plane granules (magat_hip.h in_gl = 2; offs[30] != 0 marks their presence): the producer's MFMA
@@ -151,18 +138,8 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
             assert blk2.numel() == blk.numel()
             cursor_f += blk2.numel()
             raws.append(blk2)
-            # ... and a third copy for the "f16 + MX correction" arithmetic (magat_hip.h in_gl = 3): plane 0 as in the
-            # permuted copy (g1), plane 1 = per row and 32-channel slab 64 bytes [fp8(g2 * 2^5) | fp8(g1 * 2^-6)] (OCP
-            # e4m3), channels in the order the producer's lanes emit their fp8 activation bytes
-            blk3 = _mx_block(w2d, perm32)
-            if pad:
-                blk3 = torch.cat((blk3, torch.zeros(pad)))
-            assert blk3.numel() == blk.numel()
-            cursor_f += blk3.numel()
-            raws.append(blk3)
             if slot == pairs[0][0]:
                 offs[30] = offs[slot + 6] + blk.numel()        # first permuted copy (non-zero = copies present)
-                offs[31] = offs[slot + 6] + 2 * blk.numel()    # first MX copy
         pack = torch.cat([pack] + raws).contiguous()
     # BasicBlock chain kernel (csrc/block_fused.hip; 6x6 maps only, i.e. the reference's 11x11 input): layer1.conv2+ds,
     # layer2.conv1, layer2.conv2+ds as fragment-major f16 planes, appended to the pack; its float offset goes to meta["chain"]
@@ -330,31 +307,6 @@ def split_bf16x3(t):
     p1 = r.bfloat16()
     p2 = (r - p1.float()).bfloat16()
     return torch.stack((p0, p1, p2), dim=0).contiguous()
-
-
-MX_PI = [8 * ((q >> 2) & 3) + 4 * (q >> 4) + (q & 3) for q in range(32)]     # byte position -> channel of a 32-channel tile
-
-
-def _mx_block(w2d, perm32):
-    """[Cout][K] float32 weights -> the in_gl = 3 operand block (same size as split_f16x2's): plane 0 = f16 g1 with the K
-    columns of every 32-slab in plane-granule order, plane 1 = per row and slab [e4m3(g2 * 2^5) (32 B) | e4m3(g1 * 2^-6) (32 B)]
-    in MX_PI order, then the float32 inverse weight scale.  g1 + g2 = f16 split of w * 2^e as in split_f16x2."""
-    cout, K = w2d.shape
-    _, e = split_f16x2(w2d.reshape(-1))
-    ts = w2d.detach().float().cpu() * (2.0 ** e)
-    g1 = ts.half()
-    g2 = (ts - g1.float()).half()
-    base = (torch.arange(K) // 32) * 32
-    ip = base + perm32.repeat(K // 32)
-    iq = base + torch.tensor(MX_PI).repeat(K // 32)
-    f8 = lambda t: t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
-    q2 = f8(g2.float()[:, iq] * 32.0).view(cout, K // 32, 32)
-    q1 = f8(g1.float()[:, iq] / 64.0).view(cout, K // 32, 32)
-    plane1 = torch.stack((q2, q1), dim=2).reshape(cout, 2 * K).contiguous().view(torch.int16)       # [cout][K] as 16-bit
-    planes = torch.cat((g1[:, ip].contiguous().view(torch.int16).reshape(-1), plane1.reshape(-1)))
-    if planes.numel() % 2:
-        planes = torch.cat((planes, torch.zeros(1, dtype=torch.int16)))
-    return torch.cat((planes.view(torch.float32), torch.tensor([2.0 ** (-e)], dtype=torch.float32)))
 
 
 def split_f16x2(t):

@@ -417,86 +417,6 @@ def test_gat_mixed_density_batch_list_and_dense_kernels(gpu_device, mode, concat
     np.testing.assert_allclose(layer.aij.cpu().numpy(), a_ref.numpy(), rtol=0, atol=3e-6)
 
 
-@pytest.mark.parametrize("cin,cout,c2,M", [(64, 128, 0, 200), (128, 128, 64, 131), (32, 128, 32, 64), (32, 64, 0, 130),
-                                           (64, 64, 32, 77), (32, 32, 32, 129), (32, 32, 0, 40)])
-def test_conv_gemm_bf16x6_split_mfma_matches_fp64(gpu_device, cin, cout, c2, M):
-    """bf16x6 split-MFMA conv (3 bf16 planes per operand, six partial products) is fp32-accurate: compared with an
-    fp64 conv2d of the same fp32 inputs; also checks the 3-plane output format round trip."""
-    from magat_pathplanning_amd.encoder import split_bf16x3
-    nat, lib = _nat()
-    g = torch.Generator().manual_seed(cin + cout + c2)
-    x = torch.randn(M, cin, 6, 6, generator=g)
-    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
-    b = torch.randn(cout, generator=g)
-    ref = tnf.conv2d(x.double(), w.double(), b.double(), 1, 1)
-    wt = w.permute(0, 2, 3, 1).reshape(cout, -1)
-    d = nat.ConvGemmDesc()
-    keep = []
-    if c2:
-        x2 = torch.randn(M, c2, 6, 6, generator=g)
-        w2 = torch.randn(cout, c2, 1, 1, generator=g) / c2 ** 0.5
-        ref = ref + tnf.conv2d(x2.double(), w2.double())
-        wt = torch.cat((wt, w2.reshape(cout, c2)), dim=1)
-        x2s = split_bf16x3(_to_pixel_major(x2)).to(gpu_device)
-        keep.append(x2s)
-        d.in2, d.in2_pix_stride, d.C2, d.lda2, d.W2, d.stride2 = x2s.data_ptr(), M * c2, c2, c2, 6, 1
-        d.in2_plane_stride = 36 * M * c2
-    ref = ref.clamp_min(0)
-    xs = split_bf16x3(_to_pixel_major(x)).to(gpu_device)
-    ws = split_bf16x3(wt.contiguous()).to(gpu_device)
-    bd = b.to(gpu_device)
-    d.inp, d.wt, d.bias = xs.data_ptr(), ws.data_ptr(), bd.data_ptr()
-    d.in_pix_stride, d.out_pix_stride = M * cin, M * cout
-    d.in_plane_stride = 36 * M * cin
-    d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, 6, 6, 3, 3, 1, 1
-    d.Hout, d.Wout, d.Cout, d.ldc, d.relu, d.in_fmt = 6, 6, cout, cout, 1, 1
-    keep32 = [_to_pixel_major(x).to(gpu_device)]
-    if c2:
-        keep32.append(_to_pixel_major(x2).to(gpu_device))
-    for out_fmt in (0, 1, 2):
-        if out_fmt == 2:        # float32 activations split by the loader (in_fmt = 2), float32 output
-            d.in_fmt, d.inp = 2, keep32[0].data_ptr()
-            if c2:
-                d.in2 = keep32[1].data_ptr()
-            out_fmt = 0
-        d.out_fmt = out_fmt
-        if out_fmt == 0:
-            out = torch.full((36, M, cout), float("nan"), device=gpu_device)
-        else:
-            out = torch.zeros(3, 36, M, cout, dtype=torch.bfloat16, device=gpu_device)
-            d.out_plane_stride = 36 * M * cout
-        d.out = out.data_ptr()
-        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "conv_gemm bf16x6")
-        torch.cuda.synchronize()
-        got = out.cpu() if out_fmt == 0 else out.float().sum(dim=0).cpu()
-        got = _from_pixel_major(got, 6, 6)
-        err = (got.double() - ref).abs().max().item()
-        assert err <= 8e-6, (out_fmt, err)     # fp32 rounding class (the fp32 MFMA kernel sits at ~2e-6 here)
-
-
-def test_f32_conv_emits_bf16x3_planes(gpu_device):
-    nat, lib = _nat()
-    M, cin, cout = 96, 32, 64
-    g = torch.Generator().manual_seed(3)
-    x = torch.randn(36, M, cin, generator=g).to(gpu_device)
-    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(gpu_device)
-    out32 = torch.empty(36, M, cout, device=gpu_device)
-    out3 = torch.zeros(3, 36, M, cout, dtype=torch.bfloat16, device=gpu_device)
-    d = nat.ConvGemmDesc()
-    d.inp, d.wt = x.data_ptr(), w.data_ptr()
-    d.in_pix_stride, d.out_pix_stride, d.out_plane_stride = M * cin, M * cout, 36 * M * cout
-    d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, 6, 6, 1, 1, 1, 0
-    d.Hout, d.Wout, d.Cout, d.ldc = 6, 6, cout, cout
-    d.out, d.out_fmt = out32.data_ptr(), 0
-    nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "f32 out")
-    d.out, d.out_fmt = out3.data_ptr(), 1
-    nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "split out")
-    torch.cuda.synchronize()
-    rec = out3[0].float() + out3[1].float() + out3[2].float()
-    rel = ((rec - out32).abs() / out32.abs().clamp_min(1e-20)).max().item()
-    assert rel <= 2 ** -22, rel
-
-
 @pytest.mark.parametrize("mode,concat,N,G,K,P", [("KeyQuery", True, 12, 64, 3, 2), ("KeyQuery", False, 20, 128, 2, 4),
                                                 ("GAT_modified", True, 9, 32, 4, 3), ("KeyQuery", True, 30, 16, 1, 2),
                                                 ("GAT_modified", False, 40, 128, 3, 2), ("GAT_origin", True, 14, 32, 3, 4),
@@ -882,52 +802,13 @@ def test_conv_gemm_f16x3_split_mfma_matches_fp64(gpu_device, cin, cout, c2, M, s
 
 
 
-def test_conv_gemm_f16_plane_formats(gpu_device, monkeypatch, libopt):
-    """in_fmt 5 (activations already as two f16 planes) gives bit-identical results to in_fmt 4 (split on load), and
-    out_fmt 3 (epilogue writes the two planes) reproduces the float32 output to 2^-22."""
-    from magat_pathplanning_amd.encoder import split_f16x2
-    nat, lib = _nat()
-    M, cin, cout = 150, 64, 128
-    g = torch.Generator().manual_seed(5)
-    x = torch.relu(torch.randn(M, cin, 6, 6, generator=g))
-    wt = (torch.randn(cout, 9 * cin, generator=g) / (9 * cin) ** 0.5).contiguous()
-    b = torch.randn(cout, generator=g)
-    xp = _to_pixel_major(x).to(gpu_device)                           # [36][M][cin] float32
-    h1 = xp.clamp(-65504, 65504).half()
-    planes = torch.stack((h1, (xp - h1.float()).half())).contiguous()  # [2][36][M][cin]
-    ws, bd = split_f16x2(wt)[0].to(gpu_device), b.to(gpu_device)
-    outs = {}
-    # (4, 0) runs on the direct kernel, whose default K walk is channel-slab-major; the tap-major walk of the LDS-staged
-    # kernel (the other two cases) gives bit-identical sums only in the same order
-    libopt.set("MAGAT_CONV_KORDER", "0")
-    for in_fmt, out_fmt in ((4, 0), (5, 0), (4, 3)):
-        d = nat.ConvGemmDesc()
-        src = planes if in_fmt == 5 else xp
-        out = (torch.zeros(2, 36, M, cout, dtype=torch.float16, device=gpu_device) if out_fmt == 3 else
-               torch.full((36, M, cout), float("nan"), device=gpu_device))
-        d.inp, d.wt, d.bias, d.out = src.data_ptr(), ws.data_ptr(), bd.data_ptr(), out.data_ptr()
-        d.in_pix_stride, d.out_pix_stride = M * cin, M * cout
-        d.in_plane_stride, d.out_plane_stride = 36 * M * cin, 36 * M * cout
-        d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, 6, 6, 3, 3, 1, 1
-        d.Hout, d.Wout, d.Cout, d.ldc, d.relu, d.in_fmt, d.out_fmt = 6, 6, cout, cout, 1, in_fmt, out_fmt
-        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "conv_gemm f16 planes")
-        torch.cuda.synchronize()
-        outs[(in_fmt, out_fmt)] = out
-    assert torch.equal(outs[(4, 0)], outs[(5, 0)])
-    rec = outs[(4, 3)][0].float() + outs[(4, 3)][1].float()
-    ref = outs[(4, 0)]
-    assert float((rec - ref).abs().max()) <= 2.0 ** -21 * float(ref.abs().max())
-
-
 @pytest.mark.gpu
-@pytest.mark.parametrize("korder", [0, 1])
-def test_conv_gemm_f16x3_granule_layouts(gpu_device, monkeypatch, korder, libopt):
+def test_conv_gemm_f16x3_granule_layouts(gpu_device, monkeypatch, libopt):
     """Direct f16x3 kernel: float32 granule-major tiles (in_gl/out_gl = 1) are bit-identical to row-major tiles; f16
     plane granules (in_gl/out_gl = 2, K-permuted weights) agree to the rounding of the two output planes and of the
-    MFMA's internal sum order.  Residual 1x1 segment (in2), ragged M (partial last agent tile), both K walks."""
+    MFMA's internal sum order.  Residual 1x1 segment (in2), ragged M (partial last agent tile)."""
     from magat_pathplanning_amd.encoder import split_f16x2
     nat, lib = _nat()
-    libopt.set("MAGAT_CONV_KORDER", str(korder))
     M, cin, cout, c2, npix = 300, 64, 128, 32, 36
     Mp = (M + 127) // 128 * 128
     g = torch.Generator().manual_seed(11)
@@ -1102,52 +983,3 @@ def test_conv_gemm_f32_per_pixel_weights_over_pooled_map(gpu_device, M, cin, cou
     assert lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)) == -2      # MAGAT_ERR_UNSUPPORTED
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("M,cin,cmid,cout", [(256, 64, 64, 128), (150, 32, 64, 64)])
-def test_conv_gemm_f16_plus_mx_correction_chain(gpu_device, M, cin, cmid, cout):
-    """in_gl / out_gl = 3 at the C ABI: a producer conv writes the "f16 + MX correction" plane granules (plane 1 =
-    e4m3(h1) | e4m3(h2 * 2^11)), a consumer conv reads them with the third weight copy (encoder._mx_block) and issues two
-    f16 MFMAs + one block-scaled fp8 MFMA per slab.  Against float64 of the same two 3x3 convs (+ReLU between): the
-    corrections are only 4 bits wide, yet the result stays within 2e-5 of the output scale (f16x3: 3e-6), ragged agent
-    count included.  The same chain with out_gl / in_gl = 2 (three f16 products) must agree with it to that bound too."""
-    nat, lib = _nat()
-    from magat_pathplanning_amd.encoder import _mx_block, split_f16x2
-    g = torch.Generator().manual_seed(M + cin)
-    hw, Mp = 6, (M + 127) // 128 * 128
-    x = torch.relu(torch.randn(M, cin, hw, hw, generator=g))
-    wa = torch.randn(cmid, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
-    wb = torch.randn(cout, cmid, 3, 3, generator=g) / (9 * cmid) ** 0.5
-    ba, bb = torch.randn(cmid, generator=g) * 0.1, torch.randn(cout, generator=g) * 0.1
-    ref = tnf.conv2d(tnf.conv2d(x.double(), wa.double(), ba.double(), 1, 1).clamp_min(0), wb.double(), bb.double(), 1, 1)
-    wa2, wb2 = wa.permute(0, 2, 3, 1).reshape(cmid, -1).contiguous(), wb.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
-    perm32 = torch.tensor([16 * (q >> 4) + 8 * ((q & 7) >> 2) + 4 * ((q >> 3) & 1) + (q & 3) for q in range(32)])
-    kidx = (torch.arange(wb2.shape[1]) // 32) * 32 + perm32.repeat(wb2.shape[1] // 32)
-    wts = {3: _mx_block(wb2, perm32).to(gpu_device), 2: split_f16x2(wb2[:, kidx])[0].to(gpu_device)}
-    wad = split_f16x2(wa2)[0].to(gpu_device)
-    xin = torch.zeros(hw * hw, Mp, cin)
-    xin[:, :M] = _to_pixel_major(x)
-    xin = xin.to(gpu_device)
-    bad, bbd = ba.to(gpu_device), bb.to(gpu_device)
-    st = nat.current_stream(gpu_device)
-    outs = {}
-    for lay in (3, 2):
-        mid = torch.zeros(hw * hw * Mp * cmid, device=gpu_device)            # plane granules: 4 bytes per value
-        out = torch.full((hw * hw, Mp, cout), float("nan"), device=gpu_device)
-        d = nat.ConvGemmDesc()
-        d.inp, d.wt, d.bias, d.out = xin.data_ptr(), wad.data_ptr(), bad.data_ptr(), mid.data_ptr()
-        d.in_pix_stride, d.out_pix_stride = Mp * cin, Mp * cmid
-        d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, hw, hw, 3, 3, 1, 1
-        d.Hout, d.Wout, d.Cout, d.ldc, d.relu, d.in_fmt, d.in_gl, d.out_gl = hw, hw, cmid, cmid, 1, 4, 0, lay
-        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), st), "producer")
-        e = nat.ConvGemmDesc()
-        e.inp, e.wt, e.bias, e.out = mid.data_ptr(), wts[lay].data_ptr(), bbd.data_ptr(), out.data_ptr()
-        e.in_pix_stride, e.out_pix_stride = Mp * cmid, Mp * cout
-        e.M, e.Cin, e.lda, e.Hin, e.Win, e.kH, e.kW, e.stride, e.pad = M, cmid, cmid, hw, hw, 3, 3, 1, 1
-        e.Hout, e.Wout, e.Cout, e.ldc, e.relu, e.in_fmt, e.in_gl, e.out_gl = hw, hw, cout, cout, 0, 4, lay, 0
-        nat.check(lib.magat_conv_gemm_f32(ctypes.byref(e), st), "consumer")
-        torch.cuda.synchronize()
-        outs[lay] = _from_pixel_major(out[:, :M].cpu(), hw, hw).double()
-    scale = float(ref.abs().max())
-    assert float((outs[2] - ref).abs().max()) <= 3e-6 * scale
-    assert float((outs[3] - ref).abs().max()) <= 2e-5 * scale
-    assert float((outs[3] - outs[2]).abs().max()) > 0.0          # really another arithmetic

@@ -179,25 +179,12 @@ def test_guard_off_shows_what_it_protects_from(gpu_device, libopt, monkeypatch):
     assert net.range_status()["encoder_rerun"]
 
 
-def test_mx_opt_in_is_guarded_too(gpu_device, libopt, monkeypatch):
-    """OPT-IN f16 + block-scaled-fp8 correction form: its e4m3 planes saturate beyond +-448.  Activations in the thousands
-    (fine for f16x3) trip the flag there and the float32 re-run restores parity."""
+def test_ill_conditioned_checkpoint_follows_float32(gpu_device, libopt, monkeypatch):
+    """Activations in the thousands (maps of 1e3..1e5 cancelling down to logits of 3e2): inside the f16 planes' range - no
+    re-run - and as accurate as the float32 arithmetic allows there.  (MAGAT_ACT_SCALE=0: every plane at its layer's true scale.)"""
     monkeypatch.setenv("MAGAT_ACT_SCALE", "0")
-    libopt.set("MAGAT_CONV_MX", 1)
     cfg, sd, net = _scaled_model(gpu_device, 1000.0, where="layer2")
     got, ref = _run(net, cfg, sd, gpu_device)
-    st = net.range_status()
-    # (float32 itself is at ~1e-4 of the logit scale here - maps of 1e3..1e5 cancel down to logits of 3e2, the oracle runs in
-    #  float64 - and the re-run's long-K head and the fast path's per-cell head round differently: 1.5e-4 for this case)
-    lim = 1.5e-4 * max(1.0, float(ref.abs().max()))
-    assert float((got - ref).abs().max()) <= lim, (float((got - ref).abs().max()), lim, st)
-    assert st["encoder_rerun"], st
-    # the same checkpoint on the default f16x3 arithmetic stays inside the planes' range: no re-run
-    libopt.reset("MAGAT_CONV_MX")
-    got, ref = _run(net, cfg, sd, gpu_device)
-    # (2e-4 of the logit scale: with maps of 1e3..1e5 cancelling down to logits of 3e2 the float32 forms themselves differ by
-    #  1e-4 .. 2e-4 from the float64 oracle, depending on their summation order - the eight-agent stem kernel of round 4 sums
-    #  layer1.conv1's 18 k steps in one accumulator where the row-band kernel used two: 1.74e-4 here against 1.4e-4)
     err, scale = float((got - ref).abs().max()), max(1.0, float(ref.abs().max()))
     assert not net.range_status()["encoder_rerun"]
     # ... and the bound FOLLOWS the float32 arithmetic instead of the implementation (ADVICE r04): the same checkpoint on the

@@ -227,37 +227,6 @@ def test_f16x2_weight_block_reconstructs_weights():
         assert float(err.max()) <= max(2.0 ** -22 * float(w.abs().max()), 2.0 ** -24 * 2.0 ** (-e)), (amp, float(err.max()))
 
 
-def test_mx_weight_block_decodes_to_the_weights():
-    """encoder._mx_block (third weight copy of the pack, magat_hip.h in_gl = 3): plane 0 holds the f16 part g1 of the scaled
-    weights in plane-granule K order, plane 1 per row and 32-column slab [e4m3(g2 * 2^5) | e4m3(g1 * 2^-6)] in the byte
-    order the producers' lanes emit.  Decoding it back gives g1 exactly and g2 / g1 to fp8 precision; the block has the
-    size of split_f16x2's (the kernels address all three copies with one stride)."""
-    import torch
-    from magat_pathplanning_amd.encoder import MX_PI, _mx_block, split_f16x2
-    torch.manual_seed(0)
-    cout, K = 64, 9 * 32 + 32
-    w = torch.randn(cout, K) * 0.05
-    perm32 = torch.tensor([16 * (q >> 4) + 8 * ((q & 7) >> 2) + 4 * ((q >> 3) & 1) + (q & 3) for q in range(32)])
-    blk = _mx_block(w, perm32)
-    ref_blk, e = split_f16x2(w.reshape(-1))
-    assert blk.numel() == ref_blk.numel() and blk[-1] == ref_blk[-1] == 2.0 ** (-e)
-    raw = blk[:-1].view(torch.int16)
-    p0 = raw[:cout * K].view(torch.float16).view(cout, K).float()
-    p1 = raw[cout * K:2 * cout * K].contiguous().view(torch.uint8).view(cout, K // 32, 2, 32)
-    ts = w * 2.0 ** e
-    g1 = ts.half().float()
-    g2 = (ts - g1).half().float()
-    kperm = (torch.arange(K) // 32) * 32 + perm32.repeat(K // 32)
-    assert torch.equal(p0, g1[:, kperm])
-    kpi = (torch.arange(K) // 32) * 32 + torch.tensor(MX_PI).repeat(K // 32)
-    q2 = p1[:, :, 0].reshape(cout, K).view(torch.float8_e4m3fn).float() / 32.0
-    q1 = p1[:, :, 1].reshape(cout, K).view(torch.float8_e4m3fn).float() * 64.0
-    assert sorted(MX_PI) == list(range(32))
-    # e4m3: 3 mantissa bits -> relative error <= 2^-4 for normal numbers, absolute <= half a subnormal step below
-    assert ((q1 - g1[:, kpi]).abs() <= g1[:, kpi].abs() / 16 + 64.0 * 2.0 ** -10).all()
-    assert ((q2 - g2[:, kpi]).abs() <= g2[:, kpi].abs() / 16 + 2.0 ** -10 / 32.0).all()
-
-
 def test_fold_activation_scales_is_exact_and_consistent():
     """encoder.fold_activation_scales (include/magat_hip.h "Activation scales"): every entry of the block is the pack's value
     times a power of two; a block's input, conv1 output and residual input share one exponent; the 1 / weight-scale floats

@@ -23,7 +23,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     h.magat_chain_set_debug_buffer(None)
 t = buf.cpu().numpy().astype(np.float64)
-if t.any():          # (not launched when the chain kernels run as one launch, option BLOCK_FULL)
+if t.any():          # (not launched when the chain kernels run as one launch, option BLOCK_FUSED = 2)
     names = ["prologue (barrier + LDS write of the prefetched inputs)", "stage A", "barrier A", "stage B", "barrier B", "stage C (+ stores)"]
     d = t[:, 1:7] - t[:, 0:6]
     tot = t[:, 6] - t[:, 0]
@@ -41,7 +41,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     h.magat_block3_set_debug_buffer(None)
 t = buf3.cpu().numpy().astype(np.float64)
-full = bool(nat.get_option("BLOCK_FULL") and nat.get_option("BLOCK_FUSED") >= 2 and nat.get_option("BLOCK3_FUSED") >= 2)
+full = nat.get_option("BLOCK_FUSED") >= 2
 names = ["prologue (input DMA + barrier)", "conv1 half 0", "  barrier", "conv2 half 0", "  barrier", "conv1 half 1", "  barrier",
          "conv2 half 1 + residual", "  barrier", "relu + pool + store"]
 d = t[:, :, 1:11] - t[:, :, 0:10]                 # [wg][wave][phase]
@@ -59,7 +59,7 @@ if not full and t[:, 0, 13].any():
         (o[:, :, 13] - o[:, :, 9]).mean(), (o[:, :, 14] - o[:, :, 13]).mean(), (o[:, :, 15] - o[:, :, 14]).mean(),
         (o[:, :, 10] - o[:, :, 15]).mean()))
 
-# the merged kernel (option BLOCK_FULL, default): stamps 0..10 of block_full_w4_kernel, per wave, LAST group of a workgroup
+# the merged kernel (option BLOCK_FUSED = 2, default): stamps 0..10 of block_full_p_kernel, per wave, LAST group of a workgroup
 if full:
     names = ["wait inputs + barrier", "stage A (layer1.conv2)", "stage B (layer2.conv1)", "stage C (layer2.conv2)",
              "layer3.conv1 half 0", "layer3.conv2 half 0", "layer3.conv1 half 1", "layer3.conv2 half 1 + residual",
