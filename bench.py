@@ -499,6 +499,14 @@ def main():
                            fused_stem="layer1.conv1" not in kern, pooled_head=("layer3 (fused, pooled)" in kern or "layer1.conv2+layer2+layer3 (fused, pooled)" in kern))
         if "conv_first" in kern and "layer1.conv1" not in kern and cfg.CNN_mode.startswith("ResNet"):
             kern = {("conv_first+layer1.conv1 (fused)" if k == "conv_first" else k): v for k, v in kern.items()}
+        # compressMLP in the head's epilogue (option HEAD_COMPRESS; round 5): one launch carries both layers' work - the pooled
+        # map in, feat AND comp out
+        hk = "head(avgpool+fc+linear)"
+        if hk in kern and "compressMLP" not in kern and "compressMLP" in work and cfg.CNN_mode.startswith("ResNet"):
+            kern = {("head+compressMLP (one launch)" if k == hk else k): v for k, v in kern.items()}
+            hw_, cw_ = work[hk], work["compressMLP"]
+            work["head+compressMLP (one launch)"] = dict(flops=hw_["flops"] + cw_["flops"], arith=hw_["arith"],
+                                                         bytes=hw_["bytes"] + 4 * cfg.bottleneckFeature)
         agent_steps = Bk * Nk * steps
         table = {}
         for name, (cnt, tot_ms) in kern.items():

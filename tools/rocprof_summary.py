@@ -12,10 +12,11 @@ from collections import defaultdict
 
 def short(name):
     import re
-    m = re.search(r"conv_gemm_f16x3_direct_kernel<(\d+), (\d+), (true|false|0|1|2)>", name)
-    if m:                                       # f16x3 / f16 + MX correction, activations straight into registers
-        inf = {"true": "planes-in", "false": "f32-in", "0": "f32-in", "1": "planes-in", "2": "MX planes-in"}[m.group(3)]
-        return "conv_f16x3_direct<%s,TM%s,%s>" % (m.group(1), m.group(2), inf)
+    m = re.search(r"conv_gemm_f16x3_direct_kernel<(\d+), (\d+), (0|1)(?:, \(bool\))?(?:, )?(true|false|0|1)?>", name)
+    if m:                                       # f16x3, activations straight into registers (FUSE2: + a second layer in the epilogue)
+        inf = {"0": "f32-in", "1": "planes-in"}[m.group(3)]
+        fuse = m.group(4) in ("true", "1")
+        return "conv_f16x3_direct<%s,TM%s,%s%s>" % (m.group(1), m.group(2), inf, ",+layer2" if fuse else "")
     m = re.search(r"conv_gemm_bf16x6_kernel<true, (\d+), \d+, \d+, 2>", name)
     if m:                                       # NPL = 2: the f16x3 flavour of the split kernel
         return "conv_gemm_f16x3<f32-in,%s>" % m.group(1)
@@ -128,8 +129,7 @@ def main():
         pass
     TAGS = [("conv_first+layer1.conv1 (fused)", stem_kernel, 1, 0),
             ("layer1.conv2+layer2+layer3 (fused, pooled)", "block_full_", 1, 0),
-            ("head(avgpool+fc+linear)", "conv_gemm_f16x3_direct_kernel<128, 1, 0>", 2, 0),      # two launches per step:
-            ("compressMLP", "conv_gemm_f16x3_direct_kernel<128, 1, 0>", 2, 1),                 # head, then compressMLP
+            ("head+compressMLP (one launch)", "+layer2>", 1, 0),      # (matched on the SHORT name: see per_tag)
             ("gat_layer (one launch)", "gat_mfma_kernel", 1, 0),
             ("actionsMLP", "skinny_gemm_kernel", 1, 0)]
     SEQ = [t[0] for t in TAGS]
@@ -139,7 +139,7 @@ def main():
         """rows of one csv -> {tag: [values of the last nsteps steps]}"""
         got = {}
         for tag, needle, per_step, which in TAGS:
-            mine = [r for r in rows if needle in r["Kernel_Name"]]
+            mine = [r for r in rows if needle in r["Kernel_Name"] or needle in short(r["Kernel_Name"])]
             mine.sort(key=order_key)
             mine = mine[-nsteps * per_step:]
             if len(mine) == nsteps * per_step:
