@@ -319,6 +319,34 @@ def test_compress_in_the_head_epilogue_is_bit_identical(gpu_device, libopt):
     assert not net.range_status()["encoder_rerun"]
 
 
+def test_stem_binary_input_fast_path_and_general_inputs(gpu_device):
+    """Round 5: the stem skips its third split product for a group of eight agents whose state maps are exact in ONE f16 plane
+    (the reference's binary 'Project_G' channels): a sum of exact zeros.  General float32 inputs (a second plane that is not
+    zero) take all three products.  Both against the oracle; and a binary planning instance gives the same logits whether its
+    batch neighbours are binary or not (groups of eight agents are decided one by one)."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N = 6, 16                                        # 96 agents = 12 groups of eight, two per instance
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat")
+    sd = orc.init_state_dict(cfg, seed=29)
+    net = _build(cfg, sd, gpu_device)
+    xb = fov_states(B, N, seed=3)
+    g = torch.Generator().manual_seed(4)
+    xn = xb.clone()
+    xn[1::2] += 0.37 * torch.randn(xn[1::2].shape, generator=g)      # odd instances: values with a non-zero second plane
+    S = comm_gso(B, N, 20, seed=5)
+    outs = {}
+    for name, x in (("binary", xb), ("mixed", xn)):
+        ref = orc.planner_forward(x, S.clone(), sd, cfg)
+        with torch.no_grad():
+            net.addGSO(S.clone().to(gpu_device))
+            got = net(x.to(gpu_device)).cpu()
+        assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), name
+        outs[name] = got
+    for b in range(0, B, 2):                             # the binary instances of the mixed batch: the same numbers
+        assert torch.equal(outs["mixed"][b * N:(b + 1) * N], outs["binary"][b * N:(b + 1) * N]), b
+
+
 def test_shard_equivalence_across_the_encoder_chunk(gpu_device, libopt):
     """The encoder walks a batch in chunks of MAGAT_ENC_CHUNK agents (65 536).  The form of the head is chosen on the
     agent count of the whole call, so the short last chunk sums like the others and a batch that spills into a second
