@@ -79,173 +79,6 @@ long long* g_block3_dbg = nullptr;
 #define L3_STAMP(i) do { } while (0)
 #endif
 
-// One convolution stage: out = relu(conv3x3(in, CIN -> COUT) + conv1x1(in2, C2 -> COUT) + bias).
-// in / in2 / out are LDS maps (LAST: out goes to global memory).  wts: this stage's fragment-major weights.
-template <int CIN, int C2, int COUT, bool LAST>
-__device__ __forceinline__ void chain_stage(const ChainParams& p, char* lds, int in_off, int in2_off, int out_off,
-                                            const char* wts, const float* bias, float scale, int group, bool& clamped) {
-  constexpr int KSM = CIN / 16, KS2 = C2 / 16;
-  constexpr int BPT = (9 * KSM + KS2) * 2;                  // 1 KB weight blocks per channel tile
-  constexpr int PS_IN = (CIN / 8) * BLK, PS_IN2 = (C2 / 8) * BLK, PS_OUT = (COUT / 8) * BLK;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int fr = lane & 31, fh = lane >> 5;
-  const int agent = fr & 7, psl = fr >> 3;                  // row of the tile = (pixel slot of the tile, agent)
-  int ct, tl[3];
-  if (COUT == 32) {
-    ct = 0;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) tl[s] = WT32[wave][s];
-  } else {
-    ct = wave & 1;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) tl[s] = WG64[wave >> 1][s];
-  }
-  int umask = 0;
-  unsigned ab[3], az[3];        // lane base of its pixel in plane 0 / of the zero pixel (both minus nothing: offsets carry TAPBIAS)
-  int lmask[3];                 // per-lane valid taps of the slot's pixel
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const int tile = tl[s] < 0 ? 0 : tl[s];
-    if (tl[s] >= 0) umask |= TILE_TAPS[tile];
-    const int pix = TILE_PIX[tile][psl];
-    const int y = pix / 6, x = pix - 6 * y;
-    int m = 0;
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-      const int dy = tp / 3 - 1, dx = tp % 3 - 1;
-      if (y + dy >= 0 && y + dy < 6 && x + dx >= 0 && x + dx < 6) m |= 1 << tp;
-    }
-    lmask[s] = m;
-    ab[s] = (unsigned)(pix * PIXB + agent * 16 + fh * BLK);
-    az[s] = (unsigned)(ZPIX * PIXB + agent * 16 + fh * BLK);
-  }
-  f32x16 acc[3];
-#pragma unroll
-  for (int s = 0; s < 3; ++s)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-
-  // weights of one tap (index u = 0..8, 9 = the 1x1 residual segment): KSM (KS2) k steps x 2 planes, 16 bytes per lane each
-  const char* wl = wts + (size_t)ct * BPT * 1024 + lane * 16;
-  u32x4 bcur[KSM][2], bnxt[KSM][2];
-  auto load_b = [&](int u, u32x4 (&b)[KSM][2]) {
-#ifdef MAGAT_WHATIF_NO_W       // timing experiment (wrong results; tools/whatif_block3.sh): one weight fetch per stage
-    if (u != __builtin_ctz(umask | (KS2 > 0 ? 0x200 : 0))) return;
-#endif
-    const char* src = wl + (size_t)(u < 9 ? u * KSM : 9 * KSM) * 2048;
-#pragma unroll
-    for (int ks = 0; ks < KSM; ++ks)
-      if (u < 9 || ks < KS2) {
-        b[ks][0] = *reinterpret_cast<const u32x4*>(src + ks * 2048);
-        b[ks][1] = *reinterpret_cast<const u32x4*>(src + ks * 2048 + 1024);
-      }
-  };
-  const int walk = umask | (KS2 > 0 ? 0x200 : 0);           // taps this wave visits (+ the residual segment)
-  load_b(__builtin_ctz(walk), bcur);
-  constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};        // h1g1 h1g2 h2g1 (activation plane, weight plane)
-#pragma unroll
-  for (int tp = 0; tp < 9; ++tp) {
-    if (!(umask >> tp & 1)) continue;                         // wave-uniform
-    const int rest = walk >> (tp + 1);
-    if (rest) load_b(tp + 1 + __builtin_ctz(rest), bnxt);     // next visited tap: in flight under this tap's MFMAs
-    const int dy = tp / 3 - 1, dx = tp % 3 - 1;
-    const int shift = (6 * dy + dx) * PIXB + TAPBIAS;         // >= 0
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      if (tl[s] < 0 || !(TILE_TAPS[tl[s] < 0 ? 0 : tl[s]] >> tp & 1)) continue;     // wave-uniform
-      // lanes whose pixel has no neighbour at this tap (corner tile only) read the zero pixel instead
-      const unsigned a0 = ((lmask[s] >> tp & 1) ? ab[s] + (unsigned)shift : az[s] + (unsigned)TAPBIAS) + (unsigned)in_off -
-                          (unsigned)TAPBIAS;
-#pragma unroll
-      for (int ks = 0; ks < KSM; ++ks) {
-        const u32x4 a1 = *reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK);
-        const u32x4 a2 = *reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK + PS_IN);
-        const u32x4 av[2] = {a1, a2};
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bcur[ks][PB[q]]),
-                                                          __builtin_bit_cast(f16x8, av[PA[q]]), acc[s], 0, 0, 0);
-      }
-    }
-    if (rest) {
-#pragma unroll
-      for (int ks = 0; ks < KSM; ++ks) { bcur[ks][0] = bnxt[ks][0]; bcur[ks][1] = bnxt[ks][1]; }
-    }
-  }
-  if (KS2 > 0) {     // residual 1x1 branch: the block input at the same pixel
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      if (tl[s] < 0) continue;
-      const unsigned a0 = ab[s] + (unsigned)in2_off;
-#pragma unroll
-      for (int ks = 0; ks < KS2; ++ks) {
-        const u32x4 a1 = *reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK);
-        const u32x4 a2 = *reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK + PS_IN2);
-        const u32x4 av[2] = {a1, a2};
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bcur[ks][PB[q]]),
-                                                          __builtin_bit_cast(f16x8, av[PA[q]]), acc[s], 0, 0, 0);
-      }
-    }
-  }
-  // epilogue: D[channel][row]; channel = 32 ct + (r & 3) + 8 (r >> 2) + 4 fh.  Quads 2 ks, 2 ks + 1 of the lane are the next
-  // layer's k-step-ks operand (plane-granule order): chunk (ct * 2 + ks) * 2 + fh of the output map
-  f32x4 bq[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bias + 32 * ct + 8 * q + 4 * fh);
-  const int m = group * AG + agent;
-  const bool mok = m < p.M;
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    if (tl[s] < 0) continue;
-    const int pix = tile_pix(tl[s], psl);
-    if (LAST && p.out_gl == 0) {         // float32 row-major agent tiles [tile][pixel][128][COUT]
-      if (mok) {
-        float* orow = reinterpret_cast<float*>(p.out) + (long long)pix * p.out_pix_stride +
-                      magat_row_off(m, COUT, p.out_tile) + 32 * ct + 4 * fh;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 v;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[s][4 * q + c] * scale + bq[q][c], 0.f);
-          *reinterpret_cast<f32x4*>(orow + 8 * q) = v;
-        }
-      }
-      continue;
-    }
-    float cl = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      unsigned h1[4], h2[4];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int q = 2 * ks + e;
-        // (one packed fma per pair - these epilogues run with the matrix pipe idle, where v_pk_fma_f32 issues like any other
-        //  vector instruction; ReLU is the lower clamp of split2)
-        const f32x2 v01 = __builtin_elementwise_fma(f32x2{acc[s][4 * q], acc[s][4 * q + 1]}, f32x2{scale, scale}, f32x2{bq[q][0], bq[q][1]});
-        const f32x2 v23 = __builtin_elementwise_fma(f32x2{acc[s][4 * q + 2], acc[s][4 * q + 3]}, f32x2{scale, scale}, f32x2{bq[q][2], bq[q][3]});
-        split2(v01[0], v01[1], h1[2 * e], h2[2 * e], cl);
-        split2(v23[0], v23[1], h1[2 * e + 1], h2[2 * e + 1], cl);
-      }
-      const int chunk = (ct * 2 + ks) * 2 + fh;
-      if (LAST) {
-        if (mok) {
-          char* o = p.out + ((long long)pix * p.out_pix_stride + (long long)(m >> 7) * p.out_tile) * 4 + (m & 127) * 16 +
-                    (long long)chunk * 2048;
-          *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
-          *reinterpret_cast<u32x4*>(o + 256 * COUT) = u32x4{h2[0], h2[1], h2[2], h2[3]};
-        }
-      } else {
-        char* o = lds + out_off + chunk * BLK + pix * PIXB + agent * 16;
-        *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
-        *reinterpret_cast<u32x4*>(o + PS_OUT) = u32x4{h2[0], h2[1], h2[2], h2[3]};
-      }
-    }
-    clamped |= cl > 65504.f && mok;      // (rows of agents past M compute on whatever the padded tile holds)
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // layer3 of ResNetLarge in one launch: conv1 (64 -> 128) -> conv2 (128 -> 128) + downsample(64 -> 128) -> ReLU -> 2x2 sum-pool.
@@ -270,108 +103,7 @@ struct L3Params {
   int out_gl;             // block_full_p_kernel: 1 = the pooled map granule-major, [agent tile][cell 9][128 / 4][128 agents][4]
 };
 
-// row-tile groups of the conv2 waves: 33 + 36 tile-taps
-__device__ constexpr int L3_RG[2][5] = {{T_I0, T_I1, T_I2, T_ET, -1}, {T_I3, T_C, T_EB, T_EL, T_ER}};
 
-// K walk of one wave over its row tiles (run-time list, -1 = none): acc[s] += conv taps (KSM k steps each) [+ residual segment].
-// Register-lean form for the layer3 kernel, whose conv2 accumulators (80 registers) stay live across everything: the weight
-// ring holds ONE k step (two planes, 8 registers) per slot and is fetched one k step ahead - a k step is 3 MFMAs per row
-// tile, 6-15 MFMAs per wave, about an L2 round trip.
-template <int KSM, int KS2, int NS>
-__device__ __forceinline__ void conv_walk(char* lds, int in_off, int in2_off, const char* wl, const int (&tl)[NS],
-                                          f32x16 (&acc)[NS]) {
-  constexpr int PS_IN = 2 * KSM * BLK, PS_IN2 = 2 * KS2 * BLK;
-  constexpr int NSTEP = 9 * KSM + KS2;                 // k steps of the whole walk, in weight-stream order
-  // (laundered thread index: the per-tap LDS addresses below are recomputed in every call - left alone, the compiler hoists
-  //  all 9 x NS of them out of the caller's loop over the channel halves and spills them: 1.3 KB of scratch per lane)
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const int lane = tid & 63;
-  const int fr = lane & 31, fh = lane >> 5;
-  const int agent = fr & 7, psl = fr >> 3;
-  int umask = 0;
-  unsigned ab[NS];
-  int lmask[NS];
-  const unsigned az = (unsigned)(ZPIX * PIXB + agent * 16 + fh * BLK);
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int tile = tl[s] < 0 ? 0 : tl[s];
-    if (tl[s] >= 0) umask |= TILE_TAPS[tile];
-    const int pix = TILE_PIX[tile][psl];
-    const int y = pix / 6, x = pix - 6 * y;
-    int m = 0;
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-      const int dy = tp / 3 - 1, dx = tp % 3 - 1;
-      if (y + dy >= 0 && y + dy < 6 && x + dx >= 0 && x + dx < 6) m |= 1 << tp;
-    }
-    lmask[s] = m;
-    ab[s] = (unsigned)(pix * PIXB + agent * 16 + fh * BLK);
-  }
-  u32x4 bw[2][2];
-  // MAGAT_WHATIF_NO_W / MAGAT_WHATIF_NO_LDS (tools/whatif_block3.sh): timing experiments, results are WRONG - the walk
-  // without its weight stream / without its operand reads, to see in CYCLES which supply path the MFMAs wait for
-  auto load_b = [&](int step, u32x4 (&b)[2]) {
-#ifdef MAGAT_WHATIF_NO_W
-    if (step != 0) return;
-#endif
-    b[0] = *reinterpret_cast<const u32x4*>(wl + (size_t)step * 2048);
-    b[1] = *reinterpret_cast<const u32x4*>(wl + (size_t)step * 2048 + 1024);
-  };
-  load_b(0, bw[0]);
-  constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
-  static_assert(KSM % 2 == 0, "the ring slot of a k step must not depend on the tap");
-  // (run-time loop over the taps: unrolled, the scheduler computes all 9 x NS tap addresses up front and spills)
-#pragma unroll 1
-  for (int tp = 0; tp < 9; ++tp) {
-    const int dy = tp / 3 - 1, dx = tp % 3 - 1;
-    const int shift = (6 * dy + dx) * PIXB + TAPBIAS;
-    unsigned a0[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-      a0[s] = ((lmask[s] >> tp & 1) ? ab[s] + (unsigned)shift : az + (unsigned)TAPBIAS) + (unsigned)in_off - (unsigned)TAPBIAS;
-#pragma unroll
-    for (int ks = 0; ks < KSM; ++ks) {
-      const int step = tp * KSM + ks;
-      if (step + 1 < NSTEP) load_b(step + 1, bw[(step + 1) & 1]);
-      if (!(umask >> tp & 1)) continue;                 // wave-uniform (the fetch above keeps the ring in step)
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        if (tl[s] < 0 || !(TILE_TAPS[tl[s] < 0 ? 0 : tl[s]] >> tp & 1)) continue;
-#ifdef MAGAT_WHATIF_NO_LDS
-        const u32x4 av[2] = {bw[step & 1][1], bw[step & 1][0]};
-#else
-        const u32x4 av[2] = {*reinterpret_cast<const u32x4*>(lds + a0[s] + ks * 2 * BLK),
-                             *reinterpret_cast<const u32x4*>(lds + a0[s] + ks * 2 * BLK + PS_IN)};
-#endif
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bw[step & 1][PB[q]]),
-                                                          __builtin_bit_cast(f16x8, av[PA[q]]), acc[s], 0, 0, 0);
-      }
-    }
-  }
-#pragma unroll
-  for (int ks = 0; ks < KS2; ++ks) {
-    const int step = 9 * KSM + ks;
-    if (step + 1 < NSTEP) load_b(step + 1, bw[(step + 1) & 1]);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (tl[s] < 0) continue;
-      const unsigned a0 = ab[s] + (unsigned)in2_off;
-#ifdef MAGAT_WHATIF_NO_LDS
-      const u32x4 av[2] = {bw[step & 1][1], bw[step & 1][0]};
-#else
-      const u32x4 av[2] = {*reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK),
-                           *reinterpret_cast<const u32x4*>(lds + a0 + ks * 2 * BLK + PS_IN2)};
-#endif
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bw[step & 1][PB[q]]),
-                                                        __builtin_bit_cast(f16x8, av[PA[q]]), acc[s], 0, 0, 0);
-    }
-  }
-}
 
 // relu(acc * scale + bias) of a wave's row tiles as f16 plane chunks of an LDS map with COUT channels (channel tile ct)
 template <int COUT, int NS>
@@ -409,42 +141,7 @@ __device__ __forceinline__ void epi_to_lds(char* lds, int out_off, const int (&t
   }
 }
 
-// epi_to_lds with the tiles' pixels as run-time values (pix[s] < 0: no such tile in this wave's role)
-template <int COUT, int NS>
-__device__ __forceinline__ void epi_rt(char* lds, int out_off, const int (&pix)[NS], const f32x16 (&acc)[NS], int ct,
-                                       const float* bias, float scale, bool rows_ok, bool& clamped) {
-  constexpr int PS_OUT = (COUT / 8) * BLK;
-  int lane = threadIdx.x & 63;
-  asm volatile("" : "+v"(lane));
-  const int fr = lane & 31, fh = lane >> 5, agent = fr & 7;
-  f32x4 bq[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bias + 32 * ct + 8 * q + 4 * fh);
-  float cl = 0.f;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    if (pix[s] < 0) continue;             // (wave-uniform)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      unsigned h1[4], h2[4];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int q = 2 * ks + e;
-        const f32x2 v01 = __builtin_elementwise_fma(f32x2{acc[s][4 * q], acc[s][4 * q + 1]}, f32x2{scale, scale}, f32x2{bq[q][0], bq[q][1]});
-        const f32x2 v23 = __builtin_elementwise_fma(f32x2{acc[s][4 * q + 2], acc[s][4 * q + 3]}, f32x2{scale, scale}, f32x2{bq[q][2], bq[q][3]});
-        split2(v01[0], v01[1], h1[2 * e], h2[2 * e], cl);
-        split2(v23[0], v23[1], h1[2 * e + 1], h2[2 * e + 1], cl);
-      }
-      char* o = lds + out_off + ((ct * 2 + ks) * 2 + fh) * BLK + pix[s] * PIXB + agent * 16;
-      *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
-      *reinterpret_cast<u32x4*>(o + PS_OUT) = u32x4{h2[0], h2[1], h2[2], h2[3]};
-    }
-  }
-  clamped |= cl > 65504.f && rows_ok;
-}
 
-// row-tile groups of the 64-output-channel conv1 halves (as the chain kernel's stage B): 18 / 18 / 15 / 18 tile-taps
-__device__ constexpr int L3_G1[4][3] = {{T_I0, T_I1, -1}, {T_I2, T_I3, -1}, {T_C, T_ET, -1}, {T_EB, T_EL, T_ER}};
 
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -246,127 +246,6 @@ __device__ __forceinline__ void walk4(char* lds, int in_off, int in2_off, const 
 }
 
 
-// walk4 for a role whose tiles are all INTERIOR (every tap valid for every tile), KSM = 4 k steps per tap, as a ROLLED loop
-// over the three tap ROWS (the compact form of the one-launch kernel: 48 items of code instead of 144).  Same items in the
-// same order as walk4<W4I, 4, KS2, ...> - per accumulator: taps 0..8, k steps 0..3, then the residual segment - so the sums
-// are bit-identical.  What makes a rolled loop possible: a tap row is 12 k steps (a multiple of the weight ring D = 4: the
-// slot of a k step does not depend on the row) and 12 NT items (a multiple of the operand ring AV = 3); inside a row the
-// taps' pixel shifts are immediates (dx = -1, 0, 1, and 6 + dx for the look-ahead reads that belong to the next row), the row
-// itself is ONE add per tile base and iteration.  The weight k steps are contiguous in memory: a scalar pointer runs D - 1
-// k steps ahead of the products and stops at the stream's last k step (re-reads it: nothing beyond the stream is touched).
-// The residual segment (KS2 k steps over the block input, plane stride of its own) follows as straight-line items.
-#ifndef MAGAT_ROWS_AV
-#define MAGAT_ROWS_AV 3      /* operand ring of the rolled walk: 3 (as walk4) measured 1 % better than 4 on the kernel */
-#endif
-template <int NT, int KS2, int PS_IN, int PS_IN2, int NA = NT>
-__device__ __forceinline__ void walk_rows4(char* lds, int in_off, int in2_off, const char* wbase, f32x16 (&acc)[NA], bool with_res,
-                                           const int (&pix)[NT]) {
-  static_assert(NA >= NT, "accumulator array shorter than the tile list");
-  constexpr int KSM = 4, D = 4, AV = MAGAT_ROWS_AV, LA = AV - 1, NI = 3 * KSM * NT;      // items per tap row
-  static_assert(NI % AV == 0 && (3 * KSM) % D == 0, "ring sizes must divide a tap row");
-  u32x4 w[D][2], av[AV][2];
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const int lane = tid & 63;
-  const unsigned lane16 = (unsigned)lane * 16u;
-  const int fr = lane & 31, fh = lane >> 5, agent = fr & 7;
-  unsigned ab[NT], rb[NT];
-#pragma unroll
-  for (int s = 0; s < NT; ++s) {
-    ab[s] = (unsigned)(pix[s] * PIXB + agent * 16 + fh * BLK);
-    rb[s] = ab[s] + (unsigned)(in_off - 7 * PIXB);                    // tap (dy -1, dx -1): shift 6 * (-1) + (-1)
-  }
-  const int total = 9 * KSM + (with_res ? KS2 : 0);                  // k steps of this walk's weight stream
-  // the next k step to fetch: a 32-bit per-lane offset from the (scalar) stream base - the loads keep the scalar-base form of
-  // walk4 and the offset of the NEXT k step is ready a k step ahead (a 64-bit per-lane pointer formed in front of every load
-  // cost 0.3 k cycles per walk); it stops at the stream's last k step
-  unsigned voff = lane16;
-  int nfetched = 0;
-  auto load_next = [&](u32x4 (&b)[2]) {
-    b[0] = *reinterpret_cast<const u32x4*>(wbase + voff);
-    b[1] = *reinterpret_cast<const u32x4*>(wbase + (voff + 1024u));
-    ++nfetched;
-    voff += nfetched < total ? 2048u : 0u;
-  };
-  // item j of a row: tap dx = j / (KSM * NT), k step (j / NT) % KSM, tile j % NT; j >= NI: the same item of the next row
-  auto rd = [&](int j, int pl, u32x4& dst) {
-    const int row = j / NI, jj = j % NI;
-    const int dx = jj / (KSM * NT), ks = (jj / NT) % KSM, s = jj % NT;
-    dst = *reinterpret_cast<const u32x4*>(lds + rb[s] + ((6 * row + dx) * PIXB + pl * PS_IN + ks * 2 * BLK));
-  };
-#pragma unroll
-  for (int j = 0; j < D - 1; ++j) load_next(w[j]);
-#pragma unroll
-  for (int j = 0; j < LA; ++j) {
-    rd(j, 0, av[j][0]);
-    rd(j, 1, av[j][1]);
-  }
-#ifdef MAGAT_ROWS_UNROLL       // timing experiment: the same formulation as straight-line code
-#pragma unroll
-#else
-#pragma unroll 1
-#endif
-  for (int row = 0; row < 3; ++row) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int s = j % NT, kk = j / NT;                   // kk: k step inside the row, 0..11
-      if (s == 0) load_next(w[(kk + D - 1) % D]);
-      const int jn = j + LA;                               // the item whose operands are read now
-      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[kk % D][0]),
-                                                      __builtin_bit_cast(f16x8, av[j % AV][0]), acc[s], 0, 0, 0);
-      W4_PIN();
-      rd(jn, 0, av[jn % AV][0]);
-      W4_PIN();
-      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[kk % D][1]),
-                                                      __builtin_bit_cast(f16x8, av[j % AV][0]), acc[s], 0, 0, 0);
-      W4_PIN();
-      rd(jn, 1, av[jn % AV][1]);
-      W4_PIN();
-      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[kk % D][0]),
-                                                      __builtin_bit_cast(f16x8, av[j % AV][1]), acc[s], 0, 0, 0);
-      W4_PIN();
-    }
-    // (behind the last row the look-ahead reads above fetched three unused operands one map row further down: inside the
-    //  map's blocks for every interior pixel)
-#pragma unroll
-    for (int s = 0; s < NT; ++s) rb[s] += (unsigned)(6 * PIXB);
-  }
-  if (KS2 > 0 && with_res) {
-    // residual 1x1 segment: k steps 36 .. 36 + KS2 - 1 of the stream (the loop's last row fetched the first three), operands
-    // of the block input at the output pixel
-    constexpr int NR = KS2 * NT;
-    unsigned r2[NT];
-#pragma unroll
-    for (int s = 0; s < NT; ++s) r2[s] = ab[s] + (unsigned)in2_off;
-    auto rd2 = [&](int j, int pl, u32x4& dst) {
-      dst = *reinterpret_cast<const u32x4*>(lds + r2[j % NT] + (pl * PS_IN2 + (j / NT) * 2 * BLK));
-    };
-#pragma unroll
-    for (int j = 0; j < LA && j < NR; ++j) {
-      rd2(j, 0, av[j][0]);
-      rd2(j, 1, av[j][1]);
-    }
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const int s = j % NT, ks = j / NT;
-      if (s == 0 && ks + D - 1 < KS2) load_next(w[(ks + D - 1) % D]);
-      const int jn = j + LA;
-      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[ks % D][0]),
-                                                      __builtin_bit_cast(f16x8, av[j % AV][0]), acc[s], 0, 0, 0);
-      W4_PIN();
-      if (jn < NR) { rd2(jn, 0, av[jn % AV][0]); W4_PIN(); }
-      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[ks % D][1]),
-                                                      __builtin_bit_cast(f16x8, av[j % AV][0]), acc[s], 0, 0, 0);
-      W4_PIN();
-      if (jn < NR) { rd2(jn, 1, av[jn % AV][1]); W4_PIN(); }
-      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[ks % D][0]),
-                                                      __builtin_bit_cast(f16x8, av[j % AV][1]), acc[s], 0, 0, 0);
-      W4_PIN();
-    }
-  }
-}
-
-
 // row-tile split of a one-channel-tile stage over the four waves (chain stage A, layer1.conv1): 18 / 18 / 15 / 18 tile-taps
 struct W4P0 { static constexpr int NT = 2; static constexpr int t[2] = {T_I0, T_I1}; };
 struct W4P1 { static constexpr int NT = 2; static constexpr int t[2] = {T_I2, T_I3}; };

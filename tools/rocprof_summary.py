@@ -31,9 +31,9 @@ def short(name):
                    ("conv_gemm_kernel<128, 32", "conv_gemm_f32<128,32>"), ("conv_first_kernel", "conv_first"),
                    ("layer1_fused_kernel", "layer1_fused(stem+layer1.conv1)"),
                    ("stem8_kernel", "stem8(stem+layer1.conv1, eight-agent groups)"),
-                   ("block_chain_kernel", "block_chain(layer1.conv2+layer2)"), ("block3_kernel", "block3(layer3+pool)"),
+                   
                    ("block_chain_w4_kernel", "block_chain_w4(layer1.conv2+layer2)"), ("block3_w4_kernel", "block3_w4(layer3+pool)"),
-                   ("block_full_w4_kernel", "block_full_w4(layer1.conv2+layer2+layer3+pool)"),
+                   
                    ("block_full_p_kernel", "block_full_p(layer1.conv2+layer2+layer3+pool, pooling in registers)"),
                    ("gat_guard_count_kernel", "guard_count(gat)"), ("guard_count_kernel", "guard_count(encoder)"),
                    ("gat_mfma_kernel", "gat_mfma(one-launch KeyQuery layer)"), ("gat_dense_kernel", "gat_dense_kernel"), ("head_mean_relu", "head_mean_relu"),
