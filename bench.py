@@ -423,10 +423,11 @@ def main():
     net = build_model(cfg, dev)
     lib = nat.lib()
 
-    # CPU leg FIRST (rank 0, N=1 only): the GPU legs then run back to back at the end of the process
+    # The CPU leg (rank 0, N=1 only) runs LAST since round 5 (see the end of main): 128 worker processes at full load for ~40 s in
+    # FRONT of the GPU legs left the node hot and the host busy reaping them - same box, same command: 2.40 / 3.51 (a 23 ms host
+    # stall inside the timed region; the device took 2.35) / 2.46 ms per step with the CPU leg first, 2.34 without it
+    # (profiles/r05g/driver_style_runs.txt)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, net.state_dict(), N, map_w)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -658,9 +659,6 @@ def main():
             res["kernel_timing"] = ("hipEvent pairs around every library launch, on the launch stream, in a second pass of the "
                                     "same %d steps right behind the timed region (the pairs cost 2-3 %% of a step: the timed "
                                     "region runs without them)" % args.steps)
-        if cpu is not None:
-            res["cpu_baseline"] = cpu
-
     # ---- extra legs (N=1 only; never `value`) -----------------------------------------------------------------------------
     if world == 1 and rank == 0 and not args.no_extra_legs and args.workload == "c3" and not args.batch:
         esteps, ewarm = max(5, min(args.steps, 20)), 3
@@ -678,8 +676,6 @@ def main():
                     ns["gat_kernel"] = {k: tn[gk][k] for k in ("avg_us", "bound", "achieved", "peak", "unit", "frac",
                                                                 "bytes_per_agent_step") if k in tn[gk]}
                     ns["gat_kernel"]["kernel"] = gk
-        if cpu is not None:
-            ns["vs_cpu_baseline"] = round(ns["value"] / cpu["value"], 1)
         res["north_star_b1024"] = ns
         del xn, Sn
         # (b) the other single-GPU configs of BASELINE.json as their own (small) legs: c2 (N=20, batch 1024) and c5 (N=1000,
@@ -757,6 +753,13 @@ def main():
             res["train_step"] = train_step_leg(dev)
         except Exception as e:          # (a reported extra: never takes the bench line down)
             res["train_step"] = {"error": repr(e)[:200]}
+    # ---- the CPU baseline: the pinned oracle on this box's host cores, behind every GPU leg (nothing of it is inside a timed region)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        torch.cuda.synchronize(dev)
+        cpu = cpu_baseline(cfg, {k: v.detach().cpu() for k, v in net.state_dict().items()}, N, map_w)
+        res["cpu_baseline"] = cpu
+        if "north_star_b1024" in res:
+            res["north_star_b1024"]["vs_cpu_baseline"] = round(res["north_star_b1024"]["value"] / cpu["value"], 1)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -24,6 +24,19 @@ def preheat(ms_total):
     return v.value, mhz.value
 
 
+def stream_hbm(ms_total):
+    """~ms_total of plain HBM streaming (device-to-device copies of 1 GB): wakes the memory clocks the MFMA probe does not touch"""
+    a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); b.copy_(a); e1.record(); torch.cuda.synchronize()
+    per = max(e0.elapsed_time(e1), 0.05)
+    for _ in range(max(1, int(ms_total / per))):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    return 2 * a.numel() * 4 / per / 1e6      # GB/s of the first copy
+
+
 def run(nsteps):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)]
     with torch.no_grad():
@@ -39,9 +52,12 @@ with torch.no_grad():
     for _ in range(3):
         net.addGSO(S); net(x)
 torch.cuda.synchronize()
-for label, heat in (("cold (5 s idle)", 0), ("behind 150 ms of MFMA work", 150), ("cold again", 0), ("behind 400 ms of MFMA work", 400)):
-    time.sleep(5.0)
+IDLE = float(os.environ.get("RAMP_IDLE_S", "5"))
+for label, heat in (("cold (%g s idle)" % IDLE, 0), ("behind 150 ms of MFMA work", 150), ("cold again", 0), ("behind 400 ms of MFMA work", 400)):
+    time.sleep(IDLE)
     info = preheat(heat) if heat else None
+    if heat and os.environ.get("RAMP_HBM", "0") == "1":
+        stream_hbm(heat)
     t = run(80)
     grp = [sum(t[i:i + 10]) / 10 for i in range(0, 80, 10)]
     print("%-28s steps 1-5: %s | mean of steps 1-10, 11-20, ..: %s%s" % (
