@@ -435,6 +435,49 @@ template <> struct TileVec<u16> {
   }
 };
 
+// The walk order of an instance's rows: RANKED BY EDGE COUNT (descending), so that the 8 rows of a wave step have (almost) the same
+// number of edges - a step runs as many edge slots as its longest row has, and in index order that was ~9.5 slots for the 5.4
+// edges per row of config 5.  Counting sort in LDS behind the tile (one thread per row; the order inside a bin is whatever the
+// LDS atomics make it - no result depends on it: a row's arithmetic does not know its position), and the (row, first edge,
+// edge count) of EVERY position this wave walks - at most 8 steps of 8 rows (N <= 1024, 16 waves) - lands in one register
+// triple per lane for the whole kernel: lane 8 s + g holds step s, group g.  (Read inside the step's prefetch, the row pointers
+// were a second dependent round trip in front of the column and score loads of every step - round 5.)
+constexpr int TILED_SCRATCH = 13 * 1024;      // histogram [64] | rows [1024] | first edges [1024] | edge counts [1024]
+__device__ __forceinline__ void tiled_row_order(char* scratch, const int* __restrict__ ptr, int N, int t, int q, int& rowh,
+                                                int& e0h, int& degh) {
+  int* hist = reinterpret_cast<int*>(scratch);
+  int* ord = reinterpret_cast<int*>(scratch + 1024);
+  const int lane = t & 63;
+  if (t < 64) hist[t] = 0;
+  __syncthreads();
+  int e0 = 0, d = 0, key = 0, slot = 0;
+  if (t < N) {
+    e0 = ptr[t];
+    d = ptr[t + 1] - e0;
+    key = 63 - (d < 63 ? d : 63);
+    slot = atomicAdd(&hist[key], 1);
+  }
+  __syncthreads();
+  const int c = hist[lane];          // (every wave scans the 64 bins for itself)
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  const int base = __shfl(incl - c, key, 64);
+  if (t < N) {
+    ord[base + slot] = t;
+    ord[1024 + base + slot] = e0;
+    ord[2048 + base + slot] = d;
+  }
+  __syncthreads();
+  const bool ok = q < N;
+  rowh = ok ? ord[q] : 0;
+  e0h = ok ? ord[1024 + q] : 0;
+  degh = ok ? ord[2048 + q] : 0;
+}
+
 template <typename ST, int LPR>
 __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams p, int G) {
   extern __shared__ __attribute__((aligned(1024))) char tile[];
@@ -452,6 +495,9 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
   const ST* Zb = static_cast<const ST*>(p.Z) + (long long)b * N * p.NC + p.qoff + head * G;
   const ST* Xb = static_cast<const ST*>(p.X) + (long long)b * N * G;
   float* att = p.att + (long long)head * p.nnz;
+  static_assert(LPR == 8, "lane 8 s + g <-> (row step s, row group g)");
+  int rowh, e0h, degh;
+  tiled_row_order(tile + (size_t)((N + RPS - 1) / RPS) * 1024, rp, N, t, RPS * wave + (lane >> 3) * rstep + (lane & 7), rowh, e0h, degh);
   // everything a row step needs from global memory, requested one step ahead (the loop body then only touches LDS)
   struct Row {
     int e0, deg;
@@ -462,18 +508,24 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
   };
   for (int h = 0; h < NP; ++h) {
     const bool first = h == 0, last = h == NP - 1;
-    auto fetch = [&](int ib, Row& w) {
-      const int i = ib + eg;
-      w.ok = i < N;
-      const int ir = w.ok ? i : 0;
-      w.e0 = rp[ir];
-      w.deg = w.ok ? rp[ir + 1] - w.e0 : 0;
+    auto fetch = [&](int ib, int sidx, Row& w) {
+      w.ok = ib + eg < N;
+      const int ir = __shfl(rowh, 8 * sidx + eg, 64);
+      w.e0 = __shfl(e0h, 8 * sidx + eg, 64);
+      w.deg = __shfl(degh, 8 * sidx + eg, 64);
       {
         const tv_u32x4 v = *reinterpret_cast<const tv_u32x4*>(Xb + (long long)ir * G + h * FPP + es * E);
         w.xv[0] = v[0]; w.xv[1] = v[1]; w.xv[2] = v[2]; w.xv[3] = v[3];
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
+        w.cj[r] = 0;
+        w.pre[r] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        // (rows ranked by edge count: past the first batch of 8 edges most wave steps have nothing to ask for)
+        if (r > 0 && __builtin_amdgcn_ballot_w64(LPR * r < w.deg) == 0ull) break;
         const bool mine_ok = es + LPR * r < w.deg;
         w.cj[r] = mine_ok ? p.colidx[w.e0 + es + LPR * r] : 0;
         // (agent-scope load: served by L2.  The value was stored by THIS thread in the previous pass, but a plain load may
@@ -483,7 +535,7 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
       }
     };
     Row cur, nxt;
-    if (RPS * wave < N) fetch(RPS * wave, cur);           // in flight together with the slice
+    if (RPS * wave < N) fetch(RPS * wave, 0, cur);        // in flight together with the slice
     if (h > 0) __syncthreads();                       // every wave is done with the previous slice
 #ifndef CSR_WHATIF_NODMA      // (timing experiments, tools/csr_layer_bench.py: wrong results)
     tile_dma<ST, LPR>(tile, Zb + h * FPP, p.NC, N, t);
@@ -493,8 +545,8 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
 #ifdef CSR_WHATIF_NOLOOP
     if (p.N > 0) continue;
 #endif
-    for (int ib = RPS * wave; ib < N; ib += rstep) {
-      if (ib + rstep < N) fetch(ib + rstep, nxt);
+    for (int ib = RPS * wave, sidx = 0; ib < N; ib += rstep, ++sidx) {
+      if (ib + rstep < N) fetch(ib + rstep, sidx + 1, nxt);
       const int e0 = cur.e0, deg = cur.deg;
       float mine[R];
 #pragma unroll
@@ -515,6 +567,9 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
         if (__builtin_amdgcn_ballot_w64(LPR * r < deg) == 0ull) break;
 #pragma unroll
         for (int k = 0; k < LPR; k += 2) {
+          // (no row of this wave step has an edge left: at 5.4 edges per row - config 5 - the longest of 8 rows has ~9, and a
+          //  full batch of 8 slots for it ran 6-7 empty ones)
+          if (k > 0 && __builtin_amdgcn_ballot_w64(LPR * r + k < deg) == 0ull) break;
           const int ka = LPR * r + k, kb = ka + 1;
           const bool va = ka < deg, vb = kb < deg;
           // neighbour index of edge k from its owner lane (past the row's degree: row 0 of the slice, never used)
@@ -589,30 +644,65 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
   const ST* Tb = static_cast<const ST*>(p.Told) + p.told_off + (long long)b * N * p.told_ld +
                  (long long)head * p.told_head_stride;
   const ST* Ub = static_cast<const ST*>(p.Z) + (long long)b * N * p.NC + p.uoff + (head * p.K + p.k) * F;
-  struct Row {
-    int s0, deg;
+  // rows ranked by IN-edge count, their column pointers in registers for the whole kernel (see the score kernel)
+  static_assert(LPR == 8, "lane 8 s + g <-> (row step s, row group g)");
+  int rowh, s0h, degh;
+  tiled_row_order(tile + (size_t)((N + RPS - 1) / RPS) * 1024, cp, N, t, RPS * wave + (lane >> 3) * rstep + (lane & 7), rowh, s0h, degh);
+  // A step's global reads in TWO stages, each requested a whole step before it is needed: the in-edge lists (source row, CSR
+  // position) two steps ahead, the weights att[position] - which depend on them - and the U row one step ahead.
+  struct Idx {
+    int s0, deg, row;
     bool ok;
+    int src[R], pos[R];
+  };
+  struct Val {
     float acc[E];
-    int src[R];
     float wgt[R];
   };
   for (int h = 0; h < NP; ++h) {
-    auto fetch = [&](int jb, Row& w) {
-      const int j = jb + eg;
-      w.ok = j < N;
-      const int jr = w.ok ? j : 0;
-      w.s0 = cp[jr];
-      w.deg = w.ok ? cp[jr + 1] - w.s0 : 0;
-      TileVec<ST>::load(Ub + (long long)jr * p.NC + h * FPP + es * E, w.acc);
+    auto fetch_idx = [&](int jb, int sidx, Idx& w) {
+      w.ok = jb + eg < N;
+      w.row = __shfl(rowh, 8 * sidx + eg, 64);
+      w.s0 = __shfl(s0h, 8 * sidx + eg, 64);
+      w.deg = __shfl(degh, 8 * sidx + eg, 64);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
+        w.src[r] = 0;
+        w.pos[r] = -1;
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (r > 0 && __builtin_amdgcn_ballot_w64(LPR * r < w.deg) == 0ull) break;
         const bool mine_ok = es + LPR * r < w.deg;
+#ifdef CSR_WHATIF_NOIDX
+        w.src[r] = es + LPR * r; w.pos[r] = mine_ok ? w.s0 + es + LPR * r : -1;
+#else
         w.src[r] = mine_ok ? p.cscsrc[w.s0 + es + LPR * r] : 0;
-        w.wgt[r] = mine_ok ? att[p.cscpos[w.s0 + es + LPR * r]] : 0.f;
+        w.pos[r] = mine_ok ? p.cscpos[w.s0 + es + LPR * r] : -1;
+#endif
       }
     };
-    Row cur, nxt;
-    if (RPS * wave < N) fetch(RPS * wave, cur);
+    auto fetch_val = [&](int jb, const Idx& ix, Val& w) {
+      TileVec<ST>::load(Ub + (long long)ix.row * p.NC + h * FPP + es * E, w.acc);
+#pragma unroll
+      for (int r = 0; r < R; ++r) w.wgt[r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (r > 0 && __builtin_amdgcn_ballot_w64(LPR * r < ix.deg) == 0ull) break;
+        w.wgt[r] = ix.pos[r] >= 0 ? att[ix.pos[r]] : 0.f;
+      }
+    };
+    Idx cur, nxt, nx2;
+    Val cv, nv;
+    float bv[E];                 // this lane's bias columns of the pass
+#pragma unroll
+    for (int c = 0; c < E; ++c) bv[c] = (p.last && p.bias) ? p.bias[h * FPP + es * E + c] : 0.f;
+    const int jb0 = RPS * wave;
+    if (jb0 < N) {
+      fetch_idx(jb0, 0, cur);
+      if (jb0 + rstep < N) fetch_idx(jb0 + rstep, 1, nxt);
+      fetch_val(jb0, cur, cv);
+    }
     if (h > 0) __syncthreads();
 #ifndef CSR_WHATIF_NODMA
     tile_dma<ST, LPR>(tile, Tb + h * FPP, p.told_ld, N, t);
@@ -622,20 +712,25 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
 #ifdef CSR_WHATIF_NOLOOP
     if (p.N > 0) continue;
 #endif
-    for (int jb = RPS * wave; jb < N; jb += rstep) {
-      if (jb + rstep < N) fetch(jb + rstep, nxt);
-      const int j = jb + eg, deg = cur.deg;
+    for (int jb = jb0, sidx = 0; jb < N; jb += rstep, ++sidx) {
+      if (jb + 2 * rstep < N) fetch_idx(jb + 2 * rstep, sidx + 2, nx2);
+      if (jb + rstep < N) fetch_val(jb + rstep, nxt, nv);
+      const int j = cur.row, deg = cur.deg;
       float acc[E];
 #pragma unroll
-      for (int c = 0; c < E; ++c) acc[c] = cur.acc[c];
+      for (int c = 0; c < E; ++c) acc[c] = cv.acc[c];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
+#ifdef CSR_WHATIF_NOKLOOP
+        break;
+#endif
         if (__builtin_amdgcn_ballot_w64(LPR * r < deg) == 0ull) break;
 #pragma unroll
         for (int k = 0; k < LPR; ++k) {
+          if (k > 0 && __builtin_amdgcn_ballot_w64(LPR * r + k < deg) == 0ull) break;      // (as in the score loop)
           // (i, a) of edge LPR r + k from its owner lane; edges past the row's degree carry weight 0 and row 0
           const int i = __shfl(cur.src[r], gbase + k, 64);
-          const float a = __shfl(cur.wgt[r], gbase + k, 64);
+          const float a = __shfl(cv.wgt[r], gbase + k, 64);
           float tv[E];
           TileVec<ST>::load(tile + i * TILE_ROW_BYTES + es * 16, tv);
 #pragma unroll
@@ -650,12 +745,15 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
 #pragma unroll
         for (int c = 0; c < E; ++c) acc[c] = fmaf(a, tv[c], acc[c]);
       }
+#ifdef CSR_WHATIF_NOSTORE
+      if (acc[0] == 1.2345f && acc[3] == 7.f)
+#endif
       if (cur.ok) {
         const int col = h * FPP + es * E;
         if (p.last) {
           if (p.bias) {
 #pragma unroll
-            for (int c = 0; c < E; ++c) acc[c] += p.bias[col + c];
+            for (int c = 0; c < E; ++c) acc[c] += bv[c];
           }
           if (p.act_relu) {
 #pragma unroll
@@ -666,7 +764,7 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
           store_vec<E, ST>(static_cast<ST*>(p.Tnew) + (((long long)b * N + j) * p.P + head) * F + col, acc);
         }
       }
-      cur = nxt;
+      cur = nxt; nxt = nx2; cv = nv;
     }
   }
 }
@@ -680,7 +778,7 @@ int launch_tiled(const CsrParams& p, int width, bool scores, hipStream_t st) {
   constexpr int RPS = 64 / LPR;
   const long long grid = (long long)((p.B + MAGAT_NUM_XCD - 1) / MAGAT_NUM_XCD) * MAGAT_NUM_XCD * p.P;
   if (grid > 0x7fffffffLL) return MAGAT_ERR_BAD_SHAPE;
-  const size_t lds = (size_t)((p.N + RPS - 1) / RPS) * 1024;
+  const size_t lds = (size_t)((p.N + RPS - 1) / RPS) * 1024 + TILED_SCRATCH;
   const void* fn = scores ? reinterpret_cast<const void*>(&csr_tiled_scores_kernel<ST, LPR>)
                           : reinterpret_cast<const void*>(&csr_tiled_hop_kernel<ST, LPR>);
   const int slot = (scores ? MAGAT_LDS_CSR_TILED_A : MAGAT_LDS_CSR_TILED_B) + (sizeof(ST) == 2 ? 2 : 0) + (LPR == 4 ? 4 : 0);

@@ -14,7 +14,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // with -DMAGAT_EXPERIMENT_BUILD, which marks the library (magat_build_flavor() = 1; the Python binding refuses to load it
 // unless MAGAT_ALLOW_EXPERIMENT_BUILD=1).  A release build - build_native.build() without --debug - never passes extra
 // flags, so a stray environment variable cannot produce a silently wrong libmagat_hip.so.
-#if (defined(MAGAT_WHATIF_NO_W) || defined(MAGAT_WHATIF_NO_LDS) || defined(CSR_WHATIF_NODMA) || defined(CSR_WHATIF_NOLOOP) || \
+#if (defined(MAGAT_WHATIF_NO_W) || defined(MAGAT_WHATIF_NO_LDS) || defined(CSR_WHATIF_NODMA) || defined(CSR_WHATIF_NOLOOP) || defined(CSR_WHATIF_NOIDX) || defined(CSR_WHATIF_NOKLOOP) || defined(CSR_WHATIF_NOSTORE) || \
      defined(GM_WHATIF_NOQW) || defined(GM_WHATIF_NOAW) || defined(GM_WHATIF_NOYST)) && !defined(MAGAT_EXPERIMENT_BUILD)
 #error "*_WHATIF_* timing switches produce wrong results: they compile only with -DMAGAT_EXPERIMENT_BUILD (see magat_common.h)"
 #endif
