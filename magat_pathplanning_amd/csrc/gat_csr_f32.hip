@@ -1289,17 +1289,45 @@ __global__ __launch_bounds__(256) void gso_totals_kernel(const int* __restrict__
   if (t == 0) inst_tot[b] = part[0] + part[1] + part[2] + part[3];
 }
 
+// One workgroup per instance.  Round 5: every phase walks the EDGES - a thread per row over the set bits of ITS row, which it
+// holds in registers (16 words; the round-2 kernel kept the whole bit matrix in LDS and counted / filled the columns with a
+// thread per column walking all N rows twice: 150-183 us per launch at config 5 with half of the chip's CUs, one per instance,
+// tied up beside the encoder for that long).  Column degrees are LDS atomics, an in-edge takes its slot in its column's list
+// from an LDS cursor, each column's short list is then sorted by source row (registers), which makes the result the same
+// deterministic arrays as before (ascending i per column; ascending j per row comes with the bit order).  The three edge
+// arrays are STAGED in LDS (the bit matrix no longer lives there) and leave as whole contiguous runs: written edge by edge,
+// the scattered 4-byte stores alone took 70 us.  An instance with more edges than the stage holds writes and sorts through
+// global memory instead (reads at agent scope: the entries come from other threads of the workgroup).
+// a column's list in global memory (keys = source rows, values = CSR positions; the fallback of an instance whose edges do
+// not fit the LDS stage): selection sort in place.  The entries were written by other threads of the workgroup - every
+// access at agent scope (a plain load may be served by a stale line of this CU's L1)
+__device__ __forceinline__ void gso_sort_global(int* ks, int* vs, int n) {
+  auto ld = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto st = [](int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  for (int a = 0; a + 1 < n; ++a) {
+    const int ak = ld(ks + a);
+    int best = a, bk = ak;
+    for (int c = a + 1; c < n; ++c) {
+      const int ck = ld(ks + c);
+      if (ck < bk) { bk = ck; best = c; }
+    }
+    if (best != a) {
+      const int av = ld(vs + a), bv = ld(vs + best);
+      st(ks + a, bk); st(vs + a, bv); st(ks + best, ak); st(vs + best, av);
+    }
+  }
+}
+constexpr int GSO_STAGE_EDGES = 12 * 1024;      // edges of one instance the LDS stage holds (3 x 4 bytes each: 144 KB; < 2^14)
 __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long long* __restrict__ masks,
                                                              int* __restrict__ inst_tot, int* __restrict__ rowptr,
-                                                             int* __restrict__ colidx, int* __restrict__ cscptr,
-                                                             int* __restrict__ cscsrc, int* __restrict__ cscpos,
+                                                             int* colidx, int* __restrict__ cscptr, int* cscsrc, int* cscpos,
                                                              long long cap, long long* __restrict__ nnz_out, int B, int N,
                                                              int W64) {
-  extern __shared__ __align__(16) unsigned long long gsm[];
-  unsigned long long* M = gsm;                                   // [N][W64]
-  int* roff = reinterpret_cast<int*>(M + (size_t)N * W64);       // [N+1] exclusive row offsets (local)
-  const int W2 = (W64 + 1) / 2;
-  unsigned short* pre2 = reinterpret_cast<unsigned short*>(roff + (N + 2));   // [N][W2]: edges of row i in words < 2 q
+  extern __shared__ __align__(16) int gsi[];
+  int* ccnt = gsi;                    // [N] column degrees, then the fill cursors
+  int* coff = ccnt + 1024;            // [N] exclusive column offsets (local)
+  int* stage = coff + 1024;           // [3][GSO_STAGE_EDGES]: column of CSR position q | in-edge of slot k as (source row << 14 |
+                                      // local CSR position), in arrival order | the same, every column's list sorted
   __shared__ int part[17];
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // absolute offset of this instance = edges of all earlier instances (inst_tot was accumulated by the mask pass)
@@ -1308,8 +1336,14 @@ __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
   if (lane == 0) part[wave] = before;
-  const unsigned long long* src = masks + (size_t)b * N * W64;
-  for (int q = t; q < N * W64; q += 1024) M[q] = src[q];
+  // this thread's row of the bit matrix
+  unsigned long long mrow[GSO_W64_MAX];
+  {
+    const unsigned long long* src = masks + ((size_t)b * N + (t < N ? t : 0)) * W64;
+#pragma unroll
+    for (int w = 0; w < GSO_W64_MAX; ++w) mrow[w] = (t < N && w < W64) ? src[w] : 0ull;
+  }
+  ccnt[t] = 0;
   __syncthreads();
   int base = 0;
   for (int w = 0; w < 16; ++w) base += part[w];
@@ -1332,70 +1366,102 @@ __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long
     *out_total = tot;
     return wbase + inc - v;
   };
-  // rows: degrees -> offsets
+  // rows: degrees -> offsets; columns: one LDS atomic per edge
   int rdeg = 0;
-  if (t < N)
-    for (int w = 0; w < W64; ++w) rdeg += __popcll(M[t * W64 + w]);
-  int total = 0;
-  const int rex = block_scan(rdeg, &total);
-  if (t < N) roff[t] = rex;
-  if (t == 0) roff[N] = total;
-  // columns: degrees (thread per column walks the rows; a wave reads one broadcast word per row) -> offsets
-  int cdeg = 0;
-  if (t < N) {
-    const int w = t >> 6;
-    const unsigned long long bit = 1ull << (t & 63);
-    for (int i = 0; i < N; ++i) cdeg += (M[i * W64 + w] & bit) ? 1 : 0;
-  }
-  int total2 = 0;
-  const int cex = block_scan(cdeg, &total2);
-  // per row: edge count in front of every EVEN word (the odd ones add one popcount): position of an edge inside its row
-  if (t < N) {
-    int run = 0;
-    for (int q = 0; q < W2; ++q) {
-      pre2[t * W2 + q] = (unsigned short)run;
-      run += __popcll(M[t * W64 + 2 * q]);
-      if (2 * q + 1 < W64) run += __popcll(M[t * W64 + 2 * q + 1]);
-    }
-  }
-  __syncthreads();
-  int* rp = rowptr + (size_t)b * (N + 1);
-  int* cp = cscptr + (size_t)b * (N + 1);
-  for (int q = t; q <= N; q += 1024) rp[q] = base + roff[q];
-  if (t < N) cp[t] = base + cex;
-  if (t == 0) cp[N] = base + total;
-  auto row_prefix = [&](int i, int w) -> int {      // edges of row i in words < w
-    int p = pre2[i * W2 + (w >> 1)];
-    if (w & 1) p += __popcll(M[i * W64 + w - 1]);
-    return p;
-  };
-  if (b == B - 1 && t == 0 && nnz_out) *nnz_out = (long long)base + total;
-  // colidx: thread per (row, 64-bit word)
-  for (int q = t; q < N * W64; q += 1024) {
-    const int i = q / W64, w = q - i * W64;
-    unsigned long long m = M[q];
-    if (!m) continue;
-    int pos = base + roff[i] + row_prefix(i, w);
+#pragma unroll
+  for (int w = 0; w < GSO_W64_MAX; ++w) {
+    unsigned long long m = mrow[w];
+    rdeg += __popcll(m);
     while (m) {
       const int bit = __builtin_ctzll(m);
       m &= m - 1;
-      if (pos < cap) colidx[pos] = w * 64 + bit;
-      ++pos;
+      atomicAdd(&ccnt[w * 64 + bit], 1);
     }
   }
-  // CSC: thread per column, rows ascending
+  int total = 0;
+  const int rex = block_scan(rdeg, &total);      // (its barriers also order the atomics above in front of the reads below)
+  const int cdeg = t < N ? ccnt[t] : 0;
+  int total2 = 0;
+  const int cex = block_scan(cdeg, &total2);
+  coff[t] = cex;
+  ccnt[t] = 0;
+  __syncthreads();
+  int* rp = rowptr + (size_t)b * (N + 1);
+  int* cp = cscptr + (size_t)b * (N + 1);
   if (t < N) {
-    const int w = t >> 6;
-    const unsigned long long bit = 1ull << (t & 63), below = bit - 1ull;
-    int k = base + cex;
-    for (int i = 0; i < N; ++i) {
-      const unsigned long long mw = M[i * W64 + w];
-      if (mw & bit) {
-        const int pos = base + roff[i] + row_prefix(i, w) + __popcll(mw & below);
-        if (k < cap) { cscsrc[k] = i; cscpos[k] = pos; }
-        ++k;
+    rp[t] = base + rex;
+    cp[t] = base + cex;
+  }
+  if (t == 0) {
+    rp[N] = base + total;
+    cp[N] = base + total;
+  }
+  if (b == B - 1 && t == 0 && nnz_out) *nnz_out = (long long)base + total;
+  const bool staged = total <= GSO_STAGE_EDGES;
+  if (staged) {
+    int* const scol = stage;
+    int* const sin = stage + GSO_STAGE_EDGES;
+    int* const sout = stage + 2 * GSO_STAGE_EDGES;
+    // a thread per row over its edges in ascending j: the column index of every CSR position, and the in-edge into the next
+    // free slot of column j's list
+    {
+      int pos = rex;
+#pragma unroll
+      for (int w = 0; w < GSO_W64_MAX; ++w) {
+        unsigned long long m = mrow[w];
+        while (m) {
+          const int bit = __builtin_ctzll(m);
+          m &= m - 1;
+          const int j = w * 64 + bit;
+          scol[pos] = j;
+          sin[coff[j] + atomicAdd(&ccnt[j], 1)] = (t << 14) | pos;
+          ++pos;
+        }
       }
     }
+    __syncthreads();
+    // a thread per column: its list ordered by source row - every entry goes to the slot its rank names (the lists are short:
+    // 3-5 entries at config 5)
+    if (t < N)
+      for (int e = 0; e < cdeg; ++e) {
+        const int w = sin[cex + e];
+        int rank = 0;
+        for (int f = 0; f < cdeg; ++f) rank += sin[cex + f] < w ? 1 : 0;
+        sout[cex + rank] = w;
+      }
+    __syncthreads();
+    // the stage leaves as three contiguous runs
+    const long long lim = cap - base < total ? cap - base : total;
+    for (int q = t; q < lim; q += 1024) {
+      const int w = sout[q];
+      colidx[base + q] = scol[q];
+      cscsrc[base + q] = w >> 14;
+      cscpos[base + q] = base + (w & 16383);
+    }
+  } else {
+    // more edges than the stage holds: written edge by edge to global memory, the lists sorted there
+    {
+      int pos = base + rex;
+#pragma unroll
+      for (int w = 0; w < GSO_W64_MAX; ++w) {
+        unsigned long long m = mrow[w];
+        while (m) {
+          const int bit = __builtin_ctzll(m);
+          m &= m - 1;
+          const int j = w * 64 + bit;
+          if (pos < cap) colidx[pos] = j;
+          const int k = base + coff[j] + atomicAdd(&ccnt[j], 1);
+          if (k < cap) {
+            cscsrc[k] = t;
+            cscpos[k] = pos;
+          }
+          ++pos;
+        }
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    if (t < N && cdeg > 1 && (long long)base + cex + cdeg <= cap) gso_sort_global(cscsrc + base + cex, cscpos + base + cex, cdeg);
   }
   // leave inst_tot clear for the next build (every workgroup has read what it needs only after ALL of them pass this
   // point is not guaranteed - so the clearing is done by the NEXT build's memset, see the host code)
@@ -1422,8 +1488,7 @@ extern "C" int magat_gso_csr_build_phase(void* S, int s_is_f64, int scrub_nan, i
   if (!need) return MAGAT_ERR_UNSUPPORTED;                      // N > 1024: magat_gso_row_degrees / magat_gso_fill_csr
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < need) return MAGAT_ERR_WORKSPACE;
   const int W64 = (N + 63) / 64;
-  const size_t lds = (size_t)N * W64 * 8 + (size_t)(N + 2) * sizeof(int) + (size_t)N * ((W64 + 1) / 2) * sizeof(unsigned short);
-  if (lds > 160 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)(2 * 1024 + 3 * GSO_STAGE_EDGES) * sizeof(int);      // column counters / offsets + the edge stage
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned long long* masks = static_cast<unsigned long long*>(workspace);
   int* inst_tot = reinterpret_cast<int*>(static_cast<char*>(workspace) + magat_align_up((size_t)B * N * W64 * 8, 256));

@@ -77,6 +77,26 @@ def test_gso_csr_build_matches_the_definition(gpu_device, N, dtype, rule):
     assert torch.equal(Sd2.cpu(), w2)
 
 
+@pytest.mark.parametrize("N,density", [(1000, 0.05), (512, 0.06), (1000, 0.011)])
+def test_gso_csr_build_dense_instances(gpu_device, N, density):
+    """Instances with more edges than the structure kernel's LDS stage holds (12 288) are written and sorted through global
+    memory; instances around the limit take either way - the arrays are the host construction's in both."""
+    from magat_pathplanning_amd.graphml import CsrStructure
+    g = torch.Generator().manual_seed(N + int(1000 * density))
+    B = 3
+    S = (torch.rand(B, N, N, generator=g) < density).float() * (torch.rand(B, N, N, generator=g) + 0.5)
+    S[1] = S[1] * (torch.rand(N, N, generator=g) < 0.1).float()          # one sparse instance between two dense ones
+    Sd = S.clone().to(gpu_device)
+    st = CsrStructure().build(Sd, 0, scrub_nan=1, gso_mode=0)
+    rowptr, colidx, cscptr, cscsrc, cscpos, nnz = _legacy_structure(S, 0, gpu_device)
+    assert st.exact_nnz() == nnz
+    assert torch.equal(st.rowptr.cpu().long(), rowptr)
+    assert torch.equal(st.cscptr.cpu().long(), cscptr)
+    assert torch.equal(st.colidx[:nnz].cpu().long(), colidx)
+    assert torch.equal(st.csc[0][:nnz].cpu().long(), cscsrc)
+    assert torch.equal(st.csc[1][:nnz].cpu().long(), cscpos)
+
+
 def test_gso_csr_build_at_config5_size(gpu_device):
     """BASELINE config 5's full shape (128 instances x 1000 agents, 512 MB of GSO) through size-independent properties: the
     device edge total equals torch's count over the scrubbed tensor, every row's degree equals its row count, column indices
