@@ -497,6 +497,7 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
   float* att = p.att + (long long)head * p.nnz;
   static_assert(LPR == 8, "lane 8 s + g <-> (row step s, row group g)");
   int rowh, e0h, degh;
+  tile_dma<ST, LPR>(tile, Zb, p.NC, N, t);      // the first pass's slice streams in while the rows are ranked (scratch: behind the tile)
   tiled_row_order(tile + (size_t)((N + RPS - 1) / RPS) * 1024, rp, N, t, RPS * wave + (lane >> 3) * rstep + (lane & 7), rowh, e0h, degh);
   // everything a row step needs from global memory, requested one step ahead (the loop body then only touches LDS)
   struct Row {
@@ -536,10 +537,12 @@ __global__ __launch_bounds__(1024) void csr_tiled_scores_kernel(const CsrParams 
     };
     Row cur, nxt;
     if (RPS * wave < N) fetch(RPS * wave, 0, cur);        // in flight together with the slice
-    if (h > 0) __syncthreads();                       // every wave is done with the previous slice
+    if (h > 0) {
+      __syncthreads();                                // every wave is done with the previous slice
 #ifndef CSR_WHATIF_NODMA      // (timing experiments, tools/csr_layer_bench.py: wrong results)
-    tile_dma<ST, LPR>(tile, Zb + h * FPP, p.NC, N, t);
+      tile_dma<ST, LPR>(tile, Zb + h * FPP, p.NC, N, t);
 #endif
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef CSR_WHATIF_NOLOOP
@@ -647,6 +650,7 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
   // rows ranked by IN-edge count, their column pointers in registers for the whole kernel (see the score kernel)
   static_assert(LPR == 8, "lane 8 s + g <-> (row step s, row group g)");
   int rowh, s0h, degh;
+  tile_dma<ST, LPR>(tile, Tb, p.told_ld, N, t);      // (the first slice under the ranking, as in the score kernel)
   tiled_row_order(tile + (size_t)((N + RPS - 1) / RPS) * 1024, cp, N, t, RPS * wave + (lane >> 3) * rstep + (lane & 7), rowh, s0h, degh);
   // A step's global reads in TWO stages, each requested a whole step before it is needed: the in-edge lists (source row, CSR
   // position) two steps ahead, the weights att[position] - which depend on them - and the U row one step ahead.
@@ -703,10 +707,12 @@ __global__ __launch_bounds__(1024) void csr_tiled_hop_kernel(const CsrParams p, 
       if (jb0 + rstep < N) fetch_idx(jb0 + rstep, 1, nxt);
       fetch_val(jb0, cur, cv);
     }
-    if (h > 0) __syncthreads();
+    if (h > 0) {
+      __syncthreads();
 #ifndef CSR_WHATIF_NODMA
-    tile_dma<ST, LPR>(tile, Tb + h * FPP, p.told_ld, N, t);
+      tile_dma<ST, LPR>(tile, Tb + h * FPP, p.told_ld, N, t);
 #endif
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef CSR_WHATIF_NOLOOP
