@@ -1164,7 +1164,8 @@ namespace {
 // The dense (B,N,N) GSO of a large instance is big (4 MB per instance at N = 1000): addGSO's in-place scrub, the edge test
 // and the row degrees are one streaming read of it (written back only where a value changes), leaving a bit matrix
 // (N^2/8 bytes per instance).  A second kernel - one workgroup per instance, a thread per row of the bit matrix - then produces
-// everything the CSR kernels need, deterministically and without atomics: rowptr / colidx (ascending j per row), cscptr,
+// everything the CSR kernels need, deterministically (no global atomics; LDS atomics only hand out slots whose order a rank
+// placement undoes): rowptr / colidx (ascending j per row), cscptr,
 // and per in-edge its source row and CSR position (ascending i per column).
 constexpr int GSO_W64_MAX = 16;          // N <= 1024
 
