@@ -102,3 +102,42 @@ def test_fuzz_layer_slice(gpu_device, seed, count):
             bad.append((tag, err))
     assert not bad, bad
     assert declined <= count // 2
+
+
+@pytest.mark.parametrize("N,B,G,K,P,bf16,kind", [(1000, 2, 128, 2, 4, True, "hubs"), (513, 2, 64, 3, 1, False, "dense"),
+                                                  (9, 5, 64, 2, 2, True, "empty"), (1024, 1, 128, 3, 2, False, "sparse"),
+                                                  (255, 5, 128, 2, 4, True, "hubs"), (64, 9, 128, 3, 1, False, "dense")])
+def test_tiled_csr_kernels_against_the_per_edge_kernels(gpu_device, libopt, N, B, G, K, P, bf16, kind):
+    """A slice of tools/exp/fuzz_csr_tiled.py: the LDS-tiled score / hop kernels (rows walked in edge-count order, row pointers
+    in registers; round 5) against the per-edge CSR kernels of the same library on graphs with hub rows and columns (more edges
+    than the batched path holds), empty rows, dense and sparse neighbourhoods, sizes at the ends of the tiled range."""
+    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from magat_pathplanning_amd.graphml import CsrStructure, gat_forward_rows_csr
+    g = torch.Generator().manual_seed(N + K)
+    dens = {"sparse": 5.0 / N, "dense": min(0.5, 40.0 / N), "hubs": 3.0 / N, "empty": 1.0 / N}[kind]
+    S = (torch.rand(B, N, N, generator=g) < dens).float()
+    if kind == "hubs":
+        S[:, N // 3, :] = 1.0
+        S[:, :, N // 2] = 1.0
+    if kind == "empty":
+        S[:, : N // 2, :] = 0.0
+    S = S.to(gpu_device)
+    torch.manual_seed(N)
+    layer = GraphFilterBatchAttentional(G, G, K, P, attentionMode="KeyQuery").to(gpu_device).eval()
+    X = torch.randn(B, N, G, device=gpu_device) * 0.5
+    if bf16:
+        X = X.to(torch.bfloat16)
+    st = CsrStructure().build(S.clone(), 0)
+    nnz = st.ready(gpu_device)
+    csc = (st.cscptr, st.csc[0], st.csc[1])
+    outs = []
+    for tiled in (3, 0):
+        libopt.set("MAGAT_CSR_TILED", tiled)
+        out = torch.empty(B * N, P * G, dtype=X.dtype, device=gpu_device)
+        gat_forward_rows_csr(X, st.rowptr, st.colidx, nnz, layer, out=out, csc=csc)
+        outs.append(out.float())
+    libopt.reset("MAGAT_CSR_TILED")
+    a, b = outs
+    assert not bool(torch.isnan(a).any())
+    scale = float(b.abs().max()) + 1e-6
+    assert float((a - b).abs().max()) <= (2e-2 if bf16 else 2e-5) * scale
