@@ -59,7 +59,8 @@ def build(force=False, verbose=False, debug=False):
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+    # (release: local symbols stripped - the exported C ABI lives in .dynsym, kernel names in the device code objects)
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + ([] if debug else ["-Wl,-s"]) + objs + ["-o", lib])
     return lib
 
 
