@@ -622,7 +622,8 @@ int magat_mfma_sustained_f16_ex(double* tflops, double* clock_mhz, double* per_c
 #define MAGAT_FORM_CHAIN_PERSIST 5 /* chain kernel: more 8-agent groups than workgroups (persistent group loop) */
 #define MAGAT_FORM_HEAD_COMPRESS 6 /* compressMLP computed in the head GEMM's epilogue (one launch for both) */
 #define MAGAT_FORM_GUARD_ONE 7    /* range guard of the encoder as one predicated launch */
-#define MAGAT_FORMS 8
+#define MAGAT_FORM_CSR_FUSED 8    /* bf16-storage CSR layer with the maps inside the graph kernels (gat_csr_fused.hip) */
+#define MAGAT_FORMS 9
 long long magat_form_count(int id);
 int magat_form_reset(void);
 

@@ -340,16 +340,21 @@ Layout layout(int G, int F, int K, int P, int mode) {   // must match pack_layou
 }
 
 struct WsLayout {
-  size_t status, z, cscptr, cscsrc, cscpos, csctmp, att, t0, t1, ytmp, total;
+  size_t status, z, cscptr, cscsrc, cscpos, csctmp, att, t0, t1, ytmp, order, total;
 };
+// the form with the maps inside the graph kernels (gat_csr_fused.hip): bf16 storage + the column view of magat_gso_csr_build
+bool csr_fused_form(size_t esz, bool have_csc, int G, int F, int K, int P, int mode, int concat) {
+  return esz == 2 && have_csc && magat_gat_csr_fused_supported(G, F, K, P, mode, concat);
+}
 WsLayout ws_layout(int B, int N, long long nnz, int G, int F, int K, int P, int mode, int concat,
                    size_t esz = sizeof(float), bool have_csc = false) {
   const Layout L = layout(G, F, K, P, mode);
+  const bool fused = csr_fused_form(esz, have_csc, G, F, K, P, mode, concat);
   WsLayout w;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += magat_align_up(bytes, 256); return at; };
   w.status = take(256);              // range-guard status words of the maps GEMM (first bytes of the workspace)
-  w.z = take((size_t)B * N * L.NC * esz);
+  w.z = take(fused ? 0 : (size_t)B * N * L.NC * esz);      // (the fused form has no maps in memory)
   // (the column view: nothing is reserved for it when the caller brings the one magat_gso_csr_build made)
   w.cscptr = take(have_csc ? 0 : (size_t)B * (N + 1) * sizeof(int));
   w.cscsrc = take(have_csc ? 0 : (size_t)nnz * sizeof(int));
@@ -360,6 +365,7 @@ WsLayout ws_layout(int B, int N, long long nnz, int G, int F, int K, int P, int 
   w.t0 = take(tb);
   w.t1 = take(K > 3 ? tb : 0);
   w.ytmp = take(concat ? 0 : (size_t)B * N * P * F * esz);
+  w.order = take(fused ? magat_gat_csr_fused_order_bytes(B, N) : 0);
   w.total = o;
   return w;
 }
@@ -918,6 +924,13 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
   ST* tbuf[2] = {reinterpret_cast<ST*>(ws + w.t0), reinterpret_cast<ST*>(ws + w.t1)};
   ST* Ytmp = reinterpret_cast<ST*>(ws + w.ytmp);
 
+  if (csr_fused_form(sizeof(ST), have_csc, G, F, K, P, mode, concat)) {
+    // maps on the matrix cores inside the score / hop kernels: Q and U never exist in memory (gat_csr_fused.hip)
+    return magat_gat_csr_fused_forward(reinterpret_cast<const uint16_t*>(X), rowptr, colidx, cscptr, cscsrc, cscpos, nnz,
+                                                packed + magat_gat_csr_fused_offset(L.NC, G), bias, Y, ldy, y_f32, att,
+                                                reinterpret_cast<int*>(ws + w.order), B, N, P, st);
+    // (MAGAT_ERR_UNSUPPORTED: result rows / bias not 16-byte aligned)
+  }
   int rc = csr_maps_gemm<ST>(X, packed, Z, B * N, G, L, stream, reinterpret_cast<int32_t*>(ws + w.status));
   if (rc != MAGAT_OK) return rc;
 

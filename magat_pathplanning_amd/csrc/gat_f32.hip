@@ -957,7 +957,8 @@ extern "C" size_t magat_gat_packed_floats(int G, int F, int K, int P, int mode) 
   const PackLayout L = pack_layout(G, F, K, P, mode);
   if (gat_rank1_frag(G, F, mode))      // + the one-launch kernel's weight stream and the per-head score constants
     return magat_gat_frag_offset(L.NC, G) + (size_t)(P * G + P * K * F) * G + (((size_t)P + 3) & ~(size_t)3);
-  if (G == 128 && (L.NC & 127) == 0 && mode == MAGAT_MODE_KEYQUERY) return magat_gat_frag_offset(L.NC, G) + (size_t)L.NC * G;
+  if (G == 128 && (L.NC & 127) == 0 && mode == MAGAT_MODE_KEYQUERY)      // + the bf16 fragments of gat_csr_fused.hip (NC * G bf16)
+    return magat_gat_csr_fused_offset(L.NC, G) + (size_t)L.NC * G / 2 + 4;
   return magat_gat_f16_block_offset(L.NC, G) + (size_t)L.NC * G + 4;
 }
 
@@ -1036,6 +1037,10 @@ extern "C" int magat_gat_pack_weights(const float* weight, const float* weight_b
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), weight, weight_bias,
                      mixer, taps, packed, G, F, K, P, mode, L);
+  if (G == 128 && F == 128 && K == 2 && mode == MAGAT_MODE_KEYQUERY && (P == 1 || P == 2 || P == 4)) {
+    const int rc = magat_gat_csr_fused_pack(packed, packed + magat_gat_csr_fused_offset(L.NC, G), P, static_cast<hipStream_t>(stream));
+    if (rc != MAGAT_OK) return rc;
+  }
   if (gat_rank1_frag(G, F, mode)) {
     float* frag = packed + magat_gat_frag_offset(L.NC, G);
     hipLaunchKernelGGL(pack_frag_rank1_kernel, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), weight, weight_bias,

@@ -15,7 +15,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // unless MAGAT_ALLOW_EXPERIMENT_BUILD=1).  A release build - build_native.build() without --debug - never passes extra
 // flags, so a stray environment variable cannot produce a silently wrong libmagat_hip.so.
 #if (defined(MAGAT_WHATIF_NO_W) || defined(MAGAT_WHATIF_NO_LDS) || defined(CSR_WHATIF_NODMA) || defined(CSR_WHATIF_NOLOOP) || defined(CSR_WHATIF_NOIDX) || defined(CSR_WHATIF_NOKLOOP) || defined(CSR_WHATIF_NOSTORE) || \
-     defined(GM_WHATIF_NOQW) || defined(GM_WHATIF_NOAW) || defined(GM_WHATIF_NOYST)) && !defined(MAGAT_EXPERIMENT_BUILD)
+     defined(GM_WHATIF_NOQW) || defined(GM_WHATIF_NOAW) || defined(GM_WHATIF_NOYST) || defined(FUSED_WHATIF_COALESCED) || defined(FUSED_WHATIF_NOSCALAR)) && !defined(MAGAT_EXPERIMENT_BUILD)
 #error "*_WHATIF_* timing switches produce wrong results: they compile only with -DMAGAT_EXPERIMENT_BUILD (see magat_common.h)"
 #endif
 extern "C" int magat_experiment_mark(void);      // options.hip
@@ -67,7 +67,7 @@ enum MagatOpt {
   MAGAT_OPT_ENC_CHUNK, MAGAT_OPT_CONV_SPLIT, MAGAT_OPT_CONV_PCHAIN,
   MAGAT_OPT_L1_FUSED, MAGAT_OPT_HEAD_SPLITK, MAGAT_OPT_GAT_CHUNK_MB, MAGAT_OPT_GAT_SPLIT, MAGAT_OPT_RANGE_GUARD,
   MAGAT_OPT_BLOCK_FUSED, MAGAT_OPT_CSR_TILED, MAGAT_OPT_HEAD_F16, MAGAT_OPT_GAT_MFMA, MAGAT_OPT_SKINNY, MAGAT_OPT_GAT_PACK,
-  MAGAT_OPT_CONV_BNFILL, MAGAT_OPT_HEAD_COMPRESS, MAGAT_OPT_CONV_TM, MAGAT_OPT_COUNT
+  MAGAT_OPT_CONV_BNFILL, MAGAT_OPT_HEAD_COMPRESS, MAGAT_OPT_CONV_TM, MAGAT_OPT_CSR_FUSED, MAGAT_OPT_COUNT
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)
@@ -84,7 +84,10 @@ enum MagatLdsSlot {
   MAGAT_LDS_GATP_0,      // gat_mfma.hip PACK form: 8 slots (score mode x taps x merge)
   MAGAT_LDS_GATP_END = MAGAT_LDS_GATP_0 + 8,
   MAGAT_LDS_GATS_0,      // gat_small.hip: 8 slots (width x taps x merge)
-  MAGAT_LDS_GATS_END = MAGAT_LDS_GATS_0 + 8
+  MAGAT_LDS_GATS_END = MAGAT_LDS_GATS_0 + 8,
+  MAGAT_LDS_CSR_FUSED_A,  // gat_csr_fused.hip: score kernel, P = 1 | 2 | 4
+  MAGAT_LDS_CSR_FUSED_B = MAGAT_LDS_CSR_FUSED_A + 3,   // hop + tap kernel, 1 | 2 heads per workgroup
+  MAGAT_LDS_CSR_FUSED_END = MAGAT_LDS_CSR_FUSED_B + 2
 };
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of
@@ -99,6 +102,17 @@ __host__ __device__ inline size_t magat_gat_f16_block_offset(int NC, int G) {
 __host__ __device__ inline size_t magat_gat_frag_offset(int NC, int G) {
   return (magat_gat_f16_block_offset(NC, G) + (size_t)NC * G + 4 + 3) & ~(size_t)3;
 }
+// bf16-storage CSR layer with the maps inside the graph kernels (gat_csr_fused.hip: KeyQuery, K = 2, G = F = 128, concat):
+// the fragment-major bf16 weights sit behind the one-launch kernel's fragments in the packed block (NC * G / 2 more floats)
+__host__ __device__ inline size_t magat_gat_csr_fused_offset(int NC, int G) {
+  return (magat_gat_frag_offset(NC, G) + (size_t)NC * G + 3) & ~(size_t)3;
+}
+int magat_gat_csr_fused_supported(int G, int F, int K, int P, int mode, int concat);
+int magat_gat_csr_fused_pack(const float* Bt, void* frag_out, int P, hipStream_t st);
+size_t magat_gat_csr_fused_order_bytes(int B, int N);
+int magat_gat_csr_fused_forward(const uint16_t* X, const int* rowptr, const int* colidx, const int* cscptr, const int* cscsrc,
+                                const int* cscpos, long long nnz, const void* frags, const float* bias, void* Y, int ldy,
+                                int y_f32, float* att, int* order, int B, int N, int P, hipStream_t st);
 // one-launch KeyQuery layer for small graphs and narrow features (gat_small.hip: N <= 32, G = F in {32, 64}, K = 2 | 3)
 int magat_gat_small_supported(int N, int G, int F, int K, int mode);
 int magat_gat_small_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre, const float* Hs,

@@ -43,6 +43,8 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
                              // batches whose head tile was narrowed by CONV_BNFILL keep the two launches; bit-identical)
     {"CONV_TM", 2},          // direct kernel: 32-agent row groups per wave (2 = 256-agent tiles once they fill the chip; 1 = never:
                              // the reference form the 256-agent tiles are tested against, bit-identical)
+    {"CSR_FUSED", 1},        // bf16-storage CSR layer, KeyQuery, K = 2, G = F = 128, concat: the maps on the matrix cores INSIDE the two
+                             // graph kernels, hop on X (gat_csr_fused.hip); 0 = maps GEMM + tiled score / hop kernels
 };
 
 int g_val[MAGAT_OPT_COUNT];

@@ -2,6 +2,7 @@
 // the library is bracketed by hipEvents recorded on the launch stream; magat_profile_collect() (after the
 // caller has synchronised) folds them into per-tag totals.  Disabled by default: zero cost on the hot path.
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -194,20 +195,15 @@ extern "C" int magat_mfma_sustained_f16_ex(double* tflops, double* clock_mhz, do
 // ------------------------------------------------------------------------------------------------------------------------
 // Which FORM of a kernel a launch took (host-side counters, bumped where the launcher decides; tests assert on them next to the
 // per-tag launch counts: the forms below exist only at benchmark sizes and must not be swapped silently).
-namespace { long long g_forms[MAGAT_FORMS]; }
+namespace { std::atomic<long long> g_forms[MAGAT_FORMS]; }      // relaxed counters: no lock on the launch path
 void magat_form_note(int id) {
-  if (id >= 0 && id < MAGAT_FORMS) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_forms[id] += 1;
-  }
+  if (id >= 0 && id < MAGAT_FORMS) g_forms[id].fetch_add(1, std::memory_order_relaxed);
 }
 extern "C" long long magat_form_count(int id) {
   if (id < 0 || id >= MAGAT_FORMS) return -1;
-  std::lock_guard<std::mutex> lk(g_mu);
-  return g_forms[id];
+  return g_forms[id].load(std::memory_order_relaxed);
 }
 extern "C" int magat_form_reset(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  for (int i = 0; i < MAGAT_FORMS; ++i) g_forms[i] = 0;
+  for (int i = 0; i < MAGAT_FORMS; ++i) g_forms[i].store(0, std::memory_order_relaxed);
   return MAGAT_OK;
 }

@@ -216,6 +216,33 @@ def gat_layer_forward_bf16_storage(x, S4, p, mode="KeyQuery", concat=True):
     return y.permute(0, 2, 1), aij.unsqueeze(2)
 
 
+def gat_layer_forward_bf16_fused(x, S4, p):
+    """The bf16-storage layer in the order of the FUSED CSR kernels (csrc/gat_csr_fused.hip: KeyQuery, K = 2, concat) - which
+    is the reference's own order (graphML.py:1757 hop on the node features, :1768-1770 tap contraction afterwards), not the
+    Horner order of gat_layer_forward_bf16_storage.  NO REFERENCE COUNTERPART (the reference has no bf16 path): RNE-bf16
+    rounding exactly where the kernels round - the input rows X, the weights, q'_i = W_p^T x_i (the registers of the score
+    loop), the hop result z_j = sum_i a_ij x_i (the matrix-core operand) and the result; float32 arithmetic and attention.
+    x (B,G,N) f32; returns (y (B,P*F,N) f32 holding bf16-representable values, aij (B,P,1,N,N))."""
+    B, G, N = x.shape
+    X = _r16(x.permute(0, 2, 1).float())                                   # (B,N,G)
+    W = _r16(p["weight"].float()[:, 0])                                    # (P,G,G)
+    taps = _r16(p["filterWeight"].float()[:, :, 0])                        # (P,F,K,G)
+    P, F, K = taps.shape[0], taps.shape[1], taps.shape[2]
+    assert K == 2
+    bias = p.get("bias")
+    mask = edge_mask(S4, torch.float32)[:, 0, 0]
+    qp = _r16(torch.einsum("big,pgh->bpih", X, W))                         # q'_i[h] = sum_g x_i[g] W_p[g][h]
+    e = torch.einsum("bpih,bjh->bpij", qp, X)
+    m4 = mask.unsqueeze(1)
+    aij = torch.softmax(e * m4 - (1 - m4) * INFINITE_NUMBER, dim=3) * m4     # (B,P,N,N)
+    Z1 = _r16(torch.einsum("bpij,big->bpjg", aij, X))                      # z_j = sum_i a_ij x_i
+    T = torch.einsum("bng,pfg->bpnf", X, taps[:, :, 0]) + torch.einsum("bpng,pfg->bpnf", Z1, taps[:, :, 1])
+    if bias is not None:
+        T = T + bias.float().reshape(1, 1, 1, F)
+    y = _r16(torch.relu(T)).permute(0, 2, 1, 3).reshape(B, N, P * F)
+    return y.permute(0, 2, 1), aij.unsqueeze(2)
+
+
 def graph_filter_batch_forward(x, S4, weight, bias=None):
     """GraphFilterBatch.forward -> BatchLSIGF (graphML.py:5670-5689, 5485-5579), the non-attentional GNN baseline:
     z_0 = x, z_k = z_{k-1} @ S.float() (:5562), y = cat_k(z_k) contracted with weight (F,E,K,G) (:5573-5574), + bias.

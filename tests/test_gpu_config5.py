@@ -192,6 +192,7 @@ def test_config5_layer_at_1000_agents(gpu_device, storage, tiled, libopt):
     from magat_pathplanning_amd.synthetic import comm_gso
     from oracle import magat_oracle as orc
     libopt.set("CSR_TILED", tiled)  # 3: LDS-tiled kernels (default), 0: the L2-gather kernels
+    libopt.set("CSR_FUSED", 0)      # the SPLIT form (maps GEMM + score / hop kernels); the fused form: tests/test_gpu_csr_fused.py
     B = 2
     g = torch.Generator().manual_seed(15)
     layer = GraphFilterBatchAttentional(G5, G5, K5, P5, attentionMode="KeyQuery")

@@ -131,6 +131,7 @@ def test_tiled_csr_kernels_against_the_per_edge_kernels(gpu_device, libopt, N, B
     nnz = st.ready(gpu_device)
     csc = (st.cscptr, st.csc[0], st.csc[1])
     outs = []
+    libopt.set("MAGAT_CSR_FUSED", 0)          # (the split form's two kernel families; fused form: tests/test_gpu_csr_fused.py)
     for tiled in (3, 0):
         libopt.set("MAGAT_CSR_TILED", tiled)
         out = torch.empty(B * N, P * G, dtype=X.dtype, device=gpu_device)

@@ -33,7 +33,8 @@ def test_library_exports_every_declared_symbol():
     nc = 4 * 128 + 4 * 3 * 128            # fp32 [NC][G] + column bias [NC] + bf16x3 planes [3][NC][G] + f16x2 planes + scale
     base = nc * 129 + 3 * nc * 128 // 2 + nc * 128 + 4
     # + the f16x2 planes once more in matrix-core fragment order (128 features: the one-launch KeyQuery layer, gat_mfma.hip)
-    assert lib.magat_gat_packed_floats(128, 128, 3, 4, 0) == base + nc * 128
+    # + (round 6) the bf16 fragments of the fused CSR layer (gat_csr_fused.hip): NC * G bf16 = NC * G / 2 floats + 4
+    assert lib.magat_gat_packed_floats(128, 128, 3, 4, 0) == base + nc * 128 + nc * 64 + 4
     nc64 = 4 * 64 + 4 * 3 * 64
     assert lib.magat_gat_packed_floats(64, 64, 3, 4, 0) == nc64 * 65 + 3 * nc64 * 64 // 2 + nc64 * 64 + 4
     assert lib.magat_gat_workspace_bytes(2, 10, 128, 128, 2, 1, 0, 1) >= 2 * 10 * 384 * 4
