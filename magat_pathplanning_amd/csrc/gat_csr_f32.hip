@@ -927,7 +927,8 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
   if (csr_fused_form(sizeof(ST), have_csc, G, F, K, P, mode, concat)) {
     // maps on the matrix cores inside the score / hop kernels: Q and U never exist in memory (gat_csr_fused.hip)
     return magat_gat_csr_fused_forward(reinterpret_cast<const uint16_t*>(X), rowptr, colidx, cscptr, cscsrc, cscpos, nnz,
-                                                packed + magat_gat_csr_fused_offset(L.NC, G), bias, Y, ldy, y_f32, att,
+                                                packed + magat_gat_csr_fused_offset(L.NC, G), bias, Y, ldy, y_f32,
+                                                reinterpret_cast<float*>(ws + w.att), att_opt,
                                                 reinterpret_cast<int*>(ws + w.order), B, N, P, st);
     // (MAGAT_ERR_UNSUPPORTED: result rows / bias not 16-byte aligned)
   }

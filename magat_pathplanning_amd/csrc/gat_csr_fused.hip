@@ -30,6 +30,9 @@ typedef unsigned short u16;
 typedef unsigned int fu32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 fbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 fbf16x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) Int4 {      // four consecutive indices of an edge list: dword-aligned 16-byte load
+  int v[4];
+};
 
 namespace {
 
@@ -41,7 +44,7 @@ struct FusedParams {
   const int* cscsrc;
   const int* cscpos;
   const int* order;      // [2][B][N]: rows by out-degree (descending), rows by in-degree
-  float* att;            // [P][nnz]
+  float* att;            // [nnz][P]: the P heads of an edge side by side (CSR order)
   const u16* wq;         // [P][4][8][64][8]   fragments of W_p^T:  (feature tile, k step, lane, 8)
   const u16* wh;         // [P][4][16][64][8]  fragments of [H_p0 | H_p1]
   const float* bias;     // [128] or null
@@ -236,7 +239,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_scores_kernel(const F
         }
     }
     STAMP(1)
-    // edge loop: slot k = the k-th edge of every row of the group
+    // edge loop: slot k = the k-th edge of every row of the group.  The kernels are bound by the number of REQUESTS the texture
+    // path takes (about one per cycle and CU; every lane of a scattered access is one: profiles/r06a), so: neighbour indices
+    // four slots per load, the raw scores of the first eight slots stay in registers (no store + read-back), attention as
+    // [edge][head] (one store per lane and slot).
     float mx[HO], sm[HO];
 #pragma unroll
     for (int o = 0; o < HO; ++o) {
@@ -244,8 +250,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_scores_kernel(const F
       sm[o] = 0.f;
     }
     const int hbase = P >= 2 ? HO * half : 0;          // first head this lane half owns
-    float* const attr = p.att + (long long)hbase * p.nnz + e0;
-    auto slot = [&](int k, const fu32x4 (&x)[8]) __attribute__((always_inline)) {
+    float* const attr = p.att + (long long)e0 * P + hbase;      // att[(e0 + k) * P + head]
+    auto score = [&](const fu32x4 (&x)[8], float (&own)[HO]) __attribute__((always_inline)) {
       float sc[P];
 #pragma unroll
       for (int hp = 0; hp < P; ++hp) {
@@ -259,7 +265,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_scores_kernel(const F
         }
         sc[hp] = d0 + d1;
       }
-      float own[HO];
       if constexpr (P == 4) {
         own[0] = swap_add(sc[0], sc[2]);
         own[1] = swap_add(sc[1], sc[3]);
@@ -268,64 +273,115 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_scores_kernel(const F
       } else {
         own[0] = swap_add(sc[0], sc[0]);
       }
-      if (k < deg) {
+    };
+    auto track = [&](const float (&own)[HO]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int o = 0; o < HO; ++o) {
-          if (P >= 2 || half == 0) attr[(long long)o * p.nnz + k] = own[o];
-          const float m2 = fmaxf(mx[o], own[o]);
-          sm[o] = sm[o] * __expf(mx[o] - m2) + __expf(own[o] - m2);
-          mx[o] = m2;
-        }
+      for (int o = 0; o < HO; ++o) {
+        const float m2 = fmaxf(mx[o], own[o]);
+        sm[o] = sm[o] * __expf(mx[o] - m2) + __expf(own[o] - m2);
+        mx[o] = m2;
       }
     };
-    {
-      int c1 = 1 < deg ? p.colidx[e0 + 1] : row;
-      fu32x4 xa[8], xb[8];
-      gather_row(Xb, 0 < deg ? p.colidx[e0] : row, goff, xa);
-      for (int k = 0;; k += 2) {
+    auto put = [&](int k, const float (&v)[HO]) __attribute__((always_inline)) {
+      if constexpr (HO == 2) *reinterpret_cast<f32x2*>(attr + (long long)k * P) = f32x2{v[0], v[1]};
+      else if (P >= 2 || half == 0) attr[(long long)k * P] = v[0];
+    };
+    auto load4 = [&](int k0, int (&c)[4]) __attribute__((always_inline)) {
+      if (k0 + 4 <= deg) {
+        const Int4 v = *reinterpret_cast<const Int4*>(p.colidx + e0 + k0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = v.v[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = k0 + i < deg ? p.colidx[e0 + k0 + i] : row;
+      }
+    };
+    constexpr int KR = 8;                               // slots whose raw scores stay in registers
+    float rawr[KR][HO];
+    fu32x4 xa[8], xb[8];
+    int cj[4], cn[4];
+    load4(0, cj);
+    gather_row(Xb, cj[0], goff, xa);
+    bool live = true;
+#pragma unroll
+    for (int bt = 0; bt < KR / 4; ++bt) {
+      if (live) load4(4 * bt + 4, cn);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = 4 * bt + c;
+        if (live && __builtin_amdgcn_ballot_w64(k < deg) == 0ull) live = false;
+        if (live) {
+          const int nx = c < 3 ? cj[c + 1] : cn[0];
+          if ((k & 1) == 0) {
+            gather_row(Xb, nx, goff, xb);
+            score(xa, rawr[k]);
+          } else {
+            gather_row(Xb, nx, goff, xa);
+            score(xb, rawr[k]);
+          }
+          if (k < deg) track(rawr[k]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) cj[c] = cn[c];
+    }
+    if (live) {      // rows with more than KR edges: the rest through memory (raw score stored, read back below)
+      int c1 = cj[1];
+      for (int k = KR;; k += 2) {
         if (__builtin_amdgcn_ballot_w64(k < deg) == 0ull) break;
         const int c2 = k + 2 < deg ? p.colidx[e0 + k + 2] : row;
         gather_row(Xb, c1, goff, xb);
-        slot(k, xa);
+        float own[HO];
+        score(xa, own);
+        if (k < deg) {
+          put(k, own);
+          track(own);
+        }
         if (__builtin_amdgcn_ballot_w64(k + 1 < deg) == 0ull) break;
         c1 = k + 3 < deg ? p.colidx[e0 + k + 3] : row;
         gather_row(Xb, c2, goff, xa);
-        slot(k + 1, xb);
+        score(xb, own);
+        if (k + 1 < deg) {
+          put(k + 1, own);
+          track(own);
+        }
       }
     }
     STAMP(2)
-    // normalise: the raw scores come back from L2 (stored by this very lane; an agent-scope load never sees a stale L1 line),
-    // four edges per round trip
     float inv[HO];
 #pragma unroll
     for (int o = 0; o < HO; ++o) inv[o] = sm[o] > 0.f ? 1.f / sm[o] : 0.f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the raw scores' stores are acknowledged before the loads are issued)
-    if (P >= 2 || half == 0) {
-#ifdef FUSED_NORM1
-      for (int k = 0; k < deg; ++k) {
 #pragma unroll
-        for (int o = 0; o < HO; ++o) {
-          float* a = attr + (long long)o * p.nnz + k;
-          const float raw = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          *a = __expf(raw - mx[o]) * inv[o];
+    for (int k = 0; k < KR; ++k)
+      if (k < deg) {
+        float v[HO];
+#pragma unroll
+        for (int o = 0; o < HO; ++o) v[o] = __expf(rawr[k][o] - mx[o]) * inv[o];
+        put(k, v);
+      }
+    if (__builtin_amdgcn_ballot_w64(KR < deg) != 0ull) {
+      // (the raw scores' stores are acknowledged before the loads are issued; stored by this very lane, and an agent-scope
+      //  load never sees a stale L1 line)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (P >= 2 || half == 0) {
+        for (int k = KR; k < deg; k += 4) {
+          float raw[4][HO];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int o = 0; o < HO; ++o)
+              raw[c][o] = k + c < deg ? __hip_atomic_load(attr + (long long)(k + c) * P + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (k + c < deg) {
+              float v[HO];
+#pragma unroll
+              for (int o = 0; o < HO; ++o) v[o] = __expf(raw[c][o] - mx[o]) * inv[o];
+              put(k + c, v);
+            }
         }
       }
-#else
-      for (int k = 0; k < deg; k += 4) {
-        float raw[4][HO];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int o = 0; o < HO; ++o)
-            raw[c][o] = k + c < deg ? __hip_atomic_load(attr + (long long)o * p.nnz + k + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                    : 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int o = 0; o < HO; ++o)
-            if (k + c < deg) attr[(long long)o * p.nnz + k + c] = __expf(raw[c][o] - mx[o]) * inv[o];
-      }
-#endif
     }
     STAMP(3)
   }
@@ -363,7 +419,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_hop_kernel(const Fuse
     const int s0 = cp[row];
     const int deg = valid ? cp[row + 1] - s0 : 0;
     const u16* Xb = p.X + (long long)b * N * 128;
-    const float* const attg = p.att + (long long)hg * HP * p.nnz;
+    const float* const attg = p.att + hg * HP;      // att[pos * P + head]
     f32x2 acc[HP][8][4];
 #pragma unroll
     for (int h = 0; h < HP; ++h)
@@ -371,14 +427,33 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_hop_kernel(const Fuse
       for (int m = 0; m < 8; ++m)
 #pragma unroll
         for (int d = 0; d < 4; ++d) acc[h][m][d] = f32x2{0.f, 0.f};
-    auto ldidx = [&](int k, int& src, int& ps) __attribute__((always_inline)) {
-      const bool on = k < deg;
-      src = on ? p.cscsrc[s0 + k] : row;
-      ps = on ? p.cscpos[s0 + k] : -1;
+    auto load4i = [&](int k0, int (&src)[4], int (&ps)[4]) __attribute__((always_inline)) {
+      if (k0 + 4 <= deg) {
+        const Int4 a = *reinterpret_cast<const Int4*>(p.cscsrc + s0 + k0);
+        const Int4 c = *reinterpret_cast<const Int4*>(p.cscpos + s0 + k0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          src[i] = a.v[i];
+          ps[i] = c.v[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool on = k0 + i < deg;
+          src[i] = on ? p.cscsrc[s0 + k0 + i] : row;
+          ps[i] = on ? p.cscpos[s0 + k0 + i] : -1;
+        }
+      }
     };
     auto ldval = [&](int src, int ps, float (&a)[HP], fu32x4 (&x)[8]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int h = 0; h < HP; ++h) a[h] = ps >= 0 ? attg[(long long)h * p.nnz + ps] : 0.f;
+      if constexpr (HP == 2) {
+        f32x2 v = {0.f, 0.f};
+        if (ps >= 0) v = *reinterpret_cast<const f32x2*>(attg + (long long)ps * p.P);
+        a[0] = v[0];
+        a[1] = v[1];
+      } else {
+        a[0] = ps >= 0 ? attg[(long long)ps * p.P] : 0.f;
+      }
       gather_row(Xb, src, goff, x);
     };
     auto fma_slot = [&](const float (&a)[HP], const fu32x4 (&x)[8]) __attribute__((always_inline)) {
@@ -392,25 +467,34 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_hop_kernel(const Fuse
         }
     };
     {
-      int i0, p0, i1, p1, i2, p2;
+      int si[4], sp[4], ni[4], np4[4];
       float aa[HP], ab[HP];
       fu32x4 xa[8], xb[8];
-      ldidx(0, i0, p0);
-      ldidx(1, i1, p1);
-      ldval(i0, p0, aa, xa);
+      load4i(0, si, sp);
+      ldval(si[0], sp[0], aa, xa);
 #ifdef FUSED_STAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       STAMP(0)
 #endif
-      for (int k = 0;; k += 2) {
-        if (__builtin_amdgcn_ballot_w64(k < deg) == 0ull) break;
-        ldidx(k + 2, i2, p2);
-        ldval(i1, p1, ab, xb);
+      for (int k0 = 0;; k0 += 4) {
+        if (__builtin_amdgcn_ballot_w64(k0 < deg) == 0ull) break;
+        load4i(k0 + 4, ni, np4);
+        ldval(si[1], sp[1], ab, xb);
         fma_slot(aa, xa);
-        if (__builtin_amdgcn_ballot_w64(k + 1 < deg) == 0ull) break;
-        ldidx(k + 3, i1, p1);
-        ldval(i2, p2, aa, xa);
+        if (__builtin_amdgcn_ballot_w64(k0 + 1 < deg) == 0ull) break;
+        ldval(si[2], sp[2], aa, xa);
         fma_slot(ab, xb);
+        if (__builtin_amdgcn_ballot_w64(k0 + 2 < deg) == 0ull) break;
+        ldval(si[3], sp[3], ab, xb);
+        fma_slot(aa, xa);
+        if (__builtin_amdgcn_ballot_w64(k0 + 3 < deg) == 0ull) break;
+        ldval(ni[0], np4[0], aa, xa);
+        fma_slot(ab, xb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          si[i] = ni[i];
+          sp[i] = np4[i];
+        }
       }
     }
     STAMP(1)
@@ -496,6 +580,16 @@ __global__ void csr_fused_pack_kernel(const float* __restrict__ Bt, u16* __restr
   }
 }
 
+// attention [nnz][P] (the kernels' own order) -> [P][nnz] (what magat_gat_forward_*'s att_opt hands to the caller)
+__global__ void csr_fused_att_out_kernel(const float* __restrict__ a, float* __restrict__ out, long long nnz, int P) {
+  const long long total = nnz * P;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long e = idx / P;
+    const int h = (int)(idx - e * P);
+    out[(long long)h * nnz + e] = a[idx];
+  }
+}
+
 int device_cus() {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
@@ -525,7 +619,7 @@ size_t magat_gat_csr_fused_order_bytes(int B, int N) { return (size_t)2 * B * N 
 
 int magat_gat_csr_fused_forward(const uint16_t* X, const int* rowptr, const int* colidx, const int* cscptr, const int* cscsrc,
                                 const int* cscpos, long long nnz, const void* frags, const float* bias, void* Y, int ldy,
-                                int y_f32, float* att, int* order, int B, int N, int P, hipStream_t st) {
+                                int y_f32, float* att, float* att_opt, int* order, int B, int N, int P, hipStream_t st) {
   if (!(P == 1 || P == 2 || P == 4)) return MAGAT_ERR_UNSUPPORTED;
   if ((ldy & (y_f32 ? 3 : 7)) || (reinterpret_cast<uintptr_t>(Y) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
     return MAGAT_ERR_UNSUPPORTED;
@@ -580,6 +674,12 @@ int magat_gat_csr_fused_forward(const uint16_t* X, const int* rowptr, const int*
     if (HP == 2) hipLaunchKernelGGL((csr_fused_hop_kernel<2>), grid, block, lds, st, p);
     else hipLaunchKernelGGL((csr_fused_hop_kernel<1>), grid, block, lds, st, p);
     magat_prof_end(pid, st);
+    if (magat_check_launch() != MAGAT_OK) return MAGAT_ERR_LAUNCH;
+  }
+  if (att_opt && nnz > 0) {
+    long long blocks = (nnz * P + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(csr_fused_att_out_kernel, dim3((unsigned)blocks), dim3(256), 0, st, att, att_opt, nnz, P);
     if (magat_check_launch() != MAGAT_OK) return MAGAT_ERR_LAUNCH;
   }
   magat_form_note(MAGAT_FORM_CSR_FUSED);

@@ -112,7 +112,8 @@ int magat_gat_csr_fused_pack(const float* Bt, void* frag_out, int P, hipStream_t
 size_t magat_gat_csr_fused_order_bytes(int B, int N);
 int magat_gat_csr_fused_forward(const uint16_t* X, const int* rowptr, const int* colidx, const int* cscptr, const int* cscsrc,
                                 const int* cscpos, long long nnz, const void* frags, const float* bias, void* Y, int ldy,
-                                int y_f32, float* att, int* order, int B, int N, int P, hipStream_t st);
+                                int y_f32, float* att /* workspace, [nnz][P] */, float* att_opt /* [P][nnz] or null */, int* order, int B, int N,
+                                int P, hipStream_t st);
 // one-launch KeyQuery layer for small graphs and narrow features (gat_small.hip: N <= 32, G = F in {32, 64}, K = 2 | 3)
 int magat_gat_small_supported(int N, int G, int F, int K, int mode);
 int magat_gat_small_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre, const float* Hs,
