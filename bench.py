@@ -26,7 +26,13 @@ Rank 0 prints ONE JSON line.  `value` is measured with the library's DEFAULT ari
                  kernel against the 157.3 TF float32 MFMA roof
   ms_per_step_device  hipEvent pair around the K timed steps on the launch stream (ms_per_step is host wall-clock over barriers)
   cpu_baseline   the pinned CPU oracle (kind "port") on this box's host cores: processes x threads sweep over the physical
-                 cores, median of three runs of the best split, bounded sample; runs BEFORE the GPU legs
+                 cores, median of three runs of the best split, bounded sample; runs BEHIND every GPU leg (round 5)
+  roofline.legs  (round 6) the numbers of the extra legs once more in ONE compact object inside `roofline` (the object a
+                 driver keeps whole): c2 / c5 a-s/s and graph-layer fractions, batch 1024, f32_strict, the c3 graph kernel against
+                 both roofs, the published widths at N = 10 and N = 100, the batch-1 latency
+  first_steps_ms the first five steps of a device that idled for two seconds, each timed on its own (not part of `value`):
+                 what a cold caller sees before the clocks are back; `config.preheat` says what runs in front of the timed region
+  latency_b1     one planning instance per step (the reference's test_batch_size = 1 loop): median step incl. the host copy
 """
 import argparse
 import ctypes
@@ -56,6 +62,8 @@ WORKLOADS = {
     # the PUBLISHED MAGAT setting (scripts/train_DMap.sh:42, "MAGAT F-32-P4"; the released checkpoints, README.md:385-390): 10 agents,
     # 20x20 map, K=2, 4 heads of 32 features, head MEAN (no --AttentionConcat), BottomNeck_only; batch 1024 planning instances
     "published_f32p4": (1024, 10, 20, 2, 4, 32, "BottomNeck_only", "ResNetLarge_withMLP", False),
+    # ... and the same checkpoint shape on the README's 100-robot generalisation set (README.md:372-390), 50x50 map
+    "published_f32p4_n100": (512, 100, 50, 2, 4, 32, "BottomNeck_only", "ResNetLarge_withMLP", False),
 }
 GAT_STORAGE = {"c5": "bf16"}
 
@@ -85,7 +93,7 @@ def conv_arith(nat, cfg, layer):
     return "f16x3"
 
 
-def kernel_work(nat, cfg, N, S_bytes, deg=None, planned=False, fused_stem=True, pooled_head=False):
+def kernel_work(nat, cfg, N, S_bytes, deg=None, planned=False, fused_stem=True, pooled_head=False, csr_fused=False):
     """ALGORITHMIC work per AGENT-STEP for each kernel tag name: dict(flops=fp32 multiply-add flops, bytes=HBM bytes every
     kernel must move if it kept nothing it does not have to, arith=key of ARITH or None).  SURVEY.md section 8(d).  deg: mean
     out-degree, given when the layer runs on the CSR kernels (N > 128 or bf16 storage)."""
@@ -149,6 +157,12 @@ def kernel_work(nat, cfg, N, S_bytes, deg=None, planned=False, fused_stem=True, 
         w["gat_graph"] = dict(flops=0, arith=None,
                               bytes=es * (G + P * G + P * K * F + yw) + 4 * (2 + 3 * deg) + 4 * P * deg * K)
         w["gat_maps_gemm"]["bytes"] = es * (G + NC)
+        if csr_fused:
+            # maps inside the score / hop kernels (csrc/gat_csr_fused.hip): the tag's launches ARE the layer - SURVEY 8(d)'s
+            # LAYER-level bytes (X in, Y out, one CSR index + row pointer per edge / row: 2 G + 2 P F + 4 (1 + deg) in bf16) and
+            # the layer's flops (q' = W^T x and the tap contraction on the matrix cores + the edge products)
+            w["gat_graph"] = dict(flops=2 * G * P * G + 2 * P * K * G * F + 4 * P * deg * G, arith="bf16",
+                                  bytes=es * (G + yw) + 4 * (1 + deg))
     width = yw + (nfm if cfg.bottleneckMode == "BottomNeck_skipConcat" else 0)
     # the action head (width -> 5) runs as streamed float32 dot products (vector FMAs, option SKINNY): bound by its bytes; with
     # bf16 storage in the graph layer it reads that layer's rows as bf16
@@ -350,8 +364,12 @@ def cpu_baseline(cfg, sd, N, map_w, budget_s=30.0):
             "physical_cores": phys, "logical_cores": logical,
             "split_sweep": {"%dx%d" % k: round(v, 1) for k, v in sweep.items()},
             "sample": "oracle.planner_forward, %d instances x N=%d per process (same model/config), %d processes x %d threads "
-                      "(best of the swept splits of the %d physical cores), median of 3 runs of %.1f s, torch-CPU %s"
-                      % (Bc, N, best[0], best[1], phys, per, torch.__version__)}
+                      "(best of the swept splits of the %d physical cores), median of 3 runs of %.1f s, torch-CPU %s.  Port against "
+                      "the TRUE reference (importable in the build container only), same inputs, 8 threads, 3 shapes x 4 runs: "
+                      "time ratio port / reference 0.81-1.30, median 1.05 (tools/cpu_equivalence.py, "
+                      "profiles/r06a/cpu_equivalence.txt): the port understates the reference's CPU rate by up to that factor"
+                      % (Bc, N, best[0], best[1], phys, per, torch.__version__),
+            "port_over_reference_time_ratio": [0.81, 1.30]}
 
 
 def relaunch_under_torchrun(n):
@@ -500,7 +518,8 @@ def main():
         csr = Nk > 128 or cfg.gat_storage == "bf16"
         deg = float((S != 0).sum().item()) / (Bk * Nk) if csr else None
         work = kernel_work(nat, cfg, Nk, 4, deg, planned="gat_prepare" in kern and not csr,
-                           fused_stem="layer1.conv1" not in kern, pooled_head=("layer3 (fused, pooled)" in kern or "layer1.conv2+layer2+layer3 (fused, pooled)" in kern))
+                           fused_stem="layer1.conv1" not in kern, pooled_head=("layer3 (fused, pooled)" in kern or "layer1.conv2+layer2+layer3 (fused, pooled)" in kern),
+                           csr_fused=csr and cfg.gat_storage == "bf16" and "gat_graph" in kern and "gat_maps_gemm" not in kern)
         if "conv_first" in kern and "layer1.conv1" not in kern and cfg.CNN_mode.startswith("ResNet"):
             kern = {("conv_first+layer1.conv1 (fused)" if k == "conv_first" else k): v for k, v in kern.items()}
         # compressMLP in the head's epilogue (option HEAD_COMPRESS; round 5): one launch carries both layers' work - the pooled
@@ -574,6 +593,22 @@ def main():
     # start inside that ramp (r04: the instrumented pass right behind it was 4.5 % FASTER than the timed steps).  The
     # registers-only MFMA measurement this line reports anyway (`roofline.sustained_*`) now runs HERE, in front of the W warm-up
     # steps, on every rank: ~150 ms of matrix work that is not a step - W and K are untouched, the timed region is steady state.
+    # What a COLD caller sees: two untimed steps take the one-off work (weight packs, the calibration
+    # pass), the device then idles for two seconds, and the next five steps are timed one by one (synchronised each: +~20 us of
+    # host latency per step).  Not part of `value`; the pre-heat below and the W warm-up steps come after it.
+    first_steps_ms = []
+    with torch.no_grad():
+        for _ in range(2):
+            net.addGSO(S)
+            net(x)
+        torch.cuda.synchronize(dev)
+        time.sleep(2.0)
+        for _ in range(5):
+            t0_ = time.perf_counter()
+            net.addGSO(S)
+            net(x)
+            torch.cuda.synchronize(dev)
+            first_steps_ms.append(round((time.perf_counter() - t0_) * 1e3, 4))
     sus_pre = None
     try:
         sus_pre = sustained_mfma_tflops(lib, dev, reps=15, ms=10)
@@ -615,7 +650,11 @@ def main():
                           "parity": "logits within 1e-4 of the reference (gate; observed ~1e-6 with this arithmetic)",
                           "options": {k: lib_opt(nat, k) for k in ("CONV_SPLIT", "RANGE_GUARD", "BLOCK_FUSED", "HEAD_F16",
                                                                     "HEAD_COMPRESS", "GAT_MFMA", "GAT_PACK")},
-                          "global_batch": B * world, "agents": N, "parallelism": "instance-sharded x%d" % world}}
+                          "global_batch": B * world, "agents": N, "parallelism": "instance-sharded x%d" % world,
+                          "preheat": "in front of the W warm-up steps: gc.collect + freeze, and ~150 ms of registers-only MFMA work "
+                                     "(the roofline.sustained_* measurement) so that the timed region starts at the clocks the "
+                                     "chip holds under load; a cold caller's first steps: first_steps_ms"},
+               "first_steps_ms": first_steps_ms}
         if args.share_gpu:
             res["config"]["rehearsal"] = ("--share-gpu: %d ranks drive ONE device over gloo - the launch / rank logic of the "
                                           "N > 1 run, not a scaling measurement" % world)
@@ -700,6 +739,19 @@ def main():
                 leg["kernels"] = {k: {q: v[q] for q in keep if q in v} for k, v in tw.items()
                                   if k.startswith("gat_") or k in ("gso_to_csr", "range_guard", "head_mean")}
                 leg["kernel_time_ms_per_step"] = round(sum(v["ms_per_step"] for v in tw.values()), 4)
+                if wl == "c5":
+                    # the graph LAYER against SURVEY 8(d)'s layer-level bytes (2 G + 2 P F + 4 (1 + deg) per agent-step in bf16):
+                    # every launch between compressMLP's rows and the action head - row cast, (maps GEMM,) degree ranking,
+                    # score and hop kernels; `us_with_structure_build` adds the GSO -> CSR + CSC pass of addGSO
+                    degw = float((Sw != 0).sum().item()) / (Bw * Nw)
+                    lb = 2 * Gw + 2 * Pw * Gw + 4 * (1 + degw)
+                    lus = 1e3 * sum(v["ms_per_step"] for k, v in tw.items() if k in ("gat_graph", "gat_maps_gemm", "gat_cast"))
+                    sus_ = lus + 1e3 * tw.get("gso_to_csr", {}).get("ms_per_step", 0.0)
+                    leg["gat_layer"] = {"us": round(lus, 1), "us_with_structure_build": round(sus_, 1),
+                                        "bytes_per_agent_step": round(lb, 1), "edges_per_agent": round(degw, 2),
+                                        "frac": round(lb * Bw * Nw / (lus * 1e-6) / (PEAK_HBM_GBS * 1e9), 4),
+                                        "frac_with_structure_build": round(lb * Bw * Nw / (sus_ * 1e-6) / (PEAK_HBM_GBS * 1e9), 4),
+                                        "maps_in_memory": "gat_maps_gemm" in tw}
             res[wl] = leg
             del netw, xw, Sw
             torch.cuda.empty_cache()
@@ -721,6 +773,63 @@ def main():
             leg["kernels"] = {k: {q: v[q] for q in keep if q in v} for k, v in tw.items()}
         res["published_f32p4"] = leg
         del netw, xw, Sw
+        torch.cuda.empty_cache()
+        # (c2) the same published widths on the README's 100-robot generalisation set (README.md:372-390)
+        Bw, Nw, mw, Kw, Pw, Gw, bmw, cnw, ccw = WORKLOADS["published_f32p4_n100"]
+        cfgw = make_config(num_agents=Nw, nGraphFilterTaps=Kw, nAttentionHeads=Pw, bottleneckFeature=Gw, bottleneckMode=bmw,
+                           CNN_mode=cnw, AttentionConcat=ccw, device=str(dev), gat_storage="fp32")
+        netw = build_model(cfgw, dev)
+        xw, Sw = fov_states(Bw, Nw, seed=15).to(dev), comm_gso(Bw, Nw, mw, seed=16).to(dev)
+        el, kw, _ = run_leg(xw, Sw, esteps, 3, timing, net=netw)
+        leg = {"workload": "published MAGAT F-32-P4 on the 100-robot set (README.md:372-390): N=%d, %dx%d map, K=%d, P=%d, G=F=%d, "
+                           "head-mean, batch %d" % (Nw, mw, mw, Kw, Pw, Gw, Bw),
+               "steps": esteps, "value": round(Bw * Nw * esteps / el, 1), "unit": "agent-steps/s",
+               "ms_per_step": round(el / esteps * 1e3, 4),
+               "graph_layer_one_launch": bool(lib.magat_gat_one_launch_supported(Nw, Gw, Gw, Kw, 0, 0))}
+        if timing:
+            tw = kernel_table(kw, esteps, Bw, Nw, Sw, {}, cfg=cfgw)
+            keep = ("avg_us", "ms_per_step", "launches", "bound", "achieved", "peak", "unit", "frac", "bytes_per_agent_step")
+            leg["kernels"] = {k: {q: v[q] for q in keep if q in v} for k, v in tw.items() if k.startswith("gat_") or k == "head_mean"}
+        res["published_f32p4_n100"] = leg
+        del netw, xw, Sw
+        torch.cuda.empty_cache()
+        # (c3) the reference's OWN inference loop: one planning instance per step ("test_batch_size": 1,
+        # configs/dcpGAT_OE_Random.json:58; agents/decentralplannerlocal_OnlineExpert_GAT.py:1030-1055): addGSO (float64 GSO, as the
+        # simulator hands it) + forward + copy of the logits to the host, wall time per step; and the device time of the same
+        # step back to back without the copy
+        try:
+            lat = {"what": "batch 1: addGSO(float64 S) + forward + logits.cpu() per step, wall clock; K=3, P=4, BottomNeck_skipConcat",
+                   "timed_steps": 300}
+            for Nl, ml in ((10, 20), (100, 50)):
+                cfgl = make_config(num_agents=Nl, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat",
+                                   device=str(dev))
+                netl = build_model(cfgl, dev)
+                xl, Sl = fov_states(1, Nl, seed=17).to(dev), comm_gso(1, Nl, ml, seed=18, dtype=torch.float64).to(dev)
+                with torch.no_grad():
+                    for _ in range(30):
+                        netl.addGSO(Sl)
+                        netl(xl).cpu()
+                    torch.cuda.synchronize(dev)
+                    ts = []
+                    for _ in range(300):
+                        t0_ = time.perf_counter()
+                        netl.addGSO(Sl)
+                        netl(xl).cpu()
+                        ts.append((time.perf_counter() - t0_) * 1e6)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(200):
+                        netl.addGSO(Sl)
+                        netl(xl)
+                    e1.record()
+                    torch.cuda.synchronize(dev)
+                ts.sort()
+                lat["N%d" % Nl] = {"median_us": round(ts[150], 1), "mean_us": round(sum(ts) / len(ts), 1), "p90_us": round(ts[270], 1),
+                                   "device_back_to_back_us": round(e0.elapsed_time(e1) * 1e3 / 200, 1)}
+                del netl, xl, Sl
+            res["latency_b1"] = lat
+        except Exception as e:
+            res["latency_b1"] = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
         # (d) STRICT float32: every product on the float32 matrix cores (v_mfma_f32_32x32x2_f32, 157.3 TF peak) - no split
         # planes anywhere (CONV_SPLIT=0, HEAD_F16=0, GAT_SPLIT=0, GAT_MFMA=0).  The headline's f16x3 arithmetic is fp32-CLASS
@@ -753,6 +862,37 @@ def main():
             res["train_step"] = train_step_leg(dev)
         except Exception as e:          # (a reported extra: never takes the bench line down)
             res["train_step"] = {"error": repr(e)[:200]}
+        # (g) the extra legs once more, compact, INSIDE `roofline` - the object a driver keeps whole
+        if "roofline" in res:
+            def _g(d, *ks):
+                for k_ in ks:
+                    d = d.get(k_, {}) if isinstance(d, dict) else {}
+                return d if d != {} else None
+            c2k, c5k = _g(res, "c2", "kernels") or {}, _g(res, "c5", "kernels") or {}
+            g3 = res.get("roofline_gat", {})
+            res["roofline"]["legs"] = {
+                "c2": {"value": _g(res, "c2", "value"), "ms_per_step": _g(res, "c2", "ms_per_step"),
+                       "gat_us": _g(c2k, "gat_layer (one launch)", "avg_us"), "gat_frac": _g(c2k, "gat_layer (one launch)", "frac"),
+                       "gat_bound": _g(c2k, "gat_layer (one launch)", "bound")},
+                "c5": {"value": _g(res, "c5", "value"), "ms_per_step": _g(res, "c5", "ms_per_step"),
+                       "gat_graph_us_per_step": None if "gat_graph" not in c5k else round(1e3 * c5k["gat_graph"]["ms_per_step"], 1),
+                       "gat_graph_frac": _g(c5k, "gat_graph", "frac"), "gat_layer_us": _g(res, "c5", "gat_layer", "us"),
+                       "gat_layer_frac": _g(res, "c5", "gat_layer", "frac"),
+                       "gat_layer_bytes_per_agent_step": _g(res, "c5", "gat_layer", "bytes_per_agent_step"),
+                       "maps_in_memory": _g(res, "c5", "gat_layer", "maps_in_memory")},
+                "b1024": {"value": _g(res, "north_star_b1024", "value"), "gat_frac": _g(res, "north_star_b1024", "gat_kernel", "frac")},
+                "f32_strict": {"value": _g(res, "f32_strict", "value"), "frac": _g(res, "f32_strict", "roofline", "frac"),
+                               "kernel_us": _g(res, "f32_strict", "roofline", "avg_us")},
+                "gat_c3": {"us": g3.get("avg_us"), "bound": g3.get("bound"), "frac": g3.get("frac"),
+                           "frac_hbm": None if "algorithmic_gbs" not in g3 else round(g3["algorithmic_gbs"] / PEAK_HBM_GBS, 4),
+                           "frac_mfma": None if "algorithmic_tflops" not in g3 else round(g3["algorithmic_tflops"] / PEAK_16_TFLOPS, 4)},
+                "published_f32p4": {"value": _g(res, "published_f32p4", "value"),
+                                    "one_launch": _g(res, "published_f32p4", "graph_layer_one_launch")},
+                "published_f32p4_n100": {"value": _g(res, "published_f32p4_n100", "value"),
+                                         "one_launch": _g(res, "published_f32p4_n100", "graph_layer_one_launch")},
+                "latency_b1_us": {"N10": _g(res, "latency_b1", "N10", "median_us"), "N100": _g(res, "latency_b1", "N100", "median_us"),
+                                  "N10_device": _g(res, "latency_b1", "N10", "device_back_to_back_us"),
+                                  "N100_device": _g(res, "latency_b1", "N100", "device_back_to_back_us")}}
     # ---- the CPU baseline: the pinned oracle on this box's host cores, behind every GPU leg (nothing of it is inside a timed region)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         torch.cuda.synchronize(dev)

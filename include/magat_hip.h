@@ -442,6 +442,10 @@ typedef struct magat_conv_gemm_desc {
   float* out2;
   const float* in_scale2;
   int Cout2, ldc2, relu2;
+  /* (ABI 7) with the second layer: its rows ALSO as RNE bfloat16, [M][ldc2_bf16] (multiple of 4; NULL = not written) - the
+   * bf16-storage graph layer (BASELINE config 5) reads compressMLP's rows in that type: the cast pass between them is gone. */
+  void* out2_bf16;
+  int ldc2_bf16;
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 
@@ -529,6 +533,9 @@ typedef struct magat_encoder_desc {
                          form below option HEAD_SPLITK), 0 = this call's M.  A shard of a larger batch passes the GLOBAL agent
                          count here (distributed.sharded_forward does), so that every shard sums in the order the whole batch
                          would: shards then concatenate to the single-process result bit for bit whatever their size */
+  void* comp_bf16;    /* ABI 7: NULL, or [M][n_comp] bfloat16 rows that receive RNE-bf16(comp) as well: written by the epilogue that
+                         produces comp where it can (compressMLP in the head's launch), by a cast pass otherwise; after a range-guard
+                         re-run of the encoder they are rewritten from the float32 rows (same stream, predicated on the flag) */
 } magat_encoder_desc;
 /* Activation scales (ABI 3).  The split arithmetic carries a value as two f16 planes: exact for |v| <= 65504, but the SECOND
  * plane is a full 11-bit number only for |v| >~ 0.25 - a layer whose activations are all small (a small BatchNorm gamma: an

@@ -54,7 +54,8 @@ class ConvGemmDesc(ctypes.Structure):
                 ("in_scale", ctypes.c_void_p), ("acc_scale", ctypes.c_void_p), ("absmax", ctypes.c_void_p),
                 ("bf16_rows", ctypes.c_int),
                 ("wt2", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("out2", ctypes.c_void_p), ("in_scale2", ctypes.c_void_p),
-                ("Cout2", ctypes.c_int), ("ldc2", ctypes.c_int), ("relu2", ctypes.c_int)]
+                ("Cout2", ctypes.c_int), ("ldc2", ctypes.c_int), ("relu2", ctypes.c_int),
+                ("out2_bf16", ctypes.c_void_p), ("ldc2_bf16", ctypes.c_int)]
 
 
 class EncoderDesc(ctypes.Structure):
@@ -62,7 +63,7 @@ class EncoderDesc(ctypes.Structure):
                 ("n_feat", ctypes.c_int), ("n_comp", ctypes.c_int), ("pack", ctypes.c_void_p),
                 ("off", ctypes.c_int64 * 32), ("chain_off", ctypes.c_int64), ("chain3_off", ctypes.c_int64),
                 ("head16_off", ctypes.c_int64), ("comp16_off", ctypes.c_int64), ("scaled_off", ctypes.c_int64),
-                ("l1frag_off", ctypes.c_int64), ("form_agents", ctypes.c_int)]
+                ("l1frag_off", ctypes.c_int64), ("form_agents", ctypes.c_int), ("comp_bf16", ctypes.c_void_p)]
 
 
 class SimStepDesc(ctypes.Structure):

@@ -60,6 +60,8 @@ struct SplitParams {
   const u16* wt2;           // [2][Cout2][Cout] f16 planes of (weight * 2^e) followed by one float32 2^-e
   const float* bias2;
   float* out2;
+  u16* out2h;               // the same rows as RNE bf16 (null: not written), row stride ldc2h
+  int ldc2h;
   const float* in_scale2;   // power-of-two scale of `out` on its way into the planes (device float; null or 0 = 1)
   int ldc2, relu2;
 };
@@ -73,10 +75,11 @@ __device__ __forceinline__ u16 bf16_rne(float v) { return magat_bf16_rne(v); }
 __device__ __forceinline__ float bf16_f32(u16 h) { return magat_bf16_f32(h); }
 
 // two floats -> two RNE bf16 packed in one dword (lo = a, hi = b)
+// (through the compiler, not as inline asm: an asm statement that reads a register an MFMA has just written gets none of the
+//  wait states the hazard recognizer inserts for instructions it knows - round 6, gat_csr_fused.hip)
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2_t));
 }
 // (x, y) -> three packed bf16 pairs with x = x1+x2+x3, y likewise
 __device__ __forceinline__ void split_pair(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
@@ -793,7 +796,8 @@ __global__ __launch_bounds__(256, (TM == 1 && !FUSE2) ? 3 : 2) void conv_gemm_f1
   // on_tile(j, vv): called with the 16 finished values of row group 0's channel tile j (the fused second layer forms its
   // activation planes from them: accumulators and biases are then consumed ONCE, tile by tile)
   auto store_rows_t = [&](f32x16 (&ac)[TM][TN], const float scl, const f32x4 (&bb)[TN][4], const int relu, float* const obase,
-                          const int ldo, const long long otile, auto on_tile) __attribute__((always_inline)) {
+                          const int ldo, const long long otile, auto on_tile, u16* const obase16 = nullptr,
+                          const int ld16 = 0) __attribute__((always_inline)) {
     constexpr int CP = BN / 2, UP = CP / 4;             // channels / 16-byte units per pass and agent
     constexpr int JP = CP / 32;                          // channel tiles per pass
     // every wave is done reading the weight stages (FUSE2: an LDS-only barrier - __syncthreads() carries vmcnt(0) and would
@@ -829,7 +833,12 @@ __global__ __launch_bounds__(256, (TM == 1 && !FUSE2) ? 3 : 2) void conv_gemm_f1
           const int r = st * (64 / UP) + lane / UP, u = lane % UP;
           const f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * (CP * 4) + ((u ^ (r & (UP - 1))) * 16));
           const int m = mb + r;
-          if (m < p.M) *reinterpret_cast<f32x4*>(obase + magat_row_off(m, ldo, otile) + ps * CP + 4 * u) = v;
+          if (m < p.M) {
+            *reinterpret_cast<f32x4*>(obase + magat_row_off(m, ldo, otile) + ps * CP + 4 * u) = v;
+            if (obase16)      // (the bf16-storage graph layer's input rows: no cast pass behind this launch)
+              *reinterpret_cast<uint2*>(obase16 + (long long)m * ld16 + ps * CP + 4 * u) =
+                  uint2{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+          }
         }
       }
     }
@@ -940,7 +949,8 @@ __global__ __launch_bounds__(256, (TM == 1 && !FUSE2) ? 3 : 2) void conv_gemm_f1
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int c = 0; c < 4; ++c) bq2[j][q][c] = p.bias2 ? p.bias2[j * 32 + 4 * fh + 8 * q + c] : 0.f;
-    store_rows_t(acc, acc_scale2, bq2, p.relu2, p.out2, p.ldc2, (long long)MAGAT_TILE_ROWS * p.ldc2, [](int, const float (&)[16]) {});
+    store_rows_t(acc, acc_scale2, bq2, p.relu2, p.out2, p.ldc2, (long long)MAGAT_TILE_ROWS * p.ldc2, [](int, const float (&)[16]) {},
+                 p.out2h, p.ldc2h);
     return;
   }
   if (TN >= 2 && p.out_gl == 0 && vec && p.tepi) {
@@ -1077,6 +1087,8 @@ int magat_conv_gemm_bf16x6(const magat_conv_gemm_desc* d, hipStream_t st) {
   p.range_flag = reinterpret_cast<int*>(d->range_flag);
   p.wt2 = static_cast<const u16*>(d->wt2); p.bias2 = d->bias2; p.out2 = d->out2; p.in_scale2 = d->in_scale2;
   p.ldc2 = d->ldc2; p.relu2 = d->relu2;
+  p.out2h = static_cast<u16*>(d->out2_bf16); p.ldc2h = d->ldc2_bf16;
+  if (p.out2h && ((p.ldc2h & 3) || (reinterpret_cast<uintptr_t>(p.out2h) & 7))) return MAGAT_ERR_UNSUPPORTED;
   if (p.out_nt && !(d->in_fmt == 4 && d->out_fmt == 0 && d->out_gl == 0 && BN == 128 && magat_conv_direct_enabled()))
     return MAGAT_ERR_UNSUPPORTED;
   p.korder = 1;      // (direct kernel K walk: channel slab outer, taps inner; the tap-major order of round 1 re-fetched every chunk 3.6x)

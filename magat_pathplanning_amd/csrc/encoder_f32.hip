@@ -310,9 +310,8 @@ static int enc_split_mask(const magat_encoder_desc* d, int v) {
   return m;
 }
 
-// Split flavour of those layers: f16x3 (two f16 planes, three v_mfma_f32_32x32x16_f16 per product, in_fmt 4): the pack carries
-// the f16 weight planes for every layer of the mask (enc_split_mask).  (The bf16x6 flavour of round 1 was removed in round 5.)
-static bool enc_use_f16(const magat_encoder_desc* d, int l) { return d->off[24 + 2 * l] > 0 && d->off[25 + 2 * l] > 0; }
+// (Split flavour of those layers: f16x3 - two f16 planes, three v_mfma_f32_32x32x16_f16 per product, in_fmt 4; a layer is in the
+//  mask only when the pack carries its f16 weight planes.)
 
 // floats per agent of one rotating activation buffer
 static size_t enc_buf_floats_per_agent(const magat_encoder_desc* d) {
@@ -376,13 +375,14 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
   const int nblocks = d->variant == 0 ? 3 : 2;
   const bool rerun = run_if != nullptr;
   auto tagof = [&](int t) { return rerun ? MAGAT_TAG_UNTAGGED : t; };     // the re-run is timed as ONE span by the caller
+  // (ABI 7) compressMLP's rows as bf16 too; the guard's re-run and the calibration pass leave them to their callers
+  unsigned short* const comp16 = (rerun || absmax) ? nullptr : static_cast<unsigned short*>(d->comp_bf16);
   hipStream_t st = static_cast<hipStream_t>(stream);
 
   // Granule-major activation tiles ([C/4][128 agents][4], magat_hip.h in_gl/out_gl) between the layers when every
   // BasicBlock conv runs on the f16x3 direct kernel: its one-lane-per-agent fragment loads and epilogue stores are then
   // 512-byte runs.  The last conv2 writes row-major tiles again for the pooled head (fp32 MFMA kernel).
-  bool gl = split == (1 << nblocks) - 1 && magat_conv_direct_enabled();
-  for (int l = 0; l < nblocks; ++l) gl = gl && enc_use_f16(d, l);
+  const bool gl = split == (1 << nblocks) - 1 && magat_conv_direct_enabled();      // (mask bit l set <=> layer l has its f16 planes)
   // ... and, when the pack carries the K-permuted weight copies (off[30]), as f16 PLANE granules (in_gl/out_gl = 2): every
   // activation is split into its two half-precision planes once, by the epilogue that produces it, instead of once per
   // tap by every consumer's loader.  Option CONV_PCHAIN=0 keeps float32 granules.
@@ -391,11 +391,6 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
   // float offset of the permuted copy behind an f16 weight block of cout x ktot weights (two planes + one scale float,
   // padded to 4 floats)
   auto permuted = [&](int cout, int ktot) { return lay == 2 ? (int64_t)(((int64_t)cout * ktot + 1 + 3) & ~3LL) : 0; };
-  // "f16 + MX correction" chain (in_gl / out_gl = 3, third weight copy, off[31]): from block 0's output on, the second
-  // activation plane carries e4m3(h1) | e4m3(h2 * 2^11) and the consumers issue two f16 MFMAs + one block-scaled fp8 MFMA per
-  // slab instead of six f16 ones.  Block 0's own inputs (fused stem + layer1.conv1 output) stay f16 planes.
-  // OPT-IN (option CONV_MX, default 0): the fp8 correction planes are narrower arithmetic than the reference's fp32.
-  const bool mx = false;      // (the f16 + MX-correction form of rounds 1-4 was removed in round 5: narrower than fp32 and slower than the default)
   // the guard's re-run: every float32 layer behind the stem goes into ONE predicated launch (magat_conv_gemm_chain_f32)
   const bool chained = rerun;
   for (int m0 = 0; m0 < M; m0 += mc) {
@@ -411,7 +406,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // Option L1_FUSED=0 keeps the two launches.
     const bool fused1 = lay == 2 && magat_layer1_fused_lds(W) != 0 && magat_opt(MAGAT_OPT_L1_FUSED) != 0;
     // the whole chain in two launches (fused stem + the merged chain kernel): the path the activation scales are folded for
-    const bool full_path = fused1 && !mx && d->chain_off > 0 && Ho == 6 && Wo == 6 && nblocks == 3 && d->chain3_off > 0 &&
+    const bool full_path = fused1 && d->chain_off > 0 && Ho == 6 && Wo == 6 && nblocks == 3 && d->chain3_off > 0 &&
                            magat_opt(MAGAT_OPT_BLOCK_FUSED) >= 2;
     const float* sp = (full_path && d->scaled_off > 0) ? pk + d->scaled_off : nullptr;      // activation-scale block
     int rc;
@@ -457,7 +452,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
                             head_gl ? 1 : 0);
       if (rc != MAGAT_OK) return rc;
       cur = 2; hin = Ho; win = Wo; lstart = 3; pooled_in = true;
-    } else if (fused1 && !mx && d->chain_off > 0 && Ho == 6 && Wo == 6 && nblocks >= 2 && magat_opt(MAGAT_OPT_BLOCK_FUSED)) {
+    } else if (fused1 && d->chain_off > 0 && Ho == 6 && Wo == 6 && nblocks >= 2 && magat_opt(MAGAT_OPT_BLOCK_FUSED)) {
       rc = magat_block_chain(buf[1], buf[0], buf[2], nblocks == 2 ? 0 : 2, pixs(64), tiles(Ho * Wo, 64), pk + d->chain_off,
                              pk + d->off[5], pk + d->off[7], pk + d->off[9], mm, reinterpret_cast<int*>(range_flag), st);
       if (rc != MAGAT_OK) return rc;
@@ -488,8 +483,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
         g.in_fmt = 4; g.wt = pk + d->off[24 + 2 * l];
       }
       g.in_gl = g.out_gl = lay;
-      if (mx && l >= 1) { g.in_gl = g.out_gl = 3; g.wt += 2 * permuted(s.cout, 9 * s.cin); }
-      else if (lay == 2) g.wt += permuted(s.cout, 9 * s.cin);
+      if (lay == 2) g.wt += permuted(s.cout, 9 * s.cin);
       if (!(fused1 && l == 0)) {
         rc = run_or_chain(g);
         if (rc != MAGAT_OK) return rc;
@@ -511,9 +505,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
         h.in_fmt = 4; h.wt = pk + d->off[25 + 2 * l];
       }
       h.in_gl = lay; h.out_gl = l + 1 < nblocks ? lay : 0;
-      if (mx && l + 1 < nblocks) h.out_gl = 3;
-      if (mx && l >= 1) { h.in_gl = 3; h.wt += 2 * permuted(s.cout, 9 * s.cout + s.cin); }
-      else if (lay == 2) h.wt += permuted(s.cout, 9 * s.cout + s.cin);
+      if (lay == 2) h.wt += permuted(s.cout, 9 * s.cout + s.cin);
       if (fused1 && l == 0) {    // the residual branch reads the stem's stride-2 pixels, stored as an Ho x Wo map
         h.in2_tile_stride = tiles(hout * wout, s.cin); h.W2 = wout; h.stride2 = 1;
       }
@@ -544,6 +536,7 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     const int cells = (hin / 2) * (win / 2);
     const int split_max = magat_opt(MAGAT_OPT_HEAD_SPLITK);
     bool compress_done = false;      // compressMLP rode in the head's epilogue
+    bool comp16_done = false;        // ... and wrote the bf16 rows (desc.comp_bf16) too
     if (!absmax && !chained && cells > 1 && Mform <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
         (size_t)cells * d->n_feat <= enc_buf_floats_per_agent(d)) {     // the partials must fit one map buffer
       float* part = buf[(cur + 1) % 3];                 // [cells][mm][n_feat]
@@ -580,8 +573,12 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
           f.wt2 = pk + d->comp16_off; f.bias2 = pk + d->off[17]; f.out2 = comp + (size_t)m0 * ldcomp;
           f.Cout2 = d->n_comp; f.ldc2 = ldcomp; f.relu2 = 1;
           f.in_scale2 = d->scaled_off > 0 ? pk + d->scaled_off + 1350 : nullptr;
+          if (comp16) {      // (ABI 7: the bf16 rows of the bf16-storage graph layer from the same epilogue)
+            f.out2_bf16 = comp16 + (size_t)m0 * d->n_comp;
+            f.ldc2_bf16 = d->n_comp;
+          }
           rc = magat_conv_gemm_f32(&f, stream);
-          if (rc == MAGAT_OK) compress_done = true;
+          if (rc == MAGAT_OK) { compress_done = true; comp16_done = comp16 != nullptr; }
           else if (rc != MAGAT_ERR_UNSUPPORTED) return rc;
         }
       }
@@ -612,6 +609,11 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
         rc = enc_linear(feat + (size_t)m0 * ldfeat, ldfeat, pk + d->off[16], pk + d->off[17], comp + (size_t)m0 * ldcomp,
                         ldcomp, mm, d->n_comp, d->n_feat, 1, tagof(MAGAT_TAG_COMPRESS), run_if, stream, absmax ? absmax + 8 : nullptr);
       }
+      if (rc != MAGAT_OK) return rc;
+    }
+    if (comp16 && !comp16_done && !chained && d->n_comp > 0 && (d->n_comp & 3) == 0) {
+      // comp came from a launch of its own (small batches, float32 forms): one cast pass over this chunk's rows
+      rc = magat_cast_rows(comp + (size_t)m0 * ldcomp, comp16 + (size_t)m0 * d->n_comp, 1, mm, d->n_comp, ldcomp, d->n_comp, stream);
       if (rc != MAGAT_OK) return rc;
     }
     if (nchain > 0) {
@@ -694,6 +696,8 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
         if (rc != MAGAT_OK) return rc;
       }
     }
+    if (d->comp_bf16 && d->n_comp > 0 && (d->n_comp & 3) == 0)
+      return magat_cast_rows(comp, d->comp_bf16, 1, M, d->n_comp, ldcomp, d->n_comp, stream);
     return MAGAT_OK;
   }
 
@@ -712,6 +716,9 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
     hipLaunchKernelGGL(guard_count_kernel, dim3(1), dim3(1), 0, st, status);
     if (hipGetLastError() != hipSuccess) rc = MAGAT_ERR_LAUNCH;
   }
+  // the bf16 rows follow a re-run (status[2] = this forward's flag by now): a launch that returns at once otherwise
+  if (rc == MAGAT_OK && d->comp_bf16 && d->n_comp > 0 && (d->n_comp & 3) == 0)
+    rc = magat_cast_rows_if(comp, d->comp_bf16, 1, M, d->n_comp, ldcomp, d->n_comp, stream, status + 2);
   magat_prof_end(pid, st);
   return rc;
 }

@@ -1006,7 +1006,8 @@ int csr_forward(const ST* X, const int* rowptr, const int* colidx, long long nnz
 // float32 <-> bf16 (RNE) row blocks around the bf16-storage layer: src [M][ld_src] -> dst [M][ld_dst], `width` columns
 namespace {
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, long long M, int width,
-                                     int ld_src, int ld_dst) {
+                                     int ld_src, int ld_dst, const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;      // (predicated form: behind the encoder's range-guard re-run)
   const int wq = width / 4;
   const long long total = M * wq;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -1036,18 +1037,27 @@ __global__ void cast_bf16_f32_kernel(const u16* __restrict__ src, float* __restr
 }
 }  // namespace
 
+int magat_cast_rows_if(const void* src, void* dst, int to_bf16, long long M, int width, int ld_src, int ld_dst, void* stream,
+                       const int32_t* run_if);
 extern "C" int magat_cast_rows(const void* src, void* dst, int to_bf16, long long M, int width, int ld_src, int ld_dst,
                                void* stream) {
+  return magat_cast_rows_if(src, dst, to_bf16, M, width, ld_src, ld_dst, stream, nullptr);
+}
+// run_if (float32 -> bf16 only): device flag, the launch returns at once when it is zero
+int magat_cast_rows_if(const void* src, void* dst, int to_bf16, long long M, int width, int ld_src, int ld_dst, void* stream,
+                       const int32_t* run_if) {
   if (!src || !dst) return MAGAT_ERR_NULL;
+  if (run_if && !to_bf16) return MAGAT_ERR_UNSUPPORTED;
   if (M <= 0 || width <= 0 || (width & 3) || (ld_src & 3) || (ld_dst & 3) || ld_src < width || ld_dst < width)
     return MAGAT_ERR_BAD_SHAPE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   long long blocks = (M * (width / 4) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  const int pid = magat_prof_begin(MAGAT_TAG_GAT_CAST, st);
+  const int pid = magat_prof_begin(run_if ? MAGAT_TAG_UNTAGGED : MAGAT_TAG_GAT_CAST, st);      // (predicated: inside the guard's span)
   if (to_bf16)
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float*>(src),
-                       static_cast<u16*>(dst), M, width, ld_src, ld_dst);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)(run_if && blocks > 512 ? 512 : blocks)), dim3(256), 0, st,
+                       static_cast<const float*>(src), static_cast<u16*>(dst), M, width, ld_src, ld_dst,
+                       reinterpret_cast<const int*>(run_if));
   else
     hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const u16*>(src),
                        static_cast<float*>(dst), M, width, ld_src, ld_dst);
@@ -1319,37 +1329,28 @@ __global__ __launch_bounds__(256) void gso_totals_kernel(const int* __restrict__
 // arrays are STAGED in LDS (the bit matrix no longer lives there) and leave as whole contiguous runs: written edge by edge,
 // the scattered 4-byte stores alone took 70 us.  An instance with more edges than the stage holds writes and sorts through
 // global memory instead (reads at agent scope: the entries come from other threads of the workgroup).
-// a column's list in global memory (keys = source rows, values = CSR positions; the fallback of an instance whose edges do
-// not fit the LDS stage): selection sort in place.  The entries were written by other threads of the workgroup - every
-// access at agent scope (a plain load may be served by a stale line of this CU's L1)
-__device__ __forceinline__ void gso_sort_global(int* ks, int* vs, int n) {
-  auto ld = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  auto st = [](int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  for (int a = 0; a + 1 < n; ++a) {
-    const int ak = ld(ks + a);
-    int best = a, bk = ak;
-    for (int c = a + 1; c < n; ++c) {
-      const int ck = ld(ks + c);
-      if (ck < bk) { bk = ck; best = c; }
-    }
-    if (best != a) {
-      const int av = ld(vs + a), bv = ld(vs + best);
-      st(ks + a, bk); st(vs + a, bv); st(ks + best, ak); st(vs + best, av);
-    }
-  }
-}
+// Round 6: the cost per column is BOUNDED whatever the topology.  Staged path: a thread ranks its column's list
+// itself only up to GSO_SELF_SORT entries; longer lists (hub columns) are ranked by the whole workgroup, one entry per thread
+// (at most stage / 1024 = 12 steps of <= 1024 LDS reads each).  An instance with more edges than the stage holds no longer
+// sorts anything: the stage region holds the TRANSPOSED bit matrix instead (LDS atomic ORs, N x N bits = 128 KB at N = 1024),
+// and an in-edge's slot is its rank = the set bits of its column below its source row (<= 32 word popcounts) - the arrays are
+// written once, in their final order, without a global-memory atomic or a read-back (was: an O(deg^2) selection sort of
+// agent-scope loads per column, ~500 k L2 round trips per thread on a dense N = 1000 instance).
+constexpr int GSO_SELF_SORT = 32;
 constexpr int GSO_STAGE_EDGES = 12 * 1024;      // edges of one instance the LDS stage holds (3 x 4 bytes each: 144 KB; < 2^14)
 __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long long* __restrict__ masks,
                                                              int* __restrict__ inst_tot, int* __restrict__ rowptr,
                                                              int* colidx, int* __restrict__ cscptr, int* cscsrc, int* cscpos,
                                                              long long cap, long long* __restrict__ nnz_out, int B, int N,
-                                                             int W64) {
+                                                             int W64, int stage_edges) {
   extern __shared__ __align__(16) int gsi[];
   int* ccnt = gsi;                    // [N] column degrees, then the fill cursors
   int* coff = ccnt + 1024;            // [N] exclusive column offsets (local)
-  int* stage = coff + 1024;           // [3][GSO_STAGE_EDGES]: column of CSR position q | in-edge of slot k as (source row << 14 |
+  int* stage = coff + 1024;           // [3][stage_edges]: column of CSR position q | in-edge of slot k as (source row << 14 |
                                       // local CSR position), in arrival order | the same, every column's list sorted
+                                      // (stage_edges = min(GSO_STAGE_EDGES, N * N): small graphs ask for little LDS)
   __shared__ int part[17];
+  __shared__ int nbig, big[GSO_STAGE_EDGES / GSO_SELF_SORT];      // columns with more than GSO_SELF_SORT in-edges (staged path)
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // absolute offset of this instance = edges of all earlier instances (inst_tot was accumulated by the mask pass)
   int before = 0;
@@ -1365,6 +1366,7 @@ __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long
     for (int w = 0; w < GSO_W64_MAX; ++w) mrow[w] = (t < N && w < W64) ? src[w] : 0ull;
   }
   ccnt[t] = 0;
+  if (t == 0) nbig = 0;
   __syncthreads();
   int base = 0;
   for (int w = 0; w < 16; ++w) base += part[w];
@@ -1418,11 +1420,11 @@ __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long
     cp[N] = base + total;
   }
   if (b == B - 1 && t == 0 && nnz_out) *nnz_out = (long long)base + total;
-  const bool staged = total <= GSO_STAGE_EDGES;
+  const bool staged = total <= stage_edges;
   if (staged) {
     int* const scol = stage;
-    int* const sin = stage + GSO_STAGE_EDGES;
-    int* const sout = stage + 2 * GSO_STAGE_EDGES;
+    int* const sin = stage + stage_edges;
+    int* const sout = stage + 2 * stage_edges;
     // a thread per row over its edges in ascending j: the column index of every CSR position, and the in-edge into the next
     // free slot of column j's list
     {
@@ -1442,14 +1444,29 @@ __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long
     }
     __syncthreads();
     // a thread per column: its list ordered by source row - every entry goes to the slot its rank names (the lists are short:
-    // 3-5 entries at config 5)
-    if (t < N)
-      for (int e = 0; e < cdeg; ++e) {
-        const int w = sin[cex + e];
-        int rank = 0;
-        for (int f = 0; f < cdeg; ++f) rank += sin[cex + f] < w ? 1 : 0;
-        sout[cex + rank] = w;
+    // 3-5 entries at config 5); a hub column is left to the whole workgroup
+    if (t < N) {
+      if (cdeg <= GSO_SELF_SORT) {
+        for (int e = 0; e < cdeg; ++e) {
+          const int w = sin[cex + e];
+          int rank = 0;
+          for (int f = 0; f < cdeg; ++f) rank += sin[cex + f] < w ? 1 : 0;
+          sout[cex + rank] = w;
+        }
+      } else {
+        big[atomicAdd(&nbig, 1)] = t;
       }
+    }
+    __syncthreads();
+    for (int q = 0, nb = nbig; q < nb; ++q) {      // (the list's order is whatever the atomics made it: the result does not know)
+      const int j = big[q], cx = coff[j], cd = ccnt[j];
+      for (int e = t; e < cd; e += 1024) {
+        const int w = sin[cx + e];
+        int rank = 0;
+        for (int f = 0; f < cd; ++f) rank += sin[cx + f] < w ? 1 : 0;
+        sout[cx + rank] = w;
+      }
+    }
     __syncthreads();
     // the stage leaves as three contiguous runs
     const long long lim = cap - base < total ? cap - base : total;
@@ -1460,7 +1477,21 @@ __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long
       cscpos[base + q] = base + (w & 16383);
     }
   } else {
-    // more edges than the stage holds: written edge by edge to global memory, the lists sorted there
+    // more edges than the stage holds: the stage region takes the transposed bit matrix, an in-edge's slot is its rank
+    const int W32 = (N + 31) >> 5;
+    unsigned* const colm = reinterpret_cast<unsigned*>(stage);      // [N][W32] bit i of column j's words <=> edge (i -> j)
+    for (int q = t; q < N * W32; q += 1024) colm[q] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < GSO_W64_MAX; ++w) {
+      unsigned long long m = mrow[w];
+      while (m) {
+        const int bit = __builtin_ctzll(m);
+        m &= m - 1;
+        atomicOr(&colm[(w * 64 + bit) * W32 + (t >> 5)], 1u << (t & 31));
+      }
+    }
+    __syncthreads();
     {
       int pos = base + rex;
 #pragma unroll
@@ -1471,7 +1502,10 @@ __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long
           m &= m - 1;
           const int j = w * 64 + bit;
           if (pos < cap) colidx[pos] = j;
-          const int k = base + coff[j] + atomicAdd(&ccnt[j], 1);
+          const unsigned* cw = colm + j * W32;
+          int rank = __popc(cw[t >> 5] & ((1u << (t & 31)) - 1u));
+          for (int v = 0; v < (t >> 5); ++v) rank += __popc(cw[v]);
+          const long long k = (long long)base + coff[j] + rank;
           if (k < cap) {
             cscsrc[k] = t;
             cscpos[k] = pos;
@@ -1480,9 +1514,6 @@ __global__ __launch_bounds__(1024) void gso_structure_kernel(const unsigned long
         }
       }
     }
-    __threadfence();
-    __syncthreads();
-    if (t < N && cdeg > 1 && (long long)base + cex + cdeg <= cap) gso_sort_global(cscsrc + base + cex, cscpos + base + cex, cdeg);
   }
   // leave inst_tot clear for the next build (every workgroup has read what it needs only after ALL of them pass this
   // point is not guaranteed - so the clearing is done by the NEXT build's memset, see the host code)
@@ -1509,7 +1540,13 @@ extern "C" int magat_gso_csr_build_phase(void* S, int s_is_f64, int scrub_nan, i
   if (!need) return MAGAT_ERR_UNSUPPORTED;                      // N > 1024: magat_gso_row_degrees / magat_gso_fill_csr
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < need) return MAGAT_ERR_WORKSPACE;
   const int W64 = (N + 63) / 64;
-  const size_t lds = (size_t)(2 * 1024 + 3 * GSO_STAGE_EDGES) * sizeof(int);      // column counters / offsets + the edge stage
+  // column counters / offsets + the edge stage, sized by the graph (a small N asks for little LDS: several instances per CU);
+  // the stage must also hold the transposed bit matrix of an instance with more edges than it stages (N > 110 only)
+  const long long nn = (long long)N * N;
+  const int stage_edges = (int)(nn < GSO_STAGE_EDGES ? nn : GSO_STAGE_EDGES);
+  size_t stage_ints = (size_t)3 * stage_edges;
+  if (nn > GSO_STAGE_EDGES && (size_t)N * ((N + 31) / 32) > stage_ints) stage_ints = (size_t)N * ((N + 31) / 32);
+  const size_t lds = (size_t)(2 * 1024 + stage_ints) * sizeof(int);
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned long long* masks = static_cast<unsigned long long*>(workspace);
   int* inst_tot = reinterpret_cast<int*>(static_cast<char*>(workspace) + magat_align_up((size_t)B * N * W64 * 8, 256));
@@ -1533,7 +1570,7 @@ extern "C" int magat_gso_csr_build_phase(void* S, int s_is_f64, int scrub_nan, i
     if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&gso_structure_kernel), MAGAT_LDS_GSO_STRUCT, lds) != MAGAT_OK)
       return MAGAT_ERR_LAUNCH;
     hipLaunchKernelGGL(gso_structure_kernel, dim3(B), dim3(1024), lds, st, masks, inst_tot, rowptr, colidx, cscptr, cscsrc,
-                       cscpos, cap, nnz_dev, B, N, W64);
+                       cscpos, cap, nnz_dev, B, N, W64, stage_edges);
   }
   magat_prof_end(pid, st);
   return magat_check_launch();

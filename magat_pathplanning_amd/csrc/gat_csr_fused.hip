@@ -634,7 +634,7 @@ int magat_gat_csr_fused_forward(const uint16_t* X, const int* rowptr, const int*
   p.dbg = g_fused_dbg;
 #endif
   {
-    const int pid = magat_prof_begin(MAGAT_TAG_GSO_CSR, st);
+    const int pid = magat_prof_begin(MAGAT_TAG_GAT_GRAPH, st);      // (a launch of the layer: counted with its graph kernels)
     hipLaunchKernelGGL(csr_rank_kernel, dim3(B, 2), dim3(1024), 0, st, rowptr, cscptr, order, B, N);
     magat_prof_end(pid, st);
     if (magat_check_launch() != MAGAT_OK) return MAGAT_ERR_LAUNCH;

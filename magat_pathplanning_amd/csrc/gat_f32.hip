@@ -994,7 +994,7 @@ int magat_gat_maps_gemm(const float* X, const float* packed, float* Z, int M, in
                         long long ntile_stride, int32_t* status, int force_f32) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!force_f32 && magat_opt(MAGAT_OPT_GAT_SPLIT) && NC % 32 == 0 && G % 32 == 0) {
-    const int use_f16 = 1;      // (f16x3; the bf16x6 flavour was removed in round 5 - its weight planes still sit in the pack)
+    const int use_f16 = 1;      // (f16x3; the bf16x6 flavour was removed in round 5; the pack's bf16 plane 0 feeds the bf16-storage maps GEMM)
     const bool guard = status && use_f16 && magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
     magat_conv_gemm_desc d = {};
     d.in = X;
@@ -1408,7 +1408,7 @@ extern "C" int magat_gso_prepare(void* S, int s_is_f64, size_t count, int scrub_
   return magat_check_launch();
 }
 
-extern "C" int magat_abi_version(void) { return 6; }
+extern "C" int magat_abi_version(void) { return 7; }
 
 extern "C" const char* magat_error_string(int code) {
   switch (code) {

@@ -114,6 +114,8 @@ int magat_gat_csr_fused_forward(const uint16_t* X, const int* rowptr, const int*
                                 const int* cscpos, long long nnz, const void* frags, const float* bias, void* Y, int ldy,
                                 int y_f32, float* att /* workspace, [nnz][P] */, float* att_opt /* [P][nnz] or null */, int* order, int B, int N,
                                 int P, hipStream_t st);
+int magat_cast_rows_if(const void* src, void* dst, int to_bf16, long long M, int width, int ld_src, int ld_dst, void* stream,
+                       const int32_t* run_if);      // gat_csr_f32.hip: magat_cast_rows, predicated on a device flag (null = always)
 // one-launch KeyQuery layer for small graphs and narrow features (gat_small.hip: N <= 32, G = F in {32, 64}, K = 2 | 3)
 int magat_gat_small_supported(int N, int G, int F, int K, int mode);
 int magat_gat_small_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre, const float* Hs,

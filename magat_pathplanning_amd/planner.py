@@ -465,9 +465,17 @@ class DecentralPlannerGATNet(nn.Module):
         # a shard of a larger batch chooses its batch-size-dependent kernel forms on the GLOBAL agent count (set by
         # distributed.sharded_forward): the shards then concatenate to the single-process result bit for bit
         rt.desc.form_agents = max(0, int(getattr(self, "form_agents", 0) or 0))
+        # bf16 storage inside the graph layer: compressMLP's rows leave the encoder as bf16 too (ABI 7: from the epilogue that
+        # produces them - no cast pass between the two layers)
+        comp16 = None
+        if getattr(self.GFL[0], "storage_dtype", None) == torch.bfloat16 and G % 4 == 0 and rt.desc.n_comp == G:
+            comp16 = self._buf16("comp16", (M, G), dev)
+        rt.desc.comp_bf16 = comp16.data_ptr() if comp16 is not None else None
+        rt.comp16 = comp16
         nat.check(lib.magat_encoder_forward_f32(ctypes.byref(rt.desc), nat.ptr(x), nat.ptr(feat), nfm,
                                                 nat.ptr(comp), G, nat.ptr(rt.ws), rt.ws.numel(), M, stream),
                   "magat_encoder_forward_f32")
+        rt.desc.comp_bf16 = None          # (the pointer belongs to this call's buffers)
         return feat, comp
 
     def _run_actions(self, rt, feat, comp, gat, gat_rows, M, dev, stream):
@@ -558,8 +566,10 @@ class DecentralPlannerGATNet(nn.Module):
             elif layer.storage_dtype == torch.bfloat16:
                 # bf16 storage inside the GAT layer (config.gat_storage='bf16', BASELINE config 5): the layer reads
                 # and writes bf16 rows; the CNN/MLP GEMMs around it stay fp32
-                comp16 = self._buf16("comp16", (M, G), dev)
-                nat.check(lib.magat_cast_rows(nat.ptr(comp), nat.ptr(comp16), 1, M, G, G, G, stream), "magat_cast_rows")
+                comp16 = getattr(rt, "comp16", None)
+                if comp16 is None or comp16.shape[0] != M:      # (an encoder that does not write the bf16 rows itself)
+                    comp16 = self._buf16("comp16", (M, G), dev)
+                    nat.check(lib.magat_cast_rows(nat.ptr(comp), nat.ptr(comp16), 1, M, G, G, G, stream), "magat_cast_rows")
                 # the layer's bf16 rows go to the action head as they are when it runs as streamed dot products (at most 8
                 # outputs, option SKINNY: its loader widens them); otherwise the layer's last kernel stores them widened
                 # (device-built CSR + CSC structure), or a cast pass follows

@@ -38,7 +38,7 @@ def test_fused_layer_against_the_oracle(gpu_device, tag_counts, N, P):
     with torch.no_grad(), tag_counts() as tc:
         y = layer(x.to(gpu_device)).cpu()
     forms = _forms(nat)
-    assert forms["csr_fused"] == 1 and tc["gat_maps_gemm"] == 0 and tc["gat_graph"] == 2, (forms, tc.counts)
+    assert forms["csr_fused"] == 1 and tc["gat_maps_gemm"] == 0 and tc["gat_graph"] == 3, (forms, tc.counts)
     assert y.dtype == torch.float32 and tuple(y.shape) == (B, P * G5, N)
     scale = float(y_ref.abs().max())
     e_emul = float((y - y_emul).abs().max())
@@ -141,3 +141,37 @@ def test_fused_model_matches_split_model_at_config5_shape(gpu_device, libopt):
         print("fused=%d: max|dlogit| %.3e of scale %.3g, argmax agreement %.4f" % (fused, err, scale, agree))
         assert err <= 2e-2 * scale and agree >= 0.97
     assert float((got[1] - got[0]).abs().max()) <= 2e-2 * scale
+
+
+@pytest.mark.parametrize("B,N,drift", [(2, 200, False), (40, 1000, False), (3, 200, True)])
+def test_bf16_rows_of_compressmlp_leave_the_encoder(gpu_device, tag_counts, B, N, drift):
+    """ABI 7 (last clause): with bf16 storage in the graph layer compressMLP's rows come out of the encoder
+    as bf16 as well - from the epilogue that produces them when compressMLP rides in the head's launch (40 000 agents), by a
+    cast pass inside the encoder call otherwise - and there is no cast launch of the planner's own in front of the layer.  The
+    bf16 rows are RNE(comp) bit for bit, also behind a range-guard re-run (inputs driven 3000x beyond the calibration)."""
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    cfg = make_config(num_agents=N, nGraphFilterTaps=2, nAttentionHeads=4, gat_storage="bf16", device=str(gpu_device))
+    torch.manual_seed(3)
+    net = DecentralPlannerGATNet(cfg).to(gpu_device).eval()
+    x = fov_states(B, N, seed=5).to(gpu_device)
+    S = comm_gso(B, N, int(6 * N ** 0.5), seed=6).to(gpu_device)
+    with torch.no_grad():
+        net.addGSO(S.clone())
+        net(x)
+        if drift:
+            x = x * 3000.0
+        with tag_counts() as tc:
+            net.addGSO(S.clone())
+            out = net(x)
+    torch.cuda.synchronize()
+    comp, comp16 = net._rt.buffers["comp"], net._rt.buffers["comp16"]
+    assert comp16.dtype == torch.bfloat16 and tuple(comp16.shape) == (B * N, 128)
+    assert torch.equal(comp16, comp.to(torch.bfloat16))
+    assert bool(torch.isfinite(out).all()) and float(comp.abs().max()) > 0
+    if drift:
+        assert net.range_status()["encoder_rerun"]
+    if B * N >= 32768:
+        assert tc["gat_cast"] == 0 and tc["compressMLP"] == 0, tc.counts          # one launch: head + compressMLP + the bf16 rows
+    else:
+        assert tc["gat_cast"] >= 1, tc.counts                                     # the cast pass inside the encoder call
