@@ -630,7 +630,8 @@ int magat_mfma_sustained_f16_ex(double* tflops, double* clock_mhz, double* per_c
 #define MAGAT_FORM_HEAD_COMPRESS 6 /* compressMLP computed in the head GEMM's epilogue (one launch for both) */
 #define MAGAT_FORM_GUARD_ONE 7    /* range guard of the encoder as one predicated launch */
 #define MAGAT_FORM_CSR_FUSED 8    /* bf16-storage CSR layer with the maps inside the graph kernels (gat_csr_fused.hip) */
-#define MAGAT_FORMS 9
+#define MAGAT_FORM_GAT_MID 9      /* one-launch graph layer for G = F in {32, 64} on 33 .. 128 agents (gat_mid.hip) */
+#define MAGAT_FORMS 10
 long long magat_form_count(int id);
 int magat_form_reset(void);
 

@@ -1208,7 +1208,8 @@ extern "C" size_t magat_gat_workspace_bytes(int B, int N, int G, int F, int K, i
 static bool gat_one_launch(int N, int G, int F, int K, int mode, int concat) {
   (void)concat;
   return magat_opt(MAGAT_OPT_GAT_MFMA) && magat_opt(MAGAT_OPT_GAT_SPLIT) &&
-         (magat_gat_mfma_supported(N, G, F, K, mode) || magat_gat_small_supported(N, G, F, K, mode));
+         (magat_gat_mfma_supported(N, G, F, K, mode) || magat_gat_small_supported(N, G, F, K, mode) ||
+          magat_gat_mid_supported(N, G, F, K, mode));
 }
 
 extern "C" int magat_gat_one_launch_supported(int N, int G, int F, int K, int mode, int concat) {
@@ -1272,8 +1273,12 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
         ? magat_gat_mfma_forward(X, G, S, s_is_f64, masks, frag, bias, Y, ldy, B, N, K, P, concat,
                                  guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4), mode,
                                  mode == MAGAT_MODE_KEYQUERY ? nullptr : frag + (size_t)(P * G + P * K * F) * G)
-        : magat_gat_small_forward(X, G, S, s_is_f64, masks, packed + magat_gat_f16_block_offset(L.NC, G), L.NC, bias, Y, ldy, B,
-                                  N, G, K, P, concat, guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4));
+        : N <= 32
+        ? magat_gat_small_forward(X, G, S, s_is_f64, masks, packed + magat_gat_f16_block_offset(L.NC, G), L.NC, bias, Y, ldy, B,
+                                  N, G, K, P, concat, guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4))
+        // (32 / 64 features on 33 .. 128 agents: gat_mid.hip, a workgroup of ceil(N / 32) waves per instance - round 6)
+        : magat_gat_mid_forward(X, G, S, s_is_f64, packed + magat_gat_f16_block_offset(L.NC, G), L.NC, bias, Y, ldy, B, N, G, K, P,
+                                concat, guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4));
     if (rc != MAGAT_OK || !guard) return rc;
     rerun_only = true;
     p.run_if = status;

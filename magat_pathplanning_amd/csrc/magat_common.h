@@ -71,7 +71,7 @@ enum MagatOpt {
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)
-#define MAGAT_LDS_SLOTS 96
+#define MAGAT_LDS_SLOTS 128
 int magat_ensure_dyn_lds(const void* func, int slot, size_t bytes);
 enum MagatLdsSlot {
   MAGAT_LDS_GAT16, MAGAT_LDS_GAT32, MAGAT_LDS_GAT64, MAGAT_LDS_GAT128, MAGAT_LDS_GAT256, MAGAT_LDS_L1FUSED,
@@ -87,7 +87,9 @@ enum MagatLdsSlot {
   MAGAT_LDS_GATS_END = MAGAT_LDS_GATS_0 + 8,
   MAGAT_LDS_CSR_FUSED_A,  // gat_csr_fused.hip: score kernel, P = 1 | 2 | 4
   MAGAT_LDS_CSR_FUSED_B = MAGAT_LDS_CSR_FUSED_A + 3,   // hop + tap kernel, 1 | 2 heads per workgroup
-  MAGAT_LDS_CSR_FUSED_END = MAGAT_LDS_CSR_FUSED_B + 2
+  MAGAT_LDS_CSR_FUSED_END = MAGAT_LDS_CSR_FUSED_B + 2,
+  MAGAT_LDS_GATD_0 = MAGAT_LDS_CSR_FUSED_END,      // gat_mid.hip: 24 slots (width x taps x row tiles x merge)
+  MAGAT_LDS_GATD_END = MAGAT_LDS_GATD_0 + 24
 };
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of
@@ -121,6 +123,11 @@ int magat_gat_small_supported(int N, int G, int F, int K, int mode);
 int magat_gat_small_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre, const float* Hs,
                             int NC, const float* bias, float* Y, int ldy, int B, int N, int G, int K, int P, int concat,
                             int* range_flag, hipStream_t st, const float* x_scale);
+// one-launch KeyQuery layer for the published widths on graphs of 33 .. 128 agents (gat_mid.hip: G = F in {32, 64}, K = 2 | 3)
+int magat_gat_mid_supported(int N, int G, int F, int K, int mode);
+int magat_gat_mid_forward(const float* X, int ldx, const void* S, int s_is_f64, const float* Hs, int NC, const float* bias, float* Y,
+                          int ldy, int B, int N, int G, int K, int P, int concat, int* range_flag, hipStream_t st,
+                          const float* x_scale);
 // one-launch KeyQuery layer on the matrix cores (gat_mfma.hip)
 int magat_gat_mfma_supported(int N, int G, int F, int K, int mode);
 int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre,

@@ -1,0 +1,127 @@
+"""One-launch graph layer for the published feature widths on graphs of 33 .. 128 agents (csrc/gat_mid.hip, round 6; VERDICT r05
+item 3a): G = F in {32, 64}, K = 2 | 3, KeyQuery - the released F-32-P4 / B-32-P4 checkpoints on the README's 30 .. 100-robot
+sets (README.md:372-390, scripts/train_DMap.sh:42-46).  Against the pinned CPU oracle over every row-tile count (N = 33 .. 128),
+directed graphs, isolated agents, float64 GSOs, both merges; WHICH kernel ran is asserted (launch tag + form counter); the range
+guard's float32 re-run behind it."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ONE_LAUNCH = "gat_layer (one launch)"
+
+
+def _layer_and_ref(G, K, P, concat, x, S, seed):
+    from magat_pathplanning_amd import GraphFilterBatchAttentional
+    from oracle import magat_oracle as orc
+    torch.manual_seed(seed)
+    layer = GraphFilterBatchAttentional(G, G, K, P, attentionMode="KeyQuery", concatenate=concat)
+    with torch.no_grad():
+        layer.bias.uniform_(-0.1, 0.1)
+    params = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    y_ref, _ = orc.gat_layer_forward(x, S.unsqueeze(1), params, "KeyQuery", concat)
+    return layer, y_ref
+
+
+@pytest.mark.parametrize("N,G,K,P,concat,f64", [(33, 32, 2, 4, False, False), (64, 64, 3, 4, True, True), (65, 32, 3, 2, True, False),
+                                                (96, 64, 2, 1, False, False), (97, 32, 2, 4, False, True), (100, 32, 2, 4, False, False),
+                                                (100, 64, 3, 4, True, False), (128, 64, 3, 4, True, False), (128, 32, 3, 4, False, True),
+                                                (50, 32, 2, 4, False, False), (60, 64, 2, 4, True, False)])
+def test_mid_layer_against_the_oracle(gpu_device, tag_counts, N, G, K, P, concat, f64):
+    from magat_pathplanning_amd import _native as nat
+    from magat_pathplanning_amd.synthetic import directed_gso
+    B = 5
+    g = torch.Generator().manual_seed(N * 7 + G + K)
+    x = torch.randn(B, G, N, generator=g) * 0.7
+    S = torch.nan_to_num(directed_gso(B, N, 8.0 / N, seed=N + G, dtype=torch.float64 if f64 else torch.float32))
+    S[0, 3, :] = 0            # an agent without out-edges (its attention row is all zeros)
+    S[1, :, 5] = 0            # ... one nobody listens to
+    S[2] = 0                  # an instance without any edge
+    S[3, N - 1, 0] = 5e-10    # below the 1e-9 threshold: not an edge
+    layer, y_ref = _layer_and_ref(G, K, P, concat, x, S, seed=N + P)
+    layer = layer.to(gpu_device).eval()
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    assert nat.lib().magat_gat_one_launch_supported(N, G, G, K, 0, 1 if concat else 0)
+    nat.lib().magat_form_reset()
+    with torch.no_grad(), tag_counts() as tc:
+        y = layer(x.to(gpu_device)).cpu()
+    assert tc[ONE_LAUNCH] == 1 and tc["gat_maps_gemm"] == 0 and tc["gat_graph"] == 0, tc.counts
+    assert int(nat.lib().magat_form_count(nat.FORMS["gat_mid"])) == 1
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    err = float((y - y_ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(y_ref.abs().max())), err
+    # Nin < N: the layer pads the signal with zero agents and trims its output (graphML.py:4641-4646, 4670-4671)
+    nin = N - 2
+    from oracle import magat_oracle as orc
+    params = {k: v.detach().cpu() for k, v in layer.state_dict().items()}
+    y2_ref, _ = orc.gat_layer_forward(x[:, :, :nin].contiguous(), S.unsqueeze(1), params, "KeyQuery", concat)
+    with torch.no_grad():
+        y2 = layer(x[:, :, :nin].contiguous().to(gpu_device)).cpu()
+    assert float((y2 - y2_ref).abs().max()) <= 1e-5 * max(1.0, float(y2_ref.abs().max()))
+
+
+def test_mid_layer_many_instances_and_run_to_run(gpu_device):
+    """More planning instances than workgroups (the persistent instance loop), twice: bit-identical, and the sampled instances
+    equal the oracle's."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd.synthetic import comm_gso
+    B, N, G, K, P = 1100, 100, 32, 2, 4
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, G, N, generator=g) * 0.6
+    S = comm_gso(B, N, 50, seed=3)
+    layer, _ = _layer_and_ref(G, K, P, False, x[:2], S[:2], seed=9)
+    params = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    layer = layer.to(gpu_device).eval()
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    with torch.no_grad():
+        y1 = layer(x.to(gpu_device)).cpu()
+        y2 = layer(x.to(gpu_device)).cpu()
+    assert torch.equal(y1, y2)
+    pick = [0, 255, 256, 777, 1099]
+    y_ref, _ = orc.gat_layer_forward(x[pick], S[pick].unsqueeze(1), params, "KeyQuery", False)
+    assert float((y1[pick] - y_ref).abs().max()) <= 1e-5 * max(1.0, float(y_ref.abs().max()))
+
+
+def test_mid_layer_range_guard_rerun(gpu_device):
+    """Inputs beyond the f16 planes' range raise the flag; the predicated float32 form (two launches; its LDS tiles reach
+    N = 128 at these widths) rewrites the output in the same stream: still the oracle's numbers."""
+    from magat_pathplanning_amd.synthetic import comm_gso
+    B, N, G, K, P = 3, 128, 64, 3, 4
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, G, N, generator=g) * 3.0e4          # |x| up to ~1e5 > 65504
+    S = comm_gso(B, N, 50, seed=5)
+    layer, y_ref = _layer_and_ref(G, K, P, True, x, S, seed=1)
+    layer = layer.to(gpu_device).eval()
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    with torch.no_grad():
+        y = layer(x.to(gpu_device)).cpu()
+    scale = float(y_ref.abs().max())
+    assert bool(torch.isfinite(y).all())
+    assert float((y - y_ref).abs().max()) <= 2e-5 * max(1.0, scale)
+
+
+def test_published_checkpoint_shape_on_100_robots(gpu_device, tag_counts):
+    """The whole module with the published hyper-parameters (G = F = 32, P = 4, K = 2, head mean, BottomNeck_only) on 100 agents:
+    logits within 1e-4 of the oracle, the graph layer as one launch."""
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    from oracle import magat_oracle as orc
+    B, N = 6, 100
+    cfg = make_config(num_agents=N, nGraphFilterTaps=2, nAttentionHeads=4, bottleneckFeature=32, bottleneckMode="BottomNeck_only",
+                      AttentionConcat=False, device=str(gpu_device))
+    sd = orc.init_state_dict(cfg, seed=77)
+    x, S = fov_states(B, N, seed=1), comm_gso(B, N, 50, seed=2, dtype=torch.float64)
+    ref = orc.planner_forward(x, S.clone(), sd, cfg)
+    net = DecentralPlannerGATNet(cfg)
+    net.load_state_dict(sd)
+    net = net.to(gpu_device).eval()
+    with torch.no_grad():
+        net.addGSO(S.clone().to(gpu_device))
+        net(x.to(gpu_device))
+        with tag_counts() as tc:
+            net.addGSO(S.clone().to(gpu_device))
+            got = net(x.to(gpu_device)).cpu()
+    assert tc[ONE_LAUNCH] == 1 and tc["gat_maps_gemm"] == 0, tc.counts
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
