@@ -515,6 +515,14 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_hop_kernel(const Fuse
       const int head = hg * HP + h;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
+        // (the bias quads of this tile, requested in front of its matrix products: read behind them they were eight exposed L2
+        //  round trips per step - the tap phase took 22 k cycles per step for 8 k of matrix work)
+        f32x4 bqv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bqv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p.bias) bqv[j] = *reinterpret_cast<const f32x4*>(p.bias + 32 * mt + 8 * j + 4 * half);
+        }
         f32x16 y = {};
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
@@ -525,22 +533,20 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_hop_kernel(const Fuse
         float v[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + 32 * mt + 8 * j + 4 * half);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            float w = y[4 * j + i] + bq[i];
+            float w = y[4 * j + i] + bqv[j][i];
             if (p.act_relu) w = magat_relu(w);
             v[4 * j + i] = w;
           }
         }
         fu32x4 g[2];
         acc_to_granules(v, g);
-        if (valid) {
-          const long long off = ((long long)b * N + row) * p.ldy + head * 128 + 32 * mt + 8 * half;
+        if (p.y_f32) {
+          if (valid) {
+            const long long off = ((long long)b * N + row) * p.ldy + head * 128 + 32 * mt + 8 * half;
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            if (p.y_f32) {
+            for (int jj = 0; jj < 2; ++jj) {
               float* yp = static_cast<float*>(p.Y) + off + 16 * jj;
               *reinterpret_cast<f32x4*>(yp) =
                   f32x4{__builtin_bit_cast(float, g[jj][0] << 16), __builtin_bit_cast(float, g[jj][0] & 0xffff0000u),
@@ -548,8 +554,29 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_hop_kernel(const Fuse
               *reinterpret_cast<f32x4*>(yp + 4) =
                   f32x4{__builtin_bit_cast(float, g[jj][2] << 16), __builtin_bit_cast(float, g[jj][2] & 0xffff0000u),
                         __builtin_bit_cast(float, g[jj][3] << 16), __builtin_bit_cast(float, g[jj][3] & 0xffff0000u)};
-            } else {
-              *reinterpret_cast<fu32x4*>(static_cast<u16*>(p.Y) + off + 16 * jj) = g[jj];
+            }
+          }
+        } else {
+          // bf16 rows through a wave-private 4 KB stage (two column tiles = 128 bytes of 32 rows): a lane's 16-byte pieces are
+          // 32 rows apart in memory - 64 texture-path requests per store instruction, 1024 per step, a fifth of what this
+          // kernel issues (it is bound by their number: profiles/r06a) - transposed, eight lanes write a row's 128-byte run
+          // (16 requests per instruction).  16-byte units XOR-swizzled by the row pair: conflict-free both ways.
+          char* const stg = lds + HP * 65536 + wave * 4096;
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int c = 4 * (mt & 1) + 2 * jj + half;
+            *reinterpret_cast<fu32x4*>(stg + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = g[jj];
+          }
+          if (mt & 1) {
+            const int rowv = valid ? row : -1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int rr = 8 * i + (lane >> 3), ch = lane & 7;
+              const fu32x4 val = *reinterpret_cast<const fu32x4*>(stg + rr * 128 + ((ch ^ ((rr >> 1) & 7)) << 4));
+              const int rrow = __shfl(rowv, rr, 64);
+              if (rrow >= 0)
+                *reinterpret_cast<fu32x4*>(static_cast<u16*>(p.Y) + ((long long)b * N + rrow) * p.ldy + head * 128 + 32 * (mt - 1) +
+                                           8 * ch) = val;
             }
           }
         }
@@ -665,7 +692,7 @@ int magat_gat_csr_fused_forward(const uint16_t* X, const int* rowptr, const int*
     int per = per_xcd / ngrp;
     if (per < 1) per = 1;
     const int wgx = ngrp * (items < per ? items : per);
-    const size_t lds = (size_t)HP * 65536;
+    const size_t lds = (size_t)HP * 65536 + (size_t)FUSED_WAVES * 4096;      // weights + the row-store stage of every wave
     const void* fn = HP == 2 ? reinterpret_cast<const void*>(&csr_fused_hop_kernel<2>)
                              : reinterpret_cast<const void*>(&csr_fused_hop_kernel<1>);
     if (magat_ensure_dyn_lds(fn, MAGAT_LDS_CSR_FUSED_B + (HP == 2 ? 1 : 0), lds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
