@@ -178,7 +178,9 @@ def load_pmc_traffic():
     cannot be collected from inside this process, so the latest committed summary of the same workload is used."""
     import glob
     # the latest round by directory name (r02h > r02f > r01h): file times do not survive a checkout
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary_*.json")),
+    # (summaries of the other workloads - summary_<tag>_c2.json, ..._c5.json, tools/profile_round.sh <tag> c5 - are not c3's)
+    paths = sorted((q for q in glob.glob(os.path.join(ROOT, "profiles", "*", "summary_*.json"))
+                    if not os.path.basename(q)[:-5].endswith(("_c2", "_c5"))),
                    key=lambda q: os.path.basename(os.path.dirname(q)))
     if not paths:
         return {}

@@ -50,8 +50,8 @@ const char* magat_error_string(int code);
 
 /* Options.  Every tunable of the library lives in one table that is seeded from the environment (MAGAT_<NAME>) ONCE, at
  * first use, and is read / changed through these calls afterwards; nothing on the launch path calls getenv.  `name` with
- * or without the MAGAT_ prefix.  All seventeen (round 5: the A/B switches of kernel forms that lost their measurements are gone
- * with those forms; csrc/options.hip holds the table):
+ * or without the MAGAT_ prefix.  All eighteen (round 5: the A/B switches of kernel forms that lost their measurements are gone
+ * with those forms; round 6: + CSR_FUSED; csrc/options.hip holds the table):
  *   RANGE_GUARD (1)  split-arithmetic range guard (encoder and graph layer): see magat_encoder_read_status
  *   CONV_SPLIT  (7)  bit l: BasicBlock l+1 on the f16x3 split kernels; 0 = every convolution on the fp32 MFMA kernel (strict float32)
  *   CONV_PCHAIN (1), CONV_TM (2)  activation layout / tile height of the f16x3 split GEMMs (f16 plane granules against
@@ -67,11 +67,15 @@ const char* magat_error_string(int code);
  *                    until the launch has this many workgroups; results are bit-identical for every value
  *   ENC_CHUNK (65536), GAT_CHUNK_MB (2048)  workspace bounds: agents per encoder pass, size of the two-launch graph layer's maps
  *   GAT_MFMA    (1)  graph layer with G = F = 128, N <= 102, K = 2 | 3, A_opt == NULL as ONE launch of matrix-core products
- *                    (maps, scores, softmax, hops; csrc/gat_mfma.hip; G = F in {32, 64}, N <= 32: csrc/gat_small.hip); 0 = maps
+ *                    (maps, scores, softmax, hops; csrc/gat_mfma.hip; G = F in {32, 64}: N <= 32 csrc/gat_small.hip, 33 <= N <= 128
+ *                    csrc/gat_mid.hip - round 6); 0 = maps
  *                    GEMM + graph kernel;  GAT_SPLIT (1) that GEMM on the split kernels;  GAT_PACK (1) four instances per pass
  *                    at N <= 32 once the batch fills the chip (bit-identical)
  *   CSR_TILED   (3)  CSR path (N > 128 / bf16 storage): LDS-tiled score / hop kernels;  SKINNY (1) the action head as streamed
  *                    dot products
+ *   CSR_FUSED   (1)  bf16-storage CSR layer, KeyQuery, K = 2, G = F = 128, concat, P in {1, 2, 4} (BASELINE config 5): the maps on
+ *                    the matrix cores INSIDE the score / hop kernels, hop on the node features (csrc/gat_csr_fused.hip: no maps
+ *                    GEMM, no Z in memory); 0 = maps GEMM + the CSR_TILED kernels
  * Returns MAGAT_ERR_UNSUPPORTED for an unknown name. */
 int magat_set_option(const char* name, int value);
 int magat_get_option(const char* name, int* value);
@@ -120,18 +124,10 @@ int magat_gat_forward_packed_f32(const float* X, const void* S, int s_is_f64, co
                                  size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
                                  int mode, int concat, void* stream);
 
-/* GSO plan for the dense kernel (optional).  The reference hands the GSO over before the forward pass
- * (addGSO(S), graphs/models/decentralplanner_GAT_bottleneck.py:262-278, then forward(x) :283); everything the
- * graph kernel derives from S alone - per-row edge bitmasks [B][N][4] and an edge-count-balanced order in which
- * the persistent workgroups walk the instances - can therefore be made at addGSO time, on a side stream, while
- * the per-agent CNN runs.  plan: device buffer of magat_gat_gso_plan_bytes(B, N) bytes (0 = shape not
- * plannable: N > 128 or B > 8192), 256-byte aligned.  A plan is valid for the (S contents, B, N, mode) it was made
- * from; the caller orders the plan stream before the forward stream (event) and re-plans after changing S.
- * magat_gat_forward_planned_f32 = magat_gat_forward_packed_f32 plus the plan (NULL = none: identical results either
- * way - the plan changes where masks come from and the instance order, not the arithmetic). */
-size_t magat_gat_gso_plan_bytes(int B, int N);
-int magat_gat_gso_plan(const void* S, int s_is_f64, int mode, void* plan, size_t plan_bytes, int B, int N,
-                       void* stream);
+/* (ABI 7) The optional GSO plan of ABI 2-6 (magat_gat_gso_plan / magat_gat_gso_plan_bytes: edge masks + a balanced instance
+ * walk made at addGSO time) is gone: opt-in, measured slower, never the default.  magat_gat_forward_planned_f32 keeps its
+ * signature for existing bindings; `plan` must be NULL (anything else: MAGAT_ERR_UNSUPPORTED) - it then IS
+ * magat_gat_forward_packed_f32. */
 int magat_gat_forward_planned_f32(const float* X, const void* S, int s_is_f64, const float* packed,
                                  const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
                                  size_t workspace_bytes, int B, int N, int G, int F, int K, int P,

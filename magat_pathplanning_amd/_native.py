@@ -92,8 +92,6 @@ _SIGNATURES = {
     "magat_gat_workspace_bytes": (_Z, [_I] * 8),
     "magat_gat_forward_packed_f32": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_forward_planned_f32": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P, _P]),
-    "magat_gat_gso_plan_bytes": (_Z, [_I, _I]),
-    "magat_gat_gso_plan": (_I, [_P, _I, _I, _P, _Z, _I, _I, _P]),
     "magat_gat_forward_dense_f32": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_csr_workspace_bytes": (_Z, [_I, _I, ctypes.c_longlong] + [_I] * 6),
     "magat_gat_forward_csr_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),

@@ -1055,131 +1055,10 @@ extern "C" int magat_gat_dense_supported(int N, int G, int F) {
   return gat_lds_bytes(N, G, F, gat_block_threads(N) / 64) <= 160 * 1024 ? 1 : 0;
 }
 
-// ---- GSO plan (magat_gat_gso_plan): edge masks, edge counts, balanced instance walk for the persistent kernel ----------
-// Made when the GSO is handed over (addGSO), on a side stream, so it overlaps the per-agent CNN that runs before the graph
-// layer (in-stream it costs 29 us at c3 and buys 13-15 us: a loss; hidden under the MFMA-bound encoder it is free).
-// One pass over S (instead of the graph kernel's own): per row the 128-bit edge mask the graph kernel
-// otherwise stages itself, per instance the edge count.  With one workgroup per CU walking B / 256 instances each, a
-// launch ends when the unluckiest workgroup does - at c3 (510 +- 34 edges per instance) the maximum over 256 workgroups of
-// a two-instance sum is 4-13 % above the mean; score and hop phases are per-edge, so the instances are ranked by edge
-// count and dealt out in snake order (round r of workgroup w takes rank r W + w, odd rounds reversed).
-// Without a plan the graph kernel stages the masks from S itself and walks the instances in index order.
-// One 1024-thread workgroup per instance (16 waves, <= 8 rows each: every load of a wave is issued before its first
-// ballot - one memory latency per instance, not one per row); a single-workgroup kernel then ranks the instances (a
-// device-wide "last workgroup ranks" ticket serialised 512 atomics on one address: 3x slower than the second launch).
-template <typename T>
-__global__ __launch_bounds__(1024) void gat_prepare_kernel(const T* __restrict__ S, unsigned* __restrict__ masks,
-                                                           int* __restrict__ cost, int N, int origin) {
-  __shared__ int part[16];
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const T* Sp = S + (long long)b * N * N;
-  T v0[8], v1[8];
-#pragma unroll
-  for (int h = 0; h < 8; ++h) {
-    const int i = wave + 16 * h, ic = i < N ? i : N - 1;
-    v0[h] = Sp[(long long)ic * N + (lane < N ? lane : N - 1)];
-    v1[h] = Sp[(long long)ic * N + (lane + 64 < N ? lane + 64 : N - 1)];
-  }
-  int cnt = 0;
-#pragma unroll
-  for (int h = 0; h < 8; ++h) {
-    const int i = wave + 16 * h;
-    if (i >= N) break;
-    bool f0, f1;
-    if (origin) {      // GAT_origin: |float(S) + I| > 1e-9f
-      f0 = fabsf((float)v0[h] + (lane == i ? 1.f : 0.f)) > 1e-9f;
-      f1 = fabsf((float)v1[h] + (lane + 64 == i ? 1.f : 0.f)) > 1e-9f;
-    } else if (sizeof(T) == 8) {
-      f0 = fabs((double)v0[h]) > 1e-9;
-      f1 = fabs((double)v1[h]) > 1e-9;
-    } else {
-      f0 = fabsf((float)v0[h]) > 1e-9f;
-      f1 = fabsf((float)v1[h]) > 1e-9f;
-    }
-    const unsigned long long k0 = __ballot(f0 && lane < N), k1 = __ballot(f1 && lane + 64 < N);
-    cnt += __popcll(k0) + __popcll(k1);
-    if (lane == 0) {
-      unsigned* m = masks + ((long long)b * N + i) * 4;
-      m[0] = (unsigned)k0; m[1] = (unsigned)(k0 >> 32); m[2] = (unsigned)k1; m[3] = (unsigned)(k1 >> 32);
-    }
-  }
-  if (lane == 0) part[wave] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int c = 0;
-    for (int w = 0; w < 16; ++w) c += part[w];
-    cost[b] = c;
-  }
-}
-
-// rank by edge count (ties by index), deal out in snake order over W walkers
-__global__ __launch_bounds__(1024) void gat_order_kernel(const int* __restrict__ cost, int* __restrict__ order, int B,
-                                                         int W) {
-  extern __shared__ int cs[];             // B costs (padded to a multiple of 4 with -1), then B partial ranks
-  const int Bp = (B + 3) & ~3;
-  int* pr = cs + Bp;
-  for (int i = threadIdx.x; i < Bp; i += 1024) cs[i] = i < B ? cost[i] : -1;
-  __syncthreads();
-  // PARTS threads per instance, each counting over an interleaved quarter of the list with 16-byte LDS reads
-  const int parts = B <= 256 ? 4 : (B <= 512 ? 2 : 1);
-  for (int i0 = 0; i0 < B; i0 += 1024 / parts) {
-    const int i = i0 + (int)threadIdx.x / parts, part = (int)threadIdx.x % parts;
-    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-    if (i < B) {
-      const int ci = cs[i];
-      for (int j = 4 * part; j < Bp; j += 4 * parts) {
-        const int4 c = *reinterpret_cast<const int4*>(cs + j);
-        r0 += (c.x > ci || (c.x == ci && j < i)) ? 1 : 0;
-        r1 += (c.y > ci || (c.y == ci && j + 1 < i)) ? 1 : 0;
-        r2 += (c.z > ci || (c.z == ci && j + 2 < i)) ? 1 : 0;
-        r3 += (c.w > ci || (c.w == ci && j + 3 < i)) ? 1 : 0;
-      }
-    }
-    int r = r0 + r1 + r2 + r3;
-    for (int o = 1; o < parts; o <<= 1) r += __shfl_xor(r, o, 64);
-    if (i < B && part == 0) pr[i] = r;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < B; i += 1024) {
-    const int rank = pr[i];
-    const int round = rank / W, pos = rank - round * W;
-    const bool rev = (round & 1) && (round + 1) * W <= B;      // a partial last round keeps its order
-    order[round * W + (rev ? W - 1 - pos : pos)] = i;
-  }
-}
-
-constexpr int GAT_PLAN_WALKERS = 256;     // persistent graph-kernel workgroups (one per CU) the walk order is dealt to
-
-extern "C" size_t magat_gat_gso_plan_bytes(int B, int N) {
-  if (B <= 0 || N <= 0 || N > 128 || B > 8192) return 0;
-  return magat_align_up((size_t)B * N * 4 * sizeof(unsigned), 256) + magat_align_up((size_t)(2 * B + 1) * sizeof(int), 256);
-}
-
-extern "C" int magat_gat_gso_plan(const void* S, int s_is_f64, int mode, void* plan, size_t plan_bytes, int B, int N,
-                                  void* stream) {
-  if (!S || !plan) return MAGAT_ERR_NULL;
-  if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GAT_ORIGIN) return MAGAT_ERR_UNSUPPORTED;
-  const size_t need = magat_gat_gso_plan_bytes(B, N);
-  if (!need) return MAGAT_ERR_UNSUPPORTED;
-  if (plan_bytes < need || (reinterpret_cast<uintptr_t>(plan) & 255)) return MAGAT_ERR_WORKSPACE;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  char* base = static_cast<char*>(plan);
-  unsigned* masks = reinterpret_cast<unsigned*>(base);
-  int* cost = reinterpret_cast<int*>(base + magat_align_up((size_t)B * N * 4 * sizeof(unsigned), 256));
-  int* order = cost + B;
-  const int origin = mode == MAGAT_MODE_GAT_ORIGIN ? 1 : 0;
-  const int pid = magat_prof_begin(MAGAT_TAG_GAT_PREPARE, st);
-  if (s_is_f64)
-    hipLaunchKernelGGL(gat_prepare_kernel<double>, dim3(B), dim3(1024), 0, st, static_cast<const double*>(S), masks,
-                       cost, N, origin);
-  else
-    hipLaunchKernelGGL(gat_prepare_kernel<float>, dim3(B), dim3(1024), 0, st, static_cast<const float*>(S), masks, cost,
-                       N, origin);
-  hipLaunchKernelGGL(gat_order_kernel, dim3(1), dim3(1024), (size_t)(2 * B + 8) * sizeof(int), st, cost, order, B,
-                     GAT_PLAN_WALKERS);
-  magat_prof_end(pid, st);
-  return hipGetLastError() == hipSuccess ? MAGAT_OK : MAGAT_ERR_LAUNCH;
-}
+// (The optional GSO plan of rounds 2-5 - edge masks and an edge-count-balanced instance walk made at addGSO time on a side
+//  stream, magat_gat_gso_plan - was removed in round 6: opt-in, measured 0.5-1.8 % SLOWER per step at c3, never the default.
+//  magat_gat_forward_planned_f32 keeps its signature; its `plan` argument must be NULL.)
+constexpr int GAT_PLAN_WALKERS = 256;     // persistent graph-kernel workgroups (one per CU)
 
 constexpr size_t GAT_STATUS_BYTES = 256;   // status block (range guard of the maps GEMM) at the head of the workspace
 
@@ -1222,6 +1101,7 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
                                              size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
                                              int mode, int concat, const void* plan, void* stream) {
   if (!X || !S || !packed || !Y) return MAGAT_ERR_NULL;
+  if (plan) return MAGAT_ERR_UNSUPPORTED;      // (the GSO plan was removed in round 6)
   if (B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
   if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GAT_ORIGIN) return MAGAT_ERR_UNSUPPORTED;
   if (G != F || !supported_width(G) || N > 128) return MAGAT_ERR_UNSUPPORTED;
@@ -1266,7 +1146,7 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
   if (!A_opt && gat_one_launch(N, G, F, K, mode, concat) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
       (G == 128 || (reinterpret_cast<uintptr_t>(X) & 15) == 0)) {
     const bool guard = magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
-    const unsigned* masks = (plan && N <= 128) ? static_cast<const unsigned*>(plan) : nullptr;
+    const unsigned* masks = nullptr;
     const float* frag = packed + magat_gat_frag_offset(L.NC, G);
     // (128 features: gat_mfma.hip; 32 / 64 features on graphs of at most 32 agents: gat_small.hip, a wave per instance)
     const int rc = G == 128
@@ -1329,12 +1209,6 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     const int blocks = inst_slots * (P / hpb);
     p.order = nullptr;
     p.rmask_pre = nullptr;
-    if (plan && cb == B && G >= 64 && N <= 128) {     // made by magat_gat_gso_plan for this S
-      const char* base = static_cast<const char*>(plan);
-      p.rmask_pre = reinterpret_cast<const unsigned*>(base);
-      if (inst_slots == GAT_PLAN_WALKERS && inst_slots < cb)
-        p.order = reinterpret_cast<const int*>(base + magat_align_up((size_t)B * N * 4 * sizeof(unsigned), 256)) + B;
-    }
     const int gtag = rerun_only ? MAGAT_TAG_RANGE_GUARD : MAGAT_TAG_GAT_GRAPH;
     // the re-run's last launch does the guard's bookkeeping: the graph kernel of the last chunk, or the head-mean kernel
     p.book = (rerun_only && b0 + chunk >= B && (concat || all_fused)) ? reinterpret_cast<int*>(status) : nullptr;

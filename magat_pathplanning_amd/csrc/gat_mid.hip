@@ -110,16 +110,17 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
     unsigned mk[NT];
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) mk[jt] = 0u;
+    // (eight rows per batch: their loads are in flight together - one row at a time was a serial chain of 64 L2 round trips)
+#pragma unroll 8
     for (int il = 0; il < 32; ++il) {
       const int i = 32 * w + il;
 #pragma unroll
       for (int hc = 0; hc < (ROWS + 63) / 64; ++hc) {
         const int j = 64 * hc + lane;
-        bool edge = false;
-        if (i < N && j < N) {
-          if (p.s_is_f64) edge = fabs(static_cast<const double*>(p.S)[((long long)inst * N + i) * N + j]) > 1e-9;
-          else edge = fabsf(static_cast<const float*>(p.S)[((long long)inst * N + i) * N + j]) > 1e-9f;
-        }
+        // (branch-free: clamped addresses, the predicate applied to the loaded value - the batch's loads issue back to back)
+        const long long at = ((long long)inst * N + (i < N ? i : N - 1)) * N + (j < N ? j : N - 1);
+        bool edge = p.s_is_f64 ? fabs(static_cast<const double*>(p.S)[at]) > 1e-9 : fabsf(static_cast<const float*>(p.S)[at]) > 1e-9f;
+        edge = edge && i < N && j < N;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(edge);
         if (fr == il) {
           if (2 * hc < NT) mk[2 * hc] = (unsigned)bal;

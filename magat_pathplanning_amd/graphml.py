@@ -276,56 +276,9 @@ def _csr_attention_to_dense(att, rowptr, colidx, nnz, B, N, P):
     return dense.view(P, B, N, N).permute(1, 0, 2, 3).unsqueeze(2).contiguous()
 
 
-class GsoPlan:
-    """Everything the dense graph kernel derives from the GSO alone (edge bitmasks per row, an edge-count-balanced
-    instance walk), made on a side stream when the GSO is handed over so that it overlaps the per-agent CNN
-    (magat_gat_gso_plan, include/magat_hip.h).  Valid for the S contents it was made from: addGSO re-plans."""
-
-    def __init__(self):
-        self.buf = None
-        self.side = None
-        self.event = None
-        self.key = None          # (S.data_ptr(), B, N, dtype, mode) the plan was made for
-
-    def make(self, S3, mode):
-        """S3 (B,N,N) contiguous f32|f64 device tensor.  Returns True when a plan was enqueued."""
-        lib = nat.lib()
-        B, N, _ = S3.shape
-        need = lib.magat_gat_gso_plan_bytes(B, N)
-        self.key = None
-        # Opt-in (MAGAT_GSO_PLAN=1).  Measured at c3 on one MI355X: the graph kernel drops 188 -> 176 us, but the plan
-        # kernels share CUs and HBM with the first encoder kernels (70 us under contention, 29 us alone) and the step
-        # gets 0.5-1.8 % slower.  Only considered when the graph kernel is persistent (more instances than CUs).
-        if not need or B <= 256 or os.environ.get("MAGAT_GSO_PLAN", "0") != "1":
-            return False
-        dev = S3.device
-        with torch.cuda.device(dev):
-            if self.buf is None or self.buf.numel() < need or self.buf.device != dev:
-                self.buf = torch.empty(need, dtype=torch.uint8, device=dev)
-                self.side = torch.cuda.Stream(device=dev)
-            cur = torch.cuda.current_stream(dev)
-            self.side.wait_stream(cur)              # S (and the previous forward's reads of the plan) come first
-            with torch.cuda.stream(self.side):
-                nat.check(lib.magat_gat_gso_plan(nat.ptr(S3), 1 if S3.dtype == torch.float64 else 0, mode,
-                                                 nat.ptr(self.buf), self.buf.numel(), B, N,
-                                                 nat.current_stream(dev)), "magat_gat_gso_plan")
-                self.event = self.side.record_event()
-            S3.record_stream(self.side)
-        self.key = (S3.data_ptr(), B, N, S3.dtype, mode)
-        return True
-
-    def ready_ptr(self, S3, mode, dev):
-        """Pointer to pass as the plan (after ordering the current stream behind it), or None."""
-        if self.key != (S3.data_ptr(), S3.shape[0], S3.shape[1], S3.dtype, mode) or self.buf.device != dev:
-            return None
-        torch.cuda.current_stream(dev).wait_event(self.event)
-        return nat.ptr(self.buf)
-
-
-def gat_forward_rows(X, S, layer, out=None, want_attention=False, plan=None, csr=None):
+def gat_forward_rows(X, S, layer, out=None, want_attention=False, csr=None):
     """Kernel-facing form.  X (B,N,G) f32 contiguous device rows; S (B,N,N) or (B,1,N,N) f32|f64;
     out: optional (B*N, ld) float32 view whose first P*F|F columns receive the result.
-    plan: optional GsoPlan made from this S (ignored when it was made for another tensor / shape / mode).
     csr: optional CsrStructure made from this S at addGSO time (large-graph / bf16-storage path).
     Returns (out (B*N, ld) with the result in columns [0, width), aij (B,P,1,N,N) device tensor or None)."""
     if not X.is_cuda:
@@ -377,11 +330,10 @@ def gat_forward_rows(X, S, layer, out=None, want_attention=False, plan=None, csr
         ldy = out.stride(0)
         aij = torch.empty(B, P, 1, N, N, dtype=torch.float32, device=dev) if want_attention else None
         bias = None if layer.bias is None else layer.bias.detach().to(dev, torch.float32).reshape(-1).contiguous()
-        plan_ptr = plan.ready_ptr(S3, mode, dev) if plan is not None else None
         nat.check(lib.magat_gat_forward_planned_f32(
             nat.ptr(X), nat.ptr(S3), 1 if S3.dtype == torch.float64 else 0, nat.ptr(sc.packed), nat.ptr(bias),
             nat.ptr(out), ldy, nat.ptr(aij), nat.ptr(sc.workspace), sc.workspace.numel(),
-            B, N, G, F, K, P, mode, concat, plan_ptr, stream), "magat_gat_forward_planned_f32")
+            B, N, G, F, K, P, mode, concat, None, stream), "magat_gat_forward_planned_f32")
     return out, aij
 
 

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import _native as nat
 from . import encoder as enc
-from .graphml import (_MODES, CsrStructure, GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin, GsoPlan,
+from .graphml import (_MODES, CsrStructure, GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin,
                       gat_forward_rows)
 from .resnet import ResNet, ResNetSlim
 
@@ -64,7 +64,6 @@ class _Runtime:
         self.act = None
         self.buffers = {}
         self.ws = None
-        self.plan = GsoPlan()          # GSO-derived masks / walk order, made at addGSO on a side stream
         self.csr = CsrStructure()      # CSR + CSC structure of the GSO (large graphs / bf16 storage), made at addGSO
         self.calibrated = True         # activation scales of the split arithmetic folded for the current weights
         self.act_scales = None
@@ -187,7 +186,6 @@ class DecentralPlannerGATNet(nn.Module):
                 # large graph / bf16 storage: the layer runs on the CSR kernels.  ONE pass over S does the scrub and leaves
                 # the bit matrix the CSR + CSC structure is built from (no host synchronisation, nothing re-read later)
                 self._rt.csr.build(S, 1 if layer.attentionMode == "GAT_origin" else 0, scrub_nan=scrub, gso_mode=gso_mode)
-                self._rt.plan.key = None
                 self.S = S.unsqueeze(1)
                 return
             self._rt.csr.key = None
@@ -197,12 +195,7 @@ class DecentralPlannerGATNet(nn.Module):
                                                           S.numel(), 1 if scrub else 0, gso_mode,
                                                           nat.current_stream(S.device)), "magat_gso_prepare")
             self.S = S.unsqueeze(1)
-            # what the graph kernel needs from S alone is made now, on a side stream, under the per-agent CNN
-            layer = self.GFL[0]
-            if S.numel() > 0 and not (self.training or layer.storage_dtype == torch.bfloat16):
-                self._rt.plan.make(S, _MODES[layer.attentionMode])
             return
-        self._rt.plan.key = None
         self.S = S.unsqueeze(1)
         if scrub:
             self.S[torch.isnan(self.S)] = 0
@@ -586,8 +579,7 @@ class DecentralPlannerGATNet(nn.Module):
                     nat.check(lib.magat_cast_rows(nat.ptr(gat16), nat.ptr(gat), 0, M, self.gat_width, self.gat_width,
                                                   self.gat_width, stream), "magat_cast_rows")
             else:
-                _, aij = gat_forward_rows(comp.view(B, N, G), self.S, layer, out=gat, want_attention=want_att,
-                                          plan=rt.plan, csr=rt.csr)
+                _, aij = gat_forward_rows(comp.view(B, N, G), self.S, layer, out=gat, want_attention=want_att, csr=rt.csr)
             layer.aij = aij
             out = self._run_actions(rt, feat, comp, gat, gat_rows, M, dev, stream)
         return out

@@ -225,25 +225,6 @@ def test_gat_mfma_packed_at_benchmark_size(gpu_device, libopt):
     assert torch.equal(out[1], out[0])
 
 
-def test_packed_graph_layer_with_the_gso_plan(gpu_device, monkeypatch):
-    """The opt-in GSO plan (MAGAT_GSO_PLAN=1: edge masks made at addGSO on a side stream) feeds the PACK form too: a model at
-    N = 20 with enough instances for both (B > 256 for the plan, >= 2 x CUs for packing) gives the same bits with and without."""
-    from magat_pathplanning_amd import DecentralPlannerGATNet
-    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
-    B, N = 640, 20
-    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, device=str(gpu_device))
-    torch.manual_seed(3)
-    net = DecentralPlannerGATNet(cfg).to(gpu_device).eval()
-    x, S = fov_states(B, N, seed=5).to(gpu_device), comm_gso(B, N, 28, seed=6).to(gpu_device)
-    out = {}
-    for plan in ("0", "1"):
-        monkeypatch.setenv("MAGAT_GSO_PLAN", plan)
-        with torch.no_grad():
-            net.addGSO(S.clone())
-            out[plan] = net(x).clone()
-    assert torch.isfinite(out["1"]).all() and torch.equal(out["0"], out["1"])
-
-
 @pytest.mark.parametrize("N,G,K,P,concat,dt,B", [(10, 32, 2, 4, False, torch.float32, 70), (10, 32, 2, 4, True, torch.float64, 5),
                                                  (20, 64, 3, 4, True, torch.float32, 33), (32, 32, 3, 2, False, torch.float64, 9),
                                                  (1, 32, 2, 1, True, torch.float32, 3), (27, 64, 2, 3, False, torch.float32, 1030)])

@@ -550,50 +550,6 @@ def test_encoder_other_map_sizes(gpu_device, monkeypatch, hw, cnn, libopt):
         outs.append(got)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-def test_gso_plan_changes_nothing(gpu_device, monkeypatch, dtype):
-    """The opt-in GSO plan (MAGAT_GSO_PLAN=1) made at addGSO on a side stream (edge bitmasks + edge-count-balanced instance walk of the
-    persistent graph kernel, magat_gat_gso_plan) moves where the masks come from and the order instances are
-    visited in, never the arithmetic: logits are bit-identical with and without it, a plan made for another GSO
-    tensor is ignored, and a repeated addGSO with new contents in the same tensor re-plans.  B > 256 instances of
-    100 agents so that the persistent walk (one workgroup per CU, several instances each) is the path taken."""
-    from oracle import magat_oracle as orc
-    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
-    B, N = 300, 100
-    cfg = make_config(num_agents=N, CNN_mode="ResNetSlim_withMLP")
-    sd = orc.init_state_dict(cfg, seed=3)
-    net = _build(cfg, sd, gpu_device)
-    x = fov_states(B, N, seed=8).to(gpu_device)
-    S1 = comm_gso(B, N, 50, seed=9, dtype=dtype).to(gpu_device)
-    S2 = comm_gso(B, N, 50, seed=10, dtype=dtype).to(gpu_device)
-    with torch.no_grad():
-        net.addGSO(S1)                                    # default: no plan
-        assert net._rt.plan.key is None
-        want1 = net(x).clone()
-        net.addGSO(S2)
-        want2 = net(x).clone()
-        monkeypatch.setenv("MAGAT_GSO_PLAN", "1")
-        net.addGSO(S1)
-        assert net._rt.plan.key is not None
-        got1 = net(x).clone()
-        # same tensor, new contents: addGSO re-plans
-        S1.copy_(S2)
-        net.addGSO(S1)
-        got2 = net(x).clone()
-        # a plan for another tensor is not used
-        net.S = S2.unsqueeze(1)
-        got2b = net(x).clone()
-    assert (want1 - want2).abs().max().item() > 1e-3      # the two GSOs really differ
-    assert torch.equal(got1, want1)
-    assert torch.equal(got2, want2)
-    assert torch.equal(got2b, want2)
-    # and against the oracle on a sample of instances
-    idx = [0, 137, 299]
-    ref = orc.planner_forward(x.cpu().view(B, N, *x.shape[-3:])[idx], S2.cpu()[idx].clone(), sd, cfg)
-    got = got2.view(B, N, -1)[idx].reshape(-1, got2.shape[-1]).cpu()
-    assert (got - ref).abs().max().item() <= TOL
-
-
 def test_empty_batch_raises_like_the_reference(gpu_device):
     """B = 0: the reference's forward dies with a RuntimeError (flattening zero feature maps with `view(size(0), -1)` is ambiguous,
     decentralplanner_GAT_bottleneck.py:297 - checked against the real module in the build container); here the C ABI
