@@ -734,7 +734,7 @@ def main():
             leg = {"workload": "%s: N=%d, %dx%d map, K=%d, P=%d, F=%d, batch %d%s" % (
                        wl, Nw, mw, mw, Kw, Pw, Gw, Bw, ", CSR GSO, bf16 storage in the graph layer" if wl == "c5" else ""),
                    "steps": wsteps, "value": round(Bw * Nw * wsteps / el, 1), "unit": "agent-steps/s",
-                   "ms_per_step": round(el / wsteps * 1e3, 4)}
+                   "ms_per_step": round(el / wsteps * 1e3, 4), "ms_per_step_device": round(getattr(run_leg, "device_ms", 0.0), 4)}
             if timing:
                 tw = kernel_table(kw, wsteps, Bw, Nw, Sw, {}, cfg=cfgw)
                 keep = ("avg_us", "ms_per_step", "launches", "bound", "achieved", "peak", "unit", "frac", "bytes_per_agent_step")
