@@ -142,3 +142,18 @@ def test_tiled_csr_kernels_against_the_per_edge_kernels(gpu_device, libopt, N, B
     assert not bool(torch.isnan(a).any())
     scale = float(b.abs().max()) + 1e-6
     assert float((a - b).abs().max()) <= (2e-2 if bf16 else 2e-5) * scale
+
+
+def test_fused_csr_fuzz_slice(gpu_device):
+    """A slice of tools/exp/fuzz_csr_fused.py (round 6): random graphs - sparse, dense, hub rows and columns, empty rows, directed;
+    N = 1 .. 1024; P in {1, 2, 4}; bf16 or float32 result rows; attention on / off - through the fused bf16-storage CSR layer
+    against the oracle's emulation of its order (N <= 300) and against the split form of the same library."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRAFT_REPO_ROOT=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_csr_fused.py"), "24", "5"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "failures: 0" in r.stdout
