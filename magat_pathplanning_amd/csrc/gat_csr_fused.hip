@@ -530,6 +530,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_hop_kernel(const Fuse
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
           y = mfma_bf16(*reinterpret_cast<const fu32x4*>(frag + ((h * 4 + mt) * 16 + 8 + ks) * 1024), z[ks], y);
+#ifdef FUSED_STAMPS
+        { float sink = y[0]; asm volatile("" :: "v"(sink)); }      // (the chain has finished when its first result is readable)
+        STAMP(4)
+#endif
         float v[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -580,6 +584,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_hop_kernel(const Fuse
             }
           }
         }
+        STAMP(5)
       }
     }
     STAMP(3)

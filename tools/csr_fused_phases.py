@@ -36,7 +36,9 @@ torch.cuda.synchronize()
 lib.magat_csr_fused_set_debug(None)
 d = dbg.cpu().view(2, 4096, WAVES, 8).double()
 names = {0: ["prologue (order, pointers, own row, first gather)", "q' MFMA + pack", "edge loop", "normalise", "", "", "weights -> LDS", "kernel total"],
-         1: ["prologue (order, pointers, first indices / values)", "edge loop", "own row", "pack + tap MFMA + store", "", "", "weights -> LDS", "kernel total"]}
+         1: ["prologue (order, pointers, first indices / values)", "edge loop", "own row", "tap phase: rest (z pack, bias requests)",
+             "tap phase: matrix chains (16 MFMAs each)", "tap phase: epilogues (bias, relu, bf16, LDS stage, stores)", "weights -> LDS",
+             "kernel total"]}
 for k, title in ((0, "score kernel"), (1, "hop + tap kernel")):
     w = d[k].reshape(-1, 8)
     w = w[w[:, 7] > 0]
