@@ -16,4 +16,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o c3 -- $BEN
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o c3 -- python $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-extra-legs > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o c3 -- python $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-extra-legs > $OUT/pmc_write.log 2>&1
 cd $R
+# the same command once more WITHOUT the tracer (its hipEvent table goes into the summary beside the traced durations)
+python $R/bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs > $OUT/bench_untraced.json 2>/dev/null
 python tools/rocprof_summary.py $OUT $TAG

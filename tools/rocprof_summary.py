@@ -37,6 +37,12 @@ def short(name):
                    ("block_full_p_kernel", "block_full_p(layer1.conv2+layer2+layer3+pool, pooling in registers)"),
                    ("gat_guard_count_kernel", "guard_count(gat)"), ("guard_count_kernel", "guard_count(encoder)"),
                    ("gat_mfma_kernel", "gat_mfma(one-launch KeyQuery layer)"), ("gat_dense_kernel", "gat_dense_kernel"), ("head_mean_relu", "head_mean_relu"),
+                   ("gat_mid_kernel", "gat_mid(one-launch layer, G = 32 | 64, N = 33..128)"), ("gat_small_kernel", "gat_small(one-launch layer, N <= 32)"),
+                   ("csr_fused_scores_kernel", "csr_fused_scores(q' on MFMA + edge scores + softmax)"),
+                   ("csr_fused_hop_kernel", "csr_fused_hop(hop on X + taps on MFMA)"), ("csr_rank_kernel", "csr_rank(degree ranking)"),
+                   ("csr_fused_pack_kernel", "csr_fused_pack"), ("gso_mask_x4_kernel", "gso_mask_x4(GSO -> bit matrix)"),
+                   ("gso_mask_kernel", "gso_mask(GSO -> bit matrix)"), ("gso_structure_kernel", "gso_structure(CSR + CSC)"),
+                   ("gso_totals_kernel", "gso_totals"), ("cast_f32_bf16_kernel", "cast_f32_bf16"),
                    ("pack_kernel", "gat_pack"), ("gso_prepare", "gso_prepare")):
         if key in name:
             return s
@@ -61,8 +67,10 @@ def timed_launch_stats(trace_csv, steps, warmup):
     # where the timed region starts: among the kernels launched exactly once per step, the one that comes first in a step;
     # its launch number `warmup` opens the first timed step (everything before it - warm-up steps, the one-off float32
     # calibration pass of the activation scales, weight packing - is dropped for EVERY kernel)
-    once = [v for v in by.values() if len(v) == steps + warmup]
-    cut = min(once, key=lambda v: v[0][0])[warmup][0] if once else 0
+    # (bench.py also runs untimed steps in FRONT of the warm-up since round 6 - two set-up steps + the five `first_steps_ms` - so a
+    #  once-per-step kernel has steps + warmup + 7 launches: the timed steps are its LAST `steps` launches)
+    once = [v for v in by.values() if len(v) in (steps + warmup, steps + warmup + 7)]
+    cut = min(once, key=lambda v: v[0][0])[-steps][0] if once else 0
     stats = {}
     for k, v in by.items():
         d = sorted(x[1] for x in v if x[0] >= cut)
@@ -74,8 +82,11 @@ def timed_launch_stats(trace_csv, steps, warmup):
 
 def main():
     out, tag = sys.argv[1], sys.argv[2]
-    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-    warmup = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 5
+    warmup = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4].isdigit() else 2
+    # optional: the bench line of the SAME command run untraced on the same box (tools/profile_round.sh writes it): its hipEvent
+    # table is printed beside the traced durations (rocprofv3 stretches the long kernels by up to 10 %)
+    bench_json = next((a for a in sys.argv[3:] if a.endswith(".json")), os.path.join(out, "bench_untraced.json"))
     res = {"tag": tag, "kernels": {}}
     lines = []
     tr0 = find(os.path.join(out, "trace"), "*kernel_trace.csv")
@@ -90,7 +101,21 @@ def main():
                 k, v["timed_launches"], v["min_us"], v["median_us"], v["mean_us"], 100.0 * v["total_us"] / tot))
             res["kernels"].setdefault(k, {}).update(v, pct_timed=100.0 * v["total_us"] / tot)
         res["timed_kernel_us_per_step"] = tot / steps
-        lines.append("sum over kernels: %.1f us per step" % (tot / steps))
+        lines.append("sum over kernels: %.1f us per step   (TRACED durations)" % (tot / steps))
+    if os.path.exists(bench_json):
+        try:
+            bd = json.loads(open(bench_json).read().strip().splitlines()[-1])
+            lines.append("== the same command UNTRACED on the same box (bench.py, hipEvent pairs around every launch; %d timed steps): us per launch"
+                         % bd.get("steps", 0))
+            for k, v in bd.get("kernels", {}).items():
+                lines.append("%-48s launches=%4d avg_us=%10.2f  per step %8.4f ms%s" % (
+                    k, v["launches"], v["avg_us"], v["ms_per_step"], ("  frac %.4f (%s)" % (v["frac"], v["bound"])) if "frac" in v else ""))
+            lines.append("untraced: %.4f ms per step (host wall), %.4f (device), kernels %.4f; value %.0f agent-steps/s" % (
+                bd["ms_per_step"], bd.get("ms_per_step_device", 0.0), bd.get("kernel_time_ms_per_step", 0.0), bd["value"]))
+            res["untraced"] = {"ms_per_step": bd["ms_per_step"], "value": bd["value"],
+                               "kernels": {k: {"avg_us": v["avg_us"], "launches": v["launches"]} for k, v in bd.get("kernels", {}).items()}}
+        except Exception as e:
+            lines.append("(untraced bench line unreadable: %r)" % (e,))
     st = find(os.path.join(out, "trace"), "*kernel_stats.csv")
     if st:
         lines.append("== rocprofv3 --kernel-trace --stats as the tool prints it (ALL launches, warm-up steps included): durations (ns)")
@@ -184,6 +209,13 @@ def main():
         if "hbm_bytes_per_launch" in v:
             lines.append("%-28s read=%.1f MB write=%.1f MB" % (k, v["hbm_read_bytes_per_launch"] / 1e6,
                                                               v["hbm_write_bytes_per_launch"] / 1e6))
+    fused = [k for k in res["kernels"] if k.startswith(("csr_fused_scores", "csr_fused_hop", "csr_rank"))]
+    if fused and all("hbm_bytes_per_launch" in res["kernels"][k] for k in fused):
+        tb = sum(res["kernels"][k]["hbm_bytes_per_launch"] for k in fused)
+        tu = sum(res["kernels"][k].get("median_us", 0.0) for k in fused)
+        lines.append("== bf16-storage graph LAYER (config 5; degree ranking + score kernel + hop / tap kernel): %.1f MB of HBM traffic per step, "
+                     "%.1f us (traced medians)" % (tb / 1e6, tu))
+        res["csr_fused_layer"] = {"hbm_bytes_per_step": tb, "traced_us": tu}
     with open(os.path.join(out, "summary_%s.txt" % tag), "w") as f:
         f.write("\n".join(lines) + "\n")
     import datetime
