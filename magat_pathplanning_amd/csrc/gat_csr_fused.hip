@@ -239,10 +239,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_scores_kernel(const F
         }
     }
     STAMP(1)
-    // edge loop: slot k = the k-th edge of every row of the group.  The kernels are bound by the number of REQUESTS the texture
-    // path takes (about one per cycle and CU; every lane of a scattered access is one: profiles/r06a), so: neighbour indices
-    // four slots per load, the raw scores of the first eight slots stay in registers (no store + read-back), attention as
-    // [edge][head] (one store per lane and slot).
+    // edge loop: slot k = the k-th edge of every row of the group.  Both kernels run at the rate a CU gathers random 128-byte lines
+    // out of L2 (~16 GB/s per CU whatever the instruction shape: DESIGN.md 4.5), so everything that is NOT a row gather is kept
+    // small: neighbour indices four slots per load, the raw scores of the first eight slots in registers (no store + read-back),
+    // attention as [edge][head] (one store per lane and slot).
     float mx[HO], sm[HO];
 #pragma unroll
     for (int o = 0; o < HO; ++o) {
@@ -562,9 +562,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void csr_fused_hop_kernel(const Fuse
           }
         } else {
           // bf16 rows through a wave-private 4 KB stage (two column tiles = 128 bytes of 32 rows): a lane's 16-byte pieces are
-          // 32 rows apart in memory - 64 texture-path requests per store instruction, 1024 per step, a fifth of what this
-          // kernel issues (it is bound by their number: profiles/r06a) - transposed, eight lanes write a row's 128-byte run
-          // (16 requests per instruction).  16-byte units XOR-swizzled by the row pair: conflict-free both ways.
+          // 32 rows apart in memory (64 separate pieces per store instruction, 1024 per step); transposed, eight lanes write a
+          // row's 128-byte run.  16-byte units XOR-swizzled by the row pair: conflict-free both ways.  (-2.5 % of the kernel.)
           char* const stg = lds + HP * 65536 + wave * 4096;
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
