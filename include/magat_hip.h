@@ -627,7 +627,8 @@ int magat_mfma_sustained_f16_ex(double* tflops, double* clock_mhz, double* per_c
 #define MAGAT_FORM_GUARD_ONE 7    /* range guard of the encoder as one predicated launch */
 #define MAGAT_FORM_CSR_FUSED 8    /* bf16-storage CSR layer with the maps inside the graph kernels (gat_csr_fused.hip) */
 #define MAGAT_FORM_GAT_MID 9      /* one-launch graph layer for G = F in {32, 64} on 33 .. 128 agents (gat_mid.hip) */
-#define MAGAT_FORMS 10
+#define MAGAT_FORM_CHAIN_LAT 10   /* chain kernel, latency form: one agent per workgroup (block_lat.hip; option LAT_AGENTS) */
+#define MAGAT_FORMS 11
 long long magat_form_count(int id);
 int magat_form_reset(void);
 

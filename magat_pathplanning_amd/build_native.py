@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "libmagat_hip.so")
 LIB_DEBUG = os.path.join(PKG, "lib", "libmagat_hip_debug.so")
-SOURCES = ["conv_gemm_f32.hip", "conv_gemm_bf16x6.hip", "block_fused.hip", "gat_f32.hip", "gat_mfma.hip", "gat_small.hip", "gat_mid.hip", "gat_csr_f32.hip", "gat_csr_fused.hip",
+SOURCES = ["conv_gemm_f32.hip", "conv_gemm_bf16x6.hip", "block_fused.hip", "block_lat.hip", "gat_f32.hip", "gat_mfma.hip", "gat_small.hip", "gat_mid.hip", "gat_csr_f32.hip", "gat_csr_fused.hip",
            "encoder_f32.hip", "layer1_fused.hip", "stem8.hip", "conv_train.hip", "sim_frontend.hip", "profile.hip", "options.hip"]
 HEADERS = ["magat_common.h", "block_walk.h", os.path.join("..", "..", "include", "magat_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value", "-Wno-inline-asm"]

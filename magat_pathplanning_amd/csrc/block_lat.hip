@@ -1,0 +1,284 @@
+// Latency form of the BasicBlock chain (layer1.conv2 + downsample -> layer2 -> layer3 -> ReLU -> 2x2 sum-pool; reference
+// graphs/models/resnet_pytorch.py:40-73 BasicBlock, :495-524 forward) for the reference's own inference loop, which steps ONE
+// planning instance at a time (configs/dcpGAT_OE_Random.json:58 "test_batch_size": 1; agents/decentralplannerlocal_OnlineExpert_GAT.py
+// :1030-1055).  block_full_p_kernel (block_fused.hip) gives a workgroup EIGHT agents - rows of the implicit GEMMs are (pixel, agent)
+// pairs, nine 32-row tiles by tap-validity class, 13 428 matrix instructions per group - which fills the chip from 2 048 agents on
+// and leaves 10 .. 100 agents walking 136 k cycles on 2 .. 13 of 256 CUs.  Here a workgroup owns ONE agent:
+//   rows = the 36 pixels of its 6 x 6 maps = TWO row tiles (32 + 4 pixels; the second tile is 7/8 padding, and still the walk is
+//   18 tile-taps per k step against 69), every map in LDS with a ZERO BORDER (slot = 7 (y + 1) + (x + 1): one zero column
+//   serves as right border of a row and left border of the next), so every tap of every pixel is one ds_read_b128 at a
+//   compile-time offset - no validity classes, no zero-pixel selects; 2 460 matrix instructions per agent.
+//   Maps (f16 plane pairs, [plane][8-channel chunk][64 slots][16 B]): 88 KB, nothing aliased - layer3's 128-channel
+//   intermediate map fits whole.
+// Same weights (encoder.pack_chain_weights / pack_block3_weights fragments), same products in the same order per output element
+// (tap-major, k step, three plane products; a tap the eight-agent form skips for a whole tile contributes exact zeros here),
+// same split-and-store epilogues, and the 2 x 2 pooling adds pair up the pixels of a cell exactly as block_full_p_kernel's
+// in-register pooling does (corner cells: the two diagonals; edge-middle cells of the top / bottom row: the two columns; the other
+// cells: the two rows) - the pooled map is BIT-IDENTICAL to the eight-agent form's (tests/test_gpu_latency.py).
+#include "magat_common.h"
+
+namespace {
+#include "block_walk.h"
+
+namespace lat {
+constexpr int SLOTS = 64;
+constexpr int BLK1 = SLOTS * 16;                  // bytes of one (plane, chunk) block of one agent
+constexpr int M32 = 8 * BLK1, M64 = 16 * BLK1;   // 32- / 64-channel map: 2 planes x 4 / 8 chunks
+constexpr int L_X1 = 0, L_X2 = M32, L_Y = 2 * M32, L_Z = 3 * M32, L_IN3 = L_Z + M64, L_MA = L_IN3 + M64, L_MB = L_MA + M64,
+              L_TOTAL = L_MB + M64;              // 88 KB
+constexpr int RP = 7;                             // row pitch in slots
+constexpr int MINSH = -(RP + 1);                  // smallest tap shift: lane bases point there, immediates stay non-negative
+constexpr int D = 8;                              // weight ring: fragments of k step s + 7 requested under k step s
+constexpr int AV = 3;                             // operand ring, as in walk4
+constexpr int DEADSLOT = 60;                      // where the 28 padding lanes of the second row tile store (slots 0 .. 56 are the map)
+}  // namespace lat
+
+struct LatParams {
+  const char* in1; const char* in2;               // stem8's outputs: layer1.conv1 map, stem stride-2 pixels (f16 plane granules, 32 ch)
+  const char* wA; const char* wB; const char* wC; const char* w1; const char* w2a; const char* w2b;
+  const float* bA; const float* bB; const float* bC; const float* b1; const float* b2;
+  const float* sA; const float* sB; const float* sC; const float* s1; const float* s2;
+  float* out; int out_gl; int M; int* range_flag;
+};
+
+// The K walk of one wave over NT row tiles: 9 taps x KSM k steps over the map at in_off, then KS2 k steps of the residual 1 x 1
+// segment over the map at in2_off (same pixel).  ab[s]: the lane's byte offset of (its slot + MINSH) in chunk fh of a map.
+template <int NT, int KSM, int KS2, int PS_IN, int PS_IN2>
+__device__ __forceinline__ void walk1(char* lds, const unsigned (&ab)[NT], int in_off, int in2_off, const char* wbase,
+                                      unsigned lane16, f32x16 (&acc)[NT]) {
+  using namespace lat;
+  constexpr int NMAIN = 9 * KSM, NSTEP = NMAIN + KS2, NI = NSTEP * NT;
+  u32x4 w[D][2];
+  auto load_w = [&](int step, u32x4 (&b)[2]) {
+    b[0] = *reinterpret_cast<const u32x4*>(wbase + (size_t)step * 2048 + lane16);
+    b[1] = *reinterpret_cast<const u32x4*>(wbase + (size_t)step * 2048 + (lane16 + 1024u));
+  };
+  u32x4 av[AV][2];
+  auto rd = [&](int i, int pl, u32x4& dst) {
+    const int step = i / NT, s = i % NT;
+    if (step >= NMAIN) {
+      const int ks = step - NMAIN;
+      dst = *reinterpret_cast<const u32x4*>(lds + (ab[s] + (unsigned)in2_off) + (-MINSH * 16 + pl * PS_IN2 + ks * 2 * BLK1));
+    } else {
+      const int tp = step / KSM, ks = step % KSM;
+      const int sh = RP * (tp / 3 - 1) + (tp % 3 - 1) - MINSH;
+      dst = *reinterpret_cast<const u32x4*>(lds + (ab[s] + (unsigned)in_off) + (sh * 16 + pl * PS_IN + ks * 2 * BLK1));
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < D - 1; ++j)
+    if (j < NSTEP) load_w(j, w[j]);
+#pragma unroll
+  for (int j = 0; j < AV - 1; ++j)
+    if (j < NI) {
+      rd(j, 0, av[j][0]);
+      rd(j, 1, av[j][1]);
+    }
+#pragma clang loop unroll(full)
+  for (int i = 0; i < NI; ++i) {
+    const int step = i / NT, s = i % NT;
+    if (s == 0 && step + D - 1 < NSTEP) load_w(step + D - 1, w[(step + D - 1) % D]);
+    constexpr int LA = AV - 1;
+    const bool more = i + LA < NI;
+    acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[step % D][0]),
+                                                    __builtin_bit_cast(f16x8, av[i % AV][0]), acc[s], 0, 0, 0);
+    W4_PIN();
+    if (more) { rd(i + LA, 0, av[(i + LA) % AV][0]); W4_PIN(); }
+    acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[step % D][1]),
+                                                    __builtin_bit_cast(f16x8, av[i % AV][0]), acc[s], 0, 0, 0);
+    W4_PIN();
+    if (more) { rd(i + LA, 1, av[(i + LA) % AV][1]); W4_PIN(); }
+    acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[step % D][0]),
+                                                    __builtin_bit_cast(f16x8, av[i % AV][1]), acc[s], 0, 0, 0);
+    if (NT == 1) asm volatile("" : "+a"(acc[s]));      // (a lone accumulator chain is otherwise moved behind the whole walk's loads)
+    W4_PIN();
+  }
+}
+
+// one convolution of a wave: walk, then relu(acc * scale + bias) as f16 plane chunks of the output map (COUT channels; this wave's
+// 32 channels are chunk pair ct_out of it) - the arithmetic of chain_stage4 / epi_to_lds (block_fused.hip)
+template <int NT, int CIN, int C2, int COUT>
+__device__ __forceinline__ void lat_stage(char* lds, const unsigned (&ab)[NT], const unsigned (&sl16)[NT], const bool (&live)[NT],
+                                          int in_off, int in2_off, int out_off, const char* wts, int ct_out, const float* bias32,
+                                          float scale, unsigned lane16, bool& clamped) {
+  using namespace lat;
+  constexpr int KSM = CIN / 16, KS2 = C2 / 16;
+  constexpr int PS_OUT = (COUT / 8) * BLK1;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int s = 0; s < NT; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  walk1<NT, KSM, KS2, (CIN / 8) * BLK1, (C2 > 0 ? C2 / 8 : 1) * BLK1>(lds, ab, in_off, in2_off, wts, lane16, acc);
+  const int fh = (int)(lane16 >> 9);
+  f32x4 bq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bias32 + 8 * q + 4 * fh);
+#pragma unroll
+  for (int s = 0; s < NT; ++s) {
+    float cl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      unsigned h1[4], h2[4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int q = 2 * ks + e;
+        const f32x2 v01 = __builtin_elementwise_fma(f32x2{acc[s][4 * q], acc[s][4 * q + 1]}, f32x2{scale, scale}, f32x2{bq[q][0], bq[q][1]});
+        const f32x2 v23 = __builtin_elementwise_fma(f32x2{acc[s][4 * q + 2], acc[s][4 * q + 3]}, f32x2{scale, scale}, f32x2{bq[q][2], bq[q][3]});
+        split2(v01[0], v01[1], h1[2 * e], h2[2 * e], cl);
+        split2(v23[0], v23[1], h1[2 * e + 1], h2[2 * e + 1], cl);
+      }
+      // (no branch around the stores: the padding lanes of the second tile write to a slot no tap reads - with the stores under
+      //  a condition the compiler sinks the whole walk into the conditional block)
+      char* o = lds + out_off + ((ct_out * 2 + ks) * 2 + fh) * BLK1 + sl16[s];
+      *reinterpret_cast<u32x4*>(o) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+      *reinterpret_cast<u32x4*>(o + PS_OUT) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+    }
+    clamped |= cl > 65504.f && live[s];
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
+  using namespace lat;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int m = blockIdx.x;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int fr = lane & 31, fh = lane >> 5;
+  // the lane's pixels: tile s, column fr -> position g = 32 s + fr = 4 cell + e in pooled-cell order; the order of a cell's four
+  // pixels over its quad of lanes is the pairing of block_full_p_kernel's in-register pooling (file header)
+  unsigned abT[2], slT[2];
+  bool liveT[2];
+  int cellT[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int g = 32 * s + fr;
+    const bool lv = g < NPIX;
+    const int cell = lv ? g >> 2 : 0, e = g & 3;
+    const int cy = cell / 3, cx = cell - 3 * cy;
+    const bool corner = cy != 1 && cx != 1, rowmid = cx == 1 && cy != 1;
+    const int dy = corner ? (e == 1 || e == 3) : rowmid ? (e & 1) : (e >> 1);
+    const int dx = corner ? (e == 1 || e == 2) : rowmid ? (e >> 1) : (e & 1);
+    const int slot = lv ? RP * (2 * cy + dy + 1) + (2 * cx + dx + 1) : RP + 1;
+    slT[s] = (unsigned)(lv ? slot : DEADSLOT) * 16u;
+    abT[s] = (unsigned)(slot + MINSH) * 16u + (unsigned)fh * BLK1;
+    liveT[s] = lv;
+    cellT[s] = cell;
+  }
+  // the agent's two input maps: 2 x 36 pixels x 8 (plane, chunk) pieces of 16 B, requested in front of the LDS clear
+  u32x4 piece[3];
+  unsigned pdst[3];
+  {
+    const long long tile_b = (long long)(m >> 7) * NPIX * (128 * 32 * 4) + (m & 127) * 16;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int id = t + 256 * i;
+      const int map = id >= 8 * NPIX, r = id - map * 8 * NPIX;
+      const int pix = r >> 3, blk = r & 7;
+      const int y = pix / 6, x = pix - 6 * y;
+      pdst[i] = (unsigned)((map ? L_X2 : L_X1) + blk * BLK1 + (RP * (y + 1) + x + 1) * 16);
+      if (id < 16 * NPIX)
+        piece[i] = *reinterpret_cast<const u32x4*>((map ? p.in2 : p.in1) + tile_b + (long long)pix * (128 * 32 * 4) +
+                                                    (blk >> 2) * (256 * 32) + (blk & 3) * 2048);
+    }
+  }
+  const float sA = *p.sA, sB = *p.sB, sC = *p.sC, s1 = *p.s1, s2 = *p.s2;
+  for (int i = t; i < L_TOTAL / 16; i += 256) *reinterpret_cast<u32x4*>(lds + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+  L3_LDS_SYNC();
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (t + 256 * i < 16 * NPIX) *reinterpret_cast<u32x4*>(lds + pdst[i]) = piece[i];
+  __syncthreads();
+  bool clamped = false;
+  const int ct = wave & 1, tl = wave >> 1;
+  const unsigned ab1[1] = {tl ? abT[1] : abT[0]}, sl1[1] = {tl ? slT[1] : slT[0]};
+  const bool lv1[1] = {tl ? liveT[1] : liveT[0]};
+  // A: layer1.conv2 (32 -> 32) + downsample(stem stride-2 pixels)   X1, X2 -> Y      (one channel tile: waves 0 / 1 = row tile 0 / 1)
+  if (wave < 2) {
+    const unsigned abA[1] = {wave ? abT[1] : abT[0]}, slA[1] = {wave ? slT[1] : slT[0]};
+    const bool lvA[1] = {wave ? liveT[1] : liveT[0]};
+    lat_stage<1, 32, 32, 32>(lds, abA, slA, lvA, L_X1, L_X2, L_Y, p.wA, 0, p.bA, sA, lane16, clamped);
+  }
+  __syncthreads();
+  // B: layer2.conv1 (32 -> 64)   Y -> Z      (wave = channel tile x row tile)
+  lat_stage<1, 32, 0, 64>(lds, ab1, sl1, lv1, L_Y, 0, L_Z, p.wB + (size_t)ct * (18 * 2) * 1024, ct, p.bB + 32 * ct, sB, lane16, clamped);
+  __syncthreads();
+  // C: layer2.conv2 (64 -> 64) + downsample(Y)   Z, Y -> layer3's input
+  lat_stage<1, 64, 32, 64>(lds, ab1, sl1, lv1, L_Z, L_Y, L_IN3, p.wC + (size_t)ct * (38 * 2) * 1024, ct, p.bC + 32 * ct, sC, lane16,
+                           clamped);
+  __syncthreads();
+  // layer3.conv1 (64 -> 128): wave = channel tile, both row tiles; channels 0..63 -> MA, 64..127 -> MB (the two K halves of conv2)
+  lat_stage<2, 64, 0, 64>(lds, abT, slT, liveT, L_IN3, 0, wave < 2 ? L_MA : L_MB, p.w1 + (size_t)wave * 72 * 1024, wave & 1,
+                          p.b1 + 32 * wave, s1, lane16, clamped);
+  __syncthreads();
+  // layer3.conv2 (128 -> 128) + downsample(layer3's input): K over MA, then over MB + the residual segment - the eight-agent form's
+  // order - then relu(acc * s2 + bias), the 2 x 2 sums across each quad of lanes, one store per cell and channel quad
+  {
+    f32x16 acc[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+    walk1<2, 4, 0, 8 * BLK1, 8 * BLK1>(lds, abT, L_MA, 0, p.w2a + (size_t)wave * 72 * 1024, lane16, acc);
+    walk1<2, 4, 4, 8 * BLK1, 8 * BLK1>(lds, abT, L_MB, L_IN3, p.w2b + (size_t)wave * 80 * 1024, lane16, acc);
+    f32x4 bq[4];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const f32x4*>(p.b2 + 32 * wave + 8 * qd + 4 * fh);
+    float* ob = p.out + (long long)(m >> 7) * 9 * (128 * 128) +
+                (p.out_gl ? (8 * wave + fh) * 512 + (m & 127) * 4 : (m & 127) * 128 + 32 * wave + 4 * fh);
+    const int qstep = p.out_gl ? 1024 : 8;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float a = magat_relu(__builtin_fmaf(acc[s][4 * qd + c], s2, bq[qd][c]));
+          const float pr = a + dpp_mov<0xB1>(a);            // + the lane's partner in its pair (quad_perm [1,0,3,2])
+          v[c] = pr + dpp_mov<0x4E>(pr);                    // + the other pair (quad_perm [2,3,0,1])
+        }
+        if (liveT[s] && (fr & 3) == 0) *reinterpret_cast<f32x4*>(ob + (long long)cellT[s] * (128 * 128) + qstep * qd) = v;
+      }
+    }
+  }
+  if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
+}
+
+}  // namespace
+
+static size_t lat_chain_block_bytes(int cin, int c2, int cout) { return (size_t)(cout / 32) * (9 * (cin / 16) + c2 / 16) * 2 * 1024; }
+
+// Arguments: those of magat_block_full (block_fused.hip); one workgroup per agent.
+int magat_block_lat(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
+                    float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st,
+                    const float* scales, int out_gl) {
+  if (!in1 || !in2 || !wchain || !bA || !bB || !bC || !out || !w3 || !b1 || !b2) return MAGAT_ERR_NULL;
+  if (M <= 0) return MAGAT_ERR_BAD_SHAPE;
+  if (out_gl != 0 && out_gl != 1) return MAGAT_ERR_UNSUPPORTED;
+  LatParams p;
+  p.in1 = static_cast<const char*>(in1); p.in2 = static_cast<const char*>(in2);
+  const char* wb = reinterpret_cast<const char*>(wchain);
+  const size_t nA = lat_chain_block_bytes(32, 32, 32), nB = lat_chain_block_bytes(32, 0, 64), nC = lat_chain_block_bytes(64, 32, 64);
+  p.wA = wb; p.wB = wb + nA + 16; p.wC = wb + nA + 16 + nB + 16;
+  p.bA = bA; p.bB = bB; p.bC = bC;
+  p.sA = reinterpret_cast<const float*>(p.wA + nA);
+  p.sB = reinterpret_cast<const float*>(p.wB + nB);
+  p.sC = reinterpret_cast<const float*>(p.wC + nC);
+  const char* w3b = reinterpret_cast<const char*>(w3);
+  const size_t n1 = (size_t)4 * 72 * 1024, n2a = (size_t)4 * 72 * 1024, n2b = (size_t)4 * 80 * 1024;
+  p.w1 = w3b; p.w2a = w3b + n1 + 16; p.w2b = w3b + n1 + 16 + n2a + 16;
+  p.s1 = reinterpret_cast<const float*>(p.w1 + n1);
+  p.s2 = reinterpret_cast<const float*>(p.w2b + n2b);
+  p.b1 = b1; p.b2 = b2;
+  if (scales) { p.sA = scales; p.sB = scales + 1; p.sC = scales + 2; p.s1 = scales + 3; p.s2 = scales + 4; }
+  p.out = out; p.out_gl = out_gl; p.M = M; p.range_flag = range_flag;
+  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block_lat_kernel), MAGAT_LDS_BLOCK_LAT, lat::L_TOTAL) != MAGAT_OK)
+    return MAGAT_ERR_LAUNCH;
+  magat_form_note(MAGAT_FORM_CHAIN_LAT);
+  const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_FULL, st);
+  hipLaunchKernelGGL(block_lat_kernel, dim3((unsigned)M), dim3(256), lat::L_TOTAL, st, p);
+  magat_prof_end(pid, st);
+  return magat_check_launch();
+}

@@ -445,8 +445,11 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
                          magat_opt(MAGAT_OPT_HEAD_F16) && magat_conv_direct_enabled() && !head_splitk &&
                          magat_block_full_out_gl();
     if (full_path) {
-      // both chain kernels as ONE launch: layer2's output map stays in LDS as layer3's input
-      rc = magat_block_full(buf[1], buf[0], pk + d->chain_off, sp ? sp + 928 : pk + d->off[5], sp ? sp + 960 : pk + d->off[7],
+      // both chain kernels as ONE launch: layer2's output map stays in LDS as layer3's input - with eight agents per workgroup, or,
+      // for the few agents of a batch-1 step (option LAT_AGENTS, chosen on the global agent count like the head's form), one
+      // agent per workgroup (block_lat.hip: the same pooled map bit for bit, 2 460 instead of 13 428 matrix instructions deep)
+      const bool lat = !rerun && Mform <= magat_opt(MAGAT_OPT_LAT_AGENTS);
+      rc = (lat ? magat_block_lat : magat_block_full)(buf[1], buf[0], pk + d->chain_off, sp ? sp + 928 : pk + d->off[5], sp ? sp + 960 : pk + d->off[7],
                             sp ? sp + 1024 : pk + d->off[9], buf[2], pk + d->chain3_off, sp ? sp + 1088 : pk + d->off[11],
                             sp ? sp + 1216 : pk + d->off[13], mm, reinterpret_cast<int*>(range_flag), st, sp ? sp + 1344 : nullptr,
                             head_gl ? 1 : 0);

@@ -51,6 +51,10 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
                      const float* scales = nullptr,       // 5 device floats replacing the 1 / weight-scale of stages A, B, C, layer3.conv1, conv2
                      int out_gl = 0);                     // 1: pooled map granule-major (when magat_block_full_out_gl())
 int magat_block_full_out_gl();
+// the same chain with ONE agent per workgroup (block_lat.hip: the latency form of few-agent calls; bit-identical pooled map)
+int magat_block_lat(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
+                    float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st,
+                    const float* scales = nullptr, int out_gl = 0);
 int magat_block3(const void* in, float* out, const float* w, const float* b1, const float* b2, int M, int* range_flag,
                  hipStream_t st);
 int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, long long out_pix_stride, long long out_tile,
@@ -67,7 +71,7 @@ enum MagatOpt {
   MAGAT_OPT_ENC_CHUNK, MAGAT_OPT_CONV_SPLIT, MAGAT_OPT_CONV_PCHAIN,
   MAGAT_OPT_L1_FUSED, MAGAT_OPT_HEAD_SPLITK, MAGAT_OPT_GAT_CHUNK_MB, MAGAT_OPT_GAT_SPLIT, MAGAT_OPT_RANGE_GUARD,
   MAGAT_OPT_BLOCK_FUSED, MAGAT_OPT_CSR_TILED, MAGAT_OPT_HEAD_F16, MAGAT_OPT_GAT_MFMA, MAGAT_OPT_SKINNY, MAGAT_OPT_GAT_PACK,
-  MAGAT_OPT_CONV_BNFILL, MAGAT_OPT_HEAD_COMPRESS, MAGAT_OPT_CONV_TM, MAGAT_OPT_CSR_FUSED, MAGAT_OPT_COUNT
+  MAGAT_OPT_CONV_BNFILL, MAGAT_OPT_HEAD_COMPRESS, MAGAT_OPT_CONV_TM, MAGAT_OPT_CSR_FUSED, MAGAT_OPT_LAT_AGENTS, MAGAT_OPT_COUNT
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)
@@ -89,7 +93,8 @@ enum MagatLdsSlot {
   MAGAT_LDS_CSR_FUSED_B = MAGAT_LDS_CSR_FUSED_A + 3,   // hop + tap kernel, 1 | 2 heads per workgroup
   MAGAT_LDS_CSR_FUSED_END = MAGAT_LDS_CSR_FUSED_B + 2,
   MAGAT_LDS_GATD_0 = MAGAT_LDS_CSR_FUSED_END,      // gat_mid.hip: 24 slots (width x taps x row tiles x merge)
-  MAGAT_LDS_GATD_END = MAGAT_LDS_GATD_0 + 24
+  MAGAT_LDS_GATD_END = MAGAT_LDS_GATD_0 + 24,
+  MAGAT_LDS_BLOCK_LAT    // block_lat.hip
 };
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of

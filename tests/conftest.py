@@ -1,3 +1,4 @@
+import ast
 import glob
 import os
 
@@ -35,7 +36,7 @@ def load_model_fixture(path):
     import torch
     z = np.load(path, allow_pickle=False)
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
-    cfg = types.SimpleNamespace(**eval(str(z["cfg"]), {"__builtins__": {}}))
+    cfg = types.SimpleNamespace(**ast.literal_eval(str(z["cfg"])))
     return z, sd, cfg
 
 

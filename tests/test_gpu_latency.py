@@ -1,0 +1,98 @@
+"""Latency forms of the batch-1 step (the reference's own inference loop: `test_batch_size = 1`,
+configs/dcpGAT_OE_Random.json:58; agents/decentralplannerlocal_OnlineExpert_GAT.py:1030-1055): few agents take kernels that
+spread ONE planning instance over the chip.  Every latency form is held against the form it replaces BIT FOR BIT, against
+the pinned oracle at the north star's gate, and the form counters say which one ran."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _build(cfg, sd, device):
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    cfg.device = str(device)
+    net = DecentralPlannerGATNet(cfg)
+    net.load_state_dict(sd, strict=True)
+    return net.to(device).eval()
+
+
+@pytest.mark.parametrize("B,N", [(1, 10), (1, 100), (1, 1), (3, 37), (2, 128), (1, 129), (1, 7)])
+def test_one_agent_per_workgroup_chain_equals_the_eight_agent_form(gpu_device, libopt, B, N):
+    """block_lat_kernel (one agent per workgroup, zero-bordered maps, two row tiles) against block_full_p_kernel (eight agents
+    per workgroup, nine row tiles by tap-validity class): the same products in the same order per output element and the same
+    pairing of a pooled cell's four pixels - logits equal bit for bit.  Agent counts on both sides of an agent tile (128)."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd import _native as nat
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat")
+    sd = orc.init_state_dict(cfg, seed=41 + N)
+    net = _build(cfg, sd, gpu_device)
+    x = fov_states(B, N, seed=5 + N).to(gpu_device)
+    S = comm_gso(B, N, 50, seed=6 + N).to(gpu_device)
+    lib = nat.lib()
+    with torch.no_grad():
+        net.addGSO(S.clone())
+        net(x)                                           # (the first forward folds the activation scales)
+        lib.magat_form_reset()
+        net.addGSO(S.clone())
+        lat = net(x).clone()
+        assert lib.magat_form_count(nat.FORMS["chain_lat"]) == 1
+        libopt.set("MAGAT_LAT_AGENTS", 0)
+        lib.magat_form_reset()
+        net.addGSO(S.clone())
+        eight = net(x).clone()
+        assert lib.magat_form_count(nat.FORMS["chain_lat"]) == 0
+    assert torch.equal(lat, eight)
+    ref = orc.planner_forward(x.cpu(), S.cpu().clone(), sd, cfg)
+    assert float((lat.cpu() - ref).abs().max()) <= TOL
+    st = net.range_status()
+    assert not st["encoder_rerun"] and not st["gat_rerun"], st
+
+
+def test_latency_form_is_chosen_on_the_global_agent_count(gpu_device):
+    """A shard of a large batch (form_agents = the global count, distributed.sharded_forward) keeps the batched forms even when
+    the shard itself is small: shards and the whole batch stay bit-identical with default options."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd import _native as nat
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N = 6, 100
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat")
+    sd = orc.init_state_dict(cfg, seed=3)
+    net = _build(cfg, sd, gpu_device)
+    x = fov_states(B, N, seed=1).to(gpu_device)
+    S = comm_gso(B, N, 50, seed=2).to(gpu_device)
+    lib = nat.lib()
+    with torch.no_grad():
+        net.addGSO(S.clone())
+        net(x)
+        lib.magat_form_reset()
+        net.addGSO(S.clone())
+        whole = net(x).clone()
+        assert lib.magat_form_count(nat.FORMS["chain_lat"]) == 0      # 600 agents: above LAT_AGENTS
+        net.form_agents = B * N
+        lib.magat_form_reset()
+        parts = []
+        for b in range(B):
+            net.addGSO(S[b:b + 1].contiguous())
+            parts.append(net(x[b:b + 1]).clone())
+        net.form_agents = 0
+        assert lib.magat_form_count(nat.FORMS["chain_lat"]) == 0
+    assert torch.equal(torch.cat(parts), whole)
+
+
+def test_latency_chain_range_guard_rerun(gpu_device, monkeypatch):
+    """A checkpoint whose maps leave the f16 planes' range inside the chain (layer2 / layer3 maps ~1e5, activation scales off):
+    the one-agent-per-workgroup kernel raises the encoder's flag like the eight-agent form, and the predicated float32 re-run
+    produces the logits (tests/test_gpu_range.py holds the whole table of cases; 80 agents take the latency form there too)."""
+    from magat_pathplanning_amd import _native as nat
+    from test_gpu_range import _run, _scaled_model
+    monkeypatch.setenv("MAGAT_ACT_SCALE", "0")
+    cfg, sd, net = _scaled_model(gpu_device, 1.0e5, where="layer2")
+    lib = nat.lib()
+    lib.magat_form_reset()
+    got, ref = _run(net, cfg, sd, gpu_device)
+    assert lib.magat_form_count(nat.FORMS["chain_lat"]) == 1
+    st = net.range_status()
+    assert st["encoder_rerun"], st
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
