@@ -532,6 +532,11 @@ typedef struct magat_encoder_desc {
   void* comp_bf16;    /* ABI 7: NULL, or [M][n_comp] bfloat16 rows that receive RNE-bf16(comp) as well: written by the epilogue that
                          produces comp where it can (compressMLP in the head's launch), by a cast pass otherwise; after a range-guard
                          re-run of the encoder they are rewritten from the float32 rows (same stream, predicated on the flag) */
+  int64_t headfrag_off; /* ABI 8: float offsets of the head's and compressMLP's weights as FRAGMENT-major f16 planes (encoder.
+                           pack_frag_natural: the values and scale of head16 / comp16 in the order a wave fetches them), 0 = absent.  With */
+  int64_t compfrag_off; /* both (ResNetLarge, 11 x 11 maps, n_feat = n_comp = 128) the few-agent encoder runs head and compressMLP in the
+                           epilogue of the one-agent-per-workgroup chain kernel (block_lat.hip; option LAT_AGENTS): two launches for the
+                           whole encoder, its results bit-identical to the batched forms (long-K f16x3 head, f16x3 compressMLP) */
 } magat_encoder_desc;
 /* Activation scales (ABI 3).  The split arithmetic carries a value as two f16 planes: exact for |v| <= 65504, but the SECOND
  * plane is a full 11-bit number only for |v| >~ 0.25 - a layer whose activations are all small (a small BatchNorm gamma: an
@@ -628,7 +633,8 @@ int magat_mfma_sustained_f16_ex(double* tflops, double* clock_mhz, double* per_c
 #define MAGAT_FORM_CSR_FUSED 8    /* bf16-storage CSR layer with the maps inside the graph kernels (gat_csr_fused.hip) */
 #define MAGAT_FORM_GAT_MID 9      /* one-launch graph layer for G = F in {32, 64} on 33 .. 128 agents (gat_mid.hip) */
 #define MAGAT_FORM_CHAIN_LAT 10   /* chain kernel, latency form: one agent per workgroup (block_lat.hip; option LAT_AGENTS) */
-#define MAGAT_FORMS 11
+#define MAGAT_FORM_HEAD_LAT 11    /* ... with the encoder head and compressMLP in its epilogue (ABI 8: headfrag_off / compfrag_off) */
+#define MAGAT_FORMS 12
 long long magat_form_count(int id);
 int magat_form_reset(void);
 

@@ -22,7 +22,7 @@ TAGS = {0: "untagged", 1: "conv_first", 2: "layer1.conv1", 3: "layer1.conv2+ds",
 TAG_ACTIONS = 12
 # magat_form_count ids (include/magat_hip.h MAGAT_FORM_*)
 FORMS = {"head_longk": 0, "head_splitk": 1, "gat_pack": 2, "gat_persist": 3, "gat_hsplit": 4, "chain_persist": 5,
-         "head_compress": 6, "guard_one": 7, "csr_fused": 8, "gat_mid": 9, "chain_lat": 10}
+         "head_compress": 6, "guard_one": 7, "csr_fused": 8, "gat_mid": 9, "chain_lat": 10, "head_lat": 11}
 
 _lock = threading.Lock()
 _lib = None
@@ -63,7 +63,8 @@ class EncoderDesc(ctypes.Structure):
                 ("n_feat", ctypes.c_int), ("n_comp", ctypes.c_int), ("pack", ctypes.c_void_p),
                 ("off", ctypes.c_int64 * 32), ("chain_off", ctypes.c_int64), ("chain3_off", ctypes.c_int64),
                 ("head16_off", ctypes.c_int64), ("comp16_off", ctypes.c_int64), ("scaled_off", ctypes.c_int64),
-                ("l1frag_off", ctypes.c_int64), ("form_agents", ctypes.c_int), ("comp_bf16", ctypes.c_void_p)]
+                ("l1frag_off", ctypes.c_int64), ("form_agents", ctypes.c_int), ("comp_bf16", ctypes.c_void_p),
+                ("headfrag_off", ctypes.c_int64), ("compfrag_off", ctypes.c_int64)]
 
 
 class SimStepDesc(ctypes.Structure):

@@ -30,6 +30,8 @@ constexpr int RP = 7;                             // row pitch in slots
 constexpr int MINSH = -(RP + 1);                  // smallest tap shift: lane bases point there, immediates stay non-negative
 constexpr int D = 8;                              // weight ring: fragments of k step s + 7 requested under k step s
 constexpr int AV = 3;                             // operand ring, as in walk4
+constexpr int L_HP = L_X1, HP_PLANE = 4 * 9 * 2 * 32;      // the head's activation planes (HEAD): 2 x 2304 B over the dead X1
+constexpr int L_CP = L_X2, CP_PLANE = 8 * 32;              // compressMLP's: 2 x 256 B over the dead X2
 constexpr int DEADSLOT = 60;                      // where the 28 padding lanes of the second row tile store (slots 0 .. 56 are the map)
 }  // namespace lat
 
@@ -39,7 +41,67 @@ struct LatParams {
   const float* bA; const float* bB; const float* bC; const float* b1; const float* b2;
   const float* sA; const float* sB; const float* sC; const float* s1; const float* s2;
   float* out; int out_gl; int M; int* range_flag;
+  // HEAD: the encoder head and compressMLP in the epilogue (no pooled map is written then)
+  const char* hfrag; const char* cfrag; const float* hbias; const float* cbias; const float* insc; const float* insc2;
+  float* feat; float* comp; int ldfeat, ldcomp;
 };
+
+// value pair -> its two f16 planes, remembering whether a value left +-65504: the instruction sequence of split_pair_f16
+// (conv_gemm_bf16x6.hip) - the float32 loaders of the long-K head and of compressMLP, whose planes this kernel reproduces
+__device__ __forceinline__ void split_pair_lat(float x, float y, unsigned& p1, unsigned& p2, bool& clamped) {
+  clamped |= !(__builtin_fabsf(x) <= 65504.f) | !(__builtin_fabsf(y) <= 65504.f);
+  x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+  y = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
+  const f16x2 h = __builtin_convertvector(f32x2{x, y}, f16x2);
+  p1 = __builtin_bit_cast(unsigned, h);
+  float rx, ry;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rx) : "v"(p1), "v"(x));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ry) : "v"(p1), "v"(y));
+  const f16x2 r = __builtin_convertvector(f32x2{rx, ry}, f16x2);
+  p2 = __builtin_bit_cast(unsigned, r);
+}
+
+// K walk of a dense layer on ONE row of activations (the agent's): NSTEP k steps of 16, the activation operand of step s at
+// lds + abase + 32 s (second plane PS bytes behind) - every column of the 32-wide tile carries the same row -, this wave's
+// 32 output channels' weight fragments at wbase (1 KB per plane and step)
+template <int NSTEP, int PS>
+__device__ __forceinline__ void walk_lin(char* lds, unsigned abase, const char* wbase, unsigned lane16, f32x16& acc) {
+  using namespace lat;
+  u32x4 w[D][2];
+  auto load_w = [&](int step, u32x4 (&b)[2]) {
+    b[0] = *reinterpret_cast<const u32x4*>(wbase + (size_t)step * 2048 + lane16);
+    b[1] = *reinterpret_cast<const u32x4*>(wbase + (size_t)step * 2048 + (lane16 + 1024u));
+  };
+  u32x4 av[AV][2];
+  auto rd = [&](int i, int pl, u32x4& dst) { dst = *reinterpret_cast<const u32x4*>(lds + abase + (32 * i + pl * PS)); };
+#pragma unroll
+  for (int j = 0; j < D - 1; ++j)
+    if (j < NSTEP) load_w(j, w[j]);
+#pragma unroll
+  for (int j = 0; j < AV - 1; ++j)
+    if (j < NSTEP) {
+      rd(j, 0, av[j][0]);
+      rd(j, 1, av[j][1]);
+    }
+#pragma clang loop unroll(full)
+  for (int i = 0; i < NSTEP; ++i) {
+    if (i + D - 1 < NSTEP) load_w(i + D - 1, w[(i + D - 1) % D]);
+    constexpr int LA = AV - 1;
+    const bool more = i + LA < NSTEP;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[i % D][0]), __builtin_bit_cast(f16x8, av[i % AV][0]),
+                                                 acc, 0, 0, 0);
+    W4_PIN();
+    if (more) { rd(i + LA, 0, av[(i + LA) % AV][0]); W4_PIN(); }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[i % D][1]), __builtin_bit_cast(f16x8, av[i % AV][0]),
+                                                 acc, 0, 0, 0);
+    W4_PIN();
+    if (more) { rd(i + LA, 1, av[(i + LA) % AV][1]); W4_PIN(); }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[i % D][0]), __builtin_bit_cast(f16x8, av[i % AV][1]),
+                                                 acc, 0, 0, 0);
+    asm volatile("" : "+a"(acc));
+    W4_PIN();
+  }
+}
 
 // The K walk of one wave over NT row tiles: 9 taps x KSM k steps over the map at in_off, then KS2 k steps of the residual 1 x 1
 // segment over the map at in2_off (same pixel).  ab[s]: the lane's byte offset of (its slot + MINSH) in chunk fh of a map.
@@ -138,6 +200,7 @@ __device__ __forceinline__ void lat_stage(char* lds, const unsigned (&ab)[NT], c
   }
 }
 
+template <bool HEAD>
 __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
   using namespace lat;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -228,6 +291,11 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
     float* ob = p.out + (long long)(m >> 7) * 9 * (128 * 128) +
                 (p.out_gl ? (8 * wave + fh) * 512 + (m & 127) * 4 : (m & 127) * 128 + 32 * wave + 4 * fh);
     const int qstep = p.out_gl ? 1024 : 8;
+    float insc = 1.f;
+    if (HEAD) {
+      if (p.insc) insc = *p.insc;
+      if (insc == 0.f) insc = 1.f;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -239,8 +307,75 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
           const float pr = a + dpp_mov<0xB1>(a);            // + the lane's partner in its pair (quad_perm [1,0,3,2])
           v[c] = pr + dpp_mov<0x4E>(pr);                    // + the other pair (quad_perm [2,3,0,1])
         }
-        if (liveT[s] && (fr & 3) == 0) *reinterpret_cast<f32x4*>(ob + (long long)cellT[s] * (128 * 128) + qstep * qd) = v;
+        const bool owner = liveT[s] && (fr & 3) == 0;
+        if (!HEAD) {
+          if (owner) *reinterpret_cast<f32x4*>(ob + (long long)cellT[s] * (128 * 128) + qstep * qd) = v;
+        } else {
+          // the head's activation planes: pooled value x its activation scale, split as the long-K head's float32 loader splits
+          // it; operand order [32-channel slab = this wave][cell][k step][lane half][8 halves] in the dead X1 region
+          bool cl = false;
+          unsigned h1[2], h2[2];
+          split_pair_lat(v[0] * insc, v[1] * insc, h1[0], h2[0], cl);
+          split_pair_lat(v[2] * insc, v[3] * insc, h1[1], h2[1], cl);
+          const unsigned o = (unsigned)(L_HP + ((wave * 9 + cellT[s]) * 2 + (qd >> 1)) * 32 + (qd & 1) * 16 + fh * 8);
+          if (owner) {
+            *reinterpret_cast<uint2*>(lds + o) = uint2{h1[0], h1[1]};
+            *reinterpret_cast<uint2*>(lds + o + HP_PLANE) = uint2{h2[0], h2[1]};
+          }
+          clamped |= cl && owner;
+        }
       }
+    }
+  }
+  if (HEAD) {
+    L3_LDS_SYNC();
+    // ---- encoder head: feat = W_head . pooled (K = 9 x 128 in the long-K kernel's order: 32-channel slab outer, cell inner) ----
+    float insc = 1.f, insc2 = 1.f;
+    if (p.insc) insc = *p.insc;
+    if (insc == 0.f) insc = 1.f;
+    if (p.insc2) insc2 = *p.insc2;
+    if (insc2 == 0.f) insc2 = 1.f;
+    f32x16 hacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+    walk_lin<72, HP_PLANE>(lds, (unsigned)(L_HP + fh * 16), p.hfrag + (size_t)wave * 72 * 2048, lane16, hacc);
+    {
+      const float hs = *reinterpret_cast<const float*>(p.hfrag + (size_t)4 * 72 * 2048) / insc;      // (exact: powers of two)
+      bool cl = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.hbias + 32 * wave + 8 * q + 4 * fh);
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = hacc[4 * q + c] * hs + bb[c];
+        if (fr == 0) *reinterpret_cast<f32x4*>(p.feat + (long long)m * p.ldfeat + 32 * wave + 8 * q + 4 * fh) = v;
+        // compressMLP's activation planes from the very values stored (x its activation scale), operand order
+        // [k step = 2 wave + q / 2][lane half = q % 2][4 fh + c] in the dead X2 region
+        unsigned h1[2], h2[2];
+        split_pair_lat(v[0] * insc2, v[1] * insc2, h1[0], h2[0], cl);
+        split_pair_lat(v[2] * insc2, v[3] * insc2, h1[1], h2[1], cl);
+        const unsigned o = (unsigned)(L_CP + (2 * wave + (q >> 1)) * 32 + (q & 1) * 16 + fh * 8);
+        if (fr == 0) {
+          *reinterpret_cast<uint2*>(lds + o) = uint2{h1[0], h1[1]};
+          *reinterpret_cast<uint2*>(lds + o + CP_PLANE) = uint2{h2[0], h2[1]};
+        }
+      }
+      clamped |= cl;
+    }
+    L3_LDS_SYNC();
+    // ---- compressMLP: comp = relu(W_c . feat + b_c) ----
+    f32x16 cacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
+    walk_lin<8, CP_PLANE>(lds, (unsigned)(L_CP + fh * 16), p.cfrag + (size_t)wave * 8 * 2048, lane16, cacc);
+    const float cs = *reinterpret_cast<const float*>(p.cfrag + (size_t)4 * 8 * 2048) / insc2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.cbias + 32 * wave + 8 * q + 4 * fh);
+      f32x4 v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = magat_relu(cacc[4 * q + c] * cs + bb[c]);
+      if (fr == 0) *reinterpret_cast<f32x4*>(p.comp + (long long)m * p.ldcomp + 32 * wave + 8 * q + 4 * fh) = v;
     }
   }
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
@@ -253,7 +388,7 @@ static size_t lat_chain_block_bytes(int cin, int c2, int cout) { return (size_t)
 // Arguments: those of magat_block_full (block_fused.hip); one workgroup per agent.
 int magat_block_lat(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
                     float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st,
-                    const float* scales, int out_gl) {
+                    const float* scales, int out_gl, const magat_lat_head* head) {
   if (!in1 || !in2 || !wchain || !bA || !bB || !bC || !out || !w3 || !b1 || !b2) return MAGAT_ERR_NULL;
   if (M <= 0) return MAGAT_ERR_BAD_SHAPE;
   if (out_gl != 0 && out_gl != 1) return MAGAT_ERR_UNSUPPORTED;
@@ -274,11 +409,24 @@ int magat_block_lat(const void* in1, const void* in2, const float* wchain, const
   p.b1 = b1; p.b2 = b2;
   if (scales) { p.sA = scales; p.sB = scales + 1; p.sC = scales + 2; p.s1 = scales + 3; p.s2 = scales + 4; }
   p.out = out; p.out_gl = out_gl; p.M = M; p.range_flag = range_flag;
-  if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&block_lat_kernel), MAGAT_LDS_BLOCK_LAT, lat::L_TOTAL) != MAGAT_OK)
-    return MAGAT_ERR_LAUNCH;
+  p.hfrag = p.cfrag = nullptr; p.hbias = p.cbias = p.insc = p.insc2 = nullptr; p.feat = p.comp = nullptr; p.ldfeat = p.ldcomp = 0;
+  if (head) {
+    if (!head->hfrag || !head->cfrag || !head->hbias || !head->cbias || !head->feat || !head->comp) return MAGAT_ERR_NULL;
+    if ((head->ldfeat & 3) || (head->ldcomp & 3) || head->ldfeat < 128 || head->ldcomp < 128 ||
+        ((reinterpret_cast<uintptr_t>(head->feat) | reinterpret_cast<uintptr_t>(head->comp) |
+          reinterpret_cast<uintptr_t>(head->hbias) | reinterpret_cast<uintptr_t>(head->cbias)) & 15))
+      return MAGAT_ERR_BAD_SHAPE;
+    p.hfrag = reinterpret_cast<const char*>(head->hfrag); p.cfrag = reinterpret_cast<const char*>(head->cfrag);
+    p.hbias = head->hbias; p.cbias = head->cbias; p.insc = head->insc; p.insc2 = head->insc2;
+    p.feat = head->feat; p.comp = head->comp; p.ldfeat = head->ldfeat; p.ldcomp = head->ldcomp;
+  }
+  const void* fn = head ? reinterpret_cast<const void*>(&block_lat_kernel<true>) : reinterpret_cast<const void*>(&block_lat_kernel<false>);
+  if (magat_ensure_dyn_lds(fn, head ? MAGAT_LDS_BLOCK_LAT_H : MAGAT_LDS_BLOCK_LAT, lat::L_TOTAL) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
   magat_form_note(MAGAT_FORM_CHAIN_LAT);
+  if (head) magat_form_note(MAGAT_FORM_HEAD_LAT);
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_FULL, st);
-  hipLaunchKernelGGL(block_lat_kernel, dim3((unsigned)M), dim3(256), lat::L_TOTAL, st, p);
+  if (head) hipLaunchKernelGGL(block_lat_kernel<true>, dim3((unsigned)M), dim3(256), lat::L_TOTAL, st, p);
+  else hipLaunchKernelGGL(block_lat_kernel<false>, dim3((unsigned)M), dim3(256), lat::L_TOTAL, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }

@@ -425,6 +425,9 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
                              (long long)MAGAT_TILE_ROWS * 32, (long long)H * W * MAGAT_TILE_ROWS * 32, stream, 0, lay,
                              range_flag, run_if, tagof(MAGAT_TAG_CONV_FIRST), absmax);
     if (rc != MAGAT_OK) return rc;
+    bool head_done = false;          // head + compressMLP ran in the chain kernel's epilogue (latency form)
+    bool compress_done = false;      // compressMLP rode in the head's epilogue
+    bool comp16_done = false;        // ... and wrote the bf16 rows (desc.comp_bf16) too
     int cur = 0;              // buffer holding the block input
     int hin = H, win = W;
     int lstart = 0;
@@ -449,7 +452,26 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
       // for the few agents of a batch-1 step (option LAT_AGENTS, chosen on the global agent count like the head's form), one
       // agent per workgroup (block_lat.hip: the same pooled map bit for bit, 2 460 instead of 13 428 matrix instructions deep)
       const bool lat = !rerun && Mform <= magat_opt(MAGAT_OPT_LAT_AGENTS);
-      rc = (lat ? magat_block_lat : magat_block_full)(buf[1], buf[0], pk + d->chain_off, sp ? sp + 928 : pk + d->off[5], sp ? sp + 960 : pk + d->off[7],
+      // ... which then runs the encoder head and compressMLP in its epilogue as well (ABI 8 fragment-major weights): the products
+      // of the long-K f16x3 head and of the f16x3 compressMLP in their order - feat / comp bit-identical to the batched forms
+      magat_lat_head lh = {};
+      if (lat && d->headfrag_off > 0 && d->compfrag_off > 0 && d->n_feat == 128 && d->n_comp == 128 && comp && split &&
+          magat_opt(MAGAT_OPT_HEAD_F16)) {
+        lh.hfrag = pk + d->headfrag_off; lh.cfrag = pk + d->compfrag_off;
+        lh.hbias = pk + d->off[15]; lh.cbias = pk + d->off[17];
+        lh.insc = d->scaled_off > 0 ? pk + d->scaled_off + 1349 : nullptr;
+        lh.insc2 = d->scaled_off > 0 ? pk + d->scaled_off + 1350 : nullptr;
+        lh.feat = feat + (size_t)m0 * ldfeat; lh.ldfeat = ldfeat;
+        lh.comp = comp + (size_t)m0 * ldcomp; lh.ldcomp = ldcomp;
+        head_done = true;
+      }
+      if (lat)
+        rc = magat_block_lat(buf[1], buf[0], pk + d->chain_off, sp ? sp + 928 : pk + d->off[5], sp ? sp + 960 : pk + d->off[7],
+                             sp ? sp + 1024 : pk + d->off[9], buf[2], pk + d->chain3_off, sp ? sp + 1088 : pk + d->off[11],
+                             sp ? sp + 1216 : pk + d->off[13], mm, reinterpret_cast<int*>(range_flag), st,
+                             sp ? sp + 1344 : nullptr, head_gl ? 1 : 0, head_done ? &lh : nullptr);
+      else
+      rc = magat_block_full(buf[1], buf[0], pk + d->chain_off, sp ? sp + 928 : pk + d->off[5], sp ? sp + 960 : pk + d->off[7],
                             sp ? sp + 1024 : pk + d->off[9], buf[2], pk + d->chain3_off, sp ? sp + 1088 : pk + d->off[11],
                             sp ? sp + 1216 : pk + d->off[13], mm, reinterpret_cast<int*>(range_flag), st, sp ? sp + 1344 : nullptr,
                             head_gl ? 1 : 0);
@@ -538,9 +560,9 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // order as its other chunks, or the batch would differ in the last bit from the same agents presented as shards.
     const int cells = (hin / 2) * (win / 2);
     const int split_max = magat_opt(MAGAT_OPT_HEAD_SPLITK);
-    bool compress_done = false;      // compressMLP rode in the head's epilogue
-    bool comp16_done = false;        // ... and wrote the bf16 rows (desc.comp_bf16) too
-    if (!absmax && !chained && cells > 1 && Mform <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
+    if (head_done) {
+      compress_done = true;
+    } else if (!absmax && !chained && cells > 1 && Mform <= split_max && (clast & 3) == 0 && (d->n_feat & 3) == 0 &&
         (size_t)cells * d->n_feat <= enc_buf_floats_per_agent(d)) {     // the partials must fit one map buffer
       float* part = buf[(cur + 1) % 3];                 // [cells][mm][n_feat]
       if (!rerun) magat_form_note(MAGAT_FORM_HEAD_SPLITK);

@@ -1287,7 +1287,7 @@ extern "C" int magat_gso_prepare(void* S, int s_is_f64, size_t count, int scrub_
   return magat_check_launch();
 }
 
-extern "C" int magat_abi_version(void) { return 7; }
+extern "C" int magat_abi_version(void) { return 8; }
 
 extern "C" const char* magat_error_string(int code) {
   switch (code) {

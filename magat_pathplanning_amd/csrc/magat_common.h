@@ -52,9 +52,15 @@ int magat_block_full(const void* in1, const void* in2, const float* wchain, cons
                      int out_gl = 0);                     // 1: pooled map granule-major (when magat_block_full_out_gl())
 int magat_block_full_out_gl();
 // the same chain with ONE agent per workgroup (block_lat.hip: the latency form of few-agent calls; bit-identical pooled map)
+struct magat_lat_head {      // ... with the encoder head (9 x 128 -> 128) and compressMLP (128 -> 128) in its epilogue
+  const float* hfrag; const float* cfrag;       // fragment-major f16 planes + [2^-e, 0, 0, 0] (encoder.pack_frag_natural)
+  const float* hbias; const float* cbias;
+  const float* insc; const float* insc2;        // activation scales of the two layers' inputs (device floats; null / 0 = 1)
+  float* feat; int ldfeat; float* comp; int ldcomp;
+};
 int magat_block_lat(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
                     float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st,
-                    const float* scales = nullptr, int out_gl = 0);
+                    const float* scales = nullptr, int out_gl = 0, const magat_lat_head* head = nullptr);
 int magat_block3(const void* in, float* out, const float* w, const float* b1, const float* b2, int M, int* range_flag,
                  hipStream_t st);
 int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, long long out_pix_stride, long long out_tile,
@@ -94,7 +100,7 @@ enum MagatLdsSlot {
   MAGAT_LDS_CSR_FUSED_END = MAGAT_LDS_CSR_FUSED_B + 2,
   MAGAT_LDS_GATD_0 = MAGAT_LDS_CSR_FUSED_END,      // gat_mid.hip: 24 slots (width x taps x row tiles x merge)
   MAGAT_LDS_GATD_END = MAGAT_LDS_GATD_0 + 24,
-  MAGAT_LDS_BLOCK_LAT    // block_lat.hip
+  MAGAT_LDS_BLOCK_LAT, MAGAT_LDS_BLOCK_LAT_H    // block_lat.hip (without / with the head in the epilogue)
 };
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of

@@ -178,6 +178,21 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
             comp16 = torch.cat((comp16, torch.zeros(pad)))
         comp16_off = pack.numel()
         pack = torch.cat([pack, comp16]).contiguous()
+    # the head and compressMLP once more FRAGMENT-major (ABI 8; csrc/block_lat.hip: the one-agent-per-workgroup encoder of the
+    # batch-1 step runs both layers in the chain kernel's epilogue): the same f16 planes and scale as head16 / comp16, in the
+    # order a wave fetches them - no weight slab through LDS there, 1 KB blocks straight into registers
+    headfrag_off = compfrag_off = 0
+    if chain3_off and n_comp == 128 and n_feat == 128 and clast == 128 and Hp * Wp == 9:
+        nxt = sorted(o for o in offs[:18] if o > offs[14])
+        hrows = pack[offs[14]:(nxt[0] if nxt else n_f32)].reshape(n_feat, Hp * Wp * clast)
+        # k steps in the long-K head's order (conv_gemm_bf16x6.hip direct kernel, korder 1): 32-channel slab outer, pooled cell
+        # inner, two 16-channel k steps per (slab, cell)
+        hsteps = [cell * clast + 32 * cs + 16 * ks for cs in range(clast // 32) for cell in range(Hp * Wp) for ks in range(2)]
+        headfrag_off = pack.numel()
+        pack = torch.cat([pack, pack_frag_natural(hrows, hsteps)]).contiguous()
+        crows = pack[offs[16]:offs[16] + n_comp * n_feat].reshape(n_comp, n_feat)
+        compfrag_off = pack.numel()
+        pack = torch.cat([pack, pack_frag_natural(crows, [16 * ks for ks in range(n_feat // 16)])]).contiguous()
     # layer1.conv1 fragment-major for the eight-agent-group stem kernel (csrc/block_fused.hip stem8_kernel; 11x11 maps)
     l1frag_off = 0
     if H == 11 and W == 11:
@@ -186,7 +201,8 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
         l1frag_off = pack.numel()
         pack = torch.cat([pack, pack_chain_weights(w1rows, 32, 0)]).contiguous()
     meta = dict(variant=0 if large else 1, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast, chain=chain_off,
-                chain3=chain3_off, head16=head16_off, comp16=comp16_off, l1frag=l1frag_off)
+                chain3=chain3_off, head16=head16_off, comp16=comp16_off, l1frag=l1frag_off, headfrag=headfrag_off,
+                compfrag=compfrag_off)
     return pack, offs, meta
 
 
@@ -295,6 +311,33 @@ def pack_chain_weights(w, cin, c2, e=None):
                 row = (32 * ct + n_in).view(64, 1).expand(64, 8)
                 for plane in (h1, h2):
                     out.append(plane[row, col].reshape(-1))
+    blk = torch.cat(out).view(torch.int16)
+    return torch.cat((blk.view(torch.float32), torch.tensor([2.0 ** (-e), 0.0, 0.0, 0.0], dtype=torch.float32)))
+
+
+def pack_frag_natural(w, steps):
+    """[Cout][K] float32 rows -> fragment-major f16 planes with the k values in NATURAL order: for channel tile ct and k step s
+    (steps[s] = first column of its 16) one 1 KB block per plane [64 lanes][8 halves] - lane l holds, for output channel
+    32 ct + (l & 31), the weights of columns steps[s] + 8 (l >> 5) + i, i = 0..7: the A operand of v_mfma_f32_32x32x16_f16
+    against an activation operand formed from float32 values in channel order (the long-K head's and compressMLP's loaders,
+    conv_gemm_bf16x6.hip).  Planes and scale exactly as split_f16x2 makes them (h1 = f16(w 2^e), h2 = f16(w 2^e - h1)); 4 floats
+    [2^-e, 0, 0, 0] follow."""
+    w = w.detach().float().cpu()
+    cout = w.shape[0]
+    assert cout % 32 == 0
+    mx = float(w.abs().max())
+    e = 0 if mx == 0.0 else 13 - int(math.floor(math.log2(mx)))
+    e = max(-14, min(e, 24))
+    ws = w * (2.0 ** e)
+    h1 = ws.half()
+    h2 = (ws - h1.float()).half()
+    lane = torch.arange(64)
+    st = torch.tensor(steps, dtype=torch.long)
+    col = st.view(-1, 1, 1) + 8 * (lane >> 5).view(1, 64, 1) + torch.arange(8).view(1, 1, 8)      # [step][lane][8]
+    out = []
+    for ct in range(cout // 32):
+        row = (32 * ct + (lane & 31)).view(1, 64, 1).expand(len(steps), 64, 8)
+        out.append(torch.stack((h1[row, col], h2[row, col]), dim=1).reshape(-1))                    # [step][plane][lane][8]
     blk = torch.cat(out).view(torch.int16)
     return torch.cat((blk.view(torch.float32), torch.tensor([2.0 ** (-e), 0.0, 0.0, 0.0], dtype=torch.float32)))
 

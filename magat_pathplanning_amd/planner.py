@@ -329,6 +329,8 @@ class DecentralPlannerGATNet(nn.Module):
             d.head16_off = meta.get("head16", 0)
             d.comp16_off = meta.get("comp16", 0)
             d.l1frag_off = meta.get("l1frag", 0)
+            d.headfrag_off = meta.get("headfrag", 0)
+            d.compfrag_off = meta.get("compfrag", 0)
             d.scaled_off = 0
             rt.desc = d
         else:

@@ -18,10 +18,13 @@ def _build(cfg, sd, device):
 
 
 @pytest.mark.parametrize("B,N", [(1, 10), (1, 100), (1, 1), (3, 37), (2, 128), (1, 129), (1, 7)])
-def test_one_agent_per_workgroup_chain_equals_the_eight_agent_form(gpu_device, libopt, B, N):
-    """block_lat_kernel (one agent per workgroup, zero-bordered maps, two row tiles) against block_full_p_kernel (eight agents
-    per workgroup, nine row tiles by tap-validity class): the same products in the same order per output element and the same
-    pairing of a pooled cell's four pixels - logits equal bit for bit.  Agent counts on both sides of an agent tile (128)."""
+def test_one_agent_per_workgroup_encoder_equals_the_batched_forms(gpu_device, libopt, B, N):
+    """block_lat_kernel - one agent per workgroup: the BasicBlock chain on zero-bordered maps with two row tiles, then the encoder
+    head and compressMLP in its epilogue - against the BATCHED forms of the same layers run on the same few agents (options
+    LAT_AGENTS = 0, HEAD_SPLITK = 0: block_full_p_kernel with eight agents per workgroup and nine row tiles by tap-validity
+    class, the long-K f16x3 head, the f16x3 compressMLP): the same products in the same order per output element, the same
+    pairing of a pooled cell's four pixels, the same plane splits - logits equal BIT FOR BIT.  Agent counts on both sides of an
+    agent tile (128)."""
     from oracle import magat_oracle as orc
     from magat_pathplanning_amd import _native as nat
     from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
@@ -37,17 +40,50 @@ def test_one_agent_per_workgroup_chain_equals_the_eight_agent_form(gpu_device, l
         lib.magat_form_reset()
         net.addGSO(S.clone())
         lat = net(x).clone()
-        assert lib.magat_form_count(nat.FORMS["chain_lat"]) == 1
+        assert lib.magat_form_count(nat.FORMS["chain_lat"]) == 1 and lib.magat_form_count(nat.FORMS["head_lat"]) == 1
+        assert lib.magat_form_count(nat.FORMS["head_splitk"]) == 0 and lib.magat_form_count(nat.FORMS["head_longk"]) == 0
         libopt.set("MAGAT_LAT_AGENTS", 0)
+        libopt.set("MAGAT_HEAD_SPLITK", 0)
         lib.magat_form_reset()
         net.addGSO(S.clone())
-        eight = net(x).clone()
-        assert lib.magat_form_count(nat.FORMS["chain_lat"]) == 0
-    assert torch.equal(lat, eight)
+        batched = net(x).clone()
+        assert lib.magat_form_count(nat.FORMS["chain_lat"]) == 0 and lib.magat_form_count(nat.FORMS["head_longk"]) == 1
+    assert torch.equal(lat, batched)
     ref = orc.planner_forward(x.cpu(), S.cpu().clone(), sd, cfg)
     assert float((lat.cpu() - ref).abs().max()) <= TOL
     st = net.range_status()
     assert not st["encoder_rerun"] and not st["gat_rerun"], st
+
+
+@pytest.mark.parametrize("N", [10, 100])
+def test_batch_one_step_equals_its_rows_of_a_large_batch(gpu_device, N):
+    """The reference's inference loop presents ONE planning instance per step; a benchmark (or a shard of BASELINE config 3)
+    presents hundreds.  With the latency forms the logits of an instance do not depend on which: alone (one agent per
+    workgroup, head in the chain kernel's epilogue, a workgroup per attention head) or as rows of a 6 400-agent batch
+    (eight-agent groups, long-K head, packed / persistent graph kernel) - bit for bit."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd import _native as nat
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B = 6400 // N
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat")
+    sd = orc.init_state_dict(cfg, seed=77)
+    net = _build(cfg, sd, gpu_device)
+    x = fov_states(B, N, seed=8).to(gpu_device)
+    S = comm_gso(B, N, 50 if N > 20 else 20, seed=9).to(gpu_device)
+    lib = nat.lib()
+    with torch.no_grad():
+        net.addGSO(S.clone())
+        net(x)
+        lib.magat_form_reset()
+        net.addGSO(S.clone())
+        whole = net(x).clone()
+        assert lib.magat_form_count(nat.FORMS["chain_lat"]) == 0 and lib.magat_form_count(nat.FORMS["head_longk"]) == 1
+        for b in (0, 1, B // 2, B - 1):
+            lib.magat_form_reset()
+            net.addGSO(S[b:b + 1].clone())
+            alone = net(x[b:b + 1]).clone()
+            assert lib.magat_form_count(nat.FORMS["head_lat"]) == 1
+            assert torch.equal(alone, whole[b * N:(b + 1) * N]), (N, b, float((alone - whole[b * N:(b + 1) * N]).abs().max()))
 
 
 def test_latency_form_is_chosen_on_the_global_agent_count(gpu_device):
