@@ -17,7 +17,9 @@ float32 matrix-core kernels); BatchNorm / ReLU / pooling and the MLPs train thro
 """
 import ctypes
 import hashlib
+import operator
 import os
+import types
 
 import torch
 import torch.nn as nn
@@ -54,6 +56,32 @@ CAL_AGENTS = 2048      # agents of the canonical calibration batch (synthetic.ca
 
 from .train_cnn import convlayers_forward  # noqa: E402
 
+_DATA_PTR = torch.Tensor.data_ptr
+_VERSION = operator.attrgetter("_version")
+# Registration epoch: bumped whenever ANY module of the process registers a parameter, buffer or submodule (torch's global
+# registration hooks; `m.weight = nn.Parameter(..)` and `seq[0] = nn.Linear(..)` go through them) - what tells _weights_key that
+# its cached tensor list may no longer be the module tree's.  Without the hooks (an older torch) the list is re-derived per call.
+_REG_EPOCH = [0]
+
+
+def _bump_reg_epoch(*_a):
+    _REG_EPOCH[0] += 1
+
+
+def _install_registration_hooks():
+    from torch.nn.modules import module as tm
+    names = ("register_module_parameter_registration_hook", "register_module_buffer_registration_hook",
+             "register_module_module_registration_hook")
+    if not all(hasattr(tm, n) for n in names):
+        return False
+    for n in names:
+        getattr(tm, n)(_bump_reg_epoch)
+    return True
+
+
+_REG_HOOKED = _install_registration_hooks()
+
+
 class _Runtime:
     """Device-side caches of one module instance (never pickled)."""
 
@@ -65,6 +93,7 @@ class _Runtime:
         self.buffers = {}
         self.ws = None
         self.csr = CsrStructure()      # CSR + CSC structure of the GSO (large graphs / bf16 storage), made at addGSO
+        self.plan = None               # step plan of the last plain forward (DecentralPlannerGATNet._plan_build)
         self.calibrated = True         # activation scales of the split arithmetic folded for the current weights
         self.act_scales = None
         self.digest = None             # fingerprint of the folded encoder pack (what a calibration belongs to)
@@ -152,9 +181,13 @@ class DecentralPlannerGATNet(nn.Module):
             self.actionsMLP = nn.Sequential(nn.Linear(width, numAction))
         self.apply(weights_init)
         self._rt = _Runtime()
+        self._flat, self._flat_age, self._flat_epoch = None, 0, -1     # cached tensor list of _weights_key
         # agent count the batch-size-dependent kernel forms are chosen on (0: each call's own); set around a shard's forward by
         # distributed.sharded_forward (magat_encoder_desc.form_agents)
         self.form_agents = 0
+        # host side of the step: reuse everything that does not change between two forwards of the same shape (_plan_build);
+        # False = resolve buffers / workspaces / arguments on every call (the general path the plan is tested against)
+        self.step_plan = True
         # layer magnitudes the activation scales are folded from: {"digest", "absmax", "source"}.  Unlike _rt it IS pickled: a
         # spawned worker that unpickles the same weights folds the same exponents without measuring anything
         self._cal = None
@@ -164,12 +197,15 @@ class DecentralPlannerGATNet(nn.Module):
         st = self.__dict__.copy()
         st["_rt"] = None
         st["S"] = None
+        st["_flat"] = None
         return st
 
     def __setstate__(self, st):
         super().__setstate__(st)
         self._rt = _Runtime()
+        self._flat, self._flat_age, self._flat_epoch = None, 0, -1
         self.__dict__.setdefault("_cal", None)       # (modules pickled before the calibration record existed)
+        self.__dict__.setdefault("step_plan", True)
 
     # ------------------------------------------------------------------ boundary
     def addGSO(self, S):
@@ -276,28 +312,55 @@ class DecentralPlannerGATNet(nn.Module):
         return self.actionsMLP(shared)
 
     # ------------------------------------------------------------------ inference path (HIP)
-    def _weights_key(self, dev):
-        """(address, version) of every parameter and buffer of the module tree: what the folded / packed weights of the HIP
-        path were made from.  An iterative walk over the module dicts - the closed-loop step of one planning instance is
-        host-bound, and nn.Module.parameters() / buffers() (recursive generators with a memo set) were two thirds of a
-        forward's host time.  Changes under any of: load_state_dict / in-place updates (version), .to() / a replaced
-        Parameter (address), a replaced or added submodule (walked afresh every call)."""
-        key = [dev]
+    def _walk_tensors(self):
+        """Every parameter and buffer of the module tree, in a fixed walk order (an iterative walk over the module dicts:
+        nn.Module.parameters() / buffers() are recursive generators with a memo set, several times slower)."""
+        flat = []
         stack = [self]
         while stack:
             m = stack.pop()
             for t in m._parameters.values():
                 if t is not None:
-                    key.append(t.data_ptr())
-                    key.append(t._version)
+                    flat.append(t)
             for t in m._buffers.values():
                 if t is not None:
-                    key.append(t.data_ptr())
-                    key.append(t._version)
+                    flat.append(t)
             for c in m._modules.values():
                 if c is not None:
                     stack.append(c)
-        return tuple(key)
+        return flat
+
+    def _weights_key(self, dev):
+        """(device, addresses, versions) of every parameter and buffer of the module tree: what the folded / packed weights of
+        the HIP path were made from.  It sits on the critical path of the closed-loop step (nothing can be launched before
+        it), so the tensors are visited through a cached flat list with two C-level maps (6 us instead of 18 for the ~70
+        tensors of the reference's model).  Changes under any of: load_state_dict / optimizer steps / in-place updates
+        (version), .to() / .data assignment (address), a replaced Parameter / buffer / submodule anywhere in the tree (the
+        registration epoch above: the list is re-derived).  The list is also re-derived on _apply() / load_state_dict()
+        (overridden below), after unpickling and on every 64th call (the backstop for surgery on the module dicts themselves:
+        `del m._parameters[..]`; `invalidate_weights()` makes the next forward see that at once)."""
+        flat = self._flat
+        self._flat_age += 1
+        if flat is None or self._flat_epoch != _REG_EPOCH[0] or (self._flat_age & 63) == 0 or not _REG_HOOKED:
+            walked = self._walk_tensors()
+            self._flat_epoch = _REG_EPOCH[0]
+            if flat is None or len(walked) != len(flat) or any(a is not b for a, b in zip(walked, flat)):
+                flat = self._flat = walked
+        return (dev, tuple(map(_DATA_PTR, flat)), tuple(map(_VERSION, flat)))
+
+    def invalidate_weights(self):
+        """Forget the cached tensor list and the folded weights: the next forward re-derives everything from the module tree."""
+        self._flat = None
+        if self._rt is not None:
+            self._rt.key = None
+
+    def _apply(self, fn, *a, **kw):
+        self._flat = None
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._flat = None
+        return super().load_state_dict(*a, **kw)
 
     def _refresh(self, dev):
         rt = self._rt
@@ -529,6 +592,87 @@ class DecentralPlannerGATNet(nn.Module):
             self._rt.buffers[name] = t
         return t
 
+    # ------------------------------------------------------------------ step plan (host side of the closed-loop step)
+    def _plan_build(self, rt, B, N, dev):
+        """Everything of a forward that does not change from step to step, resolved ONCE for (these weights, this batch shape,
+        this device): buffers, workspaces, packed graph-layer weights, the ctypes arguments of the three C-ABI calls.  The
+        closed-loop step of one planning instance is HOST-bound (device 58 us, Python + launches 100 us at N = 10,
+        profiles/r06d): the general path re-derives all of this per call.  Built after a forward through the general path
+        (which allocates and calibrates); None when the configuration is not the plain dense float32 one."""
+        lib = nat.lib()
+        layer = self.GFL[0]
+        sc = layer._scratch
+        G, nfm, M = self.numFeatures2Share, self.numFeatureMap, B * N
+        if (layer.storage_dtype == torch.bfloat16 or self.config.use_dropout or rt.ws is None or sc.workspace is None or
+                sc.packed is None or not rt.calibrated or not lib.magat_gat_dense_supported(N, G, layer.F) or
+                self.skip not in ("skipConcat", "skipConcatGNN", "skipAddGNN", "only", "legacy")):
+            return None
+        b = rt.buffers
+        feat, comp, gat = b.get("feat"), b.get("comp"), b.get("gat")
+        if feat is None or comp is None or gat is None or feat.shape[0] != M or gat.shape[0] != M:
+            return None
+        pl = types.SimpleNamespace()
+        pl.rt_key, pl.B, pl.N, pl.dev, pl.dev_index = rt.key, B, N, dev, dev.index
+        pl.ws, pl.gws, pl.packed, pl.x_scale = rt.ws, sc.workspace, sc.packed, sc.x_scale
+        pl.feat, pl.comp, pl.gat = feat, comp, gat
+        pl.bias = None if layer.bias is None else layer.bias.detach().to(dev, torch.float32).reshape(-1).contiguous()
+        F, K, P = layer.F, layer.K, layer.P
+        mode = _MODES[layer.attentionMode]
+        concat = 1 if layer.concatenate else 0
+        pl.enc_tail = (nat.ptr(feat), nfm, nat.ptr(comp), G, nat.ptr(rt.ws), rt.ws.numel(), M)
+        pl.gat_head = nat.ptr(comp)
+        pl.gat_tail = (nat.ptr(sc.packed), nat.ptr(pl.bias), nat.ptr(gat), gat.stride(0), None, nat.ptr(sc.workspace),
+                       sc.workspace.numel(), B, N, G, F, K, P, mode, concat, None)
+        nout = rt.act[0].shape[0]
+        d = nat.ConvGemmDesc()
+        if self.skip in ("skipConcat", "skipConcatGNN", "skipAddGNN"):
+            src = feat if self.skip == "skipConcat" else comp
+            d.inp, d.Cin, d.lda = src.data_ptr(), src.shape[1], src.stride(0)
+            d.in2, d.C2, d.lda2 = gat.data_ptr(), gat.shape[1], gat.stride(0)
+            d.W2, d.stride2 = 1, 1
+        else:
+            d.inp, d.Cin, d.lda = gat.data_ptr(), gat.shape[1], gat.stride(0)
+        d.wt, d.bias = rt.act[0].data_ptr(), rt.act[1].data_ptr()
+        d.M, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad, d.Hout, d.Wout = M, 1, 1, 1, 1, 1, 0, 1, 1
+        d.Cout, d.ldc, d.relu = nout, nout, 0
+        d.tag = nat.TAG_ACTIONS
+        pl.act, pl.act_ref, pl.nout = d, ctypes.byref(d), nout
+        pl.desc_ref = ctypes.byref(rt.desc)
+        return pl
+
+    def _plan_step(self, pl, rt, x, M, dev):
+        """One forward through a step plan: three C-ABI calls (encoder, graph layer, action head) and one allocation (the
+        logits).  Same kernels, same arguments as the general path."""
+        lib = nat.lib()
+        layer = self.GFL[0]
+        S = self.S
+        rt.desc.form_agents = max(0, int(self.form_agents or 0))
+        rt.desc.comp_bf16 = None
+        switch = torch.cuda.current_device() != pl.dev_index
+        if switch:
+            prev = torch.cuda.current_device()
+            torch.cuda.set_device(pl.dev_index)
+        try:
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            rc = lib.magat_encoder_forward_f32(pl.desc_ref, ctypes.c_void_p(x.data_ptr()), *pl.enc_tail, stream)
+            if rc:
+                nat.check(rc, "magat_encoder_forward_f32")
+            layer.addGSO(S)
+            rc = lib.magat_gat_forward_planned_f32(pl.gat_head, ctypes.c_void_p(S.data_ptr()), 1 if S.dtype == torch.float64 else 0,
+                                                   *pl.gat_tail, stream)
+            if rc:
+                nat.check(rc, "magat_gat_forward_planned_f32")
+            layer.aij = None
+            out = torch.empty(M, pl.nout, dtype=torch.float32, device=dev)
+            pl.act.out = out.data_ptr()
+            rc = lib.magat_conv_gemm_f32(pl.act_ref, stream)
+            if rc:
+                nat.check(rc, "magat_conv_gemm_f32(actionsMLP.0)")
+        finally:
+            if switch:
+                torch.cuda.set_device(prev)
+        return out
+
     @torch.no_grad()
     def _forward_hip(self, x, B, N):
         if not x.is_cuda:
@@ -539,6 +683,27 @@ class DecentralPlannerGATNet(nn.Module):
         M = B * N
         rt = self._refresh(dev)
         x = x.contiguous().float()
+        G = self.numFeatures2Share
+        nfm = self.numFeatureMap
+        layer0 = self.GFL[0]
+        S = self.S
+        plain = (S.is_cuda and S.shape[-1] == N and S.shape[0] == B and S.is_contiguous() and S.device == dev and
+                 S.dtype in (torch.float32, torch.float64) and not layer0.return_attention and
+                 not getattr(self.config, "return_attentionGSO", False))
+        plain = plain and self.step_plan
+        pl = rt.plan
+        if (plain and pl is not None and pl.rt_key is rt.key and pl.B == B and pl.N == N and pl.dev == dev and pl.ws is rt.ws and
+                pl.gws is layer0._scratch.workspace and pl.packed is layer0._scratch.packed and
+                pl.x_scale == layer0._scratch.x_scale and rt.calibrated):
+            return self._plan_step(pl, rt, x, M, dev)
+        rt.plan = None
+        out = self._forward_general(rt, x, B, N, M, dev)
+        if plain:
+            rt.plan = self._plan_build(rt, B, N, dev)
+        return out
+
+    def _forward_general(self, rt, x, B, N, M, dev):
+        lib = nat.lib()
         G = self.numFeatures2Share
         nfm = self.numFeatureMap
         with torch.cuda.device(dev):
@@ -655,6 +820,8 @@ class DecentralPlannerNet(DecentralPlannerGATNet):
             self.actionsMLP = nn.Sequential(nn.Linear(nif, numAction))
         self.apply(weights_init)
         self._rt = _Runtime()
+        self._flat, self._flat_age, self._flat_epoch = None, 0, -1
+        self.step_plan = True
         self.form_agents = 0
         self._cal = None
 

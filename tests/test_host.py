@@ -280,7 +280,7 @@ def test_weights_key_sees_every_way_the_weights_can_change():
     k0 = net._weights_key(dev)
     assert net._weights_key(dev) == k0
     n_tensors = sum(1 for _ in net.parameters()) + sum(1 for _ in net.buffers())
-    assert len(k0) == 1 + 2 * n_tensors                      # every tensor is in it
+    assert len(k0) == 3 and len(k0[1]) == n_tensors and len(k0[2]) == n_tensors      # every tensor is in it (addresses, versions)
     with torch.no_grad():
         next(net.parameters()).add_(1.0)
     k1 = net._weights_key(dev)
