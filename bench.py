@@ -730,7 +730,7 @@ def main():
             xw = fov_states(Bw, Nw, seed=11).to(dev)
             Sw = comm_gso(Bw, Nw, mw, seed=12).to(dev)
             wsteps = esteps if wl == "c2" else max(3, esteps // 2)
-            el, kw, _ = run_leg(xw, Sw, wsteps, 2, timing, net=netw)
+            el, kw, _ = run_leg(xw, Sw, wsteps, 6, timing, net=netw)
             leg = {"workload": "%s: N=%d, %dx%d map, K=%d, P=%d, F=%d, batch %d%s" % (
                        wl, Nw, mw, mw, Kw, Pw, Gw, Bw, ", CSR GSO, bf16 storage in the graph layer" if wl == "c5" else ""),
                    "steps": wsteps, "value": round(Bw * Nw * wsteps / el, 1), "unit": "agent-steps/s",
@@ -763,7 +763,7 @@ def main():
                            CNN_mode=cnw, AttentionConcat=ccw, device=str(dev), gat_storage="fp32")
         netw = build_model(cfgw, dev)
         xw, Sw = fov_states(Bw, Nw, seed=13).to(dev), comm_gso(Bw, Nw, mw, seed=14).to(dev)
-        el, kw, _ = run_leg(xw, Sw, esteps, 3, timing, net=netw)
+        el, kw, _ = run_leg(xw, Sw, esteps, 24, timing, net=netw)      # (a fresh model's first ~15 steps can carry a one-off 60-90 ms runtime stall: tools/exp/pub_probe.py)
         leg = {"workload": "published MAGAT F-32-P4 (scripts/train_DMap.sh:42): N=%d, %dx%d map, K=%d, P=%d, G=F=%d, head-mean, "
                            "BottomNeck_only, batch %d" % (Nw, mw, mw, Kw, Pw, Gw, Bw),
                "steps": esteps, "value": round(Bw * Nw * esteps / el, 1), "unit": "agent-steps/s",
@@ -782,7 +782,7 @@ def main():
                            CNN_mode=cnw, AttentionConcat=ccw, device=str(dev), gat_storage="fp32")
         netw = build_model(cfgw, dev)
         xw, Sw = fov_states(Bw, Nw, seed=15).to(dev), comm_gso(Bw, Nw, mw, seed=16).to(dev)
-        el, kw, _ = run_leg(xw, Sw, esteps, 3, timing, net=netw)
+        el, kw, _ = run_leg(xw, Sw, esteps, 24, timing, net=netw)      # (a fresh model's first ~15 steps can carry a one-off 60-90 ms runtime stall: tools/exp/pub_probe.py)
         leg = {"workload": "published MAGAT F-32-P4 on the 100-robot set (README.md:372-390): N=%d, %dx%d map, K=%d, P=%d, G=F=%d, "
                            "head-mean, batch %d" % (Nw, mw, mw, Kw, Pw, Gw, Bw),
                "steps": esteps, "value": round(Bw * Nw * esteps / el, 1), "unit": "agent-steps/s",

@@ -50,8 +50,11 @@ const char* magat_error_string(int code);
 
 /* Options.  Every tunable of the library lives in one table that is seeded from the environment (MAGAT_<NAME>) ONCE, at
  * first use, and is read / changed through these calls afterwards; nothing on the launch path calls getenv.  `name` with
- * or without the MAGAT_ prefix.  All eighteen (round 5: the A/B switches of kernel forms that lost their measurements are gone
- * with those forms; round 6: + CSR_FUSED; csrc/options.hip holds the table):
+ * or without the MAGAT_ prefix.  All nineteen (round 5: the A/B switches of kernel forms that lost their measurements are gone
+ * with those forms; round 6: + CSR_FUSED, LAT_AGENTS; csrc/options.hip holds the table):
+ *   LAT_AGENTS (256) largest agent count (magat_encoder_desc.form_agents when set) whose encoder runs ONE AGENT PER WORKGROUP
+ *                    (csrc/block_lat.hip: layer1.conv2 .. layer3, pool, head and compressMLP in one launch; the batch-1 step of the
+ *                    reference's inference loop); results bit-identical to the eight-agent-group kernels; 0 = never
  *   RANGE_GUARD (1)  split-arithmetic range guard (encoder and graph layer): see magat_encoder_read_status
  *   CONV_SPLIT  (7)  bit l: BasicBlock l+1 on the f16x3 split kernels; 0 = every convolution on the fp32 MFMA kernel (strict float32)
  *   CONV_PCHAIN (1), CONV_TM (2)  activation layout / tile height of the f16x3 split GEMMs (f16 plane granules against
