@@ -44,6 +44,10 @@ struct LatParams {
   // HEAD: the encoder head and compressMLP in the epilogue (no pooled map is written then)
   const char* hfrag; const char* cfrag; const float* hbias; const float* cbias; const float* insc; const float* insc2;
   float* feat; float* comp; int ldfeat, ldcomp;
+  // GUARD (HEAD only): the encoder's range guard inside this launch - raw state maps, float32 BN-folded weights (encoder pack
+  // offsets 0..17), the status block of the workspace (book[0] working flag, [1] re-run count, [2] this forward's flag, [6]
+  // arrival counter); null = the guard's predicated launches follow as for every other form
+  const float* x; const float* pk; long long off[18]; int* book;
 };
 
 // value pair -> its two f16 planes, remembering whether a value left +-65504: the instruction sequence of split_pair_f16
@@ -200,6 +204,100 @@ __device__ __forceinline__ void lat_stage(char* lds, const unsigned (&ab)[NT], c
   }
 }
 
+// ---- the range guard's float32 re-run of ONE agent inside the latency kernel: when a plane of this agent clamped (or the stem's
+// did), the workgroup recomputes the agent from its raw state maps in plain float32 FMAs on the BN-folded float32 weights - the
+// layers of enc_run_resnet's float32 pass (encoder_f32.hip), maps in LDS as [channel][pixel].  Slow (a few hundred us) and never
+// taken by a sane checkpoint; it replaces two predicated launches per forward, which cost ~15 us of a 95 us step.
+// out[co][px] = act(bias[co] + sum_tap sum_c w[co][tap Cin + c] in[c][nb(px, tap)] + sum_c2 w[co][9 Cin + c2] res[c2][rpx])
+__device__ __forceinline__ void lat_conv_f32(const float* in, int Cin, int Win, int stride, const float* __restrict__ w, int Krow,
+                                             const float* __restrict__ bias, const float* res, int Cres, int Wres, int rstride,
+                                             float* out, int Cout) {
+  const int inpix = Win * Win, respix = Wres * Wres;
+  for (int idx = threadIdx.x; idx < Cout * 36; idx += 256) {
+    const int co = idx / 36, px = idx - 36 * co, oy = px / 6, ox = px - 6 * oy;
+    const float* wr = w + (long long)co * Krow;
+    float acc = bias[co];
+    for (int ty = 0; ty < 3; ++ty) {
+      const int iy = oy * stride + ty - 1;
+      if (iy < 0 || iy >= Win) continue;
+      for (int tx = 0; tx < 3; ++tx) {
+        const int ix = ox * stride + tx - 1;
+        if (ix < 0 || ix >= Win) continue;
+        const float* ip = in + iy * Win + ix;
+        const float* wp = wr + (ty * 3 + tx) * Cin;
+        for (int c = 0; c < Cin; ++c) acc = __builtin_fmaf(wp[c], ip[c * inpix], acc);
+      }
+    }
+    if (res) {
+      const float* rp = res + (oy * rstride) * Wres + ox * rstride;
+      const float* wp = wr + 9 * Cin;
+      for (int c = 0; c < Cres; ++c) acc = __builtin_fmaf(wp[c], rp[c * respix], acc);
+    }
+    out[idx] = magat_relu(acc);
+  }
+}
+
+__device__ void lat_fallback_f32(const LatParams& p, int m, float* L) {
+  const int t = threadIdx.x;
+  float* const XIN = L, *const A0 = L + 384, *const B1 = L + 4256, *const Y1 = L + 5408, *const B2 = L + 6560, *const Y2 = L + 8864,
+         *const B3 = L + 11168, *const Y3 = L + 15776, *const PL = L + 20384, *const FT = L + 21536;
+  const float* pk = p.pk;
+  for (int i = t; i < 363; i += 256) XIN[i] = p.x[(long long)m * 363 + i];
+  __syncthreads();
+  // stem: conv3x3(3 -> 32, pad 1) + BN + ReLU on 11 x 11; weights [32][c 9 + ty 3 + tx]
+  for (int idx = t; idx < 32 * 121; idx += 256) {
+    const int co = idx / 121, px = idx - 121 * co, oy = px / 11, ox = px - 11 * oy;
+    const float* wr = pk + p.off[0] + co * 27;
+    float acc = pk[p.off[1] + co];
+    for (int c = 0; c < 3; ++c)
+      for (int ty = 0; ty < 3; ++ty) {
+        const int iy = oy + ty - 1;
+        if (iy < 0 || iy >= 11) continue;
+        for (int tx = 0; tx < 3; ++tx) {
+          const int ix = ox + tx - 1;
+          if (ix < 0 || ix >= 11) continue;
+          acc = __builtin_fmaf(wr[c * 9 + ty * 3 + tx], XIN[c * 121 + iy * 11 + ix], acc);
+        }
+      }
+    A0[idx] = magat_relu(acc);
+  }
+  __syncthreads();
+  // layer1: conv1 stride 2, conv2 + downsample (1 x 1, stride 2, over the stem map)
+  lat_conv_f32(A0, 32, 11, 2, pk + p.off[2], 288, pk + p.off[3], nullptr, 0, 1, 1, B1, 32);
+  __syncthreads();
+  lat_conv_f32(B1, 32, 6, 1, pk + p.off[4], 288 + 32, pk + p.off[5], A0, 32, 11, 2, Y1, 32);
+  __syncthreads();
+  lat_conv_f32(Y1, 32, 6, 1, pk + p.off[6], 288, pk + p.off[7], nullptr, 0, 1, 1, B2, 64);
+  __syncthreads();
+  lat_conv_f32(B2, 64, 6, 1, pk + p.off[8], 576 + 32, pk + p.off[9], Y1, 32, 6, 1, Y2, 64);
+  __syncthreads();
+  lat_conv_f32(Y2, 64, 6, 1, pk + p.off[10], 576, pk + p.off[11], nullptr, 0, 1, 1, B3, 128);
+  __syncthreads();
+  lat_conv_f32(B3, 128, 6, 1, pk + p.off[12], 1152 + 64, pk + p.off[13], Y2, 64, 6, 1, Y3, 128);
+  __syncthreads();
+  // AvgPool2d(2) as a sum (the 1/4 lives in the head's weights) -> [cell][channel]
+  for (int idx = t; idx < 9 * 128; idx += 256) {
+    const int cell = idx >> 7, c = idx & 127, cy = cell / 3, cx = cell - 3 * cy;
+    const float* y = Y3 + c * 36 + (2 * cy) * 6 + 2 * cx;
+    PL[idx] = (y[0] + y[1]) + (y[6] + y[7]);
+  }
+  __syncthreads();
+  if (t < 128) {      // head: fc (+ Flatten + Linear) folded, [n_feat][cell 128 + c]
+    const float* wr = pk + p.off[14] + (long long)t * 1152;
+    float acc = pk[p.off[15] + t];
+    for (int k = 0; k < 1152; ++k) acc = __builtin_fmaf(wr[k], PL[k], acc);
+    FT[t] = acc;
+    p.feat[(long long)m * p.ldfeat + t] = acc;
+  }
+  __syncthreads();
+  if (t < 128) {      // compressMLP
+    const float* wr = pk + p.off[16] + (long long)t * 128;
+    float acc = pk[p.off[17] + t];
+    for (int k = 0; k < 128; ++k) acc = __builtin_fmaf(wr[k], FT[k], acc);
+    p.comp[(long long)m * p.ldcomp + t] = magat_relu(acc);
+  }
+}
+
 template <bool HEAD>
 __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
   using namespace lat;
@@ -207,6 +305,8 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int m = blockIdx.x;
+  int pre = 0;
+  if (HEAD && p.book) pre = __hip_atomic_load(p.book, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned lane16 = (unsigned)lane * 16u;
   const int fr = lane & 31, fh = lane >> 5;
   // the lane's pixels: tile s, column fr -> position g = 32 s + fr = 4 cell + e in pooled-cell order; the order of a cell's four
@@ -377,6 +477,28 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
       for (int c = 0; c < 4; ++c) v[c] = magat_relu(cacc[4 * q + c] * cs + bb[c]);
       if (fr == 0) *reinterpret_cast<f32x4*>(p.comp + (long long)m * p.ldcomp + 32 * wave + 8 * q + 4 * fh) = v;
     }
+    if (p.book) {
+      // ---- the encoder's range guard inside this launch (see lat_fallback_f32).  `pre`: the stem's clamp flag (final: the stem
+      // ran before this launch; a workgroup of THIS launch that already raised it only makes a later one recompute for nothing)
+      const int own = __syncthreads_or(clamped ? 1 : 0);
+      if (own | pre) lat_fallback_f32(p, m, reinterpret_cast<float*>(lds));
+      if (t == 0) {
+        if (own) {
+          __hip_atomic_fetch_or(p.book, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+        // bookkeeping by the workgroup that arrives last (magat_guard_book's protocol: this is the last reader of the flag)
+        const unsigned prev = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(p.book) + 6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+          const int f = __hip_atomic_load(p.book, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          p.book[2] = f;
+          if (f != 0) p.book[1] += 1;
+          __hip_atomic_store(p.book, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p.book + 6, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      return;
+    }
   }
   if (clamped && p.range_flag) atomicOr(p.range_flag, 1);
 }
@@ -388,7 +510,7 @@ static size_t lat_chain_block_bytes(int cin, int c2, int cout) { return (size_t)
 // Arguments: those of magat_block_full (block_fused.hip); one workgroup per agent.
 int magat_block_lat(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
                     float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st,
-                    const float* scales, int out_gl, const magat_lat_head* head) {
+                    const float* scales, int out_gl, const magat_lat_head* head, const magat_lat_guard* guard) {
   if (!in1 || !in2 || !wchain || !bA || !bB || !bC || !out || !w3 || !b1 || !b2) return MAGAT_ERR_NULL;
   if (M <= 0) return MAGAT_ERR_BAD_SHAPE;
   if (out_gl != 0 && out_gl != 1) return MAGAT_ERR_UNSUPPORTED;
@@ -419,6 +541,15 @@ int magat_block_lat(const void* in1, const void* in2, const float* wchain, const
     p.hfrag = reinterpret_cast<const char*>(head->hfrag); p.cfrag = reinterpret_cast<const char*>(head->cfrag);
     p.hbias = head->hbias; p.cbias = head->cbias; p.insc = head->insc; p.insc2 = head->insc2;
     p.feat = head->feat; p.comp = head->comp; p.ldfeat = head->ldfeat; p.ldcomp = head->ldcomp;
+  }
+  p.x = nullptr; p.pk = nullptr; p.book = nullptr;
+  for (int i = 0; i < 18; ++i) p.off[i] = 0;
+  if (guard) {
+    if (!head) return MAGAT_ERR_UNSUPPORTED;
+    if (!guard->x || !guard->pack || !guard->off || !guard->book) return MAGAT_ERR_NULL;
+    p.x = guard->x; p.pk = guard->pack; p.book = guard->book;
+    for (int i = 0; i < 18; ++i) p.off[i] = guard->off[i];
+    magat_form_note(MAGAT_FORM_GUARD_LAT);
   }
   const void* fn = head ? reinterpret_cast<const void*>(&block_lat_kernel<true>) : reinterpret_cast<const void*>(&block_lat_kernel<false>);
   if (magat_ensure_dyn_lds(fn, head ? MAGAT_LDS_BLOCK_LAT_H : MAGAT_LDS_BLOCK_LAT, lat::L_TOTAL) != MAGAT_OK) return MAGAT_ERR_LAUNCH;

@@ -360,7 +360,7 @@ static int enc_linear(const float* x, int ldx, const float* w, const float* b, f
 // re-run (every launch of the pass returns immediately unless *run_if != 0; only valid with split == 0).
 static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* feat, int ldfeat, float* comp, int ldcomp,
                           float* bufbase, int M, void* stream, int split, int32_t* range_flag, const int32_t* run_if,
-                          float* absmax = nullptr, int32_t* book = nullptr, bool* booked = nullptr) {
+                          float* absmax = nullptr, int32_t* book = nullptr, bool* booked = nullptr, bool* self_guarded = nullptr) {
   const int H = d->H, W = d->W;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int mc = enc_chunk_agents(M);
@@ -465,11 +465,19 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
         lh.comp = comp + (size_t)m0 * ldcomp; lh.ldcomp = ldcomp;
         head_done = true;
       }
+      // ... and the encoder's range guard too: a workgroup whose planes clamped (or the stem's did) recomputes its agent in
+      // float32 from the raw state maps, the last workgroup does the guard's bookkeeping - no predicated launches behind it
+      magat_lat_guard lg = {};
+      const bool inguard = head_done && range_flag && self_guarded && mm == M && H == 11 && W == 11;
+      if (inguard) {
+        lg.x = x + (size_t)m0 * 3 * H * W; lg.pack = pk; lg.off = d->off; lg.book = reinterpret_cast<int*>(range_flag);
+      }
       if (lat)
         rc = magat_block_lat(buf[1], buf[0], pk + d->chain_off, sp ? sp + 928 : pk + d->off[5], sp ? sp + 960 : pk + d->off[7],
                              sp ? sp + 1024 : pk + d->off[9], buf[2], pk + d->chain3_off, sp ? sp + 1088 : pk + d->off[11],
                              sp ? sp + 1216 : pk + d->off[13], mm, reinterpret_cast<int*>(range_flag), st,
-                             sp ? sp + 1344 : nullptr, head_gl ? 1 : 0, head_done ? &lh : nullptr);
+                             sp ? sp + 1344 : nullptr, head_gl ? 1 : 0, head_done ? &lh : nullptr, inguard ? &lg : nullptr);
+      if (lat && rc == MAGAT_OK && inguard) *self_guarded = true;
       else
       rc = magat_block_full(buf[1], buf[0], pk + d->chain_off, sp ? sp + 928 : pk + d->off[5], sp ? sp + 960 : pk + d->off[7],
                             sp ? sp + 1024 : pk + d->off[9], buf[2], pk + d->chain3_off, sp ? sp + 1088 : pk + d->off[11],
@@ -732,8 +740,15 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   // are recomputed in true fp32 before anything downstream reads them.
   const int split = enc_split_mask(d, magat_opt(MAGAT_OPT_CONV_SPLIT));
   const bool guard = split != 0 && magat_opt(MAGAT_OPT_RANGE_GUARD) != 0;
-  int rc = enc_run_resnet(d, x, feat, ldfeat, comp, ldcomp, bufbase, M, stream, split, guard ? status : nullptr, nullptr);
+  bool self_guarded = false;      // the latency form guarded itself (block_lat.hip): nothing to re-run, nothing to book
+  int rc = enc_run_resnet(d, x, feat, ldfeat, comp, ldcomp, bufbase, M, stream, split, guard ? status : nullptr, nullptr, nullptr,
+                          nullptr, nullptr, &self_guarded);
   if (rc != MAGAT_OK || !guard) return rc;
+  if (self_guarded) {
+    if (d->comp_bf16 && d->n_comp > 0 && (d->n_comp & 3) == 0)
+      rc = magat_cast_rows_if(comp, d->comp_bf16, 1, M, d->n_comp, ldcomp, d->n_comp, stream, status + 2);
+    return rc;
+  }
   const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);
   bool booked = false;
   rc = enc_run_resnet(d, x, feat, ldfeat, comp, ldcomp, bufbase, M, stream, 0, nullptr, status, nullptr, status, &booked);

@@ -58,9 +58,15 @@ struct magat_lat_head {      // ... with the encoder head (9 x 128 -> 128) and c
   const float* insc; const float* insc2;        // activation scales of the two layers' inputs (device floats; null / 0 = 1)
   float* feat; int ldfeat; float* comp; int ldcomp;
 };
+struct magat_lat_guard {     // ... and the encoder's range guard inside the same launch (float32 re-computation per agent)
+  const float* x;            // raw state maps [M][3][11][11]
+  const float* pack; const int64_t* off;      // the encoder pack and its float offsets 0..17 (float32 BN-folded weights)
+  int* book;                 // status block of the workspace (magat_guard_book's words)
+};
 int magat_block_lat(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
                     float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st,
-                    const float* scales = nullptr, int out_gl = 0, const magat_lat_head* head = nullptr);
+                    const float* scales = nullptr, int out_gl = 0, const magat_lat_head* head = nullptr,
+                    const magat_lat_guard* guard = nullptr);
 int magat_block3(const void* in, float* out, const float* w, const float* b1, const float* b2, int M, int* range_flag,
                  hipStream_t st);
 int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, long long out_pix_stride, long long out_tile,
