@@ -638,7 +638,8 @@ int magat_mfma_sustained_f16_ex(double* tflops, double* clock_mhz, double* per_c
 #define MAGAT_FORM_CHAIN_LAT 10   /* chain kernel, latency form: one agent per workgroup (block_lat.hip; option LAT_AGENTS) */
 #define MAGAT_FORM_HEAD_LAT 11    /* ... with the encoder head and compressMLP in its epilogue (ABI 8: headfrag_off / compfrag_off) */
 #define MAGAT_FORM_GUARD_LAT 12   /* ... and the encoder's range guard inside the same launch (no predicated launches behind it) */
-#define MAGAT_FORMS 13
+#define MAGAT_FORM_STEM_LAT 13    /* ... and the stem + layer1.conv1 in front: the whole encoder of a few-agent call is ONE launch */
+#define MAGAT_FORMS 14
 long long magat_form_count(int id);
 int magat_form_reset(void);
 

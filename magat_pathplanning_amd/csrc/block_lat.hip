@@ -32,6 +32,10 @@ constexpr int D = 8;                              // weight ring: fragments of k
 constexpr int AV = 3;                             // operand ring, as in walk4
 constexpr int L_HP = L_X1, HP_PLANE = 4 * 9 * 2 * 32;      // the head's activation planes (HEAD): 2 x 2304 B over the dead X1
 constexpr int L_CP = L_X2, CP_PLANE = 8 * 32;              // compressMLP's: 2 x 256 B over the dead X2
+// STEM: the stem and layer1.conv1 in the same launch (stem8_kernel's arithmetic for one agent): staged input planes [plane][13 rows]
+// [14 columns][c0 c1 c2 1.0] and the 11 x 11 x 32 stem map with a zero border (slot 13 (y + 1) + x + 1) behind the chain's maps
+constexpr int S_ROWB = 14 * 8, S_INPL = 13 * S_ROWB, S_RP = 13, S_SLOTS = 176, S_BLK = S_SLOTS * 16, S_DEAD = 170;
+constexpr int L_SIN = L_MB + M64, L_SMAP = L_SIN + 3072, L_TOTAL_STEM = L_SMAP + 8 * S_BLK;      // 115 712 B
 constexpr int DEADSLOT = 60;                      // where the 28 padding lanes of the second row tile store (slots 0 .. 56 are the map)
 }  // namespace lat
 
@@ -48,12 +52,27 @@ struct LatParams {
   // offsets 0..17), the status block of the workspace (book[0] working flag, [1] re-run count, [2] this forward's flag, [6]
   // arrival counter); null = the guard's predicated launches follow as for every other form
   const float* x; const float* pk; long long off[18]; int* book;
+  // STEM: stem weights [32][27] + bias (x the activation scale when folded), layer1.conv1 fragment-major + its bias
+  const float* w0; const float* b0; const char* w1f; const float* b1c;
 };
 
 // value pair -> its two f16 planes, remembering whether a value left +-65504: the instruction sequence of split_pair_f16
 // (conv_gemm_bf16x6.hip) - the float32 loaders of the long-K head and of compressMLP, whose planes this kernel reproduces
 __device__ __forceinline__ void split_pair_lat(float x, float y, unsigned& p1, unsigned& p2, bool& clamped) {
   clamped |= !(__builtin_fabsf(x) <= 65504.f) | !(__builtin_fabsf(y) <= 65504.f);
+  x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+  y = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
+  const f16x2 h = __builtin_convertvector(f32x2{x, y}, f16x2);
+  p1 = __builtin_bit_cast(unsigned, h);
+  float rx, ry;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rx) : "v"(p1), "v"(x));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ry) : "v"(p1), "v"(y));
+  const f16x2 r = __builtin_convertvector(f32x2{rx, ry}, f16x2);
+  p2 = __builtin_bit_cast(unsigned, r);
+}
+
+// signed value pair -> its two f16 planes: split2s of stem8.hip (the stem's state maps and weights)
+__device__ __forceinline__ void split2s_lat(float x, float y, unsigned& p1, unsigned& p2) {
   x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
   y = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
   const f16x2 h = __builtin_convertvector(f32x2{x, y}, f16x2);
@@ -109,10 +128,11 @@ __device__ __forceinline__ void walk_lin(char* lds, unsigned abase, const char* 
 
 // The K walk of one wave over NT row tiles: 9 taps x KSM k steps over the map at in_off, then KS2 k steps of the residual 1 x 1
 // segment over the map at in2_off (same pixel).  ab[s]: the lane's byte offset of (its slot + MINSH) in chunk fh of a map.
-template <int NT, int KSM, int KS2, int PS_IN, int PS_IN2>
+template <int NT, int KSM, int KS2, int PS_IN, int PS_IN2, int RPX = lat::RP, int BLKX = lat::BLK1>
 __device__ __forceinline__ void walk1(char* lds, const unsigned (&ab)[NT], int in_off, int in2_off, const char* wbase,
                                       unsigned lane16, f32x16 (&acc)[NT]) {
   using namespace lat;
+  constexpr int MINSHX = -(RPX + 1);      // (RPX / BLKX: row pitch and block size of the map the taps read: the chain's, or the stem map's)
   constexpr int NMAIN = 9 * KSM, NSTEP = NMAIN + KS2, NI = NSTEP * NT;
   u32x4 w[D][2];
   auto load_w = [&](int step, u32x4 (&b)[2]) {
@@ -124,11 +144,11 @@ __device__ __forceinline__ void walk1(char* lds, const unsigned (&ab)[NT], int i
     const int step = i / NT, s = i % NT;
     if (step >= NMAIN) {
       const int ks = step - NMAIN;
-      dst = *reinterpret_cast<const u32x4*>(lds + (ab[s] + (unsigned)in2_off) + (-MINSH * 16 + pl * PS_IN2 + ks * 2 * BLK1));
+      dst = *reinterpret_cast<const u32x4*>(lds + (ab[s] + (unsigned)in2_off) + (-MINSHX * 16 + pl * PS_IN2 + ks * 2 * BLK1));
     } else {
       const int tp = step / KSM, ks = step % KSM;
-      const int sh = RP * (tp / 3 - 1) + (tp % 3 - 1) - MINSH;
-      dst = *reinterpret_cast<const u32x4*>(lds + (ab[s] + (unsigned)in_off) + (sh * 16 + pl * PS_IN + ks * 2 * BLK1));
+      const int sh = RPX * (tp / 3 - 1) + (tp % 3 - 1) - MINSHX;
+      dst = *reinterpret_cast<const u32x4*>(lds + (ab[s] + (unsigned)in_off) + (sh * 16 + pl * PS_IN + ks * 2 * BLKX));
     }
   };
 #pragma unroll
@@ -163,7 +183,7 @@ __device__ __forceinline__ void walk1(char* lds, const unsigned (&ab)[NT], int i
 
 // one convolution of a wave: walk, then relu(acc * scale + bias) as f16 plane chunks of the output map (COUT channels; this wave's
 // 32 channels are chunk pair ct_out of it) - the arithmetic of chain_stage4 / epi_to_lds (block_fused.hip)
-template <int NT, int CIN, int C2, int COUT>
+template <int NT, int CIN, int C2, int COUT, int RPX = lat::RP, int BLKX = lat::BLK1>
 __device__ __forceinline__ void lat_stage(char* lds, const unsigned (&ab)[NT], const unsigned (&sl16)[NT], const bool (&live)[NT],
                                           int in_off, int in2_off, int out_off, const char* wts, int ct_out, const float* bias32,
                                           float scale, unsigned lane16, bool& clamped) {
@@ -175,7 +195,7 @@ __device__ __forceinline__ void lat_stage(char* lds, const unsigned (&ab)[NT], c
   for (int s = 0; s < NT; ++s)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-  walk1<NT, KSM, KS2, (CIN / 8) * BLK1, (C2 > 0 ? C2 / 8 : 1) * BLK1>(lds, ab, in_off, in2_off, wts, lane16, acc);
+  walk1<NT, KSM, KS2, (CIN / 8) * BLKX, (C2 > 0 ? C2 / 8 : 1) * BLK1, RPX, BLKX>(lds, ab, in_off, in2_off, wts, lane16, acc);
   const int fh = (int)(lane16 >> 9);
   f32x4 bq[4];
 #pragma unroll
@@ -298,7 +318,7 @@ __device__ void lat_fallback_f32(const LatParams& p, int m, float* L) {
   }
 }
 
-template <bool HEAD>
+template <bool HEAD, bool STEM>
 __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
   using namespace lat;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -329,10 +349,13 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
     liveT[s] = lv;
     cellT[s] = cell;
   }
-  // the agent's two input maps: 2 x 36 pixels x 8 (plane, chunk) pieces of 16 B, requested in front of the LDS clear
-  u32x4 piece[3];
-  unsigned pdst[3];
-  {
+  const float sA = *p.sA, sB = *p.sB, sC = *p.sC, s1 = *p.s1, s2 = *p.s2;
+  bool clamped = false;
+  if (!STEM) {
+    // the agent's two input maps (stem8_kernel's outputs): 2 x 36 pixels x 8 (plane, chunk) pieces of 16 B, requested in front of
+    // the LDS clear
+    u32x4 piece[3];
+    unsigned pdst[3];
     const long long tile_b = (long long)(m >> 7) * NPIX * (128 * 32 * 4) + (m & 127) * 16;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -345,15 +368,126 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
         piece[i] = *reinterpret_cast<const u32x4*>((map ? p.in2 : p.in1) + tile_b + (long long)pix * (128 * 32 * 4) +
                                                     (blk >> 2) * (256 * 32) + (blk & 3) * 2048);
     }
-  }
-  const float sA = *p.sA, sB = *p.sB, sC = *p.sC, s1 = *p.s1, s2 = *p.s2;
-  for (int i = t; i < L_TOTAL / 16; i += 256) *reinterpret_cast<u32x4*>(lds + 16 * i) = u32x4{0u, 0u, 0u, 0u};
-  L3_LDS_SYNC();
+    for (int i = t; i < L_TOTAL / 16; i += 256) *reinterpret_cast<u32x4*>(lds + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+    L3_LDS_SYNC();
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-    if (t + 256 * i < 16 * NPIX) *reinterpret_cast<u32x4*>(lds + pdst[i]) = piece[i];
-  __syncthreads();
-  bool clamped = false;
+    for (int i = 0; i < 3; ++i)
+      if (t + 256 * i < 16 * NPIX) *reinterpret_cast<u32x4*>(lds + pdst[i]) = piece[i];
+    __syncthreads();
+  } else {
+    // ---- stem (conv 3 -> 32 + BN + ReLU on 11 x 11) + layer1.conv1 (stride 2) in this launch: stem8_kernel's arithmetic for one
+    // agent - the state maps as f16 planes [c0 c1 c2 1.0] per pixel with a zero border, one k step = one tap ROW (16 K slots = the
+    // four channel slots of four neighbouring pixels, the bias rides against the constant 1.0), the stem map carried 16 x, the
+    // residual branch's input = its stride-2 pixels x 2^-4 - so X1 / X2 hold what the two launches hand over, bit for bit
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if (t < 121) {
+      const float* r = p.x + (long long)m * 363 + t;
+      v0 = r[0]; v1 = r[121]; v2 = r[242];
+    }
+    u32x4 wa[3][2];      // stem weights as this lane's row fragments: row = channel fr, k step = tap row ty (stem8.hip)
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      float wv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int slot = 8 * fh + i, tx = slot >> 2, c = slot & 3;
+        float v = 0.f;
+        if (tx < 3 && c < 3) v = p.w0[fr * 27 + c * 9 + ty * 3 + tx];
+        if (ty == 1 && tx == 1 && c == 3) v = p.b0[fr];
+        wv[i] = v * 16.f;
+      }
+      unsigned h1[4], h2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split2s_lat(wv[2 * e], wv[2 * e + 1], h1[e], h2[e]);
+      wa[ty][0] = u32x4{h1[0], h1[1], h1[2], h1[3]};
+      wa[ty][1] = u32x4{h2[0], h2[1], h2[2], h2[3]};
+    }
+    const float scale1 = *reinterpret_cast<const float*>(p.w1f + 9 * 2 * 2 * 1024) * (1.f / 16.f);
+    for (int i = t; i < L_TOTAL_STEM / 16; i += 256) *reinterpret_cast<u32x4*>(lds + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+    L3_LDS_SYNC();
+    if (t < 121) {
+      const int y = t / 11, x = t - 11 * y;
+      // (range guard of the INPUT: a NaN / Inf / |x| > 65504 entry must not become a finite clamp)
+      clamped |= !(__builtin_fabsf(v0) <= 65504.f) || !(__builtin_fabsf(v1) <= 65504.f) || !(__builtin_fabsf(v2) <= 65504.f);
+      unsigned h01, l01, h2x, l2x;
+      split2s_lat(v0, v1, h01, l01);
+      split2s_lat(v2, 1.f, h2x, l2x);
+      char* dst = lds + L_SIN + (y + 1) * S_ROWB + (x + 1) * 8;
+      *reinterpret_cast<uint2*>(dst) = uint2{h01, h2x};
+      *reinterpret_cast<uint2*>(dst + S_INPL) = uint2{l01, l2x};
+    }
+    L3_LDS_SYNC();
+    {
+      // the stem: wave w = pixels 32 w .. 32 w + 31 (pixel 120 repeated behind the map's end: stored to a dead slot)
+      const int pixr = 32 * wave + fr, pix = pixr < 121 ? pixr : 120;
+      const int y = pix / 11, x = pix - 11 * y;
+      const char* ip = lds + L_SIN + y * S_ROWB + (x + 2 * fh) * 8;
+      u32x4 xh[3], xl[3];
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        const uint2 a0 = *reinterpret_cast<const uint2*>(ip + ty * S_ROWB), a1 = *reinterpret_cast<const uint2*>(ip + ty * S_ROWB + 8);
+        const uint2 c0 = *reinterpret_cast<const uint2*>(ip + ty * S_ROWB + S_INPL), c1 = *reinterpret_cast<const uint2*>(ip + ty * S_ROWB + S_INPL + 8);
+        xh[ty] = u32x4{a0.x, a0.y, a1.x, a1.y};
+        xl[ty] = u32x4{c0.x, c0.y, c1.x, c1.y};
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      // (w hi, x hi), (w lo, x hi), (w hi, x lo) per tap row; the eight-agent kernel skips the third product for a group whose
+      // second planes are all zero - a sum of exact zeros either way
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[ty][0]), __builtin_bit_cast(f16x8, xh[ty]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[ty][1]), __builtin_bit_cast(f16x8, xh[ty]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[ty][0]), __builtin_bit_cast(f16x8, xl[ty]), acc, 0, 0, 0);
+      }
+      float cl = 0.f;
+      const bool lv = pixr < 121;
+      char* o = lds + L_SMAP + fh * S_BLK + (lv ? S_RP * (y + 1) + x + 1 : S_DEAD) * 16;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        unsigned h1[4], h2[4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int q = 2 * ks + e;
+          split2(acc[4 * q], acc[4 * q + 1], h1[2 * e], h2[2 * e], cl);
+          split2(acc[4 * q + 2], acc[4 * q + 3], h1[2 * e + 1], h2[2 * e + 1], cl);
+        }
+        *reinterpret_cast<u32x4*>(o + ks * 2 * S_BLK) = u32x4{h1[0], h1[1], h1[2], h1[3]};
+        *reinterpret_cast<u32x4*>(o + ks * 2 * S_BLK + 4 * S_BLK) = u32x4{h2[0], h2[1], h2[2], h2[3]};
+      }
+      clamped |= cl > 65504.f && lv;      // 16 x the stem output beyond the planes' range
+    }
+    L3_LDS_SYNC();
+    if (wave < 2) {
+      // layer1.conv1 over the stem map (stride 2): waves 0 / 1 = row tile 0 / 1 -> X1
+      const int g = 32 * wave + fr;
+      const bool lv = g < NPIX;
+      // (the lane's output pixel (oy, ox) is its pooled-cell-order pixel: slT holds its slot in the chain's maps)
+      const int slot7 = (int)((wave ? slT[1] : slT[0]) >> 4);
+      const int oy = lv ? slot7 / RP - 1 : 0, ox = lv ? slot7 - RP * (oy + 1) - 1 : 0;
+      const unsigned abS[1] = {(unsigned)(S_RP * (2 * oy + 1) + (2 * ox + 1) - (S_RP + 1)) * 16u + (unsigned)fh * S_BLK};
+      const unsigned slS[1] = {wave ? slT[1] : slT[0]};
+      const bool lvS[1] = {lv};
+      lat_stage<1, 32, 0, 32, S_RP, S_BLK>(lds, abS, slS, lvS, L_SMAP, 0, L_X1, p.w1f, 0, p.b1c, scale1, lane16, clamped);
+    } else {
+      // the residual branch's input: the stem map at the 36 stride-2 pixels, planes x 2^-4 -> X2
+      typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+      const h2v sc = {(_Float16)0.0625f, (_Float16)0.0625f};
+      for (int item = t - 128; item < NPIX * 8; item += 128) {
+        const int blk = item & 7, opix = item >> 3;
+        const int oy = opix / 6, ox = opix - 6 * oy;
+        u32x4 v = *reinterpret_cast<const u32x4*>(lds + L_SMAP + blk * S_BLK + (S_RP * (2 * oy + 1) + 2 * ox + 1) * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned hv = v[e];
+          v[e] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2v, hv) * sc);
+        }
+        *reinterpret_cast<u32x4*>(lds + L_X2 + blk * BLK1 + (RP * (oy + 1) + ox + 1) * 16) = v;
+      }
+    }
+    __syncthreads();
+  }
   const int ct = wave & 1, tl = wave >> 1;
   const unsigned ab1[1] = {tl ? abT[1] : abT[0]}, sl1[1] = {tl ? slT[1] : slT[0]};
   const bool lv1[1] = {tl ? liveT[1] : liveT[0]};
@@ -510,8 +644,9 @@ static size_t lat_chain_block_bytes(int cin, int c2, int cout) { return (size_t)
 // Arguments: those of magat_block_full (block_fused.hip); one workgroup per agent.
 int magat_block_lat(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
                     float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st,
-                    const float* scales, int out_gl, const magat_lat_head* head, const magat_lat_guard* guard) {
-  if (!in1 || !in2 || !wchain || !bA || !bB || !bC || !out || !w3 || !b1 || !b2) return MAGAT_ERR_NULL;
+                    const float* scales, int out_gl, const magat_lat_head* head, const magat_lat_guard* guard,
+                    const magat_lat_stem* stem) {
+  if ((!stem && (!in1 || !in2)) || !wchain || !bA || !bB || !bC || (!head && !out) || !w3 || !b1 || !b2) return MAGAT_ERR_NULL;
   if (M <= 0) return MAGAT_ERR_BAD_SHAPE;
   if (out_gl != 0 && out_gl != 1) return MAGAT_ERR_UNSUPPORTED;
   LatParams p;
@@ -551,13 +686,26 @@ int magat_block_lat(const void* in1, const void* in2, const float* wchain, const
     for (int i = 0; i < 18; ++i) p.off[i] = guard->off[i];
     magat_form_note(MAGAT_FORM_GUARD_LAT);
   }
-  const void* fn = head ? reinterpret_cast<const void*>(&block_lat_kernel<true>) : reinterpret_cast<const void*>(&block_lat_kernel<false>);
-  if (magat_ensure_dyn_lds(fn, head ? MAGAT_LDS_BLOCK_LAT_H : MAGAT_LDS_BLOCK_LAT, lat::L_TOTAL) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
+  p.w0 = p.b0 = p.b1c = nullptr; p.w1f = nullptr;
+  if (stem) {
+    if (!head) return MAGAT_ERR_UNSUPPORTED;
+    if (!stem->x || !stem->w0 || !stem->b0 || !stem->w1f || !stem->b1) return MAGAT_ERR_NULL;
+    if ((reinterpret_cast<uintptr_t>(stem->b1) | reinterpret_cast<uintptr_t>(stem->w1f)) & 15) return MAGAT_ERR_UNSUPPORTED;
+    p.x = stem->x; p.w0 = stem->w0; p.b0 = stem->b0; p.w1f = reinterpret_cast<const char*>(stem->w1f); p.b1c = stem->b1;
+    magat_form_note(MAGAT_FORM_STEM_LAT);
+  }
+  const void* fn = !head ? reinterpret_cast<const void*>(&block_lat_kernel<false, false>)
+                   : stem ? reinterpret_cast<const void*>(&block_lat_kernel<true, true>)
+                          : reinterpret_cast<const void*>(&block_lat_kernel<true, false>);
+  const size_t ldsb = stem ? lat::L_TOTAL_STEM : lat::L_TOTAL;
+  if (magat_ensure_dyn_lds(fn, !head ? MAGAT_LDS_BLOCK_LAT : stem ? MAGAT_LDS_BLOCK_LAT_S : MAGAT_LDS_BLOCK_LAT_H, ldsb) != MAGAT_OK)
+    return MAGAT_ERR_LAUNCH;
   magat_form_note(MAGAT_FORM_CHAIN_LAT);
   if (head) magat_form_note(MAGAT_FORM_HEAD_LAT);
   const int pid = magat_prof_begin(MAGAT_TAG_BLOCK_FULL, st);
-  if (head) hipLaunchKernelGGL(block_lat_kernel<true>, dim3((unsigned)M), dim3(256), lat::L_TOTAL, st, p);
-  else hipLaunchKernelGGL(block_lat_kernel<false>, dim3((unsigned)M), dim3(256), lat::L_TOTAL, st, p);
+  if (!head) hipLaunchKernelGGL((block_lat_kernel<false, false>), dim3((unsigned)M), dim3(256), ldsb, st, p);
+  else if (stem) hipLaunchKernelGGL((block_lat_kernel<true, true>), dim3((unsigned)M), dim3(256), ldsb, st, p);
+  else hipLaunchKernelGGL((block_lat_kernel<true, false>), dim3((unsigned)M), dim3(256), ldsb, st, p);
   magat_prof_end(pid, st);
   return magat_check_launch();
 }

@@ -413,7 +413,15 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // ... as the eight-agent-group kernel (block_fused.hip stem8_kernel: every stem pixel once, no im2col instructions) when
     // the map is 11 x 11 and the pack holds layer1.conv1 fragment-major (option L1_FUSED = 2, the default)
     const bool stem8 = fused1 && H == 11 && W == 11 && d->l1frag_off > 0 && magat_opt(MAGAT_OPT_L1_FUSED) >= 2;
-    if (stem8)
+    // latency form of a few-agent call (option LAT_AGENTS; block_lat.hip): ONE launch for the whole encoder - stem, layer1.conv1,
+    // the chain, head, compressMLP and the range guard with one agent per workgroup.  Decided here because it takes the stem along.
+    const int Mform0 = d->form_agents > 0 ? d->form_agents : M;
+    const bool lat_all = full_path && stem8 && !rerun && !absmax && Mform0 <= magat_opt(MAGAT_OPT_LAT_AGENTS) && mm == M &&
+                         d->headfrag_off > 0 && d->compfrag_off > 0 && d->n_feat == 128 && d->n_comp == 128 && comp && split &&
+                         magat_opt(MAGAT_OPT_HEAD_F16);
+    if (lat_all)
+      rc = MAGAT_OK;
+    else if (stem8)
       rc = magat_stem8(x + (size_t)m0 * 3 * H * W, sp ? sp : pk + d->off[0], sp ? sp + 864 : pk + d->off[1],
                        pk + d->l1frag_off, sp ? sp + 896 : pk + d->off[3], buf[1], buf[0], mm, H, W, st, range_flag);
     else if (fused1)
@@ -467,6 +475,11 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
       }
       // ... and the encoder's range guard too: a workgroup whose planes clamped (or the stem's did) recomputes its agent in
       // float32 from the raw state maps, the last workgroup does the guard's bookkeeping - no predicated launches behind it
+      magat_lat_stem ls = {};
+      if (lat_all && head_done) {
+        ls.x = x + (size_t)m0 * 3 * H * W; ls.w0 = sp ? sp : pk + d->off[0]; ls.b0 = sp ? sp + 864 : pk + d->off[1];
+        ls.w1f = pk + d->l1frag_off; ls.b1 = sp ? sp + 896 : pk + d->off[3];
+      }
       magat_lat_guard lg = {};
       const bool inguard = head_done && range_flag && self_guarded && mm == M && H == 11 && W == 11;
       if (inguard) {
@@ -476,7 +489,8 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
         rc = magat_block_lat(buf[1], buf[0], pk + d->chain_off, sp ? sp + 928 : pk + d->off[5], sp ? sp + 960 : pk + d->off[7],
                              sp ? sp + 1024 : pk + d->off[9], buf[2], pk + d->chain3_off, sp ? sp + 1088 : pk + d->off[11],
                              sp ? sp + 1216 : pk + d->off[13], mm, reinterpret_cast<int*>(range_flag), st,
-                             sp ? sp + 1344 : nullptr, head_gl ? 1 : 0, head_done ? &lh : nullptr, inguard ? &lg : nullptr);
+                             sp ? sp + 1344 : nullptr, head_gl ? 1 : 0, head_done ? &lh : nullptr, inguard ? &lg : nullptr,
+                             (lat_all && head_done) ? &ls : nullptr);
       if (lat && rc == MAGAT_OK && inguard) *self_guarded = true;
       else
       rc = magat_block_full(buf[1], buf[0], pk + d->chain_off, sp ? sp + 928 : pk + d->off[5], sp ? sp + 960 : pk + d->off[7],

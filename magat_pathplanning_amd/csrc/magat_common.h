@@ -63,10 +63,15 @@ struct magat_lat_guard {     // ... and the encoder's range guard inside the sam
   const float* pack; const int64_t* off;      // the encoder pack and its float offsets 0..17 (float32 BN-folded weights)
   int* book;                 // status block of the workspace (magat_guard_book's words)
 };
+struct magat_lat_stem {      // ... and the stem + layer1.conv1 in front (stem8_kernel's arithmetic): in1 / in2 are not read then
+  const float* x;            // raw state maps [M][3][11][11]
+  const float* w0; const float* b0;      // stem weights [32][27] and bias (magat_stem8's arguments)
+  const float* w1f; const float* b1;     // layer1.conv1 fragment-major + bias
+};
 int magat_block_lat(const void* in1, const void* in2, const float* wchain, const float* bA, const float* bB, const float* bC,
                     float* out, const float* w3, const float* b1, const float* b2, int M, int* range_flag, hipStream_t st,
                     const float* scales = nullptr, int out_gl = 0, const magat_lat_head* head = nullptr,
-                    const magat_lat_guard* guard = nullptr);
+                    const magat_lat_guard* guard = nullptr, const magat_lat_stem* stem = nullptr);
 int magat_block3(const void* in, float* out, const float* w, const float* b1, const float* b2, int M, int* range_flag,
                  hipStream_t st);
 int magat_block_chain(const void* in1, const void* in2, void* out, int out_gl, long long out_pix_stride, long long out_tile,
@@ -106,7 +111,7 @@ enum MagatLdsSlot {
   MAGAT_LDS_CSR_FUSED_END = MAGAT_LDS_CSR_FUSED_B + 2,
   MAGAT_LDS_GATD_0 = MAGAT_LDS_CSR_FUSED_END,      // gat_mid.hip: 24 slots (width x taps x row tiles x merge)
   MAGAT_LDS_GATD_END = MAGAT_LDS_GATD_0 + 24,
-  MAGAT_LDS_BLOCK_LAT, MAGAT_LDS_BLOCK_LAT_H    // block_lat.hip (without / with the head in the epilogue)
+  MAGAT_LDS_BLOCK_LAT, MAGAT_LDS_BLOCK_LAT_H, MAGAT_LDS_BLOCK_LAT_S    // block_lat.hip (chain only / + head / + stem)
 };
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of

@@ -18,10 +18,11 @@ def _build(cfg, sd, device):
 
 
 @pytest.mark.parametrize("B,N", [(1, 10), (1, 100), (1, 1), (3, 37), (2, 128), (1, 129), (1, 7)])
-def test_one_agent_per_workgroup_encoder_equals_the_batched_forms(gpu_device, libopt, B, N):
-    """block_lat_kernel - one agent per workgroup: the BasicBlock chain on zero-bordered maps with two row tiles, then the encoder
-    head and compressMLP in its epilogue - against the BATCHED forms of the same layers run on the same few agents (options
-    LAT_AGENTS = 0, HEAD_SPLITK = 0: block_full_p_kernel with eight agents per workgroup and nine row tiles by tap-validity
+def test_one_agent_per_workgroup_encoder_equals_the_batched_forms(gpu_device, libopt, tag_counts, B, N):
+    """block_lat_kernel - one agent per workgroup and ONE launch for the whole encoder: the stem and layer1.conv1 (stem8_kernel's
+    arithmetic), the BasicBlock chain on zero-bordered maps with two row tiles, the encoder head and compressMLP in its epilogue,
+    the range guard inside - against the BATCHED forms of the same layers run on the same few agents (options LAT_AGENTS = 0,
+    HEAD_SPLITK = 0: stem8_kernel and block_full_p_kernel with eight agents per workgroup and nine row tiles by tap-validity
     class, the long-K f16x3 head, the f16x3 compressMLP): the same products in the same order per output element, the same
     pairing of a pooled cell's four pixels, the same plane splits - logits equal BIT FOR BIT.  Agent counts on both sides of an
     agent tile (128)."""
@@ -38,9 +39,14 @@ def test_one_agent_per_workgroup_encoder_equals_the_batched_forms(gpu_device, li
         net.addGSO(S.clone())
         net(x)                                           # (the first forward folds the activation scales)
         lib.magat_form_reset()
-        net.addGSO(S.clone())
-        lat = net(x).clone()
+        with tag_counts() as tc:
+            net.addGSO(S.clone())
+            lat = net(x).clone()
+        # the encoder is one launch: no stem launch, no head / compressMLP launches, no encoder guard launches
+        assert tc["conv_first"] == 0 and tc["head(avgpool+fc+linear)"] == 0 and tc["compressMLP"] == 0, tc.counts
+        assert tc["layer1.conv2+layer2+layer3 (fused, pooled)"] == 1, tc.counts
         assert lib.magat_form_count(nat.FORMS["chain_lat"]) == 1 and lib.magat_form_count(nat.FORMS["head_lat"]) == 1
+        assert lib.magat_form_count(nat.FORMS["stem_lat"]) == 1 and lib.magat_form_count(nat.FORMS["guard_lat"]) == 1
         assert lib.magat_form_count(nat.FORMS["head_splitk"]) == 0 and lib.magat_form_count(nat.FORMS["head_longk"]) == 0
         libopt.set("MAGAT_LAT_AGENTS", 0)
         libopt.set("MAGAT_HEAD_SPLITK", 0)
