@@ -348,3 +348,32 @@ def test_reset_option_restores_the_environments_value():
     env.pop("MAGAT_GAT_PACK", None)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
+
+
+def test_fragment_major_head_pack_holds_the_row_major_planes():
+    """ABI 8: encoder.fold_resnet appends the head's and compressMLP's f16 planes once more fragment-major (block_lat.hip fetches
+    1 KB blocks straight into registers).  They must be the SAME halves and the same scale as the row-major planes the batched
+    kernels read (head16 / comp16) - that is what makes the one-launch encoder of a batch-1 step bit-identical to the batched
+    forms - in the long-K head's k order (32-channel slab outer, pooled cell inner)."""
+    from magat_pathplanning_amd import encoder as enc
+    from magat_pathplanning_amd.synthetic import make_config
+    cfg = make_config(device="cpu")
+    sd = orc.init_state_dict(cfg, seed=2)
+    pack, offs, meta = enc.fold_resnet(sd, 11, 11, "ConvLayers.0", (sd["ConvLayers.3.weight"], sd["ConvLayers.3.bias"]),
+                                       (sd["compressMLP.0.weight"], sd["compressMLP.0.bias"]))
+    assert meta["headfrag"] > 0 and meta["compfrag"] > 0 and meta["headfrag"] % 4 == 0 and meta["compfrag"] % 4 == 0
+    for frag_off, row_off, K, steps in (
+            (meta["headfrag"], meta["head16"], 1152, [cell * 128 + 32 * cs + 16 * ks for cs in range(4) for cell in range(9) for ks in range(2)]),
+            (meta["compfrag"], meta["comp16"], 128, [16 * ks for ks in range(8)])):
+        planes = pack[row_off:row_off + 128 * K].view(torch.int16).view(2, 128, K)
+        scale_rows = float(pack[row_off + 128 * K])
+        ns = len(steps)
+        blk = pack[frag_off:frag_off + 4 * ns * 1024 // 2].view(torch.int16).view(4, ns, 2, 64, 8)
+        assert float(pack[frag_off + 4 * ns * 512]) == scale_rows
+        lane = torch.arange(64)
+        for ct in range(4):
+            for s_, k0 in enumerate(steps):
+                for pl in range(2):
+                    want = planes[pl][(32 * ct + (lane & 31)).view(64, 1), (k0 + 8 * (lane >> 5)).view(64, 1) + torch.arange(8).view(1, 8)]
+                    assert torch.equal(blk[ct, s_, pl], want)
+
