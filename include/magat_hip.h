@@ -52,7 +52,7 @@ const char* magat_error_string(int code);
  * first use, and is read / changed through these calls afterwards; nothing on the launch path calls getenv.  `name` with
  * or without the MAGAT_ prefix.  All nineteen (round 5: the A/B switches of kernel forms that lost their measurements are gone
  * with those forms; round 6: + CSR_FUSED, LAT_AGENTS; csrc/options.hip holds the table):
- *   LAT_AGENTS (256) largest agent count (magat_encoder_desc.form_agents when set) whose encoder runs ONE AGENT PER WORKGROUP
+ *   LAT_AGENTS (512) largest agent count (magat_encoder_desc.form_agents when set) whose encoder runs ONE AGENT PER WORKGROUP
  *                    (csrc/block_lat.hip: layer1.conv2 .. layer3, pool, head and compressMLP in one launch; the batch-1 step of the
  *                    reference's inference loop); results bit-identical to the eight-agent-group kernels; 0 = never
  *   RANGE_GUARD (1)  split-arithmetic range guard (encoder and graph layer): see magat_encoder_read_status

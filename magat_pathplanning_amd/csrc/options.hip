@@ -45,7 +45,7 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
                              // the reference form the 256-agent tiles are tested against, bit-identical)
     {"CSR_FUSED", 1},        // bf16-storage CSR layer, KeyQuery, K = 2, G = F = 128, concat: the maps on the matrix cores INSIDE the two
                              // graph kernels, hop on X (gat_csr_fused.hip); 0 = maps GEMM + tiled score / hop kernels
-    {"LAT_AGENTS", 256},     // largest agent count (magat_encoder_desc.form_agents when set) that takes the LATENCY forms of the encoder:
+    {"LAT_AGENTS", 512},     // largest agent count (magat_encoder_desc.form_agents when set) that takes the LATENCY forms of the encoder:
                              // the BasicBlock chain with one agent per workgroup (block_lat.hip; bit-identical pooled map);
                              // 0 = never (the eight-agent-group kernels at every size)
 };

@@ -17,7 +17,7 @@ def _build(cfg, sd, device):
     return net.to(device).eval()
 
 
-@pytest.mark.parametrize("B,N", [(1, 10), (1, 100), (1, 1), (3, 37), (2, 128), (1, 129), (1, 7)])
+@pytest.mark.parametrize("B,N", [(1, 10), (1, 100), (1, 1), (3, 37), (2, 128), (1, 129), (1, 7), (4, 100), (4, 128), (64, 8)])
 def test_one_agent_per_workgroup_encoder_equals_the_batched_forms(gpu_device, libopt, tag_counts, B, N):
     """block_lat_kernel - one agent per workgroup and ONE launch for the whole encoder: the stem and layer1.conv1 (stem8_kernel's
     arithmetic), the BasicBlock chain on zero-bordered maps with two row tiles, the encoder head and compressMLP in its epilogue,
