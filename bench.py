@@ -825,9 +825,14 @@ def main():
                         netl(xl)
                     e1.record()
                     torch.cuda.synchronize(dev)
+                    # which forms one step takes (the one-agent-per-workgroup encoder with stem, head and guard inside: one launch)
+                    lib.magat_form_reset()
+                    netl.addGSO(Sl)
+                    netl(xl)
+                    forms_l = {k: int(lib.magat_form_count(v)) for k, v in nat.FORMS.items() if lib.magat_form_count(v)}
                 ts.sort()
                 lat["N%d" % Nl] = {"median_us": round(ts[150], 1), "mean_us": round(sum(ts) / len(ts), 1), "p90_us": round(ts[270], 1),
-                                   "device_back_to_back_us": round(e0.elapsed_time(e1) * 1e3 / 200, 1)}
+                                   "device_back_to_back_us": round(e0.elapsed_time(e1) * 1e3 / 200, 1), "forms": forms_l}
                 del netl, xl, Sl
             res["latency_b1"] = lat
         except Exception as e:

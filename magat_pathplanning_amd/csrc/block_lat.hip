@@ -1,20 +1,28 @@
-// Latency form of the BasicBlock chain (layer1.conv2 + downsample -> layer2 -> layer3 -> ReLU -> 2x2 sum-pool; reference
-// graphs/models/resnet_pytorch.py:40-73 BasicBlock, :495-524 forward) for the reference's own inference loop, which steps ONE
-// planning instance at a time (configs/dcpGAT_OE_Random.json:58 "test_batch_size": 1; agents/decentralplannerlocal_OnlineExpert_GAT.py
-// :1030-1055).  block_full_p_kernel (block_fused.hip) gives a workgroup EIGHT agents - rows of the implicit GEMMs are (pixel, agent)
-// pairs, nine 32-row tiles by tap-validity class, 13 428 matrix instructions per group - which fills the chip from 2 048 agents on
-// and leaves 10 .. 100 agents walking 136 k cycles on 2 .. 13 of 256 CUs.  Here a workgroup owns ONE agent:
-//   rows = the 36 pixels of its 6 x 6 maps = TWO row tiles (32 + 4 pixels; the second tile is 7/8 padding, and still the walk is
-//   18 tile-taps per k step against 69), every map in LDS with a ZERO BORDER (slot = 7 (y + 1) + (x + 1): one zero column
-//   serves as right border of a row and left border of the next), so every tap of every pixel is one ds_read_b128 at a
-//   compile-time offset - no validity classes, no zero-pixel selects; 2 460 matrix instructions per agent.
-//   Maps (f16 plane pairs, [plane][8-channel chunk][64 slots][16 B]): 88 KB, nothing aliased - layer3's 128-channel
-//   intermediate map fits whole.
-// Same weights (encoder.pack_chain_weights / pack_block3_weights fragments), same products in the same order per output element
-// (tap-major, k step, three plane products; a tap the eight-agent form skips for a whole tile contributes exact zeros here),
-// same split-and-store epilogues, and the 2 x 2 pooling adds pair up the pixels of a cell exactly as block_full_p_kernel's
-// in-register pooling does (corner cells: the two diagonals; edge-middle cells of the top / bottom row: the two columns; the other
-// cells: the two rows) - the pooled map is BIT-IDENTICAL to the eight-agent form's (tests/test_gpu_latency.py).
+// Latency form of the per-agent encoder - stem -> layer1 -> layer2 -> layer3 -> AvgPool -> fc (+ Flatten + Linear) -> compressMLP
+// (reference graphs/models/resnet_pytorch.py:40-73 BasicBlock, :427-524 ResNet; decentralplanner_GAT_bottleneck.py:90-166, 291-302)
+// - for the reference's own inference loop, which steps ONE planning instance at a time (configs/dcpGAT_OE_Random.json:58
+// "test_batch_size": 1; agents/decentralplannerlocal_OnlineExpert_GAT.py:1030-1055).  The batched kernels give a workgroup EIGHT
+// agents (stem8.hip, block_fused.hip: rows of the implicit GEMMs are (pixel, agent) pairs, nine 32-row tiles by tap-validity
+// class, 13 428 matrix instructions per group) - that fills the chip from 2 048 agents on and leaves 10 .. 100 agents walking
+// 136 k cycles on 2 .. 13 of 256 CUs behind seven launches.  Here a workgroup owns ONE agent and the encoder is ONE launch
+// (block_lat_kernel<HEAD, STEM>; option LAT_AGENTS, up to 512 agents):
+//   STEM   the stem and layer1.conv1 with stem8_kernel's arithmetic: state maps as f16 planes [c0 c1 c2 1.0] per pixel, one k step
+//          = one tap row, the stem map (16 x) in LDS with a zero border, layer1.conv1 over it with the stride-2 geometry, the
+//          residual branch's input = its stride-2 pixels x 2^-4;
+//   chain  rows = the 36 pixels of the agent's 6 x 6 maps = TWO row tiles (32 + 4 pixels; the second tile is 7/8 padding, and
+//          still the walk is 18 tile-taps per k step against 69), every map in LDS with a ZERO BORDER (slot = 7 (y + 1) + (x + 1):
+//          one zero column serves as right border of a row and left border of the next), so every tap of every pixel is one
+//          ds_read_b128 at a compile-time offset - no validity classes, no zero-pixel selects; 2 460 matrix instructions per
+//          agent; maps (f16 plane pairs, [plane][8-channel chunk][64 slots][16 B]): 88 KB, nothing aliased - layer3's
+//          128-channel intermediate map fits whole;
+//   HEAD   the pooled values never leave the CU: scaled and split as the long-K head's float32 loader splits them, the head's
+//          K = 9 x 128 walked in that kernel's order on fragment-major weights (ABI 8), compressMLP on the stored feature rows;
+//   guard  a workgroup whose planes clamped recomputes its agent in plain float32 (lat_fallback_f32), the last workgroup books.
+// Same weights, same products in the same order per output element (a tap the eight-agent form skips for a whole tile
+// contributes exact zeros here), same split-and-store epilogues, and the 2 x 2 pooling adds pair up the pixels of a cell exactly
+// as block_full_p_kernel's in-register pooling does (corner cells: the two diagonals; edge-middle cells of the top / bottom row:
+// the two columns; the other cells: the two rows): feat / comp are BIT-IDENTICAL to the batched kernels' - a planning instance
+// alone and as rows of a 6 400-agent batch give the same logits bit for bit (tests/test_gpu_latency.py).
 #include "magat_common.h"
 
 namespace {
