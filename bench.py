@@ -802,9 +802,14 @@ def main():
         try:
             lat = {"what": "batch 1: addGSO(float64 S) + forward + logits.cpu() per step, wall clock; K=3, P=4, BottomNeck_skipConcat",
                    "timed_steps": 300}
-            for Nl, ml in ((10, 20), (100, 50)):
-                cfgl = make_config(num_agents=Nl, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat",
-                                   device=str(dev))
+            # (+ the published MAGAT F-32-P4 checkpoint shape - bottleneck 32, K = 2, head-mean, BottomNeck_only - in the same loop)
+            for key, Nl, ml, kw_ in (("N10", 10, 20, {}), ("N100", 100, 50, {}),
+                                     ("published_f32p4_N10", 10, 20, dict(nGraphFilterTaps=2, bottleneckFeature=32, AttentionConcat=False,
+                                                                          bottleneckMode="BottomNeck_only")),
+                                     ("published_f32p4_N100", 100, 50, dict(nGraphFilterTaps=2, bottleneckFeature=32, AttentionConcat=False,
+                                                                            bottleneckMode="BottomNeck_only"))):
+                cfgl = make_config(**dict(dict(num_agents=Nl, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat",
+                                               device=str(dev)), **kw_))
                 netl = build_model(cfgl, dev)
                 xl, Sl = fov_states(1, Nl, seed=17).to(dev), comm_gso(1, Nl, ml, seed=18, dtype=torch.float64).to(dev)
                 with torch.no_grad():
@@ -831,7 +836,7 @@ def main():
                     netl(xl)
                     forms_l = {k: int(lib.magat_form_count(v)) for k, v in nat.FORMS.items() if lib.magat_form_count(v)}
                 ts.sort()
-                lat["N%d" % Nl] = {"median_us": round(ts[150], 1), "mean_us": round(sum(ts) / len(ts), 1), "p90_us": round(ts[270], 1),
+                lat[key] = {"median_us": round(ts[150], 1), "mean_us": round(sum(ts) / len(ts), 1), "p90_us": round(ts[270], 1),
                                    "device_back_to_back_us": round(e0.elapsed_time(e1) * 1e3 / 200, 1), "forms": forms_l}
                 del netl, xl, Sl
             res["latency_b1"] = lat
@@ -898,6 +903,8 @@ def main():
                 "published_f32p4_n100": {"value": _g(res, "published_f32p4_n100", "value"),
                                          "one_launch": _g(res, "published_f32p4_n100", "graph_layer_one_launch")},
                 "latency_b1_us": {"N10": _g(res, "latency_b1", "N10", "median_us"), "N100": _g(res, "latency_b1", "N100", "median_us"),
+                                  "published_f32p4_N10": _g(res, "latency_b1", "published_f32p4_N10", "median_us"),
+                                  "published_f32p4_N100": _g(res, "latency_b1", "published_f32p4_N100", "median_us"),
                                   "N10_device": _g(res, "latency_b1", "N10", "device_back_to_back_us"),
                                   "N100_device": _g(res, "latency_b1", "N100", "device_back_to_back_us")}}
     # ---- the CPU baseline: the pinned oracle on this box's host cores, behind every GPU leg (nothing of it is inside a timed region)

@@ -55,7 +55,7 @@ struct LatParams {
   float* out; int out_gl; int M; int* range_flag;
   // HEAD: the encoder head and compressMLP in the epilogue (no pooled map is written then)
   const char* hfrag; const char* cfrag; const float* hbias; const float* cbias; const float* insc; const float* insc2;
-  float* feat; float* comp; int ldfeat, ldcomp;
+  float* feat; float* comp; int ldfeat, ldcomp, ncomp;
   // GUARD (HEAD only): the encoder's range guard inside this launch - raw state maps, float32 BN-folded weights (encoder pack
   // offsets 0..17), the status block of the workspace (book[0] working flag, [1] re-run count, [2] this forward's flag, [6]
   // arrival counter); null = the guard's predicated launches follow as for every other form
@@ -318,7 +318,7 @@ __device__ void lat_fallback_f32(const LatParams& p, int m, float* L) {
     p.feat[(long long)m * p.ldfeat + t] = acc;
   }
   __syncthreads();
-  if (t < 128) {      // compressMLP
+  if (t < p.ncomp) {      // compressMLP
     const float* wr = pk + p.off[16] + (long long)t * 128;
     float acc = pk[p.off[17] + t];
     for (int k = 0; k < 128; ++k) acc = __builtin_fmaf(wr[k], FT[k], acc);
@@ -605,19 +605,21 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
       clamped |= cl;
     }
     L3_LDS_SYNC();
-    // ---- compressMLP: comp = relu(W_c . feat + b_c) ----
-    f32x16 cacc;
+    // ---- compressMLP: comp = relu(W_c . feat + b_c); ncomp = 32 | 64 | 128 outputs: the first ncomp / 32 waves ----
+    if (32 * wave < p.ncomp) {
+      f32x16 cacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
-    walk_lin<8, CP_PLANE>(lds, (unsigned)(L_CP + fh * 16), p.cfrag + (size_t)wave * 8 * 2048, lane16, cacc);
-    const float cs = *reinterpret_cast<const float*>(p.cfrag + (size_t)4 * 8 * 2048) / insc2;
+      for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
+      walk_lin<8, CP_PLANE>(lds, (unsigned)(L_CP + fh * 16), p.cfrag + (size_t)wave * 8 * 2048, lane16, cacc);
+      const float cs = *reinterpret_cast<const float*>(p.cfrag + (size_t)(p.ncomp / 32) * 8 * 2048) / insc2;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.cbias + 32 * wave + 8 * q + 4 * fh);
-      f32x4 v;
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.cbias + 32 * wave + 8 * q + 4 * fh);
+        f32x4 v;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = magat_relu(cacc[4 * q + c] * cs + bb[c]);
-      if (fr == 0) *reinterpret_cast<f32x4*>(p.comp + (long long)m * p.ldcomp + 32 * wave + 8 * q + 4 * fh) = v;
+        for (int c = 0; c < 4; ++c) v[c] = magat_relu(cacc[4 * q + c] * cs + bb[c]);
+        if (fr == 0) *reinterpret_cast<f32x4*>(p.comp + (long long)m * p.ldcomp + 32 * wave + 8 * q + 4 * fh) = v;
+      }
     }
     if (p.book) {
       // ---- the encoder's range guard inside this launch (see lat_fallback_f32).  `pre`: the stem's clamp flag (final: the stem
@@ -674,16 +676,17 @@ int magat_block_lat(const void* in1, const void* in2, const float* wchain, const
   p.b1 = b1; p.b2 = b2;
   if (scales) { p.sA = scales; p.sB = scales + 1; p.sC = scales + 2; p.s1 = scales + 3; p.s2 = scales + 4; }
   p.out = out; p.out_gl = out_gl; p.M = M; p.range_flag = range_flag;
-  p.hfrag = p.cfrag = nullptr; p.hbias = p.cbias = p.insc = p.insc2 = nullptr; p.feat = p.comp = nullptr; p.ldfeat = p.ldcomp = 0;
+  p.hfrag = p.cfrag = nullptr; p.hbias = p.cbias = p.insc = p.insc2 = nullptr; p.feat = p.comp = nullptr; p.ldfeat = p.ldcomp = 0; p.ncomp = 0;
   if (head) {
     if (!head->hfrag || !head->cfrag || !head->hbias || !head->cbias || !head->feat || !head->comp) return MAGAT_ERR_NULL;
-    if ((head->ldfeat & 3) || (head->ldcomp & 3) || head->ldfeat < 128 || head->ldcomp < 128 ||
+    if (head->ncomp != 32 && head->ncomp != 64 && head->ncomp != 128) return MAGAT_ERR_UNSUPPORTED;
+    if ((head->ldfeat & 3) || (head->ldcomp & 3) || head->ldfeat < 128 || head->ldcomp < head->ncomp ||
         ((reinterpret_cast<uintptr_t>(head->feat) | reinterpret_cast<uintptr_t>(head->comp) |
           reinterpret_cast<uintptr_t>(head->hbias) | reinterpret_cast<uintptr_t>(head->cbias)) & 15))
       return MAGAT_ERR_BAD_SHAPE;
     p.hfrag = reinterpret_cast<const char*>(head->hfrag); p.cfrag = reinterpret_cast<const char*>(head->cfrag);
     p.hbias = head->hbias; p.cbias = head->cbias; p.insc = head->insc; p.insc2 = head->insc2;
-    p.feat = head->feat; p.comp = head->comp; p.ldfeat = head->ldfeat; p.ldcomp = head->ldcomp;
+    p.feat = head->feat; p.comp = head->comp; p.ldfeat = head->ldfeat; p.ldcomp = head->ldcomp; p.ncomp = head->ncomp;
   }
   p.x = nullptr; p.pk = nullptr; p.book = nullptr;
   for (int i = 0; i < 18; ++i) p.off[i] = 0;

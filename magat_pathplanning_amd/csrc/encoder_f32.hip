@@ -417,8 +417,8 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
     // the chain, head, compressMLP and the range guard with one agent per workgroup.  Decided here because it takes the stem along.
     const int Mform0 = d->form_agents > 0 ? d->form_agents : M;
     const bool lat_all = full_path && stem8 && !rerun && !absmax && Mform0 <= magat_opt(MAGAT_OPT_LAT_AGENTS) && mm == M &&
-                         d->headfrag_off > 0 && d->compfrag_off > 0 && d->n_feat == 128 && d->n_comp == 128 && comp && split &&
-                         magat_opt(MAGAT_OPT_HEAD_F16);
+                         d->headfrag_off > 0 && d->compfrag_off > 0 && d->n_feat == 128 &&
+                         (d->n_comp == 128 || d->n_comp == 64 || d->n_comp == 32) && comp && split && magat_opt(MAGAT_OPT_HEAD_F16);
     if (lat_all)
       rc = MAGAT_OK;
     else if (stem8)
@@ -463,14 +463,14 @@ static int enc_run_resnet(const magat_encoder_desc* d, const float* x, float* fe
       // ... which then runs the encoder head and compressMLP in its epilogue as well (ABI 8 fragment-major weights): the products
       // of the long-K f16x3 head and of the f16x3 compressMLP in their order - feat / comp bit-identical to the batched forms
       magat_lat_head lh = {};
-      if (lat && d->headfrag_off > 0 && d->compfrag_off > 0 && d->n_feat == 128 && d->n_comp == 128 && comp && split &&
-          magat_opt(MAGAT_OPT_HEAD_F16)) {
+      if (lat && d->headfrag_off > 0 && d->compfrag_off > 0 && d->n_feat == 128 &&
+          (d->n_comp == 128 || d->n_comp == 64 || d->n_comp == 32) && comp && split && magat_opt(MAGAT_OPT_HEAD_F16)) {
         lh.hfrag = pk + d->headfrag_off; lh.cfrag = pk + d->compfrag_off;
         lh.hbias = pk + d->off[15]; lh.cbias = pk + d->off[17];
         lh.insc = d->scaled_off > 0 ? pk + d->scaled_off + 1349 : nullptr;
         lh.insc2 = d->scaled_off > 0 ? pk + d->scaled_off + 1350 : nullptr;
         lh.feat = feat + (size_t)m0 * ldfeat; lh.ldfeat = ldfeat;
-        lh.comp = comp + (size_t)m0 * ldcomp; lh.ldcomp = ldcomp;
+        lh.comp = comp + (size_t)m0 * ldcomp; lh.ldcomp = ldcomp; lh.ncomp = d->n_comp;
         head_done = true;
       }
       // ... and the encoder's range guard too: a workgroup whose planes clamped (or the stem's did) recomputes its agent in

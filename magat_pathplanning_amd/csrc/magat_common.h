@@ -57,6 +57,7 @@ struct magat_lat_head {      // ... with the encoder head (9 x 128 -> 128) and c
   const float* hbias; const float* cbias;
   const float* insc; const float* insc2;        // activation scales of the two layers' inputs (device floats; null / 0 = 1)
   float* feat; int ldfeat; float* comp; int ldcomp;
+  int ncomp;                                    // compressMLP's outputs: 32 | 64 | 128 (the published bottleneck widths)
 };
 struct magat_lat_guard {     // ... and the encoder's range guard inside the same launch (float32 re-computation per agent)
   const float* x;            // raw state maps [M][3][11][11]

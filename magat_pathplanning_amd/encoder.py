@@ -182,7 +182,7 @@ def fold_resnet(sd, H=11, W=11, pre="ConvLayers.0", linear=None, compress=None):
     # batch-1 step runs both layers in the chain kernel's epilogue): the same f16 planes and scale as head16 / comp16, in the
     # order a wave fetches them - no weight slab through LDS there, 1 KB blocks straight into registers
     headfrag_off = compfrag_off = 0
-    if chain3_off and n_comp == 128 and n_feat == 128 and clast == 128 and Hp * Wp == 9:
+    if chain3_off and n_comp in (32, 64, 128) and n_feat == 128 and clast == 128 and Hp * Wp == 9:
         nxt = sorted(o for o in offs[:18] if o > offs[14])
         hrows = pack[offs[14]:(nxt[0] if nxt else n_f32)].reshape(n_feat, Hp * Wp * clast)
         # k steps in the long-K head's order (conv_gemm_bf16x6.hip direct kernel, korder 1): 32-channel slab outer, pooled cell

@@ -92,6 +92,42 @@ def test_batch_one_step_equals_its_rows_of_a_large_batch(gpu_device, N):
             assert torch.equal(alone, whole[b * N:(b + 1) * N]), (N, b, float((alone - whole[b * N:(b + 1) * N]).abs().max()))
 
 
+@pytest.mark.parametrize("G,N,concat", [(32, 10, False), (32, 100, False), (64, 40, True), (64, 16, False)])
+def test_published_widths_take_the_one_launch_encoder(gpu_device, libopt, G, N, concat):
+    """The published checkpoints (MAGAT F-32-P4 / B-32-P4, scripts/train_DMap.sh:42-46: bottleneckFeature 32, K = 2, four heads,
+    head-mean) in the reference's batch-1 loop on the README's 10 .. 100-robot sets: compressMLP has 32 (64) outputs - the first
+    one (two) waves of the one-launch encoder compute them - and the graph layer is gat_small / gat_mid.  Bit-identical to the
+    batched forms of the same layers, 1e-4 from the oracle."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd import _native as nat
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    cfg = make_config(num_agents=N, nGraphFilterTaps=2, nAttentionHeads=4, bottleneckFeature=G, bottleneckMode="BottomNeck_only",
+                      AttentionConcat=concat)
+    sd = orc.init_state_dict(cfg, seed=90 + G + N)
+    net = _build(cfg, sd, gpu_device)
+    x = fov_states(1, N, seed=2 + N).to(gpu_device)
+    S = comm_gso(1, N, 20 if N <= 20 else 50, seed=3 + N, dtype=torch.float64).to(gpu_device)
+    lib = nat.lib()
+    with torch.no_grad():
+        net.addGSO(S.clone())
+        net(x)
+        lib.magat_form_reset()
+        net.addGSO(S.clone())
+        lat = net(x).clone()
+        assert lib.magat_form_count(nat.FORMS["head_lat"]) == 1 and lib.magat_form_count(nat.FORMS["stem_lat"]) == 1
+        libopt.set("MAGAT_LAT_AGENTS", 0)
+        libopt.set("MAGAT_HEAD_SPLITK", 0)
+        lib.magat_form_reset()
+        net.addGSO(S.clone())
+        batched = net(x).clone()
+        assert lib.magat_form_count(nat.FORMS["chain_lat"]) == 0
+    assert torch.equal(lat, batched)
+    ref = orc.planner_forward(x.cpu(), S.cpu().clone(), sd, cfg)
+    assert float((lat.cpu() - ref).abs().max()) <= TOL
+    st = net.range_status()
+    assert not st["encoder_rerun"] and not st["gat_rerun"], st
+
+
 def test_latency_form_is_chosen_on_the_global_agent_count(gpu_device):
     """A shard of a large batch (form_agents = the global count, distributed.sharded_forward) keeps the batched forms even when
     the shard itself is small: shards and the whole batch stay bit-identical with default options."""
