@@ -1158,7 +1158,8 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
                                   N, G, K, P, concat, guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4))
         // (32 / 64 features on 33 .. 128 agents: gat_mid.hip, a workgroup of ceil(N / 32) waves per instance - round 6)
         : magat_gat_mid_forward(X, G, S, s_is_f64, packed + magat_gat_f16_block_offset(L.NC, G), L.NC, bias, Y, ldy, B, N, G, K, P,
-                                concat, guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4));
+                                concat, guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4),
+                                concat ? nullptr : Ytmp, P * F);
     if (rc != MAGAT_OK || !guard) return rc;
     rerun_only = true;
     p.run_if = status;

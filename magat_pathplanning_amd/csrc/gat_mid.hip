@@ -32,6 +32,7 @@ struct GatMidParams {
   int B, N, P, NC, ldx, ldy, s_is_f64;
   int* range_flag;
   const float* x_scale;
+  float* Ypre; int ldpre;     // HS, head-mean: the heads' pre-activation outputs [B*N][P F] (the caller's workspace); a small kernel forms the mean
 };
 
 __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, const f32x16& c) {
@@ -51,7 +52,10 @@ __device__ __forceinline__ void split2v(float x, float y, unsigned& p1, unsigned
   split_pair(x, y, p1, p2);
 }
 
-template <int F, int KT, int NT, bool CONCAT>
+// HS (few instances: the batch-1 step of the reference's inference loop): a workgroup per (instance, HEAD) instead of per instance -
+// one planning instance of 100 agents then runs on four CUs instead of one.  A head's arithmetic does not change; with head-mean
+// the workgroups leave their pre-activation outputs in Ypre and gat_mid_mean_kernel sums them in the loop's order (bit-identical).
+template <int F, int KT, int NT, bool CONCAT, bool HS = false>
 __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) {
   extern __shared__ __align__(16) char lds[];
   constexpr int CT = F / 32, KF = F / 16, ROWS = 32 * NT, THREADS = 64 * NT;
@@ -78,7 +82,9 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
   for (int ct = 0; ct < CT; ++ct) biasv[ct] = p.bias ? p.bias[32 * ct + fr] : 0.f;
   const int myrow = 32 * w + fr;                    // this lane's agent (row j of Q / A^T, column i of the scores, ...)
 
-  for (int inst = (int)blockIdx.x; inst < p.B; inst += (int)gridDim.x) {
+  const int ninst = HS ? (int)gridDim.x / p.P : (int)gridDim.x;      // (HS: gridDim.x = instances-in-flight x P)
+  const int hlo = HS ? (int)blockIdx.x % p.P : 0, hhi = HS ? hlo + 1 : p.P;
+  for (int inst = HS ? (int)blockIdx.x / p.P : (int)blockIdx.x; inst < p.B; inst += ninst) {
     __syncthreads();      // every wave is done with the previous instance's planes
     // ---- X rows -> f16 planes (rows past N: zeros), all waves
     {
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
         for (int r = 0; r < 16; ++r) ysum[ct][r] = 0.f;
     }
 #pragma unroll 1
-    for (int hd = 0; hd < p.P; ++hd) {
+    for (int hd = hlo; hd < hhi; ++hd) {
       // this lane's 16-byte pieces of weight row (base + lane % 32): k step ks, plane pl at + pl * plane + 16 ks + 8 fh halves
       auto wfrag = [&](long long row0, int ks, int pl) __attribute__((always_inline)) {
         return *reinterpret_cast<const uint4*>(p.Hs + pl * plane + (row0 + fr) * G + 16 * ks + 8 * fh);
@@ -286,6 +292,8 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
           const float v = __builtin_fmaf(acc[0][ct][r], kOutScale, biasv[ct]);
           if constexpr (CONCAT) {
             if (j < N) yb[(long long)j * p.ldy + hd * F + 32 * ct + fr] = __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());
+          } else if constexpr (HS) {
+            if (j < N) p.Ypre[((long long)inst * N + j) * p.ldpre + hd * F + 32 * ct + fr] = v;
           } else {
             ysum[ct][r] += v;      // (graphML.py:4663-4667: mean over the heads, then ReLU)
             if (hd == p.P - 1 && j < N)
@@ -298,12 +306,27 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
   if (p.range_flag && vmax > 65504.f) atomicOr(p.range_flag, 1);
 }
 
+// head mean of the head-split form: y = relu((((0 + v_0) + v_1) + ..) / P) - the non-split kernel's sum, in its order
+__global__ __launch_bounds__(256) void gat_mid_mean_kernel(const float* __restrict__ ypre, float* __restrict__ y, long long M, int P, int F,
+                                                           int ldpre, int ldy) {
+  const long long total = M * F;
+  for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += gridDim.x * 256LL) {
+    const long long m = idx / F;
+    const int c = (int)(idx - m * F);
+    float s = 0.f;
+    for (int q = 0; q < P; ++q) s += ypre[m * ldpre + q * F + c];
+    y[m * ldy + c] = __builtin_amdgcn_fmed3f(s / (float)P, 0.f, __builtin_inff());
+  }
+}
+
 template <int F, int NT>
 constexpr size_t mid_lds() {
   constexpr size_t ROWS = 32 * NT, RS = 2 * F + 16, SA = 2 * ROWS + 16;
   constexpr size_t q = 2 * ROWS * RS, u = 2 * F * SA;
   return 2 * ROWS * RS + (q > u ? q : u) + 2 * ROWS * SA;
 }
+
+constexpr long long MID_HS_MAX_WG = 64;      // head split while instances x heads stay below this many workgroups
 
 template <int F, int KT, int NT>
 int launch_mid(const GatMidParams& p, int concat, int slot, hipStream_t st) {
@@ -320,8 +343,22 @@ int launch_mid(const GatMidParams& p, int concat, int slot, hipStream_t st) {
   if (per_cu > 4) per_cu = 4;
   long long blocks = p.B;
   if (blocks > cus * per_cu) blocks = cus * per_cu;
+  // few instances (the batch-1 step): a workgroup per (instance, head); head-mean then needs the caller's scratch rows
+  const bool hs = p.P > 1 && (long long)p.B * p.P <= MID_HS_MAX_WG && (concat || p.Ypre);
   const int pid = magat_prof_begin(MAGAT_TAG_GAT_LAYER, st);
-  if (concat) hipLaunchKernelGGL((gat_mid_kernel<F, KT, NT, true>), dim3((unsigned)blocks), dim3(64 * NT), lds, st, p);
+  if (hs) {
+    const void* fh = concat ? reinterpret_cast<const void*>(&gat_mid_kernel<F, KT, NT, true, true>)
+                            : reinterpret_cast<const void*>(&gat_mid_kernel<F, KT, NT, false, true>);
+    if (magat_ensure_dyn_lds(fh, slot + 24 + (concat ? 0 : 1), lds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
+    const unsigned g = (unsigned)(p.B * p.P);
+    if (concat) hipLaunchKernelGGL((gat_mid_kernel<F, KT, NT, true, true>), dim3(g), dim3(64 * NT), lds, st, p);
+    else {
+      hipLaunchKernelGGL((gat_mid_kernel<F, KT, NT, false, true>), dim3(g), dim3(64 * NT), lds, st, p);
+      const long long M = (long long)p.B * p.N;
+      hipLaunchKernelGGL(gat_mid_mean_kernel, dim3((unsigned)((M * F + 255) / 256)), dim3(256), 0, st, p.Ypre, p.Y, M, p.P, F, p.ldpre, p.ldy);
+    }
+    magat_form_note(MAGAT_FORM_GAT_HSPLIT);
+  } else if (concat) hipLaunchKernelGGL((gat_mid_kernel<F, KT, NT, true>), dim3((unsigned)blocks), dim3(64 * NT), lds, st, p);
   else hipLaunchKernelGGL((gat_mid_kernel<F, KT, NT, false>), dim3((unsigned)blocks), dim3(64 * NT), lds, st, p);
   magat_prof_end(pid, st);
   magat_form_note(MAGAT_FORM_GAT_MID);
@@ -345,13 +382,14 @@ int magat_gat_mid_supported(int N, int G, int F, int K, int mode) {
 // Hs: the f16 planes [2][NC][G] of the layer's pack (packed + magat_gat_f16_block_offset(NC, G))
 int magat_gat_mid_forward(const float* X, int ldx, const void* S, int s_is_f64, const float* Hs, int NC, const float* bias, float* Y,
                           int ldy, int B, int N, int G, int K, int P, int concat, int* range_flag, hipStream_t st,
-                          const float* x_scale) {
+                          const float* x_scale, float* ypre, int ldpre) {
   if (!magat_gat_mid_supported(N, G, G, K, MAGAT_MODE_KEYQUERY)) return MAGAT_ERR_UNSUPPORTED;
   if ((ldx & 3) || (reinterpret_cast<uintptr_t>(X) & 15)) return MAGAT_ERR_UNSUPPORTED;
   GatMidParams p;
   p.X = X; p.S = S; p.Hs = reinterpret_cast<const unsigned short*>(Hs); p.bias = bias; p.Y = Y;
   p.B = B; p.N = N; p.P = P; p.NC = NC; p.ldx = ldx; p.ldy = ldy; p.s_is_f64 = s_is_f64;
   p.range_flag = range_flag; p.x_scale = x_scale;
+  p.Ypre = (ypre && ldpre >= P * G) ? ypre : nullptr; p.ldpre = ldpre;
   // LDS-attribute slots: 6 per (width, taps) pair (three tile counts x two merges)
   if (G == 32) return K == 3 ? launch_mid_nt<32, 3>(p, concat, MAGAT_LDS_GATD_0, st) : launch_mid_nt<32, 2>(p, concat, MAGAT_LDS_GATD_0 + 6, st);
   return K == 3 ? launch_mid_nt<64, 3>(p, concat, MAGAT_LDS_GATD_0 + 12, st) : launch_mid_nt<64, 2>(p, concat, MAGAT_LDS_GATD_0 + 18, st);

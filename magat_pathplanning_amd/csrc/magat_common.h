@@ -93,7 +93,7 @@ enum MagatOpt {
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)
-#define MAGAT_LDS_SLOTS 128
+#define MAGAT_LDS_SLOTS 192
 int magat_ensure_dyn_lds(const void* func, int slot, size_t bytes);
 enum MagatLdsSlot {
   MAGAT_LDS_GAT16, MAGAT_LDS_GAT32, MAGAT_LDS_GAT64, MAGAT_LDS_GAT128, MAGAT_LDS_GAT256, MAGAT_LDS_L1FUSED,
@@ -110,8 +110,8 @@ enum MagatLdsSlot {
   MAGAT_LDS_CSR_FUSED_A,  // gat_csr_fused.hip: score kernel, P = 1 | 2 | 4
   MAGAT_LDS_CSR_FUSED_B = MAGAT_LDS_CSR_FUSED_A + 3,   // hop + tap kernel, 1 | 2 heads per workgroup
   MAGAT_LDS_CSR_FUSED_END = MAGAT_LDS_CSR_FUSED_B + 2,
-  MAGAT_LDS_GATD_0 = MAGAT_LDS_CSR_FUSED_END,      // gat_mid.hip: 24 slots (width x taps x row tiles x merge)
-  MAGAT_LDS_GATD_END = MAGAT_LDS_GATD_0 + 24,
+  MAGAT_LDS_GATD_0 = MAGAT_LDS_CSR_FUSED_END,      // gat_mid.hip: 24 slots (width x taps x row tiles x merge), 24 more for the head-split form
+  MAGAT_LDS_GATD_END = MAGAT_LDS_GATD_0 + 48,
   MAGAT_LDS_BLOCK_LAT, MAGAT_LDS_BLOCK_LAT_H, MAGAT_LDS_BLOCK_LAT_S    // block_lat.hip (chain only / + head / + stem)
 };
 
@@ -150,7 +150,8 @@ int magat_gat_small_forward(const float* X, int ldx, const void* S, int s_is_f64
 int magat_gat_mid_supported(int N, int G, int F, int K, int mode);
 int magat_gat_mid_forward(const float* X, int ldx, const void* S, int s_is_f64, const float* Hs, int NC, const float* bias, float* Y,
                           int ldy, int B, int N, int G, int K, int P, int concat, int* range_flag, hipStream_t st,
-                          const float* x_scale);
+                          const float* x_scale,
+                          float* ypre = nullptr, int ldpre = 0);      // head-mean scratch rows [B*N][P F]: lets few instances run a workgroup per head
 // one-launch KeyQuery layer on the matrix cores (gat_mfma.hip)
 int magat_gat_mfma_supported(int N, int G, int F, int K, int mode);
 int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre,

@@ -61,6 +61,39 @@ def test_one_agent_per_workgroup_encoder_equals_the_batched_forms(gpu_device, li
     assert not st["encoder_rerun"] and not st["gat_rerun"], st
 
 
+@pytest.mark.parametrize("N,concat", [(40, False), (100, False), (64, True)])
+def test_published_widths_batch_one_equals_its_rows_of_a_large_batch(gpu_device, N, concat):
+    """The published widths (bottleneck 32, K = 2, four heads) on 33 .. 128 agents: ONE instance runs gat_mid_kernel with a
+    workgroup per HEAD (head-mean: pre-activation rows + gat_mid_mean_kernel), a batch runs a workgroup per instance - the same
+    logits bit for bit, as for the encoder."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd import _native as nat
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B = 6400 // N
+    cfg = make_config(num_agents=N, nGraphFilterTaps=2, nAttentionHeads=4, bottleneckFeature=32, bottleneckMode="BottomNeck_only",
+                      AttentionConcat=concat)
+    sd = orc.init_state_dict(cfg, seed=13)
+    net = _build(cfg, sd, gpu_device)
+    x = fov_states(B, N, seed=8).to(gpu_device)
+    S = comm_gso(B, N, 50, seed=9).to(gpu_device)
+    lib = nat.lib()
+    with torch.no_grad():
+        net.addGSO(S.clone())
+        net(x)
+        lib.magat_form_reset()
+        net.addGSO(S.clone())
+        whole = net(x).clone()
+        assert lib.magat_form_count(nat.FORMS["gat_mid"]) == 1 and lib.magat_form_count(nat.FORMS["gat_hsplit"]) == 0
+        for b in (0, B // 2, B - 1):
+            lib.magat_form_reset()
+            net.addGSO(S[b:b + 1].clone())
+            alone = net(x[b:b + 1]).clone()
+            assert lib.magat_form_count(nat.FORMS["gat_hsplit"]) == 1 and lib.magat_form_count(nat.FORMS["head_lat"]) == 1
+            assert torch.equal(alone, whole[b * N:(b + 1) * N]), (N, b, float((alone - whole[b * N:(b + 1) * N]).abs().max()))
+    ref = orc.planner_forward(x[:2].cpu(), S[:2].cpu().clone(), sd, cfg)
+    assert float((whole[:2 * N].cpu() - ref).abs().max()) <= TOL
+
+
 @pytest.mark.parametrize("N", [10, 100])
 def test_batch_one_step_equals_its_rows_of_a_large_batch(gpu_device, N):
     """The reference's inference loop presents ONE planning instance per step; a benchmark (or a shard of BASELINE config 3)
