@@ -29,6 +29,17 @@ for (B, N, mw) in ((1, 10, 20), (1, 100, 50), (8, 100, 50)):
             net.addGSO(S); y = net(x)
         e1.record()
         torch.cuda.synchronize()
+        # ... and the step exactly as the reference's loop drives it (agents/decentralplannerlocal_OnlineExpert_GAT.py:1032-1046): the state
+        # tensor and the float64 GSO arrive as HOST tensors every step and are moved with .to(device) before addGSO / forward
+        xh, Sh = x.cpu(), S.cpu()
+        for _ in range(20):
+            net.addGSO(Sh.to(dev)); net(xh.to(dev)).cpu()
+        th = []
+        for _ in range(300):
+            t0 = time.perf_counter()
+            net.addGSO(Sh.to(dev)); y = net(xh.to(dev)); y.cpu()
+            th.append((time.perf_counter() - t0) * 1e6)
     srt = sorted(ts)
+    print("B=%d N=%3d  with host-resident inputs (two .to(device) copies per step, as the reference's loop): median %.1f us/step" % (B, N, sorted(th)[150]))
     print("B=%d N=%3d  median %.1f us/step  mean %.1f  p90 %.1f  p99 %.1f  max %.1f   back-to-back (no host copy) %.1f us/step" % (
         B, N, srt[200], sum(ts) / len(ts), srt[360], srt[396], srt[-1], e0.elapsed_time(e1) * 1000 / 200))
