@@ -445,6 +445,7 @@ typedef struct magat_conv_gemm_desc {
    * bf16-storage graph layer (BASELINE config 5) reads compressMLP's rows in that type: the cast pass between them is gone. */
   void* out2_bf16;
   int ldc2_bf16;
+  int dilation;      /* (ABI 8) tap spacing of the kH x kW window (nn.Conv2d dilation; float32 kernel only): 0 | 1 = dense */
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 
@@ -507,7 +508,9 @@ int magat_conv_first_tiled_f32(const float* x, const float* wt, const float* bia
  * and in DESIGN.md); offsets are passed explicitly so the ABI does not hard-code it.
  */
 typedef struct magat_encoder_desc {
-  int variant;     /* 0 large, 1 slim */
+  int variant;     /* 0 ResNetLarge, 1 ResNetSlim, 2 CNN_mode "Default"; (ABI 8) 3 / 4: the dilated CNNs of DecentralPlannerNet
+                      (config.use_dilated, use_dilated_version 1 / 2; graphs/models/decentralplanner.py:57-86, 138-162): conv-BN-ReLU
+                      x 5 (x 4) with dilation 1 3 1 3 (1), MaxPool2d(2) behind layers 1 and 3; pack as for variant 2 */
   int H, W;        /* FOV+2 (11) */
   int n_feat;      /* numFeatureMap: width of `feat` (128 for *_withMLP, 1152 otherwise) */
   int n_comp;      /* bottleneckFeature G (0: skip compressMLP) */

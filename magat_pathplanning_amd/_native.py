@@ -55,7 +55,7 @@ class ConvGemmDesc(ctypes.Structure):
                 ("bf16_rows", ctypes.c_int),
                 ("wt2", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("out2", ctypes.c_void_p), ("in_scale2", ctypes.c_void_p),
                 ("Cout2", ctypes.c_int), ("ldc2", ctypes.c_int), ("relu2", ctypes.c_int),
-                ("out2_bf16", ctypes.c_void_p), ("ldc2_bf16", ctypes.c_int)]
+                ("out2_bf16", ctypes.c_void_p), ("ldc2_bf16", ctypes.c_int), ("dilation", ctypes.c_int)]
 
 
 class EncoderDesc(ctypes.Structure):

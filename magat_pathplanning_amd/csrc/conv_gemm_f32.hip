@@ -41,6 +41,7 @@ struct ConvGemmParams {
   int tag;
   int pool_w;   // POOL: physical input width (input pixel (iy,ix) = sum or max of the 2x2 physical pixels)
   int pool_max; // POOL: 0 = sum (AvgPool2d with 1/4 in the weights), 1 = max (MaxPool2d)
+  int dil;      // tap spacing (nn.Conv2d dilation), >= 1
   long long wt_pix;         // per-output-pixel weight offset (floats); 0 = shared weights
   long long out_plane;
   long long out_nt;         // > 0: 128-column tile t of the row-major output lives at out + t * out_nt (row stride ldc = 128)
@@ -77,8 +78,9 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, const in
 
   // valid tap window of this output pixel
   const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-  const int ty0 = iy0 < 0 ? -iy0 : 0, tx0 = ix0 < 0 ? -ix0 : 0;
-  const int ty1 = min(p.kH, p.Hin - iy0), tx1 = min(p.kW, p.Win - ix0);
+  const int dl = p.dil;      // tap (ty, tx) reads input pixel (iy0 + ty dl, ix0 + tx dl): the taps inside the map are still a range
+  const int ty0 = iy0 < 0 ? (-iy0 + dl - 1) / dl : 0, tx0 = ix0 < 0 ? (-ix0 + dl - 1) / dl : 0;
+  const int ty1 = min(p.kH, (p.Hin - iy0 + dl - 1) / dl), tx1 = min(p.kW, (p.Win - ix0 + dl - 1) / dl);
   // (window lengths clamped at 0: with stride >= 3 both can be negative for a pixel whose window lies past the map - the input
   //  gradient over a zero-stuffed map - and their product would be a positive tap count that reads past the map)
   const int ntx = max(tx1 - tx0, 0);
@@ -114,8 +116,8 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, const in
   int cur_ty = ty0, cur_tx = tx0, cur_ks = 0;
   bool cur_main = ntaps > 0;
   auto tap_base = [&](int ty, int tx) -> const float* {
-    if (POOL) return p.in + (long long)(2 * (iy0 + ty) * p.pool_w + 2 * (ix0 + tx)) * p.in_pix_stride;
-    return p.in + (long long)((iy0 + ty) * p.Win + (ix0 + tx)) * p.in_pix_stride;
+    if (POOL) return p.in + (long long)(2 * (iy0 + ty * dl) * p.pool_w + 2 * (ix0 + tx * dl)) * p.in_pix_stride;
+    return p.in + (long long)((iy0 + ty * dl) * p.Win + (ix0 + tx * dl)) * p.in_pix_stride;
   };
   const float* cur_tap = tap_base(ty0, tx0);
   const float* const seg2_base =
@@ -569,6 +571,8 @@ static int conv_params_from_desc(const magat_conv_gemm_desc* d, ConvGemmParams& 
   p.run_if = reinterpret_cast<const int*>(d->run_if);
   p.pool_w = 0;
   p.pool_max = d->pool == 2;
+  if (d->dilation < 0 || d->dilation > 64) return MAGAT_ERR_BAD_SHAPE;
+  p.dil = d->dilation > 1 ? d->dilation : 1;
   if (d->pool) {   // input map is the 2x2 sum- or max-pool of a physical (2*Hin.. x pool_w) map
     if (d->pool_w < 2 * d->Win || (d->pool != 1 && d->pool != 2)) return MAGAT_ERR_BAD_SHAPE;
     p.pool_w = d->pool_w;
@@ -581,6 +585,7 @@ extern "C" int magat_conv_gemm_f32(const magat_conv_gemm_desc* d, void* stream) 
   if (!d || !d->in || !d->wt || !d->out) return MAGAT_ERR_NULL;
   if (d->bf16_rows && d->in_fmt != 0) return MAGAT_ERR_UNSUPPORTED;
   if (d->wt2 && d->in_fmt != 4) return MAGAT_ERR_UNSUPPORTED;      // (a second layer in the epilogue: f16x3 direct kernel only)
+  if (d->dilation > 1 && d->in_fmt != 0) return MAGAT_ERR_UNSUPPORTED;      // (dilated taps: the float32 kernel only)
   if (d->in_fmt >= 1 && d->in_fmt <= 5) return magat_conv_gemm_bf16x6(d, static_cast<hipStream_t>(stream));
   {
     const int src = skinny_try(d, static_cast<hipStream_t>(stream));

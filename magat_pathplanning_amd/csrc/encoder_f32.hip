@@ -315,7 +315,7 @@ static int enc_split_mask(const magat_encoder_desc* d, int v) {
 
 // floats per agent of one rotating activation buffer
 static size_t enc_buf_floats_per_agent(const magat_encoder_desc* d) {
-  if (d->variant == 2) return (size_t)d->H * d->W * 32;    // Default CNN: the first map is the largest
+  if (d->variant >= 2) return (size_t)d->H * d->W * 32;    // plain CNNs: the first map is the largest
   const int Ho = (d->H + 2 - 3) / 2 + 1, Wo = (d->W + 2 - 3) / 2 + 1;
   const size_t a0 = (size_t)d->H * d->W * 32;
   const size_t a3 = (size_t)Ho * Wo * (d->variant == 0 ? 128 : 64);
@@ -679,7 +679,7 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
                                          void* stream) {
   if (!d || !x || !feat || !d->pack) return MAGAT_ERR_NULL;
   if (M <= 0 || d->H < 3 || d->W < 3 || d->n_feat <= 0) return MAGAT_ERR_BAD_SHAPE;
-  if (d->variant < 0 || d->variant > 2) return MAGAT_ERR_UNSUPPORTED;
+  if (d->variant < 0 || d->variant > 4) return MAGAT_ERR_UNSUPPORTED;
   if (d->n_comp > 0 && !comp) return MAGAT_ERR_NULL;
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) ||
       workspace_bytes < magat_encoder_workspace_bytes(d, M))
@@ -696,46 +696,60 @@ extern "C" int magat_encoder_forward_f32(const magat_encoder_desc* d, const floa
   const float* pk = d->pack;
   hipStream_t st = static_cast<hipStream_t>(stream);
 
-  if (d->variant == 2) {     // CNN_mode Default: conv-BN-ReLU x5 with MaxPool2d(2) after layers 0, 2, 4 (float32 kernels only)
-    if (d->n_feat <= 0 || d->n_feat % 128) return MAGAT_ERR_BAD_SHAPE;
+  if (d->variant >= 2) {
+    // Plain CNNs (float32 kernels only): conv-BN-ReLU stacks with MaxPool2d(2) behind some layers, the pool folded into the NEXT
+    // layer's loader (or, behind the last layer, into a pooled 1x1 GEMM with identity weights).
+    //   2: CNN_mode Default - 5 layers, pools behind layers 0, 2, 4;
+    //   3 / 4 (ABI 8): the dilated CNNs of DecentralPlannerNet (use_dilated_version 1 / 2; decentralplanner.py:57-86, 138-162):
+    //          5 (4) layers with dilation = padding = 1 3 1 3 (1), pools behind layers 1 and 3
+    const int nl = d->variant == 4 ? 4 : 5;
     const int chans[6] = {3, 32, 32, 64, 64, 128};
+    const int dils[5] = {1, d->variant == 2 ? 1 : 3, 1, d->variant == 2 ? 1 : 3, 1};
+    const bool pool_after[5] = {d->variant == 2, d->variant != 2, d->variant == 2, d->variant != 2, d->variant == 2};
+    const int clast = chans[nl];
+    if (d->n_feat <= 0 || d->n_feat % clast) return MAGAT_ERR_BAD_SHAPE;
     for (int m0 = 0; m0 < M; m0 += mc) {
       const int mm = (M - m0) < mc ? (M - m0) : mc;
       int rc = magat_conv_first_tiled_f32(x + (size_t)m0 * 3 * H * W, pk + d->off[0], pk + d->off[1], buf[0], mm, H, W,
                                           stream);
       if (rc != MAGAT_OK) return rc;
       int cur = 0, hp = H, wp = W;          // physical size of the map in buf[cur]
-      for (int l = 1; l < 5; ++l) {
-        const bool pooled = (l - 1) % 2 == 0;                 // the previous layer (0, 2) was followed by a pool
+      const bool last_pooled = pool_after[nl - 1];
+      for (int l = 1; l < nl; ++l) {
+        const bool pooled = pool_after[l - 1];                // the previous layer was followed by a pool
         const int hin = pooled ? hp / 2 : hp, win = pooled ? wp / 2 : wp;
+        const bool to_feat = l == nl - 1 && !last_pooled;      // the last map IS the feature row: [cell][channel]
         magat_conv_gemm_desc g = {};
         g.in = buf[cur]; g.wt = pk + d->off[2 + 2 * (l - 1)]; g.bias = pk + d->off[3 + 2 * (l - 1)];
-        g.out = buf[(cur + 1) % 3];
-        g.in_pix_stride = pixs(chans[l]); g.out_pix_stride = pixs(chans[l + 1]);
-        g.in_tile_stride = tiles(hp * wp, chans[l]); g.out_tile_stride = tiles(hin * win, chans[l + 1]);
-        g.M = mm; g.Cin = chans[l]; g.lda = chans[l]; g.Hin = hin; g.Win = win; g.kH = g.kW = 3; g.stride = 1; g.pad = 1;
-        g.Hout = hin; g.Wout = win; g.Cout = chans[l + 1]; g.ldc = chans[l + 1]; g.relu = 1;
+        g.out = to_feat ? feat + (size_t)m0 * ldfeat : buf[(cur + 1) % 3];
+        g.in_pix_stride = pixs(chans[l]); g.out_pix_stride = to_feat ? chans[l + 1] : pixs(chans[l + 1]);
+        g.in_tile_stride = tiles(hp * wp, chans[l]); g.out_tile_stride = to_feat ? 0 : tiles(hin * win, chans[l + 1]);
+        g.M = mm; g.Cin = chans[l]; g.lda = chans[l]; g.Hin = hin; g.Win = win; g.kH = g.kW = 3; g.stride = 1;
+        g.pad = dils[l]; g.dilation = dils[l];
+        g.Hout = hin; g.Wout = win; g.Cout = chans[l + 1]; g.ldc = to_feat ? ldfeat : chans[l + 1]; g.relu = 1;
         g.tag = MAGAT_TAG_BLOCK_CONV + (l - 1);
         if (pooled) { g.pool = 2; g.pool_w = wp; }
         rc = magat_conv_gemm_f32(&g, stream);
         if (rc != MAGAT_OK) return rc;
         cur = (cur + 1) % 3; hp = hin; wp = win;
       }
-      // final MaxPool2d(2) -> feat [mm][(hp/2)(wp/2)][128]: a pooled 1x1 GEMM with identity weights, one output pixel per
-      // pooled cell.  At the reference's FOV = 9 (11 x 11 maps) that is one cell; at other map sizes the features are
-      // (cell, channel)-ordered here where the reference's Flatten is (channel, cell)-ordered - encoder.fold_default_cnn
-      // permutes the columns of every weight that reads them (compressMLP, the skip-concat half of actionsMLP) to match
-      const int hf = hp / 2, wf = wp / 2;
-      if (hf < 1 || wf < 1 || d->n_feat != 128 * hf * wf) return MAGAT_ERR_BAD_SHAPE;
-      magat_conv_gemm_desc g = {};
-      g.in = buf[cur]; g.wt = pk + d->off[14]; g.out = feat + (size_t)m0 * ldfeat;
-      g.in_pix_stride = pixs(128); g.in_tile_stride = tiles(hp * wp, 128);
-      g.M = mm; g.Cin = 128; g.lda = 128; g.Hin = hf; g.Win = wf;
-      g.kH = 1; g.kW = 1; g.stride = 1; g.pad = 0; g.Hout = hf; g.Wout = wf; g.Cout = 128; g.ldc = ldfeat;
-      g.out_pix_stride = 128;
-      g.pool = 2; g.pool_w = wp; g.tag = MAGAT_TAG_HEAD;
-      rc = magat_conv_gemm_f32(&g, stream);
-      if (rc != MAGAT_OK) return rc;
+      const int hf = last_pooled ? hp / 2 : hp, wf = last_pooled ? wp / 2 : wp;
+      if (hf < 1 || wf < 1 || d->n_feat != clast * hf * wf) return MAGAT_ERR_BAD_SHAPE;
+      if (last_pooled) {
+        // final MaxPool2d(2) -> feat [mm][hf wf][clast]: a pooled 1x1 GEMM with identity weights, one output pixel per pooled
+        // cell.  At the reference's FOV = 9 (11 x 11 maps) the Default CNN ends on one cell; at other map sizes (and for the
+        // dilated variants) the features are (cell, channel)-ordered here where the reference's Flatten is (channel, cell)-
+        // ordered - encoder.fold_default_cnn / fold_dilated_cnn permute the columns of every weight that reads them
+        magat_conv_gemm_desc g = {};
+        g.in = buf[cur]; g.wt = pk + d->off[14]; g.out = feat + (size_t)m0 * ldfeat;
+        g.in_pix_stride = pixs(clast); g.in_tile_stride = tiles(hp * wp, clast);
+        g.M = mm; g.Cin = clast; g.lda = clast; g.Hin = hf; g.Win = wf;
+        g.kH = 1; g.kW = 1; g.stride = 1; g.pad = 0; g.Hout = hf; g.Wout = wf; g.Cout = clast; g.ldc = ldfeat;
+        g.out_pix_stride = clast;
+        g.pool = 2; g.pool_w = wp; g.tag = MAGAT_TAG_HEAD;
+        rc = magat_conv_gemm_f32(&g, stream);
+        if (rc != MAGAT_OK) return rc;
+      }
       if (d->n_comp > 0) {
         rc = magat_linear_tagged_f32(feat + (size_t)m0 * ldfeat, ldfeat, pk + d->off[16], pk + d->off[17],
                                      comp + (size_t)m0 * ldcomp, ldcomp, mm, d->n_comp, d->n_feat, 1,

@@ -432,3 +432,63 @@ def fold_default_cnn(sd, H=11, W=11, pre="ConvLayers", compress=None):
         n_comp = compress[0].shape[0]
     pack = torch.cat(parts).to(torch.float32).contiguous()
     return pack, offs, dict(variant=2, H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=128, cells=(hf, wf))
+
+
+DILATED_CNN = {1: dict(chans=[3, 32, 32, 64, 64, 128], dil=[1, 3, 1, 3, 1], variant=3),
+               2: dict(chans=[3, 32, 32, 64, 64], dil=[1, 3, 1, 3], variant=4)}
+
+
+def dilated_cnn_cells(H, W):
+    """Map size behind the dilated CNNs of DecentralPlannerNet (decentralplanner.py:138-162): every convolution keeps the size
+    (padding = dilation), MaxPool2d(2) behind layers 1 and 3."""
+    return (H // 2) // 2, (W // 2) // 2
+
+
+def fold_dilated_cnn(sd, version, H=11, W=11, pre="ConvLayers", compress=None):
+    """config.use_dilated of DecentralPlannerNet (graphs/models/decentralplanner.py:57-86, 138-162): version 1 = 5 x, version 2 =
+    4 x [Conv2d(3 x 3, dilation = padding = 1 3 1 3 (1), bias) + BatchNorm2d + ReLU] with MaxPool2d(2) behind layers 1 and 3.
+    Sequential indices: conv at 0, 3, 7, 10 (, 14).  Pack as fold_default_cnn's (encoder variant 3 / 4): off[0..1] conv0, off[2+2i],
+    off[3+2i] conv i+1, off[14] identity [clast][clast] (version 2 ends on a pool), off[16..17] compressMLP with its columns
+    permuted from the reference's (channel, y, x) Flatten to the kernels' (cell, channel) order."""
+    spec = DILATED_CNN[version]
+    chans = spec["chans"]
+    nl = len(chans) - 1
+    sd = {k: v.detach().cpu() for k, v in sd.items() if k.startswith(pre)}
+    parts, offs, cursor = [], [0] * 32, [0]
+    hf, wf = dilated_cnn_cells(H, W)
+    if hf < 1 or wf < 1:
+        raise ValueError("the dilated CNNs need maps of at least 4 x 4; got %d x %d" % (H, W))
+
+    def put(slot, t):
+        t = t.reshape(-1).double()
+        offs[slot] = cursor[0]
+        pad = (-t.numel()) % 4
+        if pad:
+            t = torch.cat((t, torch.zeros(pad, dtype=t.dtype)))
+        parts.append(t)
+        cursor[0] += t.numel()
+
+    idx = 0
+    for l in range(nl):
+        w, b = sd["%s.%d.weight" % (pre, idx)].double(), sd["%s.%d.bias" % (pre, idx)].double()
+        s_, sh = _bn_scale_shift(sd, "%s.%d" % (pre, idx + 1))
+        bias = b * s_ + sh
+        if l == 0:
+            put(0, w.reshape(32, 27) * s_.view(-1, 1))
+            put(1, bias)
+        else:
+            put(2 + 2 * (l - 1), _conv_rows(w, s_))
+            put(3 + 2 * (l - 1), bias)
+        idx += 3 + (1 if l in (1, 3) else 0)
+    clast = chans[-1]
+    put(14, torch.eye(clast, dtype=torch.float64))
+    n_feat, n_comp = clast * hf * wf, 0
+    if compress is not None:
+        cw = compress[0].detach().cpu().double()
+        assert cw.shape[1] == n_feat, "compressMLP in_features must equal clast * pooled cells"
+        put(16, cell_major_columns(cw, hf, wf, c=clast))
+        put(17, compress[1].detach().cpu().double())
+        n_comp = compress[0].shape[0]
+    pack = torch.cat(parts).to(torch.float32).contiguous()
+    return pack, offs, dict(variant=spec["variant"], H=H, W=W, n_feat=n_feat, n_comp=n_comp, clast=clast, cells=(hf, wf))
+

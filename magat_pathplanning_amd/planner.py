@@ -398,8 +398,12 @@ class DecentralPlannerGATNet(nn.Module):
             rt.desc = d
         else:
             side = self.config.FOV + 2
-            pack, offs, meta = enc.fold_default_cnn(sd, side, side, "ConvLayers",
-                                                    (sd["compressMLP.0.weight"], sd["compressMLP.0.bias"]))
+            if getattr(self, "dilated_version", 0):
+                pack, offs, meta = enc.fold_dilated_cnn(sd, self.dilated_version, side, side, "ConvLayers",
+                                                        (sd["compressMLP.0.weight"], sd["compressMLP.0.bias"]))
+            else:
+                pack, offs, meta = enc.fold_default_cnn(sd, side, side, "ConvLayers",
+                                                        (sd["compressMLP.0.weight"], sd["compressMLP.0.bias"]))
             rt.pack = pack.to(dev)
             d = nat.EncoderDesc()
             d.variant, d.H, d.W = meta["variant"], meta["H"], meta["W"]
@@ -761,7 +765,7 @@ class DecentralPlannerNet(DecentralPlannerGATNet):
     compressMLP.0.*, GFL.0.{weight (F,1,K,G), bias (F,1)}, actionsMLP.*).  Inference runs on the same gfx950 kernels as
     DecentralPlannerGATNet: magat_encoder_forward_f32, the CSR graph-filter kernels (magat_gnn_forward_csr_f32) and the
     action-head GEMM; with autograd on, the graph layer's HIP forward / backward (_GnnTrainFunction) under torch autograd.
-    The reference's dilated-convolution variants (config.use_dilated) are outside the built path."""
+    config.use_dilated (decentralplanner.py:57-86, 138-162: the dilated CNNs, use_dilated_version 1 | 2) is built too (round 6)."""
 
     def __init__(self, config):
         nn.Module.__init__(self)
@@ -769,15 +773,31 @@ class DecentralPlannerNet(DecentralPlannerGATNet):
         self.config = config
         self.S = None
         self.numAgents = config.num_agents
-        if getattr(config, "use_dilated", False):
-            raise NotImplementedError("config.use_dilated: the dilated-CNN variants of DecentralPlannerNet "
-                                      "(decentralplanner.py:57-86) are outside the built hot path")
+        self.dilated_version = 0
         self.skip = "only"
         inW = inH = config.FOV + 2
         numAction = 5
         mode = config.CNN_mode
         self.cnn_mode = mode
-        if mode in ("ResNetSlim_withMLP", "ResNetLarge_withMLP"):
+        if getattr(config, "use_dilated", False):
+            # decentralplanner.py:57-86, 138-162: the dilated CNNs ("DCP v5.1 / v5.2") take precedence over CNN_mode
+            version = int(getattr(config, "use_dilated_version", 1))
+            if version not in enc.DILATED_CNN:
+                raise NotImplementedError("use_dilated_version %r (the reference defines 1 and 2)" % (version,))
+            spec = enc.DILATED_CNN[version]
+            chans, dil = spec["chans"], spec["dil"]
+            layers, w, h = [], inW, inH
+            for l in range(len(chans) - 1):
+                layers += [nn.Conv2d(chans[l], chans[l + 1], 3, stride=1, padding=dil[l], dilation=dil[l], bias=True),
+                           nn.BatchNorm2d(chans[l + 1]), nn.ReLU(inplace=True)]
+                if l in (1, 3):
+                    layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+                    w, h = (w - 2) // 2 + 1, (h - 2) // 2 + 1
+            self.ConvLayers = nn.Sequential(*layers)
+            numFeatureMap = chans[-1] * w * h
+            self.cnn_mode = "Dilated"
+            self.dilated_version = version
+        elif mode in ("ResNetSlim_withMLP", "ResNetLarge_withMLP"):
             body = ResNetSlim() if "Slim" in mode else ResNet()
             self.ConvLayers = nn.Sequential(body, nn.Dropout(0.2), nn.Flatten(),
                                             nn.Linear(1152, config.numInputFeatures, bias=True))

@@ -362,6 +362,22 @@ def default_cnn_forward(x, sd, pre="ConvLayers"):
     return x
 
 
+def dilated_cnn_forward(x, sd, version=1, pre="ConvLayers"):
+    """config.use_dilated of DecentralPlannerNet (graphs/models/decentralplanner.py:57-86: numChannel / numDilated / nPaddingSzie of
+    use_dilated_version 1 | 2; :138-162: Conv2d(3 x 3, dilation, padding) + BatchNorm2d + ReLU per layer, MaxPool2d(2, 2) behind
+    layers 1 and 3).  Sequential indices: conv, bn, relu [, pool] per layer."""
+    dil = [1, 3, 1, 3, 1] if version == 1 else [1, 3, 1, 3]
+    idx = 0
+    for l, d in enumerate(dil):
+        x = tnf.conv2d(x, sd["%s.%d.weight" % (pre, idx)], sd["%s.%d.bias" % (pre, idx)], stride=1, padding=d, dilation=d)
+        x = torch.relu(_bn(x, sd, "%s.%d" % (pre, idx + 1)))
+        idx += 3
+        if l in (1, 3):
+            x = tnf.max_pool2d(x, 2, 2)
+            idx += 1
+    return x
+
+
 def conv_layers_forward(x, sd, cnn_mode):
     """self.ConvLayers(...) then .view(B*N,-1) (…bottleneck.py:90-147, 294-297);
     Dropout is identity in eval()."""
@@ -409,7 +425,10 @@ def planner_gnn_forward(x, S, sd, cfg):
     class always scrubs NaN (:346), like the BottomNeck_only GAT file.  S is mutated in place like the reference."""
     B, N = x.shape[0], x.shape[1]
     S4 = add_gso(S, cfg.GSO_mode, "BottomNeck_only")
-    feat = conv_layers_forward(x.reshape(B * N, *x.shape[2:]), sd, cfg.CNN_mode)
+    if getattr(cfg, "use_dilated", False):      # (decentralplanner.py:138: the dilated CNNs take precedence over CNN_mode)
+        feat = dilated_cnn_forward(x.reshape(B * N, *x.shape[2:]), sd, int(getattr(cfg, "use_dilated_version", 1))).flatten(1)
+    else:
+        feat = conv_layers_forward(x.reshape(B * N, *x.shape[2:]), sd, cfg.CNN_mode)
     comp = torch.relu(tnf.linear(feat, sd["compressMLP.0.weight"], sd["compressMLP.0.bias"]))
     xg = comp.reshape(B, N, comp.shape[1]).permute(0, 2, 1)
     yg = graph_filter_batch_forward(xg, S4, sd["GFL.0.weight"], sd["GFL.0.bias"])

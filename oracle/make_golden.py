@@ -286,6 +286,42 @@ def main_gnn_model():
         print("wrote", path, os.path.getsize(path) // 1024, "KB", "max|logit| %.3g" % float(np.abs(out["logits"]).max()))
 
 
+def main_gnn_dilated():
+    """Round 6: DecentralPlannerNet with config.use_dilated (graphs/models/decentralplanner.py:57-86, 138-162: the dilated CNNs,
+    use_dilated_version 1 and 2) - model-level fixtures made by the real reference."""
+    from oracle._ref_import import import_reference_gnn_model
+    cls = import_reference_gnn_model()
+    cases = [("gnn_dilated_v1", dict(num_agents=9, nGraphFilterTaps=2), 1, 2),
+             ("gnn_dilated_v2", dict(num_agents=11, nGraphFilterTaps=3, GSO_mode="dist_GSO_one"), 2, 3)]
+    for i, (name, kw, version, B) in enumerate(cases):
+        cfg = make_config(use_dilated=True, no_ReLU=False, **kw)
+        cfg.use_dilated_version = version
+        seed = 9393 + i
+        gen = torch.Generator().manual_seed(seed)
+        torch.manual_seed(seed)
+        model = cls(cfg).eval()
+        with torch.no_grad():
+            for mod in model.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.running_mean.normal_(0, 0.2, generator=gen)
+                    mod.running_var.uniform_(0.5, 1.5, generator=gen)
+                    mod.bias.normal_(0, 0.1, generator=gen)
+        N = cfg.num_agents
+        x = fov_states(gen, B, N)
+        S = tricky_gso(gen, B, N, 0.3, True)
+        S_in = S.clone()
+        model.addGSO(S)
+        with torch.no_grad():
+            logits = model(x)
+        out = dict(x=x.numpy().astype(np.uint8), S=S_in.numpy(), S_after=model.S[:, 0].numpy(), logits=logits.numpy(),
+                   cfg=np.array(repr(vars(cfg))))
+        for k, v in model.state_dict().items():
+            out["sd/" + k] = v.numpy()
+        path = os.path.join(OUT, "gnnmodel_%s.npz" % name[4:])
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path) // 1024, "KB", "max|logit| %.3g" % float(np.abs(out["logits"]).max()))
+
+
 def main_small():
     """Round 4: layer fixtures at the PUBLISHED widths on small graphs (scripts/train_DMap.sh:42-46: 10 agents, bottleneckFeature
     32, four heads, K = 2) - the shapes the wave-per-instance one-launch kernel (csrc/gat_small.hip) takes: N <= 32,
@@ -458,6 +494,8 @@ if __name__ == "__main__":
         main_small()
     elif "--gnn-model" in sys.argv:
         main_gnn_model()
+    elif "--gnn-dilated" in sys.argv:
+        main_gnn_dilated()
     elif "--fov" in sys.argv:
         main_fov()
     elif "--directed" in sys.argv:

@@ -171,6 +171,41 @@ def test_conv_gemm_vs_conv2d(gpu_device, cin, cout, hin, stride, c2):
     np.testing.assert_allclose(got.numpy(), ref.float().numpy(), rtol=0, atol=3e-5)
 
 
+@pytest.mark.parametrize("cin,cout,hin,dil,pool", [(32, 32, 11, 3, False), (64, 64, 5, 3, False), (32, 64, 11, 2, False),
+                                                    (32, 64, 5, 1, True), (64, 128, 11, 3, True), (32, 32, 4, 3, False)])
+def test_conv_gemm_dilated_vs_conv2d(gpu_device, cin, cout, hin, dil, pool):
+    """ABI 8: nn.Conv2d(3 x 3, dilation = padding = d) + bias + ReLU on the float32 kernel (the dilated CNNs of
+    DecentralPlannerNet: dilation 3 on 11 x 11 and 5 x 5 maps, where most taps of an edge pixel leave the map), also reading the
+    2 x 2 max-pool of a physical map on load (`hin` is then the pooled size); the f16x3 kernels decline a dilated window."""
+    nat, lib = _nat()
+    M = 70
+    g = torch.Generator().manual_seed(cin + 7 * cout + hin + dil)
+    hphys = 2 * hin + 1 if pool else hin                  # (odd physical size: the last row / column falls out of the pool)
+    xp = torch.randn(M, cin, hphys, hphys, generator=g)
+    x = tnf.max_pool2d(xp, 2) if pool else xp
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = tnf.conv2d(x.double(), w.double(), b.double(), 1, dil, dil).clamp_min(0)
+    wt = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().to(gpu_device)
+    xin = _to_pixel_major(xp).to(gpu_device)
+    out = torch.full((hin * hin, M, cout), float("nan"), device=gpu_device)
+    bd = b.to(gpu_device)
+    d = nat.ConvGemmDesc()
+    d.inp, d.wt, d.bias, d.out = xin.data_ptr(), wt.data_ptr(), bd.data_ptr(), out.data_ptr()
+    d.in_pix_stride, d.out_pix_stride = M * cin, M * cout
+    d.M, d.Cin, d.lda, d.Hin, d.Win, d.kH, d.kW, d.stride, d.pad = M, cin, cin, hin, hin, 3, 3, 1, dil
+    d.Hout, d.Wout, d.Cout, d.ldc, d.relu, d.dilation = hin, hin, cout, cout, 1, dil
+    if pool:
+        d.pool, d.pool_w = 2, hphys
+    nat.check(lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)), "conv_gemm")
+    torch.cuda.synchronize()
+    got = _from_pixel_major(out.cpu(), hin, hin)
+    np.testing.assert_allclose(got.numpy(), ref.float().numpy(), rtol=0, atol=3e-5)
+    if dil > 1:
+        d.in_fmt = 4
+        assert lib.magat_conv_gemm_f32(ctypes.byref(d), nat.current_stream(gpu_device)) == -2      # MAGAT_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("H", [11, 9, 18, 19, 27])
 def test_conv_first(gpu_device, H):
     """(19 and 27: the 32 padded images of a workgroup exceed the LDS, the kernel walks row bands)"""

@@ -93,7 +93,7 @@ def test_gnn_model_oracle_matches_reference(path):
     """DecentralPlannerNet (graphs/models/decentralplanner.py; oracle/make_golden.py --gnn-model): the oracle's restatement
     against logits and the mutated GSO made by the real reference."""
     z, sd, cfg = load_model_fixture(path)
-    assert len(GNNMODEL) == 3
+    assert len(GNNMODEL) == 5
     x = torch.from_numpy(z["x"].astype(np.float32))
     S = torch.from_numpy(z["S"].copy())
     got = orc.planner_gnn_forward(x, S, sd, cfg)
