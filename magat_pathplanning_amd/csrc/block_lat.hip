@@ -62,7 +62,27 @@ struct LatParams {
   const float* x; const float* pk; long long off[18]; int* book;
   // STEM: stem weights [32][27] + bias (x the activation scale when folded), layer1.conv1 fragment-major + its bias
   const float* w0; const float* b0; const char* w1f; const float* b1c;
+  long long* dbg;      // MAGAT_DEBUG_HOOKS builds: [grid][4 waves][16] cycle stamps (tools/lat_phase_probe.py)
 };
+#ifdef MAGAT_DEBUG_HOOKS
+#define LAT_STAMP(i) do { if (p.dbg && (threadIdx.x & 63) == 0) p.dbg[((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+long long* g_lat_dbg = nullptr;
+#else
+#define LAT_STAMP(i) do { } while (0)
+#endif
+
+// The weight ring of a wave: fragments of the first D - 1 k steps of a walk.  A walk finds them REQUESTED ALREADY - by ring_fill,
+// issued behind the previous walk's last MFMA, in front of that stage's epilogue and barrier: the L2 round trip of a stage's first
+// fragments (1.5-2 k cycles with one wave per SIMD; eight stages) then hides under the epilogue instead of opening every walk
+// (tools/lat_phase_probe.py: 2-3 k cycles per stage beyond its MFMA issue time before, ~1 k after).  Every walk has >= 8 k steps.
+typedef u32x4 WRing[lat::D][2];
+__device__ __forceinline__ void ring_fill(WRing& w, const char* wbase, unsigned lane16) {
+#pragma unroll
+  for (int j = 0; j < lat::D - 1; ++j) {
+    w[j][0] = *reinterpret_cast<const u32x4*>(wbase + (size_t)j * 2048 + lane16);
+    w[j][1] = *reinterpret_cast<const u32x4*>(wbase + (size_t)j * 2048 + (lane16 + 1024u));
+  }
+}
 
 // value pair -> its two f16 planes, remembering whether a value left +-65504: the instruction sequence of split_pair_f16
 // (conv_gemm_bf16x6.hip) - the float32 loaders of the long-K head and of compressMLP, whose planes this kernel reproduces
@@ -96,18 +116,15 @@ __device__ __forceinline__ void split2s_lat(float x, float y, unsigned& p1, unsi
 // lds + abase + 32 s (second plane PS bytes behind) - every column of the 32-wide tile carries the same row -, this wave's
 // 32 output channels' weight fragments at wbase (1 KB per plane and step)
 template <int NSTEP, int PS>
-__device__ __forceinline__ void walk_lin(char* lds, unsigned abase, const char* wbase, unsigned lane16, f32x16& acc) {
+__device__ __forceinline__ void walk_lin(char* lds, unsigned abase, const char* wbase, unsigned lane16, f32x16& acc, WRing& w) {
   using namespace lat;
-  u32x4 w[D][2];
+  static_assert(NSTEP >= D - 1, "ring_fill requests D - 1 k steps");
   auto load_w = [&](int step, u32x4 (&b)[2]) {
     b[0] = *reinterpret_cast<const u32x4*>(wbase + (size_t)step * 2048 + lane16);
     b[1] = *reinterpret_cast<const u32x4*>(wbase + (size_t)step * 2048 + (lane16 + 1024u));
   };
   u32x4 av[AV][2];
   auto rd = [&](int i, int pl, u32x4& dst) { dst = *reinterpret_cast<const u32x4*>(lds + abase + (32 * i + pl * PS)); };
-#pragma unroll
-  for (int j = 0; j < D - 1; ++j)
-    if (j < NSTEP) load_w(j, w[j]);
 #pragma unroll
   for (int j = 0; j < AV - 1; ++j)
     if (j < NSTEP) {
@@ -138,11 +155,11 @@ __device__ __forceinline__ void walk_lin(char* lds, unsigned abase, const char* 
 // segment over the map at in2_off (same pixel).  ab[s]: the lane's byte offset of (its slot + MINSH) in chunk fh of a map.
 template <int NT, int KSM, int KS2, int PS_IN, int PS_IN2, int RPX = lat::RP, int BLKX = lat::BLK1>
 __device__ __forceinline__ void walk1(char* lds, const unsigned (&ab)[NT], int in_off, int in2_off, const char* wbase,
-                                      unsigned lane16, f32x16 (&acc)[NT]) {
+                                      unsigned lane16, f32x16 (&acc)[NT], WRing& w) {
   using namespace lat;
   constexpr int MINSHX = -(RPX + 1);      // (RPX / BLKX: row pitch and block size of the map the taps read: the chain's, or the stem map's)
   constexpr int NMAIN = 9 * KSM, NSTEP = NMAIN + KS2, NI = NSTEP * NT;
-  u32x4 w[D][2];
+  static_assert(NSTEP >= D - 1, "ring_fill requests D - 1 k steps");
   auto load_w = [&](int step, u32x4 (&b)[2]) {
     b[0] = *reinterpret_cast<const u32x4*>(wbase + (size_t)step * 2048 + lane16);
     b[1] = *reinterpret_cast<const u32x4*>(wbase + (size_t)step * 2048 + (lane16 + 1024u));
@@ -159,9 +176,6 @@ __device__ __forceinline__ void walk1(char* lds, const unsigned (&ab)[NT], int i
       dst = *reinterpret_cast<const u32x4*>(lds + (ab[s] + (unsigned)in_off) + (sh * 16 + pl * PS_IN + ks * 2 * BLKX));
     }
   };
-#pragma unroll
-  for (int j = 0; j < D - 1; ++j)
-    if (j < NSTEP) load_w(j, w[j]);
 #pragma unroll
   for (int j = 0; j < AV - 1; ++j)
     if (j < NI) {
@@ -194,7 +208,7 @@ __device__ __forceinline__ void walk1(char* lds, const unsigned (&ab)[NT], int i
 template <int NT, int CIN, int C2, int COUT, int RPX = lat::RP, int BLKX = lat::BLK1>
 __device__ __forceinline__ void lat_stage(char* lds, const unsigned (&ab)[NT], const unsigned (&sl16)[NT], const bool (&live)[NT],
                                           int in_off, int in2_off, int out_off, const char* wts, int ct_out, const float* bias32,
-                                          float scale, unsigned lane16, bool& clamped) {
+                                          float scale, unsigned lane16, bool& clamped, WRing& w, const char* wnext) {
   using namespace lat;
   constexpr int KSM = CIN / 16, KS2 = C2 / 16;
   constexpr int PS_OUT = (COUT / 8) * BLK1;
@@ -203,7 +217,8 @@ __device__ __forceinline__ void lat_stage(char* lds, const unsigned (&ab)[NT], c
   for (int s = 0; s < NT; ++s)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-  walk1<NT, KSM, KS2, (CIN / 8) * BLKX, (C2 > 0 ? C2 / 8 : 1) * BLK1, RPX, BLKX>(lds, ab, in_off, in2_off, wts, lane16, acc);
+  walk1<NT, KSM, KS2, (CIN / 8) * BLKX, (C2 > 0 ? C2 / 8 : 1) * BLK1, RPX, BLKX>(lds, ab, in_off, in2_off, wts, lane16, acc, w);
+  ring_fill(w, wnext, lane16);      // the wave's NEXT walk's first fragments: in flight under the epilogue and the barrier below
   const int fh = (int)(lane16 >> 9);
   f32x4 bq[4];
 #pragma unroll
@@ -336,6 +351,16 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
   int pre = 0;
   if (HEAD && p.book) pre = __hip_atomic_load(p.book, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned lane16 = (unsigned)lane * 16u;
+  // this wave's walks in order and their weight blocks: (STEM: layer1.conv1 -) A (waves 0 / 1 only) - B - C - layer3.conv1 - conv2
+  // over MA - conv2 over MB + residual (- HEAD: head - compressMLP).  The first one's ring is requested here, every later one's behind
+  // the walk in front of it (ring_fill).
+  const char* const wB_ = p.wB + (size_t)(wave & 1) * (18 * 2) * 1024;
+  const char* const wC_ = p.wC + (size_t)(wave & 1) * (38 * 2) * 1024;
+  const char* const w31_ = p.w1 + (size_t)wave * 72 * 1024;
+  const char* const w32a_ = p.w2a + (size_t)wave * 72 * 1024;
+  const char* const w32b_ = p.w2b + (size_t)wave * 80 * 1024;
+  WRing wr;
+  ring_fill(wr, wave < 2 ? (STEM ? p.w1f : p.wA) : wB_, lane16);
   const int fr = lane & 31, fh = lane >> 5;
   // the lane's pixels: tile s, column fr -> position g = 32 s + fr = 4 cell + e in pooled-cell order; the order of a cell's four
   // pixels over its quad of lanes is the pairing of block_full_p_kernel's in-register pooling (file header)
@@ -359,6 +384,7 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
   }
   const float sA = *p.sA, sB = *p.sB, sC = *p.sC, s1 = *p.s1, s2 = *p.s2;
   bool clamped = false;
+  LAT_STAMP(0);
   if (!STEM) {
     // the agent's two input maps (stem8_kernel's outputs): 2 x 36 pixels x 8 (plane, chunk) pieces of 16 B, requested in front of
     // the LDS clear
@@ -413,6 +439,7 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
     const float scale1 = *reinterpret_cast<const float*>(p.w1f + 9 * 2 * 2 * 1024) * (1.f / 16.f);
     for (int i = t; i < L_TOTAL_STEM / 16; i += 256) *reinterpret_cast<u32x4*>(lds + 16 * i) = u32x4{0u, 0u, 0u, 0u};
     L3_LDS_SYNC();
+    LAT_STAMP(1);
     if (t < 121) {
       const int y = t / 11, x = t - 11 * y;
       // (range guard of the INPUT: a NaN / Inf / |x| > 65504 entry must not become a finite clamp)
@@ -425,6 +452,7 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
       *reinterpret_cast<uint2*>(dst + S_INPL) = uint2{l01, l2x};
     }
     L3_LDS_SYNC();
+    LAT_STAMP(2);
     {
       // the stem: wave w = pixels 32 w .. 32 w + 31 (pixel 120 repeated behind the map's end: stored to a dead slot)
       const int pixr = 32 * wave + fr, pix = pixr < 121 ? pixr : 120;
@@ -467,6 +495,7 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
       clamped |= cl > 65504.f && lv;      // 16 x the stem output beyond the planes' range
     }
     L3_LDS_SYNC();
+    LAT_STAMP(3);
     if (wave < 2) {
       // layer1.conv1 over the stem map (stride 2): waves 0 / 1 = row tile 0 / 1 -> X1
       const int g = 32 * wave + fr;
@@ -477,7 +506,7 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
       const unsigned abS[1] = {(unsigned)(S_RP * (2 * oy + 1) + (2 * ox + 1) - (S_RP + 1)) * 16u + (unsigned)fh * S_BLK};
       const unsigned slS[1] = {wave ? slT[1] : slT[0]};
       const bool lvS[1] = {lv};
-      lat_stage<1, 32, 0, 32, S_RP, S_BLK>(lds, abS, slS, lvS, L_SMAP, 0, L_X1, p.w1f, 0, p.b1c, scale1, lane16, clamped);
+      lat_stage<1, 32, 0, 32, S_RP, S_BLK>(lds, abS, slS, lvS, L_SMAP, 0, L_X1, p.w1f, 0, p.b1c, scale1, lane16, clamped, wr, p.wA);
     } else {
       // the residual branch's input: the stem map at the 36 stride-2 pixels, planes x 2^-4 -> X2
       typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -494,8 +523,9 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
         *reinterpret_cast<u32x4*>(lds + L_X2 + blk * BLK1 + (RP * (oy + 1) + ox + 1) * 16) = v;
       }
     }
-    __syncthreads();
+    L3_LDS_SYNC();
   }
+  LAT_STAMP(4);
   const int ct = wave & 1, tl = wave >> 1;
   const unsigned ab1[1] = {tl ? abT[1] : abT[0]}, sl1[1] = {tl ? slT[1] : slT[0]};
   const bool lv1[1] = {tl ? liveT[1] : liveT[0]};
@@ -503,20 +533,23 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
   if (wave < 2) {
     const unsigned abA[1] = {wave ? abT[1] : abT[0]}, slA[1] = {wave ? slT[1] : slT[0]};
     const bool lvA[1] = {wave ? liveT[1] : liveT[0]};
-    lat_stage<1, 32, 32, 32>(lds, abA, slA, lvA, L_X1, L_X2, L_Y, p.wA, 0, p.bA, sA, lane16, clamped);
+    lat_stage<1, 32, 32, 32>(lds, abA, slA, lvA, L_X1, L_X2, L_Y, p.wA, 0, p.bA, sA, lane16, clamped, wr, wB_);
   }
-  __syncthreads();
+  L3_LDS_SYNC();      // (LDS hand-over only: the next walk's ring is in flight)
+  LAT_STAMP(5);
   // B: layer2.conv1 (32 -> 64)   Y -> Z      (wave = channel tile x row tile)
-  lat_stage<1, 32, 0, 64>(lds, ab1, sl1, lv1, L_Y, 0, L_Z, p.wB + (size_t)ct * (18 * 2) * 1024, ct, p.bB + 32 * ct, sB, lane16, clamped);
-  __syncthreads();
+  lat_stage<1, 32, 0, 64>(lds, ab1, sl1, lv1, L_Y, 0, L_Z, wB_, ct, p.bB + 32 * ct, sB, lane16, clamped, wr, wC_);
+  L3_LDS_SYNC();      // (LDS hand-over only: the next walk's ring is in flight)
+  LAT_STAMP(6);
   // C: layer2.conv2 (64 -> 64) + downsample(Y)   Z, Y -> layer3's input
-  lat_stage<1, 64, 32, 64>(lds, ab1, sl1, lv1, L_Z, L_Y, L_IN3, p.wC + (size_t)ct * (38 * 2) * 1024, ct, p.bC + 32 * ct, sC, lane16,
-                           clamped);
-  __syncthreads();
+  lat_stage<1, 64, 32, 64>(lds, ab1, sl1, lv1, L_Z, L_Y, L_IN3, wC_, ct, p.bC + 32 * ct, sC, lane16, clamped, wr, w31_);
+  L3_LDS_SYNC();      // (LDS hand-over only: the next walk's ring is in flight)
+  LAT_STAMP(7);
   // layer3.conv1 (64 -> 128): wave = channel tile, both row tiles; channels 0..63 -> MA, 64..127 -> MB (the two K halves of conv2)
-  lat_stage<2, 64, 0, 64>(lds, abT, slT, liveT, L_IN3, 0, wave < 2 ? L_MA : L_MB, p.w1 + (size_t)wave * 72 * 1024, wave & 1,
-                          p.b1 + 32 * wave, s1, lane16, clamped);
-  __syncthreads();
+  lat_stage<2, 64, 0, 64>(lds, abT, slT, liveT, L_IN3, 0, wave < 2 ? L_MA : L_MB, w31_, wave & 1, p.b1 + 32 * wave, s1, lane16, clamped,
+                          wr, w32a_);
+  L3_LDS_SYNC();      // (LDS hand-over only: the next walk's ring is in flight)
+  LAT_STAMP(8);
   // layer3.conv2 (128 -> 128) + downsample(layer3's input): K over MA, then over MB + the residual segment - the eight-agent form's
   // order - then relu(acc * s2 + bias), the 2 x 2 sums across each quad of lanes, one store per cell and channel quad
   {
@@ -525,8 +558,11 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-    walk1<2, 4, 0, 8 * BLK1, 8 * BLK1>(lds, abT, L_MA, 0, p.w2a + (size_t)wave * 72 * 1024, lane16, acc);
-    walk1<2, 4, 4, 8 * BLK1, 8 * BLK1>(lds, abT, L_MB, L_IN3, p.w2b + (size_t)wave * 80 * 1024, lane16, acc);
+    walk1<2, 4, 0, 8 * BLK1, 8 * BLK1>(lds, abT, L_MA, 0, w32a_, lane16, acc, wr);
+    ring_fill(wr, w32b_, lane16);
+    walk1<2, 4, 4, 8 * BLK1, 8 * BLK1>(lds, abT, L_MB, L_IN3, w32b_, lane16, acc, wr);
+    if (HEAD) ring_fill(wr, p.hfrag + (size_t)wave * 72 * 2048, lane16);
+    LAT_STAMP(9);
     f32x4 bq[4];
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const f32x4*>(p.b2 + 32 * wave + 8 * qd + 4 * fh);
@@ -571,6 +607,7 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
   }
   if (HEAD) {
     L3_LDS_SYNC();
+    LAT_STAMP(10);
     // ---- encoder head: feat = W_head . pooled (K = 9 x 128 in the long-K kernel's order: 32-channel slab outer, cell inner) ----
     float insc = 1.f, insc2 = 1.f;
     if (p.insc) insc = *p.insc;
@@ -580,7 +617,9 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
     f32x16 hacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
-    walk_lin<72, HP_PLANE>(lds, (unsigned)(L_HP + fh * 16), p.hfrag + (size_t)wave * 72 * 2048, lane16, hacc);
+    walk_lin<72, HP_PLANE>(lds, (unsigned)(L_HP + fh * 16), p.hfrag + (size_t)wave * 72 * 2048, lane16, hacc, wr);
+    if (32 * wave < p.ncomp) ring_fill(wr, p.cfrag + (size_t)wave * 8 * 2048, lane16);
+    LAT_STAMP(11);
     {
       const float hs = *reinterpret_cast<const float*>(p.hfrag + (size_t)4 * 72 * 2048) / insc;      // (exact: powers of two)
       bool cl = false;
@@ -605,12 +644,13 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
       clamped |= cl;
     }
     L3_LDS_SYNC();
+    LAT_STAMP(12);
     // ---- compressMLP: comp = relu(W_c . feat + b_c); ncomp = 32 | 64 | 128 outputs: the first ncomp / 32 waves ----
     if (32 * wave < p.ncomp) {
       f32x16 cacc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
-      walk_lin<8, CP_PLANE>(lds, (unsigned)(L_CP + fh * 16), p.cfrag + (size_t)wave * 8 * 2048, lane16, cacc);
+      walk_lin<8, CP_PLANE>(lds, (unsigned)(L_CP + fh * 16), p.cfrag + (size_t)wave * 8 * 2048, lane16, cacc, wr);
       const float cs = *reinterpret_cast<const float*>(p.cfrag + (size_t)(p.ncomp / 32) * 8 * 2048) / insc2;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -621,6 +661,7 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
         if (fr == 0) *reinterpret_cast<f32x4*>(p.comp + (long long)m * p.ldcomp + 32 * wave + 8 * q + 4 * fh) = v;
       }
     }
+    LAT_STAMP(13);
     if (p.book) {
       // ---- the encoder's range guard inside this launch (see lat_fallback_f32).  `pre`: the stem's clamp flag (final: the stem
       // ran before this launch; a workgroup of THIS launch that already raised it only makes a later one recompute for nothing)
@@ -641,6 +682,7 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
           __hip_atomic_store(p.book + 6, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      LAT_STAMP(14);
       return;
     }
   }
@@ -648,6 +690,10 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
 }
 
 }  // namespace
+
+#ifdef MAGAT_DEBUG_HOOKS
+extern "C" int magat_block_lat_set_debug_buffer(long long* dev_buf) { g_lat_dbg = dev_buf; return MAGAT_OK; }
+#endif
 
 static size_t lat_chain_block_bytes(int cin, int c2, int cout) { return (size_t)(cout / 32) * (9 * (cin / 16) + c2 / 16) * 2 * 1024; }
 
@@ -688,7 +734,10 @@ int magat_block_lat(const void* in1, const void* in2, const float* wchain, const
     p.hbias = head->hbias; p.cbias = head->cbias; p.insc = head->insc; p.insc2 = head->insc2;
     p.feat = head->feat; p.comp = head->comp; p.ldfeat = head->ldfeat; p.ldcomp = head->ldcomp; p.ncomp = head->ncomp;
   }
-  p.x = nullptr; p.pk = nullptr; p.book = nullptr;
+  p.x = nullptr; p.pk = nullptr; p.book = nullptr; p.dbg = nullptr;
+#ifdef MAGAT_DEBUG_HOOKS
+  p.dbg = g_lat_dbg;
+#endif
   for (int i = 0; i < 18; ++i) p.off[i] = 0;
   if (guard) {
     if (!head) return MAGAT_ERR_UNSUPPORTED;
