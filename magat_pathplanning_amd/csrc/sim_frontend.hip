@@ -26,6 +26,191 @@ __device__ __forceinline__ double block_sum(double v, double* red, int t, int nt
   return s;
 }
 
+// ---- lambda_max for graphs of at most 128 agents by ONE wave (round 6): the workgroup form below spends its time in barriers - two
+// block sums and two hand-overs per Lanczos step, a Sturm location every eight steps with two more per pass: 311 us for one
+// instance of 100 agents, 0.48 ms of a 3.06 ms closed-loop step at 512 x 100.  A wave owns the instance (rows lane and lane + 64):
+// no barrier at all, the two sums of a step are DPP row reductions, and the tridiagonal matrix is located ONCE: the walk runs its
+// min(N, 160) steps (or to an invariant subspace) - without reorthogonalisation the extreme Ritz value converges first and stays
+// put, copies of it appear beside it, never above it - and one Sturm multisection (64 probes per pass) follows.
+__device__ __forceinline__ double dpp_mov_f64(double v, int ctrl_sel) {
+  unsigned lo = (unsigned)__builtin_bit_cast(unsigned long long, v), hi = (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32);
+  switch (ctrl_sel) {      // (the control word must be a compile-time constant)
+    case 8: lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, true); break;
+    case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xf, 0xf, true); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x122, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x122, 0xf, 0xf, true); break;
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xf, 0xf, true); break;
+  }
+  return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+__device__ __forceinline__ double lane_bcast_f64(double v, int lane) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+// wave-uniform sum in a fixed order: the rotations inside each row of 16 lanes, then the four rows
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_mov_f64(v, 8);
+  v += dpp_mov_f64(v, 4);
+  v += dpp_mov_f64(v, 2);
+  v += dpp_mov_f64(v, 1);
+  return (lane_bcast_f64(v, 0) + lane_bcast_f64(v, 16)) + (lane_bcast_f64(v, 32) + lane_bcast_f64(v, 48));
+}
+#define SIM_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// rows: bit rows of W [N][words] (LDS); inv: the D^-1/2 scaling (ones without it); u: N + 1 doubles of LDS scratch; nbr: neighbour
+// lists, gso_nbr_words(N) words a row; alpha / b2: the tridiagonal matrix (diagonal, squared off-diagonal; LDS).  Called by wave 0
+// only (lane = 0..63), N <= 128.
+//   matrix-vector product: the bit rows are unpacked ONCE into byte lists padded with the index N (u[N] = 0) to the wave's largest
+//   degree, so that a step reads one word of four neighbours and four independent doubles per row - the walk over the set bits
+//   (ctz, clear, two dependent reads, an add) was ~120 cycles an edge and as long as the busiest lane's row.
+//   Sturm count: the determinant recurrence p_r = (alpha_r - x) p_{r-1} - beta_r^2 p_{r-2} (sign changes = eigenvalues below x)
+//   instead of the pivot recurrence: no fp64 division on the chain; rescaled every eight rows.
+// The reference's edge test is float64: sqrt(dx^2 + dy^2) < R on integer cell offsets.  The correctly rounded square root is
+// monotone, so the test is "squared distance < q" for one integer q per radius: the smallest q whose rounded root is not below R,
+// found by stepping from floor(R^2) with the very same float64 expression - exact, and no square root per pair.
+__device__ inline long long sim_dist2_bound(double R) {
+  if (!(R > 0.0)) return 0;                                  // sqrt(.) >= 0: nothing is closer than R
+  if (R >= 3.0e9) return 0x7fffffffffffffffLL;               // int32 coordinates: squared distances stay below 2^65 / 4
+  long long q = (long long)floor(R * R);
+  while (q > 0 && !(sqrt((double)(q - 1)) < R)) --q;
+  while (sqrt((double)q) < R) ++q;
+  return q;
+}
+
+__host__ __device__ inline int gso_nbr_words(int N) { return ((N + 3) >> 2) | 1; }      // odd: the lanes' rows fall in different banks
+
+__device__ double gso_lambda_wave(const unsigned* rows, int words, const double* inv, double* u, unsigned* nbr, double* alpha,
+                                  double* b2, int N, int lane) {
+  const int i0 = lane, i1 = lane + 64;
+  const bool ok0 = i0 < N, ok1 = i1 < N;
+  const int rs = gso_nbr_words(N);
+  unsigned char* nb = reinterpret_cast<unsigned char*>(nbr);
+  int d0 = 0, d1 = 0;
+  if (ok0) {
+    for (int w = 0; w < rs; ++w) nbr[i0 * rs + w] = 0x01010101u * (unsigned)N;
+    for (int w = 0; w < words; ++w)
+      for (unsigned m = rows[i0 * words + w]; m; m &= m - 1) nb[i0 * rs * 4 + d0++] = (unsigned char)(32 * w + __builtin_ctz(m));
+  }
+  if (ok1) {
+    for (int w = 0; w < rs; ++w) nbr[i1 * rs + w] = 0x01010101u * (unsigned)N;
+    for (int w = 0; w < words; ++w)
+      for (unsigned m = rows[i1 * words + w]; m; m &= m - 1) nb[i1 * rs * 4 + d1++] = (unsigned char)(32 * w + __builtin_ctz(m));
+  }
+  int dmax = d0 > d1 ? d0 : d1;
+  for (int o = 32; o; o >>= 1) { const int other = __shfl_xor(dmax, o, 64); dmax = other > dmax ? other : dmax; }
+  const int ngrp = (dmax + 3) >> 2;
+  const unsigned* n0 = nbr + (ok0 ? i0 : 0) * rs;
+  const unsigned* n1 = nbr + (ok1 ? i1 : 0) * rs;
+  const double inv0 = ok0 ? inv[i0] : 0.0, inv1 = ok1 ? inv[i1] : 0.0;
+  const double s0 = 1.0 / sqrt((double)N);
+  double v0 = ok0 ? s0 : 0.0, v1 = ok1 ? s0 : 0.0, p0 = 0.0, p1 = 0.0, bk = 0.0;
+  if (lane == 0) { u[N] = 0.0; b2[0] = 0.0; }
+  const int kmax = N < 160 ? N : 160;
+  // Sturm count of T_steps at x: eigenvalues below x = sign changes of the leading minors of T - x I
+  auto below_count = [&](double x, int steps) -> int {
+    int below = 0;
+    double pm = 1.0, pmm = 0.0;
+    for (int r0 = 0; r0 < steps; r0 += 8) {
+      const int r1 = r0 + 8 < steps ? r0 + 8 : steps;
+      for (int r = r0; r < r1; ++r) {
+        double p = fma(alpha[r] - x, pm, -(b2[r] * pmm));
+        if (p == 0.0) p = pm * 0x1p-200;               // a zero minor takes the sign of the one before it (the pivot form's +tiny)
+        below += (int)((__double2hiint(p) ^ __double2hiint(pm)) < 0);
+        pmm = pm;
+        pm = p;
+      }
+      int ex;
+      (void)frexp(pm, &ex);
+      pm = ldexp(pm, -ex);
+      pmm = ldexp(pmm, -ex);
+    }
+    return below;
+  };
+  // multisection inside [lo, hi] (lambda_max of T_steps known to lie there): lane l probes lo + (hi - lo) (l + 1) / 65
+  auto locate = [&](double lo, double hi, int steps) -> double {
+    for (int pass = 0; pass < 14 && hi - lo > 4e-16 * fmax(fabs(lo), fabs(hi)); ++pass) {
+      const double x = lo + (hi - lo) * (double)(lane + 1) / 65.0;
+      const unsigned long long ge = __ballot(below_count(x, steps) < steps);      // lambda_max >= x_lane
+      const int bt = ge ? 63 - __builtin_clzll(ge) : -1;
+      const double nlo = bt >= 0 ? lo + (hi - lo) * (double)(bt + 1) / 65.0 : lo;
+      const double nhi = bt + 1 < 64 ? lo + (hi - lo) * (double)(bt + 2) / 65.0 : hi;
+      lo = nlo;
+      hi = nhi;
+    }
+    return 0.5 * (lo + hi);
+  };
+  double glo = 0.0, ghi = 0.0;      // Gershgorin bounds of T_steps, extended row by row (wave-uniform)
+  double bprev = 0.0;               // |beta_k|
+  double lam = 0.0;
+  bool have = false;
+  int stable = 0;
+  for (int k = 0; k < kmax; ++k) {
+    if (ok0) u[i0] = inv0 * v0;
+    if (ok1) u[i1] = inv1 * v1;
+    SIM_WAVE_SYNC();
+    double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
+    for (int g = 0; g < ngrp; ++g) {
+      const unsigned q0 = n0[g], q1 = n1[g];
+      a0 += u[q0 & 255u];
+      c0 += u[(q0 >> 8) & 255u];
+      a1 += u[q1 & 255u];
+      c1 += u[(q1 >> 8) & 255u];
+      a0 += u[(q0 >> 16) & 255u];
+      c0 += u[q0 >> 24];
+      a1 += u[(q1 >> 16) & 255u];
+      c1 += u[q1 >> 24];
+    }
+    SIM_WAVE_SYNC();
+    double w0 = inv0 * (a0 + c0) - bk * p0, w1 = inv1 * (a1 + c1) - bk * p1;
+    const double ak = wave_sum_f64(v0 * w0 + v1 * w1);
+    w0 -= ak * v0;
+    w1 -= ak * v1;
+    const double bsq = wave_sum_f64(w0 * w0 + w1 * w1);
+    // 1 / sqrt by the hardware estimate and two Newton steps (the divide and the square root were a fifth of the step)
+    double rb = __builtin_amdgcn_rsq(bsq);
+    rb = fma(0.5 * rb, fma(-(bsq * rb), rb, 1.0), rb);
+    rb = fma(0.5 * rb, fma(-(bsq * rb), rb, 1.0), rb);
+    const double bn = bsq > 0.0 ? bsq * rb : 0.0;
+    if (lane == 0) { alpha[k] = ak; b2[k + 1] = bsq; }
+    const int steps = k + 1;
+    const bool breakdown = !(bn > 1e-13 * (fabs(ak) + bk + 1.0));      // invariant subspace reached: T_steps is exact
+    const bool last = breakdown || steps == kmax;
+    // bounds of T_steps: row k with its off-diagonals beta_k and (unless this is the last row) beta_{k+1}; a row's bound with the
+    // extra beta_{k+1} is also a bound without it
+    {
+      const double off = bprev + (last ? 0.0 : bn);
+      glo = k ? fmin(glo, ak - off) : ak - off;
+      ghi = k ? fmax(ghi, ak + off) : ak + off;
+    }
+    if (last || (steps & 7) == 0) {
+      SIM_WAVE_SYNC();      // alpha / b2 are written
+      if (!have) {
+        lam = locate(glo, ghi, steps);
+        have = true;
+      } else {
+        // lambda_max(T) never decreases as rows are added: one pass with the lanes at lam + tol 2^l tells whether it moved at all,
+        // and by how much at most; the multisection then runs inside that bracket only
+        const double tol = 1e-13 * fabs(lam);
+        const double x = lam + ldexp(tol, lane);
+        const unsigned long long ge = __ballot(x < ghi && below_count(x, steps) < steps);
+        if (!ge) {
+          if (++stable >= 2 && !last) break;
+        } else {
+          const int bt = 63 - __builtin_clzll(ge);
+          lam = locate(lam + ldexp(tol, bt), fmin(lam + ldexp(tol, bt + 1), ghi), steps);
+          stable = 0;
+        }
+      }
+      if (last) break;
+    }
+    p0 = v0; p1 = v1;
+    v0 = w0 * rb; v1 = w1 * rb;
+    bk = bn;
+    bprev = bn;
+  }
+  return lam;
+}
+
 // rows of W as bit masks in LDS while they fit (N <= ~1000: 128 KB); larger instances evaluate the distance test on
 // the fly (N <= 2048)
 template <bool MASK>
@@ -51,10 +236,11 @@ __global__ __launch_bounds__(SIM_THREADS) void gso_kernel(const int* __restrict_
     py[n] = pos[((long long)b * N + n) * 2 + 1];
   }
   __syncthreads();
+  const long long d2_bound = sim_dist2_bound(R);     // squareform(pdist(.)) < R in float64, as an integer test
   auto edge = [&](int i, int j) -> bool {
     if (i == j) return false;
     const long long dx = px[i] - px[j], dy = py[i] - py[j];
-    return sqrt((double)(dx * dx + dy * dy)) < R;       // squareform(pdist(.)) < R, float64 like the reference
+    return dx * dx + dy * dy < d2_bound;
   };
   // degrees (+ bit rows)
   for (int i = t; i < N; i += nt) {
@@ -83,7 +269,17 @@ __global__ __launch_bounds__(SIM_THREADS) void gso_kernel(const int* __restrict_
   __syncthreads();
   const bool has_edges = any_edge != 0;
   double lam = 0.0;
-  if (has_edges && normalize) {
+  if (has_edges && normalize && MASK && N <= 128) {
+    // small graphs: the whole eigenvalue problem inside wave 0 (gso_lambda_wave), the other waves wait at the barrier
+    double* alpha = red + 16;
+    double* b2 = alpha + 160;
+    double* u = reinterpret_cast<double*>(rows + ((N * words + 1) & ~1));      // [N + 1]
+    unsigned* nbr = reinterpret_cast<unsigned*>(u + N + 1);                    // [N][gso_nbr_words(N)]
+    if (t < 64) lam = gso_lambda_wave(rows, words, inv, u, nbr, alpha, b2, N, t);
+    if (t == 0) red[0] = lam;
+    __syncthreads();
+    lam = red[0];
+  } else if (has_edges && normalize) {
     // Lanczos on the symmetric matrix W (no reorthogonalisation: only the extreme Ritz value is wanted, and that one
     // converges first and stays put).  The all-ones start has a component along the Perron vector of every connected
     // component, so the largest Ritz value tends to lambda_max(W) = max over components.  Every LCHK steps the largest
@@ -190,12 +386,13 @@ __global__ __launch_bounds__(SIM_THREADS) void gso_kernel(const int* __restrict_
   if (lambda_out && t == 0) lambda_out[b] = lam;
   const double div = (has_edges && normalize) ? lam : 1.0;
   const long long base = (long long)b * N * N;
-  for (long long idx = t; idx < (long long)N * N; idx += nt) {
-    const int i = (int)(idx / N), j = (int)(idx - (long long)i * N);
+  const double plain = 1.0 / div;        // every edge of the plain form holds this one quotient
+  for (unsigned idx = t; idx < (unsigned)N * (unsigned)N; idx += nt) {      // N <= 2048
+    const int i = (int)(idx / (unsigned)N), j = (int)(idx - (unsigned)i * (unsigned)N);
     bool e;
     if (MASK) e = (rows[i * words + (j >> 5)] >> (j & 31)) & 1u;
     else e = edge(i, j);
-    const double val = e ? (inv[i] * 1.0 * inv[j]) / div : 0.0;
+    const double val = e ? (symmetric_norm ? (inv[i] * 1.0 * inv[j]) / div : plain) : 0.0;
     if (s_is_f64) static_cast<double*>(S)[base + idx] = val;
     else static_cast<float*>(S)[base + idx] = (float)val;
   }
@@ -204,6 +401,8 @@ __global__ __launch_bounds__(SIM_THREADS) void gso_kernel(const int* __restrict_
 size_t gso_lds_bytes(int N, bool mask) {
   size_t b = (size_t)2 * N * sizeof(int) + 8 + (size_t)3 * N * sizeof(double) + (16 + 160 + 162) * sizeof(double);
   if (mask) b += (size_t)N * ((N + 31) / 32) * sizeof(unsigned);
+  if (mask && N <= 128)      // the one-wave eigenvalue path: u [N + 1] doubles and the neighbour lists
+    b += sizeof(unsigned) + (size_t)(N + 1) * sizeof(double) + (size_t)N * gso_nbr_words(N) * sizeof(unsigned);
   return b;
 }
 
@@ -250,7 +449,11 @@ __global__ __launch_bounds__(SIM_THREADS) void fov_states_kernel(const uint8_t* 
   __syncthreads();
   const int per_agent = 3 * Wt * Wt;
   float* xb = x + (long long)b * N * per_agent;
-  for (int idx = t; idx < N * per_agent; idx += nt) {
+  // a small batch spreads an instance's tensor over gridDim.y workgroups (each builds the same bitmap; one instance of 100
+  // agents in ONE workgroup took 59 us)
+  const int total = N * per_agent, chunk = (total + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int begin = (int)blockIdx.y * chunk, end = begin + chunk < total ? begin + chunk : total;
+  for (int idx = begin + t; idx < end; idx += nt) {
     const int n = idx / per_agent, r = idx - n * per_agent;
     const int ch = r / (Wt * Wt), pix = r - ch * Wt * Wt;
     const int a = pix / Wt, c = pix - a * Wt;
@@ -292,6 +495,7 @@ __global__ __launch_bounds__(SIM_THREADS) void sim_radius_kernel(const int* __re
   while (!connected && steps < max_steps) {
     r = r * 1.1;
     ++steps;
+    const long long d2_bound = sim_dist2_bound(r);
     __syncthreads();
     for (int n = t; n < N; n += nt) seen[n] = n == 0 ? 1 : 0;
     while (true) {
@@ -304,7 +508,7 @@ __global__ __launch_bounds__(SIM_THREADS) void sim_radius_kernel(const int* __re
         for (int j = 0; j < N && !hit; ++j) {
           if (!seen[j] || j == i) continue;
           const long long dx = px[i] - px[j], dy = py[i] - py[j];
-          hit = sqrt((double)(dx * dx + dy * dy)) < r;
+          hit = dx * dx + dy * dy < d2_bound;
         }
         if (hit) { seen[i] = 1; changed = 1; }
       }
@@ -607,7 +811,9 @@ extern "C" int magat_sim_fov_states(const uint8_t* map, int map_batched, int H, 
   if (B <= 0 || N <= 0 || H <= 0 || W <= 0 || FOV <= 0 || !(FOV & 1)) return MAGAT_ERR_BAD_SHAPE;
   const size_t lds = (size_t)((H * W + 31) / 32) * sizeof(unsigned) + (size_t)N * sizeof(int);
   if (lds > 64 * 1024) return MAGAT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(fov_states_kernel, dim3(B), dim3(SIM_THREADS), lds, static_cast<hipStream_t>(stream), map,
+  int split = 1;                                           // workgroups per instance: ~512 in flight, >= 8 agents' worth each
+  while (split < 32 && (long long)B * split < 512 && N / (2 * split) >= 4) split *= 2;
+  hipLaunchKernelGGL(fov_states_kernel, dim3(B, split), dim3(SIM_THREADS), lds, static_cast<hipStream_t>(stream), map,
                      map_batched ? (long long)H * W : 0LL, H, W, pos, goal, x, FOV, N);
   return magat_check_launch();
 }

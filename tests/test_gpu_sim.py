@@ -152,6 +152,53 @@ def test_gso_large_instances_vs_oracle(gpu_device):
         np.testing.assert_allclose(got, ref, rtol=1e-9, atol=0)
 
 
+def test_gso_small_instances_one_wave_path(gpu_device):
+    """N <= 128 takes the one-wave Lanczos (neighbour lists, division-free Sturm count, early stop once the extreme Ritz
+    value stands still): every size class, dense and sparse graphs, disconnected clusters, agents on one cell, both
+    normalisations - lambda_max against numpy's eigvalsh through the oracle."""
+    from oracle import sim_oracle as so
+    from magat_pathplanning_amd.simulator import batched_gso
+    rng = np.random.default_rng(11)
+    for N, side, R in ((2, 4, 7.0), (3, 30, 7.0), (7, 10, 3.0), (8, 12, 7.0), (9, 20, 7.0), (33, 30, 7.0), (64, 40, 7.0),
+                       (65, 40, 5.5), (100, 50, 7.0), (100, 12, 7.0), (127, 60, 9.0), (128, 50, 7.0), (128, 11, 20.0)):
+        pos = rng.integers(0, side, size=(6, N, 2)).astype(np.int32)
+        if N >= 8:
+            pos[1, : N // 2] = rng.integers(0, 6, size=(N // 2, 2))
+            pos[1, N // 2:] = rng.integers(500, 506, size=(N - N // 2, 2))     # two far clusters (stacked agents included)
+            pos[2] = np.stack([np.arange(N) * 3, np.zeros(N, np.int64)], 1)     # a path graph: slowest convergence
+        dpos = torch.from_numpy(pos).to(gpu_device)
+        for sym in (False, True):
+            S, lam = batched_gso(dpos, R, symmetric_norm=sym, return_lambda=True)
+            for b in range(pos.shape[0]):
+                ref = so.gso_from_positions(pos[b], R, symmetric_norm=sym)
+                got = S[b].cpu().numpy()
+                np.testing.assert_array_equal(got != 0, ref != 0)
+                np.testing.assert_allclose(got, ref, rtol=1e-9, atol=0, err_msg="N=%d b=%d sym=%s" % (N, b, sym))
+
+
+def test_gso_edge_test_is_the_float64_one_at_awkward_radii(gpu_device):
+    """The integer form of sqrt(d2) < R: radii that ARE rounded square roots of reachable squared distances, their
+    neighbours one ulp either side, and radii grown by repeated * 1.1 like the step-0 search."""
+    from magat_pathplanning_amd.simulator import batched_gso
+    rng = np.random.default_rng(12)
+    N = 40
+    pos = rng.integers(0, 14, size=(1, N, 2)).astype(np.int32)
+    d2 = ((pos[0, :, None, :].astype(np.int64) - pos[0, None, :, :]) ** 2).sum(-1)
+    radii = []
+    for q in (1, 2, 5, 8, 13, 18, 50, 61, 98):
+        r = float(np.sqrt(np.float64(q)))
+        radii += [r, float(np.nextafter(r, 0.0)), float(np.nextafter(r, 100.0))]
+    r = 1.0
+    for _ in range(25):
+        r = r * 1.1
+        radii.append(r)
+    dpos = torch.from_numpy(pos).to(gpu_device)
+    for R in radii:
+        W = batched_gso(dpos, R, normalize=False)[0].cpu().numpy()
+        ref = (np.sqrt(d2.astype(np.float64)) < R) & ~np.eye(N, dtype=bool)
+        np.testing.assert_array_equal(W != 0, ref, err_msg="R=%r" % R)
+
+
 # ---------------------------------------------------------------- round 2: policies, episode bookkeeping, step-0 radius
 EPISODE = sorted(glob.glob(os.path.join(GOLDEN, "simepisode_*.npz")))
 RADIUS = sorted(glob.glob(os.path.join(GOLDEN, "simradius_*.npz")))

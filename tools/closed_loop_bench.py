@@ -56,7 +56,7 @@ print("B %d N %d map %dx%d: closed loop %.3f ms/step = %.2f M agent-steps/s   (f
 print("reached goals after %d random-policy steps: %d of %d agents" % (T + 3, int(out["reached"].sum()), B * N))
 
 # The attention layers read the GSO only as an edge mask (|S| > 1e-9, graphML.py:1274): the 1 / lambda_max scaling of the
-# reference's GSO (a Lanczos + Sturm eigenvalue per instance, 0.48 ms per batch here) does not reach the logits.  A GAT-only
+# reference's GSO (a Lanczos + Sturm eigenvalue per instance, 0.15 ms per batch here) does not reach the logits.  A GAT-only
 # closed loop may hand over the 0/1 adjacency instead - same logits bit for bit:
 with torch.no_grad():
     net.addGSO(S)
