@@ -50,8 +50,8 @@ const char* magat_error_string(int code);
 
 /* Options.  Every tunable of the library lives in one table that is seeded from the environment (MAGAT_<NAME>) ONCE, at
  * first use, and is read / changed through these calls afterwards; nothing on the launch path calls getenv.  `name` with
- * or without the MAGAT_ prefix.  All nineteen (round 5: the A/B switches of kernel forms that lost their measurements are gone
- * with those forms; round 6: + CSR_FUSED, LAT_AGENTS; csrc/options.hip holds the table):
+ * or without the MAGAT_ prefix.  All twenty (round 5: the A/B switches of kernel forms that lost their measurements are gone
+ * with those forms; round 6: + CSR_FUSED, LAT_AGENTS, GAT_WIDE_FROM; csrc/options.hip holds the table):
  *   LAT_AGENTS (512) largest agent count (magat_encoder_desc.form_agents when set) whose encoder runs ONE AGENT PER WORKGROUP
  *                    (csrc/block_lat.hip: layer1.conv2 .. layer3, pool, head and compressMLP in one launch; the batch-1 step of the
  *                    reference's inference loop); results bit-identical to the eight-agent-group kernels; 0 = never
@@ -71,7 +71,8 @@ const char* magat_error_string(int code);
  *   ENC_CHUNK (65536), GAT_CHUNK_MB (2048)  workspace bounds: agents per encoder pass, size of the two-launch graph layer's maps
  *   GAT_MFMA    (1)  graph layer with G = F = 128, N <= 102, K = 2 | 3, A_opt == NULL as ONE launch of matrix-core products
  *                    (maps, scores, softmax, hops; csrc/gat_mfma.hip; G = F in {32, 64}: N <= 32 csrc/gat_small.hip, 33 <= N <= 128
- *                    csrc/gat_mid.hip - round 6); 0 = maps
+ *                    csrc/gat_mid.hip - round 6; G = F = 128 from GAT_WIDE_FROM (106; lowest 103) to 128 agents: csrc/gat_mid.hip
+ *                    with the X fragments in registers - between 102 and that the two-launch form, measured faster there); 0 = maps
  *                    GEMM + graph kernel;  GAT_SPLIT (1) that GEMM on the split kernels;  GAT_PACK (1) four instances per pass
  *                    at N <= 32 once the batch fills the chip (bit-identical)
  *   CSR_TILED   (3)  CSR path (N > 128 / bf16 storage): LDS-tiled score / hop kernels;  SKINNY (1) the action head as streamed

@@ -734,6 +734,119 @@ __global__ void gat_dense_kernel(const GatParams p) {
   if (p.book) magat_guard_book(p.book);
 }
 
+// ---- The float32 form of the layer where gat_dense_kernel's tiles no longer fit: G = F = 128 on 106 .. 128 agents, KeyQuery - the
+// range guard's re-run behind gat_mid.hip's 128-wide form (a launch that returns at once unless the flag is set; when it does run,
+// speed is not its job).  From the hoisted maps Z like gat_dense_kernel; a workgroup walks (instance, head) slots with
+//   V  [N][129]    Q_p during the scores, then the hop buffer (acc_{k+1})
+//   At [N][N | 1]  At[i][j] = a_ij: row i's softmax over its edges j (graphML.py:1262-1286)
+// scores e_ij = x_i . Q_p[j]: a wave per row i, lanes j and j + 64; hops acc_k[j] = U_pk[j] + sum_i a_ij acc_{k+1}[i]
+// (graphML.py:1744-1775 in Horner form): a wave owns rows j = wave + 4 m, lanes the columns c and c + 64, the new rows stay in
+// registers until every wave is done reading the old ones.
+__global__ __launch_bounds__(256) void gat_slim_kernel(const GatParams p) {
+  extern __shared__ __align__(16) float smem[];
+  if (p.run_if && *p.run_if == 0) {
+    if (p.book) magat_guard_book_idle(p.book);
+    return;
+  }
+  constexpr int G = 128, F = 128, LDV = 129, MR = 32;
+  const int N = p.N, K = p.K, P = p.P, lda = N | 1;
+  float* V = smem;
+  float* At = V + N * LDV;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int zrow = p.zts ? 128 : p.NC;
+  auto zcol = [&](int col) -> long long { return p.zts ? (long long)(col >> 7) * p.zts + (col & 127) : (long long)col; };
+  const int c0 = lane, c1 = lane + 64;
+  const float bias0 = p.bias ? p.bias[c0] : 0.f, bias1 = p.bias ? p.bias[c1] : 0.f;
+  for (int slot = blockIdx.x; slot < p.B * P; slot += gridDim.x) {
+    const int bl = slot / P, head = slot % P;
+    const long long b = p.b0 + bl;
+    const float* Zb = p.Z + (long long)bl * N * zrow;
+    const float* Xb = p.X + b * N * p.ldx;
+    auto load_tile = [&](int col) {      // V <- columns col .. col + 127 of this instance's Z rows
+      const float* src = Zb + zcol(col);
+      for (int idx = t; idx < N * 32; idx += 256) {
+        const int n = idx >> 5, c4 = idx & 31;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long long)n * zrow + 4 * c4);
+        float* d = V + n * LDV + 4 * c4;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+      }
+    };
+    __syncthreads();      // every wave is done with the previous slot's V / At
+    if (K > 1) {
+      load_tile(p.qoff + head * G);
+      __syncthreads();
+      const int j0 = lane, j1 = lane + 64 < N ? lane + 64 : N - 1;
+      const int j0c = j0 < N ? j0 : N - 1;
+      for (int i = wave; i < N; i += 4) {
+        const float* xi = Xb + (long long)i * p.ldx;
+        float e0 = 0.f, e1 = 0.f;
+        for (int g = 0; g < G; ++g) {
+          const float xg = xi[g];
+          e0 = __builtin_fmaf(xg, V[j0c * LDV + g], e0);
+          e1 = __builtin_fmaf(xg, V[j1 * LDV + g], e1);
+        }
+        const long long srow = (b * N + i) * N;
+        const bool m0 = j0 < N && is_edge(p.S, srow + j0c, p.s_is_f64);
+        const bool m1 = lane + 64 < N && is_edge(p.S, srow + j1, p.s_is_f64);
+        float mx = fmaxf(m0 ? e0 : -__builtin_inff(), m1 ? e1 : -__builtin_inff());
+        for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float x0 = m0 ? __expf(e0 - mx) : 0.f, x1 = m1 ? __expf(e1 - mx) : 0.f;
+        float sum = x0 + x1;
+        for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;      // (a row without edges: all zeros, graphML.py:1286)
+        if (j0 < N) At[i * lda + j0] = x0 * inv;
+        if (lane + 64 < N) At[i * lda + lane + 64] = x1 * inv;
+      }
+      __syncthreads();      // At complete, Q no longer read
+    }
+    load_tile(p.uoff + (head * K + (K - 1)) * F);
+    __syncthreads();
+    float r0[MR], r1[MR];
+    for (int k = K - 2; k >= 0; --k) {
+      const float* uk = Zb + zcol(p.uoff + (head * K + k) * F);
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const int j = wave + 4 * m, jc = j < N ? j : N - 1;
+        r0[m] = uk[(long long)jc * zrow + c0];
+        r1[m] = uk[(long long)jc * zrow + c1];
+      }
+      for (int i = 0; i < N; ++i) {
+        const float v0 = V[i * LDV + c0], v1 = V[i * LDV + c1];
+        const float* arow = At + i * lda + wave;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          const float a = wave + 4 * m < N ? arow[4 * m] : 0.f;
+          r0[m] = __builtin_fmaf(a, v0, r0[m]);
+          r1[m] = __builtin_fmaf(a, v1, r1[m]);
+        }
+      }
+      if (k > 0) {
+        __syncthreads();      // every wave is done reading acc_{k+1}
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          const int j = wave + 4 * m;
+          if (j < N) { V[j * LDV + c0] = r0[m]; V[j * LDV + c1] = r1[m]; }
+        }
+        __syncthreads();
+      }
+    }
+    // output rows: acc_0 + bias; ReLU here (concat) or after the head mean (head_mean_relu_kernel)
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const int j = wave + 4 * m;
+      if (j >= N) continue;
+      float y0 = (K > 1 ? r0[m] : V[j * LDV + c0]) + bias0, y1 = (K > 1 ? r1[m] : V[j * LDV + c1]) + bias1;
+      if (p.concat) { y0 = magat_relu(y0); y1 = magat_relu(y1); }
+      float* yrow = p.Y + (b * N + j) * p.ldy + head * F;
+      yrow[c0] = y0;
+      yrow[c1] = y1;
+    }
+  }
+  if (p.book) magat_guard_book(p.book);
+}
+
+
 // mean over heads then ReLU (graphML.py:4663-4667)
 __global__ void head_mean_relu_kernel(const float* __restrict__ ytmp, float* __restrict__ y, long long M, int P,
                                       int F, int ldy, const int* __restrict__ run_if, int* book) {
@@ -1112,7 +1225,12 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     return MAGAT_ERR_WORKSPACE;
   const int threads = gat_block_threads(N);
   const size_t lds = gat_lds_bytes(N, G, F, threads / 64);
-  if (lds > 160 * 1024) return MAGAT_ERR_UNSUPPORTED;
+  // beyond gat_dense_kernel's tiles (128 features: N > 105) only the one-launch form of gat_mid.hip exists, with gat_slim_kernel
+  // as the range guard's float32 re-run; no attention tensor there (the CSR kernels serve such requests)
+  const bool slim = lds > 160 * 1024;
+  if (slim && !(G == 128 && F == 128 && mode == MAGAT_MODE_KEYQUERY && !A_opt && gat_one_launch(N, G, F, K, mode, concat) &&
+                (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0))
+    return MAGAT_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
 
   const PackLayout L = pack_layout(G, F, K, P, mode);
@@ -1149,14 +1267,15 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     const unsigned* masks = nullptr;
     const float* frag = packed + magat_gat_frag_offset(L.NC, G);
     // (128 features: gat_mfma.hip; 32 / 64 features on graphs of at most 32 agents: gat_small.hip, a wave per instance)
-    const int rc = G == 128
+    const int rc = G == 128 && magat_gat_mfma_supported(N, G, F, K, mode)
         ? magat_gat_mfma_forward(X, G, S, s_is_f64, masks, frag, bias, Y, ldy, B, N, K, P, concat,
                                  guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4), mode,
                                  mode == MAGAT_MODE_KEYQUERY ? nullptr : frag + (size_t)(P * G + P * K * F) * G)
-        : N <= 32
+        : G != 128 && N <= 32
         ? magat_gat_small_forward(X, G, S, s_is_f64, masks, packed + magat_gat_f16_block_offset(L.NC, G), L.NC, bias, Y, ldy, B,
                                   N, G, K, P, concat, guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4))
-        // (32 / 64 features on 33 .. 128 agents: gat_mid.hip, a workgroup of ceil(N / 32) waves per instance - round 6)
+        // (32 / 64 features on 33 .. 128 agents, 128 features on 103 .. 128: gat_mid.hip, a workgroup of ceil(N / 32) waves per
+        //  instance - round 6)
         : magat_gat_mid_forward(X, G, S, s_is_f64, packed + magat_gat_f16_block_offset(L.NC, G), L.NC, bias, Y, ldy, B, N, G, K, P,
                                 concat, guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4),
                                 concat ? nullptr : Ytmp, P * F);
@@ -1171,7 +1290,7 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     if (hpb_env > 0 && G >= 64 && P % hpb_env == 0) h = hpb_env;
     return h;
   };
-  bool all_fused = !concat && G >= 64;
+  bool all_fused = !concat && G >= 64 && !slim;
   for (int b0 = 0; b0 < B && all_fused; b0 += chunk) all_fused = hpb_for((B - b0) < chunk ? (B - b0) : chunk) == P;
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int cb = (B - b0) < chunk ? (B - b0) : chunk;
@@ -1213,6 +1332,16 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     const int gtag = rerun_only ? MAGAT_TAG_RANGE_GUARD : MAGAT_TAG_GAT_GRAPH;
     // the re-run's last launch does the guard's bookkeeping: the graph kernel of the last chunk, or the head-mean kernel
     p.book = (rerun_only && b0 + chunk >= B && (concat || all_fused)) ? reinterpret_cast<int*>(status) : nullptr;
+    if (slim) {
+      const size_t slds = sizeof(float) * ((size_t)N * 129 + (size_t)N * (N | 1));
+      if (magat_ensure_dyn_lds(reinterpret_cast<const void*>(&gat_slim_kernel), MAGAT_LDS_GAT_SLIM, slds) != MAGAT_OK)
+        return MAGAT_ERR_LAUNCH;
+      const int sblocks = cb * P < 128 ? cb * P : 128;      // (a no-op launch pays for every workgroup it dispatches)
+      const int pid = magat_prof_begin(gtag, st);
+      hipLaunchKernelGGL(gat_slim_kernel, dim3(sblocks), dim3(256), slds, st, p);
+      magat_prof_end(pid, st);
+      rc = magat_check_launch();
+    } else
     switch (G) {
       case 16: rc = launch_gat<16, 16>(p, blocks, threads, lds, st, gtag); break;
       case 32: rc = launch_gat<32, 32>(p, blocks, threads, lds, st, gtag); break;

@@ -16,7 +16,11 @@
 // barriers per head.  Weights come straight from the row-major f16 planes of the layer's pack (L2 / L1 hits), the edge masks
 // from coalesced row reads of S + ballots.  Values beyond the f16 range raise range_flag: the caller's predicated float32 form
 // rewrites the output (its LDS tiles reach N = 128 at these widths).
+// G = F = 128 on 103 .. 128 agents (XR form, round 6): every use of the X planes is of the wave's OWN row tile, so they need no LDS
+// at all - a lane keeps its operand fragments of row 32 w + lane % 32 in 64 registers, read straight from HBM in that layout.  What
+// is left - Q / U^T and A planes - is 139 KB: the one-launch form gat_mfma.hip (162 KB per instance, ends at N = 102) cannot reach.
 #include "magat_common.h"
+
 
 namespace {
 
@@ -55,14 +59,14 @@ __device__ __forceinline__ void split2v(float x, float y, unsigned& p1, unsigned
 // HS (few instances: the batch-1 step of the reference's inference loop): a workgroup per (instance, HEAD) instead of per instance -
 // one planning instance of 100 agents then runs on four CUs instead of one.  A head's arithmetic does not change; with head-mean
 // the workgroups leave their pre-activation outputs in Ypre and gat_mid_mean_kernel sums them in the loop's order (bit-identical).
-template <int F, int KT, int NT, bool CONCAT, bool HS = false>
+template <int F, int KT, int NT, bool CONCAT, bool HS = false, bool XR = false>
 __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) {
   extern __shared__ __align__(16) char lds[];
   constexpr int CT = F / 32, KF = F / 16, ROWS = 32 * NT, THREADS = 64 * NT;
   constexpr int RS = 2 * F + 16;             // row stride of the X / Q planes (bytes)
   constexpr int SA = 2 * ROWS + 16;          // row stride of the A / U^T planes (bytes): ROWS columns of halves + 16
   constexpr int XPL = ROWS * RS, APL = ROWS * SA, UPL = F * SA;
-  constexpr int XO = 0, QO = 2 * XPL, UO = QO;
+  constexpr int XO = 0, QO = XR ? 0 : 2 * XPL, UO = QO;      // (XR: the X planes live in registers)
   constexpr int AO = QO + (2 * XPL > 2 * UPL ? 2 * XPL : 2 * UPL);
   constexpr float kInvScale = 1.f / 256.f;
   const int t = threadIdx.x, lane = t & 63;
@@ -86,8 +90,25 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
   const int hlo = HS ? (int)blockIdx.x % p.P : 0, hhi = HS ? hlo + 1 : p.P;
   for (int inst = HS ? (int)blockIdx.x / p.P : (int)blockIdx.x; inst < p.B; inst += ninst) {
     __syncthreads();      // every wave is done with the previous instance's planes
-    // ---- X rows -> f16 planes (rows past N: zeros), all waves
-    {
+    // ---- X rows -> f16 planes (rows past N: zeros): all waves into LDS, or (XR) every lane its own operand fragments
+    uint4 xr[XR ? KF : 1][2];
+    if constexpr (XR) {
+      const float* xrow = p.X + ((long long)inst * N + (myrow < N ? myrow : N - 1)) * p.ldx + 8 * fh;
+#pragma unroll
+      for (int ks = 0; ks < KF; ++ks) {
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(xrow + 16 * ks), v1 = *reinterpret_cast<const f32x4*>(xrow + 16 * ks + 4);
+        if (myrow >= N) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+        float xv[8] = {v0[0] * xs, v0[1] * xs, v0[2] * xs, v0[3] * xs, v1[0] * xs, v1[1] * xs, v1[2] * xs, v1[3] * xs};
+        bool bad = false;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bad |= !(fabsf(xv[e]) <= 65504.f);
+        if (bad) vmax = __builtin_inff();
+        split2v(xv[0], xv[1], xr[ks][0].x, xr[ks][1].x, vmax);
+        split2v(xv[2], xv[3], xr[ks][0].y, xr[ks][1].y, vmax);
+        split2v(xv[4], xv[5], xr[ks][0].z, xr[ks][1].z, vmax);
+        split2v(xv[6], xv[7], xr[ks][0].w, xr[ks][1].w, vmax);
+      }
+    } else {
       const float* Xb = p.X + (long long)inst * N * p.ldx;
       for (int idx = t; idx < ROWS * (F / 8); idx += THREADS) {
         const int row = idx / (F / 8), ch = idx % (F / 8);
@@ -138,8 +159,8 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
     for (int jt = 0; jt < NT; ++jt) mk[jt] >>= 4 * fh;      // bit (8 (r / 4) + r % 4) = row j of accumulator register r
     __syncthreads();      // X planes complete
 
-    float ysum[CT][16];
-    if constexpr (!CONCAT) {
+    float ysum[(CONCAT || HS || XR) ? 1 : CT][16];      // (XR: the heads' outputs go through Ypre like the head-split form's)
+    if constexpr (!CONCAT && !HS && !XR) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -152,8 +173,10 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
         return *reinterpret_cast<const uint4*>(p.Hs + pl * plane + (row0 + fr) * G + 16 * ks + 8 * fh);
       };
       // operand rows of tile `tile` of the X planes
+      // (only ever the wave's own tile - which is why XR can keep them in registers)
       auto xfrag = [&](int tile, int ks, int pl) __attribute__((always_inline)) {
-        return *reinterpret_cast<const uint4*>(lds + XO + pl * XPL + (32 * tile + fr) * RS + (16 * ks + 8 * fh) * 2);
+        if constexpr (XR) return xr[ks][pl];
+        else return *reinterpret_cast<const uint4*>(lds + XO + pl * XPL + (32 * tile + fr) * RS + (16 * ks + 8 * fh) * 2);
       };
       // ---- G1 (operands swapped): Q^T tile of this wave's agents, lane = agent row j, register quads = 4 consecutive columns g
 #pragma unroll
@@ -234,10 +257,11 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
             *reinterpret_cast<unsigned short*>(o + c * SA + APL) = (unsigned short)(la[c >> 1] >> (16 * (c & 1)));
           }
         }
-      // ---- G3: U_k[i][c] for this wave's agents i and the K taps (lane = column c, registers = rows i)
+      // ---- G3: U_k[i][c] for this wave's agents i and the K taps (lane = column c, registers = rows i).  XR: a tap's product is
+      // formed when its accumulators are first needed (tap K - 1 here, tap k in front of hop k) - the same chain of products into
+      // the same accumulators, but 64 instead of 192 of them live at 128 features and three taps
       f32x16 acc[KT][CT];
-#pragma unroll
-      for (int k = 0; k < KT; ++k)
+      auto g3 = [&](int k) __attribute__((always_inline)) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
@@ -251,6 +275,12 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
             acc[k][ct] = mfma16(x1, w0, acc[k][ct]);
           }
         }
+      };
+      if constexpr (XR) g3(KT - 1);
+      else {
+#pragma unroll
+        for (int k = 0; k < KT; ++k) g3(k);
+      }
       __syncthreads();      // A planes complete; every wave is done reading the Q planes (the U^T planes take their place)
       // ---- hops (Horner): acc_k[j-tile w] += A[j][all i] U_{k+1}[all i]; the U^T planes [c][i] are rewritten from acc_{k+1}
 #pragma unroll
@@ -267,6 +297,7 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
             *reinterpret_cast<uint2*>(o) = hi;
             *reinterpret_cast<uint2*>(o + UPL) = lo;
           }
+        if constexpr (XR) g3(k);
         __syncthreads();      // U^T planes complete
 #pragma unroll
         for (int ks = 0; ks < 2 * NT; ++ks) {
@@ -292,7 +323,7 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
           const float v = __builtin_fmaf(acc[0][ct][r], kOutScale, biasv[ct]);
           if constexpr (CONCAT) {
             if (j < N) yb[(long long)j * p.ldy + hd * F + 32 * ct + fr] = __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());
-          } else if constexpr (HS) {
+          } else if constexpr (HS || XR) {
             if (j < N) p.Ypre[((long long)inst * N + j) * p.ldpre + hd * F + 32 * ct + fr] = v;
           } else {
             ysum[ct][r] += v;      // (graphML.py:4663-4667: mean over the heads, then ReLU)
@@ -319,20 +350,22 @@ __global__ __launch_bounds__(256) void gat_mid_mean_kernel(const float* __restri
   }
 }
 
-template <int F, int NT>
+template <int F, int NT, bool XR = false>
 constexpr size_t mid_lds() {
   constexpr size_t ROWS = 32 * NT, RS = 2 * F + 16, SA = 2 * ROWS + 16;
   constexpr size_t q = 2 * ROWS * RS, u = 2 * F * SA;
-  return 2 * ROWS * RS + (q > u ? q : u) + 2 * ROWS * SA;
+  return (XR ? 0 : 2 * ROWS * RS) + (q > u ? q : u) + 2 * ROWS * SA;
 }
 
 constexpr long long MID_HS_MAX_WG = 64;      // head split while instances x heads stay below this many workgroups
 
-template <int F, int KT, int NT>
-int launch_mid(const GatMidParams& p, int concat, int slot, hipStream_t st) {
-  constexpr size_t lds = mid_lds<F, NT>();
-  const void* fn = concat ? reinterpret_cast<const void*>(&gat_mid_kernel<F, KT, NT, true>)
-                          : reinterpret_cast<const void*>(&gat_mid_kernel<F, KT, NT, false>);
+// slot: LDS-attribute slots of the four kernels of this (width, taps, row tiles) class - concat, mean, and the two head-split forms
+template <int F, int KT, int NT, bool XR = false>
+int launch_mid(const GatMidParams& p, int concat, int slot, int slot_hs, hipStream_t st) {
+  constexpr size_t lds = mid_lds<F, NT, XR>();
+  static_assert(lds <= 160 * 1024, "LDS");
+  const void* fn = concat ? reinterpret_cast<const void*>(&gat_mid_kernel<F, KT, NT, true, false, XR>)
+                          : reinterpret_cast<const void*>(&gat_mid_kernel<F, KT, NT, false, false, XR>);
   if (magat_ensure_dyn_lds(fn, slot + (concat ? 0 : 1), lds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
   int cus = 256, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
@@ -347,19 +380,27 @@ int launch_mid(const GatMidParams& p, int concat, int slot, hipStream_t st) {
   const bool hs = p.P > 1 && (long long)p.B * p.P <= MID_HS_MAX_WG && (concat || p.Ypre);
   const int pid = magat_prof_begin(MAGAT_TAG_GAT_LAYER, st);
   if (hs) {
-    const void* fh = concat ? reinterpret_cast<const void*>(&gat_mid_kernel<F, KT, NT, true, true>)
-                            : reinterpret_cast<const void*>(&gat_mid_kernel<F, KT, NT, false, true>);
-    if (magat_ensure_dyn_lds(fh, slot + 24 + (concat ? 0 : 1), lds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
+    const void* fh = concat ? reinterpret_cast<const void*>(&gat_mid_kernel<F, KT, NT, true, true, XR>)
+                            : reinterpret_cast<const void*>(&gat_mid_kernel<F, KT, NT, false, true, XR>);
+    if (magat_ensure_dyn_lds(fh, slot_hs + (concat ? 0 : 1), lds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
     const unsigned g = (unsigned)(p.B * p.P);
-    if (concat) hipLaunchKernelGGL((gat_mid_kernel<F, KT, NT, true, true>), dim3(g), dim3(64 * NT), lds, st, p);
+    if (concat) hipLaunchKernelGGL((gat_mid_kernel<F, KT, NT, true, true, XR>), dim3(g), dim3(64 * NT), lds, st, p);
     else {
-      hipLaunchKernelGGL((gat_mid_kernel<F, KT, NT, false, true>), dim3(g), dim3(64 * NT), lds, st, p);
+      hipLaunchKernelGGL((gat_mid_kernel<F, KT, NT, false, true, XR>), dim3(g), dim3(64 * NT), lds, st, p);
       const long long M = (long long)p.B * p.N;
       hipLaunchKernelGGL(gat_mid_mean_kernel, dim3((unsigned)((M * F + 255) / 256)), dim3(256), 0, st, p.Ypre, p.Y, M, p.P, F, p.ldpre, p.ldy);
     }
     magat_form_note(MAGAT_FORM_GAT_HSPLIT);
-  } else if (concat) hipLaunchKernelGGL((gat_mid_kernel<F, KT, NT, true>), dim3((unsigned)blocks), dim3(64 * NT), lds, st, p);
-  else hipLaunchKernelGGL((gat_mid_kernel<F, KT, NT, false>), dim3((unsigned)blocks), dim3(64 * NT), lds, st, p);
+  } else if (concat) hipLaunchKernelGGL((gat_mid_kernel<F, KT, NT, true, false, XR>), dim3((unsigned)blocks), dim3(64 * NT), lds, st, p);
+  else {
+    hipLaunchKernelGGL((gat_mid_kernel<F, KT, NT, false, false, XR>), dim3((unsigned)blocks), dim3(64 * NT), lds, st, p);
+    if (XR) {      // (its head mean: the same sum in the same order, from the pre-activation rows)
+      const long long M = (long long)p.B * p.N;
+      long long mb = (M * F + 255) / 256;
+      if (mb > 4096) mb = 4096;
+      hipLaunchKernelGGL(gat_mid_mean_kernel, dim3((unsigned)mb), dim3(256), 0, st, p.Ypre, p.Y, M, p.P, F, p.ldpre, p.ldy);
+    }
+  }
   magat_prof_end(pid, st);
   magat_form_note(MAGAT_FORM_GAT_MID);
   return magat_check_launch();
@@ -368,29 +409,42 @@ int launch_mid(const GatMidParams& p, int concat, int slot, hipStream_t st) {
 template <int F, int KT>
 int launch_mid_nt(const GatMidParams& p, int concat, int slot, hipStream_t st) {
   const int nt = (p.N + 31) / 32;
-  if (nt == 2) return launch_mid<F, KT, 2>(p, concat, slot, st);
-  if (nt == 3) return launch_mid<F, KT, 3>(p, concat, slot + 2, st);
-  return launch_mid<F, KT, 4>(p, concat, slot + 4, st);
+  if (nt == 2) return launch_mid<F, KT, 2>(p, concat, slot, slot + 24, st);
+  if (nt == 3) return launch_mid<F, KT, 3>(p, concat, slot + 2, slot + 26, st);
+  return launch_mid<F, KT, 4>(p, concat, slot + 4, slot + 28, st);
 }
 
 }  // namespace
 
 int magat_gat_mid_supported(int N, int G, int F, int K, int mode) {
-  return mode == MAGAT_MODE_KEYQUERY && N >= 33 && N <= 128 && G == F && (G == 32 || G == 64) && (K == 2 || K == 3);
+  if (mode != MAGAT_MODE_KEYQUERY || G != F || (K != 2 && K != 3) || N > 128) return 0;
+  if (G == 128) {      // (gat_mfma.hip up to 102 agents; option GAT_WIDE_FROM: where this form takes over from the two launches)
+    const int from = magat_opt(MAGAT_OPT_GAT_WIDE_FROM);
+    return N >= (from < 103 ? 103 : from);
+  }
+  return N >= 33 && (G == 32 || G == 64);
 }
 
 // Hs: the f16 planes [2][NC][G] of the layer's pack (packed + magat_gat_f16_block_offset(NC, G))
 int magat_gat_mid_forward(const float* X, int ldx, const void* S, int s_is_f64, const float* Hs, int NC, const float* bias, float* Y,
                           int ldy, int B, int N, int G, int K, int P, int concat, int* range_flag, hipStream_t st,
                           const float* x_scale, float* ypre, int ldpre) {
-  if (!magat_gat_mid_supported(N, G, G, K, MAGAT_MODE_KEYQUERY)) return MAGAT_ERR_UNSUPPORTED;
+  // (any N of the four-row-tile class is accepted here for G = 128; WHERE this form takes over is the dispatcher's decision,
+  //  magat_gat_mid_supported / option GAT_WIDE_FROM)
+  const bool wide_ok = G == 128 && N >= 97 && N <= 128 && (K == 2 || K == 3);
+  if (!wide_ok && !magat_gat_mid_supported(N, G, G, K, MAGAT_MODE_KEYQUERY)) return MAGAT_ERR_UNSUPPORTED;
   if ((ldx & 3) || (reinterpret_cast<uintptr_t>(X) & 15)) return MAGAT_ERR_UNSUPPORTED;
   GatMidParams p;
   p.X = X; p.S = S; p.Hs = reinterpret_cast<const unsigned short*>(Hs); p.bias = bias; p.Y = Y;
   p.B = B; p.N = N; p.P = P; p.NC = NC; p.ldx = ldx; p.ldy = ldy; p.s_is_f64 = s_is_f64;
   p.range_flag = range_flag; p.x_scale = x_scale;
   p.Ypre = (ypre && ldpre >= P * G) ? ypre : nullptr; p.ldpre = ldpre;
-  // LDS-attribute slots: 6 per (width, taps) pair (three tile counts x two merges)
+  if (G == 128 && !concat && !p.Ypre) return MAGAT_ERR_WORKSPACE;      // (the 128-wide form always merges heads through Ypre)
+  // LDS-attribute slots: 6 per (width, taps) pair (three tile counts x two merges), 24 more for their head-split forms, then the
+  // eight of the 128-wide form (taps x merge, + head split)
+  if (G == 128)
+    return K == 3 ? launch_mid<128, 3, 4, true>(p, concat, MAGAT_LDS_GATD_0 + 48, MAGAT_LDS_GATD_0 + 52, st)
+                  : launch_mid<128, 2, 4, true>(p, concat, MAGAT_LDS_GATD_0 + 50, MAGAT_LDS_GATD_0 + 54, st);
   if (G == 32) return K == 3 ? launch_mid_nt<32, 3>(p, concat, MAGAT_LDS_GATD_0, st) : launch_mid_nt<32, 2>(p, concat, MAGAT_LDS_GATD_0 + 6, st);
   return K == 3 ? launch_mid_nt<64, 3>(p, concat, MAGAT_LDS_GATD_0 + 12, st) : launch_mid_nt<64, 2>(p, concat, MAGAT_LDS_GATD_0 + 18, st);
 }

@@ -89,7 +89,7 @@ enum MagatOpt {
   MAGAT_OPT_ENC_CHUNK, MAGAT_OPT_CONV_SPLIT, MAGAT_OPT_CONV_PCHAIN,
   MAGAT_OPT_L1_FUSED, MAGAT_OPT_HEAD_SPLITK, MAGAT_OPT_GAT_CHUNK_MB, MAGAT_OPT_GAT_SPLIT, MAGAT_OPT_RANGE_GUARD,
   MAGAT_OPT_BLOCK_FUSED, MAGAT_OPT_CSR_TILED, MAGAT_OPT_HEAD_F16, MAGAT_OPT_GAT_MFMA, MAGAT_OPT_SKINNY, MAGAT_OPT_GAT_PACK,
-  MAGAT_OPT_CONV_BNFILL, MAGAT_OPT_HEAD_COMPRESS, MAGAT_OPT_CONV_TM, MAGAT_OPT_CSR_FUSED, MAGAT_OPT_LAT_AGENTS, MAGAT_OPT_COUNT
+  MAGAT_OPT_CONV_BNFILL, MAGAT_OPT_HEAD_COMPRESS, MAGAT_OPT_CONV_TM, MAGAT_OPT_CSR_FUSED, MAGAT_OPT_LAT_AGENTS, MAGAT_OPT_GAT_WIDE_FROM, MAGAT_OPT_COUNT
 };
 int magat_opt(int id);
 // hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (kernel slot, device)
@@ -110,10 +110,13 @@ enum MagatLdsSlot {
   MAGAT_LDS_CSR_FUSED_A,  // gat_csr_fused.hip: score kernel, P = 1 | 2 | 4
   MAGAT_LDS_CSR_FUSED_B = MAGAT_LDS_CSR_FUSED_A + 3,   // hop + tap kernel, 1 | 2 heads per workgroup
   MAGAT_LDS_CSR_FUSED_END = MAGAT_LDS_CSR_FUSED_B + 2,
-  MAGAT_LDS_GATD_0 = MAGAT_LDS_CSR_FUSED_END,      // gat_mid.hip: 24 slots (width x taps x row tiles x merge), 24 more for the head-split form
-  MAGAT_LDS_GATD_END = MAGAT_LDS_GATD_0 + 48,
-  MAGAT_LDS_BLOCK_LAT, MAGAT_LDS_BLOCK_LAT_H, MAGAT_LDS_BLOCK_LAT_S    // block_lat.hip (chain only / + head / + stem)
+  MAGAT_LDS_GATD_0 = MAGAT_LDS_CSR_FUSED_END,      // gat_mid.hip: 24 slots (width x taps x row tiles x merge), 24 more for the head-split form, 8 of the 128-wide form
+  MAGAT_LDS_GATD_END = MAGAT_LDS_GATD_0 + 56,
+  MAGAT_LDS_BLOCK_LAT, MAGAT_LDS_BLOCK_LAT_H, MAGAT_LDS_BLOCK_LAT_S,   // block_lat.hip (chain only / + head / + stem)
+  MAGAT_LDS_GAT_SLIM,    // gat_f32.hip: gat_slim_kernel
+  MAGAT_LDS_END
 };
+static_assert(MAGAT_LDS_END <= MAGAT_LDS_SLOTS, "LDS attribute slots");
 
 // packed GAT weights: [Bt NC*G | colbias NC | pad to 4][bf16x3 planes 3*NC*G u16 | pad to 4 floats][f16x2 planes of
 // Bt * 2^8: 2*NC*G u16][float 2^-8][pad]: float offset of the f16 block

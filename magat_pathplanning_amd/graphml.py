@@ -276,6 +276,17 @@ def _csr_attention_to_dense(att, rowptr, colidx, nnz, B, N, P):
     return dense.view(P, B, N, N).permute(1, 0, 2, 3).unsqueeze(2).contiguous()
 
 
+def dense_route(N, layer, want_attention=False):
+    """True when the layer on graphs of N agents runs on the LDS-resident kernels: the two-launch form's tiles fit, or (beyond
+    them: 128 features on 106 .. 128 agents) a one-launch kernel exists - that one returns no attention tensor."""
+    lib = nat.lib()
+    if lib.magat_gat_dense_supported(N, layer.G, layer.F):
+        return True
+    return (not want_attention and
+            bool(lib.magat_gat_one_launch_supported(N, layer.G, layer.F, layer.K, _MODES[layer.attentionMode],
+                                                    1 if layer.concatenate else 0)))
+
+
 def gat_forward_rows(X, S, layer, out=None, want_attention=False, csr=None):
     """Kernel-facing form.  X (B,N,G) f32 contiguous device rows; S (B,N,N) or (B,1,N,N) f32|f64;
     out: optional (B*N, ld) float32 view whose first P*F|F columns receive the result.
@@ -302,7 +313,7 @@ def gat_forward_rows(X, S, layer, out=None, want_attention=False, csr=None):
         S3 = S3.to(X.device)
     dev = X.device
     sc = layer._scratch
-    if bf16 or not lib.magat_gat_dense_supported(N, G, F):
+    if bf16 or not dense_route(N, layer, want_attention) or (out is not None and out.data_ptr() % 16):
         # graph too large for the LDS-resident kernel (or bf16 storage): same layer through the CSR kernels
         rule = 1 if layer.attentionMode == "GAT_origin" else 0
         if CsrStructure.supported(B, N):

@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from . import _native as nat
 from . import encoder as enc
-from .graphml import (_MODES, CsrStructure, GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin,
+from .graphml import (_MODES, CsrStructure, dense_route, GraphFilterBatchAttentional, GraphFilterBatchAttentional_Origin,
                       gat_forward_rows)
 from .resnet import ResNet, ResNetSlim
 
@@ -218,7 +218,7 @@ class DecentralPlannerGATNet(nn.Module):
             B_, N_ = S.shape[0], S.shape[1]
             if (S.numel() > 0 and S.shape[1] == S.shape[2] and not self.training and
                     (layer.storage_dtype == torch.bfloat16 or
-                     not nat.lib().magat_gat_dense_supported(N_, layer.G, layer.F)) and CsrStructure.supported(B_, N_)):
+                     not dense_route(N_, layer)) and CsrStructure.supported(B_, N_)):
                 # large graph / bf16 storage: the layer runs on the CSR kernels.  ONE pass over S does the scrub and leaves
                 # the bit matrix the CSR + CSC structure is built from (no host synchronisation, nothing re-read later)
                 self._rt.csr.build(S, 1 if layer.attentionMode == "GAT_origin" else 0, scrub_nan=scrub, gso_mode=gso_mode)
@@ -608,7 +608,7 @@ class DecentralPlannerGATNet(nn.Module):
         sc = layer._scratch
         G, nfm, M = self.numFeatures2Share, self.numFeatureMap, B * N
         if (layer.storage_dtype == torch.bfloat16 or self.config.use_dropout or rt.ws is None or sc.workspace is None or
-                sc.packed is None or not rt.calibrated or not lib.magat_gat_dense_supported(N, G, layer.F) or
+                sc.packed is None or not rt.calibrated or not dense_route(N, layer) or
                 self.skip not in ("skipConcat", "skipConcatGNN", "skipAddGNN", "only", "legacy")):
             return None
         b = rt.buffers
@@ -664,6 +664,8 @@ class DecentralPlannerGATNet(nn.Module):
             layer.addGSO(S)
             rc = lib.magat_gat_forward_planned_f32(pl.gat_head, ctypes.c_void_p(S.data_ptr()), 1 if S.dtype == torch.float64 else 0,
                                                    *pl.gat_tail, stream)
+            if rc == -2:        # MAGAT_ERR_UNSUPPORTED: a library option that decides the layer's route (GAT_MFMA, GAT_WIDE_FROM)
+                return None     # changed since the plan was built - the caller drops the plan and takes the general path
             if rc:
                 nat.check(rc, "magat_gat_forward_planned_f32")
             layer.aij = None
@@ -699,7 +701,9 @@ class DecentralPlannerGATNet(nn.Module):
         if (plain and pl is not None and pl.rt_key is rt.key and pl.B == B and pl.N == N and pl.dev == dev and pl.ws is rt.ws and
                 pl.gws is layer0._scratch.workspace and pl.packed is layer0._scratch.packed and
                 pl.x_scale == layer0._scratch.x_scale and rt.calibrated):
-            return self._plan_step(pl, rt, x, M, dev)
+            out = self._plan_step(pl, rt, x, M, dev)
+            if out is not None:
+                return out
         rt.plan = None
         out = self._forward_general(rt, x, B, N, M, dev)
         if plain:

@@ -125,3 +125,156 @@ def test_published_checkpoint_shape_on_100_robots(gpu_device, tag_counts):
             got = net(x.to(gpu_device)).cpu()
     assert tc[ONE_LAUNCH] == 1 and tc["gat_maps_gemm"] == 0, tc.counts
     assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+# ---------------------------------------------------------------- 128 features on 103 .. 128 agents
+@pytest.mark.parametrize("N,K,P,concat,f64,B", [(103, 3, 4, True, False, 5), (105, 2, 4, False, True, 5), (106, 3, 4, True, False, 5),
+                                                (110, 3, 4, False, False, 5), (117, 2, 1, True, False, 3), (128, 3, 4, True, True, 5),
+                                                (128, 3, 4, False, False, 40), (128, 2, 4, True, False, 40), (127, 3, 2, False, False, 2)])
+def test_wide_layer_one_launch_up_to_128_agents(gpu_device, tag_counts, libopt, N, K, P, concat, f64, B):
+    """G = F = 128 beyond gat_mfma.hip's 102 agents: the row-tile kernel with the X fragments in registers (before: two launches up
+    to 105 agents, the CSR kernels above).  Small batches take its head-split form, 40 instances the plain one.  By default it
+    takes over at 106 agents (option GAT_WIDE_FROM; 103 .. 105: the two launches are faster) - here from 103."""
+    from magat_pathplanning_amd import _native as nat
+    from magat_pathplanning_amd.synthetic import directed_gso
+    G = 128
+    if N < 106:
+        assert not nat.lib().magat_gat_one_launch_supported(N, G, G, K, 0, 1 if concat else 0)      # the default hand-over
+        libopt.set("MAGAT_GAT_WIDE_FROM", 103)
+    g = torch.Generator().manual_seed(N * 11 + K + P)
+    x = torch.randn(B, G, N, generator=g) * 0.5
+    S = torch.nan_to_num(directed_gso(B, N, 8.0 / N, seed=N + K, dtype=torch.float64 if f64 else torch.float32))
+    S[0, 3, :] = 0
+    S[1, :, 5] = 0
+    if B > 2:
+        S[2] = 0
+    S[B - 1, N - 1, 0] = 5e-10
+    layer, y_ref = _layer_and_ref(G, K, P, concat, x, S, seed=N + P)
+    layer = layer.to(gpu_device).eval()
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    assert nat.lib().magat_gat_one_launch_supported(N, G, G, K, 0, 1 if concat else 0)
+    nat.lib().magat_form_reset()
+    with torch.no_grad(), tag_counts() as tc:
+        y = layer(x.to(gpu_device)).cpu()
+    assert tc[ONE_LAUNCH] == 1 and tc["gat_maps_gemm"] == 0 and tc["gat_graph"] == 0, tc.counts
+    assert int(nat.lib().magat_form_count(nat.FORMS["gat_mid"])) == 1
+    assert int(nat.lib().magat_form_count(nat.FORMS["gat_hsplit"])) == (1 if P > 1 and B * P <= 64 else 0)
+    err = float((y - y_ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(y_ref.abs().max())), err
+    with torch.no_grad():
+        y_again = layer(x.to(gpu_device)).cpu()
+    assert torch.equal(y, y_again)
+
+
+def test_one_launch_supported_for_every_size_up_to_128(libopt):
+    """`magat_gat_one_launch_supported(N, 32 | 64 | 128, .)` for every N <= 128 (KeyQuery, K = 2 | 3): with GAT_WIDE_FROM = 103 all
+    of them; by default every size but 103 .. 105 at 128 features, where the predicate says what the dispatcher does (two
+    launches: measured faster there)."""
+    from magat_pathplanning_amd import _native as nat
+    lib = nat.lib()
+    for wide_from, hole in ((None, [103, 104, 105]), (103, [])):
+        if wide_from is not None:
+            libopt.set("MAGAT_GAT_WIDE_FROM", wide_from)
+        for G in (32, 64, 128):
+            for K in (2, 3):
+                for concat in (0, 1):
+                    missing = [N for N in range(1, 129) if not lib.magat_gat_one_launch_supported(N, G, G, K, 0, concat)]
+                    assert missing == (hole if G == 128 else []), (G, K, concat, missing)
+                assert not lib.magat_gat_one_launch_supported(129, G, G, K, 0, 1)
+
+
+@pytest.mark.parametrize("N,K,concat", [(104, 3, True), (106, 3, True), (128, 3, False), (128, 2, True), (120, 3, False)])
+def test_wide_layer_range_guard_rerun(gpu_device, tag_counts, libopt, N, K, concat):
+    """Inputs beyond the f16 planes' range at the sizes where gat_dense_kernel's tiles no longer fit (N >= 106): the predicated
+    gat_slim_kernel rewrites the output - still the oracle's numbers, the re-run counted once, and a sane forward afterwards
+    runs no float32 work."""
+    from magat_pathplanning_amd import _native as nat
+    from magat_pathplanning_amd.synthetic import comm_gso
+    B, G, P = 3, 128, 4
+    libopt.set("MAGAT_GAT_WIDE_FROM", 103)      # (N = 104: the one-launch kernel in front of gat_dense_kernel's re-run)
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(B, G, N, generator=g) * 3.0e4
+    S = comm_gso(B, N, 50, seed=5)
+    S[1, 7, :] = 0
+    layer, y_ref = _layer_and_ref(G, K, P, concat, x, S, seed=1)
+    layer = layer.to(gpu_device).eval()
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+    with torch.no_grad():
+        y = layer(x.to(gpu_device)).cpu()
+    scale = float(y_ref.abs().max())
+    assert bool(torch.isfinite(y).all())
+    assert float((y - y_ref).abs().max()) <= 2e-5 * max(1.0, scale)
+    def status():
+        import ctypes
+        st = (ctypes.c_int32 * 2)()
+        ws = layer._scratch.workspace
+        with torch.cuda.device(ws.device):
+            nat.check(nat.lib().magat_gat_read_status(nat.ptr(ws), st, nat.current_stream(ws.device)), "magat_gat_read_status")
+        return int(st[0]), int(st[1])
+    st = status()
+    assert st[0] == 1 and st[1] == 1, st      # this forward's flag, re-runs so far
+    x_ok = torch.randn(B, G, N, generator=g) * 0.5
+    _, y_ok_ref = _layer_and_ref(G, K, P, concat, x_ok, S, seed=1)
+    with torch.no_grad():
+        y_ok = layer(x_ok.to(gpu_device)).cpu()
+    assert float((y_ok - y_ok_ref).abs().max()) <= 1e-5 * max(1.0, float(y_ok_ref.abs().max()))
+    assert status() == (0, 1)
+
+
+@pytest.mark.parametrize("N,B", [(128, 6), (120, 1), (106, 40)])
+def test_whole_model_on_106_to_128_agents_is_one_graph_launch(gpu_device, tag_counts, N, B):
+    """The default module (128 features, K = 3, P = 4, skip-concat) on more than 105 agents: the graph layer is ONE launch (no
+    CSR structure is built at addGSO any more), logits within 1e-4 of the oracle; the step plan and the general path agree bit
+    for bit."""
+    from magat_pathplanning_amd import DecentralPlannerGATNet, _native as nat
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    from oracle import magat_oracle as orc
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat", device=str(gpu_device))
+    sd = orc.init_state_dict(cfg, seed=N)
+    x, S = fov_states(B, N, seed=1), comm_gso(B, N, 50, seed=2, dtype=torch.float64)
+    ref = orc.planner_forward(x, S.clone(), sd, cfg)
+    net = DecentralPlannerGATNet(cfg)
+    net.load_state_dict(sd)
+    net = net.to(gpu_device).eval()
+    dx = x.to(gpu_device)
+    with torch.no_grad():
+        net.addGSO(S.clone().to(gpu_device))
+        first = net(dx).cpu()                      # general path (allocates, calibrates)
+        nat.lib().magat_form_reset()
+        with tag_counts() as tc:
+            net.addGSO(S.clone().to(gpu_device))
+            got = net(dx).cpu()                    # step plan
+    assert tc[ONE_LAUNCH] == 1 and tc["gat_maps_gemm"] == 0 and tc["gso_to_csr"] == 0, tc.counts
+    assert int(nat.lib().magat_form_count(nat.FORMS["gat_mid"])) == 1
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(first, got)
+    st = net.range_status()
+    assert not st["gat_rerun"] and not st["encoder_rerun"]
+
+
+def test_step_plan_survives_a_route_changing_option(gpu_device, tag_counts, libopt):
+    """A step plan built while 128 agents ran as one graph launch, then GAT_WIDE_FROM = 129 (never): the next forward drops the
+    plan, builds the CSR structure and runs the CSR kernels - same logits to float32 accuracy - and back again."""
+    from magat_pathplanning_amd import DecentralPlannerGATNet
+    from magat_pathplanning_amd.synthetic import comm_gso, fov_states, make_config
+    B, N = 3, 128
+    cfg = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat", device=str(gpu_device))
+    torch.manual_seed(5)
+    net = DecentralPlannerGATNet(cfg).to(gpu_device).eval()
+    x, S = fov_states(B, N, seed=1).to(gpu_device), comm_gso(B, N, 50, seed=2, dtype=torch.float64).to(gpu_device)
+    with torch.no_grad():
+        for _ in range(2):
+            net.addGSO(S.clone())
+            one = net(x).cpu()
+        libopt.set("MAGAT_GAT_WIDE_FROM", 129)
+        with tag_counts() as tc:
+            net.addGSO(S.clone())
+            csr = net(x).cpu()
+        assert tc[ONE_LAUNCH] == 0, tc.counts
+        libopt.restore()
+        with tag_counts() as tc:
+            net.addGSO(S.clone())
+            back = net(x).cpu()
+        assert tc[ONE_LAUNCH] == 1, tc.counts
+    assert float((one - csr).abs().max()) <= 2e-5 * max(1.0, float(one.abs().max()))
+    assert torch.equal(one, back)
