@@ -17,7 +17,7 @@ count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for it in range(count):
-    N = rng.choice([1, 2, 3, 5, 8, 10, 17, 31, 32, 33, 50, 64, 100, 102, 103, 128, 129, 150])
+    N = rng.choice([1, 2, 3, 5, 8, 10, 17, 31, 32, 33, 50, 64, 100, 102, 103, 106, 117, 128, 129, 150])
     B = rng.choice([1, 2, 3, 5]) if N < 100 else rng.choice([1, 2])
     G = rng.choice([16, 32, 64, 128])
     K = rng.choice([1, 2, 3, 4])

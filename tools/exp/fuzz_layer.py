@@ -11,7 +11,7 @@ count = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for it in range(count):
-    N = rng.choice([1, 2, 3, 7, 10, 20, 31, 32, 33, 64, 100, 102, 103, 127, 128, 129, 200, 300])
+    N = rng.choice([1, 2, 3, 7, 10, 20, 31, 32, 33, 64, 100, 102, 103, 105, 106, 113, 127, 128, 129, 200, 300])
     B = rng.choice([1, 2, 3, 4]) if N <= 128 else rng.choice([1, 2])
     G = rng.choice([16, 32, 64, 128, 256]) if N <= 128 else rng.choice([16, 32, 64, 128])
     F = G if rng.random() < 0.8 else rng.choice([16, 32, 64, 128])
