@@ -847,6 +847,148 @@ __global__ __launch_bounds__(256) void gat_slim_kernel(const GatParams p) {
 }
 
 
+// ---- The range guard's re-run for FEW instances (the closed-loop step of one planning instance: agents/..._GAT.py:1030-1055) as
+// ONE launch: behind a one-launch graph kernel the predicated float32 form was two or three launches that return at once - maps
+// GEMM, graph kernel (, head mean) - 4.5 us each of a 66 us step.  This kernel is all of them: a workgroup owns an instance, forms
+// the maps it needs itself (Q_p and U_pk tiles = X Bt^T + column bias, float32 FMAs from the float32 pack), walks the heads and
+// merges them.  KeyQuery, G = F in {32, 64, 128}, N <= 128; gat_slim_kernel's layout: V [N][G + 1], At [N][N | 1].  Speed is not
+// its job: it runs when a checkpoint's values left the f16 planes' range.
+template <int G>
+__global__ __launch_bounds__(256) void gat_rerun_small_kernel(const GatParams p, const float* __restrict__ Bt,
+                                                              const float* __restrict__ cbias) {
+  extern __shared__ __align__(16) float smem[];
+  if (p.run_if && *p.run_if == 0) {
+    if (p.book) magat_guard_book_idle(p.book);
+    return;
+  }
+  constexpr int F = G, LDV = G + 1, MR = 32, CPL = G > 64 ? 2 : 1;      // columns per lane
+  const int N = p.N, K = p.K, P = p.P, lda = N | 1;
+  float* V = smem;
+  float* At = V + N * LDV;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool cok = lane < G;                       // (G = 32: half the lanes own a column)
+  const int c0 = cok ? lane : 0, c1 = lane + 64;   // c1 only when CPL == 2
+  const float bias0 = p.bias ? p.bias[c0] : 0.f, bias1 = (p.bias && CPL == 2) ? p.bias[c1] : 0.f;
+  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    const float* Xb = p.X + (long long)b * N * p.ldx;
+    // V <- rows of X times rows col .. col + G - 1 of Bt (+ column bias)
+    auto make_tile = [&](int col) {
+      for (int idx = t; idx < N * G; idx += 256) {
+        const int n = idx / G, c = idx - n * G;
+        const float* xr = Xb + (long long)n * p.ldx;
+        const float* br = Bt + (long long)(col + c) * G;
+        float acc = cbias[col + c];
+        for (int g = 0; g < G; g += 4) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + g), bv = *reinterpret_cast<const f32x4*>(br + g);
+          acc = __builtin_fmaf(xv[0], bv[0], acc);
+          acc = __builtin_fmaf(xv[1], bv[1], acc);
+          acc = __builtin_fmaf(xv[2], bv[2], acc);
+          acc = __builtin_fmaf(xv[3], bv[3], acc);
+        }
+        V[n * LDV + c] = acc;
+      }
+    };
+    float s0[MR], s1[MR];      // head mean: running sums of (acc_0 + bias) over the heads, in head order
+#pragma unroll
+    for (int m = 0; m < MR; ++m) { s0[m] = 0.f; s1[m] = 0.f; }
+    for (int head = 0; head < P; ++head) {
+      __syncthreads();      // every wave is done with the previous head's V / At
+      if (K > 1) {
+        make_tile(p.qoff + head * G);
+        __syncthreads();
+        const int j0c = lane < N ? lane : N - 1, j1 = lane + 64 < N ? lane + 64 : N - 1;
+        for (int i = wave; i < N; i += 4) {
+          const float* xi = Xb + (long long)i * p.ldx;
+          float e0 = 0.f, e1 = 0.f;
+          for (int g = 0; g < G; ++g) {
+            const float xg = xi[g];
+            e0 = __builtin_fmaf(xg, V[j0c * LDV + g], e0);
+            e1 = __builtin_fmaf(xg, V[j1 * LDV + g], e1);
+          }
+          const long long srow = ((long long)b * N + i) * N;
+          const bool m0 = lane < N && is_edge(p.S, srow + j0c, p.s_is_f64);
+          const bool m1 = lane + 64 < N && is_edge(p.S, srow + j1, p.s_is_f64);
+          float mx = fmaxf(m0 ? e0 : -__builtin_inff(), m1 ? e1 : -__builtin_inff());
+          for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+          const float x0 = m0 ? __expf(e0 - mx) : 0.f, x1 = m1 ? __expf(e1 - mx) : 0.f;
+          float sum = x0 + x1;
+          for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o, 64);
+          const float inv = sum > 0.f ? 1.f / sum : 0.f;
+          if (lane < N) At[i * lda + lane] = x0 * inv;
+          if (lane + 64 < N) At[i * lda + lane + 64] = x1 * inv;
+        }
+        __syncthreads();
+      }
+      make_tile(p.uoff + (head * K + (K - 1)) * F);
+      __syncthreads();
+      float r0[MR], r1[MR];
+      for (int k = K - 2; k >= 0; --k) {
+        // this wave's rows of U_pk, straight into the accumulators (the same float32 sums make_tile forms)
+        const int ucol = p.uoff + (head * K + k) * F;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          const int j = wave + 4 * m, jc = j < N ? j : N - 1;
+          const float* xr = Xb + (long long)jc * p.ldx;
+          float a0 = cbias[ucol + c0], a1 = CPL == 2 ? cbias[ucol + c1] : 0.f;
+          const float* b0r = Bt + (long long)(ucol + c0) * G;
+          const float* b1r = Bt + (long long)(ucol + (CPL == 2 ? c1 : c0)) * G;
+          for (int g = 0; g < G; ++g) {
+            const float xg = xr[g];
+            a0 = __builtin_fmaf(xg, b0r[g], a0);
+            if (CPL == 2) a1 = __builtin_fmaf(xg, b1r[g], a1);
+          }
+          r0[m] = a0;
+          r1[m] = a1;
+        }
+        for (int i = 0; i < N; ++i) {
+          const float v0 = V[i * LDV + c0], v1 = CPL == 2 ? V[i * LDV + c1] : 0.f;
+          const float* arow = At + i * lda + wave;
+#pragma unroll
+          for (int m = 0; m < MR; ++m) {
+            const float a = wave + 4 * m < N ? arow[4 * m] : 0.f;
+            r0[m] = __builtin_fmaf(a, v0, r0[m]);
+            r1[m] = __builtin_fmaf(a, v1, r1[m]);
+          }
+        }
+        if (k > 0) {
+          __syncthreads();
+#pragma unroll
+          for (int m = 0; m < MR; ++m) {
+            const int j = wave + 4 * m;
+            if (j < N && cok) { V[j * LDV + c0] = r0[m]; if (CPL == 2) V[j * LDV + c1] = r1[m]; }
+          }
+          __syncthreads();
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const int j = wave + 4 * m;
+        if (j >= N) continue;
+        const float y0 = (K > 1 ? r0[m] : V[j * LDV + c0]) + bias0;
+        const float y1 = CPL == 2 ? (K > 1 ? r1[m] : V[j * LDV + c1]) + bias1 : 0.f;
+        if (p.concat) {
+          float* yrow = p.Ymean + ((long long)b * N + j) * p.ldym + head * F;
+          if (cok) yrow[c0] = magat_relu(y0);
+          if (CPL == 2) yrow[c1] = magat_relu(y1);
+        } else {
+          s0[m] += y0;
+          s1[m] += y1;
+          if (head == P - 1) {      // (graphML.py:4663-4667: mean over the heads, then the nonlinearity)
+            float* yrow = p.Ymean + ((long long)b * N + j) * p.ldym;
+            if (cok) yrow[c0] = magat_relu(s0[m] / (float)P);
+            if (CPL == 2) yrow[c1] = magat_relu(s1[m] / (float)P);
+          }
+        }
+      }
+    }
+  }
+  if (p.book) magat_guard_book(p.book);
+}
+
+constexpr long long GAT_RERUN_SMALL_UNITS = 64;      // instances x heads up to which the re-run is this one launch
+
+
 // mean over heads then ReLU (graphML.py:4663-4667)
 __global__ void head_mean_relu_kernel(const float* __restrict__ ytmp, float* __restrict__ y, long long M, int P,
                                       int F, int ldy, const int* __restrict__ run_if, int* book) {
@@ -1282,6 +1424,23 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
     if (rc != MAGAT_OK || !guard) return rc;
     rerun_only = true;
     p.run_if = status;
+    if (mode == MAGAT_MODE_KEYQUERY && (G == 32 || G == 64 || G == 128) && (long long)B * P <= GAT_RERUN_SMALL_UNITS &&
+        (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+      // few instances: the whole float32 form as ONE predicated launch (final rows straight into Y, the guard's bookkeeping too)
+      p.B = B; p.b0 = 0; p.Ymean = Y; p.ldym = ldy; p.book = reinterpret_cast<int*>(status);
+      const size_t slds = sizeof(float) * ((size_t)N * (G + 1) + (size_t)N * (N | 1));
+      const void* fn = G == 32 ? reinterpret_cast<const void*>(&gat_rerun_small_kernel<32>)
+                     : G == 64 ? reinterpret_cast<const void*>(&gat_rerun_small_kernel<64>)
+                               : reinterpret_cast<const void*>(&gat_rerun_small_kernel<128>);
+      if (magat_ensure_dyn_lds(fn, MAGAT_LDS_GAT_RERUN_S + (G == 32 ? 0 : G == 64 ? 1 : 2), slds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
+      const float* cbias = packed + (size_t)L.NC * G;
+      const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);
+      if (G == 32) hipLaunchKernelGGL(gat_rerun_small_kernel<32>, dim3(B), dim3(256), slds, st, p, packed, cbias);
+      else if (G == 64) hipLaunchKernelGGL(gat_rerun_small_kernel<64>, dim3(B), dim3(256), slds, st, p, packed, cbias);
+      else hipLaunchKernelGGL(gat_rerun_small_kernel<128>, dim3(B), dim3(256), slds, st, p, packed, cbias);
+      magat_prof_end(pid, st);
+      return magat_check_launch();
+    }
   }
   const int hpb_env = 0;      // (heads per workgroup: automatic)
   auto hpb_for = [&](int cb) {

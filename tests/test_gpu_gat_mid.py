@@ -278,3 +278,42 @@ def test_step_plan_survives_a_route_changing_option(gpu_device, tag_counts, libo
         assert tc[ONE_LAUNCH] == 1, tc.counts
     assert float((one - csr).abs().max()) <= 2e-5 * max(1.0, float(one.abs().max()))
     assert torch.equal(one, back)
+
+
+@pytest.mark.parametrize("N,G,K,P,concat,B,f64", [(10, 32, 2, 4, False, 1, True), (20, 64, 3, 4, True, 2, False), (100, 32, 2, 4, False, 1, False),
+                                                  (100, 128, 3, 4, True, 1, True), (64, 128, 2, 2, False, 3, False), (33, 64, 3, 1, False, 5, False),
+                                                  (7, 128, 3, 4, False, 16, False)])
+def test_few_instances_rerun_is_one_launch(gpu_device, tag_counts, N, G, K, P, concat, B, f64):
+    """The range guard's float32 re-run behind a one-launch graph kernel, few instances (instances x heads <= 64: the closed-loop
+    step): ONE predicated launch (gat_rerun_small_kernel forms the maps itself) instead of maps GEMM + graph kernel (+ head
+    mean).  With inputs beyond the f16 planes' range it rewrites the output - the oracle's numbers, the re-run counted; with
+    sane inputs it returns at once and the status says so."""
+    import ctypes
+    from magat_pathplanning_amd import _native as nat
+    from magat_pathplanning_amd.synthetic import directed_gso
+    g = torch.Generator().manual_seed(N + G + K)
+    x_big = torch.randn(B, G, N, generator=g) * 3.0e4
+    x_ok = torch.randn(B, G, N, generator=g) * 0.5
+    S = torch.nan_to_num(directed_gso(B, N, min(1.0, 8.0 / N), seed=N, dtype=torch.float64 if f64 else torch.float32))
+    layer, y_big_ref = _layer_and_ref(G, K, P, concat, x_big, S, seed=3)
+    _, y_ok_ref = _layer_and_ref(G, K, P, concat, x_ok, S, seed=3)
+    layer = layer.to(gpu_device).eval()
+    layer.addGSO(S.unsqueeze(1).to(gpu_device))
+
+    def status():
+        st = (ctypes.c_int32 * 2)()
+        ws = layer._scratch.workspace
+        with torch.cuda.device(ws.device):
+            nat.check(nat.lib().magat_gat_read_status(nat.ptr(ws), st, nat.current_stream(ws.device)), "magat_gat_read_status")
+        return int(st[0]), int(st[1])
+    with torch.no_grad(), tag_counts() as tc:
+        y_big = layer(x_big.to(gpu_device)).cpu()
+    assert tc[ONE_LAUNCH] == 1 and tc["range_guard"] == 1 and tc["gat_maps_gemm"] == 0 and tc["gat_graph"] == 0 and tc["head_mean"] == 0, tc.counts
+    assert bool(torch.isfinite(y_big).all())
+    assert float((y_big - y_big_ref).abs().max()) <= 2e-5 * max(1.0, float(y_big_ref.abs().max()))
+    assert status() == (1, 1)
+    with torch.no_grad(), tag_counts() as tc:
+        y_ok = layer(x_ok.to(gpu_device)).cpu()
+    assert tc[ONE_LAUNCH] == 1 and tc["range_guard"] == 1, tc.counts
+    assert float((y_ok - y_ok_ref).abs().max()) <= 1e-5 * max(1.0, float(y_ok_ref.abs().max()))
+    assert status() == (0, 1)
