@@ -860,6 +860,53 @@ def main():
         except Exception as e:
             res["latency_b1"] = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
+        # (c4) the CLOSED LOOP on the device (multiRobotSimNew's getGSO / getCurrentState / move around the
+        # forward, utils/new_simulator.py:279-321, 334-549, 745-806): per step GSO from the positions (with lambda_max) -> FOV state
+        # tensors -> addGSO + forward -> action decode + collision shielding + position update; c3's model, 512 x 100 agents on a
+        # 50 x 50 map, and one instance of 100 agents (the reference's own loop shape).  Not part of `value`.
+        try:
+            import numpy as np
+            from magat_pathplanning_amd.simulator import batched_fov_states, batched_gso, batched_move
+            cl = {"what": "batched_gso(normalize) -> batched_fov_states -> addGSO + forward -> batched_move, positions on the device"}
+            rngc = np.random.default_rng(3)
+            mapc = (rngc.random((50, 50)) < 0.08).astype(np.uint8)
+            freec = np.argwhere(mapc == 0)
+            for key, Bc, steps_c in (("b512_n100", 512, 20), ("b1_n100", 1, 200)):
+                posc = np.stack([freec[rngc.permutation(len(freec))[:100]] for _ in range(Bc)]).astype(np.int32)
+                goalc = np.stack([freec[rngc.permutation(len(freec))[:100]] for _ in range(Bc)]).astype(np.int32)
+                dm, dpos, dgoal = torch.from_numpy(mapc).to(dev), torch.from_numpy(posc).to(dev).contiguous(), torch.from_numpy(goalc).to(dev)
+                best = None
+                with torch.no_grad():
+                    for rep in range(3):
+                        for _ in range(4 if rep == 0 else 0):
+                            net.addGSO(batched_gso(dpos, 7.0))
+                            batched_move(dm, dpos, logits=net(batched_fov_states(dm, dpos, dgoal, 9)), goal=dgoal)
+                        torch.cuda.synchronize(dev)
+                        t0_ = time.perf_counter()
+                        for _ in range(steps_c):
+                            net.addGSO(batched_gso(dpos, 7.0))
+                            batched_move(dm, dpos, logits=net(batched_fov_states(dm, dpos, dgoal, 9)), goal=dgoal)
+                        torch.cuda.synchronize(dev)
+                        el_c = (time.perf_counter() - t0_) / steps_c
+                        best = el_c if best is None or el_c < best else best
+                cl[key] = {"ms_per_step": round(best * 1e3, 4), "value": round(Bc * 100 / best, 1), "unit": "agent-steps/s", "timed_steps": steps_c}
+            res["closed_loop"] = cl
+        except Exception as e:
+            res["closed_loop"] = {"error": repr(e)[:200]}
+        # (c5) the default width on more than 105 agents (400 x 128): the graph layer as one launch (gat_mid.hip, X fragments in
+        # registers; before round 6g: the CSR kernels)
+        try:
+            cfgw = make_config(num_agents=128, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat", device=str(dev))
+            netw = build_model(cfgw, dev)
+            xw, Sw = fov_states(400, 128, seed=21).to(dev), comm_gso(400, 128, 50, seed=22).to(dev)
+            elw, _, _ = run_leg(xw, Sw, esteps, ewarm, False, net=netw, repeats=2)
+            res["n128"] = {"workload": "400 x 128 agents, K=3, P=4, BottomNeck_skipConcat", "value": round(400 * 128 * esteps / elw, 1),
+                           "unit": "agent-steps/s", "ms_per_step": round(elw / esteps * 1e3, 4),
+                           "graph_layer_one_launch": bool(lib.magat_gat_one_launch_supported(128, 128, 128, 3, 0, 1))}
+            del netw, xw, Sw
+        except Exception as e:
+            res["n128"] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
         # (d) STRICT float32: every product on the float32 matrix cores (v_mfma_f32_32x32x2_f32, 157.3 TF peak) - no split
         # planes anywhere (CONV_SPLIT=0, HEAD_F16=0, GAT_SPLIT=0, GAT_MFMA=0).  The headline's f16x3 arithmetic is fp32-CLASS
         # (22-bit products, fp32 accumulation, measured error = this form's); this leg is the number a reader who wants
@@ -919,6 +966,11 @@ def main():
                                     "one_launch": _g(res, "published_f32p4", "graph_layer_one_launch")},
                 "published_f32p4_n100": {"value": _g(res, "published_f32p4_n100", "value"),
                                          "one_launch": _g(res, "published_f32p4_n100", "graph_layer_one_launch")},
+                "closed_loop": {"b512_n100_value": _g(res, "closed_loop", "b512_n100", "value"),
+                                "b512_n100_ms": _g(res, "closed_loop", "b512_n100", "ms_per_step"),
+                                "b1_n100_ms": _g(res, "closed_loop", "b1_n100", "ms_per_step")},
+                "n128": {"value": _g(res, "n128", "value"), "ms_per_step": _g(res, "n128", "ms_per_step"),
+                         "one_launch": _g(res, "n128", "graph_layer_one_launch")},
                 "latency_b1_us": {"N10": _g(res, "latency_b1", "N10", "median_us"), "N100": _g(res, "latency_b1", "N100", "median_us"),
                                   "published_f32p4_N10": _g(res, "latency_b1", "published_f32p4_N10", "median_us"),
                                   "published_f32p4_N100": _g(res, "latency_b1", "published_f32p4_N100", "median_us"),
