@@ -71,8 +71,8 @@ const char* magat_error_string(int code);
  *   ENC_CHUNK (65536), GAT_CHUNK_MB (2048)  workspace bounds: agents per encoder pass, size of the two-launch graph layer's maps
  *   GAT_MFMA    (1)  graph layer with G = F = 128, N <= 102, K = 2 | 3, A_opt == NULL as ONE launch of matrix-core products
  *                    (maps, scores, softmax, hops; csrc/gat_mfma.hip; G = F in {32, 64}: N <= 32 csrc/gat_small.hip, 33 <= N <= 128
- *                    csrc/gat_mid.hip - round 6; G = F = 128 from GAT_WIDE_FROM (106; lowest 103) to 128 agents: csrc/gat_mid.hip
- *                    with the X fragments in registers - between 102 and that the two-launch form, measured faster there); 0 = maps
+ *                    csrc/gat_mid.hip - round 6; G = F = 128 from GAT_WIDE_FROM (103, the lowest) to 128 agents: csrc/gat_mid.hip
+ *                    with the X fragments in registers - between 102 and a larger value the two-launch form / CSR kernels); 0 = maps
  *                    GEMM + graph kernel;  GAT_SPLIT (1) that GEMM on the split kernels;  GAT_PACK (1) four instances per pass
  *                    at N <= 32 once the batch fills the chip (bit-identical)
  *   CSR_TILED   (3)  CSR path (N > 128 / bf16 storage): LDS-tiled score / hop kernels;  SKINNY (1) the action head as streamed

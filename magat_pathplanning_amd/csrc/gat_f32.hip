@@ -1420,7 +1420,7 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
         //  instance - round 6)
         : magat_gat_mid_forward(X, G, S, s_is_f64, packed + magat_gat_f16_block_offset(L.NC, G), L.NC, bias, Y, ldy, B, N, G, K, P,
                                 concat, guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4),
-                                concat ? nullptr : Ytmp, P * F);
+                                concat ? nullptr : Ytmp, P * F, G == 128 ? frag : nullptr);
     if (rc != MAGAT_OK || !guard) return rc;
     rerun_only = true;
     p.run_if = status;

@@ -22,6 +22,15 @@
 #include "magat_common.h"
 
 
+#ifdef MAGAT_DEBUG_HOOKS
+// phase stamps (debug builds: tools/exp/mid_phase_probe.py): [workgroup][wave][16] cycle counters of the LAST head a wave ran
+#define MID_STAMP(i) do { if (p.dbg && (threadIdx.x & 63) == 0) p.dbg[((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+static long long* g_gat_mid_dbg = nullptr;
+extern "C" int magat_gat_mid_set_debug_buffer(long long* dev_buf) { g_gat_mid_dbg = dev_buf; return MAGAT_OK; }
+#else
+#define MID_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -36,6 +45,9 @@ struct GatMidParams {
   int B, N, P, NC, ldx, ldy, s_is_f64;
   int* range_flag;
   const float* x_scale;
+  const char* wfrag;          // XR (G = 128): the same planes fragment-major (gat_mfma.hip's stream: 64 KB blocks [P] W_p, [P K] H_pk,
+                              // a block = [32-row tile 4][k step 8][plane 2][lane 64][8 halves]) - one coalesced 1 KB read per fragment
+  long long* dbg;             // debug builds: phase stamps
   float* Ypre; int ldpre;     // HS, head-mean: the heads' pre-activation outputs [B*N][P F] (the caller's workspace); a small kernel forms the mean
 };
 
@@ -87,7 +99,9 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
   const int myrow = 32 * w + fr;                    // this lane's agent (row j of Q / A^T, column i of the scores, ...)
 
   const int ninst = HS ? (int)gridDim.x / p.P : (int)gridDim.x;      // (HS: gridDim.x = instances-in-flight x P)
-  const int hlo = HS ? (int)blockIdx.x % p.P : 0, hhi = HS ? hlo + 1 : p.P;
+  const int hlo = HS ? (int)blockIdx.x % p.P : 0;
+  int hhi = HS ? hlo + 1 : p.P;
+  if constexpr (HS && XR) asm volatile("" : "+s"(hhi));      // (a head LOOP for the compiler too: as straight-line code this form spilled 289 .. 468 registers)
   for (int inst = HS ? (int)blockIdx.x / p.P : (int)blockIdx.x; inst < p.B; inst += ninst) {
     __syncthreads();      // every wave is done with the previous instance's planes
     // ---- X rows -> f16 planes (rows past N: zeros): all waves into LDS, or (XR) every lane its own operand fragments
@@ -137,24 +151,43 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
     unsigned mk[NT];
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) mk[jt] = 0u;
-    // (eight rows per batch: their loads are in flight together - one row at a time was a serial chain of 64 L2 round trips)
-#pragma unroll 8
-    for (int il = 0; il < 32; ++il) {
-      const int i = 32 * w + il;
+    // (eight rows per batch: their loads are in flight together - one row at a time was a serial chain of 64 L2 round trips.  The
+    //  scheduling barrier keeps them so: without it the compiler moved every load next to its ballot again, one round trip a row)
+    //  The float32 | float64 choice is made ONCE around the loop: inside it, every load sat in its own branch diamond.)
+    constexpr int HC = (ROWS + 63) / 64;
+    auto build_masks = [&](auto tag) __attribute__((always_inline)) {
+      typedef decltype(tag) ST;
+      const ST* Sp = static_cast<const ST*>(p.S) + (long long)inst * N * N;
+#pragma unroll 1
+      for (int il0 = 0; il0 < 32; il0 += 8) {
+        ST sv[8][HC];
 #pragma unroll
-      for (int hc = 0; hc < (ROWS + 63) / 64; ++hc) {
-        const int j = 64 * hc + lane;
-        // (branch-free: clamped addresses, the predicate applied to the loaded value - the batch's loads issue back to back)
-        const long long at = ((long long)inst * N + (i < N ? i : N - 1)) * N + (j < N ? j : N - 1);
-        bool edge = p.s_is_f64 ? fabs(static_cast<const double*>(p.S)[at]) > 1e-9 : fabsf(static_cast<const float*>(p.S)[at]) > 1e-9f;
-        edge = edge && i < N && j < N;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(edge);
-        if (fr == il) {
-          if (2 * hc < NT) mk[2 * hc] = (unsigned)bal;
-          if (2 * hc + 1 < NT) mk[2 * hc + 1] = (unsigned)(bal >> 32);
+        for (int u = 0; u < 8; ++u) {
+          const int i = 32 * w + il0 + u;
+#pragma unroll
+          for (int hc = 0; hc < HC; ++hc) {
+            const int j = 64 * hc + lane;
+            // (branch-free: clamped addresses, the predicate applied to the loaded value - the batch's loads issue back to back)
+            sv[u][hc] = Sp[(long long)(i < N ? i : N - 1) * N + (j < N ? j : N - 1)];
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int hc = 0; hc < HC; ++hc) {
+            const int i = 32 * w + il0 + u, j = 64 * hc + lane;
+            const bool e_ = (sv[u][hc] < (ST)0 ? -sv[u][hc] : sv[u][hc]) > (ST)1e-9 && i < N && j < N;      // (NaN: no edge)
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(e_);
+            if (fr == il0 + u) {
+              if (2 * hc < NT) mk[2 * hc] = (unsigned)bal;
+              if (2 * hc + 1 < NT) mk[2 * hc + 1] = (unsigned)(bal >> 32);
+            }
+          }
       }
-    }
+    };
+    if (p.s_is_f64) build_masks(double{});
+    else build_masks(float{});
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) mk[jt] >>= 4 * fh;      // bit (8 (r / 4) + r % 4) = row j of accumulator register r
     __syncthreads();      // X planes complete
@@ -168,9 +201,13 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
     }
 #pragma unroll 1
     for (int hd = hlo; hd < hhi; ++hd) {
+      MID_STAMP(0);
       // this lane's 16-byte pieces of weight row (base + lane % 32): k step ks, plane pl at + pl * plane + 16 ks + 8 fh halves
       auto wfrag = [&](long long row0, int ks, int pl) __attribute__((always_inline)) {
-        return *reinterpret_cast<const uint4*>(p.Hs + pl * plane + (row0 + fr) * G + 16 * ks + 8 * fh);
+        if constexpr (XR)      // (row0 = 128 block + 32 tile: blocks and tiles are 64 KB / 16 KB apart)
+          return *reinterpret_cast<const uint4*>(p.wfrag + row0 * 512 + (2 * ks + pl) * 1024 + lane * 16);
+        else
+          return *reinterpret_cast<const uint4*>(p.Hs + pl * plane + (row0 + fr) * G + 16 * ks + 8 * fh);
       };
       // operand rows of tile `tile` of the X planes
       // (only ever the wave's own tile - which is why XR can keep them in registers)
@@ -178,31 +215,49 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
         if constexpr (XR) return xr[ks][pl];
         else return *reinterpret_cast<const uint4*>(lds + XO + pl * XPL + (32 * tile + fr) * RS + (16 * ks + 8 * fh) * 2);
       };
-      // ---- G1 (operands swapped): Q^T tile of this wave's agents, lane = agent row j, register quads = 4 consecutive columns g
+      // ---- G1 (operands swapped): Q^T tile of this wave's agents, lane = agent row j, register quads = 4 consecutive columns g.
+      // The weight fragments of a whole batch of column tiles (all of them; one at 128 features: 64 registers) are requested
+      // before the first product: one exposed L2 round trip per batch - requested k step by k step in front of their three
+      // matrix instructions, a wave (alone on its SIMD) sat out one per k step: 20 k cycles for 96 instructions at 128 features
+      constexpr int WB = F == 128 ? 1 : CT;      // column tiles per weight batch
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        f32x16 acc;
+      for (int cb = 0; cb < CT; cb += WB) {
+        uint4 wb[WB][KF][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const long long row0 = (long long)hd * G + 32 * ct;
+        for (int c_ = 0; c_ < WB; ++c_)
 #pragma unroll
-        for (int ks = 0; ks < KF; ++ks) {
-          const uint4 w0 = wfrag(row0, ks, 0), w1 = wfrag(row0, ks, 1), x0 = xfrag(w, ks, 0), x1 = xfrag(w, ks, 1);
-          acc = mfma16(w0, x0, acc);
-          acc = mfma16(w1, x0, acc);
-          acc = mfma16(w0, x1, acc);
-        }
+          for (int ks = 0; ks < KF; ++ks) {
+            wb[c_][ks][0] = wfrag((long long)hd * G + 32 * (cb + c_), ks, 0);
+            wb[c_][ks][1] = wfrag((long long)hd * G + 32 * (cb + c_), ks, 1);
+          }
+        __builtin_amdgcn_sched_barrier(0);      // (the requests stay in front of the products: the scheduler sinks them otherwise)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          uint2 hi, lo;
-          split2v(acc[4 * q] * kInvScale, acc[4 * q + 1] * kInvScale, hi.x, lo.x, vmax);
-          split2v(acc[4 * q + 2] * kInvScale, acc[4 * q + 3] * kInvScale, hi.y, lo.y, vmax);
-          char* o = lds + QO + myrow * RS + (32 * ct + 8 * q + 4 * fh) * 2;
-          *reinterpret_cast<uint2*>(o) = hi;
-          *reinterpret_cast<uint2*>(o + XPL) = lo;
+        for (int c_ = 0; c_ < WB; ++c_) {
+          const int ct = cb + c_;
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KF; ++ks) {
+            const uint4 w0 = wb[c_][ks][0], w1 = wb[c_][ks][1], x0 = xfrag(w, ks, 0), x1 = xfrag(w, ks, 1);
+            acc = mfma16(w0, x0, acc);
+            acc = mfma16(w1, x0, acc);
+            acc = mfma16(w0, x1, acc);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            uint2 hi, lo;
+            split2v(acc[4 * q] * kInvScale, acc[4 * q + 1] * kInvScale, hi.x, lo.x, vmax);
+            split2v(acc[4 * q + 2] * kInvScale, acc[4 * q + 3] * kInvScale, hi.y, lo.y, vmax);
+            char* o = lds + QO + myrow * RS + (32 * ct + 8 * q + 4 * fh) * 2;
+            *reinterpret_cast<uint2*>(o) = hi;
+            *reinterpret_cast<uint2*>(o + XPL) = lo;
+          }
         }
       }
+      MID_STAMP(1);
       __syncthreads();      // Q planes complete (and every wave is past the previous head's reads of the U^T region)
+      MID_STAMP(2);
       // ---- G2: E^T[j][i] = sum_g Q[j][g] X[i][g] for this wave's columns i and ALL row tiles j; lane = column i, registers = rows j
       f32x16 e[NT];
 #pragma unroll
@@ -219,6 +274,7 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
           e[jt] = mfma16(q1, x0, e[jt]);
         }
       }
+      MID_STAMP(3);
       // masked softmax of row i over its edges j (in-lane over the NT tiles + the partner lane), A planes [j][i] * 2^8
       float mx = -__builtin_inff();
 #pragma unroll
@@ -243,6 +299,7 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
         }
       sum += __shfl_xor(sum, 32, 64);
       const float inv = sum > 0.f ? 256.f / sum : 0.f;
+      MID_STAMP(4);
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -257,22 +314,36 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
             *reinterpret_cast<unsigned short*>(o + c * SA + APL) = (unsigned short)(la[c >> 1] >> (16 * (c & 1)));
           }
         }
+      MID_STAMP(5);
       // ---- G3: U_k[i][c] for this wave's agents i and the K taps (lane = column c, registers = rows i).  XR: a tap's product is
       // formed when its accumulators are first needed (tap K - 1 here, tap k in front of hop k) - the same chain of products into
       // the same accumulators, but 64 instead of 192 of them live at 128 features and three taps
       f32x16 acc[KT][CT];
       auto g3 = [&](int k) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
+        for (int cb = 0; cb < CT; cb += WB) {
+          uint4 wb[WB][KF][2];      // (a batch of weight fragments up front, like G1)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[k][ct][r] = 0.f;
-          const long long row0 = (long long)p.P * G + ((long long)hd * KT + k) * F + 32 * ct;
+          for (int c_ = 0; c_ < WB; ++c_)
 #pragma unroll
-          for (int ks = 0; ks < KF; ++ks) {
-            const uint4 w0 = wfrag(row0, ks, 0), w1 = wfrag(row0, ks, 1), x0 = xfrag(w, ks, 0), x1 = xfrag(w, ks, 1);
-            acc[k][ct] = mfma16(x0, w0, acc[k][ct]);
-            acc[k][ct] = mfma16(x0, w1, acc[k][ct]);
-            acc[k][ct] = mfma16(x1, w0, acc[k][ct]);
+            for (int ks = 0; ks < KF; ++ks) {
+              const long long row0 = (long long)p.P * G + ((long long)hd * KT + k) * F + 32 * (cb + c_);
+              wb[c_][ks][0] = wfrag(row0, ks, 0);
+              wb[c_][ks][1] = wfrag(row0, ks, 1);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c_ = 0; c_ < WB; ++c_) {
+            const int ct = cb + c_;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][ct][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KF; ++ks) {
+              const uint4 w0 = wb[c_][ks][0], w1 = wb[c_][ks][1], x0 = xfrag(w, ks, 0), x1 = xfrag(w, ks, 1);
+              acc[k][ct] = mfma16(x0, w0, acc[k][ct]);
+              acc[k][ct] = mfma16(x0, w1, acc[k][ct]);
+              acc[k][ct] = mfma16(x1, w0, acc[k][ct]);
+            }
           }
         }
       };
@@ -281,7 +352,9 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
 #pragma unroll
         for (int k = 0; k < KT; ++k) g3(k);
       }
+      MID_STAMP(6);
       __syncthreads();      // A planes complete; every wave is done reading the Q planes (the U^T planes take their place)
+      MID_STAMP(7);
       // ---- hops (Horner): acc_k[j-tile w] += A[j][all i] U_{k+1}[all i]; the U^T planes [c][i] are rewritten from acc_{k+1}
 #pragma unroll
       for (int k = KT - 2; k >= 0; --k) {
@@ -313,6 +386,7 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
           }
         }
       }
+      MID_STAMP(8);
       // ---- epilogue: lane = column c, registers = rows j of this wave's tile
       float* yb = p.Y + (long long)inst * N * p.ldy;
 #pragma unroll
@@ -331,7 +405,9 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
               yb[(long long)j * p.ldy + 32 * ct + fr] = __builtin_amdgcn_fmed3f(ysum[ct][r] / (float)p.P, 0.f, __builtin_inff());
           }
         }
+      MID_STAMP(9);
       __syncthreads();      // every wave is done with this head's U^T / A planes (the next head's G1 writes the Q planes)
+      MID_STAMP(10);
     }
   }
   if (p.range_flag && vmax > 65504.f) atomicOr(p.range_flag, 1);
@@ -428,7 +504,7 @@ int magat_gat_mid_supported(int N, int G, int F, int K, int mode) {
 // Hs: the f16 planes [2][NC][G] of the layer's pack (packed + magat_gat_f16_block_offset(NC, G))
 int magat_gat_mid_forward(const float* X, int ldx, const void* S, int s_is_f64, const float* Hs, int NC, const float* bias, float* Y,
                           int ldy, int B, int N, int G, int K, int P, int concat, int* range_flag, hipStream_t st,
-                          const float* x_scale, float* ypre, int ldpre) {
+                          const float* x_scale, float* ypre, int ldpre, const float* wfrag) {
   // (any N of the four-row-tile class is accepted here for G = 128; WHERE this form takes over is the dispatcher's decision,
   //  magat_gat_mid_supported / option GAT_WIDE_FROM)
   const bool wide_ok = G == 128 && N >= 97 && N <= 128 && (K == 2 || K == 3);
@@ -438,7 +514,13 @@ int magat_gat_mid_forward(const float* X, int ldx, const void* S, int s_is_f64, 
   p.X = X; p.S = S; p.Hs = reinterpret_cast<const unsigned short*>(Hs); p.bias = bias; p.Y = Y;
   p.B = B; p.N = N; p.P = P; p.NC = NC; p.ldx = ldx; p.ldy = ldy; p.s_is_f64 = s_is_f64;
   p.range_flag = range_flag; p.x_scale = x_scale;
+  p.dbg = nullptr;
+#ifdef MAGAT_DEBUG_HOOKS
+  p.dbg = g_gat_mid_dbg;
+#endif
   p.Ypre = (ypre && ldpre >= P * G) ? ypre : nullptr; p.ldpre = ldpre;
+  p.wfrag = reinterpret_cast<const char*>(wfrag);
+  if (G == 128 && !wfrag) return MAGAT_ERR_NULL;
   if (G == 128 && !concat && !p.Ypre) return MAGAT_ERR_WORKSPACE;      // (the 128-wide form always merges heads through Ypre)
   // LDS-attribute slots: 6 per (width, taps) pair (three tile counts x two merges), 24 more for their head-split forms, then the
   // eight of the 128-wide form (taps x merge, + head split)

@@ -155,7 +155,7 @@ int magat_gat_mid_supported(int N, int G, int F, int K, int mode);
 int magat_gat_mid_forward(const float* X, int ldx, const void* S, int s_is_f64, const float* Hs, int NC, const float* bias, float* Y,
                           int ldy, int B, int N, int G, int K, int P, int concat, int* range_flag, hipStream_t st,
                           const float* x_scale,
-                          float* ypre = nullptr, int ldpre = 0);      // head-mean scratch rows [B*N][P F]: lets few instances run a workgroup per head
+                          float* ypre = nullptr, int ldpre = 0, const float* wfrag = nullptr);      // head-mean scratch rows [B*N][P F]: lets few instances run a workgroup per head
 // one-launch KeyQuery layer on the matrix cores (gat_mfma.hip)
 int magat_gat_mfma_supported(int N, int G, int F, int K, int mode);
 int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre,

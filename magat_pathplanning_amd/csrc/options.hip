@@ -48,11 +48,10 @@ const OptEntry kOpts[MAGAT_OPT_COUNT] = {
     {"LAT_AGENTS", 512},     // largest agent count (magat_encoder_desc.form_agents when set) that takes the LATENCY forms of the encoder:
                              // the BasicBlock chain with one agent per workgroup (block_lat.hip; bit-identical pooled map);
                              // 0 = never (the eight-agent-group kernels at every size)
-    {"GAT_WIDE_FROM", 106},  // graph layer with 128 features: first agent count that takes the row-tile one-launch kernel
-                             // (gat_mid.hip, X fragments in registers) instead of what follows gat_mfma.hip's N <= 102.  106 is where
-                             // the two-launch form's LDS tiles end (above: the CSR kernels, 1.5 x slower than the one launch); at
-                             // 103 .. 105 the two launches are the faster form (0.36 against 0.43 ms per 512 instances): 103 = one
-                             // launch there as well.  Values below 103 mean 103, above 128 never
+    {"GAT_WIDE_FROM", 103},  // graph layer with 128 features: first agent count that takes the row-tile one-launch kernel
+                             // (gat_mid.hip, X fragments in registers) instead of what follows gat_mfma.hip's N <= 102: the two-launch
+                             // form up to 105 agents (0.36 against 0.25 ms per 512 instances), the CSR kernels above (0.76 against
+                             // 0.27 ms at 128 agents).  Values below 103 mean 103, above 128 never
 };
 
 int g_val[MAGAT_OPT_COUNT];

@@ -116,7 +116,7 @@ def test_gat_mfma_directed_graphs_vs_oracle(gpu_device, tag_counts, N, K, P, con
     the hops apply column-wise (z_k[j] = sum_i a_ij z_{k-1}[i], graphML.py:1757, 1274-1286) - a transposed mask or hop would
     pass every symmetric-GSO test.  synthetic.directed_gso adds a one-way edge into an otherwise isolated node, threshold
     entries (5e-10 / -3e-9), a NaN and float64 1/lambda_max values.  The profiling tag asserts which kernel ran: the
-    one-launch matrix-core kernel up to N = 102, the two-launch form at N = 103 .. 105 (the hand-over; the row-tile one-launch kernel from 106)."""
+    one-launch matrix-core kernel up to N = 102, the row-tile one-launch kernel from N = 103 (the hand-over)."""
     from oracle import magat_oracle as orc
     from magat_pathplanning_amd import _native as nat
     from magat_pathplanning_amd.synthetic import directed_gso
@@ -132,10 +132,9 @@ def test_gat_mfma_directed_graphs_vs_oracle(gpu_device, tag_counts, N, K, P, con
     with tag_counts() as tc, torch.no_grad():
         y = layer(x.to(gpu_device)).cpu()
     expect_one = bool(nat.lib().magat_gat_one_launch_supported(N, 128, 128, K, nat.MODE_KEYQUERY, int(concat)))
-    # (round 6: gat_mfma.hip up to 102 agents, gat_mid.hip's 128-wide form from GAT_WIDE_FROM = 106; 103 .. 105: two launches,
-    #  the faster form there - tests/test_gpu_gat_mid.py runs them as one launch too)
-    assert expect_one == (N <= 102 or N >= 106)
-    assert int(nat.lib().magat_form_count(nat.FORMS["gat_mid"])) == (1 if N >= 106 else 0)
+    # (round 6: every N <= 128 - gat_mfma.hip up to 102 agents, gat_mid.hip's 128-wide form above: option GAT_WIDE_FROM = 103)
+    assert expect_one
+    assert int(nat.lib().magat_form_count(nat.FORMS["gat_mid"])) == (1 if N >= 103 else 0)
     assert (tc[ONE_LAUNCH] > 0) == expect_one, tc.counts
     assert tc["gat_graph"] == (0 if expect_one else 1), tc.counts
     np.testing.assert_allclose(y.numpy(), y_ref.numpy(), rtol=0, atol=2e-5)

@@ -133,14 +133,15 @@ def test_published_checkpoint_shape_on_100_robots(gpu_device, tag_counts):
                                                 (128, 3, 4, False, False, 40), (128, 2, 4, True, False, 40), (127, 3, 2, False, False, 2)])
 def test_wide_layer_one_launch_up_to_128_agents(gpu_device, tag_counts, libopt, N, K, P, concat, f64, B):
     """G = F = 128 beyond gat_mfma.hip's 102 agents: the row-tile kernel with the X fragments in registers (before: two launches up
-    to 105 agents, the CSR kernels above).  Small batches take its head-split form, 40 instances the plain one.  By default it
-    takes over at 106 agents (option GAT_WIDE_FROM; 103 .. 105: the two launches are faster) - here from 103."""
+    to 105 agents, the CSR kernels above).  Small batches take its head-split form, 40 instances the plain one.  Option
+    GAT_WIDE_FROM (103) moves the hand-over up: with 106 the sizes 103 .. 105 are two launches again."""
     from magat_pathplanning_amd import _native as nat
     from magat_pathplanning_amd.synthetic import directed_gso
     G = 128
     if N < 106:
-        assert not nat.lib().magat_gat_one_launch_supported(N, G, G, K, 0, 1 if concat else 0)      # the default hand-over
-        libopt.set("MAGAT_GAT_WIDE_FROM", 103)
+        libopt.set("MAGAT_GAT_WIDE_FROM", 106)
+        assert not nat.lib().magat_gat_one_launch_supported(N, G, G, K, 0, 1 if concat else 0)
+        libopt.restore()
     g = torch.Generator().manual_seed(N * 11 + K + P)
     x = torch.randn(B, G, N, generator=g) * 0.5
     S = torch.nan_to_num(directed_gso(B, N, 8.0 / N, seed=N + K, dtype=torch.float64 if f64 else torch.float32))
@@ -167,12 +168,11 @@ def test_wide_layer_one_launch_up_to_128_agents(gpu_device, tag_counts, libopt, 
 
 
 def test_one_launch_supported_for_every_size_up_to_128(libopt):
-    """`magat_gat_one_launch_supported(N, 32 | 64 | 128, .)` for every N <= 128 (KeyQuery, K = 2 | 3): with GAT_WIDE_FROM = 103 all
-    of them; by default every size but 103 .. 105 at 128 features, where the predicate says what the dispatcher does (two
-    launches: measured faster there)."""
+    """`magat_gat_one_launch_supported(N, 32 | 64 | 128, .)` for every N <= 128 (KeyQuery, K = 2 | 3); with GAT_WIDE_FROM = 106 the
+    sizes 103 .. 105 at 128 features drop out - the predicate says what the dispatcher does."""
     from magat_pathplanning_amd import _native as nat
     lib = nat.lib()
-    for wide_from, hole in ((None, [103, 104, 105]), (103, [])):
+    for wide_from, hole in ((None, []), (106, [103, 104, 105])):
         if wide_from is not None:
             libopt.set("MAGAT_GAT_WIDE_FROM", wide_from)
         for G in (32, 64, 128):
@@ -191,7 +191,6 @@ def test_wide_layer_range_guard_rerun(gpu_device, tag_counts, libopt, N, K, conc
     from magat_pathplanning_amd import _native as nat
     from magat_pathplanning_amd.synthetic import comm_gso
     B, G, P = 3, 128, 4
-    libopt.set("MAGAT_GAT_WIDE_FROM", 103)      # (N = 104: the one-launch kernel in front of gat_dense_kernel's re-run)
     g = torch.Generator().manual_seed(N + K)
     x = torch.randn(B, G, N, generator=g) * 3.0e4
     S = comm_gso(B, N, 50, seed=5)
