@@ -450,6 +450,18 @@ typedef struct magat_conv_gemm_desc {
 } magat_conv_gemm_desc;
 int magat_conv_gemm_f32(const magat_conv_gemm_desc* desc_host, void* stream);
 
+/* (ABI 9) GraphFilterBatchAttentional.forward (graphML.py:4636-4671) like magat_gat_forward_packed_f32 (no attention output), and -
+ * when the launches the layer takes leave room for it - the skinny float32 layer that reads its rows inside the layer's LAST
+ * launch: `tail` describes it (what magat_conv_gemm_f32 would be called with: a 1 x 1 product with five outputs over M = B N rows -
+ * the planner's action head, graphs/models/decentralplanner_GAT_bottleneck.py:341-352).  *tail_done = 1: the tail's output is
+ * written; 0: the caller runs magat_conv_gemm_f32(tail) itself (always a valid outcome: other shapes, other modes, many
+ * instances).  Today the room is the predicated range-guard re-run of few instances (instances x heads <= 64, KeyQuery, 32 / 64 /
+ * 128 features): the closed-loop step of one planning instance is THREE launches (encoder, graph layer, re-run + action head).
+ * The tail's rows come from the same device code either way: bit-identical. */
+int magat_gat_forward_tail_f32(const float* X, const void* S, int s_is_f64, const float* packed, const float* bias, float* Y,
+                               int ldy, void* workspace, size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
+                               int mode, int concat, const magat_conv_gemm_desc* tail, int* tail_done, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training of the per-agent CNN (ABI 5; agents/decentralplannerlocal_OnlineExpert_GAT.py:556-567 trains the whole module, the
  * convolutions of resnet_pytorch.py:40-73, 427-524 are 96 % of a step's FLOPs).  The training-mode forward of a convolution and
@@ -643,7 +655,8 @@ int magat_mfma_sustained_f16_ex(double* tflops, double* clock_mhz, double* per_c
 #define MAGAT_FORM_HEAD_LAT 11    /* ... with the encoder head and compressMLP in its epilogue (ABI 8: headfrag_off / compfrag_off) */
 #define MAGAT_FORM_GUARD_LAT 12   /* ... and the encoder's range guard inside the same launch (no predicated launches behind it) */
 #define MAGAT_FORM_STEM_LAT 13    /* ... and the stem + layer1.conv1 in front: the whole encoder of a few-agent call is ONE launch */
-#define MAGAT_FORMS 14
+#define MAGAT_FORM_ACTIONS_TAIL 14 /* the action head inside the graph layer's predicated re-run launch (magat_gat_forward_tail_f32) */
+#define MAGAT_FORMS 15
 long long magat_form_count(int id);
 int magat_form_reset(void);
 

@@ -22,7 +22,7 @@ TAGS = {0: "untagged", 1: "conv_first", 2: "layer1.conv1", 3: "layer1.conv2+ds",
 TAG_ACTIONS = 12
 # magat_form_count ids (include/magat_hip.h MAGAT_FORM_*)
 FORMS = {"head_longk": 0, "head_splitk": 1, "gat_pack": 2, "gat_persist": 3, "gat_hsplit": 4, "chain_persist": 5,
-         "head_compress": 6, "guard_one": 7, "csr_fused": 8, "gat_mid": 9, "chain_lat": 10, "head_lat": 11, "guard_lat": 12, "stem_lat": 13}
+         "head_compress": 6, "guard_one": 7, "csr_fused": 8, "gat_mid": 9, "chain_lat": 10, "head_lat": 11, "guard_lat": 12, "stem_lat": 13, "actions_tail": 14}
 
 _lock = threading.Lock()
 _lib = None
@@ -93,6 +93,7 @@ _SIGNATURES = {
     "magat_gat_workspace_bytes": (_Z, [_I] * 8),
     "magat_gat_forward_packed_f32": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_forward_planned_f32": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P, _P]),
+    "magat_gat_forward_tail_f32": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _Z] + [_I] * 8 + [_P, _P, _P]),
     "magat_gat_forward_dense_f32": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),
     "magat_gat_csr_workspace_bytes": (_Z, [_I, _I, ctypes.c_longlong] + [_I] * 6),
     "magat_gat_forward_csr_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P, _P, _Z] + [_I] * 8 + [_P]),

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "magat_common.h"
+#include "skinny_rows.h"
 
 namespace {
 
@@ -400,92 +401,16 @@ int launch(ConvGemmParams& p, hipStream_t st) {
 }  // namespace
 
 // ---- skinny layers (the action head: 640 -> 5 at c3): a GEMM whose output is a handful of columns is a stream of dot products -
-// the 32-column MFMA tile spends 27 of its 32 columns on padding and the kernel ran at 0.4-0.6 of the HBM roof.  Here 16 lanes own
-// a row: every lane takes the 16-byte chunks l, l + 16, ... of the row (in, then in2), all of a batch in flight before the first
-// is used, multiplies them with the CO weight rows out of LDS ([chunk][CO] float4s: one row's chunk for every output is one
-// contiguous run) in float32 FMAs, and the 16 partial sums meet in a DPP row reduction.  Summation order is fixed (chunk order
-// inside a lane, then the reduction tree): bit-identical from run to run.
+// the 32-column MFMA tile spends 27 of its 32 columns on padding and the kernel ran at 0.4-0.6 of the HBM roof.  The row arithmetic
+// lives in skinny_rows.h (shared with gat_rerun_small_kernel, which carries the action head of few instances in its launch).
 namespace {
-struct SkinnyParams {
-  const float* in;
-  const float* in2;
-  const float* wt;     // [CO][Ktot]
-  const float* bias;
-  float* out;
-  int M, Cin, C2, lda, lda2, ldc, relu;
-  int bf16_rows;       // bit 0: in rows are bf16 (8-byte chunks of 4 values), bit 1: in2 rows
-};
-#ifdef SKINNY_BATCH_OVERRIDE
-constexpr int SKINNY_BATCH = SKINNY_BATCH_OVERRIDE;
-#else
-constexpr int SKINNY_BATCH = 8;      // chunks per lane in flight
-#endif
+typedef MagatSkinnyParams SkinnyParams;
 template <int CO>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyParams p) {
   extern __shared__ __align__(16) float sk_w[];      // [Ktot / 4][CO][4]
-  const int q1 = p.Cin >> 2, nq = q1 + (p.C2 >> 2), Ktot = 4 * nq;
-  for (int idx = threadIdx.x; idx < nq * CO; idx += 256) {
-    const int q = idx / CO, c = idx - q * CO;
-    *reinterpret_cast<f32x4*>(sk_w + (size_t)idx * 4) = *reinterpret_cast<const f32x4*>(p.wt + (size_t)c * Ktot + 4 * q);
-  }
+  magat_skinny_stage_weights<CO>(p, sk_w);
   __syncthreads();
-  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;      // 16 rows per workgroup step
-  float bv[CO];
-#pragma unroll
-  for (int c = 0; c < CO; ++c) bv[c] = p.bias ? p.bias[c] : 0.f;
-  // a lane's unit of work is a 16-byte PIECE of the row: one chunk of 4 float32 values, or two chunks of a bf16 row
-  const bool b1 = p.bf16_rows & 1, b2 = (p.bf16_rows >> 1) & 1;
-  const int np1 = b1 ? p.Cin >> 3 : q1, np2 = b2 ? p.C2 >> 3 : p.C2 >> 2, np = np1 + np2;
-  for (long long m0 = (long long)blockIdx.x * 16; m0 < p.M; m0 += (long long)gridDim.x * 16) {
-    const long long m = m0 + grp;
-    const bool ok = m < p.M;
-    const long long mr = ok ? m : p.M - 1;
-    const char* r1 = reinterpret_cast<const char*>(p.in) + mr * p.lda * (b1 ? 2 : 4);
-    const char* r2 = reinterpret_cast<const char*>(p.in2) + mr * p.lda2 * (b2 ? 2 : 4) - 16LL * np1;   // (piece pc >= np1 at r2 + 16 pc)
-    float acc[CO];
-#pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
-    auto fma4 = [&](const f32x4& xv, int q) {
-#pragma unroll
-      for (int c = 0; c < CO; ++c) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(sk_w + ((size_t)q * CO + c) * 4);
-        acc[c] = __builtin_fmaf(xv[3], w[3], __builtin_fmaf(xv[2], w[2], __builtin_fmaf(xv[1], w[1],
-                 __builtin_fmaf(xv[0], w[0], acc[c]))));
-      }
-    };
-    for (int pb = l16; pb < np; pb += 16 * SKINNY_BATCH) {
-      uint4 x[SKINNY_BATCH];
-#pragma unroll
-      for (int j = 0; j < SKINNY_BATCH; ++j) {
-        const int pq = pb + 16 * j;
-        const int pc = pq < np ? pq : l16;      // (past the row: piece l16 again, dropped below)
-        x[j] = *reinterpret_cast<const uint4*>((pc < np1 ? r1 : r2) + 16LL * pc);
-      }
-#pragma unroll
-      for (int j = 0; j < SKINNY_BATCH; ++j) {
-        const int pq = pb + 16 * j;
-        if (pq < np) {
-          const bool first = pq < np1;
-          if (first ? b1 : b2) {      // eight bf16 values: chunks q, q + 1
-            const int q = first ? 2 * pq : q1 + 2 * (pq - np1);
-            fma4(f32x4{__builtin_bit_cast(float, x[j].x << 16), __builtin_bit_cast(float, x[j].x & 0xffff0000u),
-                       __builtin_bit_cast(float, x[j].y << 16), __builtin_bit_cast(float, x[j].y & 0xffff0000u)}, q);
-            fma4(f32x4{__builtin_bit_cast(float, x[j].z << 16), __builtin_bit_cast(float, x[j].z & 0xffff0000u),
-                       __builtin_bit_cast(float, x[j].w << 16), __builtin_bit_cast(float, x[j].w & 0xffff0000u)}, q + 1);
-          } else {
-            fma4(__builtin_bit_cast(f32x4, x[j]), first ? pq : q1 + (pq - np1));
-          }
-        }
-      }
-    }
-    float mine = 0.f;
-#pragma unroll
-    for (int c = 0; c < CO; ++c) {
-      const float s = row16_sum(acc[c]) + bv[c];
-      if (l16 == c) mine = s;
-    }
-    if (ok && l16 < CO) p.out[m * p.ldc + l16] = p.relu ? magat_relu(mine) : mine;
-  }
+  magat_skinny_rows<CO>(p, sk_w, (long long)blockIdx.x * 16, p.M, (long long)gridDim.x * 16);
 }
 
 template <int CO>
@@ -502,23 +427,8 @@ int skinny_launch(const SkinnyParams& p, int tag, hipStream_t st) {
 
 // takes the layer when it is a plain row-major 1x1 product with at most 8 outputs; MAGAT_ERR_UNSUPPORTED = not this form
 int skinny_try(const magat_conv_gemm_desc* d, hipStream_t st) {
-  if (d->in_fmt != 0 || d->out_fmt != 0 || d->in_gl || d->out_gl || d->Cout > 8 || d->Cout < 1 || d->kH != 1 || d->kW != 1 ||
-      d->Hout != 1 || d->Wout != 1 || d->Hin != 1 || d->Win != 1 || d->pool || d->stride != 1 || d->pad != 0 || d->run_if ||
-      d->absmax || d->ldw || d->wt_pix_stride || d->in_tile_stride || d->in2_tile_stride || d->out_tile_stride ||
-      d->out_ntile_stride || d->in_pix_stride || d->in2_pix_stride || d->out_pix_stride || d->M < 1 ||
-      !magat_opt(MAGAT_OPT_SKINNY))
-    return MAGAT_ERR_UNSUPPORTED;
-  if ((d->Cin & 3) || (d->C2 & 3) || (d->lda & 3) || (d->lda2 & 3) || d->lda < d->Cin || d->ldc < d->Cout || d->C2 < 0 ||
-      (d->C2 > 0 && (!d->in2 || d->lda2 < d->C2 || (d->W2 > 1) || d->stride2 > 1)) ||
-      ((reinterpret_cast<uintptr_t>(d->wt) | reinterpret_cast<uintptr_t>(d->in) | reinterpret_cast<uintptr_t>(d->in2)) & 15) ||
-      (d->bf16_rows & ~3) || ((d->bf16_rows & 2) && d->C2 <= 0) ||
-      ((d->bf16_rows & 1) && ((d->Cin & 7) || (d->lda & 7))) || ((d->bf16_rows & 2) && ((d->C2 & 7) || (d->lda2 & 7))))
-    return MAGAT_ERR_UNSUPPORTED;
   SkinnyParams p;
-  p.in = static_cast<const float*>(d->in); p.in2 = d->C2 > 0 ? static_cast<const float*>(d->in2) : nullptr;
-  p.wt = static_cast<const float*>(d->wt); p.bias = static_cast<const float*>(d->bias); p.out = static_cast<float*>(d->out);
-  p.M = d->M; p.Cin = d->Cin; p.C2 = d->C2; p.lda = d->lda; p.lda2 = d->lda2; p.ldc = d->ldc; p.relu = d->relu;
-  p.bf16_rows = d->bf16_rows;
+  if (magat_skinny_params(d, &p) != MAGAT_OK) return MAGAT_ERR_UNSUPPORTED;
   switch (d->Cout) {
     case 1: return skinny_launch<1>(p, d->tag, st);
     case 2: return skinny_launch<2>(p, d->tag, st);
@@ -531,6 +441,29 @@ int skinny_try(const magat_conv_gemm_desc* d, hipStream_t st) {
   }
 }
 }  // namespace
+
+int magat_skinny_params(const magat_conv_gemm_desc* d, MagatSkinnyParams* out) {
+  if (!d || !out) return MAGAT_ERR_NULL;
+  if (d->in_fmt != 0 || d->out_fmt != 0 || d->in_gl || d->out_gl || d->Cout > 8 || d->Cout < 1 || d->kH != 1 || d->kW != 1 ||
+      d->Hout != 1 || d->Wout != 1 || d->Hin != 1 || d->Win != 1 || d->pool || d->stride != 1 || d->pad != 0 || d->run_if ||
+      d->absmax || d->ldw || d->wt_pix_stride || d->in_tile_stride || d->in2_tile_stride || d->out_tile_stride ||
+      d->out_ntile_stride || d->in_pix_stride || d->in2_pix_stride || d->out_pix_stride || d->M < 1 ||
+      !magat_opt(MAGAT_OPT_SKINNY))
+    return MAGAT_ERR_UNSUPPORTED;
+  if ((d->Cin & 3) || (d->C2 & 3) || (d->lda & 3) || (d->lda2 & 3) || d->lda < d->Cin || d->ldc < d->Cout || d->C2 < 0 ||
+      (d->C2 > 0 && (!d->in2 || d->lda2 < d->C2 || (d->W2 > 1) || d->stride2 > 1)) ||
+      ((reinterpret_cast<uintptr_t>(d->wt) | reinterpret_cast<uintptr_t>(d->in) | reinterpret_cast<uintptr_t>(d->in2)) & 15) ||
+      (d->bf16_rows & ~3) || ((d->bf16_rows & 2) && d->C2 <= 0) ||
+      ((d->bf16_rows & 1) && ((d->Cin & 7) || (d->lda & 7))) || ((d->bf16_rows & 2) && ((d->C2 & 7) || (d->lda2 & 7))))
+    return MAGAT_ERR_UNSUPPORTED;
+  MagatSkinnyParams& p = *out;
+  p.in = static_cast<const float*>(d->in); p.in2 = d->C2 > 0 ? static_cast<const float*>(d->in2) : nullptr;
+  p.wt = static_cast<const float*>(d->wt); p.bias = static_cast<const float*>(d->bias); p.out = static_cast<float*>(d->out);
+  p.M = d->M; p.Cin = d->Cin; p.C2 = d->C2; p.lda = d->lda; p.lda2 = d->lda2; p.ldc = d->ldc; p.relu = d->relu;
+  p.bf16_rows = d->bf16_rows;
+  p.Cout = d->Cout;
+  return MAGAT_OK;
+}
 
 // descriptor -> kernel parameters of the float32 kernel (shape checks included)
 static int conv_params_from_desc(const magat_conv_gemm_desc* d, ConvGemmParams& p) {

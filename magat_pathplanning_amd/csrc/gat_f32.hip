@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "magat_common.h"
+#include "skinny_rows.h"
 
 namespace {
 
@@ -853,14 +854,38 @@ __global__ __launch_bounds__(256) void gat_slim_kernel(const GatParams p) {
 // the maps it needs itself (Q_p and U_pk tiles = X Bt^T + column bias, float32 FMAs from the float32 pack), walks the heads and
 // merges them.  KeyQuery, G = F in {32, 64, 128}, N <= 128; gat_slim_kernel's layout: V [N][G + 1], At [N][N | 1].  Speed is not
 // its job: it runs when a checkpoint's values left the f16 planes' range.
-template <int G>
+// TAIL (CO > 0): the skinny float32 layer that consumes the graph layer's rows (the action head, CO outputs; skinny_rows.h) rides
+// in the same launch - each workgroup computes it for the rows of its instances, after the re-run if there was one.
+template <int G, int CO>
 __global__ __launch_bounds__(256) void gat_rerun_small_kernel(const GatParams p, const float* __restrict__ Bt,
-                                                              const float* __restrict__ cbias) {
+                                                              const float* __restrict__ cbias, const MagatSkinnyParams tail) {
   extern __shared__ __align__(16) float smem[];
+  // The launch has max(B, row groups of the tail) workgroups.  Flag clear (every forward of a sane checkpoint): all of them share
+  // the tail's rows like skinny_gemm_kernel's own launch.  Flag set: workgroup b < B recomputes instance b and then the tail's
+  // rows of THAT instance (they depend on nothing else); the others only arrive at the bookkeeping.
   if (p.run_if && *p.run_if == 0) {
+    if constexpr (CO > 0) {
+      magat_skinny_stage_weights<CO>(tail, smem);
+      __syncthreads();
+      magat_skinny_rows<CO>(tail, smem, (long long)blockIdx.x * 16, tail.M, (long long)gridDim.x * 16);
+    }
     if (p.book) magat_guard_book_idle(p.book);
     return;
   }
+  if ((int)blockIdx.x >= p.B) {
+    if (p.book) magat_guard_book(p.book);
+    return;
+  }
+  auto run_tail = [&]() {
+    if constexpr (CO > 0) {
+      __threadfence_block();
+      __syncthreads();      // the re-run's rows are written, its LDS is free
+      magat_skinny_stage_weights<CO>(tail, smem);
+      __syncthreads();
+      for (int b = blockIdx.x; b < p.B; b += gridDim.x)
+        magat_skinny_rows<CO>(tail, smem, (long long)b * p.N, (long long)(b + 1) * p.N, 16);
+    }
+  };
   constexpr int F = G, LDV = G + 1, MR = 32, CPL = G > 64 ? 2 : 1;      // columns per lane
   const int N = p.N, K = p.K, P = p.P, lda = N | 1;
   float* V = smem;
@@ -983,6 +1008,7 @@ __global__ __launch_bounds__(256) void gat_rerun_small_kernel(const GatParams p,
       }
     }
   }
+  run_tail();
   if (p.book) magat_guard_book(p.book);
 }
 
@@ -1351,12 +1377,11 @@ extern "C" int magat_gat_one_launch_supported(int N, int G, int F, int K, int mo
   return gat_one_launch(N, G, F, K, mode, concat) ? 1 : 0;
 }
 
-extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int s_is_f64, const float* packed,
-                                             const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
-                                             size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
-                                             int mode, int concat, const void* plan, void* stream) {
+// tail / tail_done: magat_gat_forward_tail_f32 (below)
+static int gat_forward_impl(const float* X, const void* S, int s_is_f64, const float* packed, const float* bias, float* Y, int ldy,
+                            float* A_opt, void* workspace, size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
+                            int mode, int concat, const magat_conv_gemm_desc* tail, int* tail_done, void* stream) {
   if (!X || !S || !packed || !Y) return MAGAT_ERR_NULL;
-  if (plan) return MAGAT_ERR_UNSUPPORTED;      // (the GSO plan was removed in round 6)
   if (B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 || P <= 0) return MAGAT_ERR_BAD_SHAPE;
   if (mode < MAGAT_MODE_KEYQUERY || mode > MAGAT_MODE_GAT_ORIGIN) return MAGAT_ERR_UNSUPPORTED;
   if (G != F || !supported_width(G) || N > 128) return MAGAT_ERR_UNSUPPORTED;
@@ -1428,17 +1453,33 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
         (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
       // few instances: the whole float32 form as ONE predicated launch (final rows straight into Y, the guard's bookkeeping too)
       p.B = B; p.b0 = 0; p.Ymean = Y; p.ldym = ldy; p.book = reinterpret_cast<int*>(status);
-      const size_t slds = sizeof(float) * ((size_t)N * (G + 1) + (size_t)N * (N | 1));
-      const void* fn = G == 32 ? reinterpret_cast<const void*>(&gat_rerun_small_kernel<32>)
-                     : G == 64 ? reinterpret_cast<const void*>(&gat_rerun_small_kernel<64>)
-                               : reinterpret_cast<const void*>(&gat_rerun_small_kernel<128>);
-      if (magat_ensure_dyn_lds(fn, MAGAT_LDS_GAT_RERUN_S + (G == 32 ? 0 : G == 64 ? 1 : 2), slds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
+      size_t slds = sizeof(float) * ((size_t)N * (G + 1) + (size_t)N * (N | 1));
+      // the layer that reads this one's rows (the action head: five outputs) in the same launch, when the caller handed it over
+      MagatSkinnyParams sp{};
+      const bool with_tail = tail && magat_skinny_params(tail, &sp) == MAGAT_OK && sp.Cout == 5 && sp.M == B * N &&
+                             (size_t)(sp.Cin + sp.C2) * 5 * sizeof(float) <= 64 * 1024;
+      if (with_tail && (size_t)(sp.Cin + sp.C2) * 5 * sizeof(float) > slds) slds = (size_t)(sp.Cin + sp.C2) * 5 * sizeof(float);
+      const int gi = G == 32 ? 0 : G == 64 ? 1 : 2;
+      const void* fns[2][3] = {{reinterpret_cast<const void*>(&gat_rerun_small_kernel<32, 0>), reinterpret_cast<const void*>(&gat_rerun_small_kernel<64, 0>),
+                                reinterpret_cast<const void*>(&gat_rerun_small_kernel<128, 0>)},
+                               {reinterpret_cast<const void*>(&gat_rerun_small_kernel<32, 5>), reinterpret_cast<const void*>(&gat_rerun_small_kernel<64, 5>),
+                                reinterpret_cast<const void*>(&gat_rerun_small_kernel<128, 5>)}};
+      if (magat_ensure_dyn_lds(fns[with_tail ? 1 : 0][gi], MAGAT_LDS_GAT_RERUN_S + gi + (with_tail ? 3 : 0), slds) != MAGAT_OK) return MAGAT_ERR_LAUNCH;
       const float* cbias = packed + (size_t)L.NC * G;
       const int pid = magat_prof_begin(MAGAT_TAG_RANGE_GUARD, st);
-      if (G == 32) hipLaunchKernelGGL(gat_rerun_small_kernel<32>, dim3(B), dim3(256), slds, st, p, packed, cbias);
-      else if (G == 64) hipLaunchKernelGGL(gat_rerun_small_kernel<64>, dim3(B), dim3(256), slds, st, p, packed, cbias);
-      else hipLaunchKernelGGL(gat_rerun_small_kernel<128>, dim3(B), dim3(256), slds, st, p, packed, cbias);
+      if (with_tail) {
+        const int tg = (B * N + 15) / 16, grid = tg > B ? tg : B;      // (B x heads <= 64, N <= 128: at most 512 workgroups)
+        if (G == 32) hipLaunchKernelGGL((gat_rerun_small_kernel<32, 5>), dim3(grid), dim3(256), slds, st, p, packed, cbias, sp);
+        else if (G == 64) hipLaunchKernelGGL((gat_rerun_small_kernel<64, 5>), dim3(grid), dim3(256), slds, st, p, packed, cbias, sp);
+        else hipLaunchKernelGGL((gat_rerun_small_kernel<128, 5>), dim3(grid), dim3(256), slds, st, p, packed, cbias, sp);
+        magat_form_note(MAGAT_FORM_ACTIONS_TAIL);
+      } else {
+        if (G == 32) hipLaunchKernelGGL((gat_rerun_small_kernel<32, 0>), dim3(B), dim3(256), slds, st, p, packed, cbias, sp);
+        else if (G == 64) hipLaunchKernelGGL((gat_rerun_small_kernel<64, 0>), dim3(B), dim3(256), slds, st, p, packed, cbias, sp);
+        else hipLaunchKernelGGL((gat_rerun_small_kernel<128, 0>), dim3(B), dim3(256), slds, st, p, packed, cbias, sp);
+      }
       magat_prof_end(pid, st);
+      if (with_tail && tail_done) *tail_done = 1;
       return magat_check_launch();
     }
   }
@@ -1525,6 +1566,29 @@ extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int 
   return MAGAT_OK;
 }
 
+extern "C" int magat_gat_forward_planned_f32(const float* X, const void* S, int s_is_f64, const float* packed,
+                                             const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
+                                             size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
+                                             int mode, int concat, const void* plan, void* stream) {
+  if (plan) return MAGAT_ERR_UNSUPPORTED;      // (the GSO plan was removed in round 6)
+  return gat_forward_impl(X, S, s_is_f64, packed, bias, Y, ldy, A_opt, workspace, workspace_bytes, B, N, G, F, K, P, mode, concat,
+                          nullptr, nullptr, stream);
+}
+
+// The layer, and - when the launches it takes leave room for it - the skinny float32 layer that reads its rows (`tail`: the action
+// head of the planner, magat_conv_gemm_desc of a 1 x 1 product with five outputs over M = B N rows) inside the layer's last launch:
+// *tail_done = 1 then, 0 when the caller has to run magat_conv_gemm_f32(tail) itself (always a valid outcome).  Today that is the
+// predicated range-guard re-run of few instances (instances x heads <= 64, KeyQuery): the closed-loop step of one planning instance
+// loses a launch.  The tail's rows are computed by skinny_rows.h's code either way: the same bits.
+extern "C" int magat_gat_forward_tail_f32(const float* X, const void* S, int s_is_f64, const float* packed, const float* bias,
+                                          float* Y, int ldy, void* workspace, size_t workspace_bytes, int B, int N, int G, int F,
+                                          int K, int P, int mode, int concat, const magat_conv_gemm_desc* tail, int* tail_done,
+                                          void* stream) {
+  if (tail_done) *tail_done = 0;
+  return gat_forward_impl(X, S, s_is_f64, packed, bias, Y, ldy, nullptr, workspace, workspace_bytes, B, N, G, F, K, P, mode, concat,
+                          tail, tail_done, stream);
+}
+
 extern "C" int magat_gat_forward_packed_f32(const float* X, const void* S, int s_is_f64, const float* packed,
                                             const float* bias, float* Y, int ldy, float* A_opt, void* workspace,
                                             size_t workspace_bytes, int B, int N, int G, int F, int K, int P,
@@ -1576,7 +1640,7 @@ extern "C" int magat_gso_prepare(void* S, int s_is_f64, size_t count, int scrub_
   return magat_check_launch();
 }
 
-extern "C" int magat_abi_version(void) { return 8; }
+extern "C" int magat_abi_version(void) { return 9; }
 
 extern "C" const char* magat_error_string(int code) {
   switch (code) {

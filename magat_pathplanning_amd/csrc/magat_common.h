@@ -114,7 +114,7 @@ enum MagatLdsSlot {
   MAGAT_LDS_GATD_END = MAGAT_LDS_GATD_0 + 56,
   MAGAT_LDS_BLOCK_LAT, MAGAT_LDS_BLOCK_LAT_H, MAGAT_LDS_BLOCK_LAT_S,   // block_lat.hip (chain only / + head / + stem)
   MAGAT_LDS_GAT_SLIM,    // gat_f32.hip: gat_slim_kernel
-  MAGAT_LDS_GAT_RERUN_S, MAGAT_LDS_GAT_RERUN_S_END = MAGAT_LDS_GAT_RERUN_S + 2,    // gat_rerun_small_kernel<32 | 64 | 128>
+  MAGAT_LDS_GAT_RERUN_S, MAGAT_LDS_GAT_RERUN_S_END = MAGAT_LDS_GAT_RERUN_S + 5,    // gat_rerun_small_kernel<32 | 64 | 128, without | with the tail>
   MAGAT_LDS_END
 };
 static_assert(MAGAT_LDS_END <= MAGAT_LDS_SLOTS, "LDS attribute slots");

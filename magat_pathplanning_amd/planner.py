@@ -625,8 +625,10 @@ class DecentralPlannerGATNet(nn.Module):
         concat = 1 if layer.concatenate else 0
         pl.enc_tail = (nat.ptr(feat), nfm, nat.ptr(comp), G, nat.ptr(rt.ws), rt.ws.numel(), M)
         pl.gat_head = nat.ptr(comp)
-        pl.gat_tail = (nat.ptr(sc.packed), nat.ptr(pl.bias), nat.ptr(gat), gat.stride(0), None, nat.ptr(sc.workspace),
-                       sc.workspace.numel(), B, N, G, F, K, P, mode, concat, None)
+        pl.gat_tail = (nat.ptr(sc.packed), nat.ptr(pl.bias), nat.ptr(gat), gat.stride(0), nat.ptr(sc.workspace),
+                       sc.workspace.numel(), B, N, G, F, K, P, mode, concat)
+        pl.tail_done = ctypes.c_int(0)
+        pl.tail_done_ref = ctypes.byref(pl.tail_done)
         nout = rt.act[0].shape[0]
         d = nat.ConvGemmDesc()
         if self.skip in ("skipConcat", "skipConcatGNN", "skipAddGNN"):
@@ -645,8 +647,9 @@ class DecentralPlannerGATNet(nn.Module):
         return pl
 
     def _plan_step(self, pl, rt, x, M, dev):
-        """One forward through a step plan: three C-ABI calls (encoder, graph layer, action head) and one allocation (the
-        logits).  Same kernels, same arguments as the general path."""
+        """One forward through a step plan: three C-ABI calls (encoder, graph layer, action head - two when the action head rode
+        in the graph layer's last launch, magat_gat_forward_tail_f32) and one allocation (the logits).  Same kernels, same
+        arguments as the general path."""
         lib = nat.lib()
         layer = self.GFL[0]
         S = self.S
@@ -662,18 +665,20 @@ class DecentralPlannerGATNet(nn.Module):
             if rc:
                 nat.check(rc, "magat_encoder_forward_f32")
             layer.addGSO(S)
-            rc = lib.magat_gat_forward_planned_f32(pl.gat_head, ctypes.c_void_p(S.data_ptr()), 1 if S.dtype == torch.float64 else 0,
-                                                   *pl.gat_tail, stream)
+            # (the logits' buffer exists before the graph layer's call: the action head may ride in the layer's last launch)
+            out = torch.empty(M, pl.nout, dtype=torch.float32, device=dev)
+            pl.act.out = out.data_ptr()
+            rc = lib.magat_gat_forward_tail_f32(pl.gat_head, ctypes.c_void_p(S.data_ptr()), 1 if S.dtype == torch.float64 else 0,
+                                                *pl.gat_tail, pl.act_ref, pl.tail_done_ref, stream)
             if rc == -2:        # MAGAT_ERR_UNSUPPORTED: a library option that decides the layer's route (GAT_MFMA, GAT_WIDE_FROM)
                 return None     # changed since the plan was built - the caller drops the plan and takes the general path
             if rc:
-                nat.check(rc, "magat_gat_forward_planned_f32")
+                nat.check(rc, "magat_gat_forward_tail_f32")
             layer.aij = None
-            out = torch.empty(M, pl.nout, dtype=torch.float32, device=dev)
-            pl.act.out = out.data_ptr()
-            rc = lib.magat_conv_gemm_f32(pl.act_ref, stream)
-            if rc:
-                nat.check(rc, "magat_conv_gemm_f32(actionsMLP.0)")
+            if not pl.tail_done.value:
+                rc = lib.magat_conv_gemm_f32(pl.act_ref, stream)
+                if rc:
+                    nat.check(rc, "magat_conv_gemm_f32(actionsMLP.0)")
         finally:
             if switch:
                 torch.cuda.set_device(prev)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = nat.lib()                       # loads without a GPU
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.magat_abi_version() == 8
+    assert lib.magat_abi_version() == 9
     assert lib.magat_build_flavor() == 0          # a release build: no timing-experiment switches compiled in
     assert lib.magat_error_string(-2).decode().startswith("unsupported")
     # pure host queries work without a device
