@@ -49,7 +49,7 @@ __device__ __forceinline__ void split2v(float x, float y, unsigned& p1, unsigned
 }
 
 template <int F, int KT, bool CONCAT>
-__global__ __launch_bounds__(256) void gat_small_kernel(const GatSmallParams p) {
+__global__ __launch_bounds__(256, F == 32 ? 2 : 1) void gat_small_kernel(const GatSmallParams p) {      // (32 features: two waves per SIMD - a second workgroup per CU at large batches)
   extern __shared__ __align__(16) char lds_all[];
   constexpr int CT = F / 32, KF = F / 16;
   constexpr int RS = 2 * F + 16;             // row stride of the X / Q planes (bytes): rows land 20 / 36 banks apart
@@ -105,16 +105,24 @@ __global__ __launch_bounds__(256) void gat_small_kernel(const GatSmallParams p) 
       if (fr < N) mk = p.rmask_pre[((long long)inst * N + fr) * 4];
     } else {
       // lane (fr, fh): row i = fr, columns j = 16 fh .. 16 fh + 15 of it; the two halves are OR-ed
+      // (the sixteen entries are requested together - clamped addresses, the predicate on the loaded value - and pinned in front
+      //  of the tests: as a loop with a run-time bound they were sixteen round trips, one after the other)
       unsigned bits = 0u;
-      if (fr < N) {
-        if (p.s_is_f64) {
-          const double* Sp = static_cast<const double*>(p.S) + ((long long)inst * N + fr) * N;
-          for (int j = 16 * fh; j < min(N, 16 * fh + 16); ++j) bits |= (fabs(Sp[j]) > 1e-9 ? 1u : 0u) << j;
-        } else {
-          const float* Sp = static_cast<const float*>(p.S) + ((long long)inst * N + fr) * N;
-          for (int j = 16 * fh; j < min(N, 16 * fh + 16); ++j) bits |= (fabsf(Sp[j]) > 1e-9f ? 1u : 0u) << j;
+      auto row_bits = [&](auto tag) __attribute__((always_inline)) {
+        typedef decltype(tag) ST;
+        const ST* Sp = static_cast<const ST*>(p.S) + ((long long)inst * N + (fr < N ? fr : N - 1)) * N;
+        ST sv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sv[u] = Sp[16 * fh + u < N ? 16 * fh + u : N - 1];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const bool e_ = (sv[u] < (ST)0 ? -sv[u] : sv[u]) > (ST)1e-9 && fr < N && 16 * fh + u < N;      // (NaN: no edge)
+          bits |= (e_ ? 1u : 0u) << (16 * fh + u);
         }
-      }
+      };
+      if (p.s_is_f64) row_bits(double{});
+      else row_bits(float{});
       mk = bits | (unsigned)__shfl_xor((int)bits, 32, 64);
     }
     mk >>= 4 * fh;      // bit (8 (r / 4) + r % 4) = row j of accumulator register r
@@ -136,15 +144,25 @@ __global__ __launch_bounds__(256) void gat_small_kernel(const GatSmallParams p) 
         return *reinterpret_cast<const uint4*>(lds + XO + pl * 32 * RS + fr * RS + (16 * ks + 8 * fh) * 2);
       };
       // ---- G1 (operands swapped): Q^T tile, lane = agent row j, register quads = 4 consecutive columns g -> Q planes [j][g]
+      // (a product's weight fragments are requested together and pinned in front of its matrix instructions: the compiler moves
+      //  every request next to its use otherwise - one exposed L2 round trip per k step at one or two waves per SIMD)
+      uint4 wq[CT][KF][2];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < KF; ++ks) {
+          wq[ct][ks][0] = wfrag((long long)hd * G + 32 * ct, ks, 0);
+          wq[ct][ks][1] = wfrag((long long)hd * G + 32 * ct, ks, 1);
+        }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const long long row0 = (long long)hd * G + 32 * ct;
 #pragma unroll
         for (int ks = 0; ks < KF; ++ks) {
-          const uint4 w0 = wfrag(row0, ks, 0), w1 = wfrag(row0, ks, 1), x0 = xfrag(ks, 0), x1 = xfrag(ks, 1);
+          const uint4 w0 = wq[ct][ks][0], w1 = wq[ct][ks][1], x0 = xfrag(ks, 0), x1 = xfrag(ks, 1);
           acc = mfma16(w0, x0, acc);
           acc = mfma16(w1, x0, acc);
           acc = mfma16(w0, x1, acc);
@@ -158,6 +176,22 @@ __global__ __launch_bounds__(256) void gat_small_kernel(const GatSmallParams p) 
           *reinterpret_cast<uint2*>(o) = hi;
           *reinterpret_cast<uint2*>(o + 32 * RS) = lo;
         }
+      }
+      // 32 features: the K taps' fragments (4 K registers quads) are requested here, in flight under G2 and the softmax
+      constexpr bool WEARLY = false;      // (requesting the taps in front of G2 cost the second wave per SIMD: 256 + registers)
+      uint4 wt[WEARLY ? KT : 1][CT][KF][2];
+      if constexpr (WEARLY) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < KF; ++ks) {
+              const long long row0 = (long long)p.P * G + ((long long)hd * KT + k) * F + 32 * ct;
+              wt[k][ct][ks][0] = wfrag(row0, ks, 0);
+              wt[k][ct][ks][1] = wfrag(row0, ks, 1);
+            }
+        __builtin_amdgcn_sched_barrier(0);
       }
       // ---- G2: E^T[j][i] = sum_g Q[j][g] X[i][g]; lane = column i, registers = rows j
       f32x16 e;
@@ -207,20 +241,35 @@ __global__ __launch_bounds__(256) void gat_small_kernel(const GatSmallParams p) 
       // ---- G3: U_k[i][c] for the K taps (lane = column c, registers = rows i)
       f32x16 acc[KT][CT];
 #pragma unroll
-      for (int k = 0; k < KT; ++k)
+      for (int k = 0; k < KT; ++k) {
+        uint4 wk[WEARLY ? 1 : CT][KF][2];      // (wider layers: a tap's fragments together, in front of its products)
+        if constexpr (!WEARLY) {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < KF; ++ks) {
+              const long long row0 = (long long)p.P * G + ((long long)hd * KT + k) * F + 32 * ct;
+              wk[ct][ks][0] = wfrag(row0, ks, 0);
+              wk[ct][ks][1] = wfrag(row0, ks, 1);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[k][ct][r] = 0.f;
-          const long long row0 = (long long)p.P * G + ((long long)hd * KT + k) * F + 32 * ct;
 #pragma unroll
           for (int ks = 0; ks < KF; ++ks) {
-            const uint4 w0 = wfrag(row0, ks, 0), w1 = wfrag(row0, ks, 1), x0 = xfrag(ks, 0), x1 = xfrag(ks, 1);
+            uint4 w0, w1;
+            if constexpr (WEARLY) { w0 = wt[k][ct][ks][0]; w1 = wt[k][ct][ks][1]; }
+            else { w0 = wk[ct][ks][0]; w1 = wk[ct][ks][1]; }
+            const uint4 x0 = xfrag(ks, 0), x1 = xfrag(ks, 1);
             acc[k][ct] = mfma16(x0, w0, acc[k][ct]);
             acc[k][ct] = mfma16(x0, w1, acc[k][ct]);
             acc[k][ct] = mfma16(x1, w0, acc[k][ct]);
           }
         }
+      }
       // ---- hops (Horner): acc_k += A U_{k+1}; the U^T planes [c][i] are rewritten from acc_{k+1}
 #pragma unroll
       for (int k = KT - 2; k >= 0; --k) {
