@@ -383,6 +383,29 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
     cellT[s] = cell;
   }
   const float sA = *p.sA, sB = *p.sB, sC = *p.sC, s1 = *p.s1, s2 = *p.s2;
+  // HEAD: everything the late phases read from memory besides their weight rings - activation scales, plane scales, biases - is
+  // requested HERE, branch-free, and pinned: next to their uses (where the compiler puts them; the optional scales each in a branch
+  // of their own) they were four exposed round trips behind the last walks of a 36 us kernel
+  float insc_h = 1.f, insc2_h = 1.f, hs_raw = 0.f, cs_raw = 0.f;
+  f32x4 hb_h[4], cb_h[4], b2_h[4];
+  if (HEAD) {
+    const float i1 = *(p.insc ? p.insc : p.sA), i2 = *(p.insc2 ? p.insc2 : p.sA);
+    insc_h = p.insc ? i1 : 1.f;
+    insc2_h = p.insc2 ? i2 : 1.f;
+    hs_raw = *reinterpret_cast<const float*>(p.hfrag + (size_t)4 * 72 * 2048);
+    cs_raw = *reinterpret_cast<const float*>(p.cfrag + (size_t)(p.ncomp / 32) * 8 * 2048);
+    const int cw = 32 * wave < p.ncomp ? wave : 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      hb_h[q] = *reinterpret_cast<const f32x4*>(p.hbias + 32 * wave + 8 * q + 4 * fh);
+      cb_h[q] = *reinterpret_cast<const f32x4*>(p.cbias + 32 * cw + 8 * q + 4 * fh);
+    }
+    if (insc_h == 0.f) insc_h = 1.f;
+    if (insc2_h == 0.f) insc2_h = 1.f;
+  }
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) b2_h[qd] = *reinterpret_cast<const f32x4*>(p.b2 + 32 * wave + 8 * qd + 4 * fh);
+  __builtin_amdgcn_sched_barrier(0);
   bool clamped = false;
   LAT_STAMP(0);
   if (!STEM) {
@@ -419,15 +442,26 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
       v0 = r[0]; v1 = r[121]; v2 = r[242];
     }
     u32x4 wa[3][2];      // stem weights as this lane's row fragments: row = channel fr, k step = tap row ty (stem8.hip)
+    // (24 weights and the bias requested together from clamped addresses, the predicate applied to the value: each in a branch of
+    //  its own they were a chain of ten round trips in front of everything else)
+    float wraw[3][8];
+    const float b0v = p.b0[fr];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int slot = 8 * fh + i, tx = slot >> 2, c = slot & 3;
+        wraw[ty][i] = p.w0[fr * 27 + ((tx < 3 && c < 3) ? c * 9 + ty * 3 + tx : 0)];
+      }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ty = 0; ty < 3; ++ty) {
       float wv[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int slot = 8 * fh + i, tx = slot >> 2, c = slot & 3;
-        float v = 0.f;
-        if (tx < 3 && c < 3) v = p.w0[fr * 27 + c * 9 + ty * 3 + tx];
-        if (ty == 1 && tx == 1 && c == 3) v = p.b0[fr];
+        float v = (tx < 3 && c < 3) ? wraw[ty][i] : 0.f;
+        if (ty == 1 && tx == 1 && c == 3) v = b0v;
         wv[i] = v * 16.f;
       }
       unsigned h1[4], h2[4];
@@ -565,15 +599,11 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
     LAT_STAMP(9);
     f32x4 bq[4];
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const f32x4*>(p.b2 + 32 * wave + 8 * qd + 4 * fh);
+    for (int qd = 0; qd < 4; ++qd) bq[qd] = b2_h[qd];
     float* ob = p.out + (long long)(m >> 7) * 9 * (128 * 128) +
                 (p.out_gl ? (8 * wave + fh) * 512 + (m & 127) * 4 : (m & 127) * 128 + 32 * wave + 4 * fh);
     const int qstep = p.out_gl ? 1024 : 8;
-    float insc = 1.f;
-    if (HEAD) {
-      if (p.insc) insc = *p.insc;
-      if (insc == 0.f) insc = 1.f;
-    }
+    const float insc = insc_h;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -609,11 +639,7 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
     L3_LDS_SYNC();
     LAT_STAMP(10);
     // ---- encoder head: feat = W_head . pooled (K = 9 x 128 in the long-K kernel's order: 32-channel slab outer, cell inner) ----
-    float insc = 1.f, insc2 = 1.f;
-    if (p.insc) insc = *p.insc;
-    if (insc == 0.f) insc = 1.f;
-    if (p.insc2) insc2 = *p.insc2;
-    if (insc2 == 0.f) insc2 = 1.f;
+    const float insc = insc_h, insc2 = insc2_h;
     f32x16 hacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
@@ -621,11 +647,11 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
     if (32 * wave < p.ncomp) ring_fill(wr, p.cfrag + (size_t)wave * 8 * 2048, lane16);
     LAT_STAMP(11);
     {
-      const float hs = *reinterpret_cast<const float*>(p.hfrag + (size_t)4 * 72 * 2048) / insc;      // (exact: powers of two)
+      const float hs = hs_raw / insc;      // (exact: powers of two)
       bool cl = false;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.hbias + 32 * wave + 8 * q + 4 * fh);
+        const f32x4 bb = hb_h[q];
         f32x4 v;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = hacc[4 * q + c] * hs + bb[c];
@@ -651,10 +677,10 @@ __global__ __launch_bounds__(256, 1) void block_lat_kernel(const LatParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
       walk_lin<8, CP_PLANE>(lds, (unsigned)(L_CP + fh * 16), p.cfrag + (size_t)wave * 8 * 2048, lane16, cacc, wr);
-      const float cs = *reinterpret_cast<const float*>(p.cfrag + (size_t)(p.ncomp / 32) * 8 * 2048) / insc2;
+      const float cs = cs_raw / insc2;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.cbias + 32 * wave + 8 * q + 4 * fh);
+        const f32x4 bb = cb_h[q];
         f32x4 v;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = magat_relu(cacc[4 * q + c] * cs + bb[c]);
