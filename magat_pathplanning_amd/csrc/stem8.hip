@@ -149,16 +149,27 @@ __global__ __launch_bounds__(512, 1) void stem8_kernel(const Stem8Params p) {
     *reinterpret_cast<unsigned*>(lds + S8_S + (i / (PIXB / 4)) * S8_BLK + 121 * PIXB + (i % (PIXB / 4)) * 4) = 0u;
   // stem weights as this lane's MFMA row fragments: row = channel fr, k step = tap row ty, K slot 8 fh + i = (pixel column
   // tx = slot / 4, channel slot c = slot % 4); slot (ty 1, tx 1, c 3) carries the bias against the constant 1.0
+  // (the 24 weights and the bias are requested together - clamped addresses, the predicate on the value - and pinned: each in a
+  //  branch of its own they were a chain of ten round trips at the head of every workgroup)
   u32x4 wa[3][2];
+  float wraw[3][8];
+  const float b0v = p.b0[fr];
+#pragma unroll
+  for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int slot = 8 * fh + i, tx = slot >> 2, c = slot & 3;
+      wraw[ty][i] = p.w0[fr * 27 + ((tx < 3 && c < 3) ? c * 9 + ty * 3 + tx : 0)];
+    }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int ty = 0; ty < 3; ++ty) {
     float wv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int slot = 8 * fh + i, tx = slot >> 2, c = slot & 3;
-      float v = 0.f;
-      if (tx < 3 && c < 3) v = p.w0[fr * 27 + c * 9 + ty * 3 + tx];
-      if (ty == 1 && tx == 1 && c == 3) v = p.b0[fr];
+      float v = (tx < 3 && c < 3) ? wraw[ty][i] : 0.f;
+      if (ty == 1 && tx == 1 && c == 3) v = b0v;
       wv[i] = v * S8_W0;
     }
     unsigned h1[4], h2[4];
