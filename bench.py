@@ -824,7 +824,11 @@ def main():
                                      ("published_f32p4_N10", 10, 20, dict(nGraphFilterTaps=2, bottleneckFeature=32, AttentionConcat=False,
                                                                           bottleneckMode="BottomNeck_only")),
                                      ("published_f32p4_N100", 100, 50, dict(nGraphFilterTaps=2, bottleneckFeature=32, AttentionConcat=False,
-                                                                            bottleneckMode="BottomNeck_only"))):
+                                                                            bottleneckMode="BottomNeck_only")),
+                                     # (head MEAN at the default width: what main.py runs unless --AttentionConcat is given,
+                                     #  main.py:115, utils/config.py:122)
+                                     ("headmean_N10", 10, 20, dict(AttentionConcat=False)),
+                                     ("headmean_N100", 100, 50, dict(AttentionConcat=False))):
                 cfgl = make_config(**dict(dict(num_agents=Nl, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat",
                                                device=str(dev)), **kw_))
                 netl = build_model(cfgl, dev)
@@ -974,6 +978,8 @@ def main():
                 "latency_b1_us": {"N10": _g(res, "latency_b1", "N10", "median_us"), "N100": _g(res, "latency_b1", "N100", "median_us"),
                                   "published_f32p4_N10": _g(res, "latency_b1", "published_f32p4_N10", "median_us"),
                                   "published_f32p4_N100": _g(res, "latency_b1", "published_f32p4_N100", "median_us"),
+                                  "headmean_N10": _g(res, "latency_b1", "headmean_N10", "median_us"),
+                                  "headmean_N100": _g(res, "latency_b1", "headmean_N100", "median_us"),
                                   "N10_device": _g(res, "latency_b1", "N10", "device_back_to_back_us"),
                                   "N100_device": _g(res, "latency_b1", "N100", "device_back_to_back_us")}}
     # ---- the CPU baseline: the pinned oracle on this box's host cores, behind every GPU leg (nothing of it is inside a timed region)

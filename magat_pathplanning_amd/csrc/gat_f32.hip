@@ -1437,7 +1437,8 @@ static int gat_forward_impl(const float* X, const void* S, int s_is_f64, const f
     const int rc = G == 128 && magat_gat_mfma_supported(N, G, F, K, mode)
         ? magat_gat_mfma_forward(X, G, S, s_is_f64, masks, frag, bias, Y, ldy, B, N, K, P, concat,
                                  guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4), mode,
-                                 mode == MAGAT_MODE_KEYQUERY ? nullptr : frag + (size_t)(P * G + P * K * F) * G)
+                                 mode == MAGAT_MODE_KEYQUERY ? nullptr : frag + (size_t)(P * G + P * K * F) * G,
+                                 concat ? nullptr : Ytmp, P * F)
         : G != 128 && N <= 32
         ? magat_gat_small_forward(X, G, S, s_is_f64, masks, packed + magat_gat_f16_block_offset(L.NC, G), L.NC, bias, Y, ldy, B,
                                   N, G, K, P, concat, guard ? status : nullptr, st, reinterpret_cast<const float*>(status + 4))

@@ -45,7 +45,8 @@ struct GatMfmaParams {
   float* Y;                   // [B*N][ldy]; concat: head p at column 128 p
   int B, N, P, ldx, ldy, concat, s_is_f64;       // (PACK: B = number of PACKS of four instances, Binst = instances)
   int Binst;
-  int hsplit;                 // 1, or P (small batches, concat): a workgroup per (instance, head) instead of per instance
+  int hsplit;                 // 1, or P (small batches): a workgroup per (instance, head) instead of per instance
+  float* Ypre; int ldpre;     // head mean + hsplit: the heads' pre-activation rows [B*N][ldpre] (column 128 p); magat_gat_mean_launch merges them
   int* range_flag;
   const float* kconst;        // rank-1 score modes: per head a1 . wb + a2 . wb (GAT_modified; zeros for GAT_origin), or null
   int origin;                 // GAT_origin: the edge rule is |float(S) + I| > 1e-9 (graphML.py:1018)
@@ -780,6 +781,11 @@ __global__ __launch_bounds__(256, 1) void gat_mfma_kernel(const GatMfmaParams p)
             if constexpr (CONCAT) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) o[e] = __builtin_amdgcn_fmed3f(o[e], 0.f, __builtin_inff());
+            } else if (p.hsplit > 1) {
+              // head split: this workgroup owns ONE head - its rows (+ bias, no ReLU) go to the scratch rows, column 128 hd;
+              // the mean kernel sums them in head order (the same sum as the read-add-write below)
+              dst = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.Ypre + (long long)b * N * p.ldpre + hd * 128) +
+                                             (long long)jg * p.ldpre * 4 + (unsigned)((cw & ~3) + (4 * h + fq) * p.ldpre) * 4u);
             } else {
               if (hd > 0 && rok) o += *dst;
               if (last) {
@@ -855,14 +861,22 @@ int launch(const GatMfmaParams& p, int slot, hipStream_t st) {
   // head mean accumulates in one workgroup's own rows of Y).
   const long long unsplit = (long long)((p.B + cus - 1) / cus) * (12 + 36 * p.P);
   const long long split = (long long)(((long long)p.B * p.P + cus - 1) / cus) * (12 + 36);
-  q.hsplit = (p.concat && p.P > 1 && split < unsplit) ? p.P : 1;
+  q.hsplit = ((p.concat || p.Ypre) && p.P > 1 && split < unsplit) ? p.P : 1;      // (head mean: through the caller's scratch rows)
   const long long units = q.hsplit > 1 ? (long long)p.B * p.P : p.B;
   const int blocks = (int)(units < (long long)cus * q.hsplit ? units : (long long)cus * q.hsplit);
   if (q.hsplit > 1) magat_form_note(MAGAT_FORM_GAT_HSPLIT);
   if (units > blocks) magat_form_note(MAGAT_FORM_GAT_PERSIST);
   const int pid = magat_prof_begin(MAGAT_TAG_GAT_LAYER, st);
   if (p.concat) hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, true, MODE>), dim3(blocks), dim3(256), lds, st, q);
-  else hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, false, MODE>), dim3(blocks), dim3(256), lds, st, q);
+  else {
+    hipLaunchKernelGGL((gat_mfma_kernel<MT, KSI, KT, false, MODE>), dim3(blocks), dim3(256), lds, st, q);
+    // head split + head mean: relu(mean over the heads) of the scratch rows, summed in head order like the unsplit form's
+    // read-add-write of Y (graphML.py:4663-4667)
+    if (q.hsplit > 1 && magat_gat_mean_launch(p.Ypre, p.Y, (long long)p.B * p.N, p.P, 128, p.ldpre, p.ldy, st) != MAGAT_OK) {
+      magat_prof_end(pid, st);
+      return MAGAT_ERR_LAUNCH;
+    }
+  }
   magat_prof_end(pid, st);
   return magat_check_launch();
 }
@@ -901,8 +915,10 @@ int magat_gat_mfma_supported(int N, int G, int F, int K, int mode) {
 
 int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64, const unsigned* rmask_pre,
                            const float* packed_frag, const float* bias, float* Y, int ldy, int B, int N, int K, int P,
-                           int concat, int* range_flag, hipStream_t st, const float* x_scale, int mode, const float* kconst) {
+                           int concat, int* range_flag, hipStream_t st, const float* x_scale, int mode, const float* kconst,
+                           float* ypre, int ldpre) {
   GatMfmaParams p;
+  p.Ypre = (!concat && ypre && ldpre >= 128 * P) ? ypre : nullptr; p.ldpre = ldpre;
   p.x_scale = x_scale;
   p.kconst = kconst; p.origin = mode == MAGAT_MODE_GAT_ORIGIN ? 1 : 0;
   p.X = X; p.ldx = ldx; p.S = S; p.s_is_f64 = s_is_f64; p.rmask_pre = rmask_pre;

@@ -492,6 +492,14 @@ int launch_mid_nt(const GatMidParams& p, int concat, int slot, hipStream_t st) {
 
 }  // namespace
 
+// head mean of pre-activation rows [M][ldpre >= P F] (gat_mfma.hip's head-split form merges its heads with it too)
+int magat_gat_mean_launch(const float* ypre, float* y, long long M, int P, int F, int ldpre, int ldy, hipStream_t st) {
+  long long mb = (M * F + 255) / 256;
+  if (mb > 4096) mb = 4096;
+  hipLaunchKernelGGL(gat_mid_mean_kernel, dim3((unsigned)mb), dim3(256), 0, st, ypre, y, M, P, F, ldpre, ldy);
+  return magat_check_launch();
+}
+
 int magat_gat_mid_supported(int N, int G, int F, int K, int mode) {
   if (mode != MAGAT_MODE_KEYQUERY || G != F || (K != 2 && K != 3) || N > 128) return 0;
   if (G == 128) {      // (gat_mfma.hip up to 102 agents; option GAT_WIDE_FROM: where this form takes over from the two launches)

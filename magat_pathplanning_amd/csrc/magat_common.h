@@ -163,7 +163,9 @@ int magat_gat_mfma_forward(const float* X, int ldx, const void* S, int s_is_f64,
                            int concat, int* range_flag, hipStream_t st,
                            const float* x_scale = nullptr,       // device float: power-of-two scale of X's planes (null / 0 = 1)
                            int mode = MAGAT_MODE_KEYQUERY,       // GAT_modified / GAT_origin: rank-1 scores (packed_frag: the rank-1 block)
-                           const float* kconst = nullptr);       // per head a1 . wb + a2 . wb (device floats), or null
+                           const float* kconst = nullptr,        // per head a1 . wb + a2 . wb (device floats), or null
+                           float* ypre = nullptr, int ldpre = 0); // head-mean scratch rows [B*N][>= 128 P]: lets few instances run a workgroup per head
+int magat_gat_mean_launch(const float* ypre, float* y, long long M, int P, int F, int ldpre, int ldy, hipStream_t st);      // gat_mid.hip
 
 // hoisted GAT maps Z [M][ldz >= NC] = X [M][G] @ Bt^T + colbias from the packed weights (gat_f32.hip): bf16x6 split when
 // NC % 32 == 0 and G % 32 == 0, else fp32 MFMA

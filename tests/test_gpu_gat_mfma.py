@@ -264,3 +264,34 @@ def test_small_graph_kernel_vs_oracle_and_two_launch_form(gpu_device, libopt, ta
     with torch.no_grad():
         yp = layer(x[perm].to(gpu_device)).cpu()
     assert torch.equal(yp, out[1][perm])
+
+
+@pytest.mark.parametrize("N,K,P", [(100, 3, 4), (10, 2, 4), (64, 3, 2), (20, 3, 3)])
+def test_gat_mfma_head_mean_head_split_equals_the_unsplit_form(gpu_device, tag_counts, N, K, P):
+    """Head MEAN - what the reference runs unless `--AttentionConcat` is given (main.py:115, utils/config.py:122) - for few
+    instances: a workgroup per (instance, head), the heads' rows through the workspace's scratch rows and the mean kernel
+    (before: one workgroup walked the P heads of an instance, 83 against 37 us per layer call at one instance of 100 agents).
+    Same sum in the same order as the unsplit form's read-add-write of Y: an instance alone equals its rows in a 1100-instance
+    batch (more instances than the round-count model splits) bit for bit; against the oracle."""
+    from oracle import magat_oracle as orc
+    from magat_pathplanning_amd import _native as nat
+    B = 1100
+    layer, S, x = _layer_and_inputs(B, N, K, P, False, seed=70 + N)
+    sd = {k: v.detach() for k, v in layer.state_dict().items()}
+    layer = layer.to(gpu_device).eval()
+    lib = nat.lib()
+    with torch.no_grad():
+        layer.addGSO(S.unsqueeze(1).to(gpu_device))
+        lib.magat_form_reset()
+        big = layer(x.to(gpu_device)).cpu()
+        assert lib.magat_form_count(nat.FORMS["gat_hsplit"]) == 0
+        for pick in ([0], [7, 8], [1099]):
+            layer.addGSO(S[pick].unsqueeze(1).to(gpu_device))
+            lib.magat_form_reset()
+            with tag_counts() as tc:
+                small = layer(x[pick].to(gpu_device)).cpu()
+            assert tc[ONE_LAUNCH] == 1, tc.counts
+            assert lib.magat_form_count(nat.FORMS["gat_hsplit"]) == 1
+            assert torch.equal(small, big[pick])
+    y_ref, _ = orc.gat_layer_forward(x[:3], S[:3].unsqueeze(1), sd, "KeyQuery", False)
+    np.testing.assert_allclose(big[:3].numpy(), y_ref.numpy(), rtol=0, atol=2e-5)
