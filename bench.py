@@ -897,6 +897,19 @@ def main():
             res["closed_loop"] = cl
         except Exception as e:
             res["closed_loop"] = {"error": repr(e)[:200]}
+        # (c4b) c3 with head MEAN (AttentionConcat = False: what main.py runs unless --AttentionConcat is given, main.py:115,
+        # utils/config.py:122): same batch, the graph layer's heads averaged, the action head over 256 instead of 640 inputs
+        try:
+            cfgm = make_config(num_agents=N, nGraphFilterTaps=3, nAttentionHeads=4, bottleneckMode="BottomNeck_skipConcat", AttentionConcat=False,
+                               device=str(dev))
+            netm = build_model(cfgm, dev)
+            elm, _, _ = run_leg(x, S, esteps, ewarm, False, net=netm, repeats=2)
+            res["c3_headmean"] = {"workload": "c3 with AttentionConcat = False (head mean)", "value": round(B * N * esteps / elm, 1),
+                                  "unit": "agent-steps/s", "ms_per_step": round(elm / esteps * 1e3, 4)}
+            del netm
+        except Exception as e:
+            res["c3_headmean"] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
         # (c5) the default width on more than 105 agents (400 x 128): the graph layer as one launch (gat_mid.hip, X fragments in
         # registers; before round 6g: the CSR kernels)
         try:
@@ -973,6 +986,7 @@ def main():
                 "closed_loop": {"b512_n100_value": _g(res, "closed_loop", "b512_n100", "value"),
                                 "b512_n100_ms": _g(res, "closed_loop", "b512_n100", "ms_per_step"),
                                 "b1_n100_ms": _g(res, "closed_loop", "b1_n100", "ms_per_step")},
+                "c3_headmean": {"value": _g(res, "c3_headmean", "value"), "ms_per_step": _g(res, "c3_headmean", "ms_per_step")},
                 "n128": {"value": _g(res, "n128", "value"), "ms_per_step": _g(res, "n128", "ms_per_step"),
                          "one_launch": _g(res, "n128", "graph_layer_one_launch")},
                 "latency_b1_us": {"N10": _g(res, "latency_b1", "N10", "median_us"), "N100": _g(res, "latency_b1", "N100", "median_us"),
