@@ -258,6 +258,24 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
       MID_STAMP(1);
       __syncthreads();      // Q planes complete (and every wave is past the previous head's reads of the U^T region)
       MID_STAMP(2);
+      // 32 features on more than 64 agents (one wave per SIMD whatever its registers: the LDS decides): the K taps' fragments -
+      // 4 K register quads - are requested here, behind the barrier (which drains the request counter), and fly under G2, the
+      // softmax and the A planes
+      constexpr bool WEARLY = !XR && F == 32 && NT >= 3;
+      uint4 wt[WEARLY ? KT : 1][CT][KF][2];
+      if constexpr (WEARLY) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < KF; ++ks) {
+              const long long row0 = (long long)p.P * G + ((long long)hd * KT + k) * F + 32 * ct;
+              wt[k][ct][ks][0] = wfrag(row0, ks, 0);
+              wt[k][ct][ks][1] = wfrag(row0, ks, 1);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // ---- G2: E^T[j][i] = sum_g Q[j][g] X[i][g] for this wave's columns i and ALL row tiles j; lane = column i, registers = rows j
       f32x16 e[NT];
 #pragma unroll
@@ -328,10 +346,10 @@ __global__ __launch_bounds__(64 * NT) void gat_mid_kernel(const GatMidParams p) 
 #pragma unroll
             for (int ks = 0; ks < KF; ++ks) {
               const long long row0 = (long long)p.P * G + ((long long)hd * KT + k) * F + 32 * (cb + c_);
-              wb[c_][ks][0] = wfrag(row0, ks, 0);
-              wb[c_][ks][1] = wfrag(row0, ks, 1);
+              if constexpr (WEARLY) { wb[c_][ks][0] = wt[k][cb + c_][ks][0]; wb[c_][ks][1] = wt[k][cb + c_][ks][1]; }
+              else { wb[c_][ks][0] = wfrag(row0, ks, 0); wb[c_][ks][1] = wfrag(row0, ks, 1); }
             }
-          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!WEARLY) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int c_ = 0; c_ < WB; ++c_) {
             const int ct = cb + c_;

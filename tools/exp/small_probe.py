@@ -10,11 +10,11 @@ from magat_pathplanning_amd import GraphFilterBatchAttentional, _native as nat
 from magat_pathplanning_amd.synthetic import comm_gso
 
 dev = torch.device("cuda:0")
-for B, N, G, K, concat in ((1024, 20, 32, 2, False), (1024, 10, 32, 2, False), (4096, 20, 32, 2, False), (1024, 20, 64, 3, True), (1, 10, 32, 2, False), (1, 20, 32, 2, False)):
+for B, N, G, K, concat in ((512, 100, 32, 2, False), (512, 100, 32, 3, True), (512, 50, 32, 2, False), (1, 100, 32, 2, False), (1024, 20, 32, 2, False), (1024, 10, 32, 2, False), (4096, 20, 32, 2, False), (1024, 20, 64, 3, True), (1, 10, 32, 2, False), (1, 20, 32, 2, False)):
     torch.manual_seed(0)
     layer = GraphFilterBatchAttentional(G, G, K, 4, attentionMode="KeyQuery", concatenate=concat).to(dev).eval()
     x = (torch.randn(B, G, N) * 0.5).to(dev)
-    S = comm_gso(B, N, 28, seed=1, dtype=torch.float64).to(dev)
+    S = comm_gso(B, N, 50 if N > 32 else 28, seed=1, dtype=torch.float64).to(dev)
     layer.addGSO(S.unsqueeze(1))
     with torch.no_grad():
         for _ in range(5):
